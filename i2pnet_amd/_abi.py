@@ -1,0 +1,46 @@
+"""ctypes description of the C ABI declared in include/i2p_ops.h.
+
+One table, used by the product loader (`_lib.py`, device library, every entry takes a trailing
+`void* stream`) and by the test-only oracle loader (`oracle/oracle.py`, same names + `_cpu`,
+no stream).  Argument kinds:
+
+    'i'  int            'f'  float           'p'  device/host pointer (void*)
+    'pp' pointer to an array of pointers (const float* const*)
+"""
+import ctypes as C
+
+# name -> argument kinds (without the trailing stream)
+SIGNATURES = {
+    "i2p_fused_conv_select_k": ["i"] * 8 + ["f", "i", "i"] + ["p"] * 10 + ["i", "i"],
+    "i2p_furthest_point_sampling": ["i", "i", "i", "p", "p", "p"],
+    "i2p_gather_points": ["i", "i", "i", "i", "p", "p", "p"],
+    "i2p_gather_points_grad": ["i", "i", "i", "i", "p", "p", "p"],
+    "i2p_ball_query": ["i", "i", "i", "f", "i", "p", "p", "p"],
+    "i2p_group_points": ["i", "i", "i", "i", "i", "p", "p", "p"],
+    "i2p_group_points_grad": ["i", "i", "i", "i", "i", "p", "p", "p"],
+    "i2p_three_nn": ["i", "i", "i", "p", "p", "p", "p"],
+    "i2p_three_interpolate": ["i", "i", "i", "i", "p", "p", "p", "p"],
+    "i2p_three_interpolate_grad": ["i", "i", "i", "i", "p", "p", "p", "p"],
+    "i2p_project_seq": ["i", "i", "i", "i", "f", "f", "p", "i", "pp", "p", "p", "pp", "p"],
+    "i2p_gather_rows": ["i", "i", "i", "i", "i", "p", "p", "p", "p"],
+    "i2p_gather_rows_grad": ["i", "i", "i", "i", "i", "p", "p", "p", "p"],
+    "i2p_knn": ["i", "i", "i", "i", "p", "p", "p"],
+}
+
+_CT = {"i": C.c_int, "f": C.c_float, "p": C.c_void_p, "pp": C.c_void_p}
+
+
+def bind(lib, name, symbol, with_stream):
+    """Attach argtypes/restype to `lib.symbol` for table entry `name` and return it."""
+    fn = getattr(lib, symbol)
+    fn.argtypes = [_CT[k] for k in SIGNATURES[name]] + ([C.c_void_p] if with_stream else [])
+    fn.restype = C.c_int
+    return fn
+
+
+def ptr_array(tensors):
+    """Host-side array of data pointers for 'pp' arguments (kept alive by the caller)."""
+    arr = (C.c_void_p * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr

@@ -1,0 +1,45 @@
+"""Loader for the in-tree HIP library.  There is NO fallback: if libi2p_ops.so is missing or
+does not load, importing any operator raises."""
+import ctypes as C
+from pathlib import Path
+
+from . import _abi
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libi2p_ops.so"
+_lib = None
+_fns = {}
+
+
+class I2POpsError(RuntimeError):
+    pass
+
+
+_ERRORS = {-1: "bad argument", -2: "kernel_size_H*kernel_size_W exceeds 150", -3: "K exceeds 150"}
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise I2POpsError(
+                f"{_LIB_PATH} not found: build it with `python -m i2pnet_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        _lib = C.CDLL(str(_LIB_PATH))
+        _lib.i2p_abi_version.restype = C.c_int
+        for name in _abi.SIGNATURES:
+            _fns[name] = _abi.bind(_lib, name, name, with_stream=True)
+    return _lib
+
+
+def call(name, *args, stream=0):
+    """Call C-ABI entry `name`; raises I2POpsError on a non-zero status (the reference's
+    launchers exit(-1) instead, e.g. fused_conv_go.cu:259-263)."""
+    load()
+    rc = _fns[name](*args, C.c_void_p(stream))
+    if rc != 0:
+        what = _ERRORS.get(rc, f"hipError_t {rc}" if rc > 0 else f"error {rc}")
+        raise I2POpsError(f"{name} failed: {what}")

@@ -1,0 +1,52 @@
+// Shared device helpers for libi2p_ops.so (gfx950 only; wave64 hard-coded).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/i2p_ops.h"
+
+#define I2P_WAVE 64
+
+// Launch-error convention of the C ABI: never exit(), return the hipError_t.
+#define I2P_RETURN_LAUNCH_STATUS()                      \
+    do {                                                \
+        hipError_t e__ = hipGetLastError();             \
+        return e__ == hipSuccess ? 0 : (int)e__;        \
+    } while (0)
+
+// The one squared-norm evaluation order used everywhere (see include/i2p_ops.h).
+__device__ __forceinline__ float i2p_sq3(float a, float b, float c) {
+    return __fmaf_rn(c, c, __fmaf_rn(b, b, __fmul_rn(a, a)));
+}
+
+__device__ __forceinline__ unsigned i2p_f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float i2p_u2f(unsigned u) { return __uint_as_float(u); }
+
+// DPP all-reduce inside a 16-lane row (every lane of the row ends with the row result).
+// quad_perm[1,0,3,2] = 0xB1, quad_perm[2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140.
+template <int CTRL>
+__device__ __forceinline__ unsigned i2p_dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ unsigned i2p_row16_min_u32(unsigned v) {
+    v = min(v, i2p_dpp_u32<0xB1>(v));
+    v = min(v, i2p_dpp_u32<0x4E>(v));
+    v = min(v, i2p_dpp_u32<0x141>(v));
+    v = min(v, i2p_dpp_u32<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ unsigned i2p_row16_add_u32(unsigned v) {
+    v += i2p_dpp_u32<0xB1>(v);
+    v += i2p_dpp_u32<0x4E>(v);
+    v += i2p_dpp_u32<0x141>(v);
+    v += i2p_dpp_u32<0x140>(v);
+    return v;
+}
+
+// Blocks of one batch sample share that sample's range image; the dispatcher places block b
+// on XCD b%8 (observed, speed only), so give each XCD a contiguous run of logical blocks and
+// its L2 sees one sample's image instead of all of them.
+__device__ __forceinline__ unsigned i2p_xcd_swizzle(unsigned bid, unsigned nblocks) {
+    if ((nblocks & 7u) != 0u) return bid;
+    const unsigned per = nblocks >> 3;
+    return (bid & 7u) * per + (bid >> 3);
+}

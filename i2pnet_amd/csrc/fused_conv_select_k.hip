@@ -1,0 +1,276 @@
+// fused_conv_select_k for gfx950 — replaces fused_conv_select_k_gpu / FusedConvSelectKLauncher
+// (reference: src/projectPN/fused_conv_select/fused_conv_go.cu:11-264).
+//
+// The reference runs ONE 512-thread block per batch sample (<= B of 256 CUs busy), each thread
+// owning a query with three 150-entry private arrays and an O(K*kt) serial selection sort.
+// Here a query is owned by a 16-lane DPP row (4 queries per wave64, 16 per 256-thread block,
+// grid = ceil(B*npoints/16) blocks):
+//
+//   A. each lane evaluates ceil(kt/16) window cells (consecutive lanes -> consecutive cells of
+//      a window row -> contiguous 12-B reads) and packs them as 64-bit keys (d2 bits : position);
+//   B. sorts its own keys in registers, parks the sorted run in LDS and keeps the head;
+//   C. K extraction steps: DPP row all-reduce (min) over the 16 heads, the owning lane records
+//      the winner and pops its next key from LDS.  K*(4 DPP + ~8) instructions per 4 queries.
+//
+// Bit-exactness.  The reference's result order under EQUAL distances depends on the swap
+// history of its selection sort, which no parallel order reproduces.  Steps A-C
+// give the unique answer whenever the K+1 smallest valid distances are distinct; equal
+// distances are detected (duplicate pops / equal consecutive minima) and that query is redone
+// by one lane running the reference's serial algorithm verbatim out of LDS (step F).  Queries
+// with distance^2 >= 1e10 (where valid entries can collide with the 1e10 sentinel) always take
+// step F.
+#include "common.h"
+
+namespace {
+
+constexpr int GROUP = 16;                 // lanes per query
+constexpr int QPB = 16;                   // queries per 256-thread block
+constexpr unsigned SENT_BITS = 0x501502F9u;   // bits of 1e10f, the reference's "empty slot" distance
+constexpr unsigned PAD_BITS = 0x7FFFFFFFu;    // padding keys (position >= kt), above everything
+
+// out-code per selected slot: pos (8 bits) | stored << 8 | valid << 9
+constexpr unsigned CODE_STORED = 0x100u, CODE_VALID = 0x200u;
+
+struct FcskParams {
+    int B, H, W, npoints, kH, kW, K, flag;
+    float dist2;
+    int stride_h, stride_w, small_h, small_w;
+    const float *xyz1, *xyz2;
+    const int *idx_n2, *random_hw;
+    int64_t *ob, *oh, *ow;
+    float *om;
+    int force_serial;
+};
+
+struct Center {
+    float x, y, z;
+    int base_h, base_w;
+    int b;
+};
+
+// One window cell: returns the reference's Dist[pos] bits and whether it was "stored"
+// (go.cu:82-180).  tab = packed (dh << 16 | dw & 0xffff) for pos < kt.
+__device__ __forceinline__ void eval_cell(const FcskParams &p, const Center &c, int tabv,
+                                          unsigned &dbits, unsigned &stored) {
+    dbits = SENT_BITS; stored = 0;
+    int h = c.base_h + (tabv >> 16);
+    int w = c.base_w + (int)(short)(tabv & 0xffff);
+    if (h < 0 || h >= p.small_h) return;                                  // go.cu:99-103 / :115
+    if (p.flag & I2P_FLAG_SHIFT) {                                        // go.cu:106-112
+        if (w < 0) w = p.small_w + w;
+        if (w >= p.small_w) w = w - p.small_w;
+    } else if (w < 0 || w >= p.small_w) {
+        return;
+    }
+    const float *q = p.xyz2 + (((size_t)c.b * p.small_h + h) * p.small_w + w) * 3;
+    const float xq = q[0], yq = q[1], zq = q[2];
+    const float d0 = i2p_sq3(xq, yq, zq);                                 // go.cu:141
+    if (d0 <= 1e-10f) return;                                             // go.cu:143
+    const float dq = fmaxf(i2p_sq3(c.x - xq, c.y - yq, c.z - zq), 1e-10f); // go.cu:154
+    if (dq > p.dist2) return;                                             // go.cu:157
+    dbits = i2p_f2u(dq); stored = 1;
+}
+
+__device__ __forceinline__ void cell_hw(const FcskParams &p, const Center &c, int tabv, int &h,
+                                        int &w) {
+    h = c.base_h + (tabv >> 16);
+    w = c.base_w + (int)(short)(tabv & 0xffff);
+    if (p.flag & I2P_FLAG_SHIFT) {
+        if (w < 0) w = p.small_w + w;
+        if (w >= p.small_w) w = w - p.small_w;
+    }
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(256) void fcsk_kernel(FcskParams p) {
+    __shared__ int tab[SLOTS * GROUP];
+    __shared__ unsigned long long lst[QPB][SLOTS * GROUP];
+    __shared__ unsigned short outc[QPB][I2P_MAX_WINDOW + 2];
+
+    const int kt = p.kH * p.kW;
+    const int tid = threadIdx.x;
+    const int g = tid >> 4, l16 = tid & 15;
+    const unsigned nblocks = gridDim.x;
+    const unsigned lb = i2p_xcd_swizzle(blockIdx.x, nblocks);
+
+    // window offset table (one integer division per entry per block instead of per candidate)
+    for (int i = tid; i < SLOTS * GROUP; i += 256) {
+        int v = 0;
+        if (i < kt) {
+            const int k = p.random_hw[i];                                 // go.cu:86
+            const int dh = k / p.kW - p.kH / 2, dw = k % p.kW - p.kW / 2; // go.cu:89-92
+            v = (dh << 16) | (dw & 0xffff);
+        }
+        tab[i] = v;
+    }
+    for (int i = l16; i < p.K; i += GROUP) outc[g][i] = 0;
+
+    const long long q = (long long)lb * QPB + g;
+    const bool in_range = q < (long long)p.B * p.npoints;
+    Center c; c.b = 0; c.x = c.y = c.z = 0.f; c.base_h = c.base_w = 0;
+    int n = 0;
+    bool live = false;
+    if (in_range) {
+        c.b = (int)(q / p.npoints); n = (int)(q % p.npoints);
+        const int ch = p.idx_n2[((size_t)c.b * p.npoints + n) * 2 + 0];   // go.cu:65-66
+        const int cw = p.idx_n2[((size_t)c.b * p.npoints + n) * 2 + 1];
+        const float *cp = p.xyz1 + (((size_t)c.b * p.H + ch) * p.W + cw) * 3;
+        c.x = cp[0]; c.y = cp[1]; c.z = cp[2];
+        const float dc = fmaxf(i2p_sq3(c.x, c.y, c.z), 1e-10f);           // go.cu:72
+        live = !(dc <= 1e-10f);                                           // go.cu:74
+        c.base_h = ch / p.stride_h; c.base_w = cw / p.stride_w;
+    }
+    __syncthreads();
+
+    // ---- A: evaluate this lane's window cells --------------------------------------------
+    unsigned long long key[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int pos = s * GROUP + l16;
+        unsigned dbits = PAD_BITS, stored = 0;
+        if (pos < kt) {
+            dbits = SENT_BITS;
+            if (live) eval_cell(p, c, tab[pos], dbits, stored);
+        }
+        key[s] = ((unsigned long long)dbits << 32) | (unsigned)(pos | (stored << 8));
+    }
+
+    // ---- B: sort own keys, park the run in LDS -------------------------------------------
+#pragma unroll
+    for (int i = 0; i < SLOTS - 1; ++i)
+#pragma unroll
+        for (int j = 0; j < SLOTS - 1 - i; ++j) {
+            const unsigned long long a = key[j], b2 = key[j + 1];
+            const bool sw = a > b2;
+            key[j] = sw ? b2 : a; key[j + 1] = sw ? a : b2;
+        }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) lst[g][s * GROUP + l16] = key[s];
+    __syncthreads();
+
+    // ---- C: K extraction steps ------------------------------------------------------------
+    unsigned head_hi = (unsigned)(key[0] >> 32), head_lo = (unsigned)key[0];
+    int ptr = 1;
+    unsigned pops = 0, steps = 0, prev = 0;
+    bool tie = false, done = !live;
+    for (int s = 0; s < p.K; ++s) {
+        const unsigned gmin = i2p_row16_min_u32(head_hi);
+        if (!done) {
+            if (gmin >= SENT_BITS) {
+                done = true;                        // only empty slots remain: nothing more to write
+            } else {
+                tie |= (s > 0 && gmin == prev);
+                prev = gmin; ++steps;
+                if (head_hi == gmin) {
+                    outc[g][s] = (unsigned short)(head_lo | CODE_VALID);
+                    ++pops;
+                    unsigned long long nx = ((unsigned long long)PAD_BITS << 32);
+                    if (ptr < SLOTS) nx = lst[g][ptr * GROUP + l16];
+                    ++ptr;
+                    head_hi = (unsigned)(nx >> 32); head_lo = (unsigned)nx;
+                }
+            }
+        }
+    }
+    {   // boundary: the (K+1)-th smallest must differ from the K-th, every pop must be unique
+        const unsigned gnext = i2p_row16_min_u32(head_hi);
+        const unsigned total = i2p_row16_add_u32(pops);
+        if (!done && steps > 0 && gnext == prev) tie = true;
+        if (total != steps) tie = true;
+    }
+    bool need_serial = live && (tie || p.force_serial);
+
+    // ---- F: exact serial redo for queries with equal distances (block-uniform branch) ------
+    if (__syncthreads_or(need_serial ? 1 : 0)) {
+        if (need_serial) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int pos = s * GROUP + l16;
+                unsigned dbits = SENT_BITS, stored = 0;
+                if (pos < kt) eval_cell(p, c, tab[pos], dbits, stored);
+                lst[g][pos] = ((unsigned long long)dbits << 32) | (unsigned)(pos | (stored << 8));
+            }
+        }
+        __syncthreads();
+        if (need_serial && l16 == 0) {
+            unsigned long long *a = lst[g];                    // a[t] = (Dist[t] bits : pos | stored)
+            for (int s = 0; s < p.K; ++s) {                                 // go.cu:183-236
+                // positions >= kt are never searched (go.cu:188); slots s >= kt stay sentinel
+                int mi = s;
+                if (s < kt) {
+                    float dm = i2p_u2f((unsigned)(a[s] >> 32));
+                    for (int t = s + 1; t < kt; ++t) {
+                        const float dt = i2p_u2f((unsigned)(a[t] >> 32));
+                        if (dt < dm) { dm = dt; mi = t; }
+                    }
+                    if (mi != s) { const unsigned long long tmp = a[mi]; a[mi] = a[s]; a[s] = tmp; }
+                    const float ds = i2p_u2f((unsigned)(a[s] >> 32));
+                    outc[g][s] = (unsigned short)(((unsigned)a[s] & 0x1ffu) | (ds < 1e10f ? CODE_VALID : 0u));
+                } else {
+                    outc[g][s] = 0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- output: coalesced along K ---------------------------------------------------------
+    if (!live) return;                                                     // go.cu:74-78: untouched
+    const size_t obase = ((size_t)c.b * p.npoints + n) * p.K;
+    const unsigned copy_code = outc[g][0];
+    for (int s = l16; s < p.K; s += GROUP) {
+        unsigned code = outc[g][s];
+        bool wr = (code & CODE_VALID) != 0;                                // go.cu:225
+        if (!wr && (p.flag & I2P_FLAG_COPY)) { code = copy_code; wr = true; } // go.cu:211-222
+        if (!wr) continue;
+        int h = 0, w = 0;                                                  // non-stored slot: idx_h = idx_w = 0
+        if (code & CODE_STORED) cell_hw(p, c, tab[code & 0xff], h, w);
+        p.ob[obase + s] = c.b; p.oh[obase + s] = h; p.ow[obase + s] = w; p.om[obase + s] = 1.0f;
+    }
+}
+
+template <int SLOTS>
+int launch(const FcskParams &p, hipStream_t st) {
+    const long long nq = (long long)p.B * p.npoints;
+    const unsigned grid = (unsigned)((nq + QPB - 1) / QPB);
+    hipLaunchKernelGGL(fcsk_kernel<SLOTS>, dim3(grid), dim3(256), 0, st, p);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+extern "C" int i2p_fused_conv_select_k(int batch_size, int H, int W, int npoints,
+                                       int kernel_size_H, int kernel_size_W, int K, int flag,
+                                       float distance, int stride_h, int stride_w,
+                                       const float *xyz1, const float *xyz2, const int *idx_n2,
+                                       const int *random_hw, int64_t *selected_b_idx,
+                                       int64_t *selected_h_idx, int64_t *selected_w_idx,
+                                       float *valid_idx, float *valid_in_dis_idx,
+                                       float *selected_mask, int small_h, int small_w,
+                                       void *stream) {
+    (void)valid_idx; (void)valid_in_dis_idx;   // accepted, never written (as the reference)
+    if (batch_size < 0 || npoints < 0 || K < 0 || kernel_size_H <= 0 || kernel_size_W <= 0 ||
+        stride_h <= 0 || stride_w <= 0 || H <= 0 || W <= 0 || small_h <= 0 || small_w <= 0)
+        return I2P_ERR_BAD_ARG;
+    const int kt = kernel_size_H * kernel_size_W;
+    if (kt > I2P_MAX_WINDOW) return I2P_ERR_WINDOW;
+    if (K > I2P_MAX_WINDOW) return I2P_ERR_K;
+    if ((long long)batch_size * npoints == 0 || K == 0) return 0;
+    if (!xyz1 || !xyz2 || !idx_n2 || !random_hw || !selected_b_idx || !selected_h_idx ||
+        !selected_w_idx || !selected_mask)
+        return I2P_ERR_BAD_ARG;
+
+    FcskParams p;
+    p.B = batch_size; p.H = H; p.W = W; p.npoints = npoints; p.kH = kernel_size_H;
+    p.kW = kernel_size_W; p.K = K; p.flag = flag; p.dist2 = distance * distance;  // go.cu:26
+    p.stride_h = stride_h; p.stride_w = stride_w; p.small_h = small_h; p.small_w = small_w;
+    p.xyz1 = xyz1; p.xyz2 = xyz2; p.idx_n2 = idx_n2; p.random_hw = random_hw;
+    p.ob = selected_b_idx; p.oh = selected_h_idx; p.ow = selected_w_idx; p.om = selected_mask;
+    // valid distances >= 1e10 would collide with the sentinel: take the verbatim serial path
+    p.force_serial = !(p.dist2 < 1e10f);
+    hipStream_t st = (hipStream_t)stream;
+    if (kt <= 16) return launch<1>(p, st);
+    if (kt <= 48) return launch<3>(p, st);
+    if (kt <= 144) return launch<9>(p, st);
+    return launch<10>(p, st);
+}

@@ -1,0 +1,232 @@
+// Spherical projection, channel-last row gather (+grad) and brute-force kNN for gfx950.
+// These are eager-PyTorch code in the reference (src/projectPN/utils.py:36-60, :111-187,
+// :343-380); they sit between the two native extensions on the same hot path.
+#include "common.h"
+#include <limits.h>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// project_seq (use_rank=False).  Three passes, all HBM/L2-bound and tiny:
+//   1. cell_winner[:] = -1
+//   2. per point: cell = f(xyz) ; atomicMax(cell_winner[cell], point index)   (deterministic:
+//      highest index wins == torch-CPU index_put_ last-writer-wins, one winner for all images)
+//   3. per cell: copy the winner's xyz / feature rows, or write zeros (no separate memset).
+// ------------------------------------------------------------------------------------------
+struct ProjConst {
+    float az_res, vres, voff;
+};
+
+__device__ __forceinline__ long long trunc_to_i64(float v) {
+    // torch-CPU `.long()` on x86: cvttss2si returns INT64_MIN for NaN / out of range
+    if (!(v >= -9.2233720368547758e18f && v < 9.2233720368547758e18f)) return LLONG_MIN;
+    return (long long)v;
+}
+
+__device__ __forceinline__ int project_cell(float x, float y, float z, int H, int W, ProjConst pc) {
+    const float PIf = 3.14159274101257324f;                                // float(np.pi)
+    const float r = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    const float fcol = __fdiv_rn(__fsub_rn(PIf, atan2f(y, x)), pc.az_res); // utils.py:147
+    const float beta = asinf(__fdiv_rn(z, r));                             // :150
+    const float frow = __fadd_rn(__fdiv_rn(beta, pc.vres), pc.voff);       // :152
+    long long icol = trunc_to_i64(fcol);
+    const long long irow_t = trunc_to_i64(frow);
+    long long irow = (long long)((unsigned long long)H - (unsigned long long)irow_t);
+    irow = irow < 0 ? 0 : (irow > H - 1 ? H - 1 : irow);                   // :154
+    icol = icol < 0 ? 0 : (icol > W - 1 ? W - 1 : icol);                   // :155
+    return (int)irow * W + (int)icol;
+}
+
+__global__ void proj_init_kernel(int total, int *__restrict__ cell_winner) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) cell_winner[i] = -1;
+}
+
+__global__ void proj_assign_kernel(int n, int H, int W, ProjConst pc, const float *__restrict__ xyz,
+                                   int *__restrict__ cell_winner) {
+    const int bi = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float *pt = xyz + ((size_t)bi * n + p) * 3;
+    const int cell = project_cell(pt[0], pt[1], pt[2], H, W, pc);
+    atomicMax(cell_winner + (size_t)bi * H * W + cell, p);
+}
+
+struct ProjFeats {
+    const float *src[5];
+    float *dst[5];
+    int dim[5];
+    int off[6];     // prefix sums of dim
+    int n_img;
+};
+
+// one thread per (cell, channel) over the concatenated channel list of all images
+__global__ void proj_fill_kernel(int n, int hw, int ctot, ProjFeats f,
+                                 const int *__restrict__ cell_winner) {
+    const int bi = blockIdx.y;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)hw * ctot) return;
+    const int cell = (int)(t / ctot), ch = (int)(t % ctot);
+    int img = 0;
+#pragma unroll
+    for (int i = 1; i < 5; ++i) if (i < f.n_img && ch >= f.off[i]) img = i;
+    const int lc = ch - f.off[img], d = f.dim[img];
+    const int w = cell_winner[(size_t)bi * hw + cell];
+    float v = 0.f;
+    if (w >= 0) v = f.src[img][((size_t)bi * n + w) * d + lc];
+    f.dst[img][((size_t)bi * hw + cell) * d + lc] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// gather_rows (+grad): out[b,q,:] = feat[b, h*W+w, :]  — gather_torch, utils.py:36-60
+// ------------------------------------------------------------------------------------------
+__global__ void gather_rows_kernel(int hw, int c, int q, int W, const float *__restrict__ feat,
+                                   const int64_t *__restrict__ h_idx,
+                                   const int64_t *__restrict__ w_idx, float *__restrict__ out) {
+    const int bi = blockIdx.y;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)q * c) return;
+    const int row = (int)(t / c), ch = (int)(t % c);
+    const long long cell = h_idx[(size_t)bi * q + row] * W + w_idx[(size_t)bi * q + row];
+    out[((size_t)bi * q + row) * c + ch] = feat[((size_t)bi * hw + cell) * c + ch];
+}
+
+__global__ void gather_rows_grad_kernel(int hw, int c, int q, int W,
+                                        const float *__restrict__ grad_out,
+                                        const int64_t *__restrict__ h_idx,
+                                        const int64_t *__restrict__ w_idx,
+                                        float *__restrict__ grad_feat) {
+    const int bi = blockIdx.y;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)q * c) return;
+    const int row = (int)(t / c), ch = (int)(t % c);
+    const long long cell = h_idx[(size_t)bi * q + row] * W + w_idx[(size_t)bi * q + row];
+    atomicAdd(grad_feat + ((size_t)bi * hw + cell) * c + ch, grad_out[((size_t)bi * q + row) * c + ch]);
+}
+
+// ------------------------------------------------------------------------------------------
+// kNN — knn_point, utils.py:366-380.  One wave per query; k rounds, each extracting the
+// smallest (distance, index) key greater than the previous one.  Distances are recomputed
+// per round (6 flops) instead of stored; fine for the 228x468 / k=32 call of cost_volume2.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float knn_dist(float qx, float qy, float qz, float qq, const float *p) {
+    const float px = p[0], py = p[1], pz = p[2];
+    const float pp = __fadd_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)), __fmul_rn(pz, pz));
+    const float dot = __fmaf_rn(qz, pz, __fmaf_rn(qy, py, __fmul_rn(qx, px)));
+    return __fadd_rn(__fadd_rn(__fmul_rn(-2.0f, dot), qq), pp);           // utils.py:362-364
+}
+
+// total order on (float d, int j) including negative d (cancellation can give d < 0)
+__device__ __forceinline__ unsigned long long knn_key(float d, int j) {
+    unsigned u = __float_as_uint(d);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned)j;
+}
+
+__global__ __launch_bounds__(256) void knn_kernel(int n, int s, int k, const float *__restrict__ xyz,
+                                                  const float *__restrict__ new_xyz,
+                                                  int *__restrict__ idx) {
+    const int bi = blockIdx.y;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (qi >= s) return;
+    const float *q = new_xyz + ((size_t)bi * s + qi) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const float qq = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));
+    const float *src = xyz + (size_t)bi * n * 3;
+    int *o = idx + ((size_t)bi * s + qi) * k;
+    unsigned long long last = 0ull;
+    bool first = true;
+    for (int t = 0; t < k; ++t) {
+        unsigned long long best = ~0ull;
+        for (int j = lane; j < n; j += 64) {
+            const float d = knn_dist(qx, qy, qz, qq, src + (size_t)j * 3);
+            if (d != d) continue;                       // NaN never selected (as `<` in the oracle)
+            const unsigned long long key = knn_key(d, j);
+            if ((first || key > last) && key < best) best = key;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long ob = __shfl_xor(best, off);
+            best = ob < best ? ob : best;
+        }
+        if (lane == 0) o[t] = (int)(unsigned)(best & 0xffffffffull);
+        last = best; first = false;
+    }
+}
+
+}  // namespace
+
+extern "C" int i2p_project_seq(int b, int n, int H, int W, float fup_deg, float fdown_deg,
+                               const float *xyz, int nfeat, const float *const *feats,
+                               const int *feat_dims, float *out_xyz, float *const *out_feats,
+                               int *cell_winner, void *stream) {
+    if (b < 0 || n < 0 || H <= 1 || W <= 0 || nfeat < 0 || nfeat > 4) return I2P_ERR_BAD_ARG;
+    if (b == 0) return 0;
+    if (!out_xyz || !cell_winner || (n > 0 && !xyz) || (nfeat > 0 && (!feats || !feat_dims || !out_feats)))
+        return I2P_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    // constants exactly as the oracle derives them (double math, rounded to fp32 once)
+    const double deg2rad = 3.14159265358979323846 / 180.0;
+    const double vdown = (double)fdown_deg * deg2rad, vup = (double)fup_deg * deg2rad;
+    const double vres_d = (vup - vdown) / (H - 1);
+    ProjConst pc;
+    pc.az_res = (float)((360.0 / W) * deg2rad);
+    pc.vres = (float)vres_d;
+    pc.voff = (float)(-vdown / vres_d);
+
+    ProjFeats f;
+    f.n_img = nfeat + 1;
+    f.src[0] = xyz; f.dst[0] = out_xyz; f.dim[0] = 3; f.off[0] = 0;
+    for (int i = 0; i < nfeat; ++i) {
+        if (feat_dims[i] <= 0 || !feats[i] || !out_feats[i]) return I2P_ERR_BAD_ARG;
+        f.src[i + 1] = feats[i]; f.dst[i + 1] = out_feats[i]; f.dim[i + 1] = feat_dims[i];
+    }
+    for (int i = nfeat + 1; i < 5; ++i) { f.src[i] = nullptr; f.dst[i] = nullptr; f.dim[i] = 0; }
+    for (int i = 0; i < 5; ++i) f.off[i + 1] = f.off[i] + f.dim[i];
+    const int ctot = f.off[5];
+    const int hw = H * W;
+
+    hipLaunchKernelGGL(proj_init_kernel, dim3((b * hw + 255) / 256), dim3(256), 0, st, b * hw, cell_winner);
+    if (n > 0)
+        hipLaunchKernelGGL(proj_assign_kernel, dim3((n + 255) / 256, b), dim3(256), 0, st, n, H, W, pc, xyz,
+                           cell_winner);
+    const long long tot = (long long)hw * ctot;
+    hipLaunchKernelGGL(proj_fill_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0, st, n, hw, ctot,
+                       f, cell_winner);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_gather_rows(int b, int hw, int c, int q, int W, const float *feat,
+                               const int64_t *h_idx, const int64_t *w_idx, float *out,
+                               void *stream) {
+    if (b < 0 || hw < 0 || c < 0 || q < 0 || W <= 0) return I2P_ERR_BAD_ARG;
+    if ((long long)b * q * c == 0) return 0;
+    if (!feat || !h_idx || !w_idx || !out) return I2P_ERR_BAD_ARG;
+    const long long tot = (long long)q * c;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0,
+                       (hipStream_t)stream, hw, c, q, W, feat, h_idx, w_idx, out);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_gather_rows_grad(int b, int hw, int c, int q, int W, const float *grad_out,
+                                    const int64_t *h_idx, const int64_t *w_idx,
+                                    float *grad_feat, void *stream) {
+    if (b < 0 || hw < 0 || c < 0 || q < 0 || W <= 0) return I2P_ERR_BAD_ARG;
+    if ((long long)b * q * c == 0) return 0;
+    if (!grad_out || !h_idx || !w_idx || !grad_feat) return I2P_ERR_BAD_ARG;
+    const long long tot = (long long)q * c;
+    hipLaunchKernelGGL(gather_rows_grad_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0,
+                       (hipStream_t)stream, hw, c, q, W, grad_out, h_idx, w_idx, grad_feat);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_knn(int b, int n, int s, int k, const float *xyz, const float *new_xyz,
+                       int *idx, void *stream) {
+    if (b < 0 || n < 0 || s < 0 || k < 0 || k > n) return I2P_ERR_BAD_ARG;
+    if ((long long)b * s == 0 || k == 0) return 0;
+    if (!xyz || !new_xyz || !idx) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(knn_kernel, dim3((s + 3) / 4, b), dim3(256), 0, (hipStream_t)stream, n, s, k, xyz,
+                       new_xyz, idx);
+    I2P_RETURN_LAUNCH_STATUS();
+}

@@ -1,0 +1,184 @@
+"""Tensor-level bindings of the C ABI (include/i2p_ops.h).
+
+`CBackend` marshals torch tensors to raw pointers for a table of C functions; the product
+instance (`hip_backend()`) is bound to libi2p_ops.so and only accepts contiguous CUDA/HIP
+tensors, launching on torch's current stream.  The argument lists are exactly the pybind
+surfaces of the reference (`fused_conv_g.cpp:15-67`, `pointnet2/src/pointnet2_api.cpp:10-24`).
+
+`set_backend()` exists so that tests and bench.py's cpu_baseline leg can run the host logic
+against the CPU oracle; nothing in this package ever installs a non-HIP backend.
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi, _lib
+
+_F32, _I32, _I64 = torch.float32, torch.int32, torch.int64
+
+
+class CBackend:
+    """Calls `fns[name](*scalars_and_pointers [, stream])`."""
+
+    def __init__(self, call, device_type, name):
+        self._call = call            # call(name, *args, stream=...)
+        self.device_type = device_type
+        self.name = name
+
+    # ---- marshalling ----------------------------------------------------------------------
+    def _p(self, t, dtype, what):
+        if not isinstance(t, torch.Tensor):
+            raise RuntimeError(f"{what} must be a tensor")
+        if t.device.type != self.device_type:
+            # reference: TORCH_CHECK(x.type().is_cuda(), ...) — fused_conv_g.cpp:11
+            raise RuntimeError(f"{what} must be a {self.device_type} tensor (got {t.device})")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{what} must be contiguous")   # fused_conv_g.cpp:12
+        if t.dtype != dtype:
+            raise RuntimeError(f"{what} must be {dtype} (got {t.dtype})")
+        return C.c_void_p(t.data_ptr())
+
+    def _stream(self):
+        if self.device_type == "cuda":
+            return torch.cuda.current_stream().cuda_stream
+        return 0
+
+    # ---- fused_conv_select_k (fused_conv_g.cpp:15-67) ---------------------------------------
+    def fused_conv_select_k(self, xyz1, xyz2, idx_n2, random_hw, H, W, npoints, kernel_size_H,
+                            kernel_size_W, K, flag, distance, stride_h, stride_w, select_b_idx,
+                            select_h_idx, select_w_idx, valid_idx, valid_in_dis_idx, select_mask,
+                            small_h, small_w):
+        batch = xyz1.size(0)                                   # fused_conv_g.cpp:50
+        self._call(
+            "i2p_fused_conv_select_k", int(batch), int(H), int(W), int(npoints),
+            int(kernel_size_H), int(kernel_size_W), int(K), int(flag), float(distance),
+            int(stride_h), int(stride_w),
+            self._p(xyz1, _F32, "xyz1"), self._p(xyz2, _F32, "xyz2"),
+            self._p(idx_n2, _I32, "idx_n2"), self._p(random_hw, _I32, "random_hw"),
+            self._p(select_b_idx, _I64, "select_b_idx"), self._p(select_h_idx, _I64, "select_h_idx"),
+            self._p(select_w_idx, _I64, "select_w_idx"), self._p(valid_idx, _F32, "valid_idx"),
+            self._p(valid_in_dis_idx, _F32, "valid_in_dis_idx"),
+            self._p(select_mask, _F32, "select_mask"), int(small_h), int(small_w),
+            stream=self._stream())
+
+    # ---- pointnet2 (pointnet2_api.cpp:10-24) ------------------------------------------------
+    def furthest_point_sampling_wrapper(self, b, n, m, points, temp, idx):
+        self._call("i2p_furthest_point_sampling", int(b), int(n), int(m),
+                   self._p(points, _F32, "points"), self._p(temp, _F32, "temp"),
+                   self._p(idx, _I32, "idx"), stream=self._stream())
+        return 1
+
+    def gather_points_wrapper(self, b, c, n, npoints, points, idx, out):
+        self._call("i2p_gather_points", int(b), int(c), int(n), int(npoints),
+                   self._p(points, _F32, "points"), self._p(idx, _I32, "idx"),
+                   self._p(out, _F32, "out"), stream=self._stream())
+        return 1
+
+    def gather_points_grad_wrapper(self, b, c, n, npoints, grad_out, idx, grad_points):
+        self._call("i2p_gather_points_grad", int(b), int(c), int(n), int(npoints),
+                   self._p(grad_out, _F32, "grad_out"), self._p(idx, _I32, "idx"),
+                   self._p(grad_points, _F32, "grad_points"), stream=self._stream())
+        return 1
+
+    def ball_query_wrapper(self, b, n, m, radius, nsample, new_xyz, xyz, idx):
+        self._call("i2p_ball_query", int(b), int(n), int(m), float(radius), int(nsample),
+                   self._p(new_xyz, _F32, "new_xyz"), self._p(xyz, _F32, "xyz"),
+                   self._p(idx, _I32, "idx"), stream=self._stream())
+        return 1
+
+    def group_points_wrapper(self, b, c, n, npoints, nsample, points, idx, out):
+        self._call("i2p_group_points", int(b), int(c), int(n), int(npoints), int(nsample),
+                   self._p(points, _F32, "points"), self._p(idx, _I32, "idx"),
+                   self._p(out, _F32, "out"), stream=self._stream())
+        return 1
+
+    def group_points_grad_wrapper(self, b, c, n, npoints, nsample, grad_out, idx, grad_points):
+        self._call("i2p_group_points_grad", int(b), int(c), int(n), int(npoints), int(nsample),
+                   self._p(grad_out, _F32, "grad_out"), self._p(idx, _I32, "idx"),
+                   self._p(grad_points, _F32, "grad_points"), stream=self._stream())
+        return 1
+
+    def three_nn_wrapper(self, b, n, m, unknown, known, dist2, idx):
+        self._call("i2p_three_nn", int(b), int(n), int(m), self._p(unknown, _F32, "unknown"),
+                   self._p(known, _F32, "known"), self._p(dist2, _F32, "dist2"),
+                   self._p(idx, _I32, "idx"), stream=self._stream())
+
+    def three_interpolate_wrapper(self, b, c, m, n, points, idx, weight, out):
+        self._call("i2p_three_interpolate", int(b), int(c), int(m), int(n),
+                   self._p(points, _F32, "points"), self._p(idx, _I32, "idx"),
+                   self._p(weight, _F32, "weight"), self._p(out, _F32, "out"),
+                   stream=self._stream())
+
+    def three_interpolate_grad_wrapper(self, b, c, n, m, grad_out, idx, weight, grad_points):
+        self._call("i2p_three_interpolate_grad", int(b), int(c), int(n), int(m),
+                   self._p(grad_out, _F32, "grad_out"), self._p(idx, _I32, "idx"),
+                   self._p(weight, _F32, "weight"), self._p(grad_points, _F32, "grad_points"),
+                   stream=self._stream())
+
+    # ---- operators that are eager PyTorch in the reference ------------------------------------
+    def project_seq(self, xyz, feats, H, W, fup, fdown):
+        """xyz [B,N,3], feats list of [B,N,D] -> (xyz_img [B,H,W,3], [feat_img [B,H,W,D]], winner [B,H*W])."""
+        B, N, _ = xyz.shape
+        dev = xyz.device
+        out_xyz = torch.empty(B, H, W, 3, dtype=_F32, device=dev)
+        outs = [torch.empty(B, H, W, f.shape[-1], dtype=_F32, device=dev) for f in feats]
+        winner = torch.empty(B, H * W, dtype=_I32, device=dev)
+        for f in feats:
+            self._p(f, _F32, "feature")
+        dims = (C.c_int * max(len(feats), 1))(*[int(f.shape[-1]) for f in feats])
+        src = _abi.ptr_array(feats)
+        dst = _abi.ptr_array(outs)
+        self._call("i2p_project_seq", int(B), int(N), int(H), int(W), float(fup), float(fdown),
+                   self._p(xyz, _F32, "xyz"), len(feats), C.cast(src, C.c_void_p),
+                   C.cast(dims, C.c_void_p), self._p(out_xyz, _F32, "out_xyz"),
+                   C.cast(dst, C.c_void_p), self._p(winner, _I32, "cell_winner"),
+                   stream=self._stream())
+        return out_xyz, outs, winner
+
+    def gather_rows(self, feat, h_idx, w_idx, W, out):
+        B, HW, Cc = feat.shape
+        Q = h_idx.shape[1]
+        self._call("i2p_gather_rows", int(B), int(HW), int(Cc), int(Q), int(W),
+                   self._p(feat, _F32, "feat"), self._p(h_idx, _I64, "h_idx"),
+                   self._p(w_idx, _I64, "w_idx"), self._p(out, _F32, "out"), stream=self._stream())
+
+    def gather_rows_grad(self, grad_out, h_idx, w_idx, W, grad_feat):
+        B, HW, Cc = grad_feat.shape
+        Q = h_idx.shape[1]
+        self._call("i2p_gather_rows_grad", int(B), int(HW), int(Cc), int(Q), int(W),
+                   self._p(grad_out, _F32, "grad_out"), self._p(h_idx, _I64, "h_idx"),
+                   self._p(w_idx, _I64, "w_idx"), self._p(grad_feat, _F32, "grad_feat"),
+                   stream=self._stream())
+
+    def knn(self, xyz, new_xyz, k, idx):
+        B, N, _ = xyz.shape
+        S = new_xyz.shape[1]
+        self._call("i2p_knn", int(B), int(N), int(S), int(k), self._p(xyz, _F32, "xyz"),
+                   self._p(new_xyz, _F32, "new_xyz"), self._p(idx, _I32, "idx"),
+                   stream=self._stream())
+
+
+_hip = None
+_active = None
+
+
+def hip_backend():
+    """The product backend: libi2p_ops.so on the current HIP device.  Raises if the library
+    is missing (no CPU fallback)."""
+    global _hip
+    if _hip is None:
+        _lib.load()
+        _hip = CBackend(_lib.call, "cuda", "hip")
+    return _hip
+
+
+def get_backend():
+    return _active if _active is not None else hip_backend()
+
+
+def set_backend(backend):
+    """Test / cpu-baseline hook only (see module docstring).  `None` restores the HIP backend."""
+    global _active
+    prev = _active
+    _active = backend
+    return prev

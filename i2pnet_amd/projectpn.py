@@ -1,0 +1,208 @@
+"""Operator layer of the projection point-cloud branch.
+
+Mirrors the function names and contracts of the reference's `src/projectPN/utils.py`
+(`get_idx_cuda`, `get_sample_idx`, `get_stride_idx_cuda`, `gather_torch`, `get_neighbor_copy`,
+`get_neighbor_att`, `check_valid`, `project_seq`, `grouping`, `square_distance`, `knn_point`,
+`index_points_group`) on top of libi2p_ops.so.  What changes is how they execute:
+
+* `gather_torch` is one HIP gather (and one scatter-add in backward) instead of an int64
+  index expansion + `torch.gather` + two permutes (utils.py:36-60);
+* `get_neighbor_*` no longer zero-fills the two `[B,N,kt,1]` float tensors the reference
+  allocates and never writes (utils.py:91-92; 3.9 MB per call at level 1);
+* `project_seq` is three small kernels with a deterministic duplicate-cell rule instead of a
+  Python loop of `index_put_` (utils.py:173-177);
+* `knn_point` never materialises the `[B,S,N]` distance matrix (utils.py:362-379).
+"""
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .fused_conv_select_k import FLAG_COPY, FLAG_SHIFT, fused_conv_select_k
+from .pointnet2_utils import grouping_operation
+
+# ---------------------------------------------------------------------------------------------
+# index grids (utils.py:8-33)
+# ---------------------------------------------------------------------------------------------
+
+
+def get_idx_cuda(B, H, W, device):
+    """[B, H*W, 2] i32 of (h, w) for every cell."""
+    return get_stride_idx_cuda(B, H, W, 1, 1, device)
+
+
+def get_stride_idx_cuda(B, out_h, out_w, stride_h, stride_w, device):
+    """[B, out_h*out_w, 2] i32 of (h*stride_h, w*stride_w)."""
+    h = torch.arange(0, out_h * stride_h, stride_h, device=device, dtype=torch.int32)
+    w = torch.arange(0, out_w * stride_w, stride_w, device=device, dtype=torch.int32)
+    grid = torch.stack(torch.meshgrid(h, w, indexing="ij"), dim=-1).reshape(1, out_h * out_w, 2)
+    return grid.expand(B, -1, -1).contiguous()
+
+
+def get_sample_idx(batch, out_h, out_w, stride_H, stride_W, device):
+    """three [batch, out_h, out_w] i64 grids (b, h*stride_H, w*stride_W)."""
+    h = torch.arange(0, out_h * stride_H, stride_H, device=device, dtype=torch.int64)
+    w = torch.arange(0, out_w * stride_W, stride_W, device=device, dtype=torch.int64)
+    b = torch.arange(batch, device=device, dtype=torch.int64)
+    return (b.view(-1, 1, 1).expand(batch, out_h, out_w).contiguous(),
+            h.view(1, -1, 1).expand(batch, out_h, out_w).contiguous(),
+            w.view(1, 1, -1).expand(batch, out_h, out_w).contiguous())
+
+
+# ---------------------------------------------------------------------------------------------
+# gather on channel-last images (utils.py:36-60)
+# ---------------------------------------------------------------------------------------------
+
+
+class _GatherRows(Function):
+    @staticmethod
+    def forward(ctx, feat, h_idx, w_idx, width):
+        # feat [B, HW, C] contiguous f32; h_idx/w_idx [B, Q] i64
+        B, HW, C = feat.shape
+        out = torch.empty(B, h_idx.shape[1], C, dtype=torch.float32, device=feat.device)
+        ops.get_backend().gather_rows(feat, h_idx, w_idx, width, out)
+        ctx.save_for_backward(h_idx, w_idx)
+        ctx.shape = (B, HW, C, width)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        h_idx, w_idx = ctx.saved_tensors
+        B, HW, C, width = ctx.shape
+        grad_feat = torch.zeros(B, HW, C, dtype=torch.float32, device=grad_out.device)
+        ops.get_backend().gather_rows_grad(grad_out.contiguous(), h_idx, w_idx, width, grad_feat)
+        return grad_feat, None, None, None
+
+
+def gather_torch(feature, neigh_b_idx, neigh_h_idx, neigh_w_idx, batch, height, width):
+    """feature [B,H,W,C] (any shape that reshapes to it), neigh_{h,w}_idx [B,H',W'] i64 ->
+    [B,H',W',C] = feature[b, h, w, :].  `neigh_b_idx` is ignored, as in the reference
+    (utils.py:48 uses only h*width+w)."""
+    nei_h, nei_w = neigh_h_idx.shape[1:3]
+    feat = feature.reshape(batch, height * width, -1)
+    if feat.dtype != torch.float32:
+        feat = feat.float()
+    h = neigh_h_idx.reshape(batch, -1).contiguous()
+    w = neigh_w_idx.reshape(batch, -1).contiguous()
+    out = _GatherRows.apply(feat.contiguous(), h, w, width)
+    return out.reshape(batch, nei_h, nei_w, -1)
+
+
+# ---------------------------------------------------------------------------------------------
+# neighbour selection (utils.py:63-103, :253-293)
+# ---------------------------------------------------------------------------------------------
+
+_arange_cache = {}
+
+
+def _window_order(kt, device):
+    key = (kt, str(device))
+    t = _arange_cache.get(key)
+    if t is None:
+        t = torch.arange(0, kt, device=device, dtype=torch.int32)     # utils.py:84
+        _arange_cache[key] = t
+    return t
+
+
+def _get_neighbor(xyz1_proj, xyz2_proj, idx_n2, kernel_shape, knn_points, stride_h, stride_w,
+                  distance, flag):
+    batch, height, width, _ = xyz1_proj.shape
+    small_h, small_w = xyz2_proj.shape[1], xyz2_proj.shape[2]
+    kt = kernel_shape[0] * kernel_shape[1]
+    n_points = idx_n2.shape[1]
+    dev = xyz1_proj.device
+    random_hw = _window_order(kt, dev)
+    sel = torch.zeros(3, batch, n_points, knn_points, 1, device=dev, dtype=torch.long)
+    mask = torch.zeros(batch, n_points, knn_points, 1, device=dev, dtype=torch.float32)
+    # never written by the operator (reference allocates [B,N,kt,1] zeros for both)
+    unused = torch.zeros(1, device=dev, dtype=torch.float32)
+    fused_conv_select_k(xyz1_proj.contiguous(), xyz2_proj.contiguous(), idx_n2.contiguous(), random_hw,
+                        height, width, n_points, kernel_shape[0], kernel_shape[1], knn_points, flag,
+                        distance, stride_h, stride_w, sel[0], sel[1], sel[2], unused, unused, mask,
+                        small_h, small_w)
+    return sel[0].squeeze(-1), sel[1].squeeze(-1), sel[2].squeeze(-1), mask
+
+
+def get_neighbor_copy(xyz1_proj, xyz2_proj, idx_n2, kernel_shape, knn_points, stride_h=1, stride_w=1,
+                      distance=10):
+    """K nearest window cells of `xyz2_proj` for the query cells `idx_n2` of `xyz1_proj`;
+    empty slots repeat the nearest hit (FLAG_SHIFT|FLAG_COPY).  -> (b,h,w idx [B,N,K] i64, mask [B,N,K,1])."""
+    return _get_neighbor(xyz1_proj, xyz2_proj, idx_n2, kernel_shape, knn_points, stride_h, stride_w,
+                         distance, FLAG_SHIFT | FLAG_COPY)
+
+
+def get_neighbor_att(xyz1_proj, xyz2_proj, idx_n2, kernel_shape, knn_points, stride_h=1, stride_w=1,
+                     distance=10):
+    """Same search, empty slots stay (0,0) with mask 0 (FLAG_SHIFT only)."""
+    return _get_neighbor(xyz1_proj, xyz2_proj, idx_n2, kernel_shape, knn_points, stride_h, stride_w,
+                         distance, FLAG_SHIFT)
+
+
+def check_valid(xyz):
+    """1.0 where the point is not the all-zero "empty cell" marker (utils.py:106-108)."""
+    return torch.any(torch.ne(xyz, 0), dim=-1, keepdim=True).float()
+
+
+# ---------------------------------------------------------------------------------------------
+# spherical projection (utils.py:111-187)
+# ---------------------------------------------------------------------------------------------
+
+
+def project_seq(xyz, features, H, W, use_rank=True, fup=2.0, fdown=-24.8):
+    """xyz [B,N,3], features list of [B,N,D] -> (xyz_proj [B,H,W,3], [feature_proj [B,H,W,D]]).
+
+    Cell of a point: col = trunc((pi - atan2(y,x)) / (2*pi/W)), row = H - trunc(asin(z/r)/dv + off),
+    clamped.  When several points share a cell the highest point index wins (with `use_rank`
+    the cloud is first ordered by decreasing range, so the nearest point wins)."""
+    xyz = xyz.float().contiguous()
+    feats = [f.float().contiguous() for f in features]
+    if use_rank:
+        with torch.no_grad():
+            rank = torch.argsort(torch.norm(xyz, p=2, dim=2), dim=1, descending=True)  # utils.py:159
+        xyz = torch.gather(xyz, 1, rank[:, :, None].expand(-1, -1, 3)).contiguous()
+        feats = [torch.gather(f, 1, rank[:, :, None].expand(-1, -1, f.shape[-1])).contiguous() for f in feats]
+    with torch.no_grad():
+        out_xyz, outs, _ = ops.get_backend().project_seq(xyz, feats, H, W, fup, fdown)
+    return out_xyz, outs
+
+
+# ---------------------------------------------------------------------------------------------
+# kNN grouping in the normalised image plane (utils.py:313-393)
+# ---------------------------------------------------------------------------------------------
+
+
+def square_distance(src, dst):
+    """[B,N,C] x [B,M,C] -> [B,N,M] squared distances (expanded form, utils.py:343-364)."""
+    dist = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    dist += torch.sum(src ** 2, -1).unsqueeze(-1)
+    dist += torch.sum(dst ** 2, -1).unsqueeze(1)
+    return dist
+
+
+def knn_point(nsample, xyz, new_xyz):
+    """indices [B,S,nsample] (i64) of the nsample nearest `xyz` points of every `new_xyz` point.
+    Ordered by (distance, index); the reference's topk(sorted=False) order is unspecified."""
+    B, S, _ = new_xyz.shape
+    idx = torch.empty(B, S, nsample, dtype=torch.int32, device=xyz.device)
+    with torch.no_grad():
+        ops.get_backend().knn(xyz.detach().float().contiguous(), new_xyz.detach().float().contiguous(),
+                              nsample, idx)
+    return idx.long()
+
+
+def index_points_group(points, knn_idx):
+    """points [B,N,C], knn_idx [B,S,K] -> [B,S,K,C] (utils.py:382-393, via group_points)."""
+    points_flipped = points.permute(0, 2, 1).contiguous()
+    return grouping_operation(points_flipped, knn_idx.int().contiguous()).permute(0, 2, 3, 1)
+
+
+def grouping(feature, K, src_xyz, q_xyz, use_xyz=False):
+    """-> grouped_xyz [B,S,K,3], xyz_diff [B,S,K,3], new_points [B,S,K,C(+3)], idx [B,S,K]"""
+    q_xyz = q_xyz.contiguous()
+    src_xyz = src_xyz.contiguous()
+    point_indices = knn_point(K, src_xyz, q_xyz)
+    grouped_xyz = index_points_group(src_xyz, point_indices)
+    xyz_diff = grouped_xyz - q_xyz.unsqueeze(2)
+    grouped_feature = index_points_group(feature, point_indices)
+    new_points = torch.cat([xyz_diff, grouped_feature], dim=-1) if use_xyz else grouped_feature
+    return grouped_xyz, xyz_diff, new_points, point_indices

@@ -1,0 +1,158 @@
+/*
+ * i2p_ops.h — C ABI of libi2p_ops.so, the MI355X (gfx950) implementation of I2PNet's
+ * native point-cloud operators.
+ *
+ * Every entry point replaces one raw launcher of the reference's two CUDA extensions
+ * (cited per function as file:line under the reference tree).  Conventions shared by all:
+ *
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers owned by the
+ *     caller (the library never allocates, frees or synchronises);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are
+ *     asynchronous on it, re-entrant, no global state, safe for hipGraph capture;
+ *   - return value: 0 on success, a positive hipError_t if a launch failed, a negative
+ *     I2P_ERR_* for a rejected argument.  The library never calls exit() (the reference's
+ *     launchers `fprintf(stderr)+exit(-1)`, e.g. fused_conv_go.cu:259-263);
+ *   - caller pre-fills are the reference's: outputs of fused_conv_select_k zeroed
+ *     (src/projectPN/utils.py:86-94), FPS `temp` = 1e10 (pointnet2/pointnet2_utils.py:56),
+ *     ball_query idx = 0 (:249), every *_grad output = 0 (:98,:177,:221);
+ *   - integer/index outputs are bit-exact w.r.t. the CPU oracle (oracle/i2p_oracle.c), which
+ *     exports the same signatures minus `stream` under the suffix `_cpu`.
+ *
+ * Squared distances are evaluated in ONE fixed order everywhere (oracle and device):
+ *     d = fmaf(dz, dz, fmaf(dy, dy, dx * dx))
+ * which is what nvcc's default FMA contraction makes of the reference's
+ * `(a)*(a) + (b)*(b) + (c)*(c)` expressions.
+ */
+#ifndef I2P_OPS_H_
+#define I2P_OPS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I2P_ERR_BAD_ARG   (-1)  /* negative size, NULL pointer with non-empty work          */
+#define I2P_ERR_WINDOW    (-2)  /* kernel_size_H*kernel_size_W > I2P_MAX_WINDOW               */
+#define I2P_ERR_K         (-3)  /* K > I2P_MAX_WINDOW                                         */
+
+/* The reference keeps `int idx_w[150], idx_h[150]; float Dist[150]` per thread
+ * (fused_conv_go.cu:52-53) and silently overflows beyond that; we reject instead. */
+#define I2P_MAX_WINDOW 150
+
+#define I2P_FLAG_COPY  1   /* fused_conv_select_k.py:6 */
+#define I2P_FLAG_SHIFT 2   /* fused_conv_select_k.py:7 */
+
+/* ABI version / build info (not in the reference). */
+int i2p_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Projection-aware neighbour selection.
+ * Replaces FusedConvSelectKLauncher (src/projectPN/fused_conv_select/fused_conv_gpu.h:35-58,
+ * fused_conv_go.cu:243-264; kernel :11-240).
+ *   xyz1 f32 [B,H,W,3], xyz2 f32 [B,small_h,small_w,3], idx_n2 i32 [B,npoints,2],
+ *   random_hw i32 [kH*kW]; outputs i64 [B,npoints,K] x3, f32 [B,npoints,K];
+ *   valid_idx / valid_in_dis_idx f32 [B,npoints,kH*kW] are accepted and never written
+ *   (as in the reference).
+ * --------------------------------------------------------------------------------------------- */
+int i2p_fused_conv_select_k(int batch_size, int H, int W, int npoints, int kernel_size_H,
+                            int kernel_size_W, int K, int flag, float distance, int stride_h,
+                            int stride_w, const float *xyz1, const float *xyz2,
+                            const int *idx_n2, const int *random_hw, int64_t *selected_b_idx,
+                            int64_t *selected_h_idx, int64_t *selected_w_idx, float *valid_idx,
+                            float *valid_in_dis_idx, float *selected_mask, int small_h,
+                            int small_w, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * pointnet2 primitives (pointnet2/src/pointnet2_api.cpp:10-24).
+ * --------------------------------------------------------------------------------------------- */
+
+/* furthest_point_sampling_kernel_launcher (pointnet2/src/sampling_gpu.h:26-27, sampling_gpu.cu:211-253).
+ * dataset f32 [B,N,3], temp f32 [B,N] (=1e10 on entry, holds min-distances on exit), idxs i32 [B,M]. */
+int i2p_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                int *idxs, void *stream);
+
+/* gather_points_kernel_launcher_fast (sampling_gpu.h:12-13, sampling_gpu.cu:26-44).
+ * points f32 [B,C,N], idx i32 [B,M] -> out f32 [B,C,M]. */
+int i2p_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,
+                      float *out, void *stream);
+
+/* gather_points_grad_kernel_launcher_fast (sampling_gpu.h:19-20, sampling_gpu.cu:65-83).
+ * grad_out f32 [B,C,M], idx i32 [B,M] -> grad_points f32 [B,C,N] += (zeroed by caller). */
+int i2p_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                           const int *idx, float *grad_points, void *stream);
+
+/* ball_query_kernel_launcher_fast (ball_query_gpu.h:12-13, ball_query_gpu.cu:48-67).
+ * new_xyz f32 [B,M,3], xyz f32 [B,N,3] -> idx i32 [B,M,nsample] (zeroed by caller). */
+int i2p_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                   const float *xyz, int *idx, void *stream);
+
+/* group_points_kernel_launcher_fast (group_points_gpu.h:13-14, group_points_gpu.cu:69-87).
+ * points f32 [B,C,N], idx i32 [B,npoints,nsample] -> out f32 [B,C,npoints,nsample]. */
+int i2p_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                     const int *idx, float *out, void *stream);
+
+/* group_points_grad_kernel_launcher_fast (group_points_gpu.h:19-20, group_points_gpu.cu:27-44).
+ * grad_out f32 [B,C,npoints,nsample] -> grad_points f32 [B,C,N] += (zeroed by caller). */
+int i2p_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                          const int *idx, float *grad_points, void *stream);
+
+/* three_nn_kernel_launcher_fast (interpolate_gpu.h:13-14, interpolate_gpu.cu:55-74).
+ * unknown f32 [B,N,3], known f32 [B,M,3] -> dist2 f32 [B,N,3] (SQUARED), idx i32 [B,N,3]. */
+int i2p_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                 int *idx, void *stream);
+
+/* three_interpolate_kernel_launcher_fast (interpolate_gpu.h:20-21, interpolate_gpu.cu:99-117).
+ * points f32 [B,C,M], idx i32 [B,N,3], weight f32 [B,N,3] -> out f32 [B,C,N]. */
+int i2p_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                          const float *weight, float *out, void *stream);
+
+/* three_interpolate_grad_kernel_launcher_fast (interpolate_gpu.h:27-28, interpolate_gpu.cu:144-160).
+ * grad_out f32 [B,C,N] -> grad_points f32 [B,C,M] += (zeroed by caller). */
+int i2p_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                               const int *idx, const float *weight, float *grad_points,
+                               void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Operators the reference implements in eager PyTorch around the two extensions.  They sit on
+ * the same hot path and are exported here so the Python layer
+ * stays a thin shim.
+ * --------------------------------------------------------------------------------------------- */
+
+/* Spherical projection, src/projectPN/utils.py:111-187 (project_seq with use_rank=False).
+ *   xyz f32 [B,N,3] (the cloud that defines the cells and fills image 0),
+ *   feats: nfeat device pointers f32 [B,N,feat_dims[i]] (nfeat <= 4),
+ *   out_xyz f32 [B,H,W,3] and out_feats[i] f32 [B,H,W,feat_dims[i]]: fully written (zero where empty),
+ *   cell_winner i32 [B,H*W] scratch, fully rewritten (-1 = empty cell, else the point index
+ *   that owns the cell).  Duplicate-cell rule: highest point index wins (= CPU index_put_
+ *   last-writer-wins), the same winner for every image.
+ *   Rows with non-finite angles (zero points) land on (row 0, col 900*W/1800) like torch-CPU's
+ *   NaN.long() -> INT64_MIN -> clamp path.
+ */
+int i2p_project_seq(int b, int n, int H, int W, float fup_deg, float fdown_deg,
+                    const float *xyz, int nfeat, const float *const *feats,
+                    const int *feat_dims, float *out_xyz, float *const *out_feats,
+                    int *cell_winner, void *stream);
+
+/* Row gather on channel-last images, src/projectPN/utils.py:36-60 (gather_torch):
+ *   out[b, q, :] = feat[b, h_idx[b,q]*W + w_idx[b,q], :]    feat f32 [B,HW,C], idx i64 [B,Q]. */
+int i2p_gather_rows(int b, int hw, int c, int q, int W, const float *feat,
+                    const int64_t *h_idx, const int64_t *w_idx, float *out, void *stream);
+
+/* Backward of i2p_gather_rows: grad_feat[b, h*W+w, :] += grad_out[b, q, :] (zeroed by caller). */
+int i2p_gather_rows_grad(int b, int hw, int c, int q, int W, const float *grad_out,
+                         const int64_t *h_idx, const int64_t *w_idx, float *grad_feat,
+                         void *stream);
+
+/* Brute-force kNN, src/projectPN/utils.py:343-380 (square_distance + topk(largest=False)).
+ *   xyz f32 [B,N,3] (searched), new_xyz f32 [B,S,3] (queries) -> idx i32 [B,S,k], ascending by
+ *   (distance, index).  The distance is the reference's expanded form
+ *   d = -2*(q.p) + |q|^2 + |p|^2 evaluated as in i2p_oracle.c; torch.topk(sorted=False) leaves
+ *   the order unspecified, so parity is on neighbour SETS. */
+int i2p_knn(int b, int n, int s, int k, const float *xyz, const float *new_xyz, int *idx,
+            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I2P_OPS_H_ */

@@ -1,0 +1,58 @@
+"""Seeded synthetic inputs shared by the CPU and GPU tests."""
+import numpy as np
+import torch
+
+
+def range_image(B, H, W, seed, empty_frac=0.2, lattice=False, scale=20.0):
+    """[B,H,W,3] f32 range-image-like tensor with `empty_frac` all-zero cells.
+    lattice=True puts points on a coarse integer lattice so that equal distances (ties) are
+    everywhere — the case the reference resolves by selection-sort swap history."""
+    g = torch.Generator().manual_seed(seed)
+    if lattice:
+        img = torch.randint(-3, 4, (B, H, W, 3), generator=g).float()
+    else:
+        # smooth surface + noise so neighbours are close in 3-D like a LiDAR scan
+        az = torch.linspace(-np.pi, np.pi, W).view(1, 1, W)
+        el = torch.linspace(-0.4, 0.05, H).view(1, H, 1)
+        r = scale * (0.5 + torch.rand(B, H, W, generator=g))
+        img = torch.stack([r * torch.cos(el) * torch.cos(az), r * torch.cos(el) * torch.sin(az),
+                           r * torch.sin(el).expand(B, H, W)], -1)
+    keep = (torch.rand(B, H, W, 1, generator=g) >= empty_frac).float()
+    return (img * keep).contiguous()
+
+
+def run_fcsk(backend, xyz1, xyz2, idx_n2, kH, kW, K, flag, distance, stride_h, stride_w, random_hw=None):
+    B, H, W, _ = xyz1.shape
+    sh, sw = xyz2.shape[1:3]
+    N = idx_n2.shape[1]
+    dev = xyz1.device
+    if random_hw is None:
+        random_hw = torch.arange(kH * kW, dtype=torch.int32, device=dev)
+    sb = torch.zeros(B, N, K, 1, dtype=torch.long, device=dev)
+    sh_ = torch.zeros_like(sb); sw_ = torch.zeros_like(sb)
+    v1 = torch.zeros(B, N, kH * kW, 1, device=dev); v2 = torch.zeros_like(v1)
+    m = torch.zeros(B, N, K, 1, device=dev)
+    backend.fused_conv_select_k(xyz1, xyz2, idx_n2, random_hw, H, W, N, kH, kW, K, flag, distance,
+                                stride_h, stride_w, sb, sh_, sw_, v1, v2, m, sh, sw)
+    return sb, sh_, sw_, m, v1, v2
+
+
+def stride_grid(B, out_h, out_w, sh, sw):
+    h = torch.arange(0, out_h * sh, sh, dtype=torch.int32)
+    w = torch.arange(0, out_w * sw, sw, dtype=torch.int32)
+    g = torch.stack(torch.meshgrid(h, w, indexing="ij"), -1).reshape(1, -1, 2)
+    return g.expand(B, -1, -1).contiguous()
+
+
+def cloud(B, N, seed, dup_frac=0.0, zero_frac=0.0):
+    g = torch.Generator().manual_seed(seed)
+    pts = (torch.rand(B, N, 3, generator=g) - 0.5) * 40.0
+    if dup_frac > 0:      # exact duplicates -> FPS ties
+        nd = int(N * dup_frac)
+        src = torch.randint(0, N, (nd,), generator=g)
+        dst = torch.randint(0, N, (nd,), generator=g)
+        pts[:, dst] = pts[:, src]
+    if zero_frac > 0:
+        nz = int(N * zero_frac)
+        pts[:, N - nz:] = 0.0
+    return pts.contiguous()

@@ -1,0 +1,214 @@
+"""GPU parity: every C-ABI entry of libi2p_ops.so against the CPU oracle on the same seeded
+inputs.  Integer / index outputs must be bit-exact; float copies bit-exact; atomically
+accumulated gradients within 1e-5 (summation order differs)."""
+import pytest
+import torch
+
+from helpers import cloud, range_image, run_fcsk, stride_grid
+
+pytestmark = pytest.mark.gpu
+FLAG_COPY, FLAG_SHIFT = 1, 2
+DEV = "cuda"
+
+
+def _both_fcsk(ob, hb, xyz1, xyz2, idx, kH, kW, K, flag, dist, sh, sw, random_hw=None):
+    ref = run_fcsk(ob, xyz1, xyz2, idx, kH, kW, K, flag, dist, sh, sw, random_hw)
+    got = run_fcsk(hb, xyz1.to(DEV), xyz2.to(DEV), idx.to(DEV), kH, kW, K, flag, dist, sh, sw,
+                   None if random_hw is None else random_hw.to(DEV))
+    torch.cuda.synchronize()
+    for name, r, g in zip(["b", "h", "w", "mask", "valid_idx", "valid_in_dis"], ref, got):
+        assert torch.equal(r, g.cpu()), f"{name} differs: {(r != g.cpu()).sum().item()} of {r.numel()}"
+
+
+# (kernel, K, flag, distance, stride) signatures of the model on reduced grids
+SIGS = [
+    ((9, 15), 32, 3, 0.75, (1, 1)),   # LiDAR_lv1
+    ((9, 15), 16, 3, 3.0, (1, 1)),    # LiDAR_lv2
+    ((5, 9), 16, 3, 6.0, (1, 1)),     # LiDAR_lv3/4, layer_idx
+    ((5, 9), 8, 3, 9.0, (1, 2)),      # set_upconv (coarse image searched with stride)
+    ((3, 5), 4, 2, 4.5, (1, 1)),      # cost volume pc-stage (FLAG_SHIFT only)
+    ((1, 3), 5, 2, 200.0, (1, 2)),    # reference smoke-test signature
+    ((10, 15), 7, 0, 5.0, (1, 1)),    # kt = 150 (max), no wrap, no copy
+    ((2, 2), 9, 1, 5.0, (1, 1)),      # K > kt, copy without wrap
+]
+
+
+@pytest.mark.parametrize("sig", SIGS)
+@pytest.mark.parametrize("lattice", [False, True])
+def test_fcsk_parity_model_signatures(oracle_backend, hip_backend, sig, lattice):
+    (kH, kW), K, flag, dist, (sh, sw) = sig
+    B, H, W = 3, 16, 90
+    x1 = range_image(B, H, W, seed=kH * 100 + K, empty_frac=0.25, lattice=lattice, scale=4.0)
+    if (sh, sw) == (1, 1):
+        x2 = x1
+        idx = stride_grid(B, H // 2, W // 3, 2, 3)
+    else:
+        x2 = range_image(B, H // sh, (W + sw - 1) // sw, seed=7, empty_frac=0.25, lattice=lattice, scale=4.0)
+        idx = stride_grid(B, H, W, 1, 1)
+    _both_fcsk(oracle_backend, hip_backend, x1, x2, idx, kH, kW, K, flag, dist if not lattice else 3.5, sh, sw)
+
+
+def test_fcsk_adversarial(oracle_backend, hip_backend):
+    B, H, W = 2, 8, 24
+    idx = stride_grid(B, H, W, 1, 1)
+    # all-empty searched image: COPY broadcasts the sentinel (0,0) with mask 1
+    x1 = range_image(B, H, W, 1, empty_frac=0.0)
+    _both_fcsk(oracle_backend, hip_backend, x1, torch.zeros_like(x1), idx, 5, 9, 6, 3, 10.0, 1, 1)
+    # every centre invalid: outputs stay the caller's zeros
+    _both_fcsk(oracle_backend, hip_backend, torch.zeros_like(x1), x1, idx, 5, 9, 6, 3, 10.0, 1, 1)
+    # identical points everywhere: all distances tie at the 1e-10 clamp
+    same = torch.ones(B, H, W, 3)
+    _both_fcsk(oracle_backend, hip_backend, same, same, idx, 3, 5, 8, 3, 1.0, 1, 1)
+    # huge search radius: distance^2 >= 1e10 forces the verbatim serial path
+    _both_fcsk(oracle_backend, hip_backend, x1, x1, idx, 3, 5, 8, 3, 2.0e5, 1, 1)
+    # shuffled window visiting order (the reference's __main__ uses randperm)
+    g = torch.Generator().manual_seed(3)
+    rhw = torch.randperm(45, generator=g).int()
+    xl = range_image(B, H, W, 9, lattice=True)
+    _both_fcsk(oracle_backend, hip_backend, xl, xl, idx, 5, 9, 7, 3, 3.0, 1, 1, random_hw=rhw)
+    _both_fcsk(oracle_backend, hip_backend, x1, x1, idx, 5, 9, 7, 2, 3.0, 1, 1, random_hw=rhw)
+    # NaN / inf coordinates must not crash and must match
+    xn = x1.clone(); xn[0, 2, 3] = float("nan"); xn[1, 4, 5, 0] = float("inf")
+    _both_fcsk(oracle_backend, hip_backend, xn, xn, idx, 3, 5, 4, 3, 5.0, 1, 1)
+
+
+def test_fcsk_full_size_level1(oracle_backend, hip_backend):
+    """BASELINE shape: 64x1800 image, 16x225 queries, 9x15 window, K=32."""
+    B = 2
+    x = range_image(B, 64, 1800, 11, empty_frac=0.15, scale=15.0)
+    idx = stride_grid(B, 16, 225, 4, 8)
+    _both_fcsk(oracle_backend, hip_backend, x, x, idx, 9, 15, 32, 3, 0.75, 1, 1)
+
+
+def test_fcsk_errors(hip_backend):
+    x = range_image(1, 4, 8, 0).to(DEV)
+    idx = stride_grid(1, 2, 2, 1, 1).to(DEV)
+    with pytest.raises(RuntimeError):
+        run_fcsk(hip_backend, x, x, idx, 11, 15, 4, 3, 1.0, 1, 1)     # window > 150
+    with pytest.raises(RuntimeError):
+        run_fcsk(hip_backend, x.cpu(), x, idx, 3, 3, 4, 3, 1.0, 1, 1)  # host tensor
+
+
+@pytest.mark.parametrize("n,m,dup,zero", [(64, 16, 0.0, 0.0), (100, 30, 0.5, 0.0), (1000, 128, 0.2, 0.1),
+                                          (1024, 256, 0.0, 0.0), (8192, 2048, 0.05, 0.02),
+                                          (9000, 64, 0.1, 0.0), (1, 1, 0.0, 0.0), (5, 5, 0.0, 0.0)])
+def test_fps_parity(oracle_backend, hip_backend, n, m, dup, zero):
+    B = 3
+    pts = cloud(B, n, seed=n + m, dup_frac=dup, zero_frac=zero)
+    ref = torch.zeros(B, m, dtype=torch.int32); rt = torch.full((B, n), 1e10)
+    oracle_backend.furthest_point_sampling_wrapper(B, n, m, pts, rt, ref)
+    got = torch.zeros(B, m, dtype=torch.int32, device=DEV); gt = torch.full((B, n), 1e10, device=DEV)
+    hip_backend.furthest_point_sampling_wrapper(B, n, m, pts.to(DEV), gt, got)
+    assert torch.equal(ref, got.cpu())
+    assert torch.equal(rt, gt.cpu())          # running min-distances are part of the interface
+
+
+def test_ball_query_parity(oracle_backend, hip_backend):
+    for (N, M, ns, r) in [(500, 77, 16, 6.0), (64, 64, 4, 100.0), (300, 10, 32, 0.01), (130, 5, 200, 1e3)]:
+        B = 2
+        xyz = cloud(B, N, N); new_xyz = cloud(B, M, M + 1)
+        new_xyz[:, : min(M, N) // 2] = xyz[:, : min(M, N) // 2]
+        ref = torch.zeros(B, M, ns, dtype=torch.int32)
+        oracle_backend.ball_query_wrapper(B, N, M, r, ns, new_xyz, xyz, ref)
+        got = torch.zeros(B, M, ns, dtype=torch.int32, device=DEV)
+        hip_backend.ball_query_wrapper(B, N, M, r, ns, new_xyz.to(DEV), xyz.to(DEV), got)
+        assert torch.equal(ref, got.cpu())
+
+
+def test_group_gather_parity(oracle_backend, hip_backend):
+    B, C, N, P, S = 2, 37, 468, 57, 32
+    g = torch.Generator().manual_seed(0)
+    feats = torch.randn(B, C, N, generator=g)
+    idx = torch.randint(0, N, (B, P, S), generator=g, dtype=torch.int32)
+    ref = torch.empty(B, C, P, S); got = torch.empty(B, C, P, S, device=DEV)
+    oracle_backend.group_points_wrapper(B, C, N, P, S, feats, idx, ref)
+    hip_backend.group_points_wrapper(B, C, N, P, S, feats.to(DEV), idx.to(DEV), got)
+    assert torch.equal(ref, got.cpu())
+    go = torch.randn(B, C, P, S, generator=g)
+    rg = torch.zeros(B, C, N); gg = torch.zeros(B, C, N, device=DEV)
+    oracle_backend.group_points_grad_wrapper(B, C, N, P, S, go, idx, rg)
+    hip_backend.group_points_grad_wrapper(B, C, N, P, S, go.to(DEV), idx.to(DEV), gg)
+    assert torch.allclose(rg, gg.cpu(), rtol=1e-5, atol=1e-5)
+    idx1 = idx[:, :, 0].contiguous()
+    ref = torch.empty(B, C, P); got = torch.empty(B, C, P, device=DEV)
+    oracle_backend.gather_points_wrapper(B, C, N, P, feats, idx1, ref)
+    hip_backend.gather_points_wrapper(B, C, N, P, feats.to(DEV), idx1.to(DEV), got)
+    assert torch.equal(ref, got.cpu())
+    go = torch.randn(B, C, P, generator=g)
+    rg = torch.zeros(B, C, N); gg = torch.zeros(B, C, N, device=DEV)
+    oracle_backend.gather_points_grad_wrapper(B, C, N, P, go, idx1, rg)
+    hip_backend.gather_points_grad_wrapper(B, C, N, P, go.to(DEV), idx1.to(DEV), gg)
+    assert torch.allclose(rg, gg.cpu(), rtol=1e-5, atol=1e-5)
+
+
+def test_three_nn_interpolate_parity(oracle_backend, hip_backend):
+    B, N, M, C = 2, 700, 1500, 19
+    unk, kn = cloud(B, N, 1), cloud(B, M, 2, dup_frac=0.2)
+    rd = torch.empty(B, N, 3); ri = torch.empty(B, N, 3, dtype=torch.int32)
+    oracle_backend.three_nn_wrapper(B, N, M, unk, kn, rd, ri)
+    gd = torch.empty(B, N, 3, device=DEV); gi = torch.empty(B, N, 3, dtype=torch.int32, device=DEV)
+    hip_backend.three_nn_wrapper(B, N, M, unk.to(DEV), kn.to(DEV), gd, gi)
+    assert torch.equal(ri, gi.cpu()) and torch.equal(rd, gd.cpu())
+    g = torch.Generator().manual_seed(0)
+    w = torch.rand(B, N, 3, generator=g); feats = torch.randn(B, C, M, generator=g)
+    ro = torch.empty(B, C, N); go = torch.empty(B, C, N, device=DEV)
+    oracle_backend.three_interpolate_wrapper(B, C, M, N, feats, ri, w, ro)
+    hip_backend.three_interpolate_wrapper(B, C, M, N, feats.to(DEV), gi, w.to(DEV), go)
+    assert torch.equal(ro, go.cpu())
+    gout = torch.randn(B, C, N, generator=g)
+    rg = torch.zeros(B, C, M); gg = torch.zeros(B, C, M, device=DEV)
+    oracle_backend.three_interpolate_grad_wrapper(B, C, N, M, gout, ri, w, rg)
+    hip_backend.three_interpolate_grad_wrapper(B, C, N, M, gout.to(DEV), gi, w.to(DEV), gg)
+    assert torch.allclose(rg, gg.cpu(), rtol=1e-5, atol=1e-5)
+
+
+def test_gather_rows_parity(oracle_backend, hip_backend):
+    B, H, W, C, Q = 2, 16, 225, 35, 904 * 16
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(B, H * W, C, generator=g)
+    h = torch.randint(0, H, (B, Q), generator=g); w = torch.randint(0, W, (B, Q), generator=g)
+    ro = torch.empty(B, Q, C); go = torch.empty(B, Q, C, device=DEV)
+    oracle_backend.gather_rows(feat, h, w, W, ro)
+    hip_backend.gather_rows(feat.to(DEV), h.to(DEV), w.to(DEV), W, go)
+    assert torch.equal(ro, go.cpu())
+    gout = torch.randn(B, Q, C, generator=g)
+    rg = torch.zeros(B, H * W, C); gg = torch.zeros(B, H * W, C, device=DEV)
+    oracle_backend.gather_rows_grad(gout, h, w, W, rg)
+    hip_backend.gather_rows_grad(gout.to(DEV), h.to(DEV), w.to(DEV), W, gg)
+    assert torch.allclose(rg, gg.cpu(), rtol=1e-4, atol=1e-4)
+
+
+def test_knn_parity(oracle_backend, hip_backend):
+    for (N, S, k) in [(468, 228, 32), (100, 7, 100), (2048, 64, 16)]:
+        B = 2
+        xyz = cloud(B, N, N + 3, dup_frac=0.1); q = cloud(B, S, S + 5)
+        ri = torch.empty(B, S, k, dtype=torch.int32); gi = torch.empty(B, S, k, dtype=torch.int32, device=DEV)
+        oracle_backend.knn(xyz, q, k, ri)
+        hip_backend.knn(xyz.to(DEV), q.to(DEV), k, gi)
+        assert torch.equal(ri, gi.cpu())
+
+
+def test_project_seq_parity(oracle_backend, hip_backend):
+    """Cells are bit-exact for points away from a bin edge (device OCML vs host libm differ in
+    the last ulp of atan2/asin); images are compared on cells whose winner agrees."""
+    B, N, H, W = 2, 20000, 64, 1800
+    g = torch.Generator().manual_seed(0)
+    az = (torch.rand(B, N, generator=g) * 2 - 1) * 3.14159
+    el = torch.deg2rad(torch.rand(B, N, generator=g) * 26.8 - 24.8)
+    r = 3 + 57 * torch.rand(B, N, generator=g)
+    xyz = torch.stack([r * torch.cos(el) * torch.cos(az), r * torch.cos(el) * torch.sin(az), r * torch.sin(el)], -1)
+    xyz[:, N - 500:] = 0.0                        # zero padding rows like the reference loaders
+    xyz = xyz.contiguous()
+    f1 = torch.rand(B, N, 1, generator=g); f2 = torch.randn(B, N, 3, generator=g)
+    rx, rf, rw = oracle_backend.project_seq(xyz, [f1, f2], H, W, 2.0, -24.8)
+    gx, gf, gw = hip_backend.project_seq(xyz.to(DEV), [f1.to(DEV), f2.to(DEV)], H, W, 2.0, -24.8)
+    same = rw == gw.cpu()
+    assert same.float().mean() > 0.9995, same.float().mean()
+    m = same.view(B, H, W, 1)
+    assert torch.equal(rx * m, gx.cpu() * m)
+    for a, b2 in zip(rf, gf):
+        assert torch.equal(a * m, b2.cpu() * m)
+    # self-consistency on the device: every filled cell holds its winner's rows
+    wn = gw.long().clamp(min=0)
+    exp = torch.gather(xyz.to(DEV), 1, wn.unsqueeze(-1).expand(-1, -1, 3)) * (gw >= 0).unsqueeze(-1)
+    assert torch.equal(exp.view(B, H, W, 3), gx)

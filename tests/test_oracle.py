@@ -1,0 +1,188 @@
+"""CPU tests: the oracle against the only known answers the reference holds for this path,
+and against independent (slow, pure-torch) restatements of the operator definitions."""
+import numpy as np
+import torch
+
+from helpers import cloud, range_image, run_fcsk, stride_grid
+from oracle import oracle
+
+FLAG_COPY, FLAG_SHIFT = 1, 2
+
+
+def test_reference_smoke_case_known_answer(oracle_backend):
+    """src/projectPN/fused_conv_select/fused_conv_select_k.py:29-139 with random_hw=arange(3):
+    H=4,W=9, small 4x5, 1x3 window, K=5, FLAG_SHIFT, stride (1,2), distance 200.
+    Hand-derived: query (0,2) -> w=[0,1,2,0,0]; query (0,0) -> w=[4,0,1,0,0] (wrap), h=0,
+    mask=[1,1,1,0,0] for both."""
+    H, W, SH, SW, K = 4, 9, 4, 5, 5
+    p1 = torch.ones(1, H, W, 3)
+    base = np.concatenate([np.arange(1, SH * (SW - 1) + 1).reshape(SH, SW - 1), np.ones((SH, 1))], 1)
+    p2 = torch.from_numpy(np.tile(base.reshape(1, SH, SW, 1).astype("float32"), [1, 1, 1, 3])).contiguous()
+    idx = torch.tensor([[[0, 2], [0, 0]]], dtype=torch.int32)
+    sb, sh, sw, m, v1, v2 = run_fcsk(oracle_backend, p1, p2, idx, 1, 3, K, FLAG_SHIFT, 200.0, 1, 2)
+    assert sw.view(2, K).tolist() == [[0, 1, 2, 0, 0], [4, 0, 1, 0, 0]]
+    assert sh.view(2, K).tolist() == [[0] * 5, [0] * 5]
+    assert sb.view(2, K).tolist() == [[0] * 5, [0] * 5]
+    assert m.view(2, K).tolist() == [[1, 1, 1, 0, 0]] * 2
+    assert float(v1.abs().sum()) == 0 and float(v2.abs().sum()) == 0     # never written
+
+
+def _fcsk_slow(xyz1, xyz2, idx_n2, kH, kW, K, flag, distance, sh_, sw_):
+    """Independent restatement via sorting with an explicit selection-sort (python)."""
+    B, H, W, _ = xyz1.shape
+    smh, smw = xyz2.shape[1:3]
+    N = idx_n2.shape[1]
+    ob = torch.zeros(B, N, K, dtype=torch.long); oh = ob.clone(); ow = ob.clone()
+    om = torch.zeros(B, N, K)
+    d2max = np.float32(distance) * np.float32(distance)
+    x1 = xyz1.numpy(); x2 = xyz2.numpy()
+    f = np.float32
+
+    def sq(a, b, c):
+        t = f(a * a)
+        t = f(np.float32(np.float64(b) * np.float64(b) + np.float64(t)))   # fma: exact product + add, one rounding
+        return f(np.float32(np.float64(c) * np.float64(c) + np.float64(t)))
+
+    for b in range(B):
+        for n in range(N):
+            ch, cw = [int(v) for v in idx_n2[b, n]]
+            c = x1[b, ch, cw]
+            if max(sq(*c), f(1e-10)) <= f(1e-10):
+                continue
+            D = [f(1e10)] * 150; ih = [0] * 150; iw = [0] * 150
+            for m in range(kH * kW):
+                h = ch // sh_ + m // kW - kH // 2
+                w = cw // sw_ + m % kW - kW // 2
+                if h < 0 or h >= smh:
+                    continue
+                if flag & 2:
+                    if w < 0: w += smw
+                    if w >= smw: w -= smw
+                elif w < 0 or w >= smw:
+                    continue
+                q = x2[b, h, w]
+                if sq(*q) <= f(1e-10):
+                    continue
+                d = max(sq(f(c[0] - q[0]), f(c[1] - q[1]), f(c[2] - q[2])), f(1e-10))
+                if d > d2max:
+                    continue
+                D[m] = d; ih[m] = h; iw[m] = w
+            for s in range(K):
+                j = s
+                for t in range(s + 1, kH * kW):
+                    if D[t] < D[j]: j = t
+                D[s], D[j] = D[j], D[s]; ih[s], ih[j] = ih[j], ih[s]; iw[s], iw[j] = iw[j], iw[s]
+                if (flag & 1) and s == 0:
+                    ob[b, n, :] = b; oh[b, n, :] = ih[0]; ow[b, n, :] = iw[0]; om[b, n, :] = 1
+                if D[s] < f(1e10):
+                    ob[b, n, s] = b; oh[b, n, s] = ih[s]; ow[b, n, s] = iw[s]; om[b, n, s] = 1
+    return ob, oh, ow, om
+
+
+def test_fcsk_oracle_vs_python_restatement(oracle_backend):
+    for seed, lattice, flag in [(0, False, 3), (1, True, 3), (2, True, 2), (3, False, 0), (4, True, 1)]:
+        x = range_image(2, 6, 20, seed, empty_frac=0.3, lattice=lattice, scale=3.0)
+        idx = stride_grid(2, 3, 10, 2, 2)
+        sb, sh, sw, m, _, _ = run_fcsk(oracle_backend, x, x, idx, 3, 5, 6, flag, 2.5, 1, 1)
+        ob, oh, ow, om = _fcsk_slow(x, x, idx, 3, 5, 6, flag, 2.5, 1, 1)
+        assert torch.equal(sb.squeeze(-1), ob) and torch.equal(sh.squeeze(-1), oh)
+        assert torch.equal(sw.squeeze(-1), ow) and torch.equal(m.squeeze(-1), om)
+
+
+def test_fcsk_rejects_oversized_window(oracle_backend):
+    x = range_image(1, 4, 8, 0)
+    idx = stride_grid(1, 2, 2, 1, 1)
+    try:
+        run_fcsk(oracle_backend, x, x, idx, 11, 15, 4, 3, 1.0, 1, 1)
+        assert False, "expected failure"
+    except RuntimeError:
+        pass
+
+
+def test_opt_n_threads():
+    # pointnet2/src/cuda_utils.h:10-14
+    for n, want in [(1, 1), (2, 2), (3, 2), (64, 64), (1000, 512), (1023, 512), (1024, 1024), (8192, 1024),
+                    (150000, 1024)]:
+        assert oracle.opt_n_threads(n) == want
+
+
+def _fps_tree_python(xyz, m, BS):
+    """Literal python emulation of sampling_gpu.cu:93-209 on one sample (float32)."""
+    n = xyz.shape[0]
+    f = np.float32
+    temp = np.full(n, 1e10, np.float32)
+    out = [0]
+    old = 0
+    X = xyz.astype(np.float32)
+    for _ in range(1, m):
+        dx = X[:, 0] - X[old, 0]; dy = X[:, 1] - X[old, 1]; dz = X[:, 2] - X[old, 2]
+        t = (dx * dx).astype(np.float32)
+        t = (dy.astype(np.float64) * dy + t).astype(np.float32)
+        d = (dz.astype(np.float64) * dz + t).astype(np.float32)
+        temp = np.minimum(d, temp)
+        D = np.full(BS, -1, np.float32); I = np.zeros(BS, np.int64)
+        for tid in range(BS):
+            ks = np.arange(tid, n, BS)
+            if len(ks):
+                j = int(np.argmax(temp[ks]))        # first max
+                D[tid] = temp[ks][j]; I[tid] = ks[j]
+        s = BS // 2
+        while s >= 1:
+            for tid in range(s):
+                if D[tid + s] > D[tid]:
+                    D[tid] = D[tid + s]; I[tid] = I[tid + s]
+            s //= 2
+        old = int(I[0]); out.append(old)
+    return out
+
+
+def test_fps_oracle_vs_python_tree(oracle_backend):
+    for n, m, dup in [(64, 16, 0.0), (100, 30, 0.5), (257, 40, 0.3)]:
+        pts = cloud(2, n, seed=n, dup_frac=dup)
+        idx = torch.zeros(2, m, dtype=torch.int32)
+        temp = torch.full((2, n), 1e10)
+        oracle_backend.furthest_point_sampling_wrapper(2, n, m, pts, temp, idx)
+        BS = oracle.opt_n_threads(n)
+        for b in range(2):
+            assert idx[b].tolist() == _fps_tree_python(pts[b].numpy(), m, BS)
+
+
+def test_ball_query_group_gather_oracle(oracle_backend):
+    B, N, M, ns, C = 2, 200, 17, 8, 5
+    xyz = cloud(B, N, 5)
+    new_xyz = xyz[:, :M].contiguous()
+    idx = torch.zeros(B, M, ns, dtype=torch.int32)
+    oracle_backend.ball_query_wrapper(B, N, M, 9.0, ns, new_xyz, xyz, idx)
+    d2 = ((new_xyz[:, :, None] - xyz[:, None]) ** 2).sum(-1)
+    for b in range(B):
+        for q in range(M):
+            hits = torch.nonzero(d2[b, q] < 81.0 - 1e-3).flatten().tolist()[:ns]
+            got = idx[b, q].tolist()
+            assert got[:len(hits)] == hits or len(hits) == 0
+            if hits:
+                assert all(g == hits[0] for g in got[len(hits):])
+    feats = torch.randn(B, C, N)
+    out = torch.empty(B, C, M, ns)
+    oracle_backend.group_points_wrapper(B, C, N, M, ns, feats, idx, out)
+    ref = torch.gather(feats.unsqueeze(2).expand(-1, -1, M, -1), 3, idx.long().unsqueeze(1).expand(-1, C, -1, -1))
+    assert torch.equal(out, ref)
+    g = torch.randn(B, C, M, ns)
+    gp = torch.zeros(B, C, N)
+    oracle_backend.group_points_grad_wrapper(B, C, N, M, ns, g, idx, gp)
+    ref_g = torch.zeros(B, C, N).scatter_add_(2, idx.long().reshape(B, 1, -1).expand(-1, C, -1), g.reshape(B, C, -1))
+    assert torch.allclose(gp, ref_g, atol=1e-5)
+
+
+def test_three_nn_interpolate_oracle(oracle_backend):
+    B, N, M, C = 2, 50, 33, 4
+    unk, kn = cloud(B, N, 7), cloud(B, M, 8)
+    d2 = torch.empty(B, N, 3); idx = torch.empty(B, N, 3, dtype=torch.int32)
+    oracle_backend.three_nn_wrapper(B, N, M, unk, kn, d2, idx)
+    full = ((unk[:, :, None] - kn[:, None]) ** 2).sum(-1)
+    ref_d, ref_i = torch.topk(full, 3, dim=-1, largest=False)
+    assert torch.equal(idx.long(), ref_i)
+    assert torch.allclose(d2, ref_d, rtol=1e-5, atol=1e-5)
+    w = torch.rand(B, N, 3); feats = torch.randn(B, C, M); out = torch.empty(B, C, N)
+    oracle_backend.three_interpolate_wrapper(B, C, M, N, feats, idx, w, out)
+    gathered = torch.gather(feats.unsqueeze(2).expand(-1, -1, N, -1), 3, idx.long().unsqueeze(1).expand(-1, C, -1, -1))
+    assert torch.allclose(out, (gathered * w.unsqueeze(1)).sum(-1), atol=1e-5)
