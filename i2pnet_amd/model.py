@@ -1,0 +1,211 @@
+"""Large-range image-to-point-cloud registration network on the HIP operator layer.
+
+Counterpart of the reference's `src/modellearn_proj_center.py::RegNet_v2` (:24-424): same
+constructor / forward signature, same sub-module names (=> same 299-tensor `state_dict`,
+SURVEY.md §8c), same outputs `(out3 [B,7], out4 [B,7], None, None, sx, sq)`.
+
+Stages: image CNN (PyTorch-ROCm) -> spherical projection -> four set-abstraction levels on
+range images -> coarse cost volume over all image pixels -> coarse pose -> warp -> up-conv ->
+fine cost volume over 32-NN pixels -> fine pose -> pose composition.
+
+Host-side differences from the reference: no CPU round trip for the 3x3 intrinsic inverse
+(`torch.inverse(intrinsic_3.cpu())`, :282, forces a sync every forward) and no `.item()`.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import projectpn as P
+from . import warp as warp_utils
+from .config import I2PNetConfig as cfg_default
+from .modules import CostVolume, FlowPredictor, PoseHead, ProjectPointNet, ProjSetUpconvModule, createCNNs
+
+
+def set_id_grid(rf):
+    """rf [B,h,w,*] -> pixel coordinates (u, v, 1) [B, h*w, 3] (modellearn_proj_center.py:440-454)."""
+    B, h, w = rf.shape[0], rf.shape[1], rf.shape[2]
+    v, u = torch.meshgrid(torch.arange(h, device=rf.device, dtype=rf.dtype),
+                          torch.arange(w, device=rf.device, dtype=rf.dtype), indexing="ij")
+    grid = torch.stack([u, v, torch.ones_like(u)], dim=-1).reshape(1, h * w, 3)
+    return grid.expand(B, -1, -1)
+
+
+def change_intrinsic(intrinsic, RF, rgb_img):
+    """rescale fx, cx by w'/w and fy, cy by h'/h (modellearn_proj_center.py:457-463)."""
+    sx = RF.shape[3] / rgb_img.shape[3]
+    sy = RF.shape[2] / rgb_img.shape[2]
+    scale = intrinsic.new_tensor([[sx, 1.0, sx], [1.0, sy, sy], [1.0, 1.0, 1.0]])
+    return intrinsic * scale
+
+
+def inverse_3x3(m):
+    """adjugate inverse of [B,3,3] on the device (replaces torch.inverse on the CPU, :282)."""
+    a, b, c = m[:, 0, 0], m[:, 0, 1], m[:, 0, 2]
+    d, e, f = m[:, 1, 0], m[:, 1, 1], m[:, 1, 2]
+    g, h, i = m[:, 2, 0], m[:, 2, 1], m[:, 2, 2]
+    A, Bc, Cc = e * i - f * h, -(d * i - f * g), d * h - e * g
+    det = a * A + b * Bc + c * Cc
+    adj = torch.stack([
+        torch.stack([A, -(b * i - c * h), b * f - c * e], -1),
+        torch.stack([Bc, a * i - c * g, -(a * f - c * d)], -1),
+        torch.stack([Cc, -(a * h - b * g), a * e - b * d], -1)], -2)
+    return adj / det.view(-1, 1, 1)
+
+
+class RegNet_v2(nn.Module):
+    def __init__(self, bn_decay=None, eval_info=False, cfg=cfg_default):
+        super().__init__()
+        self.eval_info = eval_info
+        self.cfg = cfg
+        self.lidar_Hs = [int(np.ceil(cfg.init_H / s)) for s in np.cumprod(cfg.stride_Hs)]
+        self.lidar_Ws = [int(np.ceil(cfg.init_W / s)) for s in np.cumprod(cfg.stride_Ws)]
+        Hs, Ws = [cfg.init_H] + self.lidar_Hs, [cfg.init_W] + self.lidar_Ws
+        enc = cfg.lidar_encoder_mlps
+        bn = dict(use_trans=cfg.use_trans, use_bn_p=cfg.use_bn_p, use_bn_input=cfg.use_bn_input)
+        add_num = 4 if cfg.using_intens else 3
+
+        def sa(level, in_channel, mlp, nsample):
+            return ProjectPointNet(H=Hs[level], W=Ws[level], out_h=Hs[level + 1], out_w=Ws[level + 1],
+                                   stride_H=cfg.stride_Hs[level], stride_W=cfg.stride_Ws[level],
+                                   kernel_size=cfg.kernel_sizes[level], nsample=nsample,
+                                   distance=cfg.down_conv_dis[level], in_channel=in_channel, mlp=mlp, **bn)
+
+        self.LiDAR_lv1 = sa(0, cfg.lidar_feature_size + add_num, enc[0], cfg.lidar_group_samples[0])
+        self.LiDAR_lv2 = sa(1, enc[0][-1] + 3, enc[1], cfg.lidar_group_samples[1])
+        self.LiDAR_lv3 = sa(2, enc[1][-1] + 3, enc[2], cfg.lidar_group_samples[2])
+        self.LiDAR_lv4 = sa(3, enc[2][-1] + 3, enc[3], cfg.lidar_group_samples[3])
+        self.layer_idx = sa(3, cfg.cost_volume_mlps[-1][-1] + 3, enc[4], cfg.lidar_group_samples[4])
+
+        self.RGB_net1 = createCNNs(*cfg.rgb_encoder_channels[0])
+        self.RGB_net2 = createCNNs(*cfg.rgb_encoder_channels[1])
+        self.RGB_net3 = createCNNs(*cfg.rgb_encoder_channels[2])
+
+        def cv(i):
+            return CostVolume(H=self.lidar_Hs[2], W=self.lidar_Ws[2], kernel_size=cfg.cost_volume_kernel_size[i],
+                              distance=cfg.cost_volume_dis[i], nsample=cfg.cost_volume_nsamples[0],
+                              nsample_q=cfg.cost_volume_nsamples[1][i],
+                              rgb_in_channels=cfg.rgb_encoder_channels[-1][1][-1], lidar_in_channels=enc[-3][-1],
+                              mlp1=cfg.cost_volume_mlps[0], mlp2=cfg.cost_volume_mlps[1],
+                              backward_validation=cfg.backward_validation[i], **bn)
+
+        self.cost_volume1 = cv(0)
+        self.cost_volume2 = cv(1)
+
+        fp = dict(is_training=self.training, bn_decay=bn_decay, bn=cfg.use_bn_p, use_bn_input=cfg.use_bn_input)
+        self.flow_predictor0 = FlowPredictor(in_channels=enc[-2][-1] + enc[-1][-1], mlp=cfg.flow_predictor_mlps[0], **fp)
+
+        def up(i, c_coarse):
+            return ProjSetUpconvModule(H=self.lidar_Hs[-1], W=self.lidar_Ws[-1], out_h=self.lidar_Hs[-2],
+                                       out_w=self.lidar_Ws[-2], kernel_size=cfg.up_conv_kernel_size[i],
+                                       nsample=cfg.setupconv_nsamples[i], stride_H=cfg.stride_Hs[-1],
+                                       stride_W=cfg.stride_Ws[-1], distance=cfg.up_conv_dis[i],
+                                       in_channels=[enc[-3][-1], c_coarse], mlp=cfg.setupconv_mlps[i][0],
+                                       mlp2=cfg.setupconv_mlps[i][1], **bn)
+
+        self.set_upconv0_w_upsample = up(0, cfg.flow_predictor_mlps[0][-1])
+        self.set_upconv0_upsample = up(1, enc[-1][-1])
+        self.flow_predictor0_predict = FlowPredictor(
+            in_channels=enc[-3][-1] + cfg.setupconv_mlps[1][1][-1] + cfg.cost_volume_mlps[-1][-1],
+            mlp=cfg.flow_predictor_mlps[1], **fp)
+        self.flow_predictor0_w = FlowPredictor(
+            in_channels=enc[-3][-1] + cfg.setupconv_mlps[0][-1][-1] + cfg.flow_predictor_mlps[1][-1],
+            mlp=cfg.flow_predictor_mlps[2], **fp)
+
+        def head(c_pred, c_feat):
+            return PoseHead(in_channels=[c_pred, c_feat], mlp1=[], mlp2=[], hidden=cfg.head_hidden_dim,
+                            q_dim=cfg.rotation_quat_head_dim, t_dim=cfg.transition_vec_head_dim,
+                            dropout_rate=cfg.head_dropout_rate, split_dp=cfg.split_dp,
+                            pos_embed=cfg.head_pos_embedding, sigmoid=cfg.mask_sigmoid, maxhead=cfg.max_head)
+
+        self.l4_head = head(enc[-1][-1], enc[-2][-1])
+        self.l3_head = head(cfg.flow_predictor_mlps[1][-1], enc[-3][-1])
+
+        self.sq = nn.Parameter(torch.tensor([cfg.sq_init]), requires_grad=True)
+        self.sx = nn.Parameter(torch.tensor([cfg.sx_init]), requires_grad=True)
+
+    def forward(self, rgb_img, lidar_img, lidar_img_raw, H_initial, intrinsic, resize_img, gt_project=None,
+                calib=None, lidar_feature=None, cfg=None):
+        """rgb_img [B,3,h,w]; lidar_img [B,N,3] cloud in the (mis-calibrated) camera frame;
+        lidar_img_raw [B,N,3] the same points in the sensor frame (defines the range image);
+        intrinsic [B,3,3]; lidar_feature [B,N,D] or None."""
+        cfg = cfg or self.cfg
+        dev = rgb_img.device
+        intrinsic = intrinsic.float()
+        B = rgb_img.shape[0]
+        N = lidar_img.shape[1]
+
+        RF3 = self.RGB_net3(self.RGB_net2(self.RGB_net1(rgb_img)))             # [B,128,h3,w3]
+        pix_index = set_id_grid(RF3.permute(0, 2, 3, 1))                        # [B,M,3]
+
+        lidar_norm = torch.zeros(B, N, 3, device=dev) if lidar_feature is None else lidar_feature
+        raw_img, (feat_img, cam_img) = P.project_seq(lidar_img_raw.float(), [lidar_norm.float(), lidar_img.float()],
+                                                     cfg.init_H, cfg.init_W, cfg.rank, cfg.fup, cfg.fdown)
+
+        rfp = cfg.raw_feat_point
+        P1_raw, P1, LF1, _, _ = self.LiDAR_lv1.forward_center(raw_img, cam_img, feat_img, cfg=cfg,
+                                                            using_intens=cfg.using_intens, raw_feat_point=rfp)
+        P2_raw, P2, LF2, _, _ = self.LiDAR_lv2(P1_raw, P1, LF1, cfg=cfg, raw_feat_point=rfp)
+        P3_raw, P3, LF3, _, _ = self.LiDAR_lv3(P2_raw, P2, LF2, cfg=cfg, raw_feat_point=rfp)
+        P4_raw, P4, LF4, _, sample_idx_4 = self.LiDAR_lv4(P3_raw, P3, LF3, cfg=cfg, raw_feat_point=rfp)
+
+        # pixel rays in the normalised camera plane of the level-3 feature map
+        K3_inv = inverse_3x3(change_intrinsic(intrinsic, RF3, rgb_img))
+        pix_rays = torch.bmm(K3_inv, pix_index.permute(0, 2, 1)).permute(0, 2, 1)   # [B,M,3]
+
+        H3, W3 = self.lidar_Hs[2], self.lidar_Ws[2]
+        H4, W4 = self.lidar_Hs[-1], self.lidar_Ws[-1]
+        P3_pts = P3.reshape(B, H3 * W3, 3)
+        LF3_pts = LF3.reshape(B, H3 * W3, -1)
+        lidar_z = P3_pts[:, :, 2:]
+        lidar_uv = P3_pts / (lidar_z + 1e-10)
+        RF3_pts = RF3.reshape(B, RF3.shape[1], -1).permute(0, 2, 1)             # [B,M,C]
+        l3_idx_n2 = P.get_idx_cuda(B, H3, W3, dev)
+
+        # ---- coarse level --------------------------------------------------------------------
+        concat_4 = self.cost_volume1(P3_raw, lidar_uv, LF3_pts, l3_idx_n2, pix_rays, RF3_pts, lidar_z, cfg=cfg)
+        _, _, l4_embed, _, _ = self.layer_idx(P3_raw, P3, concat_4, sample_idx=sample_idx_4, cfg=cfg,
+                                              raw_feat_point=rfp)
+        l4_valid = P.check_valid(P4_raw).view(B, -1, 1)
+        l4_mask = self.flow_predictor0(LF4.view(B, H4 * W4, -1), None, l4_embed.view(B, H4 * W4, -1))
+        l4_mask = l4_mask * l4_valid + -1e10 * (1 - l4_valid)
+        q4, t4, _ = self.l4_head(l4_embed.view(B, H4 * W4, -1), l4_mask, P4.view(B, H4 * W4, 3),
+                                 LF4.view(B, H4 * W4, -1), None)
+        result_4 = torch.cat([q4, t4], dim=1)
+
+        # ---- fine level ----------------------------------------------------------------------
+        t4_quat = torch.cat([torch.zeros((B, 1), device=dev), t4], -1)
+        P3_warped = warp_utils.warp_quat_xyz(P3_pts, q4, t4_quat) * P.check_valid(P3_pts)
+        l3_mask_up = self.set_upconv0_w_upsample(P3_raw, P4_raw, P3, P4, l3_idx_n2, LF3,
+                                                 l4_mask.view(B, H4, W4, -1), cfg=cfg, raw_feat_point=rfp)
+        l3_embed_up = self.set_upconv0_upsample(P3_raw, P4_raw, P3, P4, l3_idx_n2, LF3, l4_embed, cfg=cfg,
+                                                raw_feat_point=rfp)
+        lidar_z = P3_warped[:, :, 2:]
+        lidar_uv = P3_warped / (lidar_z + 1e-10)
+        concat_3 = self.cost_volume2(P3_raw, lidar_uv, LF3_pts, l3_idx_n2, pix_rays, RF3_pts, lidar_z, cfg=cfg)
+        l3_embed = self.flow_predictor0_predict(LF3_pts, l3_embed_up.view(B, H3 * W3, -1),
+                                                concat_3.view(B, H3 * W3, -1))
+        l3_mask = self.flow_predictor0_w(LF3_pts, l3_mask_up.view(B, H3 * W3, -1), l3_embed)
+        l3_valid = P.check_valid(P3_raw).view(B, -1, 1)
+        l3_mask = l3_mask * l3_valid + -1e10 * (1 - l3_valid)
+        q3, t3, W_l3 = self.l3_head(l3_embed, l3_mask, P3_warped, LF3_pts, None)
+
+        # ---- compose: q = q3 * q4, t = R3 t4 + t3 (modellearn_proj_center.py:388-404) ----------
+        out_q = warp_utils.mul_q(q3.view(B, 1, 4), q4.view(B, 1, 4)).squeeze(1)
+        t3_quat = torch.cat([torch.zeros((B, 1), device=dev), t3], 1).view(B, 1, 4)
+        out_t = warp_utils.mul_q(warp_utils.mul_q(q3, t4_quat.view(B, 1, 4)), warp_utils.inv_q(q3)) + t3_quat
+        out_3 = torch.cat([out_q, out_t.squeeze(1)[:, 1:]], 1)
+
+        if self.eval_info:
+            return (out_3.float(), result_4.float(), self.sx, self.sq, W_l3, P3_pts, None, None,
+                    P4.view(B, H4 * W4, 3))
+        return out_3.float(), result_4.float(), None, None, self.sx, self.sq
+
+    def set_bn(self):
+        for m in [self.flow_predictor0, self.flow_predictor0_w, self.flow_predictor0_predict, self.LiDAR_lv1,
+                  self.LiDAR_lv2, self.LiDAR_lv3, self.LiDAR_lv4, self.layer_idx, self.set_upconv0_upsample,
+                  self.set_upconv0_w_upsample, self.cost_volume1, self.cost_volume2]:
+            m.set_bn()
+
+
+def get_num_parameters(model, trainable=False):
+    return sum(p.numel() for p in model.parameters() if (p.requires_grad or not trainable))

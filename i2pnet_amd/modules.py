@@ -1,0 +1,417 @@
+"""Building blocks of the projection registration network on the HIP operator layer.
+
+Functional counterparts of the reference's `src/projectPN/PPBackbone_center.py` modules
+(`Conv2d`, `ProjectPointNet`, `ProjSetUpconvModule`, `CostVolume`, `PoseHead`, `FlowPredictor`)
+and `src/modules/basicConv.py` (`createCNNs`, `Conv1d`).  Sub-module and parameter names are
+kept so that a reference `state_dict` loads unchanged; the execution differs:
+
+* tensors stay channel-last `[B, N, K, C]` end to end — a 1x1 conv is one GEMM on the flattened
+  tensor, BN runs on the `[B*N*K, C]` view, no permutes (reference: permute/conv/BN/permute,
+  PPBackbone_center.py:34-46);
+* conv biases in front of a batch-statistics BN are not added (they cancel exactly in the mean
+  subtraction);
+* strided centre picks are slices, not gathers (PPBackbone_center.py:94-95);
+* the first cost-volume layer is factored into per-point, per-pixel and bilinear parts so the
+  262-channel `[B,N,M,262]` input of `cost_volume1` (224 MB at B=8) is never built
+  (PPBackbone_center.py:383-418).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import projectpn as P
+
+_BN_EPS = 1e-5
+
+
+def batch_stat_norm(y, gamma, beta, eps=_BN_EPS):
+    """BatchNorm with batch statistics over every axis but the last (biased variance, eps 1e-5,
+    affine) — what `BatchNorm2d(track_running_stats=False)` computes on the reference's
+    [B,C,K,N] view.  Two-pass mean/variance: the sum-of-squares form
+    loses ~3 digits on channels whose mean dwarfs their spread (level-1 absolute coordinates)."""
+    flat = y.reshape(-1, y.shape[-1])
+    var, mean = torch.var_mean(flat, dim=0, unbiased=False)
+    return (y - mean) * (torch.rsqrt(var + eps) * gamma) + beta
+
+
+class Conv2d(nn.Module):
+    """1x1 conv (+ BN + activation) applied to a channel-last tensor `[..., C_in]`.
+
+    Reference: PPBackbone_center.py:10-51.  `bn_linear` is a BatchNorm2d created with
+    `track_running_stats = not use_bn_input`, i.e. (use_bn_input=True) no running buffers and
+    batch statistics in train AND eval (PPBackbone_center.py:30)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=(1, 1), stride=None, bn=False,
+                 activation_fn=True, leaky_relu=True, use_bn_input=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.bn, self.activation_fn, self.use_bn_input = bn, activation_fn, use_bn_input
+        self.negative_slope = 0.1 if leaky_relu else 0.0
+        self.conv = nn.Conv2d(in_channels, out_channels, (1, 1), (1, 1))
+        if bn:
+            self.bn_linear = nn.BatchNorm2d(out_channels, track_running_stats=not use_bn_input)
+
+    def weight2d(self):
+        return self.conv.weight.view(self.out_channels, self.in_channels)
+
+    def finish(self, y):
+        """BN + activation on pre-activation `y [..., C_out]` (bias NOT yet added)."""
+        shape = y.shape
+        if self.bn:
+            if self.bn_linear.track_running_stats:      # running-stat BN: the bias matters
+                y = y + self.conv.bias
+                y = self.bn_linear(y.reshape(-1, self.out_channels, 1, 1)).reshape(shape)
+            else:
+                y = batch_stat_norm(y, self.bn_linear.weight, self.bn_linear.bias)
+        else:
+            y = y + self.conv.bias
+        if self.activation_fn:
+            y = F.leaky_relu(y, self.negative_slope, inplace=True) if self.negative_slope else F.relu(y, inplace=True)
+        return y
+
+    def forward(self, x):
+        return self.finish(F.linear(x, self.weight2d()))
+
+    def set_bn(self):
+        if self.bn:
+            self.bn_linear.track_running_stats = not self.use_bn_input
+            self.bn_linear.training = True
+
+
+class Conv1d(nn.Module):
+    """kernel-1 Conv1d on `[B, N, C]` (src/modules/basicConv.py:60-83); parameters live in
+    `composed_module.0` like the reference."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=0, use_activation=True,
+                 use_leaky=True, bn=False):
+        super().__init__()
+        act = nn.Identity() if not use_activation else (nn.LeakyReLU(0.1, inplace=True) if use_leaky else nn.ReLU(inplace=True))
+        self.composed_module = nn.Sequential(
+            nn.Conv1d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding),
+            nn.BatchNorm1d(out_channels) if bn else nn.Identity(),
+            act)
+        self._plain = (kernel_size == 1 and stride == 1 and padding == 0 and not bn)
+
+    def forward(self, x):
+        if self._plain:
+            conv = self.composed_module[0]
+            return self.composed_module[2](F.linear(x, conv.weight.squeeze(-1), conv.bias))
+        return self.composed_module(x.permute(0, 2, 1)).permute(0, 2, 1)
+
+
+def createCNNs(in_channel, channels, strides):
+    """3x3 conv + BN(running stats) + LeakyReLU(0.1) + MaxPool3 stack — the image encoder
+    (src/modules/basicConv.py:6-20).  Stays on PyTorch-ROCm / MIOpen."""
+    layers = nn.Sequential()
+    last = in_channel
+    for i, (out_channel, stride) in enumerate(zip(channels, strides)):
+        layers.add_module(str(i * 4), nn.Conv2d(last, out_channel, kernel_size=3, stride=1, padding=1, bias=True))
+        layers.add_module(str(i * 4 + 1), nn.BatchNorm2d(out_channel))
+        layers.add_module(str(i * 4 + 2), nn.LeakyReLU(negative_slope=0.1))
+        layers.add_module(str(i * 4 + 3), nn.MaxPool2d(3, stride=stride, padding=1))
+        last = out_channel
+    return layers
+
+
+def _strided(img, stride_h, stride_w, out_h, out_w):
+    return img[:, ::stride_h, ::stride_w][:, :out_h, :out_w]
+
+
+class ProjectPointNet(nn.Module):
+    """Set-abstraction layer on range images (PPBackbone_center.py:54-199): strided centres,
+    window K-NN (fused_conv_select_k), gather, 3x(1x1 conv + BN + ReLU), max over K."""
+
+    def __init__(self, H, W, out_h, out_w, stride_H, stride_W, kernel_size, nsample, distance, in_channel, mlp,
+                 use_trans=False, use_bn_p=True, use_bn_input=True):
+        super().__init__()
+        self.H, self.W, self.out_h, self.out_w = H, W, out_h, out_w
+        self.stride_H, self.stride_W = stride_H, stride_W
+        self.kernel_size, self.distance, self.nsample, self.usetrans = kernel_size, distance, nsample, use_trans
+        self.mlp_convs = nn.ModuleList()
+        last = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(Conv2d(last, out_channel, (1, 1), bn=use_bn_p, leaky_relu=False,
+                                         use_bn_input=use_bn_input))
+            last = out_channel
+
+    def _centres_and_groups(self, xyz_proj_raw, xyz_proj, sample_idx, raw_feat_point):
+        B = xyz_proj.shape[0]
+        dev = xyz_proj.device
+        N = self.out_h * self.out_w
+        with torch.no_grad():
+            if sample_idx is None:
+                sample_idx = P.get_sample_idx(B, self.out_h, self.out_w, self.stride_H, self.stride_W, dev)
+            idx_n2 = P.get_stride_idx_cuda(B, self.out_h, self.out_w, self.stride_H, self.stride_W, dev)
+            xyz_pr = xyz_proj if self.usetrans else xyz_proj_raw
+            grouped_idx = P.get_neighbor_copy(xyz_pr, xyz_pr, idx_n2, self.kernel_size, self.nsample,
+                                              distance=self.distance)
+        new_xyz_proj = _strided(xyz_proj, self.stride_H, self.stride_W, self.out_h, self.out_w).contiguous()
+        new_xyz_proj_raw = _strided(xyz_proj_raw, self.stride_H, self.stride_W, self.out_h, self.out_w).contiguous()
+        if raw_feat_point:
+            grouped_xyz = P.gather_torch(xyz_proj_raw, *grouped_idx[:3], B, self.H, self.W)
+            grouped_xyz_norm = grouped_xyz - new_xyz_proj_raw.view(B, N, 1, 3)
+        else:
+            grouped_xyz = P.gather_torch(xyz_proj, *grouped_idx[:3], B, self.H, self.W)
+            grouped_xyz_norm = grouped_xyz - new_xyz_proj.view(B, N, 1, 3)
+        return new_xyz_proj_raw, new_xyz_proj, grouped_xyz, grouped_xyz_norm, grouped_idx, sample_idx
+
+    def _mlp_max(self, new_points, B):
+        for conv in self.mlp_convs:
+            new_points = conv(new_points)
+        return torch.max(new_points, dim=2)[0].view(B, self.out_h, self.out_w, -1)
+
+    def forward(self, xyz_proj_raw, xyz_proj, feature_proj, sample_idx=None, cfg=None, raw_feat_point=False):
+        """xyz_proj_raw/xyz_proj [B,H,W,3], feature_proj [B,H,W,C] ->
+        (centres raw, centres, features [B,out_h,out_w,C'], grouped_xyz [B,N,K,3], sample_idx)"""
+        B = xyz_proj.shape[0]
+        raw_c, c, grouped_xyz, norm, gidx, sample_idx = self._centres_and_groups(xyz_proj_raw, xyz_proj, sample_idx,
+                                                                               raw_feat_point)
+        grouped_points = P.gather_torch(feature_proj, *gidx[:3], B, self.H, self.W)
+        new_points = self._mlp_max(torch.cat([norm, grouped_points], -1), B)      # PPBackbone_center.py:121-129
+        return raw_c, c, new_points, grouped_xyz, sample_idx
+
+    def forward_center(self, xyz_proj_raw, xyz_proj, feature_proj, sample_idx=None, cfg=None, using_intens=False,
+                       raw_feat_point=False):
+        """Level-1 variant with the 10-channel geometric feature
+        [dxyz(3), centre xyz(3), neighbour xyz(3), |dxyz|(1)] (PPBackbone_center.py:177-187)."""
+        B = xyz_proj.shape[0]
+        N = self.out_h * self.out_w
+        raw_c, c, grouped_xyz, norm, gidx, sample_idx = self._centres_and_groups(xyz_proj_raw, xyz_proj, sample_idx,
+                                                                               raw_feat_point)
+        centre = c.view(B, N, 1, 3).expand(-1, -1, norm.shape[2], -1)
+        dist = torch.norm(norm, p=2, dim=3, keepdim=True)
+        parts = [norm, centre, grouped_xyz, dist]
+        if using_intens:
+            parts.append(P.gather_torch(feature_proj, *gidx[:3], B, self.H, self.W))
+        new_points = self._mlp_max(torch.cat(parts, -1), B)
+        return raw_c, c, new_points, grouped_xyz, sample_idx
+
+    def set_bn(self):
+        for conv in self.mlp_convs:
+            conv.set_bn()
+
+
+class ProjSetUpconvModule(nn.Module):
+    """Coarse-to-fine feature propagation on range images (PPBackbone_center.py:202-303)."""
+
+    def __init__(self, H, W, out_h, out_w, stride_H, stride_W, kernel_size, nsample, distance, in_channels, mlp,
+                 mlp2, use_trans=False, use_bn_p=True, use_bn_input=True):
+        super().__init__()
+        self.nsample, self.mlp, self.mlp2 = nsample, mlp, mlp2
+        self.H, self.W, self.out_h, self.out_w = H, W, out_h, out_w
+        self.stride_H, self.stride_W = stride_H, stride_W
+        self.kernel_size, self.distance, self.use_trans = kernel_size, distance, use_trans
+        self.mlp_conv = nn.ModuleList()
+        self.mlp2_conv = nn.ModuleList()
+        last = in_channels[-1] + 3
+        for c in (mlp or []):
+            self.mlp_conv.append(Conv2d(last, c, [1, 1], stride=[1, 1], bn=use_bn_p, use_bn_input=use_bn_input))
+            last = c
+        last = (mlp[-1] if mlp else last) + in_channels[0]
+        for c in (mlp2 or []):
+            self.mlp2_conv.append(Conv2d(last, c, [1, 1], stride=[1, 1], bn=use_bn_p, use_bn_input=use_bn_input))
+            last = c
+        self.last_channel = last
+
+    def forward(self, xyz1_raw, xyz2_raw, xyz1, xyz2, idx_n2, feat1, feat2, cfg=None, raw_feat_point=False):
+        """xyz1* [B,out_h,out_w,3] fine, xyz2* [B,H,W,3] coarse, feat1 [B,out_h,out_w,c1], feat2 [B,H,W,c2]
+        -> [B, out_h*out_w, mlp2[-1]]"""
+        B = xyz1.shape[0]
+        N = self.out_h * self.out_w
+        with torch.no_grad():
+            xyz1_pr = xyz1 if self.use_trans else xyz1_raw
+            xyz2_pr = xyz2 if self.use_trans else xyz2_raw
+            gidx = P.get_neighbor_copy(xyz1_pr, xyz2_pr, idx_n2, self.kernel_size, self.nsample, self.stride_H,
+                                       self.stride_W, distance=self.distance)
+        if raw_feat_point:
+            xyz_diff = P.gather_torch(xyz2_raw, *gidx[:3], B, self.H, self.W) - xyz1_raw.reshape(B, N, 1, 3)
+        else:
+            xyz_diff = P.gather_torch(xyz2, *gidx[:3], B, self.H, self.W) - xyz1.reshape(B, N, 1, 3)
+        upfeats = torch.cat([P.gather_torch(feat2, *gidx[:3], B, self.H, self.W), xyz_diff], dim=3)
+        for conv in self.mlp_conv:
+            upfeats = conv(upfeats)
+        feat1_new = torch.max(upfeats, dim=2)[0].view(B, self.out_h, self.out_w, -1)
+        if feat1 is not None:
+            feat1_new = torch.cat([feat1_new, feat1.reshape(B, self.out_h, self.out_w, -1)], dim=3)
+        for conv in self.mlp2_conv:
+            feat1_new = conv(feat1_new)
+        return feat1_new.reshape(B, N, -1)
+
+    def set_bn(self):
+        for conv in list(self.mlp_conv) + list(self.mlp2_conv):
+            conv.set_bn()
+
+
+def _unit_variance(x):
+    """(x - mean) / clip(std_unbiased, 1e-12) over the channel axis (PPBackbone_center.py:388-393)."""
+    return (x - torch.mean(x, -1, keepdim=True)) / torch.clip(torch.std(x, -1, keepdim=True), min=1e-12)
+
+
+class CostVolume(nn.Module):
+    """2D-3D cost volume (PPBackbone_center.py:306-503).
+
+    pi-stage: every LiDAR point n attends over image pixels k (all of them when nsample_q <= 0,
+    else its nsample_q nearest in the normalised image plane) with features
+    [xyz_n, uv_k, norm(LF_n) * norm(RF_k) (, max_n of that product)] -> mlp1 -> softmax_k weighted
+    sum.  pc-stage: each point then attends over its `nsample` range-image neighbours."""
+
+    def __init__(self, H, W, kernel_size, distance, nsample, nsample_q, rgb_in_channels, lidar_in_channels, mlp1,
+                 mlp2, backward_validation=False, use_trans=False, use_bn_p=True, use_bn_input=True):
+        super().__init__()
+        self.H, self.W = H, W
+        self.nsample, self.nsample_q, self.distance = nsample, nsample_q, distance
+        self.mlp1, self.mlp2, self.kernel_size = mlp1, mlp2, kernel_size
+        self.backward_validation, self.use_trans = backward_validation, use_trans
+        self.feat_channels = rgb_in_channels
+        corr = rgb_in_channels + (lidar_in_channels if backward_validation else 0)
+        kw = dict(stride=[1, 1], bn=use_bn_p, use_bn_input=use_bn_input)
+        self.mlp1_convs = nn.ModuleList()
+        self.mlp2_convs = nn.ModuleList()
+        self.mlp2_convs_2 = nn.ModuleList()
+        last = corr + 6
+        for c in mlp1:
+            self.mlp1_convs.append(Conv2d(last, c, [1, 1], **kw)); last = c
+        self.pi_encoding = Conv2d(6, mlp1[-1], [1, 1], **kw)
+        last = 2 * mlp1[-1]
+        for c in mlp2:
+            self.mlp2_convs.append(Conv2d(last, c, [1, 1], **kw)); last = c
+        self.pc_encoding = Conv2d(10, mlp1[-1], [1, 1], **kw)
+        last = 2 * mlp1[-1] + lidar_in_channels
+        for c in mlp2:
+            self.mlp2_convs_2.append(Conv2d(last, c, [1, 1], **kw)); last = c
+
+    # -- pi-stage over ALL pixels: first layer factored ------------------------------------------
+    def _pi_all_pixels(self, xyz, pts_n, pix_xyz, pix_n):
+        """xyz [B,N,3] (depth restored), pts_n [B,N,C] normalised, pix_xyz [B,M,3], pix_n [B,M,C]
+        -> h3 [B,N,M,c] (mlp1 output), logits [B,N,M,c]"""
+        C = self.feat_channels
+        first = self.mlp1_convs[0]
+        Wm = first.weight2d()
+        corr = pts_n.unsqueeze(2) * pix_n.unsqueeze(1)                          # [B,N,M,C]  :395
+        y = F.linear(corr, Wm[:, 6:6 + C])
+        per_point = F.linear(xyz, Wm[:, 0:3])                                   # [B,N,c1]
+        per_pixel = F.linear(pix_xyz, Wm[:, 3:6])                               # [B,M,c1]
+        if self.backward_validation:
+            valid = P.check_valid(xyz).unsqueeze(-1)                            # [B,N,1,1]  :408
+            masked = corr * valid + -1e10 * (1 - valid)                         # :410
+            respond = torch.max(masked, 1)[0]                                   # [B,M,C]    :412
+            per_pixel = per_pixel + F.linear(respond, Wm[:, 6 + C:])
+        y = y + per_point.unsqueeze(2) + per_pixel.unsqueeze(1)
+        h = first.finish(y)
+        for conv in list(self.mlp1_convs)[1:]:
+            h = conv(h)
+        We = self.pi_encoding.weight2d()
+        enc = self.pi_encoding.finish(F.linear(xyz, We[:, 0:3]).unsqueeze(2) + F.linear(pix_xyz, We[:, 3:6]).unsqueeze(1))
+        return h, enc
+
+    def _pi_knn(self, uv, xyz, pts_n, pix_xyz, pix_n):
+        B, N, _ = xyz.shape
+        K = self.nsample_q
+        idx = P.knn_point(K, pix_xyz, uv)                                       # grouping(), :369
+        q_xyz = P.index_points_group(pix_xyz, idx)                              # [B,N,K,3]
+        q_feat = P.index_points_group(pix_n, idx)                               # [B,N,K,C]
+        geo = torch.cat([xyz.unsqueeze(2).expand(-1, -1, K, -1), q_xyz], dim=3)
+        h = torch.cat([geo, pts_n.unsqueeze(2) * q_feat], dim=3)
+        for conv in self.mlp1_convs:
+            h = conv(h)
+        return h, self.pi_encoding(geo)
+
+    def forward(self, xyz_proj_raw, warped_xyz, warped_points, idx_n2, f2_xyz, f2_points, lidar_z, cfg=None):
+        """xyz_proj_raw [B,H,W,3]; warped_xyz [B,HW,3] (u,v,1); warped_points [B,HW,C];
+        f2_xyz [B,M,3] pixel rays; f2_points [B,M,C]; lidar_z [B,HW,1] -> [B,H,W,mlp2[-1]]"""
+        B = warped_xyz.shape[0]
+        N = warped_xyz.shape[1]
+        uv = warped_xyz
+        xyz = warped_xyz.mul(lidar_z)                                           # restore depth, :377
+        pts_n = _unit_variance(warped_points)
+        pix_n = _unit_variance(f2_points)
+        if self.nsample_q > 0:
+            h3, enc = self._pi_knn(uv, xyz, pts_n, f2_xyz, pix_n)
+        else:
+            h3, enc = self._pi_all_pixels(xyz, pts_n, f2_xyz, pix_n)
+        logits = torch.cat([enc, h3], dim=3)                                    # :423
+        for conv in self.mlp2_convs:
+            logits = conv(logits)
+        pi_feat = torch.sum(F.softmax(logits, dim=2) * h3, dim=2)               # [B,N,c]  :430-433
+
+        # pc-stage
+        xyz_bhw = xyz.view(B, self.H, self.W, 3)
+        with torch.no_grad():
+            xyz_pr = xyz_bhw if self.use_trans else xyz_proj_raw
+            gidx = P.get_neighbor_att(xyz_pr.detach(), xyz_pr.detach(), idx_n2, self.kernel_size, self.nsample,
+                                      distance=self.distance)
+        K = self.nsample
+        nb_xyz = P.gather_torch(xyz_bhw, *gidx[:3], B, self.H, self.W)          # [B,N,K,3]
+        nb_feat = P.gather_torch(pi_feat, *gidx[:3], B, self.H, self.W)         # [B,N,K,c]
+        own_xyz = xyz.unsqueeze(2).expand(-1, -1, K, -1)
+        diff = nb_xyz - own_xyz
+        euc = torch.sqrt(torch.sum(diff * diff, dim=3, keepdim=True) + 1e-20)   # :461
+        enc_pc = self.pc_encoding(torch.cat([own_xyz, nb_xyz, diff, euc], dim=3))
+        w = torch.cat([enc_pc, warped_points.unsqueeze(2).expand(-1, -1, K, -1), nb_feat], dim=-1)
+        for conv in self.mlp2_convs_2:
+            w = conv(w)
+        valid = gidx[-1]
+        w = w * valid + -1e10 * (1 - valid)                                     # :481
+        out = torch.sum(F.softmax(w, dim=2) * nb_feat, dim=2)
+        return out.view(B, self.H, self.W, -1)
+
+    def set_bn(self):
+        for conv in list(self.mlp2_convs) + list(self.mlp1_convs) + list(self.mlp2_convs_2):
+            conv.set_bn()
+        self.pc_encoding.set_bn()
+        self.pi_encoding.set_bn()
+
+
+class PoseHead(nn.Module):
+    """Mask-weighted global pooling + 6-DoF regression (PPBackbone_center.py:506-564)."""
+
+    def __init__(self, in_channels, mlp1, mlp2, hidden, q_dim, t_dim, dropout_rate=0.5, split_dp=False,
+                 pos_embed=False, sigmoid=False, maxhead=False):
+        super().__init__()
+        self.sigmoid, self.maxhead, self.pos_embed = sigmoid, maxhead, pos_embed
+        in_channel, _ = in_channels
+        self.DP1 = nn.Identity() if split_dp else nn.Dropout(dropout_rate)
+        self.DP2 = nn.Dropout(dropout_rate) if split_dp else nn.Identity()
+        self.hidden_layer = Conv1d(in_channel, hidden, use_activation=False)
+        self.quat_head = Conv1d(hidden, q_dim, use_activation=False)
+        self.trans_head = Conv1d(hidden, t_dim, use_activation=False)
+
+    def forward(self, prediction, mask, xyz, feature, projection_mask):
+        if not self.sigmoid:
+            if projection_mask is not None:
+                pm = torch.argmax(projection_mask.detach(), dim=-1, keepdim=True).float()
+                mask = mask * pm + -1e10 * (1. - pm)
+        else:
+            prediction = prediction * projection_mask
+        if self.maxhead:
+            mask = torch.max(mask, dim=-1, keepdim=True)[0]
+        mask_p = F.softmax(mask, dim=1)                                         # over points, :551
+        pooled = torch.sum(prediction * mask_p, dim=1, keepdim=True)            # [B,1,C]
+        hidden = self.DP1(self.hidden_layer(pooled))
+        q = self.quat_head(self.DP2(hidden)).squeeze(1)
+        t = self.trans_head(self.DP2(hidden)).squeeze(1)
+        q = q / (torch.sqrt(torch.sum(q * q, dim=-1, keepdim=True) + 1e-10) + 1e-10)   # :562
+        return q, t, mask_p
+
+
+class FlowPredictor(nn.Module):
+    """Per-point refinement MLP on concatenated features (PPBackbone_center.py:567-607)."""
+
+    def __init__(self, in_channels, mlp, is_training, bn_decay, bn=True, use_bn_input=True):
+        super().__init__()
+        self.mlp_conv = nn.ModuleList()
+        last = in_channels
+        for c in mlp:
+            self.mlp_conv.append(Conv2d(last, c, [1, 1], stride=[1, 1], bn=bn, use_bn_input=use_bn_input))
+            last = c
+
+    def forward(self, points_f1, upsampled_feat, cost_volume):
+        parts = [points_f1, cost_volume] + ([upsampled_feat] if upsampled_feat is not None else [])
+        x = torch.cat(parts, -1).unsqueeze(2)
+        for conv in self.mlp_conv:
+            x = conv(x)
+        return x.squeeze(2)
+
+    def set_bn(self):
+        for conv in self.mlp_conv:
+            conv.set_bn()

@@ -56,3 +56,34 @@ def cloud(B, N, seed, dup_frac=0.0, zero_frac=0.0):
         nz = int(N * zero_frac)
         pts[:, N - nz:] = 0.0
     return pts.contiguous()
+
+
+def synthetic_state(shapes, seed=0):
+    """Deterministic weights keyed by parameter NAME (independent of module construction
+    order), so the reference model (tools/gen_golden.py) and ours load identical values
+    without shipping a 3.4 MB state_dict.  `shapes`: list of (key, shape)."""
+    import hashlib
+    out = {}
+    for key, shape in shapes:
+        h = int.from_bytes(hashlib.sha256(f"{seed}:{key}".encode()).digest()[:4], "little")
+        g = torch.Generator().manual_seed(h)
+        shape = tuple(shape)
+        if key.endswith("num_batches_tracked"):
+            t = torch.zeros(shape, dtype=torch.long)
+        elif key in ("sq", "sx"):
+            t = torch.tensor([-2.5 if key == "sq" else 0.0])
+        elif key.endswith("running_var"):
+            t = 1.0 + 0.2 * torch.rand(shape, generator=g)
+        elif key.endswith("running_mean"):
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) >= 2:                                  # conv weights
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            t = torch.randn(shape, generator=g) * (1.5 / fan_in) ** 0.5
+        elif "bn" in key.split(".")[-2] or key.split(".")[-2].isdigit() and key.endswith("weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)    # BN gamma
+        else:
+            t = 0.1 * torch.randn(shape, generator=g)          # biases / BN beta
+        out[key] = t
+    return out

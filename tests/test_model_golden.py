@@ -1,0 +1,134 @@
+"""The network (i2pnet_amd.model.RegNet_v2) against golden vectors produced by the REFERENCE
+Python model (tools/gen_golden.py; reference imported in the build container with the CPU
+oracle as its native extension).  CPU variant: our host logic on the oracle backend;
+GPU variant: the product path on libi2p_ops.so.  Tolerance: 1e-4 relative (BASELINE.json)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import synthetic_state
+
+GOLD = Path(__file__).resolve().parent / "golden"
+CASES = ["kitti", "nus"]
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64); b = torch.as_tensor(b, dtype=torch.float64)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _run(tag, device):
+    from i2pnet_amd import synth
+    from i2pnet_amd.config import CONFIGS
+    from i2pnet_amd.loss import Get_loss
+    from i2pnet_amd.model import RegNet_v2
+
+    gold = np.load(GOLD / f"model_{tag}.npz")
+    cfg_name, B, N, img_h, img_w, seed, beams = gold["meta"].tolist()
+    B, N, img_h, img_w, seed, beams = int(B), int(N), int(img_h), int(img_w), int(seed), int(beams)
+    cfg = CONFIGS[cfg_name]
+    model = RegNet_v2(cfg=cfg)
+    # state_dict layout == the reference's (names, order-insensitive, shapes)
+    ours = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    theirs = {k: tuple(int(x) for x in s.split(",") if x) for k, s in zip(gold["state_keys"].tolist(), gold["state_shapes"].tolist())}
+    assert ours == theirs
+    model.load_state_dict(synthetic_state(list(theirs.items()), seed=seed))
+    model.eval().to(device)
+    batch = {k: v.to(device) for k, v in synth.make_batch(B, N, img_h, img_w, seed=seed, beams=beams, fup=cfg.fup,
+                                                           fdown=cfg.fdown, unique_cells=(cfg.init_H, cfg.init_W)).items()}
+    acts = {}
+
+    def keep(name):
+        def f(mod, inp, out):
+            o = out[2] if isinstance(out, tuple) else out
+            if o.requires_grad:
+                o.retain_grad()
+            acts[name] = o
+        return f
+
+    for name in [k[4:] for k in gold.files if k.startswith("act.")]:
+        if name == "LiDAR_lv1":
+            orig = model.LiDAR_lv1.forward_center
+
+            def fc(*a, _orig=orig, **k):
+                out = _orig(*a, **k)
+                out[2].retain_grad(); acts["LiDAR_lv1"] = out[2]
+                return out
+            model.LiDAR_lv1.forward_center = fc
+        else:
+            getattr(model, name).register_forward_hook(keep(name))
+
+    out3, out4, _, _, sx, sq = model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"], batch["init_extrinsic"],
+                                     batch["init_intrinsic"], None, None, None, batch["lidar_feats"], cfg=cfg)
+    loss, lq, lx = Get_loss(out3, out4, batch["decalib_real_gt"], batch["decalib_dual_gt"], sx, sq, cfg=cfg)
+    loss.backward()
+    return gold, model, acts, out3, out4, loss
+
+
+def _check(gold, model, acts, out3, out4, loss, tol):
+    report = {}
+    for name, t in acts.items():
+        report["act." + name] = _rel(t.detach().cpu().reshape(-1, t.shape[-1]), gold["act." + name])
+    report["out3"] = _rel(out3.detach().cpu(), gold["out3"])
+    report["out4"] = _rel(out4.detach().cpu(), gold["out4"])
+    report["loss"] = abs(loss.item() - gold["loss"][0]) / abs(gold["loss"][0])
+    for name, t in acts.items():
+        if "actgrad." + name in gold.files and t.grad is not None:
+            report["actgrad." + name] = _rel(t.grad.cpu().reshape(-1, t.shape[-1]), gold["actgrad." + name])
+    params = dict(model.named_parameters())
+    for k in [f[6:] for f in gold.files if f.startswith("pgrad.")]:
+        report["pgrad." + k] = _rel(params[k].grad.cpu(), gold["pgrad." + k])
+    # Gradient norms of all parameters.  Several of the reference's gradients are ill-conditioned
+    # in fp32 (set_upconv0_w_upsample consumes the -1e10 mask values as features; level 1 consumes
+    # absolute coordinates): the fixture carries an fp64 evaluation, and |ref32 - fp64| is the
+    # noise floor no fp32 implementation can beat.  We must be as close to fp64 as the reference is
+    # (x4 margin), and within 1e-4 wherever the reference itself is.
+    gn = dict(zip(gold["grad_keys"].tolist(), gold["grad_norm"].tolist()))
+    g64 = dict(zip(gold["grad_keys"].tolist(), gold["grad_norm64"].tolist()))
+    worst = 0.0
+    mod_floor = {}                     # fp32 noise floor of the reference per top-level module
+    for k in params:
+        if gn[k] > 1e-4 and g64[k] > 0.0:
+            m = k.split(".")[0]
+            mod_floor[m] = max(mod_floor.get(m, 0.0), abs(gn[k] - g64[k]) / g64[k])
+    for k, p in params.items():
+        g = 0.0 if p.grad is None else float(p.grad.double().norm())
+        if gn[k] <= 1e-4 or g64[k] == 0.0:
+            # conv biases in front of a batch-stat BN: exactly 0 here and in fp64, rounding noise there
+            assert g <= max(1e-3, 4 * gn[k]), (k, g, gn[k])
+            continue
+        floor = mod_floor[k.split(".")[0]]
+        err = abs(g - g64[k]) / g64[k]
+        worst = max(worst, err / max(4 * floor, tol))
+    report["grad_norm_worst"] = worst
+    limits = {k: tol for k in report}
+    limits["grad_norm_worst"] = 1.0                       # already normalised by its own limit
+    for k in report:                                       # measured fp32 noise of the reference itself
+        if k.startswith("actgrad.") or k.startswith("pgrad."):
+            limits[k] = 1e-3
+    limits["pgrad.LiDAR_lv1.mlp_convs.0.conv.weight"] = 5e-3   # |ref32 - fp64| = 1.7e-3 (tools/gen_golden.py)
+    bad = {k: v for k, v in report.items() if not v <= limits[k]}
+    assert not bad, f"beyond {tol}: {bad}\nall: {report}"
+    return report
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_model_matches_reference_on_cpu_oracle(tag, oracle_backend):
+    from i2pnet_amd import ops
+    prev = ops.set_backend(oracle_backend)
+    try:
+        torch.manual_seed(0)
+        res = _run(tag, "cpu")
+        _check(*res, tol=1e-4)
+    finally:
+        ops.set_backend(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", CASES)
+def test_model_matches_reference_on_gpu(tag, hip_backend):
+    torch.manual_seed(0)
+    res = _run(tag, "cuda")
+    _check(*res, tol=1e-4)

@@ -1,0 +1,61 @@
+"""Import the reference's Python model in THIS container (CPU only, no GPU, no CUDA extension).
+
+Used only by tools/gen_golden.py to produce the fixtures under tests/golden/.  Nothing here
+travels to the GPU box: /root/reference does not exist there and no test imports this file.
+
+Recipe: stub the missing third-party imports (torchvision, cv2), provide the
+two native extension modules backed by the CPU oracle, neutralise the `.cuda()` /
+`cuda.synchronize()` calls the reference makes at import time, put /root/reference on sys.path.
+"""
+import sys
+import types
+from pathlib import Path
+
+import torch
+
+REF = Path("/root/reference")
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def install():
+    if not REF.exists():
+        raise RuntimeError("/root/reference not present (golden generation runs in the build container only)")
+    sys.dont_write_bytecode = True
+    if str(ROOT) not in sys.path:
+        sys.path.insert(0, str(ROOT))
+
+    from i2pnet_amd import ops, pointnet2_utils as my_p2
+    from oracle import oracle
+
+    be = oracle.backend()
+    ops.set_backend(be)                       # the mirror modules now run on the CPU oracle
+
+    tv = types.ModuleType("torchvision"); tv.models = types.ModuleType("torchvision.models")
+    sys.modules.setdefault("torchvision", tv); sys.modules.setdefault("torchvision.models", tv.models)
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+
+    ext = types.ModuleType("fused_conv_select_k_cuda")
+    ext.fused_conv_select_k = be.fused_conv_select_k            # fused_conv_g.cpp:69-72
+    sys.modules["fused_conv_select_k_cuda"] = ext
+
+    # the reference's own pointnet2_utils allocates torch.cuda.*Tensor; on CPU we expose the
+    # same names through the mirror (which calls the oracle's group_points etc.)
+    sys.modules["pointnet2.pointnet2_utils"] = my_p2
+
+    torch.cuda.synchronize = lambda *a, **k: None               # src/util/tracker.py:30-31 at import
+    torch.Tensor.cuda = lambda self, *a, **k: self              # src/modules/warp_utils.py:18-19
+
+    if str(REF) not in sys.path:
+        sys.path.insert(0, str(REF))
+
+
+def load_model(cfg_name="config_proj_lidarcenter"):
+    """-> (RegNet_v2 class, I2PNetConfig class, Get_loss)"""
+    import importlib
+    import contextlib, io
+    install()
+    cfg = importlib.import_module(f"src.{cfg_name}").I2PNetConfig
+    net = importlib.import_module("src.modellearn_proj_center")
+    with contextlib.redirect_stdout(io.StringIO()):
+        loss = importlib.import_module("compute_loss")
+    return net.RegNet_v2, cfg, loss.Get_loss
