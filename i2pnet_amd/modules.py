@@ -50,6 +50,11 @@ class Conv2d(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, (1, 1), (1, 1))
         if bn:
             self.bn_linear = nn.BatchNorm2d(out_channels, track_running_stats=not use_bn_input)
+            if use_bn_input:
+                # a bias in front of a batch-statistics BN cancels in the mean subtraction: it is kept
+                # in the state_dict for checkpoint compatibility but takes no part in training
+                # (keeps DDP free of unused-parameter bookkeeping)
+                self.conv.bias.requires_grad_(False)
 
     def weight2d(self):
         return self.conv.weight.view(self.out_channels, self.in_channels)
