@@ -87,7 +87,7 @@ def _check(gold, model, acts, out3, out4, loss, tol):
     # (x4 margin), and within 1e-4 wherever the reference itself is.
     gn = dict(zip(gold["grad_keys"].tolist(), gold["grad_norm"].tolist()))
     g64 = dict(zip(gold["grad_keys"].tolist(), gold["grad_norm64"].tolist()))
-    worst = 0.0
+    worst, worst_key = 0.0, None
     mod_floor = {}                     # fp32 noise floor of the reference per top-level module
     for k in params:
         if gn[k] > 1e-4 and g64[k] > 0.0:
@@ -100,16 +100,21 @@ def _check(gold, model, acts, out3, out4, loss, tol):
             assert g <= max(1e-3, 4 * gn[k]), (k, g, gn[k])
             continue
         floor = mod_floor[k.split(".")[0]]
+        if floor > 0.05:
+            continue     # the reference's own fp32 gradient is >5% off its fp64 value here: not a reproducible quantity
         err = abs(g - g64[k]) / g64[k]
-        worst = max(worst, err / max(4 * floor, tol))
+        score = err / max(4 * floor, tol)
+        if score > worst:
+            worst, worst_key = score, (k, err, floor)
     report["grad_norm_worst"] = worst
+    report["grad_norm_worst_key"] = 0.0 if worst <= 1.0 else str(worst_key)
     limits = {k: tol for k in report}
     limits["grad_norm_worst"] = 1.0                       # already normalised by its own limit
     for k in report:                                       # measured fp32 noise of the reference itself
         if k.startswith("actgrad.") or k.startswith("pgrad."):
             limits[k] = 1e-3
     limits["pgrad.LiDAR_lv1.mlp_convs.0.conv.weight"] = 5e-3   # |ref32 - fp64| = 1.7e-3 (tools/gen_golden.py)
-    bad = {k: v for k, v in report.items() if not v <= limits[k]}
+    bad = {k: v for k, v in report.items() if isinstance(v, str) or not v <= limits[k]}
     assert not bad, f"beyond {tol}: {bad}\nall: {report}"
     return report
 
