@@ -4,7 +4,7 @@ One table, used by the product loader (`_lib.py`, device library, every entry ta
 `void* stream`) and by the test-only oracle loader (`oracle/oracle.py`, same names + `_cpu`,
 no stream).  Argument kinds:
 
-    'i'  int            'f'  float           'p'  device/host pointer (void*)
+    'i'  int   'l' long long   'f'  float           'p'  device/host pointer (void*)
     'pp' pointer to an array of pointers (const float* const*)
 """
 import ctypes as C
@@ -25,9 +25,13 @@ SIGNATURES = {
     "i2p_gather_rows": ["i", "i", "i", "i", "i", "p", "p", "p", "p"],
     "i2p_gather_rows_grad": ["i", "i", "i", "i", "i", "p", "p", "p", "p"],
     "i2p_knn": ["i", "i", "i", "i", "p", "p", "p"],
+    "i2p_bn_stats": ["l", "i", "p", "p"],
+    "i2p_bn_act_fwd": ["l", "i", "p", "p", "p", "p", "f", "f", "p", "p"],
+    "i2p_bn_act_bwd_stats": ["l", "i", "p", "p", "p", "p", "p", "f", "p"],
+    "i2p_bn_act_bwd": ["l", "i", "p", "p", "p", "p", "p", "f", "p", "p", "p", "p"],
 }
 
-_CT = {"i": C.c_int, "f": C.c_float, "p": C.c_void_p, "pp": C.c_void_p}
+_CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "p": C.c_void_p, "pp": C.c_void_p}
 
 
 def bind(lib, name, symbol, with_stream):

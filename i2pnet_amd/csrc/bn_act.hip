@@ -1,0 +1,301 @@
+// Batch-statistics BatchNorm + (Leaky)ReLU on channel-last activations [rows, C] for gfx950.
+// Replaces the eager permute / BatchNorm2d / activation / permute of every point-branch Conv2d
+// of the reference (src/projectPN/PPBackbone_center.py:34-46) — see include/i2p_ops.h.
+//
+// All four kernels are HBM-streaming: float4 per lane along C (coalesced 16 B/lane), grid-stride
+// over rows, fp64 per-lane partial sums, one LDS reduction and C fp64 atomics per block.
+//   forward : bn_stats (1 read)            + bn_act_fwd (1 read, 1 write)
+//   backward: bn_act_bwd_stats (2 reads)   + bn_act_bwd (2 reads, 1 write)
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int MAX_BLOCKS = 2048;
+
+struct BnGeom {
+    int cv;        // float4 columns = C/4
+    int rpb;       // rows per block iteration = THREADS / cv
+};
+
+__device__ __forceinline__ float act_fwd(float z, float slope) { return z > 0.f ? z : z * slope; }
+
+// ---- vector path: C % 4 == 0 and (C/4) divides 256 -------------------------------------------
+__global__ __launch_bounds__(THREADS) void bn_stats_v4(long long rows, int c, BnGeom g,
+                                                        const float4 *__restrict__ y,
+                                                        double *__restrict__ sums) {
+    __shared__ double red[THREADS][8];
+    const int vcol = threadIdx.x % g.cv, rsub = threadIdx.x / g.cv;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (long long r = (long long)blockIdx.x * g.rpb + rsub; r < rows; r += (long long)gridDim.x * g.rpb) {
+        const float4 v = y[r * g.cv + vcol];
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][4 + i] = q[i]; }
+    __syncthreads();
+    if (threadIdx.x < g.cv) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = threadIdx.x; t < THREADS; t += g.cv)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] += red[t][i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            atomicAdd(sums + vcol * 4 + i, a[i]);
+            atomicAdd(sums + c + vcol * 4 + i, a[4 + i]);
+        }
+    }
+}
+
+struct ChanCoef { float mean, invstd, scale, beta; };
+
+__device__ __forceinline__ ChanCoef coef_from_sums(const double *sums, int c, int ch, long long rows,
+                                                   const float *gamma, const float *beta, float eps) {
+    const double m = sums[ch] / (double)rows;
+    double var = sums[c + ch] / (double)rows - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    ChanCoef k;
+    k.mean = (float)m;
+    k.invstd = rsqrtf((float)var + eps);
+    k.scale = k.invstd * gamma[ch];
+    k.beta = beta[ch];
+    return k;
+}
+
+__global__ __launch_bounds__(THREADS) void bn_act_fwd_v4(long long rows, int c, BnGeom g,
+                                                          const float4 *__restrict__ y,
+                                                          const double *__restrict__ sums,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float eps, float slope,
+                                                          float4 *__restrict__ out,
+                                                          float *__restrict__ mean_invstd) {
+    const int vcol = threadIdx.x % g.cv, rsub = threadIdx.x / g.cv;
+    ChanCoef k[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k[i] = coef_from_sums(sums, c, vcol * 4 + i, rows, gamma, beta, eps);
+    if (blockIdx.x == 0 && rsub == 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { mean_invstd[vcol * 4 + i] = k[i].mean; mean_invstd[c + vcol * 4 + i] = k[i].invstd; }
+    for (long long r = (long long)blockIdx.x * g.rpb + rsub; r < rows; r += (long long)gridDim.x * g.rpb) {
+        const float4 v = y[r * g.cv + vcol];
+        float4 o;
+        o.x = act_fwd((v.x - k[0].mean) * k[0].scale + k[0].beta, slope);
+        o.y = act_fwd((v.y - k[1].mean) * k[1].scale + k[1].beta, slope);
+        o.z = act_fwd((v.z - k[2].mean) * k[2].scale + k[2].beta, slope);
+        o.w = act_fwd((v.w - k[3].mean) * k[3].scale + k[3].beta, slope);
+        out[r * g.cv + vcol] = o;
+    }
+}
+
+struct BwdCoef { float mean, invstd, scale, beta; };
+
+__device__ __forceinline__ void dz_xhat(float yv, float go, const BwdCoef &k, float slope, float &dz, float &xh) {
+    xh = (yv - k.mean) * k.invstd;
+    const float z = (yv - k.mean) * k.scale + k.beta;      // identical expression to the forward
+    dz = z > 0.f ? go : go * slope;
+}
+
+__global__ __launch_bounds__(THREADS) void bn_act_bwd_stats_v4(long long rows, int c, BnGeom g,
+                                                                const float4 *__restrict__ dout,
+                                                                const float4 *__restrict__ y,
+                                                                const float *__restrict__ mean_invstd,
+                                                                const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, float slope,
+                                                                double *__restrict__ dsums) {
+    __shared__ double red[THREADS][8];
+    const int vcol = threadIdx.x % g.cv, rsub = threadIdx.x / g.cv;
+    BwdCoef k[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = vcol * 4 + i;
+        k[i].mean = mean_invstd[ch]; k[i].invstd = mean_invstd[c + ch];
+        k[i].scale = k[i].invstd * gamma[ch]; k[i].beta = beta[ch];
+    }
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (long long r = (long long)blockIdx.x * g.rpb + rsub; r < rows; r += (long long)gridDim.x * g.rpb) {
+        const float4 v = y[r * g.cv + vcol], go = dout[r * g.cv + vcol];
+        float dz, xh;
+        dz_xhat(v.x, go.x, k[0], slope, dz, xh); s[0] += dz; q[0] += (double)dz * xh;
+        dz_xhat(v.y, go.y, k[1], slope, dz, xh); s[1] += dz; q[1] += (double)dz * xh;
+        dz_xhat(v.z, go.z, k[2], slope, dz, xh); s[2] += dz; q[2] += (double)dz * xh;
+        dz_xhat(v.w, go.w, k[3], slope, dz, xh); s[3] += dz; q[3] += (double)dz * xh;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][4 + i] = q[i]; }
+    __syncthreads();
+    if (threadIdx.x < g.cv) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = threadIdx.x; t < THREADS; t += g.cv)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] += red[t][i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            atomicAdd(dsums + vcol * 4 + i, a[i]);
+            atomicAdd(dsums + c + vcol * 4 + i, a[4 + i]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void bn_act_bwd_v4(long long rows, int c, BnGeom g,
+                                                          const float4 *__restrict__ dout,
+                                                          const float4 *__restrict__ y,
+                                                          const float *__restrict__ mean_invstd,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float slope,
+                                                          const double *__restrict__ dsums,
+                                                          float4 *__restrict__ dy, float *__restrict__ dgamma,
+                                                          float *__restrict__ dbeta) {
+    const int vcol = threadIdx.x % g.cv, rsub = threadIdx.x / g.cv;
+    BwdCoef k[4];
+    float m1[4], m2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = vcol * 4 + i;
+        k[i].mean = mean_invstd[ch]; k[i].invstd = mean_invstd[c + ch];
+        k[i].scale = k[i].invstd * gamma[ch]; k[i].beta = beta[ch];
+        m1[i] = (float)(dsums[ch] / (double)rows); m2[i] = (float)(dsums[c + ch] / (double)rows);
+        if (blockIdx.x == 0 && rsub == 0) { dbeta[ch] = (float)dsums[ch]; dgamma[ch] = (float)dsums[c + ch]; }
+    }
+    for (long long r = (long long)blockIdx.x * g.rpb + rsub; r < rows; r += (long long)gridDim.x * g.rpb) {
+        const float4 v = y[r * g.cv + vcol], go = dout[r * g.cv + vcol];
+        float4 o; float dz, xh;
+        dz_xhat(v.x, go.x, k[0], slope, dz, xh); o.x = k[0].scale * (dz - m1[0] - xh * m2[0]);
+        dz_xhat(v.y, go.y, k[1], slope, dz, xh); o.y = k[1].scale * (dz - m1[1] - xh * m2[1]);
+        dz_xhat(v.z, go.z, k[2], slope, dz, xh); o.z = k[2].scale * (dz - m1[2] - xh * m2[2]);
+        dz_xhat(v.w, go.w, k[3], slope, dz, xh); o.w = k[3].scale * (dz - m1[3] - xh * m2[3]);
+        dy[r * g.cv + vcol] = o;
+    }
+}
+
+// ---- generic path (any C): one thread per element, channel = index % C ------------------------
+__global__ void bn_stats_gen(long long total, int c, const float *__restrict__ y, double *__restrict__ sums) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const float v = y[i]; const int ch = (int)(i % c);
+        atomicAdd(sums + ch, (double)v); atomicAdd(sums + c + ch, (double)v * v);
+    }
+}
+__global__ void bn_act_fwd_gen(long long total, long long rows, int c, const float *__restrict__ y,
+                               const double *__restrict__ sums, const float *__restrict__ gamma,
+                               const float *__restrict__ beta, float eps, float slope, float *__restrict__ out,
+                               float *__restrict__ mean_invstd) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        const ChanCoef k = coef_from_sums(sums, c, ch, rows, gamma, beta, eps);
+        if (i < c) { mean_invstd[ch] = k.mean; mean_invstd[c + ch] = k.invstd; }
+        out[i] = act_fwd((y[i] - k.mean) * k.scale + k.beta, slope);
+    }
+}
+__global__ void bn_act_bwd_stats_gen(long long total, int c, const float *__restrict__ dout,
+                                     const float *__restrict__ y, const float *__restrict__ mean_invstd,
+                                     const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
+                                     double *__restrict__ dsums) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        BwdCoef k; k.mean = mean_invstd[ch]; k.invstd = mean_invstd[c + ch]; k.scale = k.invstd * gamma[ch]; k.beta = beta[ch];
+        float dz, xh; dz_xhat(y[i], dout[i], k, slope, dz, xh);
+        atomicAdd(dsums + ch, (double)dz); atomicAdd(dsums + c + ch, (double)dz * xh);
+    }
+}
+__global__ void bn_act_bwd_gen(long long total, long long rows, int c, const float *__restrict__ dout,
+                               const float *__restrict__ y, const float *__restrict__ mean_invstd,
+                               const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
+                               const double *__restrict__ dsums, float *__restrict__ dy, float *__restrict__ dgamma,
+                               float *__restrict__ dbeta) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        BwdCoef k; k.mean = mean_invstd[ch]; k.invstd = mean_invstd[c + ch]; k.scale = k.invstd * gamma[ch]; k.beta = beta[ch];
+        if (i < c) { dbeta[ch] = (float)dsums[ch]; dgamma[ch] = (float)dsums[c + ch]; }
+        float dz, xh; dz_xhat(y[i], dout[i], k, slope, dz, xh);
+        dy[i] = k.scale * (dz - (float)(dsums[ch] / (double)rows) - xh * (float)(dsums[c + ch] / (double)rows));
+    }
+}
+
+inline bool vec_ok(int c, const void *a, const void *b) {
+    if (c % 4 != 0) return false;
+    const int cv = c / 4;
+    if (cv > THREADS || THREADS % cv != 0) return false;
+    return ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0);
+}
+inline BnGeom geom(int c) { BnGeom g; g.cv = c / 4; g.rpb = THREADS / g.cv; return g; }
+inline unsigned grid_for(long long rows, int rpb) {
+    long long b = (rows + rpb - 1) / rpb;
+    return (unsigned)(b < 1 ? 1 : (b > MAX_BLOCKS ? MAX_BLOCKS : b));
+}
+inline unsigned grid_gen(long long total) {
+    long long b = (total + THREADS - 1) / THREADS;
+    return (unsigned)(b < 1 ? 1 : (b > MAX_BLOCKS ? MAX_BLOCKS : b));
+}
+
+}  // namespace
+
+extern "C" int i2p_bn_stats(long long rows, int c, const float *y, double *sums, void *stream) {
+    if (rows < 0 || c <= 0) return I2P_ERR_BAD_ARG;
+    if (rows == 0) return 0;
+    if (!y || !sums) return I2P_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (vec_ok(c, y, y)) {
+        const BnGeom g = geom(c);
+        hipLaunchKernelGGL(bn_stats_v4, dim3(grid_for(rows, g.rpb)), dim3(THREADS), 0, st, rows, c, g,
+                           (const float4 *)y, sums);
+    } else {
+        hipLaunchKernelGGL(bn_stats_gen, dim3(grid_gen(rows * c)), dim3(THREADS), 0, st, rows * c, c, y, sums);
+    }
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_bn_act_fwd(long long rows, int c, const float *y, const double *sums,
+                              const float *gamma, const float *beta, float eps, float slope,
+                              float *out, float *mean_invstd, void *stream) {
+    if (rows < 0 || c <= 0) return I2P_ERR_BAD_ARG;
+    if (rows == 0) return 0;
+    if (!y || !sums || !gamma || !beta || !out || !mean_invstd) return I2P_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (vec_ok(c, y, out)) {
+        const BnGeom g = geom(c);
+        hipLaunchKernelGGL(bn_act_fwd_v4, dim3(grid_for(rows, g.rpb)), dim3(THREADS), 0, st, rows, c, g,
+                           (const float4 *)y, sums, gamma, beta, eps, slope, (float4 *)out, mean_invstd);
+    } else {
+        hipLaunchKernelGGL(bn_act_fwd_gen, dim3(grid_gen(rows * c)), dim3(THREADS), 0, st, rows * c, rows, c, y,
+                           sums, gamma, beta, eps, slope, out, mean_invstd);
+    }
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_bn_act_bwd_stats(long long rows, int c, const float *dout, const float *y,
+                                    const float *mean_invstd, const float *gamma, const float *beta,
+                                    float slope, double *dsums, void *stream) {
+    if (rows < 0 || c <= 0) return I2P_ERR_BAD_ARG;
+    if (rows == 0) return 0;
+    if (!dout || !y || !mean_invstd || !gamma || !beta || !dsums) return I2P_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (vec_ok(c, y, dout)) {
+        const BnGeom g = geom(c);
+        hipLaunchKernelGGL(bn_act_bwd_stats_v4, dim3(grid_for(rows, g.rpb)), dim3(THREADS), 0, st, rows, c, g,
+                           (const float4 *)dout, (const float4 *)y, mean_invstd, gamma, beta, slope, dsums);
+    } else {
+        hipLaunchKernelGGL(bn_act_bwd_stats_gen, dim3(grid_gen(rows * c)), dim3(THREADS), 0, st, rows * c, c, dout, y,
+                           mean_invstd, gamma, beta, slope, dsums);
+    }
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_bn_act_bwd(long long rows, int c, const float *dout, const float *y,
+                              const float *mean_invstd, const float *gamma, const float *beta,
+                              float slope, const double *dsums, float *dy, float *dgamma, float *dbeta,
+                              void *stream) {
+    if (rows < 0 || c <= 0) return I2P_ERR_BAD_ARG;
+    if (rows == 0) return 0;
+    if (!dout || !y || !mean_invstd || !gamma || !beta || !dsums || !dy || !dgamma || !dbeta) return I2P_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (vec_ok(c, y, dout) && ((uintptr_t)dy % 16 == 0)) {
+        const BnGeom g = geom(c);
+        hipLaunchKernelGGL(bn_act_bwd_v4, dim3(grid_for(rows, g.rpb)), dim3(THREADS), 0, st, rows, c, g,
+                           (const float4 *)dout, (const float4 *)y, mean_invstd, gamma, beta, slope, dsums,
+                           (float4 *)dy, dgamma, dbeta);
+    } else {
+        hipLaunchKernelGGL(bn_act_bwd_gen, dim3(grid_gen(rows * c)), dim3(THREADS), 0, st, rows * c, rows, c, dout, y,
+                           mean_invstd, gamma, beta, slope, dsums, dy, dgamma, dbeta);
+    }
+    I2P_RETURN_LAUNCH_STATUS();
+}

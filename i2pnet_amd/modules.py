@@ -19,9 +19,41 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from . import projectpn as P
 
 _BN_EPS = 1e-5
+
+
+class _BatchStatNormAct(torch.autograd.Function):
+    """BN(batch statistics) + (Leaky)ReLU as two HIP kernels forward and two backward
+    (csrc/bn_act.hip); saves only the pre-BN tensor and 2C statistics."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, eps, slope):
+        shape = y.shape
+        y2 = y.reshape(-1, shape[-1])
+        if not y2.is_contiguous():
+            y2 = y2.contiguous()
+        out, mean_invstd = ops.get_backend().bn_act_forward(y2, gamma.detach(), beta.detach(), eps, slope)
+        ctx.save_for_backward(y2, mean_invstd, gamma, beta)
+        ctx.slope, ctx.shape = slope, shape
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        y2, mean_invstd, gamma, beta = ctx.saved_tensors
+        go = grad_out.reshape(y2.shape)
+        if not go.is_contiguous():
+            go = go.contiguous()
+        dy, dgamma, dbeta = ops.get_backend().bn_act_backward(go, y2, mean_invstd, gamma.detach(), beta.detach(),
+                                                             ctx.slope)
+        return dy.view(ctx.shape), dgamma, dbeta, None, None
+
+
+def bn_act(y, gamma, beta, slope, eps=_BN_EPS):
+    """act(BatchNorm_batchstats(y)) over every axis but the last; slope 0.1 LeakyReLU, 0 ReLU, 1 none."""
+    return _BatchStatNormAct.apply(y, gamma, beta, eps, slope)
 
 
 def batch_stat_norm(y, gamma, beta, eps=_BN_EPS):
@@ -67,7 +99,8 @@ class Conv2d(nn.Module):
                 y = y + self.conv.bias
                 y = self.bn_linear(y.reshape(-1, self.out_channels, 1, 1)).reshape(shape)
             else:
-                y = batch_stat_norm(y, self.bn_linear.weight, self.bn_linear.bias)
+                slope = self.negative_slope if self.activation_fn else 1.0
+                return bn_act(y, self.bn_linear.weight, self.bn_linear.bias, slope)
         else:
             y = y + self.conv.bias
         if self.activation_fn:

@@ -158,6 +158,39 @@ class CBackend:
                    stream=self._stream())
 
 
+    # ---- batch-stat BatchNorm + activation (PPBackbone_center.py:28-46) ---------------------------
+    def bn_act_forward(self, y, gamma, beta, eps, slope):
+        """y [rows,c] f32 -> (out [rows,c], mean_invstd [2c]) with batch statistics."""
+        rows, c = y.shape
+        dev = y.device
+        sums = torch.zeros(2 * c, dtype=torch.float64, device=dev)
+        out = torch.empty_like(y)
+        mean_invstd = torch.empty(2 * c, dtype=_F32, device=dev)
+        st = self._stream()
+        self._call("i2p_bn_stats", int(rows), int(c), self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums"),
+                   stream=st)
+        self._call("i2p_bn_act_fwd", int(rows), int(c), self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums"),
+                   self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(eps), float(slope),
+                   self._p(out, _F32, "out"), self._p(mean_invstd, _F32, "mean_invstd"), stream=st)
+        return out, mean_invstd
+
+    def bn_act_backward(self, dout, y, mean_invstd, gamma, beta, slope):
+        """-> (dy [rows,c], dgamma [c], dbeta [c])"""
+        rows, c = y.shape
+        dev = y.device
+        dsums = torch.zeros(2 * c, dtype=torch.float64, device=dev)
+        dy = torch.empty_like(y)
+        dgamma = torch.empty(c, dtype=_F32, device=dev)
+        dbeta = torch.empty(c, dtype=_F32, device=dev)
+        st = self._stream()
+        args = (self._p(dout, _F32, "dout"), self._p(y, _F32, "y"), self._p(mean_invstd, _F32, "mean_invstd"),
+                self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(slope))
+        self._call("i2p_bn_act_bwd_stats", int(rows), int(c), *args, self._p(dsums, torch.float64, "dsums"), stream=st)
+        self._call("i2p_bn_act_bwd", int(rows), int(c), *args, self._p(dsums, torch.float64, "dsums"),
+                   self._p(dy, _F32, "dy"), self._p(dgamma, _F32, "dgamma"), self._p(dbeta, _F32, "dbeta"), stream=st)
+        return dy, dgamma, dbeta
+
+
 _hip = None
 _active = None
 

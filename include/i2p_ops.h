@@ -152,6 +152,37 @@ int i2p_gather_rows_grad(int b, int hw, int c, int q, int W, const float *grad_o
 int i2p_knn(int b, int n, int s, int k, const float *xyz, const float *new_xyz, int *idx,
             void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Batch-statistics BatchNorm + (Leaky)ReLU on channel-last activations y [rows, c].
+ * This is what every point-branch `Conv2d` of the reference runs after its 1x1 conv
+ * (src/projectPN/PPBackbone_center.py:28-46: nn.BatchNorm2d(track_running_stats=False) on the
+ * [B,C,K,N] view, i.e. biased batch variance over rows, eps 1e-5, affine; then ReLU or
+ * LeakyReLU(0.1)), done in eager PyTorch there (permute / conv / BN / act / permute).
+ *   out = act((y - mean) * (invstd * gamma) + beta),  act(z) = z > 0 ? z : slope * z
+ *   slope: 0.1 LeakyReLU, 0 ReLU, 1 no activation.
+ * Statistics are accumulated in fp64 (sum, sum of squares): robust when |mean| >> std.
+ * --------------------------------------------------------------------------------------------- */
+
+/* sums f64 [2*c] (zeroed by caller) += { sum_r y[r,:], sum_r y[r,:]^2 } */
+int i2p_bn_stats(long long rows, int c, const float *y, double *sums, void *stream);
+
+/* forward: writes out [rows,c] and mean_invstd f32 [2*c] (saved for backward) */
+int i2p_bn_act_fwd(long long rows, int c, const float *y, const double *sums, const float *gamma,
+                   const float *beta, float eps, float slope, float *out, float *mean_invstd,
+                   void *stream);
+
+/* backward pass 1: dsums f64 [2*c] (zeroed by caller) += { sum dz, sum dz*xhat },
+ * dz = dout * act'(z) recomputed from y */
+int i2p_bn_act_bwd_stats(long long rows, int c, const float *dout, const float *y,
+                         const float *mean_invstd, const float *gamma, const float *beta,
+                         float slope, double *dsums, void *stream);
+
+/* backward pass 2: dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dgamma = sum dz*xhat,
+ * dbeta = sum dz (f32 [c] each, written) */
+int i2p_bn_act_bwd(long long rows, int c, const float *dout, const float *y,
+                   const float *mean_invstd, const float *gamma, const float *beta, float slope,
+                   const double *dsums, float *dy, float *dgamma, float *dbeta, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -212,3 +212,31 @@ def test_project_seq_parity(oracle_backend, hip_backend):
     wn = gw.long().clamp(min=0)
     exp = torch.gather(xyz.to(DEV), 1, wn.unsqueeze(-1).expand(-1, -1, 3)) * (gw >= 0).unsqueeze(-1)
     assert torch.equal(exp.view(B, H, W, 3), gx)
+
+
+@pytest.mark.parametrize("rows,c,slope", [(1000, 16, 0.0), (12345, 64, 0.1), (853, 128, 0.1), (70000, 256, 0.0),
+                                           (999, 10, 1.0), (4096, 32, 1.0)])
+def test_bn_act_parity(oracle_backend, hip_backend, rows, c, slope):
+    """fused BN(batch stats)+activation: HIP vs oracle (1e-5) and vs a plain torch fp32/fp64 reference."""
+    g = torch.Generator().manual_seed(rows + c)
+    y = torch.randn(rows, c, generator=g) * (1 + torch.arange(c).float() / c) + 50.0 * torch.randn(c, generator=g)
+    gamma = 1 + 0.1 * torch.randn(c, generator=g); beta = 0.1 * torch.randn(c, generator=g)
+    go = torch.randn(rows, c, generator=g)
+    ro, rmi = oracle_backend.bn_act_forward(y, gamma, beta, 1e-5, slope)
+    ho, hmi = hip_backend.bn_act_forward(y.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, slope)
+    assert torch.allclose(rmi, hmi.cpu(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(ro, ho.cpu(), rtol=1e-5, atol=1e-5)
+    rdy, rdg, rdb = oracle_backend.bn_act_backward(go, y, rmi, gamma, beta, slope)
+    hdy, hdg, hdb = hip_backend.bn_act_backward(go.to(DEV), y.to(DEV), hmi, gamma.to(DEV), beta.to(DEV), slope)
+    assert torch.allclose(rdy, hdy.cpu(), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(rdg, hdg.cpu(), rtol=1e-4, atol=1e-3) and torch.allclose(rdb, hdb.cpu(), rtol=1e-4, atol=1e-3)
+    # independent reference: torch autograd in float64
+    yd = y.double().requires_grad_(True); gd = gamma.double().requires_grad_(True); bd = beta.double().requires_grad_(True)
+    var, mean = torch.var_mean(yd, dim=0, unbiased=False)
+    z = (yd - mean) * torch.rsqrt(var + 1e-5) * gd + bd
+    a = torch.where(z > 0, z, z * slope)
+    a.backward(go.double())
+    assert torch.allclose(ho.cpu().double(), a.detach(), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(hdy.cpu().double(), yd.grad, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(hdg.cpu().double(), gd.grad, rtol=1e-3, atol=1e-2)
+    assert torch.allclose(hdb.cpu().double(), bd.grad, rtol=1e-3, atol=1e-2)
