@@ -11,7 +11,10 @@
 namespace {
 
 constexpr int THREADS = 256;
-constexpr int MAX_BLOCKS = 2048;
+constexpr int MAX_BLOCKS = 2048;      // streaming (apply) kernels
+constexpr int MAX_STAT_BLOCKS = 1024; // reduction kernels: fewer, fatter blocks
+constexpr int UNROLL = 4;             // independent 16-B loads in flight per lane in the reductions
+constexpr int REP = I2P_BN_REPLICAS;  // same-address fp64 atomics cost ~90 ns each: spread them
 
 struct BnGeom {
     int cv;        // float4 columns = C/4
@@ -27,10 +30,20 @@ __global__ __launch_bounds__(THREADS) void bn_stats_v4(long long rows, int c, Bn
     __shared__ double red[THREADS][8];
     const int vcol = threadIdx.x % g.cv, rsub = threadIdx.x / g.cv;
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    for (long long r = (long long)blockIdx.x * g.rpb + rsub; r < rows; r += (long long)gridDim.x * g.rpb) {
-        const float4 v = y[r * g.cv + vcol];
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-        q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+    const long long stride = (long long)gridDim.x * g.rpb;
+    for (long long r0 = (long long)blockIdx.x * g.rpb + rsub; r0 < rows; r0 += stride * UNROLL) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const long long r = r0 + u * stride;
+            v[u] = r < rows ? y[r * g.cv + vcol] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w;
+            q[0] += (double)v[u].x * v[u].x; q[1] += (double)v[u].y * v[u].y;
+            q[2] += (double)v[u].z * v[u].z; q[3] += (double)v[u].w * v[u].w;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][4 + i] = q[i]; }
@@ -42,18 +55,26 @@ __global__ __launch_bounds__(THREADS) void bn_stats_v4(long long rows, int c, Bn
             for (int i = 0; i < 8; ++i) a[i] += red[t][i];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            atomicAdd(sums + vcol * 4 + i, a[i]);
-            atomicAdd(sums + c + vcol * 4 + i, a[4 + i]);
+            double *rep = sums + (size_t)(blockIdx.x % REP) * 2 * c;
+            atomicAdd(rep + vcol * 4 + i, a[i]);
+            atomicAdd(rep + c + vcol * 4 + i, a[4 + i]);
         }
     }
 }
 
 struct ChanCoef { float mean, invstd, scale, beta; };
 
+__device__ __forceinline__ double rep_sum(const double *sums, int c, int idx) {
+    double a = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < REP; ++r) a += sums[(size_t)r * 2 * c + idx];
+    return a;
+}
+
 __device__ __forceinline__ ChanCoef coef_from_sums(const double *sums, int c, int ch, long long rows,
                                                    const float *gamma, const float *beta, float eps) {
-    const double m = sums[ch] / (double)rows;
-    double var = sums[c + ch] / (double)rows - m * m;
+    const double m = rep_sum(sums, c, ch) / (double)rows;
+    double var = rep_sum(sums, c, c + ch) / (double)rows - m * m;
     var = var < 0.0 ? 0.0 : var;
     ChanCoef k;
     k.mean = (float)m;
@@ -113,13 +134,24 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_stats_v4(long long rows, i
         k[i].scale = k[i].invstd * gamma[ch]; k[i].beta = beta[ch];
     }
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    for (long long r = (long long)blockIdx.x * g.rpb + rsub; r < rows; r += (long long)gridDim.x * g.rpb) {
-        const float4 v = y[r * g.cv + vcol], go = dout[r * g.cv + vcol];
-        float dz, xh;
-        dz_xhat(v.x, go.x, k[0], slope, dz, xh); s[0] += dz; q[0] += (double)dz * xh;
-        dz_xhat(v.y, go.y, k[1], slope, dz, xh); s[1] += dz; q[1] += (double)dz * xh;
-        dz_xhat(v.z, go.z, k[2], slope, dz, xh); s[2] += dz; q[2] += (double)dz * xh;
-        dz_xhat(v.w, go.w, k[3], slope, dz, xh); s[3] += dz; q[3] += (double)dz * xh;
+    const long long stride = (long long)gridDim.x * g.rpb;
+    for (long long r0 = (long long)blockIdx.x * g.rpb + rsub; r0 < rows; r0 += stride * 2) {
+        float4 v[2], go[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long r = r0 + u * stride;
+            const bool ok = r < rows;
+            v[u] = ok ? y[r * g.cv + vcol] : make_float4(0.f, 0.f, 0.f, 0.f);
+            go[u] = ok ? dout[r * g.cv + vcol] : make_float4(0.f, 0.f, 0.f, 0.f);   // dz = 0: no contribution
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float dz, xh;
+            dz_xhat(v[u].x, go[u].x, k[0], slope, dz, xh); s[0] += dz; q[0] += (double)dz * xh;
+            dz_xhat(v[u].y, go[u].y, k[1], slope, dz, xh); s[1] += dz; q[1] += (double)dz * xh;
+            dz_xhat(v[u].z, go[u].z, k[2], slope, dz, xh); s[2] += dz; q[2] += (double)dz * xh;
+            dz_xhat(v[u].w, go[u].w, k[3], slope, dz, xh); s[3] += dz; q[3] += (double)dz * xh;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][4 + i] = q[i]; }
@@ -131,8 +163,9 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_stats_v4(long long rows, i
             for (int i = 0; i < 8; ++i) a[i] += red[t][i];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            atomicAdd(dsums + vcol * 4 + i, a[i]);
-            atomicAdd(dsums + c + vcol * 4 + i, a[4 + i]);
+            double *rep = dsums + (size_t)(blockIdx.x % REP) * 2 * c;
+            atomicAdd(rep + vcol * 4 + i, a[i]);
+            atomicAdd(rep + c + vcol * 4 + i, a[4 + i]);
         }
     }
 }
@@ -154,8 +187,9 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_v4(long long rows, int c, 
         const int ch = vcol * 4 + i;
         k[i].mean = mean_invstd[ch]; k[i].invstd = mean_invstd[c + ch];
         k[i].scale = k[i].invstd * gamma[ch]; k[i].beta = beta[ch];
-        m1[i] = (float)(dsums[ch] / (double)rows); m2[i] = (float)(dsums[c + ch] / (double)rows);
-        if (blockIdx.x == 0 && rsub == 0) { dbeta[ch] = (float)dsums[ch]; dgamma[ch] = (float)dsums[c + ch]; }
+        const double sd = rep_sum(dsums, c, ch), sx = rep_sum(dsums, c, c + ch);
+        m1[i] = (float)(sd / (double)rows); m2[i] = (float)(sx / (double)rows);
+        if (blockIdx.x == 0 && rsub == 0) { dbeta[ch] = (float)sd; dgamma[ch] = (float)sx; }
     }
     for (long long r = (long long)blockIdx.x * g.rpb + rsub; r < rows; r += (long long)gridDim.x * g.rpb) {
         const float4 v = y[r * g.cv + vcol], go = dout[r * g.cv + vcol];
@@ -172,7 +206,8 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_v4(long long rows, int c, 
 __global__ void bn_stats_gen(long long total, int c, const float *__restrict__ y, double *__restrict__ sums) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const float v = y[i]; const int ch = (int)(i % c);
-        atomicAdd(sums + ch, (double)v); atomicAdd(sums + c + ch, (double)v * v);
+        double *rep = sums + (size_t)(blockIdx.x % REP) * 2 * c;
+        atomicAdd(rep + ch, (double)v); atomicAdd(rep + c + ch, (double)v * v);
     }
 }
 __global__ void bn_act_fwd_gen(long long total, long long rows, int c, const float *__restrict__ y,
@@ -194,7 +229,8 @@ __global__ void bn_act_bwd_stats_gen(long long total, int c, const float *__rest
         const int ch = (int)(i % c);
         BwdCoef k; k.mean = mean_invstd[ch]; k.invstd = mean_invstd[c + ch]; k.scale = k.invstd * gamma[ch]; k.beta = beta[ch];
         float dz, xh; dz_xhat(y[i], dout[i], k, slope, dz, xh);
-        atomicAdd(dsums + ch, (double)dz); atomicAdd(dsums + c + ch, (double)dz * xh);
+        double *rep = dsums + (size_t)(blockIdx.x % REP) * 2 * c;
+        atomicAdd(rep + ch, (double)dz); atomicAdd(rep + c + ch, (double)dz * xh);
     }
 }
 __global__ void bn_act_bwd_gen(long long total, long long rows, int c, const float *__restrict__ dout,
@@ -205,9 +241,10 @@ __global__ void bn_act_bwd_gen(long long total, long long rows, int c, const flo
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int ch = (int)(i % c);
         BwdCoef k; k.mean = mean_invstd[ch]; k.invstd = mean_invstd[c + ch]; k.scale = k.invstd * gamma[ch]; k.beta = beta[ch];
-        if (i < c) { dbeta[ch] = (float)dsums[ch]; dgamma[ch] = (float)dsums[c + ch]; }
+        const double sd = rep_sum(dsums, c, ch), sx = rep_sum(dsums, c, c + ch);
+        if (i < c) { dbeta[ch] = (float)sd; dgamma[ch] = (float)sx; }
         float dz, xh; dz_xhat(y[i], dout[i], k, slope, dz, xh);
-        dy[i] = k.scale * (dz - (float)(dsums[ch] / (double)rows) - xh * (float)(dsums[c + ch] / (double)rows));
+        dy[i] = k.scale * (dz - (float)(sd / (double)rows) - xh * (float)(sx / (double)rows));
     }
 }
 
@@ -221,6 +258,10 @@ inline BnGeom geom(int c) { BnGeom g; g.cv = c / 4; g.rpb = THREADS / g.cv; retu
 inline unsigned grid_for(long long rows, int rpb) {
     long long b = (rows + rpb - 1) / rpb;
     return (unsigned)(b < 1 ? 1 : (b > MAX_BLOCKS ? MAX_BLOCKS : b));
+}
+inline unsigned grid_stat(long long rows, int rpb, int unroll) {
+    long long b = (rows + (long long)rpb * unroll - 1) / ((long long)rpb * unroll);
+    return (unsigned)(b < 1 ? 1 : (b > MAX_STAT_BLOCKS ? MAX_STAT_BLOCKS : b));
 }
 inline unsigned grid_gen(long long total) {
     long long b = (total + THREADS - 1) / THREADS;
@@ -236,7 +277,7 @@ extern "C" int i2p_bn_stats(long long rows, int c, const float *y, double *sums,
     hipStream_t st = (hipStream_t)stream;
     if (vec_ok(c, y, y)) {
         const BnGeom g = geom(c);
-        hipLaunchKernelGGL(bn_stats_v4, dim3(grid_for(rows, g.rpb)), dim3(THREADS), 0, st, rows, c, g,
+        hipLaunchKernelGGL(bn_stats_v4, dim3(grid_stat(rows, g.rpb, UNROLL)), dim3(THREADS), 0, st, rows, c, g,
                            (const float4 *)y, sums);
     } else {
         hipLaunchKernelGGL(bn_stats_gen, dim3(grid_gen(rows * c)), dim3(THREADS), 0, st, rows * c, c, y, sums);
@@ -271,7 +312,7 @@ extern "C" int i2p_bn_act_bwd_stats(long long rows, int c, const float *dout, co
     hipStream_t st = (hipStream_t)stream;
     if (vec_ok(c, y, dout)) {
         const BnGeom g = geom(c);
-        hipLaunchKernelGGL(bn_act_bwd_stats_v4, dim3(grid_for(rows, g.rpb)), dim3(THREADS), 0, st, rows, c, g,
+        hipLaunchKernelGGL(bn_act_bwd_stats_v4, dim3(grid_stat(rows, g.rpb, 2)), dim3(THREADS), 0, st, rows, c, g,
                            (const float4 *)dout, (const float4 *)y, mean_invstd, gamma, beta, slope, dsums);
     } else {
         hipLaunchKernelGGL(bn_act_bwd_stats_gen, dim3(grid_gen(rows * c)), dim3(THREADS), 0, st, rows * c, c, dout, y,

@@ -15,6 +15,7 @@ import torch
 from . import _abi, _lib
 
 _F32, _I32, _I64 = torch.float32, torch.int32, torch.int64
+BN_REPLICAS = 32          # I2P_BN_REPLICAS in include/i2p_ops.h
 
 
 class CBackend:
@@ -163,7 +164,7 @@ class CBackend:
         """y [rows,c] f32 -> (out [rows,c], mean_invstd [2c]) with batch statistics."""
         rows, c = y.shape
         dev = y.device
-        sums = torch.zeros(2 * c, dtype=torch.float64, device=dev)
+        sums = torch.zeros(BN_REPLICAS * 2 * c, dtype=torch.float64, device=dev)
         out = torch.empty_like(y)
         mean_invstd = torch.empty(2 * c, dtype=_F32, device=dev)
         st = self._stream()
@@ -178,7 +179,7 @@ class CBackend:
         """-> (dy [rows,c], dgamma [c], dbeta [c])"""
         rows, c = y.shape
         dev = y.device
-        dsums = torch.zeros(2 * c, dtype=torch.float64, device=dev)
+        dsums = torch.zeros(BN_REPLICAS * 2 * c, dtype=torch.float64, device=dev)
         dy = torch.empty_like(y)
         dgamma = torch.empty(c, dtype=_F32, device=dev)
         dbeta = torch.empty(c, dtype=_F32, device=dev)

@@ -163,7 +163,12 @@ int i2p_knn(int b, int n, int s, int k, const float *xyz, const float *new_xyz, 
  * Statistics are accumulated in fp64 (sum, sum of squares): robust when |mean| >> std.
  * --------------------------------------------------------------------------------------------- */
 
-/* sums f64 [2*c] (zeroed by caller) += { sum_r y[r,:], sum_r y[r,:]^2 } */
+/* Partial sums are spread over I2P_BN_REPLICAS copies (same-address fp64 atomics serialise):
+ * every `sums` / `dsums` buffer is f64 [I2P_BN_REPLICAS][2*c], zeroed by the caller; the true
+ * sums are the sums over the replica axis. */
+#define I2P_BN_REPLICAS 32
+
+/* sums[rep][0:c] += sum_r y[r,:],  sums[rep][c:2c] += sum_r y[r,:]^2 */
 int i2p_bn_stats(long long rows, int c, const float *y, double *sums, void *stream);
 
 /* forward: writes out [rows,c] and mean_invstd f32 [2*c] (saved for backward) */
@@ -171,7 +176,7 @@ int i2p_bn_act_fwd(long long rows, int c, const float *y, const double *sums, co
                    const float *beta, float eps, float slope, float *out, float *mean_invstd,
                    void *stream);
 
-/* backward pass 1: dsums f64 [2*c] (zeroed by caller) += { sum dz, sum dz*xhat },
+/* backward pass 1: dsums (replicated, zeroed by caller) += { sum dz, sum dz*xhat },
  * dz = dout * act'(z) recomputed from y */
 int i2p_bn_act_bwd_stats(long long rows, int c, const float *dout, const float *y,
                          const float *mean_invstd, const float *gamma, const float *beta,

@@ -1,0 +1,54 @@
+"""Micro-benchmarks of the hand-written kernels at the model's shapes (events on the launch
+stream; achieved GB/s on algorithmic bytes).  `python tools/bench_kernels.py [--batch 8]`"""
+import argparse
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+from i2pnet_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record(); e.synchronize()
+    return s.elapsed_time(e) / iters * 1e3      # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    a = ap.parse_args()
+    dev = "cuda"
+    hip = ops.hip_backend()
+    B = a.batch
+    print(f"{'kernel':34s} {'shape':24s} {'us':>9s} {'GB/s':>9s}")
+    for name, rows, c in [("cv1 128ch", B * 228 * 468, 128), ("cv1 64ch", B * 228 * 468, 64), ("L1 16ch", B * 3600 * 32, 16),
+                          ("L1 32ch", B * 3600 * 32, 32), ("L2 64ch", B * 904 * 16, 64), ("L4 256ch", B * 116 * 16, 256)]:
+        y = torch.randn(rows, c, device=dev); g = torch.ones(c, device=dev); b = torch.zeros(c, device=dev)
+        go = torch.randn(rows, c, device=dev)
+        sums = torch.zeros(32 * 2 * c, dtype=torch.float64, device=dev)
+        out = torch.empty_like(y); mi = torch.empty(2 * c, device=dev); dy = torch.empty_like(y)
+        dg = torch.empty(c, device=dev); db = torch.empty(c, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        P = lambda t: t.data_ptr()
+        nbytes = rows * c * 4
+        from i2pnet_amd import _lib
+        t = timeit(lambda: _lib.call("i2p_bn_stats", rows, c, P(y), P(sums), stream=st))
+        print(f"{'bn_stats':34s} {name:24s} {t:9.1f} {nbytes / t / 1e3:9.0f}")
+        t = timeit(lambda: _lib.call("i2p_bn_act_fwd", rows, c, P(y), P(sums), P(g), P(b), 1e-5, 0.1, P(out), P(mi), stream=st))
+        print(f"{'bn_act_fwd':34s} {name:24s} {t:9.1f} {2 * nbytes / t / 1e3:9.0f}")
+        t = timeit(lambda: _lib.call("i2p_bn_act_bwd_stats", rows, c, P(go), P(y), P(mi), P(g), P(b), 0.1, P(sums), stream=st))
+        print(f"{'bn_act_bwd_stats':34s} {name:24s} {t:9.1f} {2 * nbytes / t / 1e3:9.0f}")
+        t = timeit(lambda: _lib.call("i2p_bn_act_bwd", rows, c, P(go), P(y), P(mi), P(g), P(b), 0.1, P(sums), P(dy), P(dg), P(db), stream=st))
+        print(f"{'bn_act_bwd':34s} {name:24s} {t:9.1f} {3 * nbytes / t / 1e3:9.0f}")
+
+
+if __name__ == "__main__":
+    main()
