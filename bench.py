@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--layout", default="scan", choices=["scan", "centre"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=1, help="capture the step in one hipGraph (single-GPU runs)")
     args = ap.parse_args()
 
     from i2pnet_amd import synth
@@ -101,8 +102,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    tr = Trainer(cfg=cfg, device=device, world_size=world, local_rank=local_rank)
+    use_graph = bool(args.graph) and world == 1
+    tr = Trainer(cfg=cfg, device=device, world_size=world, local_rank=local_rank, capturable=use_graph)
     batch = synth.make_batch(args.batch, args.points, 375, 1242, seed=1000 + rank, device=device, layout=args.layout)
+    graph_live = tr.capture(batch) if use_graph else False
 
     def sync():
         if world > 1:
@@ -133,7 +136,7 @@ def main():
             "config": {"workload": "configs[1]: synthetic KITTI-shaped batch, 375x1242 RGB + %d-pt cloud (%s layout), "
                                    "fp32 forward+loss+backward+clip+Adam" % (args.points, args.layout),
                        "per_gpu_batch": args.batch, "global_batch": global_batch,
-                       "parallelism": f"dp{world}", "final_loss": round(float(loss), 4)},
+                       "parallelism": f"dp{world}", "hipgraph": graph_live, "final_loss": round(float(loss), 4)},
             "roofline": level1_select_roofline(args.batch, device),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -34,7 +34,7 @@ def init_distributed(backend):
 
 class Trainer:
     def __init__(self, cfg=I2PNetConfig, device="cuda", lr=1e-3, clip=10.0, world_size=1, local_rank=0,
-                 seed=0):
+                 seed=0, capturable=False):
         torch.manual_seed(seed)                 # identical initial weights on every rank
         self.cfg, self.device, self.clip = cfg, torch.device(device), clip
         self.net = RegNet_v2(cfg=cfg).to(self.device)
@@ -44,12 +44,53 @@ class Trainer:
             self.model = nn.parallel.DistributedDataParallel(
                 self.net, bucket_cap_mb=64, broadcast_buffers=False, gradient_as_bucket_view=True, **kw)
         self.params = [p for p in self.net.parameters() if p.requires_grad]
-        self.optimizer = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0001)
+        self.optimizer = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0001,
+                                          capturable=capturable and self.device.type == "cuda")
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, 0.99)
+        self._graph = None
+        self._static = None
+        self._static_out = None
+
+    # ---- whole-step hipGraph ------------------------------------------------------------------
+    def capture(self, batch, warmup=3):
+        """Capture forward+loss+backward+clip+Adam as ONE hipGraph (static shapes; ~2000 kernel
+        launches per step otherwise keep the host thread on the critical path).  `batch` provides
+        the static input buffers; later `step()` calls copy into them and replay.
+        Requires `capturable=True`.  Returns True if the graph is live, False if capture failed
+        (the trainer then keeps running eagerly)."""
+        assert self.device.type == "cuda"
+        self._static = {k: v.clone() for k, v in batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._eager_step(self._static)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._static_out = self._eager_step(self._static)
+            self._graph = graph
+            return True
+        except Exception as e:                      # noqa: BLE001 — fall back to eager, loudly
+            print(f"[i2pnet_amd.train] hipGraph capture failed, staying eager: {type(e).__name__}: {e}", flush=True)
+            self._graph = None
+            torch.cuda.synchronize()
+            return False
 
     def step(self, batch):
         """one optimisation step on a sample dict (keys of the reference loader); returns the
         loss tensors without synchronising."""
+        if self._graph is not None:
+            for k, v in batch.items():
+                if self._static[k] is not v:
+                    self._static[k].copy_(v, non_blocking=True)
+            self._graph.replay()
+            return self._static_out
+        return self._eager_step(batch)
+
+    def _eager_step(self, batch):
         self.model.train()
         out3, out4, _, _, sx, sq = self.model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"],
                                               batch.get("init_extrinsic"), batch["init_intrinsic"], None, None, None,
