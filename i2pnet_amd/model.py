@@ -34,8 +34,12 @@ def change_intrinsic(intrinsic, RF, rgb_img):
     """rescale fx, cx by w'/w and fy, cy by h'/h (modellearn_proj_center.py:457-463)."""
     sx = RF.shape[3] / rgb_img.shape[3]
     sy = RF.shape[2] / rgb_img.shape[2]
-    scale = intrinsic.new_tensor([[sx, 1.0, sx], [1.0, sy, sy], [1.0, 1.0, 1.0]])
-    return intrinsic * scale
+    out = intrinsic.clone()          # python scalars only: no host->device copy (hipGraph-capturable)
+    out[:, 0, 0] *= sx
+    out[:, 0, 2] *= sx
+    out[:, 1, 1] *= sy
+    out[:, 1, 2] *= sy
+    return out
 
 
 def inverse_3x3(m):

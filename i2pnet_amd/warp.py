@@ -8,8 +8,8 @@ def inv_q(q):
     B = q.shape[0]
     q = q.reshape(B, 4)
     n2 = torch.sum(q * q, dim=-1, keepdim=True) + 1e-10
-    sign = q.new_tensor([1.0, -1.0, -1.0, -1.0])
-    return (q * sign) / n2
+    conj = torch.cat([q[:, :1], -q[:, 1:]], dim=-1)     # no host constant: hipGraph-capturable
+    return conj / n2
 
 
 def mul_q(a, b):
