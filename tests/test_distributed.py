@@ -1,0 +1,92 @@
+"""Data-parallel step on CPU: 2 processes, gloo, oracle operators.  Checks what the RCCL path
+relies on: identical parameters on every rank after a step, and gradients equal to the mean of
+the per-rank gradients (DDP all-reduce), with BN statistics local to a rank."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from i2pnet_amd import ops, synth
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd.train import Trainer, init_distributed
+    from oracle import oracle
+    ops.set_backend(oracle.backend())
+    init_distributed("gloo")
+    tr = Trainer(cfg=cfg, device="cpu", world_size=world, local_rank=rank, seed=0)
+    tr.net.l3_head.DP1.p = 0.0; tr.net.l4_head.DP1.p = 0.0          # dropout off: ranks must be comparable
+    batch = synth.make_batch(1, 4096, 160, 512, seed=10 + rank)
+    tr.step(batch)
+    grads = {k: p.grad.clone() for k, p in tr.net.named_parameters() if p.grad is not None}
+    params = {k: p.detach().clone() for k, p in tr.net.named_parameters()}
+    torch.save({"grads": grads, "params": params}, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _single(seed_rank, out):
+    from i2pnet_amd import ops, synth
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd.loss import Get_loss
+    from i2pnet_amd.train import Trainer
+    tr = Trainer(cfg=cfg, device="cpu", seed=0)
+    tr.net.l3_head.DP1.p = 0.0; tr.net.l4_head.DP1.p = 0.0
+    tr.model.train()
+    b = synth.make_batch(1, 4096, 160, 512, seed=10 + seed_rank)
+    o3, o4, _, _, sx, sq = tr.model(b["rgb"], b["lidar"], b["raw_point_xyz"], None, b["init_intrinsic"], None, None, None,
+                                    b["lidar_feats"], cfg=cfg)
+    loss, _, _ = Get_loss(o3, o4, b["decalib_real_gt"], b["decalib_dual_gt"], sx, sq, cfg=cfg)
+    loss.backward()
+    out[seed_rank] = {k: p.grad.clone() for k, p in tr.net.named_parameters() if p.grad is not None}
+
+
+def test_ddp_gloo_two_ranks(tmp_path, oracle_backend):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
+    for k in r0["params"]:                                    # replicas stay in lock-step
+        assert torch.equal(r0["params"][k], r1["params"][k]), k
+    for k in r0["grads"]:                                     # both ranks hold the all-reduced gradient
+        assert torch.equal(r0["grads"][k], r1["grads"][k]), k
+    # ... which is the mean of the two single-process gradients (pre-clip: clip acts after the all-reduce)
+    from i2pnet_amd import ops
+    prev = ops.set_backend(oracle_backend)
+    try:
+        torch.set_num_threads(4)
+        single = {}
+        _single(0, single); _single(1, single)
+    finally:
+        ops.set_backend(prev)
+    tot = sum(float((0.5 * (single[0][k] + single[1][k])).double().norm() ** 2) for k in single[0]) ** 0.5
+    scale = min(1.0, 10.0 / (tot + 1e-6))                     # Trainer clips the global norm at 10
+    # per-parameter check, except the mask up-conv whose fp32 gradient is rounding noise in the
+    # reference as well (it consumes -1e10 mask values) — that one only enters the global norm
+    num = den = 0.0
+    errs = {}
+    for k in single[0]:
+        want = 0.5 * (single[0][k] + single[1][k]) * scale
+        diff = (r0["grads"][k] - want).double()
+        num += float(diff.norm() ** 2); den += float(want.double().norm() ** 2)
+        errs[k] = float(diff.norm()) / (float(want.double().norm()) + 1e-9)
+    # (conv biases in front of a train-mode BN likewise carry pure rounding noise: only parameters
+    # holding at least 1e-3 of the global gradient norm are checked individually)
+    wn = {k: float((0.5 * (single[0][k] + single[1][k]) * scale).double().norm()) for k in single[0]}
+    bad = {k: v for k, v in errs.items() if v > 2e-2 and not k.startswith("set_upconv0_w_upsample")
+           and wn[k] > 1e-3 * den ** 0.5}
+    assert not bad, bad
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
