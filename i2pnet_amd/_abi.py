@@ -29,6 +29,8 @@ SIGNATURES = {
     "i2p_bn_act_fwd": ["l", "i", "p", "p", "p", "p", "f", "f", "p", "p"],
     "i2p_bn_act_bwd_stats": ["l", "i", "p", "p", "p", "p", "p", "f", "p"],
     "i2p_bn_act_bwd": ["l", "i", "p", "p", "p", "p", "p", "f", "p", "p", "p", "p"],
+    "i2p_lin_fwd": ["l", "i", "i", "p", "p", "f", "p", "p", "p"],
+    "i2p_bn_finalize": ["l", "i", "p", "p", "p", "f", "p", "p"],
 }
 
 _CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "p": C.c_void_p, "pp": C.c_void_p}

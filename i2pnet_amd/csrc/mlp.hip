@@ -1,0 +1,231 @@
+// Fused per-point linear layers (1x1 conv) on fp32 MFMA for gfx950.
+//
+// Every point-branch layer of the reference is  conv1x1 -> BatchNorm(batch statistics) ->
+// (Leaky)ReLU  on a [B,N,K,C] tensor (src/projectPN/PPBackbone_center.py:10-51), run there as
+// separate eager kernels with a full HBM round trip each.  Batch statistics force one global
+// reduction per layer, so a layer cannot be fused with its own BN — but it CAN be fused with the
+// BN + activation of the layer BEFORE it and with the statistics of its own output:
+//
+//   lin_fwd :  Y = act_in(bn_in(X)) . W^T          X [rows,Cin] pre-BN output of the previous layer
+//              sums += { sum Y, sum Y^2 }           (fp64, replica-spread atomics, as bn_act.hip)
+//   lin_bwd :  G  = bn_out_backward(dZ, Y)          formed on load from dZ (grad w.r.t. BN output
+//                                                   pre-activation... see below) and Y
+//              dW += G^T . X'      (wgrad)          X' = act_in(bn_in(X)) recomputed on load
+//              dZin = (G . W) * act_in'(z_in)       (dgrad, continues into the previous BN)
+//              dsums_in += { sum dZin, sum dZin * xhat_in }
+//
+// so a chain of L layers costs L kernels forward (read X, write Y once each) and L backward
+// (read dZ, Y, X; write dZin), with no materialised BN outputs, activations or x-hats.
+//
+// GEMM core: v_mfma_f32_32x32x2_f32 (exact fp32, 256 FLOP/clk/CU), W stationary in LDS
+// ([Cout][Cin+1] floats, +1 pad => conflict-free ds_read_b32 fragments), 128-row activation
+// tiles staged through LDS with the BN/activation transform applied on the way in, 4 waves x
+// (32 rows x Cout) accumulators.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int THREADS = 256;
+constexpr int REP = I2P_BN_REPLICAS;
+
+__device__ __forceinline__ float act_apply(float z, float slope) { return z > 0.f ? z : z * slope; }
+
+struct LinFwdParams {
+    long long rows;
+    int cin, cout;          // logical sizes
+    int cin_p, cout_p;      // cin rounded up to even, cout rounded up to 32
+    int ldk;                // LDS row stride in floats (cin_p + 1)
+    const float *x;         // [rows, cin]
+    const float *in_coef;   // [3][cin] mean, scale(=invstd*gamma), beta of the BN in front, or nullptr
+    float slope_in;         // activation in front (1 = none)
+    const float *w;         // [cout, cin]
+    float *y;               // [rows, cout]
+    double *sums;           // [REP][2*cout] (zeroed by caller) or nullptr
+};
+
+// one 32x32 C/D fragment: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+__device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <int TILE_R, int NT>
+__global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
+    extern __shared__ float smem[];
+    float *Ws = smem;                                   // [cout_p][ldk]
+    float *As = smem + (size_t)p.cout_p * p.ldk;        // [TILE_R][ldk]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int ROWS_PER_WAVE = TILE_R / 4;           // 32
+    static_assert(ROWS_PER_WAVE == 32, "one 32-row MFMA strip per wave");
+
+    // ---- stationary weights ------------------------------------------------------------------
+    for (int i = tid; i < p.cout_p * p.cin_p; i += THREADS) {
+        const int co = i / p.cin_p, ci = i - co * p.cin_p;
+        Ws[co * p.ldk + ci] = (co < p.cout && ci < p.cin) ? p.w[(size_t)co * p.cin + ci] : 0.f;
+    }
+
+    double ssum[NT], ssq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { ssum[j] = 0.0; ssq[j] = 0.0; }
+
+    const long long ntiles = (p.rows + TILE_R - 1) / TILE_R;
+    const bool vec4 = (p.cin & 3) == 0;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long row0 = tile * TILE_R;
+        __syncthreads();                                // previous tile's fragments are consumed (and Ws is written)
+        // ---- stage the activation tile, BN + activation of the previous layer applied on load ---
+        if (vec4) {
+            const int c4n = p.cin >> 2;
+            for (int i = tid; i < TILE_R * c4n; i += THREADS) {
+                const int r = i / c4n, c4 = i - r * c4n;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row0 + r < p.rows) {
+                    v = *reinterpret_cast<const float4 *>(p.x + (size_t)(row0 + r) * p.cin + c4 * 4);
+                    if (p.in_coef) {
+                        const float4 m = *reinterpret_cast<const float4 *>(p.in_coef + c4 * 4);
+                        const float4 s = *reinterpret_cast<const float4 *>(p.in_coef + p.cin + c4 * 4);
+                        const float4 b = *reinterpret_cast<const float4 *>(p.in_coef + 2 * p.cin + c4 * 4);
+                        v.x = act_apply((v.x - m.x) * s.x + b.x, p.slope_in);
+                        v.y = act_apply((v.y - m.y) * s.y + b.y, p.slope_in);
+                        v.z = act_apply((v.z - m.z) * s.z + b.z, p.slope_in);
+                        v.w = act_apply((v.w - m.w) * s.w + b.w, p.slope_in);
+                    }
+                }
+                float *dst = As + r * p.ldk + c4 * 4;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+        } else {
+            for (int i = tid; i < TILE_R * p.cin_p; i += THREADS) {
+                const int r = i / p.cin_p, c = i - r * p.cin_p;
+                float v = 0.f;
+                if (row0 + r < p.rows && c < p.cin) {
+                    v = p.x[(size_t)(row0 + r) * p.cin + c];
+                    if (p.in_coef)
+                        v = act_apply((v - p.in_coef[c]) * p.in_coef[p.cin + c] + p.in_coef[2 * p.cin + c], p.slope_in);
+                }
+                As[r * p.ldk + c] = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- 32 x (32*NT) strip per wave on the matrix cores -----------------------------------
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        const float *arow = As + (wave * 32 + (lane & 31)) * p.ldk + (lane >> 5);
+        const float *brow = Ws + (lane & 31) * p.ldk + (lane >> 5);
+        for (int kk = 0; kk < p.cin_p; kk += 2) {
+            const float a = arow[kk];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float b = brow[(size_t)j * 32 * p.ldk + kk];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+            }
+        }
+
+        // ---- epilogue: store Y, accumulate per-channel statistics -------------------------------
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int ch = j * 32 + (lane & 31);
+            if (ch < p.cout) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long long r = row0 + wave * 32 + frag_row(e, lane);
+                    if (r < p.rows) {
+                        const float v = acc[j][e];
+                        p.y[(size_t)r * p.cout + ch] = v;
+                        ssum[j] += v; ssq[j] += (double)v * v;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- block reduction of the statistics, one atomic per channel per block --------------------
+    if (p.sums) {
+        __syncthreads();
+        double *red = reinterpret_cast<double *>(smem);          // [THREADS][2*NT] doubles (<= 32 KB)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { red[(size_t)tid * 2 * NT + j] = ssum[j]; red[(size_t)tid * 2 * NT + NT + j] = ssq[j]; }
+        __syncthreads();
+        for (int i = tid; i < 2 * NT * 32; i += THREADS) {       // i -> (which, j, col)
+            const int which = i / (NT * 32), rem = i - which * NT * 32, j = rem >> 5, col = rem & 31;
+            const int ch = j * 32 + col;
+            if (ch < p.cout) {
+                double a = 0.0;
+                for (int w = 0; w < 4; ++w)                      // lanes col and col+32 of every wave
+                    a += red[(size_t)(w * 64 + col) * 2 * NT + which * NT + j] +
+                         red[(size_t)(w * 64 + col + 32) * 2 * NT + which * NT + j];
+                atomicAdd(p.sums + (size_t)(blockIdx.x % REP) * 2 * p.cout + which * p.cout + ch, a);
+            }
+        }
+    }
+}
+
+// mean/scale/beta of a BN from its replica sums:  coef [3][c]
+__global__ void bn_finalize_kernel(long long rows, int c, const double *__restrict__ sums,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                   float *__restrict__ coef, float *__restrict__ mean_invstd) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < REP; ++r) { s += sums[(size_t)r * 2 * c + ch]; q += sums[(size_t)r * 2 * c + c + ch]; }
+    const double m = s / (double)rows;
+    double var = q / (double)rows - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    const float invstd = rsqrtf((float)var + eps);
+    coef[ch] = (float)m; coef[c + ch] = invstd * gamma[ch]; coef[2 * c + ch] = beta[ch];
+    if (mean_invstd) { mean_invstd[ch] = (float)m; mean_invstd[c + ch] = invstd; }
+}
+
+template <int NT>
+int launch_fwd(const LinFwdParams &p, hipStream_t st) {
+    constexpr int TILE_R = 128;
+    const size_t lds = ((size_t)p.cout_p + TILE_R) * p.ldk * sizeof(float);
+    const size_t red = (size_t)THREADS * 2 * NT * sizeof(double);
+    const size_t bytes = lds > red ? lds : red;
+    if (bytes > 160 * 1024) return I2P_ERR_BAD_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lin_fwd_kernel<TILE_R, NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const long long ntiles = (p.rows + TILE_R - 1) / TILE_R;
+    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);      // persistent: one block per CU
+    hipLaunchKernelGGL((lin_fwd_kernel<TILE_R, NT>), dim3(grid), dim3(THREADS), bytes, st, p);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+extern "C" int i2p_lin_fwd(long long rows, int cin, int cout, const float *x, const float *in_coef,
+                           float slope_in, const float *w, float *y, double *sums, void *stream) {
+    if (rows < 0 || cin <= 0 || cout <= 0 || cout > 256) return I2P_ERR_BAD_ARG;
+    if (rows == 0) return 0;
+    if (!x || !w || !y) return I2P_ERR_BAD_ARG;
+    LinFwdParams p;
+    p.rows = rows; p.cin = cin; p.cout = cout;
+    p.cin_p = (cin + 1) & ~1; p.cout_p = (cout + 31) & ~31; p.ldk = p.cin_p + 1;
+    p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.w = w; p.y = y; p.sums = sums;
+    hipStream_t st = (hipStream_t)stream;
+    switch (p.cout_p / 32) {
+        case 1: return launch_fwd<1>(p, st);
+        case 2: return launch_fwd<2>(p, st);
+        case 3: return launch_fwd<3>(p, st);
+        case 4: return launch_fwd<4>(p, st);
+        case 5: return launch_fwd<5>(p, st);
+        case 6: return launch_fwd<6>(p, st);
+        case 7: return launch_fwd<7>(p, st);
+        default: return launch_fwd<8>(p, st);
+    }
+}
+
+extern "C" int i2p_bn_finalize(long long rows, int c, const double *sums, const float *gamma,
+                               const float *beta, float eps, float *coef, float *mean_invstd, void *stream) {
+    if (rows <= 0 || c <= 0 || !sums || !gamma || !beta || !coef) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream, rows, c, sums, gamma,
+                       beta, eps, coef, mean_invstd);
+    I2P_RETURN_LAUNCH_STATUS();
+}

@@ -191,6 +191,30 @@ class CBackend:
                    self._p(dy, _F32, "dy"), self._p(dgamma, _F32, "dgamma"), self._p(dbeta, _F32, "dbeta"), stream=st)
         return dy, dgamma, dbeta
 
+    # ---- fused linear layers (csrc/mlp.hip) -----------------------------------------------------
+    def lin_forward(self, x, in_coef, slope_in, w, want_stats=True):
+        """x [rows,cin]; in_coef [3,cin] or None; w [cout,cin] -> (y [rows,cout], sums or None)."""
+        rows, cin = x.shape
+        cout = w.shape[0]
+        dev = x.device
+        y = torch.empty(rows, cout, dtype=_F32, device=dev)
+        sums = torch.zeros(BN_REPLICAS * 2 * cout, dtype=torch.float64, device=dev) if want_stats else None
+        self._call("i2p_lin_fwd", int(rows), int(cin), int(cout), self._p(x, _F32, "x"),
+                   self._p(in_coef, _F32, "in_coef") if in_coef is not None else None, float(slope_in),
+                   self._p(w, _F32, "w"), self._p(y, _F32, "y"),
+                   self._p(sums, torch.float64, "sums") if sums is not None else None, stream=self._stream())
+        return y, sums
+
+    def bn_finalize(self, rows, sums, gamma, beta, eps):
+        """-> (coef [3,c] = mean, invstd*gamma, beta ; mean_invstd [2c])"""
+        c = gamma.shape[0]
+        coef = torch.empty(3, c, dtype=_F32, device=gamma.device)
+        mean_invstd = torch.empty(2 * c, dtype=_F32, device=gamma.device)
+        self._call("i2p_bn_finalize", int(rows), int(c), self._p(sums, torch.float64, "sums"),
+                   self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(eps), self._p(coef, _F32, "coef"),
+                   self._p(mean_invstd, _F32, "mean_invstd"), stream=self._stream())
+        return coef, mean_invstd
+
 
 _hip = None
 _active = None

@@ -188,6 +188,26 @@ int i2p_bn_act_bwd(long long rows, int c, const float *dout, const float *y,
                    const float *mean_invstd, const float *gamma, const float *beta, float slope,
                    const double *dsums, float *dy, float *dgamma, float *dbeta, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused per-point linear layer (1x1 conv) — csrc/mlp.hip.  One reference `Conv2d` block is
+ * conv1x1 -> BN(batch stats) -> act (PPBackbone_center.py:34-46); a chain of them is executed
+ * as one kernel per layer that applies the PREVIOUS layer's BN + activation on load and
+ * accumulates its OWN output statistics:
+ *     y[r,:] = act_in((x[r,:] - mean_in) * scale_in + beta_in) . W^T ;  sums += {sum y, sum y^2}
+ *   x f32 [rows,cin]; in_coef f32 [3][cin] = {mean, invstd*gamma, beta} or NULL (x used as is);
+ *   slope_in: activation in front (1 = none); w f32 [cout,cin] (conv weight, bias dropped: it
+ *   cancels in the following batch-stat BN); y f32 [rows,cout]; sums replicated f64 (see
+ *   I2P_BN_REPLICAS) or NULL.  cout <= 256, (round32(cout)+128)*(cin+2)*4 B <= 160 KB of LDS,
+ *   else I2P_ERR_BAD_ARG (callers then use a library GEMM).
+ * --------------------------------------------------------------------------------------------- */
+int i2p_lin_fwd(long long rows, int cin, int cout, const float *x, const float *in_coef,
+                float slope_in, const float *w, float *y, double *sums, void *stream);
+
+/* coef f32 [3][c] = {mean, rsqrt(var+eps)*gamma, beta} (and mean_invstd f32 [2][c] if not NULL)
+ * from replicated sums of a [rows,c] tensor. */
+int i2p_bn_finalize(long long rows, int c, const double *sums, const float *gamma, const float *beta,
+                    float eps, float *coef, float *mean_invstd, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -243,3 +243,37 @@ def test_bn_act_parity(oracle_backend, hip_backend, rows, c, slope):
     assert bad.float().mean() < 1e-5, bad.float().mean()
     assert torch.allclose(hdg.cpu().double(), gd.grad, rtol=1e-3, atol=1e-2)
     assert torch.allclose(hdb.cpu().double(), bd.grad, rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("rows,cin,cout,with_bn", [(1000, 128, 128, True), (4133, 64, 64, True), (777, 10, 16, False),
+                                                   (5000, 35, 32, False), (2048, 128, 64, True), (300, 67, 128, False),
+                                                   (12800, 16, 32, True), (999, 131, 128, False), (640, 128, 256, True)])
+def test_lin_fwd_parity(oracle_backend, hip_backend, rows, cin, cout, with_bn):
+    """fused (BN+act on load) x W^T + output statistics: HIP MFMA kernel vs oracle (k-ordered fmaf
+    chain) and vs torch fp64.  Asymmetric W catches transposed fragments."""
+    g = torch.Generator().manual_seed(rows + cin)
+    x = torch.randn(rows, cin, generator=g) * 2 + 1
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5 + torch.arange(cout).view(-1, 1) * 0.01
+    coef = None
+    if with_bn:
+        coef = torch.stack([torch.randn(cin, generator=g), 0.5 + torch.rand(cin, generator=g),
+                            0.1 * torch.randn(cin, generator=g)]).contiguous()
+    ry, rs = oracle_backend.lin_forward(x, coef, 0.1, w)
+    hy, hs = hip_backend.lin_forward(x.to(DEV), None if coef is None else coef.to(DEV), 0.1, w.to(DEV))
+    scale = float(ry.abs().max())
+    assert float((ry - hy.cpu()).abs().max()) <= 2e-6 * scale + 1e-6
+    rsum = rs.view(32, 2, cout).sum(0); hsum = hs.cpu().view(32, 2, cout).sum(0)
+    assert torch.allclose(rsum, hsum, rtol=1e-6, atol=1e-4 * rows ** 0.5)
+    xd = x.double()
+    if with_bn:
+        z = (xd - coef[0].double()) * coef[1].double() + coef[2].double()
+        xd = torch.where(z > 0, z, z * 0.1)
+    yd = xd @ w.double().t()
+    assert float((yd - hy.cpu().double()).abs().max()) <= 1e-5 * float(yd.abs().max())
+    gam = 1 + 0.1 * torch.randn(cout, generator=g); bet = 0.1 * torch.randn(cout, generator=g)
+    rc, rmi = oracle_backend.bn_finalize(rows, rs, gam, bet, 1e-5)
+    hc, hmi = hip_backend.bn_finalize(rows, hs, gam.to(DEV), bet.to(DEV), 1e-5)
+    assert torch.allclose(rc, hc.cpu(), rtol=1e-5, atol=1e-6) and torch.allclose(rmi, hmi.cpu(), rtol=1e-5, atol=1e-6)
+    var, mean = torch.var_mean(yd, dim=0, unbiased=False)
+    assert torch.allclose(hc.cpu()[0].double(), mean, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(hc.cpu()[1].double(), torch.rsqrt(var + 1e-5) * gam.double(), rtol=1e-4)
