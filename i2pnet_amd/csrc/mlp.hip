@@ -41,8 +41,9 @@ struct LinFwdParams {
     const float *in_coef;   // [3][cin] mean, scale(=invstd*gamma), beta of the BN in front, or nullptr
     float slope_in;         // activation in front (1 = none)
     const float *w;         // [cout, cin]
-    float *y;               // [rows, cout]
-    double *sums;           // [REP][2*cout] (zeroed by caller) or nullptr
+    float *y;               // [rows, y_ld], this launch writes columns [ch_off, ch_off+cout)
+    double *sums;           // [REP][2*cout_total] (zeroed by caller) or nullptr
+    int y_ld, ch_off, cout_total;
 };
 
 // one 32x32 C/D fragment: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
                     const long long r = row0 + wave * 32 + frag_row(e, lane);
                     if (r < p.rows) {
                         const float v = acc[j][e];
-                        p.y[(size_t)r * p.cout + ch] = v;
+                        p.y[(size_t)r * p.y_ld + p.ch_off + ch] = v;
                         ssum[j] += v; ssq[j] += (double)v * v;
                     }
                 }
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
                 for (int w = 0; w < 4; ++w)                      // lanes col and col+32 of every wave
                     a += red[(size_t)(w * 64 + col) * 2 * NT + which * NT + j] +
                          red[(size_t)(w * 64 + col + 32) * 2 * NT + which * NT + j];
-                atomicAdd(p.sums + (size_t)(blockIdx.x % REP) * 2 * p.cout + which * p.cout + ch, a);
+                atomicAdd(p.sums + (size_t)(blockIdx.x % REP) * 2 * p.cout_total + which * p.cout_total + p.ch_off + ch, a);
             }
         }
     }
@@ -205,21 +206,32 @@ extern "C" int i2p_lin_fwd(long long rows, int cin, int cout, const float *x, co
     if (rows < 0 || cin <= 0 || cout <= 0 || cout > 256) return I2P_ERR_BAD_ARG;
     if (rows == 0) return 0;
     if (!x || !w || !y) return I2P_ERR_BAD_ARG;
-    LinFwdParams p;
-    p.rows = rows; p.cin = cin; p.cout = cout;
-    p.cin_p = (cin + 1) & ~1; p.cout_p = (cout + 31) & ~31; p.ldk = p.cin_p + 1;
-    p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.w = w; p.y = y; p.sums = sums;
     hipStream_t st = (hipStream_t)stream;
-    switch (p.cout_p / 32) {
-        case 1: return launch_fwd<1>(p, st);
-        case 2: return launch_fwd<2>(p, st);
-        case 3: return launch_fwd<3>(p, st);
-        case 4: return launch_fwd<4>(p, st);
-        case 5: return launch_fwd<5>(p, st);
-        case 6: return launch_fwd<6>(p, st);
-        case 7: return launch_fwd<7>(p, st);
-        default: return launch_fwd<8>(p, st);
+    // output channels are processed in slices whose weights fit the LDS next to a 128-row tile
+    const int cin_p = (cin + 1) & ~1, ldk = cin_p + 1;
+    int slice = (cout + 31) & ~31;
+    while (slice > 32 && ((size_t)slice + 128) * ldk * sizeof(float) > 160 * 1024) slice -= 32;
+    if (((size_t)slice + 128) * ldk * sizeof(float) > 160 * 1024) return I2P_ERR_BAD_ARG;
+    for (int off = 0; off < cout; off += slice) {
+        LinFwdParams p;
+        p.rows = rows; p.cin = cin; p.cout = (cout - off < slice) ? cout - off : slice;
+        p.cin_p = cin_p; p.cout_p = (p.cout + 31) & ~31; p.ldk = ldk;
+        p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.w = w + (size_t)off * cin; p.y = y; p.sums = sums;
+        p.y_ld = cout; p.ch_off = off; p.cout_total = cout;
+        int rc;
+        switch (p.cout_p / 32) {
+            case 1: rc = launch_fwd<1>(p, st); break;
+            case 2: rc = launch_fwd<2>(p, st); break;
+            case 3: rc = launch_fwd<3>(p, st); break;
+            case 4: rc = launch_fwd<4>(p, st); break;
+            case 5: rc = launch_fwd<5>(p, st); break;
+            case 6: rc = launch_fwd<6>(p, st); break;
+            case 7: rc = launch_fwd<7>(p, st); break;
+            default: rc = launch_fwd<8>(p, st); break;
+        }
+        if (rc) return rc;
     }
+    return 0;
 }
 
 extern "C" int i2p_bn_finalize(long long rows, int c, const double *sums, const float *gamma,

@@ -197,8 +197,9 @@ int i2p_bn_act_bwd(long long rows, int c, const float *dout, const float *y,
  *   x f32 [rows,cin]; in_coef f32 [3][cin] = {mean, invstd*gamma, beta} or NULL (x used as is);
  *   slope_in: activation in front (1 = none); w f32 [cout,cin] (conv weight, bias dropped: it
  *   cancels in the following batch-stat BN); y f32 [rows,cout]; sums replicated f64 (see
- *   I2P_BN_REPLICAS) or NULL.  cout <= 256, (round32(cout)+128)*(cin+2)*4 B <= 160 KB of LDS,
- *   else I2P_ERR_BAD_ARG (callers then use a library GEMM).
+ *   I2P_BN_REPLICAS) or NULL.  cout <= 256; output channels are processed in slices whose
+ *   weights fit the 160 KB LDS next to a 128-row tile; I2P_ERR_BAD_ARG if (32+128)*(cin+2)*4 B
+ *   does not fit (cin > ~250: callers then use a library GEMM).
  * --------------------------------------------------------------------------------------------- */
 int i2p_lin_fwd(long long rows, int cin, int cout, const float *x, const float *in_coef,
                 float slope_in, const float *w, float *y, double *sums, void *stream);

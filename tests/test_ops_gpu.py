@@ -241,8 +241,9 @@ def test_bn_act_parity(oracle_backend, hip_backend, rows, c, slope):
     # in fp64: allow a 1e-5 fraction of such elements
     bad = ~torch.isclose(hdy.cpu().double(), yd.grad, rtol=1e-3, atol=1e-4)
     assert bad.float().mean() < 1e-5, bad.float().mean()
-    assert torch.allclose(hdg.cpu().double(), gd.grad, rtol=1e-3, atol=1e-2)
-    assert torch.allclose(hdb.cpu().double(), bd.grad, rtol=1e-3, atol=1e-2)
+    # (one activation-branch flip moves a channel's dgamma/dbeta by |go * xhat| ~ a few units)
+    assert torch.allclose(hdg.cpu().double(), gd.grad, rtol=1e-3, atol=1e-2 + 1e-4 * rows)
+    assert torch.allclose(hdb.cpu().double(), bd.grad, rtol=1e-3, atol=1e-2 + 1e-4 * rows)
 
 
 @pytest.mark.parametrize("rows,cin,cout,with_bn", [(1000, 128, 128, True), (4133, 64, 64, True), (777, 10, 16, False),

@@ -48,6 +48,25 @@ def main():
         print(f"{'bn_act_bwd_stats':34s} {name:24s} {t:9.1f} {2 * nbytes / t / 1e3:9.0f}")
         t = timeit(lambda: _lib.call("i2p_bn_act_bwd", rows, c, P(go), P(y), P(mi), P(g), P(b), 0.1, P(sums), P(dy), P(dg), P(db), stream=st))
         print(f"{'bn_act_bwd':34s} {name:24s} {t:9.1f} {3 * nbytes / t / 1e3:9.0f}")
+    bench_lin(B)
+
+
+def bench_lin(B):
+    import torch.nn.functional as F
+    hip = ops.hip_backend()
+    dev = "cuda"
+    print(f"{'layer':34s} {'shape':24s} {'us':>9s} {'TFLOP/s':>9s} {'GB/s':>9s}")
+    for name, rows, cin, cout in [("cv1 128->128", B * 228 * 468, 128, 128), ("cv1 128->64", B * 228 * 468, 128, 64),
+                                  ("cv1 64->64", B * 228 * 468, 64, 64), ("L1 16->32", B * 3600 * 32, 16, 32),
+                                  ("L1 10->16", B * 3600 * 32, 10, 16), ("L2 35->32", B * 904 * 16, 35, 32),
+                                  ("L3 64->128", B * 228 * 16, 64, 128)]:
+        x = torch.randn(rows, cin, device=dev); w = torch.randn(cout, cin, device=dev) / cin ** 0.5
+        coef = torch.stack([torch.zeros(cin), torch.ones(cin), torch.zeros(cin)]).to(dev).contiguous()
+        t = timeit(lambda: hip.lin_forward(x, coef, 0.1, w))
+        fl = 2.0 * rows * cin * cout; by = rows * (cin + cout) * 4
+        print(f"{'lin_fwd (BN-on-load + stats)':34s} {name:24s} {t:9.1f} {fl / t / 1e6:9.1f} {by / t / 1e3:9.0f}")
+        t = timeit(lambda: F.linear(x, w))
+        print(f"{'torch F.linear (hipBLASLt)':34s} {name:24s} {t:9.1f} {fl / t / 1e6:9.1f} {by / t / 1e3:9.0f}")
 
 
 if __name__ == "__main__":
