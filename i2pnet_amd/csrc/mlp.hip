@@ -49,56 +49,97 @@ struct LinFwdParams {
 // one 32x32 C/D fragment: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// ---- activation-tile staging: global -> registers (issued early) -> transform -> LDS -------------
+// vec4 path (cin % 4 == 0, cin <= 128): 128 rows x cin/4 float4 chunks = <= 16 chunks per thread.
+constexpr int MAXCH = 16;
+
+struct StageGeom {
+    int c4n;        // float4 chunks per row
+    int nchunk;     // TILE_R * c4n
+    int shift;      // log2(c4n) if c4n is a power of two, else -1
+};
+
+__device__ __forceinline__ void chunk_rc(const StageGeom &g, int i, int &r, int &c4) {
+    if (g.shift >= 0) { r = i >> g.shift; c4 = i & (g.c4n - 1); }
+    else { r = i / g.c4n; c4 = i - r * g.c4n; }
+}
+
+template <int TILE_R>
+__device__ __forceinline__ void stage_fetch(const LinFwdParams &p, const StageGeom &g, long long row0, int tid,
+                                            float4 (&v)[MAXCH]) {
+#pragma unroll
+    for (int u = 0; u < MAXCH; ++u) {
+        const int i = tid + u * THREADS;
+        int r, c4; chunk_rc(g, i, r, c4);
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < g.nchunk && row0 + r < p.rows)
+            v[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)(row0 + r) * p.cin + c4 * 4);
+    }
+}
+
+template <int TILE_R>
+__device__ __forceinline__ void stage_commit(const LinFwdParams &p, const StageGeom &g, long long row0, int tid,
+                                             const float4 (&v)[MAXCH], float *As) {
+#pragma unroll
+    for (int u = 0; u < MAXCH; ++u) {
+        const int i = tid + u * THREADS;
+        if (i < g.nchunk) {
+            int r, c4; chunk_rc(g, i, r, c4);
+            float4 t = v[u];
+            if (p.in_coef && row0 + r < p.rows) {      // padding rows stay exactly 0 (they feed nothing)
+                const float4 m = *reinterpret_cast<const float4 *>(p.in_coef + c4 * 4);
+                const float4 s = *reinterpret_cast<const float4 *>(p.in_coef + p.cin + c4 * 4);
+                const float4 b = *reinterpret_cast<const float4 *>(p.in_coef + 2 * p.cin + c4 * 4);
+                t.x = act_apply((t.x - m.x) * s.x + b.x, p.slope_in);
+                t.y = act_apply((t.y - m.y) * s.y + b.y, p.slope_in);
+                t.z = act_apply((t.z - m.z) * s.z + b.z, p.slope_in);
+                t.w = act_apply((t.w - m.w) * s.w + b.w, p.slope_in);
+            }
+            float *dst = As + r * p.ldk + c4 * 4;
+            dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+        }
+    }
+}
+
 template <int TILE_R, int NT>
 __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
     extern __shared__ float smem[];
     float *Ws = smem;                                   // [cout_p][ldk]
     float *As = smem + (size_t)p.cout_p * p.ldk;        // [TILE_R][ldk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int ROWS_PER_WAVE = TILE_R / 4;           // 32
-    static_assert(ROWS_PER_WAVE == 32, "one 32-row MFMA strip per wave");
+    static_assert(TILE_R / 4 == 32, "one 32-row MFMA strip per wave");
 
     // ---- stationary weights ------------------------------------------------------------------
     for (int i = tid; i < p.cout_p * p.cin_p; i += THREADS) {
         const int co = i / p.cin_p, ci = i - co * p.cin_p;
         Ws[co * p.ldk + ci] = (co < p.cout && ci < p.cin) ? p.w[(size_t)co * p.cin + ci] : 0.f;
     }
+    if (p.cin_p != p.cin)                               // the zero K-padding column of the activation tile
+        for (int r = tid; r < TILE_R; r += THREADS) As[r * p.ldk + p.cin] = 0.f;
 
     double ssum[NT], ssq[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) { ssum[j] = 0.0; ssq[j] = 0.0; }
 
     const long long ntiles = (p.rows + TILE_R - 1) / TILE_R;
-    const bool vec4 = (p.cin & 3) == 0;
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool vec4 = (p.cin & 3) == 0 && (p.cin >> 2) * TILE_R <= MAXCH * THREADS;
+    StageGeom g;
+    g.c4n = p.cin >> 2; g.nchunk = TILE_R * g.c4n;
+    g.shift = (g.c4n > 0 && (g.c4n & (g.c4n - 1)) == 0) ? (31 - __clz(g.c4n)) : -1;
+
+    float4 pf[MAXCH];
+    long long tile = blockIdx.x;
+    if (vec4 && tile < ntiles) stage_fetch<TILE_R>(p, g, tile * TILE_R, tid, pf);
+    for (; tile < ntiles; tile += gridDim.x) {
         const long long row0 = tile * TILE_R;
         __syncthreads();                                // previous tile's fragments are consumed (and Ws is written)
-        // ---- stage the activation tile, BN + activation of the previous layer applied on load ---
         if (vec4) {
-            const int c4n = p.cin >> 2;
-            for (int i = tid; i < TILE_R * c4n; i += THREADS) {
-                const int r = i / c4n, c4 = i - r * c4n;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row0 + r < p.rows) {
-                    v = *reinterpret_cast<const float4 *>(p.x + (size_t)(row0 + r) * p.cin + c4 * 4);
-                    if (p.in_coef) {
-                        const float4 m = *reinterpret_cast<const float4 *>(p.in_coef + c4 * 4);
-                        const float4 s = *reinterpret_cast<const float4 *>(p.in_coef + p.cin + c4 * 4);
-                        const float4 b = *reinterpret_cast<const float4 *>(p.in_coef + 2 * p.cin + c4 * 4);
-                        v.x = act_apply((v.x - m.x) * s.x + b.x, p.slope_in);
-                        v.y = act_apply((v.y - m.y) * s.y + b.y, p.slope_in);
-                        v.z = act_apply((v.z - m.z) * s.z + b.z, p.slope_in);
-                        v.w = act_apply((v.w - m.w) * s.w + b.w, p.slope_in);
-                    }
-                }
-                float *dst = As + r * p.ldk + c4 * 4;
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-            }
-        } else {
-            for (int i = tid; i < TILE_R * p.cin_p; i += THREADS) {
-                const int r = i / p.cin_p, c = i - r * p.cin_p;
+            stage_commit<TILE_R>(p, g, row0, tid, pf, As);
+        } else {                                        // generic channel counts: scalar, no prefetch
+            for (int i = tid; i < TILE_R * p.cin; i += THREADS) {
+                const int r = i / p.cin, c = i - r * p.cin;
                 float v = 0.f;
-                if (row0 + r < p.rows && c < p.cin) {
+                if (row0 + r < p.rows) {
                     v = p.x[(size_t)(row0 + r) * p.cin + c];
                     if (p.in_coef)
                         v = act_apply((v - p.in_coef[c]) * p.in_coef[p.cin + c] + p.in_coef[2 * p.cin + c], p.slope_in);
@@ -107,6 +148,8 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
             }
         }
         __syncthreads();
+        // next tile's loads fly during this tile's MFMA loop
+        if (vec4 && tile + gridDim.x < ntiles) stage_fetch<TILE_R>(p, g, (tile + gridDim.x) * TILE_R, tid, pf);
 
         // ---- 32 x (32*NT) strip per wave on the matrix cores -----------------------------------
         f32x16 acc[NT];
@@ -116,6 +159,7 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
         const float *arow = As + (wave * 32 + (lane & 31)) * p.ldk + (lane >> 5);
         const float *brow = Ws + (lane & 31) * p.ldk + (lane >> 5);
+#pragma unroll 4
         for (int kk = 0; kk < p.cin_p; kk += 2) {
             const float a = arow[kk];
 #pragma unroll
