@@ -159,14 +159,27 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
         const float *arow = As + (wave * 32 + (lane & 31)) * p.ldk + (lane >> 5);
         const float *brow = Ws + (lane & 31) * p.ldk + (lane >> 5);
-#pragma unroll 4
-        for (int kk = 0; kk < p.cin_p; kk += 2) {
-            const float a = arow[kk];
+        // software-pipelined: the fragments of step k+1 are in flight while step k's MFMAs issue
+        // (hipcc otherwise emits ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per MFMA)
+        float a_cur = arow[0], b_cur[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float b = brow[(size_t)j * 32 * p.ldk + kk];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
-            }
+        for (int j = 0; j < NT; ++j) b_cur[j] = brow[(size_t)j * 32 * p.ldk];
+#pragma unroll 2
+        for (int kk = 0; kk < p.cin_p; kk += 2) {
+            const int kn = (kk + 2 < p.cin_p) ? kk + 2 : kk;
+            const float a_nxt = arow[kn];
+            float b_nxt[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b_nxt[j] = brow[(size_t)j * 32 * p.ldk + kn];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
+            // keep the order "issue next step's NT+1 LDS reads, then this step's NT MFMAs"
+            __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b_cur[j] = b_nxt[j];
         }
 
         // ---- epilogue: store Y, accumulate per-channel statistics -------------------------------
