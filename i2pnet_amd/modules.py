@@ -330,9 +330,18 @@ class CostVolume(nn.Module):
         per_point = F.linear(xyz, Wm[:, 0:3])                                   # [B,N,c1]
         per_pixel = F.linear(pix_xyz, Wm[:, 3:6])                               # [B,M,c1]
         if self.backward_validation:
-            valid = P.check_valid(xyz).unsqueeze(-1)                            # [B,N,1,1]  :408
-            masked = corr * valid + -1e10 * (1 - valid)                         # :410
-            respond = torch.max(masked, 1)[0]                                   # [B,M,C]    :412
+            # max over points of the masked correlation (:408-414) in closed form: for a fixed pixel
+            # channel g, max_n fl(f_n * g) = fl(g * max_n f_n) if g >= 0 else fl(g * min_n f_n)
+            # (rounding is monotone), taken over valid points; -1e10 if no point is valid.  Avoids
+            # three passes over the [B,N,M,C] tensor; the gradient still reaches the arg-max/min point.
+            valid = P.check_valid(xyz)                                          # [B,N,1]
+            f_max = torch.max(torch.where(valid > 0, pts_n, torch.full_like(pts_n, -float("inf"))), 1, keepdim=True)[0]
+            f_min = torch.min(torch.where(valid > 0, pts_n, torch.full_like(pts_n, float("inf"))), 1, keepdim=True)[0]
+            any_valid = (valid.sum(1, keepdim=True) > 0)
+            f_max = torch.where(any_valid, f_max, torch.zeros_like(f_max))      # no inf*0 in the backward
+            f_min = torch.where(any_valid, f_min, torch.zeros_like(f_min))
+            respond = torch.where(pix_n >= 0, pix_n * f_max, pix_n * f_min)     # [B,M,C]
+            respond = torch.where(any_valid, respond, torch.full_like(respond, -1e10))
             per_pixel = per_pixel + F.linear(respond, Wm[:, 6 + C:])
         y = y + per_point.unsqueeze(2) + per_pixel.unsqueeze(1)
         h = first.finish(y)
