@@ -31,6 +31,7 @@ SIGNATURES = {
     "i2p_bn_act_bwd": ["l", "i", "p", "p", "p", "p", "p", "f", "p", "p", "p", "p"],
     "i2p_lin_fwd": ["l", "i", "i", "p", "p", "f", "p", "p", "p"],
     "i2p_bn_finalize": ["l", "i", "p", "p", "p", "f", "p", "p"],
+    "i2p_lin_bwd": ["l", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 5,
 }
 
 _CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "p": C.c_void_p, "pp": C.c_void_p}

@@ -256,6 +256,283 @@ int launch_fwd(const LinFwdParams &p, hipStream_t st) {
     I2P_RETURN_LAUNCH_STATUS();
 }
 
+
+// =================================================================================================
+// Backward of one fused layer.
+//   g^y  = scale_out * (gz - m1 - xhat_out * m2)         BN backward of THIS layer, formed on load
+//          (or gz itself when out_coef == nullptr: the caller already holds dL/dy)
+//   x'   = act_in(bn_in(x))                               recomputed on load (never materialised)
+//   dW  += g^y^T . x'                                     wgrad  (per-block partial, reduced after)
+//   gz_in = (g^y . W) * act_in'(z_in)                     dgrad, continues into the previous BN
+//   in_dsums += { sum gz_in, sum gz_in * xhat_in }
+// Block-synchronous 64-row tiles: LDS holds W [cout_p][cin_p+1], G [64][cout_p+1], X' [64][cin_p+1].
+// =================================================================================================
+struct LinBwdParams {
+    long long rows;
+    int cin, cout, cin_p, cout_p;      // *_p rounded up to 32
+    int ldw, ldg, ldx;                 // LDS strides (cin_p+1, cout_p+1, cin_p+1)
+    const float *gz, *y, *out_coef, *out_mi;
+    const double *out_dsums;
+    const float *x, *in_coef, *in_mi;
+    float slope_in;
+    const float *w;
+    float *gz_in;
+    double *in_dsums;
+    float *dw_partial;
+};
+
+constexpr int BWD_R = 64;
+
+template <int NTI, int NTO>
+__global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
+    extern __shared__ float smem[];
+    float *Ws = smem;                                      // [cout_p][ldw]
+    float *Gs = Ws + (size_t)p.cout_p * p.ldw;             // [BWD_R][ldg]
+    float *Xs = Gs + (size_t)BWD_R * p.ldg;                // [BWD_R][ldx]
+    float *Co = Xs + (size_t)BWD_R * p.ldx;                // [5][cout_p]: m1, m2, scale, mean, invstd of the BN behind
+    float *Ci = Co + 5 * p.cout_p;                         // [4][cin_p]: mean, scale, beta, invstd of the BN in front
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int DT = 2 * NTI;                            // dgrad tiles per row tile pair
+    constexpr int DPW = (DT + 3) / 4;
+    constexpr int WT = NTO * NTI;
+    constexpr int WPW = (WT + 3) / 4;
+
+    for (int i = tid; i < p.cout_p * p.cin_p; i += THREADS) {
+        const int co = i / p.cin_p, ci = i - co * p.cin_p;
+        Ws[co * p.ldw + ci] = (co < p.cout && ci < p.cin) ? p.w[(size_t)co * p.cin + ci] : 0.f;
+    }
+    // per-channel constants once per block (the replica sums are 64 fp64 loads per channel)
+    for (int ch = tid; ch < p.cout; ch += THREADS) {
+        float m1 = 0.f, m2 = 0.f, sc = 1.f, mu = 0.f, is = 1.f;
+        if (p.out_coef) {
+            double sd = 0.0, sx = 0.0;
+            for (int rp = 0; rp < REP; ++rp) { sd += p.out_dsums[(size_t)rp * 2 * p.cout + ch]; sx += p.out_dsums[(size_t)rp * 2 * p.cout + p.cout + ch]; }
+            m1 = (float)(sd / (double)p.rows); m2 = (float)(sx / (double)p.rows);
+            sc = p.out_coef[p.cout + ch]; mu = p.out_mi[ch]; is = p.out_mi[p.cout + ch];
+        }
+        Co[ch] = m1; Co[p.cout_p + ch] = m2; Co[2 * p.cout_p + ch] = sc; Co[3 * p.cout_p + ch] = mu; Co[4 * p.cout_p + ch] = is;
+    }
+    for (int ch = tid; ch < p.cin; ch += THREADS) {
+        float mu = 0.f, sc = 1.f, be = 0.f, is = 1.f;
+        if (p.in_coef) { mu = p.in_coef[ch]; sc = p.in_coef[p.cin + ch]; be = p.in_coef[2 * p.cin + ch]; is = p.in_mi[p.cin + ch]; }
+        Ci[ch] = mu; Ci[p.cin_p + ch] = sc; Ci[2 * p.cin_p + ch] = be; Ci[3 * p.cin_p + ch] = is;
+    }
+    // zero the K-padding columns once (staging only writes logical columns)
+    for (int i = tid; i < BWD_R * (p.cout_p - p.cout); i += THREADS) {
+        const int r = i / (p.cout_p - p.cout), c = p.cout + i % (p.cout_p - p.cout);
+        Gs[r * p.ldg + c] = 0.f;
+    }
+    for (int i = tid; i < BWD_R * (p.cin_p - p.cin); i += THREADS) {
+        const int r = i / (p.cin_p - p.cin), c = p.cin + i % (p.cin_p - p.cin);
+        Xs[r * p.ldx + c] = 0.f;
+    }
+
+    f32x16 accw[WPW];
+#pragma unroll
+    for (int t = 0; t < WPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accw[t][e] = 0.f;
+    double dsum[DPW], dsxh[DPW];
+#pragma unroll
+    for (int t = 0; t < DPW; ++t) { dsum[t] = 0.0; dsxh[t] = 0.0; }
+
+    const long long ntiles = (p.rows + BWD_R - 1) / BWD_R;
+    const int co4 = p.cout >> 2, ci4 = p.cin >> 2;         // float4 chunks (channel counts are multiples of 4)
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long row0 = tile * BWD_R;
+        __syncthreads();
+        // ---- stage G = BN-backward(gz, y) --------------------------------------------------------
+        for (int i0 = tid; i0 < BWD_R * co4; i0 += THREADS * 4) {
+            float4 g[4], yv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * THREADS, r = i / co4, c4 = i - r * co4;
+                g[u] = make_float4(0.f, 0.f, 0.f, 0.f); yv[u] = g[u];
+                if (i < BWD_R * co4 && row0 + r < p.rows) {
+                    g[u] = *reinterpret_cast<const float4 *>(p.gz + (size_t)(row0 + r) * p.cout + c4 * 4);
+                    if (p.out_coef) yv[u] = *reinterpret_cast<const float4 *>(p.y + (size_t)(row0 + r) * p.cout + c4 * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * THREADS, r = i / co4, c4 = i - r * co4;
+                if (i < BWD_R * co4) {
+                    float gv[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+                    if (p.out_coef && row0 + r < p.rows) {
+                        const float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int ch = c4 * 4 + q;
+                            const float xh = (yy[q] - Co[3 * p.cout_p + ch]) * Co[4 * p.cout_p + ch];
+                            gv[q] = Co[2 * p.cout_p + ch] * (gv[q] - Co[ch] - xh * Co[p.cout_p + ch]);
+                        }
+                    }
+                    float *dst = Gs + r * p.ldg + c4 * 4;
+                    dst[0] = gv[0]; dst[1] = gv[1]; dst[2] = gv[2]; dst[3] = gv[3];
+                }
+            }
+        }
+        // ---- stage X' = act(bn(x)) ----------------------------------------------------------------
+        for (int i0 = tid; i0 < BWD_R * ci4; i0 += THREADS * 4) {
+            float4 xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * THREADS, r = i / ci4, c4 = i - r * ci4;
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < BWD_R * ci4 && row0 + r < p.rows)
+                    xv[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)(row0 + r) * p.cin + c4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * THREADS, r = i / ci4, c4 = i - r * ci4;
+                if (i < BWD_R * ci4) {
+                    float v[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+                    if (p.in_coef && row0 + r < p.rows) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int ch = c4 * 4 + q;
+                            v[q] = act_apply((v[q] - Ci[ch]) * Ci[p.cin_p + ch] + Ci[2 * p.cin_p + ch], p.slope_in);
+                        }
+                    }
+                    float *dst = Xs + r * p.ldx + c4 * 4;
+                    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- wgrad: accw[co tile][ci tile] += G^T . X'   (K = 64 rows) -----------------------------
+#pragma unroll
+        for (int t = 0; t < WPW; ++t) {
+            const int tw = wave + 4 * t;
+            if (tw < WT) {
+                const int to = tw / NTI, ti = tw - to * NTI;
+                const float *ap = Gs + (lane >> 5) * p.ldg + to * 32 + (lane & 31);
+                const float *bp = Xs + (lane >> 5) * p.ldx + ti * 32 + (lane & 31);
+                float a_cur = ap[0], b_cur = bp[0];
+#pragma unroll 4
+                for (int kk = 0; kk < BWD_R; kk += 2) {
+                    const int kn = kk + 2 < BWD_R ? kk + 2 : kk;
+                    const float a_nxt = ap[(size_t)kn * p.ldg], b_nxt = bp[(size_t)kn * p.ldx];
+                    accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur, accw[t], 0, 0, 0);
+                    a_cur = a_nxt; b_cur = b_nxt;
+                }
+            }
+        }
+        // ---- dgrad: (row tile, ci tile) = G . W   (K = cout) ---------------------------------------
+        if (p.gz_in) {
+#pragma unroll
+            for (int t = 0; t < DPW; ++t) {
+                const int td = wave + 4 * t;
+                if (td < DT) {
+                    const int rt = td / NTI, ti = td - rt * NTI;
+                    f32x16 acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                    const float *ap = Gs + (rt * 32 + (lane & 31)) * p.ldg + (lane >> 5);
+                    const float *bp = Ws + (lane >> 5) * p.ldw + ti * 32 + (lane & 31);
+                    float a_cur = ap[0], b_cur = bp[0];
+#pragma unroll 4
+                    for (int kk = 0; kk < p.cout_p; kk += 2) {
+                        const int kn = kk + 2 < p.cout_p ? kk + 2 : kk;
+                        const float a_nxt = ap[kn], b_nxt = bp[(size_t)kn * p.ldw];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur, acc, 0, 0, 0);
+                        a_cur = a_nxt; b_cur = b_nxt;
+                    }
+                    // epilogue: previous layer's activation derivative + BN-backward statistics
+                    const int ci = ti * 32 + (lane & 31);
+                    if (ci < p.cin) {
+                        float cm = 0.f, cs = 1.f, cb = 0.f, cinv = 1.f;
+                        if (p.in_coef) { cm = Ci[ci]; cs = Ci[p.cin_p + ci]; cb = Ci[2 * p.cin_p + ci]; cinv = Ci[3 * p.cin_p + ci]; }
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const long long r = row0 + rt * 32 + frag_row(e, lane);
+                            if (r < p.rows) {
+                                float gv = acc[e];
+                                if (p.in_coef) {
+                                    const float xr = p.x[(size_t)r * p.cin + ci];
+                                    const float z = (xr - cm) * cs + cb;
+                                    gv = z > 0.f ? gv : gv * p.slope_in;
+                                    const float xh = (xr - cm) * cinv;
+                                    dsum[t] += gv; dsxh[t] += (double)gv * xh;
+                                }
+                                p.gz_in[(size_t)r * p.cin + ci] = gv;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- statistics of gz_in: lanes l and l+32 own the same channel ---------------------------------
+    if (p.in_dsums && p.gz_in && p.in_coef) {
+#pragma unroll
+        for (int t = 0; t < DPW; ++t) {
+            const int td = wave + 4 * t;
+            double a = dsum[t] + __shfl_xor(dsum[t], 32);
+            double b = dsxh[t] + __shfl_xor(dsxh[t], 32);
+            if (td < DT && lane < 32) {
+                const int ti = td % NTI, ci = ti * 32 + lane;
+                if (ci < p.cin) {
+                    double *rep = p.in_dsums + (size_t)(blockIdx.x % REP) * 2 * p.cin;
+                    atomicAdd(rep + ci, a); atomicAdd(rep + p.cin + ci, b);
+                }
+            }
+        }
+    }
+    // ---- per-block wgrad partial ----------------------------------------------------------------------
+    float *part = p.dw_partial + (size_t)blockIdx.x * p.cout * p.cin;
+#pragma unroll
+    for (int t = 0; t < WPW; ++t) {
+        const int tw = wave + 4 * t;
+        if (tw < WT) {
+            const int to = tw / NTI, ti = tw - to * NTI;
+            const int ci = ti * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = to * 32 + frag_row(e, lane);
+                if (co < p.cout && ci < p.cin) part[(size_t)co * p.cin + ci] = accw[t][e];
+            }
+        }
+    }
+}
+
+__global__ void reduce_partials_kernel(int nparts, int n, const float *__restrict__ parts, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int b = 0; b < nparts; ++b) a += parts[(size_t)b * n + i];
+    out[i] = a;
+}
+
+template <int NTI, int NTO>
+int launch_bwd(LinBwdParams &p, float *dw, hipStream_t st, unsigned grid) {
+    const size_t bytes = ((size_t)p.cout_p * p.ldw + (size_t)BWD_R * p.ldg + (size_t)BWD_R * p.ldx + 5 * (size_t)p.cout_p + 4 * (size_t)p.cin_p) * sizeof(float);
+    if (bytes > 160 * 1024) return I2P_ERR_BAD_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lin_bwd_kernel<NTI, NTO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lin_bwd_kernel<NTI, NTO>), dim3(grid), dim3(THREADS), bytes, st, p);
+    const int n = p.cout * p.cin;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (int)grid, n, p.dw_partial, dw);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+template <int NTI>
+int dispatch_bwd_o(LinBwdParams &p, float *dw, hipStream_t st, unsigned grid) {
+    switch (p.cout_p / 32) {
+        case 1: return launch_bwd<NTI, 1>(p, dw, st, grid);
+        case 2: return launch_bwd<NTI, 2>(p, dw, st, grid);
+        case 3: return launch_bwd<NTI, 3>(p, dw, st, grid);
+        case 4: return launch_bwd<NTI, 4>(p, dw, st, grid);
+        default: return I2P_ERR_BAD_ARG;
+    }
+}
+
 }  // namespace
 
 extern "C" int i2p_lin_fwd(long long rows, int cin, int cout, const float *x, const float *in_coef,
@@ -297,4 +574,37 @@ extern "C" int i2p_bn_finalize(long long rows, int c, const double *sums, const 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream, rows, c, sums, gamma,
                        beta, eps, coef, mean_invstd);
     I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_lin_bwd_grid(long long rows) {
+    const long long ntiles = (rows + BWD_R - 1) / BWD_R;
+    return (int)(ntiles < 256 ? (ntiles < 1 ? 1 : ntiles) : 256);
+}
+
+extern "C" int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, const float *y,
+                           const float *out_coef, const float *out_mi, const double *out_dsums,
+                           const float *x, const float *in_coef, const float *in_mi, float slope_in,
+                           const float *w, float *gz_in, double *in_dsums, float *dw_partial, float *dw,
+                           void *stream) {
+    if (rows <= 0 || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3)) return I2P_ERR_BAD_ARG;
+    if (!gz || !x || !w || !dw_partial || !dw) return I2P_ERR_BAD_ARG;
+    if (out_coef && (!y || !out_mi || !out_dsums)) return I2P_ERR_BAD_ARG;
+    if (in_coef && !in_mi) return I2P_ERR_BAD_ARG;
+    LinBwdParams p;
+    p.rows = rows; p.cin = cin; p.cout = cout;
+    p.cin_p = (cin + 31) & ~31; p.cout_p = (cout + 31) & ~31;
+    p.ldw = p.cin_p + 1; p.ldg = p.cout_p + 1; p.ldx = p.cin_p + 1;
+    p.gz = gz; p.y = y; p.out_coef = out_coef; p.out_mi = out_mi; p.out_dsums = out_dsums;
+    p.x = x; p.in_coef = in_coef; p.in_mi = in_mi; p.slope_in = slope_in; p.w = w;
+    p.gz_in = gz_in; p.in_dsums = in_dsums; p.dw_partial = dw_partial;
+    const unsigned grid = (unsigned)i2p_lin_bwd_grid(rows);
+    hipStream_t st = (hipStream_t)stream;
+    switch (p.cin_p / 32) {
+        case 1: return dispatch_bwd_o<1>(p, dw, st, grid);
+        case 2: return dispatch_bwd_o<2>(p, dw, st, grid);
+        case 3: return dispatch_bwd_o<3>(p, dw, st, grid);
+        case 4: return dispatch_bwd_o<4>(p, dw, st, grid);
+        case 5: return dispatch_bwd_o<5>(p, dw, st, grid);
+        default: return I2P_ERR_BAD_ARG;
+    }
 }

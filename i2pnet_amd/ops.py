@@ -205,6 +205,25 @@ class CBackend:
                    self._p(sums, torch.float64, "sums") if sums is not None else None, stream=self._stream())
         return y, sums
 
+    def lin_backward(self, gz, y, out_coef, out_mi, out_dsums, x, in_coef, in_mi, slope_in, w, need_gx=True):
+        """-> (gz_in [rows,cin] or None, in_dsums or None, dw [cout,cin]); see i2p_lin_bwd."""
+        rows, cout = gz.shape
+        cin = x.shape[1]
+        dev = gz.device
+        gz_in = torch.empty(rows, cin, dtype=_F32, device=dev) if need_gx else None
+        in_dsums = (torch.zeros(BN_REPLICAS * 2 * cin, dtype=torch.float64, device=dev)
+                    if (need_gx and in_coef is not None) else None)
+        grid = 256 if self.device_type == "cuda" else 1
+        part = torch.empty(min(grid, (rows + 63) // 64) * cout * cin, dtype=_F32, device=dev)
+        dw = torch.empty(cout, cin, dtype=_F32, device=dev)
+        P = lambda t, dt=_F32, n="t": (self._p(t, dt, n) if t is not None else None)
+        self._call("i2p_lin_bwd", int(rows), int(cin), int(cout), P(gz, _F32, "gz"), P(y, _F32, "y"),
+                   P(out_coef, _F32, "out_coef"), P(out_mi, _F32, "out_mi"), P(out_dsums, torch.float64, "out_dsums"),
+                   P(x, _F32, "x"), P(in_coef, _F32, "in_coef"), P(in_mi, _F32, "in_mi"), float(slope_in),
+                   P(w, _F32, "w"), P(gz_in, _F32, "gz_in"), P(in_dsums, torch.float64, "in_dsums"),
+                   P(part, _F32, "dw_partial"), P(dw, _F32, "dw"), stream=self._stream())
+        return gz_in, in_dsums, dw
+
     def bn_finalize(self, rows, sums, gamma, beta, eps):
         """-> (coef [3,c] = mean, invstd*gamma, beta ; mean_invstd [2c])"""
         c = gamma.shape[0]

@@ -209,6 +209,21 @@ int i2p_lin_fwd(long long rows, int cin, int cout, const float *x, const float *
 int i2p_bn_finalize(long long rows, int c, const double *sums, const float *gamma, const float *beta,
                     float eps, float *coef, float *mean_invstd, void *stream);
 
+/* Backward of one fused layer (csrc/mlp.hip).  With z = BN(y), a = act(z) of THIS layer:
+ *   g^y   = scale_out*(gz - mean(gz) - xhat_out*mean(gz*xhat_out))   (or gz itself if out_coef NULL)
+ *   dw    = g^y^T . act_in(bn_in(x))                                   f32 [cout,cin], written
+ *   gz_in = (g^y . w) * act_in'(z_in)                                  f32 [rows,cin], written (skipped if NULL)
+ *   in_dsums += { sum gz_in, sum gz_in*xhat_in }                       replicated f64, zeroed by caller
+ * gz f32 [rows,cout]; y f32 [rows,cout]; out_coef [3][cout], out_mi [2][cout] (mean, invstd),
+ * out_dsums replicated {sum gz, sum gz*xhat_out}; x f32 [rows,cin] the previous pre-BN tensor with
+ * in_coef [3][cin], in_mi [2][cin] (or both NULL: x is the raw layer input, gz_in = dL/dx);
+ * dw_partial f32 scratch [i2p_lin_bwd_grid(rows)][cout*cin].  cin, cout multiples of 4, <= 160 / 128. */
+int i2p_lin_bwd_grid(long long rows);
+int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, const float *y,
+                const float *out_coef, const float *out_mi, const double *out_dsums, const float *x,
+                const float *in_coef, const float *in_mi, float slope_in, const float *w, float *gz_in,
+                double *in_dsums, float *dw_partial, float *dw, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
