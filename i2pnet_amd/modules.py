@@ -21,6 +21,21 @@ import torch.nn.functional as F
 
 from . import ops
 from . import projectpn as P
+from .fused import mlp_stack
+
+# run Conv2d stacks on the fused MFMA layer kernels (csrc/mlp.hip); False = library GEMM + BN kernels per block
+USE_FUSED_MLP = True
+
+
+def run_stack(x, convs, first_bn=None):
+    convs = list(convs)
+    if USE_FUSED_MLP:
+        return mlp_stack(x, convs, first_bn)
+    if first_bn is not None:
+        x = first_bn.finish(x)
+    for conv in convs:
+        x = conv(x)
+    return x
 
 _BN_EPS = 1e-5
 
@@ -194,8 +209,7 @@ class ProjectPointNet(nn.Module):
         return new_xyz_proj_raw, new_xyz_proj, grouped_xyz, grouped_xyz_norm, grouped_idx, sample_idx
 
     def _mlp_max(self, new_points, B):
-        for conv in self.mlp_convs:
-            new_points = conv(new_points)
+        new_points = run_stack(new_points, self.mlp_convs)
         return torch.max(new_points, dim=2)[0].view(B, self.out_h, self.out_w, -1)
 
     def forward(self, xyz_proj_raw, xyz_proj, feature_proj, sample_idx=None, cfg=None, raw_feat_point=False):
@@ -266,13 +280,11 @@ class ProjSetUpconvModule(nn.Module):
         else:
             xyz_diff = P.gather_torch(xyz2, *gidx[:3], B, self.H, self.W) - xyz1.reshape(B, N, 1, 3)
         upfeats = torch.cat([P.gather_torch(feat2, *gidx[:3], B, self.H, self.W), xyz_diff], dim=3)
-        for conv in self.mlp_conv:
-            upfeats = conv(upfeats)
+        upfeats = run_stack(upfeats, self.mlp_conv)
         feat1_new = torch.max(upfeats, dim=2)[0].view(B, self.out_h, self.out_w, -1)
         if feat1 is not None:
             feat1_new = torch.cat([feat1_new, feat1.reshape(B, self.out_h, self.out_w, -1)], dim=3)
-        for conv in self.mlp2_conv:
-            feat1_new = conv(feat1_new)
+        feat1_new = run_stack(feat1_new, self.mlp2_conv)
         return feat1_new.reshape(B, N, -1)
 
     def set_bn(self):
@@ -344,9 +356,7 @@ class CostVolume(nn.Module):
             respond = torch.where(any_valid, respond, torch.full_like(respond, -1e10))
             per_pixel = per_pixel + F.linear(respond, Wm[:, 6 + C:])
         y = y + per_point.unsqueeze(2) + per_pixel.unsqueeze(1)
-        h = first.finish(y)
-        for conv in list(self.mlp1_convs)[1:]:
-            h = conv(h)
+        h = run_stack(y, list(self.mlp1_convs)[1:], first_bn=first)
         We = self.pi_encoding.weight2d()
         enc = self.pi_encoding.finish(F.linear(xyz, We[:, 0:3]).unsqueeze(2) + F.linear(pix_xyz, We[:, 3:6]).unsqueeze(1))
         return h, enc
@@ -358,10 +368,8 @@ class CostVolume(nn.Module):
         q_xyz = P.index_points_group(pix_xyz, idx)                              # [B,N,K,3]
         q_feat = P.index_points_group(pix_n, idx)                               # [B,N,K,C]
         geo = torch.cat([xyz.unsqueeze(2).expand(-1, -1, K, -1), q_xyz], dim=3)
-        h = torch.cat([geo, pts_n.unsqueeze(2) * q_feat], dim=3)
-        for conv in self.mlp1_convs:
-            h = conv(h)
-        return h, self.pi_encoding(geo)
+        h = run_stack(torch.cat([geo, pts_n.unsqueeze(2) * q_feat], dim=3), self.mlp1_convs)
+        return h, run_stack(geo, [self.pi_encoding])
 
     def forward(self, xyz_proj_raw, warped_xyz, warped_points, idx_n2, f2_xyz, f2_points, lidar_z, cfg=None):
         """xyz_proj_raw [B,H,W,3]; warped_xyz [B,HW,3] (u,v,1); warped_points [B,HW,C];
@@ -376,9 +384,7 @@ class CostVolume(nn.Module):
             h3, enc = self._pi_knn(uv, xyz, pts_n, f2_xyz, pix_n)
         else:
             h3, enc = self._pi_all_pixels(xyz, pts_n, f2_xyz, pix_n)
-        logits = torch.cat([enc, h3], dim=3)                                    # :423
-        for conv in self.mlp2_convs:
-            logits = conv(logits)
+        logits = run_stack(torch.cat([enc, h3], dim=3), self.mlp2_convs)        # :423
         pi_feat = torch.sum(F.softmax(logits, dim=2) * h3, dim=2)               # [B,N,c]  :430-433
 
         # pc-stage
@@ -393,10 +399,9 @@ class CostVolume(nn.Module):
         own_xyz = xyz.unsqueeze(2).expand(-1, -1, K, -1)
         diff = nb_xyz - own_xyz
         euc = torch.sqrt(torch.sum(diff * diff, dim=3, keepdim=True) + 1e-20)   # :461
-        enc_pc = self.pc_encoding(torch.cat([own_xyz, nb_xyz, diff, euc], dim=3))
+        enc_pc = run_stack(torch.cat([own_xyz, nb_xyz, diff, euc], dim=3), [self.pc_encoding])
         w = torch.cat([enc_pc, warped_points.unsqueeze(2).expand(-1, -1, K, -1), nb_feat], dim=-1)
-        for conv in self.mlp2_convs_2:
-            w = conv(w)
+        w = run_stack(w, self.mlp2_convs_2)
         valid = gidx[-1]
         w = w * valid + -1e10 * (1 - valid)                                     # :481
         out = torch.sum(F.softmax(w, dim=2) * nb_feat, dim=2)
@@ -454,9 +459,7 @@ class FlowPredictor(nn.Module):
 
     def forward(self, points_f1, upsampled_feat, cost_volume):
         parts = [points_f1, cost_volume] + ([upsampled_feat] if upsampled_feat is not None else [])
-        x = torch.cat(parts, -1).unsqueeze(2)
-        for conv in self.mlp_conv:
-            x = conv(x)
+        x = run_stack(torch.cat(parts, -1).unsqueeze(2), self.mlp_conv)
         return x.squeeze(2)
 
     def set_bn(self):
