@@ -498,12 +498,22 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
     }
 }
 
-__global__ void reduce_partials_kernel(int nparts, int n, const float *__restrict__ parts, float *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// dW = sum over blocks of the per-block partials: 32 outputs x 8 partial-lanes per block
+__global__ __launch_bounds__(256) void reduce_partials_kernel(int nparts, int n, const float *__restrict__ parts,
+                                                               float *__restrict__ out) {
+    __shared__ float red[8][32];
+    const int o = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
     float a = 0.f;
-    for (int b = 0; b < nparts; ++b) a += parts[(size_t)b * n + i];
-    out[i] = a;
+    if (o < n)
+        for (int b = pl; b < nparts; b += 8) a += parts[(size_t)b * n + o];
+    red[pl][threadIdx.x & 31] = a;
+    __syncthreads();
+    if (pl == 0 && o < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][threadIdx.x & 31];
+        out[o] = t;
+    }
 }
 
 template <int NTI, int NTO>
@@ -518,7 +528,7 @@ int launch_bwd(LinBwdParams &p, float *dw, hipStream_t st, unsigned grid) {
     }
     hipLaunchKernelGGL((lin_bwd_kernel<NTI, NTO>), dim3(grid), dim3(THREADS), bytes, st, p);
     const int n = p.cout * p.cin;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (int)grid, n, p.dw_partial, dw);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, p.dw_partial, dw);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
