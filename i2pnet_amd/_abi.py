@@ -32,6 +32,8 @@ SIGNATURES = {
     "i2p_lin_fwd": ["l", "i", "i", "p", "p", "f", "p", "p", "p"],
     "i2p_bn_finalize": ["l", "i", "p", "p", "p", "f", "p", "p"],
     "i2p_lin_bwd": ["l", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 5,
+    "i2p_pair_lin_fwd": ["i"] * 5 + ["p"] * 7,
+    "i2p_pair_lin_bwd": ["i"] * 5 + ["p"] * 14,
 }
 
 _CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "p": C.c_void_p, "pp": C.c_void_p}

@@ -44,7 +44,20 @@ struct LinFwdParams {
     float *y;               // [rows, y_ld], this launch writes columns [ch_off, ch_off+cout)
     double *sums;           // [REP][2*cout_total] (zeroed by caller) or nullptr
     int y_ld, ch_off, cout_total;
+    // pair mode (cost volume, all point x pixel pairs): rows = (b, n, k) over B x N x M,
+    //   input row = pair_f[b,n,:] * x[b,k,:]   (x is then the [B,M,cin] pixel tensor)
+    //   y[r,:]   += bias_n[b,n,:] + bias_k[b,k,:]
+    const float *pair_f;    // [B,N,cin] or nullptr (plain mode)
+    const float *bias_n;    // [B,N,cout_total] or nullptr
+    const float *bias_k;    // [B,M,cout_total] or nullptr
+    int pair_N, pair_M;
 };
+
+__device__ __forceinline__ void pair_index(long long r, int N, int M, long long &bn, long long &bk) {
+    const long long b_n = r / M;                 // b*N + n
+    const int k = (int)(r - b_n * M);
+    bn = b_n; bk = (b_n / N) * M + k;            // b*M + k
+}
 
 // one 32x32 C/D fragment: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
@@ -72,8 +85,11 @@ __device__ __forceinline__ void stage_fetch(const LinFwdParams &p, const StageGe
         const int i = tid + u * THREADS;
         int r, c4; chunk_rc(g, i, r, c4);
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < g.nchunk && row0 + r < p.rows)
-            v[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)(row0 + r) * p.cin + c4 * 4);
+        if (i < g.nchunk && row0 + r < p.rows) {
+            long long src = row0 + r;
+            if (p.pair_f) { long long bn; pair_index(row0 + r, p.pair_N, p.pair_M, bn, src); }
+            v[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)src * p.cin + c4 * 4);
+        }
     }
 }
 
@@ -86,6 +102,11 @@ __device__ __forceinline__ void stage_commit(const LinFwdParams &p, const StageG
         if (i < g.nchunk) {
             int r, c4; chunk_rc(g, i, r, c4);
             float4 t = v[u];
+            if (p.pair_f && row0 + r < p.rows) {
+                long long bn, bk; pair_index(row0 + r, p.pair_N, p.pair_M, bn, bk);
+                const float4 f = *reinterpret_cast<const float4 *>(p.pair_f + (size_t)bn * p.cin + c4 * 4);
+                t.x *= f.x; t.y *= f.y; t.z *= f.z; t.w *= f.w;
+            }
             if (p.in_coef && row0 + r < p.rows) {      // padding rows stay exactly 0 (they feed nothing)
                 const float4 m = *reinterpret_cast<const float4 *>(p.in_coef + c4 * 4);
                 const float4 s = *reinterpret_cast<const float4 *>(p.in_coef + p.cin + c4 * 4);
@@ -191,7 +212,12 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
                 for (int e = 0; e < 16; ++e) {
                     const long long r = row0 + wave * 32 + frag_row(e, lane);
                     if (r < p.rows) {
-                        const float v = acc[j][e];
+                        float v = acc[j][e];
+                        if (p.bias_n) {
+                            long long bn, bk; pair_index(r, p.pair_N, p.pair_M, bn, bk);
+                            v = (v + p.bias_n[(size_t)bn * p.cout_total + p.ch_off + ch]) +
+                                p.bias_k[(size_t)bk * p.cout_total + p.ch_off + ch];
+                        }
                         p.y[(size_t)r * p.y_ld + p.ch_off + ch] = v;
                         ssum[j] += v; ssq[j] += (double)v * v;
                     }
@@ -279,6 +305,13 @@ struct LinBwdParams {
     float *gz_in;
     double *in_dsums;
     float *dw_partial;
+    // pair mode (first cost-volume layer): x' = pair_f[b,n,:] * pair_g[b,k,:]; instead of gz_in the
+    // dgrad result T = g^y . W is reduced on the fly into
+    //   d_f[b,n,:] += sum_k T * pair_g ,  d_g[b,k,:] += sum_n T * pair_f      (fp32 atomics, zeroed by caller)
+    // and the bias gradients  d_bn[b,n,:] += sum_k g^y ,  d_bk[b,k,:] += sum_n g^y.
+    const float *pair_f, *pair_g;
+    float *d_f, *d_g, *d_bn, *d_bk;
+    int pair_N, pair_M;
 };
 
 constexpr int BWD_R = 64;
@@ -367,6 +400,11 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
                             gv[q] = Co[2 * p.cout_p + ch] * (gv[q] - Co[ch] - xh * Co[p.cout_p + ch]);
                         }
                     }
+                    if (p.d_bk && row0 + r < p.rows) {
+                        long long bn, bk; pair_index(row0 + r, p.pair_N, p.pair_M, bn, bk);
+                        float *dk = p.d_bk + (size_t)bk * p.cout + c4 * 4;
+                        atomicAdd(dk + 0, gv[0]); atomicAdd(dk + 1, gv[1]); atomicAdd(dk + 2, gv[2]); atomicAdd(dk + 3, gv[3]);
+                    }
                     float *dst = Gs + r * p.ldg + c4 * 4;
                     dst[0] = gv[0]; dst[1] = gv[1]; dst[2] = gv[2]; dst[3] = gv[3];
                 }
@@ -379,8 +417,16 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * THREADS, r = i / ci4, c4 = i - r * ci4;
                 xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < BWD_R * ci4 && row0 + r < p.rows)
-                    xv[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)(row0 + r) * p.cin + c4 * 4);
+                if (i < BWD_R * ci4 && row0 + r < p.rows) {
+                    if (p.pair_f) {
+                        long long bn, bk; pair_index(row0 + r, p.pair_N, p.pair_M, bn, bk);
+                        const float4 f = *reinterpret_cast<const float4 *>(p.pair_f + (size_t)bn * p.cin + c4 * 4);
+                        const float4 gg = *reinterpret_cast<const float4 *>(p.pair_g + (size_t)bk * p.cin + c4 * 4);
+                        xv[u] = make_float4(f.x * gg.x, f.y * gg.y, f.z * gg.z, f.w * gg.w);
+                    } else {
+                        xv[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)(row0 + r) * p.cin + c4 * 4);
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -400,6 +446,19 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
             }
         }
         __syncthreads();
+        if (p.d_bn) {       // per-point bias gradient: column sums of G over the (at most two) points of this tile
+            for (int ch = tid; ch < p.cout; ch += THREADS) {
+                long long bn0 = row0 / p.pair_M;
+                const long long split = (bn0 + 1) * p.pair_M - row0;           // rows [0,split) belong to bn0
+                float s0 = 0.f, s1 = 0.f;
+                for (int r = 0; r < BWD_R; ++r) {
+                    const float gvv = Gs[r * p.ldg + ch];
+                    if (r < split) s0 += gvv; else s1 += gvv;
+                }
+                atomicAdd(p.d_bn + (size_t)bn0 * p.cout + ch, s0);
+                if (split < BWD_R && row0 + split < p.rows) atomicAdd(p.d_bn + (size_t)(bn0 + 1) * p.cout + ch, s1);
+            }
+        }
 
         // ---- wgrad: accw[co tile][ci tile] += G^T . X'   (K = 64 rows) -----------------------------
 #pragma unroll
@@ -420,7 +479,7 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
             }
         }
         // ---- dgrad: (row tile, ci tile) = G . W   (K = cout) ---------------------------------------
-        if (p.gz_in) {
+        if (p.gz_in || p.d_f) {
 #pragma unroll
             for (int t = 0; t < DPW; ++t) {
                 const int td = wave + 4 * t;
@@ -441,7 +500,27 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
                     }
                     // epilogue: previous layer's activation derivative + BN-backward statistics
                     const int ci = ti * 32 + (lane & 31);
-                    if (ci < p.cin) {
+                    if (p.d_f) {
+                        if (ci < p.cin) {
+                            long long cur_bn = -1; float run = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const long long r = row0 + rt * 32 + frag_row(e, lane);
+                                if (r < p.rows) {
+                                    long long bn, bk; pair_index(r, p.pair_N, p.pair_M, bn, bk);
+                                    const float tv = acc[e];
+                                    atomicAdd(p.d_g + (size_t)bk * p.cin + ci, tv * p.pair_f[(size_t)bn * p.cin + ci]);
+                                    const float contrib = tv * p.pair_g[(size_t)bk * p.cin + ci];
+                                    if (bn != cur_bn) {
+                                        if (cur_bn >= 0) atomicAdd(p.d_f + (size_t)cur_bn * p.cin + ci, run);
+                                        cur_bn = bn; run = 0.f;
+                                    }
+                                    run += contrib;
+                                }
+                            }
+                            if (cur_bn >= 0) atomicAdd(p.d_f + (size_t)cur_bn * p.cin + ci, run);
+                        }
+                    } else if (ci < p.cin) {
                         float cm = 0.f, cs = 1.f, cb = 0.f, cinv = 1.f;
                         if (p.in_coef) { cm = Ci[ci]; cs = Ci[p.cin_p + ci]; cb = Ci[2 * p.cin_p + ci]; cinv = Ci[3 * p.cin_p + ci]; }
 #pragma unroll
@@ -545,8 +624,9 @@ int dispatch_bwd_o(LinBwdParams &p, float *dw, hipStream_t st, unsigned grid) {
 
 }  // namespace
 
-extern "C" int i2p_lin_fwd(long long rows, int cin, int cout, const float *x, const float *in_coef,
-                           float slope_in, const float *w, float *y, double *sums, void *stream) {
+static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const float *in_coef, float slope_in,
+                        const float *w, float *y, double *sums, const float *pair_f, const float *bias_n,
+                        const float *bias_k, int pair_N, int pair_M, void *stream) {
     if (rows < 0 || cin <= 0 || cout <= 0 || cout > 256) return I2P_ERR_BAD_ARG;
     if (rows == 0) return 0;
     if (!x || !w || !y) return I2P_ERR_BAD_ARG;
@@ -562,6 +642,7 @@ extern "C" int i2p_lin_fwd(long long rows, int cin, int cout, const float *x, co
         p.cin_p = cin_p; p.cout_p = (p.cout + 31) & ~31; p.ldk = ldk;
         p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.w = w + (size_t)off * cin; p.y = y; p.sums = sums;
         p.y_ld = cout; p.ch_off = off; p.cout_total = cout;
+        p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
         int rc;
         switch (p.cout_p / 32) {
             case 1: rc = launch_fwd<1>(p, st); break;
@@ -578,6 +659,18 @@ extern "C" int i2p_lin_fwd(long long rows, int cin, int cout, const float *x, co
     return 0;
 }
 
+extern "C" int i2p_lin_fwd(long long rows, int cin, int cout, const float *x, const float *in_coef,
+                           float slope_in, const float *w, float *y, double *sums, void *stream) {
+    return lin_fwd_impl(rows, cin, cout, x, in_coef, slope_in, w, y, sums, nullptr, nullptr, nullptr, 1, 1, stream);
+}
+
+extern "C" int i2p_pair_lin_fwd(int B, int N, int M, int cin, int cout, const float *f, const float *g,
+                                const float *bias_n, const float *bias_k, const float *w, float *y, double *sums,
+                                void *stream) {
+    if (B <= 0 || N <= 0 || M <= 0 || (cin & 3) || cin > 128 || !f || !bias_n || !bias_k) return I2P_ERR_BAD_ARG;
+    return lin_fwd_impl((long long)B * N * M, cin, cout, g, nullptr, 1.0f, w, y, sums, f, bias_n, bias_k, N, M, stream);
+}
+
 extern "C" int i2p_bn_finalize(long long rows, int c, const double *sums, const float *gamma,
                                const float *beta, float eps, float *coef, float *mean_invstd, void *stream) {
     if (rows <= 0 || c <= 0 || !sums || !gamma || !beta || !coef) return I2P_ERR_BAD_ARG;
@@ -591,13 +684,15 @@ extern "C" int i2p_lin_bwd_grid(long long rows) {
     return (int)(ntiles < 256 ? (ntiles < 1 ? 1 : ntiles) : 256);
 }
 
-extern "C" int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, const float *y,
-                           const float *out_coef, const float *out_mi, const double *out_dsums,
-                           const float *x, const float *in_coef, const float *in_mi, float slope_in,
-                           const float *w, float *gz_in, double *in_dsums, float *dw_partial, float *dw,
-                           void *stream) {
+struct PairBwd { const float *f, *g; float *d_f, *d_g, *d_bn, *d_bk; int N, M; };
+
+static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, const float *y,
+                        const float *out_coef, const float *out_mi, const double *out_dsums,
+                        const float *x, const float *in_coef, const float *in_mi, float slope_in,
+                        const float *w, float *gz_in, double *in_dsums, float *dw_partial, float *dw,
+                        const PairBwd *pair, void *stream) {
     if (rows <= 0 || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3)) return I2P_ERR_BAD_ARG;
-    if (!gz || !x || !w || !dw_partial || !dw) return I2P_ERR_BAD_ARG;
+    if (!gz || (!x && !pair) || !w || !dw_partial || !dw) return I2P_ERR_BAD_ARG;
     if (out_coef && (!y || !out_mi || !out_dsums)) return I2P_ERR_BAD_ARG;
     if (in_coef && !in_mi) return I2P_ERR_BAD_ARG;
     LinBwdParams p;
@@ -607,6 +702,11 @@ extern "C" int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, c
     p.gz = gz; p.y = y; p.out_coef = out_coef; p.out_mi = out_mi; p.out_dsums = out_dsums;
     p.x = x; p.in_coef = in_coef; p.in_mi = in_mi; p.slope_in = slope_in; p.w = w;
     p.gz_in = gz_in; p.in_dsums = in_dsums; p.dw_partial = dw_partial;
+    p.pair_f = p.pair_g = nullptr; p.d_f = p.d_g = p.d_bn = p.d_bk = nullptr; p.pair_N = p.pair_M = 1;
+    if (pair) {
+        p.pair_f = pair->f; p.pair_g = pair->g; p.d_f = pair->d_f; p.d_g = pair->d_g; p.d_bn = pair->d_bn;
+        p.d_bk = pair->d_bk; p.pair_N = pair->N; p.pair_M = pair->M;
+    }
     const unsigned grid = (unsigned)i2p_lin_bwd_grid(rows);
     hipStream_t st = (hipStream_t)stream;
     switch (p.cin_p / 32) {
@@ -617,4 +717,23 @@ extern "C" int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, c
         case 5: return dispatch_bwd_o<5>(p, dw, st, grid);
         default: return I2P_ERR_BAD_ARG;
     }
+}
+
+extern "C" int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, const float *y,
+                           const float *out_coef, const float *out_mi, const double *out_dsums,
+                           const float *x, const float *in_coef, const float *in_mi, float slope_in,
+                           const float *w, float *gz_in, double *in_dsums, float *dw_partial, float *dw,
+                           void *stream) {
+    return lin_bwd_impl(rows, cin, cout, gz, y, out_coef, out_mi, out_dsums, x, in_coef, in_mi, slope_in, w, gz_in,
+                        in_dsums, dw_partial, dw, nullptr, stream);
+}
+
+extern "C" int i2p_pair_lin_bwd(int B, int N, int M, int cin, int cout, const float *gz, const float *y,
+                                const float *out_coef, const float *out_mi, const double *out_dsums,
+                                const float *f, const float *g, const float *w, float *d_f, float *d_g,
+                                float *d_bias_n, float *d_bias_k, float *dw_partial, float *dw, void *stream) {
+    if (B <= 0 || N <= 0 || M <= 0 || M < BWD_R || !f || !g || !d_f || !d_g || !d_bias_n || !d_bias_k) return I2P_ERR_BAD_ARG;
+    PairBwd pr; pr.f = f; pr.g = g; pr.d_f = d_f; pr.d_g = d_g; pr.d_bn = d_bias_n; pr.d_bk = d_bias_k; pr.N = N; pr.M = M;
+    return lin_bwd_impl((long long)B * N * M, cin, cout, gz, y, out_coef, out_mi, out_dsums, nullptr, nullptr, nullptr,
+                        1.0f, w, nullptr, nullptr, dw_partial, dw, &pr, stream);
 }

@@ -224,6 +224,38 @@ class CBackend:
                    P(part, _F32, "dw_partial"), P(dw, _F32, "dw"), stream=self._stream())
         return gz_in, in_dsums, dw
 
+    def pair_lin_forward(self, f, g, bias_n, bias_k, w):
+        """f [B,N,C], g [B,M,C], bias_n [B,N,Co], bias_k [B,M,Co], w [Co,C] -> y [B*N*M, Co], sums"""
+        B, N, C = f.shape
+        M = g.shape[1]
+        Co = w.shape[0]
+        y = torch.empty(B * N * M, Co, dtype=_F32, device=f.device)
+        sums = torch.zeros(BN_REPLICAS * 2 * Co, dtype=torch.float64, device=f.device)
+        self._call("i2p_pair_lin_fwd", int(B), int(N), int(M), int(C), int(Co), self._p(f, _F32, "f"),
+                   self._p(g, _F32, "g"), self._p(bias_n, _F32, "bias_n"), self._p(bias_k, _F32, "bias_k"),
+                   self._p(w, _F32, "w"), self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums"),
+                   stream=self._stream())
+        return y, sums
+
+    def pair_lin_backward(self, gy, f, g, w):
+        """gy = dL/dy [B*N*M, Co] -> (d_f, d_g, d_bias_n, d_bias_k, dw)"""
+        B, N, C = f.shape
+        M = g.shape[1]
+        Co = w.shape[0]
+        dev = f.device
+        d_f = torch.zeros(B, N, C, dtype=_F32, device=dev); d_g = torch.zeros(B, M, C, dtype=_F32, device=dev)
+        d_bn = torch.zeros(B, N, Co, dtype=_F32, device=dev); d_bk = torch.zeros(B, M, Co, dtype=_F32, device=dev)
+        rows = B * N * M
+        grid = 256 if self.device_type == "cuda" else 1
+        part = torch.empty(min(grid, (rows + 63) // 64) * Co * C, dtype=_F32, device=dev)
+        dw = torch.empty(Co, C, dtype=_F32, device=dev)
+        self._call("i2p_pair_lin_bwd", int(B), int(N), int(M), int(C), int(Co), self._p(gy, _F32, "gy"), None, None,
+                   None, None, self._p(f, _F32, "f"), self._p(g, _F32, "g"), self._p(w, _F32, "w"),
+                   self._p(d_f, _F32, "d_f"), self._p(d_g, _F32, "d_g"), self._p(d_bn, _F32, "d_bn"),
+                   self._p(d_bk, _F32, "d_bk"), self._p(part, _F32, "part"), self._p(dw, _F32, "dw"),
+                   stream=self._stream())
+        return d_f, d_g, d_bn, d_bk, dw
+
     def bn_finalize(self, rows, sums, gamma, beta, eps):
         """-> (coef [3,c] = mean, invstd*gamma, beta ; mean_invstd [2c])"""
         c = gamma.shape[0]

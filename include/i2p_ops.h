@@ -224,6 +224,26 @@ int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, const float 
                 const float *in_coef, const float *in_mi, float slope_in, const float *w, float *gz_in,
                 double *in_dsums, float *dw_partial, float *dw, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * First layer of the all-pixel cost volume (src/projectPN/PPBackbone_center.py:383-418): the
+ * reference builds [B,N,M,6+C(+C)] = cat(xyz_n, uv_k, norm(LF_n)*norm(RF_k) (, max-response_k))
+ * and runs a 1x1 conv on it.  Factored here as
+ *     y[b,n,k,:] = (f[b,n,:] * g[b,k,:]) . w^T + bias_n[b,n,:] + bias_k[b,k,:]
+ * (bias_n = w_xyz . xyz_n, bias_k = w_uv . uv_k + w_bv . response_k, computed by the caller on
+ * the small [B,N,*] / [B,M,*] tensors) so the [B,N,M,C] product is never materialised.
+ *   f f32 [B,N,cin], g f32 [B,M,cin], bias_n f32 [B,N,cout], bias_k f32 [B,M,cout],
+ *   w f32 [cout,cin]; y f32 [B*N*M, cout] (pre-BN), sums replicated f64 or NULL.
+ * Backward (g^y = dL/dy given directly when out_coef is NULL, else BN-backward on load):
+ *   dw [cout,cin] written; d_f, d_g, d_bias_n, d_bias_k accumulated with fp32 atomics (zeroed by caller).
+ * --------------------------------------------------------------------------------------------- */
+int i2p_pair_lin_fwd(int B, int N, int M, int cin, int cout, const float *f, const float *g,
+                     const float *bias_n, const float *bias_k, const float *w, float *y, double *sums,
+                     void *stream);
+int i2p_pair_lin_bwd(int B, int N, int M, int cin, int cout, const float *gz, const float *y,
+                     const float *out_coef, const float *out_mi, const double *out_dsums, const float *f,
+                     const float *g, const float *w, float *d_f, float *d_g, float *d_bias_n,
+                     float *d_bias_k, float *dw_partial, float *dw, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -346,3 +346,28 @@ def test_lin_bwd_parity(oracle_backend, hip_backend, rows, cin, cout, in_bn, out
         gx = hg.cpu().double()
     bad = ~torch.isclose(gx, xd.grad, rtol=2e-3, atol=2e-4 * float(xd.grad.abs().max()))
     assert bad.float().mean() < 1e-4, bad.float().mean()
+
+
+@pytest.mark.parametrize("B,N,M,C,Co", [(2, 57, 80, 128, 128), (1, 228, 468, 128, 128), (3, 10, 70, 64, 32)])
+def test_pair_lin_parity(oracle_backend, hip_backend, B, N, M, C, Co):
+    """factored first cost-volume layer (bilinear point x pixel product on MFMA): HIP vs oracle and
+    vs the materialised torch formulation in fp64 (forward and all five gradients)."""
+    g_ = torch.Generator().manual_seed(B * N + M)
+    f = torch.randn(B, N, C, generator=g_); g = torch.randn(B, M, C, generator=g_)
+    bn = torch.randn(B, N, Co, generator=g_); bk = torch.randn(B, M, Co, generator=g_)
+    w = torch.randn(Co, C, generator=g_) / C ** 0.5 + torch.arange(Co).view(-1, 1) * 0.002
+    ry, rs = oracle_backend.pair_lin_forward(f, g, bn, bk, w)
+    hy, hs = hip_backend.pair_lin_forward(f.to(DEV), g.to(DEV), bn.to(DEV), bk.to(DEV), w.to(DEV))
+    assert float((ry - hy.cpu()).abs().max()) <= 3e-6 * float(ry.abs().max()) + 1e-6
+    assert torch.allclose(rs.view(32, 2, Co).sum(0), hs.cpu().view(32, 2, Co).sum(0), rtol=1e-6, atol=1e-3)
+    fd, gd, bnd, bkd, wd = [t.double().requires_grad_(True) for t in (f, g, bn, bk, w)]
+    yd = torch.einsum("bnc,bkc,oc->bnko", fd, gd, wd) + bnd[:, :, None] + bkd[:, None]
+    assert float((yd.reshape(-1, Co) - hy.cpu().double()).abs().max()) <= 1e-5 * float(yd.abs().max())
+    gy = torch.randn(B * N * M, Co, generator=g_)
+    yd.backward(gy.view(B, N, M, Co).double())
+    r = oracle_backend.pair_lin_backward(gy, f, g, w)
+    h = hip_backend.pair_lin_backward(gy.to(DEV), f.to(DEV), g.to(DEV), w.to(DEV))
+    for name, rr, hh, ref in zip(["d_f", "d_g", "d_bn", "d_bk", "dw"], r, h, [fd.grad, gd.grad, bnd.grad, bkd.grad, wd.grad]):
+        sc = float(ref.abs().max())
+        assert float((rr - hh.cpu()).abs().max()) <= 3e-4 * sc, name
+        assert float((hh.cpu().double() - ref).abs().max()) <= 3e-4 * sc, name
