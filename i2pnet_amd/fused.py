@@ -143,6 +143,31 @@ def _bn_bwd_from_gz(be, gz, y, mi, gamma, beta, dsums):
     return dy, dg, db
 
 
+class _PairLinear(Function):
+    """y[b,n,k,:] = (f[b,n,:]*g[b,k,:]) . W^T + bias_n[b,n,:] + bias_k[b,k,:]  ->  [B*N*M, Co] (pre-BN)."""
+
+    @staticmethod
+    def forward(ctx, f, g, bias_n, bias_k, W):
+        f, g, bias_n, bias_k, W = [t.contiguous() for t in (f, g, bias_n, bias_k, W)]
+        y, _ = ops.get_backend().pair_lin_forward(f.detach(), g.detach(), bias_n.detach(), bias_k.detach(), W.detach())
+        ctx.save_for_backward(f, g, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        f, g, W = ctx.saved_tensors
+        d_f, d_g, d_bn, d_bk, dw = ops.get_backend().pair_lin_backward(gy.contiguous(), f, g, W)
+        return d_f, d_g, d_bn, d_bk, dw
+
+
+def pair_linear(f, g, bias_n, bias_k, W):
+    return _PairLinear.apply(f, g, bias_n, bias_k, W)
+
+
+def pair_fits(cin, cout):
+    return cin % 4 == 0 and cin <= 128 and layer_fits(cin, cout)
+
+
 def _slope(conv):
     return conv.negative_slope if conv.activation_fn else 1.0
 

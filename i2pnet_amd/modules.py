@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import ops
 from . import projectpn as P
-from .fused import mlp_stack
+from .fused import mlp_stack, pair_fits, pair_linear
 
 # run Conv2d stacks on the fused MFMA layer kernels (csrc/mlp.hip); False = library GEMM + BN kernels per block
 USE_FUSED_MLP = True
@@ -337,8 +337,6 @@ class CostVolume(nn.Module):
         C = self.feat_channels
         first = self.mlp1_convs[0]
         Wm = first.weight2d()
-        corr = pts_n.unsqueeze(2) * pix_n.unsqueeze(1)                          # [B,N,M,C]  :395
-        y = F.linear(corr, Wm[:, 6:6 + C])
         per_point = F.linear(xyz, Wm[:, 0:3])                                   # [B,N,c1]
         per_pixel = F.linear(pix_xyz, Wm[:, 3:6])                               # [B,M,c1]
         if self.backward_validation:
@@ -355,7 +353,13 @@ class CostVolume(nn.Module):
             respond = torch.where(pix_n >= 0, pix_n * f_max, pix_n * f_min)     # [B,M,C]
             respond = torch.where(any_valid, respond, torch.full_like(respond, -1e10))
             per_pixel = per_pixel + F.linear(respond, Wm[:, 6 + C:])
-        y = y + per_point.unsqueeze(2) + per_pixel.unsqueeze(1)
+        B_, N_ = pts_n.shape[0], pts_n.shape[1]
+        if USE_FUSED_MLP and pair_fits(C, first.out_channels) and pix_n.shape[1] >= 64:
+            # bilinear term on the matrix cores straight from the [B,N,C] / [B,M,C] factors
+            y = pair_linear(pts_n, pix_n, per_point, per_pixel, Wm[:, 6:6 + C]).view(B_, N_, pix_n.shape[1], -1)
+        else:
+            corr = pts_n.unsqueeze(2) * pix_n.unsqueeze(1)                      # [B,N,M,C]  :395
+            y = F.linear(corr, Wm[:, 6:6 + C]) + per_point.unsqueeze(2) + per_pixel.unsqueeze(1)
         h = run_stack(y, list(self.mlp1_convs)[1:], first_bn=first)
         We = self.pi_encoding.weight2d()
         enc = self.pi_encoding.finish(F.linear(xyz, We[:, 0:3]).unsqueeze(2) + F.linear(pix_xyz, We[:, 3:6]).unsqueeze(1))
