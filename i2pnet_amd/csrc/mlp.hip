@@ -53,10 +53,20 @@ struct LinFwdParams {
     int pair_N, pair_M;
 };
 
-__device__ __forceinline__ void pair_index(long long r, int N, int M, long long &bn, long long &bk) {
-    const long long b_n = r / M;                 // b*N + n
-    const int k = (int)(r - b_n * M);
-    bn = b_n; bk = (b_n / N) * M + k;            // b*M + k
+// (b,n,k) bookkeeping of pair mode without per-element 64-bit divisions: one division pair per
+// TILE (row0 is block-uniform), then rows inside the tile walk forward by wrap-around.
+struct PairTile { int bn0, k0, b0, n0; };
+__device__ __forceinline__ PairTile pair_tile(long long row0, int N, int M) {
+    PairTile t;
+    t.bn0 = (int)(row0 / M); t.k0 = (int)(row0 - (long long)t.bn0 * M);
+    t.b0 = t.bn0 / N; t.n0 = t.bn0 - t.b0 * N;
+    return t;
+}
+__device__ __forceinline__ void pair_row(const PairTile &t, int d, int N, int M, int &bn, int &bk) {
+    int k = t.k0 + d, n = t.n0, b = t.b0;
+    bn = t.bn0;
+    while (k >= M) { k -= M; ++bn; if (++n == N) { n = 0; ++b; } }
+    bk = b * M + k;
 }
 
 // one 32x32 C/D fragment: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -80,6 +90,8 @@ __device__ __forceinline__ void chunk_rc(const StageGeom &g, int i, int &r, int 
 template <int TILE_R>
 __device__ __forceinline__ void stage_fetch(const LinFwdParams &p, const StageGeom &g, long long row0, int tid,
                                             float4 (&v)[MAXCH]) {
+    PairTile pt; pt.bn0 = pt.k0 = pt.b0 = pt.n0 = 0;
+    if (p.pair_f) pt = pair_tile(row0, p.pair_N, p.pair_M);
 #pragma unroll
     for (int u = 0; u < MAXCH; ++u) {
         const int i = tid + u * THREADS;
@@ -87,7 +99,7 @@ __device__ __forceinline__ void stage_fetch(const LinFwdParams &p, const StageGe
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < g.nchunk && row0 + r < p.rows) {
             long long src = row0 + r;
-            if (p.pair_f) { long long bn; pair_index(row0 + r, p.pair_N, p.pair_M, bn, src); }
+            if (p.pair_f) { int bn, bk; pair_row(pt, r, p.pair_N, p.pair_M, bn, bk); src = bk; }
             v[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)src * p.cin + c4 * 4);
         }
     }
@@ -96,6 +108,8 @@ __device__ __forceinline__ void stage_fetch(const LinFwdParams &p, const StageGe
 template <int TILE_R>
 __device__ __forceinline__ void stage_commit(const LinFwdParams &p, const StageGeom &g, long long row0, int tid,
                                              const float4 (&v)[MAXCH], float *As) {
+    PairTile pt; pt.bn0 = pt.k0 = pt.b0 = pt.n0 = 0;
+    if (p.pair_f) pt = pair_tile(row0, p.pair_N, p.pair_M);
 #pragma unroll
     for (int u = 0; u < MAXCH; ++u) {
         const int i = tid + u * THREADS;
@@ -103,7 +117,7 @@ __device__ __forceinline__ void stage_commit(const LinFwdParams &p, const StageG
             int r, c4; chunk_rc(g, i, r, c4);
             float4 t = v[u];
             if (p.pair_f && row0 + r < p.rows) {
-                long long bn, bk; pair_index(row0 + r, p.pair_N, p.pair_M, bn, bk);
+                int bn, bk; pair_row(pt, r, p.pair_N, p.pair_M, bn, bk);
                 const float4 f = *reinterpret_cast<const float4 *>(p.pair_f + (size_t)bn * p.cin + c4 * 4);
                 t.x *= f.x; t.y *= f.y; t.z *= f.z; t.w *= f.w;
             }
@@ -204,6 +218,8 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
         }
 
         // ---- epilogue: store Y, accumulate per-channel statistics -------------------------------
+        PairTile ept; ept.bn0 = ept.k0 = ept.b0 = ept.n0 = 0;
+        if (p.bias_n) ept = pair_tile(row0, p.pair_N, p.pair_M);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int ch = j * 32 + (lane & 31);
@@ -214,7 +230,7 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
                     if (r < p.rows) {
                         float v = acc[j][e];
                         if (p.bias_n) {
-                            long long bn, bk; pair_index(r, p.pair_N, p.pair_M, bn, bk);
+                            int bn, bk; pair_row(ept, wave * 32 + frag_row(e, lane), p.pair_N, p.pair_M, bn, bk);
                             v = (v + p.bias_n[(size_t)bn * p.cout_total + p.ch_off + ch]) +
                                 p.bias_k[(size_t)bk * p.cout_total + p.ch_off + ch];
                         }
@@ -373,6 +389,8 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
     const int co4 = p.cout >> 2, ci4 = p.cin >> 2;         // float4 chunks (channel counts are multiples of 4)
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long row0 = tile * BWD_R;
+        PairTile bpt; bpt.bn0 = bpt.k0 = bpt.b0 = bpt.n0 = 0;
+        if (p.pair_f) bpt = pair_tile(row0, p.pair_N, p.pair_M);
         __syncthreads();
         // ---- stage G = BN-backward(gz, y) --------------------------------------------------------
         for (int i0 = tid; i0 < BWD_R * co4; i0 += THREADS * 4) {
@@ -401,7 +419,7 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
                         }
                     }
                     if (p.d_bk && row0 + r < p.rows) {
-                        long long bn, bk; pair_index(row0 + r, p.pair_N, p.pair_M, bn, bk);
+                        int bn, bk; pair_row(bpt, r, p.pair_N, p.pair_M, bn, bk);
                         float *dk = p.d_bk + (size_t)bk * p.cout + c4 * 4;
                         atomicAdd(dk + 0, gv[0]); atomicAdd(dk + 1, gv[1]); atomicAdd(dk + 2, gv[2]); atomicAdd(dk + 3, gv[3]);
                     }
@@ -419,7 +437,7 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
                 xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (i < BWD_R * ci4 && row0 + r < p.rows) {
                     if (p.pair_f) {
-                        long long bn, bk; pair_index(row0 + r, p.pair_N, p.pair_M, bn, bk);
+                        int bn, bk; pair_row(bpt, r, p.pair_N, p.pair_M, bn, bk);
                         const float4 f = *reinterpret_cast<const float4 *>(p.pair_f + (size_t)bn * p.cin + c4 * 4);
                         const float4 gg = *reinterpret_cast<const float4 *>(p.pair_g + (size_t)bk * p.cin + c4 * 4);
                         xv[u] = make_float4(f.x * gg.x, f.y * gg.y, f.z * gg.z, f.w * gg.w);
@@ -448,8 +466,8 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
         __syncthreads();
         if (p.d_bn) {       // per-point bias gradient: column sums of G over the (at most two) points of this tile
             for (int ch = tid; ch < p.cout; ch += THREADS) {
-                long long bn0 = row0 / p.pair_M;
-                const long long split = (bn0 + 1) * p.pair_M - row0;           // rows [0,split) belong to bn0
+                const long long bn0 = bpt.bn0;
+                const long long split = p.pair_M - bpt.k0;                      // rows [0,split) belong to bn0
                 float s0 = 0.f, s1 = 0.f;
                 for (int r = 0; r < BWD_R; ++r) {
                     const float gvv = Gs[r * p.ldg + ch];
@@ -502,12 +520,12 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
                     const int ci = ti * 32 + (lane & 31);
                     if (p.d_f) {
                         if (ci < p.cin) {
-                            long long cur_bn = -1; float run = 0.f;
+                            int cur_bn = -1; float run = 0.f;
 #pragma unroll
                             for (int e = 0; e < 16; ++e) {
                                 const long long r = row0 + rt * 32 + frag_row(e, lane);
                                 if (r < p.rows) {
-                                    long long bn, bk; pair_index(r, p.pair_N, p.pair_M, bn, bk);
+                                    int bn, bk; pair_row(bpt, rt * 32 + frag_row(e, lane), p.pair_N, p.pair_M, bn, bk);
                                     const float tv = acc[e];
                                     atomicAdd(p.d_g + (size_t)bk * p.cin + ci, tv * p.pair_f[(size_t)bn * p.cin + ci]);
                                     const float contrib = tv * p.pair_g[(size_t)bk * p.cin + ci];

@@ -49,6 +49,7 @@ def main():
         t = timeit(lambda: _lib.call("i2p_bn_act_bwd", rows, c, P(go), P(y), P(mi), P(g), P(b), 0.1, P(sums), P(dy), P(dg), P(db), stream=st))
         print(f"{'bn_act_bwd':34s} {name:24s} {t:9.1f} {3 * nbytes / t / 1e3:9.0f}")
     bench_lin(B)
+    bench_pair(B)
 
 
 def bench_lin(B):
@@ -67,6 +68,25 @@ def bench_lin(B):
         print(f"{'lin_fwd (BN-on-load + stats)':34s} {name:24s} {t:9.1f} {fl / t / 1e6:9.1f} {by / t / 1e3:9.0f}")
         t = timeit(lambda: F.linear(x, w))
         print(f"{'torch F.linear (hipBLASLt)':34s} {name:24s} {t:9.1f} {fl / t / 1e6:9.1f} {by / t / 1e3:9.0f}")
+
+
+def bench_pair(B):
+    hip = ops.hip_backend(); dev = "cuda"
+    N, M, C = 228, 468, 128
+    f = torch.randn(B, N, C, device=dev); g = torch.randn(B, M, C, device=dev)
+    bn = torch.randn(B, N, C, device=dev); bk = torch.randn(B, M, C, device=dev); w = torch.randn(C, C, device=dev) / 11
+    t = timeit(lambda: hip.pair_lin_forward(f, g, bn, bk, w))
+    fl = 2.0 * B * N * M * C * C
+    print(f"{'pair_lin_fwd (cv1 layer 1)':34s} {'B*228*468 x 128->128':24s} {t:9.1f} {fl / t / 1e6:9.1f}")
+    gy = torch.randn(B * N * M, C, device=dev)
+    t = timeit(lambda: hip.pair_lin_backward(gy, f, g, w))
+    print(f"{'pair_lin_bwd (cv1 layer 1)':34s} {'B*228*468 x 128->128':24s} {t:9.1f} {2 * fl / t / 1e6:9.1f}")
+    import torch.nn.functional as F
+    def torch_path():
+        corr = f.unsqueeze(2) * g.unsqueeze(1)
+        return F.linear(corr, w) + bn.unsqueeze(2) + bk.unsqueeze(1)
+    t = timeit(torch_path)
+    print(f"{'torch: mul + F.linear + 2 adds':34s} {'(forward only)':24s} {t:9.1f} {fl / t / 1e6:9.1f}")
 
 
 if __name__ == "__main__":
