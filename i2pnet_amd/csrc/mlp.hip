@@ -22,6 +22,7 @@
 // tiles staged through LDS with the BN/activation transform applied on the way in, 4 waves x
 // (32 rows x Cout) accumulators.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -47,6 +48,7 @@ struct LinFwdParams {
     // pair mode (cost volume, all point x pixel pairs): rows = (b, n, k) over B x N x M,
     //   input row = pair_f[b,n,:] * x[b,k,:]   (x is then the [B,M,cin] pixel tensor)
     //   y[r,:]   += bias_n[b,n,:] + bias_k[b,k,:]
+    int ablate;             // diagnostic only (I2P_LIN_ABLATE): 1 no MFMA loop, 2 no stores, 4 no stats, 8 no staging
     const float *pair_f;    // [B,N,cin] or nullptr (plain mode)
     const float *bias_n;    // [B,N,cout_total] or nullptr
     const float *bias_k;    // [B,M,cout_total] or nullptr
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
         const long long row0 = tile * TILE_R;
         __syncthreads();                                // previous tile's fragments are consumed (and Ws is written)
         if (vec4) {
-            stage_commit<TILE_R>(p, g, row0, tid, pf, As);
+            if (!(p.ablate & 8)) stage_commit<TILE_R>(p, g, row0, tid, pf, As);
         } else {                                        // generic channel counts: scalar, no prefetch
             for (int i = tid; i < TILE_R * p.cin; i += THREADS) {
                 const int r = i / p.cin, c = i - r * p.cin;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
         }
         __syncthreads();
         // next tile's loads fly during this tile's MFMA loop
-        if (vec4 && tile + gridDim.x < ntiles) stage_fetch<TILE_R>(p, g, (tile + gridDim.x) * TILE_R, tid, pf);
+        if (vec4 && tile + gridDim.x < ntiles && !(p.ablate & 8)) stage_fetch<TILE_R>(p, g, (tile + gridDim.x) * TILE_R, tid, pf);
 
         // ---- 32 x (32*NT) strip per wave on the matrix cores -----------------------------------
         f32x16 acc[NT];
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) b_cur[j] = brow[(size_t)j * 32 * p.ldk];
 #pragma unroll 2
-        for (int kk = 0; kk < p.cin_p; kk += 2) {
+        for (int kk = 0; kk < ((p.ablate & 1) ? 2 : p.cin_p); kk += 2) {
             const int kn = (kk + 2 < p.cin_p) ? kk + 2 : kk;
             const float a_nxt = arow[kn];
             float b_nxt[NT];
@@ -234,8 +236,8 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
                             v = (v + p.bias_n[(size_t)bn * p.cout_total + p.ch_off + ch]) +
                                 p.bias_k[(size_t)bk * p.cout_total + p.ch_off + ch];
                         }
-                        p.y[(size_t)r * p.y_ld + p.ch_off + ch] = v;
-                        ssum[j] += v; ssq[j] += (double)v * v;
+                        if (!(p.ablate & 2)) p.y[(size_t)r * p.y_ld + p.ch_off + ch] = v;
+                        if (!(p.ablate & 4)) { ssum[j] += v; ssq[j] += (double)v * v; }
                     }
                 }
             }
@@ -661,6 +663,7 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
         p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.w = w + (size_t)off * cin; p.y = y; p.sums = sums;
         p.y_ld = cout; p.ch_off = off; p.cout_total = cout;
         p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
+        { const char *ab = getenv("I2P_LIN_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
         int rc;
         switch (p.cout_p / 32) {
             case 1: rc = launch_fwd<1>(p, st); break;
