@@ -597,6 +597,245 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
     }
 }
 
+// =================================================================================================
+// Backward of the factored first cost-volume layer (pair mode), re-tiled for its reductions.
+// A block owns one 64-pixel tile of one sample and a chunk of the points; it walks the points n
+// with the pixel tile fixed, so the per-pixel sums (d_g, d_bias_k) accumulate in registers across
+// the walk and the per-point sums (d_f, d_bias_n) are column sums of one tile:
+//   grid = B x ceil(M/64) x NC,   atomics per block: 2*64*C at the end + 2*C per point.
+// =================================================================================================
+struct PairBwdParams {
+    int B, N, M, NC, NL;               // NC point chunks of NL points
+    int cin, cout, cin_p, cout_p, ldw, ldg, ldx;
+    long long rows;
+    const float *gz, *y, *out_coef, *out_mi;
+    const double *out_dsums;
+    const float *f, *g, *w;
+    float *d_f, *d_g, *d_bn, *d_bk, *dw_partial;
+};
+
+template <int NTI, int NTO>
+__global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
+    extern __shared__ float smem[];
+    float *Ws = smem;
+    float *Gs = Ws + (size_t)p.cout_p * p.ldw;
+    float *Xs = Gs + (size_t)BWD_R * p.ldg;
+    float *Co = Xs + (size_t)BWD_R * p.ldx;                // [5][cout_p]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int DT = 2 * NTI, DPW = (DT + 3) / 4, WT = NTO * NTI, WPW = (WT + 3) / 4;
+    constexpr int GCH = (BWD_R * NTO * 8 + THREADS - 1) / THREADS;    // G chunks (float4) per thread, cout = 32*NTO max
+    constexpr int XCH = (BWD_R * NTI * 8 + THREADS - 1) / THREADS;
+
+    const int KT = (p.M + BWD_R - 1) / BWD_R;
+    int bid = blockIdx.x;
+    const int nc = bid % p.NC; bid /= p.NC;
+    const int kt = bid % KT; const int b = bid / KT;
+    const int k0 = kt * BWD_R;
+    const int n_begin = nc * p.NL, n_end = min(p.N, n_begin + p.NL);
+    const int co4 = p.cout >> 2, ci4 = p.cin >> 2;
+
+    for (int i = tid; i < p.cout_p * p.cin_p; i += THREADS) {
+        const int co = i / p.cin_p, ci = i - co * p.cin_p;
+        Ws[co * p.ldw + ci] = (co < p.cout && ci < p.cin) ? p.w[(size_t)co * p.cin + ci] : 0.f;
+    }
+    for (int ch = tid; ch < p.cout; ch += THREADS) {
+        float m1 = 0.f, m2 = 0.f, sc = 1.f, mu = 0.f, is = 1.f;
+        if (p.out_coef) {
+            double sd = 0.0, sx = 0.0;
+            for (int rp = 0; rp < REP; ++rp) { sd += p.out_dsums[(size_t)rp * 2 * p.cout + ch]; sx += p.out_dsums[(size_t)rp * 2 * p.cout + p.cout + ch]; }
+            m1 = (float)(sd / (double)p.rows); m2 = (float)(sx / (double)p.rows);
+            sc = p.out_coef[p.cout + ch]; mu = p.out_mi[ch]; is = p.out_mi[p.cout + ch];
+        }
+        Co[ch] = m1; Co[p.cout_p + ch] = m2; Co[2 * p.cout_p + ch] = sc; Co[3 * p.cout_p + ch] = mu; Co[4 * p.cout_p + ch] = is;
+    }
+    for (int i = tid; i < BWD_R * (p.cout_p - p.cout); i += THREADS) {
+        const int r = i / (p.cout_p - p.cout), c = p.cout + i % (p.cout_p - p.cout);
+        Gs[r * p.ldg + c] = 0.f;
+    }
+    for (int i = tid; i < BWD_R * (p.cin_p - p.cin); i += THREADS) {
+        const int r = i / (p.cin_p - p.cin), c = p.cin + i % (p.cin_p - p.cin);
+        Xs[r * p.ldx + c] = 0.f;
+    }
+
+    // pixel-tile operands that do not change along the walk: this thread's g chunks (staging layout)
+    // and this lane's g values in the dgrad fragment layout
+    float4 gk_chunk[XCH];
+#pragma unroll
+    for (int u = 0; u < XCH; ++u) {
+        const int i = tid + u * THREADS, r = i / ci4, c4 = i - r * ci4;
+        gk_chunk[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < BWD_R * ci4 && k0 + r < p.M)
+            gk_chunk[u] = *reinterpret_cast<const float4 *>(p.g + ((size_t)b * p.M + k0 + r) * p.cin + c4 * 4);
+    }
+    float gk_frag[DPW][16];
+#pragma unroll
+    for (int t = 0; t < DPW; ++t) {
+        const int td = wave + 4 * t, rt = td / NTI, ti = td - rt * NTI, ci = ti * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = rt * 32 + frag_row(e, lane);
+            gk_frag[t][e] = (td < DT && ci < p.cin && k0 + r < p.M) ? p.g[((size_t)b * p.M + k0 + r) * p.cin + ci] : 0.f;
+        }
+    }
+
+    f32x16 accw[WPW];
+#pragma unroll
+    for (int t = 0; t < WPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accw[t][e] = 0.f;
+    float dg_acc[DPW][16];
+#pragma unroll
+    for (int t = 0; t < DPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dg_acc[t][e] = 0.f;
+    float4 dbk_acc[GCH];
+#pragma unroll
+    for (int u = 0; u < GCH; ++u) dbk_acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int n = n_begin; n < n_end; ++n) {
+        const size_t bn = (size_t)b * p.N + n;
+        const size_t rbase = bn * p.M + k0;                // global row of tile row 0
+        __syncthreads();
+        // ---- stage G (BN-backward on load), accumulate the per-pixel bias gradient -------------------
+        {
+            float4 gq[GCH], yq[GCH];
+#pragma unroll
+            for (int u = 0; u < GCH; ++u) {
+                const int i = tid + u * THREADS, r = i / co4, c4 = i - r * co4;
+                gq[u] = make_float4(0.f, 0.f, 0.f, 0.f); yq[u] = gq[u];
+                if (i < BWD_R * co4 && k0 + r < p.M) {
+                    gq[u] = *reinterpret_cast<const float4 *>(p.gz + (rbase + r) * p.cout + c4 * 4);
+                    if (p.out_coef) yq[u] = *reinterpret_cast<const float4 *>(p.y + (rbase + r) * p.cout + c4 * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GCH; ++u) {
+                const int i = tid + u * THREADS, r = i / co4, c4 = i - r * co4;
+                if (i < BWD_R * co4) {
+                    float gv[4] = {gq[u].x, gq[u].y, gq[u].z, gq[u].w};
+                    if (p.out_coef && k0 + r < p.M) {
+                        const float yy[4] = {yq[u].x, yq[u].y, yq[u].z, yq[u].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int ch = c4 * 4 + q;
+                            const float xh = (yy[q] - Co[3 * p.cout_p + ch]) * Co[4 * p.cout_p + ch];
+                            gv[q] = Co[2 * p.cout_p + ch] * (gv[q] - Co[ch] - xh * Co[p.cout_p + ch]);
+                        }
+                    }
+                    dbk_acc[u].x += gv[0]; dbk_acc[u].y += gv[1]; dbk_acc[u].z += gv[2]; dbk_acc[u].w += gv[3];
+                    float *dst = Gs + r * p.ldg + c4 * 4;
+                    dst[0] = gv[0]; dst[1] = gv[1]; dst[2] = gv[2]; dst[3] = gv[3];
+                }
+            }
+        }
+        // ---- stage X' = f[b,n,:] * g[b,k,:] ----------------------------------------------------------
+#pragma unroll
+        for (int u = 0; u < XCH; ++u) {
+            const int i = tid + u * THREADS, r = i / ci4, c4 = i - r * ci4;
+            if (i < BWD_R * ci4) {
+                const float4 fv = *reinterpret_cast<const float4 *>(p.f + bn * p.cin + c4 * 4);
+                float *dst = Xs + r * p.ldx + c4 * 4;
+                dst[0] = fv.x * gk_chunk[u].x; dst[1] = fv.y * gk_chunk[u].y; dst[2] = fv.z * gk_chunk[u].z; dst[3] = fv.w * gk_chunk[u].w;
+            }
+        }
+        __syncthreads();
+        // ---- per-point bias gradient: column sums of G ------------------------------------------------
+        for (int ch = tid; ch < p.cout; ch += THREADS) {
+            float s0 = 0.f;
+            for (int r = 0; r < BWD_R; ++r) s0 += Gs[r * p.ldg + ch];
+            atomicAdd(p.d_bn + bn * p.cout + ch, s0);
+        }
+        // ---- wgrad --------------------------------------------------------------------------------------
+#pragma unroll
+        for (int t = 0; t < WPW; ++t) {
+            const int tw = wave + 4 * t;
+            if (tw < WT) {
+                const int to = tw / NTI, ti = tw - to * NTI;
+                const float *ap = Gs + (lane >> 5) * p.ldg + to * 32 + (lane & 31);
+                const float *bp = Xs + (lane >> 5) * p.ldx + ti * 32 + (lane & 31);
+                float a_cur = ap[0], b_cur = bp[0];
+#pragma unroll 4
+                for (int kk = 0; kk < BWD_R; kk += 2) {
+                    const int kn = kk + 2 < BWD_R ? kk + 2 : kk;
+                    const float a_nxt = ap[(size_t)kn * p.ldg], b_nxt = bp[(size_t)kn * p.ldx];
+                    accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur, accw[t], 0, 0, 0);
+                    a_cur = a_nxt; b_cur = b_nxt;
+                }
+            }
+        }
+        // ---- dgrad T = G . W, folded into d_g (registers) and d_f (column sums -> atomics) -----------------
+#pragma unroll
+        for (int t = 0; t < DPW; ++t) {
+            const int td = wave + 4 * t;
+            if (td < DT) {
+                const int rt = td / NTI, ti = td - rt * NTI;
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                const float *ap = Gs + (rt * 32 + (lane & 31)) * p.ldg + (lane >> 5);
+                const float *bp = Ws + (lane >> 5) * p.ldw + ti * 32 + (lane & 31);
+                float a_cur = ap[0], b_cur = bp[0];
+#pragma unroll 4
+                for (int kk = 0; kk < p.cout_p; kk += 2) {
+                    const int kn = kk + 2 < p.cout_p ? kk + 2 : kk;
+                    const float a_nxt = ap[kn], b_nxt = bp[(size_t)kn * p.ldw];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur, acc, 0, 0, 0);
+                    a_cur = a_nxt; b_cur = b_nxt;
+                }
+                const int ci = ti * 32 + (lane & 31);
+                if (ci < p.cin) {
+                    const float fv = p.f[bn * p.cin + ci];
+                    float colsum = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {           // rows beyond M hold G = 0 => T = 0
+                        dg_acc[t][e] += acc[e] * fv;
+                        colsum += acc[e] * gk_frag[t][e];
+                    }
+                    colsum += __shfl_xor(colsum, 32);
+                    if (lane < 32) atomicAdd(p.d_f + bn * p.cin + ci, colsum);
+                }
+            }
+        }
+    }
+
+    // ---- flush the per-pixel accumulators ------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < DPW; ++t) {
+        const int td = wave + 4 * t;
+        if (td < DT) {
+            const int rt = td / NTI, ti = td - rt * NTI, ci = ti * 32 + (lane & 31);
+            if (ci < p.cin)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = rt * 32 + frag_row(e, lane);
+                    if (k0 + r < p.M) atomicAdd(p.d_g + ((size_t)b * p.M + k0 + r) * p.cin + ci, dg_acc[t][e]);
+                }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < GCH; ++u) {
+        const int i = tid + u * THREADS, r = i / co4, c4 = i - r * co4;
+        if (i < BWD_R * co4 && k0 + r < p.M) {
+            float *dk = p.d_bk + ((size_t)b * p.M + k0 + r) * p.cout + c4 * 4;
+            atomicAdd(dk + 0, dbk_acc[u].x); atomicAdd(dk + 1, dbk_acc[u].y); atomicAdd(dk + 2, dbk_acc[u].z); atomicAdd(dk + 3, dbk_acc[u].w);
+        }
+    }
+    float *part = p.dw_partial + (size_t)blockIdx.x * p.cout * p.cin;
+#pragma unroll
+    for (int t = 0; t < WPW; ++t) {
+        const int tw = wave + 4 * t;
+        if (tw < WT) {
+            const int to = tw / NTI, ti = tw - to * NTI;
+            const int ci = ti * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = to * 32 + frag_row(e, lane);
+                if (co < p.cout && ci < p.cin) part[(size_t)co * p.cin + ci] = accw[t][e];
+            }
+        }
+    }
+}
+
 // dW = sum over blocks of the per-block partials: 32 outputs x 8 partial-lanes per block
 __global__ __launch_bounds__(256) void reduce_partials_kernel(int nparts, int n, const float *__restrict__ parts,
                                                                float *__restrict__ out) {
@@ -749,12 +988,52 @@ extern "C" int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, c
                         in_dsums, dw_partial, dw, nullptr, stream);
 }
 
+extern "C" int i2p_pair_lin_bwd_grid(int B, int N, int M) {
+    const int KT = (M + BWD_R - 1) / BWD_R;
+    int NC = 256 / (B * KT > 0 ? B * KT : 1);
+    NC = NC < 1 ? 1 : (NC > N ? N : NC);
+    return B * KT * NC;
+}
+
+template <int NTI, int NTO>
+static int launch_pair_bwd(PairBwdParams &p, float *dw, hipStream_t st, unsigned grid) {
+    const size_t bytes = ((size_t)p.cout_p * p.ldw + (size_t)BWD_R * p.ldg + (size_t)BWD_R * p.ldx + 5 * (size_t)p.cout_p) * sizeof(float);
+    if (bytes > 160 * 1024) return I2P_ERR_BAD_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pair_bwd_kernel<NTI, NTO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((pair_bwd_kernel<NTI, NTO>), dim3(grid), dim3(THREADS), bytes, st, p);
+    const int n = p.cout * p.cin;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, p.dw_partial, dw);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int i2p_pair_lin_bwd(int B, int N, int M, int cin, int cout, const float *gz, const float *y,
                                 const float *out_coef, const float *out_mi, const double *out_dsums,
                                 const float *f, const float *g, const float *w, float *d_f, float *d_g,
                                 float *d_bias_n, float *d_bias_k, float *dw_partial, float *dw, void *stream) {
-    if (B <= 0 || N <= 0 || M <= 0 || M < BWD_R || !f || !g || !d_f || !d_g || !d_bias_n || !d_bias_k) return I2P_ERR_BAD_ARG;
-    PairBwd pr; pr.f = f; pr.g = g; pr.d_f = d_f; pr.d_g = d_g; pr.d_bn = d_bias_n; pr.d_bk = d_bias_k; pr.N = N; pr.M = M;
-    return lin_bwd_impl((long long)B * N * M, cin, cout, gz, y, out_coef, out_mi, out_dsums, nullptr, nullptr, nullptr,
-                        1.0f, w, nullptr, nullptr, dw_partial, dw, &pr, stream);
+    if (B <= 0 || N <= 0 || M <= 0 || (cin & 3) || (cout & 3) || cin > 128 || cout > 128) return I2P_ERR_BAD_ARG;
+    if (!gz || !f || !g || !w || !d_f || !d_g || !d_bias_n || !d_bias_k || !dw_partial || !dw) return I2P_ERR_BAD_ARG;
+    if (out_coef && (!y || !out_mi || !out_dsums)) return I2P_ERR_BAD_ARG;
+    PairBwdParams p;
+    p.B = B; p.N = N; p.M = M;
+    const int KT = (M + BWD_R - 1) / BWD_R;
+    const unsigned grid = (unsigned)i2p_pair_lin_bwd_grid(B, N, M);
+    p.NC = (int)grid / (B * KT); p.NL = (N + p.NC - 1) / p.NC;
+    p.cin = cin; p.cout = cout; p.cin_p = (cin + 31) & ~31; p.cout_p = (cout + 31) & ~31;
+    p.ldw = p.cin_p + 1; p.ldg = p.cout_p + 1; p.ldx = p.cin_p + 1;
+    p.rows = (long long)B * N * M;
+    p.gz = gz; p.y = y; p.out_coef = out_coef; p.out_mi = out_mi; p.out_dsums = out_dsums;
+    p.f = f; p.g = g; p.w = w; p.d_f = d_f; p.d_g = d_g; p.d_bn = d_bias_n; p.d_bk = d_bias_k; p.dw_partial = dw_partial;
+    hipStream_t st = (hipStream_t)stream;
+    const int nti = p.cin_p / 32, nto = p.cout_p / 32;
+    if (nti == 4 && nto == 4) return launch_pair_bwd<4, 4>(p, dw, st, grid);
+    if (nti == 2 && nto == 2) return launch_pair_bwd<2, 2>(p, dw, st, grid);
+    if (nti == 2 && nto == 1) return launch_pair_bwd<2, 1>(p, dw, st, grid);
+    if (nti == 4 && nto == 2) return launch_pair_bwd<4, 2>(p, dw, st, grid);
+    if (nti == 1 && nto == 1) return launch_pair_bwd<1, 1>(p, dw, st, grid);
+    return I2P_ERR_BAD_ARG;
 }

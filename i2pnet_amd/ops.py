@@ -245,9 +245,10 @@ class CBackend:
         dev = f.device
         d_f = torch.zeros(B, N, C, dtype=_F32, device=dev); d_g = torch.zeros(B, M, C, dtype=_F32, device=dev)
         d_bn = torch.zeros(B, N, Co, dtype=_F32, device=dev); d_bk = torch.zeros(B, M, Co, dtype=_F32, device=dev)
-        rows = B * N * M
-        grid = 256 if self.device_type == "cuda" else 1
-        part = torch.empty(min(grid, (rows + 63) // 64) * Co * C, dtype=_F32, device=dev)
+        KT = (M + 63) // 64
+        NC = max(1, min(N, 256 // (B * KT)))
+        grid = B * KT * NC if self.device_type == "cuda" else 1          # i2p_pair_lin_bwd_grid
+        part = torch.empty(grid * Co * C, dtype=_F32, device=dev)
         dw = torch.empty(Co, C, dtype=_F32, device=dev)
         self._call("i2p_pair_lin_bwd", int(B), int(N), int(M), int(C), int(Co), self._p(gy, _F32, "gy"), None, None,
                    None, None, self._p(f, _F32, "f"), self._p(g, _F32, "g"), self._p(w, _F32, "w"),

@@ -239,6 +239,8 @@ int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, const float 
 int i2p_pair_lin_fwd(int B, int N, int M, int cin, int cout, const float *f, const float *g,
                      const float *bias_n, const float *bias_k, const float *w, float *y, double *sums,
                      void *stream);
+/* dw_partial: f32 scratch [i2p_pair_lin_bwd_grid(B,N,M)][cout*cin] */
+int i2p_pair_lin_bwd_grid(int B, int N, int M);
 int i2p_pair_lin_bwd(int B, int N, int M, int cin, int cout, const float *gz, const float *y,
                      const float *out_coef, const float *out_mi, const double *out_dsums, const float *f,
                      const float *g, const float *w, float *d_f, float *d_g, float *d_bias_n,

@@ -31,7 +31,7 @@ def test_hip_library_builds_loads_and_exports_all_symbols():
     lib.i2p_abi_version.restype = ctypes.c_int
     assert lib.i2p_abi_version() == 1
     # the ctypes table covers every compute entry the header declares
-    helpers = {"i2p_abi_version", "i2p_lin_bwd_grid"}          # no stream argument: bound separately
+    helpers = {"i2p_abi_version", "i2p_lin_bwd_grid", "i2p_pair_lin_bwd_grid"}          # no stream argument: bound separately
     assert set(_abi.SIGNATURES) == set(_declared()) - helpers
 
 
