@@ -265,6 +265,204 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
     }
 }
 
+// =================================================================================================
+// lin_fwd, second generation (cin % 4 == 0, cin <= 128): no block barrier in the tile loop.
+// 8 waves per CU (2 per SIMD); every wave owns 16-row strips end to end — fetch (registers, one
+// strip ahead) -> transform -> its private LDS strip -> v_mfma_f32_16x16x4_f32 against the shared
+// stationary W -> epilogue through the same LDS strip (full-row float4 stores) — so one wave's
+// memory phases run under the other wave's MFMAs on the same SIMD.  The first generation
+// (block-synchronous 128-row tiles) measured staging + epilogue + MFMA strictly serialised
+// (tools/ablate_lin_fwd.py: 157 + 200 + 300 us on the 853632x128x128 layer).
+// =================================================================================================
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int F2_THREADS = 512;
+constexpr int F2_ROWS = 16;
+constexpr int F2_CH = 8;                 // float4 chunks per lane per strip (16 rows x 128 ch max)
+
+template <int NT16>
+__global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p) {
+    extern __shared__ float smem[];
+    const int ldk = p.ldk;                                  // cin + 2: 8-byte aligned rows, conflict-free fragments
+    float *Ws = smem;                                       // [cout_p16][ldk]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *As = smem + (size_t)p.cout_p * ldk + (size_t)wave * F2_ROWS * ldk;   // this wave's strip
+
+    for (int i = tid; i < p.cout_p * p.cin; i += F2_THREADS) {
+        const int co = i / p.cin, ci = i - co * p.cin;
+        Ws[co * ldk + ci] = (co < p.cout) ? p.w[(size_t)co * p.cin + ci] : 0.f;
+    }
+    __syncthreads();                                        // the only block barrier
+
+    const int c4n = p.cin >> 2;
+    const int shift = ((c4n & (c4n - 1)) == 0) ? (31 - __clz(c4n)) : -1;
+    const int nchunk = F2_ROWS * c4n;
+    // per-channel BN coefficients of this lane's chunks: constant across strips when c4n divides 64
+    const bool coef_const = p.in_coef && (64 % c4n == 0);
+    float4 cm = make_float4(0.f, 0.f, 0.f, 0.f), cs = cm, cb = cm;
+    if (coef_const) {
+        const int c4 = lane % c4n;
+        cm = *reinterpret_cast<const float4 *>(p.in_coef + c4 * 4);
+        cs = *reinterpret_cast<const float4 *>(p.in_coef + p.cin + c4 * 4);
+        cb = *reinterpret_cast<const float4 *>(p.in_coef + 2 * p.cin + c4 * 4);
+    }
+
+    double ssum[NT16], ssq[NT16];
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) { ssum[j] = 0.0; ssq[j] = 0.0; }
+
+    const long long nstrips = (p.rows + F2_ROWS - 1) / F2_ROWS;
+    const long long sstride = (long long)gridDim.x * 8;
+    long long strip = (long long)blockIdx.x * 8 + wave;
+
+    auto fetch = [&](long long st, float4 (&v)[F2_CH]) {
+        const long long row0 = st * F2_ROWS;
+        PairTile pt; pt.bn0 = pt.k0 = pt.b0 = pt.n0 = 0;
+        if (p.pair_f) pt = pair_tile(row0, p.pair_N, p.pair_M);
+#pragma unroll
+        for (int u = 0; u < F2_CH; ++u) {
+            const int i = lane + u * 64;
+            int r, c4;
+            if (shift >= 0) { r = i >> shift; c4 = i & (c4n - 1); } else { r = i / c4n; c4 = i - r * c4n; }
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < nchunk && row0 + r < p.rows) {
+                long long src = row0 + r;
+                if (p.pair_f) { int bn, bk; pair_row(pt, r, p.pair_N, p.pair_M, bn, bk); src = bk; }
+                v[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)src * p.cin + c4 * 4);
+            }
+        }
+    };
+
+    float4 pf[F2_CH];
+    if (strip < nstrips) fetch(strip, pf);
+    for (; strip < nstrips; strip += sstride) {
+        const long long row0 = strip * F2_ROWS;
+        PairTile pt; pt.bn0 = pt.k0 = pt.b0 = pt.n0 = 0;
+        if (p.pair_f) pt = pair_tile(row0, p.pair_N, p.pair_M);
+        // ---- commit: transform + write this wave's strip ----------------------------------------------
+#pragma unroll
+        for (int u = 0; u < F2_CH; ++u) {
+            const int i = lane + u * 64;
+            if (i < nchunk) {
+                int r, c4;
+                if (shift >= 0) { r = i >> shift; c4 = i & (c4n - 1); } else { r = i / c4n; c4 = i - r * c4n; }
+                float4 t = pf[u];
+                if (row0 + r < p.rows) {
+                    if (p.pair_f) {
+                        int bn, bk; pair_row(pt, r, p.pair_N, p.pair_M, bn, bk);
+                        const float4 f = *reinterpret_cast<const float4 *>(p.pair_f + (size_t)bn * p.cin + c4 * 4);
+                        t.x *= f.x; t.y *= f.y; t.z *= f.z; t.w *= f.w;
+                    }
+                    if (p.in_coef) {
+                        float4 m = cm, sc = cs, b = cb;
+                        if (!coef_const) {
+                            m = *reinterpret_cast<const float4 *>(p.in_coef + c4 * 4);
+                            sc = *reinterpret_cast<const float4 *>(p.in_coef + p.cin + c4 * 4);
+                            b = *reinterpret_cast<const float4 *>(p.in_coef + 2 * p.cin + c4 * 4);
+                        }
+                        t.x = act_apply((t.x - m.x) * sc.x + b.x, p.slope_in);
+                        t.y = act_apply((t.y - m.y) * sc.y + b.y, p.slope_in);
+                        t.z = act_apply((t.z - m.z) * sc.z + b.z, p.slope_in);
+                        t.w = act_apply((t.w - m.w) * sc.w + b.w, p.slope_in);
+                    }
+                }
+                float2 *dst = reinterpret_cast<float2 *>(As + r * ldk + c4 * 4);
+                dst[0] = make_float2(t.x, t.y); dst[1] = make_float2(t.z, t.w);
+            }
+        }
+        if (strip + sstride < nstrips) fetch(strip + sstride, pf);       // next strip's loads fly under the MFMAs
+
+        // ---- 16 x (16*NT16) on the matrix cores ---------------------------------------------------------
+        f32x4 acc[NT16];
+#pragma unroll
+        for (int j = 0; j < NT16; ++j) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; acc[j][3] = 0.f; }
+        const float *arow = As + (lane & 15) * ldk + (lane >> 4);
+        const float *brow = Ws + (lane & 15) * ldk + (lane >> 4);
+        float a_cur = arow[0], b_cur[NT16];
+#pragma unroll
+        for (int j = 0; j < NT16; ++j) b_cur[j] = brow[(size_t)j * 16 * ldk];
+#pragma unroll 2
+        for (int kk = 0; kk < p.cin; kk += 4) {
+            const int kn = (kk + 4 < p.cin) ? kk + 4 : kk;
+            const float a_nxt = arow[kn];
+            float b_nxt[NT16];
+#pragma unroll
+            for (int j = 0; j < NT16; ++j) b_nxt[j] = brow[(size_t)j * 16 * ldk + kn];
+#pragma unroll
+            for (int j = 0; j < NT16; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NT16 + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT16, 0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int j = 0; j < NT16; ++j) b_cur[j] = b_nxt[j];
+        }
+
+        // ---- epilogue: bias (pair mode), statistics, transpose through the strip, full-row stores --------
+        // C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + e
+#pragma unroll
+        for (int j = 0; j < NT16; ++j) {
+            const int ch = j * 16 + (lane & 15);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = (lane >> 4) * 4 + e;
+                float v = acc[j][e];
+                if (p.bias_n && ch < p.cout && row0 + r < p.rows) {
+                    int bn, bk; pair_row(pt, r, p.pair_N, p.pair_M, bn, bk);
+                    v = (v + p.bias_n[(size_t)bn * p.cout_total + p.ch_off + ch]) +
+                        p.bias_k[(size_t)bk * p.cout_total + p.ch_off + ch];
+                }
+                if (row0 + r < p.rows) { s1 += v; s2 = fmaf(v, v, s2); }
+                As[r * ldk + ch] = v;               // ch < cout_p16 <= cin is NOT guaranteed: see launcher (ldk >= cout_p)
+            }
+            ssum[j] += (double)s1; ssq[j] += (double)s2;
+        }
+        {
+            const int o4n = p.cout >> 2;                 // float4 per output row (cout % 4 == 0)
+            for (int i = lane; i < F2_ROWS * o4n; i += 64) {
+                const int r = i / o4n, c4 = i - r * o4n;
+                if (row0 + r < p.rows) {
+                    const float2 lo = *reinterpret_cast<const float2 *>(As + r * ldk + c4 * 4);
+                    const float2 hi = *reinterpret_cast<const float2 *>(As + r * ldk + c4 * 4 + 2);
+                    *reinterpret_cast<float4 *>(p.y + (size_t)(row0 + r) * p.y_ld + p.ch_off + c4 * 4) =
+                        make_float4(lo.x, lo.y, hi.x, hi.y);
+                }
+            }
+        }
+    }
+
+    if (p.sums) {
+#pragma unroll
+        for (int j = 0; j < NT16; ++j) {
+            double a = ssum[j], b = ssq[j];
+            a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+            a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+            const int ch = j * 16 + lane;
+            if (lane < 16 && ch < p.cout) {
+                double *rep = p.sums + (size_t)((blockIdx.x * 8 + wave) % REP) * 2 * p.cout_total;
+                atomicAdd(rep + p.ch_off + ch, a); atomicAdd(rep + p.cout_total + p.ch_off + ch, b);
+            }
+        }
+    }
+}
+
+template <int NT16>
+int launch_fwd2(const LinFwdParams &p, hipStream_t st) {
+    const size_t bytes = ((size_t)p.cout_p + 8 * F2_ROWS) * p.ldk * sizeof(float);
+    if (bytes > 160 * 1024) return I2P_ERR_BAD_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lin_fwd2_kernel<NT16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const long long nstrips = (p.rows + F2_ROWS - 1) / F2_ROWS;
+    long long g = (nstrips + 7) / 8;
+    const unsigned grid = (unsigned)(g < 256 ? (g < 1 ? 1 : g) : 256);
+    hipLaunchKernelGGL((lin_fwd2_kernel<NT16>), dim3(grid), dim3(F2_THREADS), bytes, st, p);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
 // mean/scale/beta of a BN from its replica sums:  coef [3][c]
 __global__ void bn_finalize_kernel(long long rows, int c, const double *__restrict__ sums,
                                    const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
@@ -890,6 +1088,35 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
     if (rows == 0) return 0;
     if (!x || !w || !y) return I2P_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    {
+        const char *ab = getenv("I2P_LIN_FWD_GEN");            // diagnostic: "1" forces the first-generation kernel
+        const bool gen2_ok = (cin % 4 == 0) && cin <= 128 && cin >= 4 && (cout % 4 == 0) && !(ab && ab[0] == '1');
+        if (gen2_ok) {
+            // strip LDS rows hold max(cin, slice) floats (+2): the epilogue transposes the outputs through them
+            for (int off = 0; off < cout; off += 128) {
+                LinFwdParams p;
+                p.rows = rows; p.cin = cin; p.cout = (cout - off < 128) ? cout - off : 128;
+                p.cin_p = cin; p.cout_p = (p.cout + 15) & ~15;
+                p.ldk = ((cin > p.cout_p ? cin : p.cout_p) + 2);
+                p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.w = w + (size_t)off * cin; p.y = y; p.sums = sums;
+                p.y_ld = cout; p.ch_off = off; p.cout_total = cout; p.ablate = 0;
+                p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
+                int rc;
+                switch (p.cout_p / 16) {
+                    case 1: rc = launch_fwd2<1>(p, st); break;
+                    case 2: rc = launch_fwd2<2>(p, st); break;
+                    case 3: rc = launch_fwd2<3>(p, st); break;
+                    case 4: rc = launch_fwd2<4>(p, st); break;
+                    case 5: rc = launch_fwd2<5>(p, st); break;
+                    case 6: rc = launch_fwd2<6>(p, st); break;
+                    case 7: rc = launch_fwd2<7>(p, st); break;
+                    default: rc = launch_fwd2<8>(p, st); break;
+                }
+                if (rc) return rc;
+            }
+            return 0;
+        }
+    }
     // output channels are processed in slices whose weights fit the LDS next to a 128-row tile
     const int cin_p = (cin + 1) & ~1, ldk = cin_p + 1;
     int slice = (cout + 31) & ~31;

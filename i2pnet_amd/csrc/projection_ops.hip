@@ -91,6 +91,10 @@ __global__ void gather_rows_kernel(int hw, int c, int q, int W, const float *__r
     out[((size_t)bi * q + row) * c + ch] = feat[((size_t)bi * hw + cell) * c + ch];
 }
 
+// Scatter-add backward.  Neighbour lists repeat the nearest hit in their empty slots
+// (FLAG_COPY), so consecutive rows very often target the same cell: a thread walks RUN consecutive
+// rows for one channel, sums equal-cell runs in a register and issues one atomic per run.
+constexpr int GRAD_RUN = 8;
 __global__ void gather_rows_grad_kernel(int hw, int c, int q, int W,
                                         const float *__restrict__ grad_out,
                                         const int64_t *__restrict__ h_idx,
@@ -98,10 +102,21 @@ __global__ void gather_rows_grad_kernel(int hw, int c, int q, int W,
                                         float *__restrict__ grad_feat) {
     const int bi = blockIdx.y;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)q * c) return;
-    const int row = (int)(t / c), ch = (int)(t % c);
-    const long long cell = h_idx[(size_t)bi * q + row] * W + w_idx[(size_t)bi * q + row];
-    atomicAdd(grad_feat + ((size_t)bi * hw + cell) * c + ch, grad_out[((size_t)bi * q + row) * c + ch]);
+    const int nrun = (q + GRAD_RUN - 1) / GRAD_RUN;
+    if (t >= (long long)nrun * c) return;
+    const int run = (int)(t / c), ch = (int)(t % c);
+    const int r0 = run * GRAD_RUN, r1 = min(q, r0 + GRAD_RUN);
+    long long cur = -1; float acc = 0.f;
+    for (int row = r0; row < r1; ++row) {
+        const long long cell = h_idx[(size_t)bi * q + row] * W + w_idx[(size_t)bi * q + row];
+        const float gv = grad_out[((size_t)bi * q + row) * c + ch];
+        if (cell != cur) {
+            if (cur >= 0) atomicAdd(grad_feat + ((size_t)bi * hw + cur) * c + ch, acc);
+            cur = cell; acc = 0.f;
+        }
+        acc += gv;
+    }
+    if (cur >= 0) atomicAdd(grad_feat + ((size_t)bi * hw + cur) * c + ch, acc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -215,7 +230,7 @@ extern "C" int i2p_gather_rows_grad(int b, int hw, int c, int q, int W, const fl
     if (b < 0 || hw < 0 || c < 0 || q < 0 || W <= 0) return I2P_ERR_BAD_ARG;
     if ((long long)b * q * c == 0) return 0;
     if (!grad_out || !h_idx || !w_idx || !grad_feat) return I2P_ERR_BAD_ARG;
-    const long long tot = (long long)q * c;
+    const long long tot = (long long)((q + GRAD_RUN - 1) / GRAD_RUN) * c;
     hipLaunchKernelGGL(gather_rows_grad_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0,
                        (hipStream_t)stream, hw, c, q, W, grad_out, h_idx, w_idx, grad_feat);
     I2P_RETURN_LAUNCH_STATUS();
