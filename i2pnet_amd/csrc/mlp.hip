@@ -292,6 +292,10 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
         Ws[co * ldk + ci] = (co < p.cout) ? p.w[(size_t)co * p.cin + ci] : 0.f;
     }
     __syncthreads();                                        // the only block barrier
+    // Waves w and w+4 share a SIMD and would otherwise run in lockstep (both in their MFMA phase, then
+    // both in their memory phase: measured, the phases simply add up).  A static priority for the
+    // second half lets it win the matrix pipe, finish its MFMA phase first and fall out of phase.
+    if (wave >= 4 && !(p.ablate & 32)) __builtin_amdgcn_s_setprio(1);
 
     const int c4n = p.cin >> 2;
     const int shift = ((c4n & (c4n - 1)) == 0) ? (31 - __clz(c4n)) : -1;
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
     };
 
     float4 pf[F2_CH];
-    if (strip < nstrips) fetch(strip, pf);
+    if (strip < nstrips && !(p.ablate & 8)) fetch(strip, pf);
     for (; strip < nstrips; strip += sstride) {
         const long long row0 = strip * F2_ROWS;
         PairTile pt; pt.bn0 = pt.k0 = pt.b0 = pt.n0 = 0;
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
 #pragma unroll
         for (int u = 0; u < F2_CH; ++u) {
             const int i = lane + u * 64;
-            if (i < nchunk) {
+            if (i < nchunk && !(p.ablate & 8)) {
                 int r, c4;
                 if (shift >= 0) { r = i >> shift; c4 = i & (c4n - 1); } else { r = i / c4n; c4 = i - r * c4n; }
                 float4 t = pf[u];
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
                 dst[0] = make_float2(t.x, t.y); dst[1] = make_float2(t.z, t.w);
             }
         }
-        if (strip + sstride < nstrips) fetch(strip + sstride, pf);       // next strip's loads fly under the MFMAs
+        if (strip + sstride < nstrips && !(p.ablate & 8)) fetch(strip + sstride, pf);       // next strip's loads fly under the MFMAs
 
         // ---- 16 x (16*NT16) on the matrix cores ---------------------------------------------------------
         f32x4 acc[NT16];
@@ -377,24 +381,35 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
         for (int j = 0; j < NT16; ++j) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; acc[j][3] = 0.f; }
         const float *arow = As + (lane & 15) * ldk + (lane >> 4);
         const float *brow = Ws + (lane & 15) * ldk + (lane >> 4);
-        float a_cur = arow[0], b_cur[NT16];
+        // Ping-pong fragment registers, two k-steps per iteration: the operands of a step were requested a
+        // full step (8 MFMAs = 256 cycles) earlier, so no s_waitcnt ever sits between two MFMAs and no
+        // register copies are needed (a single-buffered version measured 72 % of the MFMA issue rate).
+        const int K4 = ((p.ablate & 1) ? 4 : p.cin) >> 2;
+        float a0 = arow[0], b0[NT16], a1 = 0.f, b1[NT16];
 #pragma unroll
-        for (int j = 0; j < NT16; ++j) b_cur[j] = brow[(size_t)j * 16 * ldk];
-#pragma unroll 2
-        for (int kk = 0; kk < p.cin; kk += 4) {
-            const int kn = (kk + 4 < p.cin) ? kk + 4 : kk;
-            const float a_nxt = arow[kn];
-            float b_nxt[NT16];
+        for (int j = 0; j < NT16; ++j) { b0[j] = brow[(size_t)j * 16 * ldk]; b1[j] = 0.f; }
+        int st4 = 0;
+        for (; st4 + 1 < K4; st4 += 2) {
+            const int k1 = (st4 + 1) * 4;
+            a1 = arow[k1];
 #pragma unroll
-            for (int j = 0; j < NT16; ++j) b_nxt[j] = brow[(size_t)j * 16 * ldk + kn];
+            for (int j = 0; j < NT16; ++j) b1[j] = brow[(size_t)j * 16 * ldk + k1];
 #pragma unroll
-            for (int j = 0; j < NT16; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
+            for (int j = 0; j < NT16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[j], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, NT16 + 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, NT16, 0);
-            a_cur = a_nxt;
+            const int k2 = (st4 + 2 < K4 ? st4 + 2 : st4 + 1) * 4;
+            a0 = arow[k2];
 #pragma unroll
-            for (int j = 0; j < NT16; ++j) b_cur[j] = b_nxt[j];
+            for (int j = 0; j < NT16; ++j) b0[j] = brow[(size_t)j * 16 * ldk + k2];
+#pragma unroll
+            for (int j = 0; j < NT16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[j], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NT16 + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT16, 0);
+        }
+        if (st4 < K4) {
+#pragma unroll
+            for (int j = 0; j < NT16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[j], acc[j], 0, 0, 0);
         }
 
         // ---- epilogue: bias (pair mode), statistics, transpose through the strip, full-row stores --------
@@ -412,14 +427,14 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
                     v = (v + p.bias_n[(size_t)bn * p.cout_total + p.ch_off + ch]) +
                         p.bias_k[(size_t)bk * p.cout_total + p.ch_off + ch];
                 }
-                if (row0 + r < p.rows) { s1 += v; s2 = fmaf(v, v, s2); }
-                As[r * ldk + ch] = v;               // ch < cout_p16 <= cin is NOT guaranteed: see launcher (ldk >= cout_p)
+                if (row0 + r < p.rows && !(p.ablate & 4)) { s1 += v; s2 = fmaf(v, v, s2); }
+                if (!(p.ablate & 16)) As[r * ldk + ch] = v;               // ch < cout_p16 <= cin is NOT guaranteed: see launcher (ldk >= cout_p)
             }
             ssum[j] += (double)s1; ssq[j] += (double)s2;
         }
         {
             const int o4n = p.cout >> 2;                 // float4 per output row (cout % 4 == 0)
-            for (int i = lane; i < F2_ROWS * o4n; i += 64) {
+            for (int i = lane; i < ((p.ablate & 2) ? 0 : F2_ROWS * o4n); i += 64) {
                 const int r = i / o4n, c4 = i - r * o4n;
                 if (row0 + r < p.rows) {
                     const float2 lo = *reinterpret_cast<const float2 *>(As + r * ldk + c4 * 4);
@@ -1099,7 +1114,8 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
                 p.cin_p = cin; p.cout_p = (p.cout + 15) & ~15;
                 p.ldk = ((cin > p.cout_p ? cin : p.cout_p) + 2);
                 p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.w = w + (size_t)off * cin; p.y = y; p.sums = sums;
-                p.y_ld = cout; p.ch_off = off; p.cout_total = cout; p.ablate = 0;
+                p.y_ld = cout; p.ch_off = off; p.cout_total = cout;
+                { const char *ab2 = getenv("I2P_LIN_ABLATE"); p.ablate = ab2 ? atoi(ab2) : 0; }
                 p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
                 int rc;
                 switch (p.cout_p / 16) {
