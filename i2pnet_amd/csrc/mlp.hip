@@ -279,11 +279,21 @@ constexpr int F2_THREADS = 512;
 constexpr int F2_ROWS = 16;
 constexpr int F2_CH = 8;                 // float4 chunks per lane per strip (16 rows x 128 ch max)
 
-template <int NT16>
+// branch-free (b,n,k) walk for a 16-row strip (M >= 16: at most one wrap inside a strip)
+__device__ __forceinline__ void pair_row16(const PairTile &t, int d, int N, int M, int &bn, int &bk) {
+    int k = t.k0 + d;
+    const int wrap = k >= M ? 1 : 0;
+    k -= wrap * M;
+    const int n = t.n0 + wrap;
+    const int b = t.b0 + (n >= N ? 1 : 0);
+    bn = t.bn0 + wrap; bk = b * M + k;
+}
+
+template <int NT16, bool PAIR>
 __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p) {
     extern __shared__ float smem[];
-    const int ldk = p.ldk;                                  // cin + 2: 8-byte aligned rows, conflict-free fragments
-    float *Ws = smem;                                       // [cout_p16][ldk]
+    const int ldk = p.ldk;                                  // max(cin, cout_p) + 2: 8-byte aligned rows
+    float *Ws = smem;                                       // [cout_p][ldk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *As = smem + (size_t)p.cout_p * ldk + (size_t)wave * F2_ROWS * ldk;   // this wave's strip
 
@@ -292,88 +302,96 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
         Ws[co * ldk + ci] = (co < p.cout) ? p.w[(size_t)co * p.cin + ci] : 0.f;
     }
     __syncthreads();                                        // the only block barrier
-    // Waves w and w+4 share a SIMD and would otherwise run in lockstep (both in their MFMA phase, then
-    // both in their memory phase: measured, the phases simply add up).  A static priority for the
-    // second half lets it win the matrix pipe, finish its MFMA phase first and fall out of phase.
-    if (wave >= 4 && !(p.ablate & 32)) __builtin_amdgcn_s_setprio(1);
 
-    const int c4n = p.cin >> 2;
-    const int shift = ((c4n & (c4n - 1)) == 0) ? (31 - __clz(c4n)) : -1;
-    const int nchunk = F2_ROWS * c4n;
-    // per-channel BN coefficients of this lane's chunks: constant across strips when c4n divides 64
-    const bool coef_const = p.in_coef && (64 % c4n == 0);
-    float4 cm = make_float4(0.f, 0.f, 0.f, 0.f), cs = cm, cb = cm;
-    if (coef_const) {
-        const int c4 = lane % c4n;
-        cm = *reinterpret_cast<const float4 *>(p.in_coef + c4 * 4);
-        cs = *reinterpret_cast<const float4 *>(p.in_coef + p.cin + c4 * 4);
-        cb = *reinterpret_cast<const float4 *>(p.in_coef + 2 * p.cin + c4 * 4);
+    // ---- per-lane chunk geometry, fixed for the whole kernel -----------------------------------------
+    const int c4n = p.cin >> 2, nchunk = F2_ROWS * c4n;
+    int in_r[F2_CH], in_c4[F2_CH];
+    bool in_ok[F2_CH];
+#pragma unroll
+    for (int u = 0; u < F2_CH; ++u) {
+        const int i = lane + u * 64;
+        in_ok[u] = i < nchunk;
+        const int ic = in_ok[u] ? i : nchunk - 1;
+        in_r[u] = ic / c4n; in_c4[u] = ic - in_r[u] * c4n;
+    }
+    const int o4n = p.cout >> 2;                            // 4, 8, 16 or 32 (launcher): divides 64
+    const int o_shift = 31 - __clz(o4n);
+    const int o_c4 = lane & (o4n - 1);                      // this lane's 4 output channels in the store phase
+    constexpr int OCH = F2_CH;                              // <= 8 output chunks per lane (16 rows x 32 float4)
+
+    // BN coefficients of the input chunks (loaded once; 3 float4 per chunk slot when they differ per slot)
+    float4 cm = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(1.f, 1.f, 1.f, 1.f), cb = cm;
+    if (p.in_coef) {                                        // (cin/4) divides 64: every slot of a lane has the same channels
+        cm = *reinterpret_cast<const float4 *>(p.in_coef + in_c4[0] * 4);
+        cs = *reinterpret_cast<const float4 *>(p.in_coef + p.cin + in_c4[0] * 4);
+        cb = *reinterpret_cast<const float4 *>(p.in_coef + 2 * p.cin + in_c4[0] * 4);
     }
 
-    double ssum[NT16], ssq[NT16];
-#pragma unroll
-    for (int j = 0; j < NT16; ++j) { ssum[j] = 0.0; ssq[j] = 0.0; }
+    double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
 
     const long long nstrips = (p.rows + F2_ROWS - 1) / F2_ROWS;
     const long long sstride = (long long)gridDim.x * 8;
+    const long long last_row = p.rows - 1;
     long long strip = (long long)blockIdx.x * 8 + wave;
 
+    // all loads of a strip are issued back to back, no control flow in between (clamped addresses)
     auto fetch = [&](long long st, float4 (&v)[F2_CH]) {
         const long long row0 = st * F2_ROWS;
         PairTile pt; pt.bn0 = pt.k0 = pt.b0 = pt.n0 = 0;
-        if (p.pair_f) pt = pair_tile(row0, p.pair_N, p.pair_M);
+        if (PAIR) pt = pair_tile(row0, p.pair_N, p.pair_M);
 #pragma unroll
         for (int u = 0; u < F2_CH; ++u) {
-            const int i = lane + u * 64;
-            int r, c4;
-            if (shift >= 0) { r = i >> shift; c4 = i & (c4n - 1); } else { r = i / c4n; c4 = i - r * c4n; }
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < nchunk && row0 + r < p.rows) {
-                long long src = row0 + r;
-                if (p.pair_f) { int bn, bk; pair_row(pt, r, p.pair_N, p.pair_M, bn, bk); src = bk; }
-                v[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)src * p.cin + c4 * 4);
+            long long row = row0 + in_r[u];
+            int d = in_r[u];
+            if (row > last_row) { d = (int)(last_row - row0); row = last_row; }
+            long long src = row;
+            if (PAIR) { int bn, bk; pair_row16(pt, d, p.pair_N, p.pair_M, bn, bk); src = bk; }
+            v[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)src * p.cin + in_c4[u] * 4);
+        }
+    };
+
+    // Order inside an iteration (vmcnt retires in order and counts stores too):
+    //   MFMA(s) -> outputs of s to registers -> commit(s+1) [waits the loads issued one MFMA phase ago]
+    //   -> stores(s) -> fetch(s+2).   The stores of a strip are thus always OLDER than the loads the next
+    //   commit waits for, and both had a whole MFMA phase to land; no wait ever exposes store latency.
+    auto commit = [&](long long st, const float4 (&v)[F2_CH]) {
+        const long long row0 = st * F2_ROWS;
+        PairTile pt; pt.bn0 = pt.k0 = pt.b0 = pt.n0 = 0;
+        if (PAIR) pt = pair_tile(row0, p.pair_N, p.pair_M);
+#pragma unroll
+        for (int u = 0; u < F2_CH; ++u) {
+            float4 t = v[u];
+            if (PAIR) {
+                int d = in_r[u];
+                if (row0 + d > last_row) d = (int)(last_row - row0);
+                int bn, bk; pair_row16(pt, d, p.pair_N, p.pair_M, bn, bk);
+                const float4 f = *reinterpret_cast<const float4 *>(p.pair_f + (size_t)bn * p.cin + in_c4[u] * 4);
+                t.x *= f.x; t.y *= f.y; t.z *= f.z; t.w *= f.w;
+            }
+            if (p.in_coef) {                                // launcher guarantees one channel set per lane
+                const float4 m = cm, sc = cs, bb = cb;
+                t.x = act_apply((t.x - m.x) * sc.x + bb.x, p.slope_in);
+                t.y = act_apply((t.y - m.y) * sc.y + bb.y, p.slope_in);
+                t.z = act_apply((t.z - m.z) * sc.z + bb.z, p.slope_in);
+                t.w = act_apply((t.w - m.w) * sc.w + bb.w, p.slope_in);
+            }
+            if (in_ok[u]) {
+                float2 *dst = reinterpret_cast<float2 *>(As + in_r[u] * ldk + in_c4[u] * 4);
+                dst[0] = make_float2(t.x, t.y); dst[1] = make_float2(t.z, t.w);
             }
         }
     };
 
     float4 pf[F2_CH];
-    if (strip < nstrips && !(p.ablate & 8)) fetch(strip, pf);
+    if (strip < nstrips) {
+        fetch(strip, pf);
+        commit(strip, pf);
+        if (strip + sstride < nstrips) fetch(strip + sstride, pf);
+    }
     for (; strip < nstrips; strip += sstride) {
         const long long row0 = strip * F2_ROWS;
         PairTile pt; pt.bn0 = pt.k0 = pt.b0 = pt.n0 = 0;
-        if (p.pair_f) pt = pair_tile(row0, p.pair_N, p.pair_M);
-        // ---- commit: transform + write this wave's strip ----------------------------------------------
-#pragma unroll
-        for (int u = 0; u < F2_CH; ++u) {
-            const int i = lane + u * 64;
-            if (i < nchunk && !(p.ablate & 8)) {
-                int r, c4;
-                if (shift >= 0) { r = i >> shift; c4 = i & (c4n - 1); } else { r = i / c4n; c4 = i - r * c4n; }
-                float4 t = pf[u];
-                if (row0 + r < p.rows) {
-                    if (p.pair_f) {
-                        int bn, bk; pair_row(pt, r, p.pair_N, p.pair_M, bn, bk);
-                        const float4 f = *reinterpret_cast<const float4 *>(p.pair_f + (size_t)bn * p.cin + c4 * 4);
-                        t.x *= f.x; t.y *= f.y; t.z *= f.z; t.w *= f.w;
-                    }
-                    if (p.in_coef) {
-                        float4 m = cm, sc = cs, b = cb;
-                        if (!coef_const) {
-                            m = *reinterpret_cast<const float4 *>(p.in_coef + c4 * 4);
-                            sc = *reinterpret_cast<const float4 *>(p.in_coef + p.cin + c4 * 4);
-                            b = *reinterpret_cast<const float4 *>(p.in_coef + 2 * p.cin + c4 * 4);
-                        }
-                        t.x = act_apply((t.x - m.x) * sc.x + b.x, p.slope_in);
-                        t.y = act_apply((t.y - m.y) * sc.y + b.y, p.slope_in);
-                        t.z = act_apply((t.z - m.z) * sc.z + b.z, p.slope_in);
-                        t.w = act_apply((t.w - m.w) * sc.w + b.w, p.slope_in);
-                    }
-                }
-                float2 *dst = reinterpret_cast<float2 *>(As + r * ldk + c4 * 4);
-                dst[0] = make_float2(t.x, t.y); dst[1] = make_float2(t.z, t.w);
-            }
-        }
-        if (strip + sstride < nstrips && !(p.ablate & 8)) fetch(strip + sstride, pf);       // next strip's loads fly under the MFMAs
+        if (PAIR) pt = pair_tile(row0, p.pair_N, p.pair_M);
 
         // ---- 16 x (16*NT16) on the matrix cores ---------------------------------------------------------
         f32x4 acc[NT16];
@@ -384,7 +402,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
         // Ping-pong fragment registers, two k-steps per iteration: the operands of a step were requested a
         // full step (8 MFMAs = 256 cycles) earlier, so no s_waitcnt ever sits between two MFMAs and no
         // register copies are needed (a single-buffered version measured 72 % of the MFMA issue rate).
-        const int K4 = ((p.ablate & 1) ? 4 : p.cin) >> 2;
+        const int K4 = p.cin >> 2;
         float a0 = arow[0], b0[NT16], a1 = 0.f, b1[NT16];
 #pragma unroll
         for (int j = 0; j < NT16; ++j) { b0[j] = brow[(size_t)j * 16 * ldk]; b1[j] = 0.f; }
@@ -412,48 +430,61 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
             for (int j = 0; j < NT16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[j], acc[j], 0, 0, 0);
         }
 
-        // ---- epilogue: bias (pair mode), statistics, transpose through the strip, full-row stores --------
-        // C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + e
+        // ---- epilogue 1: fragments -> this wave's strip (C/D of 16x16: col = lane&15, row = (lane>>4)*4+e) ----
 #pragma unroll
         for (int j = 0; j < NT16; ++j) {
             const int ch = j * 16 + (lane & 15);
-            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = (lane >> 4) * 4 + e;
-                float v = acc[j][e];
-                if (p.bias_n && ch < p.cout && row0 + r < p.rows) {
-                    int bn, bk; pair_row(pt, r, p.pair_N, p.pair_M, bn, bk);
-                    v = (v + p.bias_n[(size_t)bn * p.cout_total + p.ch_off + ch]) +
-                        p.bias_k[(size_t)bk * p.cout_total + p.ch_off + ch];
-                }
-                if (row0 + r < p.rows && !(p.ablate & 4)) { s1 += v; s2 = fmaf(v, v, s2); }
-                if (!(p.ablate & 16)) As[r * ldk + ch] = v;               // ch < cout_p16 <= cin is NOT guaranteed: see launcher (ldk >= cout_p)
-            }
-            ssum[j] += (double)s1; ssq[j] += (double)s2;
+            for (int e = 0; e < 4; ++e) As[((lane >> 4) * 4 + e) * ldk + ch] = acc[j][e];
         }
-        {
-            const int o4n = p.cout >> 2;                 // float4 per output row (cout % 4 == 0)
-            for (int i = lane; i < ((p.ablate & 2) ? 0 : F2_ROWS * o4n); i += 64) {
-                const int r = i / o4n, c4 = i - r * o4n;
-                if (row0 + r < p.rows) {
-                    const float2 lo = *reinterpret_cast<const float2 *>(As + r * ldk + c4 * 4);
-                    const float2 hi = *reinterpret_cast<const float2 *>(As + r * ldk + c4 * 4 + 2);
-                    *reinterpret_cast<float4 *>(p.y + (size_t)(row0 + r) * p.y_ld + p.ch_off + c4 * 4) =
-                        make_float4(lo.x, lo.y, hi.x, hi.y);
+        // ---- epilogue 2: row-major float4 chunks to registers: bias (pair mode), statistics -----------------
+        float4 ov[OCH];
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < OCH; ++u) {
+            const int r = (lane + u * 64) >> o_shift;       // chunk (r, o_c4)
+            ov[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < F2_ROWS) {
+                const float2 lo = *reinterpret_cast<const float2 *>(As + r * ldk + o_c4 * 4);
+                const float2 hi = *reinterpret_cast<const float2 *>(As + r * ldk + o_c4 * 4 + 2);
+                float4 v = make_float4(lo.x, lo.y, hi.x, hi.y);
+                if (PAIR) {
+                    int d = r;
+                    if (row0 + d > last_row) d = (int)(last_row - row0);
+                    int bn, bk; pair_row16(pt, d, p.pair_N, p.pair_M, bn, bk);
+                    const float4 a = *reinterpret_cast<const float4 *>(p.bias_n + (size_t)bn * p.cout_total + p.ch_off + o_c4 * 4);
+                    const float4 c = *reinterpret_cast<const float4 *>(p.bias_k + (size_t)bk * p.cout_total + p.ch_off + o_c4 * 4);
+                    v.x = (v.x + a.x) + c.x; v.y = (v.y + a.y) + c.y; v.z = (v.z + a.z) + c.z; v.w = (v.w + a.w) + c.w;
                 }
+                if (row0 + r <= last_row) {
+                    s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
+                    s2[0] = fmaf(v.x, v.x, s2[0]); s2[1] = fmaf(v.y, v.y, s2[1]);
+                    s2[2] = fmaf(v.z, v.z, s2[2]); s2[3] = fmaf(v.w, v.w, s2[3]);
+                }
+                ov[u] = v;
             }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ssum[q] += (double)s1[q]; ssq[q] += (double)s2[q]; }
+        // ---- the strip is free again: stage the next one, then store this one's outputs ---------------------
+        if (strip + sstride < nstrips) commit(strip + sstride, pf);
+#pragma unroll
+        for (int u = 0; u < OCH; ++u) {
+            const int r = (lane + u * 64) >> o_shift;
+            if (r < F2_ROWS && row0 + r <= last_row)
+                *reinterpret_cast<float4 *>(p.y + (size_t)(row0 + r) * p.y_ld + p.ch_off + o_c4 * 4) = ov[u];
+        }
+        if (strip + 2 * sstride < nstrips) fetch(strip + 2 * sstride, pf);
     }
 
     if (p.sums) {
+        // lanes with equal (lane & (o4n-1)) own the same 4 channels
 #pragma unroll
-        for (int j = 0; j < NT16; ++j) {
-            double a = ssum[j], b = ssq[j];
-            a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
-            a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
-            const int ch = j * 16 + lane;
-            if (lane < 16 && ch < p.cout) {
+        for (int q = 0; q < 4; ++q) {
+            double a = ssum[q], b = ssq[q];
+            for (int off = 32; off >= o4n; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+            if (lane < o4n) {
+                const int ch = lane * 4 + q;
                 double *rep = p.sums + (size_t)((blockIdx.x * 8 + wave) % REP) * 2 * p.cout_total;
                 atomicAdd(rep + p.ch_off + ch, a); atomicAdd(rep + p.cout_total + p.ch_off + ch, b);
             }
@@ -461,21 +492,32 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
     }
 }
 
-template <int NT16>
+template <int NT16, bool PAIR>
 int launch_fwd2(const LinFwdParams &p, hipStream_t st) {
     const size_t bytes = ((size_t)p.cout_p + 8 * F2_ROWS) * p.ldk * sizeof(float);
     if (bytes > 160 * 1024) return I2P_ERR_BAD_ARG;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lin_fwd2_kernel<NT16>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lin_fwd2_kernel<NT16, PAIR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const long long nstrips = (p.rows + F2_ROWS - 1) / F2_ROWS;
     long long g = (nstrips + 7) / 8;
     const unsigned grid = (unsigned)(g < 256 ? (g < 1 ? 1 : g) : 256);
-    hipLaunchKernelGGL((lin_fwd2_kernel<NT16>), dim3(grid), dim3(F2_THREADS), bytes, st, p);
+    hipLaunchKernelGGL((lin_fwd2_kernel<NT16, PAIR>), dim3(grid), dim3(F2_THREADS), bytes, st, p);
     I2P_RETURN_LAUNCH_STATUS();
+}
+
+template <bool PAIR>
+int dispatch_fwd2(const LinFwdParams &p, hipStream_t st) {
+    switch (p.cout_p / 16) {
+        case 1: return launch_fwd2<1, PAIR>(p, st);
+        case 2: return launch_fwd2<2, PAIR>(p, st);
+        case 4: return launch_fwd2<4, PAIR>(p, st);
+        case 8: return launch_fwd2<8, PAIR>(p, st);
+        default: return I2P_ERR_BAD_ARG;
+    }
 }
 
 // mean/scale/beta of a BN from its replica sums:  coef [3][c]
@@ -1105,29 +1147,22 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
     hipStream_t st = (hipStream_t)stream;
     {
         const char *ab = getenv("I2P_LIN_FWD_GEN");            // diagnostic: "1" forces the first-generation kernel
-        const bool gen2_ok = (cin % 4 == 0) && cin <= 128 && cin >= 4 && (cout % 4 == 0) && !(ab && ab[0] == '1');
+        auto pow2_16_128 = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
+        const int slice_w = cout > 128 ? 128 : cout;
+        const bool gen2_ok = (cin % 4 == 0) && cin <= 128 && cin >= 4 && (cout % slice_w == 0) && pow2_16_128(slice_w) &&
+                             !(ab && ab[0] == '1') && (!pair_f || pair_M >= F2_ROWS) &&
+                             (!in_coef || 64 % (cin / 4) == 0);
         if (gen2_ok) {
             // strip LDS rows hold max(cin, slice) floats (+2): the epilogue transposes the outputs through them
-            for (int off = 0; off < cout; off += 128) {
+            for (int off = 0; off < cout; off += slice_w) {
                 LinFwdParams p;
-                p.rows = rows; p.cin = cin; p.cout = (cout - off < 128) ? cout - off : 128;
-                p.cin_p = cin; p.cout_p = (p.cout + 15) & ~15;
+                p.rows = rows; p.cin = cin; p.cout = slice_w;
+                p.cin_p = cin; p.cout_p = slice_w;
                 p.ldk = ((cin > p.cout_p ? cin : p.cout_p) + 2);
                 p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.w = w + (size_t)off * cin; p.y = y; p.sums = sums;
-                p.y_ld = cout; p.ch_off = off; p.cout_total = cout;
-                { const char *ab2 = getenv("I2P_LIN_ABLATE"); p.ablate = ab2 ? atoi(ab2) : 0; }
+                p.y_ld = cout; p.ch_off = off; p.cout_total = cout; p.ablate = 0;
                 p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
-                int rc;
-                switch (p.cout_p / 16) {
-                    case 1: rc = launch_fwd2<1>(p, st); break;
-                    case 2: rc = launch_fwd2<2>(p, st); break;
-                    case 3: rc = launch_fwd2<3>(p, st); break;
-                    case 4: rc = launch_fwd2<4>(p, st); break;
-                    case 5: rc = launch_fwd2<5>(p, st); break;
-                    case 6: rc = launch_fwd2<6>(p, st); break;
-                    case 7: rc = launch_fwd2<7>(p, st); break;
-                    default: rc = launch_fwd2<8>(p, st); break;
-                }
+                const int rc = pair_f ? dispatch_fwd2<true>(p, st) : dispatch_fwd2<false>(p, st);
                 if (rc) return rc;
             }
             return 0;

@@ -7,7 +7,7 @@ hip = ops.hip_backend()
 rows, cin, cout = 8*228*468, 128, 128
 x = torch.randn(rows, cin, device="cuda"); w = torch.randn(cout, cin, device="cuda")/11
 coef = torch.stack([torch.zeros(cin), torch.ones(cin), torch.zeros(cin)]).cuda().contiguous()
-for ab in [0, 0, 30, 1, 8]:
+for ab in [0, 0, 0]:
     os.environ["I2P_LIN_ABLATE"] = str(ab)
     t = timeit(lambda: hip.lin_forward(x, coef, 0.1, w))
     print("ablate", ab, "%.1f us" % t)
