@@ -27,12 +27,64 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
-def level1_select_roofline(B, device, iters=50):
-    """fused_conv_select_k at level 1 (64x1800 image, 3600 queries, 9x15 window, K=32).
-    Algorithmic bytes per sample: image 64*1800*12 + idx_n2 3600*8 read,
-    3600*32*(3*8+4) written = 1.41 MB + 3.23 MB = 4.64 MB."""
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* (fp32 in/acc) = the fp32 vector peak
+
+
+def _event_time_us(launch, iters):
+    for _ in range(3):
+        launch()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()                    # torch's current stream == the stream the kernels are launched on
+    for _ in range(iters):
+        launch()
+    end.record(); end.synchronize()
+    return start.elapsed_time(end) / iters * 1e3
+
+
+def kernel_rooflines(B, device):
+    """Live timings (events on the launch stream) of the hand-written kernels that dominate the step.
+
+    * lin_bwd_kernel<4,4>: backward of a 128->128 cost-volume layer on [B*228*468, 128] — BN-backward on
+      load, wgrad + dgrad on v_mfma_f32_32x32x2_f32, previous activation derivative + BN-backward
+      statistics in the epilogue.  MFMA-bound: 2 GEMMs x 2*rows*128*128 flop (SURVEY.md §8d counts the
+      same contraction, 15.1 GFLOP/sample forward for the whole pi-stage).
+    * lin_fwd2_kernel<8,pair>: forward of the factored first cost-volume layer (bilinear point x pixel
+      product formed on load, never materialised).
+    * fcsk_kernel<9>: level-1 fused_conv_select_k, HBM-bound on 4.64 MB/sample.
+    """
     from i2pnet_amd import ops, projectpn as P, synth
     hip = ops.hip_backend()
+    N, M, C = 228, 468, 128
+    rows = B * N * M
+    g = torch.Generator(device=device).manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g, device=device)
+    # --- lin_bwd 128 -> 128 with both BNs live ---------------------------------------------------------
+    x = rnd(rows, C); w = rnd(C, C) / C ** 0.5
+    gam = torch.ones(C, device=device); bet = torch.zeros(C, device=device)
+    sx = torch.zeros(ops.BN_REPLICAS * 2 * C, dtype=torch.float64, device=device)
+    hip._call("i2p_bn_stats", rows, C, hip._p(x, torch.float32, "x"), hip._p(sx, torch.float64, "s"), stream=hip._stream())
+    in_coef, in_mi = hip.bn_finalize(rows, sx, gam, bet, 1e-5)
+    y, sy = hip.lin_forward(x, in_coef, 0.1, w)
+    out_coef, out_mi = hip.bn_finalize(rows, sy, gam, bet, 1e-5)
+    gz = rnd(rows, C)
+    ods = torch.zeros(ops.BN_REPLICAS * 2 * C, dtype=torch.float64, device=device)
+    t_bwd = _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), 10)
+    flop_bwd = 2 * 2.0 * rows * C * C
+    bwd = {"kernel": "lin_bwd_kernel<4,4> (cost-volume 128->128 layer backward, fused BN-bwd/wgrad/dgrad/stats)",
+           "bound": "mfma", "achieved": round(flop_bwd / t_bwd / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(flop_bwd / t_bwd / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+           "avg_kernel_us": round(t_bwd, 1), "flop_per_launch": flop_bwd,
+           "hbm_bytes_per_launch_algorithmic": rows * C * 4 * 4, "note": "time includes the tiny dW partial-reduction kernel"}
+    del x, y, gz
+    # --- pair-mode forward (first cost-volume layer) -----------------------------------------------------
+    f = rnd(B, N, C); gk = rnd(B, M, C); bn = rnd(B, N, C); bk = rnd(B, M, C)
+    t_pf = _event_time_us(lambda: hip.pair_lin_forward(f, gk, bn, bk, w), 10)
+    flop_pf = 2.0 * rows * C * C
+    pf = {"kernel": "lin_fwd2_kernel<8,pair> (first cost-volume layer forward)", "bound": "mfma",
+          "achieved": round(flop_pf / t_pf / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+          "frac": round(flop_pf / t_pf / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "avg_kernel_us": round(t_pf, 1),
+          "hbm_GBps_on_output": round(rows * C * 4 / t_pf / 1e3, 1)}
+    # --- level-1 neighbour selection -----------------------------------------------------------------------
     raw = synth.lidar_scan(B, 8192, torch.Generator(device=device).manual_seed(0), device, layout="centre")
     img, _, _ = hip.project_seq(raw, [], 64, 1800, 2.0, -24.8)
     idx = P.get_stride_idx_cuda(B, 16, 225, 4, 8, device)
@@ -40,25 +92,15 @@ def level1_select_roofline(B, device, iters=50):
     sel = torch.zeros(3, B, 3600, 32, 1, dtype=torch.long, device=device)
     mask = torch.zeros(B, 3600, 32, 1, device=device)
     unused = torch.zeros(1, device=device)
-
-    def launch():
-        hip.fused_conv_select_k(img, img, idx, rhw, 64, 1800, 3600, 9, 15, 32, 3, 0.75, 1, 1, sel[0], sel[1], sel[2],
-                                unused, unused, mask, 64, 1800)
-    for _ in range(5):
-        launch()
-    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()                    # same stream the kernel is launched on (torch's current stream)
-    for _ in range(iters):
-        launch()
-    end.record(); end.synchronize()
-    avg_s = start.elapsed_time(end) / iters * 1e-3
-    bytes_per_launch = B * (64 * 1800 * 12 + 3600 * 8 + 3600 * 32 * 28)
-    achieved = bytes_per_launch / avg_s / 1e9
-    live = float((mask.view(B, 3600, 32)[:, :, 0] > 0).float().mean())
-    return {"kernel": "fcsk_kernel<9> (fused_conv_select_k, level 1)", "bound": "hbm", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "avg_kernel_us": round(avg_s * 1e6, 2), "bytes_per_launch": bytes_per_launch,
-            "live_query_frac": round(live, 3)}
+    t_sel = _event_time_us(lambda: hip.fused_conv_select_k(img, img, idx, rhw, 64, 1800, 3600, 9, 15, 32, 3, 0.75, 1, 1,
+                                                           sel[0], sel[1], sel[2], unused, unused, mask, 64, 1800), 50)
+    bytes_sel = B * (64 * 1800 * 12 + 3600 * 8 + 3600 * 32 * 28)
+    selk = {"kernel": "fcsk_kernel<9> (fused_conv_select_k, level 1, all 3600 queries live)", "bound": "hbm",
+            "achieved": round(bytes_sel / t_sel / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(bytes_sel / t_sel / 1e3 / HBM_PEAK_GBS, 4), "avg_kernel_us": round(t_sel, 2),
+            "bytes_per_launch": bytes_sel}
+    bwd["other_kernels"] = [pf, selk]
+    return bwd
 
 
 def cpu_baseline(cfg, batch_size=2, steps=2):
@@ -137,7 +179,7 @@ def main():
                                    "fp32 forward+loss+backward+clip+Adam" % (args.points, args.layout),
                        "per_gpu_batch": args.batch, "global_batch": global_batch,
                        "parallelism": f"dp{world}", "hipgraph": graph_live, "final_loss": round(float(loss), 4)},
-            "roofline": level1_select_roofline(args.batch, device),
+            "roofline": kernel_rooflines(args.batch, device),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
