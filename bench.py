@@ -105,10 +105,14 @@ def kernel_rooflines(B, device):
 
 def cpu_baseline(cfg, batch_size=2, steps=2):
     """the same training step on the host: PyTorch-CPU model + CPU oracle operators."""
-    from i2pnet_amd import ops, synth
+    from i2pnet_amd import modules, ops, synth
     from i2pnet_amd.train import Trainer
     from oracle import oracle
     prev = ops.set_backend(oracle.backend())
+    # the reference's CPU path = eager PyTorch-CPU (multi-threaded GEMM / BN) + CPU restatements of its
+    # CUDA operators; the oracle's scalar restatements of OUR fused kernels are checkers, not a baseline
+    fused = (modules.USE_FUSED_MLP, modules.USE_FUSED_BN)
+    modules.USE_FUSED_MLP = modules.USE_FUSED_BN = False
     try:
         tr = Trainer(cfg=cfg, device="cpu")
         batch = synth.make_batch(batch_size, 8192, 375, 1242, seed=0)
@@ -119,6 +123,7 @@ def cpu_baseline(cfg, batch_size=2, steps=2):
         dt = time.perf_counter() - t0
     finally:
         ops.set_backend(prev)
+        modules.USE_FUSED_MLP, modules.USE_FUSED_BN = fused
     return {"value": round(batch_size * steps / dt, 4), "unit": "samples/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": f"{steps} training steps at batch {batch_size} (same shapes), host cpu_count={os.cpu_count()}"}
 

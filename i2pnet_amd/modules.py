@@ -25,6 +25,8 @@ from .fused import mlp_stack, pair_fits, pair_linear
 
 # run Conv2d stacks on the fused MFMA layer kernels (csrc/mlp.hip); False = library GEMM + BN kernels per block
 USE_FUSED_MLP = True
+# batch-stat BN + activation through the fused bn_act kernels; False = plain torch ops (two-pass statistics)
+USE_FUSED_BN = True
 
 
 def run_stack(x, convs, first_bn=None):
@@ -113,9 +115,11 @@ class Conv2d(nn.Module):
             if self.bn_linear.track_running_stats:      # running-stat BN: the bias matters
                 y = y + self.conv.bias
                 y = self.bn_linear(y.reshape(-1, self.out_channels, 1, 1)).reshape(shape)
-            else:
+            elif USE_FUSED_BN:
                 slope = self.negative_slope if self.activation_fn else 1.0
                 return bn_act(y, self.bn_linear.weight, self.bn_linear.bias, slope)
+            else:
+                y = batch_stat_norm(y, self.bn_linear.weight, self.bn_linear.bias)
         else:
             y = y + self.conv.bias
         if self.activation_fn:
