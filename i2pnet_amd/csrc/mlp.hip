@@ -53,6 +53,15 @@ struct LinFwdParams {
     const float *bias_n;    // [B,N,cout_total] or nullptr
     const float *bias_k;    // [B,M,cout_total] or nullptr
     int pair_N, pair_M;
+    // dgrad mode (MODE 2 of lin_fwd2): x = gz [rows,cin] of the layer BEHIND, x2 = its pre-BN output,
+    // g_coef [5][cin] = {mean(gz), mean(gz*xhat), scale, mean, invstd}: the tile fed to the MFMAs is
+    // g^y = scale*(gz - m1 - xhat*m2).  w_transposed: Ws[o][k] = w[k*cout + o].  Store phase:
+    // out = acc * act'(z_prev) with z_prev from ex (pre-BN tensor in front) and e_coef/e_mi; sums
+    // receive { sum out, sum out*xhat_prev }.
+    const float *x2, *g_coef;
+    int w_transposed;
+    const float *ex, *e_coef, *e_mi;
+    float e_slope;
 };
 
 // (b,n,k) bookkeeping of pair mode without per-element 64-bit divisions: one division pair per
@@ -289,7 +298,7 @@ __device__ __forceinline__ void pair_row16(const PairTile &t, int d, int N, int 
     bn = t.bn0 + wrap; bk = b * M + k;
 }
 
-template <int NT16, bool PAIR>
+template <int NT16, bool PAIR, bool DGRAD>
 __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p) {
     extern __shared__ float smem[];
     const int ldk = p.ldk;                                  // max(cin, cout_p) + 2: 8-byte aligned rows
@@ -299,7 +308,9 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
 
     for (int i = tid; i < p.cout_p * p.cin; i += F2_THREADS) {
         const int co = i / p.cin, ci = i - co * p.cin;
-        Ws[co * ldk + ci] = (co < p.cout) ? p.w[(size_t)co * p.cin + ci] : 0.f;
+        float wv = 0.f;
+        if (co < p.cout) wv = (DGRAD && p.w_transposed) ? p.w[(size_t)ci * p.cout_total + p.ch_off + co] : p.w[(size_t)co * p.cin + ci];
+        Ws[co * ldk + ci] = wv;
     }
     __syncthreads();                                        // the only block barrier
 
@@ -327,6 +338,23 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
         cb = *reinterpret_cast<const float4 *>(p.in_coef + 2 * p.cin + in_c4[0] * 4);
     }
 
+    // dgrad: BN-backward constants of this lane's input channels, and of its output channels for the store phase
+    float4 g_m1 = cm, g_m2 = cm, g_sc = cs, g_mu = cm, g_is = cs;
+    if (DGRAD && p.g_coef) {
+        g_m1 = *reinterpret_cast<const float4 *>(p.g_coef + in_c4[0] * 4);
+        g_m2 = *reinterpret_cast<const float4 *>(p.g_coef + p.cin + in_c4[0] * 4);
+        g_sc = *reinterpret_cast<const float4 *>(p.g_coef + 2 * p.cin + in_c4[0] * 4);
+        g_mu = *reinterpret_cast<const float4 *>(p.g_coef + 3 * p.cin + in_c4[0] * 4);
+        g_is = *reinterpret_cast<const float4 *>(p.g_coef + 4 * p.cin + in_c4[0] * 4);
+    }
+    float4 e_mu = cm, e_sc = cs, e_be = cm, e_is = cs;
+    if (DGRAD && p.e_coef) {
+        e_mu = *reinterpret_cast<const float4 *>(p.e_coef + p.ch_off + o_c4 * 4);
+        e_sc = *reinterpret_cast<const float4 *>(p.e_coef + p.cout_total + p.ch_off + o_c4 * 4);
+        e_be = *reinterpret_cast<const float4 *>(p.e_coef + 2 * p.cout_total + p.ch_off + o_c4 * 4);
+        e_is = *reinterpret_cast<const float4 *>(p.e_mi + p.cout_total + p.ch_off + o_c4 * 4);
+    }
+
     double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
 
     const long long nstrips = (p.rows + F2_ROWS - 1) / F2_ROWS;
@@ -335,7 +363,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
     long long strip = (long long)blockIdx.x * 8 + wave;
 
     // all loads of a strip are issued back to back, no control flow in between (clamped addresses)
-    auto fetch = [&](long long st, float4 (&v)[F2_CH]) {
+    auto fetch = [&](long long st, float4 (&v)[F2_CH], float4 (&v2)[F2_CH]) {
         const long long row0 = st * F2_ROWS;
         PairTile pt; pt.bn0 = pt.k0 = pt.b0 = pt.n0 = 0;
         if (PAIR) pt = pair_tile(row0, p.pair_N, p.pair_M);
@@ -347,6 +375,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
             long long src = row;
             if (PAIR) { int bn, bk; pair_row16(pt, d, p.pair_N, p.pair_M, bn, bk); src = bk; }
             v[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)src * p.cin + in_c4[u] * 4);
+            if (DGRAD && p.g_coef) v2[u] = *reinterpret_cast<const float4 *>(p.x2 + (size_t)src * p.cin + in_c4[u] * 4);
         }
     };
 
@@ -354,7 +383,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
     //   MFMA(s) -> outputs of s to registers -> commit(s+1) [waits the loads issued one MFMA phase ago]
     //   -> stores(s) -> fetch(s+2).   The stores of a strip are thus always OLDER than the loads the next
     //   commit waits for, and both had a whole MFMA phase to land; no wait ever exposes store latency.
-    auto commit = [&](long long st, const float4 (&v)[F2_CH]) {
+    auto commit = [&](long long st, const float4 (&v)[F2_CH], const float4 (&v2)[F2_CH]) {
         const long long row0 = st * F2_ROWS;
         PairTile pt; pt.bn0 = pt.k0 = pt.b0 = pt.n0 = 0;
         if (PAIR) pt = pair_tile(row0, p.pair_N, p.pair_M);
@@ -368,7 +397,14 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
                 const float4 f = *reinterpret_cast<const float4 *>(p.pair_f + (size_t)bn * p.cin + in_c4[u] * 4);
                 t.x *= f.x; t.y *= f.y; t.z *= f.z; t.w *= f.w;
             }
-            if (p.in_coef) {                                // launcher guarantees one channel set per lane
+            if (DGRAD && p.g_coef) {                        // BN backward of the layer behind, formed on load
+                const float4 yv = v2[u];
+                t.x = g_sc.x * (t.x - g_m1.x - ((yv.x - g_mu.x) * g_is.x) * g_m2.x);
+                t.y = g_sc.y * (t.y - g_m1.y - ((yv.y - g_mu.y) * g_is.y) * g_m2.y);
+                t.z = g_sc.z * (t.z - g_m1.z - ((yv.z - g_mu.z) * g_is.z) * g_m2.z);
+                t.w = g_sc.w * (t.w - g_m1.w - ((yv.w - g_mu.w) * g_is.w) * g_m2.w);
+            }
+            if (!DGRAD && p.in_coef) {                      // launcher guarantees one channel set per lane
                 const float4 m = cm, sc = cs, bb = cb;
                 t.x = act_apply((t.x - m.x) * sc.x + bb.x, p.slope_in);
                 t.y = act_apply((t.y - m.y) * sc.y + bb.y, p.slope_in);
@@ -382,11 +418,13 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
         }
     };
 
-    float4 pf[F2_CH];
+    float4 pf[F2_CH], pf2[F2_CH];
+#pragma unroll
+    for (int u = 0; u < F2_CH; ++u) pf2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (strip < nstrips) {
-        fetch(strip, pf);
-        commit(strip, pf);
-        if (strip + sstride < nstrips) fetch(strip + sstride, pf);
+        fetch(strip, pf, pf2);
+        commit(strip, pf, pf2);
+        if (strip + sstride < nstrips) fetch(strip + sstride, pf, pf2);
     }
     for (; strip < nstrips; strip += sstride) {
         const long long row0 = strip * F2_ROWS;
@@ -456,7 +494,21 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
                     const float4 c = *reinterpret_cast<const float4 *>(p.bias_k + (size_t)bk * p.cout_total + p.ch_off + o_c4 * 4);
                     v.x = (v.x + a.x) + c.x; v.y = (v.y + a.y) + c.y; v.z = (v.z + a.z) + c.z; v.w = (v.w + a.w) + c.w;
                 }
-                if (row0 + r <= last_row) {
+                if (DGRAD) {
+                    if (p.e_coef) {
+                        long long er = row0 + r; if (er > last_row) er = last_row;
+                        const float4 xr = *reinterpret_cast<const float4 *>(p.ex + (size_t)er * p.y_ld + p.ch_off + o_c4 * 4);
+                        const float zx = (xr.x - e_mu.x) * e_sc.x + e_be.x, zy = (xr.y - e_mu.y) * e_sc.y + e_be.y;
+                        const float zz = (xr.z - e_mu.z) * e_sc.z + e_be.z, zw = (xr.w - e_mu.w) * e_sc.w + e_be.w;
+                        v.x = zx > 0.f ? v.x : v.x * p.e_slope; v.y = zy > 0.f ? v.y : v.y * p.e_slope;
+                        v.z = zz > 0.f ? v.z : v.z * p.e_slope; v.w = zw > 0.f ? v.w : v.w * p.e_slope;
+                        if (row0 + r <= last_row) {
+                            s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
+                            s2[0] = fmaf(v.x, (xr.x - e_mu.x) * e_is.x, s2[0]); s2[1] = fmaf(v.y, (xr.y - e_mu.y) * e_is.y, s2[1]);
+                            s2[2] = fmaf(v.z, (xr.z - e_mu.z) * e_is.z, s2[2]); s2[3] = fmaf(v.w, (xr.w - e_mu.w) * e_is.w, s2[3]);
+                        }
+                    }
+                } else if (row0 + r <= last_row) {
                     s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
                     s2[0] = fmaf(v.x, v.x, s2[0]); s2[1] = fmaf(v.y, v.y, s2[1]);
                     s2[2] = fmaf(v.z, v.z, s2[2]); s2[3] = fmaf(v.w, v.w, s2[3]);
@@ -467,14 +519,14 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) { ssum[q] += (double)s1[q]; ssq[q] += (double)s2[q]; }
         // ---- the strip is free again: stage the next one, then store this one's outputs ---------------------
-        if (strip + sstride < nstrips) commit(strip + sstride, pf);
+        if (strip + sstride < nstrips) commit(strip + sstride, pf, pf2);
 #pragma unroll
         for (int u = 0; u < OCH; ++u) {
             const int r = (lane + u * 64) >> o_shift;
             if (r < F2_ROWS && row0 + r <= last_row)
                 *reinterpret_cast<float4 *>(p.y + (size_t)(row0 + r) * p.y_ld + p.ch_off + o_c4 * 4) = ov[u];
         }
-        if (strip + 2 * sstride < nstrips) fetch(strip + 2 * sstride, pf);
+        if (strip + 2 * sstride < nstrips) fetch(strip + 2 * sstride, pf, pf2);
     }
 
     if (p.sums) {
@@ -492,30 +544,30 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
     }
 }
 
-template <int NT16, bool PAIR>
+template <int NT16, bool PAIR, bool DGRAD>
 int launch_fwd2(const LinFwdParams &p, hipStream_t st) {
     const size_t bytes = ((size_t)p.cout_p + 8 * F2_ROWS) * p.ldk * sizeof(float);
     if (bytes > 160 * 1024) return I2P_ERR_BAD_ARG;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lin_fwd2_kernel<NT16, PAIR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lin_fwd2_kernel<NT16, PAIR, DGRAD>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const long long nstrips = (p.rows + F2_ROWS - 1) / F2_ROWS;
     long long g = (nstrips + 7) / 8;
     const unsigned grid = (unsigned)(g < 256 ? (g < 1 ? 1 : g) : 256);
-    hipLaunchKernelGGL((lin_fwd2_kernel<NT16, PAIR>), dim3(grid), dim3(F2_THREADS), bytes, st, p);
+    hipLaunchKernelGGL((lin_fwd2_kernel<NT16, PAIR, DGRAD>), dim3(grid), dim3(F2_THREADS), bytes, st, p);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
-template <bool PAIR>
+template <bool PAIR, bool DGRAD>
 int dispatch_fwd2(const LinFwdParams &p, hipStream_t st) {
     switch (p.cout_p / 16) {
-        case 1: return launch_fwd2<1, PAIR>(p, st);
-        case 2: return launch_fwd2<2, PAIR>(p, st);
-        case 4: return launch_fwd2<4, PAIR>(p, st);
-        case 8: return launch_fwd2<8, PAIR>(p, st);
+        case 1: return launch_fwd2<1, PAIR, DGRAD>(p, st);
+        case 2: return launch_fwd2<2, PAIR, DGRAD>(p, st);
+        case 4: return launch_fwd2<4, PAIR, DGRAD>(p, st);
+        case 8: return launch_fwd2<8, PAIR, DGRAD>(p, st);
         default: return I2P_ERR_BAD_ARG;
     }
 }
@@ -1091,6 +1143,178 @@ __global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
     }
 }
 
+// =================================================================================================
+// Backward, second generation: dgrad runs on the lin_fwd2 template (DGRAD mode); wgrad is this
+// kernel.  dW[co][ci] = sum_r g^y[r][co] * x'[r][ci] with both operands formed on load
+// (BN-backward of (gz, y); BN + activation of x).  8 waves, double-buffered 64-row G / X' tiles in
+// LDS (no weights needed => 2 x 66 KB fits), one barrier per tile; within a barrier interval each
+// wave stages the next tile, issues the loads of the one after, and runs its MFMAs, so the two
+// waves of a SIMD overlap memory and matrix phases.
+// =================================================================================================
+struct WgradParams {
+    long long rows;
+    int cin, cout, cin_p, cout_p, ldg, ldx;
+    const float *gz, *y, *g_coef;        // g_coef [5][cout] or nullptr (gz already is dL/dy)
+    const float *x, *in_coef;            // in_coef [3][cin] or nullptr
+    float slope_in;
+    float *dw_partial;
+};
+
+constexpr int WG_THREADS = 512;
+constexpr int WG_R = 64;
+
+__global__ void bnbwd_coef_kernel(long long rows, int c, const double *__restrict__ dsums,
+                                  const float *__restrict__ coef, const float *__restrict__ mi, float *__restrict__ out) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double sd = 0.0, sx = 0.0;
+    for (int r = 0; r < REP; ++r) { sd += dsums[(size_t)r * 2 * c + ch]; sx += dsums[(size_t)r * 2 * c + c + ch]; }
+    out[ch] = (float)(sd / (double)rows); out[c + ch] = (float)(sx / (double)rows);
+    out[2 * c + ch] = coef[c + ch]; out[3 * c + ch] = mi[ch]; out[4 * c + ch] = mi[c + ch];
+}
+
+template <int NTI, int NTO>
+__global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p) {
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bufsz = WG_R * (p.ldg + p.ldx);
+    float *Ct = smem + 2 * (size_t)bufsz;                  // [5][cout] then [3][cin] constants
+    float *Cg = Ct, *Cx = Ct + 5 * p.cout;
+    constexpr int WT = NTO * NTI, WPW = (WT + 7) / 8;
+    constexpr int GCH = (WG_R * NTO * 8 + WG_THREADS - 1) / WG_THREADS;   // float4 chunks per thread
+    constexpr int XCH = (WG_R * NTI * 8 + WG_THREADS - 1) / WG_THREADS;
+    const int co4 = p.cout >> 2, ci4 = p.cin >> 2;
+
+    for (int i = tid; i < 5 * p.cout; i += WG_THREADS) Cg[i] = p.g_coef ? p.g_coef[i] : 0.f;
+    for (int i = tid; i < 3 * p.cin; i += WG_THREADS) Cx[i] = p.in_coef ? p.in_coef[i] : 0.f;
+    // zero the padding columns of both buffers once
+    for (int b = 0; b < 2; ++b) {
+        float *Gs = smem + (size_t)b * bufsz, *Xs = Gs + WG_R * p.ldg;
+        for (int i = tid; i < WG_R * (p.cout_p - p.cout); i += WG_THREADS)
+            Gs[(i / (p.cout_p - p.cout)) * p.ldg + p.cout + i % (p.cout_p - p.cout)] = 0.f;
+        for (int i = tid; i < WG_R * (p.cin_p - p.cin); i += WG_THREADS)
+            Xs[(i / (p.cin_p - p.cin)) * p.ldx + p.cin + i % (p.cin_p - p.cin)] = 0.f;
+    }
+    __syncthreads();
+
+    const long long ntiles = (p.rows + WG_R - 1) / WG_R;
+    const long long last_row = p.rows - 1;
+
+    float4 rg[GCH], ry[GCH], rx[XCH];
+    auto fetch = [&](long long tile) {
+        const long long row0 = tile * WG_R;
+#pragma unroll
+        for (int u = 0; u < GCH; ++u) {
+            int i = tid + u * WG_THREADS; if (i >= WG_R * co4) i = WG_R * co4 - 1;
+            const int r = i / co4, c4 = i - r * co4;
+            long long row = row0 + r; if (row > last_row) row = last_row;
+            rg[u] = *reinterpret_cast<const float4 *>(p.gz + (size_t)row * p.cout + c4 * 4);
+            if (p.g_coef) ry[u] = *reinterpret_cast<const float4 *>(p.y + (size_t)row * p.cout + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < XCH; ++u) {
+            int i = tid + u * WG_THREADS; if (i >= WG_R * ci4) i = WG_R * ci4 - 1;
+            const int r = i / ci4, c4 = i - r * ci4;
+            long long row = row0 + r; if (row > last_row) row = last_row;
+            rx[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)row * p.cin + c4 * 4);
+        }
+    };
+    auto commit = [&](long long tile, int buf) {
+        const long long row0 = tile * WG_R;
+        float *Gs = smem + (size_t)buf * bufsz, *Xs = Gs + WG_R * p.ldg;
+#pragma unroll
+        for (int u = 0; u < GCH; ++u) {
+            const int i = tid + u * WG_THREADS;
+            if (i < WG_R * co4) {
+                const int r = i / co4, c4 = i - r * co4;
+                float gv[4] = {rg[u].x, rg[u].y, rg[u].z, rg[u].w};
+                if (row0 + r > last_row) { gv[0] = gv[1] = gv[2] = gv[3] = 0.f; }    // rows past the end contribute nothing
+                else if (p.g_coef) {
+                    const float yy[4] = {ry[u].x, ry[u].y, ry[u].z, ry[u].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ch = c4 * 4 + q;
+                        const float xh = (yy[q] - Cg[3 * p.cout + ch]) * Cg[4 * p.cout + ch];
+                        gv[q] = Cg[2 * p.cout + ch] * (gv[q] - Cg[ch] - xh * Cg[p.cout + ch]);
+                    }
+                }
+                float *dst = Gs + r * p.ldg + c4 * 4;
+                dst[0] = gv[0]; dst[1] = gv[1]; dst[2] = gv[2]; dst[3] = gv[3];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < XCH; ++u) {
+            const int i = tid + u * WG_THREADS;
+            if (i < WG_R * ci4) {
+                const int r = i / ci4, c4 = i - r * ci4;
+                float v[4] = {rx[u].x, rx[u].y, rx[u].z, rx[u].w};
+                if (p.in_coef) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ch = c4 * 4 + q;
+                        v[q] = act_apply((v[q] - Cx[ch]) * Cx[p.cin + ch] + Cx[2 * p.cin + ch], p.slope_in);
+                    }
+                }
+                float *dst = Xs + r * p.ldx + c4 * 4;
+                dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+            }
+        }
+    };
+
+    f32x16 acc[WPW];
+#pragma unroll
+    for (int t = 0; t < WPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    long long tile = blockIdx.x;
+    int cur = 0;
+    if (tile < ntiles) {
+        fetch(tile); commit(tile, 0);
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+    }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+        if (tile + gridDim.x < ntiles) commit(tile + gridDim.x, cur ^ 1);
+        if (tile + 2 * (long long)gridDim.x < ntiles) fetch(tile + 2 * (long long)gridDim.x);
+        const float *Gs = smem + (size_t)cur * bufsz, *Xs = Gs + WG_R * p.ldg;
+#pragma unroll
+        for (int t = 0; t < WPW; ++t) {
+            const int tw = wave + 8 * t;
+            if (tw < WT) {
+                const int to = tw / NTI, ti = tw - to * NTI;
+                const float *ap = Gs + (lane >> 5) * p.ldg + to * 32 + (lane & 31);
+                const float *bp = Xs + (lane >> 5) * p.ldx + ti * 32 + (lane & 31);
+                float a0 = ap[0], b0 = bp[0], a1, b1;
+#pragma unroll 4
+                for (int kk = 0; kk < WG_R; kk += 4) {
+                    a1 = ap[(size_t)(kk + 2) * p.ldg]; b1 = bp[(size_t)(kk + 2) * p.ldx];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[t], 0, 0, 0);
+                    const int kn = kk + 4 < WG_R ? kk + 4 : kk + 2;
+                    a0 = ap[(size_t)kn * p.ldg]; b0 = bp[(size_t)kn * p.ldx];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    float *part = p.dw_partial + (size_t)blockIdx.x * p.cout * p.cin;
+#pragma unroll
+    for (int t = 0; t < WPW; ++t) {
+        const int tw = wave + 8 * t;
+        if (tw < WT) {
+            const int to = tw / NTI, ti = tw - to * NTI;
+            const int ci = ti * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = to * 32 + frag_row(e, lane);
+                if (co < p.cout && ci < p.cin) part[(size_t)co * p.cin + ci] = acc[t][e];
+            }
+        }
+    }
+}
+
 // dW = sum over blocks of the per-block partials: 32 outputs x 8 partial-lanes per block
 __global__ __launch_bounds__(256) void reduce_partials_kernel(int nparts, int n, const float *__restrict__ parts,
                                                                float *__restrict__ out) {
@@ -1162,7 +1386,8 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
                 p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.w = w + (size_t)off * cin; p.y = y; p.sums = sums;
                 p.y_ld = cout; p.ch_off = off; p.cout_total = cout; p.ablate = 0;
                 p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
-                const int rc = pair_f ? dispatch_fwd2<true>(p, st) : dispatch_fwd2<false>(p, st);
+                p.x2 = nullptr; p.g_coef = nullptr; p.w_transposed = 0; p.ex = p.e_coef = p.e_mi = nullptr; p.e_slope = 1.f;
+                const int rc = pair_f ? dispatch_fwd2<true, false>(p, st) : dispatch_fwd2<false, false>(p, st);
                 if (rc) return rc;
             }
             return 0;
@@ -1181,6 +1406,7 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
         p.y_ld = cout; p.ch_off = off; p.cout_total = cout;
         p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
         { const char *ab = getenv("I2P_LIN_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
+        p.x2 = nullptr; p.g_coef = nullptr; p.w_transposed = 0; p.ex = p.e_coef = p.e_mi = nullptr; p.e_slope = 1.f;
         int rc;
         switch (p.cout_p / 32) {
             case 1: rc = launch_fwd<1>(p, st); break;
@@ -1222,6 +1448,30 @@ extern "C" int i2p_lin_bwd_grid(long long rows) {
     return (int)(ntiles < 256 ? (ntiles < 1 ? 1 : ntiles) : 256);
 }
 
+template <int NTI, int NTO>
+static int launch_wgrad_t(const WgradParams &q, float *dw, hipStream_t st, unsigned grid, size_t bytes) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lin_wgrad_kernel<NTI, NTO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lin_wgrad_kernel<NTI, NTO>), dim3(grid), dim3(WG_THREADS), bytes, st, q);
+    const int n = q.cout * q.cin;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, q.dw_partial, dw);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+static int launch_wgrad(const WgradParams &q, float *dw, hipStream_t st, unsigned grid, size_t bytes) {
+    const int nti = q.cin_p / 32, nto = q.cout_p / 32;
+#define WG_CASE(I, O) if (nti == I && nto == O) return launch_wgrad_t<I, O>(q, dw, st, grid, bytes)
+    WG_CASE(1, 1); WG_CASE(1, 2); WG_CASE(1, 4); WG_CASE(2, 1); WG_CASE(2, 2); WG_CASE(2, 4);
+    WG_CASE(3, 1); WG_CASE(3, 2); WG_CASE(3, 4); WG_CASE(4, 1); WG_CASE(4, 2); WG_CASE(4, 4);
+    WG_CASE(5, 1); WG_CASE(5, 2); WG_CASE(5, 4);
+#undef WG_CASE
+    return I2P_ERR_BAD_ARG;
+}
+
 struct PairBwd { const float *f, *g; float *d_f, *d_g, *d_bn, *d_bk; int N, M; };
 
 static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, const float *y,
@@ -1247,6 +1497,38 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
     }
     const unsigned grid = (unsigned)i2p_lin_bwd_grid(rows);
     hipStream_t st = (hipStream_t)stream;
+    {   // second-generation path: separate dgrad (lin_fwd2 DGRAD) and wgrad kernels
+        auto pow2w = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
+        const char *gen = getenv("I2P_LIN_BWD_GEN");
+        const bool dgrad_ok = !gz_in || (pow2w(cin) && pow2w(cout));
+        const size_t wg_lds = (2 * (size_t)WG_R * (p.cout_p + 1 + p.cin_p + 1) + 5 * (size_t)cout + 3 * (size_t)cin) * sizeof(float);
+        if (!pair && !(gen && gen[0] == '1') && dgrad_ok && pow2w(cout) && wg_lds <= 160 * 1024 && cin <= 160) {
+            float *g_coef = nullptr;
+            if (out_coef) {
+                g_coef = dw_partial + (size_t)grid * cout * cin;                 // 5*cout floats behind the partials
+                hipLaunchKernelGGL(bnbwd_coef_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, rows, cout, out_dsums, out_coef,
+                                   out_mi, g_coef);
+            }
+            if (gz_in) {
+                LinFwdParams q;
+                q.rows = rows; q.cin = cout; q.cout = cin; q.cin_p = cout; q.cout_p = cin;
+                q.ldk = (cout > cin ? cout : cin) + 2;
+                q.x = gz; q.x2 = y; q.g_coef = g_coef; q.in_coef = nullptr; q.slope_in = 1.f;
+                q.w = w; q.w_transposed = 1; q.y = gz_in; q.sums = in_coef ? in_dsums : nullptr;
+                q.y_ld = cin; q.ch_off = 0; q.cout_total = cin; q.ablate = 0;
+                q.pair_f = q.bias_n = q.bias_k = nullptr; q.pair_N = q.pair_M = 1;
+                q.ex = in_coef ? x : nullptr; q.e_coef = in_coef; q.e_mi = in_mi; q.e_slope = slope_in;
+                const int rc = dispatch_fwd2<false, true>(q, st);
+                if (rc) return rc;
+            }
+            WgradParams wq;
+            wq.rows = rows; wq.cin = cin; wq.cout = cout; wq.cin_p = p.cin_p; wq.cout_p = p.cout_p;
+            wq.ldg = p.cout_p + 1; wq.ldx = p.cin_p + 1;
+            wq.gz = gz; wq.y = y; wq.g_coef = g_coef; wq.x = x; wq.in_coef = in_coef; wq.slope_in = slope_in;
+            wq.dw_partial = dw_partial;
+            return launch_wgrad(wq, dw, st, grid, wg_lds);
+        }
+    }
     switch (p.cin_p / 32) {
         case 1: return dispatch_bwd_o<1>(p, dw, st, grid);
         case 2: return dispatch_bwd_o<2>(p, dw, st, grid);

@@ -214,7 +214,7 @@ class CBackend:
         in_dsums = (torch.zeros(BN_REPLICAS * 2 * cin, dtype=torch.float64, device=dev)
                     if (need_gx and in_coef is not None) else None)
         grid = 256 if self.device_type == "cuda" else 1
-        part = torch.empty(min(grid, (rows + 63) // 64) * cout * cin, dtype=_F32, device=dev)
+        part = torch.empty(min(grid, (rows + 63) // 64) * cout * cin + 8 * cout, dtype=_F32, device=dev)
         dw = torch.empty(cout, cin, dtype=_F32, device=dev)
         P = lambda t, dt=_F32, n="t": (self._p(t, dt, n) if t is not None else None)
         self._call("i2p_lin_bwd", int(rows), int(cin), int(cout), P(gz, _F32, "gz"), P(y, _F32, "y"),

@@ -217,7 +217,7 @@ int i2p_bn_finalize(long long rows, int c, const double *sums, const float *gamm
  * gz f32 [rows,cout]; y f32 [rows,cout]; out_coef [3][cout], out_mi [2][cout] (mean, invstd),
  * out_dsums replicated {sum gz, sum gz*xhat_out}; x f32 [rows,cin] the previous pre-BN tensor with
  * in_coef [3][cin], in_mi [2][cin] (or both NULL: x is the raw layer input, gz_in = dL/dx);
- * dw_partial f32 scratch [i2p_lin_bwd_grid(rows)][cout*cin].  cin, cout multiples of 4, <= 160 / 128. */
+ * dw_partial f32 scratch of i2p_lin_bwd_grid(rows)*cout*cin + 8*cout floats.  cin, cout multiples of 4, <= 160 / 128. */
 int i2p_lin_bwd_grid(long long rows);
 int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, const float *y,
                 const float *out_coef, const float *out_mi, const double *out_dsums, const float *x,
