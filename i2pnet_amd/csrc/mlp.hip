@@ -1200,6 +1200,23 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
     const long long ntiles = (p.rows + WG_R - 1) / WG_R;
     const long long last_row = p.rows - 1;
 
+    // chunk geometry and per-channel constants of this thread: fixed for the whole kernel when the float4
+    // column count divides the block size (all power-of-two widths); otherwise constants come from the LDS table
+    const bool g_fix = (WG_THREADS % co4) == 0, x_fix = (WG_THREADS % ci4) == 0;
+    float4 k_m1 = make_float4(0.f, 0.f, 0.f, 0.f), k_m2 = k_m1, k_sc = make_float4(1.f, 1.f, 1.f, 1.f), k_mu = k_m1, k_is = k_sc;
+    float4 x_mu = k_m1, x_sc = k_sc, x_be = k_m1;
+    if (p.g_coef && g_fix) {
+        const int c4 = tid % co4;
+        k_m1 = *reinterpret_cast<const float4 *>(p.g_coef + c4 * 4); k_m2 = *reinterpret_cast<const float4 *>(p.g_coef + p.cout + c4 * 4);
+        k_sc = *reinterpret_cast<const float4 *>(p.g_coef + 2 * p.cout + c4 * 4); k_mu = *reinterpret_cast<const float4 *>(p.g_coef + 3 * p.cout + c4 * 4);
+        k_is = *reinterpret_cast<const float4 *>(p.g_coef + 4 * p.cout + c4 * 4);
+    }
+    if (p.in_coef && x_fix) {
+        const int c4 = tid % ci4;
+        x_mu = *reinterpret_cast<const float4 *>(p.in_coef + c4 * 4); x_sc = *reinterpret_cast<const float4 *>(p.in_coef + p.cin + c4 * 4);
+        x_be = *reinterpret_cast<const float4 *>(p.in_coef + 2 * p.cin + c4 * 4);
+    }
+
     float4 rg[GCH], ry[GCH], rx[XCH];
     auto fetch = [&](long long tile) {
         const long long row0 = tile * WG_R;
@@ -1227,19 +1244,20 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
             const int i = tid + u * WG_THREADS;
             if (i < WG_R * co4) {
                 const int r = i / co4, c4 = i - r * co4;
-                float gv[4] = {rg[u].x, rg[u].y, rg[u].z, rg[u].w};
-                if (row0 + r > last_row) { gv[0] = gv[1] = gv[2] = gv[3] = 0.f; }    // rows past the end contribute nothing
+                float4 g = rg[u];
+                if (row0 + r > last_row) g = make_float4(0.f, 0.f, 0.f, 0.f);         // rows past the end contribute nothing
                 else if (p.g_coef) {
-                    const float yy[4] = {ry[u].x, ry[u].y, ry[u].z, ry[u].w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int ch = c4 * 4 + q;
-                        const float xh = (yy[q] - Cg[3 * p.cout + ch]) * Cg[4 * p.cout + ch];
-                        gv[q] = Cg[2 * p.cout + ch] * (gv[q] - Cg[ch] - xh * Cg[p.cout + ch]);
+                    float4 m1 = k_m1, m2 = k_m2, sc = k_sc, mu = k_mu, is = k_is;
+                    if (!g_fix) {
+                        m1 = *reinterpret_cast<const float4 *>(Cg + c4 * 4); m2 = *reinterpret_cast<const float4 *>(Cg + p.cout + c4 * 4);
+                        sc = *reinterpret_cast<const float4 *>(Cg + 2 * p.cout + c4 * 4); mu = *reinterpret_cast<const float4 *>(Cg + 3 * p.cout + c4 * 4);
+                        is = *reinterpret_cast<const float4 *>(Cg + 4 * p.cout + c4 * 4);
                     }
+                    const float4 yv = ry[u];
+                    g.x = sc.x * (g.x - m1.x - ((yv.x - mu.x) * is.x) * m2.x); g.y = sc.y * (g.y - m1.y - ((yv.y - mu.y) * is.y) * m2.y);
+                    g.z = sc.z * (g.z - m1.z - ((yv.z - mu.z) * is.z) * m2.z); g.w = sc.w * (g.w - m1.w - ((yv.w - mu.w) * is.w) * m2.w);
                 }
-                float *dst = Gs + r * p.ldg + c4 * 4;
-                dst[0] = gv[0]; dst[1] = gv[1]; dst[2] = gv[2]; dst[3] = gv[3];
+                *reinterpret_cast<float4 *>(Gs + r * p.ldg + c4 * 4) = g;
             }
         }
 #pragma unroll
@@ -1247,16 +1265,17 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
             const int i = tid + u * WG_THREADS;
             if (i < WG_R * ci4) {
                 const int r = i / ci4, c4 = i - r * ci4;
-                float v[4] = {rx[u].x, rx[u].y, rx[u].z, rx[u].w};
+                float4 v = rx[u];
                 if (p.in_coef) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int ch = c4 * 4 + q;
-                        v[q] = act_apply((v[q] - Cx[ch]) * Cx[p.cin + ch] + Cx[2 * p.cin + ch], p.slope_in);
+                    float4 mu = x_mu, sc = x_sc, be = x_be;
+                    if (!x_fix) {
+                        mu = *reinterpret_cast<const float4 *>(Cx + c4 * 4); sc = *reinterpret_cast<const float4 *>(Cx + p.cin + c4 * 4);
+                        be = *reinterpret_cast<const float4 *>(Cx + 2 * p.cin + c4 * 4);
                     }
+                    v.x = act_apply((v.x - mu.x) * sc.x + be.x, p.slope_in); v.y = act_apply((v.y - mu.y) * sc.y + be.y, p.slope_in);
+                    v.z = act_apply((v.z - mu.z) * sc.z + be.z, p.slope_in); v.w = act_apply((v.w - mu.w) * sc.w + be.w, p.slope_in);
                 }
-                float *dst = Xs + r * p.ldx + c4 * 4;
-                dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+                *reinterpret_cast<float4 *>(Xs + r * p.ldx + c4 * 4) = v;
             }
         }
     };
@@ -1501,7 +1520,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
         auto pow2w = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
         const char *gen = getenv("I2P_LIN_BWD_GEN");
         const bool dgrad_ok = !gz_in || (pow2w(cin) && pow2w(cout));
-        const size_t wg_lds = (2 * (size_t)WG_R * (p.cout_p + 1 + p.cin_p + 1) + 5 * (size_t)cout + 3 * (size_t)cin) * sizeof(float);
+        const size_t wg_lds = (2 * (size_t)WG_R * (p.cout_p + p.cin_p) + 5 * (size_t)cout + 3 * (size_t)cin) * sizeof(float);
         if (!pair && !(gen && gen[0] == '1') && dgrad_ok && pow2w(cout) && wg_lds <= 160 * 1024 && cin <= 160) {
             float *g_coef = nullptr;
             if (out_coef) {
@@ -1523,7 +1542,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
             }
             WgradParams wq;
             wq.rows = rows; wq.cin = cin; wq.cout = cout; wq.cin_p = p.cin_p; wq.cout_p = p.cout_p;
-            wq.ldg = p.cout_p + 1; wq.ldx = p.cin_p + 1;
+            wq.ldg = p.cout_p; wq.ldx = p.cin_p;        // 16-B aligned rows; fragments are read along channels
             wq.gz = gz; wq.y = y; wq.g_coef = g_coef; wq.x = x; wq.in_coef = in_coef; wq.slope_in = slope_in;
             wq.dw_partial = dw_partial;
             return launch_wgrad(wq, dw, st, grid, wg_lds);
