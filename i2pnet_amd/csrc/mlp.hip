@@ -1173,7 +1173,7 @@ __global__ void bnbwd_coef_kernel(long long rows, int c, const double *__restric
     out[2 * c + ch] = coef[c + ch]; out[3 * c + ch] = mi[ch]; out[4 * c + ch] = mi[c + ch];
 }
 
-template <int NTI, int NTO>
+template <int NTI, int NTO, bool FIXC>
 __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p) {
     extern __shared__ float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
 
     // chunk geometry and per-channel constants of this thread: fixed for the whole kernel when the float4
     // column count divides the block size (all power-of-two widths); otherwise constants come from the LDS table
-    const bool g_fix = (WG_THREADS % co4) == 0, x_fix = (WG_THREADS % ci4) == 0;
+    constexpr bool g_fix = FIXC, x_fix = FIXC;
     float4 k_m1 = make_float4(0.f, 0.f, 0.f, 0.f), k_m2 = k_m1, k_sc = make_float4(1.f, 1.f, 1.f, 1.f), k_mu = k_m1, k_is = k_sc;
     float4 x_mu = k_m1, x_sc = k_sc, x_be = k_m1;
     if (p.g_coef && g_fix) {
@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
                 if (row0 + r > last_row) g = make_float4(0.f, 0.f, 0.f, 0.f);         // rows past the end contribute nothing
                 else if (p.g_coef) {
                     float4 m1 = k_m1, m2 = k_m2, sc = k_sc, mu = k_mu, is = k_is;
-                    if (!g_fix) {
+                    if constexpr (!g_fix) {
                         m1 = *reinterpret_cast<const float4 *>(Cg + c4 * 4); m2 = *reinterpret_cast<const float4 *>(Cg + p.cout + c4 * 4);
                         sc = *reinterpret_cast<const float4 *>(Cg + 2 * p.cout + c4 * 4); mu = *reinterpret_cast<const float4 *>(Cg + 3 * p.cout + c4 * 4);
                         is = *reinterpret_cast<const float4 *>(Cg + 4 * p.cout + c4 * 4);
@@ -1268,7 +1268,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
                 float4 v = rx[u];
                 if (p.in_coef) {
                     float4 mu = x_mu, sc = x_sc, be = x_be;
-                    if (!x_fix) {
+                    if constexpr (!x_fix) {
                         mu = *reinterpret_cast<const float4 *>(Cx + c4 * 4); sc = *reinterpret_cast<const float4 *>(Cx + p.cin + c4 * 4);
                         be = *reinterpret_cast<const float4 *>(Cx + 2 * p.cin + c4 * 4);
                     }
@@ -1467,15 +1467,15 @@ extern "C" int i2p_lin_bwd_grid(long long rows) {
     return (int)(ntiles < 256 ? (ntiles < 1 ? 1 : ntiles) : 256);
 }
 
-template <int NTI, int NTO>
+template <int NTI, int NTO, bool FIXC>
 static int launch_wgrad_t(const WgradParams &q, float *dw, hipStream_t st, unsigned grid, size_t bytes) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lin_wgrad_kernel<NTI, NTO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lin_wgrad_kernel<NTI, NTO, FIXC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((lin_wgrad_kernel<NTI, NTO>), dim3(grid), dim3(WG_THREADS), bytes, st, q);
+    hipLaunchKernelGGL((lin_wgrad_kernel<NTI, NTO, FIXC>), dim3(grid), dim3(WG_THREADS), bytes, st, q);
     const int n = q.cout * q.cin;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, q.dw_partial, dw);
     I2P_RETURN_LAUNCH_STATUS();
@@ -1483,7 +1483,8 @@ static int launch_wgrad_t(const WgradParams &q, float *dw, hipStream_t st, unsig
 
 static int launch_wgrad(const WgradParams &q, float *dw, hipStream_t st, unsigned grid, size_t bytes) {
     const int nti = q.cin_p / 32, nto = q.cout_p / 32;
-#define WG_CASE(I, O) if (nti == I && nto == O) return launch_wgrad_t<I, O>(q, dw, st, grid, bytes)
+    const bool fixc = (WG_THREADS % (q.cout >> 2)) == 0 && (WG_THREADS % (q.cin >> 2)) == 0;
+#define WG_CASE(I, O) if (nti == I && nto == O) return fixc ? launch_wgrad_t<I, O, true>(q, dw, st, grid, bytes) : launch_wgrad_t<I, O, false>(q, dw, st, grid, bytes)
     WG_CASE(1, 1); WG_CASE(1, 2); WG_CASE(1, 4); WG_CASE(2, 1); WG_CASE(2, 2); WG_CASE(2, 4);
     WG_CASE(3, 1); WG_CASE(3, 2); WG_CASE(3, 4); WG_CASE(4, 1); WG_CASE(4, 2); WG_CASE(4, 4);
     WG_CASE(5, 1); WG_CASE(5, 2); WG_CASE(5, 4);
