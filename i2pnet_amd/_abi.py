@@ -34,6 +34,10 @@ SIGNATURES = {
     "i2p_lin_bwd": ["l", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 5,
     "i2p_pair_lin_fwd": ["i"] * 5 + ["p"] * 7,
     "i2p_pair_lin_bwd": ["i"] * 5 + ["p"] * 14,
+    "i2p_lin_fwd_2src": ["l", "i", "i", "i", "p", "p", "f", "p", "p", "f", "p", "p", "p"],
+    "i2p_lin_bwd_2src": ["l", "i", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 3 + ["f"] + ["p"] * 8,
+    "i2p_cv_softmax_wsum_fwd": ["i"] * 4 + ["p", "p", "f", "p", "p", "f", "p", "p"],
+    "i2p_cv_softmax_wsum_bwd": ["i"] * 4 + ["p"] * 6 + ["f", "p", "p", "f", "p", "p", "p"],
 }
 
 _CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "p": C.c_void_p, "pp": C.c_void_p}

@@ -62,6 +62,15 @@ struct LinFwdParams {
     int w_transposed;
     const float *ex, *e_coef, *e_mi;
     float e_slope;
+    // two-source mode (input = [x | xb] along channels, no concatenated tensor): the first split_c
+    // channels come from x [rows, split_c] with in_coef/slope_in, the rest from xb [rows, cin-split_c]
+    // with in_coef_b/slope_b.  In DGRAD mode the OUTPUT is split the same way: columns < split_c go
+    // to y/ex/e_coef/sums, the rest to yb/exb/e_coef_b/sums_b, and e_add [rows, cout-split_c] (dL/da
+    // arriving from another consumer of that activation) is added before the activation derivative.
+    int split_c;
+    const float *xb, *in_coef_b;
+    float slope_b;
+    float *yb; const float *exb, *e_coef_b, *e_mi_b, *e_add; double *sums_b; float e_slope_b;
 };
 
 // (b,n,k) bookkeeping of pair mode without per-element 64-bit divisions: one division pair per
@@ -331,11 +340,18 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
     constexpr int OCH = F2_CH;                              // <= 8 output chunks per lane (16 rows x 32 float4)
 
     // BN coefficients of the input chunks (loaded once; 3 float4 per chunk slot when they differ per slot)
+    // input source of this lane (its channel set is the same in every chunk slot)
+    const bool in_b = !DGRAD && p.xb && in_c4[0] * 4 >= p.split_c;
+    const float *src_x = in_b ? p.xb : p.x;
+    const int src_ld = (!DGRAD && p.xb) ? (in_b ? p.cin - p.split_c : p.split_c) : p.cin;
+    const int src_c0 = in_b ? in_c4[0] * 4 - p.split_c : in_c4[0] * 4;
+    const float *src_coef = in_b ? p.in_coef_b : p.in_coef;
+    const float in_slope = in_b ? p.slope_b : p.slope_in;
     float4 cm = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(1.f, 1.f, 1.f, 1.f), cb = cm;
-    if (p.in_coef) {                                        // (cin/4) divides 64: every slot of a lane has the same channels
-        cm = *reinterpret_cast<const float4 *>(p.in_coef + in_c4[0] * 4);
-        cs = *reinterpret_cast<const float4 *>(p.in_coef + p.cin + in_c4[0] * 4);
-        cb = *reinterpret_cast<const float4 *>(p.in_coef + 2 * p.cin + in_c4[0] * 4);
+    if (src_coef) {                                         // (cin/4) divides 64: every slot of a lane has the same channels
+        cm = *reinterpret_cast<const float4 *>(src_coef + src_c0);
+        cs = *reinterpret_cast<const float4 *>(src_coef + src_ld + src_c0);
+        cb = *reinterpret_cast<const float4 *>(src_coef + 2 * src_ld + src_c0);
     }
 
     // dgrad: BN-backward constants of this lane's input channels, and of its output channels for the store phase
@@ -347,12 +363,24 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
         g_mu = *reinterpret_cast<const float4 *>(p.g_coef + 3 * p.cin + in_c4[0] * 4);
         g_is = *reinterpret_cast<const float4 *>(p.g_coef + 4 * p.cin + in_c4[0] * 4);
     }
-    float4 e_mu = cm, e_sc = cs, e_be = cm, e_is = cs;
-    if (DGRAD && p.e_coef) {
-        e_mu = *reinterpret_cast<const float4 *>(p.e_coef + p.ch_off + o_c4 * 4);
-        e_sc = *reinterpret_cast<const float4 *>(p.e_coef + p.cout_total + p.ch_off + o_c4 * 4);
-        e_be = *reinterpret_cast<const float4 *>(p.e_coef + 2 * p.cout_total + p.ch_off + o_c4 * 4);
-        e_is = *reinterpret_cast<const float4 *>(p.e_mi + p.cout_total + p.ch_off + o_c4 * 4);
+    // output destination of this lane's 4 channels (DGRAD two-destination mode splits the columns)
+    const bool out_b = DGRAD && p.yb && (p.ch_off + o_c4 * 4) >= p.split_c;
+    float *dst_y = out_b ? p.yb : p.y;
+    const int dst_ld = (DGRAD && p.yb) ? (out_b ? p.cout_total - p.split_c : p.split_c) : p.y_ld;
+    const int dst_c0 = (DGRAD && p.yb) ? (out_b ? p.ch_off + o_c4 * 4 - p.split_c : p.ch_off + o_c4 * 4) : p.ch_off + o_c4 * 4;
+    const float *e_x = out_b ? p.exb : p.ex;
+    const float *e_cf = out_b ? p.e_coef_b : p.e_coef;
+    const float *e_m = out_b ? p.e_mi_b : p.e_mi;
+    const float e_sl = out_b ? p.e_slope_b : p.e_slope;
+    const float *e_ad = out_b ? p.e_add : nullptr;
+    double *dst_sums = out_b ? p.sums_b : p.sums;
+    const int sums_c = (DGRAD && p.yb) ? dst_ld : p.cout_total;
+    float4 e_mu = make_float4(0.f, 0.f, 0.f, 0.f), e_sc = make_float4(1.f, 1.f, 1.f, 1.f), e_be = e_mu, e_is = e_sc;
+    if (DGRAD && e_cf) {
+        e_mu = *reinterpret_cast<const float4 *>(e_cf + dst_c0);
+        e_sc = *reinterpret_cast<const float4 *>(e_cf + dst_ld + dst_c0);
+        e_be = *reinterpret_cast<const float4 *>(e_cf + 2 * dst_ld + dst_c0);
+        e_is = *reinterpret_cast<const float4 *>(e_m + dst_ld + dst_c0);
     }
 
     double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
@@ -374,7 +402,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
             if (row > last_row) { d = (int)(last_row - row0); row = last_row; }
             long long src = row;
             if (PAIR) { int bn, bk; pair_row16(pt, d, p.pair_N, p.pair_M, bn, bk); src = bk; }
-            v[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)src * p.cin + in_c4[u] * 4);
+            v[u] = *reinterpret_cast<const float4 *>(src_x + (size_t)src * src_ld + src_c0);
             if (DGRAD && p.g_coef) v2[u] = *reinterpret_cast<const float4 *>(p.x2 + (size_t)src * p.cin + in_c4[u] * 4);
         }
     };
@@ -404,12 +432,12 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
                 t.z = g_sc.z * (t.z - g_m1.z - ((yv.z - g_mu.z) * g_is.z) * g_m2.z);
                 t.w = g_sc.w * (t.w - g_m1.w - ((yv.w - g_mu.w) * g_is.w) * g_m2.w);
             }
-            if (!DGRAD && p.in_coef) {                      // launcher guarantees one channel set per lane
+            if (!DGRAD && src_coef) {                       // launcher guarantees one channel set per lane
                 const float4 m = cm, sc = cs, bb = cb;
-                t.x = act_apply((t.x - m.x) * sc.x + bb.x, p.slope_in);
-                t.y = act_apply((t.y - m.y) * sc.y + bb.y, p.slope_in);
-                t.z = act_apply((t.z - m.z) * sc.z + bb.z, p.slope_in);
-                t.w = act_apply((t.w - m.w) * sc.w + bb.w, p.slope_in);
+                t.x = act_apply((t.x - m.x) * sc.x + bb.x, in_slope);
+                t.y = act_apply((t.y - m.y) * sc.y + bb.y, in_slope);
+                t.z = act_apply((t.z - m.z) * sc.z + bb.z, in_slope);
+                t.w = act_apply((t.w - m.w) * sc.w + bb.w, in_slope);
             }
             if (in_ok[u]) {
                 float2 *dst = reinterpret_cast<float2 *>(As + in_r[u] * ldk + in_c4[u] * 4);
@@ -495,13 +523,18 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
                     v.x = (v.x + a.x) + c.x; v.y = (v.y + a.y) + c.y; v.z = (v.z + a.z) + c.z; v.w = (v.w + a.w) + c.w;
                 }
                 if (DGRAD) {
-                    if (p.e_coef) {
+                    if (e_ad) {
                         long long er = row0 + r; if (er > last_row) er = last_row;
-                        const float4 xr = *reinterpret_cast<const float4 *>(p.ex + (size_t)er * p.y_ld + p.ch_off + o_c4 * 4);
+                        const float4 ad = *reinterpret_cast<const float4 *>(e_ad + (size_t)er * dst_ld + dst_c0);
+                        v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                    }
+                    if (e_cf) {
+                        long long er = row0 + r; if (er > last_row) er = last_row;
+                        const float4 xr = *reinterpret_cast<const float4 *>(e_x + (size_t)er * dst_ld + dst_c0);
                         const float zx = (xr.x - e_mu.x) * e_sc.x + e_be.x, zy = (xr.y - e_mu.y) * e_sc.y + e_be.y;
                         const float zz = (xr.z - e_mu.z) * e_sc.z + e_be.z, zw = (xr.w - e_mu.w) * e_sc.w + e_be.w;
-                        v.x = zx > 0.f ? v.x : v.x * p.e_slope; v.y = zy > 0.f ? v.y : v.y * p.e_slope;
-                        v.z = zz > 0.f ? v.z : v.z * p.e_slope; v.w = zw > 0.f ? v.w : v.w * p.e_slope;
+                        v.x = zx > 0.f ? v.x : v.x * e_sl; v.y = zy > 0.f ? v.y : v.y * e_sl;
+                        v.z = zz > 0.f ? v.z : v.z * e_sl; v.w = zw > 0.f ? v.w : v.w * e_sl;
                         if (row0 + r <= last_row) {
                             s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
                             s2[0] = fmaf(v.x, (xr.x - e_mu.x) * e_is.x, s2[0]); s2[1] = fmaf(v.y, (xr.y - e_mu.y) * e_is.y, s2[1]);
@@ -524,21 +557,20 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
         for (int u = 0; u < OCH; ++u) {
             const int r = (lane + u * 64) >> o_shift;
             if (r < F2_ROWS && row0 + r <= last_row)
-                *reinterpret_cast<float4 *>(p.y + (size_t)(row0 + r) * p.y_ld + p.ch_off + o_c4 * 4) = ov[u];
+                *reinterpret_cast<float4 *>(dst_y + (size_t)(row0 + r) * dst_ld + dst_c0) = ov[u];
         }
         if (strip + 2 * sstride < nstrips) fetch(strip + 2 * sstride, pf, pf2);
     }
 
-    if (p.sums) {
+    if (p.sums || (DGRAD && p.sums_b)) {
         // lanes with equal (lane & (o4n-1)) own the same 4 channels
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             double a = ssum[q], b = ssq[q];
             for (int off = 32; off >= o4n; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
-            if (lane < o4n) {
-                const int ch = lane * 4 + q;
-                double *rep = p.sums + (size_t)((blockIdx.x * 8 + wave) % REP) * 2 * p.cout_total;
-                atomicAdd(rep + p.ch_off + ch, a); atomicAdd(rep + p.cout_total + p.ch_off + ch, b);
+            if (lane < o4n && dst_sums) {
+                double *rep = dst_sums + (size_t)((blockIdx.x * 8 + wave) % REP) * 2 * sums_c;
+                atomicAdd(rep + dst_c0 + q, a); atomicAdd(rep + sums_c + dst_c0 + q, b);
             }
         }
     }
@@ -1158,6 +1190,9 @@ struct WgradParams {
     const float *x, *in_coef;            // in_coef [3][cin] or nullptr
     float slope_in;
     float *dw_partial;
+    int split_c;                         // two-source input: channels >= split_c come from xb / in_coef_b / slope_b
+    const float *xb, *in_coef_b;
+    float slope_b;
 };
 
 constexpr int WG_THREADS = 512;
@@ -1211,10 +1246,16 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
         k_sc = *reinterpret_cast<const float4 *>(p.g_coef + 2 * p.cout + c4 * 4); k_mu = *reinterpret_cast<const float4 *>(p.g_coef + 3 * p.cout + c4 * 4);
         k_is = *reinterpret_cast<const float4 *>(p.g_coef + 4 * p.cout + c4 * 4);
     }
-    if (p.in_coef && x_fix) {
-        const int c4 = tid % ci4;
-        x_mu = *reinterpret_cast<const float4 *>(p.in_coef + c4 * 4); x_sc = *reinterpret_cast<const float4 *>(p.in_coef + p.cin + c4 * 4);
-        x_be = *reinterpret_cast<const float4 *>(p.in_coef + 2 * p.cin + c4 * 4);
+    // source of this thread's X' chunks (two-source mode needs the per-thread-constant layout)
+    const bool x_b = p.xb && (tid % ci4) * 4 >= p.split_c;
+    const float *xs_ptr = x_b ? p.xb : p.x;
+    const int xs_ld = p.xb ? (x_b ? p.cin - p.split_c : p.split_c) : p.cin;
+    const int xs_c0 = x_b ? (tid % ci4) * 4 - p.split_c : (tid % ci4) * 4;
+    const float *xs_coef = x_b ? p.in_coef_b : p.in_coef;
+    const float xs_slope = x_b ? p.slope_b : p.slope_in;
+    if (xs_coef && x_fix) {
+        x_mu = *reinterpret_cast<const float4 *>(xs_coef + xs_c0); x_sc = *reinterpret_cast<const float4 *>(xs_coef + xs_ld + xs_c0);
+        x_be = *reinterpret_cast<const float4 *>(xs_coef + 2 * xs_ld + xs_c0);
     }
 
     float4 rg[GCH], ry[GCH], rx[XCH];
@@ -1233,7 +1274,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
             int i = tid + u * WG_THREADS; if (i >= WG_R * ci4) i = WG_R * ci4 - 1;
             const int r = i / ci4, c4 = i - r * ci4;
             long long row = row0 + r; if (row > last_row) row = last_row;
-            rx[u] = *reinterpret_cast<const float4 *>(p.x + (size_t)row * p.cin + c4 * 4);
+            rx[u] = x_fix ? *reinterpret_cast<const float4 *>(xs_ptr + (size_t)row * xs_ld + xs_c0)
+                          : *reinterpret_cast<const float4 *>(p.x + (size_t)row * p.cin + c4 * 4);
         }
     };
     auto commit = [&](long long tile, int buf) {
@@ -1266,14 +1308,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
             if (i < WG_R * ci4) {
                 const int r = i / ci4, c4 = i - r * ci4;
                 float4 v = rx[u];
-                if (p.in_coef) {
+                if (x_fix ? (xs_coef != nullptr) : (p.in_coef != nullptr)) {
                     float4 mu = x_mu, sc = x_sc, be = x_be;
                     if constexpr (!x_fix) {
                         mu = *reinterpret_cast<const float4 *>(Cx + c4 * 4); sc = *reinterpret_cast<const float4 *>(Cx + p.cin + c4 * 4);
                         be = *reinterpret_cast<const float4 *>(Cx + 2 * p.cin + c4 * 4);
                     }
-                    v.x = act_apply((v.x - mu.x) * sc.x + be.x, p.slope_in); v.y = act_apply((v.y - mu.y) * sc.y + be.y, p.slope_in);
-                    v.z = act_apply((v.z - mu.z) * sc.z + be.z, p.slope_in); v.w = act_apply((v.w - mu.w) * sc.w + be.w, p.slope_in);
+                    const float sl = x_fix ? xs_slope : p.slope_in;
+                    v.x = act_apply((v.x - mu.x) * sc.x + be.x, sl); v.y = act_apply((v.y - mu.y) * sc.y + be.y, sl);
+                    v.z = act_apply((v.z - mu.z) * sc.z + be.z, sl); v.w = act_apply((v.w - mu.w) * sc.w + be.w, sl);
                 }
                 *reinterpret_cast<float4 *>(Xs + r * p.ldx + c4 * 4) = v;
             }
@@ -1383,7 +1426,8 @@ int dispatch_bwd_o(LinBwdParams &p, float *dw, hipStream_t st, unsigned grid) {
 
 static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const float *in_coef, float slope_in,
                         const float *w, float *y, double *sums, const float *pair_f, const float *bias_n,
-                        const float *bias_k, int pair_N, int pair_M, void *stream) {
+                        const float *bias_k, int pair_N, int pair_M, void *stream, const float *xb = nullptr,
+                        const float *in_coef_b = nullptr, float slope_b = 1.f, int split_c = 0) {
     if (rows < 0 || cin <= 0 || cout <= 0 || cout > 256) return I2P_ERR_BAD_ARG;
     if (rows == 0) return 0;
     if (!x || !w || !y) return I2P_ERR_BAD_ARG;
@@ -1394,7 +1438,7 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
         const int slice_w = cout > 128 ? 128 : cout;
         const bool gen2_ok = (cin % 4 == 0) && cin <= 128 && cin >= 4 && (cout % slice_w == 0) && pow2_16_128(slice_w) &&
                              !(ab && ab[0] == '1') && (!pair_f || pair_M >= F2_ROWS) &&
-                             (!in_coef || 64 % (cin / 4) == 0);
+                             ((!in_coef && !in_coef_b) || 64 % (cin / 4) == 0) && (!xb || (split_c % 4 == 0 && split_c > 0 && split_c < cin));
         if (gen2_ok) {
             // strip LDS rows hold max(cin, slice) floats (+2): the epilogue transposes the outputs through them
             for (int off = 0; off < cout; off += slice_w) {
@@ -1406,12 +1450,14 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
                 p.y_ld = cout; p.ch_off = off; p.cout_total = cout; p.ablate = 0;
                 p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
                 p.x2 = nullptr; p.g_coef = nullptr; p.w_transposed = 0; p.ex = p.e_coef = p.e_mi = nullptr; p.e_slope = 1.f;
+                p.split_c = 0; p.xb = xb; p.in_coef_b = in_coef_b; p.slope_b = slope_b; p.yb = nullptr; p.exb = p.e_coef_b = p.e_mi_b = p.e_add = nullptr; p.sums_b = nullptr; p.e_slope_b = 1.f; p.split_c = split_c;
                 const int rc = pair_f ? dispatch_fwd2<true, false>(p, st) : dispatch_fwd2<false, false>(p, st);
                 if (rc) return rc;
             }
             return 0;
         }
     }
+    if (xb) return I2P_ERR_BAD_ARG;                        // two-source input exists only in the second generation
     // output channels are processed in slices whose weights fit the LDS next to a 128-row tile
     const int cin_p = (cin + 1) & ~1, ldk = cin_p + 1;
     int slice = (cout + 31) & ~31;
@@ -1426,6 +1472,7 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
         p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
         { const char *ab = getenv("I2P_LIN_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
         p.x2 = nullptr; p.g_coef = nullptr; p.w_transposed = 0; p.ex = p.e_coef = p.e_mi = nullptr; p.e_slope = 1.f;
+                p.split_c = 0; p.xb = xb; p.in_coef_b = in_coef_b; p.slope_b = slope_b; p.yb = nullptr; p.exb = p.e_coef_b = p.e_mi_b = p.e_add = nullptr; p.sums_b = nullptr; p.e_slope_b = 1.f; p.split_c = split_c;
         int rc;
         switch (p.cout_p / 32) {
             case 1: rc = launch_fwd<1>(p, st); break;
@@ -1445,6 +1492,14 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
 extern "C" int i2p_lin_fwd(long long rows, int cin, int cout, const float *x, const float *in_coef,
                            float slope_in, const float *w, float *y, double *sums, void *stream) {
     return lin_fwd_impl(rows, cin, cout, x, in_coef, slope_in, w, y, sums, nullptr, nullptr, nullptr, 1, 1, stream);
+}
+
+extern "C" int i2p_lin_fwd_2src(long long rows, int cin_a, int cin_b, int cout, const float *xa, const float *coef_a,
+                                float slope_a, const float *xb, const float *coef_b, float slope_b, const float *w,
+                                float *y, double *sums, void *stream) {
+    if (!xa || !xb || cin_a <= 0 || cin_b <= 0) return I2P_ERR_BAD_ARG;
+    return lin_fwd_impl(rows, cin_a + cin_b, cout, xa, coef_a, slope_a, w, y, sums, nullptr, nullptr, nullptr, 1, 1, stream,
+                        xb, coef_b, slope_b, cin_a);
 }
 
 extern "C" int i2p_pair_lin_fwd(int B, int N, int M, int cin, int cout, const float *f, const float *g,
@@ -1493,12 +1548,13 @@ static int launch_wgrad(const WgradParams &q, float *dw, hipStream_t st, unsigne
 }
 
 struct PairBwd { const float *f, *g; float *d_f, *d_g, *d_bn, *d_bk; int N, M; };
+struct TwoBwd { int split_c; const float *xb, *in_coef_b, *in_mi_b; float slope_b; float *gz_in_b; double *in_dsums_b; const float *e_add; };
 
 static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, const float *y,
                         const float *out_coef, const float *out_mi, const double *out_dsums,
                         const float *x, const float *in_coef, const float *in_mi, float slope_in,
                         const float *w, float *gz_in, double *in_dsums, float *dw_partial, float *dw,
-                        const PairBwd *pair, void *stream) {
+                        const PairBwd *pair, void *stream, const TwoBwd *two = nullptr) {
     if (rows <= 0 || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3)) return I2P_ERR_BAD_ARG;
     if (!gz || (!x && !pair) || !w || !dw_partial || !dw) return I2P_ERR_BAD_ARG;
     if (out_coef && (!y || !out_mi || !out_dsums)) return I2P_ERR_BAD_ARG;
@@ -1522,7 +1578,9 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
         const char *gen = getenv("I2P_LIN_BWD_GEN");
         const bool dgrad_ok = !gz_in || (pow2w(cin) && pow2w(cout));
         const size_t wg_lds = (2 * (size_t)WG_R * (p.cout_p + p.cin_p) + 5 * (size_t)cout + 3 * (size_t)cin) * sizeof(float);
-        if (!pair && !(gen && gen[0] == '1') && dgrad_ok && pow2w(cout) && wg_lds <= 160 * 1024 && cin <= 160) {
+        const bool gen2 = !pair && !(gen && gen[0] == '1') && dgrad_ok && pow2w(cout) && wg_lds <= 160 * 1024 && cin <= 160;
+        if (two && !(gen2 && pow2w(cin))) return I2P_ERR_BAD_ARG;
+        if (gen2) {
             float *g_coef = nullptr;
             if (out_coef) {
                 g_coef = dw_partial + (size_t)grid * cout * cin;                 // 5*cout floats behind the partials
@@ -1538,6 +1596,8 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
                 q.y_ld = cin; q.ch_off = 0; q.cout_total = cin; q.ablate = 0;
                 q.pair_f = q.bias_n = q.bias_k = nullptr; q.pair_N = q.pair_M = 1;
                 q.ex = in_coef ? x : nullptr; q.e_coef = in_coef; q.e_mi = in_mi; q.e_slope = slope_in;
+                q.split_c = 0; q.xb = nullptr; q.in_coef_b = nullptr; q.slope_b = 1.f; q.yb = nullptr; q.exb = q.e_coef_b = q.e_mi_b = q.e_add = nullptr; q.sums_b = nullptr; q.e_slope_b = 1.f;
+                if (two) { q.split_c = two->split_c; q.yb = two->gz_in_b; q.exb = two->xb; q.e_coef_b = two->in_coef_b; q.e_mi_b = two->in_mi_b; q.e_add = two->e_add; q.sums_b = two->in_dsums_b; q.e_slope_b = two->slope_b; q.ex = x; }
                 const int rc = dispatch_fwd2<false, true>(q, st);
                 if (rc) return rc;
             }
@@ -1546,6 +1606,8 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
             wq.ldg = p.cout_p; wq.ldx = p.cin_p;        // 16-B aligned rows; fragments are read along channels
             wq.gz = gz; wq.y = y; wq.g_coef = g_coef; wq.x = x; wq.in_coef = in_coef; wq.slope_in = slope_in;
             wq.dw_partial = dw_partial;
+            wq.split_c = 0; wq.xb = nullptr; wq.in_coef_b = nullptr; wq.slope_b = 1.f;
+            if (two) { wq.split_c = two->split_c; wq.xb = two->xb; wq.in_coef_b = two->in_coef_b; wq.slope_b = two->slope_b; }
             return launch_wgrad(wq, dw, st, grid, wg_lds);
         }
     }
@@ -1616,4 +1678,17 @@ extern "C" int i2p_pair_lin_bwd(int B, int N, int M, int cin, int cout, const fl
     if (nti == 4 && nto == 2) return launch_pair_bwd<4, 2>(p, dw, st, grid);
     if (nti == 1 && nto == 1) return launch_pair_bwd<1, 1>(p, dw, st, grid);
     return I2P_ERR_BAD_ARG;
+}
+
+extern "C" int i2p_lin_bwd_2src(long long rows, int cin_a, int cin_b, int cout, const float *gz, const float *y,
+                                const float *out_coef, const float *out_mi, const double *out_dsums,
+                                const float *xa, const float *coef_a, const float *mi_a, float slope_a,
+                                const float *xb, const float *coef_b, const float *mi_b, float slope_b,
+                                const float *e_add_b, const float *w, float *gz_a, double *dsums_a, float *gz_b,
+                                double *dsums_b, float *dw_partial, float *dw, void *stream) {
+    if (!xa || !xb || !coef_a || !coef_b || !gz_a || !gz_b || !dsums_a || !dsums_b) return I2P_ERR_BAD_ARG;
+    TwoBwd t; t.split_c = cin_a; t.xb = xb; t.in_coef_b = coef_b; t.in_mi_b = mi_b; t.slope_b = slope_b;
+    t.gz_in_b = gz_b; t.in_dsums_b = dsums_b; t.e_add = e_add_b;
+    return lin_bwd_impl(rows, cin_a + cin_b, cout, gz, y, out_coef, out_mi, out_dsums, xa, coef_a, mi_a, slope_a, w, gz_a,
+                        dsums_a, dw_partial, dw, nullptr, stream, &t);
 }

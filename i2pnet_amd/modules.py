@@ -21,12 +21,14 @@ import torch.nn.functional as F
 
 from . import ops
 from . import projectpn as P
-from .fused import mlp_stack, pair_fits, pair_linear
+from .fused import cv_pi_tail, cv_tail_fits, mlp_stack, pair_fits, pair_linear
 
 # run Conv2d stacks on the fused MFMA layer kernels (csrc/mlp.hip); False = library GEMM + BN kernels per block
 USE_FUSED_MLP = True
 # batch-stat BN + activation through the fused bn_act kernels; False = plain torch ops (two-pass statistics)
 USE_FUSED_BN = True
+# cost_volume1's mlp1[1:] / pi_encoding / mlp2 / softmax-weighted sum as one fused autograd node
+USE_CV_TAIL = True
 
 
 def run_stack(x, convs, first_bn=None):
@@ -364,10 +366,16 @@ class CostVolume(nn.Module):
         else:
             corr = pts_n.unsqueeze(2) * pix_n.unsqueeze(1)                      # [B,N,M,C]  :395
             y = F.linear(corr, Wm[:, 6:6 + C]) + per_point.unsqueeze(2) + per_pixel.unsqueeze(1)
-        h = run_stack(y, list(self.mlp1_convs)[1:], first_bn=first)
         We = self.pi_encoding.weight2d()
-        enc = self.pi_encoding.finish(F.linear(xyz, We[:, 0:3]).unsqueeze(2) + F.linear(pix_xyz, We[:, 3:6]).unsqueeze(1))
-        return h, enc
+        ye = F.linear(xyz, We[:, 0:3]).unsqueeze(2) + F.linear(pix_xyz, We[:, 3:6]).unsqueeze(1)   # pre-BN, [B,N,M,c]
+        rest = list(self.mlp1_convs)[1:]
+        if USE_FUSED_MLP and USE_CV_TAIL and cv_tail_fits(first, rest, self.pi_encoding, list(self.mlp2_convs)):
+            M_ = pix_n.shape[1]
+            return None, None, cv_pi_tail(y.reshape(B_ * N_ * M_, -1), ye.reshape(B_ * N_ * M_, -1), (B_, N_, M_), first,
+                                          rest, self.pi_encoding, list(self.mlp2_convs))
+        h = run_stack(y, rest, first_bn=first)
+        enc = self.pi_encoding.finish(ye)
+        return h, enc, None
 
     def _pi_knn(self, uv, xyz, pts_n, pix_xyz, pix_n):
         B, N, _ = xyz.shape
@@ -388,12 +396,14 @@ class CostVolume(nn.Module):
         xyz = warped_xyz.mul(lidar_z)                                           # restore depth, :377
         pts_n = _unit_variance(warped_points)
         pix_n = _unit_variance(f2_points)
+        pi_feat = None
         if self.nsample_q > 0:
             h3, enc = self._pi_knn(uv, xyz, pts_n, f2_xyz, pix_n)
         else:
-            h3, enc = self._pi_all_pixels(xyz, pts_n, f2_xyz, pix_n)
-        logits = run_stack(torch.cat([enc, h3], dim=3), self.mlp2_convs)        # :423
-        pi_feat = torch.sum(F.softmax(logits, dim=2) * h3, dim=2)               # [B,N,c]  :430-433
+            h3, enc, pi_feat = self._pi_all_pixels(xyz, pts_n, f2_xyz, pix_n)
+        if pi_feat is None:
+            logits = run_stack(torch.cat([enc, h3], dim=3), self.mlp2_convs)    # :423
+            pi_feat = torch.sum(F.softmax(logits, dim=2) * h3, dim=2)           # [B,N,c]  :430-433
 
         # pc-stage
         xyz_bhw = xyz.view(B, self.H, self.W, 3)

@@ -257,6 +257,65 @@ class CBackend:
                    stream=self._stream())
         return d_f, d_g, d_bn, d_bk, dw
 
+    # ---- cost-volume tail --------------------------------------------------------------------------
+    def bn_stats(self, x):
+        rows, c = x.shape
+        sums = torch.zeros(BN_REPLICAS * 2 * c, dtype=torch.float64, device=x.device)
+        self._call("i2p_bn_stats", int(rows), int(c), self._p(x, _F32, "x"), self._p(sums, torch.float64, "sums"),
+                   stream=self._stream())
+        return sums
+
+    def lin_forward_2src(self, xa, coef_a, slope_a, xb, coef_b, slope_b, w):
+        rows, ca = xa.shape
+        cb = xb.shape[1]
+        cout = w.shape[0]
+        y = torch.empty(rows, cout, dtype=_F32, device=xa.device)
+        sums = torch.zeros(BN_REPLICAS * 2 * cout, dtype=torch.float64, device=xa.device)
+        self._call("i2p_lin_fwd_2src", int(rows), int(ca), int(cb), int(cout), self._p(xa, _F32, "xa"),
+                   self._p(coef_a, _F32, "coef_a"), float(slope_a), self._p(xb, _F32, "xb"),
+                   self._p(coef_b, _F32, "coef_b"), float(slope_b), self._p(w, _F32, "w"), self._p(y, _F32, "y"),
+                   self._p(sums, torch.float64, "sums"), stream=self._stream())
+        return y, sums
+
+    def lin_backward_2src(self, gz, y, out_coef, out_mi, out_dsums, xa, coef_a, mi_a, slope_a, xb, coef_b, mi_b,
+                          slope_b, e_add_b, w):
+        """-> (gz_a, dsums_a, gz_b, dsums_b, dw)"""
+        rows, cout = gz.shape
+        ca, cb = xa.shape[1], xb.shape[1]
+        dev = gz.device
+        gz_a = torch.empty(rows, ca, dtype=_F32, device=dev); gz_b = torch.empty(rows, cb, dtype=_F32, device=dev)
+        ds_a = torch.zeros(BN_REPLICAS * 2 * ca, dtype=torch.float64, device=dev)
+        ds_b = torch.zeros(BN_REPLICAS * 2 * cb, dtype=torch.float64, device=dev)
+        grid = 256 if self.device_type == "cuda" else 1
+        part = torch.empty(min(grid, (rows + 63) // 64) * cout * (ca + cb) + 8 * cout, dtype=_F32, device=dev)
+        dw = torch.empty(cout, ca + cb, dtype=_F32, device=dev)
+        P = lambda t, dt=_F32: (self._p(t, dt, "t") if t is not None else None)
+        self._call("i2p_lin_bwd_2src", int(rows), int(ca), int(cb), int(cout), P(gz), P(y), P(out_coef), P(out_mi),
+                   P(out_dsums, torch.float64), P(xa), P(coef_a), P(mi_a), float(slope_a), P(xb), P(coef_b), P(mi_b),
+                   float(slope_b), P(e_add_b), P(w), P(gz_a), P(ds_a, torch.float64), P(gz_b), P(ds_b, torch.float64),
+                   P(part), P(dw), stream=self._stream())
+        return gz_a, ds_a, gz_b, ds_b, dw
+
+    def cv_softmax_wsum_forward(self, B, N, M, y5, coef5, slope5, y3, coef3, slope3):
+        C = y5.shape[1]
+        out = torch.empty(B, N, C, dtype=_F32, device=y5.device)
+        msave = torch.empty(B * N, 2, C, dtype=_F32, device=y5.device)
+        self._call("i2p_cv_softmax_wsum_fwd", int(B), int(N), int(M), int(C), self._p(y5, _F32, "y5"),
+                   self._p(coef5, _F32, "coef5"), float(slope5), self._p(y3, _F32, "y3"), self._p(coef3, _F32, "coef3"),
+                   float(slope3), self._p(out, _F32, "out"), self._p(msave, _F32, "msave"), stream=self._stream())
+        return out, msave
+
+    def cv_softmax_wsum_backward(self, B, N, M, g_out, out, msave, y5, coef5, mi5, slope5, y3, coef3, slope3):
+        C = y5.shape[1]
+        gz5 = torch.empty_like(y5); ga3 = torch.empty_like(y3)
+        ds5 = torch.zeros(BN_REPLICAS * 2 * C, dtype=torch.float64, device=y5.device)
+        self._call("i2p_cv_softmax_wsum_bwd", int(B), int(N), int(M), int(C), self._p(g_out, _F32, "g_out"),
+                   self._p(out, _F32, "out"), self._p(msave, _F32, "msave"), self._p(y5, _F32, "y5"),
+                   self._p(coef5, _F32, "coef5"), self._p(mi5, _F32, "mi5"), float(slope5), self._p(y3, _F32, "y3"),
+                   self._p(coef3, _F32, "coef3"), float(slope3), self._p(gz5, _F32, "gz5"),
+                   self._p(ds5, torch.float64, "ds5"), self._p(ga3, _F32, "ga3"), stream=self._stream())
+        return gz5, ds5, ga3
+
     def bn_finalize(self, rows, sums, gamma, beta, eps):
         """-> (coef [3,c] = mean, invstd*gamma, beta ; mean_invstd [2c])"""
         c = gamma.shape[0]

@@ -246,6 +246,33 @@ int i2p_pair_lin_bwd(int B, int N, int M, int cin, int cout, const float *gz, co
                      const float *g, const float *w, float *d_f, float *d_g, float *d_bias_n,
                      float *d_bias_k, float *dw_partial, float *dw, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Cost-volume tail (PPBackbone_center.py:420-433) without concatenated / activated tensors.
+ *  - two-source layer: the input of mlp2[0] is cat(pi_xyz_encoding, pi_feat1_new) = two different
+ *    pre-BN tensors xa [rows,cin_a], xb [rows,cin_b], each with its own BN coefficients / activation;
+ *    the backward writes the two halves of gz_in separately and adds e_add_b (the gradient that
+ *    reaches activation b from its other consumer, the weighted sum) before the activation derivative.
+ *  - softmax-weighted sum over the M pixels of every point, on the pre-BN logits y5 and values y3:
+ *      out[b,n,:] = sum_k softmax_k(act(bn5(y5))) * act(bn3(y3));  msave f32 [B*N,2,C] (max, exp-sum)
+ *      backward: gz5 (+ replicated BN-backward sums of bn5) and ga3 = dL/d act(bn3(y3)).
+ * --------------------------------------------------------------------------------------------- */
+int i2p_lin_fwd_2src(long long rows, int cin_a, int cin_b, int cout, const float *xa, const float *coef_a,
+                     float slope_a, const float *xb, const float *coef_b, float slope_b, const float *w,
+                     float *y, double *sums, void *stream);
+int i2p_lin_bwd_2src(long long rows, int cin_a, int cin_b, int cout, const float *gz, const float *y,
+                     const float *out_coef, const float *out_mi, const double *out_dsums, const float *xa,
+                     const float *coef_a, const float *mi_a, float slope_a, const float *xb,
+                     const float *coef_b, const float *mi_b, float slope_b, const float *e_add_b,
+                     const float *w, float *gz_a, double *dsums_a, float *gz_b, double *dsums_b,
+                     float *dw_partial, float *dw, void *stream);
+int i2p_cv_softmax_wsum_fwd(int B, int N, int M, int C, const float *y5, const float *coef5, float slope5,
+                            const float *y3, const float *coef3, float slope3, float *out, float *msave,
+                            void *stream);
+int i2p_cv_softmax_wsum_bwd(int B, int N, int M, int C, const float *g_out, const float *out,
+                            const float *msave, const float *y5, const float *coef5, const float *mi5,
+                            float slope5, const float *y3, const float *coef3, float slope3, float *gz5,
+                            double *dsums5, float *ga3, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

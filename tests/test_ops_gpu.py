@@ -371,3 +371,51 @@ def test_pair_lin_parity(oracle_backend, hip_backend, B, N, M, C, Co):
         sc = float(ref.abs().max())
         assert float((rr - hh.cpu()).abs().max()) <= 3e-4 * sc, name
         assert float((hh.cpu().double() - ref).abs().max()) <= 3e-4 * sc, name
+
+
+def test_cv_tail_ops_parity(oracle_backend, hip_backend):
+    """two-source fused layer (fwd/bwd) and softmax-weighted sum (fwd/bwd): HIP vs oracle."""
+    B, N, M, Ca, Cb, Co = 2, 23, 70, 64, 64, 128
+    rows = B * N * M
+    g = torch.Generator().manual_seed(5)
+    xa = torch.randn(rows, Ca, generator=g); xb = torch.randn(rows, Cb, generator=g) * 2 + 0.3
+    w = torch.randn(Co, Ca + Cb, generator=g) / 11 + torch.arange(Co).view(-1, 1) * 0.002
+    mk = lambda c: (1 + 0.1 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g))
+    (ga, ba), (gb, bb), (go, bo) = mk(Ca), mk(Cb), mk(Co)
+
+    def run(be, dev):
+        t = lambda v: v.to(dev)
+        ca, ma = be.bn_finalize(rows, be.bn_stats(t(xa)), t(ga), t(ba), 1e-5)
+        cb, mb = be.bn_finalize(rows, be.bn_stats(t(xb)), t(gb), t(bb), 1e-5)
+        y, st = be.lin_forward_2src(t(xa), ca, 0.1, t(xb), cb, 0.1, t(w))
+        co, mo = be.bn_finalize(rows, st, t(go), t(bo), 1e-5)
+        gz = torch.randn(rows, Co, generator=torch.Generator().manual_seed(9)).to(dev)
+        xh = (y - mo[:Co]) * mo[Co:]
+        ods = torch.zeros(32, 2, Co, dtype=torch.float64, device=dev)
+        ods[0, 0] = gz.double().sum(0); ods[0, 1] = (gz.double() * xh.double()).sum(0)
+        e_add = torch.randn(rows, Cb, generator=torch.Generator().manual_seed(10)).to(dev)
+        bw = be.lin_backward_2src(gz, y, co, mo, ods.reshape(-1).contiguous(), t(xa), ca, ma, 0.1, t(xb), cb, mb, 0.1, e_add, t(w))
+        # softmax-weighted sum on (y[:, :64] as logits, xb as values)
+        y5 = y[:, :64].contiguous(); c5 = torch.stack([co[0, :64], co[1, :64], co[2, :64]]).contiguous()
+        m5 = torch.cat([mo[:64], mo[Co:Co + 64]]).contiguous()
+        out, ms = be.cv_softmax_wsum_forward(B, N, M, y5, c5, 0.1, t(xb), cb, 0.1)
+        gout = torch.randn(B, N, 64, generator=torch.Generator().manual_seed(11)).to(dev)
+        sb = be.cv_softmax_wsum_backward(B, N, M, gout, out, ms, y5, c5, m5, 0.1, t(xb), cb, 0.1)
+        return [y, *bw, out, *sb]
+
+    ref = run(oracle_backend, "cpu"); got = run(hip_backend, DEV)
+    names = ["y", "gz_a", "ds_a", "gz_b", "ds_b", "dw", "out", "gz5", "ds5", "ga3"]
+    for n_, r, h in zip(names, ref, got):
+        h = h.cpu()
+        if r.dtype == torch.float64:
+            c = r.numel() // 64
+            r = r.view(32, 2, -1).sum(0); h = h.view(32, 2, -1).sum(0)
+            assert torch.allclose(r, h, rtol=1e-4, atol=1e-2), n_
+        else:
+            assert float((r - h).abs().max()) <= 3e-4 * float(r.abs().max()) + 1e-6, n_
+    # softmax-weighted sum against plain torch
+    y5 = ref[0][:, :64]
+    h5 = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(y5, None, None, go[:64], bo[:64], True, 0.0, 1e-5), 0.1)
+    h3 = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(xb, None, None, gb, bb, True, 0.0, 1e-5), 0.1)
+    want = (torch.softmax(h5.view(B, N, M, 64), 2) * h3.view(B, N, M, 64)).sum(2)
+    assert torch.allclose(got[6].cpu(), want, rtol=1e-4, atol=1e-5)
