@@ -402,7 +402,8 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
             if (row > last_row) { d = (int)(last_row - row0); row = last_row; }
             long long src = row;
             if (PAIR) { int bn, bk; pair_row16(pt, d, p.pair_N, p.pair_M, bn, bk); src = bk; }
-            v[u] = *reinterpret_cast<const float4 *>(src_x + (size_t)src * src_ld + src_c0);
+            // (two-source mode requires one channel set per lane; plain mode takes the slot's own column)
+            v[u] = *reinterpret_cast<const float4 *>(src_x + (size_t)src * src_ld + ((!DGRAD && p.xb) ? src_c0 : in_c4[u] * 4));
             if (DGRAD && p.g_coef) v2[u] = *reinterpret_cast<const float4 *>(p.x2 + (size_t)src * p.cin + in_c4[u] * 4);
         }
     };
@@ -1438,7 +1439,7 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
         const int slice_w = cout > 128 ? 128 : cout;
         const bool gen2_ok = (cin % 4 == 0) && cin <= 128 && cin >= 4 && (cout % slice_w == 0) && pow2_16_128(slice_w) &&
                              !(ab && ab[0] == '1') && (!pair_f || pair_M >= F2_ROWS) &&
-                             ((!in_coef && !in_coef_b) || 64 % (cin / 4) == 0) && (!xb || (split_c % 4 == 0 && split_c > 0 && split_c < cin));
+                             ((!in_coef && !in_coef_b) || 64 % (cin / 4) == 0) && (!xb || (split_c % 4 == 0 && split_c > 0 && split_c < cin && 64 % (cin / 4) == 0));
         if (gen2_ok) {
             // strip LDS rows hold max(cin, slice) floats (+2): the epilogue transposes the outputs through them
             for (int off = 0; off < cout; off += slice_w) {
