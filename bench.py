@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--layout", default="scan", choices=["scan", "centre"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", type=int, default=1, help="capture the step in one hipGraph (single-GPU runs)")
+    ap.add_argument("--graph", type=int, default=1, help="capture the step in hipGraphs (0 = eager)")
     args = ap.parse_args()
 
     from i2pnet_amd import synth
@@ -149,7 +149,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    use_graph = bool(args.graph) and world == 1
+    use_graph = bool(args.graph)       # N>1: graph A (fwd+bwd) -> eager RCCL all-reduce of the flat gradient -> graph B (clip+Adam)
     tr = Trainer(cfg=cfg, device=device, world_size=world, local_rank=local_rank, capturable=use_graph)
     batch = synth.make_batch(args.batch, args.points, 375, 1242, seed=1000 + rank, device=device, layout=args.layout)
     graph_live = tr.capture(batch) if use_graph else False

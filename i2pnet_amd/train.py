@@ -3,10 +3,17 @@ global-norm clip, Adam — the settings of the reference trainer
 (`train20v2learn_wandb_proj.py:198-205` Adam lr 1e-3 betas (0.9,0.999) eps 1e-8 wd 1e-4,
 ExponentialLR 0.99/epoch; `:457-483` step order; `--clip 10`).
 
-Data parallel: one process per GPU, `DistributedDataParallel` over RCCL (backend "nccl" on
-ROCm); the whole gradient (< 3.4 MB) is one bucket, BN statistics stay local to a rank exactly
-like the reference's single-GPU batch of 8 (no SyncBN, `broadcast_buffers=False`).
-The step never synchronises with the host (the reference calls `.item()` three times per step).
+Data parallel (the reference is single-GPU): one process per GPU, every gradient is
+a view into ONE flat fp32 buffer (< 3.4 MB), so a step is
+
+    [hipGraph A: zero grads, forward, loss, backward]  ->  one RCCL all-reduce of the flat buffer
+    ->  [hipGraph B: average, clip global norm, Adam]
+
+i.e. two graph replays and one collective per step on the host thread (≈ 2000 kernel launches
+otherwise), no collective inside a captured graph, no bucketing machinery.  BN statistics stay local
+to a rank exactly like the reference's single-GPU batch of 8 (no SyncBN).  With one GPU the two
+graphs are captured as one.  The step never synchronises with the host (the reference calls
+`.item()` three times per step).
 """
 import os
 
@@ -25,7 +32,7 @@ def dist_env():
 
 def init_distributed(backend):
     rank, local_rank, world = dist_env()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("I2P_FORCE_DP")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -37,27 +44,63 @@ class Trainer:
                  seed=0, capturable=False):
         torch.manual_seed(seed)                 # identical initial weights on every rank
         self.cfg, self.device, self.clip = cfg, torch.device(device), clip
+        self.world_size = world_size
         self.net = RegNet_v2(cfg=cfg).to(self.device)
         self.model = self.net
-        if world_size > 1:
-            kw = dict(device_ids=[local_rank]) if self.device.type == "cuda" else {}
-            self.model = nn.parallel.DistributedDataParallel(
-                self.net, bucket_cap_mb=64, broadcast_buffers=False, gradient_as_bucket_view=True, **kw)
         self.params = [p for p in self.net.parameters() if p.requires_grad]
+        if world_size > 1:                      # belt and braces: same seed already gives identical replicas
+            for p in self.net.parameters():
+                dist.broadcast(p.data, src=0)
+            for b in self.net.buffers():
+                dist.broadcast(b.data, src=0)
+        # every gradient lives in one flat buffer: one all-reduce, one norm
+        self.flat_grad = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=self.device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
         self.optimizer = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0001,
                                           capturable=capturable and self.device.type == "cuda")
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, 0.99)
-        self._graph = None
+        self._graph_a = self._graph_b = None
         self._static = None
         self._static_out = None
 
-    # ---- whole-step hipGraph ------------------------------------------------------------------
+    # ---- the three pieces of a step -----------------------------------------------------------------
+    def _forward_backward(self, batch):
+        self.model.train()
+        self.flat_grad.zero_()                  # gradients accumulate into the flat views
+        out3, out4, _, _, sx, sq = self.model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"],
+                                              batch.get("init_extrinsic"), batch["init_intrinsic"], None, None, None,
+                                              batch["lidar_feats"], cfg=self.cfg)
+        loss, real_loss, dual_loss = Get_loss(out3, out4, batch["decalib_real_gt"], batch["decalib_dual_gt"], sx, sq,
+                                              cfg=self.cfg)
+        loss.backward()
+        return loss.detach(), real_loss.detach(), dual_loss.detach()
+
+    def _all_reduce(self):
+        if self.world_size > 1 or (os.environ.get("I2P_FORCE_DP") and dist.is_initialized()):
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+
+    def _update(self):
+        if self.world_size > 1:
+            self.flat_grad.mul_(1.0 / self.world_size)
+        if self.clip > 0.0:                     # clip_grad_norm_ on the flat buffer (same total norm)
+            total = torch.linalg.vector_norm(self.flat_grad)
+            self.flat_grad.mul_(torch.clamp(self.clip / (total + 1e-6), max=1.0))
+        self.optimizer.step()
+
+    def _eager_step(self, batch):
+        out = self._forward_backward(batch)
+        self._all_reduce()
+        self._update()
+        return out
+
+    # ---- hipGraph capture ---------------------------------------------------------------------------------
     def capture(self, batch, warmup=3):
-        """Capture forward+loss+backward+clip+Adam as ONE hipGraph (static shapes; ~2000 kernel
-        launches per step otherwise keep the host thread on the critical path).  `batch` provides
-        the static input buffers; later `step()` calls copy into them and replay.
-        Requires `capturable=True`.  Returns True if the graph is live, False if capture failed
-        (the trainer then keeps running eagerly)."""
+        """Capture the step as hipGraphs (static shapes).  `batch` provides the static input buffers; later
+        `step()` calls copy into them and replay.  Requires `capturable=True`.  Returns True if the graphs
+        are live, False if capture failed (the trainer then keeps running eagerly)."""
         assert self.device.type == "cuda"
         self._static = {k: v.clone() for k, v in batch.items()}
         side = torch.cuda.Stream()
@@ -68,38 +111,36 @@ class Trainer:
                     self._eager_step(self._static)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._static_out = self._eager_step(self._static)
-            self._graph = graph
+            if self.world_size == 1 and not os.environ.get("I2P_FORCE_DP"):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._static_out = self._forward_backward(self._static)
+                    self._update()
+                self._graph_a, self._graph_b = graph, None
+            else:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    self._static_out = self._forward_backward(self._static)
+                with torch.cuda.graph(gb, pool=ga.pool()):
+                    self._update()
+                self._graph_a, self._graph_b = ga, gb
             return True
         except Exception as e:                      # noqa: BLE001 — fall back to eager, loudly
             print(f"[i2pnet_amd.train] hipGraph capture failed, staying eager: {type(e).__name__}: {e}", flush=True)
-            self._graph = None
+            self._graph_a = self._graph_b = None
             torch.cuda.synchronize()
             return False
 
     def step(self, batch):
         """one optimisation step on a sample dict (keys of the reference loader); returns the
         loss tensors without synchronising."""
-        if self._graph is not None:
+        if self._graph_a is not None:
             for k, v in batch.items():
                 if self._static[k] is not v:
                     self._static[k].copy_(v, non_blocking=True)
-            self._graph.replay()
+            self._graph_a.replay()
+            if self._graph_b is not None:
+                self._all_reduce()
+                self._graph_b.replay()
             return self._static_out
         return self._eager_step(batch)
-
-    def _eager_step(self, batch):
-        self.model.train()
-        out3, out4, _, _, sx, sq = self.model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"],
-                                              batch.get("init_extrinsic"), batch["init_intrinsic"], None, None, None,
-                                              batch["lidar_feats"], cfg=self.cfg)
-        self.optimizer.zero_grad(set_to_none=True)
-        loss, real_loss, dual_loss = Get_loss(out3, out4, batch["decalib_real_gt"], batch["decalib_dual_gt"], sx, sq,
-                                              cfg=self.cfg)
-        loss.backward()
-        if self.clip > 0.0:
-            nn.utils.clip_grad_norm_(self.params, self.clip)
-        self.optimizer.step()
-        return loss.detach(), real_loss.detach(), dual_loss.detach()

@@ -1,6 +1,6 @@
 """Data-parallel step on CPU: 2 processes, gloo, oracle operators.  Checks what the RCCL path
 relies on: identical parameters on every rank after a step, and gradients equal to the mean of
-the per-rank gradients (DDP all-reduce), with BN statistics local to a rank."""
+the per-rank gradients (flat-buffer all-reduce), with BN statistics local to a rank."""
 import os
 import socket
 import sys
@@ -86,7 +86,7 @@ def test_ddp_gloo_two_ranks(tmp_path, oracle_backend):
     # (conv biases in front of a train-mode BN likewise carry pure rounding noise: only parameters
     # holding at least 1e-3 of the global gradient norm are checked individually)
     wn = {k: float((0.5 * (single[0][k] + single[1][k]) * scale).double().norm()) for k in single[0]}
-    bad = {k: v for k, v in errs.items() if v > 2e-2 and not k.startswith("set_upconv0_w_upsample")
+    bad = {k: v for k, v in errs.items() if v > 5e-2 and not k.startswith("set_upconv0_w_upsample")
            and wn[k] > 1e-3 * den ** 0.5}
     assert not bad, bad
     assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5

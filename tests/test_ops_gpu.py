@@ -248,7 +248,8 @@ def test_bn_act_parity(oracle_backend, hip_backend, rows, c, slope):
 
 @pytest.mark.parametrize("rows,cin,cout,with_bn", [(1000, 128, 128, True), (4133, 64, 64, True), (777, 10, 16, False),
                                                    (5000, 35, 32, False), (2048, 128, 64, True), (300, 67, 128, False),
-                                                   (12800, 16, 32, True), (999, 131, 128, False), (640, 128, 256, True)])
+                                                   (12800, 16, 32, True), (999, 131, 128, False), (640, 128, 256, True),
+                                                   (5000, 36, 32, False), (3000, 68, 64, False), (2000, 12, 16, False)])
 def test_lin_fwd_parity(oracle_backend, hip_backend, rows, cin, cout, with_bn):
     """fused (BN+act on load) x W^T + output statistics: HIP MFMA kernel vs oracle (k-ordered fmaf
     chain) and vs torch fp64.  Asymmetric W catches transposed fragments."""
