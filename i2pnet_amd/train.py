@@ -3,11 +3,13 @@ global-norm clip, Adam — the settings of the reference trainer
 (`train20v2learn_wandb_proj.py:198-205` Adam lr 1e-3 betas (0.9,0.999) eps 1e-8 wd 1e-4,
 ExponentialLR 0.99/epoch; `:457-483` step order; `--clip 10`).
 
-Data parallel (the reference is single-GPU): one process per GPU, every gradient is
-a view into ONE flat fp32 buffer (< 3.4 MB), so a step is
+Data parallel (the reference is single-GPU): one process per GPU.  Parameters, Adam
+moments and the gathered gradient each live in ONE flat fp32 buffer (3.4 MB; the module parameters are
+views into it), so a step is
 
-    [hipGraph A: zero grads, forward, loss, backward]  ->  one RCCL all-reduce of the flat buffer
-    ->  [hipGraph B: average, clip global norm, Adam]
+    [hipGraph A: forward, loss, backward, pack gradients into the flat buffer]
+    ->  one RCCL all-reduce of the flat buffer
+    ->  [hipGraph B: average, clip global norm, Adam on the flat buffers (a dozen elementwise kernels)]
 
 i.e. two graph replays and one collective per step on the host thread (≈ 2000 kernel launches
 otherwise), no collective inside a captured graph, no bucketing machinery.  BN statistics stay local
@@ -39,6 +41,37 @@ def init_distributed(backend):
     return rank, local_rank, world
 
 
+class FlatAdam:
+    """Adam with L2 weight decay (the arithmetic of `torch.optim.Adam`, no amsgrad) on flat buffers;
+    step count and learning rate are device scalars so the update can sit in a hipGraph and the
+    ExponentialLR decay is one multiply."""
+
+    def __init__(self, param, grad, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.param, self.grad = param, grad
+        self.beta1, self.beta2, self.eps, self.weight_decay = betas[0], betas[1], eps, weight_decay
+        self.exp_avg = torch.zeros_like(param)
+        self.exp_avg_sq = torch.zeros_like(param)
+        self.step_t = torch.zeros((), dtype=torch.float32, device=param.device)
+        self.lr_t = torch.full((), lr, dtype=torch.float32, device=param.device)
+
+    @torch.no_grad()
+    def step(self):
+        g = self.grad
+        self.step_t += 1.0
+        if self.weight_decay != 0.0:
+            g = g.add(self.param, alpha=self.weight_decay)
+        self.exp_avg.lerp_(g, 1.0 - self.beta1)
+        self.exp_avg_sq.mul_(self.beta2).addcmul_(g, g, value=1.0 - self.beta2)
+        bc1 = 1.0 - torch.pow(self.beta1, self.step_t)
+        bc2_sqrt = (1.0 - torch.pow(self.beta2, self.step_t)).sqrt()
+        denom = (self.exp_avg_sq.sqrt() / bc2_sqrt).add_(self.eps)
+        self.param.sub_(self.exp_avg / denom * (self.lr_t / bc1))
+
+    @torch.no_grad()
+    def decay_lr(self, gamma):
+        self.lr_t.mul_(gamma)
+
+
 class Trainer:
     def __init__(self, cfg=I2PNetConfig, device="cuda", lr=1e-3, clip=10.0, world_size=1, local_rank=0,
                  seed=0, capturable=False):
@@ -53,15 +86,21 @@ class Trainer:
                 dist.broadcast(p.data, src=0)
             for b in self.net.buffers():
                 dist.broadcast(b.data, src=0)
-        # every gradient lives in one flat buffer: one all-reduce, one norm
-        self.flat_grad = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=self.device)
+        # trainable parameters become views into one flat buffer; gradients are packed into another:
+        # one all-reduce, one norm, one Adam
+        n = sum(p.numel() for p in self.params)
+        self.flat_param = torch.empty(n, dtype=torch.float32, device=self.device)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.device)
         off = 0
-        for p in self.params:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-            off += p.numel()
-        self.optimizer = torch.optim.Adam(self.params, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0001,
-                                          capturable=capturable and self.device.type == "cuda")
-        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, 0.99)
+        with torch.no_grad():
+            for p in self.params:
+                view = self.flat_param[off:off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                off += p.numel()
+        self.optimizer = FlatAdam(self.flat_param, self.flat_grad, lr, betas=(0.9, 0.999), eps=1e-08,
+                                  weight_decay=0.0001)
+        self.lr_gamma = 0.99                    # ExponentialLR(0.99) per epoch: call `epoch_end()`
         self._graph_a = self._graph_b = None
         self._static = None
         self._static_out = None
@@ -69,14 +108,36 @@ class Trainer:
     # ---- the three pieces of a step -----------------------------------------------------------------
     def _forward_backward(self, batch):
         self.model.train()
-        self.flat_grad.zero_()                  # gradients accumulate into the flat views
+        for p in self.params:                   # autograd then hands its buffers over instead of accumulating
+            p.grad = None
         out3, out4, _, _, sx, sq = self.model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"],
                                               batch.get("init_extrinsic"), batch["init_intrinsic"], None, None, None,
                                               batch["lidar_feats"], cfg=self.cfg)
         loss, real_loss, dual_loss = Get_loss(out3, out4, batch["decalib_real_gt"], batch["decalib_dual_gt"], sx, sq,
                                               cfg=self.cfg)
         loss.backward()
+        zero = None
+        grads = []
+        for p in self.params:
+            if p.grad is None:                  # parameter not reached by this loss
+                zero = torch.zeros((), device=self.device) if zero is None else zero
+                grads.append(zero.expand(p.numel()))
+            else:
+                grads.append(p.grad.reshape(-1))
+        torch.cat(grads, out=self.flat_grad)
         return loss.detach(), real_loss.detach(), dual_loss.detach()
+
+    def named_grads(self):
+        """the gradients the optimiser consumed last step (all-reduced, averaged, clipped), by parameter name"""
+        names = [k for k, p in self.net.named_parameters() if p.requires_grad]
+        out, off = {}, 0
+        for k, p in zip(names, self.params):
+            out[k] = self.flat_grad[off:off + p.numel()].view_as(p).clone()
+            off += p.numel()
+        return out
+
+    def epoch_end(self):
+        self.optimizer.decay_lr(self.lr_gamma)
 
     def _all_reduce(self):
         if self.world_size > 1 or (os.environ.get("I2P_FORCE_DP") and dist.is_initialized()):

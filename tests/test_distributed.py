@@ -32,7 +32,7 @@ def _worker(rank, world, port, out_dir):
     tr.net.l3_head.DP1.p = 0.0; tr.net.l4_head.DP1.p = 0.0          # dropout off: ranks must be comparable
     batch = synth.make_batch(1, 4096, 160, 512, seed=10 + rank)
     tr.step(batch)
-    grads = {k: p.grad.clone() for k, p in tr.net.named_parameters() if p.grad is not None}
+    grads = tr.named_grads()
     params = {k: p.detach().clone() for k, p in tr.net.named_parameters()}
     torch.save({"grads": grads, "params": params}, os.path.join(out_dir, f"rank{rank}.pt"))
     torch.distributed.barrier()
@@ -90,3 +90,22 @@ def test_ddp_gloo_two_ranks(tmp_path, oracle_backend):
            and wn[k] > 1e-3 * den ** 0.5}
     assert not bad, bad
     assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+
+
+def test_flat_adam_matches_torch_adam():
+    """FlatAdam (device-scalar step/lr, flat buffers) reproduces torch.optim.Adam with L2 weight decay."""
+    from i2pnet_amd.train import FlatAdam
+    torch.manual_seed(0)
+    w = torch.randn(1000)
+    ref = torch.nn.Parameter(w.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, 0.99)
+    flat, g = w.clone(), torch.zeros(1000)
+    mine = FlatAdam(flat, g, 1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    for it in range(20):
+        grad = torch.randn(1000) * (10.0 ** (it % 3 - 1))
+        ref.grad = grad.clone(); opt.step()
+        g.copy_(grad); mine.step()
+        if it % 5 == 4:
+            sched.step(); mine.decay_lr(0.99)
+        assert torch.allclose(flat, ref.data, rtol=1e-5, atol=1e-7), it
