@@ -245,3 +245,44 @@ extern "C" int i2p_knn(int b, int n, int s, int k, const float *xyz, const float
                        new_xyz, idx);
     I2P_RETURN_LAUNCH_STATUS();
 }
+
+
+/* -------------------------------------------------------------------------------------------
+ * Hamilton product with broadcasting over the point axis — src/modules/warp_utils.py:25-55
+ * (the reference evaluates it with 16 elementwise multiplies, 12 adds and a stack; its autograd
+ * backward is ~80 tiny launches per product).  One thread per output quaternion; the expression
+ * order of the reference is kept term by term (compiled with -ffp-contract=off).
+ * conj_a / conj_b: use the conjugate of that operand (what the backward needs:
+ * d/da = g (x) conj(b), d/db = conj(a) (x) g).
+ * ------------------------------------------------------------------------------------------- */
+__global__ void quat_mul_kernel(int total, int n, int na, int nb, int conj_a, int conj_b,
+                                const float4 *__restrict__ a, const float4 *__restrict__ b,
+                                float4 *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int bi = i / n, pi = i - bi * n;
+    float4 qa = a[(size_t)bi * na + (na == 1 ? 0 : pi)];
+    float4 qb = b[(size_t)bi * nb + (nb == 1 ? 0 : pi)];
+    if (conj_a) { qa.y = -qa.y; qa.z = -qa.z; qa.w = -qa.w; }
+    if (conj_b) { qb.y = -qb.y; qb.z = -qb.z; qb.w = -qb.w; }
+    const float aw = qa.x, ax = qa.y, ay = qa.z, az = qa.w;
+    const float bw = qb.x, bx = qb.y, by = qb.z, bz = qb.w;
+    float4 o;
+    o.x = ((aw * bw - ax * bx) - ay * by) - az * bz;
+    o.y = ((aw * bx + ax * bw) + ay * bz) - az * by;
+    o.z = ((aw * by - ax * bz) + ay * bw) + az * bx;
+    o.w = ((aw * bz + ax * by) - ay * bx) + az * bw;
+    out[i] = o;
+}
+
+extern "C" int i2p_quat_mul(int b, int na, int nb, int conj_a, int conj_b, const float *qa, const float *qb,
+                            float *out, void *stream) {
+    const int n = na > nb ? na : nb;
+    if (b < 0 || na < 1 || nb < 1 || (na != n && na != 1) || (nb != n && nb != 1)) return I2P_ERR_BAD_ARG;
+    const long long total = (long long)b * n;
+    if (total == 0) return 0;
+    if (total > 0x7fffffffLL) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(quat_mul_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (int)total, n, na, nb, conj_a, conj_b, (const float4 *)qa, (const float4 *)qb, (float4 *)out);
+    I2P_RETURN_LAUNCH_STATUS();
+}

@@ -50,7 +50,7 @@ class _MlpChain(Function):
         k = 0
         if first_bn:
             g0, b0 = p[0], p[1]; k = 2
-            sums = torch.zeros(ops.BN_REPLICAS * 2 * x.shape[1], dtype=torch.float64, device=x.device)
+            sums = ops.zeros(ops.BN_REPLICAS * 2 * x.shape[1], torch.float64, x.device)
             be._call("i2p_bn_stats", int(rows), int(x.shape[1]), be._p(x, torch.float32, "x"),
                      be._p(sums, torch.float64, "sums"), stream=be._stream())
             in_coef, mi = be.bn_finalize(rows, sums, g0.detach(), b0.detach(), _EPS)
@@ -70,7 +70,7 @@ class _MlpChain(Function):
         mi_last = torch.empty_like(mis[-1])
         last_g, last_b = (p[-2], p[-1]) if nl else (p[0], p[1])
         if nl == 0:      # only the leading BN: recompute its sums for the apply kernel
-            sums = torch.zeros(ops.BN_REPLICAS * 2 * x.shape[1], dtype=torch.float64, device=x.device)
+            sums = ops.zeros(ops.BN_REPLICAS * 2 * x.shape[1], torch.float64, x.device)
             be._call("i2p_bn_stats", int(rows), int(x.shape[1]), be._p(x, torch.float32, "x"),
                      be._p(sums, torch.float64, "sums"), stream=be._stream())
         c_last = ys[-1].shape[1]

@@ -18,6 +18,51 @@ _F32, _I32, _I64 = torch.float32, torch.int32, torch.int64
 BN_REPLICAS = 32          # I2P_BN_REPLICAS in include/i2p_ops.h
 
 
+class _ZeroArena:
+    """One pre-zeroed byte buffer per device for the many small accumulators of a training step
+    (replicated fp64 BN sums, small gradient buffers): a step clears it with ONE memset
+    (`begin_step`) instead of ~150 separate fills of a few KB each, and hands out 256-byte aligned
+    slices.  Slices live until the next `begin_step` on that device — i.e. for exactly one
+    forward+backward; with no arena active (inference, unit tests) `zeros` is `torch.zeros`."""
+    SIZE = 32 << 20
+    MAX_REQUEST = 512 << 10
+
+    def __init__(self):
+        self.buf = {}
+        self.cursor = {}
+
+    def begin_step(self, device):
+        device = torch.device(device)
+        if device not in self.buf:
+            self.buf[device] = torch.zeros(self.SIZE, dtype=torch.uint8, device=device)
+        else:
+            self.buf[device].zero_()
+        self.cursor[device] = 0
+
+    def end(self, device):
+        self.cursor.pop(torch.device(device), None)
+
+    def zeros(self, shape, dtype, device):
+        device = torch.device(device) if not isinstance(device, torch.device) else device
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        cur = self.cursor.get(device)
+        numel = 1
+        for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+            numel *= int(d)
+        nbytes = numel * torch.empty((), dtype=dtype).element_size()
+        if cur is None or nbytes > self.MAX_REQUEST or cur + nbytes > self.SIZE or numel == 0:
+            return torch.zeros(shape, dtype=dtype, device=device)
+        self.cursor[device] = (cur + nbytes + 255) & ~255
+        return self.buf[device][cur:cur + nbytes].view(dtype).view(shape)
+
+
+_arena = _ZeroArena()
+begin_step = _arena.begin_step      # called by the trainer at the top of every forward+backward
+end_step = _arena.end
+zeros = _arena.zeros
+
+
 class CBackend:
     """Calls `fns[name](*scalars_and_pointers [, stream])`."""
 
@@ -159,12 +204,21 @@ class CBackend:
                    stream=self._stream())
 
 
+    def quat_mul(self, a, b, conj_a=False, conj_b=False):
+        """a [B,Na,4] (x) b [B,Nb,4], Na/Nb in {1,N} -> [B,N,4] (warp_utils.py:25-55)"""
+        B, na, _ = a.shape
+        nb = b.shape[1]
+        out = torch.empty(B, max(na, nb), 4, dtype=_F32, device=a.device)
+        self._call("i2p_quat_mul", int(B), int(na), int(nb), int(bool(conj_a)), int(bool(conj_b)), self._p(a, _F32, "a"),
+                   self._p(b, _F32, "b"), self._p(out, _F32, "out"), stream=self._stream())
+        return out
+
     # ---- batch-stat BatchNorm + activation (PPBackbone_center.py:28-46) ---------------------------
     def bn_act_forward(self, y, gamma, beta, eps, slope):
         """y [rows,c] f32 -> (out [rows,c], mean_invstd [2c]) with batch statistics."""
         rows, c = y.shape
         dev = y.device
-        sums = torch.zeros(BN_REPLICAS * 2 * c, dtype=torch.float64, device=dev)
+        sums = zeros(BN_REPLICAS * 2 * c, torch.float64, dev)
         out = torch.empty_like(y)
         mean_invstd = torch.empty(2 * c, dtype=_F32, device=dev)
         st = self._stream()
@@ -179,7 +233,7 @@ class CBackend:
         """-> (dy [rows,c], dgamma [c], dbeta [c])"""
         rows, c = y.shape
         dev = y.device
-        dsums = torch.zeros(BN_REPLICAS * 2 * c, dtype=torch.float64, device=dev)
+        dsums = zeros(BN_REPLICAS * 2 * c, torch.float64, dev)
         dy = torch.empty_like(y)
         dgamma = torch.empty(c, dtype=_F32, device=dev)
         dbeta = torch.empty(c, dtype=_F32, device=dev)
@@ -198,7 +252,7 @@ class CBackend:
         cout = w.shape[0]
         dev = x.device
         y = torch.empty(rows, cout, dtype=_F32, device=dev)
-        sums = torch.zeros(BN_REPLICAS * 2 * cout, dtype=torch.float64, device=dev) if want_stats else None
+        sums = zeros(BN_REPLICAS * 2 * cout, torch.float64, dev) if want_stats else None
         self._call("i2p_lin_fwd", int(rows), int(cin), int(cout), self._p(x, _F32, "x"),
                    self._p(in_coef, _F32, "in_coef") if in_coef is not None else None, float(slope_in),
                    self._p(w, _F32, "w"), self._p(y, _F32, "y"),
@@ -211,7 +265,7 @@ class CBackend:
         cin = x.shape[1]
         dev = gz.device
         gz_in = torch.empty(rows, cin, dtype=_F32, device=dev) if need_gx else None
-        in_dsums = (torch.zeros(BN_REPLICAS * 2 * cin, dtype=torch.float64, device=dev)
+        in_dsums = (zeros(BN_REPLICAS * 2 * cin, torch.float64, dev)
                     if (need_gx and in_coef is not None) else None)
         grid = 256 if self.device_type == "cuda" else 1
         part = torch.empty(min(grid, (rows + 63) // 64) * cout * cin + 8 * cout, dtype=_F32, device=dev)
@@ -230,7 +284,7 @@ class CBackend:
         M = g.shape[1]
         Co = w.shape[0]
         y = torch.empty(B * N * M, Co, dtype=_F32, device=f.device)
-        sums = torch.zeros(BN_REPLICAS * 2 * Co, dtype=torch.float64, device=f.device)
+        sums = zeros(BN_REPLICAS * 2 * Co, torch.float64, f.device)
         self._call("i2p_pair_lin_fwd", int(B), int(N), int(M), int(C), int(Co), self._p(f, _F32, "f"),
                    self._p(g, _F32, "g"), self._p(bias_n, _F32, "bias_n"), self._p(bias_k, _F32, "bias_k"),
                    self._p(w, _F32, "w"), self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums"),
@@ -243,8 +297,8 @@ class CBackend:
         M = g.shape[1]
         Co = w.shape[0]
         dev = f.device
-        d_f = torch.zeros(B, N, C, dtype=_F32, device=dev); d_g = torch.zeros(B, M, C, dtype=_F32, device=dev)
-        d_bn = torch.zeros(B, N, Co, dtype=_F32, device=dev); d_bk = torch.zeros(B, M, Co, dtype=_F32, device=dev)
+        d_f = zeros((B, N, C), _F32, dev); d_g = zeros((B, M, C), _F32, dev)
+        d_bn = zeros((B, N, Co), _F32, dev); d_bk = zeros((B, M, Co), _F32, dev)
         KT = (M + 63) // 64
         NC = max(1, min(N, 256 // (B * KT)))
         grid = B * KT * NC if self.device_type == "cuda" else 1          # i2p_pair_lin_bwd_grid
@@ -260,7 +314,7 @@ class CBackend:
     # ---- cost-volume tail --------------------------------------------------------------------------
     def bn_stats(self, x):
         rows, c = x.shape
-        sums = torch.zeros(BN_REPLICAS * 2 * c, dtype=torch.float64, device=x.device)
+        sums = zeros(BN_REPLICAS * 2 * c, torch.float64, x.device)
         self._call("i2p_bn_stats", int(rows), int(c), self._p(x, _F32, "x"), self._p(sums, torch.float64, "sums"),
                    stream=self._stream())
         return sums
@@ -270,7 +324,7 @@ class CBackend:
         cb = xb.shape[1]
         cout = w.shape[0]
         y = torch.empty(rows, cout, dtype=_F32, device=xa.device)
-        sums = torch.zeros(BN_REPLICAS * 2 * cout, dtype=torch.float64, device=xa.device)
+        sums = zeros(BN_REPLICAS * 2 * cout, torch.float64, xa.device)
         self._call("i2p_lin_fwd_2src", int(rows), int(ca), int(cb), int(cout), self._p(xa, _F32, "xa"),
                    self._p(coef_a, _F32, "coef_a"), float(slope_a), self._p(xb, _F32, "xb"),
                    self._p(coef_b, _F32, "coef_b"), float(slope_b), self._p(w, _F32, "w"), self._p(y, _F32, "y"),
@@ -284,8 +338,8 @@ class CBackend:
         ca, cb = xa.shape[1], xb.shape[1]
         dev = gz.device
         gz_a = torch.empty(rows, ca, dtype=_F32, device=dev); gz_b = torch.empty(rows, cb, dtype=_F32, device=dev)
-        ds_a = torch.zeros(BN_REPLICAS * 2 * ca, dtype=torch.float64, device=dev)
-        ds_b = torch.zeros(BN_REPLICAS * 2 * cb, dtype=torch.float64, device=dev)
+        ds_a = zeros(BN_REPLICAS * 2 * ca, torch.float64, dev)
+        ds_b = zeros(BN_REPLICAS * 2 * cb, torch.float64, dev)
         grid = 256 if self.device_type == "cuda" else 1
         part = torch.empty(min(grid, (rows + 63) // 64) * cout * (ca + cb) + 8 * cout, dtype=_F32, device=dev)
         dw = torch.empty(cout, ca + cb, dtype=_F32, device=dev)
@@ -308,7 +362,7 @@ class CBackend:
     def cv_softmax_wsum_backward(self, B, N, M, g_out, out, msave, y5, coef5, mi5, slope5, y3, coef3, slope3):
         C = y5.shape[1]
         gz5 = torch.empty_like(y5); ga3 = torch.empty_like(y3)
-        ds5 = torch.zeros(BN_REPLICAS * 2 * C, dtype=torch.float64, device=y5.device)
+        ds5 = zeros(BN_REPLICAS * 2 * C, torch.float64, y5.device)
         self._call("i2p_cv_softmax_wsum_bwd", int(B), int(N), int(M), int(C), self._p(g_out, _F32, "g_out"),
                    self._p(out, _F32, "out"), self._p(msave, _F32, "msave"), self._p(y5, _F32, "y5"),
                    self._p(coef5, _F32, "coef5"), self._p(mi5, _F32, "mi5"), float(slope5), self._p(y3, _F32, "y3"),

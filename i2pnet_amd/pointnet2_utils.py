@@ -78,7 +78,7 @@ class GatherOperation(Function):
     def backward(ctx, grad_out):
         idx, Cn, N = ctx.for_backwards
         B, npoint = idx.size()
-        grad_features = torch.zeros(B, Cn, N, dtype=torch.float32, device=grad_out.device)
+        grad_features = ops.zeros((B, Cn, N), torch.float32, grad_out.device)
         ops.get_backend().gather_points_grad_wrapper(B, Cn, N, npoint, grad_out.contiguous(), idx,
                                                      grad_features)
         return grad_features, None
@@ -123,7 +123,7 @@ class ThreeInterpolate(Function):
     def backward(ctx, grad_out: torch.Tensor):
         idx, weight, m = ctx.three_interpolate_for_backward
         B, c, n = grad_out.size()
-        grad_features = torch.zeros(B, c, m, dtype=torch.float32, device=grad_out.device)
+        grad_features = ops.zeros((B, c, m), torch.float32, grad_out.device)
         ops.get_backend().three_interpolate_grad_wrapper(B, c, n, m, grad_out.contiguous(), idx, weight,
                                                          grad_features)
         return grad_features, None, None
@@ -148,7 +148,7 @@ class GroupingOperation(Function):
     def backward(ctx, grad_out: torch.Tensor):
         idx, N = ctx.for_backwards
         B, Cn, npoint, nsample = grad_out.size()
-        grad_features = torch.zeros(B, Cn, N, dtype=torch.float32, device=grad_out.device)
+        grad_features = ops.zeros((B, Cn, N), torch.float32, grad_out.device)
         ops.get_backend().group_points_grad_wrapper(B, Cn, N, npoint, nsample, grad_out.contiguous(), idx,
                                                     grad_features)
         return grad_features, None

@@ -69,7 +69,7 @@ class _GatherRows(Function):
     def backward(ctx, grad_out):
         h_idx, w_idx = ctx.saved_tensors
         B, HW, C, width = ctx.shape
-        grad_feat = torch.zeros(B, HW, C, dtype=torch.float32, device=grad_out.device)
+        grad_feat = ops.zeros((B, HW, C), torch.float32, grad_out.device)
         ops.get_backend().gather_rows_grad(grad_out.contiguous(), h_idx, w_idx, width, grad_feat)
         return grad_feat, None, None, None
 

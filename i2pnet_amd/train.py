@@ -23,6 +23,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import ops
 from .config import I2PNetConfig
 from .loss import Get_loss
 from .model import RegNet_v2
@@ -108,6 +109,7 @@ class Trainer:
     # ---- the three pieces of a step -----------------------------------------------------------------
     def _forward_backward(self, batch):
         self.model.train()
+        ops.begin_step(self.device)             # one memset for every small accumulator of this step
         for p in self.params:                   # autograd then hands its buffers over instead of accumulating
             p.grad = None
         out3, out4, _, _, sx, sq = self.model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"],

@@ -2,6 +2,35 @@
 src/modules/warp_utils.py:10-55, :78-94).  Device-agnostic (the reference hard-codes .cuda())."""
 import torch
 
+from . import ops
+
+
+class _QuatMul(torch.autograd.Function):
+    """Hamilton product as one HIP launch (csrc/projection_ops.hip `quat_mul_kernel`); the product is
+    bilinear, so both gradients are the same kernel with one operand conjugated."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        return ops.get_backend().quat_mul(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        be = ops.get_backend()
+        g = g.contiguous()
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = be.quat_mul(g, b, conj_b=True)                 # dL/da = g (x) conj(b)
+            if a.shape[1] == 1 and ga.shape[1] != 1:
+                ga = ga.sum(1, keepdim=True)
+        if ctx.needs_input_grad[1]:
+            gb = be.quat_mul(a, g, conj_a=True)                 # dL/db = conj(a) (x) g
+            if b.shape[1] == 1 and gb.shape[1] != 1:
+                gb = gb.sum(1, keepdim=True)
+        return ga, gb
+
 
 def inv_q(q):
     """q [B,4] or [B,1,4] (w,x,y,z) -> conj(q) / (|q|^2 + 1e-10), [B,4]"""
@@ -18,13 +47,7 @@ def mul_q(a, b):
         a = a.unsqueeze(1)
     if b.ndim == 2:
         b = b.unsqueeze(1)
-    aw, ax, ay, az = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
-    bw, bx, by, bz = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
-    return torch.stack([
-        aw * bw - ax * bx - ay * by - az * bz,
-        aw * bx + ax * bw + ay * bz - az * by,
-        aw * by - ax * bz + ay * bw + az * bx,
-        aw * bz + ax * by - ay * bx + az * bw], dim=-1)
+    return _QuatMul.apply(a, b)
 
 
 def warp_quat_xyz(lidar_xyz, Hi_quat, H_trans):

@@ -225,6 +225,16 @@ int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, const float 
                 double *in_dsums, float *dw_partial, float *dw, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Hamilton product out = a (x) b with broadcasting over the point axis (src/modules/warp_utils.py:25-55
+ * `mul_q`; used by `warp_quat_xyz` :78-94 and the pose composition, modellearn_proj_center.py:388-404).
+ *   qa f32 [b,na,4], qb f32 [b,nb,4] as (w,x,y,z); na, nb in {1, n}; out f32 [b,max(na,nb),4].
+ *   conj_a / conj_b != 0: that operand is conjugated first (the two gradient products
+ *   d/da = g (x) conj(b), d/db = conj(a) (x) g are calls of this same entry).
+ * --------------------------------------------------------------------------------------------- */
+int i2p_quat_mul(int b, int na, int nb, int conj_a, int conj_b, const float *qa, const float *qb,
+                 float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * First layer of the all-pixel cost volume (src/projectPN/PPBackbone_center.py:383-418): the
  * reference builds [B,N,M,6+C(+C)] = cat(xyz_n, uv_k, norm(LF_n)*norm(RF_k) (, max-response_k))
  * and runs a 1x1 conv on it.  Factored here as

@@ -188,6 +188,16 @@ def test_knn_parity(oracle_backend, hip_backend):
         assert torch.equal(ri, gi.cpu())
 
 
+def test_quat_mul_parity(oracle_backend, hip_backend):
+    g = torch.Generator().manual_seed(5)
+    for na, nb in [(1, 1), (1, 1440), (1440, 1), (1440, 1440)]:
+        a = torch.randn(8, na, 4, generator=g); b = torch.randn(8, nb, 4, generator=g)
+        for ca, cb in [(False, False), (True, False), (False, True)]:
+            r = oracle_backend.quat_mul(a, b, conj_a=ca, conj_b=cb)
+            h = hip_backend.quat_mul(a.to(DEV), b.to(DEV), conj_a=ca, conj_b=cb)
+            assert torch.equal(r, h.cpu()), (na, nb, ca, cb)
+
+
 def test_project_seq_parity(oracle_backend, hip_backend):
     """Cells are bit-exact for points away from a bin edge (device OCML vs host libm differ in
     the last ulp of atan2/asin); images are compared on cells whose winner agrees."""

@@ -186,3 +186,43 @@ def test_three_nn_interpolate_oracle(oracle_backend):
     oracle_backend.three_interpolate_wrapper(B, C, M, N, feats, idx, w, out)
     gathered = torch.gather(feats.unsqueeze(2).expand(-1, -1, N, -1), 3, idx.long().unsqueeze(1).expand(-1, C, -1, -1))
     assert torch.allclose(out, (gathered * w.unsqueeze(1)).sum(-1), atol=1e-5)
+
+
+def _mul_q_formula(a, b):
+    """the reference's elementwise formula (src/modules/warp_utils.py:41-53) in plain torch"""
+    r0 = a[..., 0] * b[..., 0] - a[..., 1] * b[..., 1] - a[..., 2] * b[..., 2] - a[..., 3] * b[..., 3]
+    r1 = a[..., 0] * b[..., 1] + a[..., 1] * b[..., 0] + a[..., 2] * b[..., 3] - a[..., 3] * b[..., 2]
+    r2 = a[..., 0] * b[..., 2] - a[..., 1] * b[..., 3] + a[..., 2] * b[..., 0] + a[..., 3] * b[..., 1]
+    r3 = a[..., 0] * b[..., 3] + a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1] + a[..., 3] * b[..., 0]
+    return torch.stack([r0, r1, r2, r3], -1)
+
+
+def test_quat_mul_oracle_and_autograd(oracle_backend):
+    """oracle quat_mul == the elementwise formula bit for bit (all broadcast shapes), and the
+    custom autograd node of i2pnet_amd.warp.mul_q gives the formula's gradients."""
+    from i2pnet_amd import ops, warp
+    g = torch.Generator().manual_seed(3)
+    prev = ops.set_backend(oracle_backend)
+    try:
+        for na, nb in [(1, 1), (1, 37), (37, 1), (37, 37)]:
+            a = torch.randn(3, na, 4, generator=g); b = torch.randn(3, nb, 4, generator=g)
+            assert torch.equal(oracle_backend.quat_mul(a, b), _mul_q_formula(a, b))
+            conj = torch.tensor([1.0, -1.0, -1.0, -1.0])
+            assert torch.equal(oracle_backend.quat_mul(a, b, conj_a=True), _mul_q_formula(a * conj, b))
+            assert torch.equal(oracle_backend.quat_mul(a, b, conj_b=True), _mul_q_formula(a, b * conj))
+            a1, b1 = a.clone().requires_grad_(), b.clone().requires_grad_()
+            a2, b2 = a.clone().requires_grad_(), b.clone().requires_grad_()
+            w = torch.randn(3, max(na, nb), 4, generator=g)
+            (warp.mul_q(a1, b1) * w).sum().backward()
+            (_mul_q_formula(a2, b2) * w).sum().backward()
+            assert torch.allclose(a1.grad, a2.grad, rtol=1e-5, atol=1e-5)
+            assert torch.allclose(b1.grad, b2.grad, rtol=1e-5, atol=1e-5)
+        # [B,4] operands and the warp of a cloud
+        q = torch.randn(2, 4, generator=g); t = torch.cat([torch.zeros(2, 1), torch.randn(2, 3, generator=g)], 1)
+        p = torch.randn(2, 50, 3, generator=g)
+        out = warp.warp_quat_xyz(p, q, t)
+        homo = torch.cat([torch.zeros(2, 50, 1), p], -1)
+        want = (_mul_q_formula(_mul_q_formula(q.unsqueeze(1), homo), warp.inv_q(q).unsqueeze(1)) + t.unsqueeze(1))[..., 1:]
+        assert torch.equal(out, want)
+    finally:
+        ops.set_backend(prev)
