@@ -44,37 +44,60 @@ def _event_time_us(launch, iters):
 def kernel_rooflines(B, device):
     """Live timings (events on the launch stream) of the hand-written kernels that dominate the step.
 
-    * lin_bwd_kernel<4,4>: backward of a 128->128 cost-volume layer on [B*228*468, 128] — BN-backward on
-      load, wgrad + dgrad on v_mfma_f32_32x32x2_f32, previous activation derivative + BN-backward
-      statistics in the epilogue.  MFMA-bound: 2 GEMMs x 2*rows*128*128 flop (SURVEY.md §8d counts the
-      same contraction, 15.1 GFLOP/sample forward for the whole pi-stage).
-    * lin_fwd2_kernel<8,pair>: forward of the factored first cost-volume layer (bilinear point x pixel
-      product formed on load, never materialised).
-    * fcsk_kernel<9>: level-1 fused_conv_select_k, HBM-bound on 4.64 MB/sample.
+    * `roofline`: lin_fwd2_kernel<8,false,false> — one fused 128->128 layer of the all-pixel cost volume on
+      [B*228*468, 128]: previous BN + LeakyReLU applied on load, GEMM on v_mfma_f32_16x16x4_f32, fp64 BN
+      statistics of the output in the epilogue.  The same template instantiated with DGRAD / PAIR is the
+      largest consumer of the step (profiles/r01_f_steady_kernel_stats.csv).  MFMA-bound:
+      2*rows*128*128 flop (SURVEY.md §8d counts the same contraction) against 157.3 TFLOP/s = 178 us;
+      the HBM floor (read x, write y: rows*128*4*2 B at 8 TB/s) is 109 us.
+      `traffic` = HBM bytes per launch from the PMC passes of tools/pmc_traffic.sh
+      (profiles/r01_pmc_*.txt): 2*FETCH_SIZE + WRITE_SIZE KiB with the gfx950 halving of FETCH_SIZE
+      calibrated on bn_stats_v4 / bn_act_fwd_v4 over the same tensor (MI355X_MICROARCH.md, HBM section).
+    * other_kernels: backward of the same layer (dgrad on the forward template + double-buffered wgrad +
+      partial reduction), the factored first cost-volume layer (product formed on load), and level-1
+      fused_conv_select_k (HBM-bound on 4.64 MB/sample).
     """
-    from i2pnet_amd import ops, projectpn as P, synth
+    from i2pnet_amd import _lib, ops, projectpn as P, synth
     hip = ops.hip_backend()
     N, M, C = 228, 468, 128
     rows = B * N * M
     g = torch.Generator(device=device).manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g, device=device)
-    # --- lin_bwd 128 -> 128 with both BNs live ---------------------------------------------------------
     x = rnd(rows, C); w = rnd(C, C) / C ** 0.5
     gam = torch.ones(C, device=device); bet = torch.zeros(C, device=device)
-    sx = torch.zeros(ops.BN_REPLICAS * 2 * C, dtype=torch.float64, device=device)
-    hip._call("i2p_bn_stats", rows, C, hip._p(x, torch.float32, "x"), hip._p(sx, torch.float64, "s"), stream=hip._stream())
+    sx = hip.bn_stats(x)
     in_coef, in_mi = hip.bn_finalize(rows, sx, gam, bet, 1e-5)
-    y, sy = hip.lin_forward(x, in_coef, 0.1, w)
+    # --- the roofline kernel: exactly one launch per call, buffers preallocated ---------------------------
+    y = torch.empty(rows, C, device=device)
+    sy = torch.zeros(ops.BN_REPLICAS * 2 * C, dtype=torch.float64, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    t_fwd = _event_time_us(lambda: _lib.call("i2p_lin_fwd", rows, C, C, x.data_ptr(), in_coef.data_ptr(), 0.1, w.data_ptr(),
+                                             y.data_ptr(), sy.data_ptr(), stream=st), 20)
+    flop_fwd = 2.0 * rows * C * C
+    alg_bytes = rows * C * 4 * 2 + C * C * 4
+    # PMC passes (profiles/r01_pmc_FETCH_SIZE.txt, r01_pmc_WRITE_SIZE.txt) at B=8: FETCH_SIZE 213830.7 KiB (x2 on
+    # gfx950) + WRITE_SIZE 443200.0 KiB per launch; scaled by rows for other batch sizes
+    traffic = (2 * 213830.7 + 443200.0) * 1024.0 * rows / (8 * N * M)
+    fwd = {"kernel": "lin_fwd2_kernel<8,false,false> (cost-volume 128->128 layer forward: BN+act on load, MFMA GEMM, "
+                     "fp64 BN statistics in the epilogue)",
+           "bound": "mfma", "achieved": round(flop_fwd / t_fwd / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(flop_fwd / t_fwd / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": round(traffic),
+           "avg_kernel_us": round(t_fwd, 1), "flop_per_launch": flop_fwd, "hbm_bytes_per_launch_algorithmic": alg_bytes,
+           "hbm_GBps_algorithmic": round(alg_bytes / t_fwd / 1e3, 1)}
+    hip.lin_forward(x, in_coef, 0.1, w)
+    torch.cuda.synchronize()
+    sy.zero_()
+    _lib.call("i2p_lin_fwd", rows, C, C, x.data_ptr(), in_coef.data_ptr(), 0.1, w.data_ptr(), y.data_ptr(), sy.data_ptr(),
+              stream=st)
     out_coef, out_mi = hip.bn_finalize(rows, sy, gam, bet, 1e-5)
     gz = rnd(rows, C)
     ods = torch.zeros(ops.BN_REPLICAS * 2 * C, dtype=torch.float64, device=device)
     t_bwd = _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), 10)
     flop_bwd = 2 * 2.0 * rows * C * C
-    bwd = {"kernel": "lin_bwd_kernel<4,4> (cost-volume 128->128 layer backward, fused BN-bwd/wgrad/dgrad/stats)",
+    bwd = {"kernel": "lin_fwd2_kernel<8,false,true> + lin_wgrad_kernel<4,4,true> + reduce_partials (backward of the same layer)",
            "bound": "mfma", "achieved": round(flop_bwd / t_bwd / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": round(flop_bwd / t_bwd / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-           "avg_kernel_us": round(t_bwd, 1), "flop_per_launch": flop_bwd,
-           "hbm_bytes_per_launch_algorithmic": rows * C * 4 * 4, "note": "time includes the tiny dW partial-reduction kernel"}
+           "frac": round(flop_bwd / t_bwd / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "avg_us": round(t_bwd, 1),
+           "flop_per_call": flop_bwd}
     del x, y, gz
     # --- pair-mode forward (first cost-volume layer) -----------------------------------------------------
     f = rnd(B, N, C); gk = rnd(B, M, C); bn = rnd(B, N, C); bk = rnd(B, M, C)
@@ -99,8 +122,8 @@ def kernel_rooflines(B, device):
             "achieved": round(bytes_sel / t_sel / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(bytes_sel / t_sel / 1e3 / HBM_PEAK_GBS, 4), "avg_kernel_us": round(t_sel, 2),
             "bytes_per_launch": bytes_sel}
-    bwd["other_kernels"] = [pf, selk]
-    return bwd
+    fwd["other_kernels"] = [bwd, pf, selk]
+    return fwd
 
 
 def cpu_baseline(cfg, batch_size=2, steps=2):

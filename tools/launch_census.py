@@ -78,6 +78,7 @@ def main():
             if o is not None:
                 seq_owner.setdefault(e.sequence_nr, o)
     by_mod = collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
+    by_mod_op = collections.defaultdict(lambda: collections.Counter())
     for e in evs:
         if e.device_type != torch.autograd.DeviceType.CPU or not e.kernels:
             continue
@@ -98,12 +99,14 @@ def main():
         o = owner(e)
         if o is not None:
             by_mod[o][0] += n; by_mod[o][1] += t
+            by_mod_op[o]["fwd " + e.name] += n
         else:
             p = e
             while p is not None and not (p.sequence_nr is not None and p.sequence_nr >= 0 and "Backward" in p.name):
                 p = p.cpu_parent
             o = seq_owner.get(p.sequence_nr, "(model.forward glue)") if p is not None else "(other: optimizer, packing)"
             by_mod[o][2] += n; by_mod[o][3] += t
+            by_mod_op[o]["bwd " + (p.name.replace("autograd::engine::evaluate_function: ", "") if p is not None else e.name)] += n
     tot_n = sum(v[0] for v in by_op.values()); tot_t = sum(v[1] for v in by_op.values())
     print(f"# launches {tot_n}  device time {tot_t / 1e3:.2f} ms")
     print("## by aten op")
@@ -112,6 +115,9 @@ def main():
     print("## by module: fwd launches, fwd ms, bwd launches, bwd ms")
     for k, v in sorted(by_mod.items(), key=lambda kv: -(kv[1][0] + kv[1][2])):
         print(f"{v[0]:5d} {v[1] / 1e3:8.3f}  {v[2]:5d} {v[3] / 1e3:8.3f}  {k}")
+    print("## per module: launches by op / autograd node")
+    for k, v in sorted(by_mod.items(), key=lambda kv: -(kv[1][0] + kv[1][2])):
+        print(f"[{k}] " + ", ".join(f"{name} x{c}" for name, c in by_mod_op[k].most_common(40)))
     print("## by source line / autograd node")
     for k, (n, t) in sorted(by_line.items(), key=lambda kv: -kv[1][0])[: a.top]:
         print(f"{n:5d} {t / 1e3:8.3f} ms  {k[:140]}")
