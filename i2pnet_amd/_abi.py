@@ -31,6 +31,8 @@ SIGNATURES = {
     "i2p_bn_act_bwd": ["l", "i", "p", "p", "p", "p", "p", "f", "p", "p", "p", "p"],
     "i2p_lin_fwd": ["l", "i", "i", "p", "p", "f", "p", "p", "p"],
     "i2p_quat_mul": ["i", "i", "i", "i", "i", "p", "p", "p"],
+    "i2p_row_unitvar_fwd": ["i", "i", "p", "p", "p"],
+    "i2p_row_unitvar_bwd": ["i", "i", "p", "p", "p", "p"],
     "i2p_bn_finalize": ["l", "i", "p", "p", "p", "f", "p", "p"],
     "i2p_lin_bwd": ["l", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 5,
     "i2p_pair_lin_fwd": ["i"] * 5 + ["p"] * 7,

@@ -286,3 +286,89 @@ extern "C" int i2p_quat_mul(int b, int na, int nb, int conj_a, int conj_b, const
                        (int)total, n, na, nb, conj_a, conj_b, (const float4 *)qa, (const float4 *)qb, (float4 *)out);
     I2P_RETURN_LAUNCH_STATUS();
 }
+
+
+/* -------------------------------------------------------------------------------------------
+ * Row-wise "unit variance" of the cost-volume inputs — src/projectPN/PPBackbone_center.py:388-393:
+ *     y = (x - mean_c(x)) / clip(std_c(x) (unbiased), min=1e-12)
+ * (torch: mean, sub, std, clip, div forward and ~14 autograd launches backward; here one launch each way).
+ * One wave per row, c <= 256 (4 values per lane), two-pass variance.
+ * stat f32 [rows,2] = {1/d, s > 1e-12 ? 1 : 0} for the backward:
+ *     gx = (gy - mean(gy) - [s>1e-12] * y * sum(gy*y)/(c-1)) / d
+ * ------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ void row_unitvar_fwd_kernel(int rows, int c, const float *__restrict__ x, float *__restrict__ y,
+                                       float *__restrict__ stat) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * c;
+    float v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        v[j] = k < c ? xr[k] : 0.f;
+        s += v[j];
+    }
+    const float mean = wave_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        v[j] = k < c ? v[j] - mean : 0.f;
+        q += v[j] * v[j];
+    }
+    const float sd = sqrtf(wave_sum(q) / (float)(c - 1));
+    const float d = fmaxf(sd, 1e-12f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        if (k < c) y[(size_t)row * c + k] = v[j] / d;
+    }
+    if (lane == 0) { stat[2 * row] = 1.0f / d; stat[2 * row + 1] = sd > 1e-12f ? 1.f : 0.f; }
+}
+
+__global__ void row_unitvar_bwd_kernel(int rows, int c, const float *__restrict__ gy, const float *__restrict__ y,
+                                       const float *__restrict__ stat, float *__restrict__ gx) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float g[4], yy[4];
+    float sg = 0.f, sgy = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        g[j] = k < c ? gy[(size_t)row * c + k] : 0.f;
+        yy[j] = k < c ? y[(size_t)row * c + k] : 0.f;
+        sg += g[j]; sgy += g[j] * yy[j];
+    }
+    const float mg = wave_sum(sg) / (float)c;
+    const float proj = stat[2 * row + 1] * wave_sum(sgy) / (float)(c - 1);
+    const float inv_d = stat[2 * row];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        if (k < c) gx[(size_t)row * c + k] = (g[j] - mg - yy[j] * proj) * inv_d;
+    }
+}
+
+extern "C" int i2p_row_unitvar_fwd(int rows, int c, const float *x, float *y, float *stat, void *stream) {
+    if (rows < 0 || c < 2 || c > 256) return I2P_ERR_BAD_ARG;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(row_unitvar_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, c, x, y, stat);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_row_unitvar_bwd(int rows, int c, const float *gy, const float *y, const float *stat, float *gx,
+                                   void *stream) {
+    if (rows < 0 || c < 2 || c > 256) return I2P_ERR_BAD_ARG;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(row_unitvar_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, c, gy, y, stat, gx);
+    I2P_RETURN_LAUNCH_STATUS();
+}

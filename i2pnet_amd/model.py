@@ -18,7 +18,8 @@ import torch.nn as nn
 from . import projectpn as P
 from . import warp as warp_utils
 from .config import I2PNetConfig as cfg_default
-from .modules import CostVolume, FlowPredictor, PoseHead, ProjectPointNet, ProjSetUpconvModule, createCNNs
+from .modules import (CostVolume, FlowPredictor, PoseHead, ProjectPointNet, ProjSetUpconvModule, _unit_variance,
+                      createCNNs)
 
 
 def set_id_grid(rf):
@@ -171,7 +172,9 @@ class RegNet_v2(nn.Module):
         l3_idx_n2 = P.get_idx_cuda(B, H3, W3, dev)
 
         # ---- coarse level --------------------------------------------------------------------
-        concat_4 = self.cost_volume1(P3_raw, lidar_uv, LF3_pts, l3_idx_n2, pix_rays, RF3_pts, lidar_z, cfg=cfg)
+        normalised = (_unit_variance(LF3_pts), _unit_variance(RF3_pts))        # shared by both cost volumes
+        concat_4 = self.cost_volume1(P3_raw, lidar_uv, LF3_pts, l3_idx_n2, pix_rays, RF3_pts, lidar_z, cfg=cfg,
+                                     normalised=normalised)
         _, _, l4_embed, _, _ = self.layer_idx(P3_raw, P3, concat_4, sample_idx=sample_idx_4, cfg=cfg,
                                               raw_feat_point=rfp)
         l4_valid = P.check_valid(P4_raw).view(B, -1, 1)
@@ -190,7 +193,8 @@ class RegNet_v2(nn.Module):
                                                 raw_feat_point=rfp)
         lidar_z = P3_warped[:, :, 2:]
         lidar_uv = P3_warped / (lidar_z + 1e-10)
-        concat_3 = self.cost_volume2(P3_raw, lidar_uv, LF3_pts, l3_idx_n2, pix_rays, RF3_pts, lidar_z, cfg=cfg)
+        concat_3 = self.cost_volume2(P3_raw, lidar_uv, LF3_pts, l3_idx_n2, pix_rays, RF3_pts, lidar_z, cfg=cfg,
+                                     normalised=normalised)
         l3_embed = self.flow_predictor0_predict(LF3_pts, l3_embed_up.view(B, H3 * W3, -1),
                                                 concat_3.view(B, H3 * W3, -1))
         l3_mask = self.flow_predictor0_w(LF3_pts, l3_mask_up.view(B, H3 * W3, -1), l3_embed)

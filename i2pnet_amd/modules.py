@@ -158,10 +158,37 @@ class Conv1d(nn.Module):
         return self.composed_module(x.permute(0, 2, 1)).permute(0, 2, 1)
 
 
+class _ImageCNN(nn.Sequential):
+    """`Sequential` of (Conv2d 3x3, BatchNorm2d, LeakyReLU, MaxPool2d) blocks with the reference's child
+    names; in training the conv bias is not added: in front of a batch-statistics BN it cancels in the
+    output and its gradient is exactly zero, but adding it and reducing its gradient costs two passes over
+    the largest tensors of the network (238 MB at level 1).  The running mean is corrected by
+    the bias so that eval mode (running statistics, bias added) sees the same buffers."""
+
+    def forward(self, x):
+        mods = list(self)
+        fast = self.training and all(mods[i + 1].track_running_stats and mods[i + 1].momentum is not None
+                                     for i in range(0, len(mods), 4))
+        if not fast:
+            return super().forward(x)
+        bns = [mods[i + 1] for i in range(0, len(mods), 4)]
+        with torch.no_grad():
+            # rm' = (1-m) rm + m (mean_without_bias + bias): pre-add m/(1-m) * bias (before autograd saves the buffer)
+            for i, b in zip(range(0, len(mods), 4), bns):
+                b.running_mean.add_(mods[i].bias, alpha=b.momentum / (1.0 - b.momentum))
+            torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
+        for i in range(0, len(mods), 4):
+            conv, bn, act, pool = mods[i:i + 4]
+            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+            y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+            x = pool(act(y))
+        return x
+
+
 def createCNNs(in_channel, channels, strides):
     """3x3 conv + BN(running stats) + LeakyReLU(0.1) + MaxPool3 stack — the image encoder
     (src/modules/basicConv.py:6-20).  Stays on PyTorch-ROCm / MIOpen."""
-    layers = nn.Sequential()
+    layers = _ImageCNN()
     last = in_channel
     for i, (out_channel, stride) in enumerate(zip(channels, strides)):
         layers.add_module(str(i * 4), nn.Conv2d(last, out_channel, kernel_size=3, stride=1, padding=1, bias=True))
@@ -298,8 +325,25 @@ class ProjSetUpconvModule(nn.Module):
             conv.set_bn()
 
 
+class _UnitVariance(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        y, stat = ops.get_backend().row_unitvar_forward(x2)
+        ctx.save_for_backward(y, stat)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, stat = ctx.saved_tensors
+        return ops.get_backend().row_unitvar_backward(gy.reshape(y.shape).contiguous(), y, stat).view(gy.shape)
+
+
 def _unit_variance(x):
-    """(x - mean) / clip(std_unbiased, 1e-12) over the channel axis (PPBackbone_center.py:388-393)."""
+    """(x - mean) / clip(std_unbiased, 1e-12) over the channel axis (PPBackbone_center.py:388-393),
+    one HIP launch forward and one backward (csrc/projection_ops.hip)."""
+    if 2 <= x.shape[-1] <= 256:
+        return _UnitVariance.apply(x)
     return (x - torch.mean(x, -1, keepdim=True)) / torch.clip(torch.std(x, -1, keepdim=True), min=1e-12)
 
 
@@ -343,8 +387,10 @@ class CostVolume(nn.Module):
         C = self.feat_channels
         first = self.mlp1_convs[0]
         Wm = first.weight2d()
-        per_point = F.linear(xyz, Wm[:, 0:3])                                   # [B,N,c1]
-        per_pixel = F.linear(pix_xyz, Wm[:, 3:6])                               # [B,M,c1]
+        # one split (one cat in the backward) instead of four slices (four zero-filled full-size gradients)
+        w_parts = torch.split(Wm, [3, 3, C] + ([Wm.shape[1] - 6 - C] if Wm.shape[1] > 6 + C else []), dim=1)
+        per_point = F.linear(xyz, w_parts[0])                                   # [B,N,c1]
+        per_pixel = F.linear(pix_xyz, w_parts[1])                               # [B,M,c1]
         if self.backward_validation:
             # max over points of the masked correlation (:408-414) in closed form: for a fixed pixel
             # channel g, max_n fl(f_n * g) = fl(g * max_n f_n) if g >= 0 else fl(g * min_n f_n)
@@ -358,16 +404,16 @@ class CostVolume(nn.Module):
             f_min = torch.where(any_valid, f_min, torch.zeros_like(f_min))
             respond = torch.where(pix_n >= 0, pix_n * f_max, pix_n * f_min)     # [B,M,C]
             respond = torch.where(any_valid, respond, torch.full_like(respond, -1e10))
-            per_pixel = per_pixel + F.linear(respond, Wm[:, 6 + C:])
+            per_pixel = per_pixel + F.linear(respond, w_parts[3])
         B_, N_ = pts_n.shape[0], pts_n.shape[1]
         if USE_FUSED_MLP and pair_fits(C, first.out_channels) and pix_n.shape[1] >= 64:
             # bilinear term on the matrix cores straight from the [B,N,C] / [B,M,C] factors
-            y = pair_linear(pts_n, pix_n, per_point, per_pixel, Wm[:, 6:6 + C]).view(B_, N_, pix_n.shape[1], -1)
+            y = pair_linear(pts_n, pix_n, per_point, per_pixel, w_parts[2]).view(B_, N_, pix_n.shape[1], -1)
         else:
             corr = pts_n.unsqueeze(2) * pix_n.unsqueeze(1)                      # [B,N,M,C]  :395
-            y = F.linear(corr, Wm[:, 6:6 + C]) + per_point.unsqueeze(2) + per_pixel.unsqueeze(1)
-        We = self.pi_encoding.weight2d()
-        ye = F.linear(xyz, We[:, 0:3]).unsqueeze(2) + F.linear(pix_xyz, We[:, 3:6]).unsqueeze(1)   # pre-BN, [B,N,M,c]
+            y = F.linear(corr, w_parts[2]) + per_point.unsqueeze(2) + per_pixel.unsqueeze(1)
+        we_parts = torch.split(self.pi_encoding.weight2d(), [3, 3], dim=1)
+        ye = F.linear(xyz, we_parts[0]).unsqueeze(2) + F.linear(pix_xyz, we_parts[1]).unsqueeze(1)   # pre-BN, [B,N,M,c]
         rest = list(self.mlp1_convs)[1:]
         if USE_FUSED_MLP and USE_CV_TAIL and cv_tail_fits(first, rest, self.pi_encoding, list(self.mlp2_convs)):
             M_ = pix_n.shape[1]
@@ -387,15 +433,18 @@ class CostVolume(nn.Module):
         h = run_stack(torch.cat([geo, pts_n.unsqueeze(2) * q_feat], dim=3), self.mlp1_convs)
         return h, run_stack(geo, [self.pi_encoding])
 
-    def forward(self, xyz_proj_raw, warped_xyz, warped_points, idx_n2, f2_xyz, f2_points, lidar_z, cfg=None):
+    def forward(self, xyz_proj_raw, warped_xyz, warped_points, idx_n2, f2_xyz, f2_points, lidar_z, cfg=None,
+                normalised=None):
         """xyz_proj_raw [B,H,W,3]; warped_xyz [B,HW,3] (u,v,1); warped_points [B,HW,C];
-        f2_xyz [B,M,3] pixel rays; f2_points [B,M,C]; lidar_z [B,HW,1] -> [B,H,W,mlp2[-1]]"""
+        f2_xyz [B,M,3] pixel rays; f2_points [B,M,C]; lidar_z [B,HW,1] -> [B,H,W,mlp2[-1]].
+        `normalised` = (unit-variance warped_points, unit-variance f2_points) if the caller already has
+        them (both cost volumes of the network normalise the same two tensors)."""
         B = warped_xyz.shape[0]
         N = warped_xyz.shape[1]
         uv = warped_xyz
         xyz = warped_xyz.mul(lidar_z)                                           # restore depth, :377
-        pts_n = _unit_variance(warped_points)
-        pix_n = _unit_variance(f2_points)
+        pts_n, pix_n = normalised if normalised is not None else (_unit_variance(warped_points),
+                                                                  _unit_variance(f2_points))
         pi_feat = None
         if self.nsample_q > 0:
             h3, enc = self._pi_knn(uv, xyz, pts_n, f2_xyz, pix_n)

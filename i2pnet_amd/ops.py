@@ -213,6 +213,22 @@ class CBackend:
                    self._p(b, _F32, "b"), self._p(out, _F32, "out"), stream=self._stream())
         return out
 
+    def row_unitvar_forward(self, x):
+        """x [rows,c] -> (y, stat [rows,2]) (PPBackbone_center.py:388-393)"""
+        rows, c = x.shape
+        y = torch.empty_like(x)
+        stat = torch.empty(rows, 2, dtype=_F32, device=x.device)
+        self._call("i2p_row_unitvar_fwd", int(rows), int(c), self._p(x, _F32, "x"), self._p(y, _F32, "y"),
+                   self._p(stat, _F32, "stat"), stream=self._stream())
+        return y, stat
+
+    def row_unitvar_backward(self, gy, y, stat):
+        rows, c = y.shape
+        gx = torch.empty_like(y)
+        self._call("i2p_row_unitvar_bwd", int(rows), int(c), self._p(gy, _F32, "gy"), self._p(y, _F32, "y"),
+                   self._p(stat, _F32, "stat"), self._p(gx, _F32, "gx"), stream=self._stream())
+        return gx
+
     # ---- batch-stat BatchNorm + activation (PPBackbone_center.py:28-46) ---------------------------
     def bn_act_forward(self, y, gamma, beta, eps, slope):
         """y [rows,c] f32 -> (out [rows,c], mean_invstd [2c]) with batch statistics."""

@@ -32,13 +32,23 @@ class _QuatMul(torch.autograd.Function):
         return ga, gb
 
 
+_CONJ_SIGN = {}
+
+
+def _conj_sign(device):
+    """(1,-1,-1,-1) on `device`, created once (the first, eager, call — never inside a hipGraph capture)."""
+    s = _CONJ_SIGN.get(device)
+    if s is None:
+        s = _CONJ_SIGN[device] = torch.tensor([1.0, -1.0, -1.0, -1.0], device=device)
+    return s
+
+
 def inv_q(q):
     """q [B,4] or [B,1,4] (w,x,y,z) -> conj(q) / (|q|^2 + 1e-10), [B,4]"""
     B = q.shape[0]
     q = q.reshape(B, 4)
     n2 = torch.sum(q * q, dim=-1, keepdim=True) + 1e-10
-    conj = torch.cat([q[:, :1], -q[:, 1:]], dim=-1)     # no host constant: hipGraph-capturable
-    return conj / n2
+    return (q * _conj_sign(q.device)) / n2
 
 
 def mul_q(a, b):

@@ -235,6 +235,16 @@ int i2p_quat_mul(int b, int na, int nb, int conj_a, int conj_b, const float *qa,
                  float *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Row-wise unit variance of the cost-volume operands (src/projectPN/PPBackbone_center.py:388-393):
+ *     y[r,:] = (x[r,:] - mean(x[r,:])) / clip(std_unbiased(x[r,:]), 1e-12)
+ * x, y f32 [rows,c], 2 <= c <= 256; stat f32 [rows,2] = {1/d, std > 1e-12 ? 1 : 0} (saved for the backward).
+ * Backward: gx = (gy - mean(gy) - stat1 * y * sum(gy*y)/(c-1)) * stat0.
+ * --------------------------------------------------------------------------------------------- */
+int i2p_row_unitvar_fwd(int rows, int c, const float *x, float *y, float *stat, void *stream);
+int i2p_row_unitvar_bwd(int rows, int c, const float *gy, const float *y, const float *stat, float *gx,
+                        void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * First layer of the all-pixel cost volume (src/projectPN/PPBackbone_center.py:383-418): the
  * reference builds [B,N,M,6+C(+C)] = cat(xyz_n, uv_k, norm(LF_n)*norm(RF_k) (, max-response_k))
  * and runs a 1x1 conv on it.  Factored here as

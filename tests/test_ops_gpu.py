@@ -198,6 +198,21 @@ def test_quat_mul_parity(oracle_backend, hip_backend):
             assert torch.equal(r, h.cpu()), (na, nb, ca, cb)
 
 
+def test_row_unitvar_parity(oracle_backend, hip_backend):
+    g = torch.Generator().manual_seed(9)
+    for rows, c in [(1824, 64), (3744, 128), (100, 37), (5, 256)]:
+        x = torch.randn(rows, c, generator=g) * 2 + 0.5
+        x[3] = -1.0
+        gy = torch.randn(rows, c, generator=g)
+        ry, rs = oracle_backend.row_unitvar_forward(x)
+        hy, hs = hip_backend.row_unitvar_forward(x.to(DEV))
+        assert torch.allclose(ry, hy.cpu(), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(rs, hs.cpu(), rtol=1e-5, atol=0)
+        rg = oracle_backend.row_unitvar_backward(gy, ry, rs)
+        hg = hip_backend.row_unitvar_backward(gy.to(DEV), hy, hs)
+        assert torch.allclose(rg, hg.cpu(), rtol=1e-4, atol=1e-5)
+
+
 def test_project_seq_parity(oracle_backend, hip_backend):
     """Cells are bit-exact for points away from a bin edge (device OCML vs host libm differ in
     the last ulp of atan2/asin); images are compared on cells whose winner agrees."""

@@ -226,3 +226,54 @@ def test_quat_mul_oracle_and_autograd(oracle_backend):
         assert torch.equal(out, want)
     finally:
         ops.set_backend(prev)
+
+
+def test_row_unitvar_oracle_vs_torch(oracle_backend):
+    """oracle row_unitvar == (x-mean)/clip(std,1e-12) and its autograd, incl. a constant row (clipped std)."""
+    from i2pnet_amd import modules, ops
+    g = torch.Generator().manual_seed(7)
+    prev = ops.set_backend(oracle_backend)
+    try:
+        for c in (64, 128, 37):
+            x = torch.randn(50, c, generator=g) * 3 + 1
+            x[7] = 2.5                                       # zero variance: std clipped at 1e-12
+            x1 = x.clone().requires_grad_(); x2 = x.clone().requires_grad_()
+            y1 = modules._unit_variance(x1.view(5, 10, c))
+            y2 = (x2 - torch.mean(x2, -1, keepdim=True)) / torch.clip(torch.std(x2, -1, keepdim=True), min=1e-12)
+            assert torch.allclose(y1.view(50, c), y2, rtol=1e-5, atol=1e-6)
+            w = torch.randn(50, c, generator=g)
+            (y1.view(50, c) * w).sum().backward(); (y2 * w).sum().backward()
+            keep = torch.ones(50, dtype=torch.bool); keep[7] = False        # torch's std backward is NaN at std == 0
+            assert torch.allclose(x1.grad[keep], x2.grad[keep], rtol=1e-4, atol=1e-5)
+            assert torch.isfinite(x1.grad).all()
+    finally:
+        ops.set_backend(prev)
+
+
+def test_image_cnn_bias_skip_equivalent():
+    """training-mode image encoder without the (cancelling) conv bias == the plain Sequential:
+    same output, same running statistics, zero bias gradient."""
+    import copy
+    import torch.nn as nn
+    from i2pnet_amd.modules import createCNNs
+    torch.manual_seed(0)
+    fast = createCNNs(3, [8, 8], [2, 1])
+    for m in fast:
+        if isinstance(m, nn.Conv2d):
+            nn.init.normal_(m.bias, std=0.5)
+    plain = nn.Sequential(*copy.deepcopy(list(fast)))
+    x = torch.randn(2, 3, 20, 24)
+    fast.train(); plain.train()
+    yf = fast(x); yp = plain(x)
+    assert torch.allclose(yf, yp, rtol=1e-4, atol=1e-5)
+    for a, b in zip(fast.buffers(), plain.buffers()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-5)
+    yf.square().sum().backward(); yp.square().sum().backward()
+    for (n, a), b in zip(fast.named_parameters(), plain.parameters()):
+        if n.endswith("0.bias") or n.endswith("4.bias"):
+            assert a.grad is None or float(a.grad.abs().max()) == 0.0
+            assert float(b.grad.abs().max()) < 1e-3 * float(yp.square().sum())
+        else:
+            assert torch.allclose(a.grad, b.grad, rtol=2e-3, atol=1e-3 * float(b.grad.abs().max()))
+    fast.eval(); plain.eval()
+    assert torch.allclose(fast(x), plain(x), rtol=1e-4, atol=1e-5)
