@@ -215,14 +215,24 @@ __global__ __launch_bounds__(256) void fcsk_kernel(FcskParams p) {
     __syncthreads();
 
     // ---- output: coalesced along K ---------------------------------------------------------
-    if (!live) return;                                                     // go.cu:74-78: untouched
+    const bool fill = (p.flag & I2P_FLAG_FILL) != 0;
+    if (!live && !(fill && in_range)) return;                              // go.cu:74-78: untouched
     const size_t obase = ((size_t)c.b * p.npoints + n) * p.K;
+    if (!live) {                                                           // FILL: what torch.zeros would hold
+        for (int s = l16; s < p.K; s += GROUP) {
+            p.ob[obase + s] = 0; p.oh[obase + s] = 0; p.ow[obase + s] = 0; p.om[obase + s] = 0.0f;
+        }
+        return;
+    }
     const unsigned copy_code = outc[g][0];
     for (int s = l16; s < p.K; s += GROUP) {
         unsigned code = outc[g][s];
         bool wr = (code & CODE_VALID) != 0;                                // go.cu:225
         if (!wr && (p.flag & I2P_FLAG_COPY)) { code = copy_code; wr = true; } // go.cu:211-222
-        if (!wr) continue;
+        if (!wr) {
+            if (fill) { p.ob[obase + s] = 0; p.oh[obase + s] = 0; p.ow[obase + s] = 0; p.om[obase + s] = 0.0f; }
+            continue;
+        }
         int h = 0, w = 0;                                                  // non-stored slot: idx_h = idx_w = 0
         if (code & CODE_STORED) cell_hw(p, c, tab[code & 0xff], h, w);
         p.ob[obase + s] = c.b; p.oh[obase + s] = h; p.ow[obase + s] = w; p.om[obase + s] = 1.0f;

@@ -7,6 +7,7 @@ from . import ops
 
 FLAG_COPY = 0b0001    # broadcast the nearest hit to all K slots (fused_conv_go.cu:211-222)
 FLAG_SHIFT = 0b0010   # circular wrap along W (fused_conv_go.cu:96-113)
+FLAG_FILL = 0b0100    # extension: untouched slots are written as 0, outputs need no zero-fill (include/i2p_ops.h)
 
 
 def fused_conv_select_k(xyz1, xyz2, idx_n2, random_hw, H, W, npoints, kernel_size_H,
@@ -16,7 +17,7 @@ def fused_conv_select_k(xyz1, xyz2, idx_n2, random_hw, H, W, npoints, kernel_siz
     """
     xyz1 [B,H,W,3] f32 query image, xyz2 [B,small_h,small_w,3] f32 searched image,
     idx_n2 [B,npoints,2] i32 query cells, random_hw [kH*kW] i32 window visiting order.
-    Outputs (caller-allocated, caller-zeroed; only valid slots are written):
+    Outputs (caller-allocated, caller-zeroed unless FLAG_FILL; only valid slots are written):
     select_{b,h,w}_idx [B,npoints,K,1] i64, select_mask [B,npoints,K,1] f32;
     valid_idx / valid_in_dis_idx [B,npoints,kH*kW,1] f32 are returned untouched.
     """

@@ -22,39 +22,48 @@ from .modules import (CostVolume, FlowPredictor, PoseHead, ProjectPointNet, Proj
                       createCNNs)
 
 
+_const_cache = {}
+
+
+def _const(key, make):
+    """small constant tensors (pixel grid, intrinsic scale) built once per shape/device, outside any
+    hipGraph capture (the first, eager, step)"""
+    t = _const_cache.get(key)
+    if t is None:
+        t = _const_cache[key] = make()
+    return t
+
+
 def set_id_grid(rf):
     """rf [B,h,w,*] -> pixel coordinates (u, v, 1) [B, h*w, 3] (modellearn_proj_center.py:440-454)."""
     B, h, w = rf.shape[0], rf.shape[1], rf.shape[2]
-    v, u = torch.meshgrid(torch.arange(h, device=rf.device, dtype=rf.dtype),
-                          torch.arange(w, device=rf.device, dtype=rf.dtype), indexing="ij")
-    grid = torch.stack([u, v, torch.ones_like(u)], dim=-1).reshape(1, h * w, 3)
-    return grid.expand(B, -1, -1)
+
+    def make():
+        v, u = torch.meshgrid(torch.arange(h, device=rf.device, dtype=rf.dtype),
+                              torch.arange(w, device=rf.device, dtype=rf.dtype), indexing="ij")
+        return torch.stack([u, v, torch.ones_like(u)], dim=-1).reshape(1, h * w, 3)
+    return _const(("grid", h, w, str(rf.device), rf.dtype), make).expand(B, -1, -1)
 
 
 def change_intrinsic(intrinsic, RF, rgb_img):
-    """rescale fx, cx by w'/w and fy, cy by h'/h (modellearn_proj_center.py:457-463)."""
+    """rescale fx, cx by w'/w and fy, cy by h'/h (modellearn_proj_center.py:457-463): one multiply
+    by a constant [3,3] scale (rows 0 and 1; exact — the same products as the four in-place scalings)."""
     sx = RF.shape[3] / rgb_img.shape[3]
     sy = RF.shape[2] / rgb_img.shape[2]
-    out = intrinsic.clone()          # python scalars only: no host->device copy (hipGraph-capturable)
-    out[:, 0, 0] *= sx
-    out[:, 0, 2] *= sx
-    out[:, 1, 1] *= sy
-    out[:, 1, 2] *= sy
-    return out
+    scale = _const(("kscale", sx, sy, str(intrinsic.device)),
+                   lambda: torch.tensor([[sx, 1.0, sx], [1.0, sy, sy], [1.0, 1.0, 1.0]], device=intrinsic.device))
+    return intrinsic * scale
 
 
 def inverse_3x3(m):
-    """adjugate inverse of [B,3,3] on the device (replaces torch.inverse on the CPU, :282)."""
-    a, b, c = m[:, 0, 0], m[:, 0, 1], m[:, 0, 2]
-    d, e, f = m[:, 1, 0], m[:, 1, 1], m[:, 1, 2]
-    g, h, i = m[:, 2, 0], m[:, 2, 1], m[:, 2, 2]
-    A, Bc, Cc = e * i - f * h, -(d * i - f * g), d * h - e * g
-    det = a * A + b * Bc + c * Cc
-    adj = torch.stack([
-        torch.stack([A, -(b * i - c * h), b * f - c * e], -1),
-        torch.stack([Bc, a * i - c * g, -(a * f - c * d)], -1),
-        torch.stack([Cc, -(a * h - b * g), a * e - b * d], -1)], -2)
-    return adj / det.view(-1, 1, 1)
+    """adjugate inverse of [B,3,3] on the device (replaces torch.inverse on the CPU, :282):
+    rows of the adjugate-transpose are cross products of the rows of m, det = r0 . (r1 x r2)."""
+    r0, r1, r2 = m[:, 0], m[:, 1], m[:, 2]
+    c0 = torch.linalg.cross(r1, r2, dim=-1)
+    c1 = torch.linalg.cross(r2, r0, dim=-1)
+    c2 = torch.linalg.cross(r0, r1, dim=-1)
+    det = (r0 * c0).sum(-1)
+    return torch.stack([c0, c1, c2], dim=-1) / det.view(-1, 1, 1)
 
 
 class RegNet_v2(nn.Module):

@@ -18,7 +18,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
-from .fused_conv_select_k import FLAG_COPY, FLAG_SHIFT, fused_conv_select_k
+from .fused_conv_select_k import FLAG_COPY, FLAG_FILL, FLAG_SHIFT, fused_conv_select_k
 from .pointnet2_utils import grouping_operation
 
 # ---------------------------------------------------------------------------------------------
@@ -31,8 +31,25 @@ def get_idx_cuda(B, H, W, device):
     return get_stride_idx_cuda(B, H, W, 1, 1, device)
 
 
+_grid_cache = {}
+
+
+def _cached(key, make):
+    """constant index grids are built once per (shape, device): read-only for every consumer, and
+    a training step re-creating them costs ~60 tiny launches"""
+    t = _grid_cache.get(key)
+    if t is None:
+        t = _grid_cache[key] = make()
+    return t
+
+
 def get_stride_idx_cuda(B, out_h, out_w, stride_h, stride_w, device):
-    """[B, out_h*out_w, 2] i32 of (h*stride_h, w*stride_w)."""
+    """[B, out_h*out_w, 2] i32 of (h*stride_h, w*stride_w) (read-only: cached per shape and device)."""
+    return _cached(("stride", B, out_h, out_w, stride_h, stride_w, str(device)),
+                   lambda: _make_stride_idx(B, out_h, out_w, stride_h, stride_w, device))
+
+
+def _make_stride_idx(B, out_h, out_w, stride_h, stride_w, device):
     h = torch.arange(0, out_h * stride_h, stride_h, device=device, dtype=torch.int32)
     w = torch.arange(0, out_w * stride_w, stride_w, device=device, dtype=torch.int32)
     grid = torch.stack(torch.meshgrid(h, w, indexing="ij"), dim=-1).reshape(1, out_h * out_w, 2)
@@ -40,7 +57,12 @@ def get_stride_idx_cuda(B, out_h, out_w, stride_h, stride_w, device):
 
 
 def get_sample_idx(batch, out_h, out_w, stride_H, stride_W, device):
-    """three [batch, out_h, out_w] i64 grids (b, h*stride_H, w*stride_W)."""
+    """three [batch, out_h, out_w] i64 grids (b, h*stride_H, w*stride_W) (read-only: cached)."""
+    return _cached(("sample", batch, out_h, out_w, stride_H, stride_W, str(device)),
+                   lambda: _make_sample_idx(batch, out_h, out_w, stride_H, stride_W, device))
+
+
+def _make_sample_idx(batch, out_h, out_w, stride_H, stride_W, device):
     h = torch.arange(0, out_h * stride_H, stride_H, device=device, dtype=torch.int64)
     w = torch.arange(0, out_w * stride_W, stride_W, device=device, dtype=torch.int64)
     b = torch.arange(batch, device=device, dtype=torch.int64)
@@ -112,12 +134,13 @@ def _get_neighbor(xyz1_proj, xyz2_proj, idx_n2, kernel_shape, knn_points, stride
     n_points = idx_n2.shape[1]
     dev = xyz1_proj.device
     random_hw = _window_order(kt, dev)
-    sel = torch.zeros(3, batch, n_points, knn_points, 1, device=dev, dtype=torch.long)
-    mask = torch.zeros(batch, n_points, knn_points, 1, device=dev, dtype=torch.float32)
+    # FLAG_FILL: the operator writes every slot, so no zero-fill of the outputs (reference: torch.zeros, utils.py:77-82)
+    sel = torch.empty(3, batch, n_points, knn_points, 1, device=dev, dtype=torch.long)
+    mask = torch.empty(batch, n_points, knn_points, 1, device=dev, dtype=torch.float32)
     # never written by the operator (reference allocates [B,N,kt,1] zeros for both)
-    unused = torch.zeros(1, device=dev, dtype=torch.float32)
+    unused = _cached(("unused", str(dev)), lambda: torch.zeros(1, device=dev, dtype=torch.float32))
     fused_conv_select_k(xyz1_proj.contiguous(), xyz2_proj.contiguous(), idx_n2.contiguous(), random_hw,
-                        height, width, n_points, kernel_shape[0], kernel_shape[1], knn_points, flag,
+                        height, width, n_points, kernel_shape[0], kernel_shape[1], knn_points, flag | FLAG_FILL,
                         distance, stride_h, stride_w, sel[0], sel[1], sel[2], unused, unused, mask,
                         small_h, small_w)
     return sel[0].squeeze(-1), sel[1].squeeze(-1), sel[2].squeeze(-1), mask

@@ -42,6 +42,10 @@ extern "C" {
 
 #define I2P_FLAG_COPY  1   /* fused_conv_select_k.py:6 */
 #define I2P_FLAG_SHIFT 2   /* fused_conv_select_k.py:7 */
+/* extension (not in the reference): slots the reference leaves untouched (dead queries, unselected slots
+ * without FLAG_COPY) are WRITTEN as index 0 / mask 0, so the caller need not zero-fill the outputs first
+ * (the reference relies on torch.zeros outputs, utils.py:77-82). */
+#define I2P_FLAG_FILL  4
 
 /* ABI version / build info (not in the reference). */
 int i2p_abi_version(void);

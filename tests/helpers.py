@@ -21,17 +21,17 @@ def range_image(B, H, W, seed, empty_frac=0.2, lattice=False, scale=20.0):
     return (img * keep).contiguous()
 
 
-def run_fcsk(backend, xyz1, xyz2, idx_n2, kH, kW, K, flag, distance, stride_h, stride_w, random_hw=None):
+def run_fcsk(backend, xyz1, xyz2, idx_n2, kH, kW, K, flag, distance, stride_h, stride_w, random_hw=None, init=0):
     B, H, W, _ = xyz1.shape
     sh, sw = xyz2.shape[1:3]
     N = idx_n2.shape[1]
     dev = xyz1.device
     if random_hw is None:
         random_hw = torch.arange(kH * kW, dtype=torch.int32, device=dev)
-    sb = torch.zeros(B, N, K, 1, dtype=torch.long, device=dev)
-    sh_ = torch.zeros_like(sb); sw_ = torch.zeros_like(sb)
+    sb = torch.full((B, N, K, 1), init, dtype=torch.long, device=dev)
+    sh_ = sb.clone(); sw_ = sb.clone()
     v1 = torch.zeros(B, N, kH * kW, 1, device=dev); v2 = torch.zeros_like(v1)
-    m = torch.zeros(B, N, K, 1, device=dev)
+    m = torch.full((B, N, K, 1), float(init), device=dev)
     backend.fused_conv_select_k(xyz1, xyz2, idx_n2, random_hw, H, W, N, kH, kW, K, flag, distance,
                                 stride_h, stride_w, sb, sh_, sw_, v1, v2, m, sh, sw)
     return sb, sh_, sw_, m, v1, v2

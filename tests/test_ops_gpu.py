@@ -72,6 +72,21 @@ def test_fcsk_adversarial(oracle_backend, hip_backend):
     _both_fcsk(oracle_backend, hip_backend, xn, xn, idx, 3, 5, 4, 3, 5.0, 1, 1)
 
 
+def test_fcsk_fill_flag(oracle_backend, hip_backend):
+    """FLAG_FILL (extension): garbage-initialised outputs come out exactly as zero-initialised ones
+    without the flag — on the HIP kernel and on the oracle — for COPY and non-COPY searches."""
+    B, H, W = 2, 16, 90
+    x = range_image(B, H, W, seed=4, empty_frac=0.4, scale=4.0)
+    idx = stride_grid(B, H, W, 1, 1)
+    for flag in (2, 3):
+        want = run_fcsk(oracle_backend, x, x, idx, 5, 9, 8, flag, 1.5, 1, 1)
+        got_o = run_fcsk(oracle_backend, x, x, idx, 5, 9, 8, flag | 4, 1.5, 1, 1, init=77)
+        got_h = run_fcsk(hip_backend, x.to(DEV), x.to(DEV), idx.to(DEV), 5, 9, 8, flag | 4, 1.5, 1, 1, init=77)
+        for w_, o_, h_ in zip(want[:4], got_o[:4], got_h[:4]):
+            assert torch.equal(w_, o_)
+            assert torch.equal(w_, h_.cpu())
+
+
 def test_fcsk_full_size_level1(oracle_backend, hip_backend):
     """BASELINE shape: 64x1800 image, 16x225 queries, 9x15 window, K=32."""
     B = 2
