@@ -134,8 +134,8 @@ def cpu_baseline(cfg, batch_size=2, steps=2):
     prev = ops.set_backend(oracle.backend())
     # the reference's CPU path = eager PyTorch-CPU (multi-threaded GEMM / BN) + CPU restatements of its
     # CUDA operators; the oracle's scalar restatements of OUR fused kernels are checkers, not a baseline
-    fused = (modules.USE_FUSED_MLP, modules.USE_FUSED_BN)
-    modules.USE_FUSED_MLP = modules.USE_FUSED_BN = False
+    fused = (modules.USE_FUSED_MLP, modules.USE_FUSED_BN, modules.USE_FUSED_IMG)
+    modules.USE_FUSED_MLP = modules.USE_FUSED_BN = modules.USE_FUSED_IMG = False
     try:
         tr = Trainer(cfg=cfg, device="cpu")
         batch = synth.make_batch(batch_size, 8192, 375, 1242, seed=0)
@@ -146,7 +146,7 @@ def cpu_baseline(cfg, batch_size=2, steps=2):
         dt = time.perf_counter() - t0
     finally:
         ops.set_backend(prev)
-        modules.USE_FUSED_MLP, modules.USE_FUSED_BN = fused
+        modules.USE_FUSED_MLP, modules.USE_FUSED_BN, modules.USE_FUSED_IMG = fused
     return {"value": round(batch_size * steps / dt, 4), "unit": "samples/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": f"{steps} training steps at batch {batch_size} (same shapes), host cpu_count={os.cpu_count()}"}
 

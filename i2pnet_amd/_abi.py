@@ -33,6 +33,8 @@ SIGNATURES = {
     "i2p_quat_mul": ["i", "i", "i", "i", "i", "p", "p", "p"],
     "i2p_row_unitvar_fwd": ["i", "i", "p", "p", "p"],
     "i2p_row_unitvar_bwd": ["i", "i", "p", "p", "p", "p"],
+    "i2p_img_bn_pool_fwd": ["i", "i", "i", "i", "i", "p", "p", "p", "p", "f", "f", "f", "p", "p", "p", "p", "p", "p"],
+    "i2p_img_bn_pool_bwd": ["i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "f", "p", "p", "p", "p"],
     "i2p_bn_finalize": ["l", "i", "p", "p", "p", "f", "p", "p"],
     "i2p_lin_bwd": ["l", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 5,
     "i2p_pair_lin_fwd": ["i"] * 5 + ["p"] * 7,

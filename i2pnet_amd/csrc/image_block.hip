@@ -1,0 +1,259 @@
+// Image-encoder block tail for gfx950: BatchNorm2d (batch statistics, running buffers updated) +
+// LeakyReLU(0.1) + MaxPool2d(3, stride, padding 1) on the NHWC output of a 3x3 convolution
+// (reference: src/modules/basicConv.py:6-20, 15 such blocks in front of the cost volumes).
+//
+// PyTorch/MIOpen runs this as 3 BN kernels + LeakyReLU + pooling forward (4 full-tensor reads, 2 full
+// writes + the pooled write) and 3 BN-backward kernels + LeakyReLU backward + pooling backward
+// (≈ 9 full-tensor passes); the largest tensor is 238 MB at batch 8.  Here:
+//   forward : bn_stats (1 read; csrc/bn_act.hip)  +  img_pool_fwd (1 read, pooled write + 1-byte arg-max)
+//   backward: img_bwd_stats (pooled-size reads + arg-max gathers)  +  img_bwd_dx (1 read, 1 write)
+// The conv output is never normalised/activated in memory; the backward recomputes z = bn(y) on load.
+// HBM-streaming kernels: float4 per lane along C, consecutive lanes along C then W (coalesced).
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int REP = I2P_BN_REPLICAS;
+constexpr int MAX_STAT_BLOCKS = 1024;
+
+struct PoolGeom {
+    int B, H, W, C, s, Ho, Wo, cv;
+};
+
+__device__ __forceinline__ double rep_sum(const double *sums, int c, int idx) {
+    double a = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < REP; ++r) a += sums[(size_t)r * 2 * c + idx];
+    return a;
+}
+
+// per-channel batch statistics -> mean_invstd [2C]; running buffers (momentum update, unbiased variance,
+// running mean of conv+bias when the caller skipped the cancelling conv bias)
+__global__ void img_finalize_kernel(long long n, int c, const double *__restrict__ sums, float eps, float momentum,
+                                    const float *__restrict__ conv_bias, float *__restrict__ running_mean,
+                                    float *__restrict__ running_var, float *__restrict__ mean_invstd) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const double m = rep_sum(sums, c, ch) / (double)n;
+    double var = rep_sum(sums, c, c + ch) / (double)n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    mean_invstd[ch] = (float)m;
+    mean_invstd[c + ch] = rsqrtf((float)var + eps);
+    if (running_mean) {
+        const float mb = (float)m + (conv_bias ? conv_bias[ch] : 0.f);
+        running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mb;
+        const float unbiased = (float)(var * ((double)n / (double)(n > 1 ? n - 1 : 1)));
+        running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+    }
+}
+
+struct Coef4 { float mean[4], invstd[4], scale[4], beta[4]; };
+
+__device__ __forceinline__ Coef4 load_coef(const float *mean_invstd, const float *gamma, const float *beta, int c,
+                                           int vcol) {
+    Coef4 k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = vcol * 4 + i;
+        k.mean[i] = mean_invstd[ch]; k.invstd[i] = mean_invstd[c + ch];
+        k.scale[i] = k.invstd[i] * gamma[ch]; k.beta[i] = beta[ch];
+    }
+    return k;
+}
+
+__device__ __forceinline__ float bn_z(float y, const Coef4 &k, int i) { return (y - k.mean[i]) * k.scale[i] + k.beta[i]; }
+
+__global__ __launch_bounds__(THREADS) void img_pool_fwd_kernel(PoolGeom g, const float4 *__restrict__ y,
+                                                                const float *__restrict__ mean_invstd,
+                                                                const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, float slope,
+                                                                float4 *__restrict__ out, uchar4 *__restrict__ arg) {
+    const long long total = (long long)g.B * g.Ho * g.Wo * g.cv;
+    const int vcol = threadIdx.x % g.cv;              // THREADS % cv == 0 and the grid stride is a multiple of THREADS
+    const Coef4 k = load_coef(mean_invstd, gamma, beta, g.C, vcol);
+    for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
+        long long r = t / g.cv;
+        const int wo = (int)(r % g.Wo); r /= g.Wo;
+        const int ho = (int)(r % g.Ho);
+        const int b = (int)(r / g.Ho);
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned char bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = ho * g.s - 1 + kh;
+            if (h < 0 || h >= g.H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int w = wo * g.s - 1 + kw;
+                if (w < 0 || w >= g.W) continue;
+                const float4 v = y[(((long long)b * g.H + h) * g.W + w) * g.cv + vcol];
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float z = bn_z(vv[i], k, i);
+                    const float a = z > 0.f ? z : z * slope;
+                    if (a > best[i] || a != a) { best[i] = a; bi[i] = (unsigned char)(kh * 3 + kw); }   // first max wins
+                }
+            }
+        }
+        out[t] = make_float4(best[0], best[1], best[2], best[3]);
+        arg[t] = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+    }
+}
+
+// sums over all conv-output positions of gz = dL/dz (z = BN output) and gz*xhat, visited through the pooled
+// outputs: each pooled element routes its gradient to its arg-max position.
+__global__ __launch_bounds__(THREADS) void img_bwd_stats_kernel(PoolGeom g, const float4 *__restrict__ gout,
+                                                                 const uchar4 *__restrict__ arg,
+                                                                 const float *__restrict__ y,
+                                                                 const float *__restrict__ mean_invstd,
+                                                                 const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, float slope,
+                                                                 double *__restrict__ dsums) {
+    __shared__ double red[THREADS][8];
+    const long long total = (long long)g.B * g.Ho * g.Wo * g.cv;
+    const int vcol = threadIdx.x % g.cv;
+    const Coef4 k = load_coef(mean_invstd, gamma, beta, g.C, vcol);
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
+        long long r = t / g.cv;
+        const int wo = (int)(r % g.Wo); r /= g.Wo;
+        const int ho = (int)(r % g.Ho);
+        const int b = (int)(r / g.Ho);
+        const float4 go = gout[t];
+        const uchar4 a = arg[t];
+        const float gv[4] = {go.x, go.y, go.z, go.w};
+        const unsigned char av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int h = ho * g.s - 1 + av[i] / 3, w = wo * g.s - 1 + av[i] % 3;
+            const float yv = y[((((long long)b * g.H + h) * g.W + w) * g.cv + vcol) * 4 + i];
+            const float z = bn_z(yv, k, i);
+            const float gz = z > 0.f ? gv[i] : gv[i] * slope;
+            const float xh = (yv - k.mean[i]) * k.invstd[i];
+            s[i] += gz; q[i] += (double)gz * xh;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][4 + i] = q[i]; }
+    __syncthreads();
+    if (threadIdx.x < g.cv) {
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = threadIdx.x; t < THREADS; t += g.cv)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += red[t][i];
+        double *rep = dsums + (size_t)(blockIdx.x % REP) * 2 * g.C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            atomicAdd(rep + vcol * 4 + i, acc[i]);
+            atomicAdd(rep + g.C + vcol * 4 + i, acc[4 + i]);
+        }
+    }
+}
+
+// dL/dy of the conv output: gather the pooled gradients whose arg-max is this position, LeakyReLU', BN backward.
+__global__ __launch_bounds__(THREADS) void img_bwd_dx_kernel(PoolGeom g, const float4 *__restrict__ gout,
+                                                              const uchar4 *__restrict__ arg,
+                                                              const float4 *__restrict__ y,
+                                                              const float *__restrict__ mean_invstd,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, float slope,
+                                                              const double *__restrict__ dsums,
+                                                              float4 *__restrict__ dy, float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta) {
+    const long long total = (long long)g.B * g.H * g.W * g.cv;
+    const int vcol = threadIdx.x % g.cv;
+    const Coef4 k = load_coef(mean_invstd, gamma, beta, g.C, vcol);
+    const double n = (double)g.B * g.H * g.W;
+    float mg[4], mgx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double sg = rep_sum(dsums, g.C, vcol * 4 + i), sgx = rep_sum(dsums, g.C, g.C + vcol * 4 + i);
+        mg[i] = (float)(sg / n); mgx[i] = (float)(sgx / n);
+        if (blockIdx.x == 0 && threadIdx.x < g.cv) { dbeta[vcol * 4 + i] = (float)sg; dgamma[vcol * 4 + i] = (float)sgx; }
+    }
+    for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
+        long long r = t / g.cv;
+        const int w = (int)(r % g.W); r /= g.W;
+        const int h = (int)(r % g.H);
+        const int b = (int)(r / g.H);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // outputs ho with ho*s-1 <= h <= ho*s+1
+        const int ho0 = max(0, (h - 1 + g.s - 1) / g.s), ho1 = min(g.Ho - 1, (h + 1) / g.s);
+        const int wo0 = max(0, (w - 1 + g.s - 1) / g.s), wo1 = min(g.Wo - 1, (w + 1) / g.s);
+        for (int ho = ho0; ho <= ho1; ++ho)
+            for (int wo = wo0; wo <= wo1; ++wo) {
+                const unsigned char p = (unsigned char)((h - (ho * g.s - 1)) * 3 + (w - (wo * g.s - 1)));
+                const long long o = (((long long)b * g.Ho + ho) * g.Wo + wo) * g.cv + vcol;
+                const uchar4 a = arg[o];
+                if (a.x != p && a.y != p && a.z != p && a.w != p) continue;
+                const float4 go = gout[o];
+                acc[0] += a.x == p ? go.x : 0.f; acc[1] += a.y == p ? go.y : 0.f;
+                acc[2] += a.z == p ? go.z : 0.f; acc[3] += a.w == p ? go.w : 0.f;
+            }
+        const float4 v = y[t];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        float o4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float z = bn_z(vv[i], k, i);
+            const float gz = z > 0.f ? acc[i] : acc[i] * slope;
+            const float xh = (vv[i] - k.mean[i]) * k.invstd[i];
+            o4[i] = k.scale[i] * (gz - mg[i] - xh * mgx[i]);
+        }
+        dy[t] = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    }
+}
+
+bool geom_ok(int B, int H, int W, int C, int s) {
+    return B >= 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0 && (THREADS % (C / 4)) == 0 && (s == 1 || s == 2);
+}
+
+PoolGeom make_geom(int B, int H, int W, int C, int s) {
+    PoolGeom g;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.s = s; g.cv = C / 4;
+    g.Ho = (H - 1) / s + 1; g.Wo = (W - 1) / s + 1;        // floor((H + 2*1 - 3)/s) + 1
+    return g;
+}
+
+unsigned grid_for(long long total, int cap) {
+    long long b = (total + THREADS - 1) / THREADS;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int i2p_img_bn_pool_fwd(int B, int H, int W, int C, int stride, const float *y, const double *sums,
+                                   const float *gamma, const float *beta, float eps, float slope, float momentum,
+                                   const float *conv_bias, float *running_mean, float *running_var, float *out,
+                                   unsigned char *arg, float *mean_invstd, void *stream) {
+    if (!geom_ok(B, H, W, C, stride)) return I2P_ERR_BAD_ARG;
+    if (B == 0) return 0;
+    const PoolGeom g = make_geom(B, H, W, C, stride);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(img_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (long long)B * H * W, C, sums, eps,
+                       momentum, conv_bias, running_mean, running_var, mean_invstd);
+    const long long total = (long long)B * g.Ho * g.Wo * g.cv;
+    hipLaunchKernelGGL(img_pool_fwd_kernel, dim3(grid_for(total, 1 << 20)), dim3(THREADS), 0, st, g, (const float4 *)y,
+                       mean_invstd, gamma, beta, slope, (float4 *)out, (uchar4 *)arg);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_img_bn_pool_bwd(int B, int H, int W, int C, int stride, const float *gout, const unsigned char *arg,
+                                   const float *y, const float *mean_invstd, const float *gamma, const float *beta,
+                                   float slope, double *dsums, float *dy, float *dgamma, float *dbeta, void *stream) {
+    if (!geom_ok(B, H, W, C, stride)) return I2P_ERR_BAD_ARG;
+    if (B == 0) return 0;
+    const PoolGeom g = make_geom(B, H, W, C, stride);
+    hipStream_t st = (hipStream_t)stream;
+    const long long tot_o = (long long)B * g.Ho * g.Wo * g.cv, tot_i = (long long)B * H * W * g.cv;
+    hipLaunchKernelGGL(img_bwd_stats_kernel, dim3(grid_for(tot_o, MAX_STAT_BLOCKS)), dim3(THREADS), 0, st, g,
+                       (const float4 *)gout, (const uchar4 *)arg, y, mean_invstd, gamma, beta, slope, dsums);
+    hipLaunchKernelGGL(img_bwd_dx_kernel, dim3(grid_for(tot_i, 1 << 20)), dim3(THREADS), 0, st, g, (const float4 *)gout,
+                       (const uchar4 *)arg, (const float4 *)y, mean_invstd, gamma, beta, slope, dsums, (float4 *)dy,
+                       dgamma, dbeta);
+    I2P_RETURN_LAUNCH_STATUS();
+}

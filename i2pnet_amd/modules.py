@@ -29,6 +29,8 @@ USE_FUSED_MLP = True
 USE_FUSED_BN = True
 # cost_volume1's mlp1[1:] / pi_encoding / mlp2 / softmax-weighted sum as one fused autograd node
 USE_CV_TAIL = True
+# image-encoder blocks: BN(batch statistics) + LeakyReLU + MaxPool3 as fused HIP kernels behind MIOpen's conv
+USE_FUSED_IMG = True
 
 
 def run_stack(x, convs, first_bn=None):
@@ -158,12 +160,52 @@ class Conv1d(nn.Module):
         return self.composed_module(x.permute(0, 2, 1)).permute(0, 2, 1)
 
 
+class _BnActPool(torch.autograd.Function):
+    """BatchNorm2d(train) + LeakyReLU + MaxPool2d(3, stride, 1) on a channels_last conv output, two HIP
+    launches each way (csrc/image_block.hip); saves the conv output, the 1-byte arg-max and 2C statistics
+    (PyTorch saves the conv output, the BN output, the activation output and int64 pool indices)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, conv_bias, running_mean, running_var, stride, momentum, eps, slope):
+        y_nhwc = y.permute(0, 2, 3, 1)                      # channels_last storage seen as [B,H,W,C]
+        if not y_nhwc.is_contiguous():
+            y_nhwc = y_nhwc.contiguous()
+        out, arg, mi = ops.get_backend().img_bn_pool_forward(
+            y_nhwc, gamma.detach(), beta.detach(), eps, slope, stride, momentum, conv_bias.detach(),
+            running_mean, running_var)
+        ctx.save_for_backward(y_nhwc, arg, mi, gamma, beta)
+        ctx.stride, ctx.slope = stride, slope
+        return out.permute(0, 3, 1, 2)                      # [B,C,Ho,Wo] view with channels_last strides
+
+    @staticmethod
+    def backward(ctx, g):
+        y_nhwc, arg, mi, gamma, beta = ctx.saved_tensors
+        g_nhwc = g.permute(0, 2, 3, 1)
+        if not g_nhwc.is_contiguous():
+            g_nhwc = g_nhwc.contiguous()
+        dy, dgamma, dbeta = ops.get_backend().img_bn_pool_backward(g_nhwc, arg, y_nhwc, mi, gamma.detach(), beta.detach(),
+                                                                   ctx.slope, ctx.stride)
+        return dy.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, None
+
+
 class _ImageCNN(nn.Sequential):
     """`Sequential` of (Conv2d 3x3, BatchNorm2d, LeakyReLU, MaxPool2d) blocks with the reference's child
-    names; in training the conv bias is not added: in front of a batch-statistics BN it cancels in the
+    names.  In training the conv bias is not added: in front of a batch-statistics BN it cancels in the
     output and its gradient is exactly zero, but adding it and reducing its gradient costs two passes over
-    the largest tensors of the network (238 MB at level 1).  The running mean is corrected by
-    the bias so that eval mode (running statistics, bias added) sees the same buffers."""
+    the largest tensors of the network (238 MB at level 1); it only enters the running mean, so that eval
+    mode (running statistics, bias added) sees the same buffers.  With USE_FUSED_IMG the BN + LeakyReLU +
+    MaxPool tail of every block runs on the fused HIP kernels; the 3x3 convolution stays on MIOpen."""
+
+    def _fusable(self, mods):
+        for i in range(0, len(mods), 4):
+            conv, bn, act, pool = mods[i:i + 4]
+            c = conv.out_channels
+            ok = (bn.track_running_stats and bn.momentum is not None and isinstance(act, nn.LeakyReLU)
+                  and pool.kernel_size == 3 and pool.padding == 1 and pool.stride in (1, 2) and pool.dilation == 1
+                  and not pool.ceil_mode and c % 4 == 0 and 256 % (c // 4) == 0)
+            if not ok:
+                return False
+        return True
 
     def forward(self, x):
         mods = list(self)
@@ -172,6 +214,16 @@ class _ImageCNN(nn.Sequential):
         if not fast:
             return super().forward(x)
         bns = [mods[i + 1] for i in range(0, len(mods), 4)]
+        if USE_FUSED_IMG and x.dtype == torch.float32 and self._fusable(mods):
+            with torch.no_grad():
+                torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
+            x = x.contiguous(memory_format=torch.channels_last)
+            for i in range(0, len(mods), 4):
+                conv, bn, act, pool = mods[i:i + 4]
+                y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+                x = _BnActPool.apply(y, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
+                                     bn.momentum, bn.eps, act.negative_slope)
+            return x
         with torch.no_grad():
             # rm' = (1-m) rm + m (mean_without_bias + bias): pre-add m/(1-m) * bias (before autograd saves the buffer)
             for i, b in zip(range(0, len(mods), 4), bns):

@@ -229,6 +229,39 @@ class CBackend:
                    self._p(stat, _F32, "stat"), self._p(gx, _F32, "gx"), stream=self._stream())
         return gx
 
+    # ---- image-encoder block tail: BN(batch stats) + LeakyReLU + MaxPool3 (basicConv.py:13-17) -----------
+    def img_bn_pool_forward(self, y, gamma, beta, eps, slope, stride, momentum=0.0, conv_bias=None,
+                            running_mean=None, running_var=None):
+        """y [B,H,W,C] (NHWC-contiguous conv output) -> (out [B,Ho,Wo,C], arg u8 [B,Ho,Wo,C], mean_invstd [2C]);
+        updates the running buffers in place when given."""
+        B, H, W, Cc = y.shape
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        sums = self.bn_stats(y.view(B * H * W, Cc))
+        out = torch.empty(B, Ho, Wo, Cc, dtype=_F32, device=y.device)
+        arg = torch.empty(B, Ho, Wo, Cc, dtype=torch.uint8, device=y.device)
+        mean_invstd = torch.empty(2 * Cc, dtype=_F32, device=y.device)
+        opt = lambda t, what: self._p(t, _F32, what) if t is not None else None
+        self._call("i2p_img_bn_pool_fwd", int(B), int(H), int(W), int(Cc), int(stride), self._p(y, _F32, "y"),
+                   self._p(sums, torch.float64, "sums"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"),
+                   float(eps), float(slope), float(momentum), opt(conv_bias, "conv_bias"),
+                   opt(running_mean, "running_mean"), opt(running_var, "running_var"), self._p(out, _F32, "out"),
+                   self._p(arg, torch.uint8, "arg"), self._p(mean_invstd, _F32, "mean_invstd"), stream=self._stream())
+        return out, arg, mean_invstd
+
+    def img_bn_pool_backward(self, gout, arg, y, mean_invstd, gamma, beta, slope, stride):
+        """-> (dy [B,H,W,C], dgamma [C], dbeta [C])"""
+        B, H, W, Cc = y.shape
+        dy = torch.empty_like(y)
+        dgamma = torch.empty(Cc, dtype=_F32, device=y.device)
+        dbeta = torch.empty(Cc, dtype=_F32, device=y.device)
+        dsums = zeros(BN_REPLICAS * 2 * Cc, torch.float64, y.device)
+        self._call("i2p_img_bn_pool_bwd", int(B), int(H), int(W), int(Cc), int(stride), self._p(gout, _F32, "gout"),
+                   self._p(arg, torch.uint8, "arg"), self._p(y, _F32, "y"), self._p(mean_invstd, _F32, "mean_invstd"),
+                   self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(slope),
+                   self._p(dsums, torch.float64, "dsums"), self._p(dy, _F32, "dy"), self._p(dgamma, _F32, "dgamma"),
+                   self._p(dbeta, _F32, "dbeta"), stream=self._stream())
+        return dy, dgamma, dbeta
+
     # ---- batch-stat BatchNorm + activation (PPBackbone_center.py:28-46) ---------------------------
     def bn_act_forward(self, y, gamma, beta, eps, slope):
         """y [rows,c] f32 -> (out [rows,c], mean_invstd [2c]) with batch statistics."""

@@ -249,6 +249,25 @@ int i2p_row_unitvar_bwd(int rows, int c, const float *gy, const float *y, const 
                         void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Image-encoder block tail (src/modules/basicConv.py:13-17: BatchNorm2d -> LeakyReLU(0.1) -> MaxPool2d(3,
+ * stride, padding=1)) in training mode, on the NHWC output y f32 [B,H,W,C] of the block's 3x3 convolution.
+ *   sums: replicated {sum y, sum y^2} (i2p_bn_stats over rows = B*H*W); C % 4 == 0, (C/4) | 256; stride 1 or 2.
+ *   forward: mean_invstd f32 [2C] written; running_mean/var (may be NULL) updated with `momentum` (unbiased
+ *     variance; conv_bias, may be NULL, is added to the batch mean first: the bias the caller left out of y
+ *     because it cancels in the normalisation); out f32 [B,Ho,Wo,C], Ho = (H-1)/stride+1;
+ *     arg u8 [B,Ho,Wo,C] = window position kh*3+kw of the maximum (first maximum in scan order).
+ *   backward: gout f32 [B,Ho,Wo,C] -> dy f32 [B,H,W,C] (gradient of the conv output), dgamma, dbeta f32 [C];
+ *     dsums replicated f64 scratch, zeroed by the caller.
+ * --------------------------------------------------------------------------------------------- */
+int i2p_img_bn_pool_fwd(int B, int H, int W, int C, int stride, const float *y, const double *sums,
+                        const float *gamma, const float *beta, float eps, float slope, float momentum,
+                        const float *conv_bias, float *running_mean, float *running_var, float *out,
+                        unsigned char *arg, float *mean_invstd, void *stream);
+int i2p_img_bn_pool_bwd(int B, int H, int W, int C, int stride, const float *gout, const unsigned char *arg,
+                        const float *y, const float *mean_invstd, const float *gamma, const float *beta,
+                        float slope, double *dsums, float *dy, float *dgamma, float *dbeta, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * First layer of the all-pixel cost volume (src/projectPN/PPBackbone_center.py:383-418): the
  * reference builds [B,N,M,6+C(+C)] = cat(xyz_n, uv_k, norm(LF_n)*norm(RF_k) (, max-response_k))
  * and runs a 1x1 conv on it.  Factored here as

@@ -228,6 +228,42 @@ def test_row_unitvar_parity(oracle_backend, hip_backend):
         assert torch.allclose(rg, hg.cpu(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("stride,C,H,W", [(1, 16, 37, 53), (2, 16, 37, 53), (2, 32, 24, 40), (1, 64, 12, 20), (2, 128, 24, 78)])
+def test_img_bn_pool_parity(oracle_backend, hip_backend, stride, C, H, W):
+    """image-encoder block tail: HIP vs oracle (arg-max bit-exact away from ties, values 1e-5) and vs
+    torch's batch_norm -> leaky_relu -> max_pool2d on the GPU (gradient of the conv output)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(C + stride)
+    B = 3
+    y = torch.randn(B, H, W, C, generator=g) * 2 + 0.3
+    gam = torch.randn(C, generator=g); bet = torch.randn(C, generator=g) * 0.2; bias = torch.randn(C, generator=g) * 0.1
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    rm_o, rv_o, rm_h, rv_h = rm.clone(), rv.clone(), rm.clone().to(DEV), rv.clone().to(DEV)
+    ro, ra, rmi = oracle_backend.img_bn_pool_forward(y, gam, bet, 1e-5, 0.1, stride, 0.1, bias, rm_o, rv_o)
+    ho, ha, hmi = hip_backend.img_bn_pool_forward(y.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5, 0.1, stride, 0.1, bias.to(DEV),
+                                                  rm_h, rv_h)
+    assert torch.allclose(rmi, hmi.cpu(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(ro, ho.cpu(), rtol=1e-5, atol=1e-5)
+    assert (ra == ha.cpu()).float().mean() > 0.9999
+    assert torch.allclose(rm_o, rm_h.cpu(), rtol=1e-5, atol=1e-6) and torch.allclose(rv_o, rv_h.cpu(), rtol=1e-5, atol=1e-6)
+    gout = torch.randn(ro.shape, generator=g)
+    rdy, rdg, rdb = oracle_backend.img_bn_pool_backward(gout, ra, y, rmi, gam, bet, 0.1, stride)
+    hdy, hdg, hdb = hip_backend.img_bn_pool_backward(gout.to(DEV), ra.to(DEV), y.to(DEV), rmi.to(DEV), gam.to(DEV),
+                                                     bet.to(DEV), 0.1, stride)
+    sc = float(rdy.abs().max())
+    assert torch.allclose(rdy, hdy.cpu(), rtol=1e-4, atol=1e-5 * sc)
+    assert torch.allclose(rdg, hdg.cpu(), rtol=1e-4, atol=1e-4 * float(rdg.abs().max()))
+    assert torch.allclose(rdb, hdb.cpu(), rtol=1e-4, atol=1e-4 * float(rdb.abs().max()))
+    # torch on the GPU
+    yt = y.to(DEV).permute(0, 3, 1, 2).clone().requires_grad_()
+    gt, bt = gam.to(DEV).requires_grad_(), bet.to(DEV).requires_grad_()
+    out_t = F.max_pool2d(F.leaky_relu(F.batch_norm(yt, None, None, gt, bt, True, 0.1, 1e-5), 0.1), 3, stride, 1)
+    assert torch.allclose(out_t.permute(0, 2, 3, 1), ho, rtol=1e-4, atol=1e-4)
+    (out_t * gout.to(DEV).permute(0, 3, 1, 2)).sum().backward()
+    assert torch.allclose(yt.grad.permute(0, 2, 3, 1), hdy, rtol=1e-3, atol=1e-4 * sc)
+    assert torch.allclose(gt.grad, hdg, rtol=1e-3, atol=1e-3 * float(rdg.abs().max()))
+
+
 def test_project_seq_parity(oracle_backend, hip_backend):
     """Cells are bit-exact for points away from a bin edge (device OCML vs host libm differ in
     the last ulp of atan2/asin); images are compared on cells whose winner agrees."""

@@ -1,6 +1,7 @@
 """CPU tests: the oracle against the only known answers the reference holds for this path,
 and against independent (slow, pure-torch) restatements of the operator definitions."""
 import numpy as np
+import pytest
 import torch
 
 from helpers import cloud, range_image, run_fcsk, stride_grid
@@ -250,12 +251,17 @@ def test_row_unitvar_oracle_vs_torch(oracle_backend):
         ops.set_backend(prev)
 
 
-def test_image_cnn_bias_skip_equivalent():
+@pytest.mark.parametrize("fused", [False, True])
+def test_image_cnn_bias_skip_equivalent(oracle_backend, fused, monkeypatch):
     """training-mode image encoder without the (cancelling) conv bias == the plain Sequential:
-    same output, same running statistics, zero bias gradient."""
+    same output, same running statistics, zero bias gradient — for the torch tail and the fused tail
+    (oracle operators on CPU)."""
     import copy
     import torch.nn as nn
+    from i2pnet_amd import modules, ops
     from i2pnet_amd.modules import createCNNs
+    monkeypatch.setattr(modules, "USE_FUSED_IMG", fused)
+    monkeypatch.setattr(ops, "_active", oracle_backend)
     torch.manual_seed(0)
     fast = createCNNs(3, [8, 8], [2, 1])
     for m in fast:
@@ -277,3 +283,44 @@ def test_image_cnn_bias_skip_equivalent():
             assert torch.allclose(a.grad, b.grad, rtol=2e-3, atol=1e-3 * float(b.grad.abs().max()))
     fast.eval(); plain.eval()
     assert torch.allclose(fast(x), plain(x), rtol=1e-4, atol=1e-5)
+
+
+def _img_tail_torch(y, bn, slope, stride):
+    import torch.nn.functional as F
+    z = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+    return F.max_pool2d(F.leaky_relu(z, slope), 3, stride, 1)
+
+
+@pytest.mark.parametrize("stride,C,H,W", [(1, 16, 9, 13), (2, 16, 9, 13), (2, 32, 10, 12), (1, 128, 5, 7)])
+def test_img_bn_pool_oracle_vs_torch(oracle_backend, stride, C, H, W):
+    """oracle image-block tail == F.batch_norm(train) -> leaky_relu -> max_pool2d(3, stride, 1): output,
+    running buffers, and gradients w.r.t. the conv output, gamma and beta."""
+    import torch.nn as nn
+    from i2pnet_amd import modules, ops
+    g = torch.Generator().manual_seed(stride * 100 + C)
+    B = 2
+    y = torch.randn(B, C, H, W, generator=g).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(C, generator=g) * 0.3
+    bn_a, bn_b = nn.BatchNorm2d(C), nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.randn(C, generator=g)); bn_a.bias.copy_(torch.randn(C, generator=g) * 0.2)   # negative gammas too
+        bn_a.running_mean.normal_(generator=g); bn_a.running_var.uniform_(0.5, 1.5, generator=g)
+    bn_b.load_state_dict(bn_a.state_dict())
+    prev = ops.set_backend(oracle_backend)
+    try:
+        y1 = y.clone().requires_grad_(); y2 = y.clone().requires_grad_()
+        out1 = modules._BnActPool.apply(y1, bn_a.weight, bn_a.bias, bias, bn_a.running_mean, bn_a.running_var, stride,
+                                        bn_a.momentum, bn_a.eps, 0.1)
+        out2 = _img_tail_torch(y2 + bias.view(1, -1, 1, 1), bn_b, 0.1, stride)
+        assert out1.shape == out2.shape
+        assert torch.allclose(out1, out2, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-4, atol=1e-6)
+        w = torch.randn(out2.shape, generator=g)
+        (out1 * w).sum().backward(); (out2 * w).sum().backward()
+        sc = float(y2.grad.abs().max())
+        assert torch.allclose(y1.grad, y2.grad, rtol=1e-3, atol=1e-4 * sc)
+        assert torch.allclose(bn_a.weight.grad, bn_b.weight.grad, rtol=1e-3, atol=1e-4 * float(bn_b.weight.grad.abs().max()))
+        assert torch.allclose(bn_a.bias.grad, bn_b.bias.grad, rtol=1e-3, atol=1e-4 * float(bn_b.bias.grad.abs().max()))
+    finally:
+        ops.set_backend(prev)
