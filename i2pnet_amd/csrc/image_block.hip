@@ -152,6 +152,16 @@ __global__ __launch_bounds__(THREADS) void img_bwd_stats_kernel(PoolGeom g, cons
     }
 }
 
+// dbeta = sum gz, dgamma = sum gz*xhat from the replicated fp64 sums (one thread per channel, so that the
+// streaming kernel below does not re-reduce 2*REP doubles per channel in every thread)
+__global__ void img_bwd_coef_kernel(int c, const double *__restrict__ dsums, float *__restrict__ dgamma,
+                                    float *__restrict__ dbeta) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    dbeta[ch] = (float)rep_sum(dsums, c, ch);
+    dgamma[ch] = (float)rep_sum(dsums, c, c + ch);
+}
+
 // dL/dy of the conv output: gather the pooled gradients whose arg-max is this position, LeakyReLU', BN backward.
 __global__ __launch_bounds__(THREADS) void img_bwd_dx_kernel(PoolGeom g, const float4 *__restrict__ gout,
                                                               const uchar4 *__restrict__ arg,
@@ -159,20 +169,15 @@ __global__ __launch_bounds__(THREADS) void img_bwd_dx_kernel(PoolGeom g, const f
                                                               const float *__restrict__ mean_invstd,
                                                               const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, float slope,
-                                                              const double *__restrict__ dsums,
-                                                              float4 *__restrict__ dy, float *__restrict__ dgamma,
-                                                              float *__restrict__ dbeta) {
+                                                              float4 *__restrict__ dy, const float *__restrict__ dgamma,
+                                                              const float *__restrict__ dbeta) {
     const long long total = (long long)g.B * g.H * g.W * g.cv;
     const int vcol = threadIdx.x % g.cv;
     const Coef4 k = load_coef(mean_invstd, gamma, beta, g.C, vcol);
-    const double n = (double)g.B * g.H * g.W;
+    const float n = (float)((long long)g.B * g.H * g.W);
     float mg[4], mgx[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double sg = rep_sum(dsums, g.C, vcol * 4 + i), sgx = rep_sum(dsums, g.C, g.C + vcol * 4 + i);
-        mg[i] = (float)(sg / n); mgx[i] = (float)(sgx / n);
-        if (blockIdx.x == 0 && threadIdx.x < g.cv) { dbeta[vcol * 4 + i] = (float)sg; dgamma[vcol * 4 + i] = (float)sgx; }
-    }
+    for (int i = 0; i < 4; ++i) { mg[i] = dbeta[vcol * 4 + i] / n; mgx[i] = dgamma[vcol * 4 + i] / n; }
     for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         long long r = t / g.cv;
         const int w = (int)(r % g.W); r /= g.W;
@@ -252,8 +257,9 @@ extern "C" int i2p_img_bn_pool_bwd(int B, int H, int W, int C, int stride, const
     const long long tot_o = (long long)B * g.Ho * g.Wo * g.cv, tot_i = (long long)B * H * W * g.cv;
     hipLaunchKernelGGL(img_bwd_stats_kernel, dim3(grid_for(tot_o, MAX_STAT_BLOCKS)), dim3(THREADS), 0, st, g,
                        (const float4 *)gout, (const uchar4 *)arg, y, mean_invstd, gamma, beta, slope, dsums);
+    hipLaunchKernelGGL(img_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, C, dsums, dgamma, dbeta);
     hipLaunchKernelGGL(img_bwd_dx_kernel, dim3(grid_for(tot_i, 1 << 20)), dim3(THREADS), 0, st, g, (const float4 *)gout,
-                       (const uchar4 *)arg, (const float4 *)y, mean_invstd, gamma, beta, slope, dsums, (float4 *)dy,
+                       (const uchar4 *)arg, (const float4 *)y, mean_invstd, gamma, beta, slope, (float4 *)dy,
                        dgamma, dbeta);
     I2P_RETURN_LAUNCH_STATUS();
 }
