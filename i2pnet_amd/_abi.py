@@ -36,7 +36,7 @@ SIGNATURES = {
     "i2p_img_bn_pool_fwd": ["i", "i", "i", "i", "i", "p", "p", "p", "p", "f", "f", "f", "p", "p", "p", "p", "p", "p"],
     "i2p_img_bn_pool_bwd": ["i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "f", "p", "p", "p", "p"],
     "i2p_bn_finalize": ["l", "i", "p", "p", "p", "f", "p", "p"],
-    "i2p_lin_bwd": ["l", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 5,
+    "i2p_lin_bwd": ["l", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 5 + ["f"],
     "i2p_pair_lin_fwd": ["i"] * 5 + ["p"] * 7,
     "i2p_pair_lin_bwd": ["i"] * 5 + ["p"] * 14,
     "i2p_lin_fwd_2src": ["l", "i", "i", "i", "p", "p", "f", "p", "p", "f", "p", "p", "p"],

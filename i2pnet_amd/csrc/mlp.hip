@@ -58,7 +58,8 @@ struct LinFwdParams {
     // g^y = scale*(gz - m1 - xhat*m2).  w_transposed: Ws[o][k] = w[k*cout + o].  Store phase:
     // out = acc * act'(z_prev) with z_prev from ex (pre-BN tensor in front) and e_coef/e_mi; sums
     // receive { sum out, sum out*xhat_prev }.
-    const float *x2, *g_coef;
+    const float *x2, *g_coef;   // g_coef [6][cin]: + beta (row 5)
+    float g_slope;              // gz arrives as dL/da of the layer behind (a = act(z), slope g_slope): apply act'(z) on load; 1 = gz is dL/dz
     int w_transposed;
     const float *ex, *e_coef, *e_mi;
     float e_slope;
@@ -355,8 +356,10 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
     }
 
     // dgrad: BN-backward constants of this lane's input channels, and of its output channels for the store phase
-    float4 g_m1 = cm, g_m2 = cm, g_sc = cs, g_mu = cm, g_is = cs;
+    float4 g_m1 = cm, g_m2 = cm, g_sc = cs, g_mu = cm, g_is = cs, g_be = cm;
+    const bool g_act = DGRAD && p.g_coef && p.g_slope != 1.f;
     if (DGRAD && p.g_coef) {
+        g_be = *reinterpret_cast<const float4 *>(p.g_coef + 5 * p.cin + in_c4[0] * 4);
         g_m1 = *reinterpret_cast<const float4 *>(p.g_coef + in_c4[0] * 4);
         g_m2 = *reinterpret_cast<const float4 *>(p.g_coef + p.cin + in_c4[0] * 4);
         g_sc = *reinterpret_cast<const float4 *>(p.g_coef + 2 * p.cin + in_c4[0] * 4);
@@ -428,6 +431,12 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
             }
             if (DGRAD && p.g_coef) {                        // BN backward of the layer behind, formed on load
                 const float4 yv = v2[u];
+                if (g_act) {                                // dL/da -> dL/dz of the layer behind
+                    t.x = (yv.x - g_mu.x) * g_sc.x + g_be.x > 0.f ? t.x : t.x * p.g_slope;
+                    t.y = (yv.y - g_mu.y) * g_sc.y + g_be.y > 0.f ? t.y : t.y * p.g_slope;
+                    t.z = (yv.z - g_mu.z) * g_sc.z + g_be.z > 0.f ? t.z : t.z * p.g_slope;
+                    t.w = (yv.w - g_mu.w) * g_sc.w + g_be.w > 0.f ? t.w : t.w * p.g_slope;
+                }
                 t.x = g_sc.x * (t.x - g_m1.x - ((yv.x - g_mu.x) * g_is.x) * g_m2.x);
                 t.y = g_sc.y * (t.y - g_m1.y - ((yv.y - g_mu.y) * g_is.y) * g_m2.y);
                 t.z = g_sc.z * (t.z - g_m1.z - ((yv.z - g_mu.z) * g_is.z) * g_m2.z);
@@ -656,6 +665,7 @@ struct LinBwdParams {
     int cin, cout, cin_p, cout_p;      // *_p rounded up to 32
     int ldw, ldg, ldx;                 // LDS strides (cin_p+1, cout_p+1, cin_p+1)
     const float *gz, *y, *out_coef, *out_mi;
+    float slope_out;            // gz is dL/da of this layer's activation (slope_out): act'(z) applied on load; 1 = gz is dL/dz
     const double *out_dsums;
     const float *x, *in_coef, *in_mi;
     float slope_in;
@@ -680,8 +690,8 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
     float *Ws = smem;                                      // [cout_p][ldw]
     float *Gs = Ws + (size_t)p.cout_p * p.ldw;             // [BWD_R][ldg]
     float *Xs = Gs + (size_t)BWD_R * p.ldg;                // [BWD_R][ldx]
-    float *Co = Xs + (size_t)BWD_R * p.ldx;                // [5][cout_p]: m1, m2, scale, mean, invstd of the BN behind
-    float *Ci = Co + 5 * p.cout_p;                         // [4][cin_p]: mean, scale, beta, invstd of the BN in front
+    float *Co = Xs + (size_t)BWD_R * p.ldx;                // [6][cout_p]: m1, m2, scale, mean, invstd, beta of the BN behind
+    float *Ci = Co + 6 * p.cout_p;                         // [4][cin_p]: mean, scale, beta, invstd of the BN in front
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int DT = 2 * NTI;                            // dgrad tiles per row tile pair
     constexpr int DPW = (DT + 3) / 4;
@@ -694,14 +704,15 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
     }
     // per-channel constants once per block (the replica sums are 64 fp64 loads per channel)
     for (int ch = tid; ch < p.cout; ch += THREADS) {
-        float m1 = 0.f, m2 = 0.f, sc = 1.f, mu = 0.f, is = 1.f;
+        float m1 = 0.f, m2 = 0.f, sc = 1.f, mu = 0.f, is = 1.f, be = 0.f;
         if (p.out_coef) {
             double sd = 0.0, sx = 0.0;
             for (int rp = 0; rp < REP; ++rp) { sd += p.out_dsums[(size_t)rp * 2 * p.cout + ch]; sx += p.out_dsums[(size_t)rp * 2 * p.cout + p.cout + ch]; }
             m1 = (float)(sd / (double)p.rows); m2 = (float)(sx / (double)p.rows);
-            sc = p.out_coef[p.cout + ch]; mu = p.out_mi[ch]; is = p.out_mi[p.cout + ch];
+            sc = p.out_coef[p.cout + ch]; mu = p.out_mi[ch]; is = p.out_mi[p.cout + ch]; be = p.out_coef[2 * p.cout + ch];
         }
         Co[ch] = m1; Co[p.cout_p + ch] = m2; Co[2 * p.cout_p + ch] = sc; Co[3 * p.cout_p + ch] = mu; Co[4 * p.cout_p + ch] = is;
+        Co[5 * p.cout_p + ch] = be;
     }
     for (int ch = tid; ch < p.cin; ch += THREADS) {
         float mu = 0.f, sc = 1.f, be = 0.f, is = 1.f;
@@ -757,6 +768,8 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
                         for (int q = 0; q < 4; ++q) {
                             const int ch = c4 * 4 + q;
                             const float xh = (yy[q] - Co[3 * p.cout_p + ch]) * Co[4 * p.cout_p + ch];
+                            if (p.slope_out != 1.f && !((yy[q] - Co[3 * p.cout_p + ch]) * Co[2 * p.cout_p + ch] + Co[5 * p.cout_p + ch] > 0.f))
+                                gv[q] *= p.slope_out;                           // dL/da -> dL/dz
                             gv[q] = Co[2 * p.cout_p + ch] * (gv[q] - Co[ch] - xh * Co[p.cout_p + ch]);
                         }
                     }
@@ -949,6 +962,7 @@ struct PairBwdParams {
     int cin, cout, cin_p, cout_p, ldw, ldg, ldx;
     long long rows;
     const float *gz, *y, *out_coef, *out_mi;
+    float slope_out;            // gz is dL/da of this layer's activation (slope_out): act'(z) applied on load; 1 = gz is dL/dz
     const double *out_dsums;
     const float *f, *g, *w;
     float *d_f, *d_g, *d_bn, *d_bk, *dw_partial;
@@ -1187,7 +1201,8 @@ __global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
 struct WgradParams {
     long long rows;
     int cin, cout, cin_p, cout_p, ldg, ldx;
-    const float *gz, *y, *g_coef;        // g_coef [5][cout] or nullptr (gz already is dL/dy)
+    const float *gz, *y, *g_coef;        // g_coef [6][cout] or nullptr (gz already is dL/dy)
+    float g_slope;                       // != 1: gz is dL/da of an activation with this slope (act' applied on load)
     const float *x, *in_coef;            // in_coef [3][cin] or nullptr
     float slope_in;
     float *dw_partial;
@@ -1207,6 +1222,7 @@ __global__ void bnbwd_coef_kernel(long long rows, int c, const double *__restric
     for (int r = 0; r < REP; ++r) { sd += dsums[(size_t)r * 2 * c + ch]; sx += dsums[(size_t)r * 2 * c + c + ch]; }
     out[ch] = (float)(sd / (double)rows); out[c + ch] = (float)(sx / (double)rows);
     out[2 * c + ch] = coef[c + ch]; out[3 * c + ch] = mi[ch]; out[4 * c + ch] = mi[c + ch];
+    out[5 * c + ch] = coef[2 * c + ch];
 }
 
 template <int NTI, int NTO, bool FIXC>
@@ -1215,13 +1231,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bufsz = WG_R * (p.ldg + p.ldx);
     float *Ct = smem + 2 * (size_t)bufsz;                  // [5][cout] then [3][cin] constants
-    float *Cg = Ct, *Cx = Ct + 5 * p.cout;
+    float *Cg = Ct, *Cx = Ct + 6 * p.cout;
     constexpr int WT = NTO * NTI, WPW = (WT + 7) / 8;
     constexpr int GCH = (WG_R * NTO * 8 + WG_THREADS - 1) / WG_THREADS;   // float4 chunks per thread
     constexpr int XCH = (WG_R * NTI * 8 + WG_THREADS - 1) / WG_THREADS;
     const int co4 = p.cout >> 2, ci4 = p.cin >> 2;
 
-    for (int i = tid; i < 5 * p.cout; i += WG_THREADS) Cg[i] = p.g_coef ? p.g_coef[i] : 0.f;
+    for (int i = tid; i < 6 * p.cout; i += WG_THREADS) Cg[i] = p.g_coef ? p.g_coef[i] : 0.f;
     for (int i = tid; i < 3 * p.cin; i += WG_THREADS) Cx[i] = p.in_coef ? p.in_coef[i] : 0.f;
     // zero the padding columns of both buffers once
     for (int b = 0; b < 2; ++b) {
@@ -1239,13 +1255,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
     // chunk geometry and per-channel constants of this thread: fixed for the whole kernel when the float4
     // column count divides the block size (all power-of-two widths); otherwise constants come from the LDS table
     constexpr bool g_fix = FIXC, x_fix = FIXC;
-    float4 k_m1 = make_float4(0.f, 0.f, 0.f, 0.f), k_m2 = k_m1, k_sc = make_float4(1.f, 1.f, 1.f, 1.f), k_mu = k_m1, k_is = k_sc;
+    float4 k_m1 = make_float4(0.f, 0.f, 0.f, 0.f), k_m2 = k_m1, k_sc = make_float4(1.f, 1.f, 1.f, 1.f), k_mu = k_m1, k_is = k_sc, k_be = k_m1;
+    const bool g_act = p.g_coef && p.g_slope != 1.f;
     float4 x_mu = k_m1, x_sc = k_sc, x_be = k_m1;
     if (p.g_coef && g_fix) {
         const int c4 = tid % co4;
         k_m1 = *reinterpret_cast<const float4 *>(p.g_coef + c4 * 4); k_m2 = *reinterpret_cast<const float4 *>(p.g_coef + p.cout + c4 * 4);
         k_sc = *reinterpret_cast<const float4 *>(p.g_coef + 2 * p.cout + c4 * 4); k_mu = *reinterpret_cast<const float4 *>(p.g_coef + 3 * p.cout + c4 * 4);
         k_is = *reinterpret_cast<const float4 *>(p.g_coef + 4 * p.cout + c4 * 4);
+        k_be = *reinterpret_cast<const float4 *>(p.g_coef + 5 * p.cout + c4 * 4);
     }
     // source of this thread's X' chunks (two-source mode needs the per-thread-constant layout)
     const bool x_b = p.xb && (tid % ci4) * 4 >= p.split_c;
@@ -1290,13 +1308,18 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
                 float4 g = rg[u];
                 if (row0 + r > last_row) g = make_float4(0.f, 0.f, 0.f, 0.f);         // rows past the end contribute nothing
                 else if (p.g_coef) {
-                    float4 m1 = k_m1, m2 = k_m2, sc = k_sc, mu = k_mu, is = k_is;
+                    float4 m1 = k_m1, m2 = k_m2, sc = k_sc, mu = k_mu, is = k_is, be = k_be;
                     if constexpr (!g_fix) {
+                        be = *reinterpret_cast<const float4 *>(Cg + 5 * p.cout + c4 * 4);
                         m1 = *reinterpret_cast<const float4 *>(Cg + c4 * 4); m2 = *reinterpret_cast<const float4 *>(Cg + p.cout + c4 * 4);
                         sc = *reinterpret_cast<const float4 *>(Cg + 2 * p.cout + c4 * 4); mu = *reinterpret_cast<const float4 *>(Cg + 3 * p.cout + c4 * 4);
                         is = *reinterpret_cast<const float4 *>(Cg + 4 * p.cout + c4 * 4);
                     }
                     const float4 yv = ry[u];
+                    if (g_act) {                                                      // dL/da -> dL/dz
+                        g.x = (yv.x - mu.x) * sc.x + be.x > 0.f ? g.x : g.x * p.g_slope; g.y = (yv.y - mu.y) * sc.y + be.y > 0.f ? g.y : g.y * p.g_slope;
+                        g.z = (yv.z - mu.z) * sc.z + be.z > 0.f ? g.z : g.z * p.g_slope; g.w = (yv.w - mu.w) * sc.w + be.w > 0.f ? g.w : g.w * p.g_slope;
+                    }
                     g.x = sc.x * (g.x - m1.x - ((yv.x - mu.x) * is.x) * m2.x); g.y = sc.y * (g.y - m1.y - ((yv.y - mu.y) * is.y) * m2.y);
                     g.z = sc.z * (g.z - m1.z - ((yv.z - mu.z) * is.z) * m2.z); g.w = sc.w * (g.w - m1.w - ((yv.w - mu.w) * is.w) * m2.w);
                 }
@@ -1398,7 +1421,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int nparts, int n,
 
 template <int NTI, int NTO>
 int launch_bwd(LinBwdParams &p, float *dw, hipStream_t st, unsigned grid) {
-    const size_t bytes = ((size_t)p.cout_p * p.ldw + (size_t)BWD_R * p.ldg + (size_t)BWD_R * p.ldx + 5 * (size_t)p.cout_p + 4 * (size_t)p.cin_p) * sizeof(float);
+    const size_t bytes = ((size_t)p.cout_p * p.ldw + (size_t)BWD_R * p.ldg + (size_t)BWD_R * p.ldx + 6 * (size_t)p.cout_p + 4 * (size_t)p.cin_p) * sizeof(float);
     if (bytes > 160 * 1024) return I2P_ERR_BAD_ARG;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1555,7 +1578,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
                         const float *out_coef, const float *out_mi, const double *out_dsums,
                         const float *x, const float *in_coef, const float *in_mi, float slope_in,
                         const float *w, float *gz_in, double *in_dsums, float *dw_partial, float *dw,
-                        const PairBwd *pair, void *stream, const TwoBwd *two = nullptr) {
+                        const PairBwd *pair, void *stream, const TwoBwd *two = nullptr, float slope_out = 1.f) {
     if (rows <= 0 || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3)) return I2P_ERR_BAD_ARG;
     if (!gz || (!x && !pair) || !w || !dw_partial || !dw) return I2P_ERR_BAD_ARG;
     if (out_coef && (!y || !out_mi || !out_dsums)) return I2P_ERR_BAD_ARG;
@@ -1565,6 +1588,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
     p.cin_p = (cin + 31) & ~31; p.cout_p = (cout + 31) & ~31;
     p.ldw = p.cin_p + 1; p.ldg = p.cout_p + 1; p.ldx = p.cin_p + 1;
     p.gz = gz; p.y = y; p.out_coef = out_coef; p.out_mi = out_mi; p.out_dsums = out_dsums;
+    p.slope_out = out_coef ? slope_out : 1.f;
     p.x = x; p.in_coef = in_coef; p.in_mi = in_mi; p.slope_in = slope_in; p.w = w;
     p.gz_in = gz_in; p.in_dsums = in_dsums; p.dw_partial = dw_partial;
     p.pair_f = p.pair_g = nullptr; p.d_f = p.d_g = p.d_bn = p.d_bk = nullptr; p.pair_N = p.pair_M = 1;
@@ -1578,13 +1602,13 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
         auto pow2w = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
         const char *gen = getenv("I2P_LIN_BWD_GEN");
         const bool dgrad_ok = !gz_in || (pow2w(cin) && pow2w(cout));
-        const size_t wg_lds = (2 * (size_t)WG_R * (p.cout_p + p.cin_p) + 5 * (size_t)cout + 3 * (size_t)cin) * sizeof(float);
+        const size_t wg_lds = (2 * (size_t)WG_R * (p.cout_p + p.cin_p) + 6 * (size_t)cout + 3 * (size_t)cin) * sizeof(float);
         const bool gen2 = !pair && !(gen && gen[0] == '1') && dgrad_ok && pow2w(cout) && wg_lds <= 160 * 1024 && cin <= 160;
         if (two && !(gen2 && pow2w(cin))) return I2P_ERR_BAD_ARG;
         if (gen2) {
             float *g_coef = nullptr;
             if (out_coef) {
-                g_coef = dw_partial + (size_t)grid * cout * cin;                 // 5*cout floats behind the partials
+                g_coef = dw_partial + (size_t)grid * cout * cin;                 // 6*cout floats behind the partials
                 hipLaunchKernelGGL(bnbwd_coef_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, rows, cout, out_dsums, out_coef,
                                    out_mi, g_coef);
             }
@@ -1592,7 +1616,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
                 LinFwdParams q;
                 q.rows = rows; q.cin = cout; q.cout = cin; q.cin_p = cout; q.cout_p = cin;
                 q.ldk = (cout > cin ? cout : cin) + 2;
-                q.x = gz; q.x2 = y; q.g_coef = g_coef; q.in_coef = nullptr; q.slope_in = 1.f;
+                q.x = gz; q.x2 = y; q.g_coef = g_coef; q.g_slope = p.slope_out; q.in_coef = nullptr; q.slope_in = 1.f;
                 q.w = w; q.w_transposed = 1; q.y = gz_in; q.sums = in_coef ? in_dsums : nullptr;
                 q.y_ld = cin; q.ch_off = 0; q.cout_total = cin; q.ablate = 0;
                 q.pair_f = q.bias_n = q.bias_k = nullptr; q.pair_N = q.pair_M = 1;
@@ -1605,7 +1629,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
             WgradParams wq;
             wq.rows = rows; wq.cin = cin; wq.cout = cout; wq.cin_p = p.cin_p; wq.cout_p = p.cout_p;
             wq.ldg = p.cout_p; wq.ldx = p.cin_p;        // 16-B aligned rows; fragments are read along channels
-            wq.gz = gz; wq.y = y; wq.g_coef = g_coef; wq.x = x; wq.in_coef = in_coef; wq.slope_in = slope_in;
+            wq.gz = gz; wq.y = y; wq.g_coef = g_coef; wq.g_slope = p.slope_out; wq.x = x; wq.in_coef = in_coef; wq.slope_in = slope_in;
             wq.dw_partial = dw_partial;
             wq.split_c = 0; wq.xb = nullptr; wq.in_coef_b = nullptr; wq.slope_b = 1.f;
             if (two) { wq.split_c = two->split_c; wq.xb = two->xb; wq.in_coef_b = two->in_coef_b; wq.slope_b = two->slope_b; }
@@ -1626,9 +1650,9 @@ extern "C" int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, c
                            const float *out_coef, const float *out_mi, const double *out_dsums,
                            const float *x, const float *in_coef, const float *in_mi, float slope_in,
                            const float *w, float *gz_in, double *in_dsums, float *dw_partial, float *dw,
-                           void *stream) {
+                           float slope_out, void *stream) {
     return lin_bwd_impl(rows, cin, cout, gz, y, out_coef, out_mi, out_dsums, x, in_coef, in_mi, slope_in, w, gz_in,
-                        in_dsums, dw_partial, dw, nullptr, stream);
+                        in_dsums, dw_partial, dw, nullptr, stream, nullptr, slope_out);
 }
 
 extern "C" int i2p_pair_lin_bwd_grid(int B, int N, int M) {
@@ -1670,6 +1694,7 @@ extern "C" int i2p_pair_lin_bwd(int B, int N, int M, int cin, int cout, const fl
     p.ldw = p.cin_p + 1; p.ldg = p.cout_p + 1; p.ldx = p.cin_p + 1;
     p.rows = (long long)B * N * M;
     p.gz = gz; p.y = y; p.out_coef = out_coef; p.out_mi = out_mi; p.out_dsums = out_dsums;
+    p.slope_out = 1.f;
     p.f = f; p.g = g; p.w = w; p.d_f = d_f; p.d_g = d_g; p.d_bn = d_bias_n; p.d_bk = d_bias_k; p.dw_partial = dw_partial;
     hipStream_t st = (hipStream_t)stream;
     const int nti = p.cin_p / 32, nto = p.cout_p / 32;

@@ -97,22 +97,24 @@ class _MlpChain(Function):
         mis = ([] if first_bn else [None]) + ms
         grads = [None] * len(p)
         g_out = g_out.contiguous()
-        # BN + activation of the last block: dL/dy_L and its gamma/beta gradients
         last_g, last_b = (p[-2], p[-1]) if nl else (p[0], p[1])
-        gz, dg, db = be.bn_act_backward(g_out, ys[-1], mis[-1], last_g.detach(), last_b.detach(), slopes[-1])
-        if nl:
-            grads[-2], grads[-1] = dg, db
-        else:
+        if not nl:          # only the leading BN: dL/dx and its gamma/beta gradients
+            gz, dg, db = be.bn_act_backward(g_out, ys[-1], mis[-1], last_g.detach(), last_b.detach(), slopes[-1])
             grads[0], grads[1] = dg, db
             return (gz if ctx.x_needs_grad else None), None, None, *grads
-        y_out = out_coef = out_mi = out_ds = None           # top layer: gz already is dL/dy
+        # last block: only the statistics pass over (dL/da, y_L); the activation derivative and the BN backward are
+        # applied by the layer kernels as they load dL/da (slope_out), so dL/dy_L is never written
+        out_ds = be.bn_act_backward_stats(g_out, ys[-1], mis[-1], last_g.detach(), last_b.detach(), slopes[-1])
+        s = _rep_sum(out_ds, ys[-1].shape[1])
+        grads[-2], grads[-1] = s[1].float(), s[0].float()
+        gz, y_out, out_coef, out_mi, slope_out = g_out, ys[-1], coefs[-1], mis[-1], slopes[-1]
         for i in range(nl, 0, -1):
             W = p[k + 3 * (i - 1)]
             has_in = coefs[i - 1] is not None
             need_gx = has_in or ctx.x_needs_grad
             gz_in, in_ds, dw = be.lin_backward(gz, y_out, out_coef, out_mi, out_ds, ys[i - 1], coefs[i - 1],
                                                mis[i - 1], slopes[i - 1] if has_in else 1.0, W.detach(),
-                                               need_gx=need_gx)
+                                               need_gx=need_gx, slope_out=slope_out)
             grads[k + 3 * (i - 1)] = dw
             if has_in:
                 s = _rep_sum(in_ds, ys[i - 1].shape[1])
@@ -120,7 +122,7 @@ class _MlpChain(Function):
                     grads[k + 3 * (i - 2) + 1], grads[k + 3 * (i - 2) + 2] = s[1].float(), s[0].float()
                 else:
                     grads[0], grads[1] = s[1].float(), s[0].float()
-            gz, y_out, out_coef, out_mi, out_ds = gz_in, ys[i - 1], coefs[i - 1], mis[i - 1], in_ds
+            gz, y_out, out_coef, out_mi, out_ds, slope_out = gz_in, ys[i - 1], coefs[i - 1], mis[i - 1], in_ds, 1.0
         gx = None
         if ctx.x_needs_grad:
             if first_bn:       # finish the leading BN: dL/dx = scale*(gz - mean(gz) - xhat*mean(gz*xhat))

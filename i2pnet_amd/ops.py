@@ -278,6 +278,15 @@ class CBackend:
                    self._p(out, _F32, "out"), self._p(mean_invstd, _F32, "mean_invstd"), stream=st)
         return out, mean_invstd
 
+    def bn_act_backward_stats(self, dout, y, mean_invstd, gamma, beta, slope):
+        """replicated {sum gz, sum gz*xhat} with gz = dout * act'(bn(y)) — the statistics half of bn_act_backward"""
+        rows, c = y.shape
+        dsums = zeros(BN_REPLICAS * 2 * c, torch.float64, y.device)
+        self._call("i2p_bn_act_bwd_stats", int(rows), int(c), self._p(dout, _F32, "dout"), self._p(y, _F32, "y"),
+                   self._p(mean_invstd, _F32, "mean_invstd"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"),
+                   float(slope), self._p(dsums, torch.float64, "dsums"), stream=self._stream())
+        return dsums
+
     def bn_act_backward(self, dout, y, mean_invstd, gamma, beta, slope):
         """-> (dy [rows,c], dgamma [c], dbeta [c])"""
         rows, c = y.shape
@@ -308,8 +317,10 @@ class CBackend:
                    self._p(sums, torch.float64, "sums") if sums is not None else None, stream=self._stream())
         return y, sums
 
-    def lin_backward(self, gz, y, out_coef, out_mi, out_dsums, x, in_coef, in_mi, slope_in, w, need_gx=True):
-        """-> (gz_in [rows,cin] or None, in_dsums or None, dw [cout,cin]); see i2p_lin_bwd."""
+    def lin_backward(self, gz, y, out_coef, out_mi, out_dsums, x, in_coef, in_mi, slope_in, w, need_gx=True,
+                     slope_out=1.0):
+        """-> (gz_in [rows,cin] or None, in_dsums or None, dw [cout,cin]); see i2p_lin_bwd.
+        slope_out != 1: `gz` is dL/da of this layer's activation (applied on load)."""
         rows, cout = gz.shape
         cin = x.shape[1]
         dev = gz.device
@@ -324,7 +335,7 @@ class CBackend:
                    P(out_coef, _F32, "out_coef"), P(out_mi, _F32, "out_mi"), P(out_dsums, torch.float64, "out_dsums"),
                    P(x, _F32, "x"), P(in_coef, _F32, "in_coef"), P(in_mi, _F32, "in_mi"), float(slope_in),
                    P(w, _F32, "w"), P(gz_in, _F32, "gz_in"), P(in_dsums, torch.float64, "in_dsums"),
-                   P(part, _F32, "dw_partial"), P(dw, _F32, "dw"), stream=self._stream())
+                   P(part, _F32, "dw_partial"), P(dw, _F32, "dw"), float(slope_out), stream=self._stream())
         return gz_in, in_dsums, dw
 
     def pair_lin_forward(self, f, g, bias_n, bias_k, w):

@@ -221,12 +221,16 @@ int i2p_bn_finalize(long long rows, int c, const double *sums, const float *gamm
  * gz f32 [rows,cout]; y f32 [rows,cout]; out_coef [3][cout], out_mi [2][cout] (mean, invstd),
  * out_dsums replicated {sum gz, sum gz*xhat_out}; x f32 [rows,cin] the previous pre-BN tensor with
  * in_coef [3][cin], in_mi [2][cin] (or both NULL: x is the raw layer input, gz_in = dL/dx);
- * dw_partial f32 scratch of i2p_lin_bwd_grid(rows)*cout*cin + 8*cout floats.  cin, cout multiples of 4, <= 160 / 128. */
+ * dw_partial f32 scratch of i2p_lin_bwd_grid(rows)*cout*cin + 8*cout floats.  cin, cout multiples of 4, <= 160 / 128.
+ * slope_out: 1 when gz is dL/dz (the usual case: the previous call's gz_in).  For the LAST layer of a stack the
+ * caller holds dL/da (a = act(z) with this slope, out_coef required): the activation derivative is applied on
+ * load, with out_dsums = {sum gz, sum gz*xhat} of the resulting gz (i2p_bn_act_bwd_stats) — the stack's output
+ * gradient is then read twice instead of being rewritten as dL/dy first. */
 int i2p_lin_bwd_grid(long long rows);
 int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, const float *y,
                 const float *out_coef, const float *out_mi, const double *out_dsums, const float *x,
                 const float *in_coef, const float *in_mi, float slope_in, const float *w, float *gz_in,
-                double *in_dsums, float *dw_partial, float *dw, void *stream);
+                double *in_dsums, float *dw_partial, float *dw, float slope_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Hamilton product out = a (x) b with broadcasting over the point axis (src/modules/warp_utils.py:25-55

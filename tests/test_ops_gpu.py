@@ -264,6 +264,40 @@ def test_img_bn_pool_parity(oracle_backend, hip_backend, stride, C, H, W):
     assert torch.allclose(gt.grad, hdg, rtol=1e-3, atol=1e-3 * float(rdg.abs().max()))
 
 
+@pytest.mark.parametrize("rows,cin,cout,slope_out", [(3000, 64, 128, 0.0), (5000, 32, 32, 0.1), (2000, 36, 32, 0.0),
+                                                     (4000, 128, 64, 0.1), (1500, 68, 64, 0.0)])
+def test_lin_bwd_last_layer_slope_out(oracle_backend, hip_backend, rows, cin, cout, slope_out):
+    """last layer of a stack: lin_backward(dL/da, slope_out) == lin_backward(dL/dy from bn_act_backward) —
+    oracle vs oracle (the identity), HIP vs oracle (gen-2 kernels for power-of-two widths, gen-1 otherwise)."""
+    g = torch.Generator().manual_seed(rows + cin)
+    x = torch.randn(rows, cin, generator=g) * 2 + 0.5
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    gin = 1 + 0.1 * torch.randn(cin, generator=g); bin_ = 0.2 * torch.randn(cin, generator=g)
+    gout = torch.randn(cout, generator=g); bout = 0.3 * torch.randn(cout, generator=g)        # negative gammas too
+    ga = torch.randn(rows, cout, generator=g)
+
+    def run(be, dev, fused):
+        X, W, GA = x.to(dev), w.to(dev), ga.to(dev)
+        in_coef, in_mi = be.bn_finalize(rows, be.bn_stats(X), gin.to(dev), bin_.to(dev), 1e-5)
+        Y, ys = be.lin_forward(X, in_coef, 0.1, W)
+        out_coef, out_mi = be.bn_finalize(rows, ys, gout.to(dev), bout.to(dev), 1e-5)
+        if fused:
+            ods = be.bn_act_backward_stats(GA, Y, out_mi, gout.to(dev), bout.to(dev), slope_out)
+            return be.lin_backward(GA, Y, out_coef, out_mi, ods, X, in_coef, in_mi, 0.1, W, slope_out=slope_out)
+        gy, _, _ = be.bn_act_backward(GA, Y, out_mi, gout.to(dev), bout.to(dev), slope_out)
+        return be.lin_backward(gy, None, None, None, None, X, in_coef, in_mi, 0.1, W)
+    r0 = run(oracle_backend, "cpu", False)
+    r1 = run(oracle_backend, "cpu", True)
+    h1 = run(hip_backend, DEV, True)
+    for a, b, c, tol in ((r0[0], r1[0], h1[0], 3e-5), (r0[2], r1[2], h1[2], 2e-4)):
+        sc = float(a.abs().max())
+        assert float((a - b).abs().max()) <= tol * sc + 1e-6
+        assert float((a - c.cpu()).abs().max()) <= tol * sc + 1e-6
+    s0 = r0[1].view(32, 2, cin).sum(0); s1 = r1[1].view(32, 2, cin).sum(0); sh = h1[1].cpu().view(32, 2, cin).sum(0)
+    assert torch.allclose(s0, s1, rtol=1e-4, atol=1e-3 * rows ** 0.5)
+    assert torch.allclose(s0, sh, rtol=1e-4, atol=1e-3 * rows ** 0.5)
+
+
 def test_project_seq_parity(oracle_backend, hip_backend):
     """Cells are bit-exact for points away from a bin edge (device OCML vs host libm differ in
     the last ulp of atan2/asin); images are compared on cells whose winner agrees."""
