@@ -87,7 +87,112 @@ __global__ __launch_bounds__(THREADS) void sm_bwd_kernel(SmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Gradient of the position encoding of the all-pixel cost volume.  Its pre-BN tensor is an outer sum
+//     ye[b,n,k,:] = enc_n[b,n,:] + enc_k[b,k,:]                                 (PPBackbone_center.py:416-418)
+// so the gradients of the two small factors are the k- and n-sums of dL/dye.  pair_sum reads gz_e ONCE and
+// produces both sums; the BN backward dL/dye = scale*(gz - m1 - xhat*m2) is then applied in closed form on
+// the [B,N,C] / [B,M,C] factors (sum_k xhat = invstd*(M*enc_n + sum_k enc_k - M*mean)): the [B,N,M,C]
+// gradient of ye is never written and never re-read by two reductions.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PS_NL = 8;          // point rows per block
+
+__global__ __launch_bounds__(THREADS) void pair_sum_kernel(int B, int N, int M, int C, const float4 *__restrict__ g,
+                                                            float *__restrict__ sum_k, float *__restrict__ sum_n) {
+    __shared__ float4 red[THREADS][PS_NL];                     // 32 KB
+    const int cv = C >> 2, ks = THREADS / cv;                   // k-slots per block
+    const int c4 = threadIdx.x % cv, kslot = threadIdx.x / cv;
+    const int chunks = (N + PS_NL - 1) / PS_NL;
+    const int b = blockIdx.x / chunks, n0 = (blockIdx.x - b * chunks) * PS_NL;
+    float4 acc[PS_NL];
+#pragma unroll
+    for (int j = 0; j < PS_NL; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = kslot; k < M; k += ks) {
+        float4 v[PS_NL];
+#pragma unroll
+        for (int j = 0; j < PS_NL; ++j) {
+            const int n = n0 + j;
+            v[j] = n < N ? g[(((size_t)b * N + n) * M + k) * cv + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < PS_NL; ++j) {
+            acc[j].x += v[j].x; acc[j].y += v[j].y; acc[j].z += v[j].z; acc[j].w += v[j].w;
+            t.x += v[j].x; t.y += v[j].y; t.z += v[j].z; t.w += v[j].w;
+        }
+        float *dst = sum_n + ((size_t)b * M + k) * C + c4 * 4;
+        atomicAdd(dst + 0, t.x); atomicAdd(dst + 1, t.y); atomicAdd(dst + 2, t.z); atomicAdd(dst + 3, t.w);
+    }
+#pragma unroll
+    for (int j = 0; j < PS_NL; ++j) red[threadIdx.x][j] = acc[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < PS_NL * cv; i += THREADS) {
+        const int j = i / cv, c = i - j * cv;
+        if (n0 + j >= N) continue;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < ks; ++q) { const float4 r = red[q * cv + c][j]; a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+        *reinterpret_cast<float4 *>(sum_k + ((size_t)b * N + n0 + j) * C + c * 4) = a;
+    }
+}
+
+// PB_SLICES blocks per batch sample: E_k = sum_k enc_k[b], E_n = sum_n enc_n[b] (recomputed per block: tiny),
+// then the closed-form BN backward on this block's slice of the two factors
+constexpr int PB_SLICES = 8;
+
+__global__ __launch_bounds__(THREADS) void pair_bias_bn_bwd_kernel(int B, int N, int M, int C, const float *__restrict__ sum_k,
+                                                                    const float *__restrict__ sum_n,
+                                                                    const float *__restrict__ enc_n,
+                                                                    const float *__restrict__ enc_k,
+                                                                    const double *__restrict__ dsums,
+                                                                    const float *__restrict__ coef, const float *__restrict__ mi,
+                                                                    float *__restrict__ d_enc_n, float *__restrict__ d_enc_k) {
+    __shared__ float part[2][THREADS];
+    __shared__ float Ek[256], En[256], m1s[256], m2s[256];
+    const int b = blockIdx.x / PB_SLICES, slice = blockIdx.x % PB_SLICES;
+    const int G = THREADS / C, grp = threadIdx.x / C, c0 = threadIdx.x % C;      // C divides THREADS
+    const double rows = (double)B * N * M;
+    float ek = 0.f, en = 0.f;
+    for (int k = grp; k < M; k += G) ek += enc_k[((size_t)b * M + k) * C + c0];
+    for (int n = grp; n < N; n += G) en += enc_n[((size_t)b * N + n) * C + c0];
+    part[0][threadIdx.x] = ek; part[1][threadIdx.x] = en;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float a = 0.f, d = 0.f;
+        for (int q = 0; q < G; ++q) { a += part[0][q * C + threadIdx.x]; d += part[1][q * C + threadIdx.x]; }
+        Ek[threadIdx.x] = a; En[threadIdx.x] = d;
+        double sd = 0.0, sx = 0.0;
+        for (int r = 0; r < I2P_BN_REPLICAS; ++r) { sd += dsums[(size_t)r * 2 * C + threadIdx.x]; sx += dsums[(size_t)r * 2 * C + C + threadIdx.x]; }
+        m1s[threadIdx.x] = (float)(sd / rows); m2s[threadIdx.x] = (float)(sx / rows);
+    }
+    __syncthreads();
+    for (int i = slice * THREADS + threadIdx.x; i < N * C; i += PB_SLICES * THREADS) {
+        const int c = i % C;
+        const float scale = coef[C + c], mean = mi[c], is = mi[C + c];
+        const float sxh = is * ((float)M * enc_n[(size_t)b * N * C + i] + Ek[c] - (float)M * mean);
+        d_enc_n[(size_t)b * N * C + i] = scale * (sum_k[(size_t)b * N * C + i] - (float)M * m1s[c] - m2s[c] * sxh);
+    }
+    for (int i = slice * THREADS + threadIdx.x; i < M * C; i += PB_SLICES * THREADS) {
+        const int c = i % C;
+        const float scale = coef[C + c], mean = mi[c], is = mi[C + c];
+        const float sxh = is * ((float)N * enc_k[(size_t)b * M * C + i] + En[c] - (float)N * mean);
+        d_enc_k[(size_t)b * M * C + i] = scale * (sum_n[(size_t)b * M * C + i] - (float)N * m1s[c] - m2s[c] * sxh);
+    }
+}
+
 }  // namespace
+
+extern "C" int i2p_pair_bias_bn_bwd(int B, int N, int M, int C, const float *gz, const float *enc_n, const float *enc_k,
+                                    const double *dsums, const float *coef, const float *mi, float *sum_k, float *sum_n,
+                                    float *d_enc_n, float *d_enc_k, void *stream) {
+    if (B <= 0 || N <= 0 || M <= 0 || C <= 0 || C > 256 || (C & 3) || THREADS % C) return I2P_ERR_BAD_ARG;
+    if (!gz || !enc_n || !enc_k || !dsums || !coef || !mi || !sum_k || !sum_n || !d_enc_n || !d_enc_k) return I2P_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = (N + PS_NL - 1) / PS_NL;
+    hipLaunchKernelGGL(pair_sum_kernel, dim3(B * chunks), dim3(THREADS), 0, st, B, N, M, C, (const float4 *)gz, sum_k, sum_n);
+    hipLaunchKernelGGL(pair_bias_bn_bwd_kernel, dim3(B * PB_SLICES), dim3(THREADS), 0, st, B, N, M, C, sum_k, sum_n, enc_n, enc_k, dsums,
+                       coef, mi, d_enc_n, d_enc_k);
+    I2P_RETURN_LAUNCH_STATUS();
+}
 
 extern "C" int i2p_cv_softmax_wsum_fwd(int B, int N, int M, int C, const float *y5, const float *coef5, float slope5,
                                        const float *y3, const float *coef3, float slope3, float *out, float *msave,

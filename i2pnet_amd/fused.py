@@ -171,39 +171,47 @@ def pair_fits(cin, cout):
 
 
 class _CvPiTail(Function):
-    """The cost volume's pi-stage behind its first layer, as one autograd node on pre-BN tensors:
+    """The all-pixel pi-stage of the cost volume as one autograd node on pre-BN tensors:
 
+        y1[b,n,k,:] = (f[b,n,:]*g[b,k,:]) . W1^T + bias_n[b,n,:] + bias_k[b,k,:]      (factored first layer)
         y1 -(bn1,act)-> W2 -> y2 -(bn2,act)-> W3 -> y3
+        ye[b,n,k,:] = enc_n[b,n,:] + enc_k[b,k,:]                                     (position encoding, pre-BN)
         [ye -(bne,act) | y3 -(bn3,act)] -> W4 -> y4 -(bn4,act)-> W5 -> y5
         out[b,n,:] = sum_k softmax_k(act(bn5(y5))) * act(bn3(y3))
 
-    (PPBackbone_center.py:415-433).  Nothing but y1..y5, ye and their statistics is materialised: no
-    activation tensors, no concatenation, no softmax tensor."""
+    (PPBackbone_center.py:383-433).  Nothing but y1..y5, ye and their statistics is materialised: no
+    point x pixel product, no activation tensors, no concatenation, no softmax tensor; in the backward
+    neither dL/dy1 nor dL/dye is written (BN backward on load in the pair kernel / in closed form on the
+    encoding factors)."""
 
     @staticmethod
-    def forward(ctx, y1, ye, dims, slopes, g1, b1, W2, g2, b2, W3, g3, b3, ge, be, W4, g4, b4, W5, g5, b5):
+    def forward(ctx, f, g, bias_n, bias_k, W1, enc_n, enc_k, slopes, g1, b1, W2, g2, b2, W3, g3, b3, ge, be, W4, g4, b4,
+                W5, g5, b5):
         be_ = ops.get_backend()
-        B, N, M = dims
-        rows = y1.shape[0]
+        f, g, bias_n, bias_k, W1, enc_n, enc_k = [t.detach().contiguous() for t in (f, g, bias_n, bias_k, W1, enc_n, enc_k)]
+        B, N, M = f.shape[0], f.shape[1], g.shape[1]
+        rows = B * N * M
         s1, s2, s3, se, s4, s5 = slopes
         d = lambda t: t.detach()
-        c1, m1 = be_.bn_finalize(rows, be_.bn_stats(y1), d(g1), d(b1), _EPS)
+        y1, st1 = be_.pair_lin_forward(f, g, bias_n, bias_k, W1)
+        c1, m1 = be_.bn_finalize(rows, st1, d(g1), d(b1), _EPS)
         y2, st2 = be_.lin_forward(y1, c1, s1, d(W2)); c2, m2 = be_.bn_finalize(rows, st2, d(g2), d(b2), _EPS)
         y3, st3 = be_.lin_forward(y2, c2, s2, d(W3)); c3, m3 = be_.bn_finalize(rows, st3, d(g3), d(b3), _EPS)
+        ye = (enc_n.unsqueeze(2) + enc_k.unsqueeze(1)).view(rows, -1)
         ce, me = be_.bn_finalize(rows, be_.bn_stats(ye), d(ge), d(be), _EPS)
         y4, st4 = be_.lin_forward_2src(ye, ce, se, y3, c3, s3, d(W4)); c4, m4 = be_.bn_finalize(rows, st4, d(g4), d(b4), _EPS)
         y5, st5 = be_.lin_forward(y4, c4, s4, d(W5)); c5, m5 = be_.bn_finalize(rows, st5, d(g5), d(b5), _EPS)
         out, msave = be_.cv_softmax_wsum_forward(B, N, M, y5, c5, s5, y3, c3, s3)
         ctx.save_for_backward(y1, ye, y2, y3, y4, y5, c1, m1, c2, m2, c3, m3, ce, me, c4, m4, c5, m5, out, msave,
-                              W2, W3, W4, W5, g1, b1, ge, be)
-        ctx.dims, ctx.slopes = dims, slopes
+                              W2, W3, W4, W5, f, g, W1, enc_n, enc_k)
+        ctx.dims, ctx.slopes = (B, N, M), slopes
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         be_ = ops.get_backend()
         (y1, ye, y2, y3, y4, y5, c1, m1, c2, m2, c3, m3, ce, me, c4, m4, c5, m5, out, msave,
-         W2, W3, W4, W5, g1, b1, ge, be) = ctx.saved_tensors
+         W2, W3, W4, W5, f, g, W1, enc_n, enc_k) = ctx.saved_tensors
         B, N, M = ctx.dims
         s1, s2, s3, se, s4, s5 = ctx.slopes
         d = lambda t: t.detach()
@@ -218,20 +226,24 @@ class _CvPiTail(Function):
         r2 = _rep_sum(ds2, y2.shape[1])
         gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2))
         r1 = _rep_sum(ds1, y1.shape[1])
-        dy1, _, _ = _bn_bwd_from_gz(be_, gz1, y1, m1, g1, b1, ds1)
-        dye, _, _ = _bn_bwd_from_gz(be_, gze, ye, me, ge, be, dse)
-        return (dy1, dye, None, None,
+        # first layer: BN backward of bn1 formed on load inside the pair kernel
+        d_f, d_g, d_bn, d_bk, dW1 = be_.pair_lin_backward(gz1, f, g, W1, y=y1, out_coef=c1, out_mi=m1, out_dsums=ds1)
+        # position encoding: k-/n-sums of dL/dye in closed form from one pass over gz_e
+        d_en, d_ek = be_.pair_bias_bn_backward(B, N, M, gze, enc_n, enc_k, dse, ce, me)
+        return (d_f, d_g, d_bn, d_bk, dW1, d_en, d_ek, None,
                 f32(r1[1]), f32(r1[0]), dW2, f32(r2[1]), f32(r2[0]), dW3, f32(r3[1]), f32(r3[0]),
                 f32(re[1]), f32(re[0]), dW4, f32(r4[1]), f32(r4[0]), dW5, f32(r5[1]), f32(r5[0]))
 
 
-def cv_pi_tail(y1, ye, dims, first, mlp1_rest, enc, mlp2):
-    """y1 [rows,128] / ye [rows,64] pre-BN tensors of mlp1[0] / pi_encoding; -> pi_feat [B,N,c]"""
+def cv_pi_tail(f, g, bias_n, bias_k, W1, enc_n, enc_k, first, mlp1_rest, enc, mlp2):
+    """f [B,N,C] / g [B,M,C] normalised point / pixel features, bias_n/bias_k the per-point / per-pixel parts of
+    the first layer, W1 its bilinear weight block, enc_n/enc_k the factors of the position encoding
+    -> pi_feat [B,N,c]"""
     c2, c3 = mlp1_rest
     c4, c5 = mlp2
     slopes = tuple(_slope(m) for m in (first, c2, c3, enc, c4, c5))
     bn = lambda m: (m.bn_linear.weight, m.bn_linear.bias)
-    return _CvPiTail.apply(y1.contiguous(), ye.contiguous(), dims, slopes, *bn(first), c2.weight2d(), *bn(c2),
+    return _CvPiTail.apply(f, g, bias_n, bias_k, W1, enc_n, enc_k, slopes, *bn(first), c2.weight2d(), *bn(c2),
                            c3.weight2d(), *bn(c3), *bn(enc), c4.weight2d(), *bn(c4), c5.weight2d(), *bn(c5))
 
 

@@ -458,19 +458,20 @@ class CostVolume(nn.Module):
             respond = torch.where(any_valid, respond, torch.full_like(respond, -1e10))
             per_pixel = per_pixel + F.linear(respond, w_parts[3])
         B_, N_ = pts_n.shape[0], pts_n.shape[1]
-        if USE_FUSED_MLP and pair_fits(C, first.out_channels) and pix_n.shape[1] >= 64:
+        we_parts = torch.split(self.pi_encoding.weight2d(), [3, 3], dim=1)
+        enc_n, enc_k = F.linear(xyz, we_parts[0]), F.linear(pix_xyz, we_parts[1])    # factors of the pre-BN encoding
+        rest = list(self.mlp1_convs)[1:]
+        pair_ok = USE_FUSED_MLP and pair_fits(C, first.out_channels) and pix_n.shape[1] >= 64
+        if pair_ok and USE_CV_TAIL and cv_tail_fits(first, rest, self.pi_encoding, list(self.mlp2_convs)):
+            return None, None, cv_pi_tail(pts_n, pix_n, per_point, per_pixel, w_parts[2], enc_n, enc_k, first, rest,
+                                          self.pi_encoding, list(self.mlp2_convs))
+        if pair_ok:
             # bilinear term on the matrix cores straight from the [B,N,C] / [B,M,C] factors
             y = pair_linear(pts_n, pix_n, per_point, per_pixel, w_parts[2]).view(B_, N_, pix_n.shape[1], -1)
         else:
             corr = pts_n.unsqueeze(2) * pix_n.unsqueeze(1)                      # [B,N,M,C]  :395
             y = F.linear(corr, w_parts[2]) + per_point.unsqueeze(2) + per_pixel.unsqueeze(1)
-        we_parts = torch.split(self.pi_encoding.weight2d(), [3, 3], dim=1)
-        ye = F.linear(xyz, we_parts[0]).unsqueeze(2) + F.linear(pix_xyz, we_parts[1]).unsqueeze(1)   # pre-BN, [B,N,M,c]
-        rest = list(self.mlp1_convs)[1:]
-        if USE_FUSED_MLP and USE_CV_TAIL and cv_tail_fits(first, rest, self.pi_encoding, list(self.mlp2_convs)):
-            M_ = pix_n.shape[1]
-            return None, None, cv_pi_tail(y.reshape(B_ * N_ * M_, -1), ye.reshape(B_ * N_ * M_, -1), (B_, N_, M_), first,
-                                          rest, self.pi_encoding, list(self.mlp2_convs))
+        ye = enc_n.unsqueeze(2) + enc_k.unsqueeze(1)                            # pre-BN, [B,N,M,c]
         h = run_stack(y, rest, first_bn=first)
         enc = self.pi_encoding.finish(ye)
         return h, enc, None

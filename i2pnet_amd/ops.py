@@ -351,8 +351,9 @@ class CBackend:
                    stream=self._stream())
         return y, sums
 
-    def pair_lin_backward(self, gy, f, g, w):
-        """gy = dL/dy [B*N*M, Co] -> (d_f, d_g, d_bias_n, d_bias_k, dw)"""
+    def pair_lin_backward(self, gy, f, g, w, y=None, out_coef=None, out_mi=None, out_dsums=None):
+        """gy = dL/dy [B*N*M, Co] (or dL/dz with the BN behind given by y/out_coef/out_mi/out_dsums: BN backward
+        on load) -> (d_f, d_g, d_bias_n, d_bias_k, dw)"""
         B, N, C = f.shape
         M = g.shape[1]
         Co = w.shape[0]
@@ -364,8 +365,9 @@ class CBackend:
         grid = B * KT * NC if self.device_type == "cuda" else 1          # i2p_pair_lin_bwd_grid
         part = torch.empty(grid * Co * C, dtype=_F32, device=dev)
         dw = torch.empty(Co, C, dtype=_F32, device=dev)
-        self._call("i2p_pair_lin_bwd", int(B), int(N), int(M), int(C), int(Co), self._p(gy, _F32, "gy"), None, None,
-                   None, None, self._p(f, _F32, "f"), self._p(g, _F32, "g"), self._p(w, _F32, "w"),
+        opt = lambda t, dt=_F32: self._p(t, dt, "bn") if t is not None else None
+        self._call("i2p_pair_lin_bwd", int(B), int(N), int(M), int(C), int(Co), self._p(gy, _F32, "gy"), opt(y),
+                   opt(out_coef), opt(out_mi), opt(out_dsums, torch.float64), self._p(f, _F32, "f"), self._p(g, _F32, "g"), self._p(w, _F32, "w"),
                    self._p(d_f, _F32, "d_f"), self._p(d_g, _F32, "d_g"), self._p(d_bn, _F32, "d_bn"),
                    self._p(d_bk, _F32, "d_bk"), self._p(part, _F32, "part"), self._p(dw, _F32, "dw"),
                    stream=self._stream())
@@ -429,6 +431,20 @@ class CBackend:
                    self._p(coef3, _F32, "coef3"), float(slope3), self._p(gz5, _F32, "gz5"),
                    self._p(ds5, torch.float64, "ds5"), self._p(ga3, _F32, "ga3"), stream=self._stream())
         return gz5, ds5, ga3
+
+    def pair_bias_bn_backward(self, B, N, M, gz, enc_n, enc_k, dsums, coef, mi):
+        """-> (d_enc_n [B,N,C], d_enc_k [B,M,C]); see i2p_pair_bias_bn_bwd"""
+        C = gz.shape[1]
+        dev = gz.device
+        sum_k = torch.empty(B, N, C, dtype=_F32, device=dev)
+        sum_n = zeros((B, M, C), _F32, dev)
+        d_n = torch.empty(B, N, C, dtype=_F32, device=dev); d_k = torch.empty(B, M, C, dtype=_F32, device=dev)
+        self._call("i2p_pair_bias_bn_bwd", int(B), int(N), int(M), int(C), self._p(gz, _F32, "gz"),
+                   self._p(enc_n, _F32, "enc_n"), self._p(enc_k, _F32, "enc_k"), self._p(dsums, torch.float64, "dsums"),
+                   self._p(coef, _F32, "coef"), self._p(mi, _F32, "mi"), self._p(sum_k, _F32, "sum_k"),
+                   self._p(sum_n, _F32, "sum_n"), self._p(d_n, _F32, "d_enc_n"), self._p(d_k, _F32, "d_enc_k"),
+                   stream=self._stream())
+        return d_n, d_k
 
     def bn_finalize(self, rows, sums, gamma, beta, eps):
         """-> (coef [3,c] = mean, invstd*gamma, beta ; mean_invstd [2c])"""

@@ -320,6 +320,16 @@ int i2p_cv_softmax_wsum_bwd(int B, int N, int M, int C, const float *g_out, cons
                             float slope5, const float *y3, const float *coef3, float slope3, float *gz5,
                             double *dsums5, float *ga3, void *stream);
 
+/* Gradient of the factors of the all-pixel position encoding ye[b,n,k,:] = enc_n[b,n,:] + enc_k[b,k,:]
+ * (PPBackbone_center.py:416-418: pi_encoding applied to cat(xyz_n, uv_k), a 1x1 conv => an outer sum):
+ *   gz f32 [B*N*M, C] = dL/dz_e (z_e = BN(ye)), dsums replicated {sum gz, sum gz*xhat}, coef [3][C], mi [2][C];
+ *   d_enc_n f32 [B,N,C] = sum_k dL/dye, d_enc_k f32 [B,M,C] = sum_n dL/dye, dL/dye = scale*(gz - m1 - xhat*m2).
+ *   sum_k f32 [B,N,C] (written), sum_n f32 [B,M,C] (ZEROED BY THE CALLER, accumulated with atomics): scratch.
+ * gz is read once; the [B,N,M,C] gradient of ye is never formed.  C % 4 == 0, C | 256. */
+int i2p_pair_bias_bn_bwd(int B, int N, int M, int C, const float *gz, const float *enc_n, const float *enc_k,
+                         const double *dsums, const float *coef, const float *mi, float *sum_k, float *sum_n,
+                         float *d_enc_n, float *d_enc_k, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -484,6 +484,77 @@ def test_pair_lin_parity(oracle_backend, hip_backend, B, N, M, C, Co):
         assert float((hh.cpu().double() - ref).abs().max()) <= 3e-4 * sc, name
 
 
+def _pair_bn_case(B, N, M, C, Co, seed):
+    g_ = torch.Generator().manual_seed(seed)
+    f = torch.randn(B, N, C, generator=g_); g = torch.randn(B, M, C, generator=g_)
+    bn = torch.randn(B, N, Co, generator=g_); bk = torch.randn(B, M, Co, generator=g_)
+    w = torch.randn(Co, C, generator=g_) / C ** 0.5
+    gam = torch.randn(Co, generator=g_); bet = 0.2 * torch.randn(Co, generator=g_)
+    gz = torch.randn(B * N * M, Co, generator=g_)
+    return f, g, bn, bk, w, gam, bet, gz
+
+
+@pytest.mark.parametrize("B,N,M,C,Co", [(2, 23, 70, 128, 128), (1, 9, 130, 64, 64), (3, 17, 64, 128, 64)])
+def test_pair_lin_bwd_bn_on_load(oracle_backend, hip_backend, B, N, M, C, Co):
+    """pair layer backward with the BN behind it formed on load: HIP vs oracle, and both vs the two-step
+    path (bn_act_backward with slope 1 -> dL/dy, then the plain pair backward)."""
+    f, g, bn, bk, w, gam, bet, gz = _pair_bn_case(B, N, M, C, Co, 31)
+    rows = B * N * M
+
+    def run(be, dev, on_load):
+        t = lambda v: v.to(dev)
+        y, st = be.pair_lin_forward(t(f), t(g), t(bn), t(bk), t(w))
+        coef, mi = be.bn_finalize(rows, st, t(gam), t(bet), 1e-5)
+        ds = be.bn_act_backward_stats(t(gz), y, mi, t(gam), t(bet), 1.0)
+        if on_load:
+            return be.pair_lin_backward(t(gz), t(f), t(g), t(w), y=y, out_coef=coef, out_mi=mi, out_dsums=ds)
+        dy, _, _ = be.bn_act_backward(t(gz), y, mi, t(gam), t(bet), 1.0)
+        return be.pair_lin_backward(dy, t(f), t(g), t(w))
+    r0 = run(oracle_backend, "cpu", False); r1 = run(oracle_backend, "cpu", True); h1 = run(hip_backend, DEV, True)
+    for name, a, b_, c_ in zip(["d_f", "d_g", "d_bn", "d_bk", "dw"], r0, r1, h1):
+        sc = float(a.abs().max())
+        assert float((a - b_).abs().max()) <= 3e-4 * sc, name
+        assert float((a - c_.cpu()).abs().max()) <= 3e-4 * sc, name
+
+
+@pytest.mark.parametrize("B,N,M,C", [(2, 23, 70, 64), (8, 228, 468, 64), (1, 5, 9, 128)])
+def test_pair_bias_bn_bwd_parity(oracle_backend, hip_backend, B, N, M, C):
+    """gradient of the position-encoding factors (closed-form BN backward of an outer sum): HIP vs the literal
+    oracle evaluation; small case also vs torch autograd in fp64."""
+    g_ = torch.Generator().manual_seed(B + N)
+    en = torch.randn(B, N, C, generator=g_) * 2; ek = torch.randn(B, M, C, generator=g_) + 0.5
+    gam = torch.randn(C, generator=g_); bet = 0.1 * torch.randn(C, generator=g_)
+    rows = B * N * M
+    gz = torch.randn(rows, C, generator=g_)
+    ye = (en[:, :, None] + ek[:, None]).reshape(rows, C).contiguous()
+    if rows > 100000:       # the literal oracle loop is slow: compare with the same closed form in fp64 torch
+        coef, mi = hip_backend.bn_finalize(rows, hip_backend.bn_stats(ye.to(DEV)), gam.to(DEV), bet.to(DEV), 1e-5)
+        ds = hip_backend.bn_act_backward_stats(gz.to(DEV), ye.to(DEV), mi, gam.to(DEV), bet.to(DEV), 1.0)
+        hn, hk = hip_backend.pair_bias_bn_backward(B, N, M, gz.to(DEV), en.to(DEV), ek.to(DEV), ds, coef, mi)
+        yd = ye.double(); m = yd.mean(0); v = yd.var(0, unbiased=False); is_ = (v + 1e-5).rsqrt()
+        xh = (yd - m) * is_; gd = gz.double()
+        dy = (is_ * gam.double()) * (gd - gd.mean(0) - xh * (gd * xh).mean(0))
+        dy = dy.view(B, N, M, C)
+        assert torch.allclose(hn.cpu().double(), dy.sum(2), rtol=1e-3, atol=2e-3 * float(dy.sum(2).abs().max()))
+        assert torch.allclose(hk.cpu().double(), dy.sum(1), rtol=1e-3, atol=2e-3 * float(dy.sum(1).abs().max()))
+        return
+
+    def run(be, dev):
+        t = lambda v_: v_.to(dev)
+        coef, mi = be.bn_finalize(rows, be.bn_stats(t(ye)), t(gam), t(bet), 1e-5)
+        ds = be.bn_act_backward_stats(t(gz), t(ye), mi, t(gam), t(bet), 1.0)
+        return be.pair_bias_bn_backward(B, N, M, t(gz), t(en), t(ek), ds, coef, mi)
+    rn, rk = run(oracle_backend, "cpu"); hn, hk = run(hip_backend, DEV)
+    assert float((rn - hn.cpu()).abs().max()) <= 1e-3 * float(rn.abs().max())
+    assert float((rk - hk.cpu()).abs().max()) <= 1e-3 * float(rk.abs().max())
+    end, ekd = en.double().requires_grad_(), ek.double().requires_grad_()
+    yed = (end[:, :, None] + ekd[:, None]).reshape(rows, C)
+    z = torch.nn.functional.batch_norm(yed, None, None, gam.double(), bet.double(), True, 0.0, 1e-5)
+    z.backward(gz.double())
+    assert float((rn.double() - end.grad).abs().max()) <= 1e-3 * float(end.grad.abs().max())
+    assert float((rk.double() - ekd.grad).abs().max()) <= 1e-3 * float(ekd.grad.abs().max())
+
+
 def test_cv_tail_ops_parity(oracle_backend, hip_backend):
     """two-source fused layer (fwd/bwd) and softmax-weighted sum (fwd/bwd): HIP vs oracle."""
     B, N, M, Ca, Cb, Co = 2, 23, 70, 64, 64, 128
