@@ -311,7 +311,9 @@ __device__ __forceinline__ void pair_row16(const PairTile &t, int d, int N, int 
 template <int NT16, bool PAIR, bool DGRAD>
 __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p) {
     extern __shared__ float smem[];
-    const int ldk = p.ldk;                                  // max(cin, cout_p) + 2: 8-byte aligned rows
+    const int ldk = p.ldk;                                  // max(cin, cout_p) + 2 (8-byte aligned rows), or + 4 (16-byte, wide-K path)
+    // (forward / pair instantiations only: the dgrad instantiation is register-bound and keeps the narrow loop)
+    const bool wide_k = !DGRAD && ((p.cin & 15) == 0) && ((ldk & 3) == 0) && !(p.ablate & 16);
     float *Ws = smem;                                       // [cout_p][ldk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *As = smem + (size_t)p.cout_p * ldk + (size_t)wave * F2_ROWS * ldk;   // this wave's strip
@@ -478,7 +480,48 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
         // Ping-pong fragment registers, two k-steps per iteration: the operands of a step were requested a
         // full step (8 MFMAs = 256 cycles) earlier, so no s_waitcnt ever sits between two MFMAs and no
         // register copies are needed (a single-buffered version measured 72 % of the MFMA issue rate).
-        const int K4 = p.cin >> 2;
+        const int K4 = (p.ablate & 1) ? 0 : (p.cin >> 2);
+        if (wide_k) {
+            // K permuted across the four k-slots of the fragment layout: slot q = lane>>4 owns the CONTIGUOUS range
+            // k in [q*L, (q+1)*L), L = cin/4 (A and B use the same permutation, so the product is unchanged).  One
+            // ds_read_b128 then feeds four k-steps: 9 wide LDS reads per 32 MFMAs instead of 36 narrow ones with
+            // per-read address arithmetic, and the MFMAs issue back to back.  Rows are 16-byte aligned and
+            // ldk = 4 (mod 32), so the eight lanes of a 128-byte LDS pass hit 32 distinct banks.
+            const int L = K4;
+            const float *aw = As + (lane & 15) * ldk + (lane >> 4) * L;
+            const float *bw = Ws + (lane & 15) * ldk + (lane >> 4) * L;
+            // B fragments single-buffered in two halves: while the MFMAs of one half of the column tiles run, the
+            // other half's registers are refilled for the next 4 k-steps (an accumulator is revisited after
+            // NT16/2 >= 4 MFMAs = 128 cycles > the 40-cycle dependent latency); A is double-buffered (4 VGPRs each).
+            constexpr int H = NT16 >= 2 ? NT16 / 2 : 1;
+            f32x4 av = *reinterpret_cast<const f32x4 *>(aw), an = av;
+            f32x4 bv[NT16];
+#pragma unroll
+            for (int j = 0; j < NT16; ++j) bv[j] = *reinterpret_cast<const f32x4 *>(bw + (size_t)j * 16 * ldk);
+            for (int s4 = 0; s4 < L; s4 += 4) {
+                const int sn = s4 + 4 < L ? s4 + 4 : s4;          // next chunk (the last one re-reads itself: harmless)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < H; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[j][e], acc[j], 0, 0, 0);
+                an = *reinterpret_cast<const f32x4 *>(aw + sn);
+#pragma unroll
+                for (int j = 0; j < H; ++j) bv[j] = *reinterpret_cast<const f32x4 *>(bw + (size_t)j * 16 * ldk + sn);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * H, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, H + 1, 0);
+                if (NT16 >= 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = H; j < NT16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[j][e], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = H; j < NT16; ++j) bv[j] = *reinterpret_cast<const f32x4 *>(bw + (size_t)j * 16 * ldk + sn);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * (NT16 - H), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NT16 - H, 0);
+                }
+                av = an;
+            }
+        } else {
         float a0 = arow[0], b0[NT16], a1 = 0.f, b1[NT16];
 #pragma unroll
         for (int j = 0; j < NT16; ++j) { b0[j] = brow[(size_t)j * 16 * ldk]; b1[j] = 0.f; }
@@ -504,6 +547,8 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
         if (st4 < K4) {
 #pragma unroll
             for (int j = 0; j < NT16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[j], acc[j], 0, 0, 0);
+        }
+
         }
 
         // ---- epilogue 1: fragments -> this wave's strip (C/D of 16x16: col = lane&15, row = (lane>>4)*4+e) ----
@@ -551,7 +596,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
                             s2[2] = fmaf(v.z, (xr.z - e_mu.z) * e_is.z, s2[2]); s2[3] = fmaf(v.w, (xr.w - e_mu.w) * e_is.w, s2[3]);
                         }
                     }
-                } else if (row0 + r <= last_row) {
+                } else if (row0 + r <= last_row && !(p.ablate & 4)) {
                     s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
                     s2[0] = fmaf(v.x, v.x, s2[0]); s2[1] = fmaf(v.y, v.y, s2[1]);
                     s2[2] = fmaf(v.z, v.z, s2[2]); s2[3] = fmaf(v.w, v.w, s2[3]);
@@ -562,14 +607,14 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) { ssum[q] += (double)s1[q]; ssq[q] += (double)s2[q]; }
         // ---- the strip is free again: stage the next one, then store this one's outputs ---------------------
-        if (strip + sstride < nstrips) commit(strip + sstride, pf, pf2);
+        if (strip + sstride < nstrips && !(p.ablate & 8)) commit(strip + sstride, pf, pf2);
 #pragma unroll
         for (int u = 0; u < OCH; ++u) {
             const int r = (lane + u * 64) >> o_shift;
-            if (r < F2_ROWS && row0 + r <= last_row)
+            if (r < F2_ROWS && row0 + r <= last_row && !(p.ablate & 2))
                 *reinterpret_cast<float4 *>(dst_y + (size_t)(row0 + r) * dst_ld + dst_c0) = ov[u];
         }
-        if (strip + 2 * sstride < nstrips) fetch(strip + 2 * sstride, pf, pf2);
+        if (strip + 2 * sstride < nstrips && !(p.ablate & 8)) fetch(strip + 2 * sstride, pf, pf2);
     }
 
     if (p.sums || (DGRAD && p.sums_b)) {
@@ -1469,9 +1514,10 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
                 LinFwdParams p;
                 p.rows = rows; p.cin = cin; p.cout = slice_w;
                 p.cin_p = cin; p.cout_p = slice_w;
-                p.ldk = ((cin > p.cout_p ? cin : p.cout_p) + 2);
+                p.ldk = (cin > p.cout_p ? cin : p.cout_p) + ((cin & 15) == 0 ? 4 : 2);   // +4: 16-byte rows, ldk = 4 mod 32 (wide-K fragments)
                 p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.w = w + (size_t)off * cin; p.y = y; p.sums = sums;
-                p.y_ld = cout; p.ch_off = off; p.cout_total = cout; p.ablate = 0;
+                p.y_ld = cout; p.ch_off = off; p.cout_total = cout;
+                { const char *abl = getenv("I2P_LIN_ABLATE"); p.ablate = abl ? atoi(abl) : 0; }   // diagnostic only
                 p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
                 p.x2 = nullptr; p.g_coef = nullptr; p.w_transposed = 0; p.ex = p.e_coef = p.e_mi = nullptr; p.e_slope = 1.f;
                 p.split_c = 0; p.xb = xb; p.in_coef_b = in_coef_b; p.slope_b = slope_b; p.yb = nullptr; p.exb = p.e_coef_b = p.e_mi_b = p.e_add = nullptr; p.sums_b = nullptr; p.e_slope_b = 1.f; p.split_c = split_c;
