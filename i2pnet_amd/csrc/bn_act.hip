@@ -202,6 +202,51 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_v4(long long rows, int c, 
     }
 }
 
+// ---- BN + activation + max over the K neighbours of a group (set-abstraction tail) ---------------------------
+// out[g,:] = max_k act(bn(y[g*K+k,:])), arg[g,:] = first k attaining it (PPBackbone_center.py:129,
+// torch.max(new_points, dim=2)): the activated [groups*K, C] tensor is never written.  Thread per (group, float4).
+__global__ __launch_bounds__(THREADS) void bn_act_maxk_fwd_v4(long long groups, int K, int c, const float4 *__restrict__ y,
+                                                               const float *__restrict__ coef, float slope,
+                                                               float4 *__restrict__ out, uchar4 *__restrict__ arg) {
+    const int cv = c >> 2;
+    const long long total = groups * cv;
+    const int vcol = threadIdx.x % cv;
+    const float4 mu = *reinterpret_cast<const float4 *>(coef + vcol * 4), sc = *reinterpret_cast<const float4 *>(coef + c + vcol * 4),
+                 be = *reinterpret_cast<const float4 *>(coef + 2 * c + vcol * 4);
+    for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
+        const long long g = t / cv;
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uchar4 bi = make_uchar4(0, 0, 0, 0);
+        const float4 *src = y + g * K * cv + vcol;
+        for (int k = 0; k < K; ++k) {
+            const float4 v = src[(size_t)k * cv];
+            const float ax = act_fwd((v.x - mu.x) * sc.x + be.x, slope), ay = act_fwd((v.y - mu.y) * sc.y + be.y, slope);
+            const float az = act_fwd((v.z - mu.z) * sc.z + be.z, slope), aw = act_fwd((v.w - mu.w) * sc.w + be.w, slope);
+            if (ax > best.x || ax != ax) { best.x = ax; bi.x = (unsigned char)k; }
+            if (ay > best.y || ay != ay) { best.y = ay; bi.y = (unsigned char)k; }
+            if (az > best.z || az != az) { best.z = az; bi.z = (unsigned char)k; }
+            if (aw > best.w || aw != aw) { best.w = aw; bi.w = (unsigned char)k; }
+        }
+        out[t] = best; arg[t] = bi;
+    }
+}
+
+// backward of the max: dense dL/da [groups*K, C] written in ONE pass (torch: zeros + scatter)
+__global__ __launch_bounds__(THREADS) void unpool_k_v4(long long groups, int K, int c, const float4 *__restrict__ g,
+                                                        const uchar4 *__restrict__ arg, float4 *__restrict__ gd) {
+    const int cv = c >> 2;
+    const long long total = groups * K * cv;
+    for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
+        const long long r = t / cv;
+        const int vcol = (int)(t - r * cv);
+        const long long grp = r / K;
+        const unsigned char k = (unsigned char)(r - grp * K);
+        const float4 gv = g[grp * cv + vcol];
+        const uchar4 a = arg[grp * cv + vcol];
+        gd[t] = make_float4(a.x == k ? gv.x : 0.f, a.y == k ? gv.y : 0.f, a.z == k ? gv.z : 0.f, a.w == k ? gv.w : 0.f);
+    }
+}
+
 // ---- generic path (any C): one thread per element, channel = index % C ------------------------
 __global__ void bn_stats_gen(long long total, int c, const float *__restrict__ y, double *__restrict__ sums) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -338,5 +383,31 @@ extern "C" int i2p_bn_act_bwd(long long rows, int c, const float *dout, const fl
         hipLaunchKernelGGL(bn_act_bwd_gen, dim3(grid_gen(rows * c)), dim3(THREADS), 0, st, rows * c, rows, c, dout, y,
                            mean_invstd, gamma, beta, slope, dsums, dy, dgamma, dbeta);
     }
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_bn_act_maxk_fwd(long long groups, int K, int c, const float *y, const float *coef, float slope,
+                                   float *out, unsigned char *arg, void *stream) {
+    if (groups < 0 || K <= 0 || K > 255 || c <= 0 || (c & 3) || THREADS % (c >> 2)) return I2P_ERR_BAD_ARG;
+    if (groups == 0) return 0;
+    if (!y || !coef || !out || !arg) return I2P_ERR_BAD_ARG;
+    const long long total = groups * (c >> 2);
+    long long blocks = (total + THREADS - 1) / THREADS;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL(bn_act_maxk_fwd_v4, dim3((unsigned)blocks), dim3(THREADS), 0, (hipStream_t)stream, groups, K, c,
+                       (const float4 *)y, coef, slope, (float4 *)out, (uchar4 *)arg);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_unpool_k(long long groups, int K, int c, const float *g, const unsigned char *arg, float *gd,
+                            void *stream) {
+    if (groups < 0 || K <= 0 || K > 255 || c <= 0 || (c & 3)) return I2P_ERR_BAD_ARG;
+    if (groups == 0) return 0;
+    if (!g || !arg || !gd) return I2P_ERR_BAD_ARG;
+    const long long total = groups * K * (c >> 2);
+    long long blocks = (total + THREADS - 1) / THREADS;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL(unpool_k_v4, dim3((unsigned)blocks), dim3(THREADS), 0, (hipStream_t)stream, groups, K, c,
+                       (const float4 *)g, (const uchar4 *)arg, (float4 *)gd);
     I2P_RETURN_LAUNCH_STATUS();
 }

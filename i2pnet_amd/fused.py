@@ -25,7 +25,7 @@ def layer_fits(cin, cout):
     if cin % 4 or cout % 4 or cout > 128:
         return False
     cin_p, cout_p = _r32(cin), _r32(cout)
-    bwd = (cout_p * (cin_p + 1) + 64 * (cout_p + 1) + 64 * (cin_p + 1) + 5 * cout_p + 4 * cin_p) * 4
+    bwd = (cout_p * (cin_p + 1) + 64 * (cout_p + 1) + 64 * (cin_p + 1) + 6 * cout_p + 4 * cin_p) * 4
     fwd = (32 + 128) * (cin + 2) * 4
     return cin_p <= 160 and bwd <= _LDS and fwd <= _LDS
 
@@ -41,7 +41,9 @@ class _MlpChain(Function):
     (index 0 = the optional leading BN)."""
 
     @staticmethod
-    def forward(ctx, x, first_bn, slopes, *params):
+    def forward(ctx, x, first_bn, slopes, pool_k, *params):
+        """pool_k > 0: the output is the max over groups of pool_k consecutive rows (set-abstraction tail),
+        [rows/pool_k, c]; the activated [rows, c] tensor is not materialised."""
         be = ops.get_backend()
         rows = x.shape[0]
         p = list(params)
@@ -65,6 +67,15 @@ class _MlpChain(Function):
             in_coef, mi = be.bn_finalize(rows, sums, g.detach(), b.detach(), _EPS)
             coefs.append(in_coef); mis.append(mi); ys.append(y)
             slope_in = slopes[i + 1]
+        ctx.pool_k = 0
+        if pool_k and nl and ys[-1].shape[1] % 4 == 0 and 256 % (ys[-1].shape[1] // 4) == 0 and pool_k <= 255:
+            out, arg = be.bn_act_maxk_forward(ys[-1], coefs[-1], slopes[-1], pool_k)
+            ctx.pool_k = pool_k
+            ctx.first_bn, ctx.slopes, ctx.nl, ctx.k = first_bn, slopes, nl, k
+            ctx.save_for_backward(*ys, *[c for c in coefs if c is not None], *[m for m in mis if m is not None], *p, arg)
+            ctx.n_ys, ctx.n_coef = len(ys), len([c for c in coefs if c is not None])
+            ctx.x_needs_grad = x.requires_grad
+            return out
         # the stack's output: BN + activation of the last pre-BN tensor, materialised once
         out = torch.empty_like(ys[-1])
         mi_last = torch.empty_like(mis[-1])
@@ -82,12 +93,17 @@ class _MlpChain(Function):
         ctx.save_for_backward(*ys, *[c for c in coefs if c is not None], *[m for m in mis if m is not None], *p)
         ctx.n_ys, ctx.n_coef = len(ys), len([c for c in coefs if c is not None])
         ctx.x_needs_grad = x.requires_grad
+        if pool_k:                                      # shapes the fused tail does not cover
+            return out.view(rows // pool_k, pool_k, -1).max(1)[0]
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         be = ops.get_backend()
         saved = list(ctx.saved_tensors)
+        if ctx.pool_k:
+            arg = saved.pop()
+            g_out = be.unpool_k(g_out.contiguous(), arg, ctx.pool_k)        # dense dL/da in one pass
         ys = saved[:ctx.n_ys]
         cf = saved[ctx.n_ys:ctx.n_ys + ctx.n_coef]
         ms = saved[ctx.n_ys + ctx.n_coef:ctx.n_ys + 2 * ctx.n_coef]
@@ -101,7 +117,7 @@ class _MlpChain(Function):
         if not nl:          # only the leading BN: dL/dx and its gamma/beta gradients
             gz, dg, db = be.bn_act_backward(g_out, ys[-1], mis[-1], last_g.detach(), last_b.detach(), slopes[-1])
             grads[0], grads[1] = dg, db
-            return (gz if ctx.x_needs_grad else None), None, None, *grads
+            return (gz if ctx.x_needs_grad else None), None, None, None, *grads
         # last block: only the statistics pass over (dL/da, y_L); the activation derivative and the BN backward are
         # applied by the layer kernels as they load dL/da (slope_out), so dL/dy_L is never written
         out_ds = be.bn_act_backward_stats(g_out, ys[-1], mis[-1], last_g.detach(), last_b.detach(), slopes[-1])
@@ -129,7 +145,7 @@ class _MlpChain(Function):
                 gx, _, _ = _bn_bwd_from_gz(be, gz, ys[0], mis[0], p[0], p[1], out_ds)
             else:
                 gx = gz
-        return gx, None, None, *grads
+        return gx, None, None, None, *grads
 
 
 def _bn_bwd_from_gz(be, gz, y, mi, gamma, beta, dsums):
@@ -262,10 +278,12 @@ def _slope(conv):
     return conv.negative_slope if conv.activation_fn else 1.0
 
 
-def mlp_stack(x, convs, first_bn=None):
+def mlp_stack(x, convs, first_bn=None, pool_k=0):
     """Apply `convs` (list of modules.Conv2d with batch-stat BN) to channel-last `x [..., C]`.
     `first_bn`: a Conv2d whose BN+activation still has to be applied to `x` (x is its pre-BN output).
-    Consecutive blocks that fit the fused kernels run as one chain; others run block by block."""
+    Consecutive blocks that fit the fused kernels run as one chain; others run block by block.
+    `pool_k`: x is `[..., K, C]` with K = pool_k and the result is the max over that axis `[..., C']`
+    (fused into the last chain when it ends the stack)."""
     lead = x.shape[:-1]
     cur = x.reshape(-1, x.shape[-1])
     pending_bn = first_bn
@@ -289,14 +307,20 @@ def mlp_stack(x, convs, first_bn=None):
             xin = cur
             for t, c in enumerate(run):
                 W = c.weight2d()
-                if t == 0 and pending_bn is None and xin.shape[1] % 4:       # pad raw input channels to a multiple of 4
-                    pad = 4 - xin.shape[1] % 4
-                    xin = F.pad(xin, (0, pad)); W = F.pad(W, (0, pad))
+                if t == 0 and pending_bn is None:
+                    if xin.shape[1] % 4:                 # pad raw input channels to a multiple of 4
+                        xin = F.pad(xin, (0, 4 - xin.shape[1] % 4))
+                    if xin.shape[1] > W.shape[1]:        # (callers may deliver the zero channels already: modules.cat_padded)
+                        W = F.pad(W, (0, xin.shape[1] - W.shape[1]))
                 params += [W, c.bn_linear.weight, c.bn_linear.bias]; slopes.append(_slope(c))
-            cur = _MlpChain.apply(xin.contiguous(), pending_bn is not None, tuple(slopes), *params)
+            pool_here = pool_k if (j >= n and run) else 0
+            cur = _MlpChain.apply(xin.contiguous(), pending_bn is not None, tuple(slopes), pool_here, *params)
+            if pool_here:
+                return cur.reshape(*lead[:-1], cur.shape[-1])
             pending_bn = None
             i = j
         if i < n and not run:           # block that does not fit: library GEMM + fused BN/activation kernels
-            cur = convs[i](cur)
+            cur = convs[i](cur[:, :convs[i].in_channels] if cur.shape[1] > convs[i].in_channels else cur)
             i += 1
-    return cur.reshape(*lead, cur.shape[-1])
+    cur = cur.reshape(*lead, cur.shape[-1])
+    return torch.max(cur, dim=-2)[0] if pool_k else cur

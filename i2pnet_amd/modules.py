@@ -33,15 +33,27 @@ USE_CV_TAIL = True
 USE_FUSED_IMG = True
 
 
-def run_stack(x, convs, first_bn=None):
+def run_stack(x, convs, first_bn=None, pool_k=0):
+    """`pool_k`: x is [..., K, C]; additionally take the max over the K axis (fused into the last layer kernel's
+    BN/activation pass when the stack runs on the fused kernels)."""
     convs = list(convs)
     if USE_FUSED_MLP:
-        return mlp_stack(x, convs, first_bn)
+        return mlp_stack(x, convs, first_bn, pool_k)
     if first_bn is not None:
         x = first_bn.finish(x)
     for conv in convs:
         x = conv(x)
-    return x
+    return torch.max(x, dim=-2)[0] if pool_k else x
+
+
+def cat_padded(parts, dim=-1):
+    """torch.cat(parts, -1) with zero channels appended up to a multiple of 4 (what the fused layer kernels
+    consume): the padding rides along in the one cat kernel instead of a separate fill + copy of the tensor."""
+    c = sum(t.shape[-1] for t in parts)
+    pad = (-c) % 4
+    if pad and USE_FUSED_MLP:
+        parts = list(parts) + [parts[0].new_zeros(()).expand(*parts[0].shape[:-1], pad)]
+    return torch.cat(parts, dim)
 
 _BN_EPS = 1e-5
 
@@ -294,8 +306,8 @@ class ProjectPointNet(nn.Module):
         return new_xyz_proj_raw, new_xyz_proj, grouped_xyz, grouped_xyz_norm, grouped_idx, sample_idx
 
     def _mlp_max(self, new_points, B):
-        new_points = run_stack(new_points, self.mlp_convs)
-        return torch.max(new_points, dim=2)[0].view(B, self.out_h, self.out_w, -1)
+        new_points = run_stack(new_points, self.mlp_convs, pool_k=new_points.shape[2])      # max over K, :129
+        return new_points.view(B, self.out_h, self.out_w, -1)
 
     def forward(self, xyz_proj_raw, xyz_proj, feature_proj, sample_idx=None, cfg=None, raw_feat_point=False):
         """xyz_proj_raw/xyz_proj [B,H,W,3], feature_proj [B,H,W,C] ->
@@ -304,7 +316,7 @@ class ProjectPointNet(nn.Module):
         raw_c, c, grouped_xyz, norm, gidx, sample_idx = self._centres_and_groups(xyz_proj_raw, xyz_proj, sample_idx,
                                                                                raw_feat_point)
         grouped_points = P.gather_torch(feature_proj, *gidx[:3], B, self.H, self.W)
-        new_points = self._mlp_max(torch.cat([norm, grouped_points], -1), B)      # PPBackbone_center.py:121-129
+        new_points = self._mlp_max(cat_padded([norm, grouped_points]), B)         # PPBackbone_center.py:121-129
         return raw_c, c, new_points, grouped_xyz, sample_idx
 
     def forward_center(self, xyz_proj_raw, xyz_proj, feature_proj, sample_idx=None, cfg=None, using_intens=False,
@@ -320,7 +332,7 @@ class ProjectPointNet(nn.Module):
         parts = [norm, centre, grouped_xyz, dist]
         if using_intens:
             parts.append(P.gather_torch(feature_proj, *gidx[:3], B, self.H, self.W))
-        new_points = self._mlp_max(torch.cat(parts, -1), B)
+        new_points = self._mlp_max(cat_padded(parts), B)
         return raw_c, c, new_points, grouped_xyz, sample_idx
 
     def set_bn(self):
@@ -364,9 +376,8 @@ class ProjSetUpconvModule(nn.Module):
             xyz_diff = P.gather_torch(xyz2_raw, *gidx[:3], B, self.H, self.W) - xyz1_raw.reshape(B, N, 1, 3)
         else:
             xyz_diff = P.gather_torch(xyz2, *gidx[:3], B, self.H, self.W) - xyz1.reshape(B, N, 1, 3)
-        upfeats = torch.cat([P.gather_torch(feat2, *gidx[:3], B, self.H, self.W), xyz_diff], dim=3)
-        upfeats = run_stack(upfeats, self.mlp_conv)
-        feat1_new = torch.max(upfeats, dim=2)[0].view(B, self.out_h, self.out_w, -1)
+        upfeats = cat_padded([P.gather_torch(feat2, *gidx[:3], B, self.H, self.W), xyz_diff])
+        feat1_new = run_stack(upfeats, self.mlp_conv, pool_k=upfeats.shape[2]).view(B, self.out_h, self.out_w, -1)
         if feat1 is not None:
             feat1_new = torch.cat([feat1_new, feat1.reshape(B, self.out_h, self.out_w, -1)], dim=3)
         feat1_new = run_stack(feat1_new, self.mlp2_conv)

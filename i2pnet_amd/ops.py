@@ -278,6 +278,23 @@ class CBackend:
                    self._p(out, _F32, "out"), self._p(mean_invstd, _F32, "mean_invstd"), stream=st)
         return out, mean_invstd
 
+    def bn_act_maxk_forward(self, y, coef, slope, K):
+        """y [groups*K, c] pre-BN -> (out [groups,c] = max_k act(bn(y)), arg u8 [groups,c])"""
+        rows, c = y.shape
+        groups = rows // K
+        out = torch.empty(groups, c, dtype=_F32, device=y.device)
+        arg = torch.empty(groups, c, dtype=torch.uint8, device=y.device)
+        self._call("i2p_bn_act_maxk_fwd", int(groups), int(K), int(c), self._p(y, _F32, "y"), self._p(coef, _F32, "coef"),
+                   float(slope), self._p(out, _F32, "out"), self._p(arg, torch.uint8, "arg"), stream=self._stream())
+        return out, arg
+
+    def unpool_k(self, g, arg, K):
+        groups, c = g.shape
+        gd = torch.empty(groups * K, c, dtype=_F32, device=g.device)
+        self._call("i2p_unpool_k", int(groups), int(K), int(c), self._p(g, _F32, "g"), self._p(arg, torch.uint8, "arg"),
+                   self._p(gd, _F32, "gd"), stream=self._stream())
+        return gd
+
     def bn_act_backward_stats(self, dout, y, mean_invstd, gamma, beta, slope):
         """replicated {sum gz, sum gz*xhat} with gz = dout * act'(bn(y)) — the statistics half of bn_act_backward"""
         rows, c = y.shape

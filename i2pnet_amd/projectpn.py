@@ -214,9 +214,15 @@ def knn_point(nsample, xyz, new_xyz):
 
 
 def index_points_group(points, knn_idx):
-    """points [B,N,C], knn_idx [B,S,K] -> [B,S,K,C] (utils.py:382-393, via group_points)."""
-    points_flipped = points.permute(0, 2, 1).contiguous()
-    return grouping_operation(points_flipped, knn_idx.int().contiguous()).permute(0, 2, 3, 1)
+    """points [B,N,C], knn_idx [B,S,K] -> [B,S,K,C] (utils.py:382-393).  The reference transposes to [B,C,N] for
+    `group_points` and back; here the channel-last row gather (and its run-merging scatter-add backward, which
+    adds C contiguous floats per row instead of one strided float per (channel, sample)) does it in place."""
+    B, N, C = points.shape
+    S, K = knn_idx.shape[1], knn_idx.shape[2]
+    w = knn_idx.reshape(B, S * K).long().contiguous()
+    h = _cached(("zero_rows", B, S * K, str(points.device)), lambda: torch.zeros(B, S * K, dtype=torch.long, device=points.device))
+    pts = points if points.dtype == torch.float32 else points.float()
+    return _GatherRows.apply(pts.contiguous(), h, w, N).view(B, S, K, C)
 
 
 def grouping(feature, K, src_xyz, q_xyz, use_xyz=False):

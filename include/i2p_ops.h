@@ -320,6 +320,15 @@ int i2p_cv_softmax_wsum_bwd(int B, int N, int M, int C, const float *g_out, cons
                             float slope5, const float *y3, const float *coef3, float slope3, float *gz5,
                             double *dsums5, float *ga3, void *stream);
 
+/* Set-abstraction tail (PPBackbone_center.py:28-46 + :129 `torch.max(new_points, dim=2)`): BN + activation of the
+ * last pre-BN tensor y f32 [groups*K, c] and the max over the K neighbours of each group in one pass:
+ *   out f32 [groups, c], arg u8 [groups, c] (first k attaining the maximum); coef f32 [3][c] from i2p_bn_finalize.
+ * i2p_unpool_k is its gradient routing: gd f32 [groups*K, c] = g[grp,:] at row grp*K+arg, 0 elsewhere (one write).
+ * c % 4 == 0, (c/4) | 256, K <= 255. */
+int i2p_bn_act_maxk_fwd(long long groups, int K, int c, const float *y, const float *coef, float slope,
+                        float *out, unsigned char *arg, void *stream);
+int i2p_unpool_k(long long groups, int K, int c, const float *g, const unsigned char *arg, float *gd, void *stream);
+
 /* Gradient of the factors of the all-pixel position encoding ye[b,n,k,:] = enc_n[b,n,:] + enc_k[b,k,:]
  * (PPBackbone_center.py:416-418: pi_encoding applied to cat(xyz_n, uv_k), a 1x1 conv => an outer sum):
  *   gz f32 [B*N*M, C] = dL/dz_e (z_e = BN(ye)), dsums replicated {sum gz, sum gz*xhat}, coef [3][C], mi [2][C];

@@ -298,6 +298,25 @@ def test_lin_bwd_last_layer_slope_out(oracle_backend, hip_backend, rows, cin, co
     assert torch.allclose(s0, sh, rtol=1e-4, atol=1e-3 * rows ** 0.5)
 
 
+@pytest.mark.parametrize("groups,K,c", [(28800, 32, 32), (7232, 16, 64), (1824, 16, 128), (100, 8, 16), (5, 255, 64)])
+def test_bn_act_maxk_parity(oracle_backend, hip_backend, groups, K, c):
+    g = torch.Generator().manual_seed(groups + K)
+    y = torch.randn(groups * K, c, generator=g) * 2 + 0.3
+    y.view(groups, K, c)[:, K // 2:] = y.view(groups, K, c)[:, :1]                 # duplicated neighbours: ties
+    coef = torch.stack([0.3 * torch.randn(c, generator=g), torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)]).contiguous()
+    for slope in (0.0, 0.1):
+        ro, ra = oracle_backend.bn_act_maxk_forward(y, coef, slope, K)
+        ho, ha = hip_backend.bn_act_maxk_forward(y.to(DEV), coef.to(DEV), slope, K)
+        assert torch.equal(ro, ho.cpu()) and torch.equal(ra, ha.cpu())
+        z = (y - coef[0]) * coef[1] + coef[2]
+        want = torch.where(z > 0, z, z * slope).view(groups, K, c).max(1)[0]
+        assert torch.allclose(ro, want, rtol=1e-6, atol=1e-6)
+    gg = torch.randn(groups, c, generator=g)
+    rd = oracle_backend.unpool_k(gg, ra, K); hd = hip_backend.unpool_k(gg.to(DEV), ra.to(DEV), K)
+    assert torch.equal(rd, hd.cpu())
+    assert torch.equal(rd.view(groups, K, c).sum(1), gg)
+
+
 def test_project_seq_parity(oracle_backend, hip_backend):
     """Cells are bit-exact for points away from a bin edge (device OCML vs host libm differ in
     the last ulp of atan2/asin); images are compared on cells whose winner agrees."""

@@ -324,3 +324,40 @@ def test_img_bn_pool_oracle_vs_torch(oracle_backend, stride, C, H, W):
         assert torch.allclose(bn_a.bias.grad, bn_b.bias.grad, rtol=1e-3, atol=1e-4 * float(bn_b.bias.grad.abs().max()))
     finally:
         ops.set_backend(prev)
+
+
+def test_maxk_tail_oracle_vs_torch(oracle_backend):
+    """fused set-abstraction tail through mlp_stack(pool_k) == unfused stack + torch.max (values and gradients),
+    incl. an input whose channel count is padded by cat_padded and duplicated neighbour rows (exact ties)."""
+    from i2pnet_amd import modules, ops
+    torch.manual_seed(0)
+    prev = ops.set_backend(oracle_backend)
+    try:
+        B, N, K = 2, 13, 8
+        convs = torch.nn.ModuleList([modules.Conv2d(7, 16, bn=True, leaky_relu=False), modules.Conv2d(16, 32, bn=True, leaky_relu=False)])
+        for c in convs:
+            torch.nn.init.normal_(c.bn_linear.weight, 1.0, 0.3); torch.nn.init.normal_(c.bn_linear.bias, 0.0, 0.3)
+        a = torch.randn(B, N, K, 3); b = torch.randn(B, N, K, 4)
+        a[:, :, 5:] = a[:, :, :1]; b[:, :, 5:] = b[:, :, :1]            # FLAG_COPY-style duplicated neighbours
+        a1, b1 = a.clone().requires_grad_(), b.clone().requires_grad_()
+        a2, b2 = a.clone().requires_grad_(), b.clone().requires_grad_()
+        out1 = modules.run_stack(modules.cat_padded([a1, b1]), convs, pool_k=K)
+        modules.USE_FUSED_MLP = False
+        try:
+            out2 = modules.run_stack(torch.cat([a2, b2], -1), convs, pool_k=K)
+        finally:
+            modules.USE_FUSED_MLP = True
+        assert out1.shape == (B, N, 32)
+        assert torch.allclose(out1, out2, rtol=1e-4, atol=1e-5)
+        w = torch.randn(B, N, 32)
+        g1 = torch.autograd.grad((out1 * w).sum(), [a1, b1] + [p for p in convs.parameters() if p.requires_grad])
+        g2 = torch.autograd.grad((out2 * w).sum(), [a2, b2] + [p for p in convs.parameters() if p.requires_grad])
+        # duplicated rows may receive the gradient at either copy: compare sums over the duplicates
+        for x, y in zip(g1[:2], g2[:2]):
+            xs = torch.cat([x[:, :, :1] + x[:, :, 5:].sum(2, keepdim=True), x[:, :, 1:5]], 2)
+            ys = torch.cat([y[:, :, :1] + y[:, :, 5:].sum(2, keepdim=True), y[:, :, 1:5]], 2)
+            assert torch.allclose(xs, ys, rtol=1e-3, atol=1e-4 * float(ys.abs().max()))
+        for x, y in zip(g1[2:], g2[2:]):
+            assert torch.allclose(x, y, rtol=1e-3, atol=1e-4 * float(y.abs().max()) + 1e-6)
+    finally:
+        ops.set_backend(prev)
