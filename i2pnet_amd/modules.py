@@ -46,11 +46,15 @@ def run_stack(x, convs, first_bn=None, pool_k=0):
     return torch.max(x, dim=-2)[0] if pool_k else x
 
 
-def cat_padded(parts, dim=-1):
+def cat_padded(parts, dim=-1, pow2=False):
     """torch.cat(parts, -1) with zero channels appended up to a multiple of 4 (what the fused layer kernels
-    consume): the padding rides along in the one cat kernel instead of a separate fill + copy of the tensor."""
+    consume): the padding rides along in the one cat kernel instead of a separate fill + copy of the tensor.
+    `pow2`: pad to 16/32/64/128 instead (inputs that need a gradient: the second-generation dgrad kernel wants a
+    power-of-two output width; these tensors are small, the first-generation fallback costs more than the zeros)."""
     c = sum(t.shape[-1] for t in parts)
     pad = (-c) % 4
+    if pow2 and c <= 128:
+        pad = next(w for w in (16, 32, 64, 128) if w >= c) - c
     if pad and USE_FUSED_MLP:
         parts = list(parts) + [parts[0].new_zeros(()).expand(*parts[0].shape[:-1], pad)]
     return torch.cat(parts, dim)
@@ -316,7 +320,7 @@ class ProjectPointNet(nn.Module):
         raw_c, c, grouped_xyz, norm, gidx, sample_idx = self._centres_and_groups(xyz_proj_raw, xyz_proj, sample_idx,
                                                                                raw_feat_point)
         grouped_points = P.gather_torch(feature_proj, *gidx[:3], B, self.H, self.W)
-        new_points = self._mlp_max(cat_padded([norm, grouped_points]), B)         # PPBackbone_center.py:121-129
+        new_points = self._mlp_max(cat_padded([norm, grouped_points], pow2=True), B)     # PPBackbone_center.py:121-129
         return raw_c, c, new_points, grouped_xyz, sample_idx
 
     def forward_center(self, xyz_proj_raw, xyz_proj, feature_proj, sample_idx=None, cfg=None, using_intens=False,
@@ -376,7 +380,7 @@ class ProjSetUpconvModule(nn.Module):
             xyz_diff = P.gather_torch(xyz2_raw, *gidx[:3], B, self.H, self.W) - xyz1_raw.reshape(B, N, 1, 3)
         else:
             xyz_diff = P.gather_torch(xyz2, *gidx[:3], B, self.H, self.W) - xyz1.reshape(B, N, 1, 3)
-        upfeats = cat_padded([P.gather_torch(feat2, *gidx[:3], B, self.H, self.W), xyz_diff])
+        upfeats = cat_padded([P.gather_torch(feat2, *gidx[:3], B, self.H, self.W), xyz_diff], pow2=True)
         feat1_new = run_stack(upfeats, self.mlp_conv, pool_k=upfeats.shape[2]).view(B, self.out_h, self.out_w, -1)
         if feat1 is not None:
             feat1_new = torch.cat([feat1_new, feat1.reshape(B, self.out_h, self.out_w, -1)], dim=3)
@@ -408,6 +412,42 @@ def _unit_variance(x):
     if 2 <= x.shape[-1] <= 256:
         return _UnitVariance.apply(x)
     return (x - torch.mean(x, -1, keepdim=True)) / torch.clip(torch.std(x, -1, keepdim=True), min=1e-12)
+
+
+class _MaxResponse(torch.autograd.Function):
+    """respond[b,k,c] = max over valid points n of pts[b,n,c] * pix[b,k,c]  (-1e10 if the sample has no valid
+    point) — the backward-validation feature of the first cost volume (PPBackbone_center.py:408-414) in closed
+    form: for a fixed pixel value g, max_n fl(f_n*g) = fl(g * max_n f_n) if g >= 0 else fl(g * min_n f_n)
+    (rounding is monotone).  One autograd node: the gradient reaches the arg-max / arg-min point like
+    torch.max's does, in ~10 launches instead of ~40."""
+
+    @staticmethod
+    def forward(ctx, pts, pix, valid):
+        vm = valid > 0                                                        # [B,N,1]
+        f_max, i_max = torch.where(vm, pts, torch.full_like(pts, -float("inf"))).max(1)      # [B,C]
+        f_min, i_min = torch.where(vm, pts, torch.full_like(pts, float("inf"))).min(1)
+        any_valid = vm.any(1)                                                 # [B,1]
+        f_max = torch.where(any_valid, f_max, torch.zeros_like(f_max))
+        f_min = torch.where(any_valid, f_min, torch.zeros_like(f_min))
+        pos = pix >= 0
+        sel = torch.where(pos, f_max.unsqueeze(1), f_min.unsqueeze(1))        # [B,M,C]
+        respond = torch.where(any_valid.unsqueeze(1), pix * sel, torch.full_like(pix, -1e10))
+        ctx.save_for_backward(pix, sel, pos, i_max, i_min, any_valid)
+        ctx.n_points = pts.shape[1]
+        return respond
+
+    @staticmethod
+    def backward(ctx, g):
+        pix, sel, pos, i_max, i_min, any_valid = ctx.saved_tensors
+        g = torch.where(any_valid.unsqueeze(1), g, torch.zeros_like(g))
+        d_pix = g * sel
+        t = g * pix
+        d_fmax = torch.where(pos, t, torch.zeros_like(t)).sum(1)              # [B,C]
+        d_fmin = t.sum(1) - d_fmax
+        d_pts = g.new_zeros(g.shape[0], ctx.n_points, g.shape[2])
+        d_pts.scatter_add_(1, i_max.unsqueeze(1), d_fmax.unsqueeze(1))
+        d_pts.scatter_add_(1, i_min.unsqueeze(1), d_fmin.unsqueeze(1))
+        return d_pts, d_pix, None
 
 
 class CostVolume(nn.Module):
@@ -459,14 +499,7 @@ class CostVolume(nn.Module):
             # channel g, max_n fl(f_n * g) = fl(g * max_n f_n) if g >= 0 else fl(g * min_n f_n)
             # (rounding is monotone), taken over valid points; -1e10 if no point is valid.  Avoids
             # three passes over the [B,N,M,C] tensor; the gradient still reaches the arg-max/min point.
-            valid = P.check_valid(xyz)                                          # [B,N,1]
-            f_max = torch.max(torch.where(valid > 0, pts_n, torch.full_like(pts_n, -float("inf"))), 1, keepdim=True)[0]
-            f_min = torch.min(torch.where(valid > 0, pts_n, torch.full_like(pts_n, float("inf"))), 1, keepdim=True)[0]
-            any_valid = (valid.sum(1, keepdim=True) > 0)
-            f_max = torch.where(any_valid, f_max, torch.zeros_like(f_max))      # no inf*0 in the backward
-            f_min = torch.where(any_valid, f_min, torch.zeros_like(f_min))
-            respond = torch.where(pix_n >= 0, pix_n * f_max, pix_n * f_min)     # [B,M,C]
-            respond = torch.where(any_valid, respond, torch.full_like(respond, -1e10))
+            respond = _MaxResponse.apply(pts_n, pix_n, P.check_valid(xyz))      # [B,M,C]
             per_pixel = per_pixel + F.linear(respond, w_parts[3])
         B_, N_ = pts_n.shape[0], pts_n.shape[1]
         we_parts = torch.split(self.pi_encoding.weight2d(), [3, 3], dim=1)

@@ -93,9 +93,15 @@ class Trainer:
         self.flat_param = torch.empty(n, dtype=torch.float32, device=self.device)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.device)
         off = 0
+        self._nhwc = []                         # 4-D parameters kept in channels_last storage (image-encoder conv weights)
         with torch.no_grad():
             for p in self.params:
-                view = self.flat_param[off:off + p.numel()].view_as(p)
+                seg = self.flat_param[off:off + p.numel()]
+                nhwc = p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last)
+                self._nhwc.append(nhwc)
+                # the view keeps the parameter's memory format (MIOpen's NHWC kernels would otherwise re-layout the
+                # weights on every call); flat order = storage order, so gradients are packed in the same order
+                view = seg.view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2) if nhwc else seg.view_as(p)
                 view.copy_(p.data)
                 p.data = view
                 off += p.numel()
@@ -120,12 +126,12 @@ class Trainer:
         loss.backward()
         zero = None
         grads = []
-        for p in self.params:
+        for p, nhwc in zip(self.params, self._nhwc):
             if p.grad is None:                  # parameter not reached by this loss
                 zero = torch.zeros((), device=self.device) if zero is None else zero
                 grads.append(zero.expand(p.numel()))
             else:
-                grads.append(p.grad.reshape(-1))
+                grads.append((p.grad.permute(0, 2, 3, 1) if nhwc else p.grad).reshape(-1))
         torch.cat(grads, out=self.flat_grad)
         return loss.detach(), real_loss.detach(), dual_loss.detach()
 
@@ -133,8 +139,9 @@ class Trainer:
         """the gradients the optimiser consumed last step (all-reduced, averaged, clipped), by parameter name"""
         names = [k for k, p in self.net.named_parameters() if p.requires_grad]
         out, off = {}, 0
-        for k, p in zip(names, self.params):
-            out[k] = self.flat_grad[off:off + p.numel()].view_as(p).clone()
+        for k, p, nhwc in zip(names, self.params, self._nhwc):
+            seg = self.flat_grad[off:off + p.numel()]
+            out[k] = (seg.view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2) if nhwc else seg.view_as(p)).clone()
             off += p.numel()
         return out
 

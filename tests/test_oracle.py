@@ -361,3 +361,26 @@ def test_maxk_tail_oracle_vs_torch(oracle_backend):
             assert torch.allclose(x, y, rtol=1e-3, atol=1e-4 * float(y.abs().max()) + 1e-6)
     finally:
         ops.set_backend(prev)
+
+
+def test_max_response_matches_literal_formulation():
+    """closed-form backward-validation feature == the reference's literal max over the masked [B,N,M,C] product
+    (PPBackbone_center.py:408-414), values and gradients, incl. a sample without any valid point."""
+    from i2pnet_amd.modules import _MaxResponse
+    g = torch.Generator().manual_seed(11)
+    B, N, M, C = 3, 17, 9, 8
+    pts = torch.randn(B, N, C, generator=g); pix = torch.randn(B, M, C, generator=g)
+    valid = (torch.rand(B, N, 1, generator=g) > 0.3).float()
+    valid[2] = 0.0
+    p1, x1 = pts.clone().requires_grad_(), pix.clone().requires_grad_()
+    p2, x2 = pts.clone().requires_grad_(), pix.clone().requires_grad_()
+    r1 = _MaxResponse.apply(p1, x1, valid)
+    corr = p2.unsqueeze(2) * x2.unsqueeze(1)                                        # [B,N,M,C]
+    masked = corr * valid.unsqueeze(2) + -1e10 * (1 - valid.unsqueeze(2))
+    r2 = masked.max(1)[0]
+    assert torch.allclose(r1, r2, rtol=1e-6, atol=1e-6)
+    w = torch.randn(B, M, C, generator=g)
+    (r1 * w).sum().backward(); (r2 * w).sum().backward()
+    assert torch.allclose(x1.grad[:2], x2.grad[:2], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(p1.grad[:2], p2.grad[:2], rtol=1e-5, atol=1e-6)
+    assert float(p1.grad[2].abs().max()) == 0.0 and float(x1.grad[2].abs().max()) == 0.0
