@@ -5,7 +5,10 @@ from pathlib import Path
 
 from . import _abi
 
-_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libi2p_ops.so"
+import os
+
+# I2P_OPS_LIB: load another build of the same ABI (A/B comparisons and bisection only)
+_LIB_PATH = Path(os.environ.get("I2P_OPS_LIB") or (Path(__file__).resolve().parent / "lib" / "libi2p_ops.so"))
 _lib = None
 _fns = {}
 
@@ -31,6 +34,8 @@ def load():
         _lib = C.CDLL(str(_LIB_PATH))
         _lib.i2p_abi_version.restype = C.c_int
         for name in _abi.SIGNATURES:
+            if os.environ.get("I2P_OPS_LIB") and not hasattr(_lib, name):
+                continue                      # older build under comparison: entries it lacks stay unbound
             _fns[name] = _abi.bind(_lib, name, name, with_stream=True)
     return _lib
 

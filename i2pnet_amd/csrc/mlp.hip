@@ -1283,7 +1283,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
     const int co4 = p.cout >> 2, ci4 = p.cin >> 2;
 
     for (int i = tid; i < 6 * p.cout; i += WG_THREADS) Cg[i] = p.g_coef ? p.g_coef[i] : 0.f;
-    for (int i = tid; i < 3 * p.cin; i += WG_THREADS) Cx[i] = p.in_coef ? p.in_coef[i] : 0.f;
+    // (two-source input: in_coef describes only the first split_c channels; that mode takes its constants from
+    //  registers, the table is not used — do not read past the end of the shorter coefficient array)
+    for (int i = tid; i < 3 * p.cin; i += WG_THREADS) Cx[i] = (p.in_coef && !p.xb) ? p.in_coef[i] : 0.f;
     // zero the padding columns of both buffers once
     for (int b = 0; b < 2; ++b) {
         float *Gs = smem + (size_t)b * bufsz, *Xs = Gs + WG_R * p.ldg;

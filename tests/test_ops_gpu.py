@@ -574,6 +574,28 @@ def test_pair_bias_bn_bwd_parity(oracle_backend, hip_backend, B, N, M, C):
     assert float((rk.double() - ekd.grad).abs().max()) <= 1e-3 * float(ekd.grad.abs().max())
 
 
+def test_two_source_backward_repeated(hip_backend):
+    """regression: the two-source wgrad kernel used to read 3*cin coefficients from the 3*split_c-long array of
+    the first source (a memory fault whenever that small tensor ended a mapped segment).  Fresh allocations in
+    a loop make the layout vary."""
+    be = hip_backend
+    B, N, M, Ca, Cb, Co = 2, 23, 70, 64, 64, 128
+    rows = B * N * M
+    for it in range(12):
+        xa = torch.randn(rows, Ca, device=DEV); xb = torch.randn(rows, Cb, device=DEV)
+        w = torch.randn(Co, Ca + Cb, device=DEV) / 11
+        one = lambda c: (torch.ones(c, device=DEV), torch.zeros(c, device=DEV))
+        ca, ma = be.bn_finalize(rows, be.bn_stats(xa), *one(Ca), 1e-5)
+        cb, mb = be.bn_finalize(rows, be.bn_stats(xb), *one(Cb), 1e-5)
+        y, st = be.lin_forward_2src(xa, ca, 0.1, xb, cb, 0.1, w)
+        co, mo = be.bn_finalize(rows, st, *one(Co), 1e-5)
+        gz = torch.randn(rows, Co, device=DEV)
+        ods = torch.zeros(32 * 2 * Co, dtype=torch.float64, device=DEV)
+        out = be.lin_backward_2src(gz, y, co, mo, ods, xa, ca, ma, 0.1, xb, cb, mb, 0.1, torch.randn(rows, Cb, device=DEV), w)
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(t).all() for t in out)
+
+
 def test_cv_tail_ops_parity(oracle_backend, hip_backend):
     """two-source fused layer (fwd/bwd) and softmax-weighted sum (fwd/bwd): HIP vs oracle."""
     B, N, M, Ca, Cb, Co = 2, 23, 70, 64, 64, 128
