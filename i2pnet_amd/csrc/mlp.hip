@@ -324,6 +324,26 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
         if (co < p.cout) wv = (DGRAD && p.w_transposed) ? p.w[(size_t)ci * p.cout_total + p.ch_off + co] : p.w[(size_t)co * p.cin + ci];
         Ws[co * ldk + ci] = wv;
     }
+    // dgrad: per-channel constants live in an LDS table behind the strips (30 float4 registers per lane otherwise:
+    // the dgrad instantiation spilled).  Gt [6][cin] = BN-backward constants of the layer behind (identity if none),
+    // Et [4][cout_total] = mean, scale, beta, invstd of the BN in front (per destination in two-destination mode).
+    float *Gt = smem + ((size_t)p.cout_p + 8 * F2_ROWS) * ldk;
+    float *Et = Gt + 6 * p.cin;
+    if (DGRAD) {
+        for (int i = tid; i < 6 * p.cin; i += F2_THREADS) {
+            const int row = i / p.cin;
+            Gt[i] = p.g_coef ? p.g_coef[i] : ((row == 2 || row == 4) ? 1.f : 0.f);
+        }
+        for (int i = tid; i < 4 * p.cout_total; i += F2_THREADS) {
+            const int row = i / p.cout_total, ch = i - row * p.cout_total;
+            const bool b = p.yb && ch >= p.split_c;
+            const float *cf = b ? p.e_coef_b : p.e_coef, *mi = b ? p.e_mi_b : p.e_mi;
+            const int ld = p.yb ? (b ? p.cout_total - p.split_c : p.split_c) : p.cout_total, c = b ? ch - p.split_c : ch;
+            float v = (row == 1 || row == 3) ? 1.f : 0.f;
+            if (cf) v = row < 3 ? cf[row * ld + c] : mi[ld + c];
+            Et[i] = v;
+        }
+    }
     __syncthreads();                                        // the only block barrier
 
     // ---- per-lane chunk geometry, fixed for the whole kernel -----------------------------------------
@@ -358,16 +378,8 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
     }
 
     // dgrad: BN-backward constants of this lane's input channels, and of its output channels for the store phase
-    float4 g_m1 = cm, g_m2 = cm, g_sc = cs, g_mu = cm, g_is = cs, g_be = cm;
     const bool g_act = DGRAD && p.g_coef && p.g_slope != 1.f;
-    if (DGRAD && p.g_coef) {
-        g_be = *reinterpret_cast<const float4 *>(p.g_coef + 5 * p.cin + in_c4[0] * 4);
-        g_m1 = *reinterpret_cast<const float4 *>(p.g_coef + in_c4[0] * 4);
-        g_m2 = *reinterpret_cast<const float4 *>(p.g_coef + p.cin + in_c4[0] * 4);
-        g_sc = *reinterpret_cast<const float4 *>(p.g_coef + 2 * p.cin + in_c4[0] * 4);
-        g_mu = *reinterpret_cast<const float4 *>(p.g_coef + 3 * p.cin + in_c4[0] * 4);
-        g_is = *reinterpret_cast<const float4 *>(p.g_coef + 4 * p.cin + in_c4[0] * 4);
-    }
+    const float *g_tab = Gt + in_c4[0] * 4;                 // this lane's input channels (same in every chunk slot)
     // output destination of this lane's 4 channels (DGRAD two-destination mode splits the columns)
     const bool out_b = DGRAD && p.yb && (p.ch_off + o_c4 * 4) >= p.split_c;
     float *dst_y = out_b ? p.yb : p.y;
@@ -380,13 +392,8 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
     const float *e_ad = out_b ? p.e_add : nullptr;
     double *dst_sums = out_b ? p.sums_b : p.sums;
     const int sums_c = (DGRAD && p.yb) ? dst_ld : p.cout_total;
-    float4 e_mu = make_float4(0.f, 0.f, 0.f, 0.f), e_sc = make_float4(1.f, 1.f, 1.f, 1.f), e_be = e_mu, e_is = e_sc;
-    if (DGRAD && e_cf) {
-        e_mu = *reinterpret_cast<const float4 *>(e_cf + dst_c0);
-        e_sc = *reinterpret_cast<const float4 *>(e_cf + dst_ld + dst_c0);
-        e_be = *reinterpret_cast<const float4 *>(e_cf + 2 * dst_ld + dst_c0);
-        e_is = *reinterpret_cast<const float4 *>(e_m + dst_ld + dst_c0);
-    }
+    const float *e_tab = Et + p.ch_off + o_c4 * 4;          // this lane's output channels
+    (void)e_m;
 
     double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
 
@@ -432,6 +439,9 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
                 t.x *= f.x; t.y *= f.y; t.z *= f.z; t.w *= f.w;
             }
             if (DGRAD && p.g_coef) {                        // BN backward of the layer behind, formed on load
+                const float4 g_m1 = *reinterpret_cast<const float4 *>(g_tab), g_m2 = *reinterpret_cast<const float4 *>(g_tab + p.cin);
+                const float4 g_sc = *reinterpret_cast<const float4 *>(g_tab + 2 * p.cin), g_mu = *reinterpret_cast<const float4 *>(g_tab + 3 * p.cin);
+                const float4 g_is = *reinterpret_cast<const float4 *>(g_tab + 4 * p.cin), g_be = *reinterpret_cast<const float4 *>(g_tab + 5 * p.cin);
                 const float4 yv = v2[u];
                 if (g_act) {                                // dL/da -> dL/dz of the layer behind
                     t.x = (yv.x - g_mu.x) * g_sc.x + g_be.x > 0.f ? t.x : t.x * p.g_slope;
@@ -584,6 +594,8 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
                         v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
                     }
                     if (e_cf) {
+                        const float4 e_mu = *reinterpret_cast<const float4 *>(e_tab), e_sc = *reinterpret_cast<const float4 *>(e_tab + p.cout_total);
+                        const float4 e_be = *reinterpret_cast<const float4 *>(e_tab + 2 * p.cout_total), e_is = *reinterpret_cast<const float4 *>(e_tab + 3 * p.cout_total);
                         long long er = row0 + r; if (er > last_row) er = last_row;
                         const float4 xr = *reinterpret_cast<const float4 *>(e_x + (size_t)er * dst_ld + dst_c0);
                         const float zx = (xr.x - e_mu.x) * e_sc.x + e_be.x, zy = (xr.y - e_mu.y) * e_sc.y + e_be.y;
@@ -633,7 +645,7 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
 
 template <int NT16, bool PAIR, bool DGRAD>
 int launch_fwd2(const LinFwdParams &p, hipStream_t st) {
-    const size_t bytes = ((size_t)p.cout_p + 8 * F2_ROWS) * p.ldk * sizeof(float);
+    const size_t bytes = (((size_t)p.cout_p + 8 * F2_ROWS) * p.ldk + (DGRAD ? 6 * (size_t)p.cin + 4 * (size_t)p.cout_total : 0)) * sizeof(float);
     if (bytes > 160 * 1024) return I2P_ERR_BAD_ARG;
     static bool attr_set = false;
     if (!attr_set) {

@@ -9,4 +9,4 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$tag -- python bench.p
 tail -1 /tmp/prof_$tag.log | cut -c1-200
 trace=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
 mkdir -p gpurun_out
-python tools/steady_stats.py "$trace" --warmup 5 --steps 4 --top 70 --out gpurun_out/${tag}_steady_kernel_stats.csv
+python tools/steady_stats.py "$trace" --warmup 5 --steps 4 --top 70 --out gpurun_out/${tag}_steady_kernel_stats.csv --train-steps 10 --tail-out gpurun_out/${tag}_roofline_section_kernel_stats.csv

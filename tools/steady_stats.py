@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--steps", type=int, required=True)
     ap.add_argument("--out", default=None)
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--train-steps", type=int, default=0, help="total training steps in the trace (capture warm-up + warmup + steps); "
+                    "with --tail-out: kernels launched after them = bench.py's live roofline section")
+    ap.add_argument("--tail-out", default=None)
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -46,11 +49,32 @@ def main():
           f"launches_per_step={len(sel) / a.steps:.0f} distinct_kernels={len(agg)}")
     for ln in lines[: a.top + 1]:
         print(" | ".join(ln))
+    if a.tail_out and a.train_steps >= 2:
+        tail_stats(rows, marks, a.train_steps, a.tail_out)
     if a.out:
         with open(a.out, "w", newline="") as f:
             f.write(f"# steps={a.steps} wall_per_step_ms={wall / a.steps / 1e6:.3f} kernel_time_per_step_ms={tot / a.steps / 1e6:.3f} "
                     f"launches_per_step={len(sel) / a.steps:.0f}\n")
             csv.writer(f).writerows(lines)
+
+
+def tail_stats(rows, marks, n_train, out):
+    """per-kernel statistics of everything launched after the last training step (bench.py's roofline section)"""
+    step = marks[n_train - 1] - marks[n_train - 2]
+    t_end = marks[n_train - 1] + step
+    agg = defaultdict(lambda: [0, 0, 10 ** 18, 0])
+    for r in rows:
+        if int(r["Start_Timestamp"]) < t_end:
+            continue
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        e = agg[short(r["Kernel_Name"])]
+        e[0] += 1; e[1] += d; e[2] = min(e[2], d); e[3] = max(e[3], d)
+    with open(out, "w", newline="") as f:
+        f.write("# kernels launched by bench.py after the timed steps (live roofline timings); rocprofv3 --kernel-trace\n")
+        w = csv.writer(f)
+        w.writerow(("kernel", "calls", "avg_us", "min_us", "max_us"))
+        for k, (c, d, lo, hi) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+            w.writerow((k, c, f"{d / c / 1e3:.2f}", f"{lo / 1e3:.2f}", f"{hi / 1e3:.2f}"))
 
 
 if __name__ == "__main__":
