@@ -48,6 +48,7 @@ struct LinFwdParams {
     // pair mode (cost volume, all point x pixel pairs): rows = (b, n, k) over B x N x M,
     //   input row = pair_f[b,n,:] * x[b,k,:]   (x is then the [B,M,cin] pixel tensor)
     //   y[r,:]   += bias_n[b,n,:] + bias_k[b,k,:]
+    int w_vec;              // w is 16-byte aligned (set by the launcher): float4 weight staging
     int ablate;             // diagnostic only (I2P_LIN_ABLATE): 1 no MFMA loop, 2 no stores, 4 no stats, 8 no staging
     const float *pair_f;    // [B,N,cin] or nullptr (plain mode)
     const float *bias_n;    // [B,N,cout_total] or nullptr
@@ -318,11 +319,33 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *As = smem + (size_t)p.cout_p * ldk + (size_t)wave * F2_ROWS * ldk;   // this wave's strip
 
-    for (int i = tid; i < p.cout_p * p.cin; i += F2_THREADS) {
-        const int co = i / p.cin, ci = i - co * p.cin;
-        float wv = 0.f;
-        if (co < p.cout) wv = (DGRAD && p.w_transposed) ? p.w[(size_t)ci * p.cout_total + p.ch_off + co] : p.w[(size_t)co * p.cin + ci];
-        Ws[co * ldk + ci] = wv;
+    // weights -> LDS with 16-byte loads (cin, cout and ch_off are multiples of 4): 8 independent loads per thread for a
+    // 128x128 layer instead of 32 dependent scalar iterations — this prologue is most of a launch on the small layers
+    if (!p.w_vec) {                                         // weights not 16-byte aligned (caller's tensor view): scalar loads
+        for (int i = tid; i < p.cout_p * p.cin; i += F2_THREADS) {
+            const int co = i / p.cin, ci = i - co * p.cin;
+            float wv = 0.f;
+            if (co < p.cout) wv = (DGRAD && p.w_transposed) ? p.w[(size_t)ci * p.cout_total + p.ch_off + co] : p.w[(size_t)co * p.cin + ci];
+            Ws[co * ldk + ci] = wv;
+        }
+    } else if (DGRAD && p.w_transposed) {                   // Ws[co][ci] = w[ci][ch_off + co]: contiguous along co
+        const int o4 = p.cout_p >> 2;
+        for (int i = tid; i < p.cin * o4; i += F2_THREADS) {
+            const int ci = i / o4, c4 = i - ci * o4;
+            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c4 * 4 < p.cout) wv = *reinterpret_cast<const float4 *>(p.w + (size_t)ci * p.cout_total + p.ch_off + c4 * 4);
+            Ws[(c4 * 4 + 0) * ldk + ci] = wv.x; Ws[(c4 * 4 + 1) * ldk + ci] = wv.y;
+            Ws[(c4 * 4 + 2) * ldk + ci] = wv.z; Ws[(c4 * 4 + 3) * ldk + ci] = wv.w;
+        }
+    } else {
+        const int c4n_w = p.cin >> 2;
+        for (int i = tid; i < p.cout_p * c4n_w; i += F2_THREADS) {
+            const int co = i / c4n_w, c4 = i - co * c4n_w;
+            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < p.cout) wv = *reinterpret_cast<const float4 *>(p.w + (size_t)co * p.cin + c4 * 4);
+            float2 *dst = reinterpret_cast<float2 *>(Ws + co * ldk + c4 * 4);
+            dst[0] = make_float2(wv.x, wv.y); dst[1] = make_float2(wv.z, wv.w);
+        }
     }
     // dgrad: per-channel constants live in an LDS table behind the strips (30 float4 registers per lane otherwise:
     // the dgrad instantiation spilled).  Gt [6][cin] = BN-backward constants of the layer behind (identity if none),
@@ -656,7 +679,9 @@ int launch_fwd2(const LinFwdParams &p, hipStream_t st) {
     const long long nstrips = (p.rows + F2_ROWS - 1) / F2_ROWS;
     long long g = (nstrips + 7) / 8;
     const unsigned grid = (unsigned)(g < 256 ? (g < 1 ? 1 : g) : 256);
-    hipLaunchKernelGGL((lin_fwd2_kernel<NT16, PAIR, DGRAD>), dim3(grid), dim3(F2_THREADS), bytes, st, p);
+    LinFwdParams q = p;
+    q.w_vec = ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0 && (p.cin & 3) == 0 && (p.cout_total & 3) == 0 && (p.ch_off & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((lin_fwd2_kernel<NT16, PAIR, DGRAD>), dim3(grid), dim3(F2_THREADS), bytes, st, q);
     I2P_RETURN_LAUNCH_STATUS();
 }
 

@@ -89,13 +89,18 @@ class Trainer:
                 dist.broadcast(b.data, src=0)
         # trainable parameters become views into one flat buffer; gradients are packed into another:
         # one all-reduce, one norm, one Adam
-        n = sum(p.numel() for p in self.params)
-        self.flat_param = torch.empty(n, dtype=torch.float32, device=self.device)
+        # every parameter starts on a 16-byte boundary of the flat buffers (the layer kernels stage weights with
+        # 16-byte loads when they can); the padding elements stay zero in all four buffers
+        self._offsets, n = [], 0
+        for p in self.params:
+            self._offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.flat_param = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.device)
-        off = 0
+        self._zero = torch.zeros((), dtype=torch.float32, device=self.device)
         self._nhwc = []                         # 4-D parameters kept in channels_last storage (image-encoder conv weights)
         with torch.no_grad():
-            for p in self.params:
+            for p, off in zip(self.params, self._offsets):
                 seg = self.flat_param[off:off + p.numel()]
                 nhwc = p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last)
                 self._nhwc.append(nhwc)
@@ -104,7 +109,6 @@ class Trainer:
                 view = seg.view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2) if nhwc else seg.view_as(p)
                 view.copy_(p.data)
                 p.data = view
-                off += p.numel()
         self.optimizer = FlatAdam(self.flat_param, self.flat_grad, lr, betas=(0.9, 0.999), eps=1e-08,
                                   weight_decay=0.0001)
         self.lr_gamma = 0.99                    # ExponentialLR(0.99) per epoch: call `epoch_end()`
@@ -124,25 +128,25 @@ class Trainer:
         loss, real_loss, dual_loss = Get_loss(out3, out4, batch["decalib_real_gt"], batch["decalib_dual_gt"], sx, sq,
                                               cfg=self.cfg)
         loss.backward()
-        zero = None
+        zero = self._zero
         grads = []
         for p, nhwc in zip(self.params, self._nhwc):
             if p.grad is None:                  # parameter not reached by this loss
-                zero = torch.zeros((), device=self.device) if zero is None else zero
                 grads.append(zero.expand(p.numel()))
             else:
                 grads.append((p.grad.permute(0, 2, 3, 1) if nhwc else p.grad).reshape(-1))
+            if p.numel() % 4:                   # alignment padding of the flat layout
+                grads.append(zero.expand(4 - p.numel() % 4))
         torch.cat(grads, out=self.flat_grad)
         return loss.detach(), real_loss.detach(), dual_loss.detach()
 
     def named_grads(self):
         """the gradients the optimiser consumed last step (all-reduced, averaged, clipped), by parameter name"""
         names = [k for k, p in self.net.named_parameters() if p.requires_grad]
-        out, off = {}, 0
-        for k, p, nhwc in zip(names, self.params, self._nhwc):
+        out = {}
+        for k, p, nhwc, off in zip(names, self.params, self._nhwc, self._offsets):
             seg = self.flat_grad[off:off + p.numel()]
             out[k] = (seg.view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2) if nhwc else seg.view_as(p)).clone()
-            off += p.numel()
         return out
 
     def epoch_end(self):
