@@ -1305,6 +1305,7 @@ __global__ void bnbwd_coef_kernel(long long rows, int c, const double *__restric
     out[ch] = (float)(sd / (double)rows); out[c + ch] = (float)(sx / (double)rows);
     out[2 * c + ch] = coef[c + ch]; out[3 * c + ch] = mi[ch]; out[4 * c + ch] = mi[c + ch];
     out[5 * c + ch] = coef[2 * c + ch];
+    out[6 * c + ch] = (float)sd; out[7 * c + ch] = (float)sx;      // = dbeta, dgamma of this BN (returned to the caller)
 }
 
 template <int NTI, int NTO, bool FIXC>
@@ -1690,13 +1691,15 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
         const size_t wg_lds = (2 * (size_t)WG_R * (p.cout_p + p.cin_p) + 6 * (size_t)cout + 3 * (size_t)cin) * sizeof(float);
         const bool gen2 = !pair && !(gen && gen[0] == '1') && dgrad_ok && pow2w(cout) && wg_lds <= 160 * 1024 && cin <= 160;
         if (two && !(gen2 && pow2w(cin))) return I2P_ERR_BAD_ARG;
+        // per-channel BN-backward constants behind the partials: [8][cout] = m1, m2, scale, mean, invstd, beta, and
+        // the raw sums {sum gz, sum gz*xhat} = dbeta, dgamma of the BN behind (read back by the caller)
+        float *g_coef = nullptr;
+        if (out_coef && !pair) {
+            g_coef = dw_partial + (size_t)grid * cout * cin;
+            hipLaunchKernelGGL(bnbwd_coef_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, rows, cout, out_dsums, out_coef,
+                               out_mi, g_coef);
+        }
         if (gen2) {
-            float *g_coef = nullptr;
-            if (out_coef) {
-                g_coef = dw_partial + (size_t)grid * cout * cin;                 // 6*cout floats behind the partials
-                hipLaunchKernelGGL(bnbwd_coef_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, rows, cout, out_dsums, out_coef,
-                                   out_mi, g_coef);
-            }
             if (gz_in) {
                 LinFwdParams q;
                 q.rows = rows; q.cin = cout; q.cout = cin; q.cin_p = cout; q.cout_p = cin;

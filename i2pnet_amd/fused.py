@@ -121,8 +121,6 @@ class _MlpChain(Function):
         # last block: only the statistics pass over (dL/da, y_L); the activation derivative and the BN backward are
         # applied by the layer kernels as they load dL/da (slope_out), so dL/dy_L is never written
         out_ds = be.bn_act_backward_stats(g_out, ys[-1], mis[-1], last_g.detach(), last_b.detach(), slopes[-1])
-        s = _rep_sum(out_ds, ys[-1].shape[1])
-        grads[-2], grads[-1] = s[1].float(), s[0].float()
         gz, y_out, out_coef, out_mi, slope_out = g_out, ys[-1], coefs[-1], mis[-1], slopes[-1]
         for i in range(nl, 0, -1):
             W = p[k + 3 * (i - 1)]
@@ -132,13 +130,12 @@ class _MlpChain(Function):
                                                mis[i - 1], slopes[i - 1] if has_in else 1.0, W.detach(),
                                                need_gx=need_gx, slope_out=slope_out)
             grads[k + 3 * (i - 1)] = dw
-            if has_in:
-                s = _rep_sum(in_ds, ys[i - 1].shape[1])
-                if i - 1 >= 1:
-                    grads[k + 3 * (i - 2) + 1], grads[k + 3 * (i - 2) + 2] = s[1].float(), s[0].float()
-                else:
-                    grads[0], grads[1] = s[1].float(), s[0].float()
+            # gamma/beta gradients of the BN behind layer i: reduced from out_ds by the launcher (scratch tail)
+            grads[k + 3 * (i - 1) + 1], grads[k + 3 * (i - 1) + 2] = be.last_bn_grads
             gz, y_out, out_coef, out_mi, out_ds, slope_out = gz_in, ys[i - 1], coefs[i - 1], mis[i - 1], in_ds, 1.0
+        if first_bn:            # leading BN: its sums were accumulated by the last dgrad call
+            s = _rep_sum(out_ds, ys[0].shape[1])
+            grads[0], grads[1] = s[1].float(), s[0].float()
         gx = None
         if ctx.x_needs_grad:
             if first_bn:       # finish the leading BN: dL/dx = scale*(gz - mean(gz) - xhat*mean(gz*xhat))
@@ -233,22 +230,21 @@ class _CvPiTail(Function):
         d = lambda t: t.detach()
         f32 = lambda t: t.float()
         gz5, ds5, ga3 = be_.cv_softmax_wsum_backward(B, N, M, g_out.contiguous(), out, msave, y5, c5, m5, s5, y3, c3, s3)
-        r5 = _rep_sum(ds5, y5.shape[1])
-        gz4, ds4, dW5 = be_.lin_backward(gz5, y5, c5, m5, ds5, y4, c4, m4, s4, d(W5))
-        r4 = _rep_sum(ds4, y4.shape[1])
+        # (gamma/beta gradients of a BN come back reduced from the call that consumes its sums: `last_bn_grads`)
+        gz4, ds4, dW5 = be_.lin_backward(gz5, y5, c5, m5, ds5, y4, c4, m4, s4, d(W5)); dg5, db5 = be_.last_bn_grads
         gze, dse, gz3, ds3, dW4 = be_.lin_backward_2src(gz4, y4, c4, m4, ds4, ye, ce, me, se, y3, c3, m3, s3, ga3, d(W4))
-        re, r3 = _rep_sum(dse, ye.shape[1]), _rep_sum(ds3, y3.shape[1])
-        gz2, ds2, dW3 = be_.lin_backward(gz3, y3, c3, m3, ds3, y2, c2, m2, s2, d(W3))
-        r2 = _rep_sum(ds2, y2.shape[1])
-        gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2))
+        dg4, db4 = be_.last_bn_grads
+        re = _rep_sum(dse, ye.shape[1])
+        gz2, ds2, dW3 = be_.lin_backward(gz3, y3, c3, m3, ds3, y2, c2, m2, s2, d(W3)); dg3, db3 = be_.last_bn_grads
+        gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2)); dg2, db2 = be_.last_bn_grads
         r1 = _rep_sum(ds1, y1.shape[1])
         # first layer: BN backward of bn1 formed on load inside the pair kernel
         d_f, d_g, d_bn, d_bk, dW1 = be_.pair_lin_backward(gz1, f, g, W1, y=y1, out_coef=c1, out_mi=m1, out_dsums=ds1)
         # position encoding: k-/n-sums of dL/dye in closed form from one pass over gz_e
         d_en, d_ek = be_.pair_bias_bn_backward(B, N, M, gze, enc_n, enc_k, dse, ce, me)
         return (d_f, d_g, d_bn, d_bk, dW1, d_en, d_ek, None,
-                f32(r1[1]), f32(r1[0]), dW2, f32(r2[1]), f32(r2[0]), dW3, f32(r3[1]), f32(r3[0]),
-                f32(re[1]), f32(re[0]), dW4, f32(r4[1]), f32(r4[0]), dW5, f32(r5[1]), f32(r5[0]))
+                f32(r1[1]), f32(r1[0]), dW2, dg2, db2, dW3, dg3, db3,
+                f32(re[1]), f32(re[0]), dW4, dg4, db4, dW5, dg5, db5)
 
 
 def cv_pi_tail(f, g, bias_n, bias_k, W1, enc_n, enc_k, first, mlp1_rest, enc, mlp2):

@@ -337,7 +337,9 @@ class CBackend:
     def lin_backward(self, gz, y, out_coef, out_mi, out_dsums, x, in_coef, in_mi, slope_in, w, need_gx=True,
                      slope_out=1.0):
         """-> (gz_in [rows,cin] or None, in_dsums or None, dw [cout,cin]); see i2p_lin_bwd.
-        slope_out != 1: `gz` is dL/da of this layer's activation (applied on load)."""
+        slope_out != 1: `gz` is dL/da of this layer's activation (applied on load).
+        `self.last_bn_grads` = (dgamma, dbeta) [cout] of the BN behind this layer when out_coef is given
+        (reduced from out_dsums by the launcher; views into the scratch tensor), else None."""
         rows, cout = gz.shape
         cin = x.shape[1]
         dev = gz.device
@@ -353,6 +355,8 @@ class CBackend:
                    P(x, _F32, "x"), P(in_coef, _F32, "in_coef"), P(in_mi, _F32, "in_mi"), float(slope_in),
                    P(w, _F32, "w"), P(gz_in, _F32, "gz_in"), P(in_dsums, torch.float64, "in_dsums"),
                    P(part, _F32, "dw_partial"), P(dw, _F32, "dw"), float(slope_out), stream=self._stream())
+        n = part.numel()
+        self.last_bn_grads = (part[n - cout:], part[n - 2 * cout:n - cout]) if out_coef is not None else None
         return gz_in, in_dsums, dw
 
     def pair_lin_forward(self, f, g, bias_n, bias_k, w):
@@ -427,6 +431,8 @@ class CBackend:
                    P(out_dsums, torch.float64), P(xa), P(coef_a), P(mi_a), float(slope_a), P(xb), P(coef_b), P(mi_b),
                    float(slope_b), P(e_add_b), P(w), P(gz_a), P(ds_a, torch.float64), P(gz_b), P(ds_b, torch.float64),
                    P(part), P(dw), stream=self._stream())
+        n = part.numel()
+        self.last_bn_grads = (part[n - cout:], part[n - 2 * cout:n - cout]) if out_coef is not None else None
         return gz_a, ds_a, gz_b, ds_b, dw
 
     def cv_softmax_wsum_forward(self, B, N, M, y5, coef5, slope5, y3, coef3, slope3):

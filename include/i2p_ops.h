@@ -221,7 +221,9 @@ int i2p_bn_finalize(long long rows, int c, const double *sums, const float *gamm
  * gz f32 [rows,cout]; y f32 [rows,cout]; out_coef [3][cout], out_mi [2][cout] (mean, invstd),
  * out_dsums replicated {sum gz, sum gz*xhat_out}; x f32 [rows,cin] the previous pre-BN tensor with
  * in_coef [3][cin], in_mi [2][cin] (or both NULL: x is the raw layer input, gz_in = dL/dx);
- * dw_partial f32 scratch of i2p_lin_bwd_grid(rows)*cout*cin + 8*cout floats.  cin, cout multiples of 4, <= 160 / 128.
+ * dw_partial f32 scratch of i2p_lin_bwd_grid(rows)*cout*cin + 8*cout floats; when out_coef is given its LAST 2*cout
+ * floats hold, on return, {sum gz [cout], sum gz*xhat [cout]} reduced over the replicas = dbeta, dgamma of the BN
+ * behind this layer.  cin, cout multiples of 4, <= 160 / 128.
  * slope_out: 1 when gz is dL/dz (the usual case: the previous call's gz_in).  For the LAST layer of a stack the
  * caller holds dL/da (a = act(z) with this slope, out_coef required): the activation derivative is applied on
  * load, with out_dsums = {sum gz, sum gz*xhat} of the resulting gz (i2p_bn_act_bwd_stats) — the stack's output
