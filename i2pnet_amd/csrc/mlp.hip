@@ -923,13 +923,15 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
                 const int to = tw / NTI, ti = tw - to * NTI;
                 const float *ap = Gs + (lane >> 5) * p.ldg + to * 32 + (lane & 31);
                 const float *bp = Xs + (lane >> 5) * p.ldx + ti * 32 + (lane & 31);
-                float a_cur = ap[0], b_cur = bp[0];
+                // ping-pong fragments, two k-steps per iteration: operands are requested a full MFMA (64 cycles) before use
+                float a0 = ap[0], b0 = bp[0], a1, b1;
 #pragma unroll 4
-                for (int kk = 0; kk < BWD_R; kk += 2) {
-                    const int kn = kk + 2 < BWD_R ? kk + 2 : kk;
-                    const float a_nxt = ap[(size_t)kn * p.ldg], b_nxt = bp[(size_t)kn * p.ldx];
-                    accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur, accw[t], 0, 0, 0);
-                    a_cur = a_nxt; b_cur = b_nxt;
+                for (int kk = 0; kk < BWD_R; kk += 4) {
+                    a1 = ap[(size_t)(kk + 2) * p.ldg]; b1 = bp[(size_t)(kk + 2) * p.ldx];
+                    accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, accw[t], 0, 0, 0);
+                    const int kn = kk + 4 < BWD_R ? kk + 4 : kk + 2;
+                    a0 = ap[(size_t)kn * p.ldg]; b0 = bp[(size_t)kn * p.ldx];
+                    accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, accw[t], 0, 0, 0);
                 }
             }
         }
@@ -1069,6 +1071,8 @@ __global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
     const int k0 = kt * BWD_R;
     const int n_begin = nc * p.NL, n_end = min(p.N, n_begin + p.NL);
     const int co4 = p.cout >> 2, ci4 = p.cin >> 2;
+    const bool col_fix = (THREADS % co4) == 0;              // a thread's G chunks all carry the same 4 channels
+    const bool x_fix = (THREADS % ci4) == 0;                // ... and its X' chunks the same 4 input channels
 
     for (int i = tid; i < p.cout_p * p.cin_p; i += THREADS) {
         const int co = i / p.cin_p, ci = i - co * p.cin_p;
@@ -1128,22 +1132,43 @@ __global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
 #pragma unroll
     for (int u = 0; u < GCH; ++u) dbk_acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // The G / y chunks and the f row of point n+1 are requested while point n's tiles are on the matrix cores: with one
+    // wave per SIMD (132 KB of LDS per block) nothing else hides the load latency (the first version of this kernel
+    // spent 3/4 of its time waiting: 1.58 ms for 0.39 ms of MFMA work).
+    float *Rs = Co + 5 * p.cout_p;                          // [THREADS/co4][cout] partial column sums (d_bias_n)
+    float4 gq[GCH], yq[GCH], f_next = make_float4(0.f, 0.f, 0.f, 0.f);
+    float fd_next[DPW];
+    auto prefetch = [&](int n) {
+        const size_t bn = (size_t)b * p.N + n;
+        const size_t rbase = bn * p.M + k0;
+#pragma unroll
+        for (int u = 0; u < GCH; ++u) {
+            const int i = tid + u * THREADS, r = i / co4, c4 = i - r * co4;
+            gq[u] = make_float4(0.f, 0.f, 0.f, 0.f); yq[u] = gq[u];
+            if (i < BWD_R * co4 && k0 + r < p.M) {
+                gq[u] = *reinterpret_cast<const float4 *>(p.gz + (rbase + r) * p.cout + c4 * 4);
+                if (p.out_coef) yq[u] = *reinterpret_cast<const float4 *>(p.y + (rbase + r) * p.cout + c4 * 4);
+            }
+        }
+        f_next = *reinterpret_cast<const float4 *>(p.f + bn * p.cin + (tid % ci4) * 4);
+#pragma unroll
+        for (int t = 0; t < DPW; ++t) {
+            const int td = wave + 4 * t, rt = td / NTI, ti = td - rt * NTI, ci = ti * 32 + (lane & 31);
+            fd_next[t] = (td < DT && ci < p.cin) ? p.f[bn * p.cin + ci] : 0.f;
+        }
+    };
+    if (n_begin < n_end) prefetch(n_begin);
+
     for (int n = n_begin; n < n_end; ++n) {
         const size_t bn = (size_t)b * p.N + n;
-        const size_t rbase = bn * p.M + k0;                // global row of tile row 0
         __syncthreads();
         // ---- stage G (BN-backward on load), accumulate the per-pixel bias gradient -------------------
-        {
-            float4 gq[GCH], yq[GCH];
+        const float4 f_cur = f_next;
+        float fd_cur[DPW];
 #pragma unroll
-            for (int u = 0; u < GCH; ++u) {
-                const int i = tid + u * THREADS, r = i / co4, c4 = i - r * co4;
-                gq[u] = make_float4(0.f, 0.f, 0.f, 0.f); yq[u] = gq[u];
-                if (i < BWD_R * co4 && k0 + r < p.M) {
-                    gq[u] = *reinterpret_cast<const float4 *>(p.gz + (rbase + r) * p.cout + c4 * 4);
-                    if (p.out_coef) yq[u] = *reinterpret_cast<const float4 *>(p.y + (rbase + r) * p.cout + c4 * 4);
-                }
-            }
+        for (int t = 0; t < DPW; ++t) fd_cur[t] = fd_next[t];
+        {
+            float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);   // this thread's rows, its 4 channels (co4 divides THREADS)
 #pragma unroll
             for (int u = 0; u < GCH; ++u) {
                 const int i = tid + u * THREADS, r = i / co4, c4 = i - r * co4;
@@ -1159,26 +1184,33 @@ __global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
                         }
                     }
                     dbk_acc[u].x += gv[0]; dbk_acc[u].y += gv[1]; dbk_acc[u].z += gv[2]; dbk_acc[u].w += gv[3];
+                    csum.x += gv[0]; csum.y += gv[1]; csum.z += gv[2]; csum.w += gv[3];
                     float *dst = Gs + r * p.ldg + c4 * 4;
                     dst[0] = gv[0]; dst[1] = gv[1]; dst[2] = gv[2]; dst[3] = gv[3];
                 }
             }
+            if (col_fix) *reinterpret_cast<float4 *>(Rs + (tid / co4) * p.cout + (tid % co4) * 4) = csum;
         }
         // ---- stage X' = f[b,n,:] * g[b,k,:] ----------------------------------------------------------
 #pragma unroll
         for (int u = 0; u < XCH; ++u) {
             const int i = tid + u * THREADS, r = i / ci4, c4 = i - r * ci4;
             if (i < BWD_R * ci4) {
-                const float4 fv = *reinterpret_cast<const float4 *>(p.f + bn * p.cin + c4 * 4);
+                const float4 fv = x_fix ? f_cur : *reinterpret_cast<const float4 *>(p.f + bn * p.cin + c4 * 4);
                 float *dst = Xs + r * p.ldx + c4 * 4;
                 dst[0] = fv.x * gk_chunk[u].x; dst[1] = fv.y * gk_chunk[u].y; dst[2] = fv.z * gk_chunk[u].z; dst[3] = fv.w * gk_chunk[u].w;
             }
         }
+        if (n + 1 < n_end) prefetch(n + 1);                 // lands while the MFMAs below run
         __syncthreads();
         // ---- per-point bias gradient: column sums of G ------------------------------------------------
         for (int ch = tid; ch < p.cout; ch += THREADS) {
             float s0 = 0.f;
-            for (int r = 0; r < BWD_R; ++r) s0 += Gs[r * p.ldg + ch];
+            if (col_fix) {
+                for (int q = 0; q < THREADS / co4; ++q) s0 += Rs[q * p.cout + ch];
+            } else {
+                for (int r = 0; r < BWD_R; ++r) s0 += Gs[r * p.ldg + ch];
+            }
             atomicAdd(p.d_bn + bn * p.cout + ch, s0);
         }
         // ---- wgrad --------------------------------------------------------------------------------------
@@ -1189,13 +1221,15 @@ __global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
                 const int to = tw / NTI, ti = tw - to * NTI;
                 const float *ap = Gs + (lane >> 5) * p.ldg + to * 32 + (lane & 31);
                 const float *bp = Xs + (lane >> 5) * p.ldx + ti * 32 + (lane & 31);
-                float a_cur = ap[0], b_cur = bp[0];
+                // ping-pong fragments, two k-steps per iteration: operands are requested a full MFMA (64 cycles) before use
+                float a0 = ap[0], b0 = bp[0], a1, b1;
 #pragma unroll 4
-                for (int kk = 0; kk < BWD_R; kk += 2) {
-                    const int kn = kk + 2 < BWD_R ? kk + 2 : kk;
-                    const float a_nxt = ap[(size_t)kn * p.ldg], b_nxt = bp[(size_t)kn * p.ldx];
-                    accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur, accw[t], 0, 0, 0);
-                    a_cur = a_nxt; b_cur = b_nxt;
+                for (int kk = 0; kk < BWD_R; kk += 4) {
+                    a1 = ap[(size_t)(kk + 2) * p.ldg]; b1 = bp[(size_t)(kk + 2) * p.ldx];
+                    accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, accw[t], 0, 0, 0);
+                    const int kn = kk + 4 < BWD_R ? kk + 4 : kk + 2;
+                    a0 = ap[(size_t)kn * p.ldg]; b0 = bp[(size_t)kn * p.ldx];
+                    accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, accw[t], 0, 0, 0);
                 }
             }
         }
@@ -1210,17 +1244,18 @@ __global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
                 const float *ap = Gs + (rt * 32 + (lane & 31)) * p.ldg + (lane >> 5);
                 const float *bp = Ws + (lane >> 5) * p.ldw + ti * 32 + (lane & 31);
-                float a_cur = ap[0], b_cur = bp[0];
+                float a0 = ap[0], b0 = bp[0], a1, b1;
 #pragma unroll 4
-                for (int kk = 0; kk < p.cout_p; kk += 2) {
-                    const int kn = kk + 2 < p.cout_p ? kk + 2 : kk;
-                    const float a_nxt = ap[kn], b_nxt = bp[(size_t)kn * p.ldw];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur, acc, 0, 0, 0);
-                    a_cur = a_nxt; b_cur = b_nxt;
+                for (int kk = 0; kk < p.cout_p; kk += 4) {           // cout_p is a multiple of 32
+                    a1 = ap[kk + 2]; b1 = bp[(size_t)(kk + 2) * p.ldw];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+                    const int kn = kk + 4 < p.cout_p ? kk + 4 : kk + 2;
+                    a0 = ap[kn]; b0 = bp[(size_t)kn * p.ldw];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
                 }
                 const int ci = ti * 32 + (lane & 31);
                 if (ci < p.cin) {
-                    const float fv = p.f[bn * p.cin + ci];
+                    const float fv = fd_cur[t];
                     float colsum = 0.f;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {           // rows beyond M hold G = 0 => T = 0
@@ -1752,7 +1787,8 @@ extern "C" int i2p_pair_lin_bwd_grid(int B, int N, int M) {
 
 template <int NTI, int NTO>
 static int launch_pair_bwd(PairBwdParams &p, float *dw, hipStream_t st, unsigned grid) {
-    const size_t bytes = ((size_t)p.cout_p * p.ldw + (size_t)BWD_R * p.ldg + (size_t)BWD_R * p.ldx + 5 * (size_t)p.cout_p) * sizeof(float);
+    const size_t bytes = ((size_t)p.cout_p * p.ldw + (size_t)BWD_R * p.ldg + (size_t)BWD_R * p.ldx + 5 * (size_t)p.cout_p +
+                          (size_t)THREADS * 4) * sizeof(float);       // + partial column sums [THREADS/co4][cout]
     if (bytes > 160 * 1024) return I2P_ERR_BAD_ARG;
     static bool attr_set = false;
     if (!attr_set) {
