@@ -947,13 +947,14 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
                     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
                     const float *ap = Gs + (rt * 32 + (lane & 31)) * p.ldg + (lane >> 5);
                     const float *bp = Ws + (lane >> 5) * p.ldw + ti * 32 + (lane & 31);
-                    float a_cur = ap[0], b_cur = bp[0];
+                    float a0 = ap[0], b0 = bp[0], a1, b1;            // ping-pong fragments (see pair_bwd_kernel)
 #pragma unroll 4
-                    for (int kk = 0; kk < p.cout_p; kk += 2) {
-                        const int kn = kk + 2 < p.cout_p ? kk + 2 : kk;
-                        const float a_nxt = ap[kn], b_nxt = bp[(size_t)kn * p.ldw];
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur, acc, 0, 0, 0);
-                        a_cur = a_nxt; b_cur = b_nxt;
+                    for (int kk = 0; kk < p.cout_p; kk += 4) {
+                        a1 = ap[kk + 2]; b1 = bp[(size_t)(kk + 2) * p.ldw];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+                        const int kn = kk + 4 < p.cout_p ? kk + 4 : kk + 2;
+                        a0 = ap[kn]; b0 = bp[(size_t)kn * p.ldw];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
                     }
                     // epilogue: previous layer's activation derivative + BN-backward statistics
                     const int ci = ti * 32 + (lane & 31);
