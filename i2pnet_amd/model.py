@@ -195,32 +195,46 @@ class RegNet_v2(nn.Module):
 
         # ---- fine level ----------------------------------------------------------------------
         t4_quat = torch.cat([torch.zeros((B, 1), device=dev), t4], -1)
-        P3_warped = warp_utils.warp_quat_xyz(P3_pts, q4, t4_quat) * P.check_valid(P3_pts)
         l3_mask_up = self.set_upconv0_w_upsample(P3_raw, P4_raw, P3, P4, l3_idx_n2, LF3,
                                                  l4_mask.view(B, H4, W4, -1), cfg=cfg, raw_feat_point=rfp)
         l3_embed_up = self.set_upconv0_upsample(P3_raw, P4_raw, P3, P4, l3_idx_n2, LF3, l4_embed, cfg=cfg,
                                                 raw_feat_point=rfp)
-        lidar_z = P3_warped[:, :, 2:]
-        lidar_uv = P3_warped / (lidar_z + 1e-10)
-        concat_3 = self.cost_volume2(P3_raw, lidar_uv, LF3_pts, l3_idx_n2, pix_rays, RF3_pts, lidar_z, cfg=cfg,
-                                     normalised=normalised)
-        l3_embed = self.flow_predictor0_predict(LF3_pts, l3_embed_up.view(B, H3 * W3, -1),
-                                                concat_3.view(B, H3 * W3, -1))
-        l3_mask = self.flow_predictor0_w(LF3_pts, l3_mask_up.view(B, H3 * W3, -1), l3_embed)
-        l3_valid = P.check_valid(P3_raw).view(B, -1, 1)
-        l3_mask = l3_mask * l3_valid + -1e10 * (1 - l3_valid)
-        q3, t3, W_l3 = self.l3_head(l3_embed, l3_mask, P3_warped, LF3_pts, None)
-
-        # ---- compose: q = q3 * q4, t = R3 t4 + t3 (modellearn_proj_center.py:388-404) ----------
-        out_q = warp_utils.mul_q(q3.view(B, 1, 4), q4.view(B, 1, 4)).squeeze(1)
-        t3_quat = torch.cat([torch.zeros((B, 1), device=dev), t3], 1).view(B, 1, 4)
-        out_t = warp_utils.mul_q(warp_utils.mul_q(q3, t4_quat.view(B, 1, 4)), warp_utils.inv_q(q3)) + t3_quat
-        out_3 = torch.cat([out_q, out_t.squeeze(1)[:, 1:]], 1)
+        fine = dict(P3_pts=P3_pts, P3_raw=P3_raw, LF3_pts=LF3_pts, l3_idx_n2=l3_idx_n2, pix_rays=pix_rays, RF3_pts=RF3_pts,
+                    normalised=normalised, l3_embed_up=l3_embed_up.view(B, H3 * W3, -1),
+                    l3_mask_up=l3_mask_up.view(B, H3 * W3, -1), l3_valid=P.check_valid(P3_raw).view(B, -1, 1),
+                    p3_valid=P.check_valid(P3_pts), cfg=cfg)
+        out_3, W_l3 = self._refine(fine, q4, t4_quat)
 
         if self.eval_info:
             return (out_3.float(), result_4.float(), self.sx, self.sq, W_l3, P3_pts, None, None,
                     P4.view(B, H4 * W4, 3))
         return out_3.float(), result_4.float(), None, None, self.sx, self.sq
+
+    def _fine_step(self, f, q_prev, t_prev_quat):
+        """one fine registration step (modellearn_proj_center.py:332-404): warp the level-3 cloud by the
+        previous estimate, 32-NN cost volume against the image, refine embedding and mask, regress (q3, t3) and
+        compose with the previous estimate: q = q3 * q_prev, t = R3 t_prev + t3.
+        -> (composed pose [B,7], q3 [B,4], t3 [B,3], mask weights)"""
+        B = q_prev.shape[0]
+        dev = q_prev.device
+        P3_warped = warp_utils.warp_quat_xyz(f["P3_pts"], q_prev, t_prev_quat) * f["p3_valid"]
+        lidar_z = P3_warped[:, :, 2:]
+        lidar_uv = P3_warped / (lidar_z + 1e-10)
+        concat_3 = self.cost_volume2(f["P3_raw"], lidar_uv, f["LF3_pts"], f["l3_idx_n2"], f["pix_rays"], f["RF3_pts"],
+                                     lidar_z, cfg=f["cfg"], normalised=f["normalised"])
+        l3_embed = self.flow_predictor0_predict(f["LF3_pts"], f["l3_embed_up"], concat_3.view(B, concat_3.shape[1] * concat_3.shape[2], -1))
+        l3_mask = self.flow_predictor0_w(f["LF3_pts"], f["l3_mask_up"], l3_embed)
+        l3_mask = l3_mask * f["l3_valid"] + -1e10 * (1 - f["l3_valid"])
+        q3, t3, W_l3 = self.l3_head(l3_embed, l3_mask, P3_warped, f["LF3_pts"], None)
+        # compose: q = q3 * q_prev, t = R3 t_prev + t3 (modellearn_proj_center.py:388-404)
+        out_q = warp_utils.mul_q(q3.view(B, 1, 4), q_prev.view(B, 1, 4)).squeeze(1)
+        t3_quat = torch.cat([torch.zeros((B, 1), device=dev), t3], 1).view(B, 1, 4)
+        out_t = warp_utils.mul_q(warp_utils.mul_q(q3, t_prev_quat.view(B, 1, 4)), warp_utils.inv_q(q3)) + t3_quat
+        return torch.cat([out_q, out_t.squeeze(1)[:, 1:]], 1), q3, t3, W_l3
+
+    def _refine(self, fine, q4, t4_quat):
+        out_3, _, _, W_l3 = self._fine_step(fine, q4, t4_quat)
+        return out_3, W_l3
 
     def set_bn(self):
         for m in [self.flow_predictor0, self.flow_predictor0_w, self.flow_predictor0_predict, self.LiDAR_lv1,
@@ -231,3 +245,21 @@ class RegNet_v2(nn.Module):
 
 def get_num_parameters(model, trainable=False):
     return sum(p.numel() for p in model.parameters() if (p.requires_grad or not trainable))
+
+
+class RegNet_v2_iter(RegNet_v2):
+    """Iterative fine registration (reference: src/modellearn_proj_center_iter.py:346-404): the fine step is
+    repeated `n_iters` times.  As in the reference, iteration i >= 1 warps the cloud by the RAW head output
+    (q3, t3) of iteration i-1 (not by the composed pose), and the returned pose composes the last (q3, t3) with
+    the estimate that iteration started from.  Same parameters / state_dict as RegNet_v2."""
+
+    n_iters = 6
+
+    def _refine(self, fine, q4, t4_quat):
+        B = q4.shape[0]
+        q_it, t_it = q4, t4_quat
+        out_3 = W_l3 = None
+        for _ in range(self.n_iters):
+            out_3, q3, t3, W_l3 = self._fine_step(fine, q_it, t_it)
+            q_it, t_it = q3, torch.cat([torch.zeros((B, 1), device=q3.device), t3], -1)
+        return out_3, W_l3

@@ -143,3 +143,44 @@ def test_model_matches_reference_on_gpu(tag, hip_backend):
     # measures 2e-3 (activation gradients) to 2e-2 (individual parameter tensors) between two
     # identical runs, fused or not.  Hence statistical limits here; the CPU variant holds 1e-4/1e-3.
     _check(*res, tol=1e-4, grad_tol=5e-2, grad_tensor_tol=2e-2)
+
+
+def _run_iter(device):
+    """iterative fine registration against the reference's modellearn_proj_center_iter outputs"""
+    from i2pnet_amd import synth
+    from i2pnet_amd.config import CONFIGS
+    from i2pnet_amd.model import RegNet_v2_iter
+
+    gold = np.load(GOLD / "model_kitti_iter.npz")
+    cfg_name, B, N, img_h, img_w, seed, beams = gold["meta"].tolist()
+    B, N, img_h, img_w, seed, beams = int(B), int(N), int(img_h), int(img_w), int(seed), int(beams)
+    cfg = CONFIGS[cfg_name]
+    model = RegNet_v2_iter(cfg=cfg)
+    assert sorted(model.state_dict().keys()) == sorted(gold["state_keys"].tolist())
+    model.load_state_dict(synthetic_state([(k, tuple(v.shape)) for k, v in model.state_dict().items()], seed=seed))
+    model.eval().to(device)
+    batch = {k: v.to(device) for k, v in synth.make_batch(B, N, img_h, img_w, seed=seed, beams=beams, fup=cfg.fup,
+                                                           fdown=cfg.fdown, unique_cells=(cfg.init_H, cfg.init_W)).items()}
+    with torch.no_grad():
+        out3, out4 = model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"], batch["init_extrinsic"],
+                           batch["init_intrinsic"], None, None, None, batch["lidar_feats"], cfg=cfg)[:2]
+    return gold, out3.cpu(), out4.cpu()
+
+
+def test_iterative_model_vs_reference_cpu_oracle(oracle_backend):
+    from i2pnet_amd import ops
+    prev = ops.set_backend(oracle_backend)
+    try:
+        gold, out3, out4 = _run_iter("cpu")
+    finally:
+        ops.set_backend(prev)
+    # six chained fine steps: each step's 1e-5-level differences feed the next warp
+    assert _rel(out4, gold["out4"]) < 1e-4
+    assert _rel(out3, gold["out3"]) < 5e-4
+
+
+@pytest.mark.gpu
+def test_iterative_model_vs_reference_gpu():
+    gold, out3, out4 = _run_iter("cuda")
+    assert _rel(out4, gold["out4"]) < 1e-4
+    assert _rel(out3, gold["out3"]) < 5e-4

@@ -97,6 +97,27 @@ def run(cfg_name, tag, B, N, img_h, img_w, seed, beams):
           "size", (OUT / f"model_{tag}.npz").stat().st_size)
 
 
+def run_iter(cfg_name, tag, B, N, img_h, img_w, seed, beams):
+    """iterative fine registration (src/modellearn_proj_center_iter.py): forward outputs only"""
+    RegNet, cfg, _ = ref_harness.load_model(cfg_name, module="modellearn_proj_center_iter")
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = RegNet(cfg=cfg)
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    model.load_state_dict(synthetic_state(shapes, seed=seed))
+    model.eval()
+    batch = synth.make_batch(B, N, img_h, img_w, seed=seed, beams=beams, fup=cfg.fup, fdown=cfg.fdown,
+                             unique_cells=(cfg.init_H, cfg.init_W))
+    with torch.no_grad():
+        out = model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"], batch["init_extrinsic"], batch["init_intrinsic"],
+                    None, None, None, batch["lidar_feats"], cfg=cfg)
+    data = {"out3": out[0].numpy(), "out4": out[1].numpy(),
+            "state_keys": np.array([k for k, _ in shapes]),
+            "meta": np.array([cfg_name, str(B), str(N), str(img_h), str(img_w), str(seed), str(beams)])}
+    np.savez_compressed(OUT / f"model_{tag}.npz", **data)
+    print(tag, "out3", out[0].numpy().round(4).tolist())
+
+
 def fp64_gradients(cfg_name, shapes, seed, batch):
     from i2pnet_amd import ops, projectpn as P
     from i2pnet_amd.config import CONFIGS
@@ -145,5 +166,8 @@ def fp64_gradients(cfg_name, shapes, seed, batch):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "iter":
+        run_iter("config_proj_lidarcenter", "kitti_iter", B=2, N=8192, img_h=375, img_w=1242, seed=3, beams=64)
+        sys.exit(0)
     run("config_proj_lidarcenter", "kitti", B=2, N=8192, img_h=375, img_w=1242, seed=3, beams=64)
     run("config_proj_lidarcenter_nus", "nus", B=2, N=16384, img_h=160, img_w=512, seed=5, beams=32)

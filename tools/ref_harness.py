@@ -49,13 +49,13 @@ def install():
         sys.path.insert(0, str(REF))
 
 
-def load_model(cfg_name="config_proj_lidarcenter"):
+def load_model(cfg_name="config_proj_lidarcenter", module="modellearn_proj_center"):
     """-> (RegNet_v2 class, I2PNetConfig class, Get_loss)"""
     import importlib
     import contextlib, io
     install()
     cfg = importlib.import_module(f"src.{cfg_name}").I2PNetConfig
-    net = importlib.import_module("src.modellearn_proj_center")
+    net = importlib.import_module(f"src.{module}")
     with contextlib.redirect_stdout(io.StringIO()):
         loss = importlib.import_module("compute_loss")
     return net.RegNet_v2, cfg, loss.Get_loss
