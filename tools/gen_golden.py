@@ -118,6 +118,43 @@ def run_iter(cfg_name, tag, B, N, img_h, img_w, seed, beams):
     print(tag, "out3", out[0].numpy().round(4).tolist())
 
 
+def _sa_inputs(B, N, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    xyz = (torch.rand(B, 3, N, generator=g) - 0.5) * 20.0
+    pts = torch.randn(B, D, N, generator=g)
+    return xyz, pts
+
+
+def run_set_abstraction():
+    """pointnet_util.PointNetSetAbstraction of the reference (small-range model building block)"""
+    ref_harness.install()
+    import importlib
+    pu = importlib.import_module("pointnet_util")
+    B, N, D, S, K, seed = 2, 1024, 5, 128, 16, 21
+    sa = pu.PointNetSetAbstraction(npoint=S, radius=None, nsample=K, in_channel=3 + D, mlp=[16, 32], group_all=False)
+    shapes = [(k, tuple(v.shape)) for k, v in sa.state_dict().items()]
+    sa.load_state_dict(synthetic_state(shapes, seed=seed))
+    xyz, pts = _sa_inputs(B, N, D, seed)
+    pts.requires_grad_()
+    sa.train()
+    new_xyz, new_points, grouped_xyz, fps_idx, _ = sa(xyz, pts)
+    w = torch.randn(new_points.shape, generator=torch.Generator().manual_seed(seed + 1))
+    (new_points * w).sum().backward()
+    data = {"new_xyz": new_xyz.detach().numpy(), "new_points": new_points.detach().numpy(),
+            "fps_idx": fps_idx.numpy().astype(np.int64),
+            "grouped_xyz_sorted": np.sort(grouped_xyz.detach().numpy().reshape(B, S, K * 3), axis=-1),
+            "pts_grad": pts.grad.numpy(),
+            "w0_grad": sa.mlp_convs[0].weight.grad.numpy(), "bn1_gamma_grad": sa.mlp_bns[1].weight.grad.numpy(),
+            "running_mean1": sa.mlp_bns[1].running_mean.numpy().copy(), "running_var1": sa.mlp_bns[1].running_var.numpy().copy(),
+            "state_keys": np.array([k for k, _ in shapes]), "state_shapes": np.array([",".join(map(str, s_)) for _, s_ in shapes]),
+            "meta": np.array([B, N, D, S, K, seed])}
+    sa.eval()
+    with torch.no_grad():
+        data["new_points_eval"] = sa(xyz, pts.detach())[1].numpy()
+    np.savez_compressed(OUT / "set_abstraction.npz", **data)
+    print("set_abstraction", data["new_points"].shape, float(np.abs(data["new_points"]).mean()))
+
+
 def fp64_gradients(cfg_name, shapes, seed, batch):
     from i2pnet_amd import ops, projectpn as P
     from i2pnet_amd.config import CONFIGS
@@ -166,6 +203,9 @@ def fp64_gradients(cfg_name, shapes, seed, batch):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sa":
+        run_set_abstraction()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "iter":
         run_iter("config_proj_lidarcenter", "kitti_iter", B=2, N=8192, img_h=375, img_w=1242, seed=3, beams=64)
         sys.exit(0)
