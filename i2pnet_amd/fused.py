@@ -247,6 +247,68 @@ class _CvPiTail(Function):
                 f32(re[1]), f32(re[0]), dW4, dg4, db4, dW5, dg5, db5)
 
 
+class _CvKnnTail(Function):
+    """The pi-stage of the kNN cost volume (PPBackbone_center.py:367-433 with nsample_q > 0) as one autograd node:
+    the same tail as `_CvPiTail`, with materialised first-layer inputs x1 [rows, cin1] (geometry + correlation,
+    zero-padded to a multiple of 4) and xe [rows, cine] (geometry) instead of the factored pair form.  No
+    activated tensor, no concatenation and no softmax tensor is written; rows = B*N*K, softmax over K."""
+
+    @staticmethod
+    def forward(ctx, x1, xe, W1, We, dims, slopes, g1, b1, W2, g2, b2, W3, g3, b3, ge, be, W4, g4, b4, W5, g5, b5):
+        be_ = ops.get_backend()
+        B, N, K = dims
+        rows = B * N * K
+        s1, s2, s3, se, s4, s5 = slopes
+        d = lambda t: t.detach()
+        x1, xe, W1, We = [t.detach().contiguous() for t in (x1, xe, W1, We)]
+        y1, st1 = be_.lin_forward(x1, None, 1.0, W1); c1, m1 = be_.bn_finalize(rows, st1, d(g1), d(b1), _EPS)
+        y2, st2 = be_.lin_forward(y1, c1, s1, d(W2)); c2, m2 = be_.bn_finalize(rows, st2, d(g2), d(b2), _EPS)
+        y3, st3 = be_.lin_forward(y2, c2, s2, d(W3)); c3, m3 = be_.bn_finalize(rows, st3, d(g3), d(b3), _EPS)
+        ye, ste = be_.lin_forward(xe, None, 1.0, We); ce, me = be_.bn_finalize(rows, ste, d(ge), d(be), _EPS)
+        y4, st4 = be_.lin_forward_2src(ye, ce, se, y3, c3, s3, d(W4)); c4, m4 = be_.bn_finalize(rows, st4, d(g4), d(b4), _EPS)
+        y5, st5 = be_.lin_forward(y4, c4, s4, d(W5)); c5, m5 = be_.bn_finalize(rows, st5, d(g5), d(b5), _EPS)
+        out, msave = be_.cv_softmax_wsum_forward(B, N, K, y5, c5, s5, y3, c3, s3)
+        ctx.save_for_backward(y1, ye, y2, y3, y4, y5, c1, m1, c2, m2, c3, m3, ce, me, c4, m4, c5, m5, out, msave,
+                              W2, W3, W4, W5, x1, xe, W1, We)
+        ctx.dims, ctx.slopes = dims, slopes
+        ctx.need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        be_ = ops.get_backend()
+        (y1, ye, y2, y3, y4, y5, c1, m1, c2, m2, c3, m3, ce, me, c4, m4, c5, m5, out, msave,
+         W2, W3, W4, W5, x1, xe, W1, We) = ctx.saved_tensors
+        B, N, K = ctx.dims
+        s1, s2, s3, se, s4, s5 = ctx.slopes
+        d = lambda t: t.detach()
+        gz5, ds5, ga3 = be_.cv_softmax_wsum_backward(B, N, K, g_out.contiguous(), out, msave, y5, c5, m5, s5, y3, c3, s3)
+        gz4, ds4, dW5 = be_.lin_backward(gz5, y5, c5, m5, ds5, y4, c4, m4, s4, d(W5)); dg5, db5 = be_.last_bn_grads
+        gze, dse, gz3, ds3, dW4 = be_.lin_backward_2src(gz4, y4, c4, m4, ds4, ye, ce, me, se, y3, c3, m3, s3, ga3, d(W4))
+        dg4, db4 = be_.last_bn_grads
+        gz2, ds2, dW3 = be_.lin_backward(gz3, y3, c3, m3, ds3, y2, c2, m2, s2, d(W3)); dg3, db3 = be_.last_bn_grads
+        gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2)); dg2, db2 = be_.last_bn_grads
+        dx1, _, dW1 = be_.lin_backward(gz1, y1, c1, m1, ds1, x1, None, None, 1.0, W1, need_gx=ctx.need[0]); dg1, db1 = be_.last_bn_grads
+        dxe, _, dWe = be_.lin_backward(gze, ye, ce, me, dse, xe, None, None, 1.0, We, need_gx=ctx.need[1]); dge, dbe = be_.last_bn_grads
+        return (dx1, dxe, dW1, dWe, None, None, dg1, db1, dW2, dg2, db2, dW3, dg3, db3, dge, dbe, dW4, dg4, db4, dW5, dg5, db5)
+
+
+def cv_knn_tail(x1, xe, dims, first, mlp1_rest, enc, mlp2):
+    """x1 [B,N,K,cin1] / xe [B,N,K,cine] (channel counts already padded to a multiple of 4) -> pi_feat [B,N,c]"""
+    c2, c3 = mlp1_rest
+    c4, c5 = mlp2
+    slopes = tuple(_slope(m) for m in (first, c2, c3, enc, c4, c5))
+    bn = lambda m: (m.bn_linear.weight, m.bn_linear.bias)
+    rows = dims[0] * dims[1] * dims[2]
+    W1, We = first.weight2d(), enc.weight2d()
+    if x1.shape[-1] > W1.shape[1]:
+        W1 = F.pad(W1, (0, x1.shape[-1] - W1.shape[1]))
+    if xe.shape[-1] > We.shape[1]:
+        We = F.pad(We, (0, xe.shape[-1] - We.shape[1]))
+    return _CvKnnTail.apply(x1.reshape(rows, -1), xe.reshape(rows, -1), W1, We, dims, slopes, *bn(first), c2.weight2d(), *bn(c2),
+                            c3.weight2d(), *bn(c3), *bn(enc), c4.weight2d(), *bn(c4), c5.weight2d(), *bn(c5))
+
+
 def cv_pi_tail(f, g, bias_n, bias_k, W1, enc_n, enc_k, first, mlp1_rest, enc, mlp2):
     """f [B,N,C] / g [B,M,C] normalised point / pixel features, bias_n/bias_k the per-point / per-pixel parts of
     the first layer, W1 its bilinear weight block, enc_n/enc_k the factors of the position encoding

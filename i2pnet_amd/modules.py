@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import ops
 from . import projectpn as P
-from .fused import cv_pi_tail, cv_tail_fits, mlp_stack, pair_fits, pair_linear
+from .fused import cv_knn_tail, cv_pi_tail, cv_tail_fits, layer_fits, mlp_stack, pair_fits, pair_linear
 
 # run Conv2d stacks on the fused MFMA layer kernels (csrc/mlp.hip); False = library GEMM + BN kernels per block
 USE_FUSED_MLP = True
@@ -526,9 +526,17 @@ class CostVolume(nn.Module):
         idx = P.knn_point(K, pix_xyz, uv)                                       # grouping(), :369
         q_xyz = P.index_points_group(pix_xyz, idx)                              # [B,N,K,3]
         q_feat = P.index_points_group(pix_n, idx)                               # [B,N,K,C]
-        geo = torch.cat([xyz.unsqueeze(2).expand(-1, -1, K, -1), q_xyz], dim=3)
+        own = xyz.unsqueeze(2).expand(-1, -1, K, -1)
+        first, rest = self.mlp1_convs[0], list(self.mlp1_convs)[1:]
+        c1 = (first.in_channels + 3) // 4 * 4
+        if (USE_FUSED_MLP and USE_CV_TAIL and K <= 255 and cv_tail_fits(first, rest, self.pi_encoding, list(self.mlp2_convs))
+                and layer_fits(c1, first.out_channels) and layer_fits(8, self.pi_encoding.out_channels)):
+            x1 = cat_padded([own, q_xyz, pts_n.unsqueeze(2) * q_feat])         # [B,N,K,6+C(+pad)]
+            xe = cat_padded([own, q_xyz])                                       # [B,N,K,8]
+            return None, None, cv_knn_tail(x1, xe, (B, N, K), first, rest, self.pi_encoding, list(self.mlp2_convs))
+        geo = torch.cat([own, q_xyz], dim=3)
         h = run_stack(torch.cat([geo, pts_n.unsqueeze(2) * q_feat], dim=3), self.mlp1_convs)
-        return h, run_stack(geo, [self.pi_encoding])
+        return h, run_stack(geo, [self.pi_encoding]), None
 
     def forward(self, xyz_proj_raw, warped_xyz, warped_points, idx_n2, f2_xyz, f2_points, lidar_z, cfg=None,
                 normalised=None):
@@ -544,7 +552,7 @@ class CostVolume(nn.Module):
                                                                   _unit_variance(f2_points))
         pi_feat = None
         if self.nsample_q > 0:
-            h3, enc = self._pi_knn(uv, xyz, pts_n, f2_xyz, pix_n)
+            h3, enc, pi_feat = self._pi_knn(uv, xyz, pts_n, f2_xyz, pix_n)
         else:
             h3, enc, pi_feat = self._pi_all_pixels(xyz, pts_n, f2_xyz, pix_n)
         if pi_feat is None:
