@@ -297,7 +297,6 @@ __global__ __launch_bounds__(THREADS) void lin_fwd_kernel(LinFwdParams p) {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int F2_THREADS = 512;
 constexpr int F2_ROWS = 16;
-constexpr int F2_CH = 8;                 // float4 chunks per lane per strip (16 rows x 128 ch max)
 
 // branch-free (b,n,k) walk for a 16-row strip (M >= 16: at most one wrap inside a strip)
 __device__ __forceinline__ void pair_row16(const PairTile &t, int d, int N, int M, int &bn, int &bk) {
@@ -309,8 +308,12 @@ __device__ __forceinline__ void pair_row16(const PairTile &t, int d, int N, int 
     bn = t.bn0 + wrap; bk = b * M + k;
 }
 
-template <int NT16, bool PAIR, bool DGRAD>
-__global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p) {
+// CH = float4 chunks per lane per strip = max(cin, cout)/16 rounded up to 2, 4 or 8: the narrow layers (<= 64
+// channels) carry half the prefetch / output registers of the 128-wide ones and run 4 waves per SIMD instead of 2
+// (they are HBM-bound: more loads in flight, not more math, is what they need).
+template <int NT16, bool PAIR, bool DGRAD, int CH>
+__global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(LinFwdParams p) {
+    constexpr int F2_CH = CH;
     extern __shared__ float smem[];
     const int ldk = p.ldk;                                  // max(cin, cout_p) + 2 (8-byte aligned rows), or + 4 (16-byte, wide-K path)
     // (forward / pair instantiations only: the dgrad instantiation is register-bound and keeps the narrow loop)
@@ -666,32 +669,41 @@ __global__ __launch_bounds__(F2_THREADS, 2) void lin_fwd2_kernel(LinFwdParams p)
     }
 }
 
-template <int NT16, bool PAIR, bool DGRAD>
+template <int NT16, bool PAIR, bool DGRAD, int CH>
 int launch_fwd2(const LinFwdParams &p, hipStream_t st) {
     const size_t bytes = (((size_t)p.cout_p + 8 * F2_ROWS) * p.ldk + (DGRAD ? 6 * (size_t)p.cin + 4 * (size_t)p.cout_total : 0)) * sizeof(float);
     if (bytes > 160 * 1024) return I2P_ERR_BAD_ARG;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lin_fwd2_kernel<NT16, PAIR, DGRAD>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lin_fwd2_kernel<NT16, PAIR, DGRAD, CH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const long long nstrips = (p.rows + F2_ROWS - 1) / F2_ROWS;
     long long g = (nstrips + 7) / 8;
-    const unsigned grid = (unsigned)(g < 256 ? (g < 1 ? 1 : g) : 256);
+    // persistent grid: as many blocks as the occupancy of this instantiation keeps resident per CU
+    const int per_cu = CH <= 4 ? (bytes <= 52 * 1024 ? 3 : (bytes <= 80 * 1024 ? 2 : 1)) : 1;
+    const long long cap = 256LL * (per_cu > 2 ? 2 : per_cu);
+    const unsigned grid = (unsigned)(g < cap ? (g < 1 ? 1 : g) : cap);
     LinFwdParams q = p;
     q.w_vec = ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0 && (p.cin & 3) == 0 && (p.cout_total & 3) == 0 && (p.ch_off & 3) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((lin_fwd2_kernel<NT16, PAIR, DGRAD>), dim3(grid), dim3(F2_THREADS), bytes, st, q);
+    hipLaunchKernelGGL((lin_fwd2_kernel<NT16, PAIR, DGRAD, CH>), dim3(grid), dim3(F2_THREADS), bytes, st, q);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
 template <bool PAIR, bool DGRAD>
 int dispatch_fwd2(const LinFwdParams &p, hipStream_t st) {
+    const int wide = p.cin > p.cout ? p.cin : p.cout;      // channels a strip row holds (input and output phases)
+    static const char *env = getenv("I2P_LIN_CH");          // diagnostic: 8 = always the wide instantiation
+    const bool narrow_ok = !PAIR && !(env && env[0] == '8');
+    const bool ch2 = narrow_ok && wide <= 32, ch4 = false;   // (4-chunk instantiations spill at 128 VGPRs and measure no faster: unused)
     switch (p.cout_p / 16) {
-        case 1: return launch_fwd2<1, PAIR, DGRAD>(p, st);
-        case 2: return launch_fwd2<2, PAIR, DGRAD>(p, st);
-        case 4: return launch_fwd2<4, PAIR, DGRAD>(p, st);
-        case 8: return launch_fwd2<8, PAIR, DGRAD>(p, st);
+        case 1: return ch2 ? launch_fwd2<1, PAIR, DGRAD, 2>(p, st) : ch4 ? launch_fwd2<1, PAIR, DGRAD, 4>(p, st)
+                                                                         : launch_fwd2<1, PAIR, DGRAD, 8>(p, st);
+        case 2: return ch2 ? launch_fwd2<2, PAIR, DGRAD, 2>(p, st) : ch4 ? launch_fwd2<2, PAIR, DGRAD, 4>(p, st)
+                                                                         : launch_fwd2<2, PAIR, DGRAD, 8>(p, st);
+        case 4: return ch4 ? launch_fwd2<4, PAIR, DGRAD, 4>(p, st) : launch_fwd2<4, PAIR, DGRAD, 8>(p, st);
+        case 8: return launch_fwd2<8, PAIR, DGRAD, 8>(p, st);
         default: return I2P_ERR_BAD_ARG;
     }
 }
