@@ -35,16 +35,16 @@ def main():
     assert len(marks) >= a.warmup + a.steps + 1, (len(marks), "proj_assign_kernel launches")
     t0, t1 = marks[a.warmup], marks[a.warmup + a.steps]
     sel = [r for r in rows if t0 <= int(r["Start_Timestamp"]) < t1]
-    agg = defaultdict(lambda: [0, 0])
+    agg = defaultdict(lambda: [0, 0, 0])
     for r in sel:
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         e = agg[short(r["Kernel_Name"])]
-        e[0] += 1; e[1] += d
+        e[0] += 1; e[1] += d; e[2] = max(e[2], d)
     tot = sum(v[1] for v in agg.values())
     wall = t1 - t0
-    lines = [("kernel", "calls_per_step", "total_us_per_step", "avg_us", "pct_of_kernel_time")]
-    for k, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        lines.append((k, f"{c / a.steps:.1f}", f"{d / a.steps / 1e3:.1f}", f"{d / c / 1e3:.2f}", f"{100.0 * d / tot:.2f}"))
+    lines = [("kernel", "calls_per_step", "total_us_per_step", "avg_us", "pct_of_kernel_time", "max_us")]
+    for k, (c, d, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        lines.append((k, f"{c / a.steps:.1f}", f"{d / a.steps / 1e3:.1f}", f"{d / c / 1e3:.2f}", f"{100.0 * d / tot:.2f}", f"{mx / 1e3:.1f}"))
     print(f"# steps={a.steps} wall_per_step_ms={wall / a.steps / 1e6:.3f} kernel_time_per_step_ms={tot / a.steps / 1e6:.3f} "
           f"launches_per_step={len(sel) / a.steps:.0f} distinct_kernels={len(agg)}")
     for ln in lines[: a.top + 1]:
