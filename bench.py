@@ -167,6 +167,7 @@ def main():
     from i2pnet_amd.config import I2PNetConfig as cfg
     from i2pnet_amd.train import Trainer, init_distributed
 
+    torch.backends.cudnn.benchmark = True   # MIOpen exhaustive find for the 15 image-encoder convolutions (in the warm-up steps)
     rank, local_rank, world = init_distributed("nccl")
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     torch.cuda.set_device(local_rank)
