@@ -321,6 +321,51 @@ def cv_pi_tail(f, g, bias_n, bias_k, W1, enc_n, enc_k, first, mlp1_rest, enc, ml
                            c3.weight2d(), *bn(c3), *bn(enc), c4.weight2d(), *bn(c4), c5.weight2d(), *bn(c5))
 
 
+_IDENT = {}
+
+
+def _identity_coef(c, device):
+    key = (c, str(device))
+    t = _IDENT.get(key)
+    if t is None:
+        coef = torch.stack([torch.zeros(c), torch.ones(c), torch.zeros(c)]).to(device).contiguous()
+        mi = torch.cat([torch.zeros(c), torch.ones(c)]).to(device).contiguous()
+        t = _IDENT[key] = (coef, mi)
+    return t
+
+
+class _SoftmaxPool(Function):
+    """out[b,:] = sum_n softmax_n(mask[b,n,:]) * value[b,n,:]  (PoseHead, PPBackbone_center.py:551-552) on the
+    cost-volume softmax-weighted-sum kernels with identity BN coefficients: one launch each way instead of
+    softmax / mul / sum and their five autograd nodes."""
+
+    @staticmethod
+    def forward(ctx, mask, value):
+        B, N, C = mask.shape
+        be_ = ops.get_backend()
+        coef, mi = _identity_coef(C, mask.device)
+        m2, v2 = mask.detach().reshape(B * N, C).contiguous(), value.detach().reshape(B * N, C).contiguous()
+        out, msave = be_.cv_softmax_wsum_forward(B, 1, N, m2, coef, 1.0, v2, coef, 1.0)
+        ctx.save_for_backward(m2, v2, out, msave)
+        ctx.dims = (B, N, C)
+        return out.view(B, 1, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        m2, v2, out, msave = ctx.saved_tensors
+        B, N, C = ctx.dims
+        be_ = ops.get_backend()
+        coef, mi = _identity_coef(C, m2.device)
+        gmask, _, gval = be_.cv_softmax_wsum_backward(B, 1, N, g.reshape(B, 1, C).contiguous(), out, msave, m2, coef, mi, 1.0,
+                                                      v2, coef, 1.0)
+        return gmask.view(B, N, C), gval.view(B, N, C)
+
+
+def softmax_pool(mask, value):
+    """mask, value [B,N,C] -> [B,1,C]; C must divide 256 (else use the torch formulation)"""
+    return _SoftmaxPool.apply(mask, value)
+
+
 def cv_tail_fits(first, mlp1_rest, enc, mlp2):
     if len(mlp1_rest) != 2 or len(mlp2) != 2:
         return False

@@ -137,6 +137,7 @@ class RegNet_v2(nn.Module):
 
         self.l4_head = head(enc[-1][-1], enc[-2][-1])
         self.l3_head = head(cfg.flow_predictor_mlps[1][-1], enc[-3][-1])
+        self.l3_head.training_needs_weights = eval_info      # W_l3 is only returned with eval_info
 
         self.sq = nn.Parameter(torch.tensor([cfg.sq_init]), requires_grad=True)
         self.sx = nn.Parameter(torch.tensor([cfg.sx_init]), requires_grad=True)

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import ops
 from . import projectpn as P
-from .fused import cv_knn_tail, cv_pi_tail, cv_tail_fits, layer_fits, mlp_stack, pair_fits, pair_linear
+from .fused import cv_knn_tail, cv_pi_tail, cv_tail_fits, layer_fits, mlp_stack, pair_fits, pair_linear, softmax_pool
 
 # run Conv2d stacks on the fused MFMA layer kernels (csrc/mlp.hip); False = library GEMM + BN kernels per block
 USE_FUSED_MLP = True
@@ -596,6 +596,7 @@ class PoseHead(nn.Module):
         in_channel, _ = in_channels
         self.DP1 = nn.Identity() if split_dp else nn.Dropout(dropout_rate)
         self.DP2 = nn.Dropout(dropout_rate) if split_dp else nn.Identity()
+        self.training_needs_weights = False     # set True to get the softmax weights back (eval_info visualisation)
         self.hidden_layer = Conv1d(in_channel, hidden, use_activation=False)
         self.quat_head = Conv1d(hidden, q_dim, use_activation=False)
         self.trans_head = Conv1d(hidden, t_dim, use_activation=False)
@@ -609,8 +610,14 @@ class PoseHead(nn.Module):
             prediction = prediction * projection_mask
         if self.maxhead:
             mask = torch.max(mask, dim=-1, keepdim=True)[0]
-        mask_p = F.softmax(mask, dim=1)                                         # over points, :551
-        pooled = torch.sum(prediction * mask_p, dim=1, keepdim=True)            # [B,1,C]
+        C = mask.shape[-1]
+        if (USE_FUSED_MLP and not self.training_needs_weights and mask.shape == prediction.shape and C % 4 == 0
+                and 256 % C == 0 and mask.dtype == torch.float32):
+            mask_p = None                                                       # (weights not materialised)
+            pooled = softmax_pool(mask, prediction)                             # :551-552 in one launch
+        else:
+            mask_p = F.softmax(mask, dim=1)                                     # over points, :551
+            pooled = torch.sum(prediction * mask_p, dim=1, keepdim=True)        # [B,1,C]
         hidden = self.DP1(self.hidden_layer(pooled))
         q = self.quat_head(self.DP2(hidden)).squeeze(1)
         t = self.trans_head(self.DP2(hidden)).squeeze(1)

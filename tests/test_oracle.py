@@ -384,3 +384,27 @@ def test_max_response_matches_literal_formulation():
     assert torch.allclose(x1.grad[:2], x2.grad[:2], rtol=1e-5, atol=1e-6)
     assert torch.allclose(p1.grad[:2], p2.grad[:2], rtol=1e-5, atol=1e-6)
     assert float(p1.grad[2].abs().max()) == 0.0 and float(x1.grad[2].abs().max()) == 0.0
+
+
+def test_softmax_pool_matches_torch(oracle_backend):
+    """PoseHead pooling on the softmax-weighted-sum kernels == softmax(mask, 1) * value summed over points,
+    incl. the -1e10 masked rows (values and both gradients)."""
+    from i2pnet_amd import ops
+    from i2pnet_amd.fused import softmax_pool
+    g = torch.Generator().manual_seed(2)
+    B, N, C = 3, 57, 64
+    mask = torch.randn(B, N, C, generator=g) * 3; val = torch.randn(B, N, C, generator=g)
+    mask[:, 10:20] = -1e10
+    prev = ops.set_backend(oracle_backend)
+    try:
+        m1, v1 = mask.clone().requires_grad_(), val.clone().requires_grad_()
+        m2, v2 = mask.clone().requires_grad_(), val.clone().requires_grad_()
+        o1 = softmax_pool(m1, v1)
+        o2 = torch.sum(v2 * torch.softmax(m2, dim=1), dim=1, keepdim=True)
+        assert torch.allclose(o1, o2, rtol=1e-5, atol=1e-6)
+        w = torch.randn(B, 1, C, generator=g)
+        (o1 * w).sum().backward(); (o2 * w).sum().backward()
+        assert torch.allclose(v1.grad, v2.grad, rtol=1e-4, atol=1e-6)
+        assert torch.allclose(m1.grad, m2.grad, rtol=1e-4, atol=1e-6)
+    finally:
+        ops.set_backend(prev)
