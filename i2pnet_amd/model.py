@@ -19,7 +19,7 @@ from . import projectpn as P
 from . import warp as warp_utils
 from .config import I2PNetConfig as cfg_default
 from .modules import (CostVolume, FlowPredictor, PoseHead, ProjectPointNet, ProjSetUpconvModule, _unit_variance,
-                      createCNNs)
+                      createCNNs, mask_fill)
 
 
 _const_cache = {}
@@ -189,7 +189,7 @@ class RegNet_v2(nn.Module):
                                               raw_feat_point=rfp)
         l4_valid = P.check_valid(P4_raw).view(B, -1, 1)
         l4_mask = self.flow_predictor0(LF4.view(B, H4 * W4, -1), None, l4_embed.view(B, H4 * W4, -1))
-        l4_mask = l4_mask * l4_valid + -1e10 * (1 - l4_valid)
+        l4_mask = mask_fill(l4_mask, l4_valid)                                  # modellearn_proj_center.py:318
         q4, t4, _ = self.l4_head(l4_embed.view(B, H4 * W4, -1), l4_mask, P4.view(B, H4 * W4, 3),
                                  LF4.view(B, H4 * W4, -1), None)
         result_4 = torch.cat([q4, t4], dim=1)
@@ -225,7 +225,7 @@ class RegNet_v2(nn.Module):
                                      lidar_z, cfg=f["cfg"], normalised=f["normalised"])
         l3_embed = self.flow_predictor0_predict(f["LF3_pts"], f["l3_embed_up"], concat_3.view(B, concat_3.shape[1] * concat_3.shape[2], -1))
         l3_mask = self.flow_predictor0_w(f["LF3_pts"], f["l3_mask_up"], l3_embed)
-        l3_mask = l3_mask * f["l3_valid"] + -1e10 * (1 - f["l3_valid"])
+        l3_mask = mask_fill(l3_mask, f["l3_valid"])                             # :376
         q3, t3, W_l3 = self.l3_head(l3_embed, l3_mask, P3_warped, f["LF3_pts"], None)
         # compose: q = q3 * q_prev, t = R3 t_prev + t3 (modellearn_proj_center.py:388-404)
         out_q = warp_utils.mul_q(q3.view(B, 1, 4), q_prev.view(B, 1, 4)).squeeze(1)

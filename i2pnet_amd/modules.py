@@ -46,6 +46,13 @@ def run_stack(x, convs, first_bn=None, pool_k=0):
     return torch.max(x, dim=-2)[0] if pool_k else x
 
 
+def mask_fill(x, valid):
+    """x*valid + (-1e10)*(1-valid) for a 0/1 mask (the reference's way of masking logits, e.g.
+    modellearn_proj_center.py:318, PPBackbone_center.py:481) as one select: identical values (x*1 + -0.0 = x,
+    x*0 + -1e10 = -1e10 for finite x) and identical gradient (valid), in one launch each way instead of ~8."""
+    return torch.where(valid > 0, x, -1e10)
+
+
 def cat_padded(parts, dim=-1, pow2=False):
     """torch.cat(parts, -1) with zero channels appended up to a multiple of 4 (what the fused layer kernels
     consume): the padding rides along in the one cat kernel instead of a separate fill + copy of the tensor.
@@ -575,7 +582,7 @@ class CostVolume(nn.Module):
         w = torch.cat([enc_pc, warped_points.unsqueeze(2).expand(-1, -1, K, -1), nb_feat], dim=-1)
         w = run_stack(w, self.mlp2_convs_2)
         valid = gidx[-1]
-        w = w * valid + -1e10 * (1 - valid)                                     # :481
+        w = mask_fill(w, valid)                                                 # :481
         out = torch.sum(F.softmax(w, dim=2) * nb_feat, dim=2)
         return out.view(B, self.H, self.W, -1)
 
