@@ -155,6 +155,44 @@ def run_set_abstraction():
     print("set_abstraction", data["new_points"].shape, float(np.abs(data["new_points"]).mean()))
 
 
+def run_small_range():
+    """small-range model (src/modellearn.py, src/config_lidarcenter.py), SURVEY f1: eval forward and a train-mode
+    forward/backward (dropout off)"""
+    import importlib
+    ref_harness.install()
+    cfg = importlib.import_module("src.config_lidarcenter").I2PNetConfig
+    net = importlib.import_module("src.modellearn")
+    with contextlib.redirect_stdout(io.StringIO()):
+        Get_loss = importlib.import_module("compute_loss").Get_loss
+        torch.manual_seed(0)
+        model = net.RegNet_v2(cfg=cfg)
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    seed, B, N, img_h, img_w = 7, 2, 8192, 160, 512
+    model.load_state_dict(synthetic_state(shapes, seed=seed))
+    batch = synth.make_batch(B, N, img_h, img_w, seed=seed)
+    args = (batch["rgb"], batch["lidar"], batch["init_extrinsic"], batch["init_intrinsic"], None, None, None, batch["lidar_feats"])
+    model.eval()
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        o3, o4 = model(*args, cfg=cfg, lidar_img_raw=batch["raw_point_xyz"])[:2]
+    data = {"eval_out3": o3.numpy(), "eval_out4": o4.numpy()}
+    model.train()
+    model.l3_head.DP1.p = 0.0; model.l4_head.DP1.p = 0.0
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = model(*args, cfg=cfg, lidar_img_raw=batch["raw_point_xyz"])
+    loss, lq, lx = Get_loss(out[0], out[1], batch["decalib_real_gt"], batch["decalib_dual_gt"], out[4], out[5], cfg=cfg)
+    loss.backward()
+    data.update({"train_out3": out[0].detach().numpy(), "train_out4": out[1].detach().numpy(),
+                 "loss": np.array([loss.item(), lq.item(), lx.item()])})
+    keys = [k for k, _ in model.named_parameters()]
+    data["grad_keys"] = np.array(keys)
+    data["grad_norm"] = np.array([0.0 if p.grad is None else float(p.grad.double().norm()) for _, p in model.named_parameters()])
+    data["state_keys"] = np.array([k for k, _ in shapes])
+    data["state_shapes"] = np.array([",".join(map(str, s_)) for _, s_ in shapes])
+    data["meta"] = np.array([seed, B, N, img_h, img_w])
+    np.savez_compressed(OUT / "model_small_range.npz", **data)
+    print("small_range eval out3", o3.numpy().round(4).tolist(), "loss", loss.item())
+
+
 def fp64_gradients(cfg_name, shapes, seed, batch):
     from i2pnet_amd import ops, projectpn as P
     from i2pnet_amd.config import CONFIGS
@@ -203,6 +241,9 @@ def fp64_gradients(cfg_name, shapes, seed, batch):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "small":
+        run_small_range()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sa":
         run_set_abstraction()
         sys.exit(0)
