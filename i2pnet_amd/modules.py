@@ -100,6 +100,27 @@ def bn_act(y, gamma, beta, slope, eps=_BN_EPS):
     return _BatchStatNormAct.apply(y, gamma, beta, eps, slope)
 
 
+def bn_act_running(y, conv_bias, bn, slope):
+    """Training-mode BatchNorm (batch statistics for the output, running buffers updated with momentum and the
+    unbiased variance like torch.nn.BatchNorm2d) + activation on a channel-last pre-activation `y` from which the
+    conv bias was left out (it cancels in the output; it only enters the running mean).  Runs on the fused
+    batch-statistics kernels: MIOpen's spatial BN on the [rows, C, 1, 1] view of these tensors is ~30x slower
+    (8.8 ms for a 524 288 x 32 tensor)."""
+    out = bn_act(y, bn.weight, bn.bias, slope, bn.eps)
+    if bn.track_running_stats and bn.momentum is not None:
+        with torch.no_grad():
+            c = y.shape[-1]
+            n = y.numel() // c
+            s = ops.get_backend().last_bn_sums.view(ops.BN_REPLICAS, 2, c).sum(0)
+            mean = s[0] / n
+            var = (s[1] / n - mean * mean).clamp_min(0.0)
+            mb = mean.float() if conv_bias is None else mean.float() + conv_bias.detach()
+            bn.running_mean.mul_(1 - bn.momentum).add_(mb * bn.momentum)
+            bn.running_var.mul_(1 - bn.momentum).add_((var * (n / max(n - 1, 1))).float() * bn.momentum)
+            bn.num_batches_tracked += 1
+    return out
+
+
 def batch_stat_norm(y, gamma, beta, eps=_BN_EPS):
     """BatchNorm with batch statistics over every axis but the last (biased variance, eps 1e-5,
     affine) — what `BatchNorm2d(track_running_stats=False)` computes on the reference's
@@ -139,7 +160,10 @@ class Conv2d(nn.Module):
         """BN + activation on pre-activation `y [..., C_out]` (bias NOT yet added)."""
         shape = y.shape
         if self.bn:
-            if self.bn_linear.track_running_stats:      # running-stat BN: the bias matters
+            if self.bn_linear.track_running_stats:      # BatchNorm2d with running buffers (small-range model)
+                if self.bn_linear.training and USE_FUSED_BN and self.bn_linear.momentum is not None:
+                    return bn_act_running(y, self.conv.bias, self.bn_linear,
+                                          self.negative_slope if self.activation_fn else 1.0)
                 y = y + self.conv.bias
                 y = self.bn_linear(y.reshape(-1, self.out_channels, 1, 1)).reshape(shape)
             elif USE_FUSED_BN:

@@ -264,10 +264,12 @@ class CBackend:
 
     # ---- batch-stat BatchNorm + activation (PPBackbone_center.py:28-46) ---------------------------
     def bn_act_forward(self, y, gamma, beta, eps, slope):
-        """y [rows,c] f32 -> (out [rows,c], mean_invstd [2c]) with batch statistics."""
+        """y [rows,c] f32 -> (out [rows,c], mean_invstd [2c]) with batch statistics.
+        `self.last_bn_sums` = the replicated fp64 {sum y, sum y^2} (callers that also keep running statistics)."""
         rows, c = y.shape
         dev = y.device
         sums = zeros(BN_REPLICAS * 2 * c, torch.float64, dev)
+        self.last_bn_sums = sums
         out = torch.empty_like(y)
         mean_invstd = torch.empty(2 * c, dtype=_F32, device=dev)
         st = self._stream()

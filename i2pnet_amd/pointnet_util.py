@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import ops
 from . import projectpn as P
-from .modules import bn_act
+from .modules import bn_act_running
 from .pointnet2_utils import FurthestPointSampling
 
 
@@ -114,17 +114,7 @@ class PointNetSetAbstraction(nn.Module):
         W = conv.weight.view(conv.out_channels, conv.in_channels)
         if self.training or not bn.track_running_stats:
             y = F.linear(x, W)                          # the bias cancels in the batch-statistics BN
-            if bn.track_running_stats and bn.momentum is not None:
-                with torch.no_grad():
-                    flat = y.detach().reshape(-1, y.shape[-1])
-                    n = flat.shape[0]
-                    s = ops.get_backend().bn_stats(flat.contiguous()).view(ops.BN_REPLICAS, 2, -1).sum(0)
-                    mean = s[0] / n
-                    var = (s[1] / n - mean * mean).clamp_min(0.0)
-                    bn.running_mean.mul_(1 - bn.momentum).add_((mean.float() + conv.bias.detach()) * bn.momentum)
-                    bn.running_var.mul_(1 - bn.momentum).add_((var * (n / max(n - 1, 1))).float() * bn.momentum)
-                    bn.num_batches_tracked += 1
-            return bn_act(y, bn.weight, bn.bias, 0.0, bn.eps)
+            return bn_act_running(y, conv.bias, bn, 0.0)
         y = F.linear(x, W, conv.bias)
         y = (y - bn.running_mean) * (torch.rsqrt(bn.running_var + bn.eps) * bn.weight) + bn.bias
         return F.relu(y)

@@ -75,11 +75,14 @@ class FlatAdam:
 
 class Trainer:
     def __init__(self, cfg=I2PNetConfig, device="cuda", lr=1e-3, clip=10.0, world_size=1, local_rank=0,
-                 seed=0, capturable=False):
+                 seed=0, capturable=False, net_cls=RegNet_v2, call=None):
+        """`net_cls` / `call`: another registration network with the same outputs (e.g. the small-range model,
+        i2pnet_amd.small_range.RegNet_v2) and how to call it: call(net, batch, cfg) -> its output tuple."""
         torch.manual_seed(seed)                 # identical initial weights on every rank
         self.cfg, self.device, self.clip = cfg, torch.device(device), clip
         self.world_size = world_size
-        self.net = RegNet_v2(cfg=cfg).to(self.device)
+        self._call = call
+        self.net = net_cls(cfg=cfg).to(self.device)
         self.model = self.net
         self.params = [p for p in self.net.parameters() if p.requires_grad]
         if world_size > 1:                      # belt and braces: same seed already gives identical replicas
@@ -122,9 +125,12 @@ class Trainer:
         ops.begin_step(self.device)             # one memset for every small accumulator of this step
         for p in self.params:                   # autograd then hands its buffers over instead of accumulating
             p.grad = None
-        out3, out4, _, _, sx, sq = self.model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"],
-                                              batch.get("init_extrinsic"), batch["init_intrinsic"], None, None, None,
-                                              batch["lidar_feats"], cfg=self.cfg)
+        if self._call is not None:
+            out3, out4, _, _, sx, sq = self._call(self.model, batch, self.cfg)
+        else:
+            out3, out4, _, _, sx, sq = self.model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"],
+                                                  batch.get("init_extrinsic"), batch["init_intrinsic"], None, None, None,
+                                                  batch["lidar_feats"], cfg=self.cfg)
         loss, real_loss, dual_loss = Get_loss(out3, out4, batch["decalib_real_gt"], batch["decalib_dual_gt"], sx, sq,
                                               cfg=self.cfg)
         loss.backward()
