@@ -34,6 +34,24 @@ def _rep_sum(dsums, c):
     return dsums.view(ops.BN_REPLICAS, 2, c).sum(0)
 
 
+def _update_running(running, idx, mi, rows):
+    """BatchNorm2d bookkeeping for chains whose BNs keep running buffers: momentum update from this batch's mean /
+    unbiased variance (mean_invstd from bn_finalize; the conv bias, left out of the GEMM, re-enters the mean)."""
+    if not running or running[idx] is None:
+        return
+    bn, bias = running[idx]
+    if not bn.track_running_stats or bn.momentum is None:
+        return
+    with torch.no_grad():
+        c = mi.shape[0] // 2
+        mean, invstd = mi[:c], mi[c:]
+        var = (1.0 / (invstd * invstd) - _EPS).clamp_min(0.0)
+        mb = mean if bias is None else mean + bias.detach()
+        bn.running_mean.mul_(1 - bn.momentum).add_(mb * bn.momentum)
+        bn.running_var.mul_(1 - bn.momentum).add_(var * (rows / max(rows - 1, 1)) * bn.momentum)
+        bn.num_batches_tracked += 1
+
+
 class _MlpChain(Function):
     """x [rows,c0] (raw input, or a pre-BN tensor when `first_bn`) -> act(BN(...)) of the last block.
 
@@ -41,9 +59,11 @@ class _MlpChain(Function):
     (index 0 = the optional leading BN)."""
 
     @staticmethod
-    def forward(ctx, x, first_bn, slopes, pool_k, *params):
+    def forward(ctx, x, first_bn, slopes, pool_k, running, *params):
         """pool_k > 0: the output is the max over groups of pool_k consecutive rows (set-abstraction tail),
-        [rows/pool_k, c]; the activated [rows, c] tensor is not materialised."""
+        [rows/pool_k, c]; the activated [rows, c] tensor is not materialised.
+        `running`: None, or one entry per BN of the chain (index 0 = the leading BN): (BatchNorm module, conv bias)
+        whose running buffers are updated from this batch's statistics (models with BatchNorm2d running stats)."""
         be = ops.get_backend()
         rows = x.shape[0]
         p = list(params)
@@ -56,6 +76,7 @@ class _MlpChain(Function):
             be._call("i2p_bn_stats", int(rows), int(x.shape[1]), be._p(x, torch.float32, "x"),
                      be._p(sums, torch.float64, "sums"), stream=be._stream())
             in_coef, mi = be.bn_finalize(rows, sums, g0.detach(), b0.detach(), _EPS)
+            _update_running(running, 0, mi, rows)
             coefs.append(in_coef); mis.append(mi); slope_in = slopes[0]
         else:
             coefs.append(None); mis.append(None)
@@ -65,6 +86,7 @@ class _MlpChain(Function):
             W, g, b = p[k + 3 * i], p[k + 3 * i + 1], p[k + 3 * i + 2]
             y, sums = be.lin_forward(ys[-1], in_coef, slope_in, W.detach())
             in_coef, mi = be.bn_finalize(rows, sums, g.detach(), b.detach(), _EPS)
+            _update_running(running, i + 1, mi, rows)
             coefs.append(in_coef); mis.append(mi); ys.append(y)
             slope_in = slopes[i + 1]
         ctx.pool_k = 0
@@ -117,7 +139,7 @@ class _MlpChain(Function):
         if not nl:          # only the leading BN: dL/dx and its gamma/beta gradients
             gz, dg, db = be.bn_act_backward(g_out, ys[-1], mis[-1], last_g.detach(), last_b.detach(), slopes[-1])
             grads[0], grads[1] = dg, db
-            return (gz if ctx.x_needs_grad else None), None, None, None, *grads
+            return (gz if ctx.x_needs_grad else None), None, None, None, None, *grads
         # last block: only the statistics pass over (dL/da, y_L); the activation derivative and the BN backward are
         # applied by the layer kernels as they load dL/da (slope_out), so dL/dy_L is never written
         out_ds = be.bn_act_backward_stats(g_out, ys[-1], mis[-1], last_g.detach(), last_b.detach(), slopes[-1])
@@ -142,7 +164,7 @@ class _MlpChain(Function):
                 gx, _, _ = _bn_bwd_from_gz(be, gz, ys[0], mis[0], p[0], p[1], out_ds)
             else:
                 gx = gz
-        return gx, None, None, None, *grads
+        return gx, None, None, None, None, *grads
 
 
 def _bn_bwd_from_gz(be, gz, y, mi, gamma, beta, dsums):
@@ -377,6 +399,13 @@ def cv_tail_fits(first, mlp1_rest, enc, mlp2):
     return ok and 256 % c5.out_channels == 0 and all(m.bn and not m.bn_linear.track_running_stats for m in (first, c2, c3, enc, c4, c5))
 
 
+def _batch_stat(conv):
+    """the conv's BN normalises with THIS batch's statistics: always for the projection model's BNs
+    (track_running_stats False), in training mode for BatchNorm2d with running buffers"""
+    bn = conv.bn_linear
+    return (not bn.track_running_stats) or (bn.training and bn.momentum is not None)
+
+
 def _slope(conv):
     return conv.negative_slope if conv.activation_fn else 1.0
 
@@ -387,6 +416,8 @@ def mlp_stack(x, convs, first_bn=None, pool_k=0):
     Consecutive blocks that fit the fused kernels run as one chain; others run block by block.
     `pool_k`: x is `[..., K, C]` with K = pool_k and the result is the max over that axis `[..., C']`
     (fused into the last chain when it ends the stack)."""
+    if first_bn is not None and not _batch_stat(first_bn):      # running-statistics BN in eval mode: plain affine
+        x, first_bn = first_bn.finish(x), None
     lead = x.shape[:-1]
     cur = x.reshape(-1, x.shape[-1])
     pending_bn = first_bn
@@ -398,11 +429,15 @@ def mlp_stack(x, convs, first_bn=None, pool_k=0):
         while j < n:
             c = convs[j]
             cin_eff = (cin + 3) // 4 * 4 if not run and pending_bn is None else cin
-            if not (c.bn and not c.bn_linear.track_running_stats and layer_fits(cin_eff, c.out_channels)):
+            if not (c.bn and _batch_stat(c) and layer_fits(cin_eff, c.out_channels)):
                 break
             run.append(c); cin = c.out_channels; j += 1
         if run or pending_bn is not None:
             params, slopes = [], []
+            keeps = lambda m: (m.bn_linear, m.conv.bias) if m.bn_linear.track_running_stats else None
+            running = [keeps(pending_bn) if pending_bn is not None else None] + [keeps(c) for c in run]
+            if not any(r is not None for r in running):
+                running = None
             if pending_bn is not None:
                 params += [pending_bn.bn_linear.weight, pending_bn.bn_linear.bias]; slopes.append(_slope(pending_bn))
             else:
@@ -417,7 +452,7 @@ def mlp_stack(x, convs, first_bn=None, pool_k=0):
                         W = F.pad(W, (0, xin.shape[1] - W.shape[1]))
                 params += [W, c.bn_linear.weight, c.bn_linear.bias]; slopes.append(_slope(c))
             pool_here = pool_k if (j >= n and run) else 0
-            cur = _MlpChain.apply(xin.contiguous(), pending_bn is not None, tuple(slopes), pool_here, *params)
+            cur = _MlpChain.apply(xin.contiguous(), pending_bn is not None, tuple(slopes), pool_here, running, *params)
             if pool_here:
                 return cur.reshape(*lead[:-1], cur.shape[-1])
             pending_bn = None

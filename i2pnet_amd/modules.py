@@ -64,7 +64,7 @@ def cat_padded(parts, dim=-1, pow2=False):
         pad = next(w for w in (16, 32, 64, 128) if w >= c) - c
     if pad and USE_FUSED_MLP:
         parts = list(parts) + [parts[0].new_zeros(()).expand(*parts[0].shape[:-1], pad)]
-    return torch.cat(parts, dim)
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim)
 
 _BN_EPS = 1e-5
 

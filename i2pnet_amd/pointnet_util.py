@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import modules, ops
 from . import projectpn as P
 from .modules import bn_act_running
 from .pointnet2_utils import FurthestPointSampling
@@ -93,6 +93,22 @@ def sample_and_group_all(xyz, points):
     return new_xyz, new_points
 
 
+class _ConvBnView:
+    """what `fused.mlp_stack` reads of a layer, for the reference's separate `mlp_convs[i]` / `mlp_bns[i]` modules"""
+
+    def __init__(self, conv, bn):
+        self.conv, self.bn_linear = conv, bn
+        self.bn, self.activation_fn, self.negative_slope = True, True, 0.0          # BatchNorm2d + ReLU (:299)
+        self.in_channels, self.out_channels = conv.in_channels, conv.out_channels
+
+    def weight2d(self):
+        return self.conv.weight.view(self.out_channels, self.in_channels)
+
+    def __call__(self, x):                                   # layer outside the fused kernels' shape limits
+        y = F.linear(x, self.weight2d())
+        return bn_act_running(y, self.conv.bias, self.bn_linear, 0.0)
+
+
 class PointNetSetAbstraction(nn.Module):
     """FPS -> kNN grouping -> (1x1 conv + BatchNorm2d + ReLU) x len(mlp) -> max over the group
     (pointnet_util.py:257-314).  Inputs/outputs channel-major like the reference: xyz [B,3,N], points [B,D,N]
@@ -131,7 +147,14 @@ class PointNetSetAbstraction(nn.Module):
                 self.npoint, self.radius, self.nsample, xyz, points, returnfps=True, sample_idx=sample_idx,
                 raw_feat_point=raw_feat_point, raw_xyz=raw_xyz, feat_mode=feat_mode)
         x = new_points                                   # [B,S,K,C] stays channel-last (reference: permute to [B,C,K,S])
-        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-            x = self._layer(x, conv, bn)
-        new_points = torch.max(x, 2)[0].permute(0, 2, 1)    # [B,D',S]
+        if self.training and modules.USE_FUSED_MLP:
+            # fused layer kernels (BN + ReLU of the previous layer on load, statistics in the epilogue, max over the
+            # group fused into the last BN/activation pass); running buffers updated from the chain's statistics
+            stack = [_ConvBnView(conv, bn) for conv, bn in zip(self.mlp_convs, self.mlp_bns)]
+            pooled = modules.run_stack(modules.cat_padded([x]), stack, pool_k=x.shape[2])     # [B,S,D']
+            new_points = pooled.permute(0, 2, 1)
+        else:
+            for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+                x = self._layer(x, conv, bn)
+            new_points = torch.max(x, 2)[0].permute(0, 2, 1)    # [B,D',S]
         return new_xyz.permute(0, 2, 1), new_points, grouped_xyz, fps_idx, (new_raw_xyz if raw_feat_point else None)
