@@ -220,8 +220,8 @@ class _CvPiTail(Function):
     encoding factors)."""
 
     @staticmethod
-    def forward(ctx, f, g, bias_n, bias_k, W1, enc_n, enc_k, slopes, g1, b1, W2, g2, b2, W3, g3, b3, ge, be, W4, g4, b4,
-                W5, g5, b5):
+    def forward(ctx, f, g, bias_n, bias_k, W1, enc_n, enc_k, slopes, running, g1, b1, W2, g2, b2, W3, g3, b3, ge, be, W4,
+                g4, b4, W5, g5, b5):
         be_ = ops.get_backend()
         f, g, bias_n, bias_k, W1, enc_n, enc_k = [t.detach().contiguous() for t in (f, g, bias_n, bias_k, W1, enc_n, enc_k)]
         B, N, M = f.shape[0], f.shape[1], g.shape[1]
@@ -236,6 +236,8 @@ class _CvPiTail(Function):
         ce, me = be_.bn_finalize(rows, be_.bn_stats(ye), d(ge), d(be), _EPS)
         y4, st4 = be_.lin_forward_2src(ye, ce, se, y3, c3, s3, d(W4)); c4, m4 = be_.bn_finalize(rows, st4, d(g4), d(b4), _EPS)
         y5, st5 = be_.lin_forward(y4, c4, s4, d(W5)); c5, m5 = be_.bn_finalize(rows, st5, d(g5), d(b5), _EPS)
+        for i_, m_ in enumerate((m1, m2, m3, me, m4, m5)):       # BatchNorm2d running buffers (small-range model)
+            _update_running(running, i_, m_, rows)
         out, msave = be_.cv_softmax_wsum_forward(B, N, M, y5, c5, s5, y3, c3, s3)
         ctx.save_for_backward(y1, ye, y2, y3, y4, y5, c1, m1, c2, m2, c3, m3, ce, me, c4, m4, c5, m5, out, msave,
                               W2, W3, W4, W5, f, g, W1, enc_n, enc_k)
@@ -264,7 +266,7 @@ class _CvPiTail(Function):
         d_f, d_g, d_bn, d_bk, dW1 = be_.pair_lin_backward(gz1, f, g, W1, y=y1, out_coef=c1, out_mi=m1, out_dsums=ds1)
         # position encoding: k-/n-sums of dL/dye in closed form from one pass over gz_e
         d_en, d_ek = be_.pair_bias_bn_backward(B, N, M, gze, enc_n, enc_k, dse, ce, me)
-        return (d_f, d_g, d_bn, d_bk, dW1, d_en, d_ek, None,
+        return (d_f, d_g, d_bn, d_bk, dW1, d_en, d_ek, None, None,
                 f32(r1[1]), f32(r1[0]), dW2, dg2, db2, dW3, dg3, db3,
                 f32(re[1]), f32(re[0]), dW4, dg4, db4, dW5, dg5, db5)
 
@@ -276,7 +278,7 @@ class _CvKnnTail(Function):
     activated tensor, no concatenation and no softmax tensor is written; rows = B*N*K, softmax over K."""
 
     @staticmethod
-    def forward(ctx, x1, xe, W1, We, dims, slopes, g1, b1, W2, g2, b2, W3, g3, b3, ge, be, W4, g4, b4, W5, g5, b5):
+    def forward(ctx, x1, xe, W1, We, dims, slopes, running, g1, b1, W2, g2, b2, W3, g3, b3, ge, be, W4, g4, b4, W5, g5, b5):
         be_ = ops.get_backend()
         B, N, K = dims
         rows = B * N * K
@@ -289,6 +291,8 @@ class _CvKnnTail(Function):
         ye, ste = be_.lin_forward(xe, None, 1.0, We); ce, me = be_.bn_finalize(rows, ste, d(ge), d(be), _EPS)
         y4, st4 = be_.lin_forward_2src(ye, ce, se, y3, c3, s3, d(W4)); c4, m4 = be_.bn_finalize(rows, st4, d(g4), d(b4), _EPS)
         y5, st5 = be_.lin_forward(y4, c4, s4, d(W5)); c5, m5 = be_.bn_finalize(rows, st5, d(g5), d(b5), _EPS)
+        for i_, m_ in enumerate((m1, m2, m3, me, m4, m5)):
+            _update_running(running, i_, m_, rows)
         out, msave = be_.cv_softmax_wsum_forward(B, N, K, y5, c5, s5, y3, c3, s3)
         ctx.save_for_backward(y1, ye, y2, y3, y4, y5, c1, m1, c2, m2, c3, m3, ce, me, c4, m4, c5, m5, out, msave,
                               W2, W3, W4, W5, x1, xe, W1, We)
@@ -312,7 +316,7 @@ class _CvKnnTail(Function):
         gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2)); dg2, db2 = be_.last_bn_grads
         dx1, _, dW1 = be_.lin_backward(gz1, y1, c1, m1, ds1, x1, None, None, 1.0, W1, need_gx=ctx.need[0]); dg1, db1 = be_.last_bn_grads
         dxe, _, dWe = be_.lin_backward(gze, ye, ce, me, dse, xe, None, None, 1.0, We, need_gx=ctx.need[1]); dge, dbe = be_.last_bn_grads
-        return (dx1, dxe, dW1, dWe, None, None, dg1, db1, dW2, dg2, db2, dW3, dg3, db3, dge, dbe, dW4, dg4, db4, dW5, dg5, db5)
+        return (dx1, dxe, dW1, dWe, None, None, None, dg1, db1, dW2, dg2, db2, dW3, dg3, db3, dge, dbe, dW4, dg4, db4, dW5, dg5, db5)
 
 
 def cv_knn_tail(x1, xe, dims, first, mlp1_rest, enc, mlp2):
@@ -321,13 +325,14 @@ def cv_knn_tail(x1, xe, dims, first, mlp1_rest, enc, mlp2):
     c4, c5 = mlp2
     slopes = tuple(_slope(m) for m in (first, c2, c3, enc, c4, c5))
     bn = lambda m: (m.bn_linear.weight, m.bn_linear.bias)
+    running = _running_list((first, c2, c3, enc, c4, c5))
     rows = dims[0] * dims[1] * dims[2]
     W1, We = first.weight2d(), enc.weight2d()
     if x1.shape[-1] > W1.shape[1]:
         W1 = F.pad(W1, (0, x1.shape[-1] - W1.shape[1]))
     if xe.shape[-1] > We.shape[1]:
         We = F.pad(We, (0, xe.shape[-1] - We.shape[1]))
-    return _CvKnnTail.apply(x1.reshape(rows, -1), xe.reshape(rows, -1), W1, We, dims, slopes, *bn(first), c2.weight2d(), *bn(c2),
+    return _CvKnnTail.apply(x1.reshape(rows, -1), xe.reshape(rows, -1), W1, We, dims, slopes, running, *bn(first), c2.weight2d(), *bn(c2),
                             c3.weight2d(), *bn(c3), *bn(enc), c4.weight2d(), *bn(c4), c5.weight2d(), *bn(c5))
 
 
@@ -339,7 +344,7 @@ def cv_pi_tail(f, g, bias_n, bias_k, W1, enc_n, enc_k, first, mlp1_rest, enc, ml
     c4, c5 = mlp2
     slopes = tuple(_slope(m) for m in (first, c2, c3, enc, c4, c5))
     bn = lambda m: (m.bn_linear.weight, m.bn_linear.bias)
-    return _CvPiTail.apply(f, g, bias_n, bias_k, W1, enc_n, enc_k, slopes, *bn(first), c2.weight2d(), *bn(c2),
+    return _CvPiTail.apply(f, g, bias_n, bias_k, W1, enc_n, enc_k, slopes, _running_list((first, c2, c3, enc, c4, c5)), *bn(first), c2.weight2d(), *bn(c2),
                            c3.weight2d(), *bn(c3), *bn(enc), c4.weight2d(), *bn(c4), c5.weight2d(), *bn(c5))
 
 
@@ -396,7 +401,12 @@ def cv_tail_fits(first, mlp1_rest, enc, mlp2):
     p2 = lambda c: c in (16, 32, 64, 128)
     chans = [first.out_channels, c2.out_channels, c3.out_channels, enc.out_channels, c4.out_channels, c5.out_channels]
     ok = all(p2(c) for c in chans) and c4.in_channels == enc.out_channels + c3.out_channels and c5.out_channels == c3.out_channels
-    return ok and 256 % c5.out_channels == 0 and all(m.bn and not m.bn_linear.track_running_stats for m in (first, c2, c3, enc, c4, c5))
+    return ok and 256 % c5.out_channels == 0 and all(m.bn and _batch_stat(m) for m in (first, c2, c3, enc, c4, c5))
+
+
+def _running_list(convs):
+    r = [(m.bn_linear, m.conv.bias) if m.bn_linear.track_running_stats else None for m in convs]
+    return r if any(x is not None for x in r) else None
 
 
 def _batch_stat(conv):

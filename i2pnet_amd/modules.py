@@ -496,6 +496,7 @@ class CostVolume(nn.Module):
         self.nsample, self.nsample_q, self.distance = nsample, nsample_q, distance
         self.mlp1, self.mlp2, self.kernel_size = mlp1, mlp2, kernel_size
         self.backward_validation, self.use_trans = backward_validation, use_trans
+        self.mask_invalid = True        # empty range-image cells (all-zero points) are masked; point-based subclasses: no such cells
         self.feat_channels = rgb_in_channels
         corr = rgb_in_channels + (lidar_in_channels if backward_validation else 0)
         kw = dict(stride=[1, 1], bn=use_bn_p, use_bn_input=use_bn_input)
@@ -530,7 +531,8 @@ class CostVolume(nn.Module):
             # channel g, max_n fl(f_n * g) = fl(g * max_n f_n) if g >= 0 else fl(g * min_n f_n)
             # (rounding is monotone), taken over valid points; -1e10 if no point is valid.  Avoids
             # three passes over the [B,N,M,C] tensor; the gradient still reaches the arg-max/min point.
-            respond = _MaxResponse.apply(pts_n, pix_n, P.check_valid(xyz))      # [B,M,C]
+            valid = P.check_valid(xyz) if self.mask_invalid else torch.ones_like(xyz[:, :, :1])
+            respond = _MaxResponse.apply(pts_n, pix_n, valid)                   # [B,M,C]
             per_pixel = per_pixel + F.linear(respond, w_parts[3])
         B_, N_ = pts_n.shape[0], pts_n.shape[1]
         we_parts = torch.split(self.pi_encoding.weight2d(), [3, 3], dim=1)

@@ -108,6 +108,7 @@ class CostVolumeKnn(CostVolume):
         super().__init__(H=1, W=1, kernel_size=None, distance=None, nsample=nsample, nsample_q=nsample_q,
                          rgb_in_channels=rgb_in_channels, lidar_in_channels=lidar_in_channels, mlp1=mlp1, mlp2=mlp2,
                          backward_validation=backward_validation, use_bn_input=False)
+        self.mask_invalid = False
 
     def forward(self, warped_xyz, warped_points, f2_xyz, f2_points, lidar_z):
         """warped_xyz [B,N,3] (u,v,1); warped_points [B,N,C]; f2_xyz [B,M,3]; f2_points [B,M,C]; lidar_z [B,N,1]
@@ -117,24 +118,15 @@ class CostVolumeKnn(CostVolume):
         xyz = warped_xyz.mul(lidar_z)                                           # restore depth, :139
         pts_n = _unit_variance(warped_points)                                   # :149-153
         pix_n = _unit_variance(f2_points)
+        # pi-stage: the projection model's implementation (factored first layer / fused tail when the layer kernels
+        # apply, i.e. in training mode; plain layers otherwise) with the point mask switched off
         if self.nsample_q > 0:
-            K = self.nsample_q
-            idx = knn_point(K, f2_xyz.contiguous(), uv.contiguous())            # grouping(f2_points, K, f2_xyz, warped_xyz), :128
-            q_xyz, q_feat = index_points(f2_xyz, idx), index_points(pix_n, idx)
-            geo = torch.cat([xyz.unsqueeze(2).expand(-1, -1, K, -1), q_xyz], dim=3)
-            h3 = run_stack(torch.cat([geo, pts_n.unsqueeze(2) * q_feat], dim=3), self.mlp1_convs)
-            enc = run_stack(geo, [self.pi_encoding])
+            h3, enc, pi_feat = self._pi_knn(uv, xyz, pts_n, f2_xyz, pix_n)
         else:
-            M = f2_xyz.shape[1]
-            geo = torch.cat([xyz.unsqueeze(2).expand(-1, -1, M, -1), f2_xyz.unsqueeze(1).expand(-1, N, -1, -1)], dim=3)
-            parts = [geo, pts_n.unsqueeze(2) * pix_n.unsqueeze(1)]              # [B,N,M,C]  :154
-            if self.backward_validation:                                        # max over points of the correlation, :167-176
-                respond = _MaxResponse.apply(pts_n, pix_n, torch.ones(B, N, 1, device=xyz.device))
-                parts.append(respond.unsqueeze(1).expand(-1, N, -1, -1))
-            h3 = run_stack(torch.cat(parts, dim=3), self.mlp1_convs)
-            enc = run_stack(geo, [self.pi_encoding])
-        logits = run_stack(torch.cat([enc, h3], dim=3), self.mlp2_convs)        # :190-196
-        pi_feat = torch.sum(torch.softmax(logits, dim=2) * h3, dim=2)           # [B,N,c]
+            h3, enc, pi_feat = self._pi_all_pixels(xyz, pts_n, f2_xyz, pix_n)
+        if pi_feat is None:
+            logits = run_stack(torch.cat([enc, h3], dim=3), self.mlp2_convs)    # :190-196
+            pi_feat = torch.sum(torch.softmax(logits, dim=2) * h3, dim=2)       # [B,N,c]
 
         # pc-stage: kNN over the warped points (:204-240)
         K = self.nsample
