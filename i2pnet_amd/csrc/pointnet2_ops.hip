@@ -126,6 +126,106 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, int bs,
 }
 
 // ------------------------------------------------------------------------------------------
+// Second-generation FPS for clouds that fit a thread block's registers (n <= 8192): what bounds the kernel is
+// the chain of m-1 dependent block-wide arg-max reductions, so every iteration is trimmed to
+//   * candidates as ONE 64-bit key  (distance bits : ~(rank << 13 | k))  — the distance is a non-negative float, so
+//     its bit pattern orders like the value, and the low word reproduces the reference's tie rule (smaller
+//     bit-reversed rank, then smaller index) under an unsigned max;
+//   * a DPP row reduction (4 steps, no LDS traffic) + 4 scalar lane reads per wave instead of 18 ds_bpermutes;
+//   * one barrier; every wave reduces the 16 wave keys redundantly;
+//   * the winner's coordinates from an LDS copy of the cloud (96 KB) instead of a dependent global load.
+// First generation (kept for n > 8192): 2.4 us per iteration at n = 8192.
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ void fps_dpp_max(unsigned &hi, unsigned &lo) {
+    const unsigned ohi = i2p_dpp_u32<CTRL>(hi), olo = i2p_dpp_u32<CTRL>(lo);
+    const bool take = (ohi > hi) || (ohi == hi && olo > lo);
+    hi = take ? ohi : hi; lo = take ? olo : lo;
+}
+
+__device__ __forceinline__ unsigned long long fps_row_max(unsigned hi, unsigned lo) {
+    fps_dpp_max<0xB1>(hi, lo);      // quad_perm [1,0,3,2]
+    fps_dpp_max<0x4E>(hi, lo);      // quad_perm [2,3,0,1]
+    fps_dpp_max<0x141>(hi, lo);     // row_half_mirror
+    fps_dpp_max<0x140>(hi, lo);     // row_mirror: every lane of a 16-lane row now holds the row maximum
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// T threads own the cloud (8 points each): fewer waves for the small pyramid levels = a cheaper barrier; the thread
+// count only changes which thread holds a point, not the result (the tie rule lives in the key).
+template <int T>
+__global__ __launch_bounds__(T) void fps_kernel_fast(int n, int m, int bs, const float *__restrict__ dataset,
+                                                                float *__restrict__ temp, int *__restrict__ idxs) {
+    extern __shared__ float s_pts[];                                      // [n][3] copy of this sample's cloud
+    __shared__ unsigned long long s_key[2][(T / I2P_WAVE)];
+    const int bi = blockIdx.x;
+    dataset += (size_t)bi * n * 3; temp += (size_t)bi * n; idxs += (size_t)bi * m;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int bs_mask = bs - 1;
+    const int bs_shift = 32 - (31 - __clz(bs));
+    for (int i = tid; i < n * 3; i += T) s_pts[i] = dataset[i];
+
+    float px[FPS_REG_PTS], py[FPS_REG_PTS], pz[FPS_REG_PTS], td[FPS_REG_PTS];
+    unsigned lo_k[FPS_REG_PTS];                                           // ~(rank << 13 | k): constant per point
+#pragma unroll
+    for (int i = 0; i < FPS_REG_PTS; ++i) {
+        const int k = tid + i * T;
+        if (k < n) {
+            px[i] = dataset[k * 3 + 0]; py[i] = dataset[k * 3 + 1]; pz[i] = dataset[k * 3 + 2];
+            td[i] = temp[k];
+            lo_k[i] = ~((fps_rank(k, bs_mask, bs_shift) << 13) | (unsigned)k);
+        } else { px[i] = py[i] = pz[i] = 0.f; td[i] = 0.f; lo_k[i] = 0u; }
+    }
+    __syncthreads();
+
+    int old = 0;
+    if (tid == 0) idxs[0] = 0;                                            // sampling_gpu.cu:112-114
+    for (int j = 1; j < m; ++j) {
+        const float x1 = s_pts[old * 3 + 0], y1 = s_pts[old * 3 + 1], z1 = s_pts[old * 3 + 2];
+        unsigned bhi = 0u, blo = 0u;                                      // an idle thread never wins (real keys have lo != 0)
+#pragma unroll
+        for (int i = 0; i < FPS_REG_PTS; ++i) {
+            const int k = tid + i * T;
+            if (k < n) {
+                const float d = i2p_sq3(px[i] - x1, py[i] - y1, pz[i] - z1);      // :132
+                const float d2 = fminf(d, td[i]);                                  // :133
+                td[i] = d2;
+                const unsigned hi = i2p_f2u(d2);
+                const bool take = (hi > bhi) || (hi == bhi && lo_k[i] > blo);
+                bhi = take ? hi : bhi; blo = take ? lo_k[i] : blo;
+            }
+        }
+        unsigned long long key = fps_row_max(bhi, blo);
+        {   // the four 16-lane rows of the wave
+            const unsigned h1 = __builtin_amdgcn_readlane((unsigned)(key >> 32), 16), l1 = __builtin_amdgcn_readlane((unsigned)key, 16);
+            const unsigned h2 = __builtin_amdgcn_readlane((unsigned)(key >> 32), 32), l2 = __builtin_amdgcn_readlane((unsigned)key, 32);
+            const unsigned h3 = __builtin_amdgcn_readlane((unsigned)(key >> 32), 48), l3 = __builtin_amdgcn_readlane((unsigned)key, 48);
+            const unsigned h0 = __builtin_amdgcn_readlane((unsigned)(key >> 32), 0), l0 = __builtin_amdgcn_readlane((unsigned)key, 0);
+            unsigned long long k0 = ((unsigned long long)h0 << 32) | l0, k1 = ((unsigned long long)h1 << 32) | l1;
+            unsigned long long k2 = ((unsigned long long)h2 << 32) | l2, k3 = ((unsigned long long)h3 << 32) | l3;
+            k0 = k0 > k1 ? k0 : k1; k2 = k2 > k3 ? k2 : k3;
+            key = k0 > k2 ? k0 : k2;                                       // wave-uniform
+        }
+        unsigned wlo = (unsigned)key;
+        if (T > I2P_WAVE) {
+            const int buf = j & 1;
+            if (lane == 0) s_key[buf][wv] = key;
+            __syncthreads();
+            unsigned long long ck = lane < (T / I2P_WAVE) ? s_key[buf][lane] : 0ull;   // lanes 0..15 = row 0
+            ck = fps_row_max((unsigned)(ck >> 32), (unsigned)ck);
+            wlo = __builtin_amdgcn_readlane((unsigned)ck, 0);
+        }
+        old = (int)((~wlo) & 0x1fffu);
+        if (tid == 0) idxs[j] = old;                                      // :205-207
+    }
+#pragma unroll
+    for (int i = 0; i < FPS_REG_PTS; ++i) {
+        const int k = tid + i * T;
+        if (k < n) temp[k] = td[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // gather_points (+grad) — sampling_gpu.cu:8-24 / :46-63.  One thread per output point walks
 // the channel chunk so idx is read once, stores are coalesced along M for every channel.
 // ------------------------------------------------------------------------------------------
@@ -302,7 +402,23 @@ extern "C" int i2p_furthest_point_sampling(int b, int n, int m, const float *dat
     int bs = 1 << pow_2;
     bs = bs > 1024 ? 1024 : bs; bs = bs < 1 ? 1 : bs;
     hipStream_t st = (hipStream_t)stream;
-    if (n <= FPS_THREADS * FPS_REG_PTS)
+    static const char *gen = getenv("I2P_FPS_GEN");                       // diagnostic: 1 = first-generation kernel
+    if (n <= FPS_THREADS * FPS_REG_PTS && !(gen && gen[0] == '1')) {
+        const size_t lds = (size_t)n * 3 * sizeof(float);
+        if (n <= 64 * FPS_REG_PTS) {
+            hipLaunchKernelGGL(fps_kernel_fast<64>, dim3(b), dim3(64), lds, st, n, m, bs, dataset, temp, idxs);
+        } else if (n <= 256 * FPS_REG_PTS) {
+            hipLaunchKernelGGL(fps_kernel_fast<256>, dim3(b), dim3(256), lds, st, n, m, bs, dataset, temp, idxs);
+        } else {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fps_kernel_fast<FPS_THREADS>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, FPS_THREADS * FPS_REG_PTS * 3 * (int)sizeof(float));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(fps_kernel_fast<FPS_THREADS>, dim3(b), dim3(FPS_THREADS), lds, st, n, m, bs, dataset, temp, idxs);
+        }
+    } else if (n <= FPS_THREADS * FPS_REG_PTS)
         hipLaunchKernelGGL(fps_kernel<true>, dim3(b), dim3(FPS_THREADS), 0, st, n, m, bs, dataset, temp, idxs);
     else
         hipLaunchKernelGGL(fps_kernel<false>, dim3(b), dim3(FPS_THREADS), 0, st, n, m, bs, dataset, temp, idxs);
