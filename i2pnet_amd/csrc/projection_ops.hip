@@ -170,6 +170,82 @@ __global__ __launch_bounds__(256) void knn_kernel(int n, int s, int k, const flo
     }
 }
 
+// Second-generation kNN: ONE scan of the cloud per query instead of k.  Every lane keeps the KT smallest keys of its
+// own points in a sorted register list; the k winners are then popped by k wave-wide minimum reductions (DPP, no LDS).
+// A lane whose list runs dry although it had to drop candidates re-scans its points above its last popped key
+// (rare: k/64 winners per lane on average).  Same keys, same total order, same output as knn_kernel.
+constexpr int KNN_KT = 4;
+
+template <int CTRL>
+__device__ __forceinline__ void knn_dpp_min(unsigned &hi, unsigned &lo) {
+    const unsigned ohi = i2p_dpp_u32<CTRL>(hi), olo = i2p_dpp_u32<CTRL>(lo);
+    const bool take = (ohi < hi) || (ohi == hi && olo < lo);
+    hi = take ? ohi : hi; lo = take ? olo : lo;
+}
+
+__device__ __forceinline__ unsigned long long knn_wave_min(unsigned long long key) {
+    unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+    knn_dpp_min<0xB1>(hi, lo); knn_dpp_min<0x4E>(hi, lo); knn_dpp_min<0x141>(hi, lo); knn_dpp_min<0x140>(hi, lo);
+    unsigned long long r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        r[q] = ((unsigned long long)__builtin_amdgcn_readlane(hi, 16 * q) << 32) | __builtin_amdgcn_readlane(lo, 16 * q);
+    const unsigned long long a = r[0] < r[1] ? r[0] : r[1], b = r[2] < r[3] ? r[2] : r[3];
+    return a < b ? a : b;
+}
+
+__global__ __launch_bounds__(256) void knn_kernel2(int n, int s, int k, const float *__restrict__ xyz,
+                                                   const float *__restrict__ new_xyz, int *__restrict__ idx) {
+    const int bi = blockIdx.y;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (qi >= s) return;
+    const float *q = new_xyz + ((size_t)bi * s + qi) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const float qq = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));
+    const float *src = xyz + (size_t)bi * n * 3;
+    int *o = idx + ((size_t)bi * s + qi) * k;
+
+    unsigned long long L[KNN_KT];
+    bool dropped = false;
+    unsigned long long mine = 0ull;                    // last key popped from THIS lane (valid once popped_any)
+    bool popped_any = false;
+    auto scan = [&]() {
+#pragma unroll
+        for (int i = 0; i < KNN_KT; ++i) L[i] = ~0ull;
+        dropped = false;
+        for (int j = lane; j < n; j += 64) {
+            const float d = knn_dist(qx, qy, qz, qq, src + (size_t)j * 3);
+            if (d != d) continue;                       // NaN never selected (as `<` in the oracle)
+            unsigned long long key = knn_key(d, j);
+            if (popped_any && key <= mine) continue;    // already delivered
+            if (key >= L[KNN_KT - 1]) { dropped = true; continue; }
+            if (L[KNN_KT - 1] != ~0ull) dropped = true; // the current tail falls off
+#pragma unroll
+            for (int i = 0; i < KNN_KT; ++i) {          // sorted insertion by a bubble of swaps
+                const unsigned long long cur = L[i];
+                const bool sw = key < cur;
+                L[i] = sw ? key : cur; key = sw ? cur : key;
+            }
+        }
+    };
+    scan();
+    for (int t = 0; t < k; ++t) {
+        const unsigned long long best = knn_wave_min(L[0]);
+        if (lane == 0) o[t] = (int)(unsigned)(best & 0xffffffffull);
+        if (L[0] == best && best != ~0ull) {            // the owning lane pops its head (keys are unique)
+            mine = best; popped_any = true;
+#pragma unroll
+            for (int i = 0; i + 1 < KNN_KT; ++i) L[i] = L[i + 1];
+            L[KNN_KT - 1] = ~0ull;
+        }
+        const bool need = (L[0] == ~0ull) && dropped;
+        if (__ballot(need) != 0ull) {
+            if (need) scan();
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int i2p_project_seq(int b, int n, int H, int W, float fup_deg, float fdown_deg,
@@ -241,8 +317,11 @@ extern "C" int i2p_knn(int b, int n, int s, int k, const float *xyz, const float
     if (b < 0 || n < 0 || s < 0 || k < 0 || k > n) return I2P_ERR_BAD_ARG;
     if ((long long)b * s == 0 || k == 0) return 0;
     if (!xyz || !new_xyz || !idx) return I2P_ERR_BAD_ARG;
-    hipLaunchKernelGGL(knn_kernel, dim3((s + 3) / 4, b), dim3(256), 0, (hipStream_t)stream, n, s, k, xyz,
-                       new_xyz, idx);
+    static const char *gen = getenv("I2P_KNN_GEN");                        // diagnostic: 1 = first-generation kernel
+    if (gen && gen[0] == '1')
+        hipLaunchKernelGGL(knn_kernel, dim3((s + 3) / 4, b), dim3(256), 0, (hipStream_t)stream, n, s, k, xyz, new_xyz, idx);
+    else
+        hipLaunchKernelGGL(knn_kernel2, dim3((s + 3) / 4, b), dim3(256), 0, (hipStream_t)stream, n, s, k, xyz, new_xyz, idx);
     I2P_RETURN_LAUNCH_STATUS();
 }
 

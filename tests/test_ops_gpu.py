@@ -203,6 +203,26 @@ def test_knn_parity(oracle_backend, hip_backend):
         assert torch.equal(ri, gi.cpu())
 
 
+def test_knn_refill_and_nan(oracle_backend, hip_backend):
+    """second-generation kNN: every near neighbour in ONE lane's slice (indices = 0 mod 64) forces the per-lane
+    re-scan path; NaN points are never selected; large cloud."""
+    g = torch.Generator().manual_seed(12)
+    B, N, S, k = 2, 4096, 37, 32
+    xyz = (torch.rand(B, N, 3, generator=g) - 0.5) * 100
+    q = (torch.rand(B, S, 3, generator=g) - 0.5) * 2
+    xyz[:, ::64] = (torch.rand(B, N // 64, 3, generator=g) - 0.5) * 2           # the 64 closest points share a lane
+    xyz[0, 5] = float("nan"); xyz[1, 64 * 3, 1] = float("nan")
+    ri = torch.empty(B, S, k, dtype=torch.int32); gi = torch.empty(B, S, k, dtype=torch.int32, device=DEV)
+    oracle_backend.knn(xyz, q, k, ri); hip_backend.knn(xyz.to(DEV), q.to(DEV), k, gi)
+    assert torch.equal(ri, gi.cpu())
+    assert int((ri % 64 == 0).sum()) > 0.9 * ri.numel()
+    B, N, S, k = 1, 8192, 300, 32
+    xyz = (torch.rand(B, N, 3, generator=g) - 0.5) * 60; q = xyz[:, :S].clone()
+    ri = torch.empty(B, S, k, dtype=torch.int32); gi = torch.empty(B, S, k, dtype=torch.int32, device=DEV)
+    oracle_backend.knn(xyz, q, k, ri); hip_backend.knn(xyz.to(DEV), q.to(DEV), k, gi)
+    assert torch.equal(ri, gi.cpu())
+
+
 def test_quat_mul_parity(oracle_backend, hip_backend):
     g = torch.Generator().manual_seed(5)
     for na, nb in [(1, 1), (1, 1440), (1440, 1), (1440, 1440)]:
