@@ -43,6 +43,7 @@ SIGNATURES = {
     "i2p_lin_bwd_2src": ["l", "i", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 3 + ["f"] + ["p"] * 8,
     "i2p_bn_act_maxk_fwd": ["l", "i", "i", "p", "p", "f", "p", "p"],
     "i2p_unpool_k": ["l", "i", "i", "p", "p", "p"],
+    "i2p_pose_loss": ["i", "i"] + ["p"] * 10,
     "i2p_pair_bias_bn_bwd": ["i"] * 4 + ["p"] * 10,
     "i2p_cv_softmax_wsum_fwd": ["i"] * 4 + ["p", "p", "f", "p", "p", "f", "p", "p"],
     "i2p_cv_softmax_wsum_bwd": ["i"] * 4 + ["p"] * 6 + ["f", "p", "p", "f", "p", "p", "p"],

@@ -451,3 +451,73 @@ extern "C" int i2p_row_unitvar_bwd(int rows, int c, const float *gy, const float
     hipLaunchKernelGGL(row_unitvar_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, c, gy, y, stat, gx);
     I2P_RETURN_LAUNCH_STATUS();
 }
+
+/* -------------------------------------------------------------------------------------------
+ * Learned-uncertainty pose loss and its gradient in one launch — compute_loss.py:102-133 (`Get_loss`):
+ *   per level L (coarse = out4, weight 1.6; fine = out3, weight 0.8):
+ *     lq = mean_b sqrt(sum_4 (q_gt - q)^2 + 1e-10),  lx = mean |t - t_gt| (l1) or mean_b sqrt(sum_3 (t - t_gt)^2 + 1e-10)
+ *     l  = lx*exp(-w_x) + w_x + lq*exp(-w_q) + w_q
+ *   loss3 = {1.6 l_c + 0.8 l_f, 1.6 lq_c + 0.8 lq_f, 1.6 lx_c + 0.8 lx_f}
+ * (eager PyTorch: 28 launches forward, 36 backward, all on [B,7] tensors).  One block; B <= 1024.
+ * ------------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__(64) void pose_loss_kernel(int B, int l1, const float *__restrict__ out3,
+                                                        const float *__restrict__ out4, const float *__restrict__ qgt,
+                                                        const float *__restrict__ tgt, const float *__restrict__ wx,
+                                                        const float *__restrict__ wq, float *__restrict__ loss3,
+                                                        float *__restrict__ d_out3, float *__restrict__ d_out4,
+                                                        float *__restrict__ d_w) {
+    const int lane = threadIdx.x;
+    const float ex = expf(-wx[0]), eq = expf(-wq[0]);
+    float lq[2] = {0.f, 0.f}, lx[2] = {0.f, 0.f};               // 0 = coarse (out4), 1 = fine (out3)
+    for (int b = lane; b < B; b += 64) {
+#pragma unroll
+        for (int L = 0; L < 2; ++L) {
+            const float *o = (L == 0 ? out4 : out3) + (size_t)b * 7;
+            float *d = (L == 0 ? d_out4 : d_out3) + (size_t)b * 7;
+            const float wL = L == 0 ? 1.6f : 0.8f;
+            float dq[4], s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dq[i] = qgt[b * 4 + i] - o[i]; s += dq[i] * dq[i]; }
+            const float nq = sqrtf(s + 1e-10f);
+            lq[L] += nq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = wL * eq * (-dq[i] / nq) / (float)B;
+            float dt[3], st = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { dt[i] = o[4 + i] - tgt[b * 3 + i]; st += dt[i] * dt[i]; }
+            if (l1) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    lx[L] += fabsf(dt[i]);
+                    d[4 + i] = wL * ex * (dt[i] > 0.f ? 1.f : (dt[i] < 0.f ? -1.f : 0.f)) / (float)(3 * B);
+                }
+            } else {
+                const float nt = sqrtf(st + 1e-10f);
+                lx[L] += nt;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) d[4 + i] = wL * ex * (dt[i] / nt) / (float)B;
+            }
+        }
+    }
+#pragma unroll
+    for (int L = 0; L < 2; ++L) { lq[L] = wave_sum(lq[L]) / (float)B; lx[L] = wave_sum(lx[L]) / (float)(l1 ? 3 * B : B); }
+    if (lane == 0) {
+        const float lc = lx[0] * ex + wx[0] + lq[0] * eq + wq[0], lf = lx[1] * ex + wx[0] + lq[1] * eq + wq[0];
+        loss3[0] = 1.6f * lc + 0.8f * lf;
+        loss3[1] = 1.6f * lq[0] + 0.8f * lq[1];
+        loss3[2] = 1.6f * lx[0] + 0.8f * lx[1];
+        d_w[0] = 1.6f * (1.f - lx[0] * ex) + 0.8f * (1.f - lx[1] * ex);       // d loss / d w_x
+        d_w[1] = 1.6f * (1.f - lq[0] * eq) + 0.8f * (1.f - lq[1] * eq);       // d loss / d w_q
+    }
+}
+
+extern "C" int i2p_pose_loss(int B, int l1_trans, const float *out3, const float *out4, const float *q_gt, const float *t_gt,
+                             const float *w_x, const float *w_q, float *loss3, float *d_out3, float *d_out4, float *d_w,
+                             void *stream) {
+    if (B <= 0 || B > 1024) return I2P_ERR_BAD_ARG;
+    if (!out3 || !out4 || !q_gt || !t_gt || !w_x || !w_q || !loss3 || !d_out3 || !d_out4 || !d_w) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pose_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, B, l1_trans, out3, out4, q_gt, t_gt, w_x, w_q,
+                       loss3, d_out3, d_out4, d_w);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+

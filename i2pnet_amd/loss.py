@@ -1,11 +1,36 @@
 """Learned-uncertainty pose loss (reference: compute_loss.py:102-133, `Get_loss`)."""
 import torch
 
+from . import ops
+
+USE_FUSED_LOSS = True       # one HIP launch for the loss and its gradient (False: the torch formulation below)
+
+
+class _PoseLoss(torch.autograd.Function):
+    """loss and dloss/d(out3, out4, w_x, w_q) from one launch of `pose_loss_kernel` (csrc/projection_ops.hip); the
+    rotation / translation parts are returned for logging only (not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, out3, out4, q_gt, t_gt, w_x, w_q, l1):
+        f = lambda t: t.detach().float().contiguous()
+        loss3, d3, d4, d_w = ops.get_backend().pose_loss(f(out3), f(out4), f(q_gt), f(t_gt), f(w_x), f(w_q), l1)
+        ctx.save_for_backward(d3, d4, d_w)
+        real, dual = loss3[1:2], loss3[2:3]
+        ctx.mark_non_differentiable(real, dual)
+        return loss3[0:1], real, dual
+
+    @staticmethod
+    def backward(ctx, g, _g_real, _g_dual):
+        d3, d4, d_w = ctx.saved_tensors
+        return d3 * g, d4 * g, None, None, d_w[0:1] * g, d_w[1:2] * g, None
+
 
 def Get_loss(out3, out4, qq_gt, t_gt, w_x, w_q, cfg):
-    """-> (loss, rotation part, translation part); weights 0.8 on the fine pose `out3`,
-    1.6 on the coarse pose `out4` (compute_loss.py:127-130).  Both poses are evaluated in one stacked
-    pass ([2,B,7]) — the same arithmetic per element as the reference's two calls, half the launches."""
+    """-> (loss [1], rotation part, translation part); weights 0.8 on the fine pose `out3`, 1.6 on the coarse pose
+    `out4` (compute_loss.py:127-130)."""
+    B = out3.shape[0]
+    if USE_FUSED_LOSS and B <= 1024 and out3.dtype == torch.float32:
+        return _PoseLoss.apply(out3, out4, qq_gt, t_gt, w_x, w_q, bool(cfg.l1_trans_loss))
     out = torch.stack([out4, out3])                                    # [2,B,7]: coarse, fine
     dq = qq_gt.unsqueeze(0) - out[:, :, :4]
     loss_q = torch.sqrt(torch.sum(dq * dq, dim=-1) + 1e-10).mean(dim=1)             # [2]  compute_loss.py:112

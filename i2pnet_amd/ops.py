@@ -471,6 +471,18 @@ class CBackend:
                    stream=self._stream())
         return d_n, d_k
 
+    def pose_loss(self, out3, out4, q_gt, t_gt, w_x, w_q, l1_trans):
+        """-> (loss3 [3], d_out3 [B,7], d_out4 [B,7], d_w [2]); compute_loss.py:102-133"""
+        B = out3.shape[0]
+        dev = out3.device
+        loss3 = torch.empty(3, dtype=_F32, device=dev); d_w = torch.empty(2, dtype=_F32, device=dev)
+        d3 = torch.empty(B, 7, dtype=_F32, device=dev); d4 = torch.empty(B, 7, dtype=_F32, device=dev)
+        self._call("i2p_pose_loss", int(B), int(bool(l1_trans)), self._p(out3, _F32, "out3"), self._p(out4, _F32, "out4"),
+                   self._p(q_gt, _F32, "q_gt"), self._p(t_gt, _F32, "t_gt"), self._p(w_x, _F32, "w_x"), self._p(w_q, _F32, "w_q"),
+                   self._p(loss3, _F32, "loss3"), self._p(d3, _F32, "d_out3"), self._p(d4, _F32, "d_out4"), self._p(d_w, _F32, "d_w"),
+                   stream=self._stream())
+        return loss3, d3, d4, d_w
+
     def bn_finalize(self, rows, sums, gamma, beta, eps):
         """-> (coef [3,c] = mean, invstd*gamma, beta ; mean_invstd [2c])"""
         c = gamma.shape[0]

@@ -341,6 +341,14 @@ int i2p_pair_bias_bn_bwd(int B, int N, int M, int C, const float *gz, const floa
                          const double *dsums, const float *coef, const float *mi, float *sum_k, float *sum_n,
                          float *d_enc_n, float *d_enc_k, void *stream);
 
+/* Learned-uncertainty pose loss (compute_loss.py:102-133 `Get_loss`) and its gradient in one launch:
+ *   out3 (fine), out4 (coarse) f32 [B,7] = (q[4], t[3]); q_gt f32 [B,4]; t_gt f32 [B,3]; w_x, w_q f32 [1] (the learned
+ *   log-uncertainties sx, sq); l1_trans: translation term is mean |dt| (cfg.l1_trans_loss) else mean ||dt||.
+ *   loss3 f32 [3] = {loss, rotation part, translation part}; d_out3, d_out4 f32 [B,7] = dloss/dout; d_w f32 [2] =
+ *   {dloss/dw_x, dloss/dw_q}.  B <= 1024. */
+int i2p_pose_loss(int B, int l1_trans, const float *out3, const float *out4, const float *q_gt, const float *t_gt,
+                  const float *w_x, const float *w_q, float *loss3, float *d_out3, float *d_out4, float *d_w, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,6 +223,18 @@ def test_knn_refill_and_nan(oracle_backend, hip_backend):
     assert torch.equal(ri, gi.cpu())
 
 
+def test_pose_loss_parity(oracle_backend, hip_backend):
+    g = torch.Generator().manual_seed(8)
+    for B, l1 in [(8, True), (8, False), (100, True), (1, True)]:
+        o3, o4 = torch.randn(B, 7, generator=g), torch.randn(B, 7, generator=g)
+        qg, tg = torch.randn(B, 4, generator=g), torch.randn(B, 3, generator=g)
+        wx, wq = torch.tensor([0.2]), torch.tensor([-2.5])
+        r = oracle_backend.pose_loss(o3, o4, qg, tg, wx, wq, l1)
+        h = hip_backend.pose_loss(*[t.to(DEV) for t in (o3, o4, qg, tg, wx, wq)], l1)
+        for a, b in zip(r, h):
+            assert torch.allclose(a, b.cpu(), rtol=1e-5, atol=1e-6)
+
+
 def test_quat_mul_parity(oracle_backend, hip_backend):
     g = torch.Generator().manual_seed(5)
     for na, nb in [(1, 1), (1, 1440), (1440, 1), (1440, 1440)]:

@@ -408,3 +408,33 @@ def test_softmax_pool_matches_torch(oracle_backend):
         assert torch.allclose(m1.grad, m2.grad, rtol=1e-4, atol=1e-6)
     finally:
         ops.set_backend(prev)
+
+
+@pytest.mark.parametrize("l1", [True, False])
+def test_pose_loss_oracle_vs_torch(oracle_backend, l1):
+    """fused pose loss (value + gradient in one call) == the torch formulation of compute_loss.py:102-133 and its
+    autograd, for both translation terms"""
+    from i2pnet_amd import loss as L, ops
+
+    class Cfg:
+        l1_trans_loss = l1
+    g = torch.Generator().manual_seed(4)
+    B = 5
+    o3, o4 = torch.randn(B, 7, generator=g), torch.randn(B, 7, generator=g)
+    qg, tg = torch.randn(B, 4, generator=g), torch.randn(B, 3, generator=g)
+    prev = ops.set_backend(oracle_backend)
+    try:
+        res = []
+        for fused in (True, False):
+            L.USE_FUSED_LOSS = fused
+            a3, a4 = o3.clone().requires_grad_(), o4.clone().requires_grad_()
+            wx, wq = torch.tensor([0.3], requires_grad=True), torch.tensor([-2.5], requires_grad=True)
+            loss, real, dual = L.Get_loss(a3, a4, qg, tg, wx, wq, Cfg)
+            (loss * 1.7).sum().backward()
+            res.append((loss.detach(), real.detach().reshape(-1), dual.detach().reshape(-1), a3.grad, a4.grad, wx.grad, wq.grad))
+    finally:
+        L.USE_FUSED_LOSS = True
+        ops.set_backend(prev)
+    for a, b in zip(*res):
+        assert a.shape == b.shape or a.numel() == b.numel()
+        assert torch.allclose(a.reshape(-1), b.reshape(-1), rtol=1e-5, atol=1e-6)

@@ -36,6 +36,12 @@ def main():
         mod.forward = f
     for name, mod in tr.net.named_children():
         wrap(name, mod)
+    fc = tr.net.LiDAR_lv1.forward_center
+
+    def fc_wrapped(*x, **k):
+        with record_function("M:LiDAR_lv1"):
+            return fc(*x, **k)
+    tr.net.LiDAR_lv1.forward_center = fc_wrapped
     import i2pnet_amd.warp as W
     for fn in ("mul_q", "inv_q", "warp_quat_xyz"):
         orig = getattr(W, fn)
