@@ -316,8 +316,7 @@ __global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(L
     constexpr int F2_CH = CH;
     extern __shared__ float smem[];
     const int ldk = p.ldk;                                  // max(cin, cout_p) + 2 (8-byte aligned rows), or + 4 (16-byte, wide-K path)
-    // (forward / pair instantiations only: the dgrad instantiation is register-bound and keeps the narrow loop)
-    const bool wide_k = !DGRAD && ((p.cin & 15) == 0) && ((ldk & 3) == 0) && !(p.ablate & 16);
+    const bool wide_k = ((p.cin & 15) == 0) && ((ldk & 3) == 0) && !(p.ablate & 16);
     float *Ws = smem;                                       // [cout_p][ldk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *As = smem + (size_t)p.cout_p * ldk + (size_t)wave * F2_ROWS * ldk;   // this wave's strip
@@ -374,15 +373,23 @@ __global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(L
 
     // ---- per-lane chunk geometry, fixed for the whole kernel -----------------------------------------
     const int c4n = p.cin >> 2, nchunk = F2_ROWS * c4n;
-    int in_r[F2_CH], in_c4[F2_CH];
-    bool in_ok[F2_CH];
+    // (dgrad: cin/4 is a power of two dividing 64, so the geometry is two shifts of the lane id — keeping the three
+    //  arrays in registers is what pushed the dgrad instantiation into spilling)
+    int in_r_[DGRAD ? 1 : F2_CH], in_c4_[DGRAD ? 1 : F2_CH];
+    bool in_ok_[DGRAD ? 1 : F2_CH];
+    const int c4_shift = 31 - __clz(c4n);
+    if (!DGRAD) {
 #pragma unroll
-    for (int u = 0; u < F2_CH; ++u) {
-        const int i = lane + u * 64;
-        in_ok[u] = i < nchunk;
-        const int ic = in_ok[u] ? i : nchunk - 1;
-        in_r[u] = ic / c4n; in_c4[u] = ic - in_r[u] * c4n;
-    }
+        for (int u = 0; u < (DGRAD ? 1 : F2_CH); ++u) {
+            const int i = lane + u * 64;
+            in_ok_[u] = i < nchunk;
+            const int ic = in_ok_[u] ? i : nchunk - 1;
+            in_r_[u] = ic / c4n; in_c4_[u] = ic - in_r_[u] * c4n;
+        }
+    } else { in_r_[0] = 0; in_c4_[0] = lane & (c4n - 1); in_ok_[0] = true; }
+    auto IR = [&](int u) -> int { if (DGRAD) { const int r = (lane + u * 64) >> c4_shift; return r < F2_ROWS ? r : F2_ROWS - 1; } return in_r_[u]; };
+    auto IC = [&](int u) -> int { return DGRAD ? in_c4_[0] : in_c4_[u]; };
+    auto IOK = [&](int u) -> bool { return DGRAD ? (lane + u * 64) < nchunk : in_ok_[u]; };
     const int o4n = p.cout >> 2;                            // 4, 8, 16 or 32 (launcher): divides 64
     const int o_shift = 31 - __clz(o4n);
     const int o_c4 = lane & (o4n - 1);                      // this lane's 4 output channels in the store phase
@@ -390,10 +397,10 @@ __global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(L
 
     // BN coefficients of the input chunks (loaded once; 3 float4 per chunk slot when they differ per slot)
     // input source of this lane (its channel set is the same in every chunk slot)
-    const bool in_b = !DGRAD && p.xb && in_c4[0] * 4 >= p.split_c;
+    const bool in_b = !DGRAD && p.xb && IC(0) * 4 >= p.split_c;
     const float *src_x = in_b ? p.xb : p.x;
     const int src_ld = (!DGRAD && p.xb) ? (in_b ? p.cin - p.split_c : p.split_c) : p.cin;
-    const int src_c0 = in_b ? in_c4[0] * 4 - p.split_c : in_c4[0] * 4;
+    const int src_c0 = in_b ? IC(0) * 4 - p.split_c : IC(0) * 4;
     const float *src_coef = in_b ? p.in_coef_b : p.in_coef;
     const float in_slope = in_b ? p.slope_b : p.slope_in;
     float4 cm = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(1.f, 1.f, 1.f, 1.f), cb = cm;
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(L
 
     // dgrad: BN-backward constants of this lane's input channels, and of its output channels for the store phase
     const bool g_act = DGRAD && p.g_coef && p.g_slope != 1.f;
-    const float *g_tab = Gt + in_c4[0] * 4;                 // this lane's input channels (same in every chunk slot)
+    const float *g_tab = Gt + IC(0) * 4;                 // this lane's input channels (same in every chunk slot)
     // output destination of this lane's 4 channels (DGRAD two-destination mode splits the columns)
     const bool out_b = DGRAD && p.yb && (p.ch_off + o_c4 * 4) >= p.split_c;
     float *dst_y = out_b ? p.yb : p.y;
@@ -435,14 +442,14 @@ __global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(L
         if (PAIR) pt = pair_tile(row0, p.pair_N, p.pair_M);
 #pragma unroll
         for (int u = 0; u < F2_CH; ++u) {
-            long long row = row0 + in_r[u];
-            int d = in_r[u];
+            long long row = row0 + IR(u);
+            int d = IR(u);
             if (row > last_row) { d = (int)(last_row - row0); row = last_row; }
             long long src = row;
             if (PAIR) { int bn, bk; pair_row16(pt, d, p.pair_N, p.pair_M, bn, bk); src = bk; }
             // (two-source mode requires one channel set per lane; plain mode takes the slot's own column)
-            v[u] = *reinterpret_cast<const float4 *>(src_x + (size_t)src * src_ld + ((!DGRAD && p.xb) ? src_c0 : in_c4[u] * 4));
-            if (DGRAD && p.g_coef) v2[u] = *reinterpret_cast<const float4 *>(p.x2 + (size_t)src * p.cin + in_c4[u] * 4);
+            v[u] = *reinterpret_cast<const float4 *>(src_x + (size_t)src * src_ld + ((!DGRAD && p.xb) ? src_c0 : IC(u) * 4));
+            if (DGRAD && p.g_coef) v2[u] = *reinterpret_cast<const float4 *>(p.x2 + (size_t)src * p.cin + IC(u) * 4);
         }
     };
 
@@ -458,10 +465,10 @@ __global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(L
         for (int u = 0; u < F2_CH; ++u) {
             float4 t = v[u];
             if (PAIR) {
-                int d = in_r[u];
+                int d = IR(u);
                 if (row0 + d > last_row) d = (int)(last_row - row0);
                 int bn, bk; pair_row16(pt, d, p.pair_N, p.pair_M, bn, bk);
-                const float4 f = *reinterpret_cast<const float4 *>(p.pair_f + (size_t)bn * p.cin + in_c4[u] * 4);
+                const float4 f = *reinterpret_cast<const float4 *>(p.pair_f + (size_t)bn * p.cin + IC(u) * 4);
                 t.x *= f.x; t.y *= f.y; t.z *= f.z; t.w *= f.w;
             }
             if (DGRAD && p.g_coef) {                        // BN backward of the layer behind, formed on load
@@ -487,8 +494,8 @@ __global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(L
                 t.z = act_apply((t.z - m.z) * sc.z + bb.z, in_slope);
                 t.w = act_apply((t.w - m.w) * sc.w + bb.w, in_slope);
             }
-            if (in_ok[u]) {
-                float2 *dst = reinterpret_cast<float2 *>(As + in_r[u] * ldk + in_c4[u] * 4);
+            if (IOK(u)) {
+                float2 *dst = reinterpret_cast<float2 *>(As + IR(u) * ldk + IC(u) * 4);
                 dst[0] = make_float2(t.x, t.y); dst[1] = make_float2(t.z, t.w);
             }
         }
@@ -1751,7 +1758,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
             if (gz_in) {
                 LinFwdParams q;
                 q.rows = rows; q.cin = cout; q.cout = cin; q.cin_p = cout; q.cout_p = cin;
-                q.ldk = (cout > cin ? cout : cin) + 2;
+                q.ldk = (cout > cin ? cout : cin) + ((cout & 15) == 0 ? 4 : 2);      // +4: 16-byte rows for the wide-K fragments
                 q.x = gz; q.x2 = y; q.g_coef = g_coef; q.g_slope = p.slope_out; q.in_coef = nullptr; q.slope_in = 1.f;
                 q.w = w; q.w_transposed = 1; q.y = gz_in; q.sums = in_coef ? in_dsums : nullptr;
                 q.y_ld = cin; q.ch_off = 0; q.cout_total = cin; q.ablate = 0;
