@@ -49,6 +49,7 @@ struct LinFwdParams {
     //   input row = pair_f[b,n,:] * x[b,k,:]   (x is then the [B,M,cin] pixel tensor)
     //   y[r,:]   += bias_n[b,n,:] + bias_k[b,k,:]
     int w_vec;              // w is 16-byte aligned (set by the launcher): float4 weight staging
+    int nslice;             // output-channel slices over blockIdx.y (small layers; set by the launcher)
     int ablate;             // diagnostic only (I2P_LIN_ABLATE): 1 no MFMA loop, 2 no stores, 4 no stats, 8 no staging
     const float *pair_f;    // [B,N,cin] or nullptr (plain mode)
     const float *bias_n;    // [B,N,cout_total] or nullptr
@@ -312,8 +313,17 @@ __device__ __forceinline__ void pair_row16(const PairTile &t, int d, int N, int 
 // channels) carry half the prefetch / output registers of the 128-wide ones and run 4 waves per SIMD instead of 2
 // (they are HBM-bound: more loads in flight, not more math, is what they need).
 template <int NT16, bool PAIR, bool DGRAD, int CH>
-__global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(LinFwdParams p) {
+__global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(LinFwdParams p_in) {
     constexpr int F2_CH = CH;
+    // Small layers (a few thousand rows) would leave most CUs idle and put a whole 16 x cout strip on one wave
+    // (256 dependent-issue MFMAs = 3.4 us for 128 x 128): the launcher then splits the OUTPUT channels over
+    // blockIdx.y — each slice is the same kernel on cout/nslice columns (its own weights rows, ch_off, statistics).
+    LinFwdParams p = p_in;
+    if (p.nslice > 1) {
+        const int sl = blockIdx.y;
+        p.ch_off += sl * p.cout;
+        if (!(DGRAD && p.w_transposed)) p.w += (size_t)sl * p.cout * p.cin;
+    }
     extern __shared__ float smem[];
     const int ldk = p.ldk;                                  // max(cin, cout_p) + 2 (8-byte aligned rows), or + 4 (16-byte, wide-K path)
     const bool wide_k = ((p.cin & 15) == 0) && ((ldk & 3) == 0) && !(p.ablate & 16);
@@ -693,13 +703,23 @@ int launch_fwd2(const LinFwdParams &p, hipStream_t st) {
     const long long cap = 256LL * (per_cu > 2 ? 2 : per_cu);
     const unsigned grid = (unsigned)(g < cap ? (g < 1 ? 1 : g) : cap);
     LinFwdParams q = p;
-    q.w_vec = ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0 && (p.cin & 3) == 0 && (p.cout_total & 3) == 0 && (p.ch_off & 3) == 0) ? 1 : 0;
-    hipLaunchKernelGGL((lin_fwd2_kernel<NT16, PAIR, DGRAD, CH>), dim3(grid), dim3(F2_THREADS), bytes, st, q);
+    q.w_vec = ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0 && (p.cin & 3) == 0 && (p.cout_total & 3) == 0 && (p.ch_off & 3) == 0 &&
+               (p.cout & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((lin_fwd2_kernel<NT16, PAIR, DGRAD, CH>), dim3(grid, p.nslice > 1 ? p.nslice : 1), dim3(F2_THREADS), bytes, st, q);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
 template <bool PAIR, bool DGRAD>
-int dispatch_fwd2(const LinFwdParams &p, hipStream_t st) {
+int dispatch_fwd2(const LinFwdParams &p_in, hipStream_t st) {
+    LinFwdParams p = p_in;
+    p.nslice = 1;
+    {   // small layers: slice the output channels over blockIdx.y until ~256 blocks exist (slices stay >= 16 wide)
+        static const char *env = getenv("I2P_LIN_SLICE");   // diagnostic: 0 = never slice
+        const long long g = ((p.rows + F2_ROWS - 1) / F2_ROWS + 7) / 8;
+        int S = 1;
+        while (!(env && env[0] == '0') && g * S < 192 && p.cout / (2 * S) >= 16 && ((p.cout / (2 * S)) & 15) == 0) S *= 2;
+        if (S > 1) { p.nslice = S; p.cout /= S; p.cout_p = p.cout; }
+    }
     const int wide = p.cin > p.cout ? p.cin : p.cout;      // channels a strip row holds (input and output phases)
     static const char *env = getenv("I2P_LIN_CH");          // diagnostic: 8 = always the wide instantiation
     const bool narrow_ok = !PAIR && !(env && env[0] == '8');
