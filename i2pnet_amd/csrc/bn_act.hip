@@ -92,9 +92,14 @@ __global__ __launch_bounds__(THREADS) void bn_act_fwd_v4(long long rows, int c, 
                                                           float4 *__restrict__ out,
                                                           float *__restrict__ mean_invstd) {
     const int vcol = threadIdx.x % g.cv, rsub = threadIdx.x / g.cv;
+    // per-channel constants once per BLOCK (the replica reduction is 64 fp64 loads per channel: done per thread it
+    // cost ~90 us of L2 traffic on every launch with >= 2048 blocks, whatever the tensor size)
+    __shared__ ChanCoef s_k[1024];            // c <= 4 * THREADS (vec_ok)
+    for (int ch = threadIdx.x; ch < c; ch += THREADS) s_k[ch] = coef_from_sums(sums, c, ch, rows, gamma, beta, eps);
+    __syncthreads();
     ChanCoef k[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) k[i] = coef_from_sums(sums, c, vcol * 4 + i, rows, gamma, beta, eps);
+    for (int i = 0; i < 4; ++i) k[i] = s_k[vcol * 4 + i];
     if (blockIdx.x == 0 && rsub == 0)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { mean_invstd[vcol * 4 + i] = k[i].mean; mean_invstd[c + vcol * 4 + i] = k[i].invstd; }
@@ -180,6 +185,13 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_v4(long long rows, int c, 
                                                           float4 *__restrict__ dy, float *__restrict__ dgamma,
                                                           float *__restrict__ dbeta) {
     const int vcol = threadIdx.x % g.cv, rsub = threadIdx.x / g.cv;
+    __shared__ float s_m1[1024], s_m2[1024];               // replica sums reduced once per block (see bn_act_fwd_v4)
+    for (int ch = threadIdx.x; ch < c; ch += THREADS) {
+        const double sd = rep_sum(dsums, c, ch), sx = rep_sum(dsums, c, c + ch);
+        s_m1[ch] = (float)(sd / (double)rows); s_m2[ch] = (float)(sx / (double)rows);
+        if (blockIdx.x == 0) { dbeta[ch] = (float)sd; dgamma[ch] = (float)sx; }
+    }
+    __syncthreads();
     BwdCoef k[4];
     float m1[4], m2[4];
 #pragma unroll
@@ -187,9 +199,7 @@ __global__ __launch_bounds__(THREADS) void bn_act_bwd_v4(long long rows, int c, 
         const int ch = vcol * 4 + i;
         k[i].mean = mean_invstd[ch]; k[i].invstd = mean_invstd[c + ch];
         k[i].scale = k[i].invstd * gamma[ch]; k[i].beta = beta[ch];
-        const double sd = rep_sum(dsums, c, ch), sx = rep_sum(dsums, c, c + ch);
-        m1[i] = (float)(sd / (double)rows); m2[i] = (float)(sx / (double)rows);
-        if (blockIdx.x == 0 && rsub == 0) { dbeta[ch] = (float)sd; dgamma[ch] = (float)sx; }
+        m1[i] = s_m1[ch]; m2[i] = s_m2[ch];
     }
     for (long long r = (long long)blockIdx.x * g.rpb + rsub; r < rows; r += (long long)gridDim.x * g.rpb) {
         const float4 v = y[r * g.cv + vcol], go = dout[r * g.cv + vcol];

@@ -1,0 +1,17 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+rm -rf /tmp/tr; rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/tr.log 2>&1
+f=$(find /tmp/tr -name '*kernel_trace.csv' | head -1)
+python - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+marks = [i for i, r in enumerate(rows) if "proj_assign_kernel" in r["Kernel_Name"]]
+a, b = marks[5], marks[6]            # one graph-replayed training step
+for r in rows[a:b]:
+    n = r["Kernel_Name"]
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    if ("bn_act_fwd_v4" in n or "bn_act_bwd_v4" in n or "direct_copy" in n or "FillFunctor" in n) and d > 25:
+        g = [r.get(k) for k in r if "Grid" in k or "Workgroup" in k]
+        print(f"{d:8.1f} us {g} {n[:60]}")
+PY
