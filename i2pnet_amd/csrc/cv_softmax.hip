@@ -95,19 +95,20 @@ __global__ __launch_bounds__(THREADS) void sm_bwd_kernel(SmParams p) {
 // the [B,N,C] / [B,M,C] factors (sum_k xhat = invstd*(M*enc_n + sum_k enc_k - M*mean)): the [B,N,M,C]
 // gradient of ye is never written and never re-read by two reductions.
 // ---------------------------------------------------------------------------------------------------
-constexpr int PS_NL = 8;          // point rows per block
+constexpr int PS_NL = 16;         // point rows per block (halves the sum_n atomics of 8)
 
 __global__ __launch_bounds__(THREADS) void pair_sum_kernel(int B, int N, int M, int C, const float4 *__restrict__ g,
                                                             float *__restrict__ sum_k, float *__restrict__ sum_n) {
-    __shared__ float4 red[THREADS][PS_NL];                     // 32 KB
+    __shared__ float4 red[THREADS][PS_NL];                     // 64 KB
     const int cv = C >> 2, ks = THREADS / cv;                   // k-slots per block
     const int c4 = threadIdx.x % cv, kslot = threadIdx.x / cv;
     const int chunks = (N + PS_NL - 1) / PS_NL;
     const int b = blockIdx.x / chunks, n0 = (blockIdx.x - b * chunks) * PS_NL;
+    const int kseg = (M + gridDim.y - 1) / gridDim.y, k_lo = blockIdx.y * kseg, k_hi = min(M, k_lo + kseg);
     float4 acc[PS_NL];
 #pragma unroll
     for (int j = 0; j < PS_NL; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = kslot; k < M; k += ks) {
+    for (int k = k_lo + kslot; k < k_hi; k += ks) {
         float4 v[PS_NL];
 #pragma unroll
         for (int j = 0; j < PS_NL; ++j) {
@@ -131,7 +132,8 @@ __global__ __launch_bounds__(THREADS) void pair_sum_kernel(int B, int N, int M, 
         if (n0 + j >= N) continue;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int q = 0; q < ks; ++q) { const float4 r = red[q * cv + c][j]; a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
-        *reinterpret_cast<float4 *>(sum_k + ((size_t)b * N + n0 + j) * C + c * 4) = a;
+        float *dk = sum_k + ((size_t)b * N + n0 + j) * C + c * 4;               // k-range slices add up (zeroed by the caller)
+        atomicAdd(dk + 0, a.x); atomicAdd(dk + 1, a.y); atomicAdd(dk + 2, a.z); atomicAdd(dk + 3, a.w);
     }
 }
 
@@ -151,9 +153,21 @@ __global__ __launch_bounds__(THREADS) void pair_bias_bn_bwd_kernel(int B, int N,
     const int b = blockIdx.x / PB_SLICES, slice = blockIdx.x % PB_SLICES;
     const int G = THREADS / C, grp = threadIdx.x / C, c0 = threadIdx.x % C;      // C divides THREADS
     const double rows = (double)B * N * M;
-    float ek = 0.f, en = 0.f;
-    for (int k = grp; k < M; k += G) ek += enc_k[((size_t)b * M + k) * C + c0];
-    for (int n = grp; n < N; n += G) en += enc_n[((size_t)b * N + n) * C + c0];
+    // 8 independent loads in flight per thread (a plain `e += x[k]` loop issued them one L2 latency apart: 70 us)
+    auto colsum = [&](const float *src, int rows_) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = grp;
+        for (; k + 7 * G < rows_; k += 8 * G) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[((size_t)b * rows_ + k + u * G) * C + c0];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += v[u];
+        }
+        for (; k < rows_; k += G) a[0] += src[((size_t)b * rows_ + k) * C + c0];
+        return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    };
+    const float ek = colsum(enc_k, M), en = colsum(enc_n, N);
     part[0][threadIdx.x] = ek; part[1][threadIdx.x] = en;
     __syncthreads();
     if (threadIdx.x < C) {
@@ -188,7 +202,8 @@ extern "C" int i2p_pair_bias_bn_bwd(int B, int N, int M, int C, const float *gz,
     if (!gz || !enc_n || !enc_k || !dsums || !coef || !mi || !sum_k || !sum_n || !d_enc_n || !d_enc_k) return I2P_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int chunks = (N + PS_NL - 1) / PS_NL;
-    hipLaunchKernelGGL(pair_sum_kernel, dim3(B * chunks), dim3(THREADS), 0, st, B, N, M, C, (const float4 *)gz, sum_k, sum_n);
+    // k range split 4 ways: 4x the blocks (one block per CU left most of the HBM bandwidth unused)
+    hipLaunchKernelGGL(pair_sum_kernel, dim3(B * chunks, 4), dim3(THREADS), 0, st, B, N, M, C, (const float4 *)gz, sum_k, sum_n);
     hipLaunchKernelGGL(pair_bias_bn_bwd_kernel, dim3(B * PB_SLICES), dim3(THREADS), 0, st, B, N, M, C, sum_k, sum_n, enc_n, enc_k, dsums,
                        coef, mi, d_enc_n, d_enc_k);
     I2P_RETURN_LAUNCH_STATUS();

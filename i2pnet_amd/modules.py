@@ -454,9 +454,12 @@ class _MaxResponse(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pts, pix, valid):
-        vm = valid > 0                                                        # [B,N,1]
-        f_max, i_max = torch.where(vm, pts, torch.full_like(pts, -float("inf"))).max(1)      # [B,C]
-        f_min, i_min = torch.where(vm, pts, torch.full_like(pts, float("inf"))).min(1)
+        vm = (valid > 0)                                                      # [B,N,1]
+        # reduce along a CONTIGUOUS axis: ATen's reduction over the strided point axis of [B,N,C] runs 1024 threads
+        # that each walk N strided elements (45 us per call for 8 x 228 x 128)
+        pt, vt = pts.transpose(1, 2).contiguous(), vm.transpose(1, 2)         # [B,C,N], [B,1,N]
+        f_max, i_max = torch.where(vt, pt, -float("inf")).max(2)              # [B,C]
+        f_min, i_min = torch.where(vt, pt, float("inf")).min(2)
         any_valid = vm.any(1)                                                 # [B,1]
         f_max = torch.where(any_valid, f_max, torch.zeros_like(f_max))
         f_min = torch.where(any_valid, f_min, torch.zeros_like(f_min))

@@ -461,7 +461,7 @@ class CBackend:
         """-> (d_enc_n [B,N,C], d_enc_k [B,M,C]); see i2p_pair_bias_bn_bwd"""
         C = gz.shape[1]
         dev = gz.device
-        sum_k = torch.empty(B, N, C, dtype=_F32, device=dev)
+        sum_k = zeros((B, N, C), _F32, dev)
         sum_n = zeros((B, M, C), _F32, dev)
         d_n = torch.empty(B, N, C, dtype=_F32, device=dev); d_k = torch.empty(B, M, C, dtype=_F32, device=dev)
         self._call("i2p_pair_bias_bn_bwd", int(B), int(N), int(M), int(C), self._p(gz, _F32, "gz"),

@@ -335,7 +335,7 @@ int i2p_unpool_k(long long groups, int K, int c, const float *g, const unsigned 
  * (PPBackbone_center.py:416-418: pi_encoding applied to cat(xyz_n, uv_k), a 1x1 conv => an outer sum):
  *   gz f32 [B*N*M, C] = dL/dz_e (z_e = BN(ye)), dsums replicated {sum gz, sum gz*xhat}, coef [3][C], mi [2][C];
  *   d_enc_n f32 [B,N,C] = sum_k dL/dye, d_enc_k f32 [B,M,C] = sum_n dL/dye, dL/dye = scale*(gz - m1 - xhat*m2).
- *   sum_k f32 [B,N,C] (written), sum_n f32 [B,M,C] (ZEROED BY THE CALLER, accumulated with atomics): scratch.
+ *   sum_k f32 [B,N,C], sum_n f32 [B,M,C]: scratch, both ZEROED BY THE CALLER (accumulated with atomics).
  * gz is read once; the [B,N,M,C] gradient of ye is never formed.  C % 4 == 0, C | 256. */
 int i2p_pair_bias_bn_bwd(int B, int N, int M, int C, const float *gz, const float *enc_n, const float *enc_k,
                          const double *dsums, const float *coef, const float *mi, float *sum_k, float *sum_n,

@@ -11,7 +11,7 @@ a, b = marks[5], marks[6]            # one graph-replayed training step
 for r in rows[a:b]:
     n = r["Kernel_Name"]
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    if ("bn_act_fwd_v4" in n or "bn_act_bwd_v4" in n or "direct_copy" in n or "FillFunctor" in n) and d > 25:
+    if d > 35 and not any(k in n for k in ("lin_", "pair_bwd", "igemm", "img_", "Cijk")):
         g = [r.get(k) for k in r if "Grid" in k or "Workgroup" in k]
         print(f"{d:8.1f} us {g} {n[:60]}")
 PY
