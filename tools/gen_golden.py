@@ -240,7 +240,49 @@ def fp64_gradients(cfg_name, shapes, seed, batch):
         (P.gather_torch, P._get_neighbor, P.index_points_group, P.project_seq, P.knn_point, torch.Tensor.float) = saved
 
 
+def run_metrics():
+    """evaluation metrics (metric.py): the reference's numpy/scipy functions on seeded poses"""
+    import importlib
+    import types
+    ref_harness.install()
+    # metric.py imports src/util/lie_metric/MSEE.py, which needs geomstats and future (both absent here), for
+    # eval_msee / eval_mrr only (the kitti_rgg protocol).  None of the functions recorded below touch it, so the
+    # import is satisfied with an empty module; MSEE / MRR stay unpinned.
+    ms = types.ModuleType("src.util.lie_metric.MSEE"); ms.SE3_to_se3 = ms.cal_metric = None
+    sys.modules.setdefault("src.util.lie_metric.MSEE", ms)
+    metric = importlib.import_module("metric")
+    g = torch.Generator().manual_seed(11)
+    B = 48
+    q_gt = torch.nn.functional.normalize(torch.randn(B, 4, generator=g), dim=-1)
+    # predictions: small and large errors, a few un-normalised (the model normalises, a foreign caller may not)
+    q_pr = torch.nn.functional.normalize(q_gt + torch.randn(B, 4, generator=g) * torch.logspace(-3, 0, B).unsqueeze(-1), dim=-1)
+    q_pr[-4:] *= torch.tensor([1.02, 0.97, 1.1, 0.9]).unsqueeze(-1)
+    t_gt = torch.randn(B, 3, generator=g) * 5
+    t_pr = t_gt + torch.randn(B, 3, generator=g) * torch.logspace(-2, 1, B).unsqueeze(-1)
+    ang = torch.randn(B, 3, generator=g)
+    from scipy.spatial.transform import Rotation
+    init = np.concatenate([Rotation.from_rotvec(ang.numpy()).as_matrix(), (torch.randn(B, 3, 1, generator=g) * 8).numpy()], -1)
+    out3 = torch.cat([q_pr, t_pr], -1)
+    dv = {"decalib_real_gt": q_gt, "decalib_dual_gt": t_gt, "init_extrinsic": init}
+    pred, gt, pred_raw, gt_raw = metric.getExtrinsic(out3, dv, out_raw=True)
+    rre1, rte1 = metric.cal_rete_once(out3, dv)
+    errs = np.stack(metric.calibration_error_batch(pred_raw, gt_raw), -1)
+    ev = metric.RteRreEval()
+    r, t = ev.addBatch(pred_raw[:20], gt_raw[:20]); r2, t2 = ev.addBatch(pred_raw[20:], gt_raw[20:])
+    evt = metric.RteRreEval(threshold=True)
+    evt.addBatch(pred_raw, gt_raw)
+    np.savez_compressed(OUT / "metrics.npz", out3=out3.numpy(), q_gt=q_gt.numpy(), t_gt=t_gt.numpy(), init=init,
+                        pred=pred, gt=gt, pred_raw=pred_raw, gt_raw=gt_raw, rete_once=np.array([rre1, rte1]), errs=errs,
+                        rre=np.array(r + r2), rte=np.array(t + t2), seq=np.array(ev.evalSeq()),
+                        seq_th=np.array(evt.evalSeq()), recall_th=np.array(evt.get_recall()),
+                        inv=metric.inv_extrinsic(pred), euler=metric.rotmat_to_euler(gt[:, :, :3], out="deg"))
+    print("metrics.npz", (OUT / "metrics.npz").stat().st_size, "bytes; recall", evt.get_recall(), "seq", ev.evalSeq())
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":
+        run_metrics()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         run_small_range()
         sys.exit(0)
