@@ -17,9 +17,25 @@ constexpr int THREADS = 256;
 constexpr int REP = I2P_BN_REPLICAS;
 constexpr int MAX_STAT_BLOCKS = 1024;
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 struct PoolGeom {
-    int B, H, W, C, s, Ho, Wo, cv;
+    int B, H, W, C, s, Ho, Wo, cv, cvs;      // cvs = log2(cv) (cv divides THREADS, so it is a power of two)
 };
+
+// flat float4 index -> (b, row, col): 32-bit divisions unless the tensor has 2^31 float4 or more (a 64-bit
+// division by a run-time divisor is ~100 VALU instructions; three of them per element made these streaming
+// kernels instruction-bound at 2.5 TB/s)
+template <bool WIDE> struct Idx { using type = unsigned; };
+template <> struct Idx<true> { using type = unsigned long long; };
+template <bool WIDE>
+__device__ __forceinline__ void decode(typename Idx<WIDE>::type t, int cvs, int rows, int cols, int &b, int &r, int &c) {
+    typename Idx<WIDE>::type q = t >> cvs;
+    const typename Idx<WIDE>::type q2 = q / (unsigned)cols;
+    c = (int)(q - q2 * (unsigned)cols);
+    b = (int)(q2 / (unsigned)rows);
+    r = (int)(q2 - (typename Idx<WIDE>::type)b * (unsigned)rows);
+}
 
 __device__ __forceinline__ double rep_sum(const double *sums, int c, int idx) {
     double a = 0.0;
@@ -64,19 +80,18 @@ __device__ __forceinline__ Coef4 load_coef(const float *mean_invstd, const float
 
 __device__ __forceinline__ float bn_z(float y, const Coef4 &k, int i) { return (y - k.mean[i]) * k.scale[i] + k.beta[i]; }
 
+template <bool WIDE>
 __global__ __launch_bounds__(THREADS) void img_pool_fwd_kernel(PoolGeom g, const float4 *__restrict__ y,
                                                                 const float *__restrict__ mean_invstd,
                                                                 const float *__restrict__ gamma,
                                                                 const float *__restrict__ beta, float slope,
                                                                 float4 *__restrict__ out, uchar4 *__restrict__ arg) {
     const long long total = (long long)g.B * g.Ho * g.Wo * g.cv;
-    const int vcol = threadIdx.x % g.cv;              // THREADS % cv == 0 and the grid stride is a multiple of THREADS
+    const int vcol = threadIdx.x & (g.cv - 1);              // THREADS % cv == 0 and the grid stride is a multiple of THREADS
     const Coef4 k = load_coef(mean_invstd, gamma, beta, g.C, vcol);
     for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
-        long long r = t / g.cv;
-        const int wo = (int)(r % g.Wo); r /= g.Wo;
-        const int ho = (int)(r % g.Ho);
-        const int b = (int)(r / g.Ho);
+        int b, ho, wo;
+        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.Ho, g.Wo, b, ho, wo);
         float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         unsigned char bi[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -104,6 +119,7 @@ __global__ __launch_bounds__(THREADS) void img_pool_fwd_kernel(PoolGeom g, const
 
 // sums over all conv-output positions of gz = dL/dz (z = BN output) and gz*xhat, visited through the pooled
 // outputs: each pooled element routes its gradient to its arg-max position.
+template <bool WIDE>
 __global__ __launch_bounds__(THREADS) void img_bwd_stats_kernel(PoolGeom g, const float4 *__restrict__ gout,
                                                                  const uchar4 *__restrict__ arg,
                                                                  const float *__restrict__ y,
@@ -113,14 +129,12 @@ __global__ __launch_bounds__(THREADS) void img_bwd_stats_kernel(PoolGeom g, cons
                                                                  double *__restrict__ dsums) {
     __shared__ double red[THREADS][8];
     const long long total = (long long)g.B * g.Ho * g.Wo * g.cv;
-    const int vcol = threadIdx.x % g.cv;
+    const int vcol = threadIdx.x & (g.cv - 1);
     const Coef4 k = load_coef(mean_invstd, gamma, beta, g.C, vcol);
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
-        long long r = t / g.cv;
-        const int wo = (int)(r % g.Wo); r /= g.Wo;
-        const int ho = (int)(r % g.Ho);
-        const int b = (int)(r / g.Ho);
+        int b, ho, wo;
+        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.Ho, g.Wo, b, ho, wo);
         const float4 go = gout[t];
         const uchar4 a = arg[t];
         const float gv[4] = {go.x, go.y, go.z, go.w};
@@ -163,6 +177,7 @@ __global__ void img_bwd_coef_kernel(int c, const double *__restrict__ dsums, flo
 }
 
 // dL/dy of the conv output: gather the pooled gradients whose arg-max is this position, LeakyReLU', BN backward.
+template <bool WIDE>
 __global__ __launch_bounds__(THREADS) void img_bwd_dx_kernel(PoolGeom g, const float4 *__restrict__ gout,
                                                               const uchar4 *__restrict__ arg,
                                                               const float4 *__restrict__ y,
@@ -172,17 +187,15 @@ __global__ __launch_bounds__(THREADS) void img_bwd_dx_kernel(PoolGeom g, const f
                                                               float4 *__restrict__ dy, const float *__restrict__ dgamma,
                                                               const float *__restrict__ dbeta) {
     const long long total = (long long)g.B * g.H * g.W * g.cv;
-    const int vcol = threadIdx.x % g.cv;
+    const int vcol = threadIdx.x & (g.cv - 1);
     const Coef4 k = load_coef(mean_invstd, gamma, beta, g.C, vcol);
     const float n = (float)((long long)g.B * g.H * g.W);
     float mg[4], mgx[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { mg[i] = dbeta[vcol * 4 + i] / n; mgx[i] = dgamma[vcol * 4 + i] / n; }
     for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
-        long long r = t / g.cv;
-        const int w = (int)(r % g.W); r /= g.W;
-        const int h = (int)(r % g.H);
-        const int b = (int)(r / g.H);
+        int b, h, w;
+        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.H, g.W, b, h, w);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         // outputs ho with ho*s-1 <= h <= ho*s+1
         const int ho0 = max(0, (h - 1 + g.s - 1) / g.s), ho1 = min(g.Ho - 1, (h + 1) / g.s);
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(THREADS) void img_bwd_dx_kernel(PoolGeom g, const f
                 acc[0] += a.x == p ? go.x : 0.f; acc[1] += a.y == p ? go.y : 0.f;
                 acc[2] += a.z == p ? go.z : 0.f; acc[3] += a.w == p ? go.w : 0.f;
             }
-        const float4 v = y[t];
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(y) + t);   // streamed once: keep arg / gout in L2
         const float vv[4] = {v.x, v.y, v.z, v.w};
         float o4[4];
 #pragma unroll
@@ -207,17 +220,20 @@ __global__ __launch_bounds__(THREADS) void img_bwd_dx_kernel(PoolGeom g, const f
             const float xh = (vv[i] - k.mean[i]) * k.invstd[i];
             o4[i] = k.scale[i] * (gz - mg[i] - xh * mgx[i]);
         }
-        dy[t] = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        const v4f o = {o4[0], o4[1], o4[2], o4[3]};
+        __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(dy) + t);
     }
 }
 
 bool geom_ok(int B, int H, int W, int C, int s) {
-    return B >= 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0 && (THREADS % (C / 4)) == 0 && (s == 1 || s == 2);
+    return B >= 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0 && (THREADS % (C / 4)) == 0 && ((C / 4) & (C / 4 - 1)) == 0 && (s == 1 || s == 2);
 }
 
 PoolGeom make_geom(int B, int H, int W, int C, int s) {
     PoolGeom g;
     g.B = B; g.H = H; g.W = W; g.C = C; g.s = s; g.cv = C / 4;
+    g.cvs = 0;
+    while ((1 << g.cvs) < g.cv) ++g.cvs;
     g.Ho = (H - 1) / s + 1; g.Wo = (W - 1) / s + 1;        // floor((H + 2*1 - 3)/s) + 1
     return g;
 }
@@ -242,8 +258,12 @@ extern "C" int i2p_img_bn_pool_fwd(int B, int H, int W, int C, int stride, const
     hipLaunchKernelGGL(img_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (long long)B * H * W, C, sums, eps,
                        momentum, conv_bias, running_mean, running_var, mean_invstd);
     const long long total = (long long)B * g.Ho * g.Wo * g.cv;
-    hipLaunchKernelGGL(img_pool_fwd_kernel, dim3(grid_for(total, 1 << 20)), dim3(THREADS), 0, st, g, (const float4 *)y,
-                       mean_invstd, gamma, beta, slope, (float4 *)out, (uchar4 *)arg);
+    if (total < (1ll << 31))
+        hipLaunchKernelGGL(img_pool_fwd_kernel<false>, dim3(grid_for(total, 1 << 20)), dim3(THREADS), 0, st, g,
+                           (const float4 *)y, mean_invstd, gamma, beta, slope, (float4 *)out, (uchar4 *)arg);
+    else
+        hipLaunchKernelGGL(img_pool_fwd_kernel<true>, dim3(grid_for(total, 1 << 20)), dim3(THREADS), 0, st, g,
+                           (const float4 *)y, mean_invstd, gamma, beta, slope, (float4 *)out, (uchar4 *)arg);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
@@ -255,11 +275,21 @@ extern "C" int i2p_img_bn_pool_bwd(int B, int H, int W, int C, int stride, const
     const PoolGeom g = make_geom(B, H, W, C, stride);
     hipStream_t st = (hipStream_t)stream;
     const long long tot_o = (long long)B * g.Ho * g.Wo * g.cv, tot_i = (long long)B * H * W * g.cv;
-    hipLaunchKernelGGL(img_bwd_stats_kernel, dim3(grid_for(tot_o, MAX_STAT_BLOCKS)), dim3(THREADS), 0, st, g,
-                       (const float4 *)gout, (const uchar4 *)arg, y, mean_invstd, gamma, beta, slope, dsums);
+    const bool wide = tot_i >= (1ll << 31);
+    if (!wide)
+        hipLaunchKernelGGL(img_bwd_stats_kernel<false>, dim3(grid_for(tot_o, MAX_STAT_BLOCKS)), dim3(THREADS), 0, st, g,
+                           (const float4 *)gout, (const uchar4 *)arg, y, mean_invstd, gamma, beta, slope, dsums);
+    else
+        hipLaunchKernelGGL(img_bwd_stats_kernel<true>, dim3(grid_for(tot_o, MAX_STAT_BLOCKS)), dim3(THREADS), 0, st, g,
+                           (const float4 *)gout, (const uchar4 *)arg, y, mean_invstd, gamma, beta, slope, dsums);
     hipLaunchKernelGGL(img_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, C, dsums, dgamma, dbeta);
-    hipLaunchKernelGGL(img_bwd_dx_kernel, dim3(grid_for(tot_i, 1 << 20)), dim3(THREADS), 0, st, g, (const float4 *)gout,
-                       (const uchar4 *)arg, (const float4 *)y, mean_invstd, gamma, beta, slope, (float4 *)dy,
-                       dgamma, dbeta);
+    if (!wide)
+        hipLaunchKernelGGL(img_bwd_dx_kernel<false>, dim3(grid_for(tot_i, 1 << 20)), dim3(THREADS), 0, st, g,
+                           (const float4 *)gout, (const uchar4 *)arg, (const float4 *)y, mean_invstd, gamma, beta, slope,
+                           (float4 *)dy, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL(img_bwd_dx_kernel<true>, dim3(grid_for(tot_i, 1 << 20)), dim3(THREADS), 0, st, g,
+                           (const float4 *)gout, (const uchar4 *)arg, (const float4 *)y, mean_invstd, gamma, beta, slope,
+                           (float4 *)dy, dgamma, dbeta);
     I2P_RETURN_LAUNCH_STATUS();
 }

@@ -153,7 +153,7 @@ class _MlpChain(Function):
                                                need_gx=need_gx, slope_out=slope_out)
             grads[k + 3 * (i - 1)] = dw
             # gamma/beta gradients of the BN behind layer i: reduced from out_ds by the launcher (scratch tail)
-            grads[k + 3 * (i - 1) + 1], grads[k + 3 * (i - 1) + 2] = be.last_bn_grads
+            grads[k + 3 * (i - 1) + 1], grads[k + 3 * (i - 1) + 2] = be.take_bn_grads()
             gz, y_out, out_coef, out_mi, out_ds, slope_out = gz_in, ys[i - 1], coefs[i - 1], mis[i - 1], in_ds, 1.0
         if first_bn:            # leading BN: its sums were accumulated by the last dgrad call
             s = _rep_sum(out_ds, ys[0].shape[1])
@@ -255,12 +255,12 @@ class _CvPiTail(Function):
         f32 = lambda t: t.float()
         gz5, ds5, ga3 = be_.cv_softmax_wsum_backward(B, N, M, g_out.contiguous(), out, msave, y5, c5, m5, s5, y3, c3, s3)
         # (gamma/beta gradients of a BN come back reduced from the call that consumes its sums: `last_bn_grads`)
-        gz4, ds4, dW5 = be_.lin_backward(gz5, y5, c5, m5, ds5, y4, c4, m4, s4, d(W5)); dg5, db5 = be_.last_bn_grads
+        gz4, ds4, dW5 = be_.lin_backward(gz5, y5, c5, m5, ds5, y4, c4, m4, s4, d(W5)); dg5, db5 = be_.take_bn_grads()
         gze, dse, gz3, ds3, dW4 = be_.lin_backward_2src(gz4, y4, c4, m4, ds4, ye, ce, me, se, y3, c3, m3, s3, ga3, d(W4))
-        dg4, db4 = be_.last_bn_grads
+        dg4, db4 = be_.take_bn_grads()
         re = _rep_sum(dse, ye.shape[1])
-        gz2, ds2, dW3 = be_.lin_backward(gz3, y3, c3, m3, ds3, y2, c2, m2, s2, d(W3)); dg3, db3 = be_.last_bn_grads
-        gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2)); dg2, db2 = be_.last_bn_grads
+        gz2, ds2, dW3 = be_.lin_backward(gz3, y3, c3, m3, ds3, y2, c2, m2, s2, d(W3)); dg3, db3 = be_.take_bn_grads()
+        gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2)); dg2, db2 = be_.take_bn_grads()
         r1 = _rep_sum(ds1, y1.shape[1])
         # first layer: BN backward of bn1 formed on load inside the pair kernel
         d_f, d_g, d_bn, d_bk, dW1 = be_.pair_lin_backward(gz1, f, g, W1, y=y1, out_coef=c1, out_mi=m1, out_dsums=ds1)
@@ -309,13 +309,13 @@ class _CvKnnTail(Function):
         s1, s2, s3, se, s4, s5 = ctx.slopes
         d = lambda t: t.detach()
         gz5, ds5, ga3 = be_.cv_softmax_wsum_backward(B, N, K, g_out.contiguous(), out, msave, y5, c5, m5, s5, y3, c3, s3)
-        gz4, ds4, dW5 = be_.lin_backward(gz5, y5, c5, m5, ds5, y4, c4, m4, s4, d(W5)); dg5, db5 = be_.last_bn_grads
+        gz4, ds4, dW5 = be_.lin_backward(gz5, y5, c5, m5, ds5, y4, c4, m4, s4, d(W5)); dg5, db5 = be_.take_bn_grads()
         gze, dse, gz3, ds3, dW4 = be_.lin_backward_2src(gz4, y4, c4, m4, ds4, ye, ce, me, se, y3, c3, m3, s3, ga3, d(W4))
-        dg4, db4 = be_.last_bn_grads
-        gz2, ds2, dW3 = be_.lin_backward(gz3, y3, c3, m3, ds3, y2, c2, m2, s2, d(W3)); dg3, db3 = be_.last_bn_grads
-        gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2)); dg2, db2 = be_.last_bn_grads
-        dx1, _, dW1 = be_.lin_backward(gz1, y1, c1, m1, ds1, x1, None, None, 1.0, W1, need_gx=ctx.need[0]); dg1, db1 = be_.last_bn_grads
-        dxe, _, dWe = be_.lin_backward(gze, ye, ce, me, dse, xe, None, None, 1.0, We, need_gx=ctx.need[1]); dge, dbe = be_.last_bn_grads
+        dg4, db4 = be_.take_bn_grads()
+        gz2, ds2, dW3 = be_.lin_backward(gz3, y3, c3, m3, ds3, y2, c2, m2, s2, d(W3)); dg3, db3 = be_.take_bn_grads()
+        gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2)); dg2, db2 = be_.take_bn_grads()
+        dx1, _, dW1 = be_.lin_backward(gz1, y1, c1, m1, ds1, x1, None, None, 1.0, W1, need_gx=ctx.need[0]); dg1, db1 = be_.take_bn_grads()
+        dxe, _, dWe = be_.lin_backward(gze, ye, ce, me, dse, xe, None, None, 1.0, We, need_gx=ctx.need[1]); dge, dbe = be_.take_bn_grads()
         return (dx1, dxe, dW1, dWe, None, None, None, dg1, db1, dW2, dg2, db2, dW3, dg3, db3, dge, dbe, dW4, dg4, db4, dW5, dg5, db5)
 
 

@@ -361,6 +361,13 @@ class CBackend:
         self.last_bn_grads = (part[n - cout:], part[n - 2 * cout:n - cout]) if out_coef is not None else None
         return gz_in, in_dsums, dw
 
+    def take_bn_grads(self):
+        """(dgamma, dbeta) of the last lin_backward / lin_backward_2src, handing the reference over: a pair still
+        referenced from here when autograd's AccumulateGrad sees it is CLONED instead of adopted (one copy launch
+        per tensor)."""
+        g, self.last_bn_grads = self.last_bn_grads, None
+        return g
+
     def pair_lin_forward(self, f, g, bias_n, bias_k, w):
         """f [B,N,C], g [B,M,C], bias_n [B,N,Co], bias_k [B,M,Co], w [Co,C] -> y [B*N*M, Co], sums"""
         B, N, C = f.shape
