@@ -259,10 +259,10 @@ extern "C" int i2p_img_bn_pool_fwd(int B, int H, int W, int C, int stride, const
                        momentum, conv_bias, running_mean, running_var, mean_invstd);
     const long long total = (long long)B * g.Ho * g.Wo * g.cv;
     if (total < (1ll << 31))
-        hipLaunchKernelGGL(img_pool_fwd_kernel<false>, dim3(grid_for(total, 1 << 20)), dim3(THREADS), 0, st, g,
+        hipLaunchKernelGGL(img_pool_fwd_kernel<false>, dim3(grid_for(total, 1 << 14)), dim3(THREADS), 0, st, g,
                            (const float4 *)y, mean_invstd, gamma, beta, slope, (float4 *)out, (uchar4 *)arg);
     else
-        hipLaunchKernelGGL(img_pool_fwd_kernel<true>, dim3(grid_for(total, 1 << 20)), dim3(THREADS), 0, st, g,
+        hipLaunchKernelGGL(img_pool_fwd_kernel<true>, dim3(grid_for(total, 1 << 14)), dim3(THREADS), 0, st, g,
                            (const float4 *)y, mean_invstd, gamma, beta, slope, (float4 *)out, (uchar4 *)arg);
     I2P_RETURN_LAUNCH_STATUS();
 }
@@ -284,11 +284,11 @@ extern "C" int i2p_img_bn_pool_bwd(int B, int H, int W, int C, int stride, const
                            (const float4 *)gout, (const uchar4 *)arg, y, mean_invstd, gamma, beta, slope, dsums);
     hipLaunchKernelGGL(img_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, C, dsums, dgamma, dbeta);
     if (!wide)
-        hipLaunchKernelGGL(img_bwd_dx_kernel<false>, dim3(grid_for(tot_i, 1 << 20)), dim3(THREADS), 0, st, g,
+        hipLaunchKernelGGL(img_bwd_dx_kernel<false>, dim3(grid_for(tot_i, 1 << 12)), dim3(THREADS), 0, st, g,
                            (const float4 *)gout, (const uchar4 *)arg, (const float4 *)y, mean_invstd, gamma, beta, slope,
                            (float4 *)dy, dgamma, dbeta);
     else
-        hipLaunchKernelGGL(img_bwd_dx_kernel<true>, dim3(grid_for(tot_i, 1 << 20)), dim3(THREADS), 0, st, g,
+        hipLaunchKernelGGL(img_bwd_dx_kernel<true>, dim3(grid_for(tot_i, 1 << 12)), dim3(THREADS), 0, st, g,
                            (const float4 *)gout, (const uchar4 *)arg, (const float4 *)y, mean_invstd, gamma, beta, slope,
                            (float4 *)dy, dgamma, dbeta);
     I2P_RETURN_LAUNCH_STATUS();
