@@ -31,6 +31,8 @@ SIGNATURES = {
     "i2p_bn_act_bwd": ["l", "i", "p", "p", "p", "p", "p", "f", "p", "p", "p", "p"],
     "i2p_lin_fwd": ["l", "i", "i", "p", "p", "f", "p", "p", "p"],
     "i2p_quat_mul": ["i", "i", "i", "i", "i", "p", "p", "p"],
+    "i2p_quat_unit_fwd": ["i", "l", "p", "p"],
+    "i2p_quat_unit_bwd": ["i", "l", "p", "p", "p"],
     "i2p_row_unitvar_fwd": ["i", "i", "p", "p", "p"],
     "i2p_row_unitvar_bwd": ["i", "i", "p", "p", "p", "p"],
     "i2p_img_bn_pool_fwd": ["i", "i", "i", "i", "i", "p", "p", "p", "p", "f", "f", "f", "p", "p", "p", "p", "p", "p"],

@@ -354,6 +354,55 @@ __global__ void quat_mul_kernel(int total, int n, int na, int nb, int conj_a, in
     out[i] = o;
 }
 
+// per-quaternion inverse / normalisation and their gradients (include/i2p_ops.h: i2p_quat_unit_*)
+__global__ void quat_unit_fwd_kernel(int mode, long long rows, const float4 *__restrict__ q, float4 *__restrict__ out) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float4 v = q[r];
+    const float n2 = (v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) + 1e-10f;
+    if (mode == 0) {
+        out[r] = make_float4(v.x / n2, -v.y / n2, -v.z / n2, -v.w / n2);
+    } else {
+        const float d = sqrtf(n2) + 1e-10f;
+        out[r] = make_float4(v.x / d, v.y / d, v.z / d, v.w / d);
+    }
+}
+
+__global__ void quat_unit_bwd_kernel(int mode, long long rows, const float4 *__restrict__ q, const float4 *__restrict__ g,
+                                     float4 *__restrict__ dq) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float4 v = q[r], go = g[r];
+    const float n2 = (v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) + 1e-10f;
+    if (mode == 0) {
+        // out_j = s_j q_j / n2  ->  dq = (s o g - 2 q <g, out>) / n2
+        const float dot = (go.x * v.x - go.y * v.y - go.z * v.z - go.w * v.w) / n2;
+        dq[r] = make_float4((go.x - 2.f * v.x * dot) / n2, (-go.y - 2.f * v.y * dot) / n2,
+                            (-go.z - 2.f * v.z * dot) / n2, (-go.w - 2.f * v.w * dot) / n2);
+    } else {
+        // out = q / d, d = r + 1e-10, r = sqrt(n2)  ->  dq = g / d - q <g, q> / (d^2 r)
+        const float rr = sqrtf(n2), d = rr + 1e-10f;
+        const float k = (go.x * v.x + go.y * v.y + go.z * v.z + go.w * v.w) / (d * d * rr);
+        dq[r] = make_float4(go.x / d - v.x * k, go.y / d - v.y * k, go.z / d - v.z * k, go.w / d - v.w * k);
+    }
+}
+
+extern "C" int i2p_quat_unit_fwd(int mode, long long rows, const float *q, float *out, void *stream) {
+    if (rows < 0 || (mode != 0 && mode != 1)) return I2P_ERR_BAD_ARG;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(quat_unit_fwd_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, mode, rows,
+                       (const float4 *)q, (float4 *)out);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_quat_unit_bwd(int mode, long long rows, const float *q, const float *g, float *dq, void *stream) {
+    if (rows < 0 || (mode != 0 && mode != 1)) return I2P_ERR_BAD_ARG;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(quat_unit_bwd_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, mode, rows,
+                       (const float4 *)q, (const float4 *)g, (float4 *)dq);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int i2p_quat_mul(int b, int na, int nb, int conj_a, int conj_b, const float *qa, const float *qb,
                             float *out, void *stream) {
     const int n = na > nb ? na : nb;

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from . import ops
 from . import projectpn as P
+from . import warp as warp_utils
 from .fused import cv_knn_tail, cv_pi_tail, cv_tail_fits, layer_fits, mlp_stack, pair_fits, pair_linear, softmax_pool
 
 # run Conv2d stacks on the fused MFMA layer kernels (csrc/mlp.hip); False = library GEMM + BN kernels per block
@@ -657,7 +658,7 @@ class PoseHead(nn.Module):
         hidden = self.DP1(self.hidden_layer(pooled))
         q = self.quat_head(self.DP2(hidden)).squeeze(1)
         t = self.trans_head(self.DP2(hidden)).squeeze(1)
-        q = q / (torch.sqrt(torch.sum(q * q, dim=-1, keepdim=True) + 1e-10) + 1e-10)   # :562
+        q = warp_utils.normalise_q(q)                                           # :562, one launch
         return q, t, mask_p
 
 

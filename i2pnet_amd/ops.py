@@ -213,6 +213,20 @@ class CBackend:
                    self._p(b, _F32, "b"), self._p(out, _F32, "out"), stream=self._stream())
         return out
 
+    def quat_unit_forward(self, mode, q):
+        """mode 0: conj(q)/(|q|^2+1e-10) (warp_utils.py:10-22); mode 1: q/(sqrt(|q|^2+1e-10)+1e-10)
+        (PPBackbone_center.py:562).  q [...,4] -> same shape"""
+        out = torch.empty_like(q)
+        self._call("i2p_quat_unit_fwd", int(mode), int(q.numel() // 4), self._p(q, _F32, "q"), self._p(out, _F32, "out"),
+                   stream=self._stream())
+        return out
+
+    def quat_unit_backward(self, mode, q, g):
+        dq = torch.empty_like(q)
+        self._call("i2p_quat_unit_bwd", int(mode), int(q.numel() // 4), self._p(q, _F32, "q"), self._p(g, _F32, "g"),
+                   self._p(dq, _F32, "dq"), stream=self._stream())
+        return dq
+
     def row_unitvar_forward(self, x):
         """x [rows,c] -> (y, stat [rows,2]) (PPBackbone_center.py:388-393)"""
         rows, c = x.shape

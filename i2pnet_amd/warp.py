@@ -32,6 +32,30 @@ class _QuatMul(torch.autograd.Function):
         return ga, gb
 
 
+class _QuatUnit(torch.autograd.Function):
+    """mode 0: conj(q) / (|q|^2 + 1e-10); mode 1: q / (sqrt(|q|^2 + 1e-10) + 1e-10) — one launch forward, one
+    backward (csrc/projection_ops.hip `quat_unit_*_kernel`) instead of 5-6 and 10-12 elementwise kernels."""
+
+    @staticmethod
+    def forward(ctx, q, mode):
+        q = q.contiguous()
+        ctx.save_for_backward(q)
+        ctx.mode = mode
+        return ops.get_backend().quat_unit_forward(mode, q)
+
+    @staticmethod
+    def backward(ctx, g):
+        (q,) = ctx.saved_tensors
+        return ops.get_backend().quat_unit_backward(ctx.mode, q, g.contiguous()), None
+
+
+def normalise_q(q):
+    """q [...,4] -> q / (sqrt(|q|^2 + 1e-10) + 1e-10) (PPBackbone_center.py:562)"""
+    if q.dtype != torch.float32:
+        return q / (torch.sqrt(torch.sum(q * q, dim=-1, keepdim=True) + 1e-10) + 1e-10)
+    return _QuatUnit.apply(q, 1)
+
+
 _CONJ_SIGN = {}
 
 
@@ -47,6 +71,8 @@ def inv_q(q):
     """q [B,4] or [B,1,4] (w,x,y,z) -> conj(q) / (|q|^2 + 1e-10), [B,4]"""
     B = q.shape[0]
     q = q.reshape(B, 4)
+    if q.dtype == torch.float32:
+        return _QuatUnit.apply(q, 0)
     n2 = torch.sum(q * q, dim=-1, keepdim=True) + 1e-10
     return (q * _conj_sign(q.device)) / n2
 

@@ -245,6 +245,16 @@ int i2p_quat_mul(int b, int na, int nb, int conj_a, int conj_b, const float *qa,
                  float *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Per-quaternion scalings, forward and backward, one launch each (PyTorch runs 5-6 tiny kernels forward and
+ * 10-12 backward for each):
+ *   mode 0  inverse   : out = conj(q) / (|q|^2 + 1e-10)                      (src/modules/warp_utils.py:10-22 `inv_q`)
+ *   mode 1  normalise : out = q / (sqrt(|q|^2 + 1e-10) + 1e-10)              (src/projectPN/PPBackbone_center.py:562)
+ * q, out f32 [rows,4] as (w,x,y,z).  Backward: dq f32 [rows,4] from g = dL/dout and the forward INPUT q.
+ * --------------------------------------------------------------------------------------------- */
+int i2p_quat_unit_fwd(int mode, long long rows, const float *q, float *out, void *stream);
+int i2p_quat_unit_bwd(int mode, long long rows, const float *q, const float *g, float *dq, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Row-wise unit variance of the cost-volume operands (src/projectPN/PPBackbone_center.py:388-393):
  *     y[r,:] = (x[r,:] - mean(x[r,:])) / clip(std_unbiased(x[r,:]), 1e-12)
  * x, y f32 [rows,c], 2 <= c <= 256; stat f32 [rows,2] = {1/d, std > 1e-12 ? 1 : 0} (saved for the backward).

@@ -245,6 +245,25 @@ def test_quat_mul_parity(oracle_backend, hip_backend):
             assert torch.equal(r, h.cpu()), (na, nb, ca, cb)
 
 
+def test_quat_unit_parity(oracle_backend, hip_backend):
+    g = torch.Generator().manual_seed(6)
+    for rows in (2, 8, 1000):
+        q = torch.randn(rows, 4, generator=g) * torch.logspace(-3, 1, rows).unsqueeze(-1)
+        q[0] = 0.0
+        go = torch.randn(rows, 4, generator=g)
+        for mode in (0, 1):
+            r = oracle_backend.quat_unit_forward(mode, q)
+            h = hip_backend.quat_unit_forward(mode, q.to(DEV))
+            assert torch.allclose(r[1:], h.cpu()[1:], rtol=1e-6, atol=0), (rows, mode)
+            assert torch.equal(r[0], h.cpu()[0])
+            rb = oracle_backend.quat_unit_backward(mode, q, go)
+            hb = hip_backend.quat_unit_backward(mode, q.to(DEV), go.to(DEV))
+            assert torch.allclose(rb[1:], hb.cpu()[1:], rtol=1e-4, atol=1e-7 * float(rb[1:].abs().max())), (rows, mode)
+            assert torch.isfinite(hb).all()
+    with pytest.raises(Exception):
+        hip_backend.quat_unit_forward(2, torch.zeros(1, 4, device=DEV))
+
+
 def test_row_unitvar_parity(oracle_backend, hip_backend):
     g = torch.Generator().manual_seed(9)
     for rows, c in [(1824, 64), (3744, 128), (100, 37), (5, 256)]:

@@ -198,6 +198,32 @@ def _mul_q_formula(a, b):
     return torch.stack([r0, r1, r2, r3], -1)
 
 
+def test_quat_unit_oracle_and_autograd(oracle_backend):
+    """inv_q (warp_utils.py:10-22) and the pose head's normalisation (PPBackbone_center.py:562): the oracle equals the
+    reference expressions, and the autograd nodes give the gradients autograd derives for those expressions."""
+    from i2pnet_amd import ops, warp
+    g = torch.Generator().manual_seed(13)
+    conj = torch.tensor([1.0, -1.0, -1.0, -1.0])
+    exprs = {0: lambda q: (q * conj) / (torch.sum(q * q, dim=-1, keepdim=True) + 1e-10),
+             1: lambda q: q / (torch.sqrt(torch.sum(q * q, dim=-1, keepdim=True) + 1e-10) + 1e-10)}
+    prev = ops.set_backend(oracle_backend)
+    try:
+        for mode, fn in ((0, warp.inv_q), (1, warp.normalise_q)):
+            q = torch.randn(9, 4, generator=g) * torch.logspace(-2, 1, 9).unsqueeze(-1)
+            w = torch.randn(9, 4, generator=g)
+            q1, q2 = q.clone().requires_grad_(), q.clone().requires_grad_()
+            o1, o2 = fn(q1), exprs[mode](q2)
+            assert torch.allclose(o1, o2, rtol=1e-6, atol=1e-7)
+            (o1 * w).sum().backward(); (o2 * w).sum().backward()
+            assert torch.allclose(q1.grad, q2.grad, rtol=1e-5, atol=1e-6), mode
+        assert warp.inv_q(torch.randn(3, 1, 4, generator=g)).shape == (3, 4)
+        z = torch.zeros(2, 4, requires_grad=True)                   # all-zero quaternion: finite (the 1e-10 terms)
+        warp.normalise_q(z).sum().backward()
+        assert torch.isfinite(z.grad).all()
+    finally:
+        ops.set_backend(prev)
+
+
 def test_quat_mul_oracle_and_autograd(oracle_backend):
     """oracle quat_mul == the elementwise formula bit for bit (all broadcast shapes), and the
     custom autograd node of i2pnet_amd.warp.mul_q gives the formula's gradients."""
