@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import ops
 from . import projectpn as P
 from . import warp as warp_utils
 from .config import I2PNetConfig as cfg_default
@@ -195,7 +196,7 @@ class RegNet_v2(nn.Module):
         result_4 = torch.cat([q4, t4], dim=1)
 
         # ---- fine level ----------------------------------------------------------------------
-        t4_quat = torch.cat([torch.zeros((B, 1), device=dev), t4], -1)
+        t4_quat = torch.cat([ops.zero_scalar(dev, t4.dtype).expand(B, 1), t4], -1)
         l3_mask_up = self.set_upconv0_w_upsample(P3_raw, P4_raw, P3, P4, l3_idx_n2, LF3,
                                                  l4_mask.view(B, H4, W4, -1), cfg=cfg, raw_feat_point=rfp)
         l3_embed_up = self.set_upconv0_upsample(P3_raw, P4_raw, P3, P4, l3_idx_n2, LF3, l4_embed, cfg=cfg,
@@ -229,7 +230,7 @@ class RegNet_v2(nn.Module):
         q3, t3, W_l3 = self.l3_head(l3_embed, l3_mask, P3_warped, f["LF3_pts"], None)
         # compose: q = q3 * q_prev, t = R3 t_prev + t3 (modellearn_proj_center.py:388-404)
         out_q = warp_utils.mul_q(q3.view(B, 1, 4), q_prev.view(B, 1, 4)).squeeze(1)
-        t3_quat = torch.cat([torch.zeros((B, 1), device=dev), t3], 1).view(B, 1, 4)
+        t3_quat = torch.cat([ops.zero_scalar(dev, t3.dtype).expand(B, 1), t3], 1).view(B, 1, 4)
         out_t = warp_utils.mul_q(warp_utils.mul_q(q3, t_prev_quat.view(B, 1, 4)), warp_utils.inv_q(q3)) + t3_quat
         return torch.cat([out_q, out_t.squeeze(1)[:, 1:]], 1), q3, t3, W_l3
 
@@ -262,5 +263,5 @@ class RegNet_v2_iter(RegNet_v2):
         out_3 = W_l3 = None
         for _ in range(self.n_iters):
             out_3, q3, t3, W_l3 = self._fine_step(fine, q_it, t_it)
-            q_it, t_it = q3, torch.cat([torch.zeros((B, 1), device=q3.device), t3], -1)
+            q_it, t_it = q3, torch.cat([ops.zero_scalar(q3.device, t3.dtype).expand(B, 1), t3], -1)
         return out_3, W_l3

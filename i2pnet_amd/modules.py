@@ -64,7 +64,7 @@ def cat_padded(parts, dim=-1, pow2=False):
     if pow2 and c <= 128:
         pad = next(w for w in (16, 32, 64, 128) if w >= c) - c
     if pad and USE_FUSED_MLP:
-        parts = list(parts) + [parts[0].new_zeros(()).expand(*parts[0].shape[:-1], pad)]
+        parts = list(parts) + [ops.zero_scalar(parts[0].device, parts[0].dtype).expand(*parts[0].shape[:-1], pad)]
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim)
 
 _BN_EPS = 1e-5
@@ -462,11 +462,11 @@ class _MaxResponse(torch.autograd.Function):
         f_max, i_max = torch.where(vt, pt, -float("inf")).max(2)              # [B,C]
         f_min, i_min = torch.where(vt, pt, float("inf")).min(2)
         any_valid = vm.any(1)                                                 # [B,1]
-        f_max = torch.where(any_valid, f_max, torch.zeros_like(f_max))
-        f_min = torch.where(any_valid, f_min, torch.zeros_like(f_min))
+        f_max = torch.where(any_valid, f_max, 0.0)
+        f_min = torch.where(any_valid, f_min, 0.0)
         pos = pix >= 0
         sel = torch.where(pos, f_max.unsqueeze(1), f_min.unsqueeze(1))        # [B,M,C]
-        respond = torch.where(any_valid.unsqueeze(1), pix * sel, torch.full_like(pix, -1e10))
+        respond = torch.where(any_valid.unsqueeze(1), pix * sel, -1e10)
         ctx.save_for_backward(pix, sel, pos, i_max, i_min, any_valid)
         ctx.n_points = pts.shape[1]
         return respond
@@ -474,12 +474,12 @@ class _MaxResponse(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         pix, sel, pos, i_max, i_min, any_valid = ctx.saved_tensors
-        g = torch.where(any_valid.unsqueeze(1), g, torch.zeros_like(g))
+        g = torch.where(any_valid.unsqueeze(1), g, 0.0)
         d_pix = g * sel
         t = g * pix
-        d_fmax = torch.where(pos, t, torch.zeros_like(t)).sum(1)              # [B,C]
+        d_fmax = torch.where(pos, t, 0.0).sum(1)                              # [B,C]
         d_fmin = t.sum(1) - d_fmax
-        d_pts = g.new_zeros(g.shape[0], ctx.n_points, g.shape[2])
+        d_pts = ops.zeros((g.shape[0], ctx.n_points, g.shape[2]), g.dtype, g.device)
         d_pts.scatter_add_(1, i_max.unsqueeze(1), d_fmax.unsqueeze(1))
         d_pts.scatter_add_(1, i_min.unsqueeze(1), d_fmin.unsqueeze(1))
         return d_pts, d_pix, None

@@ -58,6 +58,17 @@ class _ZeroArena:
 
 
 _arena = _ZeroArena()
+_ZERO = {}
+
+
+def zero_scalar(device, dtype=torch.float32):
+    """A permanent read-only 0-d zero on `device` (expand it where a constant zero operand is needed: padding
+    channels of a cat, the real part of a pure quaternion) — a fresh `new_zeros(())` is one fill launch each time."""
+    device = torch.device(device)
+    key = (str(device), dtype)
+    if key not in _ZERO:
+        _ZERO[key] = torch.zeros((), dtype=dtype, device=device)
+    return _ZERO[key]
 begin_step = _arena.begin_step      # called by the trainer at the top of every forward+backward
 end_step = _arena.end
 zeros = _arena.zeros

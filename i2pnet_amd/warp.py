@@ -89,6 +89,6 @@ def mul_q(a, b):
 def warp_quat_xyz(lidar_xyz, Hi_quat, H_trans):
     """p' = q [0,p] q^-1 + t for p [B,N,3], q [B,4], t [B,4] = [0,tx,ty,tz] -> [B,N,3]"""
     B, N, _ = lidar_xyz.shape
-    homo = torch.cat([lidar_xyz.new_zeros(B, N, 1), lidar_xyz], -1)
+    homo = torch.cat([ops.zero_scalar(lidar_xyz.device, lidar_xyz.dtype).expand(B, N, 1), lidar_xyz], -1)
     homo = mul_q(mul_q(Hi_quat, homo), inv_q(Hi_quat)) + H_trans.reshape(B, 1, 4)
     return homo[:, :, 1:4]
