@@ -464,3 +464,25 @@ def test_pose_loss_oracle_vs_torch(oracle_backend, l1):
     for a, b in zip(*res):
         assert a.shape == b.shape or a.numel() == b.numel()
         assert torch.allclose(a.reshape(-1), b.reshape(-1), rtol=1e-5, atol=1e-6)
+
+
+def test_zero_arena_prefix_reset():
+    """ops.zeros hands out slices of one buffer that `begin_step` clears with a single memset over the prefix ever used:
+    slices come back zero, at the same addresses, and requests above the limit fall back to torch.zeros."""
+    from i2pnet_amd import ops
+    d = torch.device("cpu")
+    ops.begin_step(d)
+    a = ops.zeros((1000,), torch.float32, d); a.fill_(3)
+    b = ops.zeros((300 << 10,), torch.uint8, d); b.fill_(7)
+    ops.begin_step(d)
+    a2 = ops.zeros((1000,), torch.float32, d); b2 = ops.zeros((300 << 10,), torch.uint8, d)
+    c2 = ops.zeros((100 << 10,), torch.float32, d)                  # beyond the previous step's high-water mark
+    assert a2.data_ptr() == a.data_ptr() and float(a2.abs().sum()) == 0 and int(b2.sum()) == 0 and float(c2.sum()) == 0
+    c2.fill_(1)
+    ops.begin_step(d)
+    big = ops.zeros((2 << 20,), torch.float32, d)                   # 8 MB: not from the arena
+    a3 = ops.zeros((1000,), torch.float32, d); ops.zeros((300 << 10,), torch.uint8, d)
+    c3 = ops.zeros((100 << 10,), torch.float32, d)
+    assert float(big.sum()) == 0 and a3.data_ptr() == a.data_ptr() and c3.data_ptr() == c2.data_ptr() and float(c3.sum()) == 0
+    ops.end_step(d)
+    assert float(ops.zeros((4,), torch.float32, d).sum()) == 0      # no arena active: plain torch.zeros
