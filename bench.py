@@ -213,7 +213,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():        # also the forced 1-rank group of tools/ddp_smoke.sh
         dist.barrier()
         dist.destroy_process_group()
 
