@@ -11,6 +11,8 @@ fine cost volume over 32-NN pixels -> fine pose -> pose composition.
 Host-side differences from the reference: no CPU round trip for the 3x3 intrinsic inverse
 (`torch.inverse(intrinsic_3.cpu())`, :282, forces a sync every forward) and no `.item()`.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -65,6 +67,21 @@ def inverse_3x3(m):
     c2 = torch.linalg.cross(r0, r1, dim=-1)
     det = (r0 * c0).sum(-1)
     return torch.stack([c0, c1, c2], dim=-1) / det.view(-1, 1, 1)
+
+
+# image encoder || LiDAR pyramid on two HIP streams (fork / join captured into the hipGraph).  Measured on MI355X, A/B
+# on one box: 485-488 samples/s with the two branches against 491-495 in one stream — the pyramid's small launches do not
+# hide under the encoder's kernels, they slow them down — so it stays OFF unless I2P_OVERLAP=1.
+OVERLAP_BRANCHES = os.environ.get("I2P_OVERLAP", "0") == "1"
+_SIDE = {}
+
+
+def _side_stream(dev):
+    dev = torch.device(dev)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=key)
+    return _SIDE[key]
 
 
 class RegNet_v2(nn.Module):
@@ -143,6 +160,36 @@ class RegNet_v2(nn.Module):
         self.sq = nn.Parameter(torch.tensor([cfg.sq_init]), requires_grad=True)
         self.sx = nn.Parameter(torch.tensor([cfg.sx_init]), requires_grad=True)
 
+    def _image_branch(self, rgb_img, intrinsic):
+        """image encoder -> (RF3 [B,128,h3,w3], pixel rays [B,M,3], RF3 as points [B,M,C], its unit-variance form)"""
+        rgb_img = rgb_img.contiguous(memory_format=torch.channels_last)
+        RF3 = self.RGB_net3(self.RGB_net2(self.RGB_net1(rgb_img)))             # [B,128,h3,w3]
+        pix_index = set_id_grid(RF3.permute(0, 2, 3, 1))                        # [B,M,3]
+        # pixel rays in the normalised camera plane of the level-3 feature map
+        K3_inv = inverse_3x3(change_intrinsic(intrinsic, RF3, rgb_img))
+        pix_rays = torch.bmm(K3_inv, pix_index.permute(0, 2, 1)).permute(0, 2, 1)   # [B,M,3]
+        RF3_pts = RF3.reshape(RF3.shape[0], RF3.shape[1], -1).permute(0, 2, 1)  # [B,M,C]
+        return RF3, pix_rays, RF3_pts, _unit_variance(RF3_pts)
+
+    def _lidar_branch(self, lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev):
+        """spherical projection + the four set-abstraction levels -> everything the cost volumes and heads read"""
+        lidar_norm = torch.zeros(B, N, 3, device=dev) if lidar_feature is None else lidar_feature
+        raw_img, (feat_img, cam_img) = P.project_seq(lidar_img_raw.float(), [lidar_norm.float(), lidar_img.float()],
+                                                     cfg.init_H, cfg.init_W, cfg.rank, cfg.fup, cfg.fdown)
+        rfp = cfg.raw_feat_point
+        P1_raw, P1, LF1, _, _ = self.LiDAR_lv1.forward_center(raw_img, cam_img, feat_img, cfg=cfg,
+                                                            using_intens=cfg.using_intens, raw_feat_point=rfp)
+        P2_raw, P2, LF2, _, _ = self.LiDAR_lv2(P1_raw, P1, LF1, cfg=cfg, raw_feat_point=rfp)
+        P3_raw, P3, LF3, _, _ = self.LiDAR_lv3(P2_raw, P2, LF2, cfg=cfg, raw_feat_point=rfp)
+        P4_raw, P4, LF4, _, sample_idx_4 = self.LiDAR_lv4(P3_raw, P3, LF3, cfg=cfg, raw_feat_point=rfp)
+        H3, W3 = self.lidar_Hs[2], self.lidar_Ws[2]
+        P3_pts = P3.reshape(B, H3 * W3, 3)
+        LF3_pts = LF3.reshape(B, H3 * W3, -1)
+        lidar_z = P3_pts[:, :, 2:]
+        lidar_uv = P3_pts / (lidar_z + 1e-10)
+        return (P3_raw, P3, LF3, P4_raw, P4, LF4, sample_idx_4, P3_pts, LF3_pts, lidar_z, lidar_uv,
+                _unit_variance(LF3_pts))
+
     def forward(self, rgb_img, lidar_img, lidar_img_raw, H_initial, intrinsic, resize_img, gt_project=None,
                 calib=None, lidar_feature=None, cfg=None):
         """rgb_img [B,3,h,w]; lidar_img [B,N,3] cloud in the (mis-calibrated) camera frame;
@@ -154,36 +201,30 @@ class RegNet_v2(nn.Module):
         B = rgb_img.shape[0]
         N = lidar_img.shape[1]
 
-        rgb_img = rgb_img.contiguous(memory_format=torch.channels_last)
-        RF3 = self.RGB_net3(self.RGB_net2(self.RGB_net1(rgb_img)))             # [B,128,h3,w3]
-        pix_index = set_id_grid(RF3.permute(0, 2, 3, 1))                        # [B,M,3]
-
-        lidar_norm = torch.zeros(B, N, 3, device=dev) if lidar_feature is None else lidar_feature
-        raw_img, (feat_img, cam_img) = P.project_seq(lidar_img_raw.float(), [lidar_norm.float(), lidar_img.float()],
-                                                     cfg.init_H, cfg.init_W, cfg.rank, cfg.fup, cfg.fdown)
-
+        # The image encoder and the LiDAR pyramid are independent until the first cost volume; with OVERLAP_BRANCHES the
+        # pyramid is issued on a side stream (two parallel branches in the captured hipGraph, forward and backward).
+        side = _side_stream(dev) if (OVERLAP_BRANCHES and rgb_img.is_cuda) else None
+        if side is not None:
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                lidar = self._lidar_branch(lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev)
+            RF3, pix_rays, RF3_pts, RF3_unit = self._image_branch(rgb_img, intrinsic)
+            cur.wait_stream(side)
+            for t in lidar:                               # produced on `side`, consumed (and later freed) under `cur`
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+        else:
+            RF3, pix_rays, RF3_pts, RF3_unit = self._image_branch(rgb_img, intrinsic)
+            lidar = self._lidar_branch(lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev)
+        (P3_raw, P3, LF3, P4_raw, P4, LF4, sample_idx_4, P3_pts, LF3_pts, lidar_z, lidar_uv, LF3_unit) = lidar
         rfp = cfg.raw_feat_point
-        P1_raw, P1, LF1, _, _ = self.LiDAR_lv1.forward_center(raw_img, cam_img, feat_img, cfg=cfg,
-                                                            using_intens=cfg.using_intens, raw_feat_point=rfp)
-        P2_raw, P2, LF2, _, _ = self.LiDAR_lv2(P1_raw, P1, LF1, cfg=cfg, raw_feat_point=rfp)
-        P3_raw, P3, LF3, _, _ = self.LiDAR_lv3(P2_raw, P2, LF2, cfg=cfg, raw_feat_point=rfp)
-        P4_raw, P4, LF4, _, sample_idx_4 = self.LiDAR_lv4(P3_raw, P3, LF3, cfg=cfg, raw_feat_point=rfp)
-
-        # pixel rays in the normalised camera plane of the level-3 feature map
-        K3_inv = inverse_3x3(change_intrinsic(intrinsic, RF3, rgb_img))
-        pix_rays = torch.bmm(K3_inv, pix_index.permute(0, 2, 1)).permute(0, 2, 1)   # [B,M,3]
-
         H3, W3 = self.lidar_Hs[2], self.lidar_Ws[2]
         H4, W4 = self.lidar_Hs[-1], self.lidar_Ws[-1]
-        P3_pts = P3.reshape(B, H3 * W3, 3)
-        LF3_pts = LF3.reshape(B, H3 * W3, -1)
-        lidar_z = P3_pts[:, :, 2:]
-        lidar_uv = P3_pts / (lidar_z + 1e-10)
-        RF3_pts = RF3.reshape(B, RF3.shape[1], -1).permute(0, 2, 1)             # [B,M,C]
         l3_idx_n2 = P.get_idx_cuda(B, H3, W3, dev)
+        normalised = (LF3_unit, RF3_unit)                                       # shared by both cost volumes
 
         # ---- coarse level --------------------------------------------------------------------
-        normalised = (_unit_variance(LF3_pts), _unit_variance(RF3_pts))        # shared by both cost volumes
         concat_4 = self.cost_volume1(P3_raw, lidar_uv, LF3_pts, l3_idx_n2, pix_rays, RF3_pts, lidar_z, cfg=cfg,
                                      normalised=normalised)
         _, _, l4_embed, _, _ = self.layer_idx(P3_raw, P3, concat_4, sample_idx=sample_idx_4, cfg=cfg,
