@@ -198,7 +198,7 @@ class Evaluator:
                 self._forward(self._static)
         torch.cuda.current_stream(self.device).wait_stream(side)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):     # see train._CAPTURE_MODE
             self._out = self._forward(self._static)
 
     def _stage(self, sample):

@@ -33,6 +33,13 @@ def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+# hipGraph capture mode.  With a process group alive, the RCCL watchdog thread polls its work events
+# (hipEventQuery) at any time; under the default "global" mode such a call from ANOTHER thread during a capture is an
+# error that invalidates the capture and kills the watchdog (SIGABRT, seen in ~1 of 4 launches).  "thread_local"
+# restricts the check to the capturing thread.
+_CAPTURE_MODE = "thread_local"
+
+
 def init_distributed(backend):
     rank, local_rank, world = dist_env()
     if (world > 1 or os.environ.get("I2P_FORCE_DP")) and not dist.is_initialized():
@@ -193,15 +200,15 @@ class Trainer:
             torch.cuda.synchronize()
             if self.world_size == 1 and not os.environ.get("I2P_FORCE_DP"):
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode=_CAPTURE_MODE):
                     self._static_out = self._forward_backward(self._static)
                     self._update()
                 self._graph_a, self._graph_b = graph, None
             else:
                 ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga):
+                with torch.cuda.graph(ga, capture_error_mode=_CAPTURE_MODE):
                     self._static_out = self._forward_backward(self._static)
-                with torch.cuda.graph(gb, pool=ga.pool()):
+                with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=_CAPTURE_MODE):
                     self._update()
                 self._graph_a, self._graph_b = ga, gb
             return True
