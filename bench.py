@@ -151,17 +151,97 @@ def cpu_baseline(cfg, batch_size=2, steps=2):
             "kind": "port", "sample": f"{steps} training steps at batch {batch_size} (same shapes), host cpu_count={os.cpu_count()}"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher.  Re-executes this
+    file under `torch.distributed.run` (one process per GPU, rendezvous on 127.0.0.1, a free port), passes the
+    children's output through (rank 0 prints the one JSON line) and exits with the launcher's status."""
+    import subprocess
+    if not args.selftest_cpu:
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible: refusing to run fewer ranks "
+                  f"than asked for", file=sys.stderr, flush=True)
+            sys.exit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1) // 2)))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def _selftest_cpu(args):
+    """Launcher / timing / JSON plumbing of the N > 1 path on CPU ranks (gloo), for tests/test_bench_launcher.py:
+    the same Trainer step on a reduced shape with the CPU oracle as operator backend.  NOT a measurement: the
+    metric is named `selftest` and the mode needs I2P_BENCH_SELFTEST=1."""
+    if os.environ.get("I2P_BENCH_SELFTEST") != "1":
+        print("bench.py: --selftest-cpu is a test hook (set I2P_BENCH_SELFTEST=1)", file=sys.stderr)
+        sys.exit(2)
+    from i2pnet_amd import ops, synth
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd.train import Trainer, init_distributed
+    from oracle import oracle
+    ops.set_backend(oracle.backend())
+    torch.set_num_threads(2)
+    rank, local_rank, world = init_distributed("gloo")
+    if world != args.gpus:
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr); sys.exit(2)
+    tr = Trainer(cfg=cfg, device="cpu", world_size=world, local_rank=local_rank)
+    batch = synth.make_batch(1, 2048, 160, 512, seed=1000 + rank)
+    for _ in range(args.warmup):
+        tr.step(batch)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _, _ = tr.step(batch)
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "selftest (CPU ranks, gloo, oracle operators: launcher plumbing only)",
+                          "value": round(world * args.steps / float(t), 4), "unit": "samples/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(t) / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": "selftest", "parallelism": f"dp{world}",
+                                                          "final_loss": round(float(loss), 4)}}), flush=True)
+    if dist.is_initialized():
+        dist.barrier(); dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (configs[1]: 8)")
-    ap.add_argument("--points", type=int, default=8192)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (configs[1]: 8, configs[2]: 16)")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 4],
+                    help="BASELINE.json configs[i]: 1 = KITTI-shaped fp32 batch 8 (default, the driver's line); "
+                         "2 = KITTI-shaped bf16 activations batch 16; 4 = nuScenes range image (21x1800, 16384 points) bf16")
+    ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--layout", default="scan", choices=["scan", "centre"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="capture the step in hipGraphs (0 = eager)")
+    ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    dflt = {1: (8, 8192), 2: (16, 8192), 4: (8, 16384)}[args.config]
+    args.batch = dflt[0] if args.batch is None else args.batch
+    args.points = dflt[1] if args.points is None else args.points
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _spawn_ranks(args, sys.argv[1:])
+    if args.selftest_cpu:
+        return _selftest_cpu(args)
 
     from i2pnet_amd import synth
     from i2pnet_amd.config import I2PNetConfig as cfg
@@ -169,7 +249,12 @@ def main():
 
     torch.backends.cudnn.benchmark = True   # MIOpen exhaustive find for the 15 image-encoder convolutions (in the warm-up steps)
     rank, local_rank, world = init_distributed("nccl")
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr, flush=True)
+        sys.exit(2)
+    if torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} has no GPU (device_count={torch.cuda.device_count()})", file=sys.stderr, flush=True)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -177,6 +262,10 @@ def main():
     tr = Trainer(cfg=cfg, device=device, world_size=world, local_rank=local_rank, capturable=use_graph)
     batch = synth.make_batch(args.batch, args.points, 375, 1242, seed=1000 + rank, device=device, layout=args.layout)
     graph_live = tr.capture(batch) if use_graph else False
+    if use_graph and not graph_live:       # an eager step is 3-4x slower: never report it as the captured number
+        print("bench.py: hipGraph capture failed (see the message above); run with --graph 0 for an eager measurement",
+              file=sys.stderr, flush=True)
+        sys.exit(3)
 
     def sync():
         if world > 1:

@@ -171,6 +171,36 @@ def check_valid(xyz):
 # ---------------------------------------------------------------------------------------------
 
 
+class _ProjectSeq(torch.autograd.Function):
+    """The scatter of `project_seq` with the gradient of the reference's `index_put_` formulation (utils.py:173-177):
+    the cells are computed without gradient (utils.py:140), the scattered VALUES are differentiable — a cell's
+    gradient goes back to the point that won it (every point wins at most one cell, so the backward is a plain
+    gather along the winner map, no accumulation)."""
+
+    @staticmethod
+    def forward(ctx, H, W, fup, fdown, xyz, *feats):
+        out_xyz, outs, winner = ops.get_backend().project_seq(xyz.detach(), [f.detach() for f in feats], H, W, fup, fdown)
+        ctx.save_for_backward(winner)
+        ctx.n = xyz.shape[1]
+        ctx.mark_non_differentiable(winner)
+        return (out_xyz, winner, *outs)
+
+    @staticmethod
+    def backward(ctx, g_xyz, _g_winner, *g_feats):
+        winner, = ctx.saved_tensors                          # [B, H*W] i32, -1 = empty cell
+        B, HW = winner.shape
+        valid = winner >= 0
+        idx = winner.clamp_min(0).long()
+
+        def back(g):
+            if g is None:
+                return None
+            g = g.reshape(B, HW, -1) * valid.unsqueeze(-1)
+            out = g.new_zeros(B, ctx.n, g.shape[-1])
+            return out.scatter_add_(1, idx.unsqueeze(-1).expand(-1, -1, g.shape[-1]), g)
+        return (None, None, None, None, back(g_xyz), *[back(g) for g in g_feats])
+
+
 def project_seq(xyz, features, H, W, use_rank=True, fup=2.0, fdown=-24.8):
     """xyz [B,N,3], features list of [B,N,D] -> (xyz_proj [B,H,W,3], [feature_proj [B,H,W,D]]).
 
@@ -184,6 +214,9 @@ def project_seq(xyz, features, H, W, use_rank=True, fup=2.0, fdown=-24.8):
             rank = torch.argsort(torch.norm(xyz, p=2, dim=2), dim=1, descending=True)  # utils.py:159
         xyz = torch.gather(xyz, 1, rank[:, :, None].expand(-1, -1, 3)).contiguous()
         feats = [torch.gather(f, 1, rank[:, :, None].expand(-1, -1, f.shape[-1])).contiguous() for f in feats]
+    if torch.is_grad_enabled() and (xyz.requires_grad or any(f.requires_grad for f in feats)):
+        res = _ProjectSeq.apply(H, W, fup, fdown, xyz, *feats)      # learned inputs: differentiable scatter
+        return res[0], list(res[2:])
     with torch.no_grad():
         out_xyz, outs, _ = ops.get_backend().project_seq(xyz, feats, H, W, fup, fdown)
     return out_xyz, outs

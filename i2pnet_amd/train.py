@@ -61,6 +61,18 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros_like(param)
         self.step_t = torch.zeros((), dtype=torch.float32, device=param.device)
         self.lr_t = torch.full((), lr, dtype=torch.float32, device=param.device)
+        # 1 where the segment belongs to a parameter that receives a gradient, 0 where autograd leaves `.grad` None:
+        # torch.optim.Adam skips such parameters entirely (no decay, no moments); with g*mask == 0 both moments stay
+        # zero and the update is 0 / (0 + eps) = 0
+        self.mask = None
+
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_t, "lr": self.lr_t}
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.step_t.copy_(sd["step"]); self.lr_t.copy_(sd["lr"])
 
     @torch.no_grad()
     def step(self):
@@ -68,6 +80,8 @@ class FlatAdam:
         self.step_t += 1.0
         if self.weight_decay != 0.0:
             g = g.add(self.param, alpha=self.weight_decay)
+        if self.mask is not None:
+            g = g * self.mask
         self.exp_avg.lerp_(g, 1.0 - self.beta1)
         self.exp_avg_sq.mul_(self.beta2).addcmul_(g, g, value=1.0 - self.beta2)
         bc1 = 1.0 - torch.pow(self.beta1, self.step_t)
@@ -80,10 +94,17 @@ class FlatAdam:
         self.lr_t.mul_(gamma)
 
 
+# what a step reads of a loader sample dict (kitti_odometry_corr_lidarnone_proj.py:757-789 also carries strings
+# such as `path_info` and unused tensors such as `resize_img`: they never reach the device)
+STEP_KEYS = ("rgb", "lidar", "raw_point_xyz", "lidar_feats", "init_intrinsic", "init_extrinsic", "decalib_real_gt",
+             "decalib_dual_gt")
+
+
 class Trainer:
     def __init__(self, cfg=I2PNetConfig, device="cuda", lr=1e-3, clip=10.0, world_size=1, local_rank=0,
-                 seed=0, capturable=False, net_cls=RegNet_v2, call=None):
-        """`net_cls` / `call`: another registration network with the same outputs (e.g. the small-range model,
+                 seed=0, capturable=None, net_cls=RegNet_v2, call=None):
+        """`capturable` is accepted for compatibility and ignored (FlatAdam is always graph-safe).
+        `net_cls` / `call`: another registration network with the same outputs (e.g. the small-range model,
         i2pnet_amd.small_range.RegNet_v2) and how to call it: call(net, batch, cfg) -> its output tuple."""
         torch.manual_seed(seed)                 # identical initial weights on every rank
         self.cfg, self.device, self.clip = cfg, torch.device(device), clip
@@ -125,11 +146,20 @@ class Trainer:
         self._graph_a = self._graph_b = None
         self._static = None
         self._static_out = None
+        self._mask_known = False
 
     # ---- the three pieces of a step -----------------------------------------------------------------
     def _forward_backward(self, batch):
         self.model.train()
         ops.begin_step(self.device)             # one memset for every small accumulator of this step
+        try:
+            return self._forward_backward_in_step(batch)
+        finally:
+            # the arena belongs to THIS step: outside, ops.zeros() is torch.zeros again (a later graph capture — the
+            # evaluator's, bench_infer's — would otherwise bake arena slices in as "zero" accumulators without a memset)
+            ops.end_step(self.device)
+
+    def _forward_backward_in_step(self, batch):
         for p in self.params:                   # autograd then hands its buffers over instead of accumulating
             p.grad = None
         if self._call is not None:
@@ -143,6 +173,14 @@ class Trainer:
         loss.backward()
         zero = self._zero
         grads = []
+        if not self._mask_known:                # first step: which parameters does this loss reach at all? (host-side
+            self._mask_known = True             # knowledge: no synchronisation)
+            if any(p.grad is None for p in self.params):
+                mask = torch.ones_like(self.flat_param)
+                for p, off in zip(self.params, self._offsets):
+                    if p.grad is None:
+                        mask[off:off + (p.numel() + 3) // 4 * 4] = 0.0
+                self.optimizer.mask = mask
         for p, nhwc in zip(self.params, self._nhwc):
             if p.grad is None:                  # parameter not reached by this loss
                 grads.append(zero.expand(p.numel()))
@@ -177,7 +215,20 @@ class Trainer:
             self.flat_grad.mul_(torch.clamp(self.clip / (total + 1e-6), max=1.0))
         self.optimizer.step()
 
+    def _to_device(self, batch):
+        """the tensors a step reads, on the trainer's device as fp32 (the reference moves each entry explicitly,
+        train20v2learn_wandb_proj.py:440-450); everything else in the sample dict is ignored"""
+        out = {}
+        for k in STEP_KEYS:
+            v = batch.get(k)
+            if isinstance(v, torch.Tensor):
+                if v.device != self.device or v.dtype != torch.float32:
+                    v = v.to(self.device, dtype=torch.float32, non_blocking=True)
+                out[k] = v
+        return out
+
     def _eager_step(self, batch):
+        batch = self._to_device(batch)
         out = self._forward_backward(batch)
         self._all_reduce()
         self._update()
@@ -186,12 +237,15 @@ class Trainer:
     # ---- hipGraph capture ---------------------------------------------------------------------------------
     def capture(self, batch, warmup=3):
         """Capture the step as hipGraphs (static shapes).  `batch` provides the static input buffers; later
-        `step()` calls copy into them and replay.  Requires `capturable=True`.  Returns True if the graphs
-        are live, False if capture failed (the trainer then keeps running eagerly)."""
+        `step()` calls copy into them and replay.  Returns True if the graphs are live, False if capture failed
+        (the trainer then keeps running eagerly).  The `warmup` eager steps (allocator, MIOpen solver search) and the
+        capture pass itself run on `batch`, but parameters, Adam state, BN buffers and the RNG state are restored
+        afterwards: the first `step()` after `capture()` is optimisation step 1, as in eager training."""
         assert self.device.type == "cuda"
-        self._static = {k: v.clone() for k, v in batch.items()}
+        self._static = {k: v.clone() for k, v in self._to_device(batch).items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        snap = self._snapshot()
         try:
             with torch.cuda.stream(side):
                 for _ in range(warmup):
@@ -211,20 +265,55 @@ class Trainer:
                 with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=_CAPTURE_MODE):
                     self._update()
                 self._graph_a, self._graph_b = ga, gb
+            torch.cuda.synchronize()
+            self._restore(snap)
             return True
         except Exception as e:                      # noqa: BLE001 — fall back to eager, loudly
             print(f"[i2pnet_amd.train] hipGraph capture failed, staying eager: {type(e).__name__}: {e}", flush=True)
             self._graph_a = self._graph_b = None
             torch.cuda.synchronize()
+            self._restore(snap)
             return False
+
+    def _snapshot(self):
+        return {"param": self.flat_param.clone(), "opt": {k: v.clone() for k, v in self.optimizer.state_dict().items()},
+                "buffers": [b.clone() for b in self.net.buffers()], "frozen": [p.detach().clone() for p in self.net.parameters() if not p.requires_grad],
+                "rng": torch.cuda.get_rng_state(self.device), "rng_cpu": torch.get_rng_state()}
+
+    @torch.no_grad()
+    def _restore(self, snap):
+        self.flat_param.copy_(snap["param"])
+        self.optimizer.load_state_dict(snap["opt"])
+        for b, v in zip(self.net.buffers(), snap["buffers"]):
+            b.copy_(v)
+        for p, v in zip([p for p in self.net.parameters() if not p.requires_grad], snap["frozen"]):
+            p.copy_(v)
+        torch.cuda.set_rng_state(snap["rng"], self.device); torch.set_rng_state(snap["rng_cpu"])
+
+    # ---- checkpoints: the reference's dict layout (train20v2learn_wandb_proj.py:254-268) + the flat Adam state ----
+    def save_checkpoint(self, path, epoch=0):
+        torch.save({"epoch": epoch, "model_state_dict": self.net.state_dict(),
+                    "optimizer_state_dict": {k: v.detach().cpu() for k, v in self.optimizer.state_dict().items()},
+                    "scheduler_state_dict": {"gamma": self.lr_gamma}}, path)
+
+    def load_checkpoint(self, path):
+        ckpt = torch.load(path, map_location="cpu")
+        sd = {k[7:] if k.startswith("module.") else k: v for k, v in ckpt["model_state_dict"].items()}
+        with torch.no_grad():                       # parameters are views into the flat buffer: copy, never rebind
+            self.net.load_state_dict(sd, strict=True)
+        opt = ckpt.get("optimizer_state_dict")
+        if opt is not None and "exp_avg" in opt:    # (a reference torch.optim.Adam state has another layout: weights only)
+            self.optimizer.load_state_dict({k: v.to(self.device) for k, v in opt.items()})
+        return ckpt.get("epoch", 0)
 
     def step(self, batch):
         """one optimisation step on a sample dict (keys of the reference loader); returns the
         loss tensors without synchronising."""
         if self._graph_a is not None:
-            for k, v in batch.items():
-                if self._static[k] is not v:
-                    self._static[k].copy_(v, non_blocking=True)
+            for k, dst in self._static.items():
+                v = batch[k]
+                if dst is not v:
+                    dst.copy_(v, non_blocking=True)
             self._graph_a.replay()
             if self._graph_b is not None:
                 self._all_reduce()

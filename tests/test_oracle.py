@@ -486,3 +486,31 @@ def test_zero_arena_prefix_reset():
     assert float(big.sum()) == 0 and a3.data_ptr() == a.data_ptr() and c3.data_ptr() == c2.data_ptr() and float(c3.sum()) == 0
     ops.end_step(d)
     assert float(ops.zeros((4,), torch.float32, d).sum()) == 0      # no arena active: plain torch.zeros
+
+
+def test_project_seq_is_differentiable_in_its_values(oracle_backend):
+    """the reference's project_seq scatters with index_put_ (utils.py:173-177): gradients flow to the scattered
+    values (not through the cell indices).  Ours: a gather along the winner map."""
+    from i2pnet_amd import ops, projectpn as P, synth
+    prev = ops.set_backend(oracle_backend)
+    try:
+        xyz = synth.lidar_scan(2, 512, torch.Generator().manual_seed(0)).requires_grad_(True)
+        feat = torch.randn(2, 512, 5, generator=torch.Generator().manual_seed(1)).requires_grad_(True)
+        img, (fimg,) = P.project_seq(xyz, [feat], 16, 90, use_rank=False)
+        wx = torch.randn(img.shape, generator=torch.Generator().manual_seed(2))
+        wf = torch.randn(fimg.shape, generator=torch.Generator().manual_seed(3))
+        ((img * wx).sum() + (fimg * wf).sum()).backward()
+        # plain-torch restatement: last writer (highest index) wins a cell
+        with torch.no_grad():
+            cells = synth.spherical_cells(xyz.detach(), 16, 90)
+        gx = torch.zeros_like(xyz); gf = torch.zeros_like(feat)
+        for b in range(2):
+            win = {}
+            for n in range(512):
+                if bool((xyz[b, n] != 0).any()) or True:
+                    win[int(cells[b, n])] = n
+            for cell, n in win.items():
+                gx[b, n] = wx[b].reshape(-1, 3)[cell]; gf[b, n] = wf[b].reshape(-1, 5)[cell]
+        assert torch.allclose(xyz.grad, gx) and torch.allclose(feat.grad, gf)
+    finally:
+        ops.set_backend(prev)

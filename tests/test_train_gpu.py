@@ -37,3 +37,108 @@ def test_two_graph_dp_step_matches_single_graph(monkeypatch):
     for x, y in zip(la, lb):
         assert abs(x - y) <= 5e-2 * max(1.0, abs(x)), (la, lb)
     assert float((pa - pb).abs().max()) < 5e-2
+
+
+def _small_batch(dev, seed=5, B=2):
+    from i2pnet_amd import synth
+    return synth.make_batch(B, 8192, 375, 1242, seed=seed, device=dev)
+
+
+@pytest.mark.gpu
+def test_capture_leaves_training_state_untouched():
+    """capture() warms up and captures on the batch it is given, but the first step() afterwards is optimisation
+    step 1 from the initial weights: parameters, Adam moments, step count and BN buffers are restored."""
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd.train import Trainer
+    dev = torch.device("cuda", 0)
+    batch = _small_batch(dev)
+    tr = Trainer(cfg=cfg, device=dev, seed=0)
+    p0 = tr.flat_param.clone()
+    bufs0 = [b.clone() for b in tr.net.buffers()]
+    assert tr.capture(batch, warmup=2)
+    assert torch.equal(tr.flat_param, p0)
+    assert float(tr.optimizer.step_t) == 0.0 and float(tr.optimizer.exp_avg.abs().max()) == 0.0
+    for b, b0 in zip(tr.net.buffers(), bufs0):
+        assert torch.equal(b, b0)
+    tr.step(batch)
+    assert float(tr.optimizer.step_t) == 1.0
+
+
+@pytest.mark.gpu
+def test_loader_style_sample_dict():
+    """A reference-loader sample dict carries strings and unused tensors (kitti_odometry_corr_lidarnone_proj.py:784);
+    the trainer reads only its own keys, eager and captured, from host tensors too."""
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd.train import Trainer
+    dev = torch.device("cuda", 0)
+    host = {k: v.cpu() for k, v in _small_batch(dev).items()}
+    host["path_info"] = ["00/000000", "00/000001"]
+    host["resize_img"] = torch.zeros(2, 3, 8, 8)
+    tr = Trainer(cfg=cfg, device=dev, seed=0)
+    l_eager = tr.step(host)[0]
+    assert torch.isfinite(l_eager)
+    assert tr.capture(host, warmup=1)
+    assert torch.isfinite(tr.step(host)[0])
+
+
+@pytest.mark.gpu
+def test_evaluator_graph_after_training_step():
+    """Train, then validate in the same process (the reference workflow, train20v2learn_wandb_proj.py validate()):
+    the zero-arena of the training step must not leak into the evaluator's captured graph — every replay needs
+    freshly zeroed BN accumulators (batch-statistics BN in eval mode too)."""
+    from i2pnet_amd import evaluate as E, synth
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd.train import Trainer
+    dev = torch.device("cuda", 0)
+    tr = Trainer(cfg=cfg, device=dev, seed=0)
+    tr.step(_small_batch(dev))
+    tr.net.l3_head.DP1.p = 0.0; tr.net.l4_head.DP1.p = 0.0
+
+    def batches():
+        for i in range(4):
+            s = synth.make_batch(2, 8192, 375, 1242, seed=40 + i, device=torch.device("cpu"))
+            s["init_extrinsic"] = torch.eye(4)[:3].repeat(2, 1, 1)
+            yield s
+
+    res_g = E.Evaluator(tr.net, cfg, dev, use_graph=True).evaluate(batches())
+    res_e = E.Evaluator(tr.net, cfg, dev, use_graph=False).evaluate(batches())
+    for k in ("RRE", "RTE", "mean_roll_error", "mean_x_error"):
+        assert abs(res_g[k] - res_e[k]) <= 1e-3 * max(1.0, abs(res_e[k])), (k, res_g[k], res_e[k])
+
+
+@pytest.mark.gpu
+def test_full_step_matches_oracle_backend_step(oracle_backend):
+    """one whole optimisation step (forward, loss, backward, clip 10, Adam) on the GPU against the same
+    step with the same host logic on the CPU oracle operators: the flat parameter vector after the update.
+    Dropout off (its RNG streams differ between devices).  Adam's first step moves every weight by ~lr * sign(g), so
+    the comparison is made on the clipped gradient the optimiser consumed (relative, global) and on the parameters
+    (absolute, a fraction of lr)."""
+    from i2pnet_amd import ops, synth
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd.train import Trainer
+    dev = torch.device("cuda", 0)
+    host = synth.make_batch(2, 8192, 160, 512, seed=21, unique_cells=(64, 1800))
+
+    def one_step(device):
+        tr = Trainer(cfg=cfg, device=device, seed=0)
+        tr.net.l3_head.DP1.p = 0.0; tr.net.l4_head.DP1.p = 0.0
+        p_before = tr.flat_param.detach().cpu().clone()
+        loss = tr.step({k: v.to(device) for k, v in host.items()})[0]
+        return float(loss), tr.flat_grad.detach().cpu().double(), tr.flat_param.detach().cpu().double(), p_before.double(), tr
+
+    l_gpu, g_gpu, p_gpu, p0, tr = one_step(dev)
+    prev = ops.set_backend(oracle_backend)
+    try:
+        torch.set_num_threads(8)
+        l_cpu, g_cpu, p_cpu, p0c, _ = one_step(torch.device("cpu"))
+    finally:
+        ops.set_backend(prev)
+    assert torch.equal(p0, p0c)
+    assert abs(l_gpu - l_cpu) <= 1e-4 * abs(l_cpu), (l_gpu, l_cpu)
+    rel_g = float((g_gpu - g_cpu).norm() / g_cpu.norm())
+    assert rel_g < 2e-3, rel_g                     # whole clipped gradient, global relative L2
+    # the update itself: |dp| <= lr = 1e-3 per weight on step 1; agree to a small fraction of it in the mean
+    dp_gpu, dp_cpu = p_gpu - p0, p_cpu - p0
+    assert float(dp_cpu.abs().max()) <= 1.01e-3
+    well = g_cpu.abs() > 1e-3 * g_cpu.abs().max()   # weights whose gradient is not rounding noise: sign(g) is stable
+    assert float((dp_gpu - dp_cpu)[well].abs().mean()) < 2e-5
