@@ -126,6 +126,68 @@ def kernel_rooflines(B, device):
     return fwd
 
 
+def kernel_rooflines_bf16(B, device):
+    """configs[2] / configs[4]: live timings of the bf16-storage cost-volume kernels.  HBM-bound: a 128->128 layer reads
+    rows*128 bf16 and writes rows*128 bf16 (+ 64 KB of fp32 weights) = the BN-exact no-recompute traffic of SURVEY.md
+    §8d for one layer, halved by bf16 storage; the contraction (2*rows*128*128 flop on v_mfma_f32_32x32x16_bf16) is
+    ~1/5 of the bf16 MFMA roof at that rate.  `traffic`: PMC bytes from profiles/r02_pmc_bf16_*.txt when present."""
+    from i2pnet_amd import _lib, ops
+    hip = ops.hip_backend()
+    N, M, C = 228, 468, 128
+    rows = B * N * M
+    g = torch.Generator(device=device).manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g, device=device)
+    bf = torch.bfloat16
+    x = rnd(rows, C).to(bf); w = rnd(C, C) / C ** 0.5
+    gam = torch.ones(C, device=device); bet = torch.zeros(C, device=device)
+    y0, s0 = hip.lin_forward(x, None, 1.0, w, out_dtype=bf)
+    in_coef, in_mi = hip.bn_finalize(rows, s0, gam, bet, 1e-5)
+    x = y0                                                    # a genuine pre-BN tensor with its own statistics
+    y = torch.empty(rows, C, dtype=bf, device=device)
+    sy = torch.zeros(ops.BN_REPLICAS * 2 * C, dtype=torch.float64, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    t_fwd = _event_time_us(lambda: _lib.call("i2p_lin_fwd_bf16", rows, C, C, x.data_ptr(), 1, in_coef.data_ptr(), 0.1, w.data_ptr(),
+                                             y.data_ptr(), sy.data_ptr(), stream=st), 20)
+    alg_bytes = rows * C * 2 * 2 + C * C * 4
+    flop = 2.0 * rows * C * C
+    traffic = None
+    pmc = ROOT / "profiles" / "r02_pmc_bf16_traffic.json"
+    if pmc.exists():
+        rec = json.loads(pmc.read_text())
+        traffic = round(rec["bytes_per_launch_at_B8"] * rows / (8 * N * M))
+    fwd = {"kernel": "rg_fwd_kernel<4,true,false> (cost-volume 128->128 layer forward, bf16 storage: BN+act on load, "
+                     "v_mfma_f32_32x32x16_bf16, fp64 BN statistics of the rounded output)",
+           "bound": "hbm", "achieved": round(alg_bytes / t_fwd / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(alg_bytes / t_fwd / 1e3 / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_kernel_us": round(t_fwd, 1),
+           "bytes_per_launch_algorithmic": alg_bytes, "mfma_TFLOPs": round(flop / t_fwd / 1e6, 1)}
+    sy.zero_()
+    _lib.call("i2p_lin_fwd_bf16", rows, C, C, x.data_ptr(), 1, in_coef.data_ptr(), 0.1, w.data_ptr(), y.data_ptr(), sy.data_ptr(), stream=st)
+    out_coef, out_mi = hip.bn_finalize(rows, sy, gam, bet, 1e-5)
+    gz = (rnd(rows, C) * 0.1).to(bf)
+    ods = hip.bn_act_backward_stats_bf16(gz, y, out_coef, out_mi, 1.0)
+    t_bwd = _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), 10)
+    bwd_bytes = rows * C * 2 * (3 + 1) + rows * C * 2 * 3          # dgrad: gz, y, x in + gz_in out; wgrad: gz, y, x in
+    bwd = {"kernel": "rg_dgrad_kernel<4,false> + wgrad_bf16_kernel + reduce (backward of the same layer)", "bound": "hbm",
+           "achieved": round(bwd_bytes / t_bwd / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(bwd_bytes / t_bwd / 1e3 / HBM_PEAK_GBS, 4), "avg_us": round(t_bwd, 1), "bytes_per_call_algorithmic": bwd_bytes}
+    del gz
+    f = rnd(B, N, C); gk = rnd(B, M, C); bn = rnd(B, N, C); bk = rnd(B, M, C)
+    t_pf = _event_time_us(lambda: hip.pair_lin_forward(f, gk, bn, bk, w, out_dtype=bf), 10)
+    pf = {"kernel": "rg_fwd_kernel<4,pair> (first cost-volume layer forward: product formed on load, output bf16)", "bound": "hbm",
+          "achieved": round(rows * C * 2 / t_pf / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": round(rows * C * 2 / t_pf / 1e3 / HBM_PEAK_GBS, 4), "avg_kernel_us": round(t_pf, 1)}
+    y1, s1 = hip.pair_lin_forward(f, gk, bn, bk, w, out_dtype=bf)
+    c1, m1 = hip.bn_finalize(rows, s1, gam, bet, 1e-5)
+    gz1 = (rnd(rows, C) * 0.1).to(bf)
+    ds1 = hip.bn_act_backward_stats_bf16(gz1, y1, c1, m1, 1.0)
+    t_pb = _event_time_us(lambda: hip.pair_lin_backward(gz1, f, gk, w, y=y1, out_coef=c1, out_mi=m1, out_dsums=ds1), 10)
+    pb = {"kernel": "pair_bwd_bf16_kernel (first cost-volume layer backward)", "bound": "hbm",
+          "achieved": round(rows * C * 2 * 2 / t_pb / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": round(rows * C * 2 * 2 / t_pb / 1e3 / HBM_PEAK_GBS, 4), "avg_us": round(t_pb, 1)}
+    fwd["other_kernels"] = [bwd, pf, pb]
+    return fwd
+
+
 def cpu_baseline(cfg, batch_size=2, steps=2):
     """the same training step on the host: PyTorch-CPU model + CPU oracle operators."""
     from i2pnet_amd import modules, ops, synth
@@ -243,9 +305,13 @@ def main():
     if args.selftest_cpu:
         return _selftest_cpu(args)
 
-    from i2pnet_amd import synth
-    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd import ops, synth
+    from i2pnet_amd.config import I2PNetConfig, I2PNetConfigNuScenes
     from i2pnet_amd.train import Trainer, init_distributed
+    cfg = I2PNetConfigNuScenes if args.config == 4 else I2PNetConfig
+    bf16 = args.config in (2, 4)
+    if bf16:
+        ops.set_precision("bf16")           # bf16 storage of the fused chains' activations / gradients (configs[2], [4])
 
     torch.backends.cudnn.benchmark = True   # MIOpen exhaustive find for the 15 image-encoder convolutions (in the warm-up steps)
     rank, local_rank, world = init_distributed("nccl")
@@ -260,7 +326,8 @@ def main():
 
     use_graph = bool(args.graph)       # N>1: graph A (fwd+bwd) -> eager RCCL all-reduce of the flat gradient -> graph B (clip+Adam)
     tr = Trainer(cfg=cfg, device=device, world_size=world, local_rank=local_rank, capturable=use_graph)
-    batch = synth.make_batch(args.batch, args.points, 375, 1242, seed=1000 + rank, device=device, layout=args.layout)
+    batch = synth.make_batch(args.batch, args.points, 375, 1242, seed=1000 + rank, device=device, layout=args.layout,
+                             beams=32 if args.config == 4 else 64, fup=cfg.fup, fdown=cfg.fdown)
     graph_live = tr.capture(batch) if use_graph else False
     if use_graph and not graph_live:       # an eager step is 3-4x slower: never report it as the captured number
         print("bench.py: hipGraph capture failed (see the message above); run with --graph 0 for an eager measurement",
@@ -292,15 +359,23 @@ def main():
             "metric": "train samples/sec (img+8192-pt pair)", "value": round(global_batch * args.steps / dt, 3),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic KITTI-shaped batch, 375x1242 RGB + %d-pt cloud (%s layout), "
-                                   "fp32 forward+loss+backward+clip+Adam" % (args.points, args.layout),
+            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": {1: "configs[1]: synthetic KITTI-shaped batch, 375x1242 RGB + %d-pt cloud (%s layout), "
+                                       "fp32 forward+loss+backward+clip+Adam",
+                                    2: "configs[2]: synthetic KITTI-shaped batch, 375x1242 RGB + %d-pt cloud (%s layout), bf16 storage of "
+                                       "the fused chains' activations/gradients + bf16 MFMA point-MLP (fp32 accumulate, parameters, "
+                                       "image encoder), forward+loss+backward+clip+Adam",
+                                    4: "configs[4]: synthetic nuScenes-shaped batch (21x1800 range image), 375x1242 RGB + %d-pt cloud "
+                                       "(%s layout), bf16 storage + bf16 MFMA point-MLP, forward+loss+backward+clip+Adam"}[args.config]
+                                   % (args.points, args.layout),
                        "per_gpu_batch": args.batch, "global_batch": global_batch,
                        "parallelism": f"dp{world}", "hipgraph": graph_live, "final_loss": round(float(loss), 4)},
-            "roofline": kernel_rooflines(args.batch, device),
+            "roofline": (kernel_rooflines_bf16 if bf16 else kernel_rooflines)(args.batch, device),
         }
         if world == 1 and not args.no_cpu_baseline:
+            prev = ops.set_precision("fp32")
             line["cpu_baseline"] = cpu_baseline(cfg)
+            ops.set_precision(prev)
         print(json.dumps(line), flush=True)
     if dist.is_available() and dist.is_initialized():        # also the forced 1-rank group of tools/ddp_smoke.sh
         dist.barrier()

@@ -51,13 +51,40 @@ SIGNATURES = {
     "i2p_cv_softmax_wsum_bwd": ["i"] * 4 + ["p"] * 6 + ["f", "p", "p", "f", "p", "p", "p"],
 }
 
+# entries that exist only in the device library (bf16 storage mode, deterministic scatter, fused grouping): the CPU
+# oracle restates the reference's algorithms, not our storage formats — these are checked against fp32 results
+DEVICE_ONLY = {
+    "i2p_lin_fwd_bf16": ["l", "i", "i", "p", "i", "p", "f", "p", "p", "p"],
+    "i2p_lin_fwd_2src_bf16": ["l", "i", "i", "i", "p", "p", "f", "p", "p", "f", "p", "p", "p"],
+    "i2p_pair_lin_fwd_bf16": ["i"] * 5 + ["p"] * 7,
+    "i2p_lin_bwd_bf16": ["l", "i", "i"] + ["p"] * 6 + ["i", "p", "p", "f", "p", "p", "i", "p", "p", "p", "f"],
+    "i2p_lin_bwd_2src_bf16": ["l", "i", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 3 + ["f"] + ["p"] * 8,
+    "i2p_pair_lin_bwd_bf16": ["i"] * 5 + ["p"] * 14,
+    "i2p_outer_sum_bf16": ["i"] * 4 + ["p"] * 4,
+    "i2p_to_bf16": ["l", "p", "p"],
+    "i2p_bn_act_fwd_bf16": ["l", "i", "p", "p", "f", "p"],
+    "i2p_bn_act_maxk_fwd_bf16": ["l", "i", "i", "p", "p", "f", "p", "p"],
+    "i2p_unpool_k_bf16": ["l", "i", "i", "p", "p", "p"],
+    "i2p_bn_act_bwd_stats_bf16": ["l", "i", "p", "p", "p", "p", "f", "p"],
+    "i2p_cv_softmax_wsum_fwd_bf16": ["i"] * 4 + ["p", "p", "f", "p", "p", "f", "p", "p"],
+    "i2p_cv_softmax_wsum_bwd_bf16": ["i"] * 4 + ["p"] * 6 + ["f", "p", "p", "f", "p", "p", "p"],
+    "i2p_pair_bias_bn_bwd_bf16": ["i"] * 4 + ["p"] * 10,
+    "i2p_pair_bias_bn_finish": ["i"] * 4 + ["p"] * 9,
+}
+# plain `int f(...)` helpers without a stream argument
+HELPERS = {
+    "i2p_lin_bwd_bf16_grid": ["l"],
+    "i2p_pair_lin_bwd_bf16_grid": ["i", "i", "i"],
+}
+
 _CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "p": C.c_void_p, "pp": C.c_void_p}
 
 
 def bind(lib, name, symbol, with_stream):
     """Attach argtypes/restype to `lib.symbol` for table entry `name` and return it."""
     fn = getattr(lib, symbol)
-    fn.argtypes = [_CT[k] for k in SIGNATURES[name]] + ([C.c_void_p] if with_stream else [])
+    kinds = SIGNATURES.get(name) or DEVICE_ONLY.get(name) or HELPERS[name]
+    fn.argtypes = [_CT[k] for k in kinds] + ([C.c_void_p] if with_stream else [])
     fn.restype = C.c_int
     return fn
 

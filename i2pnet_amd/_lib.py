@@ -11,6 +11,7 @@ import os
 _LIB_PATH = Path(os.environ.get("I2P_OPS_LIB") or (Path(__file__).resolve().parent / "lib" / "libi2p_ops.so"))
 _lib = None
 _fns = {}
+_helpers = {}
 
 
 class I2POpsError(RuntimeError):
@@ -33,11 +34,20 @@ def load():
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
         _lib = C.CDLL(str(_LIB_PATH))
         _lib.i2p_abi_version.restype = C.c_int
-        for name in _abi.SIGNATURES:
+        for name in list(_abi.SIGNATURES) + list(_abi.DEVICE_ONLY):
             if os.environ.get("I2P_OPS_LIB") and not hasattr(_lib, name):
                 continue                      # older build under comparison: entries it lacks stay unbound
             _fns[name] = _abi.bind(_lib, name, name, with_stream=True)
+        for name in _abi.HELPERS:
+            if hasattr(_lib, name):
+                _helpers[name] = _abi.bind(_lib, name, name, with_stream=False)
     return _lib
+
+
+def helper(name, *args):
+    """plain `int f(ints...)` helpers of the ABI (grid sizes of scratch buffers)"""
+    load()
+    return _helpers[name](*args)
 
 
 def call(name, *args, stream=0):

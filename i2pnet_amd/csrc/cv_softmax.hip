@@ -209,6 +209,17 @@ extern "C" int i2p_pair_bias_bn_bwd(int B, int N, int M, int C, const float *gz,
     I2P_RETURN_LAUNCH_STATUS();
 }
 
+// second half of i2p_pair_bias_bn_bwd on already formed k-/n-sums (shared with the bf16 entry, whose first half reads a
+// bf16 gradient tensor)
+extern "C" int i2p_pair_bias_bn_finish(int B, int N, int M, int C, const float *sum_k, const float *sum_n, const float *enc_n,
+                                       const float *enc_k, const double *dsums, const float *coef, const float *mi,
+                                       float *d_enc_n, float *d_enc_k, void *stream) {
+    if (B <= 0 || N <= 0 || M <= 0 || C <= 0 || C > 256 || (C & 3) || THREADS % C) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pair_bias_bn_bwd_kernel, dim3(B * PB_SLICES), dim3(THREADS), 0, (hipStream_t)stream, B, N, M, C, sum_k, sum_n,
+                       enc_n, enc_k, dsums, coef, mi, d_enc_n, d_enc_k);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int i2p_cv_softmax_wsum_fwd(int B, int N, int M, int C, const float *y5, const float *coef5, float slope5,
                                        const float *y3, const float *coef3, float slope3, float *out, float *msave,
                                        void *stream) {

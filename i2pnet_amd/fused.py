@@ -30,6 +30,25 @@ def layer_fits(cin, cout):
     return cin_p <= 160 and bwd <= _LDS and fwd <= _LDS
 
 
+_BF = torch.bfloat16
+
+
+def _p2(c):
+    return c in (16, 32, 64, 128)
+
+
+def chain_bf16_ok(x, first_bn, weights):
+    """bf16 storage for this chain?  (ops.set_precision("bf16"), enough rows, shapes the bf16 kernels take:
+    every output width in {16,32,64,128}; raw fp32 input of any width % 4 == 0 up to 160 — a power of two when its
+    gradient is needed; no leading BN)"""
+    if first_bn or not weights or not ops.bf16_rows_ok(x.shape[0], x.device) or x.dtype != torch.float32:
+        return False
+    cin = x.shape[1]
+    if cin % 4 or cin > 160 or (x.requires_grad and not _p2(cin)):
+        return False
+    return all(_p2(W.shape[0]) for W in weights)
+
+
 def _rep_sum(dsums, c):
     return dsums.view(ops.BN_REPLICAS, 2, c).sum(0)
 
@@ -82,9 +101,11 @@ class _MlpChain(Function):
             coefs.append(None); mis.append(None)
         nl = (len(p) - k) // 3
         sums = None
+        bf = chain_bf16_ok(x, first_bn, [p[k + 3 * i] for i in range(nl)])
+        ctx.bf16 = bf
         for i in range(nl):
             W, g, b = p[k + 3 * i], p[k + 3 * i + 1], p[k + 3 * i + 2]
-            y, sums = be.lin_forward(ys[-1], in_coef, slope_in, W.detach())
+            y, sums = be.lin_forward(ys[-1], in_coef, slope_in, W.detach(), out_dtype=_BF if bf else torch.float32)
             in_coef, mi = be.bn_finalize(rows, sums, g.detach(), b.detach(), _EPS)
             _update_running(running, i + 1, mi, rows)
             coefs.append(in_coef); mis.append(mi); ys.append(y)
@@ -97,6 +118,15 @@ class _MlpChain(Function):
             ctx.save_for_backward(*ys, *[c for c in coefs if c is not None], *[m for m in mis if m is not None], *p, arg)
             ctx.n_ys, ctx.n_coef = len(ys), len([c for c in coefs if c is not None])
             ctx.x_needs_grad = x.requires_grad
+            return out
+        if bf:                                          # the stack's output (fp32) from the bf16 pre-BN tensor
+            out = be.bn_act_apply_bf16(ys[-1], coefs[-1], slopes[-1])
+            ctx.first_bn, ctx.slopes, ctx.nl, ctx.k = first_bn, slopes, nl, k
+            ctx.save_for_backward(*ys, *[c for c in coefs if c is not None], *[m for m in mis if m is not None], *p)
+            ctx.n_ys, ctx.n_coef = len(ys), len([c for c in coefs if c is not None])
+            ctx.x_needs_grad = x.requires_grad
+            if pool_k:
+                return out.view(rows // pool_k, pool_k, -1).max(1)[0]
             return out
         # the stack's output: BN + activation of the last pre-BN tensor, materialised once
         out = torch.empty_like(ys[-1])
@@ -123,9 +153,12 @@ class _MlpChain(Function):
     def backward(ctx, g_out):
         be = ops.get_backend()
         saved = list(ctx.saved_tensors)
+        bf = getattr(ctx, "bf16", False)
         if ctx.pool_k:
             arg = saved.pop()
-            g_out = be.unpool_k(g_out.contiguous(), arg, ctx.pool_k)        # dense dL/da in one pass
+            g_out = be.unpool_k(g_out.contiguous(), arg, ctx.pool_k, dtype=_BF if bf else torch.float32)   # dense dL/da in one pass
+        elif bf:
+            g_out = be.to_bf16(g_out)
         ys = saved[:ctx.n_ys]
         cf = saved[ctx.n_ys:ctx.n_ys + ctx.n_coef]
         ms = saved[ctx.n_ys + ctx.n_coef:ctx.n_ys + 2 * ctx.n_coef]
@@ -142,7 +175,10 @@ class _MlpChain(Function):
             return (gz if ctx.x_needs_grad else None), None, None, None, None, *grads
         # last block: only the statistics pass over (dL/da, y_L); the activation derivative and the BN backward are
         # applied by the layer kernels as they load dL/da (slope_out), so dL/dy_L is never written
-        out_ds = be.bn_act_backward_stats(g_out, ys[-1], mis[-1], last_g.detach(), last_b.detach(), slopes[-1])
+        if bf:
+            out_ds = be.bn_act_backward_stats_bf16(g_out, ys[-1], coefs[-1], mis[-1], slopes[-1])
+        else:
+            out_ds = be.bn_act_backward_stats(g_out, ys[-1], mis[-1], last_g.detach(), last_b.detach(), slopes[-1])
         gz, y_out, out_coef, out_mi, slope_out = g_out, ys[-1], coefs[-1], mis[-1], slopes[-1]
         for i in range(nl, 0, -1):
             W = p[k + 3 * (i - 1)]
@@ -228,14 +264,22 @@ class _CvPiTail(Function):
         rows = B * N * M
         s1, s2, s3, se, s4, s5 = slopes
         d = lambda t: t.detach()
-        y1, st1 = be_.pair_lin_forward(f, g, bias_n, bias_k, W1)
+        widths = (W1.shape[0], W2.shape[0], W3.shape[0], enc_n.shape[-1], W4.shape[0], W5.shape[0])
+        bf = (ops.bf16_rows_ok(rows, f.device) and all(_p2(c) for c in widths) and f.shape[-1] in (32, 64, 128)
+              and W1.shape[0] in (32, 64, 128))
+        dt = _BF if bf else torch.float32
+        y1, st1 = be_.pair_lin_forward(f, g, bias_n, bias_k, W1, out_dtype=dt)
         c1, m1 = be_.bn_finalize(rows, st1, d(g1), d(b1), _EPS)
-        y2, st2 = be_.lin_forward(y1, c1, s1, d(W2)); c2, m2 = be_.bn_finalize(rows, st2, d(g2), d(b2), _EPS)
-        y3, st3 = be_.lin_forward(y2, c2, s2, d(W3)); c3, m3 = be_.bn_finalize(rows, st3, d(g3), d(b3), _EPS)
-        ye = (enc_n.unsqueeze(2) + enc_k.unsqueeze(1)).view(rows, -1)
-        ce, me = be_.bn_finalize(rows, be_.bn_stats(ye), d(ge), d(be), _EPS)
+        y2, st2 = be_.lin_forward(y1, c1, s1, d(W2), out_dtype=dt); c2, m2 = be_.bn_finalize(rows, st2, d(g2), d(b2), _EPS)
+        y3, st3 = be_.lin_forward(y2, c2, s2, d(W3), out_dtype=dt); c3, m3 = be_.bn_finalize(rows, st3, d(g3), d(b3), _EPS)
+        if bf:
+            ye, ste = be_.outer_sum_bf16(enc_n, enc_k)
+        else:
+            ye = (enc_n.unsqueeze(2) + enc_k.unsqueeze(1)).view(rows, -1)
+            ste = be_.bn_stats(ye)
+        ce, me = be_.bn_finalize(rows, ste, d(ge), d(be), _EPS)
         y4, st4 = be_.lin_forward_2src(ye, ce, se, y3, c3, s3, d(W4)); c4, m4 = be_.bn_finalize(rows, st4, d(g4), d(b4), _EPS)
-        y5, st5 = be_.lin_forward(y4, c4, s4, d(W5)); c5, m5 = be_.bn_finalize(rows, st5, d(g5), d(b5), _EPS)
+        y5, st5 = be_.lin_forward(y4, c4, s4, d(W5), out_dtype=dt); c5, m5 = be_.bn_finalize(rows, st5, d(g5), d(b5), _EPS)
         for i_, m_ in enumerate((m1, m2, m3, me, m4, m5)):       # BatchNorm2d running buffers (small-range model)
             _update_running(running, i_, m_, rows)
         out, msave = be_.cv_softmax_wsum_forward(B, N, M, y5, c5, s5, y3, c3, s3)

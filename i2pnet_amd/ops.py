@@ -17,7 +17,33 @@ import torch
 from . import _abi, _lib
 
 _F32, _I32, _I64 = torch.float32, torch.int32, torch.int64
+_BF16 = torch.bfloat16
 BN_REPLICAS = 32          # I2P_BN_REPLICAS in include/i2p_ops.h
+
+# ---- activation storage precision of the fused layer chains ---------------------------------------------------------
+# "fp32" (default; BASELINE configs[1], the reference's precision) or "bf16" (configs[2] / configs[4]): the pre-BN
+# [rows, C] tensors of a chain and the gradients between its layers are stored as bf16 and contracted on bf16 MFMA
+# (fp32 accumulate, fp64 BN statistics, fp32 parameters / BN / softmax arithmetic) — csrc/mlp_bf16.hip, bf16_stream.hip.
+# Chains with fewer rows than BF16_MIN_ROWS stay fp32: they are launch-latency-bound, bf16 buys them nothing and the
+# pose heads / mask predictors keep full precision.
+_PRECISION = "fp32"
+BF16_MIN_ROWS = 32768
+
+
+def set_precision(name):
+    global _PRECISION
+    if name not in ("fp32", "bf16"):
+        raise ValueError(name)
+    prev, _PRECISION = _PRECISION, name
+    return prev
+
+
+def get_precision():
+    return _PRECISION
+
+
+def bf16_rows_ok(rows, device):
+    return _PRECISION == "bf16" and torch.device(device).type == "cuda" and rows >= BF16_MIN_ROWS
 
 
 class _ZeroArena:
@@ -320,16 +346,52 @@ class CBackend:
         groups = rows // K
         out = torch.empty(groups, c, dtype=_F32, device=y.device)
         arg = torch.empty(groups, c, dtype=torch.uint8, device=y.device)
-        self._call("i2p_bn_act_maxk_fwd", int(groups), int(K), int(c), self._p(y, _F32, "y"), self._p(coef, _F32, "coef"),
+        self._call("i2p_bn_act_maxk_fwd_bf16" if y.dtype == _BF16 else "i2p_bn_act_maxk_fwd", int(groups), int(K), int(c),
+                   self._p(y, y.dtype, "y"), self._p(coef, _F32, "coef"),
                    float(slope), self._p(out, _F32, "out"), self._p(arg, torch.uint8, "arg"), stream=self._stream())
         return out, arg
 
-    def unpool_k(self, g, arg, K):
+    def unpool_k(self, g, arg, K, dtype=_F32):
         groups, c = g.shape
-        gd = torch.empty(groups * K, c, dtype=_F32, device=g.device)
-        self._call("i2p_unpool_k", int(groups), int(K), int(c), self._p(g, _F32, "g"), self._p(arg, torch.uint8, "arg"),
-                   self._p(gd, _F32, "gd"), stream=self._stream())
+        gd = torch.empty(groups * K, c, dtype=dtype, device=g.device)
+        self._call("i2p_unpool_k_bf16" if dtype == _BF16 else "i2p_unpool_k", int(groups), int(K), int(c), self._p(g, _F32, "g"),
+                   self._p(arg, torch.uint8, "arg"), self._p(gd, dtype, "gd"), stream=self._stream())
         return gd
+
+    # ---- bf16-storage helpers (csrc/bf16_stream.hip) -----------------------------------------------------------
+    def to_bf16(self, x):
+        x = x.contiguous()
+        if x.numel() % 8:
+            return x.to(_BF16)
+        y = torch.empty(x.shape, dtype=_BF16, device=x.device)
+        self._call("i2p_to_bf16", int(x.numel()), self._p(x, _F32, "x"), self._p(y, _BF16, "y"), stream=self._stream())
+        return y
+
+    def outer_sum_bf16(self, enc_n, enc_k):
+        """enc_n [B,N,C], enc_k [B,M,C] -> (ye bf16 [B*N*M, C] = enc_n[b,n] + enc_k[b,k], replicated BN sums)"""
+        B, N, C = enc_n.shape
+        M = enc_k.shape[1]
+        ye = torch.empty(B * N * M, C, dtype=_BF16, device=enc_n.device)
+        sums = zeros(BN_REPLICAS * 2 * C, torch.float64, enc_n.device)
+        self._call("i2p_outer_sum_bf16", int(B), int(N), int(M), int(C), self._p(enc_n, _F32, "enc_n"), self._p(enc_k, _F32, "enc_k"),
+                   self._p(ye, _BF16, "ye"), self._p(sums, torch.float64, "sums"), stream=self._stream())
+        return ye, sums
+
+    def bn_act_apply_bf16(self, y, coef, slope):
+        """act(bn(y)) of a bf16 pre-BN tensor with finalised coefficients -> fp32 [rows, c] (a chain's output)"""
+        rows, c = y.shape
+        out = torch.empty(rows, c, dtype=_F32, device=y.device)
+        self._call("i2p_bn_act_fwd_bf16", int(rows), int(c), self._p(y, _BF16, "y"), self._p(coef, _F32, "coef"), float(slope),
+                   self._p(out, _F32, "out"), stream=self._stream())
+        return out
+
+    def bn_act_backward_stats_bf16(self, dout, y, coef, mi, slope):
+        rows, c = y.shape
+        dsums = zeros(BN_REPLICAS * 2 * c, torch.float64, y.device)
+        self._call("i2p_bn_act_bwd_stats_bf16", int(rows), int(c), self._p(dout, _BF16, "dout"), self._p(y, _BF16, "y"),
+                   self._p(coef, _F32, "coef"), self._p(mi, _F32, "mi"), float(slope), self._p(dsums, torch.float64, "dsums"),
+                   stream=self._stream())
+        return dsums
 
     def bn_act_backward_stats(self, dout, y, mean_invstd, gamma, beta, slope):
         """replicated {sum gz, sum gz*xhat} with gz = dout * act'(bn(y)) — the statistics half of bn_act_backward"""
@@ -357,11 +419,19 @@ class CBackend:
         return dy, dgamma, dbeta
 
     # ---- fused linear layers (csrc/mlp.hip) -----------------------------------------------------
-    def lin_forward(self, x, in_coef, slope_in, w, want_stats=True):
-        """x [rows,cin]; in_coef [3,cin] or None; w [cout,cin] -> (y [rows,cout], sums or None)."""
+    def lin_forward(self, x, in_coef, slope_in, w, want_stats=True, out_dtype=_F32):
+        """x [rows,cin]; in_coef [3,cin] or None; w [cout,cin] -> (y [rows,cout], sums or None).
+        out_dtype bf16: bf16-stored output (x fp32 or bf16) on the bf16 MFMA kernels."""
         rows, cin = x.shape
         cout = w.shape[0]
         dev = x.device
+        if out_dtype == _BF16:
+            y = torch.empty(rows, cout, dtype=_BF16, device=dev)
+            sums = zeros(BN_REPLICAS * 2 * cout, torch.float64, dev)
+            self._call("i2p_lin_fwd_bf16", int(rows), int(cin), int(cout), self._p(x, x.dtype, "x"), int(x.dtype == _BF16),
+                       self._p(in_coef, _F32, "in_coef") if in_coef is not None else None, float(slope_in),
+                       self._p(w, _F32, "w"), self._p(y, _BF16, "y"), self._p(sums, torch.float64, "sums"), stream=self._stream())
+            return y, sums
         y = torch.empty(rows, cout, dtype=_F32, device=dev)
         sums = zeros(BN_REPLICAS * 2 * cout, torch.float64, dev) if want_stats else None
         self._call("i2p_lin_fwd", int(rows), int(cin), int(cout), self._p(x, _F32, "x"),
@@ -379,6 +449,20 @@ class CBackend:
         rows, cout = gz.shape
         cin = x.shape[1]
         dev = gz.device
+        if gz.dtype == _BF16:
+            gz_in = torch.empty(rows, cin, dtype=x.dtype, device=dev) if need_gx else None
+            in_dsums = (zeros(BN_REPLICAS * 2 * cin, torch.float64, dev) if (need_gx and in_coef is not None) else None)
+            grid = _lib.helper("i2p_lin_bwd_bf16_grid", int(rows))
+            part = torch.empty(grid * cout * cin + 8 * cout, dtype=_F32, device=dev)
+            dw = torch.empty(cout, cin, dtype=_F32, device=dev)
+            P = lambda t, dt=_F32: (self._p(t, dt, "t") if t is not None else None)
+            self._call("i2p_lin_bwd_bf16", int(rows), int(cin), int(cout), P(gz, _BF16), P(y, _BF16), P(out_coef), P(out_mi),
+                       P(out_dsums, torch.float64), P(x, x.dtype), int(x.dtype == _BF16), P(in_coef), P(in_mi), float(slope_in),
+                       P(w), P(gz_in, x.dtype), int(x.dtype == _BF16), P(in_dsums, torch.float64), P(part), P(dw), float(slope_out),
+                       stream=self._stream())
+            n = part.numel()
+            self.last_bn_grads = (part[n - cout:], part[n - 2 * cout:n - cout]) if out_coef is not None else None
+            return gz_in, in_dsums, dw
         gz_in = torch.empty(rows, cin, dtype=_F32, device=dev) if need_gx else None
         in_dsums = (zeros(BN_REPLICAS * 2 * cin, torch.float64, dev)
                     if (need_gx and in_coef is not None) else None)
@@ -402,11 +486,18 @@ class CBackend:
         g, self.last_bn_grads = self.last_bn_grads, None
         return g
 
-    def pair_lin_forward(self, f, g, bias_n, bias_k, w):
+    def pair_lin_forward(self, f, g, bias_n, bias_k, w, out_dtype=_F32):
         """f [B,N,C], g [B,M,C], bias_n [B,N,Co], bias_k [B,M,Co], w [Co,C] -> y [B*N*M, Co], sums"""
         B, N, C = f.shape
         M = g.shape[1]
         Co = w.shape[0]
+        if out_dtype == _BF16:
+            y = torch.empty(B * N * M, Co, dtype=_BF16, device=f.device)
+            sums = zeros(BN_REPLICAS * 2 * Co, torch.float64, f.device)
+            self._call("i2p_pair_lin_fwd_bf16", int(B), int(N), int(M), int(C), int(Co), self._p(f, _F32, "f"), self._p(g, _F32, "g"),
+                       self._p(bias_n, _F32, "bias_n"), self._p(bias_k, _F32, "bias_k"), self._p(w, _F32, "w"), self._p(y, _BF16, "y"),
+                       self._p(sums, torch.float64, "sums"), stream=self._stream())
+            return y, sums
         y = torch.empty(B * N * M, Co, dtype=_F32, device=f.device)
         sums = zeros(BN_REPLICAS * 2 * Co, torch.float64, f.device)
         self._call("i2p_pair_lin_fwd", int(B), int(N), int(M), int(C), int(Co), self._p(f, _F32, "f"),
@@ -424,6 +515,16 @@ class CBackend:
         dev = f.device
         d_f = zeros((B, N, C), _F32, dev); d_g = zeros((B, M, C), _F32, dev)
         d_bn = zeros((B, N, Co), _F32, dev); d_bk = zeros((B, M, Co), _F32, dev)
+        if gy.dtype == _BF16:
+            grid = _lib.helper("i2p_pair_lin_bwd_bf16_grid", int(B), int(N), int(M))
+            part = torch.empty(grid * Co * C + 8 * Co, dtype=_F32, device=dev)
+            dw = torch.empty(Co, C, dtype=_F32, device=dev)
+            o = lambda t, dt=_F32: self._p(t, dt, "bn") if t is not None else None
+            self._call("i2p_pair_lin_bwd_bf16", int(B), int(N), int(M), int(C), int(Co), self._p(gy, _BF16, "gy"), o(y, _BF16),
+                       o(out_coef), o(out_mi), o(out_dsums, torch.float64), self._p(f, _F32, "f"), self._p(g, _F32, "g"),
+                       self._p(w, _F32, "w"), self._p(d_f, _F32, "d_f"), self._p(d_g, _F32, "d_g"), self._p(d_bn, _F32, "d_bn"),
+                       self._p(d_bk, _F32, "d_bk"), self._p(part, _F32, "part"), self._p(dw, _F32, "dw"), stream=self._stream())
+            return d_f, d_g, d_bn, d_bk, dw
         KT = (M + 63) // 64
         NC = max(1, min(N, 256 // (B * KT)))
         grid = B * KT * NC if self.device_type == "cuda" else 1          # i2p_pair_lin_bwd_grid
@@ -449,8 +550,14 @@ class CBackend:
         rows, ca = xa.shape
         cb = xb.shape[1]
         cout = w.shape[0]
-        y = torch.empty(rows, cout, dtype=_F32, device=xa.device)
+        y = torch.empty(rows, cout, dtype=xa.dtype, device=xa.device)
         sums = zeros(BN_REPLICAS * 2 * cout, torch.float64, xa.device)
+        if xa.dtype == _BF16:
+            self._call("i2p_lin_fwd_2src_bf16", int(rows), int(ca), int(cb), int(cout), self._p(xa, _BF16, "xa"),
+                       self._p(coef_a, _F32, "coef_a"), float(slope_a), self._p(xb, _BF16, "xb"), self._p(coef_b, _F32, "coef_b"),
+                       float(slope_b), self._p(w, _F32, "w"), self._p(y, _BF16, "y"), self._p(sums, torch.float64, "sums"),
+                       stream=self._stream())
+            return y, sums
         self._call("i2p_lin_fwd_2src", int(rows), int(ca), int(cb), int(cout), self._p(xa, _F32, "xa"),
                    self._p(coef_a, _F32, "coef_a"), float(slope_a), self._p(xb, _F32, "xb"),
                    self._p(coef_b, _F32, "coef_b"), float(slope_b), self._p(w, _F32, "w"), self._p(y, _F32, "y"),
@@ -463,9 +570,21 @@ class CBackend:
         rows, cout = gz.shape
         ca, cb = xa.shape[1], xb.shape[1]
         dev = gz.device
-        gz_a = torch.empty(rows, ca, dtype=_F32, device=dev); gz_b = torch.empty(rows, cb, dtype=_F32, device=dev)
+        gz_a = torch.empty(rows, ca, dtype=gz.dtype, device=dev); gz_b = torch.empty(rows, cb, dtype=gz.dtype, device=dev)
         ds_a = zeros(BN_REPLICAS * 2 * ca, torch.float64, dev)
         ds_b = zeros(BN_REPLICAS * 2 * cb, torch.float64, dev)
+        if gz.dtype == _BF16:
+            grid = _lib.helper("i2p_lin_bwd_bf16_grid", int(rows))
+            part = torch.empty(grid * cout * (ca + cb) + 8 * cout, dtype=_F32, device=dev)
+            dw = torch.empty(cout, ca + cb, dtype=_F32, device=dev)
+            P = lambda t, dt=_F32: (self._p(t, dt, "t") if t is not None else None)
+            self._call("i2p_lin_bwd_2src_bf16", int(rows), int(ca), int(cb), int(cout), P(gz, _BF16), P(y, _BF16), P(out_coef),
+                       P(out_mi), P(out_dsums, torch.float64), P(xa, _BF16), P(coef_a), P(mi_a), float(slope_a), P(xb, _BF16),
+                       P(coef_b), P(mi_b), float(slope_b), P(e_add_b, _BF16), P(w), P(gz_a, _BF16), P(ds_a, torch.float64),
+                       P(gz_b, _BF16), P(ds_b, torch.float64), P(part), P(dw), stream=self._stream())
+            n = part.numel()
+            self.last_bn_grads = (part[n - cout:], part[n - 2 * cout:n - cout]) if out_coef is not None else None
+            return gz_a, ds_a, gz_b, ds_b, dw
         grid = 256 if self.device_type == "cuda" else 1
         part = torch.empty(min(grid, (rows + 63) // 64) * cout * (ca + cb) + 8 * cout, dtype=_F32, device=dev)
         dw = torch.empty(cout, ca + cb, dtype=_F32, device=dev)
@@ -482,8 +601,9 @@ class CBackend:
         C = y5.shape[1]
         out = torch.empty(B, N, C, dtype=_F32, device=y5.device)
         msave = torch.empty(B * N, 2, C, dtype=_F32, device=y5.device)
-        self._call("i2p_cv_softmax_wsum_fwd", int(B), int(N), int(M), int(C), self._p(y5, _F32, "y5"),
-                   self._p(coef5, _F32, "coef5"), float(slope5), self._p(y3, _F32, "y3"), self._p(coef3, _F32, "coef3"),
+        dt = y5.dtype
+        self._call("i2p_cv_softmax_wsum_fwd_bf16" if dt == _BF16 else "i2p_cv_softmax_wsum_fwd", int(B), int(N), int(M), int(C), self._p(y5, dt, "y5"),
+                   self._p(coef5, _F32, "coef5"), float(slope5), self._p(y3, dt, "y3"), self._p(coef3, _F32, "coef3"),
                    float(slope3), self._p(out, _F32, "out"), self._p(msave, _F32, "msave"), stream=self._stream())
         return out, msave
 
@@ -491,11 +611,13 @@ class CBackend:
         C = y5.shape[1]
         gz5 = torch.empty_like(y5); ga3 = torch.empty_like(y3)
         ds5 = zeros(BN_REPLICAS * 2 * C, torch.float64, y5.device)
-        self._call("i2p_cv_softmax_wsum_bwd", int(B), int(N), int(M), int(C), self._p(g_out, _F32, "g_out"),
-                   self._p(out, _F32, "out"), self._p(msave, _F32, "msave"), self._p(y5, _F32, "y5"),
-                   self._p(coef5, _F32, "coef5"), self._p(mi5, _F32, "mi5"), float(slope5), self._p(y3, _F32, "y3"),
-                   self._p(coef3, _F32, "coef3"), float(slope3), self._p(gz5, _F32, "gz5"),
-                   self._p(ds5, torch.float64, "ds5"), self._p(ga3, _F32, "ga3"), stream=self._stream())
+        dt = y5.dtype
+        self._call("i2p_cv_softmax_wsum_bwd_bf16" if dt == _BF16 else "i2p_cv_softmax_wsum_bwd", int(B), int(N), int(M), int(C),
+                   self._p(g_out, _F32, "g_out"),
+                   self._p(out, _F32, "out"), self._p(msave, _F32, "msave"), self._p(y5, dt, "y5"),
+                   self._p(coef5, _F32, "coef5"), self._p(mi5, _F32, "mi5"), float(slope5), self._p(y3, dt, "y3"),
+                   self._p(coef3, _F32, "coef3"), float(slope3), self._p(gz5, dt, "gz5"),
+                   self._p(ds5, torch.float64, "ds5"), self._p(ga3, dt, "ga3"), stream=self._stream())
         return gz5, ds5, ga3
 
     def pair_bias_bn_backward(self, B, N, M, gz, enc_n, enc_k, dsums, coef, mi):
@@ -505,7 +627,8 @@ class CBackend:
         sum_k = zeros((B, N, C), _F32, dev)
         sum_n = zeros((B, M, C), _F32, dev)
         d_n = torch.empty(B, N, C, dtype=_F32, device=dev); d_k = torch.empty(B, M, C, dtype=_F32, device=dev)
-        self._call("i2p_pair_bias_bn_bwd", int(B), int(N), int(M), int(C), self._p(gz, _F32, "gz"),
+        self._call("i2p_pair_bias_bn_bwd_bf16" if gz.dtype == _BF16 else "i2p_pair_bias_bn_bwd", int(B), int(N), int(M), int(C),
+                   self._p(gz, gz.dtype, "gz"),
                    self._p(enc_n, _F32, "enc_n"), self._p(enc_k, _F32, "enc_k"), self._p(dsums, torch.float64, "dsums"),
                    self._p(coef, _F32, "coef"), self._p(mi, _F32, "mi"), self._p(sum_k, _F32, "sum_k"),
                    self._p(sum_n, _F32, "sum_n"), self._p(d_n, _F32, "d_enc_n"), self._p(d_k, _F32, "d_enc_k"),

@@ -359,6 +359,63 @@ int i2p_pair_bias_bn_bwd(int B, int N, int M, int C, const float *gz, const floa
 int i2p_pose_loss(int B, int l1_trans, const float *out3, const float *out4, const float *q_gt, const float *t_gt,
                   const float *w_x, const float *w_q, float *loss3, float *d_out3, float *d_out4, float *d_w, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * bf16 mode (BASELINE.json configs[2], configs[4]; the reference itself is fp32-only, train20v2learn_wandb_proj.py:107):
+ * the pre-BN [rows, C] tensors of the fused layer chains (PPBackbone_center.py:34-46 blocks) and the gradients between
+ * their layers are STORED as bf16 (raw bits, `unsigned short`), the contractions run on v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation, BN statistics stay fp64, parameters, BN/activation/softmax arithmetic and every other tensor
+ * stay fp32.  Every entry below is the bf16-storage twin of the entry of the same name without the suffix; a BN is
+ * evaluated as fmaf(y, invstd*gamma, beta - mean*invstd*gamma) on the rounded y in all of them.
+ * Channel counts: bf16 tensors 16/32/64/128; an fp32 `x` (a chain's raw input) any multiple of 4 up to 160 (BN on
+ * load then needs cin in {16,..,128}).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef unsigned short i2p_bf16;
+int i2p_lin_bwd_bf16_grid(long long rows);     /* blocks of the wgrad launch: dw_partial holds grid*cout*cin + 8*cout floats */
+int i2p_lin_fwd_bf16(long long rows, int cin, int cout, const void *x, int x_bf16, const float *in_coef, float slope_in,
+                     const float *w, i2p_bf16 *y, double *sums, void *stream);
+int i2p_lin_fwd_2src_bf16(long long rows, int cin_a, int cin_b, int cout, const i2p_bf16 *xa, const float *coef_a,
+                          float slope_a, const i2p_bf16 *xb, const float *coef_b, float slope_b, const float *w,
+                          i2p_bf16 *y, double *sums, void *stream);
+int i2p_pair_lin_fwd_bf16(int B, int N, int M, int cin, int cout, const float *f, const float *g, const float *bias_n,
+                          const float *bias_k, const float *w, i2p_bf16 *y, double *sums, void *stream);
+/* gz_in: bf16 [rows,cin] (gz_in_bf16 = 1: x must be bf16; activation derivative + statistics when in_coef is given) or
+ * fp32 [rows,cin] (gz_in_bf16 = 0: gradient of a raw fp32 input, no BN in front) or NULL. */
+int i2p_lin_bwd_bf16(long long rows, int cin, int cout, const i2p_bf16 *gz, const i2p_bf16 *y, const float *out_coef,
+                     const float *out_mi, const double *out_dsums, const void *x, int x_bf16, const float *in_coef,
+                     const float *in_mi, float slope_in, const float *w, void *gz_in, int gz_in_bf16, double *in_dsums,
+                     float *dw_partial, float *dw, float slope_out, void *stream);
+int i2p_lin_bwd_2src_bf16(long long rows, int cin_a, int cin_b, int cout, const i2p_bf16 *gz, const i2p_bf16 *y,
+                          const float *out_coef, const float *out_mi, const double *out_dsums, const i2p_bf16 *xa,
+                          const float *coef_a, const float *mi_a, float slope_a, const i2p_bf16 *xb, const float *coef_b,
+                          const float *mi_b, float slope_b, const i2p_bf16 *e_add_b, const float *w, i2p_bf16 *gz_a,
+                          double *dsums_a, i2p_bf16 *gz_b, double *dsums_b, float *dw_partial, float *dw, void *stream);
+int i2p_pair_lin_bwd_bf16_grid(int B, int N, int M);
+int i2p_pair_lin_bwd_bf16(int B, int N, int M, int cin, int cout, const i2p_bf16 *gz, const i2p_bf16 *y,
+                          const float *out_coef, const float *out_mi, const double *out_dsums, const float *f,
+                          const float *g, const float *w, float *d_f, float *d_g, float *d_bias_n, float *d_bias_k,
+                          float *dw_partial, float *dw, void *stream);
+/* streaming kernels on bf16 tensors (csrc/bf16_stream.hip) */
+int i2p_outer_sum_bf16(int B, int N, int M, int C, const float *enc_n, const float *enc_k, i2p_bf16 *ye, double *sums,
+                       void *stream);          /* ye[b,n,k,:] = bf16(enc_n[b,n,:] + enc_k[b,k,:]), sums += {sum, sum^2} */
+int i2p_to_bf16(long long n, const float *x, i2p_bf16 *y, void *stream);
+int i2p_bn_act_fwd_bf16(long long rows, int c, const i2p_bf16 *y, const float *coef, float slope, float *out, void *stream);
+int i2p_bn_act_maxk_fwd_bf16(long long groups, int K, int c, const i2p_bf16 *y, const float *coef, float slope, float *out,
+                             unsigned char *arg, void *stream);
+int i2p_unpool_k_bf16(long long groups, int K, int c, const float *g, const unsigned char *arg, i2p_bf16 *gd, void *stream);
+int i2p_bn_act_bwd_stats_bf16(long long rows, int c, const i2p_bf16 *dout, const i2p_bf16 *y, const float *coef,
+                              const float *mi, float slope, double *dsums, void *stream);
+int i2p_cv_softmax_wsum_fwd_bf16(int B, int N, int M, int C, const i2p_bf16 *y5, const float *coef5, float slope5,
+                                 const i2p_bf16 *y3, const float *coef3, float slope3, float *out, float *msave, void *stream);
+int i2p_cv_softmax_wsum_bwd_bf16(int B, int N, int M, int C, const float *g_out, const float *out, const float *msave,
+                                 const i2p_bf16 *y5, const float *coef5, const float *mi5, float slope5, const i2p_bf16 *y3,
+                                 const float *coef3, float slope3, i2p_bf16 *gz5, double *dsums5, i2p_bf16 *ga3, void *stream);
+int i2p_pair_bias_bn_finish(int B, int N, int M, int C, const float *sum_k, const float *sum_n, const float *enc_n,
+                            const float *enc_k, const double *dsums, const float *coef, const float *mi, float *d_enc_n,
+                            float *d_enc_k, void *stream);   /* closed-form half of i2p_pair_bias_bn_bwd on formed sums */
+int i2p_pair_bias_bn_bwd_bf16(int B, int N, int M, int C, const i2p_bf16 *gz, const float *enc_n, const float *enc_k,
+                              const double *dsums, const float *coef, const float *mi, float *sum_k, float *sum_n,
+                              float *d_enc_n, float *d_enc_k, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

