@@ -70,12 +70,16 @@ DEVICE_ONLY = {
     "i2p_cv_softmax_wsum_bwd_bf16": ["i"] * 4 + ["p"] * 6 + ["f", "p", "p", "f", "p", "p", "p"],
     "i2p_pair_bias_bn_bwd_bf16": ["i"] * 4 + ["p"] * 10,
     "i2p_pair_bias_bn_finish": ["i"] * 4 + ["p"] * 9,
+    "i2p_pair_bias_bn_bwd_det": ["i"] * 4 + ["p"] * 9,
 }
 # plain `int f(...)` helpers without a stream argument
 HELPERS = {
     "i2p_lin_bwd_bf16_grid": ["l"],
     "i2p_pair_lin_bwd_bf16_grid": ["i", "i", "i"],
+    "i2p_pair_lin_bwd_scratch": ["i", "i", "i", "i", "i"],          # returns long long
+    "i2p_pair_bias_bn_bwd_scratch": ["i", "i", "i", "i"],           # returns long long
 }
+LONG_HELPERS = {"i2p_pair_lin_bwd_scratch", "i2p_pair_bias_bn_bwd_scratch"}
 
 _CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "p": C.c_void_p, "pp": C.c_void_p}
 
@@ -85,7 +89,7 @@ def bind(lib, name, symbol, with_stream):
     fn = getattr(lib, symbol)
     kinds = SIGNATURES.get(name) or DEVICE_ONLY.get(name) or HELPERS[name]
     fn.argtypes = [_CT[k] for k in kinds] + ([C.c_void_p] if with_stream else [])
-    fn.restype = C.c_int
+    fn.restype = C.c_longlong if name in LONG_HELPERS else C.c_int
     return fn
 
 

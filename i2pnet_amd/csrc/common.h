@@ -50,3 +50,13 @@ __device__ __forceinline__ unsigned i2p_xcd_swizzle(unsigned bid, unsigned nbloc
     const unsigned per = nblocks >> 3;
     return (bid & 7u) * per + (bid >> 3);
 }
+
+// deterministic (owner-scans-in-row-order) scatter-add backward kernels, csrc/scatter_det.hip
+int i2p_det_gather_rows_grad(int b, int hw, int c, int q, int W, const float *grad_out, const int64_t *h_idx, const int64_t *w_idx,
+                             float *grad_feat, void *stream);
+int i2p_det_gather_points_grad(int b, int c, int n, int m, const float *grad_out, const int *idx, float *grad_points, void *stream);
+int i2p_det_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight,
+                                   float *grad_points, void *stream);
+// I2P_ATOMIC_SCATTER=1: the first-generation atomicAdd kernels (A/B timing only; not reproducible run to run)
+#include <cstdlib>
+inline bool i2p_atomic_scatter() { static const char *e = getenv("I2P_ATOMIC_SCATTER"); return e && e[0] == '1'; }

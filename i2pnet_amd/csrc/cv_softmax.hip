@@ -137,6 +137,57 @@ __global__ __launch_bounds__(THREADS) void pair_sum_kernel(int B, int N, int M, 
     }
 }
 
+// Deterministic variant of pair_sum: the same sweep, but every block STORES its partial sums into its own slab
+// (sum_n: one slab per point chunk, sum_k: one per k segment) instead of adding them with fp32 atomics; the closed-form
+// kernel below adds the slabs up in slab order.
+constexpr int PSD_KSEG = 4;
+__global__ __launch_bounds__(THREADS) void pair_sum_det_kernel(int B, int N, int M, int C, const float4 *__restrict__ g,
+                                                                float *__restrict__ slab_k, float *__restrict__ slab_n) {
+    __shared__ float4 red[THREADS][PS_NL];
+    const int cv = C >> 2, ks = THREADS / cv;
+    const int c4 = threadIdx.x % cv, kslot = threadIdx.x / cv;
+    const int chunks = (N + PS_NL - 1) / PS_NL;
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks, n0 = chunk * PS_NL;
+    const int kseg = (M + gridDim.y - 1) / gridDim.y, k_lo = blockIdx.y * kseg, k_hi = min(M, k_lo + kseg);
+    float4 acc[PS_NL];
+#pragma unroll
+    for (int j = 0; j < PS_NL; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = k_lo + kslot; k < k_hi; k += ks) {
+        float4 v[PS_NL];
+#pragma unroll
+        for (int j = 0; j < PS_NL; ++j) {
+            const int n = n0 + j;
+            v[j] = n < N ? g[(((size_t)b * N + n) * M + k) * cv + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < PS_NL; ++j) {
+            acc[j].x += v[j].x; acc[j].y += v[j].y; acc[j].z += v[j].z; acc[j].w += v[j].w;
+            t.x += v[j].x; t.y += v[j].y; t.z += v[j].z; t.w += v[j].w;
+        }
+        *reinterpret_cast<float4 *>(slab_n + (((size_t)chunk * B + b) * M + k) * C + c4 * 4) = t;      // unique writer
+    }
+#pragma unroll
+    for (int j = 0; j < PS_NL; ++j) red[threadIdx.x][j] = acc[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < PS_NL * cv; i += THREADS) {
+        const int j = i / cv, c = i - j * cv;
+        if (n0 + j >= N) continue;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < ks; ++q) { const float4 r = red[q * cv + c][j]; a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+        *reinterpret_cast<float4 *>(slab_k + (((size_t)blockIdx.y * B + b) * N + n0 + j) * C + c * 4) = a;
+    }
+}
+
+// sums the slabs (fixed order) into the two [B,.,C] arrays the closed-form kernel reads
+__global__ void pair_slab_sum_kernel(int nslab, long long n, const float *__restrict__ slabs, float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int s = 0; s < nslab; ++s) a += slabs[(size_t)s * n + i];
+        out[i] = a;
+    }
+}
+
 // PB_SLICES blocks per batch sample: E_k = sum_k enc_k[b], E_n = sum_n enc_n[b] (recomputed per block: tiny),
 // then the closed-form BN backward on this block's slice of the two factors
 constexpr int PB_SLICES = 8;
@@ -204,6 +255,29 @@ extern "C" int i2p_pair_bias_bn_bwd(int B, int N, int M, int C, const float *gz,
     const int chunks = (N + PS_NL - 1) / PS_NL;
     // k range split 4 ways: 4x the blocks (one block per CU left most of the HBM bandwidth unused)
     hipLaunchKernelGGL(pair_sum_kernel, dim3(B * chunks, 4), dim3(THREADS), 0, st, B, N, M, C, (const float4 *)gz, sum_k, sum_n);
+    hipLaunchKernelGGL(pair_bias_bn_bwd_kernel, dim3(B * PB_SLICES), dim3(THREADS), 0, st, B, N, M, C, sum_k, sum_n, enc_n, enc_k, dsums,
+                       coef, mi, d_enc_n, d_enc_k);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" long long i2p_pair_bias_bn_bwd_scratch(int B, int N, int M, int C) {
+    const long long chunks = (N + PS_NL - 1) / PS_NL;
+    return (long long)B * N * C * (PSD_KSEG + 1) + (long long)B * M * C * (chunks + 1);
+}
+
+// i2p_pair_bias_bn_bwd without atomics: scratch holds the slabs and the two summed arrays (i2p_pair_bias_bn_bwd_scratch floats)
+extern "C" int i2p_pair_bias_bn_bwd_det(int B, int N, int M, int C, const float *gz, const float *enc_n, const float *enc_k,
+                                        const double *dsums, const float *coef, const float *mi, float *scratch,
+                                        float *d_enc_n, float *d_enc_k, void *stream) {
+    if (B <= 0 || N <= 0 || M <= 0 || C <= 0 || C > 256 || (C & 3) || THREADS % C) return I2P_ERR_BAD_ARG;
+    if (!gz || !enc_n || !enc_k || !dsums || !coef || !mi || !scratch || !d_enc_n || !d_enc_k) return I2P_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = (N + PS_NL - 1) / PS_NL;
+    const long long nk = (long long)B * N * C, nn = (long long)B * M * C;
+    float *slab_k = scratch, *sum_k = slab_k + PSD_KSEG * nk, *slab_n = sum_k + nk, *sum_n = slab_n + (long long)chunks * nn;
+    hipLaunchKernelGGL(pair_sum_det_kernel, dim3(B * chunks, PSD_KSEG), dim3(THREADS), 0, st, B, N, M, C, (const float4 *)gz, slab_k, slab_n);
+    hipLaunchKernelGGL(pair_slab_sum_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, PSD_KSEG, nk, slab_k, sum_k);
+    hipLaunchKernelGGL(pair_slab_sum_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, chunks, nn, slab_n, sum_n);
     hipLaunchKernelGGL(pair_bias_bn_bwd_kernel, dim3(B * PB_SLICES), dim3(THREADS), 0, st, B, N, M, C, sum_k, sum_n, enc_n, enc_k, dsums,
                        coef, mi, d_enc_n, d_enc_k);
     I2P_RETURN_LAUNCH_STATUS();

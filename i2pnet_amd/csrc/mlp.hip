@@ -1111,7 +1111,23 @@ struct PairBwdParams {
     const double *out_dsums;
     const float *f, *g, *w;
     float *d_f, *d_g, *d_bn, *d_bk, *dw_partial;
+    // deterministic accumulation: every cross-block sum goes through per-block slabs that one kernel adds up in a fixed
+    // order (the first version used fp32 atomics: gradients differed run to run).  Slab s of a quantity is a full copy
+    // of its [.., C] array; writers are unique per (slab, element).
+    float *s_df;      // [2*KT][B*N*cin]   one slab per (pixel tile, 32-pixel half)
+    float *s_dbn;     // [KT][B*N*cout]
+    float *s_dg;      // [NC][B*M*cin]
+    float *s_dbk;     // [NC][B*M*cout]
 };
+
+// out[i] = (((init + s0[i]) + s1[i]) + ...) over nslab slabs of n floats, in slab order
+__global__ void slab_reduce_kernel(int nslab, long long n, const float *__restrict__ slabs, float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float a = out[i];
+        for (int s = 0; s < nslab; ++s) a += slabs[(size_t)s * n + i];
+        out[i] = a;
+    }
+}
 
 template <int NTI, int NTO>
 __global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
@@ -1272,7 +1288,7 @@ __global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
             } else {
                 for (int r = 0; r < BWD_R; ++r) s0 += Gs[r * p.ldg + ch];
             }
-            atomicAdd(p.d_bn + bn * p.cout + ch, s0);
+            p.s_dbn[((size_t)kt * p.B * p.N + bn) * p.cout + ch] = s0;
         }
         // ---- wgrad --------------------------------------------------------------------------------------
 #pragma unroll
@@ -1323,8 +1339,9 @@ __global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
                         dg_acc[t][e] += acc[e] * fv;
                         colsum += acc[e] * gk_frag[t][e];
                     }
-                    colsum += __shfl_xor(colsum, 32);
-                    if (lane < 32) atomicAdd(p.d_f + bn * p.cin + ci, colsum);
+                    // lanes l / l+32 hold pixel rows 4h.. of the same column: fixed order (h = 0 first)
+                    const float other = __shfl_xor(colsum, 32);
+                    if (lane < 32) p.s_df[((size_t)(kt * 2 + rt) * p.B * p.N + bn) * p.cin + ci] = colsum + other;
                 }
             }
         }
@@ -1340,7 +1357,7 @@ __global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int r = rt * 32 + frag_row(e, lane);
-                    if (k0 + r < p.M) atomicAdd(p.d_g + ((size_t)b * p.M + k0 + r) * p.cin + ci, dg_acc[t][e]);
+                    if (k0 + r < p.M) p.s_dg[(((size_t)nc * p.B + b) * p.M + k0 + r) * p.cin + ci] = dg_acc[t][e];
                 }
         }
     }
@@ -1348,8 +1365,8 @@ __global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
     for (int u = 0; u < GCH; ++u) {
         const int i = tid + u * THREADS, r = i / co4, c4 = i - r * co4;
         if (i < BWD_R * co4 && k0 + r < p.M) {
-            float *dk = p.d_bk + ((size_t)b * p.M + k0 + r) * p.cout + c4 * 4;
-            atomicAdd(dk + 0, dbk_acc[u].x); atomicAdd(dk + 1, dbk_acc[u].y); atomicAdd(dk + 2, dbk_acc[u].z); atomicAdd(dk + 3, dbk_acc[u].w);
+            float *dk = p.s_dbk + (((size_t)nc * p.B + b) * p.M + k0 + r) * p.cout + c4 * 4;
+            *reinterpret_cast<float4 *>(dk) = dbk_acc[u];
         }
     }
     float *part = p.dw_partial + (size_t)blockIdx.x * p.cout * p.cin;
@@ -1860,7 +1877,22 @@ static int launch_pair_bwd(PairBwdParams &p, float *dw, hipStream_t st, unsigned
     hipLaunchKernelGGL((pair_bwd_kernel<NTI, NTO>), dim3(grid), dim3(THREADS), bytes, st, p);
     const int n = p.cout * p.cin;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, p.dw_partial, dw);
+    const int KT = (p.M + BWD_R - 1) / BWD_R;
+    auto red = [&](int nslab, long long cnt, const float *slabs, float *out) {
+        long long blocks = (cnt + 255) / 256; if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nslab, cnt, slabs, out);
+    };
+    red(2 * KT, (long long)p.B * p.N * p.cin, p.s_df, p.d_f);
+    red(KT, (long long)p.B * p.N * p.cout, p.s_dbn, p.d_bn);
+    red(p.NC, (long long)p.B * p.M * p.cin, p.s_dg, p.d_g);
+    red(p.NC, (long long)p.B * p.M * p.cout, p.s_dbk, p.d_bk);
     I2P_RETURN_LAUNCH_STATUS();
+}
+
+// floats the caller provides in dw_partial: per-block weight-gradient partials + the slabs of the four pair sums
+extern "C" long long i2p_pair_lin_bwd_scratch(int B, int N, int M, int cin, int cout) {
+    const long long KT = (M + BWD_R - 1) / BWD_R, grid = i2p_pair_lin_bwd_grid(B, N, M), NC = grid / (B * KT);
+    return grid * cout * cin + 2 * KT * B * N * cin + KT * B * N * cout + NC * B * M * cin + NC * B * M * cout;
 }
 
 extern "C" int i2p_pair_lin_bwd(int B, int N, int M, int cin, int cout, const float *gz, const float *y,
@@ -1881,6 +1913,10 @@ extern "C" int i2p_pair_lin_bwd(int B, int N, int M, int cin, int cout, const fl
     p.gz = gz; p.y = y; p.out_coef = out_coef; p.out_mi = out_mi; p.out_dsums = out_dsums;
     p.slope_out = 1.f;
     p.f = f; p.g = g; p.w = w; p.d_f = d_f; p.d_g = d_g; p.d_bn = d_bias_n; p.d_bk = d_bias_k; p.dw_partial = dw_partial;
+    p.s_df = dw_partial + (size_t)grid * cout * cin;
+    p.s_dbn = p.s_df + (size_t)2 * KT * B * N * cin;
+    p.s_dg = p.s_dbn + (size_t)KT * B * N * cout;
+    p.s_dbk = p.s_dg + (size_t)p.NC * B * M * cin;
     hipStream_t st = (hipStream_t)stream;
     const int nti = p.cin_p / 32, nto = p.cout_p / 32;
     if (nti == 4 && nto == 4) return launch_pair_bwd<4, 4>(p, dw, st, grid);

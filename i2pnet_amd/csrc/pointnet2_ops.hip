@@ -440,6 +440,7 @@ extern "C" int i2p_gather_points_grad(int b, int c, int n, int npoints, const fl
     if (b < 0 || c < 0 || n < 0 || npoints < 0) return I2P_ERR_BAD_ARG;
     if ((long long)b * c * npoints == 0) return 0;
     if (!grad_out || !idx || !grad_points) return I2P_ERR_BAD_ARG;
+    if (!i2p_atomic_scatter()) return i2p_det_gather_points_grad(b, c, n, npoints, grad_out, idx, grad_points, stream);
     hipLaunchKernelGGL(gather_points_grad_kernel, chunk_grid(npoints, c, b), dim3(256), 0,
                        (hipStream_t)stream, c, n, npoints, grad_out, idx, grad_points);
     I2P_RETURN_LAUNCH_STATUS();
@@ -495,6 +496,7 @@ extern "C" int i2p_three_interpolate_grad(int b, int c, int n, int m, const floa
     if (b < 0 || c < 0 || n < 0 || m < 0) return I2P_ERR_BAD_ARG;
     if ((long long)b * c * n == 0) return 0;
     if (!grad_out || !idx || !weight || !grad_points) return I2P_ERR_BAD_ARG;
+    if (!i2p_atomic_scatter()) return i2p_det_three_interpolate_grad(b, c, n, m, grad_out, idx, weight, grad_points, stream);
     hipLaunchKernelGGL(three_interpolate_grad_kernel, chunk_grid(n, c, b), dim3(256), 0,
                        (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
     I2P_RETURN_LAUNCH_STATUS();

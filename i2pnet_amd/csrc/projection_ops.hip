@@ -306,6 +306,7 @@ extern "C" int i2p_gather_rows_grad(int b, int hw, int c, int q, int W, const fl
     if (b < 0 || hw < 0 || c < 0 || q < 0 || W <= 0) return I2P_ERR_BAD_ARG;
     if ((long long)b * q * c == 0) return 0;
     if (!grad_out || !h_idx || !w_idx || !grad_feat) return I2P_ERR_BAD_ARG;
+    if (!i2p_atomic_scatter()) return i2p_det_gather_rows_grad(b, hw, c, q, W, grad_out, h_idx, w_idx, grad_feat, stream);
     const long long tot = (long long)((q + GRAD_RUN - 1) / GRAD_RUN) * c;
     hipLaunchKernelGGL(gather_rows_grad_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0,
                        (hipStream_t)stream, hw, c, q, W, grad_out, h_idx, w_idx, grad_feat);

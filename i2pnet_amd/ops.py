@@ -525,10 +525,9 @@ class CBackend:
                        self._p(w, _F32, "w"), self._p(d_f, _F32, "d_f"), self._p(d_g, _F32, "d_g"), self._p(d_bn, _F32, "d_bn"),
                        self._p(d_bk, _F32, "d_bk"), self._p(part, _F32, "part"), self._p(dw, _F32, "dw"), stream=self._stream())
             return d_f, d_g, d_bn, d_bk, dw
-        KT = (M + 63) // 64
-        NC = max(1, min(N, 256 // (B * KT)))
-        grid = B * KT * NC if self.device_type == "cuda" else 1          # i2p_pair_lin_bwd_grid
-        part = torch.empty(grid * Co * C, dtype=_F32, device=dev)
+        # per-block weight-gradient partials + the slabs of the deterministic pair sums (i2p_pair_lin_bwd_scratch)
+        nscr = _lib.helper("i2p_pair_lin_bwd_scratch", int(B), int(N), int(M), int(C), int(Co)) if self.device_type == "cuda" else Co * C
+        part = torch.empty(nscr, dtype=_F32, device=dev)
         dw = torch.empty(Co, C, dtype=_F32, device=dev)
         opt = lambda t, dt=_F32: self._p(t, dt, "bn") if t is not None else None
         self._call("i2p_pair_lin_bwd", int(B), int(N), int(M), int(C), int(Co), self._p(gy, _F32, "gy"), opt(y),
@@ -624,9 +623,16 @@ class CBackend:
         """-> (d_enc_n [B,N,C], d_enc_k [B,M,C]); see i2p_pair_bias_bn_bwd"""
         C = gz.shape[1]
         dev = gz.device
+        d_n = torch.empty(B, N, C, dtype=_F32, device=dev); d_k = torch.empty(B, M, C, dtype=_F32, device=dev)
+        if self.device_type == "cuda" and gz.dtype == _F32:        # deterministic two-level sums (no atomics)
+            scr = torch.empty(_lib.helper("i2p_pair_bias_bn_bwd_scratch", int(B), int(N), int(M), int(C)), dtype=_F32, device=dev)
+            self._call("i2p_pair_bias_bn_bwd_det", int(B), int(N), int(M), int(C), self._p(gz, _F32, "gz"), self._p(enc_n, _F32, "enc_n"),
+                       self._p(enc_k, _F32, "enc_k"), self._p(dsums, torch.float64, "dsums"), self._p(coef, _F32, "coef"),
+                       self._p(mi, _F32, "mi"), self._p(scr, _F32, "scratch"), self._p(d_n, _F32, "d_enc_n"),
+                       self._p(d_k, _F32, "d_enc_k"), stream=self._stream())
+            return d_n, d_k
         sum_k = zeros((B, N, C), _F32, dev)
         sum_n = zeros((B, M, C), _F32, dev)
-        d_n = torch.empty(B, N, C, dtype=_F32, device=dev); d_k = torch.empty(B, M, C, dtype=_F32, device=dev)
         self._call("i2p_pair_bias_bn_bwd_bf16" if gz.dtype == _BF16 else "i2p_pair_bias_bn_bwd", int(B), int(N), int(M), int(C),
                    self._p(gz, gz.dtype, "gz"),
                    self._p(enc_n, _F32, "enc_n"), self._p(enc_k, _F32, "enc_k"), self._p(dsums, torch.float64, "dsums"),

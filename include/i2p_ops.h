@@ -409,6 +409,14 @@ int i2p_cv_softmax_wsum_fwd_bf16(int B, int N, int M, int C, const i2p_bf16 *y5,
 int i2p_cv_softmax_wsum_bwd_bf16(int B, int N, int M, int C, const float *g_out, const float *out, const float *msave,
                                  const i2p_bf16 *y5, const float *coef5, const float *mi5, float slope5, const i2p_bf16 *y3,
                                  const float *coef3, float slope3, i2p_bf16 *gz5, double *dsums5, i2p_bf16 *ga3, void *stream);
+/* deterministic variants (no floating-point atomics; fixed summation order => bitwise reproducible gradients):
+ * i2p_pair_lin_bwd takes its slabs from dw_partial, which must hold i2p_pair_lin_bwd_scratch(...) floats;
+ * i2p_pair_bias_bn_bwd_det is i2p_pair_bias_bn_bwd with caller scratch of i2p_pair_bias_bn_bwd_scratch(...) floats. */
+long long i2p_pair_lin_bwd_scratch(int B, int N, int M, int cin, int cout);
+long long i2p_pair_bias_bn_bwd_scratch(int B, int N, int M, int C);
+int i2p_pair_bias_bn_bwd_det(int B, int N, int M, int C, const float *gz, const float *enc_n, const float *enc_k,
+                             const double *dsums, const float *coef, const float *mi, float *scratch, float *d_enc_n,
+                             float *d_enc_k, void *stream);
 int i2p_pair_bias_bn_finish(int B, int N, int M, int C, const float *sum_k, const float *sum_n, const float *enc_n,
                             const float *enc_k, const double *dsums, const float *coef, const float *mi, float *d_enc_n,
                             float *d_enc_k, void *stream);   /* closed-form half of i2p_pair_bias_bn_bwd on formed sums */

@@ -303,8 +303,8 @@ def test_model_bf16_against_fp32_golden(tag):
     element; behind ~25 batch-normalised layers (each renormalises to unit variance, so perturbations add in
     quadrature, ~ sqrt(25) * 2^-9 ~ 1e-2 of a unit-variance activation: measured 0.5 % (level 1) to 2.6 % (mask
     predictors) in L2, tools/diag_bf16.py) the regressed pose is required within 8e-2 of its fp32 value relative to the
-    pose's scale (measured 2-5e-2), the loss within 5e-2 (measured 4e-3), every recorded activation within 1e-1 in
-    max-norm.  Gradients: a 1 % forward perturbation flips ReLU / max-pool / softmax-mask decisions of this
+    pose's scale (measured 2-5e-2), the loss within 5e-2 (measured 4e-3), every recorded activation within 5e-2 in
+    relative L2 norm (and 2e-1 in max-norm).  Gradients: a 1 % forward perturbation flips ReLU / max-pool / softmax-mask decisions of this
     random-weight network, so individual gradient tensors move by 10-20 % in L2 (and two fp32 runs of the same
     gradient differ by more than that on the ill-conditioned tensors): only the NORM of every
     well-conditioned parameter gradient is checked, at 35 %, plus tests/test_bf16_gpu.py::test_bf16_training_tracks_fp32
@@ -315,8 +315,10 @@ def test_model_bf16_against_fp32_golden(tag):
     assert rel(out4.detach(), gold["out4"]) < 8e-2, rel(out4.detach(), gold["out4"])
     assert abs(loss.item() - gold["loss"][0]) / abs(gold["loss"][0]) < 5e-2
     for name, t in acts.items():
-        r = rel(t.detach().reshape(-1, t.shape[-1]), gold["act." + name])
-        assert r < 1e-1, (name, r)
+        got, want = t.detach().reshape(-1, t.shape[-1]).double().cpu(), torch.as_tensor(gold["act." + name]).double()
+        r2 = float((got - want).norm() / want.norm())
+        assert r2 < 5e-2, (name, r2)                      # relative L2 (measured 0.5-2.6e-2)
+        assert rel(got, want) < 2e-1, (name, rel(got, want))
     params = dict(model.named_parameters())
     # norm of every well-conditioned parameter gradient against the reference's fp64 evaluation
     g64 = dict(zip(gold["grad_keys"].tolist(), gold["grad_norm64"].tolist()))
