@@ -71,6 +71,7 @@ DEVICE_ONLY = {
     "i2p_pair_bias_bn_bwd_bf16": ["i"] * 4 + ["p"] * 10,
     "i2p_pair_bias_bn_finish": ["i"] * 4 + ["p"] * 9,
     "i2p_pair_bias_bn_bwd_det": ["i"] * 4 + ["p"] * 9,
+    "i2p_gather_rows_grad_fx": ["i", "i", "i", "i", "i", "p", "p", "p", "p", "p"],
 }
 # plain `int f(...)` helpers without a stream argument
 HELPERS = {
@@ -78,8 +79,9 @@ HELPERS = {
     "i2p_pair_lin_bwd_bf16_grid": ["i", "i", "i"],
     "i2p_pair_lin_bwd_scratch": ["i", "i", "i", "i", "i"],          # returns long long
     "i2p_pair_bias_bn_bwd_scratch": ["i", "i", "i", "i"],           # returns long long
+    "i2p_gather_rows_grad_fx_scratch": ["i", "i", "i"],             # returns long long (bytes)
 }
-LONG_HELPERS = {"i2p_pair_lin_bwd_scratch", "i2p_pair_bias_bn_bwd_scratch"}
+LONG_HELPERS = {"i2p_pair_lin_bwd_scratch", "i2p_pair_bias_bn_bwd_scratch", "i2p_gather_rows_grad_fx_scratch"}
 
 _CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "p": C.c_void_p, "pp": C.c_void_p}
 

@@ -3,28 +3,30 @@
 // sampling_gpu.cu:46-63, interpolate_gpu.cu:120-142) without floating-point atomics.
 //
 // The reference accumulates with atomicAdd in whatever order the hardware serialises them, so its gradients are not
-// reproducible run to run; here every destination cell is OWNED by one wave, which scans the index list in ascending
-// row order and adds the matching source rows in that order:
-//     dst[cell] = (((dst[cell] + src[r1]) + src[r2]) + ...)      r1 < r2 < ... the rows that point at `cell`
-// — bit for bit the result of the serial CPU loop of the oracle (oracle/i2p_oracle.c: *_grad_cpu), independent of
-// scheduling.  The index lists of this network are short (<= 65 k rows per sample) and L2-resident, so the scan costs a
-// few microseconds; a destination needs no zero-fill beyond what the caller's contract already gives (the existing
-// content of `dst` is the start value of the sum, as with the reference's `+=`).
-//
-// One wave owns CPW consecutive destination cells; its accumulators live in LDS ([CPW][C], dynamically indexed by the
-// matching cell), lane = channel (+64, +128, ...).  Per 64-row chunk of the index list: one coalesced index load, a
-// ballot of the rows that fall into the wave's cells, then the matching rows in ascending order, four source rows
-// in flight at a time.
+// reproducible run to run.  Here every group of destination cells is OWNED by one block whose summation order is a
+// fixed function of the index list alone:
+//   * the block stages the index list in LDS (4096 rows per pass) — a scan straight from global memory was
+//     latency-bound: one dependent L2 round trip per 64 rows and wave;
+//   * its 16 waves split the ROWS of every pass into 16 contiguous ranges; a wave walks its range in ascending order,
+//     64 rows at a time: ballot of the rows that fall into the block's cells, then the matching rows one after the
+//     other (lane = channel, sixteen source rows in flight) into its private LDS accumulators;
+//   * consecutive matches of ONE cell are summed in registers and reach LDS once per run (the empty slots of the
+//     neighbour lists repeat one cell thousands of times: 93 % of the level-2 rows of a sparse scan point at cell 0);
+//   * at the end the 16 per-wave partials of a cell are added in wave order onto the existing content of `dst` (the
+//     reference's `+=` contract) by a single writer.
+// Bitwise reproducible; the association order differs from a serial loop's (the oracle's), the sum of course not.
 #include "common.h"
 
 namespace {
 
-constexpr int CPW = 16;              // destination cells per wave
-constexpr int WAVES = 4;             // waves per block
+constexpr int WAVES = 16;            // waves per block (1024 threads)
 constexpr int MAXCU = 4;             // channels per lane: C <= 256
+constexpr int SEG = 4096;            // index-list rows staged per pass (16 KB of LDS; with the accumulators 80 KB: two blocks per CU)
+constexpr int NB = 16;               // source rows in flight per wave
+constexpr int ACC_FLOATS = 1024;     // accumulator floats per wave: cells per block = ACC_FLOATS / C (1..32)
 
 struct ScatterP {
-    int ncell, c, q;                 // destination cells per sample, channels, source rows per sample
+    int ncell, c, q, cpb;            // destination cells per sample, channels, source rows per sample, cells per block
     // index of source row r: I64PAIR: h_idx[r]*W + w_idx[r]; else idx32[r]
     const int64_t *h_idx, *w_idx; int W;
     const int *idx32;
@@ -37,88 +39,144 @@ struct ScatterP {
 
 template <bool I64PAIR, bool WEIGHTED>
 __global__ __launch_bounds__(64 * WAVES) void scatter_det_kernel(ScatterP p) {
-    extern __shared__ float acc_all[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ float smem_f[];
+    int *cells = reinterpret_cast<int *>(smem_f);                      // [SEG] destination cell of every staged row
+    float *acc_all = smem_f + SEG;                                     // [WAVES][cpb][c]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
-    const int cell0 = (blockIdx.x * WAVES + wave) * CPW;
-    if (cell0 >= p.ncell) return;                      // (no block-level barrier below: waves are independent)
-    float *acc = acc_all + (size_t)wave * CPW * p.c;
-    const int cu = (p.c + 63) >> 6;
+    const int cpb = p.cpb, C = p.c;
+    const int cell0 = blockIdx.x * cpb;
+    float *acc = acc_all + (size_t)wave * cpb * C;
+    const int cu = (C + 63) >> 6;
     float *dst = p.dst + (size_t)b * p.dst_b;
     const float *src = p.src + (size_t)b * p.src_b;
-    for (int i = 0; i < CPW; ++i)
-        for (int u = 0; u < cu; ++u) {
-            const int ch = lane + 64 * u;
-            if (ch < p.c) acc[i * p.c + ch] = cell0 + i < p.ncell ? dst[(size_t)(cell0 + i) * p.dst_row + (size_t)ch * p.dst_ch] : 0.f;
-        }
+    for (int i = tid; i < WAVES * cpb * C; i += 64 * WAVES) acc_all[i] = 0.f;
     const size_t ib = (size_t)b * p.q;
-    for (int r0 = 0; r0 < p.q; r0 += 64) {
-        const int r = r0 + lane;
-        int rel = -1;
-        if (r < p.q) {
-            long long cell;
-            if constexpr (I64PAIR) cell = p.h_idx[ib + r] * p.W + p.w_idx[ib + r];
-            else cell = p.idx32[ib + r];
-            const long long d = cell - cell0;
-            rel = (d >= 0 && d < CPW) ? (int)d : -1;
+    int run_cell = -1;
+    float run[MAXCU] = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < p.q; s0 += SEG) {
+        const int slen = min(SEG, p.q - s0);
+        __syncthreads();                                               // previous pass fully scanned (and acc zeroed)
+        {   // the whole block stages the index segment once: all loads of a thread in flight together
+            constexpr int PER = SEG / (64 * WAVES);
+            long long hv[PER], wv[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int r = tid + u * 64 * WAVES;
+                hv[u] = 0; wv[u] = -1;
+                if (r < slen) {
+                    if constexpr (I64PAIR) { hv[u] = p.h_idx[ib + s0 + r]; wv[u] = p.w_idx[ib + s0 + r]; }
+                    else wv[u] = p.idx32[ib + s0 + r];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int r = tid + u * 64 * WAVES;
+                const long long cell = I64PAIR ? hv[u] * p.W + wv[u] : wv[u];
+                if (r < slen) cells[r] = (cell >= 0 && cell < p.ncell) ? (int)cell : -1;
+            }
         }
-        unsigned long long mask = __ballot(rel >= 0);
-        while (mask) {
-            int li[4], ci[4], nb = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                li[t] = 0; ci[t] = 0;
-                if (mask) {
-                    li[t] = __builtin_ctzll(mask); mask &= mask - 1;
-                    ci[t] = __builtin_amdgcn_readlane(rel, li[t]);
-                    nb = t + 1;
-                }
+        __syncthreads();
+        const int nchunk = (slen + 63) >> 6;
+        const int c_lo = (int)((long long)nchunk * wave / WAVES), c_hi = (int)((long long)nchunk * (wave + 1) / WAVES);
+        for (int ck = c_lo; ck < c_hi; ++ck) {
+            const int r0 = ck << 6;
+            const int r = r0 + lane;
+            int rel = -1;
+            if (r < slen) {
+                const int d = cells[r] - cell0;
+                rel = (cells[r] >= 0 && d >= 0 && d < cpb) ? d : -1;
             }
-            float v[4][MAXCU];
+            unsigned long long mask = __ballot(rel >= 0);
+            while (mask) {
+                int li[NB], ci[NB], nb = 0;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (t < nb) {
-                    const int row = r0 + li[t];
-                    float wgt = 1.f;
-                    if constexpr (WEIGHTED) wgt = p.weight[ib + row];
-                    const float *s = src + (size_t)(row / p.src_div) * p.src_row;
+                for (int t = 0; t < NB; ++t) {
+                    li[t] = 0; ci[t] = 0;
+                    if (mask) {
+                        li[t] = __builtin_ctzll(mask); mask &= mask - 1;
+                        ci[t] = __builtin_amdgcn_readlane(rel, li[t]);
+                        nb = t + 1;
+                    }
+                }
+                float v[NB][MAXCU];
 #pragma unroll
-                    for (int u = 0; u < MAXCU; ++u) {
-                        const int ch = lane + 64 * u;
-                        v[t][u] = (u < cu && ch < p.c) ? s[(size_t)ch * p.src_ch] : 0.f;
-                        if constexpr (WEIGHTED) v[t][u] = __fmul_rn(v[t][u], wgt);
+                for (int t = 0; t < NB; ++t) {
+                    if (t < nb) {
+                        const int row = s0 + r0 + li[t];
+                        float wgt = 1.f;
+                        if constexpr (WEIGHTED) wgt = p.weight[ib + row];
+                        const float *sp = src + (size_t)(row / p.src_div) * p.src_row;
+#pragma unroll
+                        for (int u = 0; u < MAXCU; ++u) {
+                            const int ch = lane + 64 * u;
+                            v[t][u] = (u < cu && ch < C) ? sp[(size_t)ch * p.src_ch] : 0.f;
+                            if constexpr (WEIGHTED) v[t][u] = __fmul_rn(v[t][u], wgt);
+                        }
+                    }
+                }
+                // consecutive matches of one cell are summed in registers (row order) and reach LDS once per run: the
+                // empty slots of the neighbour lists repeat one cell thousands of times
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    if (t < nb) {
+                        if (ci[t] != run_cell) {
+                            if (run_cell >= 0) {
+#pragma unroll
+                                for (int u = 0; u < MAXCU; ++u) {
+                                    const int ch = lane + 64 * u;
+                                    if (u < cu && ch < C) acc[run_cell * C + ch] += run[u];
+                                }
+                            }
+                            run_cell = ci[t];
+#pragma unroll
+                            for (int u = 0; u < MAXCU; ++u) run[u] = v[t][u];
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < MAXCU; ++u) run[u] += v[t][u];
+                        }
                     }
                 }
             }
+        }
+        if (run_cell >= 0) {                                           // flush before the LDS index copy is replaced
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (t < nb) {
-#pragma unroll
-                    for (int u = 0; u < MAXCU; ++u) {
-                        const int ch = lane + 64 * u;
-                        if (u < cu && ch < p.c) acc[ci[t] * p.c + ch] += v[t][u];
-                    }
-                }
+            for (int u = 0; u < MAXCU; ++u) {
+                const int ch = lane + 64 * u;
+                if (u < cu && ch < C) acc[run_cell * C + ch] += run[u];
             }
+            run_cell = -1;
         }
     }
-    for (int i = 0; i < CPW; ++i)
-        for (int u = 0; u < cu; ++u) {
-            const int ch = lane + 64 * u;
-            if (ch < p.c && cell0 + i < p.ncell) dst[(size_t)(cell0 + i) * p.dst_row + (size_t)ch * p.dst_ch] = acc[i * p.c + ch];
+    __syncthreads();
+    // single writer per (cell, channel): existing content + the 16 partials in wave order
+    for (int i = tid; i < cpb * C; i += 64 * WAVES) {
+        const int ci = i / C, ch = i - ci * C;
+        if (cell0 + ci < p.ncell) {
+            float *d = dst + (size_t)(cell0 + ci) * p.dst_row + (size_t)ch * p.dst_ch;
+            float a = *d;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) a += acc_all[((size_t)w * cpb + ci) * C + ch];
+            *d = a;
         }
+    }
 }
 
 template <bool I64PAIR, bool WEIGHTED>
-int launch(const ScatterP &p, int b, hipStream_t st) {
-    if (p.c > 64 * MAXCU) return I2P_ERR_BAD_ARG;
-    const size_t bytes = (size_t)WAVES * CPW * p.c * sizeof(float);
+int launch(ScatterP p, int b, hipStream_t st) {
+    if (p.c > 64 * MAXCU || p.c <= 0) return I2P_ERR_BAD_ARG;
+    int cpb = ACC_FLOATS / p.c; cpb = cpb < 1 ? 1 : (cpb > 32 ? 32 : cpb);
+    // small destinations: fewer cells per block so that the chip still sees a few hundred blocks
+    const long long want = ((long long)p.ncell * b + 511) / 512;
+    if (want < cpb) cpb = want < 1 ? 1 : (int)want;
+    p.cpb = cpb;
+    const size_t bytes = ((size_t)SEG + (size_t)WAVES * cpb * p.c) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_det_kernel<I64PAIR, WEIGHTED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const unsigned gx = (unsigned)((p.ncell + WAVES * CPW - 1) / (WAVES * CPW));
+    const unsigned gx = (unsigned)((p.ncell + cpb - 1) / cpb);
     hipLaunchKernelGGL((scatter_det_kernel<I64PAIR, WEIGHTED>), dim3(gx, b), dim3(64 * WAVES), bytes, st, p);
     I2P_RETURN_LAUNCH_STATUS();
 }
@@ -168,4 +226,87 @@ int i2p_det_three_interpolate_grad(int b, int c, int n, int m, const float *grad
         if (rc) return rc;
     }
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fixed-point variant of the channel-last row scatter-add (what the network's step uses): integer addition is
+// associative, so hardware atomics on int64 accumulators give one result whatever order they are served in —
+// deterministic at the speed of the atomic kernel.  Three launches on caller scratch:
+//   1. m = max |grad_out|                                   (unsigned max of the float bits: order-independent)
+//   2. acc[b,cell,ch] += llrint(g * 2^(40 - exponent(m)))    (int64 atomics; equal-cell runs of 8 consecutive rows are
+//                                                            merged in registers first, as in the float kernel)
+//   3. grad_feat += acc * 2^-(40 - exponent(m))              (one rounding per element)
+// Every addend is quantised to 2^-40 of the largest one: the result is within 1e-12 (relative to max|g|) of the exact
+// sum, i.e. more accurate than ANY order of float additions.  Non-finite gradients propagate as NaN.
+// scratch: acc int64 [B,HW,C] and one uint32 (max bits), BOTH ZEROED BY THE CALLER.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void absmax_bits_kernel(long long n, const float *__restrict__ x, unsigned *__restrict__ out) {
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+__device__ __forceinline__ double fx_scale(unsigned maxbits) {        // 2^(40 - exponent(max)); 1 for max == 0
+    const int e = (int)((maxbits >> 23) & 0xff) - 127;               // |max| in [2^e, 2^(e+1))
+    return maxbits ? ldexp(1.0, 40 - e) : 1.0;
+}
+
+constexpr int FX_RUN = 8;
+__global__ void scatter_fx_kernel(int hw, int c, int q, int W, const float *__restrict__ grad_out, const int64_t *__restrict__ h_idx,
+                                  const int64_t *__restrict__ w_idx, const unsigned *__restrict__ maxbits,
+                                  unsigned long long *__restrict__ acc) {
+    const int bi = blockIdx.y;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nrun = (q + FX_RUN - 1) / FX_RUN;
+    if (t >= (long long)nrun * c) return;
+    const double scale = fx_scale(*maxbits);
+    const int run = (int)(t / c), ch = (int)(t % c);
+    const int r0 = run * FX_RUN, r1 = min(q, r0 + FX_RUN);
+    long long cur = -1, sum = 0;
+    for (int row = r0; row < r1; ++row) {
+        const long long cell = h_idx[(size_t)bi * q + row] * W + w_idx[(size_t)bi * q + row];
+        const long long v = __double2ll_rn((double)grad_out[((size_t)bi * q + row) * c + ch] * scale);
+        if (cell != cur) {
+            if (cur >= 0 && cur < hw) atomicAdd(acc + ((size_t)bi * hw + cur) * c + ch, (unsigned long long)sum);
+            cur = cell; sum = 0;
+        }
+        sum += v;
+    }
+    if (cur >= 0 && cur < hw) atomicAdd(acc + ((size_t)bi * hw + cur) * c + ch, (unsigned long long)sum);
+}
+
+__global__ __launch_bounds__(256) void fx_finalize_kernel(long long n, const long long *__restrict__ acc, const unsigned *__restrict__ maxbits,
+                                                           float *__restrict__ dst) {
+    const unsigned mb = *maxbits;
+    const double inv = 1.0 / fx_scale(mb);
+    const bool bad = mb >= 0x7f800000u;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dst[i] = bad ? __uint_as_float(0x7fc00000u) : dst[i] + (float)((double)acc[i] * inv);
+}
+
+}  // namespace
+
+extern "C" long long i2p_gather_rows_grad_fx_scratch(int b, int hw, int c) { return ((long long)b * hw * c + 1) * 8; }   // bytes
+
+extern "C" int i2p_gather_rows_grad_fx(int b, int hw, int c, int q, int W, const float *grad_out, const int64_t *h_idx,
+                                       const int64_t *w_idx, void *scratch, float *grad_feat, void *stream) {
+    if (b < 0 || hw < 0 || c < 0 || q < 0 || W <= 0) return I2P_ERR_BAD_ARG;
+    if ((long long)b * q * c == 0) return 0;
+    if (!grad_out || !h_idx || !w_idx || !grad_feat || !scratch) return I2P_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(scratch);
+    unsigned *mx = reinterpret_cast<unsigned *>(acc + (size_t)b * hw * c);
+    const long long nsrc = (long long)b * q * c, ndst = (long long)b * hw * c;
+    long long g1 = (nsrc + 256 * 8 - 1) / (256 * 8); if (g1 > 1024) g1 = 1024;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)g1), dim3(256), 0, st, nsrc, grad_out, mx);
+    const long long tot = (long long)((q + FX_RUN - 1) / FX_RUN) * c;
+    hipLaunchKernelGGL(scatter_fx_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0, st, hw, c, q, W, grad_out, h_idx, w_idx, mx, acc);
+    long long g3 = (ndst + 255) / 256; if (g3 > 2048) g3 = 2048;
+    hipLaunchKernelGGL(fx_finalize_kernel, dim3((unsigned)g3), dim3(256), 0, st, ndst, reinterpret_cast<const long long *>(acc), mx, grad_feat);
+    I2P_RETURN_LAUNCH_STATUS();
 }

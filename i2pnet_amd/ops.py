@@ -237,6 +237,14 @@ class CBackend:
     def gather_rows_grad(self, grad_out, h_idx, w_idx, W, grad_feat):
         B, HW, Cc = grad_feat.shape
         Q = h_idx.shape[1]
+        if self.device_type == "cuda" and not os.environ.get("I2P_SCATTER_SCAN"):
+            # fixed-point accumulation on int64 atomics: order-independent => bitwise reproducible (scratch zeroed here)
+            nbytes = _lib.helper("i2p_gather_rows_grad_fx_scratch", int(B), int(HW), int(Cc))
+            scratch = zeros(nbytes, torch.uint8, grad_feat.device)
+            self._call("i2p_gather_rows_grad_fx", int(B), int(HW), int(Cc), int(Q), int(W), self._p(grad_out, _F32, "grad_out"),
+                       self._p(h_idx, _I64, "h_idx"), self._p(w_idx, _I64, "w_idx"), self._p(scratch, torch.uint8, "scratch"),
+                       self._p(grad_feat, _F32, "grad_feat"), stream=self._stream())
+            return
         self._call("i2p_gather_rows_grad", int(B), int(HW), int(Cc), int(Q), int(W),
                    self._p(grad_out, _F32, "grad_out"), self._p(h_idx, _I64, "h_idx"),
                    self._p(w_idx, _I64, "w_idx"), self._p(grad_feat, _F32, "grad_feat"),

@@ -417,6 +417,11 @@ long long i2p_pair_bias_bn_bwd_scratch(int B, int N, int M, int C);
 int i2p_pair_bias_bn_bwd_det(int B, int N, int M, int C, const float *gz, const float *enc_n, const float *enc_k,
                              const double *dsums, const float *coef, const float *mi, float *scratch, float *d_enc_n,
                              float *d_enc_k, void *stream);
+/* i2p_gather_rows_grad on int64 fixed-point atomics (order-independent, deterministic, 2^-40 of max|grad_out| resolution):
+ * scratch = i2p_gather_rows_grad_fx_scratch(b,hw,c) BYTES, zeroed by the caller; grad_feat is accumulated into. */
+long long i2p_gather_rows_grad_fx_scratch(int b, int hw, int c);
+int i2p_gather_rows_grad_fx(int b, int hw, int c, int q, int W, const float *grad_out, const int64_t *h_idx,
+                            const int64_t *w_idx, void *scratch, float *grad_feat, void *stream);
 int i2p_pair_bias_bn_finish(int B, int N, int M, int C, const float *sum_k, const float *sum_n, const float *enc_n,
                             const float *enc_k, const double *dsums, const float *coef, const float *mi, float *d_enc_n,
                             float *d_enc_k, void *stream);   /* closed-form half of i2p_pair_bias_bn_bwd on formed sums */
