@@ -72,6 +72,7 @@ DEVICE_ONLY = {
     "i2p_pair_bias_bn_finish": ["i"] * 4 + ["p"] * 9,
     "i2p_pair_bias_bn_bwd_det": ["i"] * 4 + ["p"] * 9,
     "i2p_gather_rows_grad_fx": ["i", "i", "i", "i", "i", "p", "p", "p", "p", "p"],
+    "i2p_sa_l1_group": ["i"] * 10 + ["f", "p", "p", "p"],
 }
 # plain `int f(...)` helpers without a stream argument
 HELPERS = {

@@ -1,0 +1,236 @@
+// Level-1 set abstraction front end as ONE kernel: window K-NN selection + neighbour gather + feature build
+// (reference: fused_conv_go.cu:49-238 for the selection; src/projectPN/utils.py:36-60 gathers;
+// PPBackbone_center.py:157-187 feature build  [dxyz_raw(3), centre xyz(3), neighbour xyz_raw(3), |dxyz|(1)]).
+//
+// The reference (and this repository's first round) runs the selection, materialises three int64 [B,N,K] index
+// tensors + a mask, gathers the neighbour coordinates row by row, subtracts, takes norms and concatenates: ~10
+// launches and 34 MB of intermediates per sample at level 1.  Here a block owns 16 consecutive query cells of one
+// output row; their 9 x 15 windows overlap almost completely, so the block stages the union strip
+// (kH rows x (kW + 15*stride_w) columns) of BOTH range images (selection coordinates and raw coordinates) in LDS once
+// — "LDS staging of per-group neighbourhoods" — selects exactly like fcsk_kernel (16-lane DPP rows, sorted per-lane
+// runs, equal distances redone serially in the reference's order), and writes the 10-channel feature rows (padded to
+// 12 floats = three 16-byte stores per neighbour) straight from the staged strip.  No index tensor exists.
+// Semantics of empty slots / empty centres are the reference's with FLAG_SHIFT|FLAG_COPY: empty slots repeat the
+// nearest hit, a query without any hit (or with an empty centre) gathers cell (0,0).
+#include "common.h"
+
+namespace {
+
+constexpr int GROUP = 16, QPB = 16;
+constexpr unsigned SENT_BITS = 0x501502F9u, PAD_BITS = 0x7FFFFFFFu;
+constexpr unsigned CODE_STORED = 0x100u, CODE_VALID = 0x200u;
+
+struct SaParams {
+    int B, H, W, out_h, out_w, stride_h, stride_w, kH, kW, K;
+    float dist2;
+    const float *sel_xyz, *raw_xyz;       // [B,H,W,3]: selection coordinates (centres + candidates), raw coordinates (features)
+    float *feat;                          // [B, out_h*out_w, K, 12]
+    int sw;                               // strip width = kW + 15*stride_w
+    int force_serial;
+};
+
+template <int SLOTS>
+__global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
+    extern __shared__ float strip[];                       // sel [kH][sw][3] then raw [kH][sw][3]
+    __shared__ int tab[SLOTS * GROUP];
+    __shared__ unsigned long long lst[QPB][SLOTS * GROUP];
+    __shared__ unsigned short outc[QPB][I2P_MAX_WINDOW + 2];
+
+    const int kt = p.kH * p.kW;
+    const int tid = threadIdx.x, g = tid >> 4, l16 = tid & 15;
+    const int wblocks = (p.out_w + QPB - 1) / QPB;
+    int bid = blockIdx.x;
+    const int wb = bid % wblocks; bid /= wblocks;
+    const int qh = bid % p.out_h; const int b = bid / p.out_h;
+    const int qw = wb * QPB + g;
+    const bool in_range = qw < p.out_w;
+    const int ch = qh * p.stride_h, cw0 = wb * QPB * p.stride_w;
+    const int h_lo = ch - p.kH / 2, w_lo = cw0 - p.kW / 2;
+    float *ssel = strip, *sraw = strip + p.kH * p.sw * 3;
+
+    // ---- stage the strip of both images (zeros outside the image rows; columns wrap: FLAG_SHIFT) ----------------
+    const int ncell = p.kH * p.sw;
+    for (int i = tid; i < ncell; i += 256) {
+        const int r = i / p.sw, cidx = i - r * p.sw;
+        const int h = h_lo + r;
+        int w = w_lo + cidx;
+        if (w < 0) w += p.W;
+        if (w >= p.W) w -= p.W;
+        float sx = 0.f, sy = 0.f, sz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f;
+        if (h >= 0 && h < p.H && w >= 0 && w < p.W) {
+            const size_t o = (((size_t)b * p.H + h) * p.W + w) * 3;
+            sx = p.sel_xyz[o]; sy = p.sel_xyz[o + 1]; sz = p.sel_xyz[o + 2];
+            rx = p.raw_xyz[o]; ry = p.raw_xyz[o + 1]; rz = p.raw_xyz[o + 2];
+        }
+        ssel[i * 3] = sx; ssel[i * 3 + 1] = sy; ssel[i * 3 + 2] = sz;
+        sraw[i * 3] = rx; sraw[i * 3 + 1] = ry; sraw[i * 3 + 2] = rz;
+    }
+    for (int i = tid; i < SLOTS * GROUP; i += 256) {
+        int v = 0;
+        if (i < kt) { const int dh = i / p.kW - p.kH / 2, dw = i % p.kW - p.kW / 2; v = (dh << 16) | (dw & 0xffff); }   // random_hw = arange (utils.py:84)
+        tab[i] = v;
+    }
+    for (int i = l16; i < p.K; i += GROUP) outc[g][i] = 0;
+    __syncthreads();
+
+    // centre of this query: strip cell (kH/2, kW/2 + g*stride_w)
+    const int ccol = p.kW / 2 + g * p.stride_w;
+    const int cc = (p.kH / 2) * p.sw + ccol;
+    const float cx = ssel[cc * 3], cy = ssel[cc * 3 + 1], cz = ssel[cc * 3 + 2];
+    const bool live = in_range && !(fmaxf(i2p_sq3(cx, cy, cz), 1e-10f) <= 1e-10f);          // go.cu:72-74
+    // window cell (dh, dw) of this query -> strip cell; rows outside the image were staged as empty cells, which the
+    // reference skips just like a zero point (go.cu:99-103 vs :143: both leave the slot unset)
+    auto eval = [&](int tabv, unsigned &dbits, unsigned &stored) {
+        dbits = SENT_BITS; stored = 0;
+        const int r = p.kH / 2 + (tabv >> 16), cidx = ccol + (int)(short)(tabv & 0xffff);
+        const float *q = ssel + (r * p.sw + cidx) * 3;
+        const float xq = q[0], yq = q[1], zq = q[2];
+        if (i2p_sq3(xq, yq, zq) <= 1e-10f) return;                                            // go.cu:141-143
+        const float dq = fmaxf(i2p_sq3(cx - xq, cy - yq, cz - zq), 1e-10f);                   // go.cu:154
+        if (dq > p.dist2) return;                                                             // go.cu:157
+        dbits = i2p_f2u(dq); stored = 1;
+    };
+
+    // ---- A/B: evaluate, sort own keys, park the runs (fcsk_kernel steps A-B) ---------------------------------
+    unsigned long long key[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int pos = s * GROUP + l16;
+        unsigned dbits = PAD_BITS, stored = 0;
+        if (pos < kt) { dbits = SENT_BITS; if (live) eval(tab[pos], dbits, stored); }
+        key[s] = ((unsigned long long)dbits << 32) | (unsigned)(pos | (stored << 8));
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS - 1; ++i)
+#pragma unroll
+        for (int j = 0; j < SLOTS - 1 - i; ++j) {
+            const unsigned long long a = key[j], b2 = key[j + 1];
+            const bool sw_ = a > b2;
+            key[j] = sw_ ? b2 : a; key[j + 1] = sw_ ? a : b2;
+        }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) lst[g][s * GROUP + l16] = key[s];
+    __syncthreads();
+
+    // ---- C: K extraction steps -------------------------------------------------------------------------------
+    unsigned head_hi = (unsigned)(key[0] >> 32), head_lo = (unsigned)key[0];
+    int ptr = 1;
+    unsigned pops = 0, steps = 0, prev = 0;
+    bool tie = false, done = !live;
+    for (int s = 0; s < p.K; ++s) {
+        const unsigned gmin = i2p_row16_min_u32(head_hi);
+        if (!done) {
+            if (gmin >= SENT_BITS) done = true;
+            else {
+                tie |= (s > 0 && gmin == prev);
+                prev = gmin; ++steps;
+                if (head_hi == gmin) {
+                    outc[g][s] = (unsigned short)(head_lo | CODE_VALID);
+                    ++pops;
+                    unsigned long long nx = ((unsigned long long)PAD_BITS << 32);
+                    if (ptr < SLOTS) nx = lst[g][ptr * GROUP + l16];
+                    ++ptr;
+                    head_hi = (unsigned)(nx >> 32); head_lo = (unsigned)nx;
+                }
+            }
+        }
+    }
+    {
+        const unsigned gnext = i2p_row16_min_u32(head_hi);
+        const unsigned total = i2p_row16_add_u32(pops);
+        if (!done && steps > 0 && gnext == prev) tie = true;
+        if (total != steps) tie = true;
+    }
+    const bool need_serial = live && (tie || p.force_serial);
+    if (__syncthreads_or(need_serial ? 1 : 0)) {                       // ---- F: reference's serial order on ties
+        if (need_serial) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int pos = s * GROUP + l16;
+                unsigned dbits = SENT_BITS, stored = 0;
+                if (pos < kt) eval(tab[pos], dbits, stored);
+                lst[g][pos] = ((unsigned long long)dbits << 32) | (unsigned)(pos | (stored << 8));
+            }
+        }
+        __syncthreads();
+        if (need_serial && l16 == 0) {
+            unsigned long long *a = lst[g];
+            for (int s = 0; s < p.K; ++s) {                                                    // go.cu:183-236
+                int mi = s;
+                if (s < kt) {
+                    float dm = i2p_u2f((unsigned)(a[s] >> 32));
+                    for (int t = s + 1; t < kt; ++t) {
+                        const float dt = i2p_u2f((unsigned)(a[t] >> 32));
+                        if (dt < dm) { dm = dt; mi = t; }
+                    }
+                    if (mi != s) { const unsigned long long tmp = a[mi]; a[mi] = a[s]; a[s] = tmp; }
+                    const float ds = i2p_u2f((unsigned)(a[s] >> 32));
+                    outc[g][s] = (unsigned short)(((unsigned)a[s] & 0x1ffu) | (ds < 1e10f ? CODE_VALID : 0u));
+                } else outc[g][s] = 0;
+            }
+        }
+    }
+    __syncthreads();
+    if (!in_range) return;
+
+    // ---- feature rows: [nbr_raw - centre_raw, centre, nbr_raw, |d|, 0, 0] ----------------------------------------
+    const float crx = sraw[cc * 3], cry = sraw[cc * 3 + 1], crz = sraw[cc * 3 + 2];
+    const float *cell00 = p.raw_xyz + (size_t)b * p.H * p.W * 3;       // what an unset slot gathers: cell (0,0)
+    const size_t obase = (((size_t)b * p.out_h + qh) * p.out_w + qw) * p.K;
+    const unsigned copy_code = live ? outc[g][0] : 0u;
+    for (int s = l16; s < p.K; s += GROUP) {
+        unsigned code = live ? outc[g][s] : 0u;
+        if (!(code & CODE_VALID)) code = copy_code;                    // FLAG_COPY (go.cu:211-222); empty centre: (0,0)
+        float nx, ny, nz;
+        if (code & CODE_STORED) {
+            const int tv = tab[code & 0xff];
+            const float *q = sraw + ((p.kH / 2 + (tv >> 16)) * p.sw + ccol + (int)(short)(tv & 0xffff)) * 3;
+            nx = q[0]; ny = q[1]; nz = q[2];
+        } else { nx = cell00[0]; ny = cell00[1]; nz = cell00[2]; }
+        const float dx = nx - crx, dy = ny - cry, dz = nz - crz;
+        const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+        float4 *o = reinterpret_cast<float4 *>(p.feat + (obase + s) * 12);
+        o[0] = make_float4(dx, dy, dz, cx); o[1] = make_float4(cy, cz, nx, ny); o[2] = make_float4(nz, dn, 0.f, 0.f);
+    }
+}
+
+template <int SLOTS>
+int launch(const SaParams &p, hipStream_t st) {
+    const size_t bytes = (size_t)p.kH * p.sw * 3 * 2 * sizeof(float);
+    if (bytes > 96 * 1024) return I2P_ERR_BAD_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sa_l1_kernel<SLOTS>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)((long long)p.B * p.out_h * ((p.out_w + QPB - 1) / QPB));
+    hipLaunchKernelGGL(sa_l1_kernel<SLOTS>, dim3(grid), dim3(256), bytes, st, p);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+// Level-1 grouping features: feat [B, out_h*out_w, K, 12] (10 channels + 2 zeros), queries = the strided cells
+// (qh*stride_h, qw*stride_w) of the H x W images, window kH x kW around them with column wrap, distance limit.
+extern "C" int i2p_sa_l1_group(int B, int H, int W, int out_h, int out_w, int stride_h, int stride_w, int kH, int kW, int K,
+                               float distance, const float *sel_xyz, const float *raw_xyz, float *feat, void *stream) {
+    if (B < 0 || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0 || stride_h <= 0 || stride_w <= 0 || kH <= 0 || kW <= 0 || K <= 0)
+        return I2P_ERR_BAD_ARG;
+    const int kt = kH * kW;
+    if (kt > I2P_MAX_WINDOW) return I2P_ERR_WINDOW;
+    if (K > I2P_MAX_WINDOW) return I2P_ERR_K;
+    if ((out_h - 1) * stride_h >= H || (out_w - 1) * stride_w >= W) return I2P_ERR_BAD_ARG;
+    if (B == 0) return 0;
+    if (!sel_xyz || !raw_xyz || !feat) return I2P_ERR_BAD_ARG;
+    SaParams p;
+    p.B = B; p.H = H; p.W = W; p.out_h = out_h; p.out_w = out_w; p.stride_h = stride_h; p.stride_w = stride_w;
+    p.kH = kH; p.kW = kW; p.K = K; p.dist2 = distance * distance; p.sel_xyz = sel_xyz; p.raw_xyz = raw_xyz; p.feat = feat;
+    p.sw = kW + (QPB - 1) * stride_w;
+    p.force_serial = !(p.dist2 < 1e10f);
+    if (p.sw > W) return I2P_ERR_BAD_ARG;                              // (a strip never wraps onto itself)
+    hipStream_t st = (hipStream_t)stream;
+    if (kt <= 16) return launch<1>(p, st);
+    if (kt <= 48) return launch<3>(p, st);
+    if (kt <= 144) return launch<9>(p, st);
+    return launch<10>(p, st);
+}

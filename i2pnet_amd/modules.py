@@ -32,6 +32,9 @@ USE_FUSED_BN = True
 USE_CV_TAIL = True
 # image-encoder blocks: BN(batch statistics) + LeakyReLU + MaxPool3 as fused HIP kernels behind MIOpen's conv
 USE_FUSED_IMG = True
+# level-1 set abstraction: selection + neighbour gather + feature build in one kernel with the window strip staged in
+# LDS (csrc/sa_group.hip); False = fused_conv_select_k + row gathers + torch feature build
+USE_FUSED_GROUP = True
 
 
 def run_stack(x, convs, first_bn=None, pool_k=0):
@@ -361,6 +364,20 @@ class ProjectPointNet(nn.Module):
         [dxyz(3), centre xyz(3), neighbour xyz(3), |dxyz|(1)] (PPBackbone_center.py:177-187)."""
         B = xyz_proj.shape[0]
         N = self.out_h * self.out_w
+        be = ops.get_backend()
+        if (USE_FUSED_GROUP and USE_FUSED_MLP and be.device_type == "cuda" and be.name == "hip" and not using_intens and self.usetrans
+                and not xyz_proj.requires_grad and not xyz_proj_raw.requires_grad
+                and self.kernel_size[1] + 15 * self.stride_W <= self.W):
+            with torch.no_grad():
+                if sample_idx is None:
+                    sample_idx = P.get_sample_idx(B, self.out_h, self.out_w, self.stride_H, self.stride_W, xyz_proj.device)
+                feat = be.sa_l1_group(xyz_proj.contiguous(), (xyz_proj_raw if raw_feat_point else xyz_proj).contiguous(), self.out_h,
+                                      self.out_w, self.stride_H, self.stride_W, self.kernel_size[0], self.kernel_size[1],
+                                      self.nsample, self.distance)
+            raw_c = _strided(xyz_proj_raw, self.stride_H, self.stride_W, self.out_h, self.out_w).contiguous()
+            c = _strided(xyz_proj, self.stride_H, self.stride_W, self.out_h, self.out_w).contiguous()
+            # (grouped_xyz, the 4th output, is not materialised on this path: the network never reads it)
+            return raw_c, c, self._mlp_max(feat, B), None, sample_idx
         raw_c, c, grouped_xyz, norm, gidx, sample_idx = self._centres_and_groups(xyz_proj_raw, xyz_proj, sample_idx,
                                                                                raw_feat_point)
         centre = c.view(B, N, 1, 3).expand(-1, -1, norm.shape[2], -1)

@@ -227,6 +227,16 @@ class CBackend:
                    stream=self._stream())
         return out_xyz, outs, winner
 
+    def sa_l1_group(self, sel_img, raw_img, out_h, out_w, stride_h, stride_w, kH, kW, K, distance):
+        """Level-1 grouping in one launch (csrc/sa_group.hip): window K-NN around the strided cells of `sel_img`
+        [B,H,W,3] + the 10-channel geometric feature rows built from `raw_img` -> [B, out_h*out_w, K, 12]."""
+        B, H, W, _ = sel_img.shape
+        feat = torch.empty(B, out_h * out_w, K, 12, dtype=_F32, device=sel_img.device)
+        self._call("i2p_sa_l1_group", int(B), int(H), int(W), int(out_h), int(out_w), int(stride_h), int(stride_w), int(kH), int(kW),
+                   int(K), float(distance), self._p(sel_img, _F32, "sel_xyz"), self._p(raw_img, _F32, "raw_xyz"),
+                   self._p(feat, _F32, "feat"), stream=self._stream())
+        return feat
+
     def gather_rows(self, feat, h_idx, w_idx, W, out):
         B, HW, Cc = feat.shape
         Q = h_idx.shape[1]

@@ -417,6 +417,12 @@ long long i2p_pair_bias_bn_bwd_scratch(int B, int N, int M, int C);
 int i2p_pair_bias_bn_bwd_det(int B, int N, int M, int C, const float *gz, const float *enc_n, const float *enc_k,
                              const double *dsums, const float *coef, const float *mi, float *scratch, float *d_enc_n,
                              float *d_enc_k, void *stream);
+/* Level-1 set-abstraction front end (PPBackbone_center.py:152-187: get_neighbor_copy + gather_torch x2 + feature build)
+ * in one launch with the window strip of both range images staged in LDS: selection = i2p_fused_conv_select_k with
+ * FLAG_SHIFT|FLAG_COPY, stride 1, random_hw = arange, centres = the cells (qh*stride_h, qw*stride_w);
+ * feat f32 [B, out_h*out_w, K, 12] = [nbr_raw - centre_raw (3), centre (3), nbr_raw (3), |.| (1), 0, 0]. */
+int i2p_sa_l1_group(int B, int H, int W, int out_h, int out_w, int stride_h, int stride_w, int kH, int kW, int K,
+                    float distance, const float *sel_xyz, const float *raw_xyz, float *feat, void *stream);
 /* i2p_gather_rows_grad on int64 fixed-point atomics (order-independent, deterministic, 2^-40 of max|grad_out| resolution):
  * scratch = i2p_gather_rows_grad_fx_scratch(b,hw,c) BYTES, zeroed by the caller; grad_feat is accumulated into. */
 long long i2p_gather_rows_grad_fx_scratch(int b, int hw, int c);

@@ -693,3 +693,36 @@ def test_cv_tail_ops_parity(oracle_backend, hip_backend):
     h3 = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(xb, None, None, gb, bb, True, 0.0, 1e-5), 0.1)
     want = (torch.softmax(h5.view(B, N, M, 64), 2) * h3.view(B, N, M, 64)).sum(2)
     assert torch.allclose(got[6].cpu(), want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lattice", [False, True])
+def test_sa_l1_group_matches_unfused_path(hip_backend, lattice):
+    """Fused level-1 grouping (selection + gather + feature build, window strip in LDS) against the unfused operator
+    chain (fused_conv_select_k -> gather_rows -> torch feature build), which is itself bit-exact against the oracle:
+    identical neighbour choices incl. ties (lattice image), empty centres, empty windows and column wrap."""
+    from i2pnet_amd import modules, projectpn as P
+    from helpers import range_image
+    B, H, W = 2, 64, 1800
+    raw = range_image(B, H, W, seed=11, empty_frac=0.5, lattice=lattice).cuda()
+    rot = torch.tensor([[0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0]], device="cuda")
+    sel = (raw @ rot.t() + torch.tensor([0.3, -0.2, 0.1], device="cuda")) * (raw != 0).any(-1, keepdim=True)
+    dist = 3.0 if lattice else 0.75
+    net = modules.ProjectPointNet(H, W, 16, 225, 4, 8, [9, 15], 32, dist, 12, [16, 16, 32], use_trans=True).cuda()
+    outs = {}
+    for fused in (True, False):
+        modules.USE_FUSED_GROUP = fused
+        try:
+            captured = {}
+            orig = net._mlp_max
+            net._mlp_max = lambda x, B_, _c=captured: _c.setdefault("feat", x.clone()) if False else (_c.__setitem__("feat", x.clone()) or orig(x, B_))
+            net.forward_center(raw, sel, None, raw_feat_point=True)
+            outs[fused] = captured["feat"]
+        finally:
+            modules.USE_FUSED_GROUP = True
+            net._mlp_max = orig
+    a, b = outs[True].reshape(B, 3600, 32, 12), outs[False].reshape(B, 3600, 32, 12)
+    assert torch.equal(a[..., :9], b[..., :9])                       # differences, centres, neighbours: pure copies / one subtraction
+    assert torch.allclose(a[..., 9], b[..., 9], rtol=1e-6, atol=0)    # |d|: torch.norm's reduction may round differently
+    assert float(a[..., 10:].abs().max()) == 0.0
+    assert float(a[..., :3].abs().max()) > 0
