@@ -122,7 +122,37 @@ def kernel_rooflines(B, device):
             "achieved": round(bytes_sel / t_sel / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(bytes_sel / t_sel / 1e3 / HBM_PEAK_GBS, 4), "avg_kernel_us": round(t_sel, 2),
             "bytes_per_launch": bytes_sel}
-    fwd["other_kernels"] = [bwd, pf, selk]
+    # --- level-1 grouping as one kernel (selection + gather + feature build, window strip staged in LDS) against the
+    #     unfused chain it replaces, on the three input densities of SURVEY.md §0.5 -----------------------------------
+    from i2pnet_amd import modules
+    grp = []
+    net = modules.ProjectPointNet(64, 1800, 16, 225, 4, 8, [9, 15], 32, 0.75, 12, [16, 16, 32], use_trans=True).to(device)
+    for name, npts, layout, zero_rows in (("8192-pt scan (7 % occupancy: most level-1 queries exit early)", 8192, "scan", 0),
+                                          ("8192-pt centre-aligned (all 3600 queries live)", 8192, "centre", 0),
+                                          ("150000-pt scan (120000 real + 30000 zero rows, the reference loader's padding)", 150000, "scan", 30000)):
+        cloud = synth.lidar_scan(B, npts, torch.Generator(device=device).manual_seed(1), device, layout=layout, zero_rows=zero_rows,
+                                 beams=64)
+        im, _, _ = hip.project_seq(cloud, [], 64, 1800, 2.0, -24.8)
+        occ = float((im != 0).any(-1).float().mean())
+        t_f = _event_time_us(lambda: hip.sa_l1_group(im, im, 16, 225, 4, 8, 9, 15, 32, 0.75), 30)
+        feats = {}
+        def chain(fused):
+            modules.USE_FUSED_GROUP = fused
+            orig = net._mlp_max
+            net._mlp_max = lambda x, B_: x                     # stop in front of the MLP: grouping front end only
+            try:
+                with torch.no_grad():
+                    feats[fused] = net.forward_center(im, im, None, raw_feat_point=True)[2]
+            finally:
+                net._mlp_max = orig; modules.USE_FUSED_GROUP = True
+        t_u = _event_time_us(lambda: chain(False), 10)
+        by = B * (2 * 64 * 1800 * 12 + 3600 * 32 * 48)
+        grp.append({"input": name, "occupancy": round(occ, 3), "fused_us": round(t_f, 1), "unfused_chain_us": round(t_u, 1),
+                    "GBps_algorithmic": round(by / t_f / 1e3, 1), "frac_of_hbm_peak": round(by / t_f / 1e3 / HBM_PEAK_GBS, 4)})
+    group = {"kernel": "sa_l1_kernel<9> (level-1 selection + gather + feature build in one launch; unfused = fused_conv_select_k + 2 row "
+                       "gathers + subtract + norm + cat, host-timed eager launches)", "bound": "hbm (in practice L2 / LDS / issue)",
+             "bytes_per_launch": B * (2 * 64 * 1800 * 12 + 3600 * 32 * 48), "cases": grp}
+    fwd["other_kernels"] = [bwd, pf, selk, group]
     return fwd
 
 

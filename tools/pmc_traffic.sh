@@ -3,10 +3,12 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+# usage: tools/pmc_traffic.sh [bf16]     (workload tools/pmc_traffic.py or tools/pmc_traffic_bf16.py)
+sfx=${1:+_$1}
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python tools/pmc_traffic.py > /tmp/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python tools/pmc_traffic$sfx.py > /tmp/pmc_$c.log 2>&1
   tail -2 /tmp/pmc_$c.log
   f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
-  python tools/pmc_summary.py "$f" | tee gpurun_out/pmc_$c.txt
+  python tools/pmc_summary.py "$f" | tee gpurun_out/pmc${sfx}_$c.txt
 done
