@@ -218,8 +218,44 @@ def kernel_rooflines_bf16(B, device):
     return fwd
 
 
+def _oracle_op_times():
+    """microseconds of the scalar (single-thread) CPU restatements of the reference's CUDA operators at the shapes of
+    one KITTI-shaped sample: what `cpu_baseline`'s step spends outside PyTorch-CPU's GEMMs."""
+    from i2pnet_amd import projectpn as P, synth
+    from oracle import oracle
+    cpu = oracle.backend()
+    out = {}
+
+    def t(fn, reps=1):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return round((time.perf_counter() - t0) / reps * 1e6, 1)
+    raw = synth.lidar_scan(1, 8192, torch.Generator().manual_seed(0), "cpu", layout="centre")
+    out["project_seq 8192 pts -> 64x1800"] = t(lambda: cpu.project_seq(raw, [], 64, 1800, 2.0, -24.8), 3)
+    img, _, _ = cpu.project_seq(raw, [], 64, 1800, 2.0, -24.8)
+    idx = P.get_stride_idx_cuda(1, 16, 225, 4, 8, "cpu")
+    rhw = torch.arange(135, dtype=torch.int32)
+    sel = torch.zeros(3, 1, 3600, 32, 1, dtype=torch.long); mask = torch.zeros(1, 3600, 32, 1); un = torch.zeros(1)
+    out["fused_conv_select_k level 1 (3600 queries x 135 cells, K=32)"] = t(
+        lambda: cpu.fused_conv_select_k(img, img, idx, rhw, 64, 1800, 3600, 9, 15, 32, 3, 0.75, 1, 1, sel[0], sel[1], sel[2], un, un, mask, 64, 1800))
+    pts = synth.lidar_scan(1, 8192, torch.Generator().manual_seed(1), "cpu")
+    fidx = torch.zeros(1, 2048, dtype=torch.int32)
+    out["furthest_point_sampling 8192 -> 2048"] = t(lambda: cpu.furthest_point_sampling_wrapper(1, 8192, 2048, pts, torch.full((1, 8192), 1e10), fidx))
+    q = torch.rand(1, 228, 3); k = torch.rand(1, 468, 3); kid = torch.zeros(1, 228, 32, dtype=torch.int32)
+    out["knn 228 x 468, k=32"] = t(lambda: cpu.knn(k, q, 32, kid), 3)
+    feat = torch.rand(1, 3600, 32); hh = torch.zeros(1, 904 * 16, dtype=torch.long); ww = torch.randint(0, 3600, (1, 904 * 16))
+    go = torch.rand(1, 904 * 16, 32); gf = torch.zeros(1, 3600, 32)
+    out["gather_rows_grad level 2 (14464 rows x 32 ch)"] = t(lambda: cpu.gather_rows_grad(go, hh, ww, 3600, gf), 3)
+    return out
+
+
 def cpu_baseline(cfg, batch_size=2, steps=2):
-    """the same training step on the host: PyTorch-CPU model + CPU oracle operators."""
+    """The same training step on the host: PyTorch-CPU model + CPU oracle operators (`kind: port`: the reference has no
+    CPU path of its own).  Two legs, bounded to about half a minute each: all host cores (torch's
+    default thread count) and the reference's OMP_NUM_THREADS=3 (train20v2learn_wandb_proj.py:22); plus the per-operator
+    times of the scalar oracle kernels."""
     from i2pnet_amd import modules, ops, synth
     from i2pnet_amd.train import Trainer
     from oracle import oracle
@@ -228,19 +264,32 @@ def cpu_baseline(cfg, batch_size=2, steps=2):
     # CUDA operators; the oracle's scalar restatements of OUR fused kernels are checkers, not a baseline
     fused = (modules.USE_FUSED_MLP, modules.USE_FUSED_BN, modules.USE_FUSED_IMG)
     modules.USE_FUSED_MLP = modules.USE_FUSED_BN = modules.USE_FUSED_IMG = False
-    try:
+    threads0 = torch.get_num_threads()
+
+    def leg(bs, nsteps, warm):
         tr = Trainer(cfg=cfg, device="cpu")
-        batch = synth.make_batch(batch_size, 8192, 375, 1242, seed=0)
-        tr.step(batch)                                   # warm-up (allocator, thread pools)
+        batch = synth.make_batch(bs, 8192, 375, 1242, seed=0)
+        for _ in range(warm):
+            tr.step(batch)                               # warm-up (allocator, thread pools)
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(nsteps):
             tr.step(batch)
-        dt = time.perf_counter() - t0
+        return bs * nsteps / (time.perf_counter() - t0)
+    try:
+        v_all = leg(batch_size, steps, 1)
+        torch.set_num_threads(3)
+        v3 = leg(1, 1, 0)                                # one cold step at batch 1: the 3-thread leg is ~10x slower
+        torch.set_num_threads(1)
+        per_op = _oracle_op_times()
     finally:
+        torch.set_num_threads(threads0)
         ops.set_backend(prev)
         modules.USE_FUSED_MLP, modules.USE_FUSED_BN, modules.USE_FUSED_IMG = fused
-    return {"value": round(batch_size * steps / dt, 4), "unit": "samples/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{steps} training steps at batch {batch_size} (same shapes), host cpu_count={os.cpu_count()}"}
+    return {"value": round(v_all, 4), "unit": "samples/s", "cores": threads0,
+            "kind": "port", "sample": f"{steps} training steps at batch {batch_size} (same shapes) after 1 warm-up step, host cpu_count={os.cpu_count()}",
+            "threads_3": {"value": round(v3, 4), "unit": "samples/s", "cores": 3,
+                          "sample": "1 training step at batch 1, no warm-up (the reference's OMP_NUM_THREADS=3)"},
+            "oracle_op_us_1_thread": per_op}
 
 
 def _free_port():

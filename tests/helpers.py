@@ -87,3 +87,32 @@ def synthetic_state(shapes, seed=0):
             t = 0.1 * torch.randn(shape, generator=g)          # biases / BN beta
         out[key] = t
     return out
+
+
+def make_kitti_tree(root, seed=7, n_points=3000, img_h=372, img_w=1030):
+    """A minimal synthetic KITTI tree in the layout of `make_dataset` (kitti_odometry_corr_lidarnone_proj.py:38-77), val
+    split (sequences 09 and 10, one frame each): velodyne .bin, colour .npy, calib.txt, the SNR .npy the loader also opens.
+    Seeded, so the test regenerates the same files instead of shipping them."""
+    import os
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    for seq in (9, 10):
+        vel = os.path.join(root, "data_odometry_velodyne", "dataset", "%02d" % seq, "velodyne")
+        snr = os.path.join(root, "data_odometry_velodyne_deepi2p_new", "data_odometry_velodyne_NWU", "sequences", "%02d" % seq, "snr0.6")
+        img = os.path.join(root, "kitti_processed_DeepI2P", "data_odometry_color_npy", "sequences", "%02d" % seq, "image_2")
+        cal = os.path.join(root, "kitti_processed_DeepI2P", "data_odometry_calib", "dataset", "sequences", "%02d" % seq)
+        for d in (vel, snr, img, cal):
+            os.makedirs(d, exist_ok=True)
+        n = n_points + 17 * seq
+        scan = np.concatenate([(rs.rand(n, 3) - 0.5) * np.array([80.0, 80.0, 6.0]), rs.rand(n, 1)], 1).astype(np.float32)
+        scan.tofile(os.path.join(vel, "000000.bin"))
+        np.save(os.path.join(snr, "000000.npy"), rs.randn(7, n).astype(np.float32))
+        np.save(os.path.join(img, "000000.npy"), rs.randint(0, 256, (img_h, img_w, 3)).astype(np.uint8))
+        P2 = np.array([[718.856, 0, 607.1928, 45.38225], [0, 718.856, 185.2157, -0.1130887], [0, 0, 1, 0.003779761]])
+        Tr = np.array([[4.276802e-04, -9.999672e-01, -8.084491e-03, -1.198459e-02], [-7.210626e-03, 8.081198e-03, -9.999413e-01, -5.403984e-02],
+                       [9.999738e-01, 4.859485e-04, -7.206933e-03, -2.921968e-01]])
+        with open(os.path.join(cal, "calib.txt"), "w") as f:
+            for k, m in (("P0", P2), ("P1", P2), ("P2", P2), ("P3", P2), ("Tr", Tr)):
+                f.write(k + ": " + " ".join("%.9e" % v for v in m.reshape(-1)) + "\n")
+
+

@@ -18,7 +18,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tools")); sys.path.insert(0, str(ROOT / "tests"))
 
 import ref_harness  # noqa: E402
-from helpers import synthetic_state  # noqa: E402
+from helpers import make_kitti_tree, synthetic_state  # noqa: E402
 from i2pnet_amd import synth  # noqa: E402
 
 OUT = ROOT / "tests" / "golden"
@@ -279,9 +279,62 @@ def run_metrics():
     print("metrics.npz", (OUT / "metrics.npz").stat().st_size, "bytes; recall", evt.get_recall(), "seq", ev.evalSeq())
 
 
+def run_loader():
+    """Sample dicts of the REFERENCE loader (val mode: centre crop, no jitter) on the synthetic tree: the pin of
+    i2pnet_amd/data.py.  cv2 is absent from the image: its one call (`cv2.resize(..., INTER_LINEAR)` at scale 0.5) is
+    served by a numpy restatement of the bilinear rule with cv2's pixel-centre convention and round-half-up — the resize
+    step is therefore pinned against that restatement, everything else against the reference's own code."""
+    import random, tempfile, types, importlib
+    ref_harness.install()
+
+    def resize(img, size, interpolation=None):
+        w, h = size
+        H, W = img.shape[:2]
+        ys = np.clip((np.arange(h) + 0.5) * (H / h) - 0.5, 0, H - 1); xs = np.clip((np.arange(w) + 0.5) * (W / w) - 0.5, 0, W - 1)
+        y0 = np.floor(ys).astype(int); x0 = np.floor(xs).astype(int)
+        y1 = np.minimum(y0 + 1, H - 1); x1 = np.minimum(x0 + 1, W - 1)
+        fy = (ys - y0)[:, None, None]; fx = (xs - x0)[None, :, None]
+        v = img.astype(np.float64)
+        out = (v[y0][:, x0] * (1 - fy) * (1 - fx) + v[y0][:, x1] * (1 - fy) * fx + v[y1][:, x0] * fy * (1 - fx) + v[y1][:, x1] * fy * fx)
+        return np.floor(out + 0.5).astype(img.dtype)
+    cv2 = sys.modules["cv2"]; cv2.resize = resize; cv2.INTER_LINEAR = 1
+    tv = sys.modules["torchvision"]; tv.transforms = types.ModuleType("torchvision.transforms"); sys.modules["torchvision.transforms"] = tv.transforms
+    ts = types.ModuleType("torch_scatter"); ts.scatter_mean = None; sys.modules["torch_scatter"] = ts
+    if not hasattr(np, "float"):
+        np.float = float                                   # generate_random_transform uses the removed alias (:401)
+    mod = importlib.import_module("src.kitti_odometry_corr_lidarnone_proj")
+    with tempfile.TemporaryDirectory() as root:
+        make_kitti_tree(root)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            ds = mod.Kitti_Odometry_Dataset({"root_path": root, "mode": "val", "d_rot": 10, "d_trans": 1.0, "fixed_decalib": False})
+        rec = {}
+        orig_perm, orig_rt = np.random.permutation, ds.generate_random_transform
+        out = {}
+        for i in range(len(ds)):
+            np.random.seed(100 + i); random.seed(200 + i)
+            np.random.permutation = lambda n, _i=i: rec.setdefault(("perm", _i), orig_perm(n))
+            ds.generate_random_transform = lambda *a, _i=i: rec.setdefault(("Pr", _i), orig_rt(*a))
+            s = ds[i]
+            out[f"perm{i}"] = rec[("perm", i)]; out[f"Pr{i}"] = rec[("Pr", i)]
+            out[f"rgb{i}"] = s["rgb"].numpy().astype(np.uint8)
+            assert np.array_equal(out[f"rgb{i}"].astype(np.float32), s["rgb"].numpy())
+            for k in ("decalib_real_gt", "decalib_dual_gt"):
+                out[f"{k}{i}"] = s[k].numpy()
+            for k in ("init_extrinsic", "init_intrinsic", "lidar", "lidar_feats", "raw_point_xyz"):
+                out[f"{k}{i}"] = np.asarray(s[k])
+            out[f"path_info{i}"] = np.array(s["path_info"])
+        np.random.permutation = orig_perm
+    np.savez_compressed(OUT / "loader_kitti.npz", n=np.array(len(ds)), **out)
+    print("loader_kitti.npz", (OUT / "loader_kitti.npz").stat().st_size, "bytes", {k: v.shape for k, v in out.items() if k.endswith("0")})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         run_metrics()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "loader":
+        run_loader()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         run_small_range()
