@@ -60,7 +60,10 @@ struct LinFwdParams {
     // g^y = scale*(gz - m1 - xhat*m2).  w_transposed: Ws[o][k] = w[k*cout + o].  Store phase:
     // out = acc * act'(z_prev) with z_prev from ex (pre-BN tensor in front) and e_coef/e_mi; sums
     // receive { sum out, sum out*xhat_prev }.
-    const float *x2, *g_coef;   // g_coef [6][cin]: + beta (row 5)
+    const float *x2, *g_coef;   // g_coef: non-null = a BN sits behind (its constants are formed in the prologue from the raw sources below)
+    const double *g_dsums;      // [REP][2*cin] replicated {sum gz, sum gz*xhat} of that BN
+    const float *g_oc, *g_omi;  // its coef [3][cin] (mean, scale, beta) and mean_invstd [2*cin]
+    long long g_rows;
     float g_slope;              // gz arrives as dL/da of the layer behind (a = act(z), slope g_slope): apply act'(z) on load; 1 = gz is dL/dz
     int w_transposed;
     const float *ex, *e_coef, *e_mi;
@@ -74,6 +77,10 @@ struct LinFwdParams {
     const float *xb, *in_coef_b;
     float slope_b;
     float *yb; const float *exb, *e_coef_b, *e_mi_b, *e_add; double *sums_b; float e_slope_b;
+    // BN finalisation by the LAST block to finish (forward modes): coef [3][cout_total] = mean, invstd*gamma, beta and
+    // mean_invstd [2*cout_total] of the output's batch statistics, formed from `sums` once every block has added its
+    // share (ticket counter, zero on entry and reset on exit) — a separate 1-block launch per layer otherwise.
+    unsigned *fin_counter; const float *fin_gamma, *fin_beta; float fin_eps; float *fin_coef, *fin_mi;
 };
 
 // (b,n,k) bookkeeping of pair mode without per-element 64-bit divisions: one division pair per
@@ -317,6 +324,40 @@ __device__ __forceinline__ void st_stream(float *ptr, const float4 &v, bool nt) 
 constexpr int F2_THREADS = 512;
 constexpr int F2_ROWS = 16;
 
+// the tail of a forward launch: see LinFwdParams::fin_counter
+// (`flag`: one word of the kernel's dynamic LDS, dead by now: a static __shared__ on top of the 160 KB carve-out fails to launch)
+template <int NTHREADS>
+__device__ __forceinline__ void finalize_by_last_block(const LinFwdParams &p, int tid, volatile int *flag) {
+    // Only device-scope ATOMICS are published here (performed at the coherence point, no cache line to write back): it is
+    // enough that this thread's atomics are acknowledged before the block takes its ticket — a full release fence
+    // (buffer_wbl2 of the freshly written y tile, by 512 threads) cost ~1 ms per step over the ~40 layer launches.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = atomicAdd(p.fin_counter, 1u);
+        *flag = (t == gridDim.x * gridDim.y - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const int c = p.cout_total;
+    for (int ch = tid; ch < c; ch += NTHREADS) {
+        double s = 0.0, q = 0.0;
+        for (int r = 0; r < REP; ++r) {                     // agent-scope loads: the sums live in L2 (written by atomics only)
+            s += __hip_atomic_load(p.sums + (size_t)r * 2 * c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q += __hip_atomic_load(p.sums + (size_t)r * 2 * c + c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const double m = s / (double)p.rows;
+        double var = q / (double)p.rows - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        const float invstd = rsqrtf((float)var + p.fin_eps);
+        p.fin_coef[ch] = (float)m; p.fin_coef[c + ch] = invstd * p.fin_gamma[ch]; p.fin_coef[2 * c + ch] = p.fin_beta[ch];
+        p.fin_mi[ch] = (float)m; p.fin_mi[c + ch] = invstd;
+    }
+    if (tid == 0) *p.fin_counter = 0u;
+}
+
+
+
 // branch-free (b,n,k) walk for a 16-row strip (M >= 16: at most one wrap inside a strip)
 __device__ __forceinline__ void pair_row16(const PairTile &t, int d, int N, int M, int &bn, int &bk) {
     int k = t.k0 + d;
@@ -383,9 +424,17 @@ __global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(L
     float *Gt = smem + ((size_t)p.cout_p + 8 * F2_ROWS) * ldk;
     float *Et = Gt + 6 * p.cin;
     if (DGRAD) {
-        for (int i = tid; i < 6 * p.cin; i += F2_THREADS) {
-            const int row = i / p.cin;
-            Gt[i] = p.g_coef ? p.g_coef[i] : ((row == 2 || row == 4) ? 1.f : 0.f);
+        // (formed here from the replica sums: a separate 1-block kernel per layer used to do this — 35 launches per step)
+        for (int ch = tid; ch < p.cin; ch += F2_THREADS) {
+            float m1 = 0.f, m2 = 0.f, sc = 1.f, mu = 0.f, is = 1.f, be = 0.f;
+            if (p.g_coef) {
+                double sd = 0.0, sx = 0.0;
+#pragma unroll 8
+                for (int rp = 0; rp < REP; ++rp) { sd += p.g_dsums[(size_t)rp * 2 * p.cin + ch]; sx += p.g_dsums[(size_t)rp * 2 * p.cin + p.cin + ch]; }
+                m1 = (float)(sd / (double)p.g_rows); m2 = (float)(sx / (double)p.g_rows);
+                sc = p.g_oc[p.cin + ch]; mu = p.g_omi[ch]; is = p.g_omi[p.cin + ch]; be = p.g_oc[2 * p.cin + ch];
+            }
+            Gt[ch] = m1; Gt[p.cin + ch] = m2; Gt[2 * p.cin + ch] = sc; Gt[3 * p.cin + ch] = mu; Gt[4 * p.cin + ch] = is; Gt[5 * p.cin + ch] = be;
         }
         for (int i = tid; i < 4 * p.cout_total; i += F2_THREADS) {
             const int row = i / p.cout_total, ch = i - row * p.cout_total;
@@ -705,6 +754,7 @@ __global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(L
             }
         }
     }
+    if (!DGRAD && p.fin_counter) finalize_by_last_block<F2_THREADS>(p, tid, reinterpret_cast<volatile int *>(smem));
 }
 
 template <int NT16, bool PAIR, bool DGRAD, int CH>
@@ -1396,7 +1446,9 @@ __global__ __launch_bounds__(THREADS) void pair_bwd_kernel(PairBwdParams p) {
 struct WgradParams {
     long long rows;
     int cin, cout, cin_p, cout_p, ldg, ldx;
-    const float *gz, *y, *g_coef;        // g_coef [6][cout] or nullptr (gz already is dL/dy)
+    const float *gz, *y, *g_coef;        // g_coef: non-null = BN behind (constants formed in the prologue), nullptr: gz already is dL/dy
+    const double *g_dsums; const float *g_oc, *g_omi; long long g_rows;   // raw sources, as in LinFwdParams
+    float *bn_out;                       // [8][cout] scratch tail: rows 6, 7 receive dbeta = sum gz, dgamma = sum gz*xhat (block 0)
     float g_slope;                       // != 1: gz is dL/da of an activation with this slope (act' applied on load)
     const float *x, *in_coef;            // in_coef [3][cin] or nullptr
     float slope_in;
@@ -1433,7 +1485,18 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
     constexpr int XCH = (WG_R * NTI * 8 + WG_THREADS - 1) / WG_THREADS;
     const int co4 = p.cout >> 2, ci4 = p.cin >> 2;
 
-    for (int i = tid; i < 6 * p.cout; i += WG_THREADS) Cg[i] = p.g_coef ? p.g_coef[i] : 0.f;
+    for (int ch = tid; ch < p.cout; ch += WG_THREADS) {
+        float m1 = 0.f, m2 = 0.f, sc = 0.f, mu = 0.f, is = 0.f, be = 0.f;
+        if (p.g_coef) {
+            double sd = 0.0, sx = 0.0;
+#pragma unroll 8
+            for (int rp = 0; rp < REP; ++rp) { sd += p.g_dsums[(size_t)rp * 2 * p.cout + ch]; sx += p.g_dsums[(size_t)rp * 2 * p.cout + p.cout + ch]; }
+            m1 = (float)(sd / (double)p.g_rows); m2 = (float)(sx / (double)p.g_rows);
+            sc = p.g_oc[p.cout + ch]; mu = p.g_omi[ch]; is = p.g_omi[p.cout + ch]; be = p.g_oc[2 * p.cout + ch];
+            if (blockIdx.x == 0 && p.bn_out) { p.bn_out[6 * p.cout + ch] = (float)sd; p.bn_out[7 * p.cout + ch] = (float)sx; }
+        }
+        Cg[ch] = m1; Cg[p.cout + ch] = m2; Cg[2 * p.cout + ch] = sc; Cg[3 * p.cout + ch] = mu; Cg[4 * p.cout + ch] = is; Cg[5 * p.cout + ch] = be;
+    }
     // (two-source input: in_coef describes only the first split_c channels; that mode takes its constants from
     //  registers, the table is not used — do not read past the end of the shorter coefficient array)
     for (int i = tid; i < 3 * p.cin; i += WG_THREADS) Cx[i] = (p.in_coef && !p.xb) ? p.in_coef[i] : 0.f;
@@ -1458,10 +1521,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p)
     float4 x_mu = k_m1, x_sc = k_sc, x_be = k_m1;
     if (p.g_coef && g_fix) {
         const int c4 = tid % co4;
-        k_m1 = *reinterpret_cast<const float4 *>(p.g_coef + c4 * 4); k_m2 = *reinterpret_cast<const float4 *>(p.g_coef + p.cout + c4 * 4);
-        k_sc = *reinterpret_cast<const float4 *>(p.g_coef + 2 * p.cout + c4 * 4); k_mu = *reinterpret_cast<const float4 *>(p.g_coef + 3 * p.cout + c4 * 4);
-        k_is = *reinterpret_cast<const float4 *>(p.g_coef + 4 * p.cout + c4 * 4);
-        k_be = *reinterpret_cast<const float4 *>(p.g_coef + 5 * p.cout + c4 * 4);
+        k_m1 = *reinterpret_cast<const float4 *>(Cg + c4 * 4); k_m2 = *reinterpret_cast<const float4 *>(Cg + p.cout + c4 * 4);
+        k_sc = *reinterpret_cast<const float4 *>(Cg + 2 * p.cout + c4 * 4); k_mu = *reinterpret_cast<const float4 *>(Cg + 3 * p.cout + c4 * 4);
+        k_is = *reinterpret_cast<const float4 *>(Cg + 4 * p.cout + c4 * 4);
+        k_be = *reinterpret_cast<const float4 *>(Cg + 5 * p.cout + c4 * 4);
     }
     // source of this thread's X' chunks (two-source mode needs the per-thread-constant layout)
     const bool x_b = p.xb && (tid % ci4) * 4 >= p.split_c;
@@ -1646,10 +1709,23 @@ int dispatch_bwd_o(LinBwdParams &p, float *dw, hipStream_t st, unsigned grid) {
 
 }  // namespace
 
+struct FinArgs { unsigned *counter; const float *gamma, *beta; float eps; float *coef, *mi; };
+
 static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const float *in_coef, float slope_in,
                         const float *w, float *y, double *sums, const float *pair_f, const float *bias_n,
                         const float *bias_k, int pair_N, int pair_M, void *stream, const float *xb = nullptr,
-                        const float *in_coef_b = nullptr, float slope_b = 1.f, int split_c = 0) {
+                        const float *in_coef_b = nullptr, float slope_b = 1.f, int split_c = 0, const FinArgs *fin = nullptr) {
+    if (fin && (!sums || !fin->counter || !fin->gamma || !fin->beta || !fin->coef || !fin->mi)) return I2P_ERR_BAD_ARG;
+    // the statistics are finalised by the layer kernel's last block when ONE second-generation launch covers the layer;
+    // otherwise by the small kernel at the end of this function
+    bool fin_done = false;
+    auto finish = [&](int rc) -> int {
+        if (rc || !fin || fin_done) return rc;
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((cout + 63) / 64), dim3(64), 0, (hipStream_t)stream, rows, cout, sums, fin->gamma,
+                           fin->beta, fin->eps, fin->coef, fin->mi);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : (int)e;
+    };
     if (rows < 0 || cin <= 0 || cout <= 0 || cout > 256) return I2P_ERR_BAD_ARG;
     if (rows == 0) return 0;
     if (!x || !w || !y) return I2P_ERR_BAD_ARG;
@@ -1672,12 +1748,17 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
                 p.y_ld = cout; p.ch_off = off; p.cout_total = cout;
                 { const char *abl = getenv("I2P_LIN_ABLATE"); p.ablate = abl ? atoi(abl) : 0; }   // diagnostic only
                 p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
-                p.x2 = nullptr; p.g_coef = nullptr; p.w_transposed = 0; p.ex = p.e_coef = p.e_mi = nullptr; p.e_slope = 1.f;
+                p.x2 = nullptr; p.g_coef = nullptr; p.g_dsums = nullptr; p.g_oc = p.g_omi = nullptr; p.g_rows = 1; p.w_transposed = 0; p.ex = p.e_coef = p.e_mi = nullptr; p.e_slope = 1.f;
                 p.split_c = 0; p.xb = xb; p.in_coef_b = in_coef_b; p.slope_b = slope_b; p.yb = nullptr; p.exb = p.e_coef_b = p.e_mi_b = p.e_add = nullptr; p.sums_b = nullptr; p.e_slope_b = 1.f; p.split_c = split_c;
+                p.fin_counter = nullptr; p.fin_gamma = p.fin_beta = nullptr; p.fin_eps = 0.f; p.fin_coef = p.fin_mi = nullptr;
+                if (fin && slice_w == cout) {
+                    p.fin_counter = fin->counter; p.fin_gamma = fin->gamma; p.fin_beta = fin->beta; p.fin_eps = fin->eps;
+                    p.fin_coef = fin->coef; p.fin_mi = fin->mi; fin_done = true;
+                }
                 const int rc = pair_f ? dispatch_fwd2<true, false>(p, st) : dispatch_fwd2<false, false>(p, st);
                 if (rc) return rc;
             }
-            return 0;
+            return finish(0);
         }
     }
     if (xb) return I2P_ERR_BAD_ARG;                        // two-source input exists only in the second generation
@@ -1694,8 +1775,9 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
         p.y_ld = cout; p.ch_off = off; p.cout_total = cout;
         p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
         { const char *ab = getenv("I2P_LIN_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
-        p.x2 = nullptr; p.g_coef = nullptr; p.w_transposed = 0; p.ex = p.e_coef = p.e_mi = nullptr; p.e_slope = 1.f;
+        p.x2 = nullptr; p.g_coef = nullptr; p.g_dsums = nullptr; p.g_oc = p.g_omi = nullptr; p.g_rows = 1; p.w_transposed = 0; p.ex = p.e_coef = p.e_mi = nullptr; p.e_slope = 1.f;
                 p.split_c = 0; p.xb = xb; p.in_coef_b = in_coef_b; p.slope_b = slope_b; p.yb = nullptr; p.exb = p.e_coef_b = p.e_mi_b = p.e_add = nullptr; p.sums_b = nullptr; p.e_slope_b = 1.f; p.split_c = split_c;
+        p.fin_counter = nullptr; p.fin_gamma = p.fin_beta = nullptr; p.fin_eps = 0.f; p.fin_coef = p.fin_mi = nullptr;
         int rc;
         switch (p.cout_p / 32) {
             case 1: rc = launch_fwd<1>(p, st); break;
@@ -1709,7 +1791,7 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
         }
         if (rc) return rc;
     }
-    return 0;
+    return finish(0);
 }
 
 extern "C" int i2p_lin_fwd(long long rows, int cin, int cout, const float *x, const float *in_coef,
@@ -1730,6 +1812,35 @@ extern "C" int i2p_pair_lin_fwd(int B, int N, int M, int cin, int cout, const fl
                                 void *stream) {
     if (B <= 0 || N <= 0 || M <= 0 || (cin & 3) || cin > 128 || !f || !bias_n || !bias_k) return I2P_ERR_BAD_ARG;
     return lin_fwd_impl((long long)B * N * M, cin, cout, g, nullptr, 1.0f, w, y, sums, f, bias_n, bias_k, N, M, stream);
+}
+
+// layer + BN finalisation in one call (`_fin`: coef [3][cout], mean_invstd [2*cout] come back with y; counter = one
+// zeroed uint32 of caller scratch)
+extern "C" int i2p_lin_fwd_fin(long long rows, int cin, int cout, const float *x, const float *in_coef, float slope_in,
+                               const float *w, float *y, double *sums, const float *gamma, const float *beta, float eps,
+                               float *coef, float *mean_invstd, unsigned *counter, void *stream) {
+    const FinArgs f{counter, gamma, beta, eps, coef, mean_invstd};
+    return lin_fwd_impl(rows, cin, cout, x, in_coef, slope_in, w, y, sums, nullptr, nullptr, nullptr, 1, 1, stream, nullptr, nullptr, 1.f, 0, &f);
+}
+
+extern "C" int i2p_lin_fwd_2src_fin(long long rows, int cin_a, int cin_b, int cout, const float *xa, const float *coef_a,
+                                    float slope_a, const float *xb, const float *coef_b, float slope_b, const float *w,
+                                    float *y, double *sums, const float *gamma, const float *beta, float eps, float *coef,
+                                    float *mean_invstd, unsigned *counter, void *stream) {
+    if (!xa || !xb || cin_a <= 0 || cin_b <= 0) return I2P_ERR_BAD_ARG;
+    const FinArgs f{counter, gamma, beta, eps, coef, mean_invstd};
+    return lin_fwd_impl(rows, cin_a + cin_b, cout, xa, coef_a, slope_a, w, y, sums, nullptr, nullptr, nullptr, 1, 1, stream,
+                        xb, coef_b, slope_b, cin_a, &f);
+}
+
+extern "C" int i2p_pair_lin_fwd_fin(int B, int N, int M, int cin, int cout, const float *f, const float *g,
+                                    const float *bias_n, const float *bias_k, const float *w, float *y, double *sums,
+                                    const float *gamma, const float *beta, float eps, float *coef, float *mean_invstd,
+                                    unsigned *counter, void *stream) {
+    if (B <= 0 || N <= 0 || M <= 0 || (cin & 3) || cin > 128 || !f || !bias_n || !bias_k) return I2P_ERR_BAD_ARG;
+    const FinArgs fa{counter, gamma, beta, eps, coef, mean_invstd};
+    return lin_fwd_impl((long long)B * N * M, cin, cout, g, nullptr, 1.0f, w, y, sums, f, bias_n, bias_k, N, M, stream, nullptr,
+                        nullptr, 1.f, 0, &fa);
 }
 
 extern "C" int i2p_bn_finalize(long long rows, int c, const double *sums, const float *gamma,
@@ -1808,9 +1919,10 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
         // the raw sums {sum gz, sum gz*xhat} = dbeta, dgamma of the BN behind (read back by the caller)
         float *g_coef = nullptr;
         if (out_coef && !pair) {
-            g_coef = dw_partial + (size_t)grid * cout * cin;
-            hipLaunchKernelGGL(bnbwd_coef_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, rows, cout, out_dsums, out_coef,
-                               out_mi, g_coef);
+            g_coef = dw_partial + (size_t)grid * cout * cin;        // [8][cout] scratch tail; rows 6, 7 = dbeta, dgamma for the caller
+            if (!gen2)                                              // (the second-generation kernels form the constants in their prologues)
+                hipLaunchKernelGGL(bnbwd_coef_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, rows, cout, out_dsums, out_coef,
+                                   out_mi, g_coef);
         }
         if (gen2) {
             if (gz_in) {
@@ -1818,11 +1930,13 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
                 q.rows = rows; q.cin = cout; q.cout = cin; q.cin_p = cout; q.cout_p = cin;
                 q.ldk = (cout > cin ? cout : cin) + ((cout & 15) == 0 ? 4 : 2);      // +4: 16-byte rows for the wide-K fragments
                 q.x = gz; q.x2 = y; q.g_coef = g_coef; q.g_slope = p.slope_out; q.in_coef = nullptr; q.slope_in = 1.f;
+                q.g_dsums = out_dsums; q.g_oc = out_coef; q.g_omi = out_mi; q.g_rows = rows;
                 q.w = w; q.w_transposed = 1; q.y = gz_in; q.sums = in_coef ? in_dsums : nullptr;
                 q.y_ld = cin; q.ch_off = 0; q.cout_total = cin; q.ablate = 0;
                 q.pair_f = q.bias_n = q.bias_k = nullptr; q.pair_N = q.pair_M = 1;
                 q.ex = in_coef ? x : nullptr; q.e_coef = in_coef; q.e_mi = in_mi; q.e_slope = slope_in;
                 q.split_c = 0; q.xb = nullptr; q.in_coef_b = nullptr; q.slope_b = 1.f; q.yb = nullptr; q.exb = q.e_coef_b = q.e_mi_b = q.e_add = nullptr; q.sums_b = nullptr; q.e_slope_b = 1.f;
+                q.fin_counter = nullptr; q.fin_gamma = q.fin_beta = nullptr; q.fin_eps = 0.f; q.fin_coef = q.fin_mi = nullptr;
                 if (two) { q.split_c = two->split_c; q.yb = two->gz_in_b; q.exb = two->xb; q.e_coef_b = two->in_coef_b; q.e_mi_b = two->in_mi_b; q.e_add = two->e_add; q.sums_b = two->in_dsums_b; q.e_slope_b = two->slope_b; q.ex = x; }
                 const int rc = dispatch_fwd2<false, true>(q, st);
                 if (rc) return rc;
@@ -1831,6 +1945,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
             wq.rows = rows; wq.cin = cin; wq.cout = cout; wq.cin_p = p.cin_p; wq.cout_p = p.cout_p;
             wq.ldg = p.cout_p; wq.ldx = p.cin_p;        // 16-B aligned rows; fragments are read along channels
             wq.gz = gz; wq.y = y; wq.g_coef = g_coef; wq.g_slope = p.slope_out; wq.x = x; wq.in_coef = in_coef; wq.slope_in = slope_in;
+            wq.g_dsums = out_dsums; wq.g_oc = out_coef; wq.g_omi = out_mi; wq.g_rows = rows; wq.bn_out = g_coef;
             wq.dw_partial = dw_partial;
             wq.split_c = 0; wq.xb = nullptr; wq.in_coef_b = nullptr; wq.slope_b = 1.f;
             if (two) { wq.split_c = two->split_c; wq.xb = two->xb; wq.in_coef_b = two->in_coef_b; wq.slope_b = two->slope_b; }

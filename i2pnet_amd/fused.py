@@ -105,8 +105,8 @@ class _MlpChain(Function):
         ctx.bf16 = bf
         for i in range(nl):
             W, g, b = p[k + 3 * i], p[k + 3 * i + 1], p[k + 3 * i + 2]
-            y, sums = be.lin_forward(ys[-1], in_coef, slope_in, W.detach(), out_dtype=_BF if bf else torch.float32)
-            in_coef, mi = be.bn_finalize(rows, sums, g.detach(), b.detach(), _EPS)
+            y, sums, in_coef, mi = be.lin_forward_fin(ys[-1], in_coef, slope_in, W.detach(), g.detach(), b.detach(), _EPS,
+                                                      out_dtype=_BF if bf else torch.float32)
             _update_running(running, i + 1, mi, rows)
             coefs.append(in_coef); mis.append(mi); ys.append(y)
             slope_in = slopes[i + 1]
@@ -268,18 +268,17 @@ class _CvPiTail(Function):
         bf = (ops.bf16_rows_ok(rows, f.device) and all(_p2(c) for c in widths) and f.shape[-1] in (32, 64, 128)
               and W1.shape[0] in (32, 64, 128))
         dt = _BF if bf else torch.float32
-        y1, st1 = be_.pair_lin_forward(f, g, bias_n, bias_k, W1, out_dtype=dt)
-        c1, m1 = be_.bn_finalize(rows, st1, d(g1), d(b1), _EPS)
-        y2, st2 = be_.lin_forward(y1, c1, s1, d(W2), out_dtype=dt); c2, m2 = be_.bn_finalize(rows, st2, d(g2), d(b2), _EPS)
-        y3, st3 = be_.lin_forward(y2, c2, s2, d(W3), out_dtype=dt); c3, m3 = be_.bn_finalize(rows, st3, d(g3), d(b3), _EPS)
+        y1, st1, c1, m1 = be_.pair_lin_forward_fin(f, g, bias_n, bias_k, W1, d(g1), d(b1), _EPS, out_dtype=dt)
+        y2, st2, c2, m2 = be_.lin_forward_fin(y1, c1, s1, d(W2), d(g2), d(b2), _EPS, out_dtype=dt)
+        y3, st3, c3, m3 = be_.lin_forward_fin(y2, c2, s2, d(W3), d(g3), d(b3), _EPS, out_dtype=dt)
         if bf:
             ye, ste = be_.outer_sum_bf16(enc_n, enc_k)
         else:
             ye = (enc_n.unsqueeze(2) + enc_k.unsqueeze(1)).view(rows, -1)
             ste = be_.bn_stats(ye)
         ce, me = be_.bn_finalize(rows, ste, d(ge), d(be), _EPS)
-        y4, st4 = be_.lin_forward_2src(ye, ce, se, y3, c3, s3, d(W4)); c4, m4 = be_.bn_finalize(rows, st4, d(g4), d(b4), _EPS)
-        y5, st5 = be_.lin_forward(y4, c4, s4, d(W5), out_dtype=dt); c5, m5 = be_.bn_finalize(rows, st5, d(g5), d(b5), _EPS)
+        y4, st4, c4, m4 = be_.lin_forward_2src_fin(ye, ce, se, y3, c3, s3, d(W4), d(g4), d(b4), _EPS)
+        y5, st5, c5, m5 = be_.lin_forward_fin(y4, c4, s4, d(W5), d(g5), d(b5), _EPS, out_dtype=dt)
         for i_, m_ in enumerate((m1, m2, m3, me, m4, m5)):       # BatchNorm2d running buffers (small-range model)
             _update_running(running, i_, m_, rows)
         out, msave = be_.cv_softmax_wsum_forward(B, N, M, y5, c5, s5, y3, c3, s3)
@@ -329,12 +328,12 @@ class _CvKnnTail(Function):
         s1, s2, s3, se, s4, s5 = slopes
         d = lambda t: t.detach()
         x1, xe, W1, We = [t.detach().contiguous() for t in (x1, xe, W1, We)]
-        y1, st1 = be_.lin_forward(x1, None, 1.0, W1); c1, m1 = be_.bn_finalize(rows, st1, d(g1), d(b1), _EPS)
-        y2, st2 = be_.lin_forward(y1, c1, s1, d(W2)); c2, m2 = be_.bn_finalize(rows, st2, d(g2), d(b2), _EPS)
-        y3, st3 = be_.lin_forward(y2, c2, s2, d(W3)); c3, m3 = be_.bn_finalize(rows, st3, d(g3), d(b3), _EPS)
-        ye, ste = be_.lin_forward(xe, None, 1.0, We); ce, me = be_.bn_finalize(rows, ste, d(ge), d(be), _EPS)
-        y4, st4 = be_.lin_forward_2src(ye, ce, se, y3, c3, s3, d(W4)); c4, m4 = be_.bn_finalize(rows, st4, d(g4), d(b4), _EPS)
-        y5, st5 = be_.lin_forward(y4, c4, s4, d(W5)); c5, m5 = be_.bn_finalize(rows, st5, d(g5), d(b5), _EPS)
+        y1, st1, c1, m1 = be_.lin_forward_fin(x1, None, 1.0, W1, d(g1), d(b1), _EPS)
+        y2, st2, c2, m2 = be_.lin_forward_fin(y1, c1, s1, d(W2), d(g2), d(b2), _EPS)
+        y3, st3, c3, m3 = be_.lin_forward_fin(y2, c2, s2, d(W3), d(g3), d(b3), _EPS)
+        ye, ste, ce, me = be_.lin_forward_fin(xe, None, 1.0, We, d(ge), d(be), _EPS)
+        y4, st4, c4, m4 = be_.lin_forward_2src_fin(ye, ce, se, y3, c3, s3, d(W4), d(g4), d(b4), _EPS)
+        y5, st5, c5, m5 = be_.lin_forward_fin(y4, c4, s4, d(W5), d(g5), d(b5), _EPS)
         for i_, m_ in enumerate((m1, m2, m3, me, m4, m5)):
             _update_running(running, i_, m_, rows)
         out, msave = be_.cv_softmax_wsum_forward(B, N, K, y5, c5, s5, y3, c3, s3)

@@ -436,6 +436,67 @@ class CBackend:
                    self._p(dy, _F32, "dy"), self._p(dgamma, _F32, "dgamma"), self._p(dbeta, _F32, "dbeta"), stream=st)
         return dy, dgamma, dbeta
 
+    # ---- layer + BN finalisation in one launch (device library; other backends: the two calls) ----------------------
+    def _fin_buffers(self, cout, dev):
+        coef = torch.empty(3, cout, dtype=_F32, device=dev)
+        mi = torch.empty(2 * cout, dtype=_F32, device=dev)
+        counter = zeros(1, torch.int32, dev)
+        return coef, mi, counter
+
+    def lin_forward_fin(self, x, in_coef, slope_in, w, gamma, beta, eps, out_dtype=_F32):
+        """lin_forward + bn_finalize of its output statistics -> (y, sums, coef [3,cout], mean_invstd [2cout])"""
+        rows, cin = x.shape
+        cout = w.shape[0]
+        if self.device_type != "cuda" or out_dtype != _F32:
+            y, sums = self.lin_forward(x, in_coef, slope_in, w, out_dtype=out_dtype)
+            coef, mi = self.bn_finalize(rows, sums, gamma, beta, eps)
+            return y, sums, coef, mi
+        dev = x.device
+        y = torch.empty(rows, cout, dtype=_F32, device=dev)
+        sums = zeros(BN_REPLICAS * 2 * cout, torch.float64, dev)
+        coef, mi, counter = self._fin_buffers(cout, dev)
+        self._call("i2p_lin_fwd_fin", int(rows), int(cin), int(cout), self._p(x, _F32, "x"),
+                   self._p(in_coef, _F32, "in_coef") if in_coef is not None else None, float(slope_in), self._p(w, _F32, "w"),
+                   self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"),
+                   float(eps), self._p(coef, _F32, "coef"), self._p(mi, _F32, "mi"), self._p(counter, torch.int32, "counter"),
+                   stream=self._stream())
+        return y, sums, coef, mi
+
+    def lin_forward_2src_fin(self, xa, coef_a, slope_a, xb, coef_b, slope_b, w, gamma, beta, eps):
+        rows, ca = xa.shape
+        cb, cout = xb.shape[1], w.shape[0]
+        if self.device_type != "cuda" or xa.dtype != _F32:
+            y, sums = self.lin_forward_2src(xa, coef_a, slope_a, xb, coef_b, slope_b, w)
+            coef, mi = self.bn_finalize(rows, sums, gamma, beta, eps)
+            return y, sums, coef, mi
+        dev = xa.device
+        y = torch.empty(rows, cout, dtype=_F32, device=dev)
+        sums = zeros(BN_REPLICAS * 2 * cout, torch.float64, dev)
+        coef, mi, counter = self._fin_buffers(cout, dev)
+        self._call("i2p_lin_fwd_2src_fin", int(rows), int(ca), int(cb), int(cout), self._p(xa, _F32, "xa"), self._p(coef_a, _F32, "coef_a"),
+                   float(slope_a), self._p(xb, _F32, "xb"), self._p(coef_b, _F32, "coef_b"), float(slope_b), self._p(w, _F32, "w"),
+                   self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"),
+                   float(eps), self._p(coef, _F32, "coef"), self._p(mi, _F32, "mi"), self._p(counter, torch.int32, "counter"),
+                   stream=self._stream())
+        return y, sums, coef, mi
+
+    def pair_lin_forward_fin(self, f, g, bias_n, bias_k, w, gamma, beta, eps, out_dtype=_F32):
+        B, N, C = f.shape
+        M, Co = g.shape[1], w.shape[0]
+        if self.device_type != "cuda" or out_dtype != _F32:
+            y, sums = self.pair_lin_forward(f, g, bias_n, bias_k, w, out_dtype=out_dtype)
+            coef, mi = self.bn_finalize(B * N * M, sums, gamma, beta, eps)
+            return y, sums, coef, mi
+        dev = f.device
+        y = torch.empty(B * N * M, Co, dtype=_F32, device=dev)
+        sums = zeros(BN_REPLICAS * 2 * Co, torch.float64, dev)
+        coef, mi, counter = self._fin_buffers(Co, dev)
+        self._call("i2p_pair_lin_fwd_fin", int(B), int(N), int(M), int(C), int(Co), self._p(f, _F32, "f"), self._p(g, _F32, "g"),
+                   self._p(bias_n, _F32, "bias_n"), self._p(bias_k, _F32, "bias_k"), self._p(w, _F32, "w"), self._p(y, _F32, "y"),
+                   self._p(sums, torch.float64, "sums"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(eps),
+                   self._p(coef, _F32, "coef"), self._p(mi, _F32, "mi"), self._p(counter, torch.int32, "counter"), stream=self._stream())
+        return y, sums, coef, mi
+
     # ---- fused linear layers (csrc/mlp.hip) -----------------------------------------------------
     def lin_forward(self, x, in_coef, slope_in, w, want_stats=True, out_dtype=_F32):
         """x [rows,cin]; in_coef [3,cin] or None; w [cout,cin] -> (y [rows,cout], sums or None).

@@ -409,6 +409,19 @@ int i2p_cv_softmax_wsum_fwd_bf16(int B, int N, int M, int C, const i2p_bf16 *y5,
 int i2p_cv_softmax_wsum_bwd_bf16(int B, int N, int M, int C, const float *g_out, const float *out, const float *msave,
                                  const i2p_bf16 *y5, const float *coef5, const float *mi5, float slope5, const i2p_bf16 *y3,
                                  const float *coef3, float slope3, i2p_bf16 *gz5, double *dsums5, i2p_bf16 *ga3, void *stream);
+/* Layer forward + BN finalisation in ONE launch: as i2p_lin_fwd / i2p_lin_fwd_2src / i2p_pair_lin_fwd, plus what
+ * i2p_bn_finalize(rows, cout, sums, gamma, beta, eps, coef, mean_invstd) would compute, formed by the last block of the
+ * layer kernel to finish; `counter` = one uint32 of caller scratch, zero on entry (left zero on exit). */
+int i2p_lin_fwd_fin(long long rows, int cin, int cout, const float *x, const float *in_coef, float slope_in, const float *w,
+                    float *y, double *sums, const float *gamma, const float *beta, float eps, float *coef,
+                    float *mean_invstd, unsigned *counter, void *stream);
+int i2p_lin_fwd_2src_fin(long long rows, int cin_a, int cin_b, int cout, const float *xa, const float *coef_a, float slope_a,
+                         const float *xb, const float *coef_b, float slope_b, const float *w, float *y, double *sums,
+                         const float *gamma, const float *beta, float eps, float *coef, float *mean_invstd,
+                         unsigned *counter, void *stream);
+int i2p_pair_lin_fwd_fin(int B, int N, int M, int cin, int cout, const float *f, const float *g, const float *bias_n,
+                         const float *bias_k, const float *w, float *y, double *sums, const float *gamma, const float *beta,
+                         float eps, float *coef, float *mean_invstd, unsigned *counter, void *stream);
 /* deterministic variants (no floating-point atomics; fixed summation order => bitwise reproducible gradients):
  * i2p_pair_lin_bwd takes its slabs from dw_partial, which must hold i2p_pair_lin_bwd_scratch(...) floats;
  * i2p_pair_bias_bn_bwd_det is i2p_pair_bias_bn_bwd with caller scratch of i2p_pair_bias_bn_bwd_scratch(...) floats. */
