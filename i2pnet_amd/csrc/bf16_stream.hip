@@ -258,50 +258,66 @@ __global__ __launch_bounds__(THREADS) void sm_bwd_bf16_kernel(SmP p) {
     reduce16(ds, dq, cv, p.C, p.dsums5);
 }
 
-// k- and n-sums of dL/dz_e (bf16) for the position-encoding factors: see cv_softmax.hip pair_sum_kernel
-constexpr int PS_NL = 8;
-__global__ __launch_bounds__(THREADS) void pair_sum_bf16_kernel(int B, int N, int M, int C, const bf16_t *__restrict__ g,
-                                                                 float *__restrict__ sum_k, float *__restrict__ sum_n) {
-    __shared__ float red[THREADS][PS_NL][8];                   // 64 KB
+// k- and n-sums of dL/dz_e (bf16) for the position-encoding factors (cv_softmax.hip: pair_sum_kernel).  Two streaming
+// passes, each with a single writer per output element (no atomics, fixed order): the tensor is 218 MB at batch 16 and
+// the second pass largely hits the 256 MB Infinity Cache.  (One pass with fp32 atomics for both sums: 423 us.)
+//   sum_n[b,k,:] = sum over points n:  thread = (b, k, 8-channel chunk), walks n with 8 loads in flight
+__global__ __launch_bounds__(THREADS) void pair_sum_n_bf16_kernel(int B, int N, int M, int C, const bf16_t *__restrict__ g,
+                                                                   float *__restrict__ sum_n) {
+    const int cv = C >> 3;
+    const long long t = (long long)blockIdx.x * THREADS + threadIdx.x;
+    if (t >= (long long)B * M * cv) return;
+    const int c8 = (int)(t % cv); const long long bk = t / cv;
+    const int k = (int)(bk % M), b = (int)(bk / M);
+    const bf16_t *src = g + (((size_t)b * N) * M + k) * C + c8 * 8;
+    const size_t nstride = (size_t)M * C;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int n = 0;
+    for (; n + 8 <= N; n += 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ld_u4_stream(src + (size_t)(n + u) * nstride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { float f[8]; bf_unpack8(v[u], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += f[i]; }
+    }
+    for (; n < N; ++n) { float f[8]; bf_unpack8(ld_u4_stream(src + (size_t)n * nstride), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += f[i]; }
+    float *o = sum_n + ((size_t)b * M + k) * C + c8 * 8;
+    *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+//   sum_k[b,n,:] = sum over pixels k:  block = one point (b,n), thread = (k phase, 8-channel chunk), block reduction
+__global__ __launch_bounds__(THREADS) void pair_sum_k_bf16_kernel(int M, int C, const bf16_t *__restrict__ g, float *__restrict__ sum_k) {
+    __shared__ float red[THREADS][8];
     const int cv = C >> 3, ks = THREADS / cv;
     const int c8 = threadIdx.x % cv, kslot = threadIdx.x / cv;
-    const int chunks = (N + PS_NL - 1) / PS_NL;
-    const int b = blockIdx.x / chunks, n0 = (blockIdx.x - b * chunks) * PS_NL;
-    const int kseg = (M + gridDim.y - 1) / gridDim.y, k_lo = blockIdx.y * kseg, k_hi = min(M, k_lo + kseg);
-    float acc[PS_NL][8];
+    const bf16_t *src = g + (size_t)blockIdx.x * M * C + c8 * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = kslot;
+    for (; k + 3 * ks < M; k += 4 * ks) {
+        uint4 v[4];
 #pragma unroll
-    for (int j = 0; j < PS_NL; ++j)
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4 *>(src + (size_t)(k + u * ks) * C);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
-    for (int k = k_lo + kslot; k < k_hi; k += ks) {
-        uint4 v[PS_NL];
+        for (int u = 0; u < 4; ++u) { float f[8]; bf_unpack8(v[u], f);
 #pragma unroll
-        for (int j = 0; j < PS_NL; ++j) {
-            const int n = n0 + j;
-            v[j] = n < N ? ld_u4_stream(g + ((((size_t)b * N + n) * M + k) * C + c8 * 8)) : make_uint4(0, 0, 0, 0);
-        }
-        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < PS_NL; ++j) {
-            float f[8]; bf_unpack8(v[j], f);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { acc[j][i] += f[i]; t[i] += f[i]; }
-        }
-        float *dst = sum_n + ((size_t)b * M + k) * C + c8 * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) atomicAdd(dst + i, t[i]);
+            for (int i = 0; i < 8; ++i) acc[i] += f[i]; }
     }
+    for (; k < M; k += ks) { float f[8]; bf_unpack8(*reinterpret_cast<const uint4 *>(src + (size_t)k * C), f);
 #pragma unroll
-    for (int j = 0; j < PS_NL; ++j)
+        for (int i = 0; i < 8; ++i) acc[i] += f[i]; }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) red[threadIdx.x][j][i] = acc[j][i];
+    for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[i];
     __syncthreads();
-    for (int idx = threadIdx.x; idx < PS_NL * C; idx += THREADS) {
-        const int j = idx / C, c = idx - j * C;
-        if (n0 + j >= N) continue;
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
         float a = 0.f;
-        for (int q = 0; q < ks; ++q) a += red[q * cv + (c >> 3)][j][c & 7];
-        atomicAdd(sum_k + ((size_t)b * N + n0 + j) * C + c, a);
+        for (int q = 0; q < ks; ++q) a += red[q * cv + (c >> 3)][c & 7];
+        sum_k[(size_t)blockIdx.x * C + c] = a;
     }
 }
 
@@ -399,8 +415,9 @@ extern "C" int i2p_pair_bias_bn_bwd_bf16(int B, int N, int M, int C, const bf16_
                                          float *d_enc_n, float *d_enc_k, void *stream) {
     if (B <= 0 || N <= 0 || M <= 0 || !ok8(C) || C > 256 || THREADS % C) return I2P_ERR_BAD_ARG;
     if (!gz || !enc_n || !enc_k || !dsums || !coef || !mi || !sum_k || !sum_n || !d_enc_n || !d_enc_k) return I2P_ERR_BAD_ARG;
-    const int chunks = (N + PS_NL - 1) / PS_NL;
-    hipLaunchKernelGGL(pair_sum_bf16_kernel, dim3(B * chunks, 4), dim3(THREADS), 0, (hipStream_t)stream, B, N, M, C, gz, sum_k, sum_n);
+    const long long tn = (long long)B * M * (C >> 3);
+    hipLaunchKernelGGL(pair_sum_n_bf16_kernel, dim3((unsigned)((tn + THREADS - 1) / THREADS)), dim3(THREADS), 0, (hipStream_t)stream, B, N, M, C, gz, sum_n);
+    hipLaunchKernelGGL(pair_sum_k_bf16_kernel, dim3(B * N), dim3(THREADS), 0, (hipStream_t)stream, M, C, gz, sum_k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     return i2p_pair_bias_bn_finish(B, N, M, C, sum_k, sum_n, enc_n, enc_k, dsums, coef, mi, d_enc_n, d_enc_k, stream);

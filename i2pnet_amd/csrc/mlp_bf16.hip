@@ -74,6 +74,24 @@ __device__ __forceinline__ void task_rc(int id, int nc, int nc_shift, int &row, 
 }
 
 // (fp32-input instantiations carry twice the prefetch registers: one block per CU, up to 512 VGPRs)
+// (b,n,k) of the rows of one strip without per-row 64-bit divisions: one 32-bit division pair per strip (wave-uniform),
+// then a row d of the strip wraps at most once (M >= 32)
+struct PairStrip { int bn0, k0, b0, n0; };
+__device__ __forceinline__ PairStrip pair_strip(long long row0, int N, int M) {
+    PairStrip t;
+    const unsigned r = (unsigned)row0;
+    t.bn0 = (int)(r / (unsigned)M); t.k0 = (int)(r - (unsigned)t.bn0 * (unsigned)M);
+    t.b0 = t.bn0 / N; t.n0 = t.bn0 - t.b0 * N;
+    return t;
+}
+__device__ __forceinline__ void pair_row_of(const PairStrip &t, int d, int N, int M, int &bn, int &bk) {
+    int k = t.k0 + d;
+    const int wrap = k >= M ? 1 : 0;
+    k -= wrap * M;
+    const int b = t.b0 + ((t.n0 + wrap) >= N ? 1 : 0);
+    bn = t.bn0 + wrap; bk = b * M + k;
+}
+
 template <int NT, bool XBF16, bool PAIR>
 __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP p) {
     extern __shared__ uint4 smem[];
@@ -124,14 +142,24 @@ __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP 
     uint4 pfb[XBF16 ? UMAX : 1];
     float4 pff[XBF16 ? 1 : PFN];
     (void)pfb; (void)pff;
+    // pair mode: a 32-row strip spans at most two points (M >= 32), so the point factor f[b,n,:] of this lane's 8 input
+    // channels is fetched ONCE per strip (two candidates) with the pixel rows, instead of one L2 round trip per row
+    float4 pf_f[PAIR ? 4 : 1];
+    long long pf_bn0 = 0;
+    int pf_k0 = 0;
+    const long long total_bn = PAIR ? p.rows / p.pM : 0;        // points of the whole batch
+    (void)pf_f; (void)pf_bn0; (void)pf_k0; (void)total_bn;
+    const int lane_c = (lane & (ncx - 1)) * 8;                   // (pair / bf16 inputs: ncx is a power of two)
 
     auto fetch = [&](long long st) {
         const long long row0 = st * RG_ROWS;
+        PairStrip ps; ps.bn0 = ps.k0 = ps.b0 = ps.n0 = 0;
+        if constexpr (PAIR) ps = pair_strip(row0, p.pN, p.pM);
 #pragma unroll
         for (int u = 0; u < UMAX; ++u) {
             if (u < U) {
                 int r, c; task_rc(lane + 64 * u, ncx, nshift, r, c);
-                long long row = row0 + r; if (row > last_row) row = last_row;
+                long long row = row0 + r; if (row > last_row) { r = (int)(last_row - row0); row = last_row; }
                 if constexpr (XBF16) {
                     const int ch = c * 8;
                     const bf16_t *src = (p.xb && ch >= p.split) ? p.xb + (size_t)row * p.xb_ld + (ch - p.split)
@@ -139,13 +167,20 @@ __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP 
                     pfb[u] = ld_u4_stream(src);
                 } else {
                     long long src = row;
-                    if constexpr (PAIR) { const long long bn = row / p.pM; const long long b = bn / p.pN; src = b * p.pM + (row - bn * p.pM); }
+                    if constexpr (PAIR) { int bn, bk; pair_row_of(ps, r, p.pN, p.pM, bn, bk); src = bk; }
                     const float *xr = reinterpret_cast<const float *>(p.x) + (size_t)src * p.x_ld;
                     const int k0 = c * 8;
                     pff[2 * u] = k0 < p.cin ? *reinterpret_cast<const float4 *>(xr + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
                     pff[2 * u + 1] = k0 + 4 < p.cin ? *reinterpret_cast<const float4 *>(xr + k0 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
+        }
+        if constexpr (PAIR) {
+            pf_bn0 = ps.bn0; pf_k0 = ps.k0;
+            const long long bn1 = ps.bn0 + 1 < total_bn ? ps.bn0 + 1 : ps.bn0;
+            const float *fa = p.pair_f + (size_t)pf_bn0 * p.cin + lane_c, *fb = p.pair_f + (size_t)bn1 * p.cin + lane_c;
+            pf_f[0] = *reinterpret_cast<const float4 *>(fa); pf_f[1] = *reinterpret_cast<const float4 *>(fa + 4);
+            pf_f[2] = *reinterpret_cast<const float4 *>(fb); pf_f[3] = *reinterpret_cast<const float4 *>(fb + 4);
         }
     };
     auto commit = [&](long long st) {
@@ -161,9 +196,8 @@ __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP 
                     f[4] = pff[2 * u + 1].x; f[5] = pff[2 * u + 1].y; f[6] = pff[2 * u + 1].z; f[7] = pff[2 * u + 1].w;
                 }
                 if constexpr (PAIR) {
-                    long long row = row0 + r; if (row > last_row) row = last_row;
-                    const float *fr = p.pair_f + (size_t)(row / p.pM) * p.cin + c * 8;
-                    const float4 f0 = *reinterpret_cast<const float4 *>(fr), f1 = *reinterpret_cast<const float4 *>(fr + 4);
+                    const bool second = pf_k0 + r >= p.pM;           // (rows past the end: values never stored)
+                    const float4 f0 = second ? pf_f[2] : pf_f[0], f1 = second ? pf_f[3] : pf_f[1];
                     f[0] *= f0.x; f[1] *= f0.y; f[2] *= f0.z; f[3] *= f0.w; f[4] *= f1.x; f[5] *= f1.y; f[6] *= f1.z; f[7] *= f1.w;
                 }
                 if (has_coef) {
@@ -186,15 +220,45 @@ __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP 
     if (strip < nstrips) fetch(strip);
     for (; strip < nstrips; strip += sstride) {
         const long long row0 = strip * RG_ROWS;
+        // pair mode: y = product + bias_n[b,n,:] + bias_k[b,k,:].  The two bias rows of this lane's output row are
+        // requested FIRST (they land under the staging work) and become the initial value of the accumulators.
+        i2p_f32x16 acc[NT];
+        float4 bnv[PAIR ? NT * 4 : 1];
+        (void)bnv;
+        if constexpr (PAIR) {
+            const PairStrip es = pair_strip(row0, p.pN, p.pM);
+            int dn = n; if (row0 + dn > last_row) dn = (int)(last_row - row0);
+            int pbn, pbk; pair_row_of(es, dn, p.pN, p.pM, pbn, pbk);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = t * 32 + 16 * h;
+                const float *bnp = p.bias_n + (size_t)pbn * p.cout + co, *bkp = p.bias_k + (size_t)pbk * p.cout + co;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f); bnv[t * 4 + j] = kk;
+                    if (co < p.cout) { kk = *reinterpret_cast<const float4 *>(bkp + 4 * j); bnv[t * 4 + j] = *reinterpret_cast<const float4 *>(bnp + 4 * j); }
+                    acc[t][4 * j] = kk.x; acc[t][4 * j + 1] = kk.y; acc[t][4 * j + 2] = kk.z; acc[t][4 * j + 3] = kk.w;
+                }
+            }
+        }
         commit(strip);
         if (strip + sstride < nstrips) fetch(strip + sstride);   // in flight during the MFMA + store phases
         __builtin_amdgcn_wave_barrier();
 
-        i2p_f32x16 acc[NT];
+        if constexpr (PAIR) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    acc[t][4 * j] += bnv[t * 4 + j].x; acc[t][4 * j + 1] += bnv[t * 4 + j].y;
+                    acc[t][4 * j + 2] += bnv[t * 4 + j].z; acc[t][4 * j + 3] += bnv[t * 4 + j].w;
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        }
         for (int ks = 0; ks < KS; ++ks) {
             const int kc = 2 * ks + h;
             const i2p_bf16x8 xb = __builtin_bit_cast(i2p_bf16x8, Ss[bf_chunk(n, kc, cpi_s)]);
@@ -207,9 +271,6 @@ __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP 
         __builtin_amdgcn_wave_barrier();
 
         // ---- fragments -> the wave's strip as bf16 rows: lane (n,h) holds channels t*32 + 16h + [0,16) of row n ----
-        long long prow = row0 + n; if (prow > last_row) prow = last_row;
-        long long pbn = 0, pbk = 0;
-        if constexpr (PAIR) { pbn = prow / p.pM; pbk = (pbn / p.pN) * p.pM + (prow - pbn * p.pM); }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int co = t * 32 + 16 * h;
@@ -217,15 +278,6 @@ __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP 
                 float v[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = acc[t][e];
-                if constexpr (PAIR) {
-                    const float *bnp = p.bias_n + (size_t)pbn * p.cout + co, *bkp = p.bias_k + (size_t)pbk * p.cout + co;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float4 a = *reinterpret_cast<const float4 *>(bnp + 4 * j), c = *reinterpret_cast<const float4 *>(bkp + 4 * j);
-                        v[4 * j] = (v[4 * j] + a.x) + c.x; v[4 * j + 1] = (v[4 * j + 1] + a.y) + c.y;
-                        v[4 * j + 2] = (v[4 * j + 2] + a.z) + c.z; v[4 * j + 3] = (v[4 * j + 3] + a.w) + c.w;
-                    }
-                }
                 float lo8[8], hi8[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { lo8[q] = v[q]; hi8[q] = v[8 + q]; }
@@ -402,6 +454,22 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rg_dgrad_kernel(DgradP p) {
         const long long row0 = strip * RG_ROWS;
         commit();
         if (strip + sstride < nstrips) fetch(strip + sstride);
+        // the store phase's operands (pre-BN tensor in front, second incoming gradient) land under the MFMA loop
+        uint4 ex_pf[OUT32 ? 1 : 2 * NT], ea_pf[OUT32 ? 1 : 2 * NT];
+        (void)ex_pf; (void)ea_pf;
+        if constexpr (!OUT32) {
+#pragma unroll
+            for (int u = 0; u < 2 * NT; ++u) {
+                ex_pf[u] = make_uint4(0, 0, 0, 0); ea_pf[u] = ex_pf[u];
+                if (u < OU) {
+                    int r = (lane + 64 * u) >> oshift; if (r >= RG_ROWS) r = RG_ROWS - 1;
+                    long long row = row0 + r; if (row > last_row) row = last_row;
+                    const size_t off = (size_t)row * dst_ld + dst_c0;
+                    if (has_e) ex_pf[u] = *reinterpret_cast<const uint4 *>(ex + off);
+                    if (eadd) ea_pf[u] = ld_u4_stream(eadd + off);
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
 
         i2p_f32x16 acc[NT];
@@ -458,12 +526,12 @@ __global__ __launch_bounds__(RG_THREADS, 1) void rg_dgrad_kernel(DgradP p) {
                         const size_t off = (size_t)(row0 + r) * dst_ld + dst_c0;
                         float f[8]; bf_unpack8(Ss[bf_chunk(r, oc, cpo_s)], f);
                         if (eadd) {
-                            float a[8]; bf_unpack8(ld_u4_stream(eadd + off), a);
+                            float a[8]; bf_unpack8(ea_pf[u], a);
 #pragma unroll
                             for (int q = 0; q < 8; ++q) f[q] += a[q];
                         }
                         if (has_e) {
-                            float xv[8]; bf_unpack8(*reinterpret_cast<const uint4 *>(ex + off), xv);
+                            float xv[8]; bf_unpack8(ex_pf[u], xv);
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
                                 f[q] = bf_bnz(xv[q], ea[q], eb[q]) > 0.f ? f[q] : f[q] * e_slope;
