@@ -15,7 +15,12 @@ CSRC = PKG / "csrc"
 LIB = PKG / "lib" / "libi2p_ops.so"
 OBJ = PKG / "lib" / "obj"
 SOURCES = ["fused_conv_select_k.hip", "pointnet2_ops.hip", "projection_ops.hip", "bn_act.hip", "mlp.hip", "cv_softmax.hip",
-           "image_block.hip", "mlp_bf16.hip", "bf16_stream.hip", "sa_group.hip", "scatter_det.hip"]
+           "image_block.hip", "mlp_bf16.hip", "bf16_stream.hip", "sa_group.hip", "scatter_det.hip", "mlp_wreg.hip"]
+# mlp_wreg.hip: one strip = 256 MFMAs with the rest of the wave's work slotted between them, written as ONE fully
+# unrolled loop — past clang's default size limit for `#pragma unroll`
+EXTRA_FLAGS = {"mlp_wreg.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
+if os.environ.get("WREG_ABL"):      # diagnostic build of the ablation switches in mlp_wreg.hip
+    EXTRA_FLAGS["mlp_wreg.hip"].append("-DWREG_ABL=" + os.environ["WREG_ABL"])
 HEADERS = [CSRC / "common.h", PKG.parent / "include" / "i2p_ops.h"]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -50,7 +55,7 @@ def build(force=False, verbose=True):
     for s in _sources():
         o = OBJ / (s + ".o")
         if force or _stale(o, [CSRC / s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", str(CSRC / s), "-o", str(o)])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", str(CSRC / s), "-o", str(o)])
 
     def run(cmd):
         if verbose:

@@ -60,3 +60,9 @@ int i2p_det_three_interpolate_grad(int b, int c, int n, int m, const float *grad
 // I2P_ATOMIC_SCATTER=1: the first-generation atomicAdd kernels (A/B timing only; not reproducible run to run)
 #include <cstdlib>
 inline bool i2p_atomic_scatter() { static const char *e = getenv("I2P_ATOMIC_SCATTER"); return e && e[0] == '1'; }
+
+// weights-stationary-in-registers fp32 layer forward for the wide layers (csrc/mlp_wreg.hip); lin_fwd_impl routes to it
+bool i2p_wreg_fwd_ok(long long rows, int cin, int cout);
+int i2p_wreg_fwd(long long rows, int cin, int cout, const float *x, int x_ld, const float *in_coef, float slope, const float *w,
+                 float *y, int y_ld, double *sums, unsigned *fin_counter, const float *fin_gamma, const float *fin_beta,
+                 float fin_eps, float *fin_coef, float *fin_mi, void *stream);

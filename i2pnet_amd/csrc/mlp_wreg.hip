@@ -1,0 +1,289 @@
+// Third-generation fp32 layer forward for the wide (64 / 128 channel) layers on many rows: WEIGHTS STATIONARY IN
+// REGISTERS.  (reference op: PPBackbone_center.py:10-51, 1x1 conv + batch-stat BN + activation, channel-last here.)
+//
+// The second generation (mlp.hip, lin_fwd2_kernel: W in LDS, two waves per SIMD with wave-private strips, x and y moved
+// through LDS to change layouts) stops at ~300 us on the 853632 x 128 x 128 layer: the two waves of a SIMD fall into
+// step (both in their MFMA phase, then both in their memory phases).  A variant of THIS kernel with two waves per SIMD
+// and half of W each measured the same 340-356 us.  Here
+//   * ONE wave per SIMD with the 512-register budget; it keeps the whole [COUT][CIN] weight matrix as MFMA A-operand
+//     fragments in registers for the life of the kernel (256 registers at 128x128): no operand traffic but x,
+//   * transposed formulation D[cout][row] = W . x^T with the K axis permuted (k-step 4f+e of k-slot q = channel
+//     16f + 4q + e): the B operand of lane (row r, slot q) for four k-steps is one aligned float4 of row r, loaded
+//     straight from global memory into the registers the MFMAs read (a load instruction covers 64-byte runs of 16 rows;
+//     the two halves of a 128-byte line are requested back to back) — no LDS staging,
+//   * D leaves each lane with 4 consecutive output channels of one row per 16-channel tile: float4 stores straight from
+//     the accumulators,
+//   * everything that is not an MFMA — the statistics and stores of the PREVIOUS strip (second accumulator set), the
+//     requests of the strip after the next one (into the x registers whose last MFMA has issued), BN + activation of the
+//     next strip's input — is cut into slots of a few instructions placed between the MFMAs of the current strip,
+//   * per-lane BN statistics live in lane-private LDS rows (read-update-write; LDS float atomics measured 3x the
+//     kernel, 64 more registers do not exist), summed across lanes / replicas in fp64 at the end.
+// Measured (tools/check_wreg.py, clocks warm): 128->128 262 us (second generation 308), 128->64 154 (187), 64->128 162
+// (200), 64->64 98 (130); the MFMA stream alone (back-to-back 16x16x4 from one wave) takes 228 us = 78 % of the nominal
+// fp32 rate, and the chip sits at its 1400 W cap at ~2.28 GHz while this kernel runs.
+#include "common.h"
+#include <type_traits>
+
+// build-time diagnostic: -DWREG_ABL=1 no statistics, 2 no stores, 4 no loads
+#ifndef WREG_ABL
+#define WREG_ABL 0
+#endif
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+constexpr int WR_THREADS = 256;
+constexpr int WR_ROWS = 16;
+constexpr int REP = I2P_BN_REPLICAS;
+
+struct WregP {
+    long long rows;              // multiple of 16
+    const float *x; int x_ld;
+    const float *in_coef;        // [3][CIN] mean, scale, beta or nullptr
+    float slope;
+    const float *w;              // [COUT][CIN]
+    float *y; int y_ld;
+    double *sums;                // [REP][2*COUT] or nullptr
+    unsigned *fin_counter; const float *fin_gamma, *fin_beta; float fin_eps; float *fin_coef, *fin_mi;
+};
+
+__device__ __forceinline__ f32x4 ldx(const float *ptr) {
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(ptr));
+}
+__device__ __forceinline__ void sty(float *ptr, const f32x4 &v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4_nt *>(ptr));
+}
+
+template <int CIN, int COUT, bool BN_IN>
+__global__ __launch_bounds__(WR_THREADS, 1) void wreg_fwd_kernel(WregP p) {
+    constexpr int NT = COUT / 16;          // output tiles of 16 channels
+    constexpr int L = CIN / 4;             // MFMA k-steps = channels per k-slot
+    constexpr int NF = L / 4;              // float4 per lane and row
+    constexpr int NTHREADS = WR_THREADS;
+    __shared__ float tab[2 * CIN];         // input BN as z = fma(x, a, b): a = scale, b = beta - mean * scale
+    __shared__ int fin_flag;
+    // per-lane statistics accumulators live in LDS (lane-private 16-byte rows, read-update-write between the MFMAs: 64
+    // registers otherwise; LDS float atomics measured 3x the whole kernel)
+    __shared__ f32x4 st_lds[2 * NT][NTHREADS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    if (BN_IN) {
+        for (int c = tid; c < CIN; c += NTHREADS) {
+            const float a = p.in_coef[CIN + c];
+            tab[c] = a; tab[CIN + c] = p.in_coef[2 * CIN + c] - p.in_coef[c] * a;
+        }
+        __syncthreads();
+    }
+
+    // weights: wr[j][f][e] = W[16j + m][16f + 4q + e]  (A operand: row = lane & 15, k-slot = lane >> 4; k-step 4f+e of
+    // slot q is channel 16f + 4q + e: the same permutation on both operands leaves the product unchanged)
+    f32x4 wr[NT][NF];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wr[j][f] = *reinterpret_cast<const f32x4 *>(p.w + (size_t)(16 * j + m) * CIN + 16 * f + 4 * q);
+
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) st_lds[i][tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const long long nstrips = p.rows / WR_ROWS;
+    const long long stride = (long long)gridDim.x * 4;
+    const long long first = (long long)blockIdx.x * 4 + wave;
+    const int n_mine = first < nstrips ? (int)((nstrips - first + stride - 1) / stride) : 0;
+    if (n_mine > 0) {
+        const size_t x_step = (size_t)stride * WR_ROWS * p.x_ld, y_step = (size_t)stride * WR_ROWS * p.y_ld;
+        const float *xsrc = p.x + ((size_t)first * WR_ROWS + m) * p.x_ld + 4 * q;      // strip being LOADED
+        float *ydst = p.y + ((size_t)first * WR_ROWS + m) * p.y_ld + 4 * q;            // strip being STORED
+        int loaded = 0;                                          // strips of this wave requested so far - 1
+
+        const float *tq = tab + 4 * q;
+        f32x4 ca[2], cb[2], zs;                                  // constants (two groups in flight) / scaled values
+        ca[0] = ca[1] = cb[0] = cb[1] = zs = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto tf_consts = [&](int f) {
+            ca[f & 1] = *reinterpret_cast<const f32x4 *>(tq + 16 * f);
+            cb[f & 1] = *reinterpret_cast<const f32x4 *>(tq + CIN + 16 * f);
+        };
+        // act(z) = max(z, slope * z) for 0 <= slope <= 1 (launcher): three short VALU groups, one per slot
+        auto tf_part = [&](f32x4 &v, int f, int part) {
+            if (part == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], ca[f & 1][e], cb[f & 1][e]);
+            } else if (part == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zs[e] = v[e] * p.slope;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(v[e], zs[e]);
+            }
+        };
+        // statistics rows in flight (LDS read -> update -> write); an LDS read is used 8 slots (~256 cycles) after its
+        // issue — with 2-3 slots the wave sat in s_waitcnt lgkmcnt between two MFMAs (measured: ~2000 cycles per strip)
+        f32x4 r1[2], r2[2];
+        r1[0] = r1[1] = r2[0] = r2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int LAT = NT * L >= 128 ? 8 : 4;
+
+        auto final_epilogue = [&](f32x4 (&prev)[NT]) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                f32x4 a = st_lds[j][tid], b = st_lds[NT + j][tid];
+                a += prev[j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) b[c] = __builtin_fmaf(prev[j][c], prev[j][c], b[c]);
+                st_lds[j][tid] = a; st_lds[NT + j][tid] = b;
+                sty(ydst + 16 * j, prev[j]);
+            }
+        };
+
+        // One strip = NT*L MFMAs issued back to back by the only wave of this SIMD; everything else the wave has to do
+        // is cut into slots of a few instructions and placed BETWEEN them (an 8-pass MFMA leaves 7 free issue slots):
+        //   slots [0, 5 NT)          statistics (lane-private LDS rows, read-update-write) + store of the PREVIOUS strip's
+        //                            accumulators (second accumulator set)
+        //   slot 4 NT (f+1) - 1      the registers of input float4 f have fed their last MFMA: request the same float4 of
+        //                            the strip after the next one into them (two buffers, a whole strip = 3.4 us at
+        //                            128x128 between a request and its first use)
+        //   slots TS(f) .. TS(f)+5   BN + activation of float4 f of the NEXT strip's input (requested one strip ago),
+        //                            constants two slots ahead of their use; TS spreads the eight groups over the strip
+        // sched_barrier(0) after every slot keeps the compiler from regrouping them (it sinks the loads to their first
+        // use and hoists the normalisation to the loads otherwise).
+        constexpr int NMF = NT * L, E_END = 5 * NT + LAT - 3, SP = (NMF - E_END - LAT - 3) / (NF - 1);
+        static_assert(SP >= 3 && 2 * SP >= LAT + 3, "slot plan");      // (constants: two groups in flight)
+        auto strip_block = [&](auto epi_tag, f32x4 (&xc)[NF], f32x4 (&xn)[NF], f32x4 (&acc)[NT], f32x4 (&prev)[NT]) {
+            constexpr bool EPI = decltype(epi_tag)::value;
+            if (loaded + 1 < n_mine) { xsrc += x_step; ++loaded; }   // (past the end: the last strip again, never used)
+#pragma unroll
+            for (int i = 0; i < NMF; ++i) {
+                const int t = i / NT, j = i % NT, f = t >> 2, e = t & 3;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][f][e], xc[f][e], t == 0 ? zero : acc[j], 0, 0, 0);
+                if (i == 4 * NT * (f + 1) - 1 && (f & 1) && !(WREG_ABL & 4)) {   // both halves of a 128-byte line together
+                    xc[f - 1] = ldx(xsrc + 16 * (f - 1)); xc[f] = ldx(xsrc + 16 * f);
+                }
+                if (EPI && i < E_END) {
+                    const int tj = i / 5, part = i % 5;                  // tile whose rows are REQUESTED / stored in this slot
+                    const int uj = (i - LAT) / 5, upart = (i - LAT) % 5; // tile whose rows are UPDATED in this slot
+                    if (!(WREG_ABL & 1)) {
+                        if (tj < NT && part == 0) { r1[tj & 1] = st_lds[tj][tid]; r2[tj & 1] = st_lds[NT + tj][tid]; }
+                        if (i >= LAT && uj < NT && upart == 0) { r1[uj & 1] += prev[uj]; st_lds[uj][tid] = r1[uj & 1]; }
+                        if (i >= LAT && uj < NT && upart == 1) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) r2[uj & 1][c] = __builtin_fmaf(prev[uj][c], prev[uj][c], r2[uj & 1][c]);
+                            st_lds[NT + uj][tid] = r2[uj & 1];
+                        }
+                    }
+                    if (tj < NT && part == 1 && !(WREG_ABL & 2)) sty(ydst + 16 * tj, prev[tj]);
+                }
+                if (EPI && i == E_END) ydst += y_step;
+                if (BN_IN && i >= E_END) {
+#pragma unroll
+                    for (int g = 0; g < NF; ++g) {                   // group g: constants at its base slot, math LAT slots later
+                        const int u = i - (E_END + g * SP);
+                        if (u == 0) tf_consts(g);
+                        if (u >= LAT && u < LAT + 3) tf_part(xn[g], g, u - LAT);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        f32x4 xa[NF], xb[NF], accA[NT], accB[NT];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) xa[f] = ldx(xsrc + 16 * f);
+        if (1 < n_mine) { xsrc += x_step; ++loaded; }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) xb[f] = ldx(xsrc + 16 * f);
+        if (BN_IN) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                tf_consts(f);
+                tf_part(xa[f], f, 0); tf_part(xa[f], f, 1); tf_part(xa[f], f, 2);
+            }
+        }
+        // block k: MFMAs on X[k&1] (and, float4 by float4, the request of strip k+2 into it), normalises X[~k&1]
+        strip_block(std::false_type{}, xa, xb, accA, accB);                      // k = 0
+        int k = 1;
+        for (; k + 1 < n_mine; k += 2) {
+            strip_block(std::true_type{}, xb, xa, accB, accA);
+            strip_block(std::true_type{}, xa, xb, accA, accB);
+        }
+        if (k < n_mine) {
+            strip_block(std::true_type{}, xb, xa, accB, accA);
+            final_epilogue(accB);
+        } else {
+            final_epilogue(accA);
+        }
+    }
+    __syncthreads();
+
+    if (p.sums) {
+        // this lane: channels 16j + 4q + e of its rows; the 16 lanes of a row group (same q) hold the same channels
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double a = (double)st_lds[j][tid][e], b = (double)st_lds[NT + j][tid][e];
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+                if (m == 0) {
+                    double *rep = p.sums + (size_t)((blockIdx.x * 4 + wave) % REP) * 2 * COUT;
+                    atomicAdd(rep + 16 * j + 4 * q + e, a); atomicAdd(rep + COUT + 16 * j + 4 * q + e, b);
+                }
+            }
+    }
+    if (p.fin_counter) {
+        // (as mlp.hip finalize_by_last_block: only device-scope atomics are published, an acknowledged-atomics wait is enough)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = atomicAdd(p.fin_counter, 1u);
+            fin_flag = (t == gridDim.x - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!fin_flag) return;
+        for (int ch = tid; ch < COUT; ch += NTHREADS) {
+            double sa = 0.0, qa = 0.0;
+            for (int r = 0; r < REP; ++r) {
+                sa += __hip_atomic_load(p.sums + (size_t)r * 2 * COUT + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                qa += __hip_atomic_load(p.sums + (size_t)r * 2 * COUT + COUT + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const double mean = sa / (double)p.rows;
+            double var = qa / (double)p.rows - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const float invstd = rsqrtf((float)var + p.fin_eps);
+            p.fin_coef[ch] = (float)mean; p.fin_coef[COUT + ch] = invstd * p.fin_gamma[ch]; p.fin_coef[2 * COUT + ch] = p.fin_beta[ch];
+            p.fin_mi[ch] = (float)mean; p.fin_mi[COUT + ch] = invstd;
+        }
+        if (tid == 0) *p.fin_counter = 0u;
+    }
+}
+
+template <int CIN, int COUT>
+int launch_wreg(const WregP &p, hipStream_t st) {
+    const long long nstrips = p.rows / WR_ROWS;
+    long long grid = (nstrips + 3) / 4;
+    if (grid > 256) grid = 256;
+    if (p.in_coef) hipLaunchKernelGGL((wreg_fwd_kernel<CIN, COUT, true>), dim3((unsigned)grid), dim3(WR_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((wreg_fwd_kernel<CIN, COUT, false>), dim3((unsigned)grid), dim3(WR_THREADS), 0, st, p);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+bool i2p_wreg_fwd_ok(long long rows, int cin, int cout) {
+    static const char *e = getenv("I2P_NO_WREG");
+    if (e && e[0] == '1') return false;
+    return rows >= 65536 && (rows % WR_ROWS) == 0 && (cin == 64 || cin == 128) && (cout == 64 || cout == 128);
+}
+
+int i2p_wreg_fwd(long long rows, int cin, int cout, const float *x, int x_ld, const float *in_coef, float slope, const float *w,
+                 float *y, int y_ld, double *sums, unsigned *fin_counter, const float *fin_gamma, const float *fin_beta,
+                 float fin_eps, float *fin_coef, float *fin_mi, void *stream) {
+    if (!i2p_wreg_fwd_ok(rows, cin, cout) || (x_ld & 3) || (y_ld & 3) || !(slope >= 0.f && slope <= 1.f)) return I2P_ERR_BAD_ARG;
+    WregP p;
+    p.rows = rows; p.x = x; p.x_ld = x_ld; p.in_coef = in_coef; p.slope = slope; p.w = w; p.y = y; p.y_ld = y_ld; p.sums = sums;
+    p.fin_counter = fin_counter; p.fin_gamma = fin_gamma; p.fin_beta = fin_beta; p.fin_eps = fin_eps; p.fin_coef = fin_coef; p.fin_mi = fin_mi;
+    hipStream_t st = (hipStream_t)stream;
+    if (cin == 128 && cout == 128) return launch_wreg<128, 128>(p, st);
+    if (cin == 128 && cout == 64) return launch_wreg<128, 64>(p, st);
+    if (cin == 64 && cout == 128) return launch_wreg<64, 128>(p, st);
+    return launch_wreg<64, 64>(p, st);
+}
