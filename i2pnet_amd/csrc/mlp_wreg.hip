@@ -117,8 +117,8 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_fwd_kernel(WregP p) {
                 for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(v[e], zs[e]);
             }
         };
-        // statistics rows in flight (LDS read -> update -> write); an LDS read is used 8 slots (~256 cycles) after its
-        // issue — with 2-3 slots the wave sat in s_waitcnt lgkmcnt between two MFMAs (measured: ~2000 cycles per strip)
+        // statistics rows in flight (LDS read -> update -> write); an LDS read is used LAT slots (~256 cycles) after its
+        // issue, so no s_waitcnt lgkmcnt sits between two MFMAs
         f32x4 r1[2], r2[2];
         r1[0] = r1[1] = r2[0] = r2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         constexpr int LAT = NT * L >= 128 ? 8 : 4;

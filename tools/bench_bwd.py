@@ -19,5 +19,5 @@ for cin, cout in [(128, 128), (128, 64), (64, 64)]:
     out_coef, out_mi = hip.bn_finalize(rows, sy, go, bo, 1e-5)
     gz = torch.randn(rows, cout, device=dev)
     ods = torch.zeros(ops.BN_REPLICAS * 2 * cout, dtype=torch.float64, device=dev)
-    t = timeit(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), iters=10)
+    t = timeit(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), iters=40, warm=60)
     print(f"lin_bwd {cin}->{cout}: {t:.1f} us  {4.0 * rows * cin * cout / t / 1e6:.1f} TFLOP/s")
