@@ -42,20 +42,21 @@ def _event_time_us(launch, iters):
 
 
 def kernel_rooflines(B, device):
-    """Live timings (events on the launch stream) of the hand-written kernels that dominate the step.
+    """Live timings (events on the launch stream) of the hand-written kernels that dominate the fp32 step.
 
-    * `roofline`: lin_fwd2_kernel<8,false,false> — one fused 128->128 layer of the all-pixel cost volume on
-      [B*228*468, 128]: previous BN + LeakyReLU applied on load, GEMM on v_mfma_f32_16x16x4_f32, fp64 BN
-      statistics of the output in the epilogue.  The same template instantiated with DGRAD / PAIR is the
-      largest consumer of the step (profiles/r01_f_steady_kernel_stats.csv).  MFMA-bound:
-      2*rows*128*128 flop (SURVEY.md §8d counts the same contraction) against 157.3 TFLOP/s = 178 us;
-      the HBM floor (read x, write y: rows*128*4*2 B at 8 TB/s) is 109 us.
-      `traffic` = HBM bytes per launch from the PMC passes of tools/pmc_traffic.sh
-      (profiles/r01_pmc_*.txt): 2*FETCH_SIZE + WRITE_SIZE KiB with the gfx950 halving of FETCH_SIZE
-      calibrated on bn_stats_v4 / bn_act_fwd_v4 over the same tensor (MI355X_MICROARCH.md, HBM section).
-    * other_kernels: backward of the same layer (dgrad on the forward template + double-buffered wgrad +
-      partial reduction), the factored first cost-volume layer (product formed on load), and level-1
-      fused_conv_select_k (HBM-bound on 4.64 MB/sample).
+    * `roofline`: the DGRAD of one fused 128->128 layer of the all-pixel cost volume on [B*228*468, 128] —
+      wreg_dgrad_kernel<128,128> (weights stationary in registers), the layer-dgrad family being the largest single
+      consumer of the step (profiles/r02_*_steady_kernel_stats.csv).  It reads gz, the layer's pre-BN output y (BN backward of the layer behind is formed on
+      load) and the pre-BN input x (activation derivative + BN-backward statistics in the store phase) and writes
+      dL/dz_in: 4 * rows*128*4 B (SURVEY.md §8d's per-layer tensor, four times) against 2*rows*128*128 flop, i.e.
+      an HBM floor of 218 us at 8 TB/s above the MFMA floor of 178 us at 157.3 TFLOP/s: HBM-bound.
+      `traffic` = PMC bytes per launch (tools/pmc_traffic.sh, profiles/r02_pmc_FETCH_SIZE.txt / WRITE_SIZE.txt:
+      2*FETCH_SIZE + WRITE_SIZE KiB, the gfx950 halving of FETCH_SIZE calibrated in the same run on bn_stats_v4).
+      The launch is timed as (dgrad + wgrad + reduction) - (wgrad + reduction): the C ABI has one backward entry;
+      the rocprofv3 summary under profiles/ has the kernel's own duration.
+    * other_kernels: the forward of the same layer (wreg_fwd_kernel: weights stationary in registers, MFMA-bound),
+      its wgrad, the factored first cost-volume layer (product formed on load), level-1 fused_conv_select_k
+      (HBM-bound on 4.64 MB/sample) and the fused level-1 grouping on the three input densities.
     """
     from i2pnet_amd import _lib, ops, projectpn as P, synth
     hip = ops.hip_backend()
@@ -67,37 +68,50 @@ def kernel_rooflines(B, device):
     gam = torch.ones(C, device=device); bet = torch.zeros(C, device=device)
     sx = hip.bn_stats(x)
     in_coef, in_mi = hip.bn_finalize(rows, sx, gam, bet, 1e-5)
-    # --- the roofline kernel: exactly one launch per call, buffers preallocated ---------------------------
     y = torch.empty(rows, C, device=device)
     sy = torch.zeros(ops.BN_REPLICAS * 2 * C, dtype=torch.float64, device=device)
     st = torch.cuda.current_stream().cuda_stream
+    scale = rows / (8 * N * M)                                   # PMC passes were taken at B=8
+    kib = 1024.0
+    # --- forward: exactly one launch per call, buffers preallocated -------------------------------------------
+    _event_time_us(lambda: _lib.call("i2p_lin_fwd", rows, C, C, x.data_ptr(), in_coef.data_ptr(), 0.1, w.data_ptr(),
+                                     y.data_ptr(), sy.data_ptr(), stream=st), 150)     # (clocks ramp for ~50 ms after idle)
     t_fwd = _event_time_us(lambda: _lib.call("i2p_lin_fwd", rows, C, C, x.data_ptr(), in_coef.data_ptr(), 0.1, w.data_ptr(),
-                                             y.data_ptr(), sy.data_ptr(), stream=st), 20)
+                                             y.data_ptr(), sy.data_ptr(), stream=st), 25)
     flop_fwd = 2.0 * rows * C * C
-    alg_bytes = rows * C * 4 * 2 + C * C * 4
-    # PMC passes (profiles/r01_pmc_FETCH_SIZE.txt, r01_pmc_WRITE_SIZE.txt) at B=8: FETCH_SIZE 213830.7 KiB (x2 on
-    # gfx950) + WRITE_SIZE 443200.0 KiB per launch; scaled by rows for other batch sizes
-    traffic = (2 * 213830.7 + 443200.0) * 1024.0 * rows / (8 * N * M)
-    fwd = {"kernel": "lin_fwd2_kernel<8,false,false> (cost-volume 128->128 layer forward: BN+act on load, MFMA GEMM, "
-                     "fp64 BN statistics in the epilogue)",
+    fwd_bytes = rows * C * 4 * 2 + C * C * 4
+    fwd = {"kernel": "wreg_fwd_kernel<128,128,true> (cost-volume 128->128 layer forward: weights stationary in registers, BN+act "
+                     "between the MFMAs, fp64-reduced BN statistics)",
            "bound": "mfma", "achieved": round(flop_fwd / t_fwd / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": round(flop_fwd / t_fwd / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": round(traffic),
-           "avg_kernel_us": round(t_fwd, 1), "flop_per_launch": flop_fwd, "hbm_bytes_per_launch_algorithmic": alg_bytes,
-           "hbm_GBps_algorithmic": round(alg_bytes / t_fwd / 1e3, 1)}
-    hip.lin_forward(x, in_coef, 0.1, w)
-    torch.cuda.synchronize()
+           "frac": round(flop_fwd / t_fwd / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "avg_kernel_us": round(t_fwd, 1),
+           "traffic": round((2 * 218199.0 + 465095.8) * kib * scale), "hbm_bytes_per_launch_algorithmic": fwd_bytes,
+           "hbm_GBps_algorithmic": round(fwd_bytes / t_fwd / 1e3, 1),
+           "note": "back-to-back 16x16x4 fp32 MFMAs from one wave per SIMD alone take 228 us on this shape (123 TFLOP/s); the "
+                   "chip runs this kernel at its 1400 W cap"}
     sy.zero_()
     _lib.call("i2p_lin_fwd", rows, C, C, x.data_ptr(), in_coef.data_ptr(), 0.1, w.data_ptr(), y.data_ptr(), sy.data_ptr(),
               stream=st)
     out_coef, out_mi = hip.bn_finalize(rows, sy, gam, bet, 1e-5)
     gz = rnd(rows, C)
     ods = torch.zeros(ops.BN_REPLICAS * 2 * C, dtype=torch.float64, device=device)
-    t_bwd = _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), 10)
-    flop_bwd = 2 * 2.0 * rows * C * C
-    bwd = {"kernel": "lin_fwd2_kernel<8,false,true> + lin_wgrad_kernel<4,4,true> + reduce_partials (backward of the same layer)",
-           "bound": "mfma", "achieved": round(flop_bwd / t_bwd / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": round(flop_bwd / t_bwd / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "avg_us": round(t_bwd, 1),
-           "flop_per_call": flop_bwd}
+    t_bwd = _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), 20)
+    t_wg = _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w, need_gx=False), 20)
+    t_dg = t_bwd - t_wg
+    dg_bytes = rows * C * 4 * 4 + C * C * 4
+    dg_flop = 2.0 * rows * C * C
+    dgrad = {"kernel": "wreg_dgrad_kernel<128,128> (cost-volume 128->128 layer dgrad: weights stationary in registers, BN backward of the "
+                       "layer behind formed between the MFMAs, activation derivative + BN-backward statistics in the store phase)",
+             "bound": "hbm", "achieved": round(dg_bytes / t_dg / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(dg_bytes / t_dg / 1e3 / HBM_PEAK_GBS, 4), "traffic": round((2 * 642460.6 + 453703.1) * kib * scale),
+             "avg_kernel_us": round(t_dg, 1), "bytes_per_launch_algorithmic": dg_bytes,
+             "mfma_TFLOPs": round(dg_flop / t_dg / 1e6, 1), "mfma_frac": round(dg_flop / t_dg / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
+             "timed_as": "lin_bwd (dgrad + wgrad + reduction) minus lin_bwd without dgrad, events on the launch stream"}
+    wg_bytes = rows * C * 4 * 3
+    wg = {"kernel": "lin_wgrad_kernel<4,4,true> + reduce_partials (wgrad of the same layer: reads gz, y, x)", "bound": "mfma",
+          "achieved": round(dg_flop / t_wg / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+          "frac": round(dg_flop / t_wg / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "avg_us": round(t_wg, 1),
+          "hbm_GBps_algorithmic": round(wg_bytes / t_wg / 1e3, 1)}
+    bwd = wg
     del x, y, gz
     # --- pair-mode forward (first cost-volume layer) -----------------------------------------------------
     f = rnd(B, N, C); gk = rnd(B, M, C); bn = rnd(B, N, C); bk = rnd(B, M, C)
@@ -152,8 +166,8 @@ def kernel_rooflines(B, device):
     group = {"kernel": "sa_l1_kernel<9> (level-1 selection + gather + feature build in one launch; unfused = fused_conv_select_k + 2 row "
                        "gathers + subtract + norm + cat, host-timed eager launches)", "bound": "hbm (in practice L2 / LDS / issue)",
              "bytes_per_launch": B * (2 * 64 * 1800 * 12 + 3600 * 32 * 48), "cases": grp}
-    fwd["other_kernels"] = [bwd, pf, selk, group]
-    return fwd
+    dgrad["other_kernels"] = [fwd, bwd, pf, selk, group]
+    return dgrad
 
 
 def kernel_rooflines_bf16(B, device):

@@ -1931,7 +1931,12 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
                                    out_mi, g_coef);
         }
         if (gen2) {
-            if (gz_in) {
+            if (gz_in && !two && out_coef && p.slope_out == 1.f && in_coef && i2p_wreg_dgrad_ok(rows, cout, cin)) {
+                // wide layer on many rows, plain BN on both sides: weights stationary in registers (csrc/mlp_wreg.hip)
+                const int rc = i2p_wreg_dgrad(rows, cout, cin, gz, y, out_dsums, out_coef, out_mi, rows, w, gz_in, x, in_coef, in_mi,
+                                              slope_in, in_dsums, stream);
+                if (rc) return rc;
+            } else if (gz_in) {
                 LinFwdParams q;
                 q.rows = rows; q.cin = cout; q.cout = cin; q.cin_p = cout; q.cout_p = cin;
                 q.ldk = (cout > cin ? cout : cin) + ((cout & 15) == 0 ? 4 : 2);      // +4: 16-byte rows for the wide-K fragments

@@ -171,7 +171,9 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_fwd_kernel(WregP p) {
                             st_lds[NT + uj][tid] = r2[uj & 1];
                         }
                     }
-                    if (tj < NT && part == 1 && !(WREG_ABL & 2)) sty(ydst + 16 * tj, prev[tj]);
+                    // both 64-byte halves of a row's 128-byte line leave in one slot (PMC WRITE_SIZE: 1.06x the tensor; one
+                    // tile per slot 1.31x; without the streaming hint 1.02x at the same speed, but y then evicts L2 contents)
+                    if (tj < NT && (tj & 1) && part == 1 && !(WREG_ABL & 2)) { sty(ydst + 16 * (tj - 1), prev[tj - 1]); sty(ydst + 16 * tj, prev[tj]); }
                 }
                 if (EPI && i == E_END) ydst += y_step;
                 if (BN_IN && i >= E_END) {
@@ -266,6 +268,243 @@ int launch_wreg(const WregP &p, hipStream_t st) {
     I2P_RETURN_LAUNCH_STATUS();
 }
 
+
+// =====================================================================================================================
+// DGRAD of the same layers on the same machinery: dL/dz_in = act_in'(z_in) .* (g^y . W), g^y = BN-backward(gz, y) of the
+// layer BEHIND formed on load, activation derivative of the layer IN FRONT + its BN-backward statistics in the store
+// phase (mlp.hip lin_fwd2_kernel<.., DGRAD> is the general version: two destinations, added gradients, any width).
+// HBM-bound (4 tensors of rows*C or rows*K floats against 2*rows*K*C flop).  Per lane and strip: gz and y as B-operand
+// float4s (ONE register set each: a float4 is re-requested for the next strip right after its last use and normalised
+// just before its first MFMA, ~7/8 of a strip later), x of the layer in front as 4-channel rows in the accumulator
+// layout, requested a strip ahead.  K = channels of gz / y, C = channels of the result.
+//   g^y = sc * (gz - m1 - (y - mu) * is * m2) = fma(sc, gz, fma(y, Bc, Ac)),  Bc = -sc * is * m2,  Ac = -sc * m1 - Bc * mu
+//   z_in = fma(x, e_sc, e_zb);  xhat_in = fma(x, e_is, e_nm)      (e_zb = beta - mean * e_sc, e_nm = -mean * e_is)
+// =====================================================================================================================
+struct WregDgradP {
+    long long rows;              // multiple of 16
+    const float *gz, *y2;        // [rows, K]
+    const double *g_dsums;       // [REP][2*K] sums {gz, gz * xhat} of the BN behind
+    const float *g_oc, *g_omi;   // its coef [3][K] (mean, scale, beta) and mean_invstd [2][K]
+    long long g_rows;
+    const float *w;              // [K][C]
+    float *gz_in;                // [rows, C]
+    const float *ex;             // [rows, C] pre-BN input of the layer
+    const float *e_coef, *e_mi;  // [3][C], [2][C] of the BN in front
+    float e_slope;
+    double *sums;                // [REP][2*C] {sum g, sum g * xhat_in}
+};
+
+template <int K, int C>
+__global__ __launch_bounds__(WR_THREADS, 1) void wreg_dgrad_kernel(WregDgradP p) {
+    constexpr int NT = C / 16;             // output tiles of 16 channels
+    constexpr int L = K / 4;               // MFMA k-steps
+    constexpr int NF = L / 4;              // float4 of gz (and of y) per lane and row
+    constexpr int G = 4 * NT;              // MFMAs per input float4
+    constexpr int NMF = NT * L;
+    __shared__ float gt[3 * K];            // sc, Ac, Bc
+    __shared__ float et[4 * C];            // e_sc, e_zb, e_is, e_nm
+    __shared__ f32x4 st_lds[2 * NT][WR_THREADS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    for (int ch = tid; ch < K; ch += WR_THREADS) {
+        double sd = 0.0, sx = 0.0;
+#pragma unroll 8
+        for (int rp = 0; rp < REP; ++rp) { sd += p.g_dsums[(size_t)rp * 2 * K + ch]; sx += p.g_dsums[(size_t)rp * 2 * K + K + ch]; }
+        const float m1 = (float)(sd / (double)p.g_rows), m2 = (float)(sx / (double)p.g_rows);
+        const float sc = p.g_oc[K + ch], mu = p.g_omi[ch], is = p.g_omi[K + ch];
+        const float bc = -sc * is * m2;
+        gt[ch] = sc; gt[K + ch] = -sc * m1 - bc * mu; gt[2 * K + ch] = bc;
+    }
+    for (int ch = tid; ch < C; ch += WR_THREADS) {
+        const float mean = p.e_coef[ch], sc = p.e_coef[C + ch], is = p.e_mi[C + ch];
+        et[ch] = sc; et[C + ch] = p.e_coef[2 * C + ch] - mean * sc; et[2 * C + ch] = is; et[3 * C + ch] = -mean * is;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) st_lds[i][tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    // weights: wr[j][f][e] = W[k = 16f + 4q + e][c = 16j + m]
+    f32x4 wr[NT][NF];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wr[j][f][e] = p.w[(size_t)(16 * f + 4 * q + e) * C + 16 * j + m];
+
+    const long long nstrips = p.rows / WR_ROWS;
+    const long long stride = (long long)gridDim.x * 4;
+    const long long first = (long long)blockIdx.x * 4 + wave;
+    const int n_mine = first < nstrips ? (int)((nstrips - first + stride - 1) / stride) : 0;
+    if (n_mine > 0) {
+        const size_t k_step = (size_t)stride * WR_ROWS * K, c_step = (size_t)stride * WR_ROWS * C;
+        // element offset of this lane's float4 #0 in the [rows, K] tensors: the strip being REQUESTED (k+1, clamped to the last)
+        size_t koff1 = ((size_t)first * WR_ROWS + m) * K + 4 * q;
+        int loaded = 0;
+        auto advance = [&]() { if (loaded + 1 < n_mine) { koff1 += k_step; ++loaded; } };
+        // [rows, C] tensors: strip being computed (its x rows are requested) and strip being stored
+        size_t coff_cur = ((size_t)first * WR_ROWS + m) * C + 4 * q, coff_prev = coff_cur;
+
+        const float *gq = gt + 4 * q, *eq = et + 4 * q;
+        f32x4 tsc, tac, tbc, tu;                                 // constants of the input float4 being normalised
+        tsc = tac = tbc = tu = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 esc, ezb, eis, enm, r1, r2, ez, et_, ev, exh, vkeep; // store-phase constants / statistics rows / temporaries
+        esc = ezb = eis = enm = r1 = r2 = ez = et_ = ev = exh = vkeep = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int LAT = 5;                                   // slots between an LDS read and its use
+        constexpr int PE = 10;                                   // store-phase slots per output tile
+        static_assert(PE * NT <= NMF && LAT + 2 <= G, "slot plan");
+
+        f32x4 x[NF], yb[NF], exr[NT], accA[NT], accB[NT];
+        auto epi_math = [&](const f32x4 &acc, const f32x4 &xr, f32x4 &v, f32x4 &xh) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float z = __builtin_fmaf(xr[c], esc[c], ezb[c]);
+                v[c] = z > 0.f ? acc[c] : acc[c] * p.e_slope;
+                xh[c] = __builtin_fmaf(xr[c], eis[c], enm[c]);
+            }
+        };
+        auto final_epilogue = [&](f32x4 (&prev)[NT]) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                esc = *reinterpret_cast<const f32x4 *>(eq + 16 * j); ezb = *reinterpret_cast<const f32x4 *>(eq + C + 16 * j);
+                eis = *reinterpret_cast<const f32x4 *>(eq + 2 * C + 16 * j); enm = *reinterpret_cast<const f32x4 *>(eq + 3 * C + 16 * j);
+                f32x4 v, xh;
+                epi_math(prev[j], exr[j], v, xh);
+                f32x4 a = st_lds[j][tid], b = st_lds[NT + j][tid];
+                a += v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) b[c] = __builtin_fmaf(v[c], xh[c], b[c]);
+                st_lds[j][tid] = a; st_lds[NT + j][tid] = b;
+                sty(p.gz_in + coff_prev + 16 * j, v);
+            }
+        };
+        auto tf_all = [&](int f) {                               // prologue: g^y of float4 f, not slotted
+            tsc = *reinterpret_cast<const f32x4 *>(gq + 16 * f); tac = *reinterpret_cast<const f32x4 *>(gq + K + 16 * f);
+            tbc = *reinterpret_cast<const f32x4 *>(gq + 2 * K + 16 * f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[f][c] = __builtin_fmaf(tsc[c], x[f][c], __builtin_fmaf(yb[f][c], tbc[c], tac[c]));
+        };
+
+        // One strip = NMF MFMAs back to back; between them, in slots of a few instructions:
+        //   store phase of the PREVIOUS strip, tile j in slots [PE j, PE j + 9]: constants + statistics rows from LDS, LAT slots
+        //     later z / act' / xhat, the store (two tiles = one 128-byte line per row together), the statistics update, and
+        //     the request of the CURRENT strip's x rows of that tile for the next store phase
+        //   input float4 f: g^y formed during the MFMA group in front of its own (f = 0: during the last group, for the
+        //     next strip); gz / y registers are re-requested for the next strip in pairs (one 128-byte line per row: PMC
+        //     FETCH_SIZE 1.28x the tensors with single float4 requests) once both have been consumed
+        auto strip_block = [&](auto epi_tag, f32x4 (&acc)[NT], f32x4 (&prev)[NT]) {
+            constexpr bool EPI = decltype(epi_tag)::value;
+#pragma unroll
+            for (int i = 0; i < NMF; ++i) {
+                const int t = i / NT, j = i % NT, f = t >> 2, e = t & 3;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][f][e], x[f][e], t == 0 ? zero : acc[j], 0, 0, 0);
+                // ---- input side -----------------------------------------------------------------------------------
+                if (i == G * (f + 1) - 1 && (f & 1)) {                                // gz of the next strip, one 128-byte line per row
+                    x[f - 1] = ldx(p.gz + koff1 + 16 * (f - 1)); x[f] = ldx(p.gz + koff1 + 16 * f);
+                }
+                {
+                    const int fn = (f + 1) % NF, u = i - G * f;                       // float4 normalised during this group
+                    if (u == 0) {
+                        tsc = *reinterpret_cast<const f32x4 *>(gq + 16 * fn); tac = *reinterpret_cast<const f32x4 *>(gq + K + 16 * fn);
+                        tbc = *reinterpret_cast<const f32x4 *>(gq + 2 * K + 16 * fn);
+                    }
+                    if (u == LAT) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) tu[c] = __builtin_fmaf(yb[fn][c], tbc[c], tac[c]);
+                    }
+                    if (u == LAT + 1) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) x[fn][c] = __builtin_fmaf(tsc[c], x[fn][c], tu[c]);
+                        // y of the next strip, one 128-byte line per row at a time: float4 0 (consumed in the last group of the
+                        // previous strip) waits for float4 1 (consumed in this strip's first group)
+                        if (fn & 1) { yb[fn - 1] = ldx(p.y2 + koff1 + 16 * (fn - 1)); yb[fn] = ldx(p.y2 + koff1 + 16 * fn); }
+                    }
+                }
+                // ---- store phase of the previous strip --------------------------------------------------------------
+                if (EPI && i < PE * NT) {
+                    const int tj = i / PE, part = i % PE;
+                    if (part == 0) {
+                        esc = *reinterpret_cast<const f32x4 *>(eq + 16 * tj); ezb = *reinterpret_cast<const f32x4 *>(eq + C + 16 * tj);
+                        r1 = st_lds[tj][tid]; r2 = st_lds[NT + tj][tid];
+                    }
+                    if (part == 1) { eis = *reinterpret_cast<const f32x4 *>(eq + 2 * C + 16 * tj); enm = *reinterpret_cast<const f32x4 *>(eq + 3 * C + 16 * tj); }
+                    if (part == LAT) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { ez[c] = __builtin_fmaf(exr[tj][c], esc[c], ezb[c]); et_[c] = prev[tj][c] * p.e_slope; }
+                    }
+                    if (part == LAT + 1) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) ev[c] = ez[c] > 0.f ? prev[tj][c] : et_[c];
+                        if (tj & 1) { sty(p.gz_in + coff_prev + 16 * (tj - 1), vkeep); sty(p.gz_in + coff_prev + 16 * tj, ev); }
+                        else vkeep = ev;
+                    }
+                    if (part == LAT + 2) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) exh[c] = __builtin_fmaf(exr[tj][c], eis[c], enm[c]);
+                        r1 += ev; st_lds[tj][tid] = r1;
+                    }
+                    if (part == LAT + 3) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) r2[c] = __builtin_fmaf(ev[c], exh[c], r2[c]);
+                        st_lds[NT + tj][tid] = r2;
+                        if (tj & 1) { exr[tj - 1] = ldx(p.ex + coff_cur + 16 * (tj - 1)); exr[tj] = ldx(p.ex + coff_cur + 16 * tj); }   // x rows of the strip being computed
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!EPI) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) exr[j] = ldx(p.ex + coff_cur + 16 * j);
+            }
+            coff_prev = coff_cur; coff_cur += c_step;                // (past the end: never dereferenced again)
+            advance();
+        };
+
+        // prologue: strip 0 raw in x / yb, float4 0 normalised
+#pragma unroll
+        for (int f = 0; f < NF; ++f) { x[f] = ldx(p.gz + koff1 + 16 * f); yb[f] = ldx(p.y2 + koff1 + 16 * f); }
+        advance();                                               // koff1 = strip 1 (clamped)
+        tf_all(0);
+        strip_block(std::false_type{}, accA, accB);              // k = 0
+        int k = 1;
+        for (; k + 1 < n_mine; k += 2) {
+            strip_block(std::true_type{}, accB, accA);
+            strip_block(std::true_type{}, accA, accB);
+        }
+        if (k < n_mine) {
+            strip_block(std::true_type{}, accB, accA);
+            final_epilogue(accB);
+        } else {
+            final_epilogue(accA);
+        }
+    }
+    __syncthreads();
+    if (p.sums) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double a = (double)st_lds[j][tid][e], b = (double)st_lds[NT + j][tid][e];
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+                if (m == 0) {
+                    double *rep = p.sums + (size_t)((blockIdx.x * 4 + wave) % REP) * 2 * C;
+                    atomicAdd(rep + 16 * j + 4 * q + e, a); atomicAdd(rep + C + 16 * j + 4 * q + e, b);
+                }
+            }
+    }
+}
+
+template <int K, int C>
+int launch_wreg_dgrad(const WregDgradP &p, hipStream_t st) {
+    const long long nstrips = p.rows / WR_ROWS;
+    long long grid = (nstrips + 3) / 4;
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL((wreg_dgrad_kernel<K, C>), dim3((unsigned)grid), dim3(WR_THREADS), 0, st, p);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
 }  // namespace
 
 bool i2p_wreg_fwd_ok(long long rows, int cin, int cout) {
@@ -286,4 +525,25 @@ int i2p_wreg_fwd(long long rows, int cin, int cout, const float *x, int x_ld, co
     if (cin == 128 && cout == 64) return launch_wreg<128, 64>(p, st);
     if (cin == 64 && cout == 128) return launch_wreg<64, 128>(p, st);
     return launch_wreg<64, 64>(p, st);
+}
+
+bool i2p_wreg_dgrad_ok(long long rows, int k, int c) {
+    static const char *e = getenv("I2P_NO_WREG");
+    if (e && e[0] == '1') return false;
+    return rows >= 65536 && (rows % WR_ROWS) == 0 && (k == 64 || k == 128) && (c == 64 || c == 128);
+}
+
+int i2p_wreg_dgrad(long long rows, int k, int c, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
+                   const float *g_omi, long long g_rows, const float *w, float *gz_in, const float *ex, const float *e_coef,
+                   const float *e_mi, float e_slope, double *sums, void *stream) {
+    if (!i2p_wreg_dgrad_ok(rows, k, c) || !gz || !y2 || !g_dsums || !g_oc || !g_omi || !w || !gz_in || !ex || !e_coef || !e_mi)
+        return I2P_ERR_BAD_ARG;
+    WregDgradP p;
+    p.rows = rows; p.gz = gz; p.y2 = y2; p.g_dsums = g_dsums; p.g_oc = g_oc; p.g_omi = g_omi; p.g_rows = g_rows; p.w = w;
+    p.gz_in = gz_in; p.ex = ex; p.e_coef = e_coef; p.e_mi = e_mi; p.e_slope = e_slope; p.sums = sums;
+    hipStream_t st = (hipStream_t)stream;
+    if (k == 128 && c == 128) return launch_wreg_dgrad<128, 128>(p, st);
+    if (k == 128 && c == 64) return launch_wreg_dgrad<128, 64>(p, st);
+    if (k == 64 && c == 128) return launch_wreg_dgrad<64, 128>(p, st);
+    return launch_wreg_dgrad<64, 64>(p, st);
 }

@@ -8,7 +8,7 @@ for path in sys.argv[1:]:
     agg = defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
         name = re.sub(r"^void ", "", r["Kernel_Name"])[:70]
-        if not any(k in name for k in ("lin_", "bn_", "pair_", "reduce_partials", "rg_", "wgrad", "bwd_stats", "fcsk", "sa_l1")):
+        if not any(k in name for k in ("lin_", "bn_", "pair_", "reduce_partials", "rg_", "wgrad", "bwd_stats", "fcsk", "sa_l1", "wreg")):
             continue
         e = agg[(name, r["Counter_Name"])]
         e[0] += 1; e[1] += float(r["Counter_Value"])

@@ -26,6 +26,8 @@ for _ in range(5):
     yp, sp = hip.pair_lin_forward(f, g, bn, bk, w)
     oc, om = hip.bn_finalize(rows, sy, gam, bet, 1e-5)
     ods = torch.zeros(ops.BN_REPLICAS * 2 * C, dtype=torch.float64, device=dev)
-    hip.lin_backward(y, y, oc, om, ods, x, coef, mi, 0.1, w)
+    gz = torch.randn(rows, C, device=dev)                  # (its own tensor: dgrad reads gz, y and x = 3 x 437 MB)
+    hip.lin_backward(gz, y, oc, om, ods, x, coef, mi, 0.1, w)
+    del gz
 torch.cuda.synchronize()
 print("tensor bytes", rows * C * 4)
