@@ -107,7 +107,7 @@ def kernel_rooflines(B, device):
              "mfma_TFLOPs": round(dg_flop / t_dg / 1e6, 1), "mfma_frac": round(dg_flop / t_dg / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
              "timed_as": "lin_bwd (dgrad + wgrad + reduction) minus lin_bwd without dgrad, events on the launch stream"}
     wg_bytes = rows * C * 4 * 3
-    wg = {"kernel": "lin_wgrad_kernel<4,4,true> + reduce_partials (wgrad of the same layer: reads gz, y, x)", "bound": "mfma",
+    wg = {"kernel": "wreg_wgrad_kernel<128,128> + reduce_partials (wgrad of the same layer: the 128x128 accumulators stationary in registers, gz / y / x rows as MFMA operands straight from global memory)", "bound": "mfma",
           "achieved": round(dg_flop / t_wg / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
           "frac": round(dg_flop / t_wg / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "avg_us": round(t_wg, 1),
           "hbm_GBps_algorithmic": round(wg_bytes / t_wg / 1e3, 1)}

@@ -70,3 +70,7 @@ bool i2p_wreg_dgrad_ok(long long rows, int k, int c);
 int i2p_wreg_dgrad(long long rows, int k, int c, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
                    const float *g_omi, long long g_rows, const float *w, float *gz_in, const float *ex, const float *e_coef,
                    const float *e_mi, float e_slope, double *sums, void *stream);
+bool i2p_wreg_wgrad_ok(long long rows, int cin, int cout);
+int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
+                   const float *g_omi, long long g_rows, float *bn_out, const float *x, const float *in_coef, float slope_in,
+                   float *dw_partial, unsigned grid, void *stream);

@@ -505,6 +505,163 @@ int launch_wreg_dgrad(const WregDgradP &p, hipStream_t st) {
     I2P_RETURN_LAUNCH_STATUS();
 }
 
+
+// =====================================================================================================================
+// WGRAD on the same machinery: dW[o][c] = sum_rows g^y[row][o] * a[row][c], a = act(BN(x)) of the layer in front.
+// The ACCUMULATORS are what stays in registers here: the whole [CO][CI] result of a wave (256 registers at 128x128),
+// rows are the contraction axis: one 16-row strip = 4 k-steps (rows 4t..4t+3, k-slot q = row 4t+q) x (CO/16)(CI/16)
+// tiles.  Tile jo of the A operand holds output channels {NO*i + jo} (i = lane & 15, NO = CO/16), so a lane's A values of
+// a k-step are NO CONTIGUOUS channels of one row of gz / y: float4 loads straight into the operand registers, no LDS,
+// no transposition; same for x (tile jc = channels {NI*n + jc}).  The per-channel constants of a lane never change.
+// g^y and a are formed in place during the previous k-step's MFMAs; a k-step's registers are re-requested for the next
+// strip right after their last MFMA.  The four waves of a block add their results through LDS in a fixed order; the
+// block's partial goes to dw_partial[block] (reduced by the caller's reduce_partials launch, as for lin_wgrad_kernel).
+// =====================================================================================================================
+struct WregWgradP {
+    long long rows;              // multiple of 16
+    const float *gz, *y2;        // [rows, CO]
+    const double *g_dsums; const float *g_oc, *g_omi; long long g_rows;
+    float *bn_out;               // [8][CO]: rows 6, 7 <- dbeta, dgamma of the BN behind (block 0)
+    const float *x;              // [rows, CI]
+    const float *in_coef;        // [3][CI] or nullptr
+    float slope_in;              // 0 <= slope <= 1
+    float *dw_partial;           // [grid][CO*CI]
+};
+
+template <int CO, int CI, bool BN_IN>
+__global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p) {
+    constexpr int NO = CO / 16, NI = CI / 16;      // tiles = channels per lane
+    constexpr int HO = NO / 4, HI = NI / 4;        // float4 per lane, row and tensor
+    constexpr int SM = NO * NI;                    // MFMAs per k-step
+    __shared__ float red[CO * CI];
+    __shared__ float gtab[3 * CO];
+    __shared__ float xtab[2 * CI];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    for (int ch = tid; ch < CO; ch += WR_THREADS) {
+        double sd = 0.0, sx = 0.0;
+#pragma unroll 8
+        for (int rp = 0; rp < REP; ++rp) { sd += p.g_dsums[(size_t)rp * 2 * CO + ch]; sx += p.g_dsums[(size_t)rp * 2 * CO + CO + ch]; }
+        const float m1 = (float)(sd / (double)p.g_rows), m2 = (float)(sx / (double)p.g_rows);
+        const float sc = p.g_oc[CO + ch], mu = p.g_omi[ch], is = p.g_omi[CO + ch];
+        const float bc = -sc * is * m2;
+        gtab[ch] = sc; gtab[CO + ch] = -sc * m1 - bc * mu; gtab[2 * CO + ch] = bc;
+        if (blockIdx.x == 0 && p.bn_out) { p.bn_out[6 * CO + ch] = (float)sd; p.bn_out[7 * CO + ch] = (float)sx; }
+    }
+    for (int ch = tid; ch < CI; ch += WR_THREADS) {
+        float a = 1.f, b = 0.f;
+        if (BN_IN) { a = p.in_coef[CI + ch]; b = p.in_coef[2 * CI + ch] - p.in_coef[ch] * a; }
+        xtab[ch] = a; xtab[CI + ch] = b;
+    }
+    __syncthreads();
+    // this lane's channels: gz / y columns NO*n .. NO*n + NO-1, x columns NI*n .. NI*n + NI-1
+    f32x4 csc[HO], cac[HO], cbc[HO], cxa[HI], cxb[HI];
+#pragma unroll
+    for (int h = 0; h < HO; ++h) {
+        csc[h] = *reinterpret_cast<const f32x4 *>(gtab + NO * n + 4 * h); cac[h] = *reinterpret_cast<const f32x4 *>(gtab + CO + NO * n + 4 * h);
+        cbc[h] = *reinterpret_cast<const f32x4 *>(gtab + 2 * CO + NO * n + 4 * h);
+    }
+#pragma unroll
+    for (int h = 0; h < HI; ++h) { cxa[h] = *reinterpret_cast<const f32x4 *>(xtab + NI * n + 4 * h); cxb[h] = *reinterpret_cast<const f32x4 *>(xtab + CI + NI * n + 4 * h); }
+
+    f32x4 acc[NO][NI];
+#pragma unroll
+    for (int jo = 0; jo < NO; ++jo)
+#pragma unroll
+        for (int jc = 0; jc < NI; ++jc) acc[jo][jc] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const long long nstrips = p.rows / WR_ROWS;
+    const long long stride = (long long)gridDim.x * 4;
+    const long long first = (long long)blockIdx.x * 4 + wave;
+    const int n_mine = first < nstrips ? (int)((nstrips - first + stride - 1) / stride) : 0;
+    if (n_mine > 0) {
+        // element offsets of row q of the strip being REQUESTED (k-step t adds 4t rows)
+        size_t goff = ((size_t)first * WR_ROWS + q) * CO + NO * n, xoff = ((size_t)first * WR_ROWS + q) * CI + NI * n;
+        const size_t g_step = (size_t)stride * WR_ROWS * CO, x_step = (size_t)stride * WR_ROWS * CI;
+        int loaded = 0;
+        f32x4 gv[4][HO], yv[4][HO], xv[4][HI];
+        auto ld_g = [&](int t) {
+#pragma unroll
+            for (int h = 0; h < HO; ++h) gv[t][h] = ldx(p.gz + goff + (size_t)4 * t * CO + 4 * h);
+        };
+        auto ld_y = [&](int t) {
+#pragma unroll
+            for (int h = 0; h < HO; ++h) yv[t][h] = ldx(p.y2 + goff + (size_t)4 * t * CO + 4 * h);
+        };
+        auto ld_x = [&](int t) {
+#pragma unroll
+            for (int h = 0; h < HI; ++h) xv[t][h] = ldx(p.x + xoff + (size_t)4 * t * CI + 4 * h);
+        };
+        auto tf_g = [&](int t, int h) {                          // g^y = fma(sc, gz, fma(y, Bc, Ac))
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gv[t][h][c] = __builtin_fmaf(csc[h][c], gv[t][h][c], __builtin_fmaf(yv[t][h][c], cbc[h][c], cac[h][c]));
+        };
+        auto tf_x = [&](int t, int h) {                          // a = max(z, slope z), z = fma(x, a, b)
+            if (!BN_IN) return;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float z = __builtin_fmaf(xv[t][h][c], cxa[h][c], cxb[h][c]);
+                xv[t][h][c] = __builtin_fmaxf(z, z * p.slope_in);
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { ld_g(t); ld_y(t); ld_x(t); }
+        if (1 < n_mine) { goff += g_step; xoff += x_step; ++loaded; }
+#pragma unroll
+        for (int h = 0; h < HO; ++h) tf_g(0, h);
+#pragma unroll
+        for (int h = 0; h < HI; ++h) tf_x(0, h);
+        ld_y(0);                                                 // y of k-step 0 of the next strip
+        for (int k = 0; k < n_mine; ++k) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int tn = (t + 1) & 3;                      // k-step whose operands are formed during this one
+#pragma unroll
+                for (int u = 0; u < SM; ++u) {
+                    const int jo = u / NI, jc = u % NI;
+                    acc[jo][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[t][jo >> 2][jo & 3], xv[t][jc >> 2][jc & 3], acc[jo][jc], 0, 0, 0);
+                    if (u >= 1 && u < 1 + HO) tf_g(tn, u - 1);
+                    if (u >= 1 + HO && u < 1 + HO + HI) tf_x(tn, u - 1 - HO);
+                    // y of step tn is consumed: request it for the strip after (t = 3: tn = 0 belongs to the NEXT strip, whose
+                    // successor is requested after the offsets advance below)
+                    if (u == 1 + HO + HI && t < 3) ld_y(tn);
+                    if (u == SM - 1) { ld_g(t); ld_x(t); }          // this step's registers: same step of the next strip
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (loaded + 1 < n_mine) { goff += g_step; xoff += x_step; ++loaded; }
+            ld_y(0);
+        }
+    }
+    // ---- the four waves add their results through LDS in a fixed order, then the block's partial leaves coalesced ----
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int jo = 0; jo < NO; ++jo)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int h = 0; h < HI; ++h) {
+                        float *dst = red + (size_t)(NO * (4 * q + e) + jo) * CI + NI * n + 4 * h;
+                        f32x4 v = {acc[jo][4 * h][e], acc[jo][4 * h + 1][e], acc[jo][4 * h + 2][e], acc[jo][4 * h + 3][e]};
+                        if (w > 0) v += *reinterpret_cast<const f32x4 *>(dst);
+                        *reinterpret_cast<f32x4 *>(dst) = v;
+                    }
+        }
+        __syncthreads();
+    }
+    float *out = p.dw_partial + (size_t)blockIdx.x * CO * CI;
+    for (int i = tid; i < CO * CI / 4; i += WR_THREADS)
+        *reinterpret_cast<f32x4 *>(out + 4 * i) = *reinterpret_cast<const f32x4 *>(red + 4 * i);
+}
+
+template <int CO, int CI>
+int launch_wreg_wgrad(const WregWgradP &p, unsigned grid, hipStream_t st) {
+    if (p.in_coef) hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, true>), dim3(grid), dim3(WR_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, false>), dim3(grid), dim3(WR_THREADS), 0, st, p);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
 }  // namespace
 
 bool i2p_wreg_fwd_ok(long long rows, int cin, int cout) {
@@ -546,4 +703,28 @@ int i2p_wreg_dgrad(long long rows, int k, int c, const float *gz, const float *y
     if (k == 128 && c == 64) return launch_wreg_dgrad<128, 64>(p, st);
     if (k == 64 && c == 128) return launch_wreg_dgrad<64, 128>(p, st);
     return launch_wreg_dgrad<64, 64>(p, st);
+}
+
+// wgrad: writes dw_partial[grid][cout*cin] (grid = the caller's i2p_lin_bwd_grid(rows), 256 for these row counts) and
+// rows 6, 7 of bn_out; the caller reduces the partials.
+bool i2p_wreg_wgrad_ok(long long rows, int cin, int cout) {
+    static const char *e = getenv("I2P_NO_WREG");
+    if (e && e[0] == '1') return false;
+    return rows >= 65536 && (rows % WR_ROWS) == 0 && (cin == 64 || cin == 128) && (cout == 64 || cout == 128);
+}
+
+int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
+                   const float *g_omi, long long g_rows, float *bn_out, const float *x, const float *in_coef, float slope_in,
+                   float *dw_partial, unsigned grid, void *stream) {
+    if (!i2p_wreg_wgrad_ok(rows, cin, cout) || !gz || !y2 || !g_dsums || !g_oc || !g_omi || !x || !dw_partial || grid == 0 ||
+        !(slope_in >= 0.f && slope_in <= 1.f))
+        return I2P_ERR_BAD_ARG;
+    WregWgradP p;
+    p.rows = rows; p.gz = gz; p.y2 = y2; p.g_dsums = g_dsums; p.g_oc = g_oc; p.g_omi = g_omi; p.g_rows = g_rows; p.bn_out = bn_out;
+    p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.dw_partial = dw_partial;
+    hipStream_t st = (hipStream_t)stream;
+    if (cout == 128 && cin == 128) return launch_wreg_wgrad<128, 128>(p, grid, st);
+    if (cout == 128 && cin == 64) return launch_wreg_wgrad<128, 64>(p, grid, st);
+    if (cout == 64 && cin == 128) return launch_wreg_wgrad<64, 128>(p, grid, st);
+    return launch_wreg_wgrad<64, 64>(p, grid, st);
 }
