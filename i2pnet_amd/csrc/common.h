@@ -73,4 +73,4 @@ int i2p_wreg_dgrad(long long rows, int k, int c, const float *gz, const float *y
 bool i2p_wreg_wgrad_ok(long long rows, int cin, int cout);
 int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
                    const float *g_omi, long long g_rows, float *bn_out, const float *x, const float *in_coef, float slope_in,
-                   float *dw_partial, unsigned grid, void *stream);
+                   const float *xb, const float *in_coef_b, float slope_b, int split, float *dw_partial, unsigned grid, void *stream);

@@ -1952,11 +1952,13 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
                 const int rc = dispatch_fwd2<false, true>(q, st);
                 if (rc) return rc;
             }
-            if (!two && out_coef && p.slope_out == 1.f && slope_in >= 0.f && slope_in <= 1.f && grid == 256 &&
+            const bool two_ok = !two || (in_coef && two->in_coef_b && two->split_c % (cin / 16) == 0 && two->slope_b >= 0.f && two->slope_b <= 1.f);
+            if (two_ok && out_coef && p.slope_out == 1.f && slope_in >= 0.f && slope_in <= 1.f && grid == 256 &&
                 i2p_wreg_wgrad_ok(rows, cin, cout)) {
                 // wide layer on many rows: the [cout][cin] accumulators stationary in registers (csrc/mlp_wreg.hip)
                 const int rc = i2p_wreg_wgrad(rows, cin, cout, gz, y, out_dsums, out_coef, out_mi, rows, g_coef, x, in_coef, slope_in,
-                                              dw_partial, grid, stream);
+                                              two ? two->xb : nullptr, two ? two->in_coef_b : nullptr, two ? two->slope_b : 1.f,
+                                              two ? two->split_c : 0, dw_partial, grid, stream);
                 if (rc) return rc;
                 const int n = cout * cin;
                 hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);

@@ -525,6 +525,9 @@ struct WregWgradP {
     const float *x;              // [rows, CI]
     const float *in_coef;        // [3][CI] or nullptr
     float slope_in;              // 0 <= slope <= 1
+    // two-source input (nullptr: one): columns [0, split) of the layer input come from x [rows, split] with in_coef
+    // [3][split], columns [split, CI) from xb [rows, CI - split] with in_coef_b; split is a multiple of CI/16
+    const float *xb, *in_coef_b; float slope_b; int split;
     float *dw_partial;           // [grid][CO*CI]
 };
 
@@ -535,7 +538,6 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
     constexpr int SM = NO * NI;                    // MFMAs per k-step
     __shared__ float red[CO * CI];
     __shared__ float gtab[3 * CO];
-    __shared__ float xtab[2 * CI];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
     for (int ch = tid; ch < CO; ch += WR_THREADS) {
@@ -548,11 +550,6 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
         gtab[ch] = sc; gtab[CO + ch] = -sc * m1 - bc * mu; gtab[2 * CO + ch] = bc;
         if (blockIdx.x == 0 && p.bn_out) { p.bn_out[6 * CO + ch] = (float)sd; p.bn_out[7 * CO + ch] = (float)sx; }
     }
-    for (int ch = tid; ch < CI; ch += WR_THREADS) {
-        float a = 1.f, b = 0.f;
-        if (BN_IN) { a = p.in_coef[CI + ch]; b = p.in_coef[2 * CI + ch] - p.in_coef[ch] * a; }
-        xtab[ch] = a; xtab[CI + ch] = b;
-    }
     __syncthreads();
     // this lane's channels: gz / y columns NO*n .. NO*n + NO-1, x columns NI*n .. NI*n + NI-1
     f32x4 csc[HO], cac[HO], cbc[HO], cxa[HI], cxb[HI];
@@ -561,8 +558,21 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
         csc[h] = *reinterpret_cast<const f32x4 *>(gtab + NO * n + 4 * h); cac[h] = *reinterpret_cast<const f32x4 *>(gtab + CO + NO * n + 4 * h);
         cbc[h] = *reinterpret_cast<const f32x4 *>(gtab + 2 * CO + NO * n + 4 * h);
     }
+    // source of this lane's x columns (its NI channels never straddle the split)
+    const bool second = p.xb && NI * n >= p.split;
+    const float *xsrc = second ? p.xb : p.x;
+    const int x_ld = p.xb ? (second ? CI - p.split : p.split) : CI, x_col = second ? NI * n - p.split : NI * n;
+    const float *xcoef = second ? p.in_coef_b : p.in_coef;
+    const float x_slope = second ? p.slope_b : p.slope_in;
 #pragma unroll
-    for (int h = 0; h < HI; ++h) { cxa[h] = *reinterpret_cast<const f32x4 *>(xtab + NI * n + 4 * h); cxb[h] = *reinterpret_cast<const f32x4 *>(xtab + CI + NI * n + 4 * h); }
+    for (int h = 0; h < HI; ++h) {
+        cxa[h] = f32x4{1.f, 1.f, 1.f, 1.f}; cxb[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (BN_IN) {
+            const f32x4 mu = *reinterpret_cast<const f32x4 *>(xcoef + x_col + 4 * h);
+            cxa[h] = *reinterpret_cast<const f32x4 *>(xcoef + x_ld + x_col + 4 * h);
+            cxb[h] = *reinterpret_cast<const f32x4 *>(xcoef + 2 * x_ld + x_col + 4 * h) - mu * cxa[h];
+        }
+    }
 
     f32x4 acc[NO][NI];
 #pragma unroll
@@ -576,8 +586,8 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
     const int n_mine = first < nstrips ? (int)((nstrips - first + stride - 1) / stride) : 0;
     if (n_mine > 0) {
         // element offsets of row q of the strip being REQUESTED (k-step t adds 4t rows)
-        size_t goff = ((size_t)first * WR_ROWS + q) * CO + NO * n, xoff = ((size_t)first * WR_ROWS + q) * CI + NI * n;
-        const size_t g_step = (size_t)stride * WR_ROWS * CO, x_step = (size_t)stride * WR_ROWS * CI;
+        size_t goff = ((size_t)first * WR_ROWS + q) * CO + NO * n, xoff = ((size_t)first * WR_ROWS + q) * x_ld + x_col;
+        const size_t g_step = (size_t)stride * WR_ROWS * CO, x_step = (size_t)stride * WR_ROWS * x_ld;
         int loaded = 0;
         f32x4 gv[4][HO], yv[4][HO], xv[4][HI];
         auto ld_g = [&](int t) {
@@ -590,7 +600,7 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
         };
         auto ld_x = [&](int t) {
 #pragma unroll
-            for (int h = 0; h < HI; ++h) xv[t][h] = ldx(p.x + xoff + (size_t)4 * t * CI + 4 * h);
+            for (int h = 0; h < HI; ++h) xv[t][h] = ldx(xsrc + xoff + (size_t)4 * t * x_ld + 4 * h);
         };
         auto tf_g = [&](int t, int h) {                          // g^y = fma(sc, gz, fma(y, Bc, Ac))
 #pragma unroll
@@ -601,7 +611,7 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float z = __builtin_fmaf(xv[t][h][c], cxa[h][c], cxb[h][c]);
-                xv[t][h][c] = __builtin_fmaxf(z, z * p.slope_in);
+                xv[t][h][c] = __builtin_fmaxf(z, z * x_slope);
             }
         };
 #pragma unroll
@@ -715,13 +725,17 @@ bool i2p_wreg_wgrad_ok(long long rows, int cin, int cout) {
 
 int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
                    const float *g_omi, long long g_rows, float *bn_out, const float *x, const float *in_coef, float slope_in,
-                   float *dw_partial, unsigned grid, void *stream) {
+                   const float *xb, const float *in_coef_b, float slope_b, int split, float *dw_partial, unsigned grid, void *stream) {
     if (!i2p_wreg_wgrad_ok(rows, cin, cout) || !gz || !y2 || !g_dsums || !g_oc || !g_omi || !x || !dw_partial || grid == 0 ||
         !(slope_in >= 0.f && slope_in <= 1.f))
+        return I2P_ERR_BAD_ARG;
+    if (xb && (split <= 0 || split >= cin || split % (cin / 16) != 0 || (split & 3) || !in_coef || !in_coef_b ||
+               !(slope_b >= 0.f && slope_b <= 1.f)))
         return I2P_ERR_BAD_ARG;
     WregWgradP p;
     p.rows = rows; p.gz = gz; p.y2 = y2; p.g_dsums = g_dsums; p.g_oc = g_oc; p.g_omi = g_omi; p.g_rows = g_rows; p.bn_out = bn_out;
     p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.dw_partial = dw_partial;
+    p.xb = xb; p.in_coef_b = in_coef_b; p.slope_b = slope_b; p.split = split;
     hipStream_t st = (hipStream_t)stream;
     if (cout == 128 && cin == 128) return launch_wreg_wgrad<128, 128>(p, grid, st);
     if (cout == 128 && cin == 64) return launch_wreg_wgrad<128, 64>(p, grid, st);

@@ -1,0 +1,114 @@
+"""Weights-/accumulators-in-registers layer kernels (csrc/mlp_wreg.hip: wide layers on >= 65536 rows) against an fp64
+torch evaluation of the fused layer (reference op: PPBackbone_center.py:10-51, 1x1 conv + batch-stat BN + LeakyReLU).
+
+fp32 contract: 1e-4 relative to the tensor's scale (measured ~6e-7).  The activation derivative may legitimately flip
+where |z| is at rounding level (z is re-evaluated from x in fp32): such elements are counted, not compared."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROWS = 65536 + 16 * 3
+R = 32
+
+
+def _bn(be, x, seed):
+    g = torch.Generator().manual_seed(seed)
+    c = x.shape[1]
+    gam = (torch.rand(c, generator=g) + 0.5).to(DEV); bet = (torch.randn(c, generator=g) * 0.1).to(DEV)
+    return be.bn_finalize(x.shape[0], be.bn_stats(x), gam, bet, 1e-5)
+
+
+def _act(z, slope):
+    return torch.where(z > 0, z, z * slope)
+
+
+def _z(x, coef, c):
+    cf = coef.view(-1).double()
+    return (x.double() - cf[:c]) * cf[c:2 * c] + cf[2 * c:]
+
+
+def _rel(got, want):
+    return float((got.double() - want).abs().max() / want.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout", [(128, 128), (128, 64), (64, 128), (64, 64)])
+@pytest.mark.parametrize("bn", [True, False])
+def test_wreg_forward(hip_backend, cin, cout, bn):
+    be = hip_backend
+    g = torch.Generator().manual_seed(cin + cout)
+    x = (torch.randn(ROWS, cin, generator=g) * 1.3 + 0.2).to(DEV); w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(DEV)
+    coef = _bn(be, x, 1)[0] if bn else None
+    y, sums = be.lin_forward(x, coef, 0.1, w)
+    a = _act(_z(x, coef, cin), 0.1) if bn else x.double()
+    ref = a @ w.double().t()
+    assert _rel(y, ref) < 1e-5
+    s = sums.view(R, 2, cout).sum(0)
+    assert _rel(s[0], ref.sum(0)) < 1e-5 * max(1.0, float(ref.abs().sum(0).max() / ref.sum(0).abs().max())) and _rel(s[1], (ref * ref).sum(0)) < 1e-5
+    # the one-launch variant with BN finalisation by the last block
+    gam = torch.ones(cout, device=DEV); bet = torch.zeros(cout, device=DEV)
+    y2, s2, cf2, mi2 = be.lin_forward_fin(x, coef, 0.1, w, gam, bet, 1e-5)
+    cf, mi = be.bn_finalize(ROWS, sums, gam, bet, 1e-5)
+    assert torch.equal(y2, y) and torch.allclose(cf2.view(-1), cf.view(-1), rtol=1e-5, atol=1e-6) and torch.allclose(mi2.view(-1), mi.view(-1), rtol=1e-5, atol=1e-6)
+
+
+def _backward_reference(gz, y, out_coef, out_mi, cout):
+    om, oc = out_mi.view(-1).double(), out_coef.view(-1).double()
+    xh = (y.double() - om[:cout]) * om[cout:]
+    s1, s2 = gz.double().sum(0), (gz.double() * xh).sum(0)
+    ods = torch.zeros(R, 2, cout, dtype=torch.float64, device=DEV); ods[0, 0] = s1; ods[0, 1] = s2
+    gy = oc[cout:2 * cout] * (gz.double() - s1 / ROWS - xh * (s2 / ROWS))
+    return ods.view(-1), gy, s1, s2
+
+
+def _check_gin(got, gy_w, z, slope):
+    ref = gy_w * torch.where(z > 0, 1.0, slope)
+    dif = (got.double() - ref).abs() / ref.abs().max()
+    flips = dif > 1e-4
+    assert int(flips.sum()) <= 4 and (not flips.any() or float(z[flips].abs().max()) < 1e-5), (int(flips.sum()), float(dif.max()))
+    assert float(dif[~flips].max()) < 1e-5
+    return ref
+
+
+@pytest.mark.parametrize("cin,cout", [(128, 128), (128, 64), (64, 128), (64, 64)])
+def test_wreg_backward(hip_backend, cin, cout):
+    be = hip_backend
+    g = torch.Generator().manual_seed(7 * cin + cout)
+    x = (torch.randn(ROWS, cin, generator=g) * 1.5 + 0.2).to(DEV); w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(DEV)
+    in_coef, in_mi = _bn(be, x, 2)
+    y, sy = be.lin_forward(x, in_coef, 0.1, w)
+    gam_o = (torch.rand(cout, generator=g) + 0.5).to(DEV); bet_o = torch.zeros(cout, device=DEV)
+    out_coef, out_mi = be.bn_finalize(ROWS, sy, gam_o, bet_o, 1e-5)
+    gz = torch.randn(ROWS, cout, generator=g).to(DEV)
+    ods, gy, s1, s2 = _backward_reference(gz, y, out_coef, out_mi, cout)
+    z = _z(x, in_coef, cin)
+    gin, ids, dw = be.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w)
+    dgamma, dbeta = be.take_bn_grads()
+    ref_gin = _check_gin(gin, gy @ w.double(), z, 0.1)
+    im = in_mi.view(-1).double()
+    xh_i = (x.double() - im[:cin]) * im[cin:]
+    got = ids.view(R, 2, cin).sum(0)
+    assert _rel(got[0], ref_gin.sum(0)) < 1e-4 * float(ref_gin.abs().sum(0).max() / ref_gin.sum(0).abs().max()) and _rel(got[1], (ref_gin * xh_i).sum(0)) < 1e-4
+    assert _rel(dw, gy.t() @ _act(z, 0.1)) < 1e-5
+    assert _rel(dbeta, s1) < 1e-5 and _rel(dgamma, s2) < 1e-5
+
+
+def test_wreg_two_source_wgrad(hip_backend):
+    be = hip_backend
+    ca = cb = 64; cout = 128
+    g = torch.Generator().manual_seed(11)
+    xa = torch.randn(ROWS, ca, generator=g).to(DEV); xb = (torch.randn(ROWS, cb, generator=g) * 2 + 0.3).to(DEV)
+    w = (torch.randn(cout, ca + cb, generator=g) / 11).to(DEV)
+    coef_a, mi_a = _bn(be, xa, 3); coef_b, mi_b = _bn(be, xb, 4)
+    y, sy = be.lin_forward_2src(xa, coef_a, 0.1, xb, coef_b, 0.25, w)
+    out_coef, out_mi = be.bn_finalize(ROWS, sy, torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV), 1e-5)
+    gz = torch.randn(ROWS, cout, generator=g).to(DEV); e_add = torch.randn(ROWS, cb, generator=g).to(DEV)
+    ods, gy, s1, s2 = _backward_reference(gz, y, out_coef, out_mi, cout)
+    za, zb = _z(xa, coef_a, ca), _z(xb, coef_b, cb)
+    a = torch.cat([_act(za, 0.1), _act(zb, 0.25)], 1)
+    assert _rel(y, a @ w.double().t()) < 1e-5
+    gz_a, ds_a, gz_b, ds_b, dw = be.lin_backward_2src(gz, y, out_coef, out_mi, ods, xa, coef_a, mi_a, 0.1, xb, coef_b, mi_b, 0.25, e_add, w)
+    assert _rel(dw, gy.t() @ a) < 1e-5
+    gw = gy @ w.double()
+    _check_gin(gz_a, gw[:, :ca], za, 0.1)
+    _check_gin(gz_b, gw[:, ca:] + e_add.double(), zb, 0.25)
