@@ -2030,7 +2030,9 @@ static int launch_pair_bwd(PairBwdParams &p, float *dw, hipStream_t st, unsigned
 // floats the caller provides in dw_partial: per-block weight-gradient partials + the slabs of the four pair sums
 extern "C" long long i2p_pair_lin_bwd_scratch(int B, int N, int M, int cin, int cout) {
     const long long KT = (M + BWD_R - 1) / BWD_R, grid = i2p_pair_lin_bwd_grid(B, N, M), NC = grid / (B * KT);
-    return grid * cout * cin + 2 * KT * B * N * cin + KT * B * N * cout + NC * B * M * cin + NC * B * M * cout;
+    const long long gen2 = grid * cout * cin + 2 * KT * B * N * cin + KT * B * N * cout + NC * B * M * cin + NC * B * M * cout;
+    const long long gen3 = i2p_wreg_pair_bwd_ok(B, N, M, cin, cout) ? i2p_wreg_pair_bwd_scratch(B, N, M, cin, cout) : 0;
+    return gen3 > gen2 ? gen3 : gen2;
 }
 
 extern "C" int i2p_pair_lin_bwd(int B, int N, int M, int cin, int cout, const float *gz, const float *y,
@@ -2040,6 +2042,27 @@ extern "C" int i2p_pair_lin_bwd(int B, int N, int M, int cin, int cout, const fl
     if (B <= 0 || N <= 0 || M <= 0 || (cin & 3) || (cout & 3) || cin > 128 || cout > 128) return I2P_ERR_BAD_ARG;
     if (!gz || !f || !g || !w || !d_f || !d_g || !d_bias_n || !d_bias_k || !dw_partial || !dw) return I2P_ERR_BAD_ARG;
     if (out_coef && (!y || !out_mi || !out_dsums)) return I2P_ERR_BAD_ARG;
+    if (out_coef && i2p_wreg_pair_bwd_ok(B, N, M, cin, cout)) {
+        // 128 x 128 on many rows: two kernels with the weights / the accumulators stationary in registers (csrc/mlp_wreg.hip)
+        int KT3 = 0, NCH3 = 0;
+        const int rc = i2p_wreg_pair_bwd(B, N, M, cin, cout, gz, y, out_dsums, out_coef, out_mi, f, g, w, dw_partial, &KT3, &NCH3, stream);
+        if (rc) return rc;
+        hipStream_t st3 = (hipStream_t)stream;
+        const int n = cout * cin;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st3, 256, n, dw_partial, dw);
+        auto red3 = [&](int nslab, long long cnt, const float *slabs, float *out) {
+            long long blocks = (cnt + 255) / 256; if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st3, nslab, cnt, slabs, out);
+        };
+        const float *s_df = dw_partial + (size_t)256 * n;
+        const float *s_dbn = s_df + (size_t)KT3 * B * N * cin, *s_dg = s_dbn + (size_t)KT3 * B * N * cout;
+        const float *s_dbk = s_dg + (size_t)NCH3 * B * M * cin;
+        red3(KT3, (long long)B * N * cin, s_df, d_f);
+        red3(KT3, (long long)B * N * cout, s_dbn, d_bias_n);
+        red3(NCH3, (long long)B * M * cin, s_dg, d_g);
+        red3(NCH3, (long long)B * M * cout, s_dbk, d_bias_k);
+        I2P_RETURN_LAUNCH_STATUS();
+    }
     PairBwdParams p;
     p.B = B; p.N = N; p.M = M;
     const int KT = (M + BWD_R - 1) / BWD_R;

@@ -672,6 +672,367 @@ int launch_wreg_wgrad(const WregWgradP &p, unsigned grid, hipStream_t st) {
     I2P_RETURN_LAUNCH_STATUS();
 }
 
+
+// =====================================================================================================================
+// Backward of the PAIR layer (first cost-volume layer: y[b,n,k,:] = W (f[b,n,:] .* g[b,k,:]) + bias_n[b,n,:] + bias_k[b,k,:],
+// BN behind; mlp.hip pair_bwd_kernel is the general version) as two kernels on the same machinery.  A wave owns one
+// (sample b, 16-pixel tile k0.., chunk of points) and walks the points n of its chunk: strip = rows (b, n, k0..k0+15),
+// contiguous in gz / y.  Rows past M in the last pixel tile are loaded from row M-1 and multiplied by 0.
+//   kernel W (this one, on the wgrad machinery): dW += g^y^T . (f .* g)  — the product operand is formed from the lane's
+//     FIXED pixel rows of g (lane-private LDS) and the strip's row of f —, d_bias_k[b,k,:] = sum_n g^y (lane-private LDS
+//     accumulators, one slab per point chunk), d_bias_n[b,n,:] = sum_k g^y (one slab per pixel tile).
+//   kernel D (below, on the dgrad machinery): dP = g^y . W; d_f[b,n,:] = sum_k dP .* g, d_g[b,k,:] = sum_n dP .* f.
+// Every cross-wave sum goes through slabs the caller reduces in a fixed order (bit-reproducible gradients).
+// =====================================================================================================================
+struct WregPairP {
+    int B, N, M, KT, NCH, NL;    // KT = ceil(M/16) pixel tiles, NCH point chunks of NL points
+    const float *gz, *y2;        // [B*N*M, CO]
+    const double *g_dsums; const float *g_oc, *g_omi; long long g_rows;
+    const float *f, *g, *w;      // [B,N,CI], [B,M,CI], [CO][CI]
+    float *dw_partial;           // [grid][CO*CI]                     (kernel W)
+    float *s_dbn, *s_dbk;        // [KT][B*N*CO], [NCH][B*M*CO]       (kernel W)
+    float *s_df, *s_dg;          // [KT][B*N*CI], [NCH][B*M*CI]       (kernel D)
+};
+
+template <int CO, int CI>
+__global__ __launch_bounds__(WR_THREADS, 1) void wreg_pair_wgrad_kernel(WregPairP p) {
+    constexpr int NO = CO / 16, NI = CI / 16, HO = NO / 4, HI = NI / 4, SM = NO * NI;
+    constexpr int NPRIV = 4 * HI + 4 * HO;                      // lane-private float4 rows: g of the lane's pixels, d_bias_k sums
+    constexpr int LDS_F = CO * CI > NPRIV * WR_THREADS * 4 ? CO * CI : NPRIV * WR_THREADS * 4;
+    __shared__ float lds[LDS_F];
+    __shared__ float gtab[3 * CO];
+    f32x4 (*priv)[WR_THREADS] = reinterpret_cast<f32x4 (*)[WR_THREADS]>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, q = lane >> 4;
+    for (int ch = tid; ch < CO; ch += WR_THREADS) {
+        double sd = 0.0, sx = 0.0;
+#pragma unroll 8
+        for (int rp = 0; rp < REP; ++rp) { sd += p.g_dsums[(size_t)rp * 2 * CO + ch]; sx += p.g_dsums[(size_t)rp * 2 * CO + CO + ch]; }
+        const float m1 = (float)(sd / (double)p.g_rows), m2 = (float)(sx / (double)p.g_rows);
+        const float sc = p.g_oc[CO + ch], mu = p.g_omi[ch], is = p.g_omi[CO + ch];
+        const float bc = -sc * is * m2;
+        gtab[ch] = sc; gtab[CO + ch] = -sc * m1 - bc * mu; gtab[2 * CO + ch] = bc;
+    }
+    __syncthreads();
+    f32x4 csc[HO], cac[HO], cbc[HO];
+#pragma unroll
+    for (int h = 0; h < HO; ++h) {
+        csc[h] = *reinterpret_cast<const f32x4 *>(gtab + NO * n16 + 4 * h); cac[h] = *reinterpret_cast<const f32x4 *>(gtab + CO + NO * n16 + 4 * h);
+        cbc[h] = *reinterpret_cast<const f32x4 *>(gtab + 2 * CO + NO * n16 + 4 * h);
+    }
+    f32x4 acc[NO][NI];
+#pragma unroll
+    for (int jo = 0; jo < NO; ++jo)
+#pragma unroll
+        for (int jc = 0; jc < NI; ++jc) acc[jo][jc] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntasks = p.B * p.KT * p.NCH;
+    for (int task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+        const int nc = task % p.NCH, kt = (task / p.NCH) % p.KT, b = task / (p.NCH * p.KT);
+        const int k0 = kt * WR_ROWS, n_begin = nc * p.NL, n_end = n_begin + p.NL < p.N ? n_begin + p.NL : p.N;
+        const int ns = n_end - n_begin;
+        if (ns <= 0) continue;
+        // this lane's pixel rows: k-step t -> pixel k0 + 4t + q
+        int rowg[4]; float vm[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = k0 + 4 * t + q;
+            vm[t] = k < p.M ? 1.f : 0.f;
+            const int kc = k < p.M ? k : p.M - 1;
+            rowg[t] = kc * CO;
+#pragma unroll
+            for (int h = 0; h < HI; ++h) priv[t * HI + h][tid] = *reinterpret_cast<const f32x4 *>(p.g + ((size_t)b * p.M + kc) * CI + NI * n16 + 4 * h);
+#pragma unroll
+            for (int h = 0; h < HO; ++h) priv[4 * HI + t * HO + h][tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        size_t gbase = ((size_t)b * p.N + n_begin) * p.M * CO + NO * n16;      // strip being REQUESTED
+        size_t fbase = ((size_t)b * p.N + n_begin) * CI + NI * n16;            // f row being REQUESTED
+        const size_t g_step = (size_t)p.M * CO;
+        int greq = 0, freq = 0;                                               // strips requested so far - 1
+        f32x4 gv[4][HO], yv[4][HO], pv[2][HI], fv[HI], fvn[HI], gfix[HI], bkr[HO], bn_sum[HO];
+        auto ld_g = [&](int t) {
+#pragma unroll
+            for (int h = 0; h < HO; ++h) gv[t][h] = ldx(p.gz + gbase + rowg[t] + 4 * h);
+        };
+        auto ld_y = [&](int t) {
+#pragma unroll
+            for (int h = 0; h < HO; ++h) yv[t][h] = ldx(p.y2 + gbase + rowg[t] + 4 * h);
+        };
+        auto ld_f = [&](f32x4 (&dst)[HI]) {
+#pragma unroll
+            for (int h = 0; h < HI; ++h) dst[h] = *reinterpret_cast<const f32x4 *>(p.f + fbase + 4 * h);
+        };
+        auto adv_g = [&]() { if (greq + 1 < ns) { gbase += g_step; ++greq; } };
+        auto adv_f = [&]() { if (freq + 1 < ns) { fbase += CI; ++freq; } };
+        auto tf_g = [&](int t, int h) {                          // g^y, zero on the rows past M; d_bias sums
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                gv[t][h][c] = vm[t] * __builtin_fmaf(csc[h][c], gv[t][h][c], __builtin_fmaf(yv[t][h][c], cbc[h][c], cac[h][c]));
+            bn_sum[h] += gv[t][h];
+        };
+#pragma unroll
+        for (int h = 0; h < HO; ++h) bn_sum[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { ld_g(t); ld_y(t); }
+        ld_f(fv); adv_f(); ld_f(fvn); adv_f();
+        adv_g();
+        // k-step 0 of the first strip: operands formed here
+#pragma unroll
+        for (int h = 0; h < HO; ++h) { tf_g(0, h); priv[4 * HI + h][tid] += gv[0][h]; }
+#pragma unroll
+        for (int h = 0; h < HI; ++h) pv[0][h] = priv[h][tid] * fv[h];
+        ld_y(0);
+        for (int sidx = 0; sidx < ns; ++sidx) {
+            const size_t bn_off = (size_t)kt * p.B * p.N * CO + ((size_t)b * p.N + n_begin + sidx) * CO + NO * n16;
+            const bool has_next = sidx + 1 < ns;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int tn = (t + 1) & 3;                      // k-step whose operands are formed during this one
+#pragma unroll
+                for (int u = 0; u < SM; ++u) {
+                    const int jo = u / NI, jc = u % NI;
+                    acc[jo][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[t][jo >> 2][jo & 3], pv[t & 1][jc >> 2][jc & 3], acc[jo][jc], 0, 0, 0);
+                    if (u == 0) {                                // lane-private rows of the step being prepared
+#pragma unroll
+                        for (int h = 0; h < HI; ++h) gfix[h] = priv[tn * HI + h][tid];
+#pragma unroll
+                        for (int h = 0; h < HO; ++h) bkr[h] = priv[4 * HI + tn * HO + h][tid];
+                    }
+                    if (t == 3 && u == 1) {                      // all four k-steps of THIS strip are in bn_sum: sum over the 4 k-slots, store
+#pragma unroll
+                        for (int h = 0; h < HO; ++h) {
+                            f32x4 v = bn_sum[h];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) { float a = v[c]; a += __shfl_xor(a, 16); a += __shfl_xor(a, 32); v[c] = a; }
+                            if (q == 0) *reinterpret_cast<f32x4 *>(p.s_dbn + bn_off + 4 * h) = v;
+                            bn_sum[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
+                    if (u >= 4 && u < 4 + HO) tf_g(tn, u - 4);
+                    if (u == 4 + HO && (t < 3 || has_next)) {        // (t = 3 prepares the NEXT strip's first step: none after the last)
+#pragma unroll
+                        for (int h = 0; h < HO; ++h) { bkr[h] += gv[tn][h]; priv[4 * HI + tn * HO + h][tid] = bkr[h]; }
+                    }
+                    if (u == 5 + HO) {
+#pragma unroll
+                        for (int h = 0; h < HI; ++h) pv[tn & 1][h] = gfix[h] * (t == 3 ? fvn[h] : fv[h]);
+                        if (t < 3) ld_y(tn);
+                    }
+                    if (u == SM - 1) ld_g(t);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            adv_g();
+            ld_y(0);
+#pragma unroll
+            for (int h = 0; h < HI; ++h) fv[h] = fvn[h];
+            ld_f(fvn); adv_f();
+        }
+        // d_bias_k of this lane's pixels
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = k0 + 4 * t + q;
+            if (k < p.M) {
+#pragma unroll
+                for (int h = 0; h < HO; ++h)
+                    *reinterpret_cast<f32x4 *>(p.s_dbk + (size_t)nc * p.B * p.M * CO + ((size_t)b * p.M + k) * CO + NO * n16 + 4 * h) = priv[4 * HI + t * HO + h][tid];
+            }
+        }
+    }
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int jo = 0; jo < NO; ++jo)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int h = 0; h < HI; ++h) {
+                        float *dst = lds + (size_t)(NO * (4 * q + e) + jo) * CI + NI * n16 + 4 * h;
+                        f32x4 v = {acc[jo][4 * h][e], acc[jo][4 * h + 1][e], acc[jo][4 * h + 2][e], acc[jo][4 * h + 3][e]};
+                        if (w > 0) v += *reinterpret_cast<const f32x4 *>(dst);
+                        *reinterpret_cast<f32x4 *>(dst) = v;
+                    }
+        }
+        __syncthreads();
+    }
+    float *out = p.dw_partial + (size_t)blockIdx.x * CO * CI;
+    for (int i = tid; i < CO * CI / 4; i += WR_THREADS)
+        *reinterpret_cast<f32x4 *>(out + 4 * i) = *reinterpret_cast<const f32x4 *>(lds + 4 * i);
+}
+
+
+// sum over the 16 lanes of a DPP row (every lane ends with the row's sum): quad_perm[1,0,3,2], quad_perm[2,3,0,1],
+// row_half_mirror, row_mirror
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, CTRL, 0xF, 0xF, false));
+}
+
+// kernel D of the pair-layer backward (see above): dP = g^y . W per strip on the dgrad machinery; d_g[b,k,:] += dP .* f[b,n,:]
+// in lane-private LDS rows (the lane's pixel is fixed, one slab per point chunk), d_f[b,n,:] = sum over the strip's 16
+// pixels of dP .* g[b,k,:] (DPP row sums, one slab per pixel tile).  K = CO (channels of gz / y), C = CI.
+template <int K, int C>
+__global__ __launch_bounds__(WR_THREADS, 1) void wreg_pair_dgrad_kernel(WregPairP p) {
+    constexpr int NT = C / 16, L = K / 4, NF = L / 4, G = 4 * NT, NMF = NT * L;
+    __shared__ float gt[3 * K];
+    __shared__ f32x4 priv[2 * NT][WR_THREADS];                  // rows [0, NT): g of the lane's pixel; [NT, 2NT): d_g sums
+    __shared__ float fbuf[4][2][C];                             // f[b,n,:] of the strip being computed / stored, per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    for (int ch = tid; ch < K; ch += WR_THREADS) {
+        double sd = 0.0, sx = 0.0;
+#pragma unroll 8
+        for (int rp = 0; rp < REP; ++rp) { sd += p.g_dsums[(size_t)rp * 2 * K + ch]; sx += p.g_dsums[(size_t)rp * 2 * K + K + ch]; }
+        const float m1 = (float)(sd / (double)p.g_rows), m2 = (float)(sx / (double)p.g_rows);
+        const float sc = p.g_oc[K + ch], mu = p.g_omi[ch], is = p.g_omi[K + ch];
+        const float bc = -sc * is * m2;
+        gt[ch] = sc; gt[K + ch] = -sc * m1 - bc * mu; gt[2 * K + ch] = bc;
+    }
+    __syncthreads();
+    f32x4 wr[NT][NF];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wr[j][f][e] = p.w[(size_t)(16 * f + 4 * q + e) * C + 16 * j + m];
+    const float *gq = gt + 4 * q;
+
+    const int ntasks = p.B * p.KT * p.NCH;
+    for (int task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+        const int nc = task % p.NCH, kt = (task / p.NCH) % p.KT, b = task / (p.NCH * p.KT);
+        const int k0 = kt * WR_ROWS, n_begin = nc * p.NL, n_end = n_begin + p.NL < p.N ? n_begin + p.NL : p.N;
+        const int ns = n_end - n_begin;
+        if (ns <= 0) continue;
+        const int kpix = k0 + m;
+        const float vm = kpix < p.M ? 1.f : 0.f;
+        const int kc = kpix < p.M ? kpix : p.M - 1;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            priv[j][tid] = *reinterpret_cast<const f32x4 *>(p.g + ((size_t)b * p.M + kc) * C + 16 * j + 4 * q);
+            priv[NT + j][tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        size_t koff = (((size_t)b * p.N + n_begin) * p.M + kc) * K + 4 * q;       // strip being REQUESTED (gz / y)
+        const size_t k_step = (size_t)p.M * K;
+        int kreq = 0;
+        auto adv_k = [&]() { if (kreq + 1 < ns) { koff += k_step; ++kreq; } };
+        size_t dfoff = (size_t)kt * p.B * p.N * C + ((size_t)b * p.N + n_begin) * C + 4 * q;   // d_f slab row of the strip being STORED
+
+        f32x4 tsc, tac, tbc, tu, gfix, dgr, tprod, frj, ftmp, x[NF], yb[NF], accA[NT], accB[NT];
+        tsc = tac = tbc = tu = gfix = dgr = tprod = frj = ftmp = f32x4{0.f, 0.f, 0.f, 0.f};
+        const size_t f_row0 = ((size_t)b * p.N + n_begin) * C;
+        int fidx = 0;                                            // strip whose f row is requested next
+        constexpr int LAT = 5, PE = 10;
+        static_assert(PE * NT <= NMF && LAT + 2 <= G, "slot plan");
+        auto row_sum = [&](f32x4 &v) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = v[c];
+                a += dpp_f32<0xB1>(a); a += dpp_f32<0x4E>(a); a += dpp_f32<0x141>(a); a += dpp_f32<0x140>(a);
+                v[c] = a;
+            }
+        };
+        auto final_epilogue = [&](f32x4 (&prev)[NT], int par) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                f32x4 d = priv[NT + j][tid], gf = priv[j][tid];
+                const f32x4 fj = *reinterpret_cast<const f32x4 *>(&fbuf[wave][par][16 * j + 4 * q]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d[c] = __builtin_fmaf(prev[j][c], fj[c], d[c]);
+                priv[NT + j][tid] = d;
+                f32x4 t = prev[j] * gf;
+                row_sum(t);
+                if (m == 0) *reinterpret_cast<f32x4 *>(p.s_df + dfoff + 16 * j) = t;
+            }
+        };
+        auto tf_all = [&](int f) {
+            tsc = *reinterpret_cast<const f32x4 *>(gq + 16 * f); tac = *reinterpret_cast<const f32x4 *>(gq + K + 16 * f);
+            tbc = *reinterpret_cast<const f32x4 *>(gq + 2 * K + 16 * f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[f][c] = vm * __builtin_fmaf(tsc[c], x[f][c], __builtin_fmaf(yb[f][c], tbc[c], tac[c]));
+        };
+        // `par`: parity of the strip being computed = fbuf row its f is written to (the store phase reads the other one)
+        auto strip_block = [&](auto epi_tag, auto par_tag, f32x4 (&acc)[NT], f32x4 (&prev)[NT]) {
+            constexpr bool EPI = decltype(epi_tag)::value;
+            constexpr int PAR = decltype(par_tag)::value;
+#pragma unroll
+            for (int i = 0; i < NMF; ++i) {
+                const int t = i / NT, j = i % NT, f = t >> 2, e = t & 3;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][f][e], x[f][e], t == 0 ? zero : acc[j], 0, 0, 0);
+                if (i == G * (f + 1) - 1 && (f & 1)) { x[f - 1] = ldx(p.gz + koff + 16 * (f - 1)); x[f] = ldx(p.gz + koff + 16 * f); }
+                // f[b,n,:] of this strip: one float4 per lane of the first C/4 lanes, through a wave-shared LDS row (32
+                // registers per lane otherwise: the kernel spilled weights, and every reload waited for vmcnt(0))
+                if (i == 1 && lane < C / 4) ftmp = *reinterpret_cast<const f32x4 *>(p.f + f_row0 + (size_t)fidx * C + 4 * lane);
+                if (i == NMF / 2 && lane < C / 4) *reinterpret_cast<f32x4 *>(&fbuf[wave][PAR][4 * lane]) = ftmp;
+                {
+                    const int fn = (f + 1) % NF, u = i - G * f;
+                    if (u == 0) {
+                        tsc = *reinterpret_cast<const f32x4 *>(gq + 16 * fn); tac = *reinterpret_cast<const f32x4 *>(gq + K + 16 * fn);
+                        tbc = *reinterpret_cast<const f32x4 *>(gq + 2 * K + 16 * fn);
+                    }
+                    if (u == LAT) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) tu[c] = __builtin_fmaf(yb[fn][c], tbc[c], tac[c]);
+                    }
+                    if (u == LAT + 1) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) x[fn][c] = vm * __builtin_fmaf(tsc[c], x[fn][c], tu[c]);
+                        if (fn & 1) { yb[fn - 1] = ldx(p.y2 + koff + 16 * (fn - 1)); yb[fn] = ldx(p.y2 + koff + 16 * fn); }
+                    }
+                }
+                if (EPI && i < PE * NT) {
+                    const int tj = i / PE, part = i % PE;
+                    if (part == 0) { gfix = priv[tj][tid]; dgr = priv[NT + tj][tid]; frj = *reinterpret_cast<const f32x4 *>(&fbuf[wave][PAR ^ 1][16 * tj + 4 * q]); }
+                    if (part == LAT) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dgr[c] = __builtin_fmaf(prev[tj][c], frj[c], dgr[c]);
+                        priv[NT + tj][tid] = dgr;
+                    }
+                    if (part == LAT + 1) tprod = prev[tj] * gfix;
+                    if (part == LAT + 2) row_sum(tprod);
+                    if (part == LAT + 3 && m == 0) *reinterpret_cast<f32x4 *>(p.s_df + dfoff + 16 * tj) = tprod;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (EPI) dfoff += C;
+            ++fidx;
+            adv_k();
+        };
+#pragma unroll
+        for (int f = 0; f < NF; ++f) { x[f] = ldx(p.gz + koff + 16 * f); yb[f] = ldx(p.y2 + koff + 16 * f); }
+        adv_k();
+        tf_all(0);
+        using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+        strip_block(std::false_type{}, P0{}, accA, accB);
+        int k = 1;
+        for (; k + 1 < ns; k += 2) {
+            strip_block(std::true_type{}, P1{}, accB, accA);
+            strip_block(std::true_type{}, P0{}, accA, accB);
+        }
+        if (k < ns) {
+            strip_block(std::true_type{}, P1{}, accB, accA);
+            final_epilogue(accB, 1);
+        } else {
+            final_epilogue(accA, 0);
+        }
+        if (kpix < p.M) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                *reinterpret_cast<f32x4 *>(p.s_dg + (size_t)nc * p.B * p.M * C + ((size_t)b * p.M + kpix) * C + 16 * j + 4 * q) = priv[NT + j][tid];
+        }
+    }
+}
+
+template <int CO, int CI>
+int launch_wreg_pair(const WregPairP &p, unsigned grid, hipStream_t st) {
+    hipLaunchKernelGGL((wreg_pair_dgrad_kernel<CO, CI>), dim3(grid), dim3(WR_THREADS), 0, st, p);
+    hipLaunchKernelGGL((wreg_pair_wgrad_kernel<CO, CI>), dim3(grid), dim3(WR_THREADS), 0, st, p);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
 }  // namespace
 
 bool i2p_wreg_fwd_ok(long long rows, int cin, int cout) {
@@ -741,4 +1102,41 @@ int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const flo
     if (cout == 128 && cin == 64) return launch_wreg_wgrad<128, 64>(p, grid, st);
     if (cout == 64 && cin == 128) return launch_wreg_wgrad<64, 128>(p, grid, st);
     return launch_wreg_wgrad<64, 64>(p, grid, st);
+}
+
+// pair-layer backward (first cost-volume layer) on the two kernels above.  Scratch layout (floats), returned by
+// i2p_wreg_pair_bwd_scratch: [256][cout*cin] block partials of dW, then the slabs s_df [KT][B*N*cin], s_dbn [KT][B*N*cout],
+// s_dg [NCH][B*M*cin], s_dbk [NCH][B*M*cout]; the caller reduces them (reduce_partials / slab_reduce, fixed order).
+static void wreg_pair_geometry(int B, int N, int M, int &KT, int &NCH, int &NL) {
+    KT = (M + WR_ROWS - 1) / WR_ROWS;
+    NCH = 1024 / (B * KT > 0 ? B * KT : 1);
+    NCH = NCH < 1 ? 1 : (NCH > N ? N : NCH);
+    NL = (N + NCH - 1) / NCH;
+    NCH = (N + NL - 1) / NL;                                     // every chunk non-empty: every slab row gets written
+}
+bool i2p_wreg_pair_bwd_ok(int B, int N, int M, int cin, int cout) {
+    static const char *e = getenv("I2P_NO_WREG");
+    if (e && e[0] == '1') return false;
+    return (long long)B * N * M >= 65536 && M >= WR_ROWS && cin == 128 && cout == 128;
+}
+long long i2p_wreg_pair_bwd_scratch(int B, int N, int M, int cin, int cout) {
+    int KT, NCH, NL; wreg_pair_geometry(B, N, M, KT, NCH, NL);
+    return 256LL * cout * cin + (long long)KT * B * N * (cin + cout) + (long long)NCH * B * M * (cin + cout);
+}
+int i2p_wreg_pair_bwd(int B, int N, int M, int cin, int cout, const float *gz, const float *y2, const double *g_dsums,
+                      const float *g_oc, const float *g_omi, const float *f, const float *g, const float *w, float *scratch,
+                      int *KT_out, int *NCH_out, void *stream) {
+    if (!i2p_wreg_pair_bwd_ok(B, N, M, cin, cout) || !gz || !y2 || !g_dsums || !g_oc || !g_omi || !f || !g || !w || !scratch)
+        return I2P_ERR_BAD_ARG;
+    WregPairP p;
+    p.B = B; p.N = N; p.M = M; wreg_pair_geometry(B, N, M, p.KT, p.NCH, p.NL);
+    p.gz = gz; p.y2 = y2; p.g_dsums = g_dsums; p.g_oc = g_oc; p.g_omi = g_omi; p.g_rows = (long long)B * N * M;
+    p.f = f; p.g = g; p.w = w;
+    p.dw_partial = scratch;
+    p.s_df = scratch + (size_t)256 * cout * cin;
+    p.s_dbn = p.s_df + (size_t)p.KT * B * N * cin;
+    p.s_dg = p.s_dbn + (size_t)p.KT * B * N * cout;
+    p.s_dbk = p.s_dg + (size_t)p.NCH * B * M * cin;
+    *KT_out = p.KT; *NCH_out = p.NCH;
+    return launch_wreg_pair<128, 128>(p, 256u, (hipStream_t)stream);
 }

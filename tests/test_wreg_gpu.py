@@ -112,3 +112,31 @@ def test_wreg_two_source_wgrad(hip_backend):
     gw = gy @ w.double()
     _check_gin(gz_a, gw[:, :ca], za, 0.1)
     _check_gin(gz_b, gw[:, ca:] + e_add.double(), zb, 0.25)
+
+
+def test_wreg_pair_backward(hip_backend):
+    """first cost-volume layer backward on the two in-register kernels (rows >= 65536, 128 x 128, M % 16 != 0: the last
+    pixel tile is partial) against fp64 torch (reference: PPBackbone_center.py:383-433, factored as in DESIGN.md §1)."""
+    be = hip_backend
+    B, N, M, C, Co = 2, 72, 468, 128, 128
+    rows = B * N * M
+    g_ = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g_).to(DEV)
+    f, g, bn, bk, w = rnd(B, N, C), rnd(B, M, C), rnd(B, N, Co), rnd(B, M, Co), rnd(Co, C) / C ** 0.5
+    y, sy = be.pair_lin_forward(f, g, bn, bk, w)
+    out_coef, out_mi = be.bn_finalize(rows, sy, (torch.rand(Co, generator=g_) + 0.5).to(DEV), torch.zeros(Co, device=DEV), 1e-5)
+    gz = rnd(rows, Co)
+    om, oc = out_mi.view(-1).double(), out_coef.view(-1).double()
+    xh = (y.double() - om[:Co]) * om[Co:]
+    s1, s2 = gz.double().sum(0), (gz.double() * xh).sum(0)
+    ods = torch.zeros(R, 2, Co, dtype=torch.float64, device=DEV); ods[0, 0] = s1; ods[0, 1] = s2
+    gy = oc[Co:2 * Co] * (gz.double() - s1 / rows - xh * (s2 / rows))
+    gy4 = gy.view(B, N, M, Co)
+    P = f.double()[:, :, None, :] * g.double()[:, None, :, :]
+    dP = (gy @ w.double()).view(B, N, M, C)
+    want = [(dP * g.double()[:, None]).sum(2), (dP * f.double()[:, :, None]).sum(1), gy4.sum(2), gy4.sum(1), gy.t() @ P.view(rows, C)]
+    got = be.pair_lin_backward(gz, f, g, w, y=y, out_coef=out_coef, out_mi=out_mi, out_dsums=ods.view(-1))
+    for name, a, r in zip(("d_f", "d_g", "d_bias_n", "d_bias_k", "dw"), got, want):
+        assert _rel(a, r) < 1e-5, name
+    again = be.pair_lin_backward(gz, f, g, w, y=y, out_coef=out_coef, out_mi=out_mi, out_dsums=ods.view(-1))
+    assert all(torch.equal(a, b) for a, b in zip(got, again))           # slab reductions in a fixed order: bit-reproducible
