@@ -66,7 +66,8 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_fwd_kernel(WregP p) {
     // per-lane statistics accumulators live in LDS (lane-private 16-byte rows, read-update-write between the MFMAs: 64
     // registers otherwise; LDS float atomics measured 3x the whole kernel)
     __shared__ f32x4 st_lds[2 * NT][NTHREADS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform on purpose: strip counters and steps live in SGPRs
     const int m = lane & 15, q = lane >> 4;
     if (BN_IN) {
         for (int c = tid; c < CIN; c += NTHREADS) {
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_dgrad_kernel(WregDgradP p)
     __shared__ float gt[3 * K];            // sc, Ac, Bc
     __shared__ float et[4 * C];            // e_sc, e_zb, e_is, e_nm
     __shared__ f32x4 st_lds[2 * NT][WR_THREADS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;     // (scalarising `wave` here makes clang spill 150 registers)
     const int m = lane & 15, q = lane >> 4;
     for (int ch = tid; ch < K; ch += WR_THREADS) {
         double sd = 0.0, sx = 0.0;
@@ -509,7 +510,7 @@ int launch_wreg_dgrad(const WregDgradP &p, hipStream_t st) {
 // =====================================================================================================================
 // WGRAD on the same machinery: dW[o][c] = sum_rows g^y[row][o] * a[row][c], a = act(BN(x)) of the layer in front.
 // The ACCUMULATORS are what stays in registers here: the whole [CO][CI] result of a wave (256 registers at 128x128),
-// rows are the contraction axis: one 16-row strip = 4 k-steps (rows 4t..4t+3, k-slot q = row 4t+q) x (CO/16)(CI/16)
+// rows are the contraction axis: one 16-row strip = 4 k-steps (k-slot q = rows 4q..4q+3, step t its row 4q+t) x (CO/16)(CI/16)
 // tiles.  Tile jo of the A operand holds output channels {NO*i + jo} (i = lane & 15, NO = CO/16), so a lane's A values of
 // a k-step are NO CONTIGUOUS channels of one row of gz / y: float4 loads straight into the operand registers, no LDS,
 // no transposition; same for x (tile jc = channels {NI*n + jc}).  The per-channel constants of a lane never change.
@@ -531,37 +532,43 @@ struct WregWgradP {
     float *dw_partial;           // [grid][CO*CI]
 };
 
-template <int CO, int CI, bool BN_IN>
+template <int CO, int CI, bool BN_IN, bool TWO>
 __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p) {
     constexpr int NO = CO / 16, NI = CI / 16;      // tiles = channels per lane
     constexpr int HO = NO / 4, HI = NI / 4;        // float4 per lane, row and tensor
     constexpr int SM = NO * NI;                    // MFMAs per k-step
     __shared__ float red[CO * CI];
     __shared__ float gtab[3 * CO];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform on purpose: strip counters and steps live in SGPRs
     const int n = lane & 15, q = lane >> 4;
     for (int ch = tid; ch < CO; ch += WR_THREADS) {
         double sd = 0.0, sx = 0.0;
 #pragma unroll 8
         for (int rp = 0; rp < REP; ++rp) { sd += p.g_dsums[(size_t)rp * 2 * CO + ch]; sx += p.g_dsums[(size_t)rp * 2 * CO + CO + ch]; }
         const float m1 = (float)(sd / (double)p.g_rows), m2 = (float)(sx / (double)p.g_rows);
+        // g^y = sc * (gz + y * Bc + Ac), Bc = -is * m2, Ac = -m1 - Bc * mu; the factor sc[o] is applied to row o of the
+        // RESULT (8 registers and a multiply per element less in the loop)
         const float sc = p.g_oc[CO + ch], mu = p.g_omi[ch], is = p.g_omi[CO + ch];
-        const float bc = -sc * is * m2;
-        gtab[ch] = sc; gtab[CO + ch] = -sc * m1 - bc * mu; gtab[2 * CO + ch] = bc;
+        const float bc = -is * m2;
+        gtab[ch] = sc; gtab[CO + ch] = -m1 - bc * mu; gtab[2 * CO + ch] = bc;
         if (blockIdx.x == 0 && p.bn_out) { p.bn_out[6 * CO + ch] = (float)sd; p.bn_out[7 * CO + ch] = (float)sx; }
     }
     __syncthreads();
     // this lane's channels: gz / y columns NO*n .. NO*n + NO-1, x columns NI*n .. NI*n + NI-1
-    f32x4 csc[HO], cac[HO], cbc[HO], cxa[HI], cxb[HI];
+    f32x4 cac[HO], cbc[HO], cxa[HI], cxb[HI];
 #pragma unroll
     for (int h = 0; h < HO; ++h) {
-        csc[h] = *reinterpret_cast<const f32x4 *>(gtab + NO * n + 4 * h); cac[h] = *reinterpret_cast<const f32x4 *>(gtab + CO + NO * n + 4 * h);
+        cac[h] = *reinterpret_cast<const f32x4 *>(gtab + CO + NO * n + 4 * h);
         cbc[h] = *reinterpret_cast<const f32x4 *>(gtab + 2 * CO + NO * n + 4 * h);
     }
     // source of this lane's x columns (its NI channels never straddle the split)
-    const bool second = p.xb && NI * n >= p.split;
+    // (one-source instantiation: everything below is uniform / compile-time — the per-lane pointer, pitch and slope of
+    //  the two-source one cost the registers that keep the 128x128 kernel free of spills inside its loop)
+    const bool second = TWO && NI * n >= p.split;
+    constexpr int x_ld = TWO ? CI / 2 : CI;                        // (two sources: the launcher takes split == CI/2 only)
     const float *xsrc = second ? p.xb : p.x;
-    const int x_ld = p.xb ? (second ? CI - p.split : p.split) : CI, x_col = second ? NI * n - p.split : NI * n;
+    const int x_col = second ? NI * n - p.split : NI * n;
     const float *xcoef = second ? p.in_coef_b : p.in_coef;
     const float x_slope = second ? p.slope_b : p.slope_in;
 #pragma unroll
@@ -585,26 +592,27 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
     const long long first = (long long)blockIdx.x * 4 + wave;
     const int n_mine = first < nstrips ? (int)((nstrips - first + stride - 1) / stride) : 0;
     if (n_mine > 0) {
-        // element offsets of row q of the strip being REQUESTED (k-step t adds 4t rows)
-        size_t goff = ((size_t)first * WR_ROWS + q) * CO + NO * n, xoff = ((size_t)first * WR_ROWS + q) * x_ld + x_col;
+        // element offsets of row 4q of the strip being REQUESTED: k-slot q owns rows 4q..4q+3, k-step t takes row 4q + t (any
+        // bijection rows <-> (slot, step) gives the same sum; this one keeps the per-step offsets inside the load immediates)
+        size_t goff = ((size_t)first * WR_ROWS + 4 * q) * CO + NO * n, xoff = ((size_t)first * WR_ROWS + 4 * q) * x_ld + x_col;
         const size_t g_step = (size_t)stride * WR_ROWS * CO, x_step = (size_t)stride * WR_ROWS * x_ld;
         int loaded = 0;
         f32x4 gv[4][HO], yv[4][HO], xv[4][HI];
         auto ld_g = [&](int t) {
 #pragma unroll
-            for (int h = 0; h < HO; ++h) gv[t][h] = ldx(p.gz + goff + (size_t)4 * t * CO + 4 * h);
+            for (int h = 0; h < HO; ++h) gv[t][h] = ldx(p.gz + goff + t * CO + 4 * h);
         };
         auto ld_y = [&](int t) {
 #pragma unroll
-            for (int h = 0; h < HO; ++h) yv[t][h] = ldx(p.y2 + goff + (size_t)4 * t * CO + 4 * h);
+            for (int h = 0; h < HO; ++h) yv[t][h] = ldx(p.y2 + goff + t * CO + 4 * h);
         };
         auto ld_x = [&](int t) {
 #pragma unroll
-            for (int h = 0; h < HI; ++h) xv[t][h] = ldx(xsrc + xoff + (size_t)4 * t * x_ld + 4 * h);
+            for (int h = 0; h < HI; ++h) xv[t][h] = ldx(xsrc + xoff + t * x_ld + 4 * h);
         };
-        auto tf_g = [&](int t, int h) {                          // g^y = fma(sc, gz, fma(y, Bc, Ac))
+        auto tf_g = [&](int t, int h) {                          // g^y / sc = gz + fma(y, Bc, Ac)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) gv[t][h][c] = __builtin_fmaf(csc[h][c], gv[t][h][c], __builtin_fmaf(yv[t][h][c], cbc[h][c], cac[h][c]));
+            for (int c = 0; c < 4; ++c) gv[t][h][c] = gv[t][h][c] + __builtin_fmaf(yv[t][h][c], cbc[h][c], cac[h][c]);
         };
         auto tf_x = [&](int t, int h) {                          // a = max(z, slope z), z = fma(x, a, b)
             if (!BN_IN) return;
@@ -654,6 +662,7 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
                     for (int h = 0; h < HI; ++h) {
                         float *dst = red + (size_t)(NO * (4 * q + e) + jo) * CI + NI * n + 4 * h;
                         f32x4 v = {acc[jo][4 * h][e], acc[jo][4 * h + 1][e], acc[jo][4 * h + 2][e], acc[jo][4 * h + 3][e]};
+                        v *= gtab[NO * (4 * q + e) + jo];                    // sc of output row o
                         if (w > 0) v += *reinterpret_cast<const f32x4 *>(dst);
                         *reinterpret_cast<f32x4 *>(dst) = v;
                     }
@@ -667,8 +676,9 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
 
 template <int CO, int CI>
 int launch_wreg_wgrad(const WregWgradP &p, unsigned grid, hipStream_t st) {
-    if (p.in_coef) hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, true>), dim3(grid), dim3(WR_THREADS), 0, st, p);
-    else hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, false>), dim3(grid), dim3(WR_THREADS), 0, st, p);
+    if (p.xb) hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, true, true>), dim3(grid), dim3(WR_THREADS), 0, st, p);
+    else if (p.in_coef) hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, true, false>), dim3(grid), dim3(WR_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, false, false>), dim3(grid), dim3(WR_THREADS), 0, st, p);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
@@ -702,7 +712,8 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_pair_wgrad_kernel(WregPair
     __shared__ float lds[LDS_F];
     __shared__ float gtab[3 * CO];
     f32x4 (*priv)[WR_THREADS] = reinterpret_cast<f32x4 (*)[WR_THREADS]>(lds);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform on purpose: strip counters and steps live in SGPRs
     const int n16 = lane & 15, q = lane >> 4;
     for (int ch = tid; ch < CO; ch += WR_THREADS) {
         double sd = 0.0, sx = 0.0;
@@ -879,7 +890,8 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_pair_dgrad_kernel(WregPair
     __shared__ float gt[3 * K];
     __shared__ f32x4 priv[2 * NT][WR_THREADS];                  // rows [0, NT): g of the lane's pixel; [NT, 2NT): d_g sums
     __shared__ float fbuf[4][2][C];                             // f[b,n,:] of the strip being computed / stored, per wave
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform on purpose: strip counters and steps live in SGPRs
     const int m = lane & 15, q = lane >> 4;
     for (int ch = tid; ch < K; ch += WR_THREADS) {
         double sd = 0.0, sx = 0.0;
@@ -1090,7 +1102,7 @@ int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const flo
     if (!i2p_wreg_wgrad_ok(rows, cin, cout) || !gz || !y2 || !g_dsums || !g_oc || !g_omi || !x || !dw_partial || grid == 0 ||
         !(slope_in >= 0.f && slope_in <= 1.f))
         return I2P_ERR_BAD_ARG;
-    if (xb && (split <= 0 || split >= cin || split % (cin / 16) != 0 || (split & 3) || !in_coef || !in_coef_b ||
+    if (xb && (split * 2 != cin || !in_coef || !in_coef_b ||
                !(slope_b >= 0.f && slope_b <= 1.f)))
         return I2P_ERR_BAD_ARG;
     WregWgradP p;
