@@ -228,3 +228,71 @@ def test_two_stream_branches_match_single_stream(monkeypatch):
     _, b3, b4 = _run_iter("cuda")
     assert _rel(b4, gold["out4"]) < 1e-4 and _rel(b3, gold["out3"]) < 5e-4
     assert _rel(b4, a4) < 1e-5 and _rel(b3, a3) < 1e-5
+
+
+def _run_train_mode(device):
+    """one TRAIN-mode step of the main model against the reference (fixture: tools/gen_golden.py train — the reference
+    module in .train(), dropout probability 0): image-encoder BatchNorm2d layers on batch statistics + running-buffer
+    update through the fused image-block kernels, end to end"""
+    from i2pnet_amd import synth
+    from i2pnet_amd.config import CONFIGS
+    from i2pnet_amd.loss import Get_loss
+    from i2pnet_amd.model import RegNet_v2
+
+    gold = np.load(GOLD / "model_kitti_train.npz")
+    cfg_name, B, N, img_h, img_w, seed, beams = gold["meta"].tolist()
+    B, N, img_h, img_w, seed, beams = int(B), int(N), int(img_h), int(img_w), int(seed), int(beams)
+    cfg = CONFIGS[cfg_name]
+    model = RegNet_v2(cfg=cfg)
+    theirs = {k: tuple(int(x) for x in s.split(",") if x) for k, s in zip(gold["state_keys"].tolist(), gold["state_shapes"].tolist())}
+    model.load_state_dict(synthetic_state(list(theirs.items()), seed=seed))
+    model.train().to(device)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    batch = {k: v.to(device) for k, v in synth.make_batch(B, N, img_h, img_w, seed=seed, beams=beams, fup=cfg.fup,
+                                                           fdown=cfg.fdown, unique_cells=(cfg.init_H, cfg.init_W)).items()}
+    out3, out4, _, _, sx, sq = model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"], batch["init_extrinsic"],
+                                     batch["init_intrinsic"], None, None, None, batch["lidar_feats"], cfg=cfg)
+    loss, _, _ = Get_loss(out3, out4, batch["decalib_real_gt"], batch["decalib_dual_gt"], sx, sq, cfg=cfg)
+    loss.backward()
+    return gold, model, out3, out4, loss
+
+
+def _check_train_mode(gold, model, out3, out4, loss, tol, grad_tol):
+    assert _rel(out3.detach().cpu(), gold["out3"]) <= tol and _rel(out4.detach().cpu(), gold["out4"]) <= tol
+    assert abs(loss.item() - gold["loss"][0]) <= tol * abs(gold["loss"][0])
+    # running buffers after the step (sum and absolute sum of every buffer; num_batches_tracked exactly)
+    state = model.state_dict()
+    for k, s, a in zip(gold["buf_keys"].tolist(), gold["buf_sum"].tolist(), gold["buf_abs_sum"].tolist()):
+        v = state[k].double()
+        assert abs(float(v.sum()) - s) <= 1e-4 * max(a, 1e-6) and abs(float(v.abs().sum()) - a) <= 1e-4 * max(a, 1e-6), k
+    # gradients: global norm, and the norm per top-level module where the reference's own value is not at rounding level
+    gn = dict(zip(gold["grad_keys"].tolist(), gold["grad_norm"].tolist()))
+    mine, ref = {}, {}
+    for k, p in model.named_parameters():
+        m = k.split(".")[0]
+        g = 0.0 if p.grad is None else float(p.grad.double().norm())
+        mine[m] = mine.get(m, 0.0) + g * g; ref[m] = ref.get(m, 0.0) + gn[k] ** 2
+    tot_m, tot_r = sum(mine.values()) ** 0.5, sum(ref.values()) ** 0.5
+    assert abs(tot_m - tot_r) <= grad_tol * tot_r, (tot_m, tot_r)
+    # (the mask up-convolution's gradient is 35 % away from fp64 in the reference itself, DESIGN.md §2: not compared)
+    bad = {m: (mine[m] ** 0.5, ref[m] ** 0.5) for m in ref
+           if m != "set_upconv0_w_upsample" and ref[m] ** 0.5 > 1e-3 * tot_r and abs(mine[m] ** 0.5 - ref[m] ** 0.5) > 20 * grad_tol * ref[m] ** 0.5}
+    assert not bad, bad
+
+
+def test_train_mode_step_matches_reference_on_cpu_oracle(oracle_backend):
+    from i2pnet_amd import ops
+    prev = ops.set_backend(oracle_backend)
+    try:
+        torch.manual_seed(0)
+        _check_train_mode(*_run_train_mode("cpu"), tol=1e-4, grad_tol=1e-3)
+    finally:
+        ops.set_backend(prev)
+
+
+@pytest.mark.gpu
+def test_train_mode_step_matches_reference_on_gpu(hip_backend):
+    torch.manual_seed(0)
+    _check_train_mode(*_run_train_mode("cuda"), tol=2e-4, grad_tol=2e-3)

@@ -514,3 +514,76 @@ def test_project_seq_is_differentiable_in_its_values(oracle_backend):
         assert torch.allclose(xyz.grad, gx) and torch.allclose(feat.grad, gf)
     finally:
         ops.set_backend(prev)
+
+
+# ---- independent pure-Python restatements of the two remaining pointnet2 search kernels -------------------------
+def _grid_cloud(B, N, seed, span=4):
+    """coordinates on a 1/4 grid (every product and sum below is exact in fp32, so ties and the r^2 boundary are hit
+    exactly) with repeated points"""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(-4 * span, 4 * span + 1, (B, N, 3), generator=g).float() / 4
+
+
+def _ball_query_python(new_xyz, xyz, radius, ns, idx):
+    """pointnet2/src/ball_query_gpu.cu:9-47, line by line: first `ns` indices with d2 < r^2 in index order, the tail
+    filled with the first hit, rows without a hit left untouched"""
+    r2 = np.float32(radius) * np.float32(radius)
+    for b in range(xyz.shape[0]):
+        for q in range(new_xyz.shape[1]):
+            cnt = 0
+            for k in range(xyz.shape[1]):
+                d = new_xyz[b, q] - xyz[b, k]
+                d2 = np.float32(d[0] * d[0]) + np.float32(d[1] * d[1]) + np.float32(d[2] * d[2])
+                if d2 < r2:
+                    if cnt == 0:
+                        idx[b, q, :] = k
+                    idx[b, q, cnt] = k
+                    cnt += 1
+                    if cnt >= ns:
+                        break
+    return idx
+
+
+def test_ball_query_oracle_vs_python_restatement(oracle_backend):
+    B, N, M, ns = 2, 60, 25, 6
+    xyz = _grid_cloud(B, N, 3)
+    new_xyz = torch.cat([xyz[:, :M - 2], torch.full((B, 2, 3), 50.0)], 1).contiguous()    # the last two queries hit nothing
+    for radius in (0.75, 1.25, 2.0):                         # 0.75^2 = 0.5625, 1.25^2 = 1.5625: reachable on the grid (boundary excluded)
+        idx = torch.full((B, M, ns), -7, dtype=torch.int32)
+        oracle_backend.ball_query_wrapper(B, N, M, radius, ns, new_xyz, xyz, idx)
+        want = _ball_query_python(new_xyz.numpy(), xyz.numpy(), radius, ns, np.full((B, M, ns), -7, np.int32))
+        assert np.array_equal(idx.numpy(), want), radius
+        assert (idx[:, -2:] == -7).all()
+
+
+def _three_nn_python(unknown, known):
+    """pointnet2/src/interpolate_gpu.cu:9-52: running best three with strict `<` (the first of equal distances wins),
+    double-typed bests initialised to 1e40, float distances"""
+    B, N = unknown.shape[:2]
+    d2 = np.zeros((B, N, 3), np.float32); idx = np.zeros((B, N, 3), np.int32)
+    for b in range(B):
+        for i in range(N):
+            best = [1e40, 1e40, 1e40]; bi = [0, 0, 0]
+            for k in range(known.shape[1]):
+                v = unknown[b, i] - known[b, k]
+                d = float(np.float32(v[0] * v[0]) + np.float32(v[1] * v[1]) + np.float32(v[2] * v[2]))
+                if d < best[0]:
+                    best = [d, best[0], best[1]]; bi = [k, bi[0], bi[1]]
+                elif d < best[1]:
+                    best = [best[0], d, best[1]]; bi = [bi[0], k, bi[1]]
+                elif d < best[2]:
+                    best[2] = d; bi[2] = k
+            with np.errstate(over="ignore"):
+                d2[b, i] = np.array(best, np.float64).astype(np.float32); idx[b, i] = bi
+    return d2, idx
+
+
+@pytest.mark.parametrize("M", [2, 3, 40])
+def test_three_nn_oracle_vs_python_restatement(oracle_backend, M):
+    B, N = 2, 30
+    unk, kn = _grid_cloud(B, N, 11, span=2), _grid_cloud(B, M, 12, span=2)      # small span: many equal distances
+    d2 = torch.empty(B, N, 3); idx = torch.empty(B, N, 3, dtype=torch.int32)
+    oracle_backend.three_nn_wrapper(B, N, M, unk, kn, d2, idx)
+    wd, wi = _three_nn_python(unk.numpy(), kn.numpy())
+    assert np.array_equal(idx.numpy(), wi)
+    assert np.array_equal(d2.numpy(), wd)                   # (M = 2: the third best stays 1e40 -> inf as float, index 0)

@@ -97,6 +97,44 @@ def run(cfg_name, tag, B, N, img_h, img_w, seed, beams):
           "size", (OUT / f"model_{tag}.npz").stat().st_size)
 
 
+def run_train(cfg_name, tag, B, N, img_h, img_w, seed, beams):
+    """TRAIN-mode step of the main model: image-encoder BatchNorm2d layers normalise with batch
+    statistics and update their running buffers, dropout present but with p = 0 (its RNG stream is not portable)."""
+    RegNet, cfg, Get_loss = ref_harness.load_model(cfg_name)
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = RegNet(cfg=cfg)
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    model.load_state_dict(synthetic_state(shapes, seed=seed))
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    batch = synth.make_batch(B, N, img_h, img_w, seed=seed, beams=beams, fup=cfg.fup, fdown=cfg.fdown,
+                             unique_cells=(cfg.init_H, cfg.init_W))
+    out3, out4, _, _, sx, sq = model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"], batch["init_extrinsic"],
+                                     batch["init_intrinsic"], None, None, None, batch["lidar_feats"], cfg=cfg)
+    loss, lq, lx = Get_loss(out3, out4, batch["decalib_real_gt"], batch["decalib_dual_gt"], sx, sq, cfg=cfg)
+    loss.backward()
+    data = {"out3": out3.detach().numpy(), "out4": out4.detach().numpy(),
+            "loss": np.array([loss.item(), lq.item(), lx.item()], np.float64)}
+    keys, gn = [], []
+    for k, p in model.named_parameters():
+        keys.append(k); gn.append(0.0 if p.grad is None else float(p.grad.double().norm()))
+    data["grad_keys"] = np.array(keys); data["grad_norm"] = np.array(gn)
+    bk, bs, ba = [], [], []
+    for k, v in model.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"):
+            bk.append(k); bs.append(float(v.double().sum())); ba.append(float(v.double().abs().sum()))
+    data["buf_keys"] = np.array(bk); data["buf_sum"] = np.array(bs); data["buf_abs_sum"] = np.array(ba)
+    data["state_keys"] = np.array([k for k, _ in shapes])
+    data["state_shapes"] = np.array([",".join(map(str, s)) for _, s in shapes])
+    data["meta"] = np.array([cfg_name, str(B), str(N), str(img_h), str(img_w), str(seed), str(beams)])
+    np.savez_compressed(OUT / f"model_{tag}.npz", **data)
+    print(tag, "out3", out3.detach().numpy().round(4).tolist(), "loss", loss.item(), "buffers", len(bk),
+          "size", (OUT / f"model_{tag}.npz").stat().st_size)
+
+
 def run_iter(cfg_name, tag, B, N, img_h, img_w, seed, beams):
     """iterative fine registration (src/modellearn_proj_center_iter.py): forward outputs only"""
     RegNet, cfg, _ = ref_harness.load_model(cfg_name, module="modellearn_proj_center_iter")
@@ -341,6 +379,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sa":
         run_set_abstraction()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        run_train("config_proj_lidarcenter", "kitti_train", B=2, N=8192, img_h=375, img_w=1242, seed=7, beams=64)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "iter":
         run_iter("config_proj_lidarcenter", "kitti_iter", B=2, N=8192, img_h=375, img_w=1242, seed=3, beams=64)
