@@ -65,7 +65,8 @@ inline bool i2p_atomic_scatter() { static const char *e = getenv("I2P_ATOMIC_SCA
 bool i2p_wreg_fwd_ok(long long rows, int cin, int cout);
 int i2p_wreg_fwd(long long rows, int cin, int cout, const float *x, int x_ld, const float *in_coef, float slope, const float *w,
                  float *y, int y_ld, double *sums, unsigned *fin_counter, const float *fin_gamma, const float *fin_beta,
-                 float fin_eps, float *fin_coef, float *fin_mi, void *stream);
+                 float fin_eps, float *fin_coef, float *fin_mi, void *stream, const float *xb = nullptr,
+                 const float *in_coef_b = nullptr, float slope_b = 1.f);
 bool i2p_wreg_dgrad_ok(long long rows, int k, int c);
 int i2p_wreg_dgrad(long long rows, int k, int c, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
                    const float *g_omi, long long g_rows, const float *w, float *gz_in, const float *ex, const float *e_coef,

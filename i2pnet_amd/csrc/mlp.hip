@@ -1730,11 +1730,12 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
     if (rows == 0) return 0;
     if (!x || !w || !y) return I2P_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (!pair_f && !xb && i2p_wreg_fwd_ok(rows, cin, cout) && slope_in >= 0.f && slope_in <= 1.f) {  // wide layer on many rows: weights stationary in registers
+    const bool two_ok3 = !xb || (split_c * 2 == cin && in_coef && in_coef_b && slope_b >= 0.f && slope_b <= 1.f);
+    if (!pair_f && two_ok3 && i2p_wreg_fwd_ok(rows, cin, cout) && slope_in >= 0.f && slope_in <= 1.f) {  // wide layer on many rows: weights stationary in registers
         fin_done = fin != nullptr;
-        return i2p_wreg_fwd(rows, cin, cout, x, cin, in_coef, slope_in, w, y, cout, sums, fin ? fin->counter : nullptr,
+        return i2p_wreg_fwd(rows, cin, cout, x, xb ? split_c : cin, in_coef, slope_in, w, y, cout, sums, fin ? fin->counter : nullptr,
                             fin ? fin->gamma : nullptr, fin ? fin->beta : nullptr, fin ? fin->eps : 0.f, fin ? fin->coef : nullptr,
-                            fin ? fin->mi : nullptr, stream);
+                            fin ? fin->mi : nullptr, stream, xb, in_coef_b, slope_b);
     }
     {
         const char *ab = getenv("I2P_LIN_FWD_GEN");            // diagnostic: "1" forces the first-generation kernel

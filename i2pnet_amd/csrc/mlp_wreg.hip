@@ -42,6 +42,7 @@ struct WregP {
     const float *x; int x_ld;
     const float *in_coef;        // [3][CIN] mean, scale, beta or nullptr
     float slope;
+    const float *xb, *in_coef_b; float slope_b;      // second source (two-source instantiation: x_ld = CIN/2 for both)
     const float *w;              // [COUT][CIN]
     float *y; int y_ld;
     double *sums;                // [REP][2*COUT] or nullptr
@@ -55,7 +56,9 @@ __device__ __forceinline__ void sty(float *ptr, const f32x4 &v) {
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4_nt *>(ptr));
 }
 
-template <int CIN, int COUT, bool BN_IN>
+// TWO: the input is two tensors of CIN/2 channels each (x, xb; own BN constants and slopes) — the layer after a
+// concatenation without the concatenation (mlp.hip i2p_lin_fwd_2src is the general version).
+template <int CIN, int COUT, bool BN_IN, bool TWO>
 __global__ __launch_bounds__(WR_THREADS, 1) void wreg_fwd_kernel(WregP p) {
     constexpr int NT = COUT / 16;          // output tiles of 16 channels
     constexpr int L = CIN / 4;             // MFMA k-steps = channels per k-slot
@@ -70,9 +73,12 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_fwd_kernel(WregP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform on purpose: strip counters and steps live in SGPRs
     const int m = lane & 15, q = lane >> 4;
     if (BN_IN) {
+        constexpr int CS = TWO ? CIN / 2 : CIN;                 // channels per source
         for (int c = tid; c < CIN; c += NTHREADS) {
-            const float a = p.in_coef[CIN + c];
-            tab[c] = a; tab[CIN + c] = p.in_coef[2 * CIN + c] - p.in_coef[c] * a;
+            const float *cf = (TWO && c >= CS) ? p.in_coef_b : p.in_coef;
+            const int cc = (TWO && c >= CS) ? c - CS : c;
+            const float a = cf[CS + cc];
+            tab[c] = a; tab[CIN + c] = cf[2 * CS + cc] - cf[cc] * a;
         }
         __syncthreads();
     }
@@ -95,6 +101,8 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_fwd_kernel(WregP p) {
     if (n_mine > 0) {
         const size_t x_step = (size_t)stride * WR_ROWS * p.x_ld, y_step = (size_t)stride * WR_ROWS * p.y_ld;
         const float *xsrc = p.x + ((size_t)first * WR_ROWS + m) * p.x_ld + 4 * q;      // strip being LOADED
+        const float *xsrc2 = TWO ? p.xb + ((size_t)first * WR_ROWS + m) * p.x_ld + 4 * q : nullptr;
+        auto xptr = [&](int f) -> const float * { return (TWO && f >= NF / 2) ? xsrc2 + 16 * (f - NF / 2) : xsrc + 16 * f; };
         float *ydst = p.y + ((size_t)first * WR_ROWS + m) * p.y_ld + 4 * q;            // strip being STORED
         int loaded = 0;                                          // strips of this wave requested so far - 1
 
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_fwd_kernel(WregP p) {
                 for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], ca[f & 1][e], cb[f & 1][e]);
             } else if (part == 1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) zs[e] = v[e] * p.slope;
+                for (int e = 0; e < 4; ++e) zs[e] = v[e] * ((TWO && f >= NF / 2) ? p.slope_b : p.slope);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(v[e], zs[e]);
@@ -151,14 +159,14 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_fwd_kernel(WregP p) {
         static_assert(SP >= 3 && 2 * SP >= LAT + 3, "slot plan");      // (constants: two groups in flight)
         auto strip_block = [&](auto epi_tag, f32x4 (&xc)[NF], f32x4 (&xn)[NF], f32x4 (&acc)[NT], f32x4 (&prev)[NT]) {
             constexpr bool EPI = decltype(epi_tag)::value;
-            if (loaded + 1 < n_mine) { xsrc += x_step; ++loaded; }   // (past the end: the last strip again, never used)
+            if (loaded + 1 < n_mine) { xsrc += x_step; if (TWO) xsrc2 += x_step; ++loaded; }   // (past the end: the last strip again, never used)
 #pragma unroll
             for (int i = 0; i < NMF; ++i) {
                 const int t = i / NT, j = i % NT, f = t >> 2, e = t & 3;
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][f][e], xc[f][e], t == 0 ? zero : acc[j], 0, 0, 0);
                 if (i == 4 * NT * (f + 1) - 1 && (f & 1) && !(WREG_ABL & 4)) {   // both halves of a 128-byte line together
-                    xc[f - 1] = ldx(xsrc + 16 * (f - 1)); xc[f] = ldx(xsrc + 16 * f);
+                    xc[f - 1] = ldx(xptr(f - 1)); xc[f] = ldx(xptr(f));
                 }
                 if (EPI && i < E_END) {
                     const int tj = i / 5, part = i % 5;                  // tile whose rows are REQUESTED / stored in this slot
@@ -190,10 +198,10 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_fwd_kernel(WregP p) {
         };
         f32x4 xa[NF], xb[NF], accA[NT], accB[NT];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) xa[f] = ldx(xsrc + 16 * f);
-        if (1 < n_mine) { xsrc += x_step; ++loaded; }
+        for (int f = 0; f < NF; ++f) xa[f] = ldx(xptr(f));
+        if (1 < n_mine) { xsrc += x_step; if (TWO) xsrc2 += x_step; ++loaded; }
 #pragma unroll
-        for (int f = 0; f < NF; ++f) xb[f] = ldx(xsrc + 16 * f);
+        for (int f = 0; f < NF; ++f) xb[f] = ldx(xptr(f));
         if (BN_IN) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
@@ -264,8 +272,9 @@ int launch_wreg(const WregP &p, hipStream_t st) {
     const long long nstrips = p.rows / WR_ROWS;
     long long grid = (nstrips + 3) / 4;
     if (grid > 256) grid = 256;
-    if (p.in_coef) hipLaunchKernelGGL((wreg_fwd_kernel<CIN, COUT, true>), dim3((unsigned)grid), dim3(WR_THREADS), 0, st, p);
-    else hipLaunchKernelGGL((wreg_fwd_kernel<CIN, COUT, false>), dim3((unsigned)grid), dim3(WR_THREADS), 0, st, p);
+    if (p.xb) hipLaunchKernelGGL((wreg_fwd_kernel<CIN, COUT, true, true>), dim3((unsigned)grid), dim3(WR_THREADS), 0, st, p);
+    else if (p.in_coef) hipLaunchKernelGGL((wreg_fwd_kernel<CIN, COUT, true, false>), dim3((unsigned)grid), dim3(WR_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((wreg_fwd_kernel<CIN, COUT, false, false>), dim3((unsigned)grid), dim3(WR_THREADS), 0, st, p);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
@@ -1055,10 +1064,13 @@ bool i2p_wreg_fwd_ok(long long rows, int cin, int cout) {
 
 int i2p_wreg_fwd(long long rows, int cin, int cout, const float *x, int x_ld, const float *in_coef, float slope, const float *w,
                  float *y, int y_ld, double *sums, unsigned *fin_counter, const float *fin_gamma, const float *fin_beta,
-                 float fin_eps, float *fin_coef, float *fin_mi, void *stream) {
+                 float fin_eps, float *fin_coef, float *fin_mi, void *stream, const float *xb, const float *in_coef_b,
+                 float slope_b) {
     if (!i2p_wreg_fwd_ok(rows, cin, cout) || (x_ld & 3) || (y_ld & 3) || !(slope >= 0.f && slope <= 1.f)) return I2P_ERR_BAD_ARG;
     WregP p;
+    if (xb && (x_ld * 2 != cin || !in_coef || !in_coef_b || !(slope_b >= 0.f && slope_b <= 1.f))) return I2P_ERR_BAD_ARG;
     p.rows = rows; p.x = x; p.x_ld = x_ld; p.in_coef = in_coef; p.slope = slope; p.w = w; p.y = y; p.y_ld = y_ld; p.sums = sums;
+    p.xb = xb; p.in_coef_b = in_coef_b; p.slope_b = slope_b;
     p.fin_counter = fin_counter; p.fin_gamma = fin_gamma; p.fin_beta = fin_beta; p.fin_eps = fin_eps; p.fin_coef = fin_coef; p.fin_mi = fin_mi;
     hipStream_t st = (hipStream_t)stream;
     if (cin == 128 && cout == 128) return launch_wreg<128, 128>(p, st);
