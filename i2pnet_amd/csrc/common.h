@@ -70,7 +70,9 @@ int i2p_wreg_fwd(long long rows, int cin, int cout, const float *x, int x_ld, co
 bool i2p_wreg_dgrad_ok(long long rows, int k, int c);
 int i2p_wreg_dgrad(long long rows, int k, int c, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
                    const float *g_omi, long long g_rows, const float *w, float *gz_in, const float *ex, const float *e_coef,
-                   const float *e_mi, float e_slope, double *sums, void *stream);
+                   const float *e_mi, float e_slope, double *sums, void *stream, float *gz_in_b = nullptr,
+                   const float *exb = nullptr, const float *e_coef_b = nullptr, const float *e_mi_b = nullptr, float e_slope_b = 1.f,
+                   const float *e_add = nullptr, double *sums_b = nullptr);
 bool i2p_wreg_wgrad_ok(long long rows, int cin, int cout);
 int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
                    const float *g_omi, long long g_rows, float *bn_out, const float *x, const float *in_coef, float slope_in,

@@ -1932,10 +1932,15 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
                                    out_mi, g_coef);
         }
         if (gen2) {
-            if (gz_in && !two && out_coef && p.slope_out == 1.f && in_coef && i2p_wreg_dgrad_ok(rows, cout, cin)) {
+            const bool two_d3 = !two || (two->split_c * 2 == cin && two->in_coef_b && two->in_mi_b && two->e_add && two->gz_in_b &&
+                                         two->in_dsums_b && in_dsums);
+            if (gz_in && two_d3 && out_coef && p.slope_out == 1.f && in_coef && i2p_wreg_dgrad_ok(rows, cout, cin)) {
                 // wide layer on many rows, plain BN on both sides: weights stationary in registers (csrc/mlp_wreg.hip)
-                const int rc = i2p_wreg_dgrad(rows, cout, cin, gz, y, out_dsums, out_coef, out_mi, rows, w, gz_in, x, in_coef, in_mi,
-                                              slope_in, in_dsums, stream);
+                const int rc = two ? i2p_wreg_dgrad(rows, cout, cin, gz, y, out_dsums, out_coef, out_mi, rows, w, gz_in, x, in_coef, in_mi,
+                                                    slope_in, in_dsums, stream, two->gz_in_b, two->xb, two->in_coef_b, two->in_mi_b,
+                                                    two->slope_b, two->e_add, two->in_dsums_b)
+                                   : i2p_wreg_dgrad(rows, cout, cin, gz, y, out_dsums, out_coef, out_mi, rows, w, gz_in, x, in_coef, in_mi,
+                                                    slope_in, in_dsums, stream);
                 if (rc) return rc;
             } else if (gz_in) {
                 LinFwdParams q;

@@ -302,10 +302,16 @@ struct WregDgradP {
     const float *e_coef, *e_mi;  // [3][C], [2][C] of the BN in front
     float e_slope;
     double *sums;                // [REP][2*C] {sum g, sum g * xhat_in}
+    // two destinations (TWO instantiation): result columns [0, C/2) -> gz_in [rows, C/2] with ex / e_coef / e_mi / sums
+    // of C/2 channels, columns [C/2, C) -> gz_in_b with exb / e_coef_b / e_mi_b / sums_b, and e_add [rows, C/2] added to
+    // the second half before its activation derivative (the gradient that reaches that tensor on another path)
+    float *gz_in_b; const float *exb, *e_coef_b, *e_mi_b, *e_add; float e_slope_b; double *sums_b;
 };
 
-template <int K, int C>
+template <int K, int C, bool TWO>
 __global__ __launch_bounds__(WR_THREADS, 1) void wreg_dgrad_kernel(WregDgradP p) {
+    constexpr int CD = TWO ? C / 2 : C;    // channels (= row pitch) of a destination
+    constexpr int NTD = CD / 16;           // tiles per destination
     constexpr int NT = C / 16;             // output tiles of 16 channels
     constexpr int L = K / 4;               // MFMA k-steps
     constexpr int NF = L / 4;              // float4 of gz (and of y) per lane and row
@@ -326,8 +332,11 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_dgrad_kernel(WregDgradP p)
         gt[ch] = sc; gt[K + ch] = -sc * m1 - bc * mu; gt[2 * K + ch] = bc;
     }
     for (int ch = tid; ch < C; ch += WR_THREADS) {
-        const float mean = p.e_coef[ch], sc = p.e_coef[C + ch], is = p.e_mi[C + ch];
-        et[ch] = sc; et[C + ch] = p.e_coef[2 * C + ch] - mean * sc; et[2 * C + ch] = is; et[3 * C + ch] = -mean * is;
+        const bool sb = TWO && ch >= CD;
+        const float *cf = sb ? p.e_coef_b : p.e_coef, *mi = sb ? p.e_mi_b : p.e_mi;
+        const int cc = sb ? ch - CD : ch;
+        const float mean = cf[cc], sc = cf[CD + cc], is = mi[CD + cc];
+        et[ch] = sc; et[C + ch] = cf[2 * CD + cc] - mean * sc; et[2 * C + ch] = is; et[3 * C + ch] = -mean * is;
     }
 #pragma unroll
     for (int i = 0; i < 2 * NT; ++i) st_lds[i][tid] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -347,29 +356,37 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_dgrad_kernel(WregDgradP p)
     const long long first = (long long)blockIdx.x * 4 + wave;
     const int n_mine = first < nstrips ? (int)((nstrips - first + stride - 1) / stride) : 0;
     if (n_mine > 0) {
-        const size_t k_step = (size_t)stride * WR_ROWS * K, c_step = (size_t)stride * WR_ROWS * C;
+        // BYTE offsets in 32 bits (launcher: every tensor < 4 GB): uniform base pointer + 32-bit lane offset is the scalar-base
+        // addressing form of global_load / global_store, one VGPR per address instead of a 64-bit pair and its arithmetic
+        const unsigned k_step = (unsigned)(stride * WR_ROWS * K * 4), c_step = (unsigned)(stride * WR_ROWS * CD * 4);
         // element offset of this lane's float4 #0 in the [rows, K] tensors: the strip being REQUESTED (k+1, clamped to the last)
-        size_t koff1 = ((size_t)first * WR_ROWS + m) * K + 4 * q;
+        unsigned koff1 = (unsigned)((((size_t)first * WR_ROWS + m) * K + 4 * q) * 4);
         int loaded = 0;
         auto advance = [&]() { if (loaded + 1 < n_mine) { koff1 += k_step; ++loaded; } };
         // [rows, C] tensors: strip being computed (its x rows are requested) and strip being stored
-        size_t coff_cur = ((size_t)first * WR_ROWS + m) * C + 4 * q, coff_prev = coff_cur;
+        unsigned coff_cur = (unsigned)((((size_t)first * WR_ROWS + m) * CD + 4 * q) * 4), coff_prev = coff_cur;
+        auto at = [](const float *base, unsigned byte_off) -> const float * { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); };
+        auto atw = [](float *base, unsigned byte_off) -> float * { return reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off); };
+        // destination of output tile j (compile-time j): pointers, column, slope
+        auto dst_of = [&](int j) -> float * { return (TWO && j >= NTD) ? p.gz_in_b + 16 * (j - NTD) : p.gz_in + 16 * j; };
+        auto ex_of = [&](int j) -> const float * { return (TWO && j >= NTD) ? p.exb + 16 * (j - NTD) : p.ex + 16 * j; };
+        auto slope_of = [&](int j) -> float { return (TWO && j >= NTD) ? p.e_slope_b : p.e_slope; };
 
         const float *gq = gt + 4 * q, *eq = et + 4 * q;
         f32x4 tsc, tac, tbc, tu;                                 // constants of the input float4 being normalised
         tsc = tac = tbc = tu = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 esc, ezb, eis, enm, r1, r2, ez, et_, ev, exh, vkeep; // store-phase constants / statistics rows / temporaries
-        esc = ezb = eis = enm = r1 = r2 = ez = et_ = ev = exh = vkeep = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 esc, ezb, eis, enm, r1, r2, ez, ev, vkeep;          // store-phase constants / statistics rows / temporaries
+        esc = ezb = eis = enm = r1 = r2 = ez = ev = vkeep = f32x4{0.f, 0.f, 0.f, 0.f};
         constexpr int LAT = 5;                                   // slots between an LDS read and its use
         constexpr int PE = 10;                                   // store-phase slots per output tile
         static_assert(PE * NT <= NMF && LAT + 2 <= G, "slot plan");
 
-        f32x4 x[NF], yb[NF], exr[NT], accA[NT], accB[NT];
-        auto epi_math = [&](const f32x4 &acc, const f32x4 &xr, f32x4 &v, f32x4 &xh) {
+        f32x4 x[NF], yb[NF], exr[NT], ead[TWO ? NTD : 1], accA[NT], accB[NT];
+        auto epi_math = [&](const f32x4 &acc, const f32x4 &xr, float slope, f32x4 &v, f32x4 &xh) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float z = __builtin_fmaf(xr[c], esc[c], ezb[c]);
-                v[c] = z > 0.f ? acc[c] : acc[c] * p.e_slope;
+                v[c] = z > 0.f ? acc[c] : acc[c] * slope;
                 xh[c] = __builtin_fmaf(xr[c], eis[c], enm[c]);
             }
         };
@@ -378,14 +395,15 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_dgrad_kernel(WregDgradP p)
             for (int j = 0; j < NT; ++j) {
                 esc = *reinterpret_cast<const f32x4 *>(eq + 16 * j); ezb = *reinterpret_cast<const f32x4 *>(eq + C + 16 * j);
                 eis = *reinterpret_cast<const f32x4 *>(eq + 2 * C + 16 * j); enm = *reinterpret_cast<const f32x4 *>(eq + 3 * C + 16 * j);
-                f32x4 v, xh;
-                epi_math(prev[j], exr[j], v, xh);
+                f32x4 v, xh, pj = prev[j];
+                if (TWO && j >= NTD) pj += ead[j - NTD];
+                epi_math(pj, exr[j], slope_of(j), v, xh);
                 f32x4 a = st_lds[j][tid], b = st_lds[NT + j][tid];
                 a += v;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) b[c] = __builtin_fmaf(v[c], xh[c], b[c]);
                 st_lds[j][tid] = a; st_lds[NT + j][tid] = b;
-                sty(p.gz_in + coff_prev + 16 * j, v);
+                sty(atw(dst_of(j), coff_prev), v);
             }
         };
         auto tf_all = [&](int f) {                               // prologue: g^y of float4 f, not slotted
@@ -411,7 +429,7 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_dgrad_kernel(WregDgradP p)
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][f][e], x[f][e], t == 0 ? zero : acc[j], 0, 0, 0);
                 // ---- input side -----------------------------------------------------------------------------------
                 if (i == G * (f + 1) - 1 && (f & 1)) {                                // gz of the next strip, one 128-byte line per row
-                    x[f - 1] = ldx(p.gz + koff1 + 16 * (f - 1)); x[f] = ldx(p.gz + koff1 + 16 * f);
+                    x[f - 1] = ldx(at(p.gz + 16 * (f - 1), koff1)); x[f] = ldx(at(p.gz + 16 * f, koff1));
                 }
                 {
                     const int fn = (f + 1) % NF, u = i - G * f;                       // float4 normalised during this group
@@ -428,7 +446,7 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_dgrad_kernel(WregDgradP p)
                         for (int c = 0; c < 4; ++c) x[fn][c] = __builtin_fmaf(tsc[c], x[fn][c], tu[c]);
                         // y of the next strip, one 128-byte line per row at a time: float4 0 (consumed in the last group of the
                         // previous strip) waits for float4 1 (consumed in this strip's first group)
-                        if (fn & 1) { yb[fn - 1] = ldx(p.y2 + koff1 + 16 * (fn - 1)); yb[fn] = ldx(p.y2 + koff1 + 16 * fn); }
+                        if (fn & 1) { yb[fn - 1] = ldx(at(p.y2 + 16 * (fn - 1), koff1)); yb[fn] = ldx(at(p.y2 + 16 * fn, koff1)); }
                     }
                 }
                 // ---- store phase of the previous strip --------------------------------------------------------------
@@ -441,31 +459,35 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_dgrad_kernel(WregDgradP p)
                     if (part == 1) { eis = *reinterpret_cast<const f32x4 *>(eq + 2 * C + 16 * tj); enm = *reinterpret_cast<const f32x4 *>(eq + 3 * C + 16 * tj); }
                     if (part == LAT) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) { ez[c] = __builtin_fmaf(exr[tj][c], esc[c], ezb[c]); et_[c] = prev[tj][c] * p.e_slope; }
+                        for (int c = 0; c < 4; ++c) ez[c] = __builtin_fmaf(exr[tj][c], esc[c], ezb[c]);
+                        ev = prev[tj];
+                        if (TWO && tj >= NTD) ev += ead[tj - NTD];
                     }
                     if (part == LAT + 1) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) ev[c] = ez[c] > 0.f ? prev[tj][c] : et_[c];
-                        if (tj & 1) { sty(p.gz_in + coff_prev + 16 * (tj - 1), vkeep); sty(p.gz_in + coff_prev + 16 * tj, ev); }
+                        for (int c = 0; c < 4; ++c) ev[c] = ez[c] > 0.f ? ev[c] : ev[c] * slope_of(tj);
+                        if (tj & 1) { sty(atw(dst_of(tj - 1), coff_prev), vkeep); sty(atw(dst_of(tj), coff_prev), ev); }
                         else vkeep = ev;
                     }
-                    if (part == LAT + 2) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) exh[c] = __builtin_fmaf(exr[tj][c], eis[c], enm[c]);
-                        r1 += ev; st_lds[tj][tid] = r1;
-                    }
+                    if (part == LAT + 2) { r1 += ev; st_lds[tj][tid] = r1; }
                     if (part == LAT + 3) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) r2[c] = __builtin_fmaf(ev[c], exh[c], r2[c]);
+                        for (int c = 0; c < 4; ++c) r2[c] = __builtin_fmaf(ev[c], __builtin_fmaf(exr[tj][c], eis[c], enm[c]), r2[c]);
                         st_lds[NT + tj][tid] = r2;
-                        if (tj & 1) { exr[tj - 1] = ldx(p.ex + coff_cur + 16 * (tj - 1)); exr[tj] = ldx(p.ex + coff_cur + 16 * tj); }   // x rows of the strip being computed
+                        if (tj & 1) {                                             // rows of the strip being computed, for its store phase
+                            exr[tj - 1] = ldx(at(ex_of(tj - 1), coff_cur)); exr[tj] = ldx(at(ex_of(tj), coff_cur));
+                            if (TWO && tj >= NTD) { ead[tj - 1 - NTD] = ldx(at(p.e_add + 16 * (tj - 1 - NTD), coff_cur)); ead[tj - NTD] = ldx(at(p.e_add + 16 * (tj - NTD), coff_cur)); }
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (!EPI) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) exr[j] = ldx(p.ex + coff_cur + 16 * j);
+                for (int j = 0; j < NT; ++j) {
+                    exr[j] = ldx(at(ex_of(j), coff_cur));
+                    if (TWO && j >= NTD) ead[j - NTD] = ldx(at(p.e_add + 16 * (j - NTD), coff_cur));
+                }
             }
             coff_prev = coff_cur; coff_cur += c_step;                // (past the end: never dereferenced again)
             advance();
@@ -473,7 +495,7 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_dgrad_kernel(WregDgradP p)
 
         // prologue: strip 0 raw in x / yb, float4 0 normalised
 #pragma unroll
-        for (int f = 0; f < NF; ++f) { x[f] = ldx(p.gz + koff1 + 16 * f); yb[f] = ldx(p.y2 + koff1 + 16 * f); }
+        for (int f = 0; f < NF; ++f) { x[f] = ldx(at(p.gz + 16 * f, koff1)); yb[f] = ldx(at(p.y2 + 16 * f, koff1)); }
         advance();                                               // koff1 = strip 1 (clamped)
         tf_all(0);
         strip_block(std::false_type{}, accA, accB);              // k = 0
@@ -499,8 +521,9 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_dgrad_kernel(WregDgradP p)
 #pragma unroll
                 for (int off = 8; off >= 1; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
                 if (m == 0) {
-                    double *rep = p.sums + (size_t)((blockIdx.x * 4 + wave) % REP) * 2 * C;
-                    atomicAdd(rep + 16 * j + 4 * q + e, a); atomicAdd(rep + C + 16 * j + 4 * q + e, b);
+                    double *rep = ((TWO && j >= NTD) ? p.sums_b : p.sums) + (size_t)((blockIdx.x * 4 + wave) % REP) * 2 * CD;
+                    const int ch = 16 * (TWO && j >= NTD ? j - NTD : j) + 4 * q + e;
+                    atomicAdd(rep + ch, a); atomicAdd(rep + CD + ch, b);
                 }
             }
     }
@@ -511,7 +534,8 @@ int launch_wreg_dgrad(const WregDgradP &p, hipStream_t st) {
     const long long nstrips = p.rows / WR_ROWS;
     long long grid = (nstrips + 3) / 4;
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL((wreg_dgrad_kernel<K, C>), dim3((unsigned)grid), dim3(WR_THREADS), 0, st, p);
+    if (p.gz_in_b) hipLaunchKernelGGL((wreg_dgrad_kernel<K, C, true>), dim3((unsigned)grid), dim3(WR_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((wreg_dgrad_kernel<K, C, false>), dim3((unsigned)grid), dim3(WR_THREADS), 0, st, p);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
@@ -1087,12 +1111,16 @@ bool i2p_wreg_dgrad_ok(long long rows, int k, int c) {
 
 int i2p_wreg_dgrad(long long rows, int k, int c, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
                    const float *g_omi, long long g_rows, const float *w, float *gz_in, const float *ex, const float *e_coef,
-                   const float *e_mi, float e_slope, double *sums, void *stream) {
+                   const float *e_mi, float e_slope, double *sums, void *stream, float *gz_in_b, const float *exb,
+                   const float *e_coef_b, const float *e_mi_b, float e_slope_b, const float *e_add, double *sums_b) {
     if (!i2p_wreg_dgrad_ok(rows, k, c) || !gz || !y2 || !g_dsums || !g_oc || !g_omi || !w || !gz_in || !ex || !e_coef || !e_mi)
         return I2P_ERR_BAD_ARG;
+    if (gz_in_b && (!exb || !e_coef_b || !e_mi_b || !e_add || !sums || !sums_b)) return I2P_ERR_BAD_ARG;
+    if ((unsigned long long)rows * (unsigned)(k > c ? k : c) * 4ull >= (1ull << 32)) return I2P_ERR_BAD_ARG;     // 32-bit byte offsets
     WregDgradP p;
     p.rows = rows; p.gz = gz; p.y2 = y2; p.g_dsums = g_dsums; p.g_oc = g_oc; p.g_omi = g_omi; p.g_rows = g_rows; p.w = w;
     p.gz_in = gz_in; p.ex = ex; p.e_coef = e_coef; p.e_mi = e_mi; p.e_slope = e_slope; p.sums = sums;
+    p.gz_in_b = gz_in_b; p.exb = exb; p.e_coef_b = e_coef_b; p.e_mi_b = e_mi_b; p.e_slope_b = e_slope_b; p.e_add = e_add; p.sums_b = sums_b;
     hipStream_t st = (hipStream_t)stream;
     if (k == 128 && c == 128) return launch_wreg_dgrad<128, 128>(p, st);
     if (k == 128 && c == 64) return launch_wreg_dgrad<128, 64>(p, st);
