@@ -1958,7 +1958,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
                 const int rc = dispatch_fwd2<false, true>(q, st);
                 if (rc) return rc;
             }
-            const bool two_ok = !two || (in_coef && two->in_coef_b && two->split_c * 2 == cin && two->slope_b >= 0.f && two->slope_b <= 1.f);
+            const bool two_ok = !two || (in_coef && two->in_coef_b && two->split_c * 2 == cin && cin == 128 && two->slope_b >= 0.f && two->slope_b <= 1.f);
             if (two_ok && out_coef && p.slope_out == 1.f && slope_in >= 0.f && slope_in <= 1.f && grid == 256 &&
                 i2p_wreg_wgrad_ok(rows, cin, cout)) {
                 // wide layer on many rows: the [cout][cin] accumulators stationary in registers (csrc/mlp_wreg.hip)

@@ -596,24 +596,24 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
         cbc[h] = *reinterpret_cast<const f32x4 *>(gtab + 2 * CO + NO * n + 4 * h);
     }
     // source of this lane's x columns (its NI channels never straddle the split)
-    // (one-source instantiation: everything below is uniform / compile-time — the per-lane pointer, pitch and slope of
-    //  the two-source one cost the registers that keep the 128x128 kernel free of spills inside its loop)
-    const bool second = TWO && NI * n >= p.split;
-    constexpr int x_ld = TWO ? CI / 2 : CI;                        // (two sources: the launcher takes split == CI/2 only)
-    const float *xsrc = second ? p.xb : p.x;
-    const int x_col = second ? NI * n - p.split : NI * n;
-    const float *xcoef = second ? p.in_coef_b : p.in_coef;
-    const float x_slope = second ? p.slope_b : p.slope_in;
+    // x columns of this lane.  One source: its NI channels NI*n .. NI*n+NI-1 (float4 h = channels NI*n + 4h ..).
+    // Two sources of CI/2 channels (HI == 2): float4 0 = channels 4n..4n+3 of x, float4 1 = channels 4n..4n+3 of xb, i.e.
+    // tile jc <-> channel (jc < 4 ? 4n + jc : CI/2 + 4n + jc - 4): every load instruction has ONE uniform base pointer
+    // (scalar-base addressing, 32-bit lane offsets) and covers whole 256-byte rows.
+    static_assert(!TWO || HI == 2, "two-source wgrad: CI = 128");
+    constexpr int x_ld = TWO ? CI / 2 : CI;
+    auto xchan = [&](int h) -> int { return TWO ? h * (CI / 2) + 4 * n : NI * n + 4 * h; };      // first channel of float4 h
 #pragma unroll
     for (int h = 0; h < HI; ++h) {
         cxa[h] = f32x4{1.f, 1.f, 1.f, 1.f}; cxb[h] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (BN_IN) {
-            const f32x4 mu = *reinterpret_cast<const f32x4 *>(xcoef + x_col + 4 * h);
-            cxa[h] = *reinterpret_cast<const f32x4 *>(xcoef + x_ld + x_col + 4 * h);
-            cxb[h] = *reinterpret_cast<const f32x4 *>(xcoef + 2 * x_ld + x_col + 4 * h) - mu * cxa[h];
+            const float *cf = (TWO && h == 1) ? p.in_coef_b : p.in_coef;
+            const int cc = TWO ? 4 * n : NI * n + 4 * h;
+            const f32x4 mu = *reinterpret_cast<const f32x4 *>(cf + cc);
+            cxa[h] = *reinterpret_cast<const f32x4 *>(cf + x_ld + cc);
+            cxb[h] = *reinterpret_cast<const f32x4 *>(cf + 2 * x_ld + cc) - mu * cxa[h];
         }
     }
-
     f32x4 acc[NO][NI];
 #pragma unroll
     for (int jo = 0; jo < NO; ++jo)
@@ -623,25 +623,32 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
     const long long nstrips = p.rows / WR_ROWS;
     const long long stride = (long long)gridDim.x * 4;
     const long long first = (long long)blockIdx.x * 4 + wave;
-    const int n_mine = first < nstrips ? (int)((nstrips - first + stride - 1) / stride) : 0;
+    // (scalar strip count: scalar loop branch and no spill reload inside the loop of the one-source instantiations; the
+    //  two-source one is spill-free in its loop without it and not with it — clang 19 register allocation, checked in the ISA)
+    const int n_mine_v = first < nstrips ? (int)((nstrips - first + stride - 1) / stride) : 0;
+    const int n_mine = TWO ? n_mine_v : __builtin_amdgcn_readfirstlane(n_mine_v);
     if (n_mine > 0) {
         // element offsets of row 4q of the strip being REQUESTED: k-slot q owns rows 4q..4q+3, k-step t takes row 4q + t (any
         // bijection rows <-> (slot, step) gives the same sum; this one keeps the per-step offsets inside the load immediates)
-        size_t goff = ((size_t)first * WR_ROWS + 4 * q) * CO + NO * n, xoff = ((size_t)first * WR_ROWS + 4 * q) * x_ld + x_col;
-        const size_t g_step = (size_t)stride * WR_ROWS * CO, x_step = (size_t)stride * WR_ROWS * x_ld;
+        // (BYTE offsets in 32 bits against uniform base pointers, launcher: every tensor < 4 GB)
+        unsigned goff = (unsigned)((((size_t)first * WR_ROWS + 4 * q) * CO + NO * n) * 4);
+        unsigned xoff = (unsigned)((((size_t)first * WR_ROWS + 4 * q) * x_ld + (TWO ? 4 * n : NI * n)) * 4);
+        const unsigned g_step = __builtin_amdgcn_readfirstlane((unsigned)(stride * WR_ROWS * CO * 4));
+        const unsigned x_step = __builtin_amdgcn_readfirstlane((unsigned)(stride * WR_ROWS * x_ld * 4));
+        auto at = [](const float *base, unsigned byte_off) -> const float * { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); };
         int loaded = 0;
         f32x4 gv[4][HO], yv[4][HO], xv[4][HI];
         auto ld_g = [&](int t) {
 #pragma unroll
-            for (int h = 0; h < HO; ++h) gv[t][h] = ldx(p.gz + goff + t * CO + 4 * h);
+            for (int h = 0; h < HO; ++h) gv[t][h] = ldx(at(p.gz + t * CO + 4 * h, goff));
         };
         auto ld_y = [&](int t) {
 #pragma unroll
-            for (int h = 0; h < HO; ++h) yv[t][h] = ldx(p.y2 + goff + t * CO + 4 * h);
+            for (int h = 0; h < HO; ++h) yv[t][h] = ldx(at(p.y2 + t * CO + 4 * h, goff));
         };
         auto ld_x = [&](int t) {
 #pragma unroll
-            for (int h = 0; h < HI; ++h) xv[t][h] = ldx(xsrc + xoff + t * x_ld + 4 * h);
+            for (int h = 0; h < HI; ++h) xv[t][h] = ldx(at(((TWO && h == 1) ? p.xb : p.x) + t * x_ld + (TWO ? 0 : 4 * h), xoff));
         };
         auto tf_g = [&](int t, int h) {                          // g^y / sc = gz + fma(y, Bc, Ac)
 #pragma unroll
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float z = __builtin_fmaf(xv[t][h][c], cxa[h][c], cxb[h][c]);
-                xv[t][h][c] = __builtin_fmaxf(z, z * x_slope);
+                xv[t][h][c] = __builtin_fmaxf(z, z * ((TWO && h == 1) ? p.slope_b : p.slope_in));
             }
         };
 #pragma unroll
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int h = 0; h < HI; ++h) {
-                        float *dst = red + (size_t)(NO * (4 * q + e) + jo) * CI + NI * n + 4 * h;
+                        float *dst = red + (size_t)(NO * (4 * q + e) + jo) * CI + xchan(h);
                         f32x4 v = {acc[jo][4 * h][e], acc[jo][4 * h + 1][e], acc[jo][4 * h + 2][e], acc[jo][4 * h + 3][e]};
                         v *= gtab[NO * (4 * q + e) + jo];                    // sc of output row o
                         if (w > 0) v += *reinterpret_cast<const f32x4 *>(dst);
@@ -709,8 +716,11 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_wgrad_kernel(WregWgradP p)
 
 template <int CO, int CI>
 int launch_wreg_wgrad(const WregWgradP &p, unsigned grid, hipStream_t st) {
-    if (p.xb) hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, true, true>), dim3(grid), dim3(WR_THREADS), 0, st, p);
-    else if (p.in_coef) hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, true, false>), dim3(grid), dim3(WR_THREADS), 0, st, p);
+    if constexpr (CI == 128) {
+        if (p.xb) { hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, true, true>), dim3(grid), dim3(WR_THREADS), 0, st, p); I2P_RETURN_LAUNCH_STATUS(); }
+    }
+    if (p.xb) return I2P_ERR_BAD_ARG;
+    if (p.in_coef) hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, true, false>), dim3(grid), dim3(WR_THREADS), 0, st, p);
     else hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, false, false>), dim3(grid), dim3(WR_THREADS), 0, st, p);
     I2P_RETURN_LAUNCH_STATUS();
 }
@@ -1142,7 +1152,8 @@ int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const flo
     if (!i2p_wreg_wgrad_ok(rows, cin, cout) || !gz || !y2 || !g_dsums || !g_oc || !g_omi || !x || !dw_partial || grid == 0 ||
         !(slope_in >= 0.f && slope_in <= 1.f))
         return I2P_ERR_BAD_ARG;
-    if (xb && (split * 2 != cin || !in_coef || !in_coef_b ||
+    if ((unsigned long long)rows * (unsigned)(cin > cout ? cin : cout) * 4ull >= (1ull << 32)) return I2P_ERR_BAD_ARG;   // 32-bit byte offsets
+    if (xb && (split * 2 != cin || cin != 128 || !in_coef || !in_coef_b ||
                !(slope_b >= 0.f && slope_b <= 1.f)))
         return I2P_ERR_BAD_ARG;
     WregWgradP p;
