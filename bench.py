@@ -117,7 +117,7 @@ def kernel_rooflines(B, device):
     f = rnd(B, N, C); gk = rnd(B, M, C); bn = rnd(B, N, C); bk = rnd(B, M, C)
     t_pf = _event_time_us(lambda: hip.pair_lin_forward(f, gk, bn, bk, w), 10)
     flop_pf = 2.0 * rows * C * C
-    pf = {"kernel": "lin_fwd2_kernel<8,pair> (first cost-volume layer forward)", "bound": "mfma",
+    pf = {"kernel": "wreg_pair_fwd_kernel<128,128> (first cost-volume layer forward: product formed from lane-private / wave-shared LDS rows, only y touches HBM)", "bound": "mfma",
           "achieved": round(flop_pf / t_pf / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
           "frac": round(flop_pf / t_pf / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "avg_kernel_us": round(t_pf, 1),
           "hbm_GBps_on_output": round(rows * C * 4 / t_pf / 1e3, 1)}

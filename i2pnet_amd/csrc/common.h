@@ -82,3 +82,6 @@ long long i2p_wreg_pair_bwd_scratch(int B, int N, int M, int cin, int cout);
 int i2p_wreg_pair_bwd(int B, int N, int M, int cin, int cout, const float *gz, const float *y2, const double *g_dsums,
                       const float *g_oc, const float *g_omi, const float *f, const float *g, const float *w, float *scratch,
                       int *KT_out, int *NCH_out, void *stream);
+int i2p_wreg_pair_fwd(int B, int N, int M, int cin, int cout, const float *f, const float *g, const float *bias_n,
+                      const float *bias_k, const float *w, float *y, double *sums, unsigned *fin_counter, const float *fin_gamma,
+                      const float *fin_beta, float fin_eps, float *fin_coef, float *fin_mi, void *stream);

@@ -1730,6 +1730,13 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
     if (rows == 0) return 0;
     if (!x || !w || !y) return I2P_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (pair_f && !xb && !in_coef && cin == 128 && cout == 128 && pair_N > 0 && pair_M > 0 && rows % ((long long)pair_N * pair_M) == 0 &&
+        i2p_wreg_pair_bwd_ok((int)(rows / ((long long)pair_N * pair_M)), pair_N, pair_M, cin, cout) && rows * 512 < (1LL << 32)) {
+        fin_done = fin != nullptr;                          // first cost-volume layer, 128 x 128 on many rows (csrc/mlp_wreg.hip)
+        return i2p_wreg_pair_fwd((int)(rows / ((long long)pair_N * pair_M)), pair_N, pair_M, cin, cout, pair_f, x, bias_n, bias_k, w, y, sums,
+                                 fin ? fin->counter : nullptr, fin ? fin->gamma : nullptr, fin ? fin->beta : nullptr, fin ? fin->eps : 0.f,
+                                 fin ? fin->coef : nullptr, fin ? fin->mi : nullptr, stream);
+    }
     const bool two_ok3 = !xb || (split_c * 2 == cin && in_coef && in_coef_b && slope_b >= 0.f && slope_b <= 1.f);
     if (!pair_f && two_ok3 && i2p_wreg_fwd_ok(rows, cin, cout) && slope_in >= 0.f && slope_in <= 1.f) {  // wide layer on many rows: weights stationary in registers
         fin_done = fin != nullptr;

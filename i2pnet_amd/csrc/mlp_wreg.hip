@@ -1088,6 +1088,189 @@ int launch_wreg_pair(const WregPairP &p, unsigned grid, hipStream_t st) {
     I2P_RETURN_LAUNCH_STATUS();
 }
 
+
+// =====================================================================================================================
+// FORWARD of the pair layer (first cost-volume layer): y[b,n,k,:] = W (f[b,n,:] .* g[b,k,:]) + bias_n[b,n,:] + bias_k[b,k,:]
+// on the tasks of the pair backward (a wave = one sample, one 16-pixel tile, a chunk of points; strip = rows (b, n, k0..)).
+// Nothing large is READ: the lane's pixel row of g and of bias_k sit in lane-private LDS rows, the strip's rows of f and
+// bias_n go through wave-shared LDS rows a strip ahead, the B operand of the next strip is formed in place from them
+// right after a float4's last MFMA.  The only HBM traffic is the 437 MB of y.  (mlp.hip lin_fwd2_kernel<.., PAIR> is
+// the general version.)
+// =====================================================================================================================
+struct WregPairFwdP {
+    int B, N, M, KT, NCH, NL;
+    const float *f, *g, *bias_n, *bias_k, *w;
+    float *y; double *sums;
+    unsigned *fin_counter; const float *fin_gamma, *fin_beta; float fin_eps; float *fin_coef, *fin_mi;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(WR_THREADS, 1) void wreg_pair_fwd_kernel(WregPairFwdP p) {
+    constexpr int NT = COUT / 16, L = CIN / 4, NF = L / 4, G = 4 * NT, NMF = NT * L;
+    __shared__ f32x4 st_lds[2 * NT][WR_THREADS];                // per-lane BN statistics
+    __shared__ f32x4 priv[NF + NT][WR_THREADS];                 // rows [0, NF): g of the lane's pixel; [NF, NF+NT): bias_k
+    __shared__ float fbuf[4][2][CIN];                           // f[b,n,:] per wave, two strips in flight
+    __shared__ float nbuf[4][2][COUT];                          // bias_n[b,n,:] per wave
+    __shared__ int fin_flag;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    f32x4 wr[NT][NF];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wr[j][f] = *reinterpret_cast<const f32x4 *>(p.w + (size_t)(16 * j + m) * CIN + 16 * f + 4 * q);
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) st_lds[i][tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntasks = p.B * p.KT * p.NCH;
+    for (int task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+        const int nc = task % p.NCH, kt = (task / p.NCH) % p.KT, b = task / (p.NCH * p.KT);
+        const int k0 = kt * WR_ROWS, n_begin = nc * p.NL, n_end = n_begin + p.NL < p.N ? n_begin + p.NL : p.N;
+        const int ns = n_end - n_begin;
+        if (ns <= 0) continue;
+        const int kpix = k0 + m;
+        const bool live = kpix < p.M;
+        const float vm = live ? 1.f : 0.f;
+        const int kc = live ? kpix : p.M - 1;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) priv[f][tid] = *reinterpret_cast<const f32x4 *>(p.g + ((size_t)b * p.M + kc) * CIN + 16 * f + 4 * q);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) priv[NF + j][tid] = *reinterpret_cast<const f32x4 *>(p.bias_k + ((size_t)b * p.M + kc) * COUT + 16 * j + 4 * q);
+        const size_t row0 = (size_t)b * p.N + n_begin;          // first (b, n) row of the chunk in f / bias_n
+        auto at = [](float *base, unsigned byte_off) -> float * { return reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off); };
+        unsigned yoff = (unsigned)(((row0 * p.M + kc) * COUT + 4 * q) * 4);      // strip being STORED (byte offset, y < 4 GB)
+        const unsigned y_step = (unsigned)((size_t)p.M * COUT * 4);
+
+        // rows of f / bias_n of strip s (clamped to the chunk) -> this lane's float4 of the row (first CIN/4 or COUT/4 lanes)
+        auto f_row = [&](int s_) { const int c = s_ < ns ? s_ : ns - 1; return *reinterpret_cast<const f32x4 *>(p.f + (row0 + c) * CIN + 4 * (lane & (CIN / 4 - 1))); };
+        auto n_row = [&](int s_) { const int c = s_ < ns ? s_ : ns - 1; return *reinterpret_cast<const f32x4 *>(p.bias_n + (row0 + c) * COUT + 4 * (lane & (COUT / 4 - 1))); };
+        if (lane < CIN / 4) { *reinterpret_cast<f32x4 *>(&fbuf[wave][0][4 * lane]) = f_row(0); *reinterpret_cast<f32x4 *>(&fbuf[wave][1][4 * lane]) = f_row(1); }
+
+        f32x4 x[NF], accA[NT], accB[NT], gfix, frow, ftmp, btmp, bk, bnr, r1, r2, ev, vkeep;
+        gfix = frow = ftmp = btmp = bk = bnr = r1 = r2 = ev = vkeep = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < NF - 1; ++f) x[f] = priv[f][tid] * *reinterpret_cast<const f32x4 *>(&fbuf[wave][0][16 * f + 4 * q]);
+        x[NF - 1] = f32x4{0.f, 0.f, 0.f, 0.f};                  // (formed in the first slots of the strip's own block)
+        constexpr int LAT = 5, PE = 10;
+        static_assert(PE * NT + LAT + 1 <= NMF && LAT + 1 < G, "slot plan");
+        int sidx = 0;                                            // strip being computed
+        auto epi_tile = [&](const f32x4 &acc, int j, int par) {  // (not slotted: last strip of the chunk)
+            f32x4 v = acc + priv[NF + j][tid] + *reinterpret_cast<const f32x4 *>(&nbuf[wave][par][16 * j + 4 * q]);
+            f32x4 a = st_lds[j][tid], c2 = st_lds[NT + j][tid];
+            const f32x4 vs = v * vm;
+            a += vs;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) c2[c] = __builtin_fmaf(vs[c], v[c], c2[c]);
+            st_lds[j][tid] = a; st_lds[NT + j][tid] = c2;
+            if (live) sty(at(p.y + 16 * j, yoff), v);
+        };
+        auto strip_block = [&](auto epi_tag, auto par_tag, f32x4 (&acc)[NT], f32x4 (&prev)[NT]) {
+            constexpr bool EPI = decltype(epi_tag)::value;
+            constexpr int PAR = decltype(par_tag)::value;        // parity of the strip being computed
+#pragma unroll
+            for (int i = 0; i < NMF; ++i) {
+                const int t = i / NT, j = i % NT, f = t >> 2, e = t & 3;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                // (the last float4 of THIS strip is formed in slots 0..LAT: its MFMAs start at slot G (NF-1))
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][f][e], x[f][e], t == 0 ? zero : acc[j], 0, 0, 0);
+                // rows of f for the strip after the next one, of bias_n for this strip: registers now, LDS half a strip later
+                if (i == 1) { if (lane < CIN / 4) ftmp = f_row(sidx + 2); if (lane < COUT / 4) btmp = n_row(sidx); }
+                if (i == NMF / 2) {
+                    if (lane < CIN / 4) *reinterpret_cast<f32x4 *>(&fbuf[wave][PAR][4 * lane]) = ftmp;
+                    if (lane < COUT / 4) *reinterpret_cast<f32x4 *>(&nbuf[wave][PAR][4 * lane]) = btmp;
+                }
+                // ---- B operand: float4 NF-1 of this strip at the start, float4 f of the NEXT strip once its last MFMA issued ----
+                if (i == 0) { gfix = priv[NF - 1][tid]; frow = *reinterpret_cast<const f32x4 *>(&fbuf[wave][PAR][16 * (NF - 1) + 4 * q]); }
+                if (i == LAT) x[NF - 1] = gfix * frow;
+                {
+                    const int fp = i / G - 1, u = i - G * (fp + 1);      // float4 whose group ended at slot G (fp + 1) - 1
+                    if (fp >= 0 && fp < NF - 1) {
+                        if (u == 0 && i >= LAT + 1) { gfix = priv[fp][tid]; frow = *reinterpret_cast<const f32x4 *>(&fbuf[wave][PAR ^ 1][16 * fp + 4 * q]); }
+                        if (u == LAT) x[fp] = gfix * frow;
+                    }
+                }
+                // ---- store phase of the previous strip ------------------------------------------------------------------
+                if (EPI && i >= LAT + 1 && i < PE * NT + LAT + 1) {
+                    const int tj = (i - LAT - 1) / PE, part = (i - LAT - 1) % PE;
+                    if (tj < NT) {
+                        if (part == 0) { bk = priv[NF + tj][tid]; bnr = *reinterpret_cast<const f32x4 *>(&nbuf[wave][PAR ^ 1][16 * tj + 4 * q]); r1 = st_lds[tj][tid]; r2 = st_lds[NT + tj][tid]; }
+                        if (part == LAT) {
+                            ev = prev[tj] + bk + bnr;
+                            if (tj & 1) { if (live) { sty(at(p.y + 16 * (tj - 1), yoff), vkeep); sty(at(p.y + 16 * tj, yoff), ev); } }
+                            else vkeep = ev;
+                        }
+                        if (part == LAT + 1) { r1 += ev * vm; st_lds[tj][tid] = r1; }
+                        if (part == LAT + 2) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) r2[c] = __builtin_fmaf(ev[c] * vm, ev[c], r2[c]);
+                            st_lds[NT + tj][tid] = r2;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (EPI) yoff += y_step;
+            ++sidx;
+        };
+        using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+        strip_block(std::false_type{}, P0{}, accA, accB);
+        int k = 1;
+        for (; k + 1 < ns; k += 2) {
+            strip_block(std::true_type{}, P1{}, accB, accA);
+            strip_block(std::true_type{}, P0{}, accA, accB);
+        }
+        if (k < ns) {
+            strip_block(std::true_type{}, P1{}, accB, accA);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) epi_tile(accB[j], j, 1);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) epi_tile(accA[j], j, 0);
+        }
+    }
+    __syncthreads();
+    if (p.sums) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double a = (double)st_lds[j][tid][e], b2 = (double)st_lds[NT + j][tid][e];
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) { a += __shfl_xor(a, off); b2 += __shfl_xor(b2, off); }
+                if (m == 0) {
+                    double *rep = p.sums + (size_t)((blockIdx.x * 4 + wave) % REP) * 2 * COUT;
+                    atomicAdd(rep + 16 * j + 4 * q + e, a); atomicAdd(rep + COUT + 16 * j + 4 * q + e, b2);
+                }
+            }
+    }
+    if (p.fin_counter) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = atomicAdd(p.fin_counter, 1u);
+            fin_flag = (t == gridDim.x - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!fin_flag) return;
+        const double rows = (double)p.B * p.N * p.M;
+        for (int ch = tid; ch < COUT; ch += WR_THREADS) {
+            double sa = 0.0, qa = 0.0;
+            for (int r = 0; r < REP; ++r) {
+                sa += __hip_atomic_load(p.sums + (size_t)r * 2 * COUT + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                qa += __hip_atomic_load(p.sums + (size_t)r * 2 * COUT + COUT + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const double mean = sa / rows;
+            double var = qa / rows - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const float invstd = rsqrtf((float)var + p.fin_eps);
+            p.fin_coef[ch] = (float)mean; p.fin_coef[COUT + ch] = invstd * p.fin_gamma[ch]; p.fin_coef[2 * COUT + ch] = p.fin_beta[ch];
+            p.fin_mi[ch] = (float)mean; p.fin_mi[COUT + ch] = invstd;
+        }
+        if (tid == 0) *p.fin_counter = 0u;
+    }
+}
+
 }  // namespace
 
 bool i2p_wreg_fwd_ok(long long rows, int cin, int cout) {
@@ -1202,4 +1385,18 @@ int i2p_wreg_pair_bwd(int B, int N, int M, int cin, int cout, const float *gz, c
     p.s_dbk = p.s_dg + (size_t)p.NCH * B * M * cin;
     *KT_out = p.KT; *NCH_out = p.NCH;
     return launch_wreg_pair<128, 128>(p, 256u, (hipStream_t)stream);
+}
+
+// pair-layer forward on wreg_pair_fwd_kernel (128 x 128, the shapes of i2p_wreg_pair_bwd_ok)
+int i2p_wreg_pair_fwd(int B, int N, int M, int cin, int cout, const float *f, const float *g, const float *bias_n,
+                      const float *bias_k, const float *w, float *y, double *sums, unsigned *fin_counter, const float *fin_gamma,
+                      const float *fin_beta, float fin_eps, float *fin_coef, float *fin_mi, void *stream) {
+    if (!i2p_wreg_pair_bwd_ok(B, N, M, cin, cout) || !f || !g || !bias_n || !bias_k || !w || !y) return I2P_ERR_BAD_ARG;
+    if ((unsigned long long)B * N * M * cout * 4ull >= (1ull << 32)) return I2P_ERR_BAD_ARG;       // 32-bit byte offsets into y
+    WregPairFwdP p;
+    p.B = B; p.N = N; p.M = M; wreg_pair_geometry(B, N, M, p.KT, p.NCH, p.NL);
+    p.f = f; p.g = g; p.bias_n = bias_n; p.bias_k = bias_k; p.w = w; p.y = y; p.sums = sums;
+    p.fin_counter = fin_counter; p.fin_gamma = fin_gamma; p.fin_beta = fin_beta; p.fin_eps = fin_eps; p.fin_coef = fin_coef; p.fin_mi = fin_mi;
+    hipLaunchKernelGGL((wreg_pair_fwd_kernel<128, 128>), dim3(256), dim3(WR_THREADS), 0, (hipStream_t)stream, p);
+    I2P_RETURN_LAUNCH_STATUS();
 }

@@ -140,3 +140,25 @@ def test_wreg_pair_backward(hip_backend):
         assert _rel(a, r) < 1e-5, name
     again = be.pair_lin_backward(gz, f, g, w, y=y, out_coef=out_coef, out_mi=out_mi, out_dsums=ods.view(-1))
     assert all(torch.equal(a, b) for a, b in zip(got, again))           # slab reductions in a fixed order: bit-reproducible
+
+
+def test_wreg_pair_forward(hip_backend):
+    """first cost-volume layer forward on wreg_pair_fwd_kernel (partial last pixel tile: M % 16 = 4) against fp64 torch,
+    plain and with the BN finalisation by the last block"""
+    be = hip_backend
+    B, N, M, C, Co = 2, 72, 468, 128, 128
+    rows = B * N * M
+    g_ = torch.Generator().manual_seed(6)
+    rnd = lambda *s: torch.randn(*s, generator=g_).to(DEV)
+    f, g, bn, bk, w = rnd(B, N, C), rnd(B, M, C), rnd(B, N, Co), rnd(B, M, Co), rnd(Co, C) / C ** 0.5
+    y, sums = be.pair_lin_forward(f, g, bn, bk, w)
+    P = (f.double()[:, :, None, :] * g.double()[:, None, :, :]).view(rows, C)
+    ref = (P @ w.double().t()).view(B, N, M, Co) + bn.double()[:, :, None, :] + bk.double()[:, None, :, :]
+    ref = ref.view(rows, Co)
+    assert _rel(y, ref) < 1e-5
+    s = sums.view(R, 2, Co).sum(0)
+    assert _rel(s[0], ref.sum(0)) < 1e-5 * float(ref.abs().sum(0).max() / ref.sum(0).abs().max()) and _rel(s[1], (ref * ref).sum(0)) < 1e-5
+    gam = torch.ones(Co, device=DEV); bet = torch.zeros(Co, device=DEV)
+    y2, s2, cf2, mi2 = be.pair_lin_forward_fin(f, g, bn, bk, w, gam, bet, 1e-5)
+    cf, mi = be.bn_finalize(rows, sums, gam, bet, 1e-5)
+    assert torch.equal(y2, y) and torch.allclose(cf2.view(-1), cf.view(-1), rtol=1e-5, atol=1e-6) and torch.allclose(mi2.view(-1), mi.view(-1), rtol=1e-5, atol=1e-6)
