@@ -85,3 +85,7 @@ int i2p_wreg_pair_bwd(int B, int N, int M, int cin, int cout, const float *gz, c
 int i2p_wreg_pair_fwd(int B, int N, int M, int cin, int cout, const float *f, const float *g, const float *bias_n,
                       const float *bias_k, const float *w, float *y, double *sums, unsigned *fin_counter, const float *fin_gamma,
                       const float *fin_beta, float fin_eps, float *fin_coef, float *fin_mi, void *stream);
+bool i2p_small_wgrad_ok(long long rows, int cin, int cout);
+int i2p_small_wgrad(long long rows, int cin, int cout, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
+                    const float *g_omi, long long g_rows, float g_slope, float *bn_out, const float *x, const float *in_coef,
+                    float slope_in, float *dw_partial, unsigned grid, void *stream);

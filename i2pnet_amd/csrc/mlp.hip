@@ -1965,6 +1965,15 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
                 const int rc = dispatch_fwd2<false, true>(q, st);
                 if (rc) return rc;
             }
+            if (!two && out_coef && grid == 256 && i2p_small_wgrad_ok(rows, cin, cout)) {
+                // narrow layer on many rows (level 1): HBM streaming, dword columns as MFMA operands (csrc/mlp_wreg.hip)
+                const int rc = i2p_small_wgrad(rows, cin, cout, gz, y, out_dsums, out_coef, out_mi, rows, p.slope_out, g_coef, x, in_coef,
+                                               slope_in, dw_partial, grid, stream);
+                if (rc) return rc;
+                const int n = cout * cin;
+                hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
+                I2P_RETURN_LAUNCH_STATUS();
+            }
             const bool two_ok = !two || (in_coef && two->in_coef_b && two->split_c * 2 == cin && cin == 128 && two->slope_b >= 0.f && two->slope_b <= 1.f);
             if (two_ok && out_coef && p.slope_out == 1.f && slope_in >= 0.f && slope_in <= 1.f && grid == 256 &&
                 i2p_wreg_wgrad_ok(rows, cin, cout)) {

@@ -1271,6 +1271,108 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_pair_fwd_kernel(WregPairFw
     }
 }
 
+
+// =====================================================================================================================
+// wgrad of the NARROW layers on many rows (level-1 set abstraction: 12/16 -> 16 -> 16 -> 32 channels on B*3600*32 rows):
+// pure HBM streaming (3 tensors of 48-128 bytes per row), the contraction is 1-2 MFMAs per 4 rows.  Rows are the K axis,
+// lane (channel n = lane & 15, k-slot q): one DWORD per tensor, tile and k-step — with 64-byte rows a load instruction of
+// the wave covers four whole rows.  No registers to speak of, so 16 waves per CU hide the latency by occupancy; the next
+// strip is requested before the current one is consumed.  (mlp.hip lin_wgrad_kernel<1,1> streams these at 2 TB/s.)
+// =====================================================================================================================
+struct SmallWgradP {
+    long long rows;              // multiple of 16
+    int cin, cout;               // cin <= 16, cout = 16 * NO
+    const float *gz, *y2;        // [rows, cout]
+    const double *g_dsums; const float *g_oc, *g_omi; long long g_rows; float g_slope;
+    float *bn_out;
+    const float *x, *in_coef; float slope_in;
+    float *dw_partial;           // [grid][cout*cin]
+};
+constexpr int SW_THREADS = 1024;
+
+template <int NO>
+__global__ __launch_bounds__(SW_THREADS) void small_wgrad_kernel(SmallWgradP p) {
+    __shared__ float red[16 * NO * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int CO = 16 * NO, CI = p.cin;
+    // per-lane constants: output channels 16 jo + n (g^y = sc (t - m1 - xhat m2), t = act'(z) gz), input channel n
+    float m1[NO], m2[NO], sc[NO], mu[NO], is[NO], zb[NO];
+#pragma unroll
+    for (int jo = 0; jo < NO; ++jo) {
+        const int ch = 16 * jo + n;
+        double sd = 0.0, sx = 0.0;
+#pragma unroll 8
+        for (int rp = 0; rp < REP; ++rp) { sd += p.g_dsums[(size_t)rp * 2 * CO + ch]; sx += p.g_dsums[(size_t)rp * 2 * CO + CO + ch]; }
+        m1[jo] = (float)(sd / (double)p.g_rows); m2[jo] = (float)(sx / (double)p.g_rows);
+        sc[jo] = p.g_oc[CO + ch]; mu[jo] = p.g_omi[ch]; is[jo] = p.g_omi[CO + ch]; zb[jo] = p.g_oc[2 * CO + ch] - mu[jo] * sc[jo];
+        if (blockIdx.x == 0 && wave == 0 && q == 0 && p.bn_out) { p.bn_out[6 * CO + ch] = (float)sd; p.bn_out[7 * CO + ch] = (float)sx; }
+    }
+    const bool xin = n < CI;
+    float xa = 1.f, xb = 0.f;
+    if (p.in_coef && xin) { xa = p.in_coef[CI + n]; xb = p.in_coef[2 * CI + n] - p.in_coef[n] * xa; }
+    const bool gact = p.g_slope != 1.f;
+
+    f32x4 acc[NO];
+#pragma unroll
+    for (int jo = 0; jo < NO; ++jo) acc[jo] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long long nstrips = p.rows / WR_ROWS;
+    const long long stride = (long long)gridDim.x * (SW_THREADS / 64);
+    float g[4][NO], yy[4][NO], xx[4], gn[4][NO], yn[4][NO], xn[4];
+    auto load = [&](long long s, float (&G)[4][NO], float (&Y)[4][NO], float (&X)[4]) {
+        const size_t r0 = (size_t)s * WR_ROWS + q;               // k-step t: row r0 + 4t
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int jo = 0; jo < NO; ++jo) {
+                G[t][jo] = __builtin_nontemporal_load(p.gz + (r0 + 4 * t) * CO + 16 * jo + n);
+                Y[t][jo] = __builtin_nontemporal_load(p.y2 + (r0 + 4 * t) * CO + 16 * jo + n);
+            }
+            X[t] = xin ? __builtin_nontemporal_load(p.x + (r0 + 4 * t) * CI + n) : 0.f;
+        }
+    };
+    long long s = (long long)blockIdx.x * (SW_THREADS / 64) + wave;
+    if (s < nstrips) load(s, g, yy, xx);
+    for (; s < nstrips; s += stride) {
+        const long long sn = s + stride < nstrips ? s + stride : s;
+        load(sn, gn, yn, xn);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float a = xx[t];
+            if (p.in_coef) { const float z = __builtin_fmaf(a, xa, xb); a = z > 0.f ? z : z * p.slope_in; }
+            if (!xin) a = 0.f;
+#pragma unroll
+            for (int jo = 0; jo < NO; ++jo) {
+                float tg = g[t][jo];
+                if (gact) tg = __builtin_fmaf(yy[t][jo], sc[jo], zb[jo]) > 0.f ? tg : tg * p.g_slope;
+                const float gy = sc[jo] * (tg - m1[jo] - ((yy[t][jo] - mu[jo]) * is[jo]) * m2[jo]);
+                acc[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(gy, a, acc[jo], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            xx[t] = xn[t];
+#pragma unroll
+            for (int jo = 0; jo < NO; ++jo) { g[t][jo] = gn[t][jo]; yy[t][jo] = yn[t][jo]; }
+        }
+    }
+    // D[o][c]: lane (c = n, q): rows o = 16 jo + 4q + e.  The waves of the block add through LDS in a fixed order.
+    for (int w = 0; w < SW_THREADS / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int jo = 0; jo < NO; ++jo)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float *dst = red + (16 * jo + 4 * q + e) * 16 + n;
+                    *dst = (w > 0 ? *dst : 0.f) + acc[jo][e];
+                }
+        }
+        __syncthreads();
+    }
+    float *out = p.dw_partial + (size_t)blockIdx.x * CO * CI;
+    for (int i = tid; i < CO * CI; i += SW_THREADS) out[i] = red[(i / CI) * 16 + i % CI];
+}
+
 }  // namespace
 
 bool i2p_wreg_fwd_ok(long long rows, int cin, int cout) {
@@ -1398,5 +1500,23 @@ int i2p_wreg_pair_fwd(int B, int N, int M, int cin, int cout, const float *f, co
     p.f = f; p.g = g; p.bias_n = bias_n; p.bias_k = bias_k; p.w = w; p.y = y; p.sums = sums;
     p.fin_counter = fin_counter; p.fin_gamma = fin_gamma; p.fin_beta = fin_beta; p.fin_eps = fin_eps; p.fin_coef = fin_coef; p.fin_mi = fin_mi;
     hipLaunchKernelGGL((wreg_pair_fwd_kernel<128, 128>), dim3(256), dim3(WR_THREADS), 0, (hipStream_t)stream, p);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+// narrow layers on many rows (cin <= 16, cout 16 or 32): streaming wgrad, partials for the caller's reduce_partials launch
+bool i2p_small_wgrad_ok(long long rows, int cin, int cout) {
+    static const char *e = getenv("I2P_NO_WREG");
+    if (e && e[0] == '1') return false;
+    return rows >= 262144 && (rows % WR_ROWS) == 0 && cin >= 4 && cin <= 16 && (cout == 16 || cout == 32);
+}
+int i2p_small_wgrad(long long rows, int cin, int cout, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
+                    const float *g_omi, long long g_rows, float g_slope, float *bn_out, const float *x, const float *in_coef,
+                    float slope_in, float *dw_partial, unsigned grid, void *stream) {
+    if (!i2p_small_wgrad_ok(rows, cin, cout) || !gz || !y2 || !g_dsums || !g_oc || !g_omi || !x || !dw_partial || grid == 0) return I2P_ERR_BAD_ARG;
+    SmallWgradP p;
+    p.rows = rows; p.cin = cin; p.cout = cout; p.gz = gz; p.y2 = y2; p.g_dsums = g_dsums; p.g_oc = g_oc; p.g_omi = g_omi; p.g_rows = g_rows;
+    p.g_slope = g_slope; p.bn_out = bn_out; p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.dw_partial = dw_partial;
+    if (cout == 16) hipLaunchKernelGGL((small_wgrad_kernel<1>), dim3(grid), dim3(SW_THREADS), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((small_wgrad_kernel<2>), dim3(grid), dim3(SW_THREADS), 0, (hipStream_t)stream, p);
     I2P_RETURN_LAUNCH_STATUS();
 }

@@ -162,3 +162,29 @@ def test_wreg_pair_forward(hip_backend):
     y2, s2, cf2, mi2 = be.pair_lin_forward_fin(f, g, bn, bk, w, gam, bet, 1e-5)
     cf, mi = be.bn_finalize(rows, sums, gam, bet, 1e-5)
     assert torch.equal(y2, y) and torch.allclose(cf2.view(-1), cf.view(-1), rtol=1e-5, atol=1e-6) and torch.allclose(mi2.view(-1), mi.view(-1), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("cin,cout,bn,slope_out", [(12, 16, False, 1.0), (16, 16, True, 1.0), (16, 32, True, 0.0)])
+def test_small_wgrad_streaming_kernel(hip_backend, cin, cout, bn, slope_out):
+    """level-1 set-abstraction layers (narrow, B*3600*32 rows): wgrad on small_wgrad_kernel against fp64 torch, incl. the
+    activation derivative of the layer's own output applied on load (slope_out = 0: ReLU in front of the max over K)"""
+    be = hip_backend
+    rows = 262144 + 16 * 5
+    g = torch.Generator().manual_seed(cin + 3 * cout)
+    x = (torch.randn(rows, cin, generator=g) * 1.5 + 0.2).to(DEV); w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(DEV)
+    in_coef, in_mi = _bn(be, x, 9) if bn else (None, None)
+    y, sy = be.lin_forward(x, in_coef, 0.1, w)
+    out_coef, out_mi = be.bn_finalize(rows, sy, (torch.rand(cout, generator=g) + 0.5).to(DEV), (torch.randn(cout, generator=g) * 0.1).to(DEV), 1e-5)
+    ga = torch.randn(rows, cout, generator=g).to(DEV)                 # dL/da of this layer's activation when slope_out != 1
+    om, oc = out_mi.view(-1).double(), out_coef.view(-1).double()
+    z_o = (y.double() - om[:cout]) * oc[cout:2 * cout] + oc[2 * cout:]
+    gzd = ga.double() * (torch.where(z_o > 0, 1.0, slope_out) if slope_out != 1.0 else 1.0)
+    xh = (y.double() - om[:cout]) * om[cout:]
+    s1, s2 = gzd.sum(0), (gzd * xh).sum(0)
+    ods = torch.zeros(R, 2, cout, dtype=torch.float64, device=DEV); ods[0, 0] = s1; ods[0, 1] = s2
+    gy = oc[cout:2 * cout] * (gzd - s1 / rows - xh * (s2 / rows))
+    a = _act(_z(x, in_coef, cin), 0.1) if bn else x.double()
+    _, _, dw = be.lin_backward(ga, y, out_coef, out_mi, ods.view(-1), x, in_coef, in_mi, 0.1, w, need_gx=False, slope_out=slope_out)
+    dgamma, dbeta = be.take_bn_grads()
+    assert _rel(dw, gy.t() @ a) < 1e-5
+    assert _rel(dbeta, s1) < 1e-5 and _rel(dgamma, s2) < 1e-5
