@@ -234,3 +234,47 @@ extern "C" int i2p_sa_l1_group(int B, int H, int W, int out_h, int out_w, int st
     if (kt <= 144) return launch<9>(p, st);
     return launch<10>(p, st);
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Set-abstraction levels 2-4, up-convolutions: the grouped input rows of the point MLP in ONE launch from the selected
+// cells (reference: gather_torch x2 + subtraction + cat, PPBackbone_center.py:94-129):
+//   out[b, n*K + k, xo:xo+3] = xyz[b, cell, 0:3] - centre[b, n, 0:3],  out[.., fo:fo+C] = feat[b, cell, 0:C],  0 elsewhere
+// (set abstraction: xo = 0, fo = 3; up-convolution: fo = 0, xo = C)
+// cell = h_idx * W + w_idx of the row.  One thread per (row, float4 of the output).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void sa_rows_kernel(int hw, int q, int K, int W, int c, int cpad, int xo, int fo, const float *__restrict__ xyz,
+                                                      const float *__restrict__ centre, const float *__restrict__ feat,
+                                                      const int64_t *__restrict__ h_idx, const int64_t *__restrict__ w_idx,
+                                                      float *__restrict__ out) {
+    const int bi = blockIdx.y, c4 = cpad >> 2;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)q * c4) return;
+    const int row = (int)(t / c4), j = (int)(t % c4);
+    const long long cell = h_idx[(size_t)bi * q + row] * W + w_idx[(size_t)bi * q + row];
+    const float *fr = feat + ((size_t)bi * hw + cell) * c;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ch = 4 * j + e;
+        float x = 0.f;
+        if (ch >= xo && ch < xo + 3) x = xyz[((size_t)bi * hw + cell) * 3 + ch - xo] - centre[((size_t)bi * (q / K) + row / K) * 3 + ch - xo];
+        else if (ch >= fo && ch < fo + c) x = fr[ch - fo];
+        v[e] = x;
+    }
+    *reinterpret_cast<float4 *>(out + ((size_t)bi * q + row) * cpad + 4 * j) = make_float4(v[0], v[1], v[2], v[3]);
+}
+}  // namespace
+
+extern "C" int i2p_sa_rows(int b, int hw, int n, int K, int W, int c, int cpad, int xyz_col, int feat_col, const float *xyz,
+                           const float *centre, const float *feat, const int64_t *h_idx, const int64_t *w_idx, float *out, void *stream) {
+    if (b <= 0 || hw <= 0 || n <= 0 || K <= 0 || W <= 0 || c < 0 || (cpad & 3) || cpad < 3 + c) return I2P_ERR_BAD_ARG;
+    if (xyz_col < 0 || feat_col < 0 || xyz_col + 3 > cpad || feat_col + c > cpad || (xyz_col < feat_col + c && feat_col < xyz_col + 3 && c > 0))
+        return I2P_ERR_BAD_ARG;
+    if (!xyz || !centre || (c && !feat) || !h_idx || !w_idx || !out) return I2P_ERR_BAD_ARG;
+    const long long tot = (long long)n * K * (cpad >> 2);
+    hipLaunchKernelGGL(sa_rows_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0, (hipStream_t)stream, hw, n * K, K, W, c, cpad,
+                       xyz_col, feat_col, xyz, centre, feat, h_idx, w_idx, out);
+    I2P_RETURN_LAUNCH_STATUS();
+}

@@ -276,9 +276,10 @@ __device__ __forceinline__ double fx_scale(unsigned maxbits) {        // 2^(40 -
 }
 
 constexpr int FX_RUN = 8;
-__global__ void scatter_fx_kernel(int hw, int c, int q, int W, const float *__restrict__ grad_out, const int64_t *__restrict__ h_idx,
-                                  const int64_t *__restrict__ w_idx, const unsigned *__restrict__ maxbits,
-                                  unsigned long long *__restrict__ acc) {
+// grad_out rows have pitch `ld` floats, the c scattered channels start at column `off` (ld = c, off = 0: a dense tensor)
+__global__ void scatter_fx_kernel(int hw, int c, int q, int W, const float *__restrict__ grad_out, int ld, int off,
+                                  const int64_t *__restrict__ h_idx, const int64_t *__restrict__ w_idx,
+                                  const unsigned *__restrict__ maxbits, unsigned long long *__restrict__ acc) {
     const int bi = blockIdx.y;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nrun = (q + FX_RUN - 1) / FX_RUN;
@@ -289,7 +290,7 @@ __global__ void scatter_fx_kernel(int hw, int c, int q, int W, const float *__re
     long long cur = -1, sum = 0;
     for (int row = r0; row < r1; ++row) {
         const long long cell = h_idx[(size_t)bi * q + row] * W + w_idx[(size_t)bi * q + row];
-        const long long v = __double2ll_rn((double)grad_out[((size_t)bi * q + row) * c + ch] * scale);
+        const long long v = __double2ll_rn((double)grad_out[((size_t)bi * q + row) * ld + off + ch] * scale);
         if (cell != cur) {
             if (cur >= 0 && cur < hw) atomicAdd(acc + ((size_t)bi * hw + cur) * c + ch, (unsigned long long)sum);
             cur = cell; sum = 0;
@@ -312,20 +313,31 @@ __global__ __launch_bounds__(256) void fx_finalize_kernel(long long n, const lon
 
 extern "C" long long i2p_gather_rows_grad_fx_scratch(int b, int hw, int c) { return ((long long)b * hw * c + 1) * 8; }   // bytes
 
-extern "C" int i2p_gather_rows_grad_fx(int b, int hw, int c, int q, int W, const float *grad_out, const int64_t *h_idx,
-                                       const int64_t *w_idx, void *scratch, float *grad_feat, void *stream) {
-    if (b < 0 || hw < 0 || c < 0 || q < 0 || W <= 0) return I2P_ERR_BAD_ARG;
+static int gather_rows_grad_fx_impl(int b, int hw, int c, int q, int W, const float *grad_out, int ld, int off, const int64_t *h_idx,
+                                    const int64_t *w_idx, void *scratch, float *grad_feat, void *stream) {
+    if (b < 0 || hw < 0 || c < 0 || q < 0 || W <= 0 || off < 0 || ld < off + c) return I2P_ERR_BAD_ARG;
     if ((long long)b * q * c == 0) return 0;
     if (!grad_out || !h_idx || !w_idx || !grad_feat || !scratch) return I2P_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(scratch);
     unsigned *mx = reinterpret_cast<unsigned *>(acc + (size_t)b * hw * c);
-    const long long nsrc = (long long)b * q * c, ndst = (long long)b * hw * c;
+    // (strided source: the maximum is taken over the WHOLE rows — a superset of the scattered columns, still a valid scale)
+    const long long nsrc = (long long)b * q * ld, ndst = (long long)b * hw * c;
     long long g1 = (nsrc + 256 * 16 - 1) / (256 * 16); if (g1 > 1024) g1 = 1024; if (g1 < 1) g1 = 1;
     hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)g1), dim3(256), 0, st, nsrc, grad_out, mx);
     const long long tot = (long long)((q + FX_RUN - 1) / FX_RUN) * c;
-    hipLaunchKernelGGL(scatter_fx_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0, st, hw, c, q, W, grad_out, h_idx, w_idx, mx, acc);
+    hipLaunchKernelGGL(scatter_fx_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0, st, hw, c, q, W, grad_out, ld, off, h_idx, w_idx, mx, acc);
     long long g3 = (ndst + 255) / 256; if (g3 > 2048) g3 = 2048;
     hipLaunchKernelGGL(fx_finalize_kernel, dim3((unsigned)g3), dim3(256), 0, st, ndst, reinterpret_cast<const long long *>(acc), mx, grad_feat);
     I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_gather_rows_grad_fx(int b, int hw, int c, int q, int W, const float *grad_out, const int64_t *h_idx,
+                                       const int64_t *w_idx, void *scratch, float *grad_feat, void *stream) {
+    return gather_rows_grad_fx_impl(b, hw, c, q, W, grad_out, c, 0, h_idx, w_idx, scratch, grad_feat, stream);
+}
+
+extern "C" int i2p_gather_rows_grad_fx_ld(int b, int hw, int c, int q, int W, const float *grad_out, int ld, int off,
+                                          const int64_t *h_idx, const int64_t *w_idx, void *scratch, float *grad_feat, void *stream) {
+    return gather_rows_grad_fx_impl(b, hw, c, q, W, grad_out, ld, off, h_idx, w_idx, scratch, grad_feat, stream);
 }

@@ -352,6 +352,20 @@ class ProjectPointNet(nn.Module):
         """xyz_proj_raw/xyz_proj [B,H,W,3], feature_proj [B,H,W,C] ->
         (centres raw, centres, features [B,out_h,out_w,C'], grouped_xyz [B,N,K,3], sample_idx)"""
         B = xyz_proj.shape[0]
+        src = xyz_proj_raw if raw_feat_point else xyz_proj
+        if USE_FUSED_GROUP and USE_FUSED_MLP and P.sa_rows_fusable(src, src, feature_proj):
+            # selection, then [dxyz, features, padding] rows in one launch (no gathered xyz / feature tensors, no cat)
+            with torch.no_grad():
+                if sample_idx is None:
+                    sample_idx = P.get_sample_idx(B, self.out_h, self.out_w, self.stride_H, self.stride_W, xyz_proj.device)
+                idx_n2 = P.get_stride_idx_cuda(B, self.out_h, self.out_w, self.stride_H, self.stride_W, xyz_proj.device)
+                xyz_pr = xyz_proj if self.usetrans else xyz_proj_raw
+                gidx = P.get_neighbor_copy(xyz_pr, xyz_pr, idx_n2, self.kernel_size, self.nsample, distance=self.distance)
+            c = _strided(xyz_proj, self.stride_H, self.stride_W, self.out_h, self.out_w).contiguous()
+            raw_c = _strided(xyz_proj_raw, self.stride_H, self.stride_W, self.out_h, self.out_w).contiguous()
+            rows = P.sa_rows(src, raw_c if raw_feat_point else c, feature_proj, gidx[1], gidx[2], self.nsample, self.W)
+            # (grouped_xyz, the 4th output, is not materialised on this path: the network never reads it)
+            return raw_c, c, self._mlp_max(rows, B), None, sample_idx
         raw_c, c, grouped_xyz, norm, gidx, sample_idx = self._centres_and_groups(xyz_proj_raw, xyz_proj, sample_idx,
                                                                                raw_feat_point)
         grouped_points = P.gather_torch(feature_proj, *gidx[:3], B, self.H, self.W)
@@ -425,11 +439,12 @@ class ProjSetUpconvModule(nn.Module):
             xyz2_pr = xyz2 if self.use_trans else xyz2_raw
             gidx = P.get_neighbor_copy(xyz1_pr, xyz2_pr, idx_n2, self.kernel_size, self.nsample, self.stride_H,
                                        self.stride_W, distance=self.distance)
-        if raw_feat_point:
-            xyz_diff = P.gather_torch(xyz2_raw, *gidx[:3], B, self.H, self.W) - xyz1_raw.reshape(B, N, 1, 3)
+        src2, src1 = (xyz2_raw, xyz1_raw) if raw_feat_point else (xyz2, xyz1)
+        if USE_FUSED_GROUP and USE_FUSED_MLP and P.sa_rows_fusable(src2, src1, feat2):
+            upfeats = P.sa_rows(src2, src1, feat2, gidx[1], gidx[2], self.nsample, self.W, xyz_first=False)
         else:
-            xyz_diff = P.gather_torch(xyz2, *gidx[:3], B, self.H, self.W) - xyz1.reshape(B, N, 1, 3)
-        upfeats = cat_padded([P.gather_torch(feat2, *gidx[:3], B, self.H, self.W), xyz_diff], pow2=True)
+            xyz_diff = P.gather_torch(src2, *gidx[:3], B, self.H, self.W) - src1.reshape(B, N, 1, 3)
+            upfeats = cat_padded([P.gather_torch(feat2, *gidx[:3], B, self.H, self.W), xyz_diff], pow2=True)
         feat1_new = run_stack(upfeats, self.mlp_conv, pool_k=upfeats.shape[2]).view(B, self.out_h, self.out_w, -1)
         if feat1 is not None:
             feat1_new = torch.cat([feat1_new, feat1.reshape(B, self.out_h, self.out_w, -1)], dim=3)

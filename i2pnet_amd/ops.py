@@ -237,6 +237,27 @@ class CBackend:
                    self._p(feat, _F32, "feat"), stream=self._stream())
         return feat
 
+    def sa_rows(self, xyz, centre, feat, h_idx, w_idx, K, W, cpad, xyz_col, feat_col):
+        """grouped MLP input rows in one launch (csrc/sa_group.hip i2p_sa_rows): xyz [B,HW,3], centre [B,N,3], feat [B,HW,C],
+        h_idx/w_idx [B,N*K] i64 -> [B, N*K, cpad]"""
+        B, HW, _ = xyz.shape
+        N, Cc = centre.shape[1], feat.shape[2]
+        out = torch.empty(B, N * K, cpad, dtype=_F32, device=xyz.device)
+        self._call("i2p_sa_rows", int(B), int(HW), int(N), int(K), int(W), int(Cc), int(cpad), int(xyz_col), int(feat_col),
+                   self._p(xyz, _F32, "xyz"), self._p(centre, _F32, "centre"), self._p(feat, _F32, "feat"), self._p(h_idx, _I64, "h_idx"),
+                   self._p(w_idx, _I64, "w_idx"), self._p(out, _F32, "out"), stream=self._stream())
+        return out
+
+    def gather_rows_grad_ld(self, grad_out, ld, off, h_idx, w_idx, W, grad_feat):
+        """gather_rows_grad from columns [off, off+C) of grad_out rows of pitch ld (fixed-point path, device only)"""
+        B, HW, Cc = grad_feat.shape
+        Q = h_idx.shape[1]
+        nbytes = _lib.helper("i2p_gather_rows_grad_fx_scratch", int(B), int(HW), int(Cc))
+        scratch = zeros(nbytes, torch.uint8, grad_feat.device)
+        self._call("i2p_gather_rows_grad_fx_ld", int(B), int(HW), int(Cc), int(Q), int(W), self._p(grad_out, _F32, "grad_out"), int(ld), int(off),
+                   self._p(h_idx, _I64, "h_idx"), self._p(w_idx, _I64, "w_idx"), self._p(scratch, torch.uint8, "scratch"),
+                   self._p(grad_feat, _F32, "grad_feat"), stream=self._stream())
+
     def gather_rows(self, feat, h_idx, w_idx, W, out):
         B, HW, Cc = feat.shape
         Q = h_idx.shape[1]

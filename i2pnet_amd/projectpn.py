@@ -96,6 +96,53 @@ class _GatherRows(Function):
         return grad_feat, None, None, None
 
 
+class _SaRows(Function):
+    """grouped rows [xyz[cell] - centre, feat[cell], zero padding] of a set-abstraction / up-convolution MLP in one launch
+    (reference: gather_torch x2 + subtraction + cat, PPBackbone_center.py:94-129, :236-262); gradient only w.r.t. the
+    features (the coordinate images are data), scattered straight from the row gradient's feature columns."""
+
+    @staticmethod
+    def forward(ctx, xyz, centre, feat, h_idx, w_idx, K, width, cpad, xyz_col, feat_col):
+        out = ops.get_backend().sa_rows(xyz, centre, feat, h_idx, w_idx, K, width, cpad, xyz_col, feat_col)
+        ctx.save_for_backward(h_idx, w_idx)
+        ctx.meta = (feat.shape, width, cpad, feat_col)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        h_idx, w_idx = ctx.saved_tensors
+        (B, HW, C), width, cpad, feat_col = ctx.meta
+        grad_feat = ops.zeros((B, HW, C), torch.float32, grad_out.device)
+        ops.get_backend().gather_rows_grad_ld(grad_out.contiguous(), cpad, feat_col, h_idx, w_idx, width, grad_feat)
+        return None, None, grad_feat, None, None, None, None, None, None, None
+
+
+def padded_width(c, pow2):
+    """channel count after modules.cat_padded: multiple of 4, or 16/32/64/128 for gradient-carrying inputs <= 128"""
+    if pow2 and c <= 128:
+        return next(w for w in (16, 32, 64, 128) if w >= c)
+    return c + (-c) % 4
+
+
+def sa_rows_fusable(xyz_img, centre, feature):
+    be = ops.get_backend()
+    return (be.device_type == "cuda" and be.name == "hip" and feature is not None and feature.dtype == torch.float32
+            and not xyz_img.requires_grad and not centre.requires_grad)
+
+
+def sa_rows(xyz_img, centre, feature, h_idx, w_idx, K, width, xyz_first=True, pow2=True):
+    """xyz_img [B,H,W,3], centre [B,N,3] (or [B,h,w,3]), feature [B,H,W,C], h_idx / w_idx [B,N,K(,1)] ->
+    [B, N, K, cpad] = cat([xyz[cell] - centre, feature[cell]]) (xyz_first) or cat([feature[cell], xyz[cell] - centre]), zero padded"""
+    B = xyz_img.shape[0]
+    C = feature.shape[-1]
+    cpad = padded_width(3 + C, pow2)
+    N = h_idx.reshape(B, -1).shape[1] // K
+    out = _SaRows.apply(xyz_img.reshape(B, -1, 3).contiguous(), centre.reshape(B, N, 3).contiguous(),
+                        feature.reshape(B, -1, C).contiguous(), h_idx.reshape(B, -1).contiguous(), w_idx.reshape(B, -1).contiguous(),
+                        K, width, cpad, 0 if xyz_first else C, 3 if xyz_first else 0)
+    return out.view(B, N, K, cpad)
+
+
 def gather_torch(feature, neigh_b_idx, neigh_h_idx, neigh_w_idx, batch, height, width):
     """feature [B,H,W,C] (any shape that reshapes to it), neigh_{h,w}_idx [B,H',W'] i64 ->
     [B,H',W',C] = feature[b, h, w, :].  `neigh_b_idx` is ignored, as in the reference

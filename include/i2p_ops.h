@@ -441,6 +441,16 @@ int i2p_sa_l1_group(int B, int H, int W, int out_h, int out_w, int stride_h, int
 long long i2p_gather_rows_grad_fx_scratch(int b, int hw, int c);
 int i2p_gather_rows_grad_fx(int b, int hw, int c, int q, int W, const float *grad_out, const int64_t *h_idx,
                             const int64_t *w_idx, void *scratch, float *grad_feat, void *stream);
+/* the same with a strided source: the c scattered channels are columns [off, off+c) of grad_out rows of pitch ld floats
+ * (backward of i2p_sa_rows: no slice copy of the grouped-row gradient) */
+int i2p_gather_rows_grad_fx_ld(int b, int hw, int c, int q, int W, const float *grad_out, int ld, int off, const int64_t *h_idx,
+                               const int64_t *w_idx, void *scratch, float *grad_feat, void *stream);
+/* Grouped input rows of a set-abstraction / up-convolution MLP in one launch (reference: gather_torch of the xyz image,
+ * subtraction of the centre, gather_torch of the feature image, cat — PPBackbone_center.py:94-129, :236-262):
+ * out f32 [b, n*K, cpad]: columns [xyz_col, +3) = xyz[b,cell,:] - centre[b,n,:], [feat_col, +c) = feat[b,cell,:], zeros elsewhere;
+ * cell = h_idx*W + w_idx [b, n*K] i64, xyz f32 [b,hw,3], centre f32 [b,n,3], feat f32 [b,hw,c]; cpad a multiple of 4, >= 3 + c. */
+int i2p_sa_rows(int b, int hw, int n, int K, int W, int c, int cpad, int xyz_col, int feat_col, const float *xyz, const float *centre,
+                const float *feat, const int64_t *h_idx, const int64_t *w_idx, float *out, void *stream);
 int i2p_pair_bias_bn_finish(int B, int N, int M, int C, const float *sum_k, const float *sum_n, const float *enc_n,
                             const float *enc_k, const double *dsums, const float *coef, const float *mi, float *d_enc_n,
                             float *d_enc_k, void *stream);   /* closed-form half of i2p_pair_bias_bn_bwd on formed sums */

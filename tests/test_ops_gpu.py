@@ -726,3 +726,29 @@ def test_sa_l1_group_matches_unfused_path(hip_backend, lattice):
     assert torch.allclose(a[..., 9], b[..., 9], rtol=1e-6, atol=0)    # |d|: torch.norm's reduction may round differently
     assert float(a[..., 10:].abs().max()) == 0.0
     assert float(a[..., :3].abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("xyz_first", [True, False])
+def test_sa_rows_matches_gather_cat(hip_backend, xyz_first):
+    """i2p_sa_rows (grouped MLP input rows in one launch, levels 2-4 / up-convolutions) against the chain it replaces:
+    gather_torch of the coordinate image - centre, gather_torch of the feature image, zero-padded cat
+    (PPBackbone_center.py:94-129, :236-262): identical values; feature gradient from the strided fixed-point scatter."""
+    from i2pnet_amd import modules, projectpn as P
+    B, H, W, C, N, K = 2, 16, 57, 35, 40, 8
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.randn(B, H, W, 3, generator=g).to(DEV); centre = torch.randn(B, N, 3, generator=g).to(DEV)
+    feat = torch.randn(B, H, W, C, generator=g).to(DEV).requires_grad_()
+    h = torch.randint(0, H, (B, N, K), generator=g).to(DEV); w = torch.randint(0, W, (B, N, K), generator=g).to(DEV)
+    h[:, :, -2:] = 0; w[:, :, -2:] = 0                                     # the reference's empty slots: cell (0, 0), many times
+    rows = P.sa_rows(xyz, centre, feat, h, w, K, W, xyz_first=xyz_first)
+    gout = torch.randn(rows.shape, generator=torch.Generator().manual_seed(4)).to(DEV)
+    (ga,) = torch.autograd.grad(rows, feat, gout)
+    d = P.gather_torch(xyz, None, h, w, B, H, W) - centre.view(B, N, 1, 3)
+    f2 = P.gather_torch(feat, None, h, w, B, H, W)
+    ref = modules.cat_padded([d, f2] if xyz_first else [f2, d], pow2=True)
+    assert rows.shape == ref.shape and torch.equal(rows, ref)
+    (gb,) = torch.autograd.grad(ref, feat, gout)
+    assert torch.allclose(ga, gb, rtol=1e-6, atol=1e-6 * float(gb.abs().max()))
+    (ga2,) = torch.autograd.grad(P.sa_rows(xyz, centre, feat, h, w, K, W, xyz_first=xyz_first), feat, gout)
+    assert torch.equal(ga, ga2)                                            # order-independent accumulation
