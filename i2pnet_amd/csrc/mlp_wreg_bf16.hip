@@ -1,0 +1,218 @@
+// wgrad of the bf16-storage layers (BASELINE configs[2] / [4]) with the ACCUMULATORS stationary in registers — the bf16
+// counterpart of mlp_wreg.hip's wreg_wgrad_kernel, replacing mlp_bf16.hip's wgrad_bf16_kernel (128-row tiles staged
+// through transposed LDS images, one barrier-synchronous block per CU: 2.7 TB/s) for the wide layers on many rows.
+// (reference op: PPBackbone_center.py:10-51, weight gradient of 1x1 conv + batch-stat BN.)
+//
+// dW[o][c] = sum_rows g^y[row][o] * a[row][c] on v_mfma_f32_32x32x16_bf16: rows are the contraction axis, a 16-row strip is
+// ONE k-step of (CO/32)(CI/32) tiles.  The MFMA wants, per lane, 8 consecutive ROWS of one channel packed two per register;
+// memory has rows of consecutive channels.  Tile jo of the A operand holds output channels {NO*i + jo} (i = lane & 31,
+// NO = CO/32): a lane then reads NO consecutive channels (8 or 4 bytes) of each of its 8 rows (k-half lane >> 5 = rows
+// 8kh..8kh+7) — whole 256/128-byte rows per load instruction —, forms g^y / a in fp32 and packs ROW PAIRS with
+// v_cvt_pk_bf16_f32 straight into the operand registers: the transposition costs nothing.  No LDS, no barrier in the
+// loop; two strips of raw data in flight per wave.  The four waves of a block add their 128x128 results through LDS in a
+// fixed order; block partials go to dw_partial[block] (reduced by the caller, as before).
+#include "bf16_common.h"
+
+namespace {
+
+constexpr int WB_THREADS = 256;
+constexpr int WB_ROWS = 16;
+
+struct WregWgradBf16P {
+    long long rows;              // multiple of 16
+    const bf16_t *gz, *y;        // [rows, CO]
+    const float *g_coef;         // [6][CO] m1, m2, scale, mean, invstd, beta of the BN behind, or nullptr (gz is dL/dy)
+    float g_slope;
+    const bf16_t *x;             // [rows, CI]
+    const float *in_coef;        // [3][CI] or nullptr
+    float slope_in;
+    float *dw_partial;           // [grid][CO*CI]
+};
+
+template <int NC> struct RawRow { unsigned v[NC / 2]; };      // NC bf16 channels of one row
+
+template <int NC>
+__device__ __forceinline__ RawRow<NC> ld_row(const bf16_t *p) {
+    RawRow<NC> r;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    if constexpr (NC == 4) { const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p)); r.v[0] = t.x; r.v[1] = t.y; }
+    else r.v[0] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p));
+    return r;
+}
+
+template <int CO, int CI>
+__global__ __launch_bounds__(WB_THREADS, 1) void wreg_wgrad_bf16_kernel(WregWgradBf16P p) {
+    constexpr int NO = CO / 32, NI = CI / 32;                   // tiles = channels per lane (4 or 2)
+    __shared__ float red[CO * CI];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    // per-lane constants of its NO output / NI input channels
+    float gA[NO], gB[NO], gC[NO], za[NO], zb[NO], xa[NI], xb[NI];
+    const bool has_g = p.g_coef != nullptr, g_act = has_g && p.g_slope != 1.f;
+#pragma unroll
+    for (int u = 0; u < NO; ++u) {
+        gA[u] = 1.f; gB[u] = 0.f; gC[u] = 0.f; za[u] = 1.f; zb[u] = 0.f;
+        if (has_g) {
+            const int ch = NO * i + u;
+            const float m1 = p.g_coef[ch], m2 = p.g_coef[CO + ch], sc = p.g_coef[2 * CO + ch], mu = p.g_coef[3 * CO + ch],
+                        is = p.g_coef[4 * CO + ch], be = p.g_coef[5 * CO + ch];
+            gA[u] = sc; gB[u] = -(sc * m2) * is; gC[u] = -(sc * m1) - gB[u] * mu; za[u] = sc; zb[u] = be - mu * sc;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        xa[u] = 1.f; xb[u] = 0.f;
+        if (p.in_coef) { const int ch = NI * i + u; xa[u] = p.in_coef[CI + ch]; xb[u] = p.in_coef[2 * CI + ch] - p.in_coef[ch] * xa[u]; }
+    }
+    i2p_f32x16 acc[NO][NI];
+#pragma unroll
+    for (int jo = 0; jo < NO; ++jo)
+#pragma unroll
+        for (int jc = 0; jc < NI; ++jc)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[jo][jc][e] = 0.f;
+
+    const long long nstrips = p.rows / WB_ROWS;
+    const long long stride = (long long)gridDim.x * 4;
+    const long long first = (long long)blockIdx.x * 4 + wave;
+    const int n_mine = __builtin_amdgcn_readfirstlane(first < nstrips ? (int)((nstrips - first + stride - 1) / stride) : 0);
+    if (n_mine > 0) {
+        // byte offsets (32 bits, launcher: tensors < 4 GB) of this lane's first row (8 kh) of the strip being REQUESTED
+        unsigned goff = (unsigned)((((size_t)first * WB_ROWS + 8 * kh) * CO + NO * i) * 2);
+        unsigned xoff = (unsigned)((((size_t)first * WB_ROWS + 8 * kh) * CI + NI * i) * 2);
+        const unsigned g_step = __builtin_amdgcn_readfirstlane((unsigned)(stride * WB_ROWS * CO * 2));
+        const unsigned x_step = __builtin_amdgcn_readfirstlane((unsigned)(stride * WB_ROWS * CI * 2));
+        int requested = 0;
+        auto at = [](const bf16_t *base, unsigned byte_off) -> const bf16_t * { return reinterpret_cast<const bf16_t *>(reinterpret_cast<const char *>(base) + byte_off); };
+        struct Raw { RawRow<NO> g[8], y[8]; RawRow<NI> x[8]; };
+        auto load = [&](Raw &R) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                R.g[j] = ld_row<NO>(at(p.gz + j * CO, goff));
+                if (has_g) R.y[j] = ld_row<NO>(at(p.y + j * CO, goff));
+                R.x[j] = ld_row<NI>(at(p.x + j * CI, xoff));
+            }
+        };
+        auto advance = [&]() { if (requested + 1 < n_mine) { goff += g_step; xoff += x_step; ++requested; } };
+        // raw strip -> operands: fp32 math per element, row pairs packed into the registers the MFMAs read
+        auto pack = [&](const Raw &R, unsigned (&A)[NO][4], unsigned (&Bm)[NI][4]) {
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {                     // rows 2jp, 2jp+1 of this lane's 8
+                float g0[NO], g1[NO];
+#pragma unroll
+                for (int u = 0; u < NO; ++u) {
+                    const unsigned w0 = R.g[2 * jp].v[u >> 1], w1 = R.g[2 * jp + 1].v[u >> 1];
+                    float t0 = (u & 1) ? bf_hi(w0) : bf_lo(w0), t1 = (u & 1) ? bf_hi(w1) : bf_lo(w1);
+                    if (has_g) {
+                        const unsigned y0w = R.y[2 * jp].v[u >> 1], y1w = R.y[2 * jp + 1].v[u >> 1];
+                        const float y0 = (u & 1) ? bf_hi(y0w) : bf_lo(y0w), y1 = (u & 1) ? bf_hi(y1w) : bf_lo(y1w);
+                        if (g_act) { t0 = bf_bnz(y0, za[u], zb[u]) > 0.f ? t0 : t0 * p.g_slope; t1 = bf_bnz(y1, za[u], zb[u]) > 0.f ? t1 : t1 * p.g_slope; }
+                        t0 = __builtin_fmaf(gA[u], t0, __builtin_fmaf(gB[u], y0, gC[u]));
+                        t1 = __builtin_fmaf(gA[u], t1, __builtin_fmaf(gB[u], y1, gC[u]));
+                    }
+                    g0[u] = t0; g1[u] = t1;
+                }
+#pragma unroll
+                for (int u = 0; u < NO; ++u) A[u][jp] = bf_pack2(g0[u], g1[u]);
+#pragma unroll
+                for (int u = 0; u < NI; ++u) {
+                    const unsigned w0 = R.x[2 * jp].v[u >> 1], w1 = R.x[2 * jp + 1].v[u >> 1];
+                    float t0 = (u & 1) ? bf_hi(w0) : bf_lo(w0), t1 = (u & 1) ? bf_hi(w1) : bf_lo(w1);
+                    if (p.in_coef) { t0 = bf_act(bf_bnz(t0, xa[u], xb[u]), p.slope_in); t1 = bf_act(bf_bnz(t1, xa[u], xb[u]), p.slope_in); }
+                    Bm[u][jp] = bf_pack2(t0, t1);
+                }
+            }
+        };
+        auto mma = [&](const unsigned (&A)[NO][4], const unsigned (&Bm)[NI][4]) {
+#pragma unroll
+            for (int jo = 0; jo < NO; ++jo) {
+                const uint4 av = make_uint4(A[jo][0], A[jo][1], A[jo][2], A[jo][3]);
+#pragma unroll
+                for (int jc = 0; jc < NI; ++jc) {
+                    const uint4 bv = make_uint4(Bm[jc][0], Bm[jc][1], Bm[jc][2], Bm[jc][3]);
+                    acc[jo][jc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(i2p_bf16x8, av), __builtin_bit_cast(i2p_bf16x8, bv), acc[jo][jc], 0, 0, 0);
+                }
+            }
+        };
+        auto strip = [&](const Raw &R) { unsigned A[NO][4], Bm[NI][4]; pack(R, A, Bm); mma(A, Bm); };
+        // strips of raw data in flight: two where the registers allow it, one at 128 x 128 (256 accumulator registers)
+        constexpr bool DEEP = CO * CI < 128 * 128;
+        if constexpr (DEEP) {
+            Raw R0, R1;
+            load(R0); advance();
+            load(R1); advance();
+            int k = 0;
+            for (; k + 1 < n_mine; k += 2) {
+                strip(R0);
+                load(R0); advance();                             // strip k + 2
+                __builtin_amdgcn_sched_barrier(0);
+                strip(R1);
+                load(R1); advance();                             // strip k + 3
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (k < n_mine) strip(R0);
+        } else {
+            // operands of strip k are packed, then strip k + 1 is requested, then the 16 MFMAs of strip k run under it
+            Raw R;
+            load(R); advance();
+            for (int k = 0; k < n_mine; ++k) {
+                unsigned A[NO][4], Bm[NI][4];
+                pack(R, A, Bm);
+                load(R); advance();
+                __builtin_amdgcn_sched_barrier(0);
+                mma(A, Bm);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // D: col = lane & 31 -> c = NI * n + jc; row = (e & 3) + 8 (e >> 2) + 4 kh -> o = NO * row + jo
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int jo = 0; jo < NO; ++jo)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int o = NO * ((e & 3) + 8 * (e >> 2) + 4 * kh) + jo;
+#pragma unroll
+                    for (int jc = 0; jc < NI; ++jc) {
+                        float *dst = red + (size_t)o * CI + NI * i + jc;
+                        *dst = (w > 0 ? *dst : 0.f) + acc[jo][jc][e];
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    float *out = p.dw_partial + (size_t)blockIdx.x * CO * CI;
+    for (int t = tid; t < CO * CI / 4; t += WB_THREADS)
+        *reinterpret_cast<float4 *>(out + 4 * t) = *reinterpret_cast<const float4 *>(red + 4 * t);
+}
+
+template <int CO, int CI>
+int launch(const WregWgradBf16P &p, unsigned grid, hipStream_t st) {
+    hipLaunchKernelGGL((wreg_wgrad_bf16_kernel<CO, CI>), dim3(grid), dim3(WB_THREADS), 0, st, p);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+bool i2p_wreg_wgrad_bf16_ok(long long rows, int cin, int cout) {
+    static const char *e = getenv("I2P_NO_WREG");
+    if (e && e[0] == '1') return false;
+    return rows >= 65536 && (rows % WB_ROWS) == 0 && (cin == 64 || cin == 128) && (cout == 64 || cout == 128) &&
+           (unsigned long long)rows * 128ull * 2ull < (1ull << 32);
+}
+
+int i2p_wreg_wgrad_bf16(long long rows, int cin, int cout, const unsigned short *gz, const unsigned short *y, const float *g_coef,
+                        float g_slope, const unsigned short *x, const float *in_coef, float slope_in, float *dw_partial, unsigned grid,
+                        void *stream) {
+    if (!i2p_wreg_wgrad_bf16_ok(rows, cin, cout) || !gz || !x || !dw_partial || grid == 0 || (g_coef && !y)) return I2P_ERR_BAD_ARG;
+    WregWgradBf16P p;
+    p.rows = rows; p.gz = gz; p.y = y; p.g_coef = g_coef; p.g_slope = g_slope; p.x = x; p.in_coef = in_coef; p.slope_in = slope_in;
+    p.dw_partial = dw_partial;
+    hipStream_t st = (hipStream_t)stream;
+    if (cout == 128 && cin == 128) return launch<128, 128>(p, grid, st);
+    if (cout == 128 && cin == 64) return launch<128, 64>(p, grid, st);
+    if (cout == 64 && cin == 128) return launch<64, 128>(p, grid, st);
+    return launch<64, 64>(p, grid, st);
+}

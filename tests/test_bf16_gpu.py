@@ -375,3 +375,25 @@ def test_bf16_training_tracks_fp32():
     assert c32[-1] < 0.8 * c32[0] and c16[-1] < 0.8 * c16[0], (c32[0], c32[-1], c16[0], c16[-1])
     tail32, tail16 = sum(c32[-5:]) / 5, sum(c16[-5:]) / 5
     assert abs(tail16 - tail32) <= 0.10 * abs(tail32), (tail32, tail16)
+
+
+@pytest.mark.parametrize("cin,cout,slope_out", [(128, 128, 1.0), (128, 64, 0.1), (64, 128, 1.0), (64, 64, 1.0)])
+def test_wgrad_bf16_in_registers(cin, cout, slope_out):
+    """wgrad of the wide bf16 layers on >= 65536 rows (csrc/mlp_wreg_bf16.hip: accumulators in registers, row pairs packed
+    into the MFMA operands without LDS) against the same fp64 evaluation of the bf16-rounded operands as test_lin_bwd_bf16"""
+    hip = _hip()
+    rows = 65536 + 16 * 7
+    x = _rnd(rows, cin, seed=11).to(BF)
+    yv = _rnd(rows, cout, seed=12).to(BF)
+    gz = _rnd(rows, cout, seed=13, scale=0.1).to(BF)
+    w = _rnd(cout, cin, seed=14, scale=cin ** -0.5)
+    oc, omi = _coef(cout, 15)
+    ic, imi = _coef(cin, 16)
+    out_ds = hip.bn_act_backward_stats_bf16(gz, yv, oc, omi, slope_out)
+    _, _, dw = hip.lin_backward(gz, yv, oc, omi, out_ds, x, ic, imi, 0.1, w, need_gx=False, slope_out=slope_out)
+    G = _g_of(gz, yv, oc, omi, out_ds, rows, slope_out)
+    xa = _bn_act(x, ic, 0.1)[0]
+    want_dw = _bfr(G).double().t() @ _bfr(xa).double()
+    assert float((dw.double() - want_dw).abs().max()) <= 2e-3 * float(want_dw.abs().max())
+    _, _, dw2 = hip.lin_backward(gz, yv, oc, omi, out_ds, x, ic, imi, 0.1, w, need_gx=False, slope_out=slope_out)
+    assert torch.equal(dw, dw2)
