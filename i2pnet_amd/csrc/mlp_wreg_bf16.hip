@@ -9,7 +9,9 @@
 // NO = CO/32): a lane then reads NO consecutive channels (8 or 4 bytes) of each of its 8 rows (k-half lane >> 5 = rows
 // 8kh..8kh+7) — whole 256/128-byte rows per load instruction —, forms g^y / a in fp32 and packs ROW PAIRS with
 // v_cvt_pk_bf16_f32 straight into the operand registers: the transposition costs nothing.  No LDS, no barrier in the
-// loop; two strips of raw data in flight per wave.  The four waves of a block add their 128x128 results through LDS in a
+// loop; two strips of raw data in flight per wave.  (A forward on the same scheme — weights in registers, x as B operand
+// straight from global memory — was measured too: 290 us against 201 us for rg_fwd_kernel at batch 16, whose LDS-staged
+// strips with two waves per SIMD already stream at 4.3-4.8 TB/s; not kept.)  The four waves of a block add their 128x128 results through LDS in a
 // fixed order; block partials go to dw_partial[block] (reduced by the caller, as before).
 #include "bf16_common.h"
 
@@ -193,6 +195,7 @@ int launch(const WregWgradBf16P &p, unsigned grid, hipStream_t st) {
     hipLaunchKernelGGL((wreg_wgrad_bf16_kernel<CO, CI>), dim3(grid), dim3(WB_THREADS), 0, st, p);
     I2P_RETURN_LAUNCH_STATUS();
 }
+
 
 }  // namespace
 

@@ -397,3 +397,4 @@ def test_wgrad_bf16_in_registers(cin, cout, slope_out):
     assert float((dw.double() - want_dw).abs().max()) <= 2e-3 * float(want_dw.abs().max())
     _, _, dw2 = hip.lin_backward(gz, yv, oc, omi, out_ds, x, ic, imi, 0.1, w, need_gx=False, slope_out=slope_out)
     assert torch.equal(dw, dw2)
+

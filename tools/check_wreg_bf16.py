@@ -21,3 +21,9 @@ for cin, cout in [(128, 128), (128, 64), (64, 128), (64, 64)]:
     by = rows * 2 * (2 * cout + cin)
     print(f"bf16 {cin}->{cout} on {rows} rows: wgrad {tw:7.1f} us = {by / tw / 1e3:5.0f} GB/s   backward {tb:7.1f} us", flush=True)
     del x, y0, xin, gz
+for cin, cout in [(128, 128), (128, 64), (64, 128), (64, 64)]:
+    x = torch.randn(rows, cin, device=dev).to(bf); w = torch.randn(cout, cin, device=dev) / cin ** 0.5
+    ic, im = hip.bn_finalize(rows, hip.bn_stats(x.float()), torch.ones(cin, device=dev), torch.zeros(cin, device=dev), 1e-5)
+    t = timeit(lambda: hip.lin_forward(x, ic, 0.1, w, out_dtype=bf), iters=30, warm=100)
+    print(f"bf16 forward {cin}->{cout} on {rows} rows: {t:7.1f} us = {rows * 2 * (cin + cout) / t / 1e3:5.0f} GB/s", flush=True)
+    del x
