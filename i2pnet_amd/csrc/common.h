@@ -93,4 +93,4 @@ int i2p_small_wgrad(long long rows, int cin, int cout, const float *gz, const fl
 bool i2p_wreg_wgrad_bf16_ok(long long rows, int cin, int cout);
 int i2p_wreg_wgrad_bf16(long long rows, int cin, int cout, const unsigned short *gz, const unsigned short *y, const float *g_coef,
                         float g_slope, const unsigned short *x, const float *in_coef, float slope_in, float *dw_partial, unsigned grid,
-                        void *stream);
+                        void *stream, const unsigned short *xb = nullptr, const float *in_coef_b = nullptr, float slope_b = 1.f);

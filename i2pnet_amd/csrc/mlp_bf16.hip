@@ -1252,10 +1252,12 @@ int bwd_impl(long long rows, int cin, int cout, const bf16_t *gz, const bf16_t *
             if (rc) return rc;
         }
     }
-    if (!two && x_bf16 && grid == 256 && i2p_wreg_wgrad_bf16_ok(rows, cin, cout)) {
+    const bool two_w3 = !two || (cin == 128 && two->split == 64 && in_coef && two->coef_b);
+    if (two_w3 && x_bf16 && grid == 256 && i2p_wreg_wgrad_bf16_ok(rows, cin, cout)) {
         // wide layer on many rows: accumulators stationary in registers, no LDS staging (csrc/mlp_wreg_bf16.hip)
         const int rc = i2p_wreg_wgrad_bf16(rows, cin, cout, gz, y, g_coef, out_coef ? slope_out : 1.f, reinterpret_cast<const bf16_t *>(x),
-                                           in_coef, slope_in, dw_partial, grid, stream);
+                                           in_coef, slope_in, dw_partial, grid, stream, two ? two->xb : nullptr, two ? two->coef_b : nullptr,
+                                           two ? two->slope_b : 1.f);
         if (rc) return rc;
         const int n = cout * cin;
         hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);

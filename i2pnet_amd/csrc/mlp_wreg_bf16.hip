@@ -25,25 +25,30 @@ struct WregWgradBf16P {
     const bf16_t *gz, *y;        // [rows, CO]
     const float *g_coef;         // [6][CO] m1, m2, scale, mean, invstd, beta of the BN behind, or nullptr (gz is dL/dy)
     float g_slope;
-    const bf16_t *x;             // [rows, CI]
-    const float *in_coef;        // [3][CI] or nullptr
+    const bf16_t *x;             // [rows, CI]  (two sources: [rows, CI/2])
+    const float *in_coef;        // [3][CI] or nullptr  (two sources: [3][CI/2])
     float slope_in;
+    const bf16_t *xb; const float *in_coef_b; float slope_b;     // second source [rows, CI/2] (TWO instantiation, CI = 128)
     float *dw_partial;           // [grid][CO*CI]
 };
 
-template <int NC> struct RawRow { unsigned v[NC / 2]; };      // NC bf16 channels of one row
+template <int NC> struct RawRow { unsigned v[(NC + 1) / 2]; };      // NC bf16 channels of one row
 
 template <int NC>
 __device__ __forceinline__ RawRow<NC> ld_row(const bf16_t *p) {
     RawRow<NC> r;
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     if constexpr (NC == 4) { const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p)); r.v[0] = t.x; r.v[1] = t.y; }
-    else r.v[0] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p));
+    else if constexpr (NC == 2) r.v[0] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p));
+    else r.v[0] = __builtin_nontemporal_load(p);             // one channel: 2 bytes (a 32-channel row = the 32 lanes of a half)
     return r;
 }
 
-template <int CO, int CI>
+// TWO: the layer input is two tensors of CI/2 channels (x, xb): a lane's four channels are 2i, 2i+1 of x and 2i, 2i+1 of xb
+// (tile jc <-> channel jc < 2 ? 2i + jc : CI/2 + 2i + jc - 2), one dword per row and source.
+template <int CO, int CI, bool TWO>
 __global__ __launch_bounds__(WB_THREADS, 1) void wreg_wgrad_bf16_kernel(WregWgradBf16P p) {
+    static_assert(!TWO || CI == 128, "two sources: 64 + 64");
     constexpr int NO = CO / 32, NI = CI / 32;                   // tiles = channels per lane (4 or 2)
     __shared__ float red[CO * CI];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -65,8 +70,13 @@ __global__ __launch_bounds__(WB_THREADS, 1) void wreg_wgrad_bf16_kernel(WregWgra
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
         xa[u] = 1.f; xb[u] = 0.f;
-        if (p.in_coef) { const int ch = NI * i + u; xa[u] = p.in_coef[CI + ch]; xb[u] = p.in_coef[2 * CI + ch] - p.in_coef[ch] * xa[u]; }
+        if (p.in_coef) {
+            const float *cf = (TWO && u >= 2) ? p.in_coef_b : p.in_coef;
+            const int ld = TWO ? CI / 2 : CI, ch = TWO ? 2 * i + (u & 1) : NI * i + u;
+            xa[u] = cf[ld + ch]; xb[u] = cf[2 * ld + ch] - cf[ch] * xa[u];
+        }
     }
+    auto xcol = [&](int u) -> int { return TWO ? (u < 2 ? 2 * i + u : CI / 2 + 2 * i + u - 2) : NI * i + u; };
     i2p_f32x16 acc[NO][NI];
 #pragma unroll
     for (int jo = 0; jo < NO; ++jo)
@@ -82,9 +92,10 @@ __global__ __launch_bounds__(WB_THREADS, 1) void wreg_wgrad_bf16_kernel(WregWgra
     if (n_mine > 0) {
         // byte offsets (32 bits, launcher: tensors < 4 GB) of this lane's first row (8 kh) of the strip being REQUESTED
         unsigned goff = (unsigned)((((size_t)first * WB_ROWS + 8 * kh) * CO + NO * i) * 2);
-        unsigned xoff = (unsigned)((((size_t)first * WB_ROWS + 8 * kh) * CI + NI * i) * 2);
+        constexpr int XLD = TWO ? CI / 2 : CI;
+        unsigned xoff = (unsigned)((((size_t)first * WB_ROWS + 8 * kh) * XLD + (TWO ? 2 : NI) * i) * 2);
         const unsigned g_step = __builtin_amdgcn_readfirstlane((unsigned)(stride * WB_ROWS * CO * 2));
-        const unsigned x_step = __builtin_amdgcn_readfirstlane((unsigned)(stride * WB_ROWS * CI * 2));
+        const unsigned x_step = __builtin_amdgcn_readfirstlane((unsigned)(stride * WB_ROWS * XLD * 2));
         int requested = 0;
         auto at = [](const bf16_t *base, unsigned byte_off) -> const bf16_t * { return reinterpret_cast<const bf16_t *>(reinterpret_cast<const char *>(base) + byte_off); };
         struct Raw { RawRow<NO> g[8], y[8]; RawRow<NI> x[8]; };
@@ -93,7 +104,10 @@ __global__ __launch_bounds__(WB_THREADS, 1) void wreg_wgrad_bf16_kernel(WregWgra
             for (int j = 0; j < 8; ++j) {
                 R.g[j] = ld_row<NO>(at(p.gz + j * CO, goff));
                 if (has_g) R.y[j] = ld_row<NO>(at(p.y + j * CO, goff));
-                R.x[j] = ld_row<NI>(at(p.x + j * CI, xoff));
+                if constexpr (TWO) {
+                    R.x[j].v[0] = ld_row<2>(at(p.x + j * XLD, xoff)).v[0];
+                    R.x[j].v[1] = ld_row<2>(at(p.xb + j * XLD, xoff)).v[0];
+                } else R.x[j] = ld_row<NI>(at(p.x + j * CI, xoff));
             }
         };
         auto advance = [&]() { if (requested + 1 < n_mine) { goff += g_step; xoff += x_step; ++requested; } };
@@ -121,7 +135,8 @@ __global__ __launch_bounds__(WB_THREADS, 1) void wreg_wgrad_bf16_kernel(WregWgra
                 for (int u = 0; u < NI; ++u) {
                     const unsigned w0 = R.x[2 * jp].v[u >> 1], w1 = R.x[2 * jp + 1].v[u >> 1];
                     float t0 = (u & 1) ? bf_hi(w0) : bf_lo(w0), t1 = (u & 1) ? bf_hi(w1) : bf_lo(w1);
-                    if (p.in_coef) { t0 = bf_act(bf_bnz(t0, xa[u], xb[u]), p.slope_in); t1 = bf_act(bf_bnz(t1, xa[u], xb[u]), p.slope_in); }
+                    const float sl = (TWO && u >= 2) ? p.slope_b : p.slope_in;
+                    if (p.in_coef) { t0 = bf_act(bf_bnz(t0, xa[u], xb[u]), sl); t1 = bf_act(bf_bnz(t1, xa[u], xb[u]), sl); }
                     Bm[u][jp] = bf_pack2(t0, t1);
                 }
             }
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(WB_THREADS, 1) void wreg_wgrad_bf16_kernel(WregWgra
                     const int o = NO * ((e & 3) + 8 * (e >> 2) + 4 * kh) + jo;
 #pragma unroll
                     for (int jc = 0; jc < NI; ++jc) {
-                        float *dst = red + (size_t)o * CI + NI * i + jc;
+                        float *dst = red + (size_t)o * CI + xcol(jc);
                         *dst = (w > 0 ? *dst : 0.f) + acc[jo][jc][e];
                     }
                 }
@@ -192,7 +207,11 @@ __global__ __launch_bounds__(WB_THREADS, 1) void wreg_wgrad_bf16_kernel(WregWgra
 
 template <int CO, int CI>
 int launch(const WregWgradBf16P &p, unsigned grid, hipStream_t st) {
-    hipLaunchKernelGGL((wreg_wgrad_bf16_kernel<CO, CI>), dim3(grid), dim3(WB_THREADS), 0, st, p);
+    if constexpr (CI == 128) {
+        if (p.xb) { hipLaunchKernelGGL((wreg_wgrad_bf16_kernel<CO, CI, true>), dim3(grid), dim3(WB_THREADS), 0, st, p); I2P_RETURN_LAUNCH_STATUS(); }
+    }
+    if (p.xb) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL((wreg_wgrad_bf16_kernel<CO, CI, false>), dim3(grid), dim3(WB_THREADS), 0, st, p);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
@@ -202,20 +221,22 @@ int launch(const WregWgradBf16P &p, unsigned grid, hipStream_t st) {
 bool i2p_wreg_wgrad_bf16_ok(long long rows, int cin, int cout) {
     static const char *e = getenv("I2P_NO_WREG");
     if (e && e[0] == '1') return false;
-    return rows >= 65536 && (rows % WB_ROWS) == 0 && (cin == 64 || cin == 128) && (cout == 64 || cout == 128) &&
+    return rows >= 65536 && (rows % WB_ROWS) == 0 && (cin == 32 || cin == 64 || cin == 128) && (cout == 32 || cout == 64 || cout == 128) &&
            (unsigned long long)rows * 128ull * 2ull < (1ull << 32);
 }
 
 int i2p_wreg_wgrad_bf16(long long rows, int cin, int cout, const unsigned short *gz, const unsigned short *y, const float *g_coef,
                         float g_slope, const unsigned short *x, const float *in_coef, float slope_in, float *dw_partial, unsigned grid,
-                        void *stream) {
+                        void *stream, const unsigned short *xb, const float *in_coef_b, float slope_b) {
     if (!i2p_wreg_wgrad_bf16_ok(rows, cin, cout) || !gz || !x || !dw_partial || grid == 0 || (g_coef && !y)) return I2P_ERR_BAD_ARG;
+    if (xb && (cin != 128 || !in_coef || !in_coef_b)) return I2P_ERR_BAD_ARG;
     WregWgradBf16P p;
     p.rows = rows; p.gz = gz; p.y = y; p.g_coef = g_coef; p.g_slope = g_slope; p.x = x; p.in_coef = in_coef; p.slope_in = slope_in;
-    p.dw_partial = dw_partial;
+    p.dw_partial = dw_partial; p.xb = xb; p.in_coef_b = in_coef_b; p.slope_b = slope_b;
     hipStream_t st = (hipStream_t)stream;
-    if (cout == 128 && cin == 128) return launch<128, 128>(p, grid, st);
-    if (cout == 128 && cin == 64) return launch<128, 64>(p, grid, st);
-    if (cout == 64 && cin == 128) return launch<64, 128>(p, grid, st);
-    return launch<64, 64>(p, grid, st);
+#define WB_CASE(O, I) if (cout == O && cin == I) return launch<O, I>(p, grid, st)
+    WB_CASE(128, 128); WB_CASE(128, 64); WB_CASE(128, 32); WB_CASE(64, 128); WB_CASE(64, 64); WB_CASE(64, 32);
+    WB_CASE(32, 128); WB_CASE(32, 64); WB_CASE(32, 32);
+#undef WB_CASE
+    return I2P_ERR_BAD_ARG;
 }

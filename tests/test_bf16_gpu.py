@@ -377,7 +377,8 @@ def test_bf16_training_tracks_fp32():
     assert abs(tail16 - tail32) <= 0.10 * abs(tail32), (tail32, tail16)
 
 
-@pytest.mark.parametrize("cin,cout,slope_out", [(128, 128, 1.0), (128, 64, 0.1), (64, 128, 1.0), (64, 64, 1.0)])
+@pytest.mark.parametrize("cin,cout,slope_out", [(128, 128, 1.0), (128, 64, 0.1), (64, 128, 1.0), (64, 64, 1.0), (32, 32, 1.0),
+                                                (32, 64, 0.1), (64, 32, 1.0), (128, 32, 1.0), (32, 128, 1.0)])
 def test_wgrad_bf16_in_registers(cin, cout, slope_out):
     """wgrad of the wide bf16 layers on >= 65536 rows (csrc/mlp_wreg_bf16.hip: accumulators in registers, row pairs packed
     into the MFMA operands without LDS) against the same fp64 evaluation of the bf16-rounded operands as test_lin_bwd_bf16"""
@@ -398,3 +399,24 @@ def test_wgrad_bf16_in_registers(cin, cout, slope_out):
     _, _, dw2 = hip.lin_backward(gz, yv, oc, omi, out_ds, x, ic, imi, 0.1, w, need_gx=False, slope_out=slope_out)
     assert torch.equal(dw, dw2)
 
+
+
+def test_wgrad_bf16_in_registers_two_sources():
+    """the 64 + 64 -> 128 layer (input = two tensors with their own BN and slopes) on the in-register wgrad: dW columns
+    [0, 64) belong to the first source, [64, 128) to the second"""
+    hip = _hip()
+    rows, cout = 65536 + 16 * 5, 128
+    xa = _rnd(rows, 64, seed=21).to(BF); xb = _rnd(rows, 64, seed=22).to(BF)
+    yv = _rnd(rows, cout, seed=23).to(BF)
+    gz = _rnd(rows, cout, seed=24, scale=0.1).to(BF)
+    w = _rnd(cout, 128, seed=25, scale=128 ** -0.5)
+    oc, omi = _coef(cout, 26)
+    ca, mia = _coef(64, 27); cb, mib = _coef(64, 28)
+    out_ds = hip.bn_act_backward_stats_bf16(gz, yv, oc, omi, 1.0)
+    dw = hip.lin_backward_2src(gz, yv, oc, omi, out_ds, xa, ca, mia, 0.1, xb, cb, mib, 1.0, None, w)[4]
+    G = _g_of(gz, yv, oc, omi, out_ds, rows, 1.0)
+    act = torch.cat([_bn_act(xa, ca, 0.1)[0], _bn_act(xb, cb, 1.0)[0]], 1)
+    want = _bfr(G).double().t() @ _bfr(act).double()
+    assert float((dw.double() - want).abs().max()) <= 2e-3 * float(want.abs().max())
+    dw2 = hip.lin_backward_2src(gz, yv, oc, omi, out_ds, xa, ca, mia, 0.1, xb, cb, mib, 1.0, None, w)[4]
+    assert torch.equal(dw, dw2)
