@@ -75,6 +75,7 @@ DEVICE_ONLY = {
     "i2p_sa_l1_group": ["i"] * 10 + ["f", "p", "p", "p"],
     "i2p_gather_rows_grad_fx_ld": ["i", "i", "i", "i", "i", "p", "i", "i", "p", "p", "p", "p"],
     "i2p_sa_rows": ["i"] * 9 + ["p"] * 6,
+    "i2p_gemm_tn": ["l", "i", "i", "p", "i", "p", "i", "p", "p"],
     "i2p_lin_fwd_fin": ["l", "i", "i", "p", "p", "f", "p", "p", "p", "p", "p", "f", "p", "p", "p"],
     "i2p_lin_fwd_2src_fin": ["l", "i", "i", "i", "p", "p", "f", "p", "p", "f", "p", "p", "p", "p", "p", "f", "p", "p", "p"],
     "i2p_pair_lin_fwd_fin": ["i"] * 5 + ["p"] * 7 + ["p", "p", "f", "p", "p", "p"],
@@ -86,8 +87,9 @@ HELPERS = {
     "i2p_pair_lin_bwd_scratch": ["i", "i", "i", "i", "i"],          # returns long long
     "i2p_pair_bias_bn_bwd_scratch": ["i", "i", "i", "i"],           # returns long long
     "i2p_gather_rows_grad_fx_scratch": ["i", "i", "i"],             # returns long long (bytes)
+    "i2p_gemm_tn_scratch": ["l", "i", "i"],                         # returns long long (bytes)
 }
-LONG_HELPERS = {"i2p_pair_lin_bwd_scratch", "i2p_pair_bias_bn_bwd_scratch", "i2p_gather_rows_grad_fx_scratch"}
+LONG_HELPERS = {"i2p_pair_lin_bwd_scratch", "i2p_pair_bias_bn_bwd_scratch", "i2p_gather_rows_grad_fx_scratch", "i2p_gemm_tn_scratch"}
 
 _CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "p": C.c_void_p, "pp": C.c_void_p}
 

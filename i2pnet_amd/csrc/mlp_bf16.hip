@@ -183,8 +183,7 @@ __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP 
             pf_f[2] = *reinterpret_cast<const float4 *>(fb); pf_f[3] = *reinterpret_cast<const float4 *>(fb + 4);
         }
     };
-    auto commit = [&](long long st) {
-        const long long row0 = st * RG_ROWS;
+    auto commit = [&](long long) {
 #pragma unroll
         for (int u = 0; u < UMAX; ++u) {
             if (u < U) {

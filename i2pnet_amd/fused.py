@@ -30,6 +30,39 @@ def layer_fits(cin, cout):
     return cin_p <= 160 and bwd <= _LDS and fwd <= _LDS
 
 
+class _LinearTN(Function):
+    """x [rows, cin] @ w[cout, cin]^T with the weight gradient on i2p_gemm_tn (rows cut over the grid) instead of the BLAS's
+    one-workgroup-per-tile tall-skinny product; forward and input gradient stay on rocBLAS (regular shapes)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        dw = ops.get_backend().gemm_tn(g, x) if ctx.needs_input_grad[1] else None
+        return gx, dw
+
+
+LINEAR_TN_MIN_ROWS = 1024
+
+
+def linear(x, w):
+    """F.linear(x, w) (no bias) for the layers outside the fused kernels: same forward; on the HIP backend and enough rows
+    the weight gradient runs on `ops.gemm_tn`"""
+    be = ops.get_backend()
+    rows = x.numel() // max(x.shape[-1], 1)
+    if (be.device_type == "cuda" and be.name == "hip" and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
+            and rows >= LINEAR_TN_MIN_ROWS and w.requires_grad and torch.is_grad_enabled()):
+        y = _LinearTN.apply(x.reshape(rows, x.shape[-1]).contiguous(), w)
+        return y.view(*x.shape[:-1], w.shape[0])
+    return F.linear(x, w)
+
+
 _BF = torch.bfloat16
 
 

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from . import ops
 from . import projectpn as P
 from . import warp as warp_utils
-from .fused import cv_knn_tail, cv_pi_tail, cv_tail_fits, layer_fits, mlp_stack, pair_fits, pair_linear, softmax_pool
+from .fused import cv_knn_tail, cv_pi_tail, cv_tail_fits, layer_fits, linear, mlp_stack, pair_fits, pair_linear, softmax_pool
 
 # run Conv2d stacks on the fused MFMA layer kernels (csrc/mlp.hip); False = library GEMM + BN kernels per block
 USE_FUSED_MLP = True
@@ -182,7 +182,7 @@ class Conv2d(nn.Module):
         return y
 
     def forward(self, x):
-        return self.finish(F.linear(x, self.weight2d()))
+        return self.finish(linear(x, self.weight2d()))
 
     def set_bn(self):
         if self.bn:
@@ -560,8 +560,8 @@ class CostVolume(nn.Module):
         Wm = first.weight2d()
         # one split (one cat in the backward) instead of four slices (four zero-filled full-size gradients)
         w_parts = torch.split(Wm, [3, 3, C] + ([Wm.shape[1] - 6 - C] if Wm.shape[1] > 6 + C else []), dim=1)
-        per_point = F.linear(xyz, w_parts[0])                                   # [B,N,c1]
-        per_pixel = F.linear(pix_xyz, w_parts[1])                               # [B,M,c1]
+        per_point = linear(xyz, w_parts[0])                                   # [B,N,c1]
+        per_pixel = linear(pix_xyz, w_parts[1])                               # [B,M,c1]
         if self.backward_validation:
             # max over points of the masked correlation (:408-414) in closed form: for a fixed pixel
             # channel g, max_n fl(f_n * g) = fl(g * max_n f_n) if g >= 0 else fl(g * min_n f_n)
@@ -569,10 +569,10 @@ class CostVolume(nn.Module):
             # three passes over the [B,N,M,C] tensor; the gradient still reaches the arg-max/min point.
             valid = P.check_valid(xyz) if self.mask_invalid else torch.ones_like(xyz[:, :, :1])
             respond = _MaxResponse.apply(pts_n, pix_n, valid)                   # [B,M,C]
-            per_pixel = per_pixel + F.linear(respond, w_parts[3])
+            per_pixel = per_pixel + linear(respond, w_parts[3])
         B_, N_ = pts_n.shape[0], pts_n.shape[1]
         we_parts = torch.split(self.pi_encoding.weight2d(), [3, 3], dim=1)
-        enc_n, enc_k = F.linear(xyz, we_parts[0]), F.linear(pix_xyz, we_parts[1])    # factors of the pre-BN encoding
+        enc_n, enc_k = linear(xyz, we_parts[0]), linear(pix_xyz, we_parts[1])    # factors of the pre-BN encoding
         rest = list(self.mlp1_convs)[1:]
         pair_ok = USE_FUSED_MLP and pair_fits(C, first.out_channels) and pix_n.shape[1] >= 64
         if pair_ok and USE_CV_TAIL and cv_tail_fits(first, rest, self.pi_encoding, list(self.mlp2_convs)):

@@ -248,6 +248,21 @@ class CBackend:
                    self._p(w_idx, _I64, "w_idx"), self._p(out, _F32, "out"), stream=self._stream())
         return out
 
+    def gemm_tn(self, a, b):
+        """a [rows, m], b [rows, n] contiguous -> a^T b [m, n], rows cut over the grid (csrc/gemm_tn.hip: the weight
+        gradient of a plain linear layer)"""
+        rows, m = a.shape
+        n = b.shape[1]
+        if b.shape[0] != rows:
+            raise ValueError("gemm_tn: operands must have the same number of rows")
+        nbytes = _lib.helper("i2p_gemm_tn_scratch", int(rows), int(m), int(n))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+        out = torch.empty(m, n, dtype=_F32, device=a.device)
+        self._call("i2p_gemm_tn", int(rows), int(m), int(n), self._p(a, _F32, "a"), int(m),
+                   self._p(b, _F32, "b"), int(n), self._p(scratch, torch.uint8, "scratch"),
+                   self._p(out, _F32, "out"), stream=self._stream())
+        return out
+
     def gather_rows_grad_ld(self, grad_out, ld, off, h_idx, w_idx, W, grad_feat):
         """gather_rows_grad from columns [off, off+C) of grad_out rows of pitch ld (fixed-point path, device only)"""
         B, HW, Cc = grad_feat.shape

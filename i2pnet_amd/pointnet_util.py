@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from . import modules, ops
 from . import projectpn as P
+from .fused import linear
 from .modules import bn_act_running
 from .pointnet2_utils import FurthestPointSampling
 
@@ -105,7 +106,7 @@ class _ConvBnView:
         return self.conv.weight.view(self.out_channels, self.in_channels)
 
     def __call__(self, x):                                   # layer outside the fused kernels' shape limits
-        y = F.linear(x, self.weight2d())
+        y = linear(x, self.weight2d())
         return bn_act_running(y, self.conv.bias, self.bn_linear, 0.0)
 
 
@@ -129,7 +130,7 @@ class PointNetSetAbstraction(nn.Module):
         """x [..., Cin] channel-last -> relu(bn(conv(x))) [..., Cout]"""
         W = conv.weight.view(conv.out_channels, conv.in_channels)
         if self.training or not bn.track_running_stats:
-            y = F.linear(x, W)                          # the bias cancels in the batch-statistics BN
+            y = linear(x, W)                            # the bias cancels in the batch-statistics BN
             return bn_act_running(y, conv.bias, bn, 0.0)
         y = F.linear(x, W, conv.bias)
         y = (y - bn.running_mean) * (torch.rsqrt(bn.running_var + bn.eps) * bn.weight) + bn.bias

@@ -451,6 +451,13 @@ int i2p_gather_rows_grad_fx_ld(int b, int hw, int c, int q, int W, const float *
  * cell = h_idx*W + w_idx [b, n*K] i64, xyz f32 [b,hw,3], centre f32 [b,n,3], feat f32 [b,hw,c]; cpad a multiple of 4, >= 3 + c. */
 int i2p_sa_rows(int b, int hw, int n, int K, int W, int c, int cpad, int xyz_col, int feat_col, const float *xyz, const float *centre,
                 const float *feat, const int64_t *h_idx, const int64_t *w_idx, float *out, void *stream);
+/* Weight gradient of a plain linear layer (autograd of F.linear in the reference: dW = g^T x, e.g. basicConv.py:22-58 layers
+ * outside the fused kernels' shape limits): out f32 [m, n] = sum_r a[r, :m]^T b[r, :n], a f32 rows of pitch lda, b of pitch ldb;
+ * rows are cut over the grid and the chunk results summed in a fixed order (bit-reproducible).
+ * scratch = i2p_gemm_tn_scratch(rows, m, n) BYTES (need not be zeroed). */
+long long i2p_gemm_tn_scratch(long long rows, int m, int n);
+int i2p_gemm_tn(long long rows, int m, int n, const float *a, int lda, const float *b, int ldb, void *scratch, float *out,
+                void *stream);
 int i2p_pair_bias_bn_finish(int B, int N, int M, int C, const float *sum_k, const float *sum_n, const float *enc_n,
                             const float *enc_k, const double *dsums, const float *coef, const float *mi, float *d_enc_n,
                             float *d_enc_k, void *stream);   /* closed-form half of i2p_pair_bias_bn_bwd on formed sums */

@@ -752,3 +752,38 @@ def test_sa_rows_matches_gather_cat(hip_backend, xyz_first):
     assert torch.allclose(ga, gb, rtol=1e-6, atol=1e-6 * float(gb.abs().max()))
     (ga2,) = torch.autograd.grad(P.sa_rows(xyz, centre, feat, h, w, K, W, xyz_first=xyz_first), feat, gout)
     assert torch.equal(ga, ga2)                                            # order-independent accumulation
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,m,n", [(14848, 256, 128), (3744, 3, 64), (1824, 64, 192), (1000, 5, 7), (33, 70, 130), (928, 128, 320)])
+def test_gemm_tn_matches_fp64(hip_backend, rows, m, n):
+    """i2p_gemm_tn (weight gradient of the plain linear layers: a^T b with the rows cut over the grid) against fp64, ragged
+    tiles and a row count that is not a multiple of the stage; two runs agree bit for bit (fixed summation order)"""
+    g = torch.Generator().manual_seed(rows + m)
+    a = torch.randn(rows, m, generator=g).cuda(); b = torch.randn(rows, n, generator=g).cuda()
+    out = hip_backend.gemm_tn(a, b)
+    want = a.double().t() @ b.double()
+    assert out.shape == (m, n)
+    assert float((out.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-4
+    assert torch.equal(out, hip_backend.gemm_tn(a, b))
+
+
+@pytest.mark.gpu
+def test_linear_weight_grad_on_gemm_tn(hip_backend):
+    """fused.linear == F.linear in value, input gradient and weight gradient (the latter on i2p_gemm_tn), strided weight view"""
+    from i2pnet_amd import fused
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 936, 200, generator=g).cuda().requires_grad_(True)
+    Wfull = torch.randn(96, 203, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(4, 936, 96, generator=g).cuda()
+    outs = []
+    for fn in (fused.linear, F.linear):
+        w = torch.split(Wfull, [3, 200], dim=1)[1]
+        y = fn(x, w)
+        gx, gw = torch.autograd.grad(y, (x, Wfull), go)
+        outs.append((y, gx, gw))
+    (y0, gx0, gw0), (y1, gx1, gw1) = outs
+    assert torch.allclose(y0, y1, rtol=1e-5, atol=1e-5) and torch.allclose(gx0, gx1, rtol=1e-5, atol=1e-5)
+    assert float((gw0 - gw1).abs().max()) <= 2e-5 * float(gw1.abs().max()) + 1e-4
+    assert float(gw0[:, :3].abs().max()) == 0.0

@@ -1,0 +1,31 @@
+"""Shapes and device time of the rocBLAS GEMMs (aten::mm / addmm / bmm / matmul) left in one eager training step."""
+import os
+import sys
+
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from i2pnet_amd import synth  # noqa: E402
+from i2pnet_amd.config import I2PNetConfig as cfg  # noqa: E402
+from i2pnet_amd.train import Trainer  # noqa: E402
+
+dev = torch.device("cuda", 0)
+tr = Trainer(cfg=cfg, device=dev)
+batch = synth.make_batch(8, 8192, 375, 1242, seed=1, device=dev)
+for _ in range(3):
+    tr.step(batch)           # eager: no capture() was called
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    tr.step(batch)
+    torch.cuda.synchronize()
+rows = []
+for e in prof.key_averages(group_by_input_shape=True):
+    if e.key in ("aten::mm", "aten::addmm", "aten::bmm"):
+        rows.append((e.device_time_total, e.count, e.key, str(e.input_shapes)))
+rows.sort(reverse=True)
+tot = 0
+for t, n, k, s in rows:
+    tot += t
+    print(f"{t:9.1f} us  x{n:<3d} {k:12s} {s}")
+print("total", tot)
