@@ -1680,6 +1680,48 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int nparts, int n,
     }
 }
 
+// the same sum on 16-byte columns: 16 float4 columns x 16 partial lanes per block (a wave reads four 256-byte runs per step,
+// four steps in flight) — the 256 x 64 KB partials of a 128 x 128 layer are read at HBM rate instead of 128-byte touches
+__global__ __launch_bounds__(256) void reduce_partials_v4_kernel(int nparts, int n4, const float4 *__restrict__ parts, float4 *__restrict__ out) {
+    __shared__ float4 red[16][16];
+    const int tx = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + tx;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o < n4) {
+        int b = pl;
+        for (; b + 48 < nparts; b += 64) {
+            const float4 v0 = parts[(size_t)b * n4 + o], v1 = parts[(size_t)(b + 16) * n4 + o];
+            const float4 v2 = parts[(size_t)(b + 32) * n4 + o], v3 = parts[(size_t)(b + 48) * n4 + o];
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+            a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+            a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+            a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+        }
+        for (; b < nparts; b += 16) {
+            const float4 v = parts[(size_t)b * n4 + o];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    red[pl][tx] = a;
+    __syncthreads();
+    if (pl == 0 && o < n4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const float4 v = red[q][tx]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        out[o] = t;
+    }
+}
+
+inline void launch_reduce_partials(int nparts, int n, const float *parts, float *out, hipStream_t st) {
+    if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(parts) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const int n4 = n >> 2;
+        hipLaunchKernelGGL(reduce_partials_v4_kernel, dim3((n4 + 15) / 16), dim3(256), 0, st, nparts, n4, reinterpret_cast<const float4 *>(parts),
+                           reinterpret_cast<float4 *>(out));
+    } else {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, nparts, n, parts, out);
+    }
+}
+
 template <int NTI, int NTO>
 int launch_bwd(LinBwdParams &p, float *dw, hipStream_t st, unsigned grid) {
     const size_t bytes = ((size_t)p.cout_p * p.ldw + (size_t)BWD_R * p.ldg + (size_t)BWD_R * p.ldx + 6 * (size_t)p.cout_p + 4 * (size_t)p.cin_p) * sizeof(float);
@@ -1692,7 +1734,7 @@ int launch_bwd(LinBwdParams &p, float *dw, hipStream_t st, unsigned grid) {
     }
     hipLaunchKernelGGL((lin_bwd_kernel<NTI, NTO>), dim3(grid), dim3(THREADS), bytes, st, p);
     const int n = p.cout * p.cin;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, p.dw_partial, dw);
+    launch_reduce_partials((int)grid, n, p.dw_partial, dw, st);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
@@ -1880,7 +1922,7 @@ static int launch_wgrad_t(const WgradParams &q, float *dw, hipStream_t st, unsig
     }
     hipLaunchKernelGGL((lin_wgrad_kernel<NTI, NTO, FIXC>), dim3(grid), dim3(WG_THREADS), bytes, st, q);
     const int n = q.cout * q.cin;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, q.dw_partial, dw);
+    launch_reduce_partials((int)grid, n, q.dw_partial, dw, st);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
@@ -1971,7 +2013,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
                                                slope_in, dw_partial, grid, stream);
                 if (rc) return rc;
                 const int n = cout * cin;
-                hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
+                launch_reduce_partials((int)grid, n, dw_partial, dw, st);
                 I2P_RETURN_LAUNCH_STATUS();
             }
             const bool two_ok = !two || (in_coef && two->in_coef_b && two->split_c * 2 == cin && cin == 128 && two->slope_b >= 0.f && two->slope_b <= 1.f);
@@ -1983,7 +2025,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
                                               two ? two->split_c : 0, dw_partial, grid, stream);
                 if (rc) return rc;
                 const int n = cout * cin;
-                hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
+                launch_reduce_partials((int)grid, n, dw_partial, dw, st);
                 I2P_RETURN_LAUNCH_STATUS();
             }
             WgradParams wq;
@@ -2036,7 +2078,7 @@ static int launch_pair_bwd(PairBwdParams &p, float *dw, hipStream_t st, unsigned
     }
     hipLaunchKernelGGL((pair_bwd_kernel<NTI, NTO>), dim3(grid), dim3(THREADS), bytes, st, p);
     const int n = p.cout * p.cin;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, p.dw_partial, dw);
+    launch_reduce_partials((int)grid, n, p.dw_partial, dw, st);
     const int KT = (p.M + BWD_R - 1) / BWD_R;
     auto red = [&](int nslab, long long cnt, const float *slabs, float *out) {
         long long blocks = (cnt + 255) / 256; if (blocks > 2048) blocks = 2048;
@@ -2071,7 +2113,7 @@ extern "C" int i2p_pair_lin_bwd(int B, int N, int M, int cin, int cout, const fl
         if (rc) return rc;
         hipStream_t st3 = (hipStream_t)stream;
         const int n = cout * cin;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 31) / 32), dim3(256), 0, st3, 256, n, dw_partial, dw);
+        launch_reduce_partials(256, n, dw_partial, dw, st3);
         auto red3 = [&](int nslab, long long cnt, const float *slabs, float *out) {
             long long blocks = (cnt + 255) / 256; if (blocks > 2048) blocks = 2048;
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st3, nslab, cnt, slabs, out);
