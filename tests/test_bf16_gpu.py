@@ -354,7 +354,10 @@ def test_bf16_mode_is_actually_bf16():
 def test_bf16_training_tracks_fp32():
     """Matched loss (BASELINE north star): 40 optimisation steps on one fixed batch in fp32 and in bf16 storage mode
     from the same initial weights: both must reduce the loss, and the bf16 curve must stay within 10 % of the fp32
-    curve's final value (dropout off: its mask would otherwise differ between the two runs' RNG consumption)."""
+    curve's final value (dropout off: its mask would otherwise differ between the two runs' RNG consumption).
+    Two fp32 runs from the same seed do not retrace each other either (MIOpen's split-K convolution weight gradients
+    accumulate with atomics; 40 Adam steps amplify the last bits: tails 4-6 % apart, tools/diag_bf16_curve.py), so the
+    fp32 curve is run twice and its own run-to-run spread is added to the allowance."""
     from i2pnet_amd import ops, synth
     from i2pnet_amd.config import I2PNetConfig as cfg
     from i2pnet_amd.train import Trainer
@@ -370,11 +373,12 @@ def test_bf16_training_tracks_fp32():
             return [float(tr.step(batch)[0]) for _ in range(40)]
         finally:
             ops.set_precision(prev); ops.BF16_MIN_ROWS = prev_r
-    c32, c16 = curve("fp32"), curve("bf16")
+    c32, c32b, c16 = curve("fp32"), curve("fp32"), curve("bf16")
     assert all(math.isfinite(v) for v in c16)
     assert c32[-1] < 0.8 * c32[0] and c16[-1] < 0.8 * c16[0], (c32[0], c32[-1], c16[0], c16[-1])
-    tail32, tail16 = sum(c32[-5:]) / 5, sum(c16[-5:]) / 5
-    assert abs(tail16 - tail32) <= 0.10 * abs(tail32), (tail32, tail16)
+    tail = lambda c: sum(c[-5:]) / 5
+    tail32, spread, tail16 = (tail(c32) + tail(c32b)) / 2, abs(tail(c32) - tail(c32b)), tail(c16)
+    assert abs(tail16 - tail32) <= 0.10 * abs(tail32) + 2 * spread, (tail(c32), tail(c32b), tail16)
 
 
 @pytest.mark.parametrize("cin,cout,slope_out", [(128, 128, 1.0), (128, 64, 0.1), (64, 128, 1.0), (64, 64, 1.0), (32, 32, 1.0),
