@@ -1262,6 +1262,15 @@ int bwd_impl(long long rows, int cin, int cout, const bf16_t *gz, const bf16_t *
         hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
         I2P_RETURN_LAUNCH_STATUS();
     }
+    if (!two && grid == 256 && i2p_small_wgrad_bf16_ok(rows, cin, cout, x_bf16)) {
+        // narrow level-1 layer on many rows: HBM streaming, one element per lane and k-step (csrc/mlp_wreg_bf16.hip)
+        const int rc = i2p_small_wgrad_bf16(rows, cin, cout, gz, y, g_coef, out_coef ? slope_out : 1.f, x, x_bf16, in_coef, slope_in, dw_partial,
+                                            grid, stream);
+        if (rc) return rc;
+        const int n = cout * cin;
+        hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
+        I2P_RETURN_LAUNCH_STATUS();
+    }
     WgradP wq{};
     wq.rows = rows; wq.cin = cin; wq.cout = cout; wq.nco = cout / 8; wq.ncx = (cin + 7) / 8;
     wq.gz = gz; wq.y = y; wq.g_coef = g_coef; wq.g_slope = out_coef ? slope_out : 1.f;

@@ -216,6 +216,115 @@ int launch(const WregWgradBf16P &p, unsigned grid, hipStream_t st) {
 }
 
 
+// =====================================================================================================================
+// wgrad of the NARROW bf16 layers on many rows (level-1 set abstraction at batch 16: 12/16 -> 16 -> 16 -> 32 channels on
+// 1.8 M rows): the same streaming scheme as mlp_wreg.hip small_wgrad_kernel — rows are the K axis of v_mfma_f32_16x16x4_f32,
+// lane (channel n = lane & 15, k-slot q) reads ONE element per tensor, tile and k-step (bf16: 2 bytes, the 16 lanes of a
+// k-slot cover a 32-byte row), 16 waves per CU hide the latency by occupancy, the next strip is requested before the
+// current one is consumed.  g^y and the activated input are formed in fp32 exactly like the bf16 layer kernels form them
+// and rounded to bf16 (the operands the bf16 MFMA path would see); accumulation fp32.
+// (wgrad_bf16_kernel stages these through LDS at 0.5 TB/s: 373 us for the 16 -> 32 layer; here HBM streaming.)
+// =====================================================================================================================
+struct SmallWgradBf16P {
+    long long rows;              // multiple of 16
+    int cin, cout;               // cin <= 16, cout = 16 * NO
+    const bf16_t *gz, *y;        // [rows, cout]
+    const float *g_coef; float g_slope;
+    const void *x;               // [rows, cin] bf16 (XBF) or f32
+    const float *in_coef; float slope_in;
+    float *dw_partial;           // [grid][cout*cin]
+};
+constexpr int SWB_THREADS = 1024;
+
+template <int NO, bool XBF>
+__global__ __launch_bounds__(SWB_THREADS) void small_wgrad_bf16_kernel(SmallWgradBf16P p) {
+    __shared__ float red[16 * NO * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int CO = 16 * NO, CI = p.cin;
+    const bool has_g = p.g_coef != nullptr, g_act = has_g && p.g_slope != 1.f;
+    float gA[NO], gB[NO], gC[NO], za[NO], zb[NO];
+#pragma unroll
+    for (int jo = 0; jo < NO; ++jo) {
+        gA[jo] = 1.f; gB[jo] = 0.f; gC[jo] = 0.f; za[jo] = 1.f; zb[jo] = 0.f;
+        if (has_g) {
+            const int ch = 16 * jo + n;
+            const float m1 = p.g_coef[ch], m2 = p.g_coef[CO + ch], sc = p.g_coef[2 * CO + ch], mu = p.g_coef[3 * CO + ch],
+                        is = p.g_coef[4 * CO + ch], be = p.g_coef[5 * CO + ch];
+            gA[jo] = sc; gB[jo] = -(sc * m2) * is; gC[jo] = -(sc * m1) - gB[jo] * mu; za[jo] = sc; zb[jo] = be - mu * sc;
+        }
+    }
+    const bool xin = n < CI;
+    float xa = 1.f, xb = 0.f;
+    if (p.in_coef && xin) { xa = p.in_coef[CI + n]; xb = p.in_coef[2 * CI + n] - p.in_coef[n] * xa; }
+    const bf16_t *xh = reinterpret_cast<const bf16_t *>(p.x);
+    const float *xf = reinterpret_cast<const float *>(p.x);
+
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[NO];
+#pragma unroll
+    for (int jo = 0; jo < NO; ++jo) acc[jo] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long long nstrips = p.rows / 16;
+    const long long stride = (long long)gridDim.x * (SWB_THREADS / 64);
+    float g[4][NO], yy[4][NO], xx[4], gn[4][NO], yn[4][NO], xn[4];
+    auto up = [](bf16_t h) -> float { return __uint_as_float((unsigned)h << 16); };
+    auto load = [&](long long s, float (&G)[4][NO], float (&Y)[4][NO], float (&X)[4]) {
+        const size_t r0 = (size_t)s * 16 + q;                    // k-step t: row r0 + 4t
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int jo = 0; jo < NO; ++jo) {
+                G[t][jo] = up(__builtin_nontemporal_load(p.gz + (r0 + 4 * t) * CO + 16 * jo + n));
+                Y[t][jo] = has_g ? up(__builtin_nontemporal_load(p.y + (r0 + 4 * t) * CO + 16 * jo + n)) : 0.f;
+            }
+            if constexpr (XBF) X[t] = xin ? up(__builtin_nontemporal_load(xh + (r0 + 4 * t) * CI + n)) : 0.f;
+            else X[t] = xin ? __builtin_nontemporal_load(xf + (r0 + 4 * t) * CI + n) : 0.f;
+        }
+    };
+    long long s = (long long)blockIdx.x * (SWB_THREADS / 64) + wave;
+    if (s < nstrips) load(s, g, yy, xx);
+    for (; s < nstrips; s += stride) {
+        const long long sn = s + stride < nstrips ? s + stride : s;
+        load(sn, gn, yn, xn);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float a = xx[t];
+            if (p.in_coef) a = bf_act(bf_bnz(a, xa, xb), p.slope_in);
+            a = xin ? bf_round(a) : 0.f;
+#pragma unroll
+            for (int jo = 0; jo < NO; ++jo) {
+                float tg = g[t][jo];
+                if (has_g) {
+                    if (g_act) tg = bf_bnz(yy[t][jo], za[jo], zb[jo]) > 0.f ? tg : tg * p.g_slope;
+                    tg = __builtin_fmaf(gA[jo], tg, __builtin_fmaf(gB[jo], yy[t][jo], gC[jo]));
+                }
+                acc[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_round(tg), a, acc[jo], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            xx[t] = xn[t];
+#pragma unroll
+            for (int jo = 0; jo < NO; ++jo) { g[t][jo] = gn[t][jo]; yy[t][jo] = yn[t][jo]; }
+        }
+    }
+    // D[o][c]: lane (c = n, q): rows o = 16 jo + 4q + e.  The waves of the block add through LDS in a fixed order.
+    for (int w = 0; w < SWB_THREADS / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int jo = 0; jo < NO; ++jo)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float *dst = red + (16 * jo + 4 * q + e) * 16 + n;
+                    *dst = (w > 0 ? *dst : 0.f) + acc[jo][e];
+                }
+        }
+        __syncthreads();
+    }
+    float *out = p.dw_partial + (size_t)blockIdx.x * CO * CI;
+    for (int i = tid; i < CO * CI; i += SWB_THREADS) out[i] = red[(i / CI) * 16 + i % CI];
+}
+
 }  // namespace
 
 bool i2p_wreg_wgrad_bf16_ok(long long rows, int cin, int cout) {
@@ -239,4 +348,28 @@ int i2p_wreg_wgrad_bf16(long long rows, int cin, int cout, const unsigned short 
     WB_CASE(32, 128); WB_CASE(32, 64); WB_CASE(32, 32);
 #undef WB_CASE
     return I2P_ERR_BAD_ARG;
+}
+
+bool i2p_small_wgrad_bf16_ok(long long rows, int cin, int cout, int x_bf16) {
+    static const char *e = getenv("I2P_NO_WREG");
+    if (e && e[0] == '1') return false;
+    return rows >= 262144 && (rows % 16) == 0 && (cout == 16 || cout == 32) && (x_bf16 ? cin == 16 : (cin >= 4 && cin <= 16 && (cin & 3) == 0));
+}
+
+int i2p_small_wgrad_bf16(long long rows, int cin, int cout, const unsigned short *gz, const unsigned short *y, const float *g_coef,
+                         float g_slope, const void *x, int x_bf16, const float *in_coef, float slope_in, float *dw_partial, unsigned grid,
+                         void *stream) {
+    if (!i2p_small_wgrad_bf16_ok(rows, cin, cout, x_bf16) || !gz || !x || !dw_partial || grid == 0 || (g_coef && !y)) return I2P_ERR_BAD_ARG;
+    SmallWgradBf16P p;
+    p.rows = rows; p.cin = cin; p.cout = cout; p.gz = gz; p.y = y; p.g_coef = g_coef; p.g_slope = g_slope; p.x = x; p.in_coef = in_coef;
+    p.slope_in = slope_in; p.dw_partial = dw_partial;
+    hipStream_t st = (hipStream_t)stream;
+    if (cout == 16) {
+        if (x_bf16) hipLaunchKernelGGL((small_wgrad_bf16_kernel<1, true>), dim3(grid), dim3(SWB_THREADS), 0, st, p);
+        else hipLaunchKernelGGL((small_wgrad_bf16_kernel<1, false>), dim3(grid), dim3(SWB_THREADS), 0, st, p);
+    } else {
+        if (x_bf16) hipLaunchKernelGGL((small_wgrad_bf16_kernel<2, true>), dim3(grid), dim3(SWB_THREADS), 0, st, p);
+        else hipLaunchKernelGGL((small_wgrad_bf16_kernel<2, false>), dim3(grid), dim3(SWB_THREADS), 0, st, p);
+    }
+    I2P_RETURN_LAUNCH_STATUS();
 }

@@ -424,3 +424,26 @@ def test_wgrad_bf16_in_registers_two_sources():
     assert float((dw.double() - want).abs().max()) <= 2e-3 * float(want.abs().max())
     dw2 = hip.lin_backward_2src(gz, yv, oc, omi, out_ds, xa, ca, mia, 0.1, xb, cb, mib, 1.0, None, w)[4]
     assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize("cin,cout,xbf,slope_out", [(16, 16, True, 1.0), (16, 32, True, 0.1), (12, 16, False, 0.0), (16, 32, False, 1.0)])
+def test_small_wgrad_bf16_streaming(cin, cout, xbf, slope_out):
+    """wgrad of the narrow level-1 layers on >= 262144 rows (csrc/mlp_wreg_bf16.hip small_wgrad_bf16_kernel: one element per
+    lane and k-step, fp32 MFMA on bf16-rounded operands) against the fp64 product of the bf16-rounded operands"""
+    hip = _hip()
+    rows = 262144 + 16 * 9
+    x = _rnd(rows, cin, seed=31)
+    x = x.to(BF) if xbf else x
+    yv = _rnd(rows, cout, seed=32).to(BF)
+    gz = _rnd(rows, cout, seed=33, scale=0.1).to(BF)
+    w = _rnd(cout, cin, seed=34, scale=cin ** -0.5)
+    oc, omi = _coef(cout, 35)
+    ic, imi = _coef(cin, 36) if xbf else (None, None)
+    out_ds = hip.bn_act_backward_stats_bf16(gz, yv, oc, omi, slope_out)
+    _, _, dw = hip.lin_backward(gz, yv, oc, omi, out_ds, x, ic, imi, 0.1, w, need_gx=False, slope_out=slope_out)
+    G = _g_of(gz, yv, oc, omi, out_ds, rows, slope_out)
+    xa = _bn_act(x, ic, 0.1)[0] if xbf else x.float()
+    want_dw = _bfr(G).double().t() @ _bfr(xa).double()
+    assert float((dw.double() - want_dw).abs().max()) <= 2e-3 * float(want_dw.abs().max())
+    _, _, dw2 = hip.lin_backward(gz, yv, oc, omi, out_ds, x, ic, imi, 0.1, w, need_gx=False, slope_out=slope_out)
+    assert torch.equal(dw, dw2)
