@@ -218,46 +218,65 @@ int launch(const WregWgradBf16P &p, unsigned grid, hipStream_t st) {
 
 // =====================================================================================================================
 // wgrad of the NARROW bf16 layers on many rows (level-1 set abstraction at batch 16: 12/16 -> 16 -> 16 -> 32 channels on
-// 1.8 M rows): the same streaming scheme as mlp_wreg.hip small_wgrad_kernel — rows are the K axis of v_mfma_f32_16x16x4_f32,
-// lane (channel n = lane & 15, k-slot q) reads ONE element per tensor, tile and k-step (bf16: 2 bytes, the 16 lanes of a
-// k-slot cover a 32-byte row), 16 waves per CU hide the latency by occupancy, the next strip is requested before the
-// current one is consumed.  g^y and the activated input are formed in fp32 exactly like the bf16 layer kernels form them
-// and rounded to bf16 (the operands the bf16 MFMA path would see); accumulation fp32.
-// (wgrad_bf16_kernel stages these through LDS at 0.5 TB/s: 373 us for the 16 -> 32 layer; here HBM streaming.)
+// 1.8 M rows): the same streaming scheme as mlp_wreg.hip small_wgrad_kernel — rows are the K axis of v_mfma_f32_16x16x4_f32
+// (k-step t of a 16-row strip = rows 4t + q, q = lane >> 4), 16 waves per CU hide the latency by occupancy, the next strip is
+// requested before the current one is consumed.  Every load is a DWORD (two bf16 channels):
+//   32-channel tensor: lane n reads channels (2n, 2n+1) of row 4t + q — the 16 lanes of a k-slot cover the 64-byte row; the
+//     low halves are tile 0 (channel 2n), the high halves tile 1 (channel 2n+1) of the same k-step;
+//   16-channel tensor: lanes n < 8 read channels (2n, 2n+1) of row 8u + q, lanes n >= 8 the same channels of row 8u + 4 + q;
+//     one DPP row rotation by 8 exchanges halves so that lane n holds channel 2(n & 7) + (n >> 3) of BOTH rows: low half =
+//     k-step 2u, high half = k-step 2u + 1.
+// g^y and the activated input are formed in fp32 exactly like the bf16 layer kernels form them and rounded to bf16 (the
+// operands the bf16 MFMA path sees); accumulation fp32.  (wgrad_bf16_kernel stages these through LDS: 373 us for 16 -> 32.)
 // =====================================================================================================================
 struct SmallWgradBf16P {
     long long rows;              // multiple of 16
     int cin, cout;               // cin <= 16, cout = 16 * NO
     const bf16_t *gz, *y;        // [rows, cout]
     const float *g_coef; float g_slope;
-    const void *x;               // [rows, cin] bf16 (XBF) or f32
+    const void *x;               // [rows, cin] bf16 (XBF, cin = 16) or f32
     const float *in_coef; float slope_in;
     float *dw_partial;           // [grid][cout*cin]
 };
 constexpr int SWB_THREADS = 1024;
+
+// 16-channel rows: the strip's two dwords of this lane -> values of k-steps 0..3 for channel 2(n&7) + (n>>3)
+__device__ __forceinline__ void swb_unzip16(const unsigned (&raw)[2], bool upper, float (&v)[4]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const unsigned own = raw[u];
+        const unsigned par = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+        v[2 * u] = upper ? bf_hi(par) : bf_lo(own);
+        v[2 * u + 1] = upper ? bf_hi(own) : bf_lo(par);
+    }
+}
 
 template <int NO, bool XBF>
 __global__ __launch_bounds__(SWB_THREADS) void small_wgrad_bf16_kernel(SmallWgradBf16P p) {
     __shared__ float red[16 * NO * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
+    const bool upper = n >= 8;
     const int CO = 16 * NO, CI = p.cin;
+    const int perm16 = 2 * (n & 7) + (n >> 3);                   // this lane's channel of a 16-channel bf16 tensor
     const bool has_g = p.g_coef != nullptr, g_act = has_g && p.g_slope != 1.f;
     float gA[NO], gB[NO], gC[NO], za[NO], zb[NO];
 #pragma unroll
     for (int jo = 0; jo < NO; ++jo) {
         gA[jo] = 1.f; gB[jo] = 0.f; gC[jo] = 0.f; za[jo] = 1.f; zb[jo] = 0.f;
         if (has_g) {
-            const int ch = 16 * jo + n;
+            const int ch = NO == 2 ? 2 * n + jo : perm16;
             const float m1 = p.g_coef[ch], m2 = p.g_coef[CO + ch], sc = p.g_coef[2 * CO + ch], mu = p.g_coef[3 * CO + ch],
                         is = p.g_coef[4 * CO + ch], be = p.g_coef[5 * CO + ch];
             gA[jo] = sc; gB[jo] = -(sc * m2) * is; gC[jo] = -(sc * m1) - gB[jo] * mu; za[jo] = sc; zb[jo] = be - mu * sc;
         }
     }
-    const bool xin = n < CI;
+    const int xch = XBF ? perm16 : n;                            // this lane's input channel
+    const bool xin = xch < CI;
     float xa = 1.f, xb = 0.f;
-    if (p.in_coef && xin) { xa = p.in_coef[CI + n]; xb = p.in_coef[2 * CI + n] - p.in_coef[n] * xa; }
-    const bf16_t *xh = reinterpret_cast<const bf16_t *>(p.x);
+    if (p.in_coef && xin) { xa = p.in_coef[CI + xch]; xb = p.in_coef[2 * CI + xch] - p.in_coef[xch] * xa; }
+    const unsigned *gzw = reinterpret_cast<const unsigned *>(p.gz), *yw = reinterpret_cast<const unsigned *>(p.y);
+    const unsigned *xw = reinterpret_cast<const unsigned *>(p.x);
     const float *xf = reinterpret_cast<const float *>(p.x);
 
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -266,56 +285,77 @@ __global__ __launch_bounds__(SWB_THREADS) void small_wgrad_bf16_kernel(SmallWgra
     for (int jo = 0; jo < NO; ++jo) acc[jo] = f32x4{0.f, 0.f, 0.f, 0.f};
     const long long nstrips = p.rows / 16;
     const long long stride = (long long)gridDim.x * (SWB_THREADS / 64);
-    float g[4][NO], yy[4][NO], xx[4], gn[4][NO], yn[4][NO], xn[4];
-    auto up = [](bf16_t h) -> float { return __uint_as_float((unsigned)h << 16); };
-    auto load = [&](long long s, float (&G)[4][NO], float (&Y)[4][NO], float (&X)[4]) {
-        const size_t r0 = (size_t)s * 16 + q;                    // k-step t: row r0 + 4t
+    constexpr int NG = NO == 2 ? 4 : 2, NX = XBF ? 2 : 4;
+    struct Raw { unsigned g[NG], y[NG]; unsigned x[NX]; };
+    auto load = [&](long long s, Raw &R) {
+        const size_t r0 = (size_t)s * 16;
+        if constexpr (NO == 2) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int jo = 0; jo < NO; ++jo) {
-                G[t][jo] = up(__builtin_nontemporal_load(p.gz + (r0 + 4 * t) * CO + 16 * jo + n));
-                Y[t][jo] = has_g ? up(__builtin_nontemporal_load(p.y + (r0 + 4 * t) * CO + 16 * jo + n)) : 0.f;
+            for (int t = 0; t < 4; ++t) {                        // row 4t + q, dword n of its 16
+                R.g[t] = __builtin_nontemporal_load(gzw + (r0 + 4 * t + q) * 16 + n);
+                R.y[t] = has_g ? __builtin_nontemporal_load(yw + (r0 + 4 * t + q) * 16 + n) : 0u;
             }
-            if constexpr (XBF) X[t] = xin ? up(__builtin_nontemporal_load(xh + (r0 + 4 * t) * CI + n)) : 0.f;
-            else X[t] = xin ? __builtin_nontemporal_load(xf + (r0 + 4 * t) * CI + n) : 0.f;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {                        // row 8u + q (+4 for the upper lanes), dword n & 7 of its 8
+                const size_t r = r0 + 8 * u + q + (upper ? 4 : 0);
+                R.g[u] = __builtin_nontemporal_load(gzw + r * 8 + (n & 7));
+                R.y[u] = has_g ? __builtin_nontemporal_load(yw + r * 8 + (n & 7)) : 0u;
+            }
+        }
+        if constexpr (XBF) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) R.x[u] = __builtin_nontemporal_load(xw + (r0 + 8 * u + q + (upper ? 4 : 0)) * 8 + (n & 7));
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) R.x[t] = xin ? __float_as_uint(__builtin_nontemporal_load(xf + (r0 + 4 * t + q) * CI + n)) : 0u;
         }
     };
+    Raw cur, nxt;
     long long s = (long long)blockIdx.x * (SWB_THREADS / 64) + wave;
-    if (s < nstrips) load(s, g, yy, xx);
+    if (s < nstrips) load(s, cur);
     for (; s < nstrips; s += stride) {
         const long long sn = s + stride < nstrips ? s + stride : s;
-        load(sn, gn, yn, xn);
+        load(sn, nxt);
+        float gv[NO][4], yv[NO][4], xv[4];
+        if constexpr (NO == 2) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { gv[0][t] = bf_lo(cur.g[t]); gv[1][t] = bf_hi(cur.g[t]); yv[0][t] = bf_lo(cur.y[t]); yv[1][t] = bf_hi(cur.y[t]); }
+        } else {
+            swb_unzip16(cur.g, upper, gv[0]); swb_unzip16(cur.y, upper, yv[0]);
+        }
+        if constexpr (XBF) swb_unzip16(cur.x, upper, xv);
+        else
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xv[t] = __uint_as_float(cur.x[t]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            float a = xx[t];
+            float a = xv[t];
             if (p.in_coef) a = bf_act(bf_bnz(a, xa, xb), p.slope_in);
             a = xin ? bf_round(a) : 0.f;
 #pragma unroll
             for (int jo = 0; jo < NO; ++jo) {
-                float tg = g[t][jo];
+                float tg = gv[jo][t];
                 if (has_g) {
-                    if (g_act) tg = bf_bnz(yy[t][jo], za[jo], zb[jo]) > 0.f ? tg : tg * p.g_slope;
-                    tg = __builtin_fmaf(gA[jo], tg, __builtin_fmaf(gB[jo], yy[t][jo], gC[jo]));
+                    if (g_act) tg = bf_bnz(yv[jo][t], za[jo], zb[jo]) > 0.f ? tg : tg * p.g_slope;
+                    tg = __builtin_fmaf(gA[jo], tg, __builtin_fmaf(gB[jo], yv[jo][t], gC[jo]));
                 }
                 acc[jo] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf_round(tg), a, acc[jo], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            xx[t] = xn[t];
-#pragma unroll
-            for (int jo = 0; jo < NO; ++jo) { g[t][jo] = gn[t][jo]; yy[t][jo] = yn[t][jo]; }
-        }
+        cur = nxt;
     }
-    // D[o][c]: lane (c = n, q): rows o = 16 jo + 4q + e.  The waves of the block add through LDS in a fixed order.
+    // D of tile jo: lane (column j = n, q), register e = row i = 4q + e; row i <-> output channel 2i + jo (32 outputs) or
+    // 2(i & 7) + (i >> 3) (16 outputs), column j <-> input channel xch.  The waves of the block add through LDS in a fixed order.
     for (int w = 0; w < SWB_THREADS / 64; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int jo = 0; jo < NO; ++jo)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float *dst = red + (16 * jo + 4 * q + e) * 16 + n;
+                    const int i = 4 * q + e;
+                    const int o = NO == 2 ? 2 * i + jo : 2 * (i & 7) + (i >> 3);
+                    float *dst = red + o * 16 + xch;
                     *dst = (w > 0 ? *dst : 0.f) + acc[jo][e];
                 }
         }
