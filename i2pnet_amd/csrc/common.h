@@ -90,6 +90,13 @@ int i2p_small_wgrad(long long rows, int cin, int cout, const float *gz, const fl
                     const float *g_omi, long long g_rows, float g_slope, float *bn_out, const float *x, const float *in_coef,
                     float slope_in, float *dw_partial, unsigned grid, void *stream);
 // bf16-storage wgrad with the accumulators in registers (csrc/mlp_wreg_bf16.hip); the caller reduces dw_partial[grid]
+// wide layers on few rows (cin > 160 or cout > 128, <= 320 channels): K-tiled fused layer kernels (csrc/mlp_big.hip)
+bool i2p_big_layer_ok(long long rows, int cin, int cout);
+int i2p_big_fwd(long long rows, int cin, int cout, const float *x, const float *in_coef, float slope_in, const float *w, float *y,
+                double *sums, void *stream);
+int i2p_big_bwd(long long rows, int cin, int cout, const float *gz, const float *y, const float *g_coef, float slope_out, const float *x,
+                const float *in_coef, const float *in_mi, float slope_in, const float *w, float *gz_in, double *in_dsums,
+                float *dw_partial, int max_chunks, float *dw, void *stream);
 bool i2p_small_wgrad_bf16_ok(long long rows, int cin, int cout, int x_bf16);
 int i2p_small_wgrad_bf16(long long rows, int cin, int cout, const unsigned short *gz, const unsigned short *y, const float *g_coef,
                          float g_slope, const void *x, int x_bf16, const float *in_coef, float slope_in, float *dw_partial, unsigned grid,

@@ -1768,10 +1768,13 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : (int)e;
     };
-    if (rows < 0 || cin <= 0 || cout <= 0 || cout > 256) return I2P_ERR_BAD_ARG;
+    if (rows < 0 || cin <= 0 || cout <= 0 || cout > 320) return I2P_ERR_BAD_ARG;
     if (rows == 0) return 0;
     if (!x || !w || !y) return I2P_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (!pair_f && !xb && i2p_big_layer_ok(rows, cin, cout))        // wide layer on few rows: K-tiled (csrc/mlp_big.hip)
+        return finish(i2p_big_fwd(rows, cin, cout, x, in_coef, slope_in, w, y, sums, stream));
+    if (cout > 256) return I2P_ERR_BAD_ARG;
     if (pair_f && !xb && !in_coef && cin == 128 && cout == 128 && pair_N > 0 && pair_M > 0 && rows % ((long long)pair_N * pair_M) == 0 &&
         i2p_wreg_pair_bwd_ok((int)(rows / ((long long)pair_N * pair_M)), pair_N, pair_M, cin, cout) && rows * 512 < (1LL << 32)) {
         fin_done = fin != nullptr;                          // first cost-volume layer, 128 x 128 on many rows (csrc/mlp_wreg.hip)
@@ -2039,6 +2042,9 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
             return launch_wgrad(wq, dw, st, grid, wg_lds);
         }
     }
+    if (!pair && !two && i2p_big_layer_ok(rows, cin, cout))        // wide layer on few rows: K-tiled dgrad + row-split wgrad (csrc/mlp_big.hip)
+        return i2p_big_bwd(rows, cin, cout, gz, y, out_coef ? dw_partial + (size_t)grid * cout * cin : nullptr, p.slope_out, x, in_coef, in_mi,
+                           slope_in, w, gz_in, in_dsums, dw_partial, (int)grid, dw, stream);
     switch (p.cin_p / 32) {
         case 1: return dispatch_bwd_o<1>(p, dw, st, grid);
         case 2: return dispatch_bwd_o<2>(p, dw, st, grid);

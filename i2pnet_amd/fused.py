@@ -6,6 +6,8 @@ load and accumulates its own output statistics) and L backward kernels; only the
 are ever materialised.  The reference runs every block as permute / conv / BN / activation /
 permute in eager PyTorch (src/projectPN/PPBackbone_center.py:34-46).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -28,6 +30,17 @@ def layer_fits(cin, cout):
     bwd = (cout_p * (cin_p + 1) + 64 * (cout_p + 1) + 64 * (cin_p + 1) + 6 * cout_p + 4 * cin_p) * 4
     fwd = (32 + 128) * (cin + 2) * 4
     return cin_p <= 160 and bwd <= _LDS and fwd <= _LDS
+
+
+USE_BIG_LAYERS = os.environ.get("I2P_NO_BIG", "0") != "1"
+
+
+def big_layer_fits(cin, cout):
+    """wide layers on few rows (cin > 160 or cout > 128, up to 320 channels): the K-tiled kernels of csrc/mlp_big.hip behind the
+    same i2p_lin_fwd / i2p_lin_bwd entries (device library only)"""
+    be = ops.get_backend()
+    return (USE_BIG_LAYERS and be.device_type == "cuda" and be.name == "hip" and cin % 4 == 0 and cout % 4 == 0
+            and cin <= 320 and cout <= 320 and (cin > 160 or cout > 128))
 
 
 class _LinearTN(Function):
@@ -515,7 +528,7 @@ def mlp_stack(x, convs, first_bn=None, pool_k=0):
         while j < n:
             c = convs[j]
             cin_eff = (cin + 3) // 4 * 4 if not run and pending_bn is None else cin
-            if not (c.bn and _batch_stat(c) and layer_fits(cin_eff, c.out_channels)):
+            if not (c.bn and _batch_stat(c) and (layer_fits(cin_eff, c.out_channels) or big_layer_fits(cin_eff, c.out_channels))):
                 break
             run.append(c); cin = c.out_channels; j += 1
         if run or pending_bn is not None:

@@ -201,9 +201,8 @@ int i2p_bn_act_bwd(long long rows, int c, const float *dout, const float *y,
  *   x f32 [rows,cin]; in_coef f32 [3][cin] = {mean, invstd*gamma, beta} or NULL (x used as is);
  *   slope_in: activation in front (1 = none); w f32 [cout,cin] (conv weight, bias dropped: it
  *   cancels in the following batch-stat BN); y f32 [rows,cout]; sums replicated f64 (see
- *   I2P_BN_REPLICAS) or NULL.  cout <= 256; output channels are processed in slices whose
- *   weights fit the 160 KB LDS next to a 128-row tile; I2P_ERR_BAD_ARG if (32+128)*(cin+2)*4 B
- *   does not fit (cin > ~250: callers then use a library GEMM).
+ *   I2P_BN_REPLICAS) or NULL.  cin <= 160 and cout <= 128: weights resident in LDS / registers (cout <= 256 in
+ *   slices); cin > 160 or cout > 128 (multiples of 4, <= 320): K-tiled kernels (csrc/mlp_big.hip), same semantics.
  * --------------------------------------------------------------------------------------------- */
 int i2p_lin_fwd(long long rows, int cin, int cout, const float *x, const float *in_coef,
                 float slope_in, const float *w, float *y, double *sums, void *stream);
@@ -223,7 +222,7 @@ int i2p_bn_finalize(long long rows, int c, const double *sums, const float *gamm
  * in_coef [3][cin], in_mi [2][cin] (or both NULL: x is the raw layer input, gz_in = dL/dx);
  * dw_partial f32 scratch of i2p_lin_bwd_grid(rows)*cout*cin + 8*cout floats; when out_coef is given its LAST 2*cout
  * floats hold, on return, {sum gz [cout], sum gz*xhat [cout]} reduced over the replicas = dbeta, dgamma of the BN
- * behind this layer.  cin, cout multiples of 4, <= 160 / 128.
+ * behind this layer.  cin, cout multiples of 4, <= 160 / 128 (weight-resident kernels) or <= 320 (K-tiled, csrc/mlp_big.hip).
  * slope_out: 1 when gz is dL/dz (the usual case: the previous call's gz_in).  For the LAST layer of a stack the
  * caller holds dL/da (a = act(z) with this slope, out_coef required): the activation derivative is applied on
  * load, with out_dsums = {sum gz, sum gz*xhat} of the resulting gz (i2p_bn_act_bwd_stats) — the stack's output
