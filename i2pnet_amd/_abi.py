@@ -61,6 +61,7 @@ DEVICE_ONLY = {
     "i2p_lin_bwd_2src_bf16": ["l", "i", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 3 + ["f"] + ["p"] * 8,
     "i2p_pair_lin_bwd_bf16": ["i"] * 5 + ["p"] * 14,
     "i2p_outer_sum_bf16": ["i"] * 4 + ["p"] * 4,
+    "i2p_outer_sum": ["i"] * 4 + ["p"] * 4,
     "i2p_to_bf16": ["l", "p", "p"],
     "i2p_bn_act_fwd_bf16": ["l", "i", "p", "p", "f", "p"],
     "i2p_bn_act_maxk_fwd_bf16": ["l", "i", "i", "p", "p", "f", "p", "p"],

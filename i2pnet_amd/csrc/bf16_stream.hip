@@ -41,9 +41,10 @@ __device__ __forceinline__ void reduce16(const double (&s)[8], const double (&q)
     }
 }
 
-// ye[b,n,k,:] = bf16(enc_n[b,n,:] + enc_k[b,k,:]) and the BN statistics of the rounded values
+// ye[b,n,k,:] = enc_n[b,n,:] + enc_k[b,k,:] (stored as bf16, or as f32 with F32) and the BN statistics of the stored values
+template <bool F32>
 __global__ __launch_bounds__(THREADS) void outer_sum_kernel(long long rows, int N, int M, int c, G8 g, const float *__restrict__ en,
-                                                             const float *__restrict__ ek, bf16_t *__restrict__ ye,
+                                                             const float *__restrict__ ek, void *__restrict__ ye_,
                                                              double *__restrict__ sums) {
     const int vcol = threadIdx.x % g.cv, rsub = threadIdx.x / g.cv;
     double s[8], q[8];
@@ -55,11 +56,20 @@ __global__ __launch_bounds__(THREADS) void outer_sum_kernel(long long rows, int 
         const float4 a0 = *reinterpret_cast<const float4 *>(pn), a1 = *reinterpret_cast<const float4 *>(pn + 4);
         const float4 b0 = *reinterpret_cast<const float4 *>(pk), b1 = *reinterpret_cast<const float4 *>(pk + 4);
         const float f[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w, a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
-        const uint4 o = bf_pack8(f);
-        float fr[8]; bf_unpack8(o, fr);
+        if constexpr (F32) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { s[i] += fr[i]; q[i] += (double)fr[i] * fr[i]; }
-        st_u4_stream(ye + (size_t)r * c + vcol * 8, o);
+            for (int i = 0; i < 8; ++i) { s[i] += f[i]; q[i] += (double)f[i] * f[i]; }
+            float *o = reinterpret_cast<float *>(ye_) + (size_t)r * c + vcol * 8;
+            __builtin_nontemporal_store(f[0], o); __builtin_nontemporal_store(f[1], o + 1); __builtin_nontemporal_store(f[2], o + 2);
+            __builtin_nontemporal_store(f[3], o + 3); __builtin_nontemporal_store(f[4], o + 4); __builtin_nontemporal_store(f[5], o + 5);
+            __builtin_nontemporal_store(f[6], o + 6); __builtin_nontemporal_store(f[7], o + 7);
+        } else {
+            const uint4 o = bf_pack8(f);
+            float fr[8]; bf_unpack8(o, fr);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s[i] += fr[i]; q[i] += (double)fr[i] * fr[i]; }
+            st_u4_stream(reinterpret_cast<bf16_t *>(ye_) + (size_t)r * c + vcol * 8, o);
+        }
     }
     reduce16(s, q, g.cv, c, sums);
 }
@@ -328,8 +338,17 @@ extern "C" int i2p_outer_sum_bf16(int B, int N, int M, int C, const float *enc_n
     if (B <= 0 || N <= 0 || M <= 0 || !ok8(C) || !enc_n || !enc_k || !ye || !sums) return I2P_ERR_BAD_ARG;
     const long long rows = (long long)B * N * M;
     const G8 g = geom8(C);
-    hipLaunchKernelGGL(outer_sum_kernel, dim3(grid_rows(rows, g.rpb, 1024)), dim3(THREADS), 0, (hipStream_t)stream, rows, N, M, C, g,
-                       enc_n, enc_k, ye, sums);
+    hipLaunchKernelGGL(outer_sum_kernel<false>, dim3(grid_rows(rows, g.rpb, 1024)), dim3(THREADS), 0, (hipStream_t)stream, rows, N, M, C, g,
+                       enc_n, enc_k, (void *)ye, sums);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_outer_sum(int B, int N, int M, int C, const float *enc_n, const float *enc_k, float *ye, double *sums, void *stream) {
+    if (B <= 0 || N <= 0 || M <= 0 || !ok8(C) || !enc_n || !enc_k || !ye || !sums) return I2P_ERR_BAD_ARG;
+    const long long rows = (long long)B * N * M;
+    const G8 g = geom8(C);
+    hipLaunchKernelGGL(outer_sum_kernel<true>, dim3(grid_rows(rows, g.rpb, 1024)), dim3(THREADS), 0, (hipStream_t)stream, rows, N, M, C, g,
+                       enc_n, enc_k, (void *)ye, sums);
     I2P_RETURN_LAUNCH_STATUS();
 }
 

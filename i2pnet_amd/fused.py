@@ -319,6 +319,8 @@ class _CvPiTail(Function):
         y3, st3, c3, m3 = be_.lin_forward_fin(y2, c2, s2, d(W3), d(g3), d(b3), _EPS, out_dtype=dt)
         if bf:
             ye, ste = be_.outer_sum_bf16(enc_n, enc_k)
+        elif be_.device_type == "cuda" and be_.name == "hip" and enc_n.shape[-1] % 8 == 0:
+            ye, ste = be_.outer_sum(enc_n, enc_k)              # the broadcast sum and its statistics in one pass
         else:
             ye = (enc_n.unsqueeze(2) + enc_k.unsqueeze(1)).view(rows, -1)
             ste = be_.bn_stats(ye)

@@ -431,6 +431,16 @@ class CBackend:
                    self._p(ye, _BF16, "ye"), self._p(sums, torch.float64, "sums"), stream=self._stream())
         return ye, sums
 
+    def outer_sum(self, enc_n, enc_k):
+        """enc_n [B,N,C], enc_k [B,M,C] -> (ye f32 [B*N*M, C] = enc_n[b,n] + enc_k[b,k], replicated BN sums) in one pass"""
+        B, N, C = enc_n.shape
+        M = enc_k.shape[1]
+        ye = torch.empty(B * N * M, C, dtype=_F32, device=enc_n.device)
+        sums = zeros(BN_REPLICAS * 2 * C, torch.float64, enc_n.device)
+        self._call("i2p_outer_sum", int(B), int(N), int(M), int(C), self._p(enc_n, _F32, "enc_n"), self._p(enc_k, _F32, "enc_k"),
+                   self._p(ye, _F32, "ye"), self._p(sums, torch.float64, "sums"), stream=self._stream())
+        return ye, sums
+
     def bn_act_apply_bf16(self, y, coef, slope):
         """act(bn(y)) of a bf16 pre-BN tensor with finalised coefficients -> fp32 [rows, c] (a chain's output)"""
         rows, c = y.shape

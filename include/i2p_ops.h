@@ -395,7 +395,10 @@ int i2p_pair_lin_bwd_bf16(int B, int N, int M, int cin, int cout, const i2p_bf16
                           float *dw_partial, float *dw, void *stream);
 /* streaming kernels on bf16 tensors (csrc/bf16_stream.hip) */
 int i2p_outer_sum_bf16(int B, int N, int M, int C, const float *enc_n, const float *enc_k, i2p_bf16 *ye, double *sums,
-                       void *stream);          /* ye[b,n,k,:] = bf16(enc_n[b,n,:] + enc_k[b,k,:]), sums += {sum, sum^2} */
+                       void *stream); /* the same in fp32 storage: ye f32 [B*N*M, C] = enc_n[b,n,:] + enc_k[b,k,:] (PPBackbone_center.py:416-421 position encoding of all
+ * point x pixel pairs, pre-BN) and its replicated BN sums in ONE pass (was: broadcast add + i2p_bn_stats) */
+int i2p_outer_sum(int B, int N, int M, int C, const float *enc_n, const float *enc_k, float *ye, double *sums, void *stream);
+         /* ye[b,n,k,:] = bf16(enc_n[b,n,:] + enc_k[b,k,:]), sums += {sum, sum^2} */
 int i2p_to_bf16(long long n, const float *x, i2p_bf16 *y, void *stream);
 int i2p_bn_act_fwd_bf16(long long rows, int c, const i2p_bf16 *y, const float *coef, float slope, float *out, void *stream);
 int i2p_bn_act_maxk_fwd_bf16(long long groups, int K, int c, const i2p_bf16 *y, const float *coef, float slope, float *out,

@@ -792,3 +792,18 @@ def test_linear_weight_grad_on_gemm_tn(hip_backend):
     assert torch.allclose(y0, y1, rtol=1e-5, atol=1e-5) and torch.allclose(gx0, gx1, rtol=1e-5, atol=1e-5)
     assert float((gw0 - gw1).abs().max()) <= 2e-5 * float(gw1.abs().max()) + 1e-4
     assert float(gw0[:, :3].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,M,C", [(2, 23, 70, 64), (1, 228, 468, 64), (3, 5, 9, 128)])
+def test_outer_sum_matches_broadcast_add(hip_backend, B, N, M, C):
+    """i2p_outer_sum (position encoding of all point x pixel pairs + its BN statistics in one pass) against the broadcast add
+    and fp64 sums it replaces: values bit-exact, sums to fp64 rounding"""
+    g = torch.Generator().manual_seed(B * N + M)
+    en = torch.randn(B, N, C, generator=g).cuda(); ek = torch.randn(B, M, C, generator=g).cuda()
+    ye, sums = hip_backend.outer_sum(en, ek)
+    want = (en.unsqueeze(2) + ek.unsqueeze(1)).reshape(B * N * M, C)
+    assert torch.equal(ye, want)
+    s = sums.view(-1, 2, C).sum(0)
+    assert torch.allclose(s[0], want.double().sum(0), rtol=1e-9, atol=1e-6)
+    assert torch.allclose(s[1], want.double().square().sum(0), rtol=1e-9, atol=1e-6)
