@@ -484,6 +484,38 @@ def softmax_pool(mask, value):
     return _SoftmaxPool.apply(mask, value)
 
 
+class _SoftmaxWsumK(Function):
+    """out[b,n,:] = sum_k softmax_k(logit[b,n,k,:]) * value[b,n,k,:] over the K neighbours of a point (pc-stage of the cost
+    volume, PPBackbone_center.py:481-487) on the same kernels (groups = B*N, M = K): one launch each way instead of
+    softmax / mul / sum and their autograd nodes."""
+
+    @staticmethod
+    def forward(ctx, logit, value):
+        B, N, K, C = logit.shape
+        be_ = ops.get_backend()
+        coef, mi = _identity_coef(C, logit.device)
+        m2, v2 = logit.detach().reshape(B * N * K, C).contiguous(), value.detach().reshape(B * N * K, C).contiguous()
+        out, msave = be_.cv_softmax_wsum_forward(B, N, K, m2, coef, 1.0, v2, coef, 1.0)
+        ctx.save_for_backward(m2, v2, out, msave)
+        ctx.dims = (B, N, K, C)
+        return out.view(B, N, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        m2, v2, out, msave = ctx.saved_tensors
+        B, N, K, C = ctx.dims
+        be_ = ops.get_backend()
+        coef, mi = _identity_coef(C, m2.device)
+        glog, _, gval = be_.cv_softmax_wsum_backward(B, N, K, g.reshape(B, N, C).contiguous(), out, msave, m2, coef, mi, 1.0,
+                                                     v2, coef, 1.0)
+        return glog.view(B, N, K, C), gval.view(B, N, K, C)
+
+
+def softmax_wsum_k(logit, value):
+    """logit, value [B,N,K,C] -> [B,N,C]; C must divide 256 (else use the torch formulation)"""
+    return _SoftmaxWsumK.apply(logit, value)
+
+
 def cv_tail_fits(first, mlp1_rest, enc, mlp2):
     if len(mlp1_rest) != 2 or len(mlp2) != 2:
         return False

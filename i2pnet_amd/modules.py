@@ -15,6 +15,8 @@ kept so that a reference `state_dict` loads unchanged; the exec
   262-channel `[B,N,M,262]` input of `cost_volume1` (224 MB at B=8) is never built
   (PPBackbone_center.py:383-418).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -22,7 +24,7 @@ import torch.nn.functional as F
 from . import ops
 from . import projectpn as P
 from . import warp as warp_utils
-from .fused import cv_knn_tail, cv_pi_tail, cv_tail_fits, layer_fits, linear, mlp_stack, pair_fits, pair_linear, softmax_pool
+from .fused import cv_knn_tail, cv_pi_tail, cv_tail_fits, layer_fits, linear, mlp_stack, pair_fits, pair_linear, softmax_pool, softmax_wsum_k
 
 # run Conv2d stacks on the fused MFMA layer kernels (csrc/mlp.hip); False = library GEMM + BN kernels per block
 USE_FUSED_MLP = True
@@ -645,7 +647,12 @@ class CostVolume(nn.Module):
         w = run_stack(w, self.mlp2_convs_2)
         valid = gidx[-1]
         w = mask_fill(w, valid)                                                 # :481
-        out = torch.sum(F.softmax(w, dim=2) * nb_feat, dim=2)
+        be = ops.get_backend()
+        if (USE_FUSED_MLP and os.environ.get("I2P_NO_SMK") != "1" and be.device_type == "cuda" and be.name == "hip" and w.dtype == torch.float32 and 256 % w.shape[-1] == 0
+                and w.shape == nb_feat.shape):
+            out = softmax_wsum_k(w, nb_feat)                                    # :483-487 in one launch each way
+        else:
+            out = torch.sum(F.softmax(w, dim=2) * nb_feat, dim=2)
         return out.view(B, self.H, self.W, -1)
 
     def set_bn(self):

@@ -807,3 +807,26 @@ def test_outer_sum_matches_broadcast_add(hip_backend, B, N, M, C):
     s = sums.view(-1, 2, C).sum(0)
     assert torch.allclose(s[0], want.double().sum(0), rtol=1e-9, atol=1e-6)
     assert torch.allclose(s[1], want.double().square().sum(0), rtol=1e-9, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,K,C", [(2, 57, 4, 64), (8, 228, 4, 64), (1, 9, 16, 128)])
+def test_softmax_wsum_k_matches_torch(hip_backend, B, N, K, C):
+    """pc-stage tail of the cost volume (softmax over the K neighbours, weighted sum of their features) on the
+    cv_softmax_wsum kernels against softmax / mul / sum, values and both gradients; fully masked groups (-1e10 logits) included"""
+    from i2pnet_amd import fused
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(N + K)
+    logit = torch.randn(B, N, K, C, generator=g).cuda()
+    logit[0, 0] = -1e10                                        # a point without valid neighbours: uniform weights
+    logit[0, 1, 1:] = -1e10
+    value = torch.randn(B, N, K, C, generator=g).cuda()
+    go = torch.randn(B, N, C, generator=g).cuda()
+    res = []
+    for fn in (fused.softmax_wsum_k, lambda l, v: torch.sum(F.softmax(l, dim=2) * v, dim=2)):
+        l, v = logit.clone().requires_grad_(True), value.clone().requires_grad_(True)
+        out = fn(l, v)
+        gl, gv = torch.autograd.grad(out, (l, v), go)
+        res.append((out, gl, gv))
+    for a, b in zip(*res):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), float((a - b).abs().max())
