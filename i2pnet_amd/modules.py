@@ -480,6 +480,16 @@ def _unit_variance(x):
     return (x - torch.mean(x, -1, keepdim=True)) / torch.clip(torch.std(x, -1, keepdim=True), min=1e-12)
 
 
+_ONES = {}
+
+
+def _ones_row(B, M, device, dtype):
+    key = (B, M, str(device), dtype)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(B, 1, M, device=device, dtype=dtype)
+    return _ONES[key]
+
+
 class _MaxResponse(torch.autograd.Function):
     """respond[b,k,c] = max over valid points n of pts[b,n,c] * pix[b,k,c]  (-1e10 if the sample has no valid
     point) — the backward-validation feature of the first cost volume (PPBackbone_center.py:408-414) in closed
@@ -511,8 +521,11 @@ class _MaxResponse(torch.autograd.Function):
         g = torch.where(any_valid.unsqueeze(1), g, 0.0)
         d_pix = g * sel
         t = g * pix
-        d_fmax = torch.where(pos, t, 0.0).sum(1)                              # [B,C]
-        d_fmin = t.sum(1) - d_fmax
+        # column sums over the pixel axis as a ones-row GEMM: ATen's reduction over the strided middle axis of [B,M,C]
+        # takes 28 us per call for 8 x 468 x 128, the rocBLAS product 6
+        ones = _ones_row(g.shape[0], g.shape[1], g.device, g.dtype)
+        d_fmax = torch.bmm(ones, torch.where(pos, t, 0.0)).squeeze(1)         # [B,C]
+        d_fmin = torch.bmm(ones, t).squeeze(1) - d_fmax
         d_pts = ops.zeros((g.shape[0], ctx.n_points, g.shape[2]), g.dtype, g.device)
         d_pts.scatter_add_(1, i_max.unsqueeze(1), d_fmax.unsqueeze(1))
         d_pts.scatter_add_(1, i_min.unsqueeze(1), d_fmin.unsqueeze(1))
