@@ -1,5 +1,11 @@
-import torch, sys
-sys.path.insert(0,'/root/repo')
+"""i2p_gemm_tn against rocBLAS (a.t() @ b) on the weight-gradient shapes of the plain linear layers (host-timed loops: both
+include the launch overhead; the in-graph figures are in profiles/)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from i2pnet_amd import ops
 be=ops.hip_backend()
 for rows,m,n in [(14848,256,128),(7296,128,256),(3744,3,64),(3744,128,128),(1824,64,192),(928,128,320)]:
