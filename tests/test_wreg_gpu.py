@@ -188,3 +188,19 @@ def test_small_wgrad_streaming_kernel(hip_backend, cin, cout, bn, slope_out):
     dgamma, dbeta = be.take_bn_grads()
     assert _rel(dw, gy.t() @ a) < 1e-5
     assert _rel(dbeta, s1) < 1e-5 and _rel(dgamma, s2) < 1e-5
+
+
+FULL_ROWS = 8 * 228 * 468          # the cost-volume layer of BASELINE configs[1]: batch 8 x 228 points x 468 pixels
+
+
+def test_wreg_forward_full_size(hip_backend, monkeypatch):
+    """the same statement at the benchmark's own size (853 632 rows, 128 -> 128)"""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "ROWS", FULL_ROWS)
+    test_wreg_forward(hip_backend, 128, 128, True)
+
+
+def test_wreg_backward_full_size(hip_backend, monkeypatch):
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "ROWS", FULL_ROWS)
+    test_wreg_backward(hip_backend, 128, 128)
