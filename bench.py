@@ -471,10 +471,18 @@ def main():
             prev = ops.set_precision("fp32")
             line["cpu_baseline"] = cpu_baseline(cfg)
             ops.set_precision(prev)
-        print(json.dumps(line), flush=True)
     if dist.is_available() and dist.is_initialized():        # also the forced 1-rank group of tools/ddp_smoke.sh
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio, which a pipe buffers until exit: flush it first so that the JSON
+        # line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
