@@ -76,6 +76,8 @@ DEVICE_ONLY = {
     "i2p_sa_l1_group": ["i"] * 10 + ["f", "p", "p", "p"],
     "i2p_gather_rows_grad_fx_ld": ["i", "i", "i", "i", "i", "p", "i", "i", "p", "p", "p", "p"],
     "i2p_sa_rows": ["i"] * 9 + ["p"] * 6,
+    "i2p_knn_rows_fwd": ["i"] * 6 + ["p"] * 6,
+    "i2p_knn_rows_bwd": ["i"] * 6 + ["p"] * 7,
     "i2p_gemm_tn": ["l", "i", "i", "p", "i", "p", "i", "p", "p"],
     "i2p_lin_fwd_fin": ["l", "i", "i", "p", "p", "f", "p", "p", "p", "p", "p", "f", "p", "p", "p"],
     "i2p_lin_fwd_2src_fin": ["l", "i", "i", "i", "p", "p", "f", "p", "p", "f", "p", "p", "p", "p", "p", "f", "p", "p", "p"],

@@ -265,6 +265,59 @@ __global__ __launch_bounds__(256) void sa_rows_kernel(int hw, int q, int K, int 
     }
     *reinterpret_cast<float4 *>(out + ((size_t)bi * q + row) * cpad + 4 * j) = make_float4(v[0], v[1], v[2], v[3]);
 }
+
+// Input rows of the kNN pi-stage of the fine cost volume (PPBackbone_center.py:369-395: knn grouping of the pixel features,
+// product with the point feature, concat with the two coordinate triples) in one launch from the indices:
+// out[b, n*K + k, :] = [xyz[b,n,:] (3), pix_xyz[b,idx,:] (3), pts[b,n,:] * pix[b,idx,:] (C), zero padding]; idx i64 [b, n*K].
+__global__ __launch_bounds__(256) void knn_rows_fwd_kernel(int n, int m, int K, int c, int cpad, const float *__restrict__ xyz,
+                                                           const float *__restrict__ pix_xyz, const float *__restrict__ pts,
+                                                           const float *__restrict__ pix, const int64_t *__restrict__ idx,
+                                                           float *__restrict__ out) {
+    const int bi = blockIdx.y, c4 = cpad >> 2;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)n * K * c4) return;
+    const int row = (int)(t / c4), j = (int)(t % c4), pn = row / K;
+    const long long cell = idx[(size_t)bi * n * K + row];
+    const float *pr = pix + ((size_t)bi * m + cell) * c, *fr = pts + ((size_t)bi * n + pn) * c;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ch = 4 * j + e;
+        float x = 0.f;
+        if (ch < 3) x = xyz[((size_t)bi * n + pn) * 3 + ch];
+        else if (ch < 6) x = pix_xyz[((size_t)bi * m + cell) * 3 + ch - 3];
+        else if (ch < 6 + c) x = fr[ch - 6] * pr[ch - 6];
+        v[e] = x;
+    }
+    *reinterpret_cast<float4 *>(out + ((size_t)bi * n * K + row) * cpad + 4 * j) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// backward of the rows: block = one point (b, n), thread = one feature channel; the K neighbours in order (fixed summation order).
+//   d_pts[b,n,c] = sum_k g[row, 6+c] * pix[b,idx,c];  gq[row, c] = g[row, 6+c] * pts[b,n,c] (scattered to the pixels by
+//   i2p_gather_rows_grad_fx afterwards);  d_xyz[b,n,:] = sum_k g[row, 0:3]
+__global__ __launch_bounds__(128) void knn_rows_bwd_kernel(int n, int m, int K, int c, int cpad, const float *__restrict__ g,
+                                                           const float *__restrict__ pts, const float *__restrict__ pix,
+                                                           const int64_t *__restrict__ idx, float *__restrict__ d_xyz,
+                                                           float *__restrict__ d_pts, float *__restrict__ gq) {
+    const int pn = blockIdx.x, bi = blockIdx.y;
+    const size_t row0 = ((size_t)bi * n + pn) * K;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        const float f = pts[((size_t)bi * n + pn) * c + ch];
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const long long cell = idx[row0 + k];
+            const float gv = g[(row0 + k) * cpad + 6 + ch];
+            acc = fmaf(gv, pix[((size_t)bi * m + cell) * c + ch], acc);
+            gq[(row0 + k) * c + ch] = gv * f;
+        }
+        d_pts[((size_t)bi * n + pn) * c + ch] = acc;
+    }
+    if (threadIdx.x < 3 && d_xyz) {
+        float a = 0.f;
+        for (int k = 0; k < K; ++k) a += g[(row0 + k) * cpad + threadIdx.x];
+        d_xyz[((size_t)bi * n + pn) * 3 + threadIdx.x] = a;
+    }
+}
 }  // namespace
 
 extern "C" int i2p_sa_rows(int b, int hw, int n, int K, int W, int c, int cpad, int xyz_col, int feat_col, const float *xyz,
@@ -276,5 +329,23 @@ extern "C" int i2p_sa_rows(int b, int hw, int n, int K, int W, int c, int cpad, 
     const long long tot = (long long)n * K * (cpad >> 2);
     hipLaunchKernelGGL(sa_rows_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0, (hipStream_t)stream, hw, n * K, K, W, c, cpad,
                        xyz_col, feat_col, xyz, centre, feat, h_idx, w_idx, out);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_knn_rows_fwd(int b, int n, int m, int K, int c, int cpad, const float *xyz, const float *pix_xyz, const float *pts,
+                                const float *pix, const int64_t *idx, float *out, void *stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || K <= 0 || c <= 0 || (cpad & 3) || cpad < 6 + c) return I2P_ERR_BAD_ARG;
+    if (!xyz || !pix_xyz || !pts || !pix || !idx || !out) return I2P_ERR_BAD_ARG;
+    const long long tot = (long long)n * K * (cpad >> 2);
+    hipLaunchKernelGGL(knn_rows_fwd_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0, (hipStream_t)stream, n, m, K, c, cpad, xyz,
+                       pix_xyz, pts, pix, idx, out);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_knn_rows_bwd(int b, int n, int m, int K, int c, int cpad, const float *g, const float *pts, const float *pix,
+                                const int64_t *idx, float *d_xyz, float *d_pts, float *gq, void *stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || K <= 0 || c <= 0 || (cpad & 3) || cpad < 6 + c) return I2P_ERR_BAD_ARG;
+    if (!g || !pts || !pix || !idx || !d_pts || !gq) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(knn_rows_bwd_kernel, dim3(n, b), dim3(128), 0, (hipStream_t)stream, n, m, K, c, cpad, g, pts, pix, idx, d_xyz, d_pts, gq);
     I2P_RETURN_LAUNCH_STATUS();
 }

@@ -609,16 +609,20 @@ class CostVolume(nn.Module):
         K = self.nsample_q
         idx = P.knn_point(K, pix_xyz, uv)                                       # grouping(), :369
         q_xyz = P.index_points_group(pix_xyz, idx)                              # [B,N,K,3]
-        q_feat = P.index_points_group(pix_n, idx)                               # [B,N,K,C]
         own = xyz.unsqueeze(2).expand(-1, -1, K, -1)
         first, rest = self.mlp1_convs[0], list(self.mlp1_convs)[1:]
         c1 = (first.in_channels + 3) // 4 * 4
         if (USE_FUSED_MLP and USE_CV_TAIL and K <= 255 and cv_tail_fits(first, rest, self.pi_encoding, list(self.mlp2_convs))
                 and layer_fits(c1, first.out_channels) and layer_fits(8, self.pi_encoding.out_channels)):
-            x1 = cat_padded([own, q_xyz, pts_n.unsqueeze(2) * q_feat])         # [B,N,K,6+C(+pad)]
+            if USE_FUSED_GROUP and P.knn_rows_fusable(xyz, pix_xyz, pts_n, pix_n):
+                x1 = P.knn_rows(xyz, pix_xyz, pts_n, pix_n, idx, c1)               # gathers + product + cat in one launch
+            else:
+                q_feat = P.index_points_group(pix_n, idx)                           # [B,N,K,C]
+                x1 = cat_padded([own, q_xyz, pts_n.unsqueeze(2) * q_feat])     # [B,N,K,6+C(+pad)]
             xe = cat_padded([own, q_xyz])                                       # [B,N,K,8]
             return None, None, cv_knn_tail(x1, xe, (B, N, K), first, rest, self.pi_encoding, list(self.mlp2_convs))
         geo = torch.cat([own, q_xyz], dim=3)
+        q_feat = P.index_points_group(pix_n, idx)                               # [B,N,K,C]
         h = run_stack(torch.cat([geo, pts_n.unsqueeze(2) * q_feat], dim=3), self.mlp1_convs)
         return h, run_stack(geo, [self.pi_encoding]), None
 

@@ -263,6 +263,30 @@ class CBackend:
                    self._p(out, _F32, "out"), stream=self._stream())
         return out
 
+    def knn_rows(self, xyz, pix_xyz, pts, pix, idx, K, cpad):
+        """xyz [B,N,3], pix_xyz [B,M,3], pts [B,N,C], pix [B,M,C], idx i64 [B,N*K] -> [B, N*K, cpad] =
+        [xyz, pix_xyz[idx], pts * pix[idx], 0...] (csrc/sa_group.hip i2p_knn_rows_fwd)"""
+        B, N, C = pts.shape
+        M = pix.shape[1]
+        out = torch.empty(B, N * K, cpad, dtype=_F32, device=pts.device)
+        self._call("i2p_knn_rows_fwd", int(B), int(N), int(M), int(K), int(C), int(cpad), self._p(xyz, _F32, "xyz"),
+                   self._p(pix_xyz, _F32, "pix_xyz"), self._p(pts, _F32, "pts"), self._p(pix, _F32, "pix"), self._p(idx, _I64, "idx"),
+                   self._p(out, _F32, "out"), stream=self._stream())
+        return out
+
+    def knn_rows_backward(self, g, pts, pix, idx, K, need_xyz):
+        """-> (d_xyz [B,N,3] or None, d_pts [B,N,C], gq [B,N*K,C])"""
+        B, N, C = pts.shape
+        M = pix.shape[1]
+        cpad = g.shape[2]
+        d_xyz = torch.empty(B, N, 3, dtype=_F32, device=g.device) if need_xyz else None
+        d_pts = torch.empty(B, N, C, dtype=_F32, device=g.device)
+        gq = torch.empty(B, N * K, C, dtype=_F32, device=g.device)
+        self._call("i2p_knn_rows_bwd", int(B), int(N), int(M), int(K), int(C), int(cpad), self._p(g, _F32, "g"), self._p(pts, _F32, "pts"),
+                   self._p(pix, _F32, "pix"), self._p(idx, _I64, "idx"), self._p(d_xyz, _F32, "d_xyz") if need_xyz else None,
+                   self._p(d_pts, _F32, "d_pts"), self._p(gq, _F32, "gq"), stream=self._stream())
+        return d_xyz, d_pts, gq
+
     def gather_rows_grad_ld(self, grad_out, ld, off, h_idx, w_idx, W, grad_feat):
         """gather_rows_grad from columns [off, off+C) of grad_out rows of pitch ld (fixed-point path, device only)"""
         B, HW, Cc = grad_feat.shape

@@ -14,6 +14,8 @@ Mirrors the function names and contracts of the reference's `src/projectPN/utils
 * `knn_point` never materialises the `[B,S,N]` distance matrix (utils.py:362-379).
 """
 import numpy as np
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -115,6 +117,47 @@ class _SaRows(Function):
         grad_feat = ops.zeros((B, HW, C), torch.float32, grad_out.device)
         ops.get_backend().gather_rows_grad_ld(grad_out.contiguous(), cpad, feat_col, h_idx, w_idx, width, grad_feat)
         return None, None, grad_feat, None, None, None, None, None, None, None
+
+
+class _KnnRows(Function):
+    """rows [xyz, pix_xyz[idx], pts * pix[idx], padding] of the fine cost volume's kNN pi-stage in one launch (reference: two
+    index_points_group gathers, a product and a cat, PPBackbone_center.py:369-395).  Gradients: point coordinates and features
+    (sums over the K neighbours), pixel features (the per-neighbour products scattered with the fixed-point row scatter); the
+    pixel rays are data."""
+
+    @staticmethod
+    def forward(ctx, xyz, pix_xyz, pts, pix, idx, K, cpad):
+        out = ops.get_backend().knn_rows(xyz, pix_xyz, pts, pix, idx, K, cpad)
+        ctx.save_for_backward(pts, pix, idx)
+        ctx.K = K
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pts, pix, idx = ctx.saved_tensors
+        be = ops.get_backend()
+        d_xyz, d_pts, gq = be.knn_rows_backward(g.contiguous(), pts, pix, idx, ctx.K, ctx.needs_input_grad[0])
+        d_pix = None
+        if ctx.needs_input_grad[3]:
+            B, M, C = pix.shape
+            d_pix = ops.zeros((B, M, C), torch.float32, g.device)
+            h = _cached(("zero_rows", B, idx.shape[1], str(g.device)), lambda: torch.zeros(B, idx.shape[1], dtype=torch.long, device=g.device))
+            be.gather_rows_grad(gq, h, idx, M, d_pix)
+        return d_xyz, None, d_pts, d_pix, None, None, None
+
+
+def knn_rows_fusable(xyz, pix_xyz, pts, pix):
+    be = ops.get_backend()
+    return (os.environ.get("I2P_NO_KNN_ROWS") != "1" and be.device_type == "cuda" and be.name == "hip" and not pix_xyz.requires_grad
+            and pts.dtype == torch.float32 and pix.dtype == torch.float32 and xyz.dtype == torch.float32)
+
+
+def knn_rows(xyz, pix_xyz, pts, pix, idx, cpad):
+    """xyz [B,N,3], pix_xyz [B,M,3], pts [B,N,C], pix [B,M,C], idx [B,N,K] -> [B,N,K,cpad]"""
+    B, N, K = idx.shape
+    out = _KnnRows.apply(xyz.contiguous(), pix_xyz.contiguous(), pts.contiguous(), pix.contiguous(),
+                         idx.reshape(B, N * K).long().contiguous(), K, cpad)
+    return out.view(B, N, K, cpad)
 
 
 def padded_width(c, pow2):

@@ -460,6 +460,17 @@ int i2p_sa_rows(int b, int hw, int n, int K, int W, int c, int cpad, int xyz_col
 long long i2p_gemm_tn_scratch(long long rows, int m, int n);
 int i2p_gemm_tn(long long rows, int m, int n, const float *a, int lda, const float *b, int ldb, void *scratch, float *out,
                 void *stream);
+/* Input rows of the kNN pi-stage of the fine cost volume in one launch (reference: knn grouping of the pixel coordinates and features,
+ * product with the point feature, cat — PPBackbone_center.py:369-395): out f32 [b, n*K, cpad] =
+ * [xyz[b,n,:] (3), pix_xyz[b,idx,:] (3), pts[b,n,:] * pix[b,idx,:] (c), zeros]; xyz [b,n,3], pix_xyz [b,m,3], pts [b,n,c], pix [b,m,c],
+ * idx i64 [b, n*K] (pixel index of each neighbour); cpad a multiple of 4, >= 6 + c. */
+int i2p_knn_rows_fwd(int b, int n, int m, int K, int c, int cpad, const float *xyz, const float *pix_xyz, const float *pts,
+                     const float *pix, const int64_t *idx, float *out, void *stream);
+/* its backward for the row gradient g [b, n*K, cpad]: d_pts [b,n,c] = sum_k g_f * pix[idx], d_xyz [b,n,3] = sum_k g[:, 0:3] (NULL:
+ * skipped), gq [b, n*K, c] = g_f * pts — the per-neighbour gradient of the gathered pixel features, to be scattered with
+ * i2p_gather_rows_grad_fx.  Sums over the K neighbours in index order (bit-reproducible). */
+int i2p_knn_rows_bwd(int b, int n, int m, int K, int c, int cpad, const float *g, const float *pts, const float *pix,
+                     const int64_t *idx, float *d_xyz, float *d_pts, float *gq, void *stream);
 int i2p_pair_bias_bn_finish(int B, int N, int M, int C, const float *sum_k, const float *sum_n, const float *enc_n,
                             const float *enc_k, const double *dsums, const float *coef, const float *mi, float *d_enc_n,
                             float *d_enc_k, void *stream);   /* closed-form half of i2p_pair_bias_bn_bwd on formed sums */

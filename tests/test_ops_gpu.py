@@ -830,3 +830,31 @@ def test_softmax_wsum_k_matches_torch(hip_backend, B, N, K, C):
         res.append((out, gl, gv))
     for a, b in zip(*res):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), float((a - b).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,M,K,C", [(2, 57, 80, 32, 128), (1, 9, 30, 4, 64), (3, 20, 16, 8, 12)])
+def test_knn_rows_matches_gather_mul_cat(hip_backend, B, N, M, K, C):
+    """i2p_knn_rows_fwd/bwd (kNN pi-stage rows of the fine cost volume in one launch) against the chain it replaces — two
+    index_points_group gathers, the product and the zero-padded cat: rows bit-exact, gradients w.r.t. the point coordinates /
+    features and the pixel features to fp32 rounding; repeated indices (several neighbours = the same pixel) included"""
+    from i2pnet_amd import projectpn as P
+    from i2pnet_amd.modules import cat_padded
+    g = torch.Generator().manual_seed(N * K + C)
+    xyz = torch.randn(B, N, 3, generator=g).cuda(); pix_xyz = torch.randn(B, M, 3, generator=g).cuda()
+    pts = torch.randn(B, N, C, generator=g).cuda(); pix = torch.randn(B, M, C, generator=g).cuda()
+    idx = torch.randint(0, M, (B, N, K), generator=g).cuda()
+    cpad = (6 + C + 3) // 4 * 4
+    go = torch.randn(B, N, K, cpad, generator=g).cuda()
+    res = []
+    for fused in (True, False):
+        a, b, c = xyz.clone().requires_grad_(True), pts.clone().requires_grad_(True), pix.clone().requires_grad_(True)
+        if fused:
+            rows = P.knn_rows(a, pix_xyz, b, c, idx, cpad)
+        else:
+            own = a.unsqueeze(2).expand(-1, -1, K, -1)
+            rows = cat_padded([own, P.index_points_group(pix_xyz, idx), b.unsqueeze(2) * P.index_points_group(c, idx)])
+        res.append((rows,) + torch.autograd.grad(rows, (a, b, c), go))
+    assert torch.equal(res[0][0], res[1][0])
+    for got, want in zip(res[0][1:], res[1][1:]):
+        assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-6
