@@ -1,0 +1,257 @@
+"""The network at the BENCHMARK's own batch sizes against the reference (VERDICT r2 missing #1).
+
+Fixtures `tests/golden/model_kitti_b8.npz` (BASELINE.json configs[1]: batch 8, 8192 points, 375x1242, fp32) and
+`model_kitti_b16.npz` (configs[2] shape: batch 16) come from the imported reference model in TRAIN mode with dropout
+probability 0 (`tools/gen_golden.py sized`; reference: src/modellearn_proj_center.py:216-424 driven as in
+train20v2learn_wandb_proj.py:31,435-483).  Batch-statistics BN (PPBackbone_center.py:30) makes the batch size part of
+the function, so these pin what the batch-2 fixtures cannot: the >= 65 536-row layer kernels (mlp_wreg.hip) inside the
+full network, at the shapes `bench.py` times.
+
+The activations are hundreds of MB at this size; the fixtures hold per-module digests — mean / L2 / abs-max of the whole
+tensor (fp64) and 256 seeded rows — plus out3 / out4 / loss, the image encoder's running buffers after the step and every
+parameter's gradient norm with its fp64 value.  The digest helpers are imported from tools/gen_golden.py (the generator),
+so generator and test cannot drift apart."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import synthetic_state
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLD = ROOT / "tests" / "golden"
+if str(ROOT / "tools") not in sys.path:
+    sys.path.insert(0, str(ROOT / "tools"))
+
+
+def _gen():
+    import gen_golden            # module import only: /root/reference is touched by its run_* functions, not here
+    return gen_golden
+
+
+def _run_sized(tag, device, precision="fp32"):
+    from i2pnet_amd import ops, synth
+    from i2pnet_amd.config import CONFIGS
+    from i2pnet_amd.loss import Get_loss
+    from i2pnet_amd.model import RegNet_v2
+
+    gold = np.load(GOLD / f"model_{tag}.npz")
+    cfg_name, B, N, img_h, img_w, seed, beams = gold["meta"].tolist()
+    B, N, img_h, img_w, seed, beams = int(B), int(N), int(img_h), int(img_w), int(seed), int(beams)
+    cfg = CONFIGS[cfg_name]
+    model = RegNet_v2(cfg=cfg)
+    theirs = {k: tuple(int(x) for x in s.split(",") if x) for k, s in zip(gold["state_keys"].tolist(), gold["state_shapes"].tolist())}
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == theirs
+    model.load_state_dict(synthetic_state(list(theirs.items()), seed=seed))
+    model.train().to(device)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    batch = {k: v.to(device) for k, v in synth.make_batch(B, N, img_h, img_w, seed=seed, beams=beams, fup=cfg.fup,
+                                                           fdown=cfg.fdown, unique_cells=(cfg.init_H, cfg.init_W)).items()}
+    acts = {}
+
+    def keep(name):
+        def f(mod, inp, out):
+            o = out[2] if isinstance(out, tuple) else out
+            if o.requires_grad:
+                o.retain_grad()
+            acts[name] = o
+        return f
+    names = sorted({k.split(".")[1] for k in gold.files if k.startswith("act.")})
+    for name in names:
+        if name == "LiDAR_lv1":
+            orig = model.LiDAR_lv1.forward_center
+
+            def fc(*a, _orig=orig, **k):
+                out = _orig(*a, **k)
+                out[2].retain_grad(); acts["LiDAR_lv1"] = out[2]
+                return out
+            model.LiDAR_lv1.forward_center = fc
+        else:
+            getattr(model, name).register_forward_hook(keep(name))
+    prev = ops.set_precision(precision)
+    try:
+        out3, out4, _, _, sx, sq = model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"], batch["init_extrinsic"],
+                                         batch["init_intrinsic"], None, None, None, batch["lidar_feats"], cfg=cfg)
+        loss, _, _ = Get_loss(out3, out4, batch["decalib_real_gt"], batch["decalib_dual_gt"], sx, sq, cfg=cfg)
+        loss.backward()
+    finally:
+        ops.set_precision(prev)
+    return gold, model, acts, out3, out4, loss
+
+
+def _rel(a, b, scale=None):
+    a = torch.as_tensor(a, dtype=torch.float64); b = torch.as_tensor(b, dtype=torch.float64)
+    return float((a - b).abs().max() / ((scale if scale is not None else b.abs().max()) + 1e-12))
+
+
+def _digest_report(gold, acts, prefix, pick):
+    """per module: (max-norm error of the 256 fixture rows relative to the tensor's abs-max, relative L2-norm error,
+    mean error relative to the abs-max)"""
+    G = _gen()
+    rep = {}
+    for name, t in acts.items():
+        key = f"{prefix}.{name}"
+        if key + ".stats" not in gold.files:
+            continue
+        t = pick(t)
+        if t is None:
+            continue
+        stats, rows = G.tensor_digest(t.detach().cpu(), name)
+        gs = gold[key + ".stats"]
+        rep[key] = (_rel(rows, gold[key + ".rows"], scale=gs[2]), abs(stats[1] - gs[1]) / (gs[1] + 1e-30),
+                    abs(stats[0] - gs[0]) / (gs[2] + 1e-30))
+    return rep
+
+
+def _grad_norm_check(gold, model, grad_tol, rgb_tol):
+    """same rule as tests/test_model_golden.py::_check: as close to the fp64 value as the reference's own fp32 gradient
+    is (x4), and within `grad_tol` where the reference is well-conditioned"""
+    params = dict(model.named_parameters())
+    gn = dict(zip(gold["grad_keys"].tolist(), gold["grad_norm"].tolist()))
+    g64 = dict(zip(gold["grad_keys"].tolist(), gold["grad_norm64"].tolist()))
+    floor = {}
+    for k in params:
+        if gn[k] > 1e-4 and g64[k] > 0.0:
+            m = k.split(".")[0]
+            floor[m] = max(floor.get(m, 0.0), abs(gn[k] - g64[k]) / g64[k])
+    worst, worst_key, checked = 0.0, None, 0
+    for k, p in params.items():
+        g = 0.0 if p.grad is None else float(p.grad.double().norm())
+        if gn[k] <= 1e-4 or g64[k] == 0.0:
+            assert g <= max(1e-3, 4 * gn[k]), (k, g, gn[k])
+            continue
+        fl = floor[k.split(".")[0]]
+        if fl > 0.05:
+            continue
+        err = abs(g - g64[k]) / g64[k]
+        score = err / max(4 * fl, rgb_tol if k.startswith("RGB_net") else grad_tol)
+        checked += 1
+        if score > worst:
+            worst, worst_key = score, (k, err, fl)
+    return worst, worst_key, checked
+
+
+def _check_fp32(gold, model, acts, out3, out4, loss, tol, grad_tol, grad_tensor_tol, rgb_tol):
+    bad = {}
+    for k, v in (("out3", _rel(out3.detach().cpu(), gold["out3"])), ("out4", _rel(out4.detach().cpu(), gold["out4"])),
+                 ("loss", abs(loss.item() - gold["loss"][0]) / abs(gold["loss"][0]))):
+        if not v <= tol:
+            bad[k] = v
+    for key, (rmax, rl2, rmean) in _digest_report(gold, acts, "act", lambda t: t).items():
+        if not (rmax <= tol and rl2 <= tol and rmean <= tol):
+            bad[key] = (rmax, rl2, rmean)
+    for key, (rmax, rl2, rmean) in _digest_report(gold, acts, "actgrad", lambda t: t.grad).items():
+        # noise floor of the reference's own fp32 activation gradient on these rows: |ref32 - fp64| (the fixture holds the
+        # fp64 evaluation of the same rows); e.g. layer_idx: 5.6e-3 — it feeds the -1e10-masked softmax heads
+        fl_max = fl_l2 = 0.0
+        if key + ".rows64" in gold.files:
+            r32, r64 = gold[key + ".rows"].astype(np.float64), gold[key + ".rows64"].astype(np.float64)
+            fl_max = float(np.abs(r32 - r64).max() / gold[key + ".stats"][2])
+            fl_l2 = float(abs(gold[key + ".stats"][1] - gold[key + ".stats64"][1]) / gold[key + ".stats64"][1])
+        if not (rmax <= grad_tensor_tol + 2 * fl_max and rl2 <= grad_tensor_tol + 2 * fl_l2):
+            bad[key] = (rmax, rl2, fl_max, fl_l2)
+    params = dict(model.named_parameters())
+    for k in [f[6:] for f in gold.files if f.startswith("pgrad.")]:
+        lim = max(5e-3, grad_tensor_tol) if k.startswith("LiDAR_lv1") else grad_tensor_tol     # |ref32 - fp64| = 1.7e-3 at level 1
+        r = _rel(params[k].grad.cpu(), gold["pgrad." + k])
+        if not r <= lim:
+            bad["pgrad." + k] = r
+    state = model.state_dict()
+    for k, s, a in zip(gold["buf_keys"].tolist(), gold["buf_sum"].tolist(), gold["buf_abs_sum"].tolist()):
+        v = state[k].double()
+        if not (abs(float(v.sum()) - s) <= 1e-4 * max(a, 1e-6) and abs(float(v.abs().sum()) - a) <= 1e-4 * max(a, 1e-6)):
+            bad["buffer." + k] = (float(v.sum()), s)
+    worst, worst_key, checked = _grad_norm_check(gold, model, grad_tol, rgb_tol)
+    assert checked > 100
+    if worst > 1.0:
+        bad["grad_norm"] = worst_key
+    assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_config1_batch8_fp32_matches_reference_on_gpu(hip_backend):
+    """BASELINE.json configs[1] — the configuration `bench.py`'s default line is measured on — against the reference at
+    that size: forward tensors 1e-4 (north_star), gradients as in tests/test_model_golden.py's GPU variant."""
+    torch.manual_seed(0)
+    _check_fp32(*_run_sized("kitti_b8", "cuda"), tol=1e-4, grad_tol=1e-3, grad_tensor_tol=2e-3, rgb_tol=1.5e-2)
+
+
+@pytest.mark.gpu
+def test_config2_shape_batch16_fp32_matches_reference_on_gpu(hip_backend):
+    """the configs[2] shape (batch 16, 1.7 M cost-volume rows) in fp32: the reference's own precision at that size"""
+    torch.manual_seed(0)
+    _check_fp32(*_run_sized("kitti_b16", "cuda"), tol=1e-4, grad_tol=1e-3, grad_tensor_tol=2e-3, rgb_tol=1.5e-2)
+
+
+@pytest.mark.gpu
+def test_config2_batch16_bf16_against_reference_on_gpu(hip_backend):
+    """BASELINE.json configs[2] (batch 16, bf16 storage of the fused chains + bf16 MFMA point-MLP) against the fp32
+    reference at that size, at the bf16 contract of DESIGN.md §2 / tests/test_bf16_gpu.py: pose < 8e-2 of its scale,
+    loss < 5e-2, every recorded activation < 1e-1 in relative L2 norm and < 3e-1 max-norm on the fixture rows, the norm
+    of the whole well-conditioned gradient within 25 %."""
+    torch.manual_seed(0)
+    gold, model, acts, out3, out4, loss = _run_sized("kitti_b16", "cuda", precision="bf16")
+    assert _rel(out3.detach().cpu(), gold["out3"]) < 8e-2
+    assert _rel(out4.detach().cpu(), gold["out4"]) < 8e-2
+    assert abs(loss.item() - gold["loss"][0]) / abs(gold["loss"][0]) < 5e-2
+    G = _gen()
+    for name, t in acts.items():
+        gs = gold[f"act.{name}.stats"]
+        stats, rows = G.tensor_digest(t.detach().cpu(), name)
+        want = torch.as_tensor(gold[f"act.{name}.rows"]).double()
+        r2 = float((torch.as_tensor(rows).double() - want).norm() / want.norm())
+        assert r2 < 1e-1, (name, r2)
+        assert abs(stats[1] - gs[1]) / gs[1] < 5e-2, (name, stats[1], gs[1])
+        assert _rel(rows, want, scale=gs[2]) < 3e-1, name
+    params = dict(model.named_parameters())
+    g64 = dict(zip(gold["grad_keys"].tolist(), gold["grad_norm64"].tolist()))
+    gn = dict(zip(gold["grad_keys"].tolist(), gold["grad_norm"].tolist()))
+    floor = {}
+    for k in params:
+        if gn[k] > 1e-4 and g64[k] > 0.0:
+            m = k.split(".")[0]
+            floor[m] = max(floor.get(m, 0.0), abs(gn[k] - g64[k]) / g64[k])
+    num = den = 0.0
+    for k, p in params.items():
+        if gn[k] <= 1e-4 or g64[k] == 0.0 or floor[k.split(".")[0]] > 1e-3 or p.grad is None:
+            continue
+        num += float(p.grad.double().norm()) ** 2; den += g64[k] ** 2
+    assert abs((num / den) ** 0.5 - 1.0) < 0.25, (num / den) ** 0.5
+
+
+def test_generator_helpers_run_at_head(oracle_backend):
+    """tools/gen_golden.py must keep running as the product changes (its fp64 leg had rotted).  The
+    fixture generator's reference-free parts — the fp64 evaluation of our network and the digest helpers — on a small
+    case: the fp64 gradient norms must agree with the fp32 run of the same network on the oracle backend."""
+    from i2pnet_amd import ops, synth
+    from i2pnet_amd.config import CONFIGS
+    from i2pnet_amd.loss import Get_loss
+    from i2pnet_amd.model import RegNet_v2
+    G = _gen()
+    cfg_name, seed = "config_proj_lidarcenter", 5
+    cfg = CONFIGS[cfg_name]
+    model = RegNet_v2(cfg=cfg)
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    batch = synth.make_batch(1, 4096, 160, 512, seed=seed, fup=cfg.fup, fdown=cfg.fdown, unique_cells=(cfg.init_H, cfg.init_W))
+    prev = ops.set_backend(oracle_backend)
+    try:
+        g64 = G.fp64_gradients(cfg_name, shapes, seed, batch)
+        model.load_state_dict(synthetic_state(shapes, seed=seed)); model.eval()
+        out3, out4, _, _, sx, sq = model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"], None, batch["init_intrinsic"],
+                                         None, None, None, batch["lidar_feats"], cfg=cfg)
+        loss, _, _ = Get_loss(out3, out4, batch["decalib_real_gt"], batch["decalib_dual_gt"], sx, sq, cfg=cfg)
+        loss.backward()
+    finally:
+        ops.set_backend(prev)
+    tot32 = sum(float(p.grad.double().norm()) ** 2 for k, p in model.named_parameters() if p.grad is not None and k in g64) ** 0.5
+    tot64 = sum(v * v for v in g64.values()) ** 0.5
+    assert len(g64) > 150 and abs(tot32 - tot64) <= 5e-2 * tot64, (tot32, tot64)
+    # digest helpers: seeded row subset is reproducible and sorted
+    r1, r2 = G.sample_rows(10000, "cost_volume1"), G.sample_rows(10000, "cost_volume1")
+    assert torch.equal(r1, r2) and len(r1) == G.SAMPLED_ROWS and bool((r1[1:] > r1[:-1]).all())
+    st, rows = G.tensor_digest(torch.arange(40.0).view(10, 4), "x")
+    assert rows.shape == (10, 4) and abs(st[2] - 39.0) < 1e-12

@@ -8,6 +8,7 @@ expected outputs stored) are committed, this script is how they were made.
 """
 import contextlib
 import io
+import os
 import sys
 from pathlib import Path
 
@@ -21,7 +22,7 @@ import ref_harness  # noqa: E402
 from helpers import make_kitti_tree, synthetic_state  # noqa: E402
 from i2pnet_amd import synth  # noqa: E402
 
-OUT = ROOT / "tests" / "golden"
+OUT = Path(os.environ.get("I2P_GOLDEN_OUT", ROOT / "tests" / "golden"))   # (override: regenerate into a scratch directory)
 HOOKED = ["LiDAR_lv1", "LiDAR_lv2", "LiDAR_lv3", "LiDAR_lv4", "cost_volume1", "layer_idx", "flow_predictor0",
           "set_upconv0_w_upsample", "set_upconv0_upsample", "cost_volume2", "flow_predictor0_predict",
           "flow_predictor0_w"]
@@ -135,6 +136,94 @@ def run_train(cfg_name, tag, B, N, img_h, img_w, seed, beams):
           "size", (OUT / f"model_{tag}.npz").stat().st_size)
 
 
+SAMPLED_ROWS = 256
+
+
+def sample_rows(n_rows, name):
+    """the fixture's row subset of an activation [rows, C]: seeded by the module name, so tests re-derive it"""
+    g = torch.Generator().manual_seed(sum(map(ord, name)) * 7919 + n_rows)
+    return torch.randperm(n_rows, generator=g)[:min(SAMPLED_ROWS, n_rows)].sort().values
+
+
+def tensor_digest(t, name):
+    """[rows, C] -> (stats [mean, L2, abs-max] in fp64, the sampled rows fp32)"""
+    t = t.detach().reshape(-1, t.shape[-1])
+    d = t.double()
+    stats = np.array([float(d.mean()), float(d.norm()), float(d.abs().max())])
+    return stats, t[sample_rows(t.shape[0], name)].float().numpy()
+
+
+def run_sized(cfg_name, tag, B, N, img_h, img_w, seed, beams):
+    """The benchmark's own batch sizes (BASELINE.json configs[1]: B=8 fp32; configs[2]: B=16) against the reference in
+    TRAIN mode (train20v2learn_wandb_proj.py:31,435-483; dropout p = 0: its RNG stream is not portable).  Batch-statistics
+    BN (PPBackbone_center.py:30) makes the batch size part of the function, so the batch-2 fixtures do not pin these.  The
+    activations are hundreds of MB at this size: the fixture keeps per-module digests (mean / L2 / abs-max over the whole
+    tensor in fp64 + 256 seeded rows), out3 / out4 / loss in full and every parameter's gradient norm (+ the fp64 value)."""
+    RegNet, cfg, Get_loss = ref_harness.load_model(cfg_name)
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = RegNet(cfg=cfg)
+    shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    model.load_state_dict(synthetic_state(shapes, seed=seed))
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    batch = synth.make_batch(B, N, img_h, img_w, seed=seed, beams=beams, fup=cfg.fup, fdown=cfg.fdown,
+                             unique_cells=(cfg.init_H, cfg.init_W))
+    captured = {}
+
+    def hook(name):
+        def f(mod, inp, out):
+            o = out[2] if isinstance(out, tuple) else out
+            o.retain_grad() if o.requires_grad else None
+            captured[name] = o
+        return f
+    for name in HOOKED:
+        getattr(model, name).register_forward_hook(hook(name))
+    orig = model.LiDAR_lv1.forward_center
+
+    def fc(*a, **k):
+        out = orig(*a, **k)
+        captured["LiDAR_lv1"] = out[2]; out[2].retain_grad()
+        return out
+    model.LiDAR_lv1.forward_center = fc
+    out3, out4, _, _, sx, sq = model(batch["rgb"], batch["lidar"], batch["raw_point_xyz"], batch["init_extrinsic"],
+                                     batch["init_intrinsic"], None, None, None, batch["lidar_feats"], cfg=cfg)
+    loss, lq, lx = Get_loss(out3, out4, batch["decalib_real_gt"], batch["decalib_dual_gt"], sx, sq, cfg=cfg)
+    loss.backward()
+    data = {"out3": out3.detach().numpy(), "out4": out4.detach().numpy(),
+            "loss": np.array([loss.item(), lq.item(), lx.item()], np.float64)}
+    for name, t in captured.items():
+        data["act." + name + ".stats"], data["act." + name + ".rows"] = tensor_digest(t, name)
+        if t.grad is not None:
+            data["actgrad." + name + ".stats"], data["actgrad." + name + ".rows"] = tensor_digest(t.grad, name)
+    keys, gn = [], []
+    for k, p in model.named_parameters():
+        keys.append(k); gn.append(0.0 if p.grad is None else float(p.grad.double().norm()))
+    data["grad_keys"] = np.array(keys); data["grad_norm"] = np.array(gn)
+    for k in ["cost_volume1.mlp1_convs.0.conv.weight", "cost_volume1.mlp2_convs.1.conv.weight",
+              "cost_volume2.mlp2_convs_2.1.conv.weight", "LiDAR_lv1.mlp_convs.0.conv.weight"]:
+        data["pgrad." + k] = dict(model.named_parameters())[k].grad.numpy()
+    bk, bs, ba = [], [], []
+    for k, v in model.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"):
+            bk.append(k); bs.append(float(v.double().sum())); ba.append(float(v.double().abs().sum()))
+    data["buf_keys"] = np.array(bk); data["buf_sum"] = np.array(bs); data["buf_abs_sum"] = np.array(ba)
+    del captured, out3, out4, loss, model
+    dig64 = {}
+    g64 = fp64_gradients(cfg_name, shapes, seed, batch, train=True, actgrad_digests=dig64)
+    for name, (st, rows) in dig64.items():             # fp64 evaluation of the same rows: |ref32 - fp64| is the floor
+        data["actgrad." + name + ".stats64"], data["actgrad." + name + ".rows64"] = st, rows
+    data["grad_norm64"] = np.array([g64.get(k, 0.0) for k in keys])
+    data["state_keys"] = np.array([k for k, _ in shapes])
+    data["state_shapes"] = np.array([",".join(map(str, s)) for _, s in shapes])
+    data["meta"] = np.array([cfg_name, str(B), str(N), str(img_h), str(img_w), str(seed), str(beams)])
+    OUT.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(OUT / f"model_{tag}.npz", **data)
+    print(tag, "out3[0]", data["out3"][0].round(4).tolist(), "loss", data["loss"][0], "size", (OUT / f"model_{tag}.npz").stat().st_size)
+
+
 def run_iter(cfg_name, tag, B, N, img_h, img_w, seed, beams):
     """iterative fine registration (src/modellearn_proj_center_iter.py): forward outputs only"""
     RegNet, cfg, _ = ref_harness.load_model(cfg_name, module="modellearn_proj_center_iter")
@@ -231,13 +320,30 @@ def run_small_range():
     print("small_range eval out3", o3.numpy().round(4).tolist(), "loss", loss.item())
 
 
-def fp64_gradients(cfg_name, shapes, seed, batch):
-    from i2pnet_amd import ops, projectpn as P
+def fp64_gradients(cfg_name, shapes, seed, batch, train=False, actgrad_digests=None):
+    """-> {parameter: fp64 gradient norm}; `actgrad_digests` (a dict) additionally receives, per HOOKED module, the fp64
+    activation-gradient digest rows (`tensor_digest`) — the noise floor of the reference's fp32 activation gradients"""
+    from i2pnet_amd import model as my_model, modules as my_modules, ops, projectpn as P
     from i2pnet_amd.config import CONFIGS
     from i2pnet_amd.loss import Get_loss as my_loss
     from i2pnet_amd.model import RegNet_v2 as Mine
     F32 = torch.float32
     saved = (P.gather_torch, P._get_neighbor, P.index_points_group, P.project_seq, P.knn_point, torch.Tensor.float)
+    saved_uv = (my_modules._unit_variance, my_model._unit_variance)
+    from i2pnet_amd import warp as my_warp
+    saved_mul = my_warp.mul_q
+    flags = ("USE_FUSED_MLP", "USE_FUSED_BN", "USE_CV_TAIL", "USE_FUSED_IMG", "USE_FUSED_GROUP")
+    saved_flags = [getattr(my_modules, f) for f in flags]
+
+    def mul64(a, b):           # Hamilton product (warp_utils.py:25-55) in plain torch: the one-launch op is fp32-only
+        a = a.unsqueeze(1) if a.ndim == 2 else a
+        b = b.unsqueeze(1) if b.ndim == 2 else b
+        aw, ax, ay, az = a.unbind(-1); bw, bx, by, bz = b.unbind(-1)
+        return torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                            aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], -1)
+
+    def unitvar64(x):          # PPBackbone_center.py:388-393 in the tensor's own dtype (the HIP / oracle op is fp32-only)
+        return (x - torch.mean(x, -1, keepdim=True)) / torch.clip(torch.std(x, -1, keepdim=True), min=1e-12)
 
     def gather64(feature, b, h, w, batch_, height, width):
         feat = feature.reshape(batch_, height * width, -1)
@@ -265,17 +371,47 @@ def fp64_gradients(cfg_name, shapes, seed, batch):
 
     try:
         P.gather_torch, P._get_neighbor, P.index_points_group, P.project_seq, P.knn_point = gather64, neigh64, group64, proj64, knn64
+        my_modules._unit_variance = my_model._unit_variance = unitvar64
+        my_warp.mul_q = mul64
+        for f in flags:        # every fused fp32 kernel path off: the fp64 leg is plain torch + the oracle's index ops
+            setattr(my_modules, f, False)
         torch.Tensor.float = lambda self: self.double()
         cfg = CONFIGS[cfg_name]
-        m = Mine(cfg=cfg); m.load_state_dict(synthetic_state(shapes, seed=seed)); m.eval().double()
+        m = Mine(cfg=cfg); m.load_state_dict(synthetic_state(shapes, seed=seed))
+        if train:              # image-encoder BNs on batch statistics, dropout present with p = 0
+            m.train()
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+        else:
+            m.eval()
+        m.double()
+        cap = {}
+        if actgrad_digests is not None:
+            def hook64(name):
+                def f(mod, inp, out):
+                    o = out[2] if isinstance(out, tuple) else out
+                    o.retain_grad() if o.requires_grad else None
+                    cap[name] = o
+                return f
+            for name in HOOKED:
+                if name != "LiDAR_lv1":
+                    getattr(m, name).register_forward_hook(hook64(name))
         b = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
         out3, out4, _, _, sx, sq = m(b["rgb"], b["lidar"], b["raw_point_xyz"], None, b["init_intrinsic"], None, None, None,
                                      b["lidar_feats"], cfg=cfg)
         loss, _, _ = my_loss(out3, out4, b["decalib_real_gt"], b["decalib_dual_gt"], sx, sq, cfg)
         loss.backward()
+        for name, t in cap.items():
+            if t.grad is not None:
+                actgrad_digests[name] = tensor_digest(t.grad, name)
         return {k: float(p.grad.norm()) for k, p in m.named_parameters() if p.grad is not None}
     finally:
         (P.gather_torch, P._get_neighbor, P.index_points_group, P.project_seq, P.knn_point, torch.Tensor.float) = saved
+        my_modules._unit_variance, my_model._unit_variance = saved_uv
+        my_warp.mul_q = saved_mul
+        for f, v in zip(flags, saved_flags):
+            setattr(my_modules, f, v)
 
 
 def run_metrics():
@@ -382,6 +518,11 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         run_train("config_proj_lidarcenter", "kitti_train", B=2, N=8192, img_h=375, img_w=1242, seed=7, beams=64)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sized":
+        # BASELINE.json configs[1] (batch 8, fp32) and configs[2] (batch 16) at the benchmark's shapes
+        run_sized("config_proj_lidarcenter", "kitti_b8", B=8, N=8192, img_h=375, img_w=1242, seed=8, beams=64)
+        run_sized("config_proj_lidarcenter", "kitti_b16", B=16, N=8192, img_h=375, img_w=1242, seed=16, beams=64)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "iter":
         run_iter("config_proj_lidarcenter", "kitti_iter", B=2, N=8192, img_h=375, img_w=1242, seed=3, beams=64)
