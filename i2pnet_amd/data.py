@@ -9,6 +9,13 @@ point shuffle (:532-533), training jitter (:332-343, :622-626), `init_extrinsic 
 150 000 rows (:699-711), image crop of the top 50 rows, x0.5 resize, 160x512 crop and the intrinsic bookkeeping
 (:713-747), keys of the sample (:770-787).
 
+nuScenes half (same sample dict, `src/nuscenes_loader_proj_nolidar.py:94-387`): `NuScenesFiles` reads the pickled split
+lists the reference reads (`[((lidar file, camera file), K, Tr, night_tag)]`, :132-166), the `.pcd.bin` sweeps (float32
+x 5 per point, what the devkit's `LidarPointCloud.from_file` does) and the camera images; `NuScenesSampleBuilder` does
+the ego-vehicle / elevation filters (:244-279), the axis swap of `raw_point_xyz` (:337-341), the 100-row crop and the
+0.32 x 0.2 resize (:287-296) on the device.  `nuscenes_pair_from_tables` derives one list entry (K, Tr) from the raw
+nuScenes JSON tables without the devkit.
+
 What the reference does in numpy / cv2 on DataLoader workers per sample (150 000-row float64 matmuls, concatenations, a
 cv2 resize) happens here in a handful of device kernels per BATCH; the host only reads the two files and draws the six
 random numbers of the perturbation.  `Prefetcher` overlaps file reading (a thread), the pinned host->device copies (a
@@ -132,19 +139,62 @@ class KittiOdometryFiles(torch.utils.data.Dataset):
 # --------------------------------------------------------------------------------------------------------------
 # device side
 # --------------------------------------------------------------------------------------------------------------
-def resize_half_u8(img):
-    """cv2.resize(img, (round(w/2), round(h/2)), INTER_LINEAR) of a uint8 image [H,W,3] (on any device): at scale 1/2 the
-    bilinear sample point of output pixel x is 2x + 0.5, i.e. the mean of source pixels 2x, 2x+1 (both axes), which
-    cv2's fixed-point path rounds half up."""
+_COEF_BITS = 11                      # cv2's INTER_RESIZE_COEF_BITS: bilinear weights as 11-bit fixed point
+
+
+def _linear_taps(n_out, n_in, clamp_weight, device):
+    """source index and the two fixed-point weights of every output coordinate along one axis, as cv2 computes them
+    (resize.cpp, `resize` linear branch): f = float((d + 0.5) * scale - 0.5) with scale = n_in / n_out in double,
+    s = floor(f), f -= s in float32, weights = cvRound((1 - f) * 2048), cvRound(f * 2048) (round half to even).
+    Along x (`clamp_weight`) an out-of-range tap is replaced by the border pixel with weight 1; along y the weights stay
+    and the ROW indices are clamped."""
+    scale = float(n_in) / float(n_out)
+    d = torch.arange(n_out, dtype=torch.float64)
+    f = ((d + 0.5) * scale - 0.5).to(torch.float32)
+    s = torch.floor(f)
+    f = f - s
+    s = s.to(torch.int64)
+    if clamp_weight:
+        lo, hi = s < 0, s >= n_in - 1
+        f = torch.where(lo | hi, torch.zeros_like(f), f)
+        s = torch.where(lo, torch.zeros_like(s), torch.where(hi, torch.full_like(s, n_in - 1), s))
+    one = torch.ones_like(f)
+    w0 = torch.round((one - f) * float(1 << _COEF_BITS)).to(torch.int64)
+    w1 = torch.round(f * float(1 << _COEF_BITS)).to(torch.int64)
+    i0 = s.clamp(0, n_in - 1); i1 = (s + 1).clamp(0, n_in - 1)
+    return i0.to(device), i1.to(device), w0.to(device), w1.to(device)
+
+
+def resize_linear_u8(img, oh, ow):
+    """`cv2.resize(img, (ow, oh), interpolation=cv2.INTER_LINEAR)` of a uint8 image [H,W,C], on any device.
+
+    cv2 (opencv-python 4.x; absent from this image) is restated from its published algorithm, modules/imgproc/src/resize.cpp:
+    * an exact 2x shrink on both axes is routed to INTER_AREA's fast path: the 2x2 mean `(a+b+c+d+2) >> 2`;
+    * otherwise the 8-bit bilinear path: 11-bit fixed-point weights (`_linear_taps`), a horizontal pass into int32
+      `S[x0]*a0 + S[x1]*a1`, then the vertical pass `(((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2`.
+    The reference loaders pass dsize = (round(w*s), round(h*s)); for odd sizes (a 1241-wide KITTI frame -> 620) the scale
+    is not exactly 2 and the second path runs."""
     H, W, _ = img.shape
-    oh, ow = int(round(H * 0.5)), int(round(W * 0.5))
-    # (an odd trailing row / column is sampled with its predecessor, like cv2's border clamp of the +1 neighbour)
-    ys = torch.arange(oh, device=img.device) * 2
-    xs = torch.arange(ow, device=img.device) * 2
-    y1 = (ys + 1).clamp_max(H - 1); x1 = (xs + 1).clamp_max(W - 1)
-    v = img.to(torch.int32)
-    s = v[ys][:, xs] + v[ys][:, x1] + v[y1][:, xs] + v[y1][:, x1]
-    return ((s + 2) // 4).to(torch.uint8)
+    dev = img.device
+    v = img.to(torch.int64)
+    if H == 2 * oh and W == 2 * ow:
+        s = v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2]
+        return ((s + 2) >> 2).to(torch.uint8)
+    x0, x1, a0, a1 = _linear_taps(ow, W, True, dev)
+    y0, y1, b0, b1 = _linear_taps(oh, H, False, dev)
+    rows = torch.unique(torch.cat([y0, y1]))                       # horizontal pass only on the rows the output touches
+    remap = torch.zeros(H, dtype=torch.int64, device=dev); remap[rows] = torch.arange(rows.numel(), device=dev)
+    src = v[rows]
+    hz = src[:, x0] * a0.view(1, -1, 1) + src[:, x1] * a1.view(1, -1, 1)                       # [rows, ow, C]
+    s0, s1 = hz[remap[y0]] >> 4, hz[remap[y1]] >> 4
+    out = (((b0.view(-1, 1, 1) * s0) >> 16) + ((b1.view(-1, 1, 1) * s1) >> 16) + 2) >> 2
+    return out.to(torch.uint8)
+
+
+def resize_half_u8(img):
+    """cv2.resize(img, (round(w/2), round(h/2)), INTER_LINEAR) — the KITTI loader's call (:716-720)"""
+    H, W, _ = img.shape
+    return resize_linear_u8(img, int(round(H * 0.5)), int(round(W * 0.5)))
 
 
 class DeviceSampleBuilder:
@@ -201,12 +251,8 @@ class DeviceSampleBuilder:
             # image: drop the top rows, halve, crop (:713-747)
             img = host["image"].to(dev, non_blocking=True)[self.crop_top:]
             K = np.copy(host["K"]).astype(np.float64); K[1, 2] -= self.crop_top
-            if self.img_scale == 0.5:
-                img = resize_half_u8(img)
-            else:
-                h0, w0, _ = img.shape
-                img = torch.nn.functional.interpolate(img.permute(2, 0, 1)[None].float(), size=(int(round(h0 * self.img_scale)), int(round(w0 * self.img_scale))),
-                                                      mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+            h0, w0, _ = img.shape
+            img = resize_linear_u8(img, int(round(h0 * self.img_scale)), int(round(w0 * self.img_scale)))
             K[0, 0] *= self.img_scale; K[0, 2] *= self.img_scale; K[1, 1] *= self.img_scale; K[1, 2] *= self.img_scale
             h, w, _ = img.shape
             if self.mode == "train":
@@ -224,6 +270,155 @@ class DeviceSampleBuilder:
         return {"rgb": rgb, "lidar": lidar, "raw_point_xyz": raw, "lidar_feats": feats, "init_extrinsic": ext, "init_intrinsic": intr,
                 "decalib_real_gt": q_gt, "decalib_dual_gt": t_gt, "path_info": paths, "index": idxs,
                 "resize_img": torch.tensor([[self.img_scale, self.img_scale]] * B)}
+
+
+# --------------------------------------------------------------------------------------------------------------
+# nuScenes (src/nuscenes_loader_proj_nolidar.py)
+# --------------------------------------------------------------------------------------------------------------
+def read_pcd_bin(path):
+    """nuScenes LIDAR_TOP sweep `.pcd.bin`: float32 (x, y, z, intensity, ring) per point -> [N,4] (the devkit's
+    `LidarPointCloud.from_file` keeps the first four of the five columns; nuscenes_loader_proj_nolidar.py:237)"""
+    return np.fromfile(path, dtype=np.float32).reshape(-1, 5)[:, :4]
+
+
+def _quat_wxyz_to_matrix(q):
+    w, x, y, z = [float(v) for v in q]
+    n = math.sqrt(w * w + x * x + y * y + z * z)
+    w, x, y, z = w / n, x / n, y / n, z / n
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=np.float64)
+
+
+def _pose(rotation_wxyz, translation):
+    P = np.identity(4)
+    P[:3, :3] = _quat_wxyz_to_matrix(rotation_wxyz); P[:3, 3] = np.asarray(translation, dtype=np.float64)
+    return P
+
+
+def nuscenes_pair_from_tables(lidar_sd, cam_sd, calibrated_sensor, ego_pose, night_tag=False):
+    """One entry `((lidar file, camera file), K, Tr, night_tag)` of the reference's split lists from the raw nuScenes
+    JSON tables (no devkit): `lidar_sd` / `cam_sd` = rows of sample_data.json, `calibrated_sensor` / `ego_pose` = dicts
+    token -> row.  Tr [4,4] maps LIDAR_TOP sensor coordinates to the camera frame through the two ego poses
+    (sensor -> ego(t_lidar) -> global -> ego(t_cam) -> camera), K = the camera's `camera_intrinsic`."""
+    cs_l, cs_c = calibrated_sensor[lidar_sd["calibrated_sensor_token"]], calibrated_sensor[cam_sd["calibrated_sensor_token"]]
+    ep_l, ep_c = ego_pose[lidar_sd["ego_pose_token"]], ego_pose[cam_sd["ego_pose_token"]]
+    lidar_to_ego = _pose(cs_l["rotation"], cs_l["translation"]); ego_l_to_global = _pose(ep_l["rotation"], ep_l["translation"])
+    cam_to_ego = _pose(cs_c["rotation"], cs_c["translation"]); ego_c_to_global = _pose(ep_c["rotation"], ep_c["translation"])
+    Tr = np.linalg.inv(cam_to_ego) @ np.linalg.inv(ego_c_to_global) @ ego_l_to_global @ lidar_to_ego
+    K = np.asarray(cs_c["camera_intrinsic"], dtype=np.float64)
+    return ((lidar_sd["filename"], cam_sd["filename"]), K, Tr, bool(night_tag))
+
+
+class NuScenesFiles(torch.utils.data.Dataset):
+    """Host half of a nuScenes sample: the sweep [N,4] f32, the camera image [900,1600,3] u8, K and Tr of the list entry.
+    Split lists and sub-directories as in the reference (:130-166): `train` = train + val lists under `<root>/trainval`,
+    `val` under `<root>/trainval`, `test` under `<root>/test`; the lists are looked up in `split_dir` (the reference
+    hard-codes ./nuScenes_datasplit relative to the working directory)."""
+
+    def __init__(self, root_path, mode="train", split_dir="./nuScenes_datasplit", random_car=True, skip=1):
+        import pickle
+        info = "randominfo" if random_car else "info"
+        lst = lambda m: os.path.join(split_dir, f"{m}_dataset_{info}_proj_day.list")
+        if mode not in ("train", "val", "test"):
+            raise NotImplementedError(mode)
+        self.mode, self.skip = mode, skip
+        self.root = os.path.join(root_path, "test" if mode == "test" else "trainval")
+        self.items = []
+        for m in {"train": ("train", "val"), "val": ("val",), "test": ("test",)}[mode]:
+            with open(lst(m), "rb") as f:
+                self.items.extend(pickle.load(f))
+
+    def __len__(self):
+        return int(np.ceil(len(self.items) / self.skip))
+
+    def __getitem__(self, index):
+        from PIL import Image
+        (lp, cp), K, Tr, _night = self.items[index * self.skip]
+        scan = read_pcd_bin(os.path.join(self.root, lp))
+        img = np.array(Image.open(os.path.join(self.root, cp)), np.uint8)
+        return {"scan": torch.from_numpy(np.ascontiguousarray(scan)), "image": torch.from_numpy(np.ascontiguousarray(img)),
+                "K": np.asarray(K, dtype=np.float64).copy(), "Tr": np.asarray(Tr, dtype=np.float64), "index": index,
+                "path_info": "%d" % (index * self.skip)}
+
+
+class NuScenesSampleBuilder(DeviceSampleBuilder):
+    """nuScenes half-samples -> one batched sample dict on the device (nuscenes_loader_proj_nolidar.py:230-387): point
+    shuffle, ego-vehicle box and elevation filters, training jitter, `init_extrinsic @ [pc;1]`, `raw_point_xyz` =
+    (y, -x, z) of the sensor-frame points, zero padding to 150 000 rows; image: top 100 rows dropped, resized by
+    (0.32, 0.2) with cv2's bilinear rule, 160x512 crop, intrinsics adjusted alike."""
+    TAN_UP, TAN_DOWN = 0.03492076949, -0.4620648698           # +2 deg / -24.8 deg elevation window (:271-275)
+
+    def __init__(self, device, mode="train", sample_point=150000, img_H=160, img_W=512, img_scale_H=0.2, img_scale_W=0.32,
+                 crop_top=100, rng=None, jitter=True):
+        super().__init__(device, mode, sample_point, img_H, img_W, img_scale_H, crop_top, rng, jitter)
+        self.img_scale_H, self.img_scale_W = img_scale_H, img_scale_W
+
+    def perturbation(self, host):
+        Pr = host.get("Pr")
+        if Pr is None:
+            Pr = random_transform(self.rng).astype(np.float32)               # (:230: float32 perturbation)
+        Pr = np.asarray(Pr)
+        calib_extrinsic = np.linalg.inv(Pr)[:3, :]
+        q = rotmat_to_quat(calib_extrinsic[:3, :3])
+        t = calib_extrinsic[:, 3]
+        init_extrinsic = np.dot(Pr, host["Tr"])[:3]
+        return Pr, init_extrinsic, q, t
+
+    @torch.no_grad()
+    def __call__(self, hosts, stream=None):
+        dev = self.device
+        B, SP = len(hosts), self.sample_point
+        lidar = torch.zeros(B, SP, 3, device=dev); raw = torch.zeros(B, SP, 3, device=dev); feats = torch.zeros(B, SP, 1, device=dev)
+        rgb = torch.empty(B, 3, self.img_H, self.img_W, device=dev)
+        ext = torch.empty(B, 3, 4, device=dev); q_gt = torch.empty(B, 4, device=dev); t_gt = torch.empty(B, 3, device=dev)
+        Ks, raw_Ks, paths, idxs, stats, counts = [], [], [], [], [], []
+        for b, host in enumerate(hosts):
+            Pr, E, q, t = self.perturbation(host)
+            scan = host["scan"].to(dev, non_blocking=True)                            # [N,4]
+            perm = host.get("perm")
+            perm = torch.randperm(scan.shape[0], device=dev) if perm is None else torch.as_tensor(perm, device=dev)   # :238
+            scan = scan[perm]
+            x, y = scan[:, 0], scan[:, 1]
+            inside = (x < 0.8) & (x > -0.8) & (y < 2.7) & (y > -2.7)                   # the ego vehicle, :243-247
+            scan = scan[~inside]
+            # 5 / 95 percentiles of (y, -x, z) after the ego filter (`pc_stat`, :253-259; diagnostic only)
+            pq = torch.tensor([0.05, 0.95], dtype=torch.float64, device=dev)
+            stats.append(torch.stack([torch.quantile(c.double(), pq) for c in (scan[:, 1], -scan[:, 0], scan[:, 2])]))
+            ratio = scan[:, 2] / torch.sqrt(scan[:, 0] * scan[:, 0] + scan[:, 1] * scan[:, 1])
+            scan = scan[(ratio < self.TAN_UP) & (ratio > self.TAN_DOWN)]                # :266-278
+            n = min(scan.shape[0], SP)
+            scan = scan[:n]
+            pc = scan[:, :3]
+            if self.jitter:
+                pc = pc + torch.clamp(0.01 * torch.randn_like(pc), -0.05, 0.05)
+            Ed = torch.as_tensor(E, dtype=torch.float64, device=dev)
+            lidar[b, :n] = (pc.double() @ Ed[:, :3].t() + Ed[:, 3]).float()             # :343-348
+            raw[b, :n, 0] = pc[:, 1]; raw[b, :n, 1] = -pc[:, 0]; raw[b, :n, 2] = pc[:, 2]   # :337-341
+            feats[b, :n, 0] = scan[:, 3]
+            counts.append(n)
+            img = host["image"].to(dev, non_blocking=True)[self.crop_top:]
+            K = np.copy(host["K"]).astype(np.float64); raw_Ks.append(np.copy(K)); K[1, 2] -= self.crop_top
+            h0, w0, _ = img.shape
+            img = resize_linear_u8(img, int(round(h0 * self.img_scale_H)), int(round(w0 * self.img_scale_W)))
+            K[0, 0] *= self.img_scale_W; K[0, 2] *= self.img_scale_W; K[1, 1] *= self.img_scale_H; K[1, 2] *= self.img_scale_H
+            h, w, _ = img.shape
+            if self.mode == "train":
+                dx, dy = self.rng.randint(0, w - self.img_W), self.rng.randint(0, h - self.img_H)
+            else:
+                dx, dy = int((w - self.img_W) / 2), int((h - self.img_H) / 2)
+            dx, dy = host.get("crop", (dx, dy))
+            rgb[b] = img[dy:dy + self.img_H, dx:dx + self.img_W].permute(2, 0, 1).float()
+            K[0, 2] -= dx; K[1, 2] -= dy
+            Ks.append(K)
+            ext[b] = torch.as_tensor(E, dtype=torch.float32); q_gt[b] = torch.as_tensor(q, dtype=torch.float32)
+            t_gt[b] = torch.as_tensor(t, dtype=torch.float32)
+            paths.append(host["path_info"]); idxs.append(host["index"])
+        intr = torch.as_tensor(np.stack(Ks), dtype=torch.float32).to(dev)
+        return {"rgb": rgb, "lidar": lidar, "raw_point_xyz": raw, "lidar_feats": feats, "init_extrinsic": ext, "init_intrinsic": intr,
+                "raw_intrinsic": torch.as_tensor(np.stack(raw_Ks), dtype=torch.float32).to(dev),
+                "decalib_real_gt": q_gt, "decalib_dual_gt": t_gt, "path_info": paths, "index": idxs, "n_points": counts,
+                "pc_stat": torch.stack(stats), "resize_img": torch.tensor([[self.img_scale_H, self.img_scale_W]] * B)}
 
 
 class Prefetcher:

@@ -116,3 +116,38 @@ def make_kitti_tree(root, seed=7, n_points=3000, img_h=372, img_w=1030):
                 f.write(k + ": " + " ".join("%.9e" % v for v in m.reshape(-1)) + "\n")
 
 
+
+
+def make_nuscenes_tree(root, split_dir, seed=11, n_points=4000, n_samples=2, img_h=900, img_w=1600):
+    """A minimal synthetic nuScenes tree in the layout `src/nuscenes_loader_proj_nolidar.py` reads: `<root>/trainval/`
+    with LIDAR_TOP `.pcd.bin` sweeps (float32 x 5 per point) and camera images (PNG: lossless), plus the pickled split
+    lists `[((lidar file, camera file), K, Tr, night_tag)]` under `split_dir` (the reference opens
+    ./nuScenes_datasplit/<mode>_dataset_randominfo_proj_day.list relative to the working directory).  Seeded."""
+    import os
+    import pickle
+    import numpy as np
+    from PIL import Image
+    rs = np.random.RandomState(seed)
+    os.makedirs(split_dir, exist_ok=True)
+    K = np.array([[1266.417203046554, 0.0, 816.2670197447984], [0.0, 1266.417203046554, 491.50706579294757], [0.0, 0.0, 1.0]])
+    entries = {"train": [], "val": [], "test": []}
+    for i in range(n_samples):
+        for mode, sub in (("val", "trainval"), ("train", "trainval"), ("test", "test")):
+            if mode != "val" and i > 0:
+                continue
+            ld = os.path.join(root, sub, "samples", "LIDAR_TOP"); cd = os.path.join(root, sub, "samples", "CAM_FRONT")
+            os.makedirs(ld, exist_ok=True); os.makedirs(cd, exist_ok=True)
+            n = n_points + 31 * i
+            xyz = (rs.rand(n, 3) - 0.5) * np.array([100.0, 100.0, 10.0]) + np.array([0.0, 0.0, -1.0])
+            xyz[: n // 10] *= np.array([0.02, 0.06, 1.0])                    # a cluster on the ego vehicle (filtered out)
+            scan = np.concatenate([xyz, rs.rand(n, 1) * 255.0, rs.randint(0, 32, (n, 1))], 1).astype(np.float32)
+            lf = os.path.join("samples", "LIDAR_TOP", f"{mode}_{i:03d}.pcd.bin"); cf = os.path.join("samples", "CAM_FRONT", f"{mode}_{i:03d}.png")
+            scan.tofile(os.path.join(root, sub, lf))
+            Image.fromarray(rs.randint(0, 256, (img_h, img_w, 3)).astype(np.uint8)).save(os.path.join(root, sub, cf))
+            a = 0.02 * (i + 1)
+            R = np.array([[np.cos(a), -np.sin(a), 0.0], [0.0, 0.0, -1.0], [np.sin(a), np.cos(a), 0.0]])
+            Tr = np.identity(4); Tr[:3, :3] = R; Tr[:3, 3] = [0.01 * i, -0.32, -0.75]
+            entries[mode].append(((lf, cf), K.copy(), Tr, False))
+    for mode, lst in entries.items():
+        with open(os.path.join(split_dir, f"{mode}_dataset_randominfo_proj_day.list"), "wb") as f:
+            pickle.dump(lst, f)

@@ -453,29 +453,141 @@ def run_metrics():
     print("metrics.npz", (OUT / "metrics.npz").stat().st_size, "bytes; recall", evt.get_recall(), "seq", ev.evalSeq())
 
 
+def cv2_resize_linear_u8(img, size, interpolation=None):
+    """numpy restatement of cv2.resize(img, (w, h), interpolation=cv2.INTER_LINEAR) for uint8 images (cv2 is absent from
+    the image; algorithm of OpenCV 4.x modules/imgproc/src/resize.cpp): exact 2x shrink on both axes -> INTER_AREA's
+    2x2 mean (a+b+c+d+2)>>2; otherwise 11-bit fixed-point bilinear, horizontal pass then
+    (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.  Written independently of i2pnet_amd/data.py::resize_linear_u8
+    (scalar loops over the output grid's taps) so that the fixture is not a self-comparison of one formula."""
+    w, h = size
+    H, W = img.shape[:2]
+    src = img.astype(np.int64)
+    if H == 2 * h and W == 2 * w:
+        return ((src[0::2, 0::2] + src[0::2, 1::2] + src[1::2, 0::2] + src[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    sx, sy = np.float64(W) / w, np.float64(H) / h
+    xo, xa = np.zeros(w, np.int64), np.zeros((w, 2), np.int64)
+    for dx in range(w):
+        fx = np.float32((dx + 0.5) * sx - 0.5)
+        ix = int(np.floor(fx)); fx = np.float32(fx - np.float32(ix))
+        if ix < 0:
+            fx, ix = np.float32(0), 0
+        if ix >= W - 1:
+            fx, ix = np.float32(0), W - 1
+        xo[dx] = ix
+        xa[dx, 0] = int(np.rint(np.float32(np.float32(1.0) - fx) * np.float32(2048.0))); xa[dx, 1] = int(np.rint(fx * np.float32(2048.0)))
+    out = np.zeros((h, w, img.shape[2]), np.uint8)
+    x1 = np.minimum(xo + 1, W - 1)
+    for dy in range(h):
+        fy = np.float32((dy + 0.5) * sy - 0.5)
+        iy = int(np.floor(fy)); fy = np.float32(fy - np.float32(iy))
+        b0 = int(np.rint(np.float32(np.float32(1.0) - fy) * np.float32(2048.0))); b1 = int(np.rint(fy * np.float32(2048.0)))
+        r0, r1 = min(max(iy, 0), H - 1), min(max(iy + 1, 0), H - 1)
+        S0 = src[r0][xo] * xa[:, :1] + src[r0][x1] * xa[:, 1:]
+        S1 = src[r1][xo] * xa[:, :1] + src[r1][x1] * xa[:, 1:]
+        out[dy] = ((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2).astype(np.uint8)
+    return out
+
+
+def _loader_stubs():
+    """third-party modules the reference loaders import that this image lacks: cv2 (resize only), torchvision.transforms
+    (train-mode ColorJitter only), torch_scatter, pyquaternion, the nuScenes devkit's LidarPointCloud"""
+    import types
+    cv2 = sys.modules["cv2"]; cv2.resize = cv2_resize_linear_u8; cv2.INTER_LINEAR = 1
+    tv = sys.modules["torchvision"]; tv.transforms = types.ModuleType("torchvision.transforms"); sys.modules["torchvision.transforms"] = tv.transforms
+    ts = types.ModuleType("torch_scatter"); ts.scatter_mean = None; sys.modules["torch_scatter"] = ts
+    pq = types.ModuleType("pyquaternion"); pq.Quaternion = None; sys.modules["pyquaternion"] = pq
+    for name in ("nuscenes", "nuscenes.utils", "nuscenes.utils.data_classes"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+
+    class LidarPointCloud:                       # devkit: points = the first 4 of 5 float32 columns, stored [4, N]
+        def __init__(self, points):
+            self.points = points
+
+        @classmethod
+        def from_file(cls, file_name):
+            return cls(np.fromfile(file_name, dtype=np.float32).reshape(-1, 5)[:, :4].T)
+    sys.modules["nuscenes.utils.data_classes"].LidarPointCloud = LidarPointCloud
+    if not hasattr(np, "float"):
+        np.float = float                                   # generate_random_transform uses the removed alias (:401)
+
+
+def run_loader_nus():
+    """Sample dicts of the REFERENCE nuScenes loader (src/nuscenes_loader_proj_nolidar.py, val mode) on the synthetic tree
+    of tests/helpers.py::make_nuscenes_tree: the pin of i2pnet_amd/data.py's nuScenes half."""
+    import random, tempfile, importlib
+    from helpers import make_nuscenes_tree
+    ref_harness.install()
+    _loader_stubs()
+    mod = importlib.import_module("src.nuscenes_loader_proj_nolidar")
+    cwd = os.getcwd()
+    out = {}
+    with tempfile.TemporaryDirectory() as work:
+        root = os.path.join(work, "nus")
+        make_nuscenes_tree(root, os.path.join(work, "nuScenes_datasplit"))
+        os.chdir(work)                                     # the loader opens ./nuScenes_datasplit/*.list
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                ds = mod.nuScenesLoader({"root_path": root, "mode": "val"})
+            rec = {}
+            orig_perm = np.random.permutation
+            orig_rt = ds.generate_random_transform
+            for i in range(len(ds)):
+                np.random.seed(300 + i); random.seed(400 + i)
+                np.random.permutation = lambda n, _i=i: rec.setdefault(("perm", _i), orig_perm(n))
+                ds.generate_random_transform = lambda *a, _i=i: rec.setdefault(("Pr", _i), orig_rt(*a))
+                s = ds[i]
+                out[f"perm{i}"] = rec[("perm", i)]; out[f"Pr{i}"] = rec[("Pr", i)]
+                out[f"rgb{i}"] = s["rgb"].numpy().astype(np.uint8)
+                assert np.array_equal(out[f"rgb{i}"].astype(np.float32), s["rgb"].numpy())
+                for k in ("decalib_real_gt", "decalib_dual_gt"):
+                    out[f"{k}{i}"] = s[k].numpy()
+                n_live = int((np.abs(np.asarray(s["lidar"])).sum(-1) > 0).sum())
+                out[f"n_live{i}"] = np.array(n_live)
+                for k in ("lidar", "lidar_feats", "raw_point_xyz"):          # the zero padding to 150 000 rows is implied
+                    out[f"{k}{i}"] = np.asarray(s[k])[:n_live + 8]
+                for k in ("init_extrinsic", "init_intrinsic", "raw_intrinsic", "resize_img"):
+                    out[f"{k}{i}"] = np.asarray(s[k])
+                out[f"pc_stat{i}"] = np.asarray(s["pc_stat"])
+                out[f"path_info{i}"] = np.array(s["path_info"])
+                assert np.asarray(s["lidar"]).shape == (150000, 3)
+        finally:
+            np.random.permutation = orig_perm
+            os.chdir(cwd)
+    np.savez_compressed(OUT / "loader_nus.npz", n=np.array(len(ds)), **out)
+    print("loader_nus.npz", (OUT / "loader_nus.npz").stat().st_size, "bytes", {k: v.shape for k, v in out.items() if k.endswith("0")})
+
+
+def run_loader_odd():
+    """KITTI frames with odd sizes (376x1241, 375x1242: real odometry sequences) through the reference loader: the x0.5
+    cv2.resize is then NOT the exact 2x2 mean — rgb crops + intrinsics only"""
+    import random, tempfile, importlib
+    ref_harness.install()
+    _loader_stubs()
+    mod = importlib.import_module("src.kitti_odometry_corr_lidarnone_proj")
+    out = {}
+    for tag, (ih, iw) in (("a", (376, 1241)), ("b", (375, 1242))):
+        with tempfile.TemporaryDirectory() as root:
+            make_kitti_tree(root, seed=13, n_points=500, img_h=ih, img_w=iw)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ds = mod.Kitti_Odometry_Dataset({"root_path": root, "mode": "val", "d_rot": 10, "d_trans": 1.0, "fixed_decalib": False})
+            np.random.seed(7); random.seed(8)
+            s = ds[0]
+            out[f"rgb_{tag}"] = s["rgb"].numpy().astype(np.uint8)
+            out[f"init_intrinsic_{tag}"] = np.asarray(s["init_intrinsic"])
+            out[f"size_{tag}"] = np.array([ih, iw])
+    np.savez_compressed(OUT / "loader_kitti_odd.npz", **out)
+    print("loader_kitti_odd.npz", (OUT / "loader_kitti_odd.npz").stat().st_size, "bytes")
+
+
 def run_loader():
     """Sample dicts of the REFERENCE loader (val mode: centre crop, no jitter) on the synthetic tree: the pin of
     i2pnet_amd/data.py.  cv2 is absent from the image: its one call (`cv2.resize(..., INTER_LINEAR)` at scale 0.5) is
-    served by a numpy restatement of the bilinear rule with cv2's pixel-centre convention and round-half-up — the resize
-    step is therefore pinned against that restatement, everything else against the reference's own code."""
+    served by `cv2_resize_linear_u8`, a numpy restatement of cv2's published 8-bit algorithm — the resize step is
+    therefore pinned against that restatement, everything else against the reference's own code."""
     import random, tempfile, types, importlib
     ref_harness.install()
 
-    def resize(img, size, interpolation=None):
-        w, h = size
-        H, W = img.shape[:2]
-        ys = np.clip((np.arange(h) + 0.5) * (H / h) - 0.5, 0, H - 1); xs = np.clip((np.arange(w) + 0.5) * (W / w) - 0.5, 0, W - 1)
-        y0 = np.floor(ys).astype(int); x0 = np.floor(xs).astype(int)
-        y1 = np.minimum(y0 + 1, H - 1); x1 = np.minimum(x0 + 1, W - 1)
-        fy = (ys - y0)[:, None, None]; fx = (xs - x0)[None, :, None]
-        v = img.astype(np.float64)
-        out = (v[y0][:, x0] * (1 - fy) * (1 - fx) + v[y0][:, x1] * (1 - fy) * fx + v[y1][:, x0] * fy * (1 - fx) + v[y1][:, x1] * fy * fx)
-        return np.floor(out + 0.5).astype(img.dtype)
-    cv2 = sys.modules["cv2"]; cv2.resize = resize; cv2.INTER_LINEAR = 1
-    tv = sys.modules["torchvision"]; tv.transforms = types.ModuleType("torchvision.transforms"); sys.modules["torchvision.transforms"] = tv.transforms
-    ts = types.ModuleType("torch_scatter"); ts.scatter_mean = None; sys.modules["torch_scatter"] = ts
-    if not hasattr(np, "float"):
-        np.float = float                                   # generate_random_transform uses the removed alias (:401)
+    _loader_stubs()
     mod = importlib.import_module("src.kitti_odometry_corr_lidarnone_proj")
     with tempfile.TemporaryDirectory() as root:
         make_kitti_tree(root)
@@ -509,6 +621,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "loader":
         run_loader()
+        run_loader_odd()
+        run_loader_nus()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         run_small_range()
