@@ -41,86 +41,205 @@ def _event_time_us(launch, iters):
     return start.elapsed_time(end) / iters * 1e3
 
 
-def kernel_rooflines(B, device):
-    """Live timings (events on the launch stream) of the hand-written kernels that dominate the fp32 step.
+PMC_JSON = ROOT / "profiles" / "r03_pmc_traffic.json"
 
-    * `roofline`: the DGRAD of one fused 128->128 layer of the all-pixel cost volume on [B*228*468, 128] —
-      wreg_dgrad_kernel<128,128> (weights stationary in registers), the layer-dgrad family being the largest single
-      consumer of the step (profiles/r02_*_steady_kernel_stats.csv).  It reads gz, the layer's pre-BN output y (BN backward of the layer behind is formed on
-      load) and the pre-BN input x (activation derivative + BN-backward statistics in the store phase) and writes
-      dL/dz_in: 4 * rows*128*4 B (SURVEY.md §8d's per-layer tensor, four times) against 2*rows*128*128 flop, i.e.
-      an HBM floor of 218 us at 8 TB/s above the MFMA floor of 178 us at 157.3 TFLOP/s: HBM-bound.
-      `traffic` = PMC bytes per launch (tools/pmc_traffic.sh, profiles/r02_pmc_FETCH_SIZE.txt / WRITE_SIZE.txt:
-      2*FETCH_SIZE + WRITE_SIZE KiB, the gfx950 halving of FETCH_SIZE calibrated in the same run on bn_stats_v4).
-      The launch is timed as (dgrad + wgrad + reduction) - (wgrad + reduction): the C ABI has one backward entry;
-      the rocprofv3 summary under profiles/ has the kernel's own duration.
-    * other_kernels: the forward of the same layer (wreg_fwd_kernel: weights stationary in registers, MFMA-bound),
-      its wgrad, the factored first cost-volume layer (product formed on load), level-1 fused_conv_select_k
-      (HBM-bound on 4.64 MB/sample) and the fused level-1 grouping on the three input densities.
+
+def _pmc_traffic(kernel, B):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r03_pmc_traffic.json, written by
+    tools/pmc_step.sh: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 halving of FETCH_SIZE calibrated in the same run on
+    bn_stats_v4), scaled from the batch the passes ran at; None when the file has no record of that kernel."""
+    if not PMC_JSON.exists():
+        return None
+    rec = json.loads(PMC_JSON.read_text()).get("kernels", {}).get(kernel)
+    if not rec or rec.get("bytes_per_launch") is None:
+        return None
+    return round(rec["bytes_per_launch"] * B / rec["B"])
+
+
+class Cv1Chain:
+    """The all-pixel cost volume's fused pi-stage node (i2pnet_amd.fused._CvPiTail: pair layer -> 128->64 -> 64->64,
+    position encoding, 64+64->128 -> 128->64, softmax-weighted sum) on the tensors' real shapes at per-GPU batch B:
+    what cost_volume1 runs inside the training step (PPBackbone_center.py:383-433).  Also the PMC workload of
+    tools/pmc_step.py."""
+
+    N, M, C = 228, 468, 128
+
+    def __init__(self, B, device, seed=0):
+        from i2pnet_amd import modules
+        from i2pnet_amd.config import I2PNetConfig as cfg
+        from i2pnet_amd.model import RegNet_v2
+        torch.manual_seed(seed)
+        self.B, self.device = B, device
+        self.cv = RegNet_v2(cfg=cfg).cost_volume1.to(device)       # the module the step runs, seeded weights
+        g = torch.Generator(device=device).manual_seed(seed)
+        rnd = lambda *s: torch.randn(*s, generator=g, device=device)
+        N, M, C = self.N, self.M, self.C
+        first = self.cv.mlp1_convs[0]
+        c1 = first.out_channels
+        ce = self.cv.pi_encoding.out_channels
+        self.inputs = [rnd(B, N, C), rnd(B, M, C), rnd(B, N, c1), rnd(B, M, c1), rnd(c1, C) / C ** 0.5, rnd(B, N, ce), rnd(B, M, ce)]
+        for t in self.inputs:
+            t.requires_grad_(True)
+        self.g_out = rnd(B, N, self.cv.mlp1_convs[-1].out_channels) * 1e-3
+        self.rows = B * N * M
+        self.modules = modules
+
+    def forward(self):
+        from i2pnet_amd.fused import cv_pi_tail
+        cv = self.cv
+        f, gk, bn, bk, w1, en, ek = self.inputs
+        return cv_pi_tail(f, gk, bn, bk, w1, en, ek, cv.mlp1_convs[0], list(cv.mlp1_convs)[1:], cv.pi_encoding,
+                          list(cv.mlp2_convs))
+
+    def time_us(self, iters=10, warm=20):
+        """(forward, backward) device time of the node, events on the launch stream around each half"""
+        from i2pnet_amd import ops
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        tf = tb = 0.0
+        for i in range(warm + iters):
+            ops.begin_step(self.device)                   # the step's zero arena (one memset instead of a fill per accumulator)
+            try:
+                e0, e1, e2 = ev(), ev(), ev()
+                e0.record()
+                out = self.forward()
+                e1.record()
+                out.backward(self.g_out)
+                e2.record()
+            finally:
+                ops.end_step(self.device)
+            e2.synchronize()
+            for t in self.inputs + list(self.cv.parameters()):
+                t.grad = None
+            if i >= warm:
+                tf += e0.elapsed_time(e1); tb += e1.elapsed_time(e2)
+        return tf / iters * 1e3, tb / iters * 1e3
+
+
+# SURVEY.md §8(d): BN-exact no-recompute traffic and flops of the cost-volume pi-stage per sample and forward (cv1, fp32)
+CV1_GB_PER_SAMPLE_FWD = 0.437
+CV1_GFLOP_PER_SAMPLE_FWD = 15.1
+
+
+def chain_roofline(B, device):
+    """cv1 forward and backward wall time (events around the fused node) against SURVEY.md §8(d)'s denominators:
+    0.437 GB and 15.1 GFLOP per sample and forward; the backward does twice the flops (dgrad + wgrad of every layer) and, BN-exact
+    and without recomputation, reads each of the six pre-BN tensors and its gradient once and writes each gradient once
+    (3 x 512 channels x 4 B per pair = 0.655 GB per sample)."""
+    ch = Cv1Chain(B, device)
+    t_f, t_b = ch.time_us()
+    fwd_b, fwd_f = CV1_GB_PER_SAMPLE_FWD * 1e9 * B, CV1_GFLOP_PER_SAMPLE_FWD * 1e9 * B
+    bwd_b, bwd_f = 1.5 * fwd_b, 2.0 * fwd_f
+    return {"node": "cost_volume1 pi-stage (_CvPiTail): pair layer, 128->64, 64->64, position encoding, 64+64->128, 128->64, softmax-weighted sum; "
+                    "batch %d, %d point x pixel pairs" % (B, ch.rows),
+            "forward_us": round(t_f, 1), "backward_us": round(t_b, 1),
+            "forward": {"hbm_GBps": round(fwd_b / t_f / 1e3, 1), "hbm_frac": round(fwd_b / t_f / 1e3 / HBM_PEAK_GBS, 4),
+                        "mfma_TFLOPs": round(fwd_f / t_f / 1e6, 1), "mfma_frac": round(fwd_f / t_f / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
+                        "bytes": fwd_b, "flop": fwd_f},
+            "backward": {"hbm_GBps": round(bwd_b / t_b / 1e3, 1), "hbm_frac": round(bwd_b / t_b / 1e3 / HBM_PEAK_GBS, 4),
+                         "mfma_TFLOPs": round(bwd_f / t_b / 1e6, 1), "mfma_frac": round(bwd_f / t_b / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
+                         "bytes": bwd_b, "flop": bwd_f},
+            "denominators": "SURVEY.md 8(d): 0.437 GB + 15.1 GFLOP per sample and forward (fp32 activations); backward 1.5x the bytes, 2x the flops",
+            "timed_as": "torch.cuda events on the launch stream around cv_pi_tail(...) and around its .backward(), eager launches, "
+                        "averaged over 10 iterations after 20 warm-up iterations"}
+
+
+def kernel_rooflines(B, device):
+    """Live timings (events on the launch stream) of hand-written kernels AS THE fp32 STEP RUNS THEM: every kernel named here
+    is an instantiation that appears in the step's rocprofv3 table (profiles/r03_*_steady_kernel_stats.csv) on the same shapes.
+
+    * `roofline`: wreg_dgrad_kernel<64,128,false> — the dgrad of a 128->64 layer of the all-pixel cost volume on
+      [B*228*468] rows (mlp1[1] and mlp2[1] of cost_volume1: two launches per step, the largest per-step time of the
+      hand-written kernels).  Weights stationary in registers; it reads gz [rows,64], the layer's pre-BN output y [rows,64]
+      (BN backward of the layer behind formed on load) and the pre-BN input x [rows,128] (activation derivative +
+      BN-backward statistics in the store phase) and writes dL/dz_in [rows,128]: rows*(2*64+2*128)*4 B against
+      2*rows*128*64 flop => HBM-bound (164 us at 8 TB/s, 89 us at 157.3 TFLOP/s).
+      `traffic` = PMC bytes per launch from profiles/r03_pmc_traffic.json (tools/pmc_step.sh).
+      Timed as (dgrad + wgrad + reduction) - (wgrad + reduction): the C ABI has one backward entry; the rocprofv3
+      table under profiles/ has the kernel's own duration.
+    * other_kernels: the forward of the same layer (wreg_fwd_kernel<128,64,true,false>), its wgrad
+      (wreg_wgrad_kernel<64,128,true,false> + reduction), the two-source 64+64->128 forward
+      (wreg_fwd_kernel<128,128,true,true>), the factored first layer (wreg_pair_fwd_kernel<128,128>), level-1
+      fused_conv_select_k and the fused level-1 grouping on the three input densities.
+    * chain: the whole cost_volume1 pi-stage node against SURVEY.md 8(d)'s per-sample bytes / flops (chain_roofline).
     """
     from i2pnet_amd import _lib, ops, projectpn as P, synth
     hip = ops.hip_backend()
-    N, M, C = 228, 468, 128
+    N, M = 228, 468
+    CI, CO = 128, 64
     rows = B * N * M
     g = torch.Generator(device=device).manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g, device=device)
-    x = rnd(rows, C); w = rnd(C, C) / C ** 0.5
-    gam = torch.ones(C, device=device); bet = torch.zeros(C, device=device)
+    x = rnd(rows, CI); w = rnd(CO, CI) / CI ** 0.5
+    gam_i = torch.ones(CI, device=device); bet_i = torch.zeros(CI, device=device)
+    gam_o = torch.ones(CO, device=device); bet_o = torch.zeros(CO, device=device)
     sx = hip.bn_stats(x)
-    in_coef, in_mi = hip.bn_finalize(rows, sx, gam, bet, 1e-5)
-    y = torch.empty(rows, C, device=device)
-    sy = torch.zeros(ops.BN_REPLICAS * 2 * C, dtype=torch.float64, device=device)
+    in_coef, in_mi = hip.bn_finalize(rows, sx, gam_i, bet_i, 1e-5)
+    y = torch.empty(rows, CO, device=device)
+    sy = torch.zeros(ops.BN_REPLICAS * 2 * CO, dtype=torch.float64, device=device)
     st = torch.cuda.current_stream().cuda_stream
-    scale = rows / (8 * N * M)                                   # PMC passes were taken at B=8
-    kib = 1024.0
+    fwd_call = lambda: _lib.call("i2p_lin_fwd", rows, CI, CO, x.data_ptr(), in_coef.data_ptr(), 0.1, w.data_ptr(),
+                                 y.data_ptr(), sy.data_ptr(), stream=st)
     # --- forward: exactly one launch per call, buffers preallocated -------------------------------------------
-    _event_time_us(lambda: _lib.call("i2p_lin_fwd", rows, C, C, x.data_ptr(), in_coef.data_ptr(), 0.1, w.data_ptr(),
-                                     y.data_ptr(), sy.data_ptr(), stream=st), 150)     # (clocks ramp for ~50 ms after idle)
-    t_fwd = _event_time_us(lambda: _lib.call("i2p_lin_fwd", rows, C, C, x.data_ptr(), in_coef.data_ptr(), 0.1, w.data_ptr(),
-                                             y.data_ptr(), sy.data_ptr(), stream=st), 25)
-    flop_fwd = 2.0 * rows * C * C
-    fwd_bytes = rows * C * 4 * 2 + C * C * 4
-    fwd = {"kernel": "wreg_fwd_kernel<128,128,true> (cost-volume 128->128 layer forward: weights stationary in registers, BN+act "
-                     "between the MFMAs, fp64-reduced BN statistics)",
-           "bound": "mfma", "achieved": round(flop_fwd / t_fwd / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": round(flop_fwd / t_fwd / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "avg_kernel_us": round(t_fwd, 1),
-           "traffic": round((2 * 218199.0 + 465095.8) * kib * scale), "hbm_bytes_per_launch_algorithmic": fwd_bytes,
-           "hbm_GBps_algorithmic": round(fwd_bytes / t_fwd / 1e3, 1),
-           "note": "back-to-back 16x16x4 fp32 MFMAs from one wave per SIMD alone take 228 us on this shape (123 TFLOP/s); the "
-                   "chip runs this kernel at its 1400 W cap"}
+    _event_time_us(fwd_call, 150)                                  # (clocks ramp for ~50 ms after idle)
+    t_fwd = _event_time_us(fwd_call, 25)
+    flop = 2.0 * rows * CI * CO
+    fwd_bytes = rows * (CI + CO) * 4 + CI * CO * 4
+    fwd = {"kernel": "wreg_fwd_kernel<128,64,true,false> (cost-volume 128->64 layer forward, 2 launches per step: weights stationary in "
+                     "registers, BN+act of the layer in front between the MFMAs, fp64-reduced BN statistics)",
+           "bound": "hbm", "achieved": round(fwd_bytes / t_fwd / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(fwd_bytes / t_fwd / 1e3 / HBM_PEAK_GBS, 4), "avg_kernel_us": round(t_fwd, 1),
+           "traffic": _pmc_traffic("wreg_fwd_kernel<128, 64, true, false>", B), "bytes_per_launch_algorithmic": fwd_bytes,
+           "mfma_TFLOPs": round(flop / t_fwd / 1e6, 1), "mfma_frac": round(flop / t_fwd / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)}
     sy.zero_()
-    _lib.call("i2p_lin_fwd", rows, C, C, x.data_ptr(), in_coef.data_ptr(), 0.1, w.data_ptr(), y.data_ptr(), sy.data_ptr(),
-              stream=st)
-    out_coef, out_mi = hip.bn_finalize(rows, sy, gam, bet, 1e-5)
-    gz = rnd(rows, C)
-    ods = torch.zeros(ops.BN_REPLICAS * 2 * C, dtype=torch.float64, device=device)
+    fwd_call()
+    out_coef, out_mi = hip.bn_finalize(rows, sy, gam_o, bet_o, 1e-5)
+    gz = rnd(rows, CO)
+    ods = torch.zeros(ops.BN_REPLICAS * 2 * CO, dtype=torch.float64, device=device)
     t_bwd = _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), 20)
     t_wg = _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w, need_gx=False), 20)
     t_dg = t_bwd - t_wg
-    dg_bytes = rows * C * 4 * 4 + C * C * 4
-    dg_flop = 2.0 * rows * C * C
-    dgrad = {"kernel": "wreg_dgrad_kernel<128,128> (cost-volume 128->128 layer dgrad: weights stationary in registers, BN backward of the "
-                       "layer behind formed between the MFMAs, activation derivative + BN-backward statistics in the store phase)",
+    dg_bytes = rows * (2 * CO + 2 * CI) * 4 + CI * CO * 4
+    dgrad = {"kernel": "wreg_dgrad_kernel<64,128,false> (cost-volume 128->64 layer dgrad, 2 launches per step: weights stationary in registers, "
+                       "BN backward of the layer behind formed between the MFMAs, activation derivative + BN-backward statistics in the store phase)",
              "bound": "hbm", "achieved": round(dg_bytes / t_dg / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(dg_bytes / t_dg / 1e3 / HBM_PEAK_GBS, 4), "traffic": round((2 * 642460.6 + 453703.1) * kib * scale),
+             "frac": round(dg_bytes / t_dg / 1e3 / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("wreg_dgrad_kernel<64, 128, false>", B),
              "avg_kernel_us": round(t_dg, 1), "bytes_per_launch_algorithmic": dg_bytes,
-             "mfma_TFLOPs": round(dg_flop / t_dg / 1e6, 1), "mfma_frac": round(dg_flop / t_dg / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
+             "mfma_TFLOPs": round(flop / t_dg / 1e6, 1), "mfma_frac": round(flop / t_dg / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
              "timed_as": "lin_bwd (dgrad + wgrad + reduction) minus lin_bwd without dgrad, events on the launch stream"}
-    wg_bytes = rows * C * 4 * 3
-    wg = {"kernel": "wreg_wgrad_kernel<128,128> + reduce_partials (wgrad of the same layer: the 128x128 accumulators stationary in registers, gz / y / x rows as MFMA operands straight from global memory)", "bound": "mfma",
-          "achieved": round(dg_flop / t_wg / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-          "frac": round(dg_flop / t_wg / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "avg_us": round(t_wg, 1),
-          "hbm_GBps_algorithmic": round(wg_bytes / t_wg / 1e3, 1)}
-    bwd = wg
+    wg_bytes = rows * (2 * CO + CI) * 4
+    wg = {"kernel": "wreg_wgrad_kernel<64,128,true,false> + reduce_partials (wgrad of the same layer: the 64x128 accumulators stationary in "
+                    "registers, gz / y / x rows as MFMA operands straight from global memory)", "bound": "hbm",
+          "achieved": round(wg_bytes / t_wg / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": round(wg_bytes / t_wg / 1e3 / HBM_PEAK_GBS, 4), "avg_us": round(t_wg, 1),
+          "traffic": _pmc_traffic("wreg_wgrad_kernel<64, 128, true, false>", B), "bytes_per_launch_algorithmic": wg_bytes,
+          "mfma_TFLOPs": round(flop / t_wg / 1e6, 1), "mfma_frac": round(flop / t_wg / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)}
     del x, y, gz
+    # --- two-source forward (position encoding 64 + mlp1 output 64 -> 128), 1 launch per step ------------------------
+    C2 = 64
+    xa, xb = rnd(rows, C2), rnd(rows, C2)
+    g2 = torch.ones(C2, device=device); b2 = torch.zeros(C2, device=device)
+    ca, _ = hip.bn_finalize(rows, hip.bn_stats(xa), g2, b2, 1e-5)
+    cb, _ = hip.bn_finalize(rows, hip.bn_stats(xb), g2, b2, 1e-5)
+    w2 = rnd(128, 2 * C2) / (2 * C2) ** 0.5
+    t_2s = _event_time_us(lambda: hip.lin_forward_2src(xa, ca, 0.1, xb, cb, 0.1, w2), 20)
+    flop2 = 2.0 * rows * 128 * 128
+    b2s = rows * (2 * C2 + 128) * 4
+    two = {"kernel": "wreg_fwd_kernel<128,128,true,true> (64+64->128 two-source layer forward, no concatenation; 1 launch per step)",
+           "bound": "mfma", "achieved": round(flop2 / t_2s / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(flop2 / t_2s / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "avg_kernel_us": round(t_2s, 1),
+           "traffic": _pmc_traffic("wreg_fwd_kernel<128, 128, true, true>", B), "bytes_per_launch_algorithmic": b2s,
+           "hbm_GBps_algorithmic": round(b2s / t_2s / 1e3, 1)}
+    del xa, xb
     # --- pair-mode forward (first cost-volume layer) -----------------------------------------------------
+    C = 128
+    w = rnd(C, C) / C ** 0.5
     f = rnd(B, N, C); gk = rnd(B, M, C); bn = rnd(B, N, C); bk = rnd(B, M, C)
     t_pf = _event_time_us(lambda: hip.pair_lin_forward(f, gk, bn, bk, w), 10)
     flop_pf = 2.0 * rows * C * C
     pf = {"kernel": "wreg_pair_fwd_kernel<128,128> (first cost-volume layer forward: product formed from lane-private / wave-shared LDS rows, only y touches HBM)", "bound": "mfma",
           "achieved": round(flop_pf / t_pf / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
           "frac": round(flop_pf / t_pf / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "avg_kernel_us": round(t_pf, 1),
-          "hbm_GBps_on_output": round(rows * C * 4 / t_pf / 1e3, 1)}
+          "traffic": _pmc_traffic("wreg_pair_fwd_kernel<128, 128>", B), "hbm_GBps_on_output": round(rows * C * 4 / t_pf / 1e3, 1)}
     # --- level-1 neighbour selection -----------------------------------------------------------------------
     raw = synth.lidar_scan(B, 8192, torch.Generator(device=device).manual_seed(0), device, layout="centre")
     img, _, _ = hip.project_seq(raw, [], 64, 1800, 2.0, -24.8)
@@ -166,7 +285,10 @@ def kernel_rooflines(B, device):
     group = {"kernel": "sa_l1_kernel<9> (level-1 selection + gather + feature build in one launch; unfused = fused_conv_select_k + 2 row "
                        "gathers + subtract + norm + cat, host-timed eager launches)", "bound": "hbm (in practice L2 / LDS / issue)",
              "bytes_per_launch": B * (2 * 64 * 1800 * 12 + 3600 * 32 * 48), "cases": grp}
-    dgrad["other_kernels"] = [fwd, bwd, pf, selk, group]
+    dgrad["other_kernels"] = [fwd, wg, two, pf, selk, group]
+    del f, gk, bn, bk
+    torch.cuda.empty_cache()
+    dgrad["chain"] = chain_roofline(B, device)
     return dgrad
 
 
@@ -387,12 +509,15 @@ def main():
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--layout", default="scan", choices=["scan", "centre"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-configs", type=int, default=1,
+                    help="after the default (--config 1) line also measure configs[2] and configs[4] in the same process and report "
+                         "them under `other_configs` (1 = at N=1 only, 2 = at any N, 0 = never)")
     ap.add_argument("--graph", type=int, default=1, help="capture the step in hipGraphs (0 = eager)")
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
-    dflt = {1: (8, 8192), 2: (16, 8192), 4: (8, 16384)}[args.config]
+    dflt = _CONFIG_DEFAULTS[args.config]
     args.batch = dflt[0] if args.batch is None else args.batch
     args.points = dflt[1] if args.points is None else args.points
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -400,15 +525,12 @@ def main():
     if args.selftest_cpu:
         return _selftest_cpu(args)
 
-    from i2pnet_amd import ops, synth
-    from i2pnet_amd.config import I2PNetConfig, I2PNetConfigNuScenes
-    from i2pnet_amd.train import Trainer, init_distributed
-    cfg = I2PNetConfigNuScenes if args.config == 4 else I2PNetConfig
-    bf16 = args.config in (2, 4)
-    if bf16:
-        ops.set_precision("bf16")           # bf16 storage of the fused chains' activations / gradients (configs[2], [4])
+    from i2pnet_amd import ops
+    from i2pnet_amd.train import dist_env, init_distributed
 
     torch.backends.cudnn.benchmark = True   # MIOpen exhaustive find for the 15 image-encoder convolutions (in the warm-up steps)
+    _, lr0, w0 = dist_env()
+    pinned = _pin_cores(lr0, w0)            # before any helper thread exists (RCCL watchdog / proxy, MIOpen find, OpenMP pool inherit it)
     rank, local_rank, world = init_distributed("nccl")
     if world != args.gpus:
         print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr, flush=True)
@@ -419,57 +541,37 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    use_graph = bool(args.graph)       # N>1: graph A (fwd+bwd) -> eager RCCL all-reduce of the flat gradient -> graph B (clip+Adam)
-    tr = Trainer(cfg=cfg, device=device, world_size=world, local_rank=local_rank, capturable=use_graph)
-    batch = synth.make_batch(args.batch, args.points, 375, 1242, seed=1000 + rank, device=device, layout=args.layout,
-                             beams=32 if args.config == 4 else 64, fup=cfg.fup, fdown=cfg.fdown)
-    graph_live = tr.capture(batch) if use_graph else False
-    if use_graph and not graph_live:       # an eager step is 3-4x slower: never report it as the captured number
-        print("bench.py: hipGraph capture failed (see the message above); run with --graph 0 for an eager measurement",
-              file=sys.stderr, flush=True)
-        sys.exit(3)
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        tr.step(batch)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _, _ = tr.step(batch)
-    sync()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    assert torch.isfinite(loss).all()
-
+    res = _run_workload(args.config, args, rank, local_rank, world, device)
+    line = None
     if rank == 0:
-        global_batch = args.batch * world
-        line = {
-            "metric": "train samples/sec (img+8192-pt pair)", "value": round(global_batch * args.steps / dt, 3),
-            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": {1: "configs[1]: synthetic KITTI-shaped batch, 375x1242 RGB + %d-pt cloud (%s layout), "
-                                       "fp32 forward+loss+backward+clip+Adam",
-                                    2: "configs[2]: synthetic KITTI-shaped batch, 375x1242 RGB + %d-pt cloud (%s layout), bf16 storage of "
-                                       "the fused chains' activations/gradients + bf16 MFMA point-MLP (fp32 accumulate, parameters, "
-                                       "image encoder), forward+loss+backward+clip+Adam",
-                                    4: "configs[4]: synthetic nuScenes-shaped batch (21x1800 range image), 375x1242 RGB + %d-pt cloud "
-                                       "(%s layout), bf16 storage + bf16 MFMA point-MLP, forward+loss+backward+clip+Adam"}[args.config]
-                                   % (args.points, args.layout),
-                       "per_gpu_batch": args.batch, "global_batch": global_batch,
-                       "parallelism": f"dp{world}", "hipgraph": graph_live, "final_loss": round(float(loss), 4)},
-            "roofline": (kernel_rooflines_bf16 if bf16 else kernel_rooflines)(args.batch, device),
-        }
+        bf16 = args.config in (2, 4)
+        line = _json_line(res, args, world)
+        line["config"]["rccl_ranks"] = dist.get_world_size() if dist.is_initialized() else 1
+        line["config"]["host_cores_per_rank"] = pinned
+        prev = ops.set_precision("bf16" if bf16 else "fp32")
+        line["roofline"] = (kernel_rooflines_bf16 if bf16 else kernel_rooflines)(args.batch, device)
+        ops.set_precision(prev)
+    # the bf16 workloads (configs[2], configs[4]) in the same process after the default line, so that the driver's record
+    # carries them too (N = 1 only: the scaling runs stay short)
+    others = []
+    if args.config == 1 and args.other_configs and (world == 1 or args.other_configs > 1):
+        for c in (2, 4):
+            a2 = argparse.Namespace(**vars(args))
+            a2.config, a2.batch, a2.points = c, *_CONFIG_DEFAULTS[c]
+            r2 = _run_workload(c, a2, rank, local_rank, world, device)
+            if rank == 0:
+                l2 = _json_line(r2, a2, world)
+                prev = ops.set_precision("bf16")
+                l2["roofline"] = kernel_rooflines_bf16(a2.batch, device)
+                ops.set_precision(prev)
+                others.append(l2)
+    if rank == 0:
+        if others:
+            line["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
+            from i2pnet_amd.config import I2PNetConfig, I2PNetConfigNuScenes
             prev = ops.set_precision("fp32")
-            line["cpu_baseline"] = cpu_baseline(cfg)
+            line["cpu_baseline"] = cpu_baseline(I2PNetConfigNuScenes if args.config == 4 else I2PNetConfig)
             ops.set_precision(prev)
     if dist.is_available() and dist.is_initialized():        # also the forced 1-rank group of tools/ddp_smoke.sh
         dist.barrier()
@@ -483,6 +585,118 @@ def main():
         except OSError:
             pass
         print(json.dumps(line), flush=True)
+
+
+_CONFIG_DEFAULTS = {1: (8, 8192), 2: (16, 8192), 4: (8, 16384)}
+
+
+def _pin_cores(local_rank, world):
+    """One contiguous group of host cores per rank: the rank's launch thread, the RCCL proxy / watchdog
+    threads and MIOpen's find threads stay off the other ranks' cores.  Groups are cut from the cores this process may
+    run on (cgroup-aware); with one rank nothing is changed.  Returns the number of cores of the group (None = not pinned)."""
+    if world <= 1 or os.environ.get("I2P_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // world
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(per, 8)))
+        return per
+    except OSError:
+        return None
+
+
+def _run_workload(config, args, rank, local_rank, world, device):
+    """W warm-up steps, then K timed steps (barrier + synchronize on both sides, MAX over ranks) of BASELINE configs[config]."""
+    from i2pnet_amd import ops, synth
+    from i2pnet_amd.config import I2PNetConfig, I2PNetConfigNuScenes
+    from i2pnet_amd.train import Trainer
+    cfg = I2PNetConfigNuScenes if config == 4 else I2PNetConfig
+    bf16 = config in (2, 4)
+    prev_prec = ops.set_precision("bf16" if bf16 else "fp32")   # bf16 storage of the fused chains' activations / gradients (configs[2], [4])
+    try:
+        use_graph = bool(args.graph)       # N>1: graph A (fwd+bwd) -> eager RCCL all-reduce of the flat gradient -> graph B (clip+Adam)
+        if world > 1:
+            # MIOpen's exhaustive find runs inside the warm-up steps of capture(): let rank 0 search first and fill the
+            # user find-db, the other ranks then read its records instead of 8 processes benchmarking concurrently on one host
+            _find_db_warmup(cfg, args, config, rank, device)
+        tr = Trainer(cfg=cfg, device=device, world_size=world, local_rank=local_rank, capturable=use_graph)
+        batch = synth.make_batch(args.batch, args.points, 375, 1242, seed=1000 + rank, device=device, layout=args.layout,
+                                 beams=32 if config == 4 else 64, fup=cfg.fup, fdown=cfg.fdown)
+        graph_live = tr.capture(batch) if use_graph else False
+        if use_graph and not graph_live:       # an eager step is 3-4x slower: never report it as the captured number
+            print("bench.py: hipGraph capture failed (see the message above); run with --graph 0 for an eager measurement",
+                  file=sys.stderr, flush=True)
+            sys.exit(3)
+
+        def sync():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            tr.step(batch)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss, _, _ = tr.step(batch)
+        sync()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        assert torch.isfinite(loss).all()
+        out = {"dt": dt, "loss": float(loss), "graph_live": graph_live}
+        del tr, batch
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        return out
+    finally:
+        ops.set_precision(prev_prec)
+
+
+def _find_db_warmup(cfg, args, config, rank, device):
+    """rank 0 runs one eager forward+backward of the image encoder's shapes (MIOpen exhaustive find -> user find-db on
+    disk), the others wait at a barrier and then find the records.  Skipped when I2P_NO_FINDDB_WARMUP=1."""
+    if os.environ.get("I2P_NO_FINDDB_WARMUP") == "1":
+        return
+    if rank == 0:
+        from i2pnet_amd.model import RegNet_v2
+        net = RegNet_v2(cfg=cfg).to(device).train()
+        rgb = torch.rand(args.batch, 3, 375, 1242, device=device) * 255.0
+        x = net.RGB_net3(net.RGB_net2(net.RGB_net1(rgb.contiguous(memory_format=torch.channels_last))))
+        x.sum().backward()
+        torch.cuda.synchronize()
+        del net, rgb, x
+        torch.cuda.empty_cache()
+    dist.barrier()
+
+
+def _json_line(res, args, world):
+    bf16 = args.config in (2, 4)
+    global_batch = args.batch * world
+    dt = res["dt"]
+    return {
+        "metric": "train samples/sec (img+8192-pt pair)", "value": round(global_batch * args.steps / dt, 3),
+        "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+        "config": {"workload": {1: "configs[1]: synthetic KITTI-shaped batch, 375x1242 RGB + %d-pt cloud (%s layout), "
+                                   "fp32 forward+loss+backward+clip+Adam",
+                                2: "configs[2]: synthetic KITTI-shaped batch, 375x1242 RGB + %d-pt cloud (%s layout), bf16 storage of "
+                                   "the fused chains' activations/gradients + bf16 MFMA point-MLP (fp32 accumulate, parameters, "
+                                   "image encoder), forward+loss+backward+clip+Adam",
+                                4: "configs[4]: synthetic nuScenes-shaped batch (21x1800 range image), 375x1242 RGB + %d-pt cloud "
+                                   "(%s layout), bf16 storage + bf16 MFMA point-MLP, forward+loss+backward+clip+Adam"}[args.config]
+                               % (args.points, args.layout),
+                   "per_gpu_batch": args.batch, "global_batch": global_batch,
+                   "parallelism": f"dp{world}", "hipgraph": res["graph_live"], "final_loss": round(res["loss"], 4)},
+    }
 
 
 if __name__ == "__main__":

@@ -135,6 +135,24 @@ def _grad_norm_check(gold, model, grad_tol, rgb_tol):
     return worst, worst_key, checked
 
 
+_FLOORS = {}
+
+
+def _pgrad_floors():
+    """per fully-stored parameter gradient: max |reference fp32 - fp64| / abs-max over the sized fixtures — how far the
+    reference's own fp32 arithmetic lands from the exact gradient of that tensor (the fixtures carry both, `pgrad.*` from
+    the imported reference, `pgrad64.*` from the fp64 evaluation; tools/gen_golden.py sized)"""
+    if not _FLOORS:
+        for tag in ("kitti_b8", "kitti_b16"):
+            g = np.load(GOLD / f"model_{tag}.npz")
+            for f in g.files:
+                if f.startswith("pgrad64."):
+                    k = f[8:]
+                    a, b = g["pgrad." + k].astype(np.float64), g[f]
+                    _FLOORS[k] = max(_FLOORS.get(k, 0.0), float(np.abs(a - b).max() / np.abs(b).max()))
+    return _FLOORS
+
+
 def _check_fp32(gold, model, acts, out3, out4, loss, tol, grad_tol, grad_tensor_tol, rgb_tol):
     bad = {}
     for k, v in (("out3", _rel(out3.detach().cpu(), gold["out3"])), ("out4", _rel(out4.detach().cpu(), gold["out4"])),
@@ -155,11 +173,14 @@ def _check_fp32(gold, model, acts, out3, out4, loss, tol, grad_tol, grad_tensor_
         if not (rmax <= grad_tensor_tol + 2 * fl_max and rl2 <= grad_tensor_tol + 2 * fl_l2):
             bad[key] = (rmax, rl2, fl_max, fl_l2)
     params = dict(model.named_parameters())
+    floors = _pgrad_floors()
     for k in [f[6:] for f in gold.files if f.startswith("pgrad.")]:
-        lim = max(5e-3, grad_tensor_tol) if k.startswith("LiDAR_lv1") else grad_tensor_tol     # |ref32 - fp64| = 1.7e-3 at level 1
+        # element-wise, relative to the tensor's abs-max; the reference's own fp32 gradient of these tensors sits up to 2.8e-3
+        # (cost_volume1.mlp2_convs.1, batch 8) / 1.5e-3 (level 1) away from its fp64 value: allow twice that floor on top
+        lim = grad_tensor_tol + 2.0 * floors.get(k, 0.0)
         r = _rel(params[k].grad.cpu(), gold["pgrad." + k])
         if not r <= lim:
-            bad["pgrad." + k] = r
+            bad["pgrad." + k] = (r, lim, _rel(params[k].grad.cpu(), gold["pgrad64." + k]) if "pgrad64." + k in gold.files else None)
     state = model.state_dict()
     for k, s, a in zip(gold["buf_keys"].tolist(), gold["buf_sum"].tolist(), gold["buf_abs_sum"].tolist()):
         v = state[k].double()

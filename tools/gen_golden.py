@@ -202,8 +202,9 @@ def run_sized(cfg_name, tag, B, N, img_h, img_w, seed, beams):
     for k, p in model.named_parameters():
         keys.append(k); gn.append(0.0 if p.grad is None else float(p.grad.double().norm()))
     data["grad_keys"] = np.array(keys); data["grad_norm"] = np.array(gn)
-    for k in ["cost_volume1.mlp1_convs.0.conv.weight", "cost_volume1.mlp2_convs.1.conv.weight",
-              "cost_volume2.mlp2_convs_2.1.conv.weight", "LiDAR_lv1.mlp_convs.0.conv.weight"]:
+    full = ["cost_volume1.mlp1_convs.0.conv.weight", "cost_volume1.mlp2_convs.1.conv.weight",
+            "cost_volume2.mlp2_convs_2.1.conv.weight", "LiDAR_lv1.mlp_convs.0.conv.weight"]
+    for k in full:
         data["pgrad." + k] = dict(model.named_parameters())[k].grad.numpy()
     bk, bs, ba = [], [], []
     for k, v in model.state_dict().items():
@@ -212,9 +213,12 @@ def run_sized(cfg_name, tag, B, N, img_h, img_w, seed, beams):
     data["buf_keys"] = np.array(bk); data["buf_sum"] = np.array(bs); data["buf_abs_sum"] = np.array(ba)
     del captured, out3, out4, loss, model
     dig64 = {}
-    g64 = fp64_gradients(cfg_name, shapes, seed, batch, train=True, actgrad_digests=dig64)
+    pg64 = {k: None for k in full}
+    g64 = fp64_gradients(cfg_name, shapes, seed, batch, train=True, actgrad_digests=dig64, pgrad_full=pg64)
     for name, (st, rows) in dig64.items():             # fp64 evaluation of the same rows: |ref32 - fp64| is the floor
         data["actgrad." + name + ".stats64"], data["actgrad." + name + ".rows64"] = st, rows
+    for k, v in pg64.items():                          # the whole fp64 gradient of the fully stored tensors: the element-wise floor
+        data["pgrad64." + k] = v
     data["grad_norm64"] = np.array([g64.get(k, 0.0) for k in keys])
     data["state_keys"] = np.array([k for k, _ in shapes])
     data["state_shapes"] = np.array([",".join(map(str, s)) for _, s in shapes])
@@ -320,9 +324,10 @@ def run_small_range():
     print("small_range eval out3", o3.numpy().round(4).tolist(), "loss", loss.item())
 
 
-def fp64_gradients(cfg_name, shapes, seed, batch, train=False, actgrad_digests=None):
+def fp64_gradients(cfg_name, shapes, seed, batch, train=False, actgrad_digests=None, pgrad_full=None):
     """-> {parameter: fp64 gradient norm}; `actgrad_digests` (a dict) additionally receives, per HOOKED module, the fp64
-    activation-gradient digest rows (`tensor_digest`) — the noise floor of the reference's fp32 activation gradients"""
+    activation-gradient digest rows (`tensor_digest`) — the noise floor of the reference's fp32 activation gradients;
+    `pgrad_full` (a dict whose keys name parameters) receives those parameters' whole fp64 gradients"""
     from i2pnet_amd import model as my_model, modules as my_modules, ops, projectpn as P
     from i2pnet_amd.config import CONFIGS
     from i2pnet_amd.loss import Get_loss as my_loss
@@ -405,6 +410,10 @@ def fp64_gradients(cfg_name, shapes, seed, batch, train=False, actgrad_digests=N
         for name, t in cap.items():
             if t.grad is not None:
                 actgrad_digests[name] = tensor_digest(t.grad, name)
+        if pgrad_full is not None:
+            named = dict(m.named_parameters())
+            for k in list(pgrad_full):
+                pgrad_full[k] = named[k].grad.detach().clone().numpy()
         return {k: float(p.grad.norm()) for k, p in m.named_parameters() if p.grad is not None}
     finally:
         (P.gather_torch, P._get_neighbor, P.index_points_group, P.project_seq, P.knn_point, torch.Tensor.float) = saved
