@@ -82,6 +82,7 @@ DEVICE_ONLY = {
     "i2p_lin_fwd_fin": ["l", "i", "i", "p", "p", "f", "p", "p", "p", "p", "p", "f", "p", "p", "p"],
     "i2p_lin_fwd_2src_fin": ["l", "i", "i", "i", "p", "p", "f", "p", "p", "f", "p", "p", "p", "p", "p", "f", "p", "p", "p"],
     "i2p_pair_lin_fwd_fin": ["i"] * 5 + ["p"] * 7 + ["p", "p", "f", "p", "p", "p"],
+    "i2p_clip_adam": ["l"] + ["p"] * 8 + ["f"] * 6 + ["p"],
 }
 # plain `int f(...)` helpers without a stream argument
 HELPERS = {

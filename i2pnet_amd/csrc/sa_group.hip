@@ -19,19 +19,32 @@ namespace {
 constexpr int GROUP = 16, QPB = 16;
 constexpr unsigned SENT_BITS = 0x501502F9u, PAD_BITS = 0x7FFFFFFFu;
 constexpr unsigned CODE_STORED = 0x100u, CODE_VALID = 0x200u;
+constexpr int STAGE_IT = 4;               // 16-byte staging loads per thread and image, all in flight before the first LDS store
 
 struct SaParams {
     int B, H, W, out_h, out_w, stride_h, stride_w, kH, kW, K;
     float dist2;
     const float *sel_xyz, *raw_xyz;       // [B,H,W,3]: selection coordinates (centres + candidates), raw coordinates (features)
     float *feat;                          // [B, out_h*out_w, K, 12]
-    int sw;                               // strip width = kW + 15*stride_w
+    int sw;                               // strip width in cells = kW + 15*stride_w
+    int pad_l;                            // cells staged to the left of the first window column (16-byte alignment of the strip rows)
+    int swf;                              // strip row pitch in floats
     int force_serial;
 };
 
-template <int SLOTS>
+// LDS accesses of one 16-lane query row are private to its wave: ordering them needs the compiler to keep program order
+// (the hardware executes a wave's LDS operations in order), not a block barrier.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// VEC: the strip rows start on a 16-byte boundary of the image row and are whole float4s (launcher checks), so a block stages
+// 2 x kH x swf/4 aligned 16-byte loads — all issued before the first LDS store: one global round trip per block instead of five.
+template <int SLOTS, bool VEC>
 __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
-    extern __shared__ float strip[];                       // sel [kH][sw][3] then raw [kH][sw][3]
+    extern __shared__ float strip[];                       // sel [kH][swf] then raw [kH][swf]
     __shared__ int tab[SLOTS * GROUP];
     __shared__ unsigned long long lst[QPB][SLOTS * GROUP];
     __shared__ unsigned short outc[QPB][I2P_MAX_WINDOW + 2];
@@ -45,45 +58,76 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
     const int qw = wb * QPB + g;
     const bool in_range = qw < p.out_w;
     const int ch = qh * p.stride_h, cw0 = wb * QPB * p.stride_w;
-    const int h_lo = ch - p.kH / 2, w_lo = cw0 - p.kW / 2;
-    float *ssel = strip, *sraw = strip + p.kH * p.sw * 3;
+    const int h_lo = ch - p.kH / 2, w_lo = cw0 - p.kW / 2 - p.pad_l;          // image cell of strip cell (0, 0)
+    float *ssel = strip, *sraw = strip + p.kH * p.swf;
+    const size_t img = (size_t)b * p.H * p.W * 3;
 
     // ---- stage the strip of both images (zeros outside the image rows; columns wrap: FLAG_SHIFT) ----------------
-    const int ncell = p.kH * p.sw;
-    for (int i = tid; i < ncell; i += 256) {
-        const int r = i / p.sw, cidx = i - r * p.sw;
-        const int h = h_lo + r;
-        int w = w_lo + cidx;
-        if (w < 0) w += p.W;
-        if (w >= p.W) w -= p.W;
-        float sx = 0.f, sy = 0.f, sz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f;
-        if (h >= 0 && h < p.H && w >= 0 && w < p.W) {
-            const size_t o = (((size_t)b * p.H + h) * p.W + w) * 3;
-            sx = p.sel_xyz[o]; sy = p.sel_xyz[o + 1]; sz = p.sel_xyz[o + 2];
-            rx = p.raw_xyz[o]; ry = p.raw_xyz[o + 1]; rz = p.raw_xyz[o + 2];
+    if (VEC) {
+        const int n4row = p.swf >> 2, n4 = p.kH * n4row, w3 = p.W * 3;
+        float4 va[STAGE_IT], vb[STAGE_IT];
+#pragma unroll
+        for (int it = 0; it < STAGE_IT; ++it) {
+            const int i = tid + it * 256;
+            va[it] = make_float4(0.f, 0.f, 0.f, 0.f); vb[it] = va[it];
+            if (i < n4) {
+                const int r = i / n4row, j = i - r * n4row;
+                const int h = h_lo + r;
+                int fo = w_lo * 3 + 4 * j;                 // float offset inside the image row; wraps on a 16-byte boundary
+                if (fo < 0) fo += w3;
+                if (fo >= w3) fo -= w3;
+                if (h >= 0 && h < p.H) {
+                    const size_t o = img + (size_t)h * w3 + fo;
+                    va[it] = *reinterpret_cast<const float4 *>(p.sel_xyz + o);
+                    vb[it] = *reinterpret_cast<const float4 *>(p.raw_xyz + o);
+                }
+            }
         }
-        ssel[i * 3] = sx; ssel[i * 3 + 1] = sy; ssel[i * 3 + 2] = sz;
-        sraw[i * 3] = rx; sraw[i * 3 + 1] = ry; sraw[i * 3 + 2] = rz;
+#pragma unroll
+        for (int it = 0; it < STAGE_IT; ++it) {
+            const int i = tid + it * 256;
+            if (i < n4) {
+                reinterpret_cast<float4 *>(ssel)[i] = va[it];
+                reinterpret_cast<float4 *>(sraw)[i] = vb[it];
+            }
+        }
+    } else {
+        const int cells = p.swf / 3, ncell = p.kH * cells;
+        for (int i = tid; i < ncell; i += 256) {
+            const int r = i / cells, cidx = i - r * cells;
+            const int h = h_lo + r;
+            int w = w_lo + cidx;
+            if (w < 0) w += p.W;
+            if (w >= p.W) w -= p.W;
+            float sx = 0.f, sy = 0.f, sz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f;
+            if (h >= 0 && h < p.H && w >= 0 && w < p.W) {
+                const size_t o = img + ((size_t)h * p.W + w) * 3;
+                sx = p.sel_xyz[o]; sy = p.sel_xyz[o + 1]; sz = p.sel_xyz[o + 2];
+                rx = p.raw_xyz[o]; ry = p.raw_xyz[o + 1]; rz = p.raw_xyz[o + 2];
+            }
+            ssel[i * 3] = sx; ssel[i * 3 + 1] = sy; ssel[i * 3 + 2] = sz;
+            sraw[i * 3] = rx; sraw[i * 3 + 1] = ry; sraw[i * 3 + 2] = rz;
+        }
     }
     for (int i = tid; i < SLOTS * GROUP; i += 256) {
         int v = 0;
         if (i < kt) { const int dh = i / p.kW - p.kH / 2, dw = i % p.kW - p.kW / 2; v = (dh << 16) | (dw & 0xffff); }   // random_hw = arange (utils.py:84)
         tab[i] = v;
     }
-    for (int i = l16; i < p.K; i += GROUP) outc[g][i] = 0;
-    __syncthreads();
+    __syncthreads();                                       // the only block barrier: strip and table are block-shared
+    if (!__any(in_range ? 1 : 0)) return;                  // a wave of queries beyond out_w (last block of a row)
 
-    // centre of this query: strip cell (kH/2, kW/2 + g*stride_w)
-    const int ccol = p.kW / 2 + g * p.stride_w;
-    const int cc = (p.kH / 2) * p.sw + ccol;
-    const float cx = ssel[cc * 3], cy = ssel[cc * 3 + 1], cz = ssel[cc * 3 + 2];
+    // centre of this query: strip cell (kH/2, pad_l + kW/2 + g*stride_w)
+    const int ccol = p.pad_l + p.kW / 2 + g * p.stride_w;
+    const int cc = (p.kH / 2) * p.swf + ccol * 3;
+    const float cx = ssel[cc], cy = ssel[cc + 1], cz = ssel[cc + 2];
     const bool live = in_range && !(fmaxf(i2p_sq3(cx, cy, cz), 1e-10f) <= 1e-10f);          // go.cu:72-74
     // window cell (dh, dw) of this query -> strip cell; rows outside the image were staged as empty cells, which the
     // reference skips just like a zero point (go.cu:99-103 vs :143: both leave the slot unset)
     auto eval = [&](int tabv, unsigned &dbits, unsigned &stored) {
         dbits = SENT_BITS; stored = 0;
         const int r = p.kH / 2 + (tabv >> 16), cidx = ccol + (int)(short)(tabv & 0xffff);
-        const float *q = ssel + (r * p.sw + cidx) * 3;
+        const float *q = ssel + r * p.swf + cidx * 3;
         const float xq = q[0], yq = q[1], zq = q[2];
         if (i2p_sq3(xq, yq, zq) <= 1e-10f) return;                                            // go.cu:141-143
         const float dq = fmaxf(i2p_sq3(cx - xq, cy - yq, cz - zq), 1e-10f);                   // go.cu:154
@@ -91,91 +135,98 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
         dbits = i2p_f2u(dq); stored = 1;
     };
 
-    // ---- A/B: evaluate, sort own keys, park the runs (fcsk_kernel steps A-B) ---------------------------------
-    unsigned long long key[SLOTS];
+    // A wave whose four queries all have empty centres (93 % of the centres of a 8192-point scan) selects nothing: it goes
+    // straight to the output rows.  Everything below up to the output is private to the wave (lst[g], outc[g]).
+    if (__any(live ? 1 : 0)) {
+        for (int i = l16; i < p.K; i += GROUP) outc[g][i] = 0;
+        // ---- A/B: evaluate, sort own keys, park the runs (fcsk_kernel steps A-B) ---------------------------------
+        unsigned long long key[SLOTS];
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int pos = s * GROUP + l16;
-        unsigned dbits = PAD_BITS, stored = 0;
-        if (pos < kt) { dbits = SENT_BITS; if (live) eval(tab[pos], dbits, stored); }
-        key[s] = ((unsigned long long)dbits << 32) | (unsigned)(pos | (stored << 8));
-    }
-#pragma unroll
-    for (int i = 0; i < SLOTS - 1; ++i)
-#pragma unroll
-        for (int j = 0; j < SLOTS - 1 - i; ++j) {
-            const unsigned long long a = key[j], b2 = key[j + 1];
-            const bool sw_ = a > b2;
-            key[j] = sw_ ? b2 : a; key[j + 1] = sw_ ? a : b2;
+        for (int s = 0; s < SLOTS; ++s) {
+            const int pos = s * GROUP + l16;
+            unsigned dbits = PAD_BITS, stored = 0;
+            if (pos < kt) { dbits = SENT_BITS; if (live) eval(tab[pos], dbits, stored); }
+            key[s] = ((unsigned long long)dbits << 32) | (unsigned)(pos | (stored << 8));
         }
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) lst[g][s * GROUP + l16] = key[s];
-    __syncthreads();
+        for (int i = 0; i < SLOTS - 1; ++i)
+#pragma unroll
+            for (int j = 0; j < SLOTS - 1 - i; ++j) {
+                const unsigned long long a = key[j], b2 = key[j + 1];
+                const bool sw_ = a > b2;
+                key[j] = sw_ ? b2 : a; key[j + 1] = sw_ ? a : b2;
+            }
+#pragma unroll
+        for (int s = 1; s < SLOTS; ++s) lst[g][s * GROUP + l16] = key[s];
+        wave_lds_sync();
 
-    // ---- C: K extraction steps -------------------------------------------------------------------------------
-    unsigned head_hi = (unsigned)(key[0] >> 32), head_lo = (unsigned)key[0];
-    int ptr = 1;
-    unsigned pops = 0, steps = 0, prev = 0;
-    bool tie = false, done = !live;
-    for (int s = 0; s < p.K; ++s) {
-        const unsigned gmin = i2p_row16_min_u32(head_hi);
-        if (!done) {
-            if (gmin >= SENT_BITS) done = true;
-            else {
-                tie |= (s > 0 && gmin == prev);
-                prev = gmin; ++steps;
-                if (head_hi == gmin) {
-                    outc[g][s] = (unsigned short)(head_lo | CODE_VALID);
-                    ++pops;
-                    unsigned long long nx = ((unsigned long long)PAD_BITS << 32);
-                    if (ptr < SLOTS) nx = lst[g][ptr * GROUP + l16];
-                    ++ptr;
-                    head_hi = (unsigned)(nx >> 32); head_lo = (unsigned)nx;
+        // ---- C: K extraction steps (ends as soon as every query of the wave is done) ----------------------------
+        unsigned head_hi = (unsigned)(key[0] >> 32), head_lo = (unsigned)key[0];
+        int ptr = 1;
+        unsigned pops = 0, steps = 0, prev = 0;
+        bool tie = false, done = !live;
+        for (int s = 0; s < p.K; ++s) {
+            if (!__any(done ? 0 : 1)) break;
+            const unsigned gmin = i2p_row16_min_u32(head_hi);
+            if (!done) {
+                if (gmin >= SENT_BITS) done = true;
+                else {
+                    tie |= (s > 0 && gmin == prev);
+                    prev = gmin; ++steps;
+                    if (head_hi == gmin) {
+                        outc[g][s] = (unsigned short)(head_lo | CODE_VALID);
+                        ++pops;
+                        unsigned long long nx = ((unsigned long long)PAD_BITS << 32);
+                        if (ptr < SLOTS) nx = lst[g][ptr * GROUP + l16];
+                        ++ptr;
+                        head_hi = (unsigned)(nx >> 32); head_lo = (unsigned)nx;
+                    }
                 }
             }
         }
-    }
-    {
-        const unsigned gnext = i2p_row16_min_u32(head_hi);
-        const unsigned total = i2p_row16_add_u32(pops);
-        if (!done && steps > 0 && gnext == prev) tie = true;
-        if (total != steps) tie = true;
-    }
-    const bool need_serial = live && (tie || p.force_serial);
-    if (__syncthreads_or(need_serial ? 1 : 0)) {                       // ---- F: reference's serial order on ties
-        if (need_serial) {
+        {
+            const unsigned gnext = i2p_row16_min_u32(head_hi);
+            const unsigned total = i2p_row16_add_u32(pops);
+            if (!done && steps > 0 && gnext == prev) tie = true;
+            if (total != steps) tie = true;
+        }
+        const bool need_serial = live && (tie || p.force_serial);
+        if (__any(need_serial ? 1 : 0)) {                                  // ---- F: reference's serial order on ties
+            wave_lds_sync();
+            if (need_serial) {
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const int pos = s * GROUP + l16;
-                unsigned dbits = SENT_BITS, stored = 0;
-                if (pos < kt) eval(tab[pos], dbits, stored);
-                lst[g][pos] = ((unsigned long long)dbits << 32) | (unsigned)(pos | (stored << 8));
+                for (int s = 0; s < SLOTS; ++s) {
+                    const int pos = s * GROUP + l16;
+                    unsigned dbits = SENT_BITS, stored = 0;
+                    if (pos < kt) eval(tab[pos], dbits, stored);
+                    lst[g][pos] = ((unsigned long long)dbits << 32) | (unsigned)(pos | (stored << 8));
+                }
+            }
+            wave_lds_sync();
+            if (need_serial && l16 == 0) {
+                unsigned long long *a = lst[g];
+                for (int s = 0; s < p.K; ++s) {                                                    // go.cu:183-236
+                    int mi = s;
+                    if (s < kt) {
+                        float dm = i2p_u2f((unsigned)(a[s] >> 32));
+                        for (int t = s + 1; t < kt; ++t) {
+                            const float dt = i2p_u2f((unsigned)(a[t] >> 32));
+                            if (dt < dm) { dm = dt; mi = t; }
+                        }
+                        if (mi != s) { const unsigned long long tmp = a[mi]; a[mi] = a[s]; a[s] = tmp; }
+                        const float ds = i2p_u2f((unsigned)(a[s] >> 32));
+                        outc[g][s] = (unsigned short)(((unsigned)a[s] & 0x1ffu) | (ds < 1e10f ? CODE_VALID : 0u));
+                    } else outc[g][s] = 0;
+                }
             }
         }
-        __syncthreads();
-        if (need_serial && l16 == 0) {
-            unsigned long long *a = lst[g];
-            for (int s = 0; s < p.K; ++s) {                                                    // go.cu:183-236
-                int mi = s;
-                if (s < kt) {
-                    float dm = i2p_u2f((unsigned)(a[s] >> 32));
-                    for (int t = s + 1; t < kt; ++t) {
-                        const float dt = i2p_u2f((unsigned)(a[t] >> 32));
-                        if (dt < dm) { dm = dt; mi = t; }
-                    }
-                    if (mi != s) { const unsigned long long tmp = a[mi]; a[mi] = a[s]; a[s] = tmp; }
-                    const float ds = i2p_u2f((unsigned)(a[s] >> 32));
-                    outc[g][s] = (unsigned short)(((unsigned)a[s] & 0x1ffu) | (ds < 1e10f ? CODE_VALID : 0u));
-                } else outc[g][s] = 0;
-            }
-        }
+        wave_lds_sync();
     }
-    __syncthreads();
     if (!in_range) return;
 
     // ---- feature rows: [nbr_raw - centre_raw, centre, nbr_raw, |d|, 0, 0] ----------------------------------------
-    const float crx = sraw[cc * 3], cry = sraw[cc * 3 + 1], crz = sraw[cc * 3 + 2];
-    const float *cell00 = p.raw_xyz + (size_t)b * p.H * p.W * 3;       // what an unset slot gathers: cell (0,0)
+    const float crx = sraw[cc], cry = sraw[cc + 1], crz = sraw[cc + 2];
+    const float *cell00 = p.raw_xyz + img;                             // what an unset slot gathers: cell (0,0)
     const size_t obase = (((size_t)b * p.out_h + qh) * p.out_w + qw) * p.K;
     const unsigned copy_code = live ? outc[g][0] : 0u;
     for (int s = l16; s < p.K; s += GROUP) {
@@ -184,7 +235,7 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
         float nx, ny, nz;
         if (code & CODE_STORED) {
             const int tv = tab[code & 0xff];
-            const float *q = sraw + ((p.kH / 2 + (tv >> 16)) * p.sw + ccol + (int)(short)(tv & 0xffff)) * 3;
+            const float *q = sraw + (p.kH / 2 + (tv >> 16)) * p.swf + (ccol + (int)(short)(tv & 0xffff)) * 3;
             nx = q[0]; ny = q[1]; nz = q[2];
         } else { nx = cell00[0]; ny = cell00[1]; nz = cell00[2]; }
         const float dx = nx - crx, dy = ny - cry, dz = nz - crz;
@@ -194,18 +245,23 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
     }
 }
 
-template <int SLOTS>
+template <int SLOTS, bool VEC>
 int launch(const SaParams &p, hipStream_t st) {
-    const size_t bytes = (size_t)p.kH * p.sw * 3 * 2 * sizeof(float);
+    const size_t bytes = (size_t)p.kH * p.swf * 2 * sizeof(float);
     if (bytes > 96 * 1024) return I2P_ERR_BAD_ARG;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sa_l1_kernel<SLOTS>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sa_l1_kernel<SLOTS, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
     const unsigned grid = (unsigned)((long long)p.B * p.out_h * ((p.out_w + QPB - 1) / QPB));
-    hipLaunchKernelGGL(sa_l1_kernel<SLOTS>, dim3(grid), dim3(256), bytes, st, p);
+    hipLaunchKernelGGL((sa_l1_kernel<SLOTS, VEC>), dim3(grid), dim3(256), bytes, st, p);
     I2P_RETURN_LAUNCH_STATUS();
+}
+
+template <int SLOTS>
+int launch_any(const SaParams &p, bool vec, hipStream_t st) {
+    return vec ? launch<SLOTS, true>(p, st) : launch<SLOTS, false>(p, st);
 }
 
 }  // namespace
@@ -228,11 +284,20 @@ extern "C" int i2p_sa_l1_group(int B, int H, int W, int out_h, int out_w, int st
     p.sw = kW + (QPB - 1) * stride_w;
     p.force_serial = !(p.dist2 < 1e10f);
     if (p.sw > W) return I2P_ERR_BAD_ARG;                              // (a strip never wraps onto itself)
+    // 16-byte staging: every strip row must start on a 16-byte boundary of its image row and hold whole float4s, and the
+    // column wrap must fall between float4s: (kW/2 + pad_l) % 4 == 0, cells per row % 4 == 0, (16*stride_w) % 4 == 0, W % 4 == 0
+    const int pad_l = (4 - (kW / 2) % 4) % 4;
+    const int cells = (p.sw + pad_l + 3) / 4 * 4;
+    const bool vec = (W % 4 == 0) && ((QPB * stride_w) % 4 == 0) && cells <= W && kH * (cells * 3 / 4) <= 256 * STAGE_IT &&
+                     ((reinterpret_cast<uintptr_t>(sel_xyz) | reinterpret_cast<uintptr_t>(raw_xyz)) & 15) == 0 &&
+                     !getenv("I2P_SA_SCALAR_STAGE");
+    p.pad_l = vec ? pad_l : 0;
+    p.swf = (vec ? cells : p.sw) * 3;
     hipStream_t st = (hipStream_t)stream;
-    if (kt <= 16) return launch<1>(p, st);
-    if (kt <= 48) return launch<3>(p, st);
-    if (kt <= 144) return launch<9>(p, st);
-    return launch<10>(p, st);
+    if (kt <= 16) return launch_any<1>(p, vec, st);
+    if (kt <= 48) return launch_any<3>(p, vec, st);
+    if (kt <= 144) return launch_any<9>(p, vec, st);
+    return launch_any<10>(p, vec, st);
 }
 
 

@@ -29,6 +29,10 @@ from .loss import Get_loss
 from .model import RegNet_v2
 
 
+# global-norm clip + Adam as two HIP launches (csrc/optim.hip); I2P_NO_FUSED_ADAM=1: the elementwise torch formulation
+USE_FUSED_ADAM = os.environ.get("I2P_NO_FUSED_ADAM", "0") != "1"
+
+
 def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
@@ -65,6 +69,7 @@ class FlatAdam:
         # torch.optim.Adam skips such parameters entirely (no decay, no moments); with g*mask == 0 both moments stay
         # zero and the update is 0 / (0 + eps) = 0
         self.mask = None
+        self._partials = self._total = None
 
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_t, "lr": self.lr_t}
@@ -88,6 +93,21 @@ class FlatAdam:
         bc2_sqrt = (1.0 - torch.pow(self.beta2, self.step_t)).sqrt()
         denom = (self.exp_avg_sq.sqrt() / bc2_sqrt).add_(self.eps)
         self.param.sub_(self.exp_avg / denom * (self.lr_t / bc1))
+
+    @torch.no_grad()
+    def fused_clip_step(self, clip, gscale=1.0):
+        """average (gscale = 1/world), clip to global norm `clip` and take the Adam step in two launches of
+        i2p_clip_adam (csrc/optim.hip) instead of ~25 elementwise launches; same arithmetic as `_update()`'s torch
+        formulation (tests/test_train_gpu.py).  HIP backend / device tensors only."""
+        be = ops.get_backend()
+        if self._partials is None:
+            self._partials = torch.zeros(256, dtype=torch.float64, device=self.param.device)
+            self._total = torch.zeros(1, dtype=torch.float32, device=self.param.device)
+        P = lambda t, dt=torch.float32: be._p(t, dt, "adam")
+        be._call("i2p_clip_adam", int(self.param.numel()), P(self.param), P(self.grad), P(self.exp_avg), P(self.exp_avg_sq),
+                 P(self.mask) if self.mask is not None else None, P(self._partials, torch.float64), P(self.step_t.view(1)),
+                 P(self.lr_t.view(1)), float(self.beta1), float(self.beta2), float(self.eps), float(self.weight_decay), float(clip),
+                 float(gscale), P(self._total), stream=be._stream())
 
     @torch.no_grad()
     def decay_lr(self, gamma):
@@ -208,6 +228,11 @@ class Trainer:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
 
     def _update(self):
+        be = ops.get_backend()
+        if (USE_FUSED_ADAM and self.device.type == "cuda" and be.name == "hip" and self.flat_param.numel() % 4 == 0
+                and self.flat_param.data_ptr() % 16 == 0 and self.flat_grad.data_ptr() % 16 == 0):
+            self.optimizer.fused_clip_step(self.clip, 1.0 / self.world_size)
+            return
         if self.world_size > 1:
             self.flat_grad.mul_(1.0 / self.world_size)
         if self.clip > 0.0:                     # clip_grad_norm_ on the flat buffer (same total norm)

@@ -478,6 +478,16 @@ int i2p_pair_bias_bn_bwd_bf16(int B, int N, int M, int C, const i2p_bf16 *gz, co
                               const double *dsums, const float *coef, const float *mi, float *sum_k, float *sum_n,
                               float *d_enc_n, float *d_enc_k, void *stream);
 
+/* Global-norm gradient clip + Adam with L2 weight decay on flat fp32 buffers in two launches (reference:
+ * train20v2learn_wandb_proj.py:198-205 torch.optim.Adam(lr 1e-3, betas (0.9, 0.999), eps 1e-8, weight_decay 1e-4) after
+ * :472-476 clip_grad_norm_(max_norm 10)).  n % 4 == 0, buffers 16-byte aligned; grad is replaced by gscale*clip_factor*grad
+ * (what the optimiser consumed); step / lr are device scalars (step is advanced by one); mask NULL or [n] of 0/1 (parameters
+ * autograd leaves without a gradient take no decay and no update, as torch.optim.Adam skips them); partials: scratch of
+ * >= 256 doubles; total_out NULL or [1] = the global norm before clipping.  clip <= 0: no clipping. */
+int i2p_clip_adam(long long n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, const float *mask, double *partials,
+                  float *step, const float *lr, float beta1, float beta2, float eps, float weight_decay, float clip, float gscale,
+                  float *total_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

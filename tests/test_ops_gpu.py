@@ -733,6 +733,51 @@ def test_sa_l1_group_matches_unfused_path(hip_backend, lattice):
     assert float(a[..., :3].abs().max()) > 0
 
 
+def _sa_l1_oracle_chain(ob, sel, raw, out_h, out_w, sh, sw, kH, kW, K, dist):
+    """what i2p_sa_l1_group fuses, on the CPU oracle: fused_conv_select_k_cpu (FLAG_SHIFT|FLAG_COPY, zero-initialised
+    outputs) -> gather_rows_cpu of the raw image -> the 10-channel feature rows of PPBackbone_center.py:177-187"""
+    B, H, W, _ = sel.shape
+    N = out_h * out_w
+    idx = stride_grid(B, out_h, out_w, sh, sw)
+    sb, shh, sww, m, _, _ = run_fcsk(ob, sel, sel, idx, kH, kW, K, 3, dist, 1, 1)
+    nb = torch.empty(B, N * K, 3)
+    ob.gather_rows(raw.reshape(B, H * W, 3).contiguous(), shh.reshape(B, N * K).contiguous(), sww.reshape(B, N * K).contiguous(), W, nb)
+    nb = nb.view(B, N, K, 3)
+    c_sel = sel[:, ::sh, ::sw][:, :out_h, :out_w].reshape(B, N, 1, 3)
+    c_raw = raw[:, ::sh, ::sw][:, :out_h, :out_w].reshape(B, N, 1, 3)
+    d = nb - c_raw
+    dn = torch.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]).unsqueeze(-1)
+    return torch.cat([d, c_sel.expand(-1, -1, K, -1), nb, dn, torch.zeros(B, N, K, 2)], -1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["scan", "dense", "lattice", "nuscenes", "scalar_stage"])
+def test_sa_l1_group_full_size_vs_oracle_chain(hip_backend, oracle_backend, case, monkeypatch):
+    """i2p_sa_l1_group at the level-1 size of the network (64 x 1800 -> 16 x 225 queries, 9 x 15 window, K = 32) against the
+    ORACLE chain it replaces (fused_conv_go.cu:49-238 + utils.py:36-60 + PPBackbone_center.py:177-187), not against another
+    HIP path: sparse scan (7 % of the cells occupied: most centres empty), dense image, lattice (ties everywhere -> the
+    serial redo), the nuScenes level-1 shape (21 rows, row stride 2) and the scalar staging path (no 16-byte alignment)."""
+    B, H, W, out_h, sh = 2, 64, 1800, 16, 4
+    dist = 0.75
+    if case == "nuscenes":
+        H, out_h, sh = 21, 11, 2
+    empty = {"scan": 0.93, "dense": 0.1, "lattice": 0.5, "nuscenes": 0.5, "scalar_stage": 0.6}[case]
+    raw = range_image(B, H, W, seed=21, empty_frac=empty, lattice=(case == "lattice"))
+    if case == "lattice":
+        dist = 3.0
+    rot = torch.tensor([[0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0]])
+    sel = ((raw @ rot.t() + torch.tensor([0.3, -0.2, 0.1])) * (raw != 0).any(-1, keepdim=True)).contiguous()
+    if case == "scalar_stage":
+        monkeypatch.setenv("I2P_SA_SCALAR_STAGE", "1")
+    got = hip_backend.sa_l1_group(sel.to(DEV), raw.to(DEV), out_h, 225, sh, 8, 9, 15, 32, dist).cpu().view(B, out_h * 225, 32, 12)
+    want = _sa_l1_oracle_chain(oracle_backend, sel, raw, out_h, 225, sh, 8, 9, 15, 32, dist)
+    assert torch.equal(got[..., :9], want[..., :9])
+    assert torch.allclose(got[..., 9], want[..., 9], rtol=2e-7, atol=0)
+    assert float(got[..., 10:].abs().max()) == 0.0
+    live = (sel[:, ::sh, ::8][:, :out_h, :225] != 0).any(-1).float().mean()
+    assert (0.02 < live < 0.2) if case == "scan" else live > 0.3
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("xyz_first", [True, False])
 def test_sa_rows_matches_gather_cat(hip_backend, xyz_first):

@@ -146,3 +146,42 @@ def test_full_step_matches_oracle_backend_step(oracle_backend):
     assert float(dp_cpu.abs().max()) <= 1.01e-3
     well = g_cpu.abs() > 1e-3 * g_cpu.abs().max()   # weights whose gradient is not rounding noise: sign(g) is stable
     assert float((dp_gpu - dp_cpu)[well].abs().mean()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 8])
+def test_fused_clip_adam_matches_torch_formulation(hip_backend, world):
+    """i2p_clip_adam (csrc/optim.hip: average, global-norm clip, Adam with L2 decay in two launches) against FlatAdam's
+    elementwise torch formulation — itself equal to torch.optim.Adam (tests/test_distributed.py) — over several steps on
+    the trainer's flat layout, with a mask of gradient-free segments, a clipped and an unclipped gradient scale."""
+    from i2pnet_amd.train import FlatAdam
+    dev = torch.device("cuda", 0)
+    n = 845 * 1000 + 4
+    g = torch.Generator(device=dev).manual_seed(3)
+    p0 = torch.randn(n, generator=g, device=dev) * 0.1
+    mask = torch.ones(n, device=dev); mask[1000:5000] = 0.0; mask[-40:] = 0.0
+    pa, pb = p0.clone(), p0.clone()
+    ga, gb = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    a = FlatAdam(pa, ga, 1e-3, weight_decay=1e-4); b = FlatAdam(pb, gb, 1e-3, weight_decay=1e-4)
+    a.mask = mask; b.mask = mask
+    clip = 10.0
+    for step, scale in enumerate([1.0, 1e-4, 3.0, 1e-3, 0.5]):        # total norm ~ 919*scale*world: clipped and unclipped steps
+        grad = torch.randn(n, generator=g, device=dev) * scale * world
+        grad[1000:5000] = 0.0; grad[-40:] = 0.0
+        ga.copy_(grad); gb.copy_(grad)
+        # torch formulation (train.Trainer._update)
+        if world > 1:
+            ga.mul_(1.0 / world)
+        total = torch.linalg.vector_norm(ga)
+        ga.mul_(torch.clamp(clip / (total + 1e-6), max=1.0))
+        a.step()
+        b.fused_clip_step(clip, 1.0 / world)
+        assert abs(float(b._total) - float(total)) <= 1e-5 * float(total)
+        assert float(b.step_t) == float(a.step_t) == step + 1
+        assert torch.allclose(gb, ga, rtol=1e-5, atol=1e-12)
+        # one Adam step moves a weight by <= lr; the two formulations must agree to a small fraction of that
+        assert float((pb - pa).abs().max()) <= 2e-6 * (step + 1), (step, float((pb - pa).abs().max()))
+        assert torch.allclose(b.exp_avg, a.exp_avg, rtol=1e-5, atol=1e-9) and torch.allclose(b.exp_avg_sq, a.exp_avg_sq, rtol=1e-5, atol=1e-12)
+    assert torch.equal(pb[1000:5000], p0[1000:5000])                   # masked segments: no decay, no update
+    a.decay_lr(0.99); b.decay_lr(0.99)
+    assert float(a.lr_t) == float(b.lr_t)
