@@ -4,7 +4,7 @@ One table, used by the product loader (`_lib.py`, device library, every entry ta
 `void* stream`) and by the test-only oracle loader (`oracle/oracle.py`, same names + `_cpu`,
 no stream).  Argument kinds:
 
-    'i'  int   'l' long long   'f'  float           'p'  device/host pointer (void*)
+    'i'  int   'l' long long   'f'  float   'd' double   'p'  device/host pointer (void*)
     'pp' pointer to an array of pointers (const float* const*)
 """
 import ctypes as C
@@ -82,7 +82,8 @@ DEVICE_ONLY = {
     "i2p_lin_fwd_fin": ["l", "i", "i", "p", "p", "f", "p", "p", "p", "p", "p", "f", "p", "p", "p"],
     "i2p_lin_fwd_2src_fin": ["l", "i", "i", "i", "p", "p", "f", "p", "p", "f", "p", "p", "p", "p", "p", "f", "p", "p", "p"],
     "i2p_pair_lin_fwd_fin": ["i"] * 5 + ["p"] * 7 + ["p", "p", "f", "p", "p", "p"],
-    "i2p_clip_adam": ["l"] + ["p"] * 8 + ["f"] * 6 + ["p"],
+    "i2p_clip_adam": ["l"] + ["p"] * 8 + ["d", "d"] + ["f"] * 4 + ["p"],
+    "i2p_lin_bwd_part": ["l", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 5 + ["f", "i", "p"],
 }
 # plain `int f(...)` helpers without a stream argument
 HELPERS = {
@@ -92,10 +93,11 @@ HELPERS = {
     "i2p_pair_bias_bn_bwd_scratch": ["i", "i", "i", "i"],           # returns long long
     "i2p_gather_rows_grad_fx_scratch": ["i", "i", "i"],             # returns long long (bytes)
     "i2p_gemm_tn_scratch": ["l", "i", "i"],                         # returns long long (bytes)
+    "i2p_lin_bwd_splittable": ["l", "i", "i", "i"],
 }
 LONG_HELPERS = {"i2p_pair_lin_bwd_scratch", "i2p_pair_bias_bn_bwd_scratch", "i2p_gather_rows_grad_fx_scratch", "i2p_gemm_tn_scratch"}
 
-_CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "p": C.c_void_p, "pp": C.c_void_p}
+_CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "d": C.c_double, "p": C.c_void_p, "pp": C.c_void_p}
 
 
 def bind(lib, name, symbol, with_stream):

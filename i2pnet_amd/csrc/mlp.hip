@@ -1943,13 +1943,35 @@ static int launch_wgrad(const WgradParams &q, float *dw, hipStream_t st, unsigne
 struct PairBwd { const float *f, *g; float *d_f, *d_g, *d_bn, *d_bk; int N, M; };
 struct TwoBwd { int split_c; const float *xb, *in_coef_b, *in_mi_b; float slope_b; float *gz_in_b; double *in_dsums_b; const float *e_add; };
 
+// which family of kernels a backward call lands on: 0 = first generation (one block-synchronous dgrad+wgrad kernel),
+// 1 = second / third generation (separate dgrad and wgrad launches), 2 = K-tiled wide layers (csrc/mlp_big.hip)
+static int lin_bwd_family(long long rows, int cin, int cout, bool need_gx, bool pair, bool two) {
+    auto pow2w = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
+    const char *gen = getenv("I2P_LIN_BWD_GEN");
+    const int cin_p = (cin + 31) & ~31, cout_p = (cout + 31) & ~31;
+    const bool dgrad_ok = !need_gx || (pow2w(cin) && pow2w(cout));
+    const size_t wg_lds = (2 * (size_t)WG_R * (cout_p + cin_p) + 6 * (size_t)cout + 3 * (size_t)cin) * sizeof(float);
+    if (!pair && !(gen && gen[0] == '1') && dgrad_ok && pow2w(cout) && wg_lds <= 160 * 1024 && cin <= 160) return 1;
+    if (!pair && !two && i2p_big_layer_ok(rows, cin, cout)) return 2;
+    return 0;
+}
+
+// `part`: 3 = the whole backward; 1 = input gradient only (dgrad: gz_in, in_dsums; no dw / dw_partial — `coef_scratch` [8*cout]
+// floats takes the BN-backward constants of the wide-layer kernels); 2 = weight gradient only (dw, the BN gradients behind the
+// partials).  The two halves read the same operands and write disjoint outputs, so a caller may issue them on two streams
+// (families 1 and 2 only: i2p_lin_bwd_splittable).
 static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, const float *y,
                         const float *out_coef, const float *out_mi, const double *out_dsums,
                         const float *x, const float *in_coef, const float *in_mi, float slope_in,
                         const float *w, float *gz_in, double *in_dsums, float *dw_partial, float *dw,
-                        const PairBwd *pair, void *stream, const TwoBwd *two = nullptr, float slope_out = 1.f) {
+                        const PairBwd *pair, void *stream, const TwoBwd *two = nullptr, float slope_out = 1.f, int part = 3,
+                        float *coef_scratch = nullptr) {
     if (rows <= 0 || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3)) return I2P_ERR_BAD_ARG;
-    if (!gz || (!x && !pair) || !w || !dw_partial || !dw) return I2P_ERR_BAD_ARG;
+    if (!gz || (!x && !pair) || !w || part < 1 || part > 3) return I2P_ERR_BAD_ARG;
+    if ((part & 2) && (!dw_partial || !dw)) return I2P_ERR_BAD_ARG;
+    if (part == 1 && (!gz_in || (out_coef && !coef_scratch))) return I2P_ERR_BAD_ARG;
+    if (part == 2) { gz_in = nullptr; in_dsums = nullptr; }
+    if (part != 3 && lin_bwd_family(rows, cin, cout, gz_in != nullptr || part == 2, pair != nullptr, two != nullptr) == 0) return I2P_ERR_BAD_ARG;
     if (out_coef && (!y || !out_mi || !out_dsums)) return I2P_ERR_BAD_ARG;
     if (in_coef && !in_mi) return I2P_ERR_BAD_ARG;
     LinBwdParams p;
@@ -1978,7 +2000,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
         // the raw sums {sum gz, sum gz*xhat} = dbeta, dgamma of the BN behind (read back by the caller)
         float *g_coef = nullptr;
         if (out_coef && !pair) {
-            g_coef = dw_partial + (size_t)grid * cout * cin;        // [8][cout] scratch tail; rows 6, 7 = dbeta, dgamma for the caller
+            g_coef = (part & 2) ? dw_partial + (size_t)grid * cout * cin : coef_scratch;   // [8][cout] scratch tail; rows 6, 7 = dbeta, dgamma for the caller
             if (!gen2)                                              // (the second-generation kernels form the constants in their prologues)
                 hipLaunchKernelGGL(bnbwd_coef_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, rows, cout, out_dsums, out_coef,
                                    out_mi, g_coef);
@@ -2010,6 +2032,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
                 const int rc = dispatch_fwd2<false, true>(q, st);
                 if (rc) return rc;
             }
+            if (!(part & 2)) I2P_RETURN_LAUNCH_STATUS();            // dgrad half only
             if (!two && out_coef && grid == 256 && i2p_small_wgrad_ok(rows, cin, cout)) {
                 // narrow layer on many rows (level 1): HBM streaming, dword columns as MFMA operands (csrc/mlp_wreg.hip)
                 const int rc = i2p_small_wgrad(rows, cin, cout, gz, y, out_dsums, out_coef, out_mi, rows, p.slope_out, g_coef, x, in_coef,
@@ -2043,8 +2066,10 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
         }
     }
     if (!pair && !two && i2p_big_layer_ok(rows, cin, cout))        // wide layer on few rows: K-tiled dgrad + row-split wgrad (csrc/mlp_big.hip)
-        return i2p_big_bwd(rows, cin, cout, gz, y, out_coef ? dw_partial + (size_t)grid * cout * cin : nullptr, p.slope_out, x, in_coef, in_mi,
-                           slope_in, w, gz_in, in_dsums, dw_partial, (int)grid, dw, stream);
+        return i2p_big_bwd(rows, cin, cout, gz, y, out_coef ? ((part & 2) ? dw_partial + (size_t)grid * cout * cin : coef_scratch) : nullptr,
+                           p.slope_out, x, in_coef, in_mi, slope_in, w, gz_in, in_dsums, (part & 2) ? dw_partial : nullptr, (int)grid,
+                           (part & 2) ? dw : nullptr, stream);
+    if (part != 3) return I2P_ERR_BAD_ARG;
     switch (p.cin_p / 32) {
         case 1: return dispatch_bwd_o<1>(p, dw, st, grid);
         case 2: return dispatch_bwd_o<2>(p, dw, st, grid);
@@ -2062,6 +2087,20 @@ extern "C" int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, c
                            float slope_out, void *stream) {
     return lin_bwd_impl(rows, cin, cout, gz, y, out_coef, out_mi, out_dsums, x, in_coef, in_mi, slope_in, w, gz_in,
                         in_dsums, dw_partial, dw, nullptr, stream, nullptr, slope_out);
+}
+
+extern "C" int i2p_lin_bwd_splittable(long long rows, int cin, int cout, int need_gx) {
+    if (rows <= 0 || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3)) return 0;
+    return lin_bwd_family(rows, cin, cout, need_gx != 0, false, false) != 0 ? 1 : 0;
+}
+
+extern "C" int i2p_lin_bwd_part(long long rows, int cin, int cout, const float *gz, const float *y,
+                                const float *out_coef, const float *out_mi, const double *out_dsums,
+                                const float *x, const float *in_coef, const float *in_mi, float slope_in,
+                                const float *w, float *gz_in, double *in_dsums, float *dw_partial, float *dw,
+                                float slope_out, int part, float *coef_scratch, void *stream) {
+    return lin_bwd_impl(rows, cin, cout, gz, y, out_coef, out_mi, out_dsums, x, in_coef, in_mi, slope_in, w, gz_in,
+                        in_dsums, dw_partial, dw, nullptr, stream, nullptr, slope_out, part, coef_scratch);
 }
 
 extern "C" int i2p_pair_lin_bwd_grid(int B, int N, int M) {

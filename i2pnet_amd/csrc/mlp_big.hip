@@ -318,7 +318,8 @@ int i2p_big_fwd(long long rows, int cin, int cout, const float *x, const float *
 int i2p_big_bwd(long long rows, int cin, int cout, const float *gz, const float *y, const float *g_coef, float slope_out, const float *x,
                 const float *in_coef, const float *in_mi, float slope_in, const float *w, float *gz_in, double *in_dsums,
                 float *dw_partial, int max_chunks, float *dw, void *stream) {
-    if (!i2p_big_layer_ok(rows, cin, cout) || !gz || !x || !w || !dw_partial || !dw || max_chunks < 1 || (g_coef && !y)) return I2P_ERR_BAD_ARG;
+    // dw == nullptr: input gradient only (the weight gradient is issued by another call, possibly on another stream)
+    if (!i2p_big_layer_ok(rows, cin, cout) || !gz || !x || !w || (dw && !dw_partial) || (!dw && !gz_in) || max_chunks < 1 || (g_coef && !y)) return I2P_ERR_BAD_ARG;
     if ((reinterpret_cast<uintptr_t>(dw_partial) | reinterpret_cast<uintptr_t>(dw)) & 15) return I2P_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (gz_in) {
@@ -328,6 +329,7 @@ int i2p_big_bwd(long long rows, int cin, int cout, const float *gz, const float 
         const dim3 grid((unsigned)((rows + BG_ROWS - 1) / BG_ROWS), (unsigned)((cin + BG_COLS - 1) / BG_COLS));
         hipLaunchKernelGGL(big_nt_kernel<true>, grid, dim3(BG_THREADS), 0, st, p);
     }
+    if (!dw) I2P_RETURN_LAUNCH_STATUS();
     BigTnP q{};
     q.rows = rows; q.m = cout; q.n = cin; q.gz = gz; q.y = y; q.g_coef = g_coef; q.g_slope = g_coef ? slope_out : 1.f; q.x = x; q.in_coef = in_coef;
     q.slope_in = slope_in; q.partial = dw_partial;

@@ -43,8 +43,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_update_kernel(long long n4,
                                                                    float4 *__restrict__ m, float4 *__restrict__ v,
                                                                    const float4 *__restrict__ mask, const double *__restrict__ partials,
                                                                    int nparts, const float *__restrict__ step, const float *__restrict__ lr,
-                                                                   float b1, float b2, float eps, float wd, float clip, float gscale,
-                                                                   float *__restrict__ total_out) {
+                                                                   float b1, float b2, float w1, float w2, float eps, float wd, float clip,
+                                                                   float gscale, float *__restrict__ total_out) {
     __shared__ float s_scale, s_bc2s, s_lrbc1;
     if (threadIdx.x == 0) {
         double t = 0.0;
@@ -61,7 +61,6 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_update_kernel(long long n4,
     }
     __syncthreads();
     const float sc = s_scale, bc2s = s_bc2s, lrbc1 = s_lrbc1;
-    const float w1 = 1.0f - b1, w2 = 1.0f - b2;
     for (long long i = (long long)blockIdx.x * ADAM_THREADS + threadIdx.x; i < n4; i += (long long)gridDim.x * ADAM_THREADS) {
         float4 g4 = grad[i], p4 = param[i], m4 = m[i], v4 = v[i];
         float4 k4 = mask ? mask[i] : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -89,7 +88,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_update_kernel(long long n4,
 // partials: >= 256 doubles of scratch.  step / lr: device scalars (fp32).  mask: nullptr or [n] 0/1.  total_out: nullptr or [1]
 // (the pre-clip global norm).  clip <= 0: no clipping.
 extern "C" int i2p_clip_adam(long long n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, const float *mask,
-                             double *partials, float *step, const float *lr, float beta1, float beta2, float eps, float weight_decay,
+                             double *partials, float *step, const float *lr, double beta1, double beta2, float eps, float weight_decay,
                              float clip, float gscale, float *total_out, void *stream) {
     if (n <= 0 || (n & 3) || !param || !grad || !exp_avg || !exp_avg_sq || !partials || !step || !lr) return I2P_ERR_BAD_ARG;
     if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
@@ -104,7 +103,8 @@ extern "C" int i2p_clip_adam(long long n, float *param, float *grad, float *exp_
                        partials, step);
     hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)nb), dim3(ADAM_THREADS), 0, st, n4, reinterpret_cast<float4 *>(param),
                        reinterpret_cast<float4 *>(grad), reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq),
-                       reinterpret_cast<const float4 *>(mask), partials, (int)nb, step, lr, beta1, beta2, eps, weight_decay, clip, gscale,
-                       total_out);
+                       reinterpret_cast<const float4 *>(mask), partials, (int)nb, step, lr, (float)beta1, (float)beta2,
+                       (float)(1.0 - beta1), (float)(1.0 - beta2),        // the lerp / addcmul weights as torch forms them: in double, then rounded
+                       eps, weight_decay, clip, gscale, total_out);
     I2P_RETURN_LAUNCH_STATUS();
 }

@@ -147,6 +147,12 @@ class _MlpChain(Function):
             coefs.append(None); mis.append(None)
         nl = (len(p) - k) // 3
         sums = None
+        # input rows zero-padded beyond the first layer's real cin (multiple of 4 / power of two for the kernels): the weight is
+        # padded HERE, outside autograd — its gradient is cut back in backward() where the wgrad runs (no ConstantPadNd node)
+        ctx.w0_cin = None
+        if nl and not first_bn and x.shape[1] > p[k].shape[1]:
+            ctx.w0_cin = p[k].shape[1]
+            p[k] = F.pad(p[k].detach(), (0, x.shape[1] - p[k].shape[1]))
         bf = chain_bf16_ok(x, first_bn, [p[k + 3 * i] for i in range(nl)])
         ctx.bf16 = bf
         for i in range(nl):
@@ -233,6 +239,8 @@ class _MlpChain(Function):
             gz_in, in_ds, dw = be.lin_backward(gz, y_out, out_coef, out_mi, out_ds, ys[i - 1], coefs[i - 1],
                                                mis[i - 1], slopes[i - 1] if has_in else 1.0, W.detach(),
                                                need_gx=need_gx, slope_out=slope_out)
+            if i == 1 and ctx.w0_cin is not None:
+                dw = be.after_wgrad(lambda dw=dw: dw[:, :ctx.w0_cin].contiguous())
             grads[k + 3 * (i - 1)] = dw
             # gamma/beta gradients of the BN behind layer i: reduced from out_ds by the launcher (scratch tail)
             grads[k + 3 * (i - 1) + 1], grads[k + 3 * (i - 1) + 2] = be.take_bn_grads()
@@ -376,6 +384,11 @@ class _CvKnnTail(Function):
         s1, s2, s3, se, s4, s5 = slopes
         d = lambda t: t.detach()
         x1, xe, W1, We = [t.detach().contiguous() for t in (x1, xe, W1, We)]
+        ctx.cins = (W1.shape[1], We.shape[1])            # real input widths: the rows carry zero padding, the weights get it here
+        if x1.shape[1] > W1.shape[1]:
+            W1 = F.pad(W1, (0, x1.shape[1] - W1.shape[1]))
+        if xe.shape[1] > We.shape[1]:
+            We = F.pad(We, (0, xe.shape[1] - We.shape[1]))
         y1, st1, c1, m1 = be_.lin_forward_fin(x1, None, 1.0, W1, d(g1), d(b1), _EPS)
         y2, st2, c2, m2 = be_.lin_forward_fin(y1, c1, s1, d(W2), d(g2), d(b2), _EPS)
         y3, st3, c3, m3 = be_.lin_forward_fin(y2, c2, s2, d(W3), d(g3), d(b3), _EPS)
@@ -406,7 +419,11 @@ class _CvKnnTail(Function):
         gz2, ds2, dW3 = be_.lin_backward(gz3, y3, c3, m3, ds3, y2, c2, m2, s2, d(W3)); dg3, db3 = be_.take_bn_grads()
         gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2)); dg2, db2 = be_.take_bn_grads()
         dx1, _, dW1 = be_.lin_backward(gz1, y1, c1, m1, ds1, x1, None, None, 1.0, W1, need_gx=ctx.need[0]); dg1, db1 = be_.take_bn_grads()
+        if W1.shape[1] > ctx.cins[0]:
+            dW1 = be_.after_wgrad(lambda: dW1[:, :ctx.cins[0]].contiguous())
         dxe, _, dWe = be_.lin_backward(gze, ye, ce, me, dse, xe, None, None, 1.0, We, need_gx=ctx.need[1]); dge, dbe = be_.take_bn_grads()
+        if We.shape[1] > ctx.cins[1]:
+            dWe = be_.after_wgrad(lambda: dWe[:, :ctx.cins[1]].contiguous())
         return (dx1, dxe, dW1, dWe, None, None, None, dg1, db1, dW2, dg2, db2, dW3, dg3, db3, dge, dbe, dW4, dg4, db4, dW5, dg5, db5)
 
 
@@ -419,10 +436,6 @@ def cv_knn_tail(x1, xe, dims, first, mlp1_rest, enc, mlp2):
     running = _running_list((first, c2, c3, enc, c4, c5))
     rows = dims[0] * dims[1] * dims[2]
     W1, We = first.weight2d(), enc.weight2d()
-    if x1.shape[-1] > W1.shape[1]:
-        W1 = F.pad(W1, (0, x1.shape[-1] - W1.shape[1]))
-    if xe.shape[-1] > We.shape[1]:
-        We = F.pad(We, (0, xe.shape[-1] - We.shape[1]))
     return _CvKnnTail.apply(x1.reshape(rows, -1), xe.reshape(rows, -1), W1, We, dims, slopes, running, *bn(first), c2.weight2d(), *bn(c2),
                             c3.weight2d(), *bn(c3), *bn(enc), c4.weight2d(), *bn(c4), c5.weight2d(), *bn(c5))
 
@@ -581,8 +594,8 @@ def mlp_stack(x, convs, first_bn=None, pool_k=0):
                 if t == 0 and pending_bn is None:
                     if xin.shape[1] % 4:                 # pad raw input channels to a multiple of 4
                         xin = F.pad(xin, (0, 4 - xin.shape[1] % 4))
-                    if xin.shape[1] > W.shape[1]:        # (callers may deliver the zero channels already: modules.cat_padded)
-                        W = F.pad(W, (0, xin.shape[1] - W.shape[1]))
+                    # (callers may deliver the zero channels already: modules.cat_padded; the weight's zero columns are added
+                    # inside the chain, outside autograd)
                 params += [W, c.bn_linear.weight, c.bn_linear.bias]; slopes.append(_slope(c))
             pool_here = pool_k if (j >= n and run) else 0
             cur = _MlpChain.apply(xin.contiguous(), pending_bn is not None, tuple(slopes), pool_here, running, *params)

@@ -109,6 +109,41 @@ end_step = _arena.end
 zeros = _arena.zeros
 
 
+class _SideWgrad:
+    """Weight gradients of the small fused layers on a second HIP stream (a parallel branch of the captured hipGraph): a
+    layer's dgrad is the only kernel the next layer's backward waits for, its wgrad + partial reduction (2 of the 3 launches)
+    only has to be done when the gradients are packed.  Opt-in per backward pass (`side_wgrad_begin` / `side_wgrad_end`, the
+    trainer's job): between the two calls every tensor a side-stream launch touches is kept alive here, `end` makes the
+    calling stream wait for the side stream.  Only valid when every weight receives ONE gradient per backward pass (a second
+    contribution would be accumulated on the main stream without waiting)."""
+    active = False
+    stream = None
+    keep = []
+    used = False
+    # layers above this many activation elements (rows * max(cin, cout)) keep both halves on one stream: they are
+    # HBM-bound and fill the chip, running two of them side by side gains nothing
+    MAX_ELEMS = int(os.environ.get("I2P_SIDE_WGRAD_MAX", 160 << 20))
+
+
+def side_wgrad_begin(device):
+    device = torch.device(device)
+    if device.type != "cuda" or os.environ.get("I2P_NO_SIDE_WGRAD") == "1":
+        return False
+    if _SideWgrad.stream is None or _SideWgrad.stream.device != device:
+        _SideWgrad.stream = torch.cuda.Stream(device=device)
+    _SideWgrad.active, _SideWgrad.used = True, False
+    return True
+
+
+def side_wgrad_end():
+    """join: the current stream waits for the side stream's weight gradients; releases the tensors kept for them"""
+    if _SideWgrad.active:
+        _SideWgrad.active = False
+        if _SideWgrad.used:
+            torch.cuda.current_stream(_SideWgrad.stream.device).wait_stream(_SideWgrad.stream)
+        _SideWgrad.keep.clear()
+
+
 class CBackend:
     """Calls `fns[name](*scalars_and_pointers [, stream])`."""
 
@@ -598,6 +633,7 @@ class CBackend:
         rows, cout = gz.shape
         cin = x.shape[1]
         dev = gz.device
+        self.last_split = False
         if gz.dtype == _BF16:
             gz_in = torch.empty(rows, cin, dtype=x.dtype, device=dev) if need_gx else None
             in_dsums = (zeros(BN_REPLICAS * 2 * cin, torch.float64, dev) if (need_gx and in_coef is not None) else None)
@@ -619,14 +655,44 @@ class CBackend:
         part = torch.empty(min(grid, (rows + 63) // 64) * cout * cin + 8 * cout, dtype=_F32, device=dev)
         dw = torch.empty(cout, cin, dtype=_F32, device=dev)
         P = lambda t, dt=_F32, n="t": (self._p(t, dt, n) if t is not None else None)
+        n = part.numel()
+        self.last_bn_grads = (part[n - cout:], part[n - 2 * cout:n - cout]) if out_coef is not None else None
+        self.last_split = False
+        if (_SideWgrad.active and need_gx and self.name == "hip" and self.device_type == "cuda" and rows * max(cin, cout) <= _SideWgrad.MAX_ELEMS
+                and _lib.helper("i2p_lin_bwd_splittable", int(rows), int(cin), int(cout), 1)):
+            # dgrad on the current stream, wgrad + partial reduction on the side stream (forked BEFORE the dgrad launch)
+            coef8 = torch.empty(8 * cout, dtype=_F32, device=dev) if out_coef is not None else None
+            args = (int(rows), int(cin), int(cout), P(gz, _F32, "gz"), P(y, _F32, "y"), P(out_coef, _F32, "out_coef"), P(out_mi, _F32, "out_mi"),
+                    P(out_dsums, torch.float64, "out_dsums"), P(x, _F32, "x"), P(in_coef, _F32, "in_coef"), P(in_mi, _F32, "in_mi"),
+                    float(slope_in), P(w, _F32, "w"))
+            cur, side = torch.cuda.current_stream(dev), _SideWgrad.stream
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._call("i2p_lin_bwd_part", *args, P(gz_in, _F32, "gz_in"), P(in_dsums, torch.float64, "in_dsums"), None, None,
+                       float(slope_out), 1, P(coef8, _F32, "coef"), stream=cur.cuda_stream)
+            side.wait_event(ev)
+            self._call("i2p_lin_bwd_part", *args, None, None, P(part, _F32, "dw_partial"), P(dw, _F32, "dw"), float(slope_out), 2, None,
+                       stream=side.cuda_stream)
+            _SideWgrad.keep.append((gz, y, out_coef, out_mi, out_dsums, x, in_coef, in_mi, w, part, dw, coef8))
+            _SideWgrad.used = True
+            self.last_split = True
+            return gz_in, in_dsums, dw
         self._call("i2p_lin_bwd", int(rows), int(cin), int(cout), P(gz, _F32, "gz"), P(y, _F32, "y"),
                    P(out_coef, _F32, "out_coef"), P(out_mi, _F32, "out_mi"), P(out_dsums, torch.float64, "out_dsums"),
                    P(x, _F32, "x"), P(in_coef, _F32, "in_coef"), P(in_mi, _F32, "in_mi"), float(slope_in),
                    P(w, _F32, "w"), P(gz_in, _F32, "gz_in"), P(in_dsums, torch.float64, "in_dsums"),
                    P(part, _F32, "dw_partial"), P(dw, _F32, "dw"), float(slope_out), stream=self._stream())
-        n = part.numel()
-        self.last_bn_grads = (part[n - cout:], part[n - 2 * cout:n - cout]) if out_coef is not None else None
         return gz_in, in_dsums, dw
+
+    def after_wgrad(self, fn):
+        """run `fn()` (launches that consume the weight gradient of the LAST lin_backward) where that gradient is produced:
+        on the side stream when the call was split, else in place"""
+        if getattr(self, "last_split", False) and _SideWgrad.active:
+            with torch.cuda.stream(_SideWgrad.stream):
+                out = fn()
+            _SideWgrad.keep.append(out)
+            return out
+        return fn()
 
     def take_bn_grads(self):
         """(dgamma, dbeta) of the last lin_backward / lin_backward_2src, handing the reference over: a pair still
@@ -718,6 +784,7 @@ class CBackend:
         rows, cout = gz.shape
         ca, cb = xa.shape[1], xb.shape[1]
         dev = gz.device
+        self.last_split = False
         gz_a = torch.empty(rows, ca, dtype=gz.dtype, device=dev); gz_b = torch.empty(rows, cb, dtype=gz.dtype, device=dev)
         ds_a = zeros(BN_REPLICAS * 2 * ca, torch.float64, dev)
         ds_b = zeros(BN_REPLICAS * 2 * cb, torch.float64, dev)

@@ -232,6 +232,16 @@ int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, const float 
                 const float *out_coef, const float *out_mi, const double *out_dsums, const float *x,
                 const float *in_coef, const float *in_mi, float slope_in, const float *w, float *gz_in,
                 double *in_dsums, float *dw_partial, float *dw, float slope_out, void *stream);
+/* The two halves of i2p_lin_bwd as separate calls (same arguments): part 1 = input gradient only (gz_in, in_dsums; dw_partial / dw
+ * unused, coef_scratch = 8*cout floats of scratch when out_coef is given), part 2 = weight gradient only (dw, dw_partial; gz_in /
+ * in_dsums unused), part 3 = both.  The halves read the same operands and write disjoint outputs: a caller may issue them on two
+ * streams so that the weight gradients leave the critical path of the backward pass.  i2p_lin_bwd_splittable: 1 if this shape has
+ * separate dgrad / wgrad kernels (parts 1 and 2 accepted), 0 if it runs on the one-kernel first-generation path (part 3 only). */
+int i2p_lin_bwd_splittable(long long rows, int cin, int cout, int need_gx);
+int i2p_lin_bwd_part(long long rows, int cin, int cout, const float *gz, const float *y,
+                     const float *out_coef, const float *out_mi, const double *out_dsums, const float *x,
+                     const float *in_coef, const float *in_mi, float slope_in, const float *w, float *gz_in,
+                     double *in_dsums, float *dw_partial, float *dw, float slope_out, int part, float *coef_scratch, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Hamilton product out = a (x) b with broadcasting over the point axis (src/modules/warp_utils.py:25-55
@@ -485,7 +495,7 @@ int i2p_pair_bias_bn_bwd_bf16(int B, int N, int M, int C, const i2p_bf16 *gz, co
  * autograd leaves without a gradient take no decay and no update, as torch.optim.Adam skips them); partials: scratch of
  * >= 256 doubles; total_out NULL or [1] = the global norm before clipping.  clip <= 0: no clipping. */
 int i2p_clip_adam(long long n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, const float *mask, double *partials,
-                  float *step, const float *lr, float beta1, float beta2, float eps, float weight_decay, float clip, float gscale,
+                  float *step, const float *lr, double beta1, double beta2, float eps, float weight_decay, float clip, float gscale,
                   float *total_out, void *stream);
 
 #ifdef __cplusplus
