@@ -301,7 +301,11 @@ __global__ __launch_bounds__(256) void big_reduce_kernel(int nparts, int count4,
 bool i2p_big_layer_ok(long long rows, int cin, int cout) {
     static const char *e = getenv("I2P_NO_BIG");
     if (e && e[0] == '1') return false;
-    return rows > 0 && (cin & 3) == 0 && (cout & 3) == 0 && cin <= BG_MAXC && cout <= BG_MAXC && (cin > 160 || cout > 128);
+    // cin in (128, 160] (132 = 128 + xyz, 136 = 128 + 6 + padding: level 4, the fine cost volume's first layer) used to run on the
+    // first-generation block-synchronous kernels (lin_fwd_kernel<128,4> 91 us, lin_bwd_kernel<5,4> 128 us per launch)
+    static const char *e2 = getenv("I2P_BIG_MIN_CIN");
+    const int min_cin = e2 ? atoi(e2) : 128;
+    return rows > 0 && (cin & 3) == 0 && (cout & 3) == 0 && cin <= BG_MAXC && cout <= BG_MAXC && (cin > min_cin || cout > 128);
 }
 
 int i2p_big_fwd(long long rows, int cin, int cout, const float *x, const float *in_coef, float slope_in, const float *w, float *y,

@@ -270,21 +270,23 @@ __global__ __launch_bounds__(256) void absmax_bits_kernel(long long n, const flo
     }
 }
 
-__device__ __forceinline__ double fx_scale(unsigned maxbits) {        // 2^(40 - exponent(max)); 1 for max == 0
+// 2^(shift - exponent(max)); 1 for max == 0.  Every addend is then < 2^(shift+1) in magnitude; `shift` = 40 leaves room for 2^21
+// addends per cell in the int64 accumulator, the launcher lowers it for longer scatters (fx_shift)
+__device__ __forceinline__ double fx_scale(unsigned maxbits, int shift) {
     const int e = (int)((maxbits >> 23) & 0xff) - 127;               // |max| in [2^e, 2^(e+1))
-    return maxbits ? ldexp(1.0, 40 - e) : 1.0;
+    return maxbits ? ldexp(1.0, shift - e) : 1.0;
 }
 
 constexpr int FX_RUN = 8;
 // grad_out rows have pitch `ld` floats, the c scattered channels start at column `off` (ld = c, off = 0: a dense tensor)
 __global__ void scatter_fx_kernel(int hw, int c, int q, int W, const float *__restrict__ grad_out, int ld, int off,
                                   const int64_t *__restrict__ h_idx, const int64_t *__restrict__ w_idx,
-                                  const unsigned *__restrict__ maxbits, unsigned long long *__restrict__ acc) {
+                                  const unsigned *__restrict__ maxbits, unsigned long long *__restrict__ acc, int shift) {
     const int bi = blockIdx.y;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nrun = (q + FX_RUN - 1) / FX_RUN;
     if (t >= (long long)nrun * c) return;
-    const double scale = fx_scale(*maxbits);
+    const double scale = fx_scale(*maxbits, shift);
     const int run = (int)(t / c), ch = (int)(t % c);
     const int r0 = run * FX_RUN, r1 = min(q, r0 + FX_RUN);
     long long cur = -1, sum = 0;
@@ -301,9 +303,9 @@ __global__ void scatter_fx_kernel(int hw, int c, int q, int W, const float *__re
 }
 
 __global__ __launch_bounds__(256) void fx_finalize_kernel(long long n, const long long *__restrict__ acc, const unsigned *__restrict__ maxbits,
-                                                           float *__restrict__ dst) {
+                                                           float *__restrict__ dst, int shift) {
     const unsigned mb = *maxbits;
-    const double inv = 1.0 / fx_scale(mb);
+    const double inv = 1.0 / fx_scale(mb, shift);
     const bool bad = mb >= 0x7f800000u;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
         dst[i] = bad ? __uint_as_float(0x7fc00000u) : dst[i] + (float)((double)acc[i] * inv);
@@ -326,9 +328,15 @@ static int gather_rows_grad_fx_impl(int b, int hw, int c, int q, int W, const fl
     long long g1 = (nsrc + 256 * 16 - 1) / (256 * 16); if (g1 > 1024) g1 = 1024; if (g1 < 1) g1 = 1;
     hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)g1), dim3(256), 0, st, nsrc, grad_out, mx);
     const long long tot = (long long)((q + FX_RUN - 1) / FX_RUN) * c;
-    hipLaunchKernelGGL(scatter_fx_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0, st, hw, c, q, W, grad_out, ld, off, h_idx, w_idx, mx, acc);
+    // all q rows of a sample may land on ONE cell (every empty-centre query gathers cell (0,0)): |sum| < q * 2^(shift+1) must stay
+    // below 2^62 -> shift = min(40, 61 - ceil(log2 q)); q <= 2^21 keeps the full 40 bits
+    int lg = 0;
+    while ((1LL << lg) < (long long)q) ++lg;
+    const int shift = lg > 21 ? 61 - lg : 40;
+    hipLaunchKernelGGL(scatter_fx_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0, st, hw, c, q, W, grad_out, ld, off, h_idx, w_idx, mx, acc,
+                       shift);
     long long g3 = (ndst + 255) / 256; if (g3 > 2048) g3 = 2048;
-    hipLaunchKernelGGL(fx_finalize_kernel, dim3((unsigned)g3), dim3(256), 0, st, ndst, reinterpret_cast<const long long *>(acc), mx, grad_feat);
+    hipLaunchKernelGGL(fx_finalize_kernel, dim3((unsigned)g3), dim3(256), 0, st, ndst, reinterpret_cast<const long long *>(acc), mx, grad_feat, shift);
     I2P_RETURN_LAUNCH_STATUS();
 }
 

@@ -40,7 +40,7 @@ def big_layer_fits(cin, cout):
     same i2p_lin_fwd / i2p_lin_bwd entries (device library only)"""
     be = ops.get_backend()
     return (USE_BIG_LAYERS and be.device_type == "cuda" and be.name == "hip" and cin % 4 == 0 and cout % 4 == 0
-            and cin <= 320 and cout <= 320 and (cin > 160 or cout > 128))
+            and cin <= 320 and cout <= 320 and (cin > 128 or cout > 128))
 
 
 class _LinearTN(Function):
@@ -178,7 +178,7 @@ class _MlpChain(Function):
             ctx.n_ys, ctx.n_coef = len(ys), len([c for c in coefs if c is not None])
             ctx.x_needs_grad = x.requires_grad
             if pool_k:
-                return out.view(rows // pool_k, pool_k, -1).max(1)[0]
+                raise RuntimeError("_MlpChain: pool_k on a shape the fused tail does not take (mlp_stack pools those outside the node)")
             return out
         # the stack's output: BN + activation of the last pre-BN tensor, materialised once
         out = torch.empty_like(ys[-1])
@@ -197,8 +197,8 @@ class _MlpChain(Function):
         ctx.save_for_backward(*ys, *[c for c in coefs if c is not None], *[m for m in mis if m is not None], *p)
         ctx.n_ys, ctx.n_coef = len(ys), len([c for c in coefs if c is not None])
         ctx.x_needs_grad = x.requires_grad
-        if pool_k:                                      # shapes the fused tail does not cover
-            return out.view(rows // pool_k, pool_k, -1).max(1)[0]
+        if pool_k:
+            raise RuntimeError("_MlpChain: pool_k on a shape the fused tail does not take (mlp_stack pools those outside the node)")
         return out
 
     @staticmethod
@@ -597,7 +597,11 @@ def mlp_stack(x, convs, first_bn=None, pool_k=0):
                     # (callers may deliver the zero channels already: modules.cat_padded; the weight's zero columns are added
                     # inside the chain, outside autograd)
                 params += [W, c.bn_linear.weight, c.bn_linear.bias]; slopes.append(_slope(c))
-            pool_here = pool_k if (j >= n and run) else 0
+            # the fused BN + activation + max-over-K tail takes widths whose float4 count divides 256 and K <= 255; other shapes
+            # pool outside the node (plain torch.max below, autograd keeps its own arg-max)
+            c_last = run[-1].out_channels if run else 0
+            pool_ok = bool(run) and c_last % 4 == 0 and 256 % (c_last // 4) == 0 and pool_k <= 255
+            pool_here = pool_k if (j >= n and pool_ok) else 0
             cur = _MlpChain.apply(xin.contiguous(), pending_bn is not None, tuple(slopes), pool_here, running, *params)
             if pool_here:
                 return cur.reshape(*lead[:-1], cur.shape[-1])

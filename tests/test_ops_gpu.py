@@ -431,7 +431,8 @@ def test_bn_act_parity(oracle_backend, hip_backend, rows, c, slope):
                                                    (12800, 16, 32, True), (999, 131, 128, False), (640, 128, 256, True),
                                                    (5000, 36, 32, False), (3000, 68, 64, False), (2000, 12, 16, False),
                                                    (1000, 256, 128, True), (928, 320, 128, True), (1824, 64, 192, True),
-                                                   (3000, 128, 320, False), (70, 192, 64, True), (14848, 128, 256, True)])
+                                                   (3000, 128, 320, False), (70, 192, 64, True), (14848, 128, 256, True),
+                                                   (14848, 132, 128, False), (58368, 136, 128, False), (1000, 160, 64, True)])
 def test_lin_fwd_parity(oracle_backend, hip_backend, rows, cin, cout, with_bn):
     """fused (BN+act on load) x W^T + output statistics: HIP MFMA kernel vs oracle (k-ordered fmaf
     chain) and vs torch fp64.  Asymmetric W catches transposed fragments."""
@@ -469,7 +470,9 @@ def test_lin_fwd_parity(oracle_backend, hip_backend, rows, cin, cout, with_bn):
                                                         (999, 132, 128, False, True), (5000, 64, 128, True, True),
                                                         (1000, 128, 256, True, True), (928, 320, 128, True, True),
                                                         (1824, 64, 192, True, True), (2000, 256, 128, True, True),
-                                                        (777, 192, 64, False, True), (500, 256, 256, True, False)])
+                                                        (777, 192, 64, False, True), (500, 256, 256, True, False),
+                                                        (14848, 132, 128, False, True), (58368, 136, 128, False, True),
+                                                        (1000, 160, 64, True, True)])
 def test_lin_bwd_parity(oracle_backend, hip_backend, rows, cin, cout, in_bn, out_bn):
     """fused layer backward (BN-backward on load, wgrad + dgrad on MFMA, activation derivative and
     statistics in the epilogue): HIP vs oracle, and the whole layer vs torch autograd in fp64."""

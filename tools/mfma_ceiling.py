@@ -5,6 +5,7 @@ design's limit (one wave per SIMD, 512 VGPRs), the power cap, or the HBM streams
     (i)   many waves per SIMD, register operands, independent accumulators (the guide's 155 TF pattern)
     (ii)  ONE wave per SIMD with 512 VGPRs, 256 back-to-back MFMAs per strip (16x16x4 and 32x32x2)
     (iii) (ii) + the HBM streams of a forward (8 loads + 8 stores of 16 B per lane per strip) / of a dgrad (24 + 8)
+    (iv)  (iii) with the loads issued one strip ahead and the stores one strip behind (software pipelining inside the wave)
 
 each with the engine clock / socket power sampled by rocm-smi while it runs.  Prints one JSON line per probe."""
 import ctypes as C
@@ -89,9 +90,13 @@ def main():
              2: "(iii) one wave/SIMD + dgrad streams (24 loads + 8 stores per lane per strip)",
              3: "(ii') one wave/SIMD, 128 x 32x32x2 per strip, no memory traffic",
              4: "(iii') one wave/SIMD, 32x32x2 + forward streams"}
-    for mode in (0, 3, 1, 4, 2):
+    names.update({5: "(iv) one wave/SIMD, 16x16x4 + forward streams, loads one strip ahead / stores one strip behind",
+                  6: "(iv') one wave/SIMD, 32x32x2 + forward streams, loads one strip ahead / stores one strip behind",
+                  7: "(iv) one wave/SIMD, 16x16x4 + dgrad streams (24 + 8), pipelined",
+                  8: "(iv') one wave/SIMD, 32x32x2 + dgrad streams (24 + 8), pipelined"})
+    for mode in (0, 3, 1, 4, 2, 5, 6, 7, 8):
         timed(names[mode], lambda st, m=mode: lib.probe_one_wave(m, blocks, strips, out.data_ptr(), src.data_ptr(), dst.data_ptr(), st))
-        byts = blocks * 4 * strips * 64 * 16 * {0: 0, 3: 0, 1: 16, 4: 16, 2: 32}[mode]
+        byts = blocks * 4 * strips * 64 * 16 * {0: 0, 3: 0, 1: 16, 4: 16, 2: 32, 5: 16, 6: 16, 7: 32, 8: 32}[mode]
         if byts:
             print(f"   (streams {byts / 1e9:.2f} GB per launch)")
 
