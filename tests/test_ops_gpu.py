@@ -906,3 +906,37 @@ def test_knn_rows_matches_gather_mul_cat(hip_backend, B, N, M, K, C):
     assert torch.equal(res[0][0], res[1][0])
     for got, want in zip(res[0][1:], res[1][1:]):
         assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cin,cout", [(14592, 64, 128), (14848, 256, 128), (58368, 136, 128), (4133, 32, 64)])
+def test_lin_bwd_split_halves_match_whole(hip_backend, monkeypatch, rows, cin, cout):
+    """i2p_lin_bwd_part: dgrad half (part 1, launch stream) + wgrad half (part 2, side stream) against the one-call backward:
+    bit-identical gz_in / statistics / dW / BN gradients (same kernels, same operands)."""
+    from i2pnet_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(rows)
+    x = torch.randn(rows, cin, generator=g, device=DEV); w = torch.randn(cout, cin, generator=g, device=DEV) / cin ** 0.5
+    gi = torch.ones(cin, device=DEV); bi = torch.zeros(cin, device=DEV); go = torch.ones(cout, device=DEV); bo = torch.zeros(cout, device=DEV)
+    in_coef, in_mi = hip_backend.bn_finalize(rows, hip_backend.bn_stats(x), gi, bi, 1e-5)
+    y, ys = hip_backend.lin_forward(x, in_coef, 0.1, w)
+    oc, omi = hip_backend.bn_finalize(rows, ys, go, bo, 1e-5)
+    gz = torch.randn(rows, cout, generator=g, device=DEV)
+    ods = hip_backend.bn_act_backward_stats(gz, y, omi, go, bo, 1.0)
+
+    def run(split):
+        if split:
+            monkeypatch.setenv("I2P_SIDE_WGRAD", "1")
+            assert ops.side_wgrad_begin(DEV)
+        try:
+            gzin, ids, dw = hip_backend.lin_backward(gz, y, oc, omi, ods, x, in_coef, in_mi, 0.1, w)
+            dg, db = hip_backend.take_bn_grads()
+            assert hip_backend.last_split == split
+        finally:
+            if split:
+                ops.side_wgrad_end()
+                monkeypatch.delenv("I2P_SIDE_WGRAD")
+        torch.cuda.synchronize()
+        return gzin.clone(), ids.clone(), dw.clone(), dg.clone(), db.clone()
+    whole, halves = run(False), run(True)
+    for a, b, name in zip(whole, halves, ("gz_in", "in_dsums", "dw", "dgamma", "dbeta")):
+        assert torch.equal(a, b), name
