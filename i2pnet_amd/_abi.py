@@ -83,6 +83,10 @@ DEVICE_ONLY = {
     "i2p_lin_fwd_2src_fin": ["l", "i", "i", "i", "p", "p", "f", "p", "p", "f", "p", "p", "p", "p", "p", "f", "p", "p", "p"],
     "i2p_pair_lin_fwd_fin": ["i"] * 5 + ["p"] * 7 + ["p", "p", "f", "p", "p", "p"],
     "i2p_clip_adam": ["l"] + ["p"] * 8 + ["d", "d"] + ["f"] * 4 + ["p"],
+    "i2p_row_valid": ["l", "i", "p", "p"],
+    "i2p_mask_fill": ["l", "i", "p", "p", "f", "p"],
+    "i2p_pad_cols": ["i", "i", "i", "p", "p"],
+    "i2p_strided_pick2": ["i"] * 7 + ["p"] * 4,
     "i2p_lin_bwd_part": ["l", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 5 + ["f", "i", "p"],
 }
 # plain `int f(...)` helpers without a stream argument

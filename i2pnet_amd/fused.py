@@ -117,6 +117,14 @@ def _update_running(running, idx, mi, rows):
         bn.num_batches_tracked += 1
 
 
+def _pad_cols(W, cpad):
+    """[cout, cin] -> [cout, cpad] with zero columns: one launch on the device library (F.pad: a fill and a copy)"""
+    be = ops.get_backend()
+    if be.name == "hip" and W.is_cuda and W.dtype == torch.float32 and W.is_contiguous():
+        return be.pad_cols(W, cpad)
+    return F.pad(W, (0, cpad - W.shape[1]))
+
+
 class _MlpChain(Function):
     """x [rows,c0] (raw input, or a pre-BN tensor when `first_bn`) -> act(BN(...)) of the last block.
 
@@ -152,7 +160,7 @@ class _MlpChain(Function):
         ctx.w0_cin = None
         if nl and not first_bn and x.shape[1] > p[k].shape[1]:
             ctx.w0_cin = p[k].shape[1]
-            p[k] = F.pad(p[k].detach(), (0, x.shape[1] - p[k].shape[1]))
+            p[k] = _pad_cols(p[k].detach(), x.shape[1])
         bf = chain_bf16_ok(x, first_bn, [p[k + 3 * i] for i in range(nl)])
         ctx.bf16 = bf
         for i in range(nl):
@@ -386,9 +394,9 @@ class _CvKnnTail(Function):
         x1, xe, W1, We = [t.detach().contiguous() for t in (x1, xe, W1, We)]
         ctx.cins = (W1.shape[1], We.shape[1])            # real input widths: the rows carry zero padding, the weights get it here
         if x1.shape[1] > W1.shape[1]:
-            W1 = F.pad(W1, (0, x1.shape[1] - W1.shape[1]))
+            W1 = _pad_cols(W1, x1.shape[1])
         if xe.shape[1] > We.shape[1]:
-            We = F.pad(We, (0, xe.shape[1] - We.shape[1]))
+            We = _pad_cols(We, xe.shape[1])
         y1, st1, c1, m1 = be_.lin_forward_fin(x1, None, 1.0, W1, d(g1), d(b1), _EPS)
         y2, st2, c2, m2 = be_.lin_forward_fin(y1, c1, s1, d(W2), d(g2), d(b2), _EPS)
         y3, st3, c3, m3 = be_.lin_forward_fin(y2, c2, s2, d(W3), d(g3), d(b3), _EPS)

@@ -52,10 +52,30 @@ def run_stack(x, convs, first_bn=None, pool_k=0):
     return torch.max(x, dim=-2)[0] if pool_k else x
 
 
+class _MaskFillRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, valid):
+        c = x.shape[-1]
+        v = valid.reshape(-1)
+        ctx.save_for_backward(v)
+        return ops.get_backend().mask_fill_rows(x.reshape(-1, c), v, -1e10).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (v,) = ctx.saved_tensors
+        c = g.shape[-1]
+        g2 = g.reshape(-1, c)
+        return ops.get_backend().mask_fill_rows(g2 if g2.is_contiguous() else g2.contiguous(), v, 0.0).view(g.shape), None
+
+
 def mask_fill(x, valid):
     """x*valid + (-1e10)*(1-valid) for a 0/1 mask (the reference's way of masking logits, e.g.
     modellearn_proj_center.py:318, PPBackbone_center.py:481) as one select: identical values (x*1 + -0.0 = x,
     x*0 + -1e10 = -1e10 for finite x) and identical gradient (valid), in one launch each way instead of ~8."""
+    be = ops.get_backend()
+    if (be.name == "hip" and x.is_cuda and x.dtype == torch.float32 and valid.dtype == torch.float32 and valid.shape[-1] == 1
+            and valid.numel() * x.shape[-1] == x.numel() and x.is_contiguous() and valid.is_contiguous() and not valid.requires_grad):
+        return _MaskFillRows.apply(x, valid)
     return torch.where(valid > 0, x, -1e10)
 
 
@@ -308,6 +328,18 @@ def _strided(img, stride_h, stride_w, out_h, out_w):
     return img[:, ::stride_h, ::stride_w][:, :out_h, :out_w]
 
 
+def _centres(xyz_proj, xyz_proj_raw, stride_h, stride_w, out_h, out_w):
+    """(contiguous strided centres of xyz_proj, of xyz_proj_raw): one launch for both on the device library"""
+    be = ops.get_backend()
+    if (be.name == "hip" and xyz_proj.is_cuda and xyz_proj.dtype == torch.float32 and xyz_proj_raw.dtype == torch.float32
+            and xyz_proj.shape == xyz_proj_raw.shape and xyz_proj.shape[-1] == 3 and xyz_proj.is_contiguous() and xyz_proj_raw.is_contiguous()
+            and not xyz_proj.requires_grad and not xyz_proj_raw.requires_grad
+            and (out_h - 1) * stride_h < xyz_proj.shape[1] and (out_w - 1) * stride_w < xyz_proj.shape[2]):
+        return be.strided_pick2(xyz_proj, xyz_proj_raw, out_h, out_w, stride_h, stride_w)
+    return (_strided(xyz_proj, stride_h, stride_w, out_h, out_w).contiguous(),
+            _strided(xyz_proj_raw, stride_h, stride_w, out_h, out_w).contiguous())
+
+
 class ProjectPointNet(nn.Module):
     """Set-abstraction layer on range images (PPBackbone_center.py:54-199): strided centres,
     window K-NN (fused_conv_select_k), gather, 3x(1x1 conv + BN + ReLU), max over K."""
@@ -363,8 +395,7 @@ class ProjectPointNet(nn.Module):
                 idx_n2 = P.get_stride_idx_cuda(B, self.out_h, self.out_w, self.stride_H, self.stride_W, xyz_proj.device)
                 xyz_pr = xyz_proj if self.usetrans else xyz_proj_raw
                 gidx = P.get_neighbor_copy(xyz_pr, xyz_pr, idx_n2, self.kernel_size, self.nsample, distance=self.distance)
-            c = _strided(xyz_proj, self.stride_H, self.stride_W, self.out_h, self.out_w).contiguous()
-            raw_c = _strided(xyz_proj_raw, self.stride_H, self.stride_W, self.out_h, self.out_w).contiguous()
+            c, raw_c = _centres(xyz_proj, xyz_proj_raw, self.stride_H, self.stride_W, self.out_h, self.out_w)
             rows = P.sa_rows(src, raw_c if raw_feat_point else c, feature_proj, gidx[1], gidx[2], self.nsample, self.W)
             # (grouped_xyz, the 4th output, is not materialised on this path: the network never reads it)
             return raw_c, c, self._mlp_max(rows, B), None, sample_idx
@@ -390,8 +421,7 @@ class ProjectPointNet(nn.Module):
                 feat = be.sa_l1_group(xyz_proj.contiguous(), (xyz_proj_raw if raw_feat_point else xyz_proj).contiguous(), self.out_h,
                                       self.out_w, self.stride_H, self.stride_W, self.kernel_size[0], self.kernel_size[1],
                                       self.nsample, self.distance)
-            raw_c = _strided(xyz_proj_raw, self.stride_H, self.stride_W, self.out_h, self.out_w).contiguous()
-            c = _strided(xyz_proj, self.stride_H, self.stride_W, self.out_h, self.out_w).contiguous()
+            c, raw_c = _centres(xyz_proj, xyz_proj_raw, self.stride_H, self.stride_W, self.out_h, self.out_w)
             # (grouped_xyz, the 4th output, is not materialised on this path: the network never reads it)
             return raw_c, c, self._mlp_max(feat, B), None, sample_idx
         raw_c, c, grouped_xyz, norm, gidx, sample_idx = self._centres_and_groups(xyz_proj_raw, xyz_proj, sample_idx,

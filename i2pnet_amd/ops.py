@@ -872,6 +872,40 @@ class CBackend:
                    stream=self._stream())
         return loss3, d3, d4, d_w
 
+    # ---- small glue kernels (csrc/glue.hip; device library only) -------------------------------------------------
+    def row_valid(self, x):
+        """x [..., c] -> 0/1 float [..., 1]: any(x != 0) over the last axis (check_valid)"""
+        c = x.shape[-1]
+        x2 = x.reshape(-1, c)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        out = torch.empty(x2.shape[0], dtype=_F32, device=x.device)
+        self._call("i2p_row_valid", int(x2.shape[0]), int(c), self._p(x2, _F32, "x"), self._p(out, _F32, "out"), stream=self._stream())
+        return out.view(*x.shape[:-1], 1)
+
+    def mask_fill_rows(self, x2, valid, fill):
+        """x2 [rows, c], valid [rows] -> valid > 0 ? x : fill"""
+        out = torch.empty_like(x2)
+        self._call("i2p_mask_fill", int(x2.shape[0]), int(x2.shape[1]), self._p(x2, _F32, "x"), self._p(valid, _F32, "valid"), float(fill),
+                   self._p(out, _F32, "out"), stream=self._stream())
+        return out
+
+    def pad_cols(self, w, cpad):
+        out = torch.empty(w.shape[0], cpad, dtype=_F32, device=w.device)
+        self._call("i2p_pad_cols", int(w.shape[0]), int(w.shape[1]), int(cpad), self._p(w, _F32, "w"), self._p(out, _F32, "out"),
+                   stream=self._stream())
+        return out
+
+    def strided_pick2(self, a, b, oh, ow, sh, sw):
+        """a, b [B,H,W,3] (b may be None) -> the [B,oh,ow,3] tensors of their cells (h*sh, w*sw)"""
+        B, H, W, _ = a.shape
+        oa = torch.empty(B, oh, ow, 3, dtype=_F32, device=a.device)
+        ob = torch.empty(B, oh, ow, 3, dtype=_F32, device=a.device) if b is not None else None
+        self._call("i2p_strided_pick2", int(B), int(H), int(W), int(oh), int(ow), int(sh), int(sw), self._p(a, _F32, "a"),
+                   self._p(b, _F32, "b") if b is not None else None, self._p(oa, _F32, "oa"), self._p(ob, _F32, "ob") if b is not None else None,
+                   stream=self._stream())
+        return oa, ob
+
     def bn_finalize(self, rows, sums, gamma, beta, eps):
         """-> (coef [3,c] = mean, invstd*gamma, beta ; mean_invstd [2c])"""
         c = gamma.shape[0]

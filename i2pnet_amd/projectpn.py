@@ -253,6 +253,9 @@ def get_neighbor_att(xyz1_proj, xyz2_proj, idx_n2, kernel_shape, knn_points, str
 
 def check_valid(xyz):
     """1.0 where the point is not the all-zero "empty cell" marker (utils.py:106-108)."""
+    be = ops.get_backend()
+    if be.name == "hip" and xyz.is_cuda and xyz.dtype == torch.float32:
+        return be.row_valid(xyz.detach())                  # one launch instead of ne + any + cast
     return torch.any(torch.ne(xyz, 0), dim=-1, keepdim=True).float()
 
 

@@ -498,6 +498,19 @@ int i2p_clip_adam(long long n, float *param, float *grad, float *exp_avg, float 
                   float *step, const float *lr, double beta1, double beta2, float eps, float weight_decay, float clip, float gscale,
                   float *total_out, void *stream);
 
+/* One-launch replacements for clusters of small elementwise launches (csrc/glue.hip).
+ * i2p_row_valid: out[r] = 1.0 if any x[r, 0..c) != 0 else 0.0 — check_valid (src/projectPN/utils.py:106-108).
+ * i2p_mask_fill: out[r, :] = valid[r] > 0 ? x[r, :] : fill — the reference's x*valid + (-1e10)*(1-valid) for a 0/1 row mask
+ *   (modellearn_proj_center.py:318,376, PPBackbone_center.py:481); its backward is the same call on the gradient with fill = 0.
+ * i2p_pad_cols: out [rows, cpad] = [w [rows, c], zeros].
+ * i2p_strided_pick2: oa[b,h,w,:] = a[b, h*sh, w*sw, :] (ob from b unless b is NULL), [B,H,W,3] -> [B,oh,ow,3] —
+ *   the strided centre picks of a set-abstraction level (PPBackbone_center.py:94-95). */
+int i2p_row_valid(long long rows, int c, const float *x, float *out, void *stream);
+int i2p_mask_fill(long long rows, int c, const float *x, const float *valid, float fill, float *out, void *stream);
+int i2p_pad_cols(int rows, int c, int cpad, const float *w, float *out, void *stream);
+int i2p_strided_pick2(int B, int H, int W, int oh, int ow, int sh, int sw, const float *a, const float *b, float *oa, float *ob,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,8 +133,10 @@ def test_pair_fwd_pixel_stationary_matches_row_order_kernel(B, N, M, monkeypatch
     y0, s0 = hip.pair_lin_forward(f, g, bn, bk, w, out_dtype=BF)
     monkeypatch.delenv("I2P_NO_PAIR_PS")
     torch.cuda.synchronize()
-    assert torch.equal(y1.view(torch.int16), y0.view(torch.int16))
-    assert torch.allclose(_sums(s1), _sums(s0), rtol=1e-12, atol=1e-9)
+    assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)), float((y1.float() - y0.float()).abs().max())
+    # (per-lane fp32 partial sums over the rows of a strip before the fp64 accumulation: the two kernels group rows differently)
+    assert torch.allclose(_sums(s1), _sums(s0), rtol=1e-5, atol=1e-2)
+    assert torch.allclose(_sums(s1)[0], y1.double().sum(0), rtol=1e-6, atol=1e-3)
 
 
 def _g_of(gz, y, coef, mi, dsums_rep, rows, slope_out):
