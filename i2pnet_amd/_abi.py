@@ -84,6 +84,8 @@ DEVICE_ONLY = {
     "i2p_pair_lin_fwd_fin": ["i"] * 5 + ["p"] * 7 + ["p", "p", "f", "p", "p", "p"],
     "i2p_clip_adam": ["l"] + ["p"] * 8 + ["d", "d"] + ["f"] * 4 + ["p"],
     "i2p_row_valid": ["l", "i", "p", "p"],
+    "i2p_max_response_fwd": ["i"] * 4 + ["p"] * 7,
+    "i2p_max_response_bwd": ["i"] * 4 + ["p"] * 7,
     "i2p_mask_fill": ["l", "i", "p", "p", "f", "p"],
     "i2p_pad_cols": ["i", "i", "i", "p", "p"],
     "i2p_strided_pick2": ["i"] * 7 + ["p"] * 4,

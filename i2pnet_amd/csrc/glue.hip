@@ -54,7 +54,108 @@ __global__ __launch_bounds__(256) void strided_pick2_kernel(int B, int H, int W,
     if (b) ob[t] = b[src];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward-validation feature of the first cost volume (PPBackbone_center.py:408-414): respond[b,k,c] = max over the valid
+// points n of pts[b,n,c] * pix[b,k,c], in closed form — for a fixed pixel value g the maximum of fl(f_n * g) is
+// fl(g * max_n f_n) if g >= 0 else fl(g * min_n f_n) (rounding is monotone) — -1e10 when the sample has no valid point.
+// The torch formulation is 18 launches forward and 14 backward on [8,468,128] tensors; here one launch each way:
+// a block owns (sample, 32 channels): it reduces max / min (+ arg) over the points, then streams the pixels.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int MR_CH = 32, MR_ROWS = 8;      // 256 threads = 8 row lanes x 32 channels
+
+__global__ __launch_bounds__(256) void maxresp_fwd_kernel(int N, int M, int C, const float *__restrict__ pts, const float *__restrict__ pix,
+                                                          const float *__restrict__ valid, float *__restrict__ respond,
+                                                          float *__restrict__ fmaxmin, int *__restrict__ imaxmin, int *__restrict__ anyv) {
+    __shared__ float smax[MR_ROWS][MR_CH], smin[MR_ROWS][MR_CH];
+    __shared__ int simax[MR_ROWS][MR_CH], simin[MR_ROWS][MR_CH], sany[MR_ROWS][MR_CH];
+    const int b = blockIdx.x, c0 = blockIdx.y * MR_CH, ch = threadIdx.x & (MR_CH - 1), r = threadIdx.x >> 5;
+    const int c = c0 + ch;
+    float vmax = -INFINITY, vmin = INFINITY; int imax = 0, imin = 0, any = 0;
+    if (c < C)
+        for (int n = r; n < N; n += MR_ROWS) {
+            if (valid[(size_t)b * N + n] > 0.f) {
+                const float v = pts[((size_t)b * N + n) * C + c];
+                any = 1;
+                if (v > vmax) { vmax = v; imax = n; }            // first maximum in point order within this lane's rows
+                if (v < vmin) { vmin = v; imin = n; }
+            }
+        }
+    smax[r][ch] = vmax; smin[r][ch] = vmin; simax[r][ch] = imax; simin[r][ch] = imin; sany[r][ch] = any;
+    __syncthreads();
+    // combine the 8 row lanes (lowest point index wins ties, like a serial scan)
+    vmax = smax[0][ch]; vmin = smin[0][ch]; imax = simax[0][ch]; imin = simin[0][ch]; any = sany[0][ch];
+#pragma unroll
+    for (int q = 1; q < MR_ROWS; ++q) {
+        const float a = smax[q][ch], d = smin[q][ch];
+        if (a > vmax || (a == vmax && simax[q][ch] < imax && sany[q][ch])) { vmax = a; imax = simax[q][ch]; }
+        if (d < vmin || (d == vmin && simin[q][ch] < imin && sany[q][ch])) { vmin = d; imin = simin[q][ch]; }
+        any |= sany[q][ch];
+    }
+    if (!any) { vmax = 0.f; vmin = 0.f; imax = imin = 0; }
+    if (c < C && r == 0) {
+        fmaxmin[((size_t)b * 2 + 0) * C + c] = vmax; fmaxmin[((size_t)b * 2 + 1) * C + c] = vmin;
+        imaxmin[((size_t)b * 2 + 0) * C + c] = imax; imaxmin[((size_t)b * 2 + 1) * C + c] = imin;
+        if (blockIdx.y == 0 && ch == 0) anyv[b] = any;
+    }
+    if (c >= C) return;
+    for (int k = r; k < M; k += MR_ROWS) {
+        const float g = pix[((size_t)b * M + k) * C + c];
+        respond[((size_t)b * M + k) * C + c] = any ? g * (g >= 0.f ? vmax : vmin) : -1e10f;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxresp_bwd_kernel(int N, int M, int C, const float *__restrict__ g, const float *__restrict__ pix,
+                                                          const float *__restrict__ fmaxmin, const int *__restrict__ imaxmin,
+                                                          const int *__restrict__ anyv, float *__restrict__ d_pts, float *__restrict__ d_pix) {
+    __shared__ float s1[MR_ROWS][MR_CH], s2[MR_ROWS][MR_CH];
+    const int b = blockIdx.x, c0 = blockIdx.y * MR_CH, ch = threadIdx.x & (MR_CH - 1), r = threadIdx.x >> 5;
+    const int c = c0 + ch;
+    const bool any = anyv[b] != 0;
+    float dmax = 0.f, dmin = 0.f;
+    if (c < C) {
+        const float vmax = fmaxmin[((size_t)b * 2 + 0) * C + c], vmin = fmaxmin[((size_t)b * 2 + 1) * C + c];
+        for (int k = r; k < M; k += MR_ROWS) {
+            const size_t o = ((size_t)b * M + k) * C + c;
+            const float gv = any ? g[o] : 0.f, pv = pix[o];
+            const bool pos = pv >= 0.f;
+            d_pix[o] = gv * (pos ? vmax : vmin);
+            const float t = gv * pv;
+            if (pos) dmax += t; else dmin += t;
+        }
+        for (int n = r; n < N; n += MR_ROWS) d_pts[((size_t)b * N + n) * C + c] = 0.f;     // this block owns d_pts[b, :, c0..c0+32)
+    }
+    s1[r][ch] = dmax; s2[r][ch] = dmin;
+    __syncthreads();
+    if (r == 0 && c < C) {
+        float a = 0.f, d = 0.f;
+#pragma unroll
+        for (int q = 0; q < MR_ROWS; ++q) { a += s1[q][ch]; d += s2[q][ch]; }
+        const int imax = imaxmin[((size_t)b * 2 + 0) * C + c], imin = imaxmin[((size_t)b * 2 + 1) * C + c];
+        // (the zero fill above was done by other threads of this block: ordered by the barrier; both rows may coincide)
+        d_pts[((size_t)b * N + imax) * C + c] += a;
+        d_pts[((size_t)b * N + imin) * C + c] += d;
+    }
+}
+
 }  // namespace
+
+// pts [B,N,C], pix [B,M,C], valid [B,N] (0/1) -> respond [B,M,C]; saves fmaxmin [B,2,C], imaxmin i32 [B,2,C], anyv i32 [B]
+extern "C" int i2p_max_response_fwd(int B, int N, int M, int C, const float *pts, const float *pix, const float *valid, float *respond,
+                                    float *fmaxmin, int *imaxmin, int *anyv, void *stream) {
+    if (B <= 0 || N <= 0 || M <= 0 || C <= 0 || !pts || !pix || !valid || !respond || !fmaxmin || !imaxmin || !anyv) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(maxresp_fwd_kernel, dim3(B, (C + MR_CH - 1) / MR_CH), dim3(256), 0, (hipStream_t)stream, N, M, C, pts, pix, valid, respond,
+                       fmaxmin, imaxmin, anyv);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+// g = dL/drespond [B,M,C] -> d_pts [B,N,C] (written completely), d_pix [B,M,C]
+extern "C" int i2p_max_response_bwd(int B, int N, int M, int C, const float *g, const float *pix, const float *fmaxmin, const int *imaxmin,
+                                    const int *anyv, float *d_pts, float *d_pix, void *stream) {
+    if (B <= 0 || N <= 0 || M <= 0 || C <= 0 || !g || !pix || !fmaxmin || !imaxmin || !anyv || !d_pts || !d_pix) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(maxresp_bwd_kernel, dim3(B, (C + MR_CH - 1) / MR_CH), dim3(256), 0, (hipStream_t)stream, N, M, C, g, pix, fmaxmin, imaxmin,
+                       anyv, d_pts, d_pix);
+    I2P_RETURN_LAUNCH_STATUS();
+}
 
 extern "C" int i2p_row_valid(long long rows, int c, const float *x, float *out, void *stream) {
     if (rows < 0 || c <= 0) return I2P_ERR_BAD_ARG;

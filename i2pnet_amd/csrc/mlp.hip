@@ -1992,7 +1992,8 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
     {   // second-generation path: separate dgrad (lin_fwd2 DGRAD) and wgrad kernels
         auto pow2w = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
         const char *gen = getenv("I2P_LIN_BWD_GEN");
-        const bool dgrad_ok = !gz_in || (pow2w(cin) && pow2w(cout));
+        // (part 2 = the wgrad half of a split call: the kernel family is the one the WHOLE call — with its input gradient — lands on)
+        const bool dgrad_ok = (!gz_in && part != 2) || (pow2w(cin) && pow2w(cout));
         const size_t wg_lds = (2 * (size_t)WG_R * (p.cout_p + p.cin_p) + 6 * (size_t)cout + 3 * (size_t)cin) * sizeof(float);
         const bool gen2 = !pair && !(gen && gen[0] == '1') && dgrad_ok && pow2w(cout) && wg_lds <= 160 * 1024 && cin <= 160;
         if (two && !(gen2 && pow2w(cin))) return I2P_ERR_BAD_ARG;

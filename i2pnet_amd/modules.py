@@ -562,6 +562,32 @@ class _MaxResponse(torch.autograd.Function):
         return d_pts, d_pix, None
 
 
+class _MaxResponseFused(torch.autograd.Function):
+    """`_MaxResponse` as one launch each way (csrc/glue.hip i2p_max_response_fwd/bwd)"""
+
+    @staticmethod
+    def forward(ctx, pts, pix, valid):
+        be = ops.get_backend()
+        pts, pix = pts.contiguous(), pix.contiguous()
+        respond, fm, im, anyv = be.max_response_forward(pts.detach(), pix.detach(), valid.detach().reshape(pts.shape[0], pts.shape[1]).contiguous())
+        ctx.save_for_backward(pix, fm, im, anyv)
+        ctx.n_points = pts.shape[1]
+        return respond
+
+    @staticmethod
+    def backward(ctx, g):
+        pix, fm, im, anyv = ctx.saved_tensors
+        d_pts, d_pix = ops.get_backend().max_response_backward(g.contiguous(), pix, fm, im, anyv, ctx.n_points)
+        return d_pts, d_pix, None
+
+
+def max_response(pts, pix, valid):
+    be = ops.get_backend()
+    if be.name == "hip" and pts.is_cuda and pts.dtype == torch.float32 and pix.dtype == torch.float32 and os.environ.get("I2P_NO_MAXRESP") != "1":
+        return _MaxResponseFused.apply(pts, pix, valid)
+    return _MaxResponse.apply(pts, pix, valid)
+
+
 class CostVolume(nn.Module):
     """2D-3D cost volume (PPBackbone_center.py:306-503).
 
@@ -613,7 +639,7 @@ class CostVolume(nn.Module):
             # (rounding is monotone), taken over valid points; -1e10 if no point is valid.  Avoids
             # three passes over the [B,N,M,C] tensor; the gradient still reaches the arg-max/min point.
             valid = P.check_valid(xyz) if self.mask_invalid else torch.ones_like(xyz[:, :, :1])
-            respond = _MaxResponse.apply(pts_n, pix_n, valid)                   # [B,M,C]
+            respond = max_response(pts_n, pix_n, valid)                         # [B,M,C]
             per_pixel = per_pixel + linear(respond, w_parts[3])
         B_, N_ = pts_n.shape[0], pts_n.shape[1]
         we_parts = torch.split(self.pi_encoding.weight2d(), [3, 3], dim=1)

@@ -906,6 +906,27 @@ class CBackend:
                    stream=self._stream())
         return oa, ob
 
+    def max_response_forward(self, pts, pix, valid):
+        """pts [B,N,C], pix [B,M,C], valid [B,N] -> (respond [B,M,C], fmaxmin [B,2,C], imaxmin i32 [B,2,C], anyv i32 [B])"""
+        B, N, Cc = pts.shape
+        M = pix.shape[1]
+        dev = pts.device
+        respond = torch.empty(B, M, Cc, dtype=_F32, device=dev)
+        fm = torch.empty(B, 2, Cc, dtype=_F32, device=dev); im = torch.empty(B, 2, Cc, dtype=_I32, device=dev)
+        anyv = torch.empty(B, dtype=_I32, device=dev)
+        self._call("i2p_max_response_fwd", int(B), int(N), int(M), int(Cc), self._p(pts, _F32, "pts"), self._p(pix, _F32, "pix"),
+                   self._p(valid, _F32, "valid"), self._p(respond, _F32, "respond"), self._p(fm, _F32, "fmaxmin"), self._p(im, _I32, "imaxmin"),
+                   self._p(anyv, _I32, "anyv"), stream=self._stream())
+        return respond, fm, im, anyv
+
+    def max_response_backward(self, g, pix, fm, im, anyv, N):
+        B, M, Cc = pix.shape
+        d_pts = torch.empty(B, N, Cc, dtype=_F32, device=g.device); d_pix = torch.empty_like(pix)
+        self._call("i2p_max_response_bwd", int(B), int(N), int(M), int(Cc), self._p(g, _F32, "g"), self._p(pix, _F32, "pix"),
+                   self._p(fm, _F32, "fmaxmin"), self._p(im, _I32, "imaxmin"), self._p(anyv, _I32, "anyv"), self._p(d_pts, _F32, "d_pts"),
+                   self._p(d_pix, _F32, "d_pix"), stream=self._stream())
+        return d_pts, d_pix
+
     def bn_finalize(self, rows, sums, gamma, beta, eps):
         """-> (coef [3,c] = mean, invstd*gamma, beta ; mean_invstd [2c])"""
         c = gamma.shape[0]

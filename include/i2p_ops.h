@@ -505,6 +505,15 @@ int i2p_clip_adam(long long n, float *param, float *grad, float *exp_avg, float 
  * i2p_pad_cols: out [rows, cpad] = [w [rows, c], zeros].
  * i2p_strided_pick2: oa[b,h,w,:] = a[b, h*sh, w*sw, :] (ob from b unless b is NULL), [B,H,W,3] -> [B,oh,ow,3] —
  *   the strided centre picks of a set-abstraction level (PPBackbone_center.py:94-95). */
+/* Backward-validation feature of the first cost volume in closed form (PPBackbone_center.py:408-414): respond[b,k,c] = max over
+ * the valid points n of pts[b,n,c]*pix[b,k,c] = pix * (pix >= 0 ? max_n pts : min_n pts), -1e10 if the sample has no valid point.
+ * pts f32 [B,N,C], pix f32 [B,M,C], valid f32 [B,N] (0/1) -> respond f32 [B,M,C]; for the backward: fmaxmin f32 [B,2,C], imaxmin
+ * i32 [B,2,C] (arg-max / arg-min point, lowest index on ties), anyv i32 [B].  Backward: g = dL/drespond -> d_pts [B,N,C] (the
+ * gradient reaches the arg-max / arg-min point, as torch.max's does; written completely), d_pix [B,M,C]. */
+int i2p_max_response_fwd(int B, int N, int M, int C, const float *pts, const float *pix, const float *valid, float *respond,
+                         float *fmaxmin, int *imaxmin, int *anyv, void *stream);
+int i2p_max_response_bwd(int B, int N, int M, int C, const float *g, const float *pix, const float *fmaxmin, const int *imaxmin,
+                         const int *anyv, float *d_pts, float *d_pix, void *stream);
 int i2p_row_valid(long long rows, int c, const float *x, float *out, void *stream);
 int i2p_mask_fill(long long rows, int c, const float *x, const float *valid, float fill, float *out, void *stream);
 int i2p_pad_cols(int rows, int c, int cpad, const float *w, float *out, void *stream);

@@ -940,3 +940,147 @@ def test_lin_bwd_split_halves_match_whole(hip_backend, monkeypatch, rows, cin, c
     whole, halves = run(False), run(True)
     for a, b, name in zip(whole, halves, ("gz_in", "in_dsums", "dw", "dgamma", "dbeta")):
         assert torch.equal(a, b), name
+
+
+# ---- device-only fused entries against the CPU ORACLE chain they replace (not against another HIP path) ----------------------
+def _on_oracle(oracle_backend, fn):
+    from i2pnet_amd import ops
+    prev = ops.set_backend(oracle_backend)
+    try:
+        return fn()
+    finally:
+        ops.set_backend(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("xyz_first", [True, False])
+def test_sa_rows_full_size_vs_oracle_chain(hip_backend, oracle_backend, xyz_first):
+    """i2p_sa_rows at the level-2 size (16 x 225 image, 904 centres x 16 neighbours, 32 channels) against the oracle chain:
+    fused_conv_select_k_cpu -> gather_rows_cpu x2 -> subtraction -> zero-padded cat (PPBackbone_center.py:94-129); forward rows
+    bit-exact, feature gradient (fixed-point scatter on the device, gather_rows_grad_cpu in the oracle) to fp32 rounding."""
+    from i2pnet_amd import modules, projectpn as P
+    B, H, W, C, oh, ow, K = 2, 16, 225, 32, 8, 113, 16
+    img = range_image(B, H, W, seed=5, empty_frac=0.4, scale=8.0)
+    feat = torch.randn(B, H, W, C, generator=torch.Generator().manual_seed(6))
+    idx = stride_grid(B, oh, ow, 2, 2)
+    centre = img[:, ::2, ::2][:, :oh, :ow].reshape(B, oh * ow, 3).contiguous()
+    gout = torch.randn(B, oh * ow, K, 128, generator=torch.Generator().manual_seed(7))
+
+    def chain():
+        f = feat.clone().requires_grad_(True)
+        sb, sh, sw, m, _, _ = run_fcsk(oracle_backend, img, img, idx, 9, 15, K, 3, 3.0, 1, 1)
+        d = P.gather_torch(img, None, sh.squeeze(-1), sw.squeeze(-1), B, H, W) - centre.view(B, -1, 1, 3)
+        f2 = P.gather_torch(f, None, sh.squeeze(-1), sw.squeeze(-1), B, H, W)
+        rows = modules.cat_padded([d, f2] if xyz_first else [f2, d], pow2=True)
+        (gf,) = torch.autograd.grad(rows, f, gout[..., :rows.shape[-1]])
+        return rows, gf, sh.squeeze(-1), sw.squeeze(-1)
+    want, want_g, sh, sw = _on_oracle(oracle_backend, chain)
+    f = feat.to(DEV).requires_grad_(True)
+    rows = P.sa_rows(img.to(DEV), centre.to(DEV), f, sh.to(DEV), sw.to(DEV), K, W, xyz_first=xyz_first)
+    assert rows.shape == want.shape and torch.equal(rows.cpu(), want)
+    (gf,) = torch.autograd.grad(rows, f, gout[..., :rows.shape[-1]].to(DEV))
+    assert float((gf.cpu() - want_g).abs().max()) <= 2e-6 * float(want_g.abs().max()) + 1e-6
+
+
+@pytest.mark.gpu
+def test_knn_rows_full_size_vs_oracle_chain(hip_backend, oracle_backend):
+    """i2p_knn_rows_fwd/bwd at the fine cost volume's size (228 points x 32 nearest of 468 pixels, 128 channels) against the
+    oracle chain: knn_cpu -> group_points_cpu gathers -> product -> cat (PPBackbone_center.py:367-395)."""
+    from i2pnet_amd import projectpn as P
+    from i2pnet_amd.modules import cat_padded
+    B, N, M, K, C = 2, 228, 468, 32, 128
+    g = torch.Generator().manual_seed(31)
+    xyz = torch.randn(B, N, 3, generator=g); pix_xyz = torch.randn(B, M, 3, generator=g)
+    pts = torch.randn(B, N, C, generator=g); pix = torch.randn(B, M, C, generator=g)
+    cpad = (6 + C + 3) // 4 * 4
+    go = torch.randn(B, N, K, cpad, generator=g)
+
+    def chain():
+        a, b, c = xyz.clone().requires_grad_(True), pts.clone().requires_grad_(True), pix.clone().requires_grad_(True)
+        idx = P.knn_point(K, pix_xyz, xyz)
+        own = a.unsqueeze(2).expand(-1, -1, K, -1)
+        rows = cat_padded([own, P.index_points_group(pix_xyz, idx), b.unsqueeze(2) * P.index_points_group(c, idx)])
+        return (rows, idx) + torch.autograd.grad(rows, (a, b, c), go)
+    want, idx, wa, wb, wc = _on_oracle(oracle_backend, chain)
+    a, b, c = xyz.to(DEV).requires_grad_(True), pts.to(DEV).requires_grad_(True), pix.to(DEV).requires_grad_(True)
+    idx_d = P.knn_point(K, pix_xyz.to(DEV), xyz.to(DEV))
+    assert torch.equal(idx_d.cpu(), idx)
+    rows = P.knn_rows(a, pix_xyz.to(DEV), b, c, idx_d, cpad)
+    assert torch.equal(rows.cpu(), want)
+    for got, ref in zip(torch.autograd.grad(rows, (a, b, c), go.to(DEV)), (wa, wb, wc)):
+        assert float((got.cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-6
+
+
+@pytest.mark.gpu
+def test_cv_tail_kernels_vs_cpu_float64(hip_backend):
+    """i2p_outer_sum and the softmax-weighted-sum kernels against plain CPU restatements in fp64 (PPBackbone_center.py:423-433,
+    :481-487): position-encoding rows bit-exact (one fp32 addition), softmax tail to 1e-6."""
+    from i2pnet_amd import fused
+    g = torch.Generator().manual_seed(77)
+    B, N, M, C = 2, 57, 468, 64
+    en, ek = torch.randn(B, N, C, generator=g), torch.randn(B, M, C, generator=g)
+    ye, sums = hip_backend.outer_sum(en.to(DEV), ek.to(DEV))
+    want = (en.unsqueeze(2) + ek.unsqueeze(1)).reshape(B * N * M, C)
+    assert torch.equal(ye.cpu(), want)
+    s = sums.cpu().view(-1, 2, C).sum(0)
+    assert torch.allclose(s[0], want.double().sum(0), rtol=1e-9, atol=1e-6) and torch.allclose(s[1], want.double().square().sum(0), rtol=1e-9, atol=1e-6)
+    K = 4
+    logit = torch.randn(B, N, K, C, generator=g); logit[0, 0] = -1e10; logit[0, 1, 1:] = -1e10
+    value = torch.randn(B, N, K, C, generator=g); go = torch.randn(B, N, C, generator=g)
+    ld, vd = logit.double().requires_grad_(True), value.double().requires_grad_(True)
+    ref = torch.sum(torch.softmax(ld, dim=2) * vd, dim=2)
+    rl, rv = torch.autograd.grad(ref, (ld, vd), go.double())
+    l, v = logit.to(DEV).requires_grad_(True), value.to(DEV).requires_grad_(True)
+    out = fused.softmax_wsum_k(l, v)
+    gl, gv = torch.autograd.grad(out, (l, v), go.to(DEV))
+    for a, b in ((out, ref), (gl, rl), (gv, rv)):
+        assert float((a.cpu().double() - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-7
+
+
+@pytest.mark.gpu
+def test_glue_kernels_vs_cpu(hip_backend):
+    """csrc/glue.hip against the torch expressions of the reference they replace, evaluated on the CPU: check_valid
+    (utils.py:106-108), the -1e10 mask fill and its gradient (modellearn_proj_center.py:318), zero-padded weights, strided
+    centre picks (PPBackbone_center.py:94-95)."""
+    from i2pnet_amd import modules, projectpn as P
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 37, 3, generator=g); x[0, :5] = 0.0; x[1, 7, :2] = 0.0; x[2, 9] = torch.tensor([0.0, -0.0, 0.0])
+    assert torch.equal(P.check_valid(x.to(DEV)).cpu(), torch.any(torch.ne(x, 0), dim=-1, keepdim=True).float())
+    for c in (64, 6):
+        a = torch.randn(4, 29, c, generator=g); valid = (torch.rand(4, 29, 1, generator=g) > 0.4).float(); go = torch.randn(4, 29, c, generator=g)
+        ad = a.to(DEV).requires_grad_(True)
+        out = modules.mask_fill(ad, valid.to(DEV))
+        (ga,) = torch.autograd.grad(out, ad, go.to(DEV))
+        ar = a.clone().requires_grad_(True)
+        ref = ar * valid + (-1e10) * (1.0 - valid)                                          # the reference's formulation
+        (gr,) = torch.autograd.grad(ref, ar, go)
+        assert torch.equal(out.cpu(), ref.detach()) and torch.equal(ga.cpu(), gr)
+    w = torch.randn(128, 131, generator=g)
+    assert torch.equal(hip_backend.pad_cols(w.to(DEV), 132).cpu(), torch.nn.functional.pad(w, (0, 1)))
+    ia, ib = torch.randn(2, 21, 1800, 3, generator=g), torch.randn(2, 21, 1800, 3, generator=g)
+    oa, ob = modules._centres(ia.to(DEV), ib.to(DEV), 2, 8, 11, 225)
+    assert torch.equal(oa.cpu(), ia[:, ::2, ::8][:, :11, :225]) and torch.equal(ob.cpu(), ib[:, ::2, ::8][:, :11, :225])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,M,C,empty", [(8, 228, 468, 128, False), (2, 57, 80, 64, True), (1, 9, 33, 20, False)])
+def test_max_response_fused_vs_torch_cpu(hip_backend, B, N, M, C, empty):
+    """i2p_max_response_fwd/bwd against the torch formulation of modules._MaxResponse evaluated on the CPU (itself the closed form of
+    PPBackbone_center.py:408-414): values bit-exact (one product per element), gradients to fp32 summation order; a sample without
+    any valid point (-1e10 everywhere, zero gradients) included."""
+    from i2pnet_amd import modules
+    g = torch.Generator().manual_seed(B * N + C)
+    pts, pix = torch.randn(B, N, C, generator=g), torch.randn(B, M, C, generator=g)
+    valid = (torch.rand(B, N, 1, generator=g) > 0.3).float()
+    if empty:
+        valid[0] = 0.0
+    go = torch.randn(B, M, C, generator=g)
+    a, b = pts.clone().requires_grad_(True), pix.clone().requires_grad_(True)
+    ref = modules._MaxResponse.apply(a, b, valid)
+    ra, rb = torch.autograd.grad(ref, (a, b), go)
+    ad, bd = pts.to(DEV).requires_grad_(True), pix.to(DEV).requires_grad_(True)
+    out = modules.max_response(ad, bd, valid.to(DEV))
+    ga, gb = torch.autograd.grad(out, (ad, bd), go.to(DEV))
+    assert torch.equal(out.cpu(), ref.detach())
+    assert torch.equal(gb.cpu(), rb)
+    assert float((ga.cpu() - ra).abs().max()) <= 1e-5 * float(ra.abs().max()) + 1e-6
