@@ -83,6 +83,8 @@ DEVICE_ONLY = {
     "i2p_lin_fwd_2src_fin": ["l", "i", "i", "i", "p", "p", "f", "p", "p", "f", "p", "p", "p", "p", "p", "f", "p", "p", "p"],
     "i2p_pair_lin_fwd_fin": ["i"] * 5 + ["p"] * 7 + ["p", "p", "f", "p", "p", "p"],
     "i2p_clip_adam": ["l"] + ["p"] * 8 + ["d", "d"] + ["f"] * 4 + ["p"],
+    "i2p_img_bn_stats_fin": ["i", "i", "i", "i", "p", "p", "p", "f", "f", "p", "p", "p", "p"],
+    "i2p_img_bn_pool_bwd_fin": ["i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "f", "p", "p", "p", "p", "p"],
     "i2p_row_valid": ["l", "i", "p", "p"],
     "i2p_max_response_fwd": ["i"] * 4 + ["p"] * 7,
     "i2p_max_response_bwd": ["i"] * 4 + ["p"] * 7,

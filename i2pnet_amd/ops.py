@@ -412,13 +412,23 @@ class CBackend:
         updates the running buffers in place when given."""
         B, H, W, Cc = y.shape
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-        sums = self.bn_stats(y.view(B * H * W, Cc))
         out = torch.empty(B, Ho, Wo, Cc, dtype=_F32, device=y.device)
         arg = torch.empty(B, Ho, Wo, Cc, dtype=torch.uint8, device=y.device)
         mean_invstd = torch.empty(2 * Cc, dtype=_F32, device=y.device)
         opt = lambda t, what: self._p(t, _F32, what) if t is not None else None
+        if self.name == "hip" and os.environ.get("I2P_NO_IMG_FIN") != "1":
+            # statistics + finalisation (mean / invstd / running buffers) in one launch: the last block finalises
+            sums = zeros(BN_REPLICAS * 2 * Cc + 1, torch.float64, y.device)      # (+1: the ticket word)
+            ticket = sums[BN_REPLICAS * 2 * Cc:].view(torch.int32)[:1]
+            self._call("i2p_img_bn_stats_fin", int(B), int(H), int(W), int(Cc), self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums"),
+                       self._p(ticket, torch.int32, "ticket"), float(eps), float(momentum), opt(conv_bias, "conv_bias"),
+                       opt(running_mean, "running_mean"), opt(running_var, "running_var"), self._p(mean_invstd, _F32, "mean_invstd"),
+                       stream=self._stream())
+            sums = None
+        else:
+            sums = self.bn_stats(y.view(B * H * W, Cc))
         self._call("i2p_img_bn_pool_fwd", int(B), int(H), int(W), int(Cc), int(stride), self._p(y, _F32, "y"),
-                   self._p(sums, torch.float64, "sums"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"),
+                   self._p(sums, torch.float64, "sums") if sums is not None else None, self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"),
                    float(eps), float(slope), float(momentum), opt(conv_bias, "conv_bias"),
                    opt(running_mean, "running_mean"), opt(running_var, "running_var"), self._p(out, _F32, "out"),
                    self._p(arg, torch.uint8, "arg"), self._p(mean_invstd, _F32, "mean_invstd"), stream=self._stream())
@@ -430,12 +440,18 @@ class CBackend:
         dy = torch.empty_like(y)
         dgamma = torch.empty(Cc, dtype=_F32, device=y.device)
         dbeta = torch.empty(Cc, dtype=_F32, device=y.device)
-        dsums = zeros(BN_REPLICAS * 2 * Cc, torch.float64, y.device)
-        self._call("i2p_img_bn_pool_bwd", int(B), int(H), int(W), int(Cc), int(stride), self._p(gout, _F32, "gout"),
-                   self._p(arg, torch.uint8, "arg"), self._p(y, _F32, "y"), self._p(mean_invstd, _F32, "mean_invstd"),
-                   self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(slope),
-                   self._p(dsums, torch.float64, "dsums"), self._p(dy, _F32, "dy"), self._p(dgamma, _F32, "dgamma"),
-                   self._p(dbeta, _F32, "dbeta"), stream=self._stream())
+        fin = self.name == "hip" and os.environ.get("I2P_NO_IMG_FIN") != "1"
+        dsums = zeros(BN_REPLICAS * 2 * Cc + (1 if fin else 0), torch.float64, y.device)
+        args = (int(B), int(H), int(W), int(Cc), int(stride), self._p(gout, _F32, "gout"),
+                self._p(arg, torch.uint8, "arg"), self._p(y, _F32, "y"), self._p(mean_invstd, _F32, "mean_invstd"),
+                self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(slope),
+                self._p(dsums, torch.float64, "dsums"), self._p(dy, _F32, "dy"), self._p(dgamma, _F32, "dgamma"),
+                self._p(dbeta, _F32, "dbeta"))
+        if fin:
+            ticket = dsums[BN_REPLICAS * 2 * Cc:].view(torch.int32)[:1]
+            self._call("i2p_img_bn_pool_bwd_fin", *args, self._p(ticket, torch.int32, "ticket"), stream=self._stream())
+        else:
+            self._call("i2p_img_bn_pool_bwd", *args, stream=self._stream())
         return dy, dgamma, dbeta
 
     # ---- batch-stat BatchNorm + activation (PPBackbone_center.py:28-46) ---------------------------

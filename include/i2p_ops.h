@@ -288,6 +288,14 @@ int i2p_img_bn_pool_fwd(int B, int H, int W, int C, int stride, const float *y, 
                         const float *gamma, const float *beta, float eps, float slope, float momentum,
                         const float *conv_bias, float *running_mean, float *running_var, float *out,
                         unsigned char *arg, float *mean_invstd, void *stream);
+/* Device library only: the statistics pass of i2p_img_bn_pool_fwd with the finalisation done by its last block (sums: zeroed
+ * [I2P_BN_REPLICAS][2C] doubles, ticket: one zeroed uint32) — call i2p_img_bn_pool_fwd with sums = NULL afterwards; and the backward
+ * with dgamma / dbeta formed by the last block of its statistics kernel. */
+int i2p_img_bn_stats_fin(int B, int H, int W, int C, const float *y, double *sums, unsigned *ticket, float eps, float momentum,
+                         const float *conv_bias, float *running_mean, float *running_var, float *mean_invstd, void *stream);
+int i2p_img_bn_pool_bwd_fin(int B, int H, int W, int C, int stride, const float *gout, const unsigned char *arg, const float *y,
+                            const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums, float *dy,
+                            float *dgamma, float *dbeta, unsigned *ticket, void *stream);
 int i2p_img_bn_pool_bwd(int B, int H, int W, int C, int stride, const float *gout, const unsigned char *arg,
                         const float *y, const float *mean_invstd, const float *gamma, const float *beta,
                         float slope, double *dsums, float *dy, float *dgamma, float *dbeta, void *stream);
