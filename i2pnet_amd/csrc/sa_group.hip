@@ -383,7 +383,115 @@ __global__ __launch_bounds__(128) void knn_rows_bwd_kernel(int n, int m, int K, 
         d_xyz[((size_t)bi * n + pn) * 3 + threadIdx.x] = a;
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// pc-stage front end of the cost volumes (PPBackbone_center.py:443-476: two gather_torch, expand, subtraction, squared norm,
+// sqrt, two cats — ~10 launches forward, ~16 backward per cost volume) in one launch each way from the selected cells:
+//   geo  [b, n*K+k, 0:12] = [xyz[b,n] (3), xyz[b,cell] (3), xyz[b,cell] - xyz[b,n] (3), sqrt(|diff|^2 + 1e-20), 0, 0]
+//   part [b, n*K+k, :]    = [pts[b,n,:] (C), feat[b,cell,:] (c)]        (columns 64.. of the mask MLP's 256-channel input)
+//   nbf  [b, n*K+k, :]    = feat[b,cell,:]                               (the values of the softmax-weighted sum)
+// cell = h_idx*W + w_idx.  One thread per float4 of a row's outputs.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pc_rows_fwd_kernel(int hw, int K, int W, int C, int c, const float *__restrict__ xyz,
+                                                          const float *__restrict__ pts, const float *__restrict__ feat,
+                                                          const int64_t *__restrict__ h_idx, const int64_t *__restrict__ w_idx,
+                                                          float *__restrict__ geo, float *__restrict__ part, float *__restrict__ nbf) {
+    const int bi = blockIdx.y;
+    const int per = 3 + ((C + c) >> 2);                       // float4 tasks per row: 3 of geo, (C+c)/4 of part (the c/4 last also fill nbf)
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long q = (long long)hw * K;
+    if (t >= q * per) return;
+    const int row = (int)(t / per), j = (int)(t % per), n = row / K;
+    const long long cell = h_idx[(size_t)bi * q + row] * W + w_idx[(size_t)bi * q + row];
+    const size_t orow = (size_t)bi * q + row;
+    if (j < 3) {
+        const float *o = xyz + ((size_t)bi * hw + n) * 3, *nb = xyz + ((size_t)bi * hw + cell) * 3;
+        const float ox = o[0], oy = o[1], oz = o[2], nx = nb[0], ny = nb[1], nz = nb[2];
+        const float dx = nx - ox, dy = ny - oy, dz = nz - oz;
+        float4 v;
+        if (j == 0) v = make_float4(ox, oy, oz, nx);
+        else if (j == 1) v = make_float4(ny, nz, dx, dy);
+        else v = make_float4(dz, sqrtf(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)), 1e-20f)), 0.f, 0.f);
+        reinterpret_cast<float4 *>(geo + orow * 12)[j] = v;
+        return;
+    }
+    const int ch = (j - 3) * 4;
+    float4 v;
+    if (ch < C) v = *reinterpret_cast<const float4 *>(pts + ((size_t)bi * hw + n) * C + ch);
+    else {
+        v = *reinterpret_cast<const float4 *>(feat + ((size_t)bi * hw + cell) * c + (ch - C));
+        *reinterpret_cast<float4 *>(nbf + orow * c + (ch - C)) = v;
+    }
+    *reinterpret_cast<float4 *>(part + orow * (C + c) + ch) = v;
+}
+
+// backward: block = one point (b, n); its K neighbours in index order (fixed summation order).
+//   d_pts[b,n,:]              = sum_k g_part[row, 0:C]
+//   comb[b,n, c:c+3]          = sum_k (g_own - g_diff - g_euc * diff/euc)      (own-point part of d_xyz; comb[b,n,0:c] = 0, [c+3] = 0)
+//   rows[row, 0:c]            = g_part[row, C:] + g_nbf[row, :]                (per-neighbour gradient of feat[cell])
+//   rows[row, c:c+3]          = g_nb + g_diff + g_euc * diff/euc               (per-neighbour gradient of xyz[cell]); rows[row, c+3] = 0
+// `rows` is then scattered onto comb by the fixed-point row scatter (i2p_gather_rows_grad_fx): comb = [d_feat | d_xyz | 0].
+__global__ __launch_bounds__(128) void pc_rows_bwd_kernel(int hw, int K, int W, int C, int c, const float *__restrict__ xyz,
+                                                          const int64_t *__restrict__ h_idx, const int64_t *__restrict__ w_idx,
+                                                          const float *__restrict__ g_geo, const float *__restrict__ g_part,
+                                                          const float *__restrict__ g_nbf, float *__restrict__ d_pts,
+                                                          float *__restrict__ comb, float *__restrict__ rows) {
+    const int n = blockIdx.x, bi = blockIdx.y, tid = threadIdx.x;
+    const size_t row0 = ((size_t)bi * hw + n) * K;
+    const int ld = c + 4;
+    for (int ch = tid; ch < C; ch += 128) {
+        float a = 0.f;
+        for (int k = 0; k < K; ++k) a += g_part[(row0 + k) * (C + c) + ch];
+        d_pts[((size_t)bi * hw + n) * C + ch] = a;
+    }
+    for (int ch = tid; ch < c; ch += 128) {
+        for (int k = 0; k < K; ++k)
+            rows[(row0 + k) * ld + ch] = g_part[(row0 + k) * (C + c) + C + ch] + (g_nbf ? g_nbf[(row0 + k) * c + ch] : 0.f);
+        comb[((size_t)bi * hw + n) * ld + ch] = 0.f;
+    }
+    if (tid < 4) {
+        float own = 0.f;
+        const float o = tid < 3 ? xyz[((size_t)bi * hw + n) * 3 + tid] : 0.f;
+        for (int k = 0; k < K; ++k) {
+            float v = 0.f;
+            if (tid < 3 && g_geo) {
+                const long long cell = h_idx[row0 + k] * W + w_idx[row0 + k];
+                const float *nb = xyz + ((size_t)bi * hw + cell) * 3, *oo = xyz + ((size_t)bi * hw + n) * 3;
+                const float dx = nb[0] - oo[0], dy = nb[1] - oo[1], dz = nb[2] - oo[2];
+                const float euc = sqrtf(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)), 1e-20f));
+                const float d = tid == 0 ? dx : (tid == 1 ? dy : dz);
+                const float *gg = g_geo + (row0 + k) * 12;
+                const float ge = gg[9] * (d / euc);                              // d euc / d diff
+                v = gg[3 + tid] + gg[6 + tid] + ge;
+                own += gg[tid] - gg[6 + tid] - ge;
+                (void)o;
+            }
+            rows[(row0 + k) * ld + c + tid] = v;
+        }
+        comb[((size_t)bi * hw + n) * ld + c + tid] = own;
+    }
+}
+
 }  // namespace
+
+extern "C" int i2p_pc_rows_fwd(int b, int hw, int K, int W, int C, int c, const float *xyz, const float *pts, const float *feat,
+                               const int64_t *h_idx, const int64_t *w_idx, float *geo, float *part, float *nbf, void *stream) {
+    if (b <= 0 || hw <= 0 || K <= 0 || W <= 0 || C < 0 || c <= 0 || (C & 3) || (c & 3)) return I2P_ERR_BAD_ARG;
+    if (!xyz || (C && !pts) || !feat || !h_idx || !w_idx || !geo || !part || !nbf) return I2P_ERR_BAD_ARG;
+    const long long tot = (long long)hw * K * (3 + ((C + c) >> 2));
+    hipLaunchKernelGGL(pc_rows_fwd_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0, (hipStream_t)stream, hw, K, W, C, c, xyz, pts, feat,
+                       h_idx, w_idx, geo, part, nbf);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+// g_geo / g_nbf may be NULL (no gradient arrived on that output); comb [b, hw, c+4], rows [b, hw*K, c+4] are written completely
+extern "C" int i2p_pc_rows_bwd(int b, int hw, int K, int W, int C, int c, const float *xyz, const int64_t *h_idx, const int64_t *w_idx,
+                               const float *g_geo, const float *g_part, const float *g_nbf, float *d_pts, float *comb, float *rows, void *stream) {
+    if (b <= 0 || hw <= 0 || K <= 0 || W <= 0 || C < 0 || c <= 0 || (C & 3) || (c & 3)) return I2P_ERR_BAD_ARG;
+    if (!xyz || !h_idx || !w_idx || !g_part || (C && !d_pts) || !comb || !rows) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pc_rows_bwd_kernel, dim3(hw, b), dim3(128), 0, (hipStream_t)stream, hw, K, W, C, c, xyz, h_idx, w_idx, g_geo, g_part, g_nbf,
+                       d_pts, comb, rows);
+    I2P_RETURN_LAUNCH_STATUS();
+}
 
 extern "C" int i2p_sa_rows(int b, int hw, int n, int K, int W, int c, int cpad, int xyz_col, int feat_col, const float *xyz,
                            const float *centre, const float *feat, const int64_t *h_idx, const int64_t *w_idx, float *out, void *stream) {

@@ -710,13 +710,19 @@ class CostVolume(nn.Module):
             gidx = P.get_neighbor_att(xyz_pr.detach(), xyz_pr.detach(), idx_n2, self.kernel_size, self.nsample,
                                       distance=self.distance)
         K = self.nsample
-        nb_xyz = P.gather_torch(xyz_bhw, *gidx[:3], B, self.H, self.W)          # [B,N,K,3]
-        nb_feat = P.gather_torch(pi_feat, *gidx[:3], B, self.H, self.W)         # [B,N,K,c]
-        own_xyz = xyz.unsqueeze(2).expand(-1, -1, K, -1)
-        diff = nb_xyz - own_xyz
-        euc = torch.sqrt(torch.sum(diff * diff, dim=3, keepdim=True) + 1e-20)   # :461
-        enc_pc = run_stack(torch.cat([own_xyz, nb_xyz, diff, euc], dim=3), [self.pc_encoding])
-        w = torch.cat([enc_pc, warped_points.unsqueeze(2).expand(-1, -1, K, -1), nb_feat], dim=-1)
+        if USE_FUSED_GROUP and USE_FUSED_MLP and P.pc_rows_fusable(xyz, warped_points, pi_feat):
+            # gathers, differences, distance and both concatenations in one launch each way (csrc/sa_group.hip)
+            geo, part, nb_feat = P.pc_rows(xyz, warped_points, pi_feat.reshape(B, N, -1), gidx[1], gidx[2], K, self.W)
+            enc_pc = run_stack(geo, [self.pc_encoding])
+            w = torch.cat([enc_pc, part], dim=-1)
+        else:
+            nb_xyz = P.gather_torch(xyz_bhw, *gidx[:3], B, self.H, self.W)          # [B,N,K,3]
+            nb_feat = P.gather_torch(pi_feat, *gidx[:3], B, self.H, self.W)         # [B,N,K,c]
+            own_xyz = xyz.unsqueeze(2).expand(-1, -1, K, -1)
+            diff = nb_xyz - own_xyz
+            euc = torch.sqrt(torch.sum(diff * diff, dim=3, keepdim=True) + 1e-20)   # :461
+            enc_pc = run_stack(torch.cat([own_xyz, nb_xyz, diff, euc], dim=3), [self.pc_encoding])
+            w = torch.cat([enc_pc, warped_points.unsqueeze(2).expand(-1, -1, K, -1), nb_feat], dim=-1)
         w = run_stack(w, self.mlp2_convs_2)
         valid = gidx[-1]
         w = mask_fill(w, valid)                                                 # :481

@@ -416,8 +416,10 @@ class CBackend:
         arg = torch.empty(B, Ho, Wo, Cc, dtype=torch.uint8, device=y.device)
         mean_invstd = torch.empty(2 * Cc, dtype=_F32, device=y.device)
         opt = lambda t, what: self._p(t, _F32, what) if t is not None else None
-        if self.name == "hip" and os.environ.get("I2P_NO_IMG_FIN") != "1":
-            # statistics + finalisation (mean / invstd / running buffers) in one launch: the last block finalises
+        # statistics + finalisation (mean / invstd / running buffers) in one launch, the last block finalising: measured SLOWER
+        # (583 vs 598 samples/s, A/B on one box — returning fp64 atomics in every block and the last block's serial re-read of
+        # the 32 replica sums cost more than the 64-thread finalize launch they replace).  Opt-in: I2P_IMG_FIN=1.
+        if self.name == "hip" and os.environ.get("I2P_IMG_FIN") == "1":
             sums = zeros(BN_REPLICAS * 2 * Cc + 1, torch.float64, y.device)      # (+1: the ticket word)
             ticket = sums[BN_REPLICAS * 2 * Cc:].view(torch.int32)[:1]
             self._call("i2p_img_bn_stats_fin", int(B), int(H), int(W), int(Cc), self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums"),
@@ -440,7 +442,7 @@ class CBackend:
         dy = torch.empty_like(y)
         dgamma = torch.empty(Cc, dtype=_F32, device=y.device)
         dbeta = torch.empty(Cc, dtype=_F32, device=y.device)
-        fin = self.name == "hip" and os.environ.get("I2P_NO_IMG_FIN") != "1"
+        fin = self.name == "hip" and os.environ.get("I2P_IMG_FIN") == "1"
         dsums = zeros(BN_REPLICAS * 2 * Cc + (1 if fin else 0), torch.float64, y.device)
         args = (int(B), int(H), int(W), int(Cc), int(stride), self._p(gout, _F32, "gout"),
                 self._p(arg, torch.uint8, "arg"), self._p(y, _F32, "y"), self._p(mean_invstd, _F32, "mean_invstd"),
@@ -921,6 +923,33 @@ class CBackend:
                    self._p(b, _F32, "b") if b is not None else None, self._p(oa, _F32, "oa"), self._p(ob, _F32, "ob") if b is not None else None,
                    stream=self._stream())
         return oa, ob
+
+    def pc_rows_forward(self, xyz, pts, feat, h_idx, w_idx, K, W):
+        """-> (geo [B,HW*K,12], part [B,HW*K,C+c], nbf [B,HW*K,c]); see i2p_pc_rows_fwd"""
+        B, HW, _ = xyz.shape
+        Cp, cf = pts.shape[2], feat.shape[2]
+        dev = xyz.device
+        geo = torch.empty(B, HW * K, 12, dtype=_F32, device=dev)
+        part = torch.empty(B, HW * K, Cp + cf, dtype=_F32, device=dev)
+        nbf = torch.empty(B, HW * K, cf, dtype=_F32, device=dev)
+        self._call("i2p_pc_rows_fwd", int(B), int(HW), int(K), int(W), int(Cp), int(cf), self._p(xyz, _F32, "xyz"), self._p(pts, _F32, "pts"),
+                   self._p(feat, _F32, "feat"), self._p(h_idx, _I64, "h_idx"), self._p(w_idx, _I64, "w_idx"), self._p(geo, _F32, "geo"),
+                   self._p(part, _F32, "part"), self._p(nbf, _F32, "nbf"), stream=self._stream())
+        return geo, part, nbf
+
+    def pc_rows_backward(self, xyz, h_idx, w_idx, K, W, Cp, cf, g_geo, g_part, g_nbf):
+        """-> (d_pts [B,HW,C], comb [B,HW,c+4] = [d_feat | d_xyz | 0] after the row scatter)"""
+        B, HW, _ = xyz.shape
+        dev = xyz.device
+        d_pts = torch.empty(B, HW, Cp, dtype=_F32, device=dev)
+        comb = torch.empty(B, HW, cf + 4, dtype=_F32, device=dev)
+        rows = torch.empty(B, HW * K, cf + 4, dtype=_F32, device=dev)
+        opt = lambda t: self._p(t, _F32, "g") if t is not None else None
+        self._call("i2p_pc_rows_bwd", int(B), int(HW), int(K), int(W), int(Cp), int(cf), self._p(xyz, _F32, "xyz"), self._p(h_idx, _I64, "h_idx"),
+                   self._p(w_idx, _I64, "w_idx"), opt(g_geo), self._p(g_part, _F32, "g_part"), opt(g_nbf), self._p(d_pts, _F32, "d_pts"),
+                   self._p(comb, _F32, "comb"), self._p(rows, _F32, "rows"), stream=self._stream())
+        self.gather_rows_grad(rows, h_idx, w_idx, W, comb)             # deterministic fixed-point scatter of the per-neighbour parts
+        return d_pts, comb
 
     def max_response_forward(self, pts, pix, valid):
         """pts [B,N,C], pix [B,M,C], valid [B,N] -> (respond [B,M,C], fmaxmin [B,2,C], imaxmin i32 [B,2,C], anyv i32 [B])"""

@@ -146,6 +146,44 @@ class _KnnRows(Function):
         return d_xyz, None, d_pts, d_pix, None, None, None
 
 
+class _PcRows(Function):
+    """the pc-stage front end of a cost volume in one launch each way (csrc/sa_group.hip i2p_pc_rows_fwd/bwd; reference:
+    PPBackbone_center.py:443-476) -> (geo [B,N,K,12], part [B,N,K,C+c], nb_feat [B,N,K,c])"""
+
+    @staticmethod
+    def forward(ctx, xyz, pts, feat, h_idx, w_idx, K, W):
+        geo, part, nbf = ops.get_backend().pc_rows_forward(xyz, pts, feat, h_idx, w_idx, K, W)
+        ctx.save_for_backward(xyz, h_idx, w_idx)
+        ctx.dims = (K, W, pts.shape[2], feat.shape[2])
+        B, HW = xyz.shape[0], xyz.shape[1]
+        return geo.view(B, HW, K, 12), part.view(B, HW, K, -1), nbf.view(B, HW, K, -1)
+
+    @staticmethod
+    def backward(ctx, g_geo, g_part, g_nbf):
+        xyz, h_idx, w_idx = ctx.saved_tensors
+        K, W, Cp, cf = ctx.dims
+        B, HW = xyz.shape[0], xyz.shape[1]
+        c = lambda t, w_: None if t is None else t.reshape(B, HW * K, w_).contiguous()
+        if g_part is None:
+            g_part = torch.zeros(B, HW * K, Cp + cf, dtype=torch.float32, device=xyz.device)
+        d_pts, comb = ops.get_backend().pc_rows_backward(xyz, h_idx, w_idx, K, W, Cp, cf, c(g_geo if ctx.needs_input_grad[0] else None, 12),
+                                                         c(g_part, Cp + cf), c(g_nbf, cf))
+        d_xyz = comb[:, :, cf:cf + 3] if ctx.needs_input_grad[0] else None
+        return d_xyz, d_pts, comb[:, :, :cf], None, None, None, None
+
+
+def pc_rows_fusable(xyz, pts, feat):
+    be = ops.get_backend()
+    return (os.environ.get("I2P_NO_PC_ROWS") != "1" and be.device_type == "cuda" and be.name == "hip" and xyz.dtype == torch.float32
+            and pts.dtype == torch.float32 and feat.dtype == torch.float32 and pts.shape[-1] % 4 == 0 and feat.shape[-1] % 4 == 0)
+
+
+def pc_rows(xyz, pts, feat, h_idx, w_idx, K, W):
+    """xyz [B,HW,3], pts [B,HW,C], feat [B,HW,c], h_idx / w_idx [B,HW,K(,1)] -> (geo, part, nb_feat), see _PcRows"""
+    B = xyz.shape[0]
+    return _PcRows.apply(xyz.contiguous(), pts.contiguous(), feat.contiguous(), h_idx.reshape(B, -1).contiguous(), w_idx.reshape(B, -1).contiguous(), K, W)
+
+
 def knn_rows_fusable(xyz, pix_xyz, pts, pix):
     be = ops.get_backend()
     return (os.environ.get("I2P_NO_KNN_ROWS") != "1" and be.device_type == "cuda" and be.name == "hip" and not pix_xyz.requires_grad

@@ -522,6 +522,17 @@ int i2p_max_response_fwd(int B, int N, int M, int C, const float *pts, const flo
                          float *fmaxmin, int *imaxmin, int *anyv, void *stream);
 int i2p_max_response_bwd(int B, int N, int M, int C, const float *g, const float *pix, const float *fmaxmin, const int *imaxmin,
                          const int *anyv, float *d_pts, float *d_pix, void *stream);
+/* pc-stage front end of the cost volumes in one launch each way (reference: two gather_torch, expand, subtraction, squared norm,
+ * sqrt, two cats — PPBackbone_center.py:443-476).  xyz f32 [b,hw,3], pts f32 [b,hw,C], feat f32 [b,hw,c], h_idx/w_idx i64 [b,hw*K]
+ * (cell = h*W + w) -> geo f32 [b,hw*K,12] = [xyz[n], xyz[cell], xyz[cell]-xyz[n], sqrt(|.|^2+1e-20), 0, 0],
+ * part f32 [b,hw*K,C+c] = [pts[n], feat[cell]], nbf f32 [b,hw*K,c] = feat[cell].
+ * Backward: g_geo / g_part / g_nbf -> d_pts [b,hw,C] (sums over the K neighbours in index order), comb f32 [b,hw,c+4] = the own-point
+ * part of [d_feat | d_xyz | 0], rows f32 [b,hw*K,c+4] = the per-neighbour parts, to be scattered onto comb with
+ * i2p_gather_rows_grad_fx (c+4 channels). */
+int i2p_pc_rows_fwd(int b, int hw, int K, int W, int C, int c, const float *xyz, const float *pts, const float *feat,
+                    const int64_t *h_idx, const int64_t *w_idx, float *geo, float *part, float *nbf, void *stream);
+int i2p_pc_rows_bwd(int b, int hw, int K, int W, int C, int c, const float *xyz, const int64_t *h_idx, const int64_t *w_idx,
+                    const float *g_geo, const float *g_part, const float *g_nbf, float *d_pts, float *comb, float *rows, void *stream);
 int i2p_row_valid(long long rows, int c, const float *x, float *out, void *stream);
 int i2p_mask_fill(long long rows, int c, const float *x, const float *valid, float fill, float *out, void *stream);
 int i2p_pad_cols(int rows, int c, int cpad, const float *w, float *out, void *stream);

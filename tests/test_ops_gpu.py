@@ -279,11 +279,15 @@ def test_row_unitvar_parity(oracle_backend, hip_backend):
         assert torch.allclose(rg, hg.cpu(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("fin", [False, True])
 @pytest.mark.parametrize("stride,C,H,W", [(1, 16, 37, 53), (2, 16, 37, 53), (2, 32, 24, 40), (1, 64, 12, 20), (2, 128, 24, 78)])
-def test_img_bn_pool_parity(oracle_backend, hip_backend, stride, C, H, W):
+def test_img_bn_pool_parity(oracle_backend, hip_backend, stride, C, H, W, fin, monkeypatch):
     """image-encoder block tail: HIP vs oracle (arg-max bit-exact away from ties, values 1e-5) and vs
-    torch's batch_norm -> leaky_relu -> max_pool2d on the GPU (gradient of the conv output)."""
+    torch's batch_norm -> leaky_relu -> max_pool2d on the GPU (gradient of the conv output).  `fin`: the variant whose statistics
+    kernels finalise in their last block (i2p_img_bn_stats_fin / i2p_img_bn_pool_bwd_fin, opt-in)."""
     import torch.nn.functional as F
+    if fin:
+        monkeypatch.setenv("I2P_IMG_FIN", "1")
     g = torch.Generator().manual_seed(C + stride)
     B = 3
     y = torch.randn(B, H, W, C, generator=g) * 2 + 0.3
@@ -1084,3 +1088,45 @@ def test_max_response_fused_vs_torch_cpu(hip_backend, B, N, M, C, empty):
     assert torch.equal(out.cpu(), ref.detach())
     assert torch.equal(gb.cpu(), rb)
     assert float((ga.cpu() - ra).abs().max()) <= 1e-5 * float(ra.abs().max()) + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("need_xyz", [True, False])
+def test_pc_rows_vs_oracle_chain(hip_backend, oracle_backend, need_xyz):
+    """i2p_pc_rows_fwd/bwd (pc-stage front end of the cost volumes in one launch each way) at the network's size (4 x 57 cells,
+    K = 4 of a 3 x 5 window, 128 + 64 channels) against the ORACLE chain it replaces: fused_conv_select_k_cpu -> gather_rows_cpu x2,
+    expand, subtraction, sqrt(sum + 1e-20), cats (PPBackbone_center.py:443-476) with gather_rows_grad_cpu in its backward: forward
+    rows bit-exact, the three input gradients to fp32 rounding."""
+    from i2pnet_amd import projectpn as P
+    B, H, W, K, C, c = 2, 4, 57, 4, 128, 64
+    N = H * W
+    img = range_image(B, H, W, seed=9, empty_frac=0.3, scale=6.0)
+    g = torch.Generator().manual_seed(10)
+    pts, feat = torch.randn(B, N, C, generator=g), torch.randn(B, N, c, generator=g)
+    idx = stride_grid(B, H, W, 1, 1)
+    g_geo, g_part, g_nbf = torch.randn(B, N, K, 12, generator=g), torch.randn(B, N, K, C + c, generator=g), torch.randn(B, N, K, c, generator=g)
+    g_geo[..., 10:] = 0.0
+
+    def chain():
+        x = img.reshape(B, N, 3).clone().requires_grad_(need_xyz); p_, f_ = pts.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+        sb, sh, sw, m, _, _ = run_fcsk(oracle_backend, img, img, idx, 3, 5, K, 2, 4.5, 1, 1)
+        hh, ww = sh.squeeze(-1), sw.squeeze(-1)
+        nb_xyz = P.gather_torch(x.view(B, H, W, 3), None, hh, ww, B, H, W)
+        nb_feat = P.gather_torch(f_, None, hh, ww, B, H, W)
+        own = x.unsqueeze(2).expand(-1, -1, K, -1)
+        diff = nb_xyz - own
+        euc = torch.sqrt(torch.sum(diff * diff, dim=3, keepdim=True) + 1e-20)
+        geo = torch.cat([own, nb_xyz, diff, euc, torch.zeros(B, N, K, 2)], dim=3)
+        part = torch.cat([p_.unsqueeze(2).expand(-1, -1, K, -1), nb_feat], dim=-1)
+        ins = ([x] if need_xyz else []) + [p_, f_]
+        grads = torch.autograd.grad([geo, part, nb_feat], ins, [g_geo, g_part, g_nbf])
+        return geo.detach(), part.detach(), nb_feat.detach(), grads, hh, ww
+    geo, part, nbf, grads, hh, ww = _on_oracle(oracle_backend, chain)
+    x = img.reshape(B, N, 3).to(DEV).requires_grad_(need_xyz); p_, f_ = pts.to(DEV).requires_grad_(True), feat.to(DEV).requires_grad_(True)
+    got = P.pc_rows(x, p_, f_, hh.to(DEV), ww.to(DEV), K, W)
+    for a, b in zip(got, (geo, part, nbf)):
+        assert torch.equal(a.cpu(), b)
+    ins = ([x] if need_xyz else []) + [p_, f_]
+    hg = torch.autograd.grad(list(got), ins, [g_geo.to(DEV), g_part.to(DEV), g_nbf.to(DEV)])
+    for a, b in zip(hg, grads):
+        assert float((a.cpu() - b).abs().max()) <= 3e-6 * float(b.abs().max()) + 1e-6
