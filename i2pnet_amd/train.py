@@ -163,6 +163,7 @@ class Trainer:
         self.optimizer = FlatAdam(self.flat_param, self.flat_grad, lr, betas=(0.9, 0.999), eps=1e-08,
                                   weight_decay=0.0001)
         self.lr_gamma = 0.99                    # ExponentialLR(0.99) per epoch: call `epoch_end()`
+        self._lr0 = lr
         # side-stream weight gradients need every weight to receive ONE gradient per backward pass (ops._SideWgrad): true for the
         # single-pass networks, not for the iterative model that applies the fine step six times
         self.side_wgrad = (self.device.type == "cuda" and getattr(net_cls, "n_iters", 1) == 1 and call is None
@@ -325,20 +326,73 @@ class Trainer:
             p.copy_(v)
         torch.cuda.set_rng_state(snap["rng"], self.device); torch.set_rng_state(snap["rng_cpu"])
 
-    # ---- checkpoints: the reference's dict layout (train20v2learn_wandb_proj.py:254-268) + the flat Adam state ----
+    # ---- checkpoints: the reference's dict layout (train20v2learn_wandb_proj.py:254-268) ------------------------------------
+    # `optimizer_state_dict` / `scheduler_state_dict` are written in torch.optim.Adam's / ExponentialLR's own state_dict layout
+    # over ALL parameters of the network in `parameters()` order — what the reference trainer's optimizer.load_state_dict /
+    # scheduler.load_state_dict (:218-221) accept — sliced from the flat moment buffers; parameters that take no part in
+    # training here (conv biases in front of batch-statistics BNs) carry zero moments.
+    def _adam_state_dict(self, epoch):
+        opt = self.optimizer
+        index = {id(p): i for i, p in enumerate(self.params)}
+        state, ids = {}, []
+        for j, p in enumerate(self.net.parameters()):
+            ids.append(j)
+            i = index.get(id(p))
+            if i is None:
+                m = v = torch.zeros_like(p, device="cpu")
+            else:
+                off, nhwc = self._offsets[i], self._nhwc[i]
+                def view(buf):
+                    seg = buf[off:off + p.numel()]
+                    t = seg.view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2) if nhwc else seg.view_as(p)
+                    return t.detach().cpu().contiguous()
+                m, v = view(opt.exp_avg), view(opt.exp_avg_sq)
+            state[j] = {"step": opt.step_t.detach().cpu().clone(), "exp_avg": m, "exp_avg_sq": v}
+        lr = float(opt.lr_t)
+        group = {"lr": lr, "betas": (opt.beta1, opt.beta2), "eps": opt.eps, "weight_decay": opt.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "initial_lr": self._lr0, "params": ids}
+        sched = {"gamma": self.lr_gamma, "base_lrs": [self._lr0], "last_epoch": int(epoch), "verbose": False, "_step_count": int(epoch) + 1,
+                 "_get_lr_called_within_step": False, "_last_lr": [lr]}
+        return {"state": state, "param_groups": [group]}, sched
+
     def save_checkpoint(self, path, epoch=0):
-        torch.save({"epoch": epoch, "model_state_dict": self.net.state_dict(),
-                    "optimizer_state_dict": {k: v.detach().cpu() for k, v in self.optimizer.state_dict().items()},
-                    "scheduler_state_dict": {"gamma": self.lr_gamma}}, path)
+        opt_sd, sched_sd = self._adam_state_dict(epoch)
+        torch.save({"epoch": epoch, "model_state_dict": self.net.state_dict(), "optimizer_state_dict": opt_sd,
+                    "scheduler_state_dict": sched_sd}, path)
 
     def load_checkpoint(self, path):
-        ckpt = torch.load(path, map_location="cpu")
+        """a checkpoint of this trainer OR of the reference trainer (torch.optim.Adam + ExponentialLR state dicts): weights,
+        Adam moments / step count and the decayed learning rate are all restored"""
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
         sd = {k[7:] if k.startswith("module.") else k: v for k, v in ckpt["model_state_dict"].items()}
         with torch.no_grad():                       # parameters are views into the flat buffer: copy, never rebind
             self.net.load_state_dict(sd, strict=True)
         opt = ckpt.get("optimizer_state_dict")
-        if opt is not None and "exp_avg" in opt:    # (a reference torch.optim.Adam state has another layout: weights only)
+        if opt is not None and "exp_avg" in opt:    # (round-1/2 checkpoints of this trainer: the flat buffers themselves)
             self.optimizer.load_state_dict({k: v.to(self.device) for k, v in opt.items()})
+        elif opt is not None and "state" in opt:
+            index = {id(p): i for i, p in enumerate(self.params)}
+            ids = opt["param_groups"][0]["params"]
+            with torch.no_grad():
+                step = None
+                for j, p in zip(ids, self.net.parameters()):
+                    st = opt["state"].get(j)
+                    i = index.get(id(p))
+                    if st is None or i is None:
+                        continue
+                    off, nhwc = self._offsets[i], self._nhwc[i]
+                    for key, buf in (("exp_avg", self.optimizer.exp_avg), ("exp_avg_sq", self.optimizer.exp_avg_sq)):
+                        seg = buf[off:off + p.numel()]
+                        dst = seg.view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2) if nhwc else seg.view_as(p)
+                        dst.copy_(st[key].to(self.device).view_as(p))
+                    step = st["step"] if step is None else step
+                if step is not None:
+                    self.optimizer.step_t.fill_(float(step))
+                self.optimizer.lr_t.fill_(float(opt["param_groups"][0]["lr"]))
+        sched = ckpt.get("scheduler_state_dict")
+        if sched is not None and "_last_lr" in sched and not (opt is not None and "state" in opt):
+            self.optimizer.lr_t.fill_(float(sched["_last_lr"][0]))
         return ckpt.get("epoch", 0)
 
     def step(self, batch):

@@ -109,3 +109,40 @@ def test_flat_adam_matches_torch_adam():
         if it % 5 == 4:
             sched.step(); mine.decay_lr(0.99)
         assert torch.allclose(flat, ref.data, rtol=1e-5, atol=1e-7), it
+
+
+def test_checkpoint_is_torch_adam_compatible(tmp_path, oracle_backend):
+    """Trainer.save_checkpoint writes what the reference trainer loads (train20v2learn_wandb_proj.py:218-221): a
+    torch.optim.Adam / ExponentialLR state dict over all parameters of the network; loading it into torch's own optimizer and
+    scheduler works, the moments are the flat buffers' slices, and Trainer.load_checkpoint restores weights, moments, step count
+    and the decayed learning rate from it."""
+    import torch
+    from i2pnet_amd import ops, synth
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd.train import Trainer
+    prev = ops.set_backend(oracle_backend)
+    try:
+        tr = Trainer(cfg=cfg, device="cpu", seed=0)
+        batch = synth.make_batch(1, 2048, 160, 512, seed=3)
+        for _ in range(2):
+            tr.step(batch)
+        tr.epoch_end()
+        tr.save_checkpoint(tmp_path / "ck.pth", epoch=1)
+        ck = torch.load(tmp_path / "ck.pth", weights_only=False)
+        # the reference's side: torch.optim.Adam over model.parameters() + ExponentialLR
+        ref_params = [torch.nn.Parameter(p.detach().clone()) for p in tr.net.parameters()]
+        opt = torch.optim.Adam(ref_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0001)
+        sch = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.99)
+        opt.load_state_dict(ck["optimizer_state_dict"]); sch.load_state_dict(ck["scheduler_state_dict"])
+        assert abs(opt.param_groups[0]["lr"] - 1e-3 * 0.99) < 1e-9 and sch.last_epoch == 1       # (the rate lives in an fp32 device scalar)
+        names = [k for k, _ in tr.net.named_parameters()]
+        k = names.index("cost_volume1.mlp1_convs.1.conv.weight")
+        st = opt.state[ref_params[k]]
+        assert float(st["step"]) == 2.0 and float(st["exp_avg"].abs().max()) > 0
+        tr2 = Trainer(cfg=cfg, device="cpu", seed=1)
+        assert tr2.load_checkpoint(tmp_path / "ck.pth") == 1
+        assert torch.equal(tr2.flat_param, tr.flat_param)
+        assert torch.equal(tr2.optimizer.exp_avg, tr.optimizer.exp_avg) and torch.equal(tr2.optimizer.exp_avg_sq, tr.optimizer.exp_avg_sq)
+        assert float(tr2.optimizer.step_t) == 2.0 and abs(float(tr2.optimizer.lr_t) - 1e-3 * 0.99) < 1e-9
+    finally:
+        ops.set_backend(prev)
