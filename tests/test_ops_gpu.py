@@ -1130,3 +1130,23 @@ def test_pc_rows_vs_oracle_chain(hip_backend, oracle_backend, need_xyz):
     hg = torch.autograd.grad(list(got), ins, [g_geo.to(DEV), g_part.to(DEV), g_nbf.to(DEV)])
     for a, b in zip(hg, grads):
         assert float((a.cpu() - b).abs().max()) <= 3e-6 * float(b.abs().max()) + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cin,cout", [(853632, 128, 64), (65584, 64, 64), (14848, 64, 128), (3000, 32, 16), (58368, 136, 128)])
+def test_last_block_finalize_is_stable_over_many_launches(hip_backend, rows, cin, cout):
+    """The BN coefficients a forward launch finalises in its LAST block (ticket atomic after the statistics atomics, csrc/mlp.hip
+    finalize_by_last_block and the wreg / big variants) against the separate i2p_bn_finalize on the same sums, bit for bit, over 150
+    back-to-back launches per shape: a lost or late partial sum (a missing release/acquire across the XCDs' L2s) would show as a
+    differing mean / invstd."""
+    g = torch.Generator(device=DEV).manual_seed(rows % 1000)
+    x = torch.randn(rows, cin, generator=g, device=DEV) * 1.5 + 0.2
+    w = torch.randn(cout, cin, generator=g, device=DEV) / cin ** 0.5
+    gam = 1 + 0.1 * torch.randn(cout, generator=g, device=DEV); bet = 0.1 * torch.randn(cout, generator=g, device=DEV)
+    in_coef, _ = hip_backend.bn_finalize(rows, hip_backend.bn_stats(x), torch.ones(cin, device=DEV), torch.zeros(cin, device=DEV), 1e-5)
+    bad = 0
+    for it in range(150):
+        y, sums, coef, mi = hip_backend.lin_forward_fin(x, in_coef, 0.1, w, gam, bet, 1e-5)
+        c2, m2 = hip_backend.bn_finalize(rows, sums, gam, bet, 1e-5)
+        bad += int(not (torch.equal(coef, c2) and torch.equal(mi, m2)))
+    assert bad == 0, bad
