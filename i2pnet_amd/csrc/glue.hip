@@ -137,6 +137,136 @@ __global__ __launch_bounds__(256) void maxresp_bwd_kernel(int N, int M, int C, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pose-head MLP (PPBackbone_center.py:553-562): hidden = W1 pooled + b1 -> dropout -> q = Wq h + bq, t = Wt h + bt ->
+// q / (sqrt(|q|^2 + 1e-10) + 1e-10) on [B, C] -> [B, 256] -> [B, 7] — three addmm, a dropout and a normalisation forward,
+// ~16 launches backward (two GEMMs + a bias reduction per layer), all on a few KB.  One block does each direction.
+//   mask [B,H]: the dropout multiplier (0 or 1/(1-p)) or NULL.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PH_THREADS = 256;
+
+__global__ __launch_bounds__(PH_THREADS) void pose_head_fwd_kernel(int B, int C, int H, const float *__restrict__ pooled, const float *__restrict__ w1,
+                                                                   const float *__restrict__ b1, const float *__restrict__ mask,
+                                                                   const float *__restrict__ wq, const float *__restrict__ bq,
+                                                                   const float *__restrict__ wt, const float *__restrict__ bt,
+                                                                   float *__restrict__ hid, float *__restrict__ qraw, float *__restrict__ q,
+                                                                   float *__restrict__ t) {
+    extern __shared__ float ph[];                           // pooled [B][C], hidden [B][H], out [B][8]
+    float *sp = ph, *sh = ph + B * C, *so = sh + B * H;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < B * C; i += PH_THREADS) sp[i] = pooled[i];
+    __syncthreads();
+    for (int h = tid; h < H; h += PH_THREADS)
+        for (int b = 0; b < B; ++b) {
+            float a = 0.f;
+            for (int c = 0; c < C; ++c) a = __builtin_fmaf(w1[(size_t)h * C + c], sp[b * C + c], a);
+            a += b1[h];
+            if (mask) a *= mask[b * H + h];
+            sh[b * H + h] = a; hid[b * H + h] = a;
+        }
+    __syncthreads();
+    for (int i = tid; i < B * 7; i += PH_THREADS) {
+        const int b = i / 7, o = i - b * 7;
+        const float *w = o < 4 ? wq + (size_t)o * H : wt + (size_t)(o - 4) * H;
+        float a = 0.f;
+        for (int h = 0; h < H; ++h) a = __builtin_fmaf(w[h], sh[b * H + h], a);
+        a += o < 4 ? bq[o] : bt[o - 4];
+        so[b * 8 + o] = a;
+        if (o < 4) qraw[b * 4 + o] = a; else t[b * 3 + o - 4] = a;
+    }
+    __syncthreads();
+    for (int b = tid; b < B; b += PH_THREADS) {
+        const float x = so[b * 8], y = so[b * 8 + 1], z = so[b * 8 + 2], w = so[b * 8 + 3];
+        const float d = sqrtf((x * x + y * y + z * z + w * w) + 1e-10f) + 1e-10f;
+        q[b * 4] = x / d; q[b * 4 + 1] = y / d; q[b * 4 + 2] = z / d; q[b * 4 + 3] = w / d;
+    }
+}
+
+__global__ __launch_bounds__(PH_THREADS) void pose_head_bwd_kernel(int B, int C, int H, const float *__restrict__ gq, const float *__restrict__ gt,
+                                                                   const float *__restrict__ qraw, const float *__restrict__ hid,
+                                                                   const float *__restrict__ mask, const float *__restrict__ pooled,
+                                                                   const float *__restrict__ w1, const float *__restrict__ wq,
+                                                                   const float *__restrict__ wt, float *__restrict__ d_pooled,
+                                                                   float *__restrict__ dw1, float *__restrict__ db1, float *__restrict__ dwq,
+                                                                   float *__restrict__ dbq, float *__restrict__ dwt, float *__restrict__ dbt) {
+    extern __shared__ float ph[];                           // pooled [B][C], d_hidden [B][H], d_out [B][8]
+    float *sp = ph, *sd = ph + B * C, *so = sd + B * H;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < B * C; i += PH_THREADS) sp[i] = pooled[i];
+    for (int b = tid; b < B; b += PH_THREADS) {             // normalisation backward (quat_unit_bwd_kernel, mode 1), then [d_qraw | d_t]
+        const float x = qraw[b * 4], y = qraw[b * 4 + 1], z = qraw[b * 4 + 2], w = qraw[b * 4 + 3];
+        const float g0 = gq ? gq[b * 4] : 0.f, g1 = gq ? gq[b * 4 + 1] : 0.f, g2 = gq ? gq[b * 4 + 2] : 0.f, g3 = gq ? gq[b * 4 + 3] : 0.f;
+        const float n2 = (x * x + y * y + z * z + w * w) + 1e-10f, rr = sqrtf(n2), d = rr + 1e-10f;
+        const float k = (g0 * x + g1 * y + g2 * z + g3 * w) / (d * d * rr);
+        so[b * 8] = g0 / d - x * k; so[b * 8 + 1] = g1 / d - y * k; so[b * 8 + 2] = g2 / d - z * k; so[b * 8 + 3] = g3 / d - w * k;
+        for (int o = 0; o < 3; ++o) so[b * 8 + 4 + o] = gt ? gt[b * 3 + o] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 7; i += PH_THREADS) {             // bias gradients of the two output layers
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += so[b * 8 + i];
+        if (i < 4) dbq[i] = a; else dbt[i - 4] = a;
+    }
+    for (int h = tid; h < H; h += PH_THREADS) {
+        float wcol[7];
+#pragma unroll
+        for (int o = 0; o < 7; ++o) wcol[o] = o < 4 ? wq[(size_t)o * H + h] : wt[(size_t)(o - 4) * H + h];
+        float dwo[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dbh = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float hv = hid[b * H + h];
+            float dh = 0.f;
+#pragma unroll
+            for (int o = 0; o < 7; ++o) { dh = __builtin_fmaf(so[b * 8 + o], wcol[o], dh); dwo[o] = __builtin_fmaf(so[b * 8 + o], hv, dwo[o]); }
+            if (mask) dh *= mask[b * H + h];
+            sd[b * H + h] = dh; dbh += dh;
+        }
+#pragma unroll
+        for (int o = 0; o < 7; ++o) { if (o < 4) dwq[(size_t)o * H + h] = dwo[o]; else dwt[(size_t)(o - 4) * H + h] = dwo[o]; }
+        db1[h] = dbh;
+    }
+    __syncthreads();
+    for (int i = tid; i < H * C; i += PH_THREADS) {         // dW1[h,c] = sum_b d_hidden[b,h] * pooled[b,c]
+        const int h = i / C, c = i - h * C;
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a = __builtin_fmaf(sd[b * H + h], sp[b * C + c], a);
+        dw1[i] = a;
+    }
+    if (d_pooled)
+        for (int i = tid; i < B * C; i += PH_THREADS) {     // d_pooled[b,c] = sum_h d_hidden[b,h] * W1[h,c]
+            const int b = i / C, c = i - b * C;
+            float a = 0.f;
+            for (int h = 0; h < H; ++h) a = __builtin_fmaf(sd[b * H + h], w1[(size_t)h * C + c], a);
+            d_pooled[i] = a;
+        }
+}
+
+}  // namespace
+
+static size_t pose_head_lds(int B, int C, int H) { return ((size_t)B * C + (size_t)B * H + (size_t)B * 8) * sizeof(float); }
+
+// pooled [B,C], w1 [H,C], b1 [H], mask [B,H] or NULL, wq [4,H], bq [4], wt [3,H], bt [3] -> hid [B,H] (post-dropout hidden, saved for the
+// backward), qraw [B,4] (unnormalised), q [B,4] = qraw / (sqrt(|qraw|^2 + 1e-10) + 1e-10), t [B,3]
+extern "C" int i2p_pose_head_fwd(int B, int C, int H, const float *pooled, const float *w1, const float *b1, const float *mask, const float *wq,
+                                 const float *bq, const float *wt, const float *bt, float *hid, float *qraw, float *q, float *t, void *stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || pose_head_lds(B, C, H) > 64 * 1024) return I2P_ERR_BAD_ARG;
+    if (!pooled || !w1 || !b1 || !wq || !bq || !wt || !bt || !hid || !qraw || !q || !t) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pose_head_fwd_kernel, dim3(1), dim3(PH_THREADS), pose_head_lds(B, C, H), (hipStream_t)stream, B, C, H, pooled, w1, b1, mask,
+                       wq, bq, wt, bt, hid, qraw, q, t);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+// gq [B,4] = dL/dq, gt [B,3] = dL/dt (either may be NULL = zero) -> every parameter gradient and d_pooled [B,C] (NULL: skipped)
+extern "C" int i2p_pose_head_bwd(int B, int C, int H, const float *gq, const float *gt, const float *qraw, const float *hid, const float *mask,
+                                 const float *pooled, const float *w1, const float *wq, const float *wt, float *d_pooled, float *dw1, float *db1,
+                                 float *dwq, float *dbq, float *dwt, float *dbt, void *stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || pose_head_lds(B, C, H) > 64 * 1024) return I2P_ERR_BAD_ARG;
+    if (!qraw || !hid || !pooled || !w1 || !wq || !wt || !dw1 || !db1 || !dwq || !dbq || !dwt || !dbt) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pose_head_bwd_kernel, dim3(1), dim3(PH_THREADS), pose_head_lds(B, C, H), (hipStream_t)stream, B, C, H, gq, gt, qraw, hid,
+                       mask, pooled, w1, wq, wt, d_pooled, dw1, db1, dwq, dbq, dwt, dbt);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+namespace {
 }  // namespace
 
 // pts [B,N,C], pix [B,M,C], valid [B,N] (0/1) -> respond [B,M,C]; saves fmaxmin [B,2,C], imaxmin i32 [B,2,C], anyv i32 [B]

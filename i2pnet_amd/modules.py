@@ -741,6 +741,56 @@ class CostVolume(nn.Module):
         self.pi_encoding.set_bn()
 
 
+class _PoseHeadMlp(torch.autograd.Function):
+    """hidden layer -> dropout -> quaternion / translation heads -> quaternion normalisation in one launch each way
+    (csrc/glue.hip i2p_pose_head_fwd/bwd; reference: three kernel-1 Conv1d + Dropout, PPBackbone_center.py:553-562)"""
+
+    @staticmethod
+    def forward(ctx, pooled, w1, b1, wq, bq, wt, bt, mask):
+        be = ops.get_backend()
+        B, C = pooled.shape
+        H = w1.shape[0]
+        dev = pooled.device
+        t = lambda x: x.detach().contiguous()
+        pooled, w1, b1, wq, bq, wt, bt = [t(x) for x in (pooled, w1, b1, wq, bq, wt, bt)]
+        hid = torch.empty(B, H, dtype=torch.float32, device=dev); qraw = torch.empty(B, 4, dtype=torch.float32, device=dev)
+        q = torch.empty(B, 4, dtype=torch.float32, device=dev); tr = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        P = lambda x: be._p(x, torch.float32, "pose_head") if x is not None else None
+        be._call("i2p_pose_head_fwd", int(B), int(C), int(H), P(pooled), P(w1), P(b1), P(mask), P(wq), P(bq), P(wt), P(bt), P(hid), P(qraw), P(q),
+                 P(tr), stream=be._stream())
+        ctx.save_for_backward(pooled, w1, wq, wt, hid, qraw, mask if mask is not None else hid.new_empty(0))
+        ctx.has_mask = mask is not None
+        return q, tr
+
+    @staticmethod
+    def backward(ctx, gq, gt):
+        pooled, w1, wq, wt, hid, qraw, mask = ctx.saved_tensors
+        be = ops.get_backend()
+        B, C = pooled.shape
+        H = w1.shape[0]
+        dev = pooled.device
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        d_pooled, dw1, db1, dwq, dbq, dwt, dbt = new(B, C), new(H, C), new(H), new(4, H), new(4), new(3, H), new(3)
+        P = lambda x: be._p(x.contiguous(), torch.float32, "pose_head") if x is not None else None
+        be._call("i2p_pose_head_bwd", int(B), int(C), int(H), P(gq), P(gt), P(qraw), P(hid), P(mask) if ctx.has_mask else None, P(pooled), P(w1),
+                 P(wq), P(wt), P(d_pooled), P(dw1), P(db1), P(dwq), P(dbq), P(dwt), P(dbt), stream=be._stream())
+        return d_pooled, dw1, db1, dwq, dbq, dwt, dbt, None
+
+
+_DROP_ONES = {}
+
+
+def _dropout_mask(drop, B, H, device):
+    """the multiplier F.dropout applies ([B,H] of 0 or 1/(1-p)) from the same generator as nn.Dropout, one launch; None when inactive"""
+    if not isinstance(drop, nn.Dropout) or not drop.training or drop.p == 0.0:
+        return None
+    key = (B, H, str(device))
+    ones = _DROP_ONES.get(key)
+    if ones is None:
+        ones = _DROP_ONES[key] = torch.ones(B, H, device=device)
+    return F.dropout(ones, drop.p, True)
+
+
 class PoseHead(nn.Module):
     """Mask-weighted global pooling + 6-DoF regression (PPBackbone_center.py:506-564)."""
 
@@ -773,6 +823,17 @@ class PoseHead(nn.Module):
         else:
             mask_p = F.softmax(mask, dim=1)                                     # over points, :551
             pooled = torch.sum(prediction * mask_p, dim=1, keepdim=True)        # [B,1,C]
+        be = ops.get_backend()
+        heads = (self.hidden_layer, self.quat_head, self.trans_head)
+        if (USE_FUSED_MLP and be.name == "hip" and pooled.is_cuda and pooled.dtype == torch.float32 and all(h._plain for h in heads)
+                and isinstance(self.DP2, nn.Identity) and pooled.shape[0] <= 32 and os.environ.get("I2P_NO_POSE_HEAD") != "1"
+                and all(isinstance(h.composed_module[2], nn.Identity) for h in heads)):
+            conv = lambda h: h.composed_module[0]
+            w1, wq, wt = (conv(h).weight.squeeze(-1) for h in heads)
+            drop = _dropout_mask(self.DP1, pooled.shape[0], w1.shape[0], pooled.device)
+            q, t = _PoseHeadMlp.apply(pooled.reshape(pooled.shape[0], -1), w1, conv(heads[0]).bias, wq, conv(heads[1]).bias, wt,
+                                      conv(heads[2]).bias, drop)
+            return q, t, mask_p
         hidden = self.DP1(self.hidden_layer(pooled))
         q = self.quat_head(self.DP2(hidden)).squeeze(1)
         t = self.trans_head(self.DP2(hidden)).squeeze(1)

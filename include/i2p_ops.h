@@ -533,6 +533,13 @@ int i2p_pc_rows_fwd(int b, int hw, int K, int W, int C, int c, const float *xyz,
                     const int64_t *h_idx, const int64_t *w_idx, float *geo, float *part, float *nbf, void *stream);
 int i2p_pc_rows_bwd(int b, int hw, int K, int W, int C, int c, const float *xyz, const int64_t *h_idx, const int64_t *w_idx,
                     const float *g_geo, const float *g_part, const float *g_nbf, float *d_pts, float *comb, float *rows, void *stream);
+/* Pose-head MLP in one launch each way (PPBackbone_center.py:553-562): hid = (W1 pooled + b1) * mask, qraw = Wq hid + bq,
+ * t = Wt hid + bt, q = qraw / (sqrt(|qraw|^2 + 1e-10) + 1e-10).  pooled f32 [B,C], w1 [H,C], mask [B,H] (dropout multiplier, NULL = none). */
+int i2p_pose_head_fwd(int B, int C, int H, const float *pooled, const float *w1, const float *b1, const float *mask, const float *wq,
+                      const float *bq, const float *wt, const float *bt, float *hid, float *qraw, float *q, float *t, void *stream);
+int i2p_pose_head_bwd(int B, int C, int H, const float *gq, const float *gt, const float *qraw, const float *hid, const float *mask,
+                      const float *pooled, const float *w1, const float *wq, const float *wt, float *d_pooled, float *dw1, float *db1,
+                      float *dwq, float *dbq, float *dwt, float *dbt, void *stream);
 int i2p_row_valid(long long rows, int c, const float *x, float *out, void *stream);
 int i2p_mask_fill(long long rows, int c, const float *x, const float *valid, float fill, float *out, void *stream);
 int i2p_pad_cols(int rows, int c, int cpad, const float *w, float *out, void *stream);

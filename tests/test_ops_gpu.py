@@ -1150,3 +1150,48 @@ def test_last_block_finalize_is_stable_over_many_launches(hip_backend, rows, cin
         c2, m2 = hip_backend.bn_finalize(rows, sums, gam, bet, 1e-5)
         bad += int(not (torch.equal(coef, c2) and torch.equal(mi, m2)))
     assert bad == 0, bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,p", [(8, 64, 0.5), (2, 64, 0.0), (16, 128, 0.5)])
+def test_pose_head_mlp_fused_vs_torch_cpu(hip_backend, B, C, p):
+    """modules.PoseHead's regression MLP (hidden Conv1d -> Dropout -> quaternion / translation Conv1d -> normalisation,
+    PPBackbone_center.py:553-562) on the fused kernels against the same module evaluated by plain torch on the CPU with the SAME
+    dropout mask: outputs and every gradient to fp32 summation order."""
+    from i2pnet_amd import modules
+    import torch.nn.functional as F
+    torch.manual_seed(B + C)
+    head = modules.PoseHead([C, C], [], [], 256, 4, 3, dropout_rate=p)
+    head.train()
+    pooled = torch.randn(B, 1, C)
+    mask = (torch.rand(B, 256) > p).float() / (1.0 - p) if p > 0 else None
+    gq, gt = torch.randn(B, 4), torch.randn(B, 3)
+    # reference: the module's torch formulation with the mask applied by hand
+    conv = lambda h: h.composed_module[0]
+    ref_in = pooled.clone().requires_grad_(True)
+    hid = F.linear(ref_in, conv(head.hidden_layer).weight.squeeze(-1), conv(head.hidden_layer).bias)
+    if mask is not None:
+        hid = hid * mask.unsqueeze(1)
+    q = F.linear(hid, conv(head.quat_head).weight.squeeze(-1), conv(head.quat_head).bias).squeeze(1)
+    t = F.linear(hid, conv(head.trans_head).weight.squeeze(-1), conv(head.trans_head).bias).squeeze(1)
+    q = q / (torch.sqrt(torch.sum(q * q, dim=-1, keepdim=True) + 1e-10) + 1e-10)
+    params = [conv(h).weight for h in (head.hidden_layer, head.quat_head, head.trans_head)] + [conv(h).bias for h in (head.hidden_layer, head.quat_head, head.trans_head)]
+    ref_g = torch.autograd.grad([q, t], [ref_in] + params, [gq, gt])
+    # fused
+    hd = modules.PoseHead([C, C], [], [], 256, 4, 3, dropout_rate=p).to(DEV)
+    hd.load_state_dict(head.state_dict())
+    x = pooled.to(DEV).requires_grad_(True)
+    dparams = [conv(h).weight for h in (hd.hidden_layer, hd.quat_head, hd.trans_head)] + [conv(h).bias for h in (hd.hidden_layer, hd.quat_head, hd.trans_head)]
+    qd, td = modules._PoseHeadMlp.apply(x.reshape(B, C), dparams[0].squeeze(-1), dparams[3], dparams[1].squeeze(-1), dparams[4], dparams[2].squeeze(-1),
+                                        dparams[5], None if mask is None else mask.to(DEV))
+    got_g = torch.autograd.grad([qd, td], [x] + dparams, [gq.to(DEV), gt.to(DEV)])
+    assert torch.allclose(qd.cpu(), q.detach(), rtol=1e-5, atol=1e-6) and torch.allclose(td.cpu(), t.detach(), rtol=1e-5, atol=1e-5)
+    for a, b in zip(got_g, ref_g):
+        assert float((a.cpu() - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6
+    # and through the module (training mode draws its own mask: compare the p = 0 / eval case only)
+    if p == 0.0:
+        valid = torch.ones(B, 57, C)
+        pred = torch.randn(B, 57, C)
+        q1, t1, _ = hd(pred.to(DEV), valid.to(DEV), None, None, None)
+        q0, t0, _ = head(pred, valid, None, None, None)
+        assert torch.allclose(q1.cpu(), q0, rtol=1e-4, atol=1e-5) and torch.allclose(t1.cpu(), t0, rtol=1e-4, atol=1e-5)
