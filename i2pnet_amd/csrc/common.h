@@ -42,6 +42,16 @@ __device__ __forceinline__ unsigned i2p_row16_add_u32(unsigned v) {
     return v;
 }
 
+// float sum over a 16-lane row (all lanes end with the row sum), returned as bits
+__device__ __forceinline__ unsigned i2p_row16_add_f32(float f) {
+    unsigned v = __float_as_uint(f);
+    v = __float_as_uint(__uint_as_float(v) + __uint_as_float(i2p_dpp_u32<0xB1>(v)));
+    v = __float_as_uint(__uint_as_float(v) + __uint_as_float(i2p_dpp_u32<0x4E>(v)));
+    v = __float_as_uint(__uint_as_float(v) + __uint_as_float(i2p_dpp_u32<0x141>(v)));
+    v = __float_as_uint(__uint_as_float(v) + __uint_as_float(i2p_dpp_u32<0x140>(v)));
+    return v;
+}
+
 // Blocks of one batch sample share that sample's range image; the dispatcher places block b
 // on XCD b%8 (observed, speed only), so give each XCD a contiguous run of logical blocks and
 // its L2 sees one sample's image instead of all of them.

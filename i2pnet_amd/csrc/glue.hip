@@ -151,28 +151,41 @@ __global__ __launch_bounds__(PH_THREADS) void pose_head_fwd_kernel(int B, int C,
                                                                    const float *__restrict__ wt, const float *__restrict__ bt,
                                                                    float *__restrict__ hid, float *__restrict__ qraw, float *__restrict__ q,
                                                                    float *__restrict__ t) {
-    extern __shared__ float ph[];                           // pooled [B][C], hidden [B][H], out [B][8]
-    float *sp = ph, *sh = ph + B * C, *so = sh + B * H;
+    extern __shared__ float ph[];                           // pooled [B][C], hidden [B][H], out [B][8], W1 [H][C+1]
+    float *sp = ph, *sh = ph + B * C, *so = sh + B * H, *sw = so + B * 8;
     const int tid = threadIdx.x;
     for (int i = tid; i < B * C; i += PH_THREADS) sp[i] = pooled[i];
+    for (int i = tid; i < H * C; i += PH_THREADS) sw[(i / C) * (C + 1) + (i % C)] = w1[i];      // coalesced; row pitch C+1: conflict-free row reads
     __syncthreads();
     for (int h = tid; h < H; h += PH_THREADS)
-        for (int b = 0; b < B; ++b) {
-            float a = 0.f;
-            for (int c = 0; c < C; ++c) a = __builtin_fmaf(w1[(size_t)h * C + c], sp[b * C + c], a);
-            a += b1[h];
-            if (mask) a *= mask[b * H + h];
-            sh[b * H + h] = a; hid[b * H + h] = a;
+        for (int b0 = 0; b0 < B; b0 += 8) {
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < C; ++c) {
+                const float w = sw[h * (C + 1) + c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (b0 + j < B) a[j] = __builtin_fmaf(w, sp[(b0 + j) * C + c], a[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (b0 + j < B) {
+                    float v = a[j] + b1[h];
+                    if (mask) v *= mask[(b0 + j) * H + h];
+                    sh[(b0 + j) * H + h] = v; hid[(b0 + j) * H + h] = v;
+                }
         }
     __syncthreads();
-    for (int i = tid; i < B * 7; i += PH_THREADS) {
-        const int b = i / 7, o = i - b * 7;
+    // the 7*B output dot products of length H: one 16-lane group per (b, o), partial sums combined with DPP row adds
+    for (int i = tid >> 4; i < B * 7; i += PH_THREADS / 16) {
+        const int b = i / 7, o = i - b * 7, l = tid & 15;
         const float *w = o < 4 ? wq + (size_t)o * H : wt + (size_t)(o - 4) * H;
         float a = 0.f;
-        for (int h = 0; h < H; ++h) a = __builtin_fmaf(w[h], sh[b * H + h], a);
-        a += o < 4 ? bq[o] : bt[o - 4];
-        so[b * 8 + o] = a;
-        if (o < 4) qraw[b * 4 + o] = a; else t[b * 3 + o - 4] = a;
+        for (int h = l; h < H; h += 16) a = __builtin_fmaf(w[h], sh[b * H + h], a);
+        a = __uint_as_float(i2p_row16_add_f32(a));
+        if (l == 0) {
+            a += o < 4 ? bq[o] : bt[o - 4];
+            so[b * 8 + o] = a;
+            if (o < 4) qraw[b * 4 + o] = a; else t[b * 3 + o - 4] = a;
+        }
     }
     __syncthreads();
     for (int b = tid; b < B; b += PH_THREADS) {
@@ -189,10 +202,12 @@ __global__ __launch_bounds__(PH_THREADS) void pose_head_bwd_kernel(int B, int C,
                                                                    const float *__restrict__ wt, float *__restrict__ d_pooled,
                                                                    float *__restrict__ dw1, float *__restrict__ db1, float *__restrict__ dwq,
                                                                    float *__restrict__ dbq, float *__restrict__ dwt, float *__restrict__ dbt) {
-    extern __shared__ float ph[];                           // pooled [B][C], d_hidden [B][H], d_out [B][8]
-    float *sp = ph, *sd = ph + B * C, *so = sd + B * H;
+    extern __shared__ float ph[];                           // pooled [B][C], d_hidden [B][H], d_out [B][8], W1 [H][C+1]
+    float *sp = ph, *sd = ph + B * C, *so = sd + B * H, *sw = so + B * 8;
     const int tid = threadIdx.x;
     for (int i = tid; i < B * C; i += PH_THREADS) sp[i] = pooled[i];
+    if (d_pooled)
+        for (int i = tid; i < H * C; i += PH_THREADS) sw[(i / C) * (C + 1) + (i % C)] = w1[i];
     for (int b = tid; b < B; b += PH_THREADS) {             // normalisation backward (quat_unit_bwd_kernel, mode 1), then [d_qraw | d_t]
         const float x = qraw[b * 4], y = qraw[b * 4 + 1], z = qraw[b * 4 + 2], w = qraw[b * 4 + 3];
         const float g0 = gq ? gq[b * 4] : 0.f, g1 = gq ? gq[b * 4 + 1] : 0.f, g2 = gq ? gq[b * 4 + 2] : 0.f, g3 = gq ? gq[b * 4 + 3] : 0.f;
@@ -235,21 +250,30 @@ __global__ __launch_bounds__(PH_THREADS) void pose_head_bwd_kernel(int B, int C,
         for (int i = tid; i < B * C; i += PH_THREADS) {     // d_pooled[b,c] = sum_h d_hidden[b,h] * W1[h,c]
             const int b = i / C, c = i - b * C;
             float a = 0.f;
-            for (int h = 0; h < H; ++h) a = __builtin_fmaf(sd[b * H + h], w1[(size_t)h * C + c], a);
+            for (int h = 0; h < H; ++h) a = __builtin_fmaf(sd[b * H + h], sw[h * (C + 1) + c], a);
             d_pooled[i] = a;
         }
 }
 
 }  // namespace
 
-static size_t pose_head_lds(int B, int C, int H) { return ((size_t)B * C + (size_t)B * H + (size_t)B * 8) * sizeof(float); }
+static size_t pose_head_lds(int B, int C, int H) { return ((size_t)B * C + (size_t)B * H + (size_t)B * 8 + (size_t)H * (C + 1)) * sizeof(float); }
+static void pose_head_attr() {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pose_head_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pose_head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done = true;
+    }
+}
 
 // pooled [B,C], w1 [H,C], b1 [H], mask [B,H] or NULL, wq [4,H], bq [4], wt [3,H], bt [3] -> hid [B,H] (post-dropout hidden, saved for the
 // backward), qraw [B,4] (unnormalised), q [B,4] = qraw / (sqrt(|qraw|^2 + 1e-10) + 1e-10), t [B,3]
 extern "C" int i2p_pose_head_fwd(int B, int C, int H, const float *pooled, const float *w1, const float *b1, const float *mask, const float *wq,
                                  const float *bq, const float *wt, const float *bt, float *hid, float *qraw, float *q, float *t, void *stream) {
-    if (B <= 0 || C <= 0 || H <= 0 || pose_head_lds(B, C, H) > 64 * 1024) return I2P_ERR_BAD_ARG;
+    if (B <= 0 || C <= 0 || H <= 0 || pose_head_lds(B, C, H) > 150 * 1024) return I2P_ERR_BAD_ARG;
     if (!pooled || !w1 || !b1 || !wq || !bq || !wt || !bt || !hid || !qraw || !q || !t) return I2P_ERR_BAD_ARG;
+    pose_head_attr();
     hipLaunchKernelGGL(pose_head_fwd_kernel, dim3(1), dim3(PH_THREADS), pose_head_lds(B, C, H), (hipStream_t)stream, B, C, H, pooled, w1, b1, mask,
                        wq, bq, wt, bt, hid, qraw, q, t);
     I2P_RETURN_LAUNCH_STATUS();
@@ -259,8 +283,9 @@ extern "C" int i2p_pose_head_fwd(int B, int C, int H, const float *pooled, const
 extern "C" int i2p_pose_head_bwd(int B, int C, int H, const float *gq, const float *gt, const float *qraw, const float *hid, const float *mask,
                                  const float *pooled, const float *w1, const float *wq, const float *wt, float *d_pooled, float *dw1, float *db1,
                                  float *dwq, float *dbq, float *dwt, float *dbt, void *stream) {
-    if (B <= 0 || C <= 0 || H <= 0 || pose_head_lds(B, C, H) > 64 * 1024) return I2P_ERR_BAD_ARG;
+    if (B <= 0 || C <= 0 || H <= 0 || pose_head_lds(B, C, H) > 150 * 1024) return I2P_ERR_BAD_ARG;
     if (!qraw || !hid || !pooled || !w1 || !wq || !wt || !dw1 || !db1 || !dwq || !dbq || !dwt || !dbt) return I2P_ERR_BAD_ARG;
+    pose_head_attr();
     hipLaunchKernelGGL(pose_head_bwd_kernel, dim3(1), dim3(PH_THREADS), pose_head_lds(B, C, H), (hipStream_t)stream, B, C, H, gq, gt, qraw, hid,
                        mask, pooled, w1, wq, wt, d_pooled, dw1, db1, dwq, dbq, dwt, dbt);
     I2P_RETURN_LAUNCH_STATUS();
