@@ -777,6 +777,11 @@ class _PoseHeadMlp(torch.autograd.Function):
         return d_pooled, dw1, db1, dwq, dbq, dwt, dbt, None
 
 
+def _pose_head_fits(B, C, H):
+    """LDS of the one-block pose-head kernels: pooled [B,C] + hidden [B,H] + outputs + W1 [H,C+1] (csrc/glue.hip pose_head_lds)"""
+    return (B * C + B * H + 8 * B + H * (C + 1)) * 4 <= 150 * 1024
+
+
 _DROP_ONES = {}
 
 
@@ -826,7 +831,8 @@ class PoseHead(nn.Module):
         be = ops.get_backend()
         heads = (self.hidden_layer, self.quat_head, self.trans_head)
         if (USE_FUSED_MLP and be.name == "hip" and pooled.is_cuda and pooled.dtype == torch.float32 and all(h._plain for h in heads)
-                and isinstance(self.DP2, nn.Identity) and pooled.shape[0] <= 32 and os.environ.get("I2P_NO_POSE_HEAD") != "1"
+                and isinstance(self.DP2, nn.Identity) and os.environ.get("I2P_NO_POSE_HEAD") != "1"
+                and _pose_head_fits(pooled.shape[0], pooled.shape[-1], self.hidden_layer.composed_module[0].out_channels)
                 and all(isinstance(h.composed_module[2], nn.Identity) for h in heads)):
             conv = lambda h: h.composed_module[0]
             w1, wq, wt = (conv(h).weight.squeeze(-1) for h in heads)

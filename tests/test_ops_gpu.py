@@ -1155,8 +1155,8 @@ def test_last_block_finalize_is_stable_over_many_launches(hip_backend, rows, cin
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,C,p", [(8, 64, 0.5), (2, 64, 0.0), (16, 128, 0.5)])
-def test_pose_head_mlp_fused_vs_torch_cpu(hip_backend, B, C, p):
+@pytest.mark.parametrize("B,C,p", [(8, 64, 0.5), (2, 64, 0.0), (16, 64, 0.5), (5, 128, 0.3)])
+def test_pose_head_mlp_fused_vs_torch_cpu(hip_backend, oracle_backend, B, C, p):
     """modules.PoseHead's regression MLP (hidden Conv1d -> Dropout -> quaternion / translation Conv1d -> normalisation,
     PPBackbone_center.py:553-562) on the fused kernels against the same module evaluated by plain torch on the CPU with the SAME
     dropout mask: outputs and every gradient to fp32 summation order."""
@@ -1195,9 +1195,9 @@ def test_pose_head_mlp_fused_vs_torch_cpu(hip_backend, B, C, p):
         valid = torch.ones(B, 57, C)
         pred = torch.randn(B, 57, C)
         q1, t1, _ = hd(pred.to(DEV), valid.to(DEV), None, None, None)
-        modules.USE_FUSED_MLP = False                      # (plain torch on the CPU for the reference module)
+        modules.USE_FUSED_MLP = False                      # (plain torch + oracle operators on the CPU for the reference module)
         try:
-            q0, t0, _ = head(pred, valid, None, None, None)
+            q0, t0, _ = _on_oracle(oracle_backend, lambda: head(pred, valid, None, None, None))
         finally:
             modules.USE_FUSED_MLP = True
         assert torch.allclose(q1.cpu(), q0, rtol=1e-4, atol=1e-5) and torch.allclose(t1.cpu(), t0, rtol=1e-4, atol=1e-5)
