@@ -418,6 +418,119 @@ extern "C" int i2p_quat_mul(int b, int na, int nb, int conj_a, int conj_b, const
 
 
 /* -------------------------------------------------------------------------------------------
+ * Warp of the level-3 cloud by the coarse pose + masking of empty cells + depth split, one launch each way
+ * (reference: warp_utils.py:78-94 warp_quat_xyz = cat, two Hamilton products, the quaternion inverse, an add, a slice;
+ * modellearn_proj_center.py:345-352 `* valid`, `z = P[:, :, 2:]`, `uv = P / (z + 1e-10)`; PPBackbone_center.py:377 `xyz = uv * z`:
+ * ~10 launches forward and ~25 backward on [B,228,3] tensors).
+ *   p' = (q (x) [0,p] (x) r + t)[1:4] * valid,  r = conj(q) / (|q|^2 + 1e-10);  z = p'_z;  uv = p' / (z + 1e-10);  xyz = uv * z
+ * Same fp32 operation order as quat_mul_kernel / quat_unit_fwd_kernel, so the values are those of the unfused chain.
+ * Backward (p and valid are data): dq [B,4], dt [B,4] (w component 0) from g_uv, g_z, g_xyz; one block per sample, the
+ * per-point contributions summed in a fixed tree order.
+ * ------------------------------------------------------------------------------------------- */
+namespace {
+__device__ __forceinline__ float4 qmul(const float4 &a, const float4 &b) {
+    const float aw = a.x, ax = a.y, ay = a.z, az = a.w, bw = b.x, bx = b.y, by = b.z, bz = b.w;
+    float4 o;
+    o.x = ((aw * bw - ax * bx) - ay * by) - az * bz;
+    o.y = ((aw * bx + ax * bw) + ay * bz) - az * by;
+    o.z = ((aw * by - ax * bz) + ay * bw) + az * bx;
+    o.w = ((aw * bz + ax * by) - ay * bx) + az * bw;
+    return o;
+}
+__device__ __forceinline__ float4 qconj(const float4 &a) { return make_float4(a.x, -a.y, -a.z, -a.w); }
+__device__ __forceinline__ float4 qinv(const float4 &v) {
+    const float n2 = (v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) + 1e-10f;
+    return make_float4(v.x / n2, -v.y / n2, -v.z / n2, -v.w / n2);
+}
+
+__global__ __launch_bounds__(256) void warp_split_fwd_kernel(int N, const float *__restrict__ p, const float4 *__restrict__ q,
+                                                             const float4 *__restrict__ t, const float *__restrict__ valid,
+                                                             float *__restrict__ uv, float *__restrict__ z, float *__restrict__ xyz) {
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const size_t i = (size_t)b * N + n;
+    const float4 qq = q[b], r = qinv(qq), tt = t[b];
+    const float4 P = make_float4(0.f, p[i * 3], p[i * 3 + 1], p[i * 3 + 2]);
+    const float4 h = qmul(qmul(qq, P), r);
+    const float v = valid ? valid[i] : 1.f;
+    const float px = (h.y + tt.y) * v, py = (h.z + tt.z) * v, pz = (h.w + tt.w) * v;
+    const float d = pz + 1e-10f;
+    const float ux = px / d, uy = py / d, uz = pz / d;
+    uv[i * 3] = ux; uv[i * 3 + 1] = uy; uv[i * 3 + 2] = uz;
+    z[i] = pz;
+    xyz[i * 3] = ux * pz; xyz[i * 3 + 1] = uy * pz; xyz[i * 3 + 2] = uz * pz;
+}
+
+__global__ __launch_bounds__(256) void warp_split_bwd_kernel(int N, const float *__restrict__ p, const float4 *__restrict__ q,
+                                                             const float4 *__restrict__ t, const float *__restrict__ valid,
+                                                             const float *__restrict__ g_uv, const float *__restrict__ g_z,
+                                                             const float *__restrict__ g_xyz, float4 *__restrict__ dq, float4 *__restrict__ dt) {
+    __shared__ float red[256][12];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float4 qq = q[b], r = qinv(qq), tt = t[b];
+    float acc[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // dq_direct (4), dr (4), dt (4)
+    for (int n = tid; n < N; n += 256) {
+        const size_t i = (size_t)b * N + n;
+        const float4 P = make_float4(0.f, p[i * 3], p[i * 3 + 1], p[i * 3 + 2]);
+        const float4 A = qmul(qq, P), h = qmul(A, r);
+        const float v = valid ? valid[i] : 1.f;
+        const float pp[3] = {(h.y + tt.y) * v, (h.z + tt.z) * v, (h.w + tt.w) * v};
+        const float zz = pp[2], d = zz + 1e-10f;
+        // p' -> (uv = p'/d, z = p'_z, xyz = uv * z):  d xyz_i / d p'_i = z/d, d xyz_i / d p'_z += p'_i * 1e-10 / d^2
+        float gp[3] = {0.f, 0.f, 0.f};
+        float gz = g_z ? g_z[i] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const float gu = (g_uv ? g_uv[i * 3 + e] : 0.f) + (g_xyz ? g_xyz[i * 3 + e] * zz : 0.f);   // gradient on uv_e (direct + through xyz = uv*z)
+            gp[e] += gu / d;
+            gz += (g_xyz ? g_xyz[i * 3 + e] * (pp[e] / d) : 0.f) - gu * pp[e] / (d * d);
+        }
+        gp[2] += gz;
+        const float4 G = make_float4(0.f, gp[0] * v, gp[1] * v, gp[2] * v);                            // through `* valid`; the w component was sliced away
+        // h = A (x) r:  dA = G (x) conj(r),  dr = conj(A) (x) G;   A = q (x) P:  dq = dA (x) conj(P)
+        const float4 dA = qmul(G, qconj(r)), dr = qmul(qconj(A), G), dqd = qmul(dA, qconj(P));
+        acc[0] += dqd.x; acc[1] += dqd.y; acc[2] += dqd.z; acc[3] += dqd.w;
+        acc[4] += dr.x; acc[5] += dr.y; acc[6] += dr.z; acc[7] += dr.w;
+        acc[9] += G.y; acc[10] += G.z; acc[11] += G.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) red[tid][e] = acc[e];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s)
+#pragma unroll
+            for (int e = 0; e < 12; ++e) red[tid][e] += red[tid + s][e];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        // r = conj(q) / n2 (quat_unit_bwd_kernel, mode 0):  dq += (s o dr - 2 q <dr, r>) / n2
+        const float n2 = (qq.x * qq.x + qq.y * qq.y + qq.z * qq.z + qq.w * qq.w) + 1e-10f;
+        const float gx = red[0][4], gy = red[0][5], gzz = red[0][6], gw = red[0][7];
+        const float dot = (gx * qq.x - gy * qq.y - gzz * qq.z - gw * qq.w) / n2;
+        dq[b] = make_float4(red[0][0] + (gx - 2.f * qq.x * dot) / n2, red[0][1] + (-gy - 2.f * qq.y * dot) / n2,
+                            red[0][2] + (-gzz - 2.f * qq.z * dot) / n2, red[0][3] + (-gw - 2.f * qq.w * dot) / n2);
+        dt[b] = make_float4(0.f, red[0][9], red[0][10], red[0][11]);
+    }
+}
+}  // namespace
+
+extern "C" int i2p_warp_split_fwd(int B, int N, const float *p, const float *q, const float *t, const float *valid, float *uv, float *z,
+                                  float *xyz, void *stream) {
+    if (B <= 0 || N <= 0 || !p || !q || !t || !uv || !z || !xyz) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(warp_split_fwd_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, N, p, (const float4 *)q, (const float4 *)t,
+                       valid, uv, z, xyz);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_warp_split_bwd(int B, int N, const float *p, const float *q, const float *t, const float *valid, const float *g_uv,
+                                  const float *g_z, const float *g_xyz, float *dq, float *dt, void *stream) {
+    if (B <= 0 || N <= 0 || !p || !q || !t || !dq || !dt) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(warp_split_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, N, p, (const float4 *)q, (const float4 *)t, valid, g_uv,
+                       g_z, g_xyz, (float4 *)dq, (float4 *)dt);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+/* -------------------------------------------------------------------------------------------
  * Row-wise "unit variance" of the cost-volume inputs — src/projectPN/PPBackbone_center.py:388-393:
  *     y = (x - mean_c(x)) / clip(std_c(x) (unbiased), min=1e-12)
  * (torch: mean, sub, std, clip, div forward and ~14 autograd launches backward; here one launch each way).

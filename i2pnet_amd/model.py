@@ -260,11 +260,18 @@ class RegNet_v2(nn.Module):
         -> (composed pose [B,7], q3 [B,4], t3 [B,3], mask weights)"""
         B = q_prev.shape[0]
         dev = q_prev.device
-        P3_warped = warp_utils.warp_quat_xyz(f["P3_pts"], q_prev, t_prev_quat) * f["p3_valid"]
-        lidar_z = P3_warped[:, :, 2:]
-        lidar_uv = P3_warped / (lidar_z + 1e-10)
+        # warp by the previous estimate, mask the empty cells, split off the depth: one launch each way on the device library
+        split = warp_utils.warp_split(f["P3_pts"], q_prev, t_prev_quat, f["p3_valid"]) if os.environ.get("I2P_NO_WARP_SPLIT") != "1" else None
+        if split is not None:
+            lidar_uv, lidar_z, xyz3 = split
+            P3_warped = None                                                     # (the pose head ignores its xyz argument)
+        else:
+            P3_warped = warp_utils.warp_quat_xyz(f["P3_pts"], q_prev, t_prev_quat) * f["p3_valid"]
+            lidar_z = P3_warped[:, :, 2:]
+            lidar_uv = P3_warped / (lidar_z + 1e-10)
+            xyz3 = None
         concat_3 = self.cost_volume2(f["P3_raw"], lidar_uv, f["LF3_pts"], f["l3_idx_n2"], f["pix_rays"], f["RF3_pts"],
-                                     lidar_z, cfg=f["cfg"], normalised=f["normalised"])
+                                     lidar_z, cfg=f["cfg"], normalised=f["normalised"], xyz=xyz3)
         l3_embed = self.flow_predictor0_predict(f["LF3_pts"], f["l3_embed_up"], concat_3.view(B, concat_3.shape[1] * concat_3.shape[2], -1))
         l3_mask = self.flow_predictor0_w(f["LF3_pts"], f["l3_mask_up"], l3_embed)
         l3_mask = mask_fill(l3_mask, f["l3_valid"])                             # :376

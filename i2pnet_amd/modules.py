@@ -683,7 +683,7 @@ class CostVolume(nn.Module):
         return h, run_stack(geo, [self.pi_encoding]), None
 
     def forward(self, xyz_proj_raw, warped_xyz, warped_points, idx_n2, f2_xyz, f2_points, lidar_z, cfg=None,
-                normalised=None):
+                normalised=None, xyz=None):
         """xyz_proj_raw [B,H,W,3]; warped_xyz [B,HW,3] (u,v,1); warped_points [B,HW,C];
         f2_xyz [B,M,3] pixel rays; f2_points [B,M,C]; lidar_z [B,HW,1] -> [B,H,W,mlp2[-1]].
         `normalised` = (unit-variance warped_points, unit-variance f2_points) if the caller already has
@@ -691,7 +691,8 @@ class CostVolume(nn.Module):
         B = warped_xyz.shape[0]
         N = warped_xyz.shape[1]
         uv = warped_xyz
-        xyz = warped_xyz.mul(lidar_z)                                           # restore depth, :377
+        if xyz is None:                                                         # (callers that already hold uv * z pass it: warp.warp_split)
+            xyz = warped_xyz.mul(lidar_z)                                       # restore depth, :377
         pts_n, pix_n = normalised if normalised is not None else (_unit_variance(warped_points),
                                                                   _unit_variance(f2_points))
         pi_feat = None

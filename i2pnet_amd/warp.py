@@ -92,3 +92,43 @@ def warp_quat_xyz(lidar_xyz, Hi_quat, H_trans):
     homo = torch.cat([ops.zero_scalar(lidar_xyz.device, lidar_xyz.dtype).expand(B, N, 1), lidar_xyz], -1)
     homo = mul_q(mul_q(Hi_quat, homo), inv_q(Hi_quat)) + H_trans.reshape(B, 1, 4)
     return homo[:, :, 1:4]
+
+
+class _WarpSplit(torch.autograd.Function):
+    """warp_quat_xyz(p, q, t) * valid, then (uv, z, xyz) = (p'/(z+1e-10), p'_z, uv*z) in one launch each way
+    (csrc/projection_ops.hip i2p_warp_split_fwd/bwd); gradients reach q and t (the cloud and the mask are data)."""
+
+    @staticmethod
+    def forward(ctx, p, q, t, valid):
+        be = ops.get_backend()
+        B, N, _ = p.shape
+        p, q, t = p.detach().contiguous(), q.detach().contiguous(), t.detach().contiguous()
+        v = valid.detach().reshape(B, N).contiguous() if valid is not None else None
+        uv = torch.empty(B, N, 3, dtype=torch.float32, device=p.device); z = torch.empty(B, N, 1, dtype=torch.float32, device=p.device)
+        xyz = torch.empty(B, N, 3, dtype=torch.float32, device=p.device)
+        P = lambda x: be._p(x, torch.float32, "warp_split") if x is not None else None
+        be._call("i2p_warp_split_fwd", int(B), int(N), P(p), P(q), P(t), P(v), P(uv), P(z), P(xyz), stream=be._stream())
+        ctx.save_for_backward(p, q, t, v if v is not None else p.new_empty(0))
+        ctx.has_valid = v is not None
+        return uv, z, xyz
+
+    @staticmethod
+    def backward(ctx, g_uv, g_z, g_xyz):
+        p, q, t, v = ctx.saved_tensors
+        be = ops.get_backend()
+        B, N, _ = p.shape
+        dq = torch.empty(B, 4, dtype=torch.float32, device=p.device); dt = torch.empty(B, 4, dtype=torch.float32, device=p.device)
+        P = lambda x: be._p(x.contiguous(), torch.float32, "warp_split") if x is not None else None
+        be._call("i2p_warp_split_bwd", int(B), int(N), P(p), P(q), P(t), P(v) if ctx.has_valid else None, P(g_uv), P(g_z), P(g_xyz), P(dq), P(dt),
+                 stream=be._stream())
+        return None, dq, dt, None
+
+
+def warp_split(p, q, t_quat, valid=None):
+    """p [B,N,3] (no gradient), q [B,4], t_quat [B,4] = [0,t], valid [B,N,1] 0/1 or None ->
+    (uv [B,N,3], z [B,N,1], xyz [B,N,3]) of the warped, masked cloud; None if the fused op does not apply"""
+    be = ops.get_backend()
+    if (be.name != "hip" or not p.is_cuda or p.dtype != torch.float32 or p.requires_grad or q.dtype != torch.float32
+            or (valid is not None and valid.requires_grad)):
+        return None
+    return _WarpSplit.apply(p, q.reshape(-1, 4), t_quat.reshape(-1, 4), valid)

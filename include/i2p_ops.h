@@ -540,6 +540,14 @@ int i2p_pose_head_fwd(int B, int C, int H, const float *pooled, const float *w1,
 int i2p_pose_head_bwd(int B, int C, int H, const float *gq, const float *gt, const float *qraw, const float *hid, const float *mask,
                       const float *pooled, const float *w1, const float *wq, const float *wt, float *d_pooled, float *dw1, float *db1,
                       float *dwq, float *dbq, float *dwt, float *dbt, void *stream);
+/* Warp of a cloud by a pose + empty-cell mask + depth split in one launch each way (warp_utils.py:78-94,
+ * modellearn_proj_center.py:345-352, PPBackbone_center.py:377): p f32 [B,N,3], q f32 [B,4] (w,x,y,z), t f32 [B,4] = [0,tx,ty,tz],
+ * valid f32 [B,N] (0/1) or NULL -> p' = (q (x) [0,p] (x) conj(q)/(|q|^2+1e-10) + t)[1:4] * valid; z [B,N] = p'_z; uv [B,N,3] = p' / (z + 1e-10);
+ * xyz [B,N,3] = uv * z.  Backward: g_uv / g_z / g_xyz (any may be NULL) -> dq [B,4], dt [B,4] (p and valid are data). */
+int i2p_warp_split_fwd(int B, int N, const float *p, const float *q, const float *t, const float *valid, float *uv, float *z, float *xyz,
+                       void *stream);
+int i2p_warp_split_bwd(int B, int N, const float *p, const float *q, const float *t, const float *valid, const float *g_uv, const float *g_z,
+                       const float *g_xyz, float *dq, float *dt, void *stream);
 int i2p_row_valid(long long rows, int c, const float *x, float *out, void *stream);
 int i2p_mask_fill(long long rows, int c, const float *x, const float *valid, float fill, float *out, void *stream);
 int i2p_pad_cols(int rows, int c, int cpad, const float *w, float *out, void *stream);

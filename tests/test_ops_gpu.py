@@ -1201,3 +1201,34 @@ def test_pose_head_mlp_fused_vs_torch_cpu(hip_backend, oracle_backend, B, C, p):
         finally:
             modules.USE_FUSED_MLP = True
         assert torch.allclose(q1.cpu(), q0, rtol=1e-4, atol=1e-5) and torch.allclose(t1.cpu(), t0, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(8, 228), (2, 600), (1, 5)])
+def test_warp_split_vs_reference_chain_on_cpu(hip_backend, oracle_backend, B, N):
+    """i2p_warp_split_fwd/bwd against the chain it replaces evaluated on the CPU with the oracle's quaternion operators
+    (warp_utils.py:78-94 warp_quat_xyz, `* valid`, z = P[:, :, 2:], uv = P / (z + 1e-10), xyz = uv * z): forward bit-exact, the pose
+    gradients to fp32 summation order."""
+    from i2pnet_amd import warp as warp_utils
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    p = torch.randn(B, N, 3, generator=g) * 10 + torch.tensor([0.0, 0.0, 20.0])
+    q = torch.randn(B, 4, generator=g); q = q / q.norm(dim=1, keepdim=True) * (1 + 0.01 * torch.randn(B, 1, generator=g))
+    t = torch.cat([torch.zeros(B, 1), torch.randn(B, 3, generator=g)], 1)
+    valid = (torch.rand(B, N, 1, generator=g) > 0.2).float()
+    gu, gz, gx = torch.randn(B, N, 3, generator=g), torch.randn(B, N, 1, generator=g), torch.randn(B, N, 3, generator=g)
+
+    def chain():
+        qq, tt = q.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        P3 = warp_utils.warp_quat_xyz(p, qq, tt) * valid
+        z = P3[:, :, 2:]
+        uv = P3 / (z + 1e-10)
+        xyz = uv.mul(z)
+        return (uv.detach(), z.detach(), xyz.detach()) + torch.autograd.grad([uv, z, xyz], [qq, tt], [gu, gz, gx])
+    uv, z, xyz, dq, dt = _on_oracle(oracle_backend, chain)
+    qd, td = q.to(DEV).requires_grad_(True), t.to(DEV).requires_grad_(True)
+    got = warp_utils.warp_split(p.to(DEV), qd, td, valid.to(DEV))
+    for a, b in zip(got, (uv, z, xyz)):
+        assert torch.equal(a.cpu(), b)
+    gq, gt = torch.autograd.grad(list(got), [qd, td], [gu.to(DEV), gz.to(DEV), gx.to(DEV)])
+    assert float((gq.cpu() - dq).abs().max()) <= 2e-5 * float(dq.abs().max()) + 1e-5
+    assert float((gt.cpu() - dt).abs().max()) <= 2e-5 * float(dt.abs().max()) + 1e-5
