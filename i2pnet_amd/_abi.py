@@ -91,6 +91,7 @@ DEVICE_ONLY = {
     "i2p_pose_head_bwd": ["i"] * 3 + ["p"] * 16,
     "i2p_warp_split_fwd": ["i", "i"] + ["p"] * 7,
     "i2p_warp_split_bwd": ["i", "i"] + ["p"] * 9,
+    "i2p_unpool_k_stats": ["l", "i", "i", "p", "p", "p", "p", "p", "p", "f", "p", "p"],
     "i2p_row_valid": ["l", "i", "p", "p"],
     "i2p_max_response_fwd": ["i"] * 4 + ["p"] * 7,
     "i2p_max_response_bwd": ["i"] * 4 + ["p"] * 7,

@@ -257,6 +257,58 @@ __global__ __launch_bounds__(THREADS) void unpool_k_v4(long long groups, int K, 
     }
 }
 
+// unpool_k_v4 + bn_act_bwd_stats_v4 in one pass: only the arg-max row of a group carries gradient, so the statistics
+// {sum gz, sum gz*xhat} (gz = dL/da * act'(bn(y))) need y at that row only — the separate statistics kernel re-read the dense
+// [groups*K, C] gradient and y (two full passes at level 1: 2 x 118 MB).  One thread per (group, float4 column); THREADS % cv == 0.
+__global__ __launch_bounds__(THREADS) void unpool_k_stats_v4(long long groups, int K, int c, const float4 *__restrict__ g,
+                                                              const uchar4 *__restrict__ arg, const float *__restrict__ y,
+                                                              const float *__restrict__ mean_invstd, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, float slope, float4 *__restrict__ gd,
+                                                              double *__restrict__ dsums) {
+    __shared__ double red[THREADS][8];
+    const int cv = c >> 2, vcol = threadIdx.x % cv;
+    BwdCoef kc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = vcol * 4 + i;
+        kc[i].mean = mean_invstd[ch]; kc[i].invstd = mean_invstd[c + ch];
+        kc[i].scale = kc[i].invstd * gamma[ch]; kc[i].beta = beta[ch];
+    }
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const long long total = groups * cv;
+    for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
+        const long long grp = t / cv;                          // (t % cv == vcol: the grid stride is a multiple of cv)
+        const float4 gv = g[t];
+        const uchar4 a = arg[t];
+        const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
+        const unsigned char aq[4] = {a.x, a.y, a.z, a.w};
+        for (int k = 0; k < K; ++k)
+            gd[(grp * K + k) * cv + vcol] = make_float4(a.x == k ? gv.x : 0.f, a.y == k ? gv.y : 0.f, a.z == k ? gv.z : 0.f, a.w == k ? gv.w : 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float yv = y[((grp * K + aq[i]) * cv + vcol) * 4 + i];
+            float dz, xh;
+            dz_xhat(yv, gq[i], kc[i], slope, dz, xh);
+            s[i] += dz; q[i] += (double)dz * xh;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][4 + i] = q[i]; }
+    __syncthreads();
+    if (threadIdx.x < cv) {
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = threadIdx.x; t < THREADS; t += cv)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += red[t][i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double *rep = dsums + (size_t)(blockIdx.x % REP) * 2 * c;
+            atomicAdd(rep + vcol * 4 + i, acc[i]);
+            atomicAdd(rep + c + vcol * 4 + i, acc[4 + i]);
+        }
+    }
+}
+
 // ---- generic path (any C): one thread per element, channel = index % C ------------------------
 __global__ void bn_stats_gen(long long total, int c, const float *__restrict__ y, double *__restrict__ sums) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -406,6 +458,21 @@ extern "C" int i2p_bn_act_maxk_fwd(long long groups, int K, int c, const float *
     if (blocks > (1 << 20)) blocks = 1 << 20;
     hipLaunchKernelGGL(bn_act_maxk_fwd_v4, dim3((unsigned)blocks), dim3(THREADS), 0, (hipStream_t)stream, groups, K, c,
                        (const float4 *)y, coef, slope, (float4 *)out, (uchar4 *)arg);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+// i2p_unpool_k + i2p_bn_act_bwd_stats of the dense result in one launch (dsums zeroed by the caller)
+extern "C" int i2p_unpool_k_stats(long long groups, int K, int c, const float *g, const unsigned char *arg, const float *y,
+                                  const float *mean_invstd, const float *gamma, const float *beta, float slope, float *gd, double *dsums,
+                                  void *stream) {
+    if (groups < 0 || K <= 0 || K > 255 || c <= 0 || (c & 3) || THREADS % (c >> 2)) return I2P_ERR_BAD_ARG;
+    if (groups == 0) return 0;
+    if (!g || !arg || !y || !mean_invstd || !gamma || !beta || !gd || !dsums) return I2P_ERR_BAD_ARG;
+    const long long total = groups * (c >> 2);
+    long long blocks = (total + THREADS - 1) / THREADS;
+    if (blocks > MAX_STAT_BLOCKS) blocks = MAX_STAT_BLOCKS;
+    hipLaunchKernelGGL(unpool_k_stats_v4, dim3((unsigned)blocks), dim3(THREADS), 0, (hipStream_t)stream, groups, K, c, (const float4 *)g,
+                       (const uchar4 *)arg, y, mean_invstd, gamma, beta, slope, (float4 *)gd, dsums);
     I2P_RETURN_LAUNCH_STATUS();
 }
 

@@ -214,9 +214,17 @@ class _MlpChain(Function):
         be = ops.get_backend()
         saved = list(ctx.saved_tensors)
         bf = getattr(ctx, "bf16", False)
+        fused_ds = None
         if ctx.pool_k:
             arg = saved.pop()
-            g_out = be.unpool_k(g_out.contiguous(), arg, ctx.pool_k, dtype=_BF if bf else torch.float32)   # dense dL/da in one pass
+            if (not bf and be.name == "hip" and ctx.nl and 256 % (g_out.shape[1] // 4) == 0 and os.environ.get("I2P_NO_UNPOOL_STATS") != "1"):
+                # dense dL/da AND the last block's BN-backward statistics in one pass (they only live on the arg-max rows)
+                n_ys = ctx.n_ys
+                last_y, last_mi = saved[n_ys - 1], saved[n_ys + 2 * ctx.n_coef - 1]
+                g_out, fused_ds = be.unpool_k_stats(g_out.contiguous(), arg, ctx.pool_k, last_y, last_mi, saved[-2].detach(), saved[-1].detach(),
+                                                    ctx.slopes[-1])
+            else:
+                g_out = be.unpool_k(g_out.contiguous(), arg, ctx.pool_k, dtype=_BF if bf else torch.float32)   # dense dL/da in one pass
         elif bf:
             g_out = be.to_bf16(g_out)
         ys = saved[:ctx.n_ys]
@@ -235,7 +243,9 @@ class _MlpChain(Function):
             return (gz if ctx.x_needs_grad else None), None, None, None, None, *grads
         # last block: only the statistics pass over (dL/da, y_L); the activation derivative and the BN backward are
         # applied by the layer kernels as they load dL/da (slope_out), so dL/dy_L is never written
-        if bf:
+        if fused_ds is not None:
+            out_ds = fused_ds
+        elif bf:
             out_ds = be.bn_act_backward_stats_bf16(g_out, ys[-1], coefs[-1], mis[-1], slopes[-1])
         else:
             out_ds = be.bn_act_backward_stats(g_out, ys[-1], mis[-1], last_g.detach(), last_b.detach(), slopes[-1])

@@ -492,6 +492,16 @@ class CBackend:
                    self._p(arg, torch.uint8, "arg"), self._p(gd, dtype, "gd"), stream=self._stream())
         return gd
 
+    def unpool_k_stats(self, g, arg, K, y, mean_invstd, gamma, beta, slope):
+        """unpool_k + bn_act_backward_stats of its result in one launch -> (dense dL/da [groups*K, c], dsums)"""
+        groups, c = g.shape
+        gd = torch.empty(groups * K, c, dtype=_F32, device=g.device)
+        dsums = zeros(BN_REPLICAS * 2 * c, torch.float64, g.device)
+        self._call("i2p_unpool_k_stats", int(groups), int(K), int(c), self._p(g, _F32, "g"), self._p(arg, torch.uint8, "arg"),
+                   self._p(y, _F32, "y"), self._p(mean_invstd, _F32, "mean_invstd"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"),
+                   float(slope), self._p(gd, _F32, "gd"), self._p(dsums, torch.float64, "dsums"), stream=self._stream())
+        return gd, dsums
+
     # ---- bf16-storage helpers (csrc/bf16_stream.hip) -----------------------------------------------------------
     def to_bf16(self, x):
         x = x.contiguous()

@@ -548,6 +548,10 @@ int i2p_warp_split_fwd(int B, int N, const float *p, const float *q, const float
                        void *stream);
 int i2p_warp_split_bwd(int B, int N, const float *p, const float *q, const float *t, const float *valid, const float *g_uv, const float *g_z,
                        const float *g_xyz, float *dq, float *dt, void *stream);
+/* i2p_unpool_k and i2p_bn_act_bwd_stats of its dense result in one launch (device library): g f32 [groups,c], arg u8 [groups,c],
+ * y f32 [groups*K,c] (the pre-BN tensor the maximum was taken over) -> gd f32 [groups*K,c], dsums += {sum gz, sum gz*xhat}. */
+int i2p_unpool_k_stats(long long groups, int K, int c, const float *g, const unsigned char *arg, const float *y, const float *mean_invstd,
+                       const float *gamma, const float *beta, float slope, float *gd, double *dsums, void *stream);
 int i2p_row_valid(long long rows, int c, const float *x, float *out, void *stream);
 int i2p_mask_fill(long long rows, int c, const float *x, const float *valid, float fill, float *out, void *stream);
 int i2p_pad_cols(int rows, int c, int cpad, const float *w, float *out, void *stream);

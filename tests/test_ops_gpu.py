@@ -1232,3 +1232,23 @@ def test_warp_split_vs_reference_chain_on_cpu(hip_backend, oracle_backend, B, N)
     gq, gt = torch.autograd.grad(list(got), [qd, td], [gu.to(DEV), gz.to(DEV), gx.to(DEV)])
     assert float((gq.cpu() - dq).abs().max()) <= 2e-5 * float(dq.abs().max()) + 1e-5
     assert float((gt.cpu() - dt).abs().max()) <= 2e-5 * float(dt.abs().max()) + 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups,K,c", [(28800, 32, 32), (7232, 16, 64), (928, 16, 128), (5, 3, 16)])
+def test_unpool_k_stats_matches_two_pass(hip_backend, oracle_backend, groups, K, c):
+    """i2p_unpool_k_stats (dense max-pool gradient + the BN-backward statistics of the layer underneath in one pass) against the
+    oracle's unpool_k_cpu -> bn_act_bwd_stats_cpu pair: gradient rows bit-exact, statistics to fp64 summation order."""
+    g = torch.Generator().manual_seed(groups + K)
+    y = torch.randn(groups * K, c, generator=g) * 1.3 + 0.2
+    gam = 1 + 0.1 * torch.randn(c, generator=g); bet = 0.1 * torch.randn(c, generator=g)
+    var, mean = torch.var_mean(y.double(), 0, unbiased=False)
+    mi = torch.cat([mean, torch.rsqrt(var + 1e-5)]).float()
+    gp = torch.randn(groups, c, generator=g)
+    arg = torch.randint(0, K, (groups, c), generator=g).to(torch.uint8)
+    want_gd = oracle_backend.unpool_k(gp, arg, K)
+    want_ds = oracle_backend.bn_act_backward_stats(want_gd, y, mi, gam, bet, 0.0)
+    gd, ds = hip_backend.unpool_k_stats(gp.to(DEV), arg.to(DEV), K, y.to(DEV), mi.to(DEV), gam.to(DEV), bet.to(DEV), 0.0)
+    assert torch.equal(gd.cpu(), want_gd)
+    a, b = ds.cpu().view(32, 2, c).sum(0), want_ds.view(32, 2, c).sum(0)
+    assert torch.allclose(a, b, rtol=1e-9, atol=1e-7 * groups ** 0.5)
