@@ -1375,10 +1375,19 @@ __global__ __launch_bounds__(SW_THREADS) void small_wgrad_kernel(SmallWgradP p) 
 
 }  // namespace
 
+// rows below which the weights-in-registers kernels hand over to the LDS-resident second generation (I2P_WREG_MIN_ROWS overrides)
+static long long wreg_min_rows() {
+    static const char *e = getenv("I2P_WREG_MIN_ROWS");
+    // 32768: the fine cost volume's layers (8 x 228 x 32 = 58 368 rows; nuScenes 43 776) run 2-3x faster here than on the
+    // second generation (A/B on one box: 615 -> 620 samples/s); below that a 1024-wave launch of 16-row strips is mostly pipeline fill
+    static const long long v = e ? atoll(e) : 32768;
+    return v;
+}
+
 bool i2p_wreg_fwd_ok(long long rows, int cin, int cout) {
     static const char *e = getenv("I2P_NO_WREG");
     if (e && e[0] == '1') return false;
-    return rows >= 65536 && (rows % WR_ROWS) == 0 && (cin == 64 || cin == 128) && (cout == 64 || cout == 128);
+    return rows >= wreg_min_rows() && (rows % WR_ROWS) == 0 && (cin == 64 || cin == 128) && (cout == 64 || cout == 128);
 }
 
 int i2p_wreg_fwd(long long rows, int cin, int cout, const float *x, int x_ld, const float *in_coef, float slope, const float *w,
@@ -1401,7 +1410,7 @@ int i2p_wreg_fwd(long long rows, int cin, int cout, const float *x, int x_ld, co
 bool i2p_wreg_dgrad_ok(long long rows, int k, int c) {
     static const char *e = getenv("I2P_NO_WREG");
     if (e && e[0] == '1') return false;
-    return rows >= 65536 && (rows % WR_ROWS) == 0 && (k == 64 || k == 128) && (c == 64 || c == 128);
+    return rows >= wreg_min_rows() && (rows % WR_ROWS) == 0 && (k == 64 || k == 128) && (c == 64 || c == 128);
 }
 
 int i2p_wreg_dgrad(long long rows, int k, int c, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
@@ -1428,7 +1437,7 @@ int i2p_wreg_dgrad(long long rows, int k, int c, const float *gz, const float *y
 bool i2p_wreg_wgrad_ok(long long rows, int cin, int cout) {
     static const char *e = getenv("I2P_NO_WREG");
     if (e && e[0] == '1') return false;
-    return rows >= 65536 && (rows % WR_ROWS) == 0 && (cin == 64 || cin == 128) && (cout == 64 || cout == 128);
+    return rows >= wreg_min_rows() && (rows % WR_ROWS) == 0 && (cin == 64 || cin == 128) && (cout == 64 || cout == 128);
 }
 
 int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,

@@ -204,3 +204,15 @@ def test_wreg_backward_full_size(hip_backend, monkeypatch):
     import sys
     monkeypatch.setattr(sys.modules[__name__], "ROWS", FULL_ROWS)
     test_wreg_backward(hip_backend, 128, 128)
+
+
+CV2_ROWS = 8 * 228 * 32            # the fine (32-NN) cost volume of configs[1]: below the round-2 threshold of 65 536 rows
+
+
+@pytest.mark.parametrize("cin,cout", [(128, 128), (128, 64), (64, 64)])
+def test_wreg_fine_cost_volume_rows(hip_backend, monkeypatch, cin, cout):
+    """the same statements at the fine cost volume's 58 368 rows (weights-in-registers kernels from 32 768 rows on, round 3)"""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "ROWS", CV2_ROWS)
+    test_wreg_forward(hip_backend, cin, cout, True)
+    test_wreg_backward(hip_backend, cin, cout)
