@@ -44,15 +44,17 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 2 x kH x swf/4 aligned 16-byte loads — all issued before the first LDS store: one global round trip per block instead of five.
 template <int SLOTS, bool VEC>
 __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
-    extern __shared__ float strip[];                       // sel [kH][swf] then raw [kH][swf]
+    extern __shared__ float strip[];                       // sel [kH][swf], raw [kH][swf], then outc u16 [QPB][K + 2 rounded up to 4]
     __shared__ int tab[SLOTS * GROUP];
-    __shared__ unsigned long long lst[QPB][SLOTS * GROUP];
-    __shared__ unsigned short outc[QPB][I2P_MAX_WINDOW + 2];
+    // parked sorted runs: distance bits and (position | stored) code apart, 6 instead of 8 bytes per candidate — the kernel is
+    // occupancy-bound (LDS per block decides how many blocks hide each other's global round trip)
+    __shared__ unsigned lst_d[QPB][SLOTS * GROUP];
+    __shared__ unsigned short lst_c[QPB][SLOTS * GROUP];
 
     const int kt = p.kH * p.kW;
     const int tid = threadIdx.x, g = tid >> 4, l16 = tid & 15;
     const int wblocks = (p.out_w + QPB - 1) / QPB;
-    int bid = blockIdx.x;
+    int bid = (int)i2p_xcd_swizzle(blockIdx.x, gridDim.x);    // a sample's blocks on one XCD: its two images stay in that L2
     const int wb = bid % wblocks; bid /= wblocks;
     const int qh = bid % p.out_h; const int b = bid / p.out_h;
     const int qw = wb * QPB + g;
@@ -60,6 +62,8 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
     const int ch = qh * p.stride_h, cw0 = wb * QPB * p.stride_w;
     const int h_lo = ch - p.kH / 2, w_lo = cw0 - p.kW / 2 - p.pad_l;          // image cell of strip cell (0, 0)
     float *ssel = strip, *sraw = strip + p.kH * p.swf;
+    const int ocp = (p.K + 2 + 3) & ~3;
+    unsigned short *outc_g = reinterpret_cast<unsigned short *>(strip + 2 * p.kH * p.swf) + g * ocp;   // this query's selected codes
     const size_t img = (size_t)b * p.H * p.W * 3;
 
     // ---- stage the strip of both images (zeros outside the image rows; columns wrap: FLAG_SHIFT) ----------------
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
     // A wave whose four queries all have empty centres (93 % of the centres of a 8192-point scan) selects nothing: it goes
     // straight to the output rows.  Everything below up to the output is private to the wave (lst[g], outc[g]).
     if (__any(live ? 1 : 0)) {
-        for (int i = l16; i < p.K; i += GROUP) outc[g][i] = 0;
+        for (int i = l16; i < p.K; i += GROUP) outc_g[i] = 0;
         // ---- A/B: evaluate, sort own keys, park the runs (fcsk_kernel steps A-B) ---------------------------------
         unsigned long long key[SLOTS];
 #pragma unroll
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
                 key[j] = sw_ ? b2 : a; key[j + 1] = sw_ ? a : b2;
             }
 #pragma unroll
-        for (int s = 1; s < SLOTS; ++s) lst[g][s * GROUP + l16] = key[s];
+        for (int s = 1; s < SLOTS; ++s) { lst_d[g][s * GROUP + l16] = (unsigned)(key[s] >> 32); lst_c[g][s * GROUP + l16] = (unsigned short)key[s]; }
         wave_lds_sync();
 
         // ---- C: K extraction steps (ends as soon as every query of the wave is done) ----------------------------
@@ -174,12 +178,11 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
                     tie |= (s > 0 && gmin == prev);
                     prev = gmin; ++steps;
                     if (head_hi == gmin) {
-                        outc[g][s] = (unsigned short)(head_lo | CODE_VALID);
+                        outc_g[s] = (unsigned short)(head_lo | CODE_VALID);
                         ++pops;
-                        unsigned long long nx = ((unsigned long long)PAD_BITS << 32);
-                        if (ptr < SLOTS) nx = lst[g][ptr * GROUP + l16];
+                        head_hi = PAD_BITS; head_lo = 0;
+                        if (ptr < SLOTS) { head_hi = lst_d[g][ptr * GROUP + l16]; head_lo = lst_c[g][ptr * GROUP + l16]; }
                         ++ptr;
-                        head_hi = (unsigned)(nx >> 32); head_lo = (unsigned)nx;
                     }
                 }
             }
@@ -199,24 +202,27 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
                     const int pos = s * GROUP + l16;
                     unsigned dbits = SENT_BITS, stored = 0;
                     if (pos < kt) eval(tab[pos], dbits, stored);
-                    lst[g][pos] = ((unsigned long long)dbits << 32) | (unsigned)(pos | (stored << 8));
+                    lst_d[g][pos] = dbits; lst_c[g][pos] = (unsigned short)(pos | (stored << 8));
                 }
             }
             wave_lds_sync();
             if (need_serial && l16 == 0) {
-                unsigned long long *a = lst[g];
+                unsigned *ad = lst_d[g]; unsigned short *ac = lst_c[g];
                 for (int s = 0; s < p.K; ++s) {                                                    // go.cu:183-236
                     int mi = s;
                     if (s < kt) {
-                        float dm = i2p_u2f((unsigned)(a[s] >> 32));
+                        float dm = i2p_u2f(ad[s]);
                         for (int t = s + 1; t < kt; ++t) {
-                            const float dt = i2p_u2f((unsigned)(a[t] >> 32));
+                            const float dt = i2p_u2f(ad[t]);
                             if (dt < dm) { dm = dt; mi = t; }
                         }
-                        if (mi != s) { const unsigned long long tmp = a[mi]; a[mi] = a[s]; a[s] = tmp; }
-                        const float ds = i2p_u2f((unsigned)(a[s] >> 32));
-                        outc[g][s] = (unsigned short)(((unsigned)a[s] & 0x1ffu) | (ds < 1e10f ? CODE_VALID : 0u));
-                    } else outc[g][s] = 0;
+                        if (mi != s) {
+                            const unsigned td = ad[mi]; ad[mi] = ad[s]; ad[s] = td;
+                            const unsigned short tc = ac[mi]; ac[mi] = ac[s]; ac[s] = tc;
+                        }
+                        const float ds = i2p_u2f(ad[s]);
+                        outc_g[s] = (unsigned short)((ac[s] & 0x1ffu) | (ds < 1e10f ? CODE_VALID : 0u));
+                    } else outc_g[s] = 0;
                 }
             }
         }
@@ -228,9 +234,9 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
     const float crx = sraw[cc], cry = sraw[cc + 1], crz = sraw[cc + 2];
     const float *cell00 = p.raw_xyz + img;                             // what an unset slot gathers: cell (0,0)
     const size_t obase = (((size_t)b * p.out_h + qh) * p.out_w + qw) * p.K;
-    const unsigned copy_code = live ? outc[g][0] : 0u;
+    const unsigned copy_code = live ? outc_g[0] : 0u;
     for (int s = l16; s < p.K; s += GROUP) {
-        unsigned code = live ? outc[g][s] : 0u;
+        unsigned code = live ? outc_g[s] : 0u;
         if (!(code & CODE_VALID)) code = copy_code;                    // FLAG_COPY (go.cu:211-222); empty centre: (0,0)
         float nx, ny, nz;
         if (code & CODE_STORED) {
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
 
 template <int SLOTS, bool VEC>
 int launch(const SaParams &p, hipStream_t st) {
-    const size_t bytes = (size_t)p.kH * p.swf * 2 * sizeof(float);
+    const size_t bytes = (size_t)p.kH * p.swf * 2 * sizeof(float) + (size_t)QPB * ((p.K + 2 + 3) & ~3) * sizeof(unsigned short);
     if (bytes > 96 * 1024) return I2P_ERR_BAD_ARG;
     static bool attr_set = false;
     if (!attr_set) {
