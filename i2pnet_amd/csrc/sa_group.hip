@@ -44,7 +44,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 2 x kH x swf/4 aligned 16-byte loads — all issued before the first LDS store: one global round trip per block instead of five.
 template <int SLOTS, bool VEC>
 __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
-    extern __shared__ float strip[];                       // sel [kH][swf], raw [kH][swf], then outc u16 [QPB][K + 2 rounded up to 4]
+    extern __shared__ float strip[];                       // sel [kH][swf], then outc u16 [QPB][K + 2 rounded up to 4]
     __shared__ int tab[SLOTS * GROUP];
     // parked sorted runs: distance bits and (position | stored) code apart, 6 instead of 8 bytes per candidate — the kernel is
     // occupancy-bound (LDS per block decides how many blocks hide each other's global round trip)
@@ -61,19 +61,29 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
     const bool in_range = qw < p.out_w;
     const int ch = qh * p.stride_h, cw0 = wb * QPB * p.stride_w;
     const int h_lo = ch - p.kH / 2, w_lo = cw0 - p.kW / 2 - p.pad_l;          // image cell of strip cell (0, 0)
-    float *ssel = strip, *sraw = strip + p.kH * p.swf;
+    // (round 3: only the SELECTION image is staged; the raw coordinates of the <= K selected cells and of the centre are gathered
+    // from global memory / L2 at the end — 15 KB less LDS per block = 5 instead of 3 blocks per CU hiding each other's round trips)
+    float *ssel = strip;
     const int ocp = (p.K + 2 + 3) & ~3;
-    unsigned short *outc_g = reinterpret_cast<unsigned short *>(strip + 2 * p.kH * p.swf) + g * ocp;   // this query's selected codes
+    unsigned short *outc_g = reinterpret_cast<unsigned short *>(strip + p.kH * p.swf) + g * ocp;   // this query's selected codes
     const size_t img = (size_t)b * p.H * p.W * 3;
 
+    // what an unset slot (and every slot of an empty centre) gathers: cell (0,0) of the raw image — requested now, so that the
+    // output phase does not start with a dependent global round trip
+    const float c00x = p.raw_xyz[img], c00y = p.raw_xyz[img + 1], c00z = p.raw_xyz[img + 2];
+    float crx = 0.f, cry = 0.f, crz = 0.f;                 // this query's centre in the raw image
+    if (in_range) {
+        const size_t o = img + ((size_t)ch * p.W + (size_t)qw * p.stride_w) * 3;
+        crx = p.raw_xyz[o]; cry = p.raw_xyz[o + 1]; crz = p.raw_xyz[o + 2];
+    }
     // ---- stage the strip of both images (zeros outside the image rows; columns wrap: FLAG_SHIFT) ----------------
     if (VEC) {
         const int n4row = p.swf >> 2, n4 = p.kH * n4row, w3 = p.W * 3;
-        float4 va[STAGE_IT], vb[STAGE_IT];
+        float4 va[STAGE_IT];
 #pragma unroll
         for (int it = 0; it < STAGE_IT; ++it) {
             const int i = tid + it * 256;
-            va[it] = make_float4(0.f, 0.f, 0.f, 0.f); vb[it] = va[it];
+            va[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < n4) {
                 const int r = i / n4row, j = i - r * n4row;
                 const int h = h_lo + r;
@@ -83,17 +93,13 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
                 if (h >= 0 && h < p.H) {
                     const size_t o = img + (size_t)h * w3 + fo;
                     va[it] = *reinterpret_cast<const float4 *>(p.sel_xyz + o);
-                    vb[it] = *reinterpret_cast<const float4 *>(p.raw_xyz + o);
                 }
             }
         }
 #pragma unroll
         for (int it = 0; it < STAGE_IT; ++it) {
             const int i = tid + it * 256;
-            if (i < n4) {
-                reinterpret_cast<float4 *>(ssel)[i] = va[it];
-                reinterpret_cast<float4 *>(sraw)[i] = vb[it];
-            }
+            if (i < n4) reinterpret_cast<float4 *>(ssel)[i] = va[it];
         }
     } else {
         const int cells = p.swf / 3, ncell = p.kH * cells;
@@ -103,14 +109,12 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
             int w = w_lo + cidx;
             if (w < 0) w += p.W;
             if (w >= p.W) w -= p.W;
-            float sx = 0.f, sy = 0.f, sz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f;
+            float sx = 0.f, sy = 0.f, sz = 0.f;
             if (h >= 0 && h < p.H && w >= 0 && w < p.W) {
                 const size_t o = img + ((size_t)h * p.W + w) * 3;
                 sx = p.sel_xyz[o]; sy = p.sel_xyz[o + 1]; sz = p.sel_xyz[o + 2];
-                rx = p.raw_xyz[o]; ry = p.raw_xyz[o + 1]; rz = p.raw_xyz[o + 2];
             }
             ssel[i * 3] = sx; ssel[i * 3 + 1] = sy; ssel[i * 3 + 2] = sz;
-            sraw[i * 3] = rx; sraw[i * 3 + 1] = ry; sraw[i * 3 + 2] = rz;
         }
     }
     for (int i = tid; i < SLOTS * GROUP; i += 256) {
@@ -165,8 +169,11 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
         wave_lds_sync();
 
         // ---- C: K extraction steps (ends as soon as every query of the wave is done) ----------------------------
+        // head = the lane's smallest remaining key, nxt = the one behind it (already in registers): a pop promotes nxt and
+        // requests the following key from LDS, whose latency is off the critical path unless the same lane pops twice in a row
         unsigned head_hi = (unsigned)(key[0] >> 32), head_lo = (unsigned)key[0];
-        int ptr = 1;
+        unsigned nxt_hi = SLOTS > 1 ? (unsigned)(key[SLOTS > 1 ? 1 : 0] >> 32) : PAD_BITS, nxt_lo = SLOTS > 1 ? (unsigned)key[SLOTS > 1 ? 1 : 0] : 0u;
+        int ptr = 2;
         unsigned pops = 0, steps = 0, prev = 0;
         bool tie = false, done = !live;
         for (int s = 0; s < p.K; ++s) {
@@ -180,8 +187,9 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
                     if (head_hi == gmin) {
                         outc_g[s] = (unsigned short)(head_lo | CODE_VALID);
                         ++pops;
-                        head_hi = PAD_BITS; head_lo = 0;
-                        if (ptr < SLOTS) { head_hi = lst_d[g][ptr * GROUP + l16]; head_lo = lst_c[g][ptr * GROUP + l16]; }
+                        head_hi = nxt_hi; head_lo = nxt_lo;
+                        nxt_hi = PAD_BITS; nxt_lo = 0;
+                        if (ptr < SLOTS) { nxt_hi = lst_d[g][ptr * GROUP + l16]; nxt_lo = lst_c[g][ptr * GROUP + l16]; }
                         ++ptr;
                     }
                 }
@@ -231,8 +239,6 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
     if (!in_range) return;
 
     // ---- feature rows: [nbr_raw - centre_raw, centre, nbr_raw, |d|, 0, 0] ----------------------------------------
-    const float crx = sraw[cc], cry = sraw[cc + 1], crz = sraw[cc + 2];
-    const float *cell00 = p.raw_xyz + img;                             // what an unset slot gathers: cell (0,0)
     const size_t obase = (((size_t)b * p.out_h + qh) * p.out_w + qw) * p.K;
     const unsigned copy_code = live ? outc_g[0] : 0u;
     for (int s = l16; s < p.K; s += GROUP) {
@@ -241,9 +247,13 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
         float nx, ny, nz;
         if (code & CODE_STORED) {
             const int tv = tab[code & 0xff];
-            const float *q = sraw + (p.kH / 2 + (tv >> 16)) * p.swf + (ccol + (int)(short)(tv & 0xffff)) * 3;
+            const int h = ch + (tv >> 16);                             // (a stored cell lies inside the image rows)
+            int w = qw * p.stride_w + (int)(short)(tv & 0xffff);
+            if (w < 0) w += p.W;
+            if (w >= p.W) w -= p.W;
+            const float *q = p.raw_xyz + img + ((size_t)h * p.W + w) * 3;
             nx = q[0]; ny = q[1]; nz = q[2];
-        } else { nx = cell00[0]; ny = cell00[1]; nz = cell00[2]; }
+        } else { nx = c00x; ny = c00y; nz = c00z; }
         const float dx = nx - crx, dy = ny - cry, dz = nz - crz;
         const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
         float4 *o = reinterpret_cast<float4 *>(p.feat + (obase + s) * 12);
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
 
 template <int SLOTS, bool VEC>
 int launch(const SaParams &p, hipStream_t st) {
-    const size_t bytes = (size_t)p.kH * p.swf * 2 * sizeof(float) + (size_t)QPB * ((p.K + 2 + 3) & ~3) * sizeof(unsigned short);
+    const size_t bytes = (size_t)p.kH * p.swf * sizeof(float) + (size_t)QPB * ((p.K + 2 + 3) & ~3) * sizeof(unsigned short);
     if (bytes > 96 * 1024) return I2P_ERR_BAD_ARG;
     static bool attr_set = false;
     if (!attr_set) {
