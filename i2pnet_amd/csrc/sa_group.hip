@@ -6,7 +6,7 @@
 // tensors + a mask, gathers the neighbour coordinates row by row, subtracts, takes norms and concatenates: ~10
 // launches and 34 MB of intermediates per sample at level 1.  Here a block owns 16 consecutive query cells of one
 // output row; their 9 x 15 windows overlap almost completely, so the block stages the union strip
-// (kH rows x (kW + 15*stride_w) columns) of BOTH range images (selection coordinates and raw coordinates) in LDS once
+// (kH rows x (kW + 15*stride_w) columns) of the selection image in LDS once (round 3: the raw coordinates are gathered at the end)
 // — "LDS staging of per-group neighbourhoods" — selects exactly like fcsk_kernel (16-lane DPP rows, sorted per-lane
 // runs, equal distances redone serially in the reference's order), and writes the 10-channel feature rows (padded to
 // 12 floats = three 16-byte stores per neighbour) straight from the staged strip.  No index tensor exists.
@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int GROUP = 16, QPB = 16;
+constexpr int GROUP = 16, QPB = 16, SA_THREADS = GROUP * QPB;
 constexpr unsigned SENT_BITS = 0x501502F9u, PAD_BITS = 0x7FFFFFFFu;
 constexpr unsigned CODE_STORED = 0x100u, CODE_VALID = 0x200u;
 constexpr int STAGE_IT = 4;               // 16-byte staging loads per thread and image, all in flight before the first LDS store
@@ -43,7 +43,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // VEC: the strip rows start on a 16-byte boundary of the image row and are whole float4s (launcher checks), so a block stages
 // 2 x kH x swf/4 aligned 16-byte loads — all issued before the first LDS store: one global round trip per block instead of five.
 template <int SLOTS, bool VEC>
-__global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
+__global__ __launch_bounds__(SA_THREADS) void sa_l1_kernel(SaParams p) {
     extern __shared__ float strip[];                       // sel [kH][swf], then outc u16 [QPB][K + 2 rounded up to 4]
     __shared__ int tab[SLOTS * GROUP];
     // parked sorted runs: distance bits and (position | stored) code apart, 6 instead of 8 bytes per candidate — the kernel is
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
         float4 va[STAGE_IT];
 #pragma unroll
         for (int it = 0; it < STAGE_IT; ++it) {
-            const int i = tid + it * 256;
+            const int i = tid + it * SA_THREADS;
             va[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < n4) {
                 const int r = i / n4row, j = i - r * n4row;
@@ -98,12 +98,12 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
         }
 #pragma unroll
         for (int it = 0; it < STAGE_IT; ++it) {
-            const int i = tid + it * 256;
+            const int i = tid + it * SA_THREADS;
             if (i < n4) reinterpret_cast<float4 *>(ssel)[i] = va[it];
         }
     } else {
         const int cells = p.swf / 3, ncell = p.kH * cells;
-        for (int i = tid; i < ncell; i += 256) {
+        for (int i = tid; i < ncell; i += SA_THREADS) {
             const int r = i / cells, cidx = i - r * cells;
             const int h = h_lo + r;
             int w = w_lo + cidx;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void sa_l1_kernel(SaParams p) {
             ssel[i * 3] = sx; ssel[i * 3 + 1] = sy; ssel[i * 3 + 2] = sz;
         }
     }
-    for (int i = tid; i < SLOTS * GROUP; i += 256) {
+    for (int i = tid; i < SLOTS * GROUP; i += SA_THREADS) {
         int v = 0;
         if (i < kt) { const int dh = i / p.kW - p.kH / 2, dw = i % p.kW - p.kW / 2; v = (dh << 16) | (dw & 0xffff); }   // random_hw = arange (utils.py:84)
         tab[i] = v;
@@ -271,7 +271,7 @@ int launch(const SaParams &p, hipStream_t st) {
         attr_set = true;
     }
     const unsigned grid = (unsigned)((long long)p.B * p.out_h * ((p.out_w + QPB - 1) / QPB));
-    hipLaunchKernelGGL((sa_l1_kernel<SLOTS, VEC>), dim3(grid), dim3(256), bytes, st, p);
+    hipLaunchKernelGGL((sa_l1_kernel<SLOTS, VEC>), dim3(grid), dim3(SA_THREADS), bytes, st, p);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
@@ -304,7 +304,7 @@ extern "C" int i2p_sa_l1_group(int B, int H, int W, int out_h, int out_w, int st
     // column wrap must fall between float4s: (kW/2 + pad_l) % 4 == 0, cells per row % 4 == 0, (16*stride_w) % 4 == 0, W % 4 == 0
     const int pad_l = (4 - (kW / 2) % 4) % 4;
     const int cells = (p.sw + pad_l + 3) / 4 * 4;
-    const bool vec = (W % 4 == 0) && ((QPB * stride_w) % 4 == 0) && cells <= W && kH * (cells * 3 / 4) <= 256 * STAGE_IT &&
+    const bool vec = (W % 4 == 0) && ((QPB * stride_w) % 4 == 0) && cells <= W && kH * (cells * 3 / 4) <= SA_THREADS * STAGE_IT &&
                      ((reinterpret_cast<uintptr_t>(sel_xyz) | reinterpret_cast<uintptr_t>(raw_xyz)) & 15) == 0 &&
                      !getenv("I2P_SA_SCALAR_STAGE");
     p.pad_l = vec ? pad_l : 0;
