@@ -61,9 +61,9 @@ __global__ __launch_bounds__(256) void strided_pick2_kernel(int B, int H, int W,
 // The torch formulation is 18 launches forward and 14 backward on [8,468,128] tensors; here one launch each way:
 // a block owns (sample, 32 channels): it reduces max / min (+ arg) over the points, then streams the pixels.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int MR_CH = 32, MR_ROWS = 8;      // 256 threads = 8 row lanes x 32 channels
+constexpr int MR_CH = 32, MR_ROWS = 32, MR_THREADS = MR_CH * MR_ROWS;      // 1024 threads = 32 row lanes x 32 channels (few blocks: the waves of a block hide each other's latencies)
 
-__global__ __launch_bounds__(256) void maxresp_fwd_kernel(int N, int M, int C, const float *__restrict__ pts, const float *__restrict__ pix,
+__global__ __launch_bounds__(MR_THREADS) void maxresp_fwd_kernel(int N, int M, int C, const float *__restrict__ pts, const float *__restrict__ pix,
                                                           const float *__restrict__ valid, float *__restrict__ respond,
                                                           float *__restrict__ fmaxmin, int *__restrict__ imaxmin, int *__restrict__ anyv) {
     __shared__ float smax[MR_ROWS][MR_CH], smin[MR_ROWS][MR_CH];
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void maxresp_fwd_kernel(int N, int M, int C, c
         }
     smax[r][ch] = vmax; smin[r][ch] = vmin; simax[r][ch] = imax; simin[r][ch] = imin; sany[r][ch] = any;
     __syncthreads();
-    // combine the 8 row lanes (lowest point index wins ties, like a serial scan)
+    // combine the row lanes (lowest point index wins ties, like a serial scan)
     vmax = smax[0][ch]; vmin = smin[0][ch]; imax = simax[0][ch]; imin = simin[0][ch]; any = sany[0][ch];
 #pragma unroll
     for (int q = 1; q < MR_ROWS; ++q) {
@@ -98,13 +98,14 @@ __global__ __launch_bounds__(256) void maxresp_fwd_kernel(int N, int M, int C, c
         if (blockIdx.y == 0 && ch == 0) anyv[b] = any;
     }
     if (c >= C) return;
+#pragma unroll 4
     for (int k = r; k < M; k += MR_ROWS) {
         const float g = pix[((size_t)b * M + k) * C + c];
         respond[((size_t)b * M + k) * C + c] = any ? g * (g >= 0.f ? vmax : vmin) : -1e10f;
     }
 }
 
-__global__ __launch_bounds__(256) void maxresp_bwd_kernel(int N, int M, int C, const float *__restrict__ g, const float *__restrict__ pix,
+__global__ __launch_bounds__(MR_THREADS) void maxresp_bwd_kernel(int N, int M, int C, const float *__restrict__ g, const float *__restrict__ pix,
                                                           const float *__restrict__ fmaxmin, const int *__restrict__ imaxmin,
                                                           const int *__restrict__ anyv, float *__restrict__ d_pts, float *__restrict__ d_pix) {
     __shared__ float s1[MR_ROWS][MR_CH], s2[MR_ROWS][MR_CH];
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256) void maxresp_bwd_kernel(int N, int M, int C, c
     float dmax = 0.f, dmin = 0.f;
     if (c < C) {
         const float vmax = fmaxmin[((size_t)b * 2 + 0) * C + c], vmin = fmaxmin[((size_t)b * 2 + 1) * C + c];
+#pragma unroll 4
         for (int k = r; k < M; k += MR_ROWS) {
             const size_t o = ((size_t)b * M + k) * C + c;
             const float gv = any ? g[o] : 0.f, pv = pix[o];
@@ -143,7 +145,30 @@ __global__ __launch_bounds__(256) void maxresp_bwd_kernel(int N, int M, int C, c
 // ~16 launches backward (two GEMMs + a bias reduction per layer), all on a few KB.  One block does each direction.
 //   mask [B,H]: the dropout multiplier (0 or 1/(1-p)) or NULL.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int PH_THREADS = 256;
+constexpr int PH_THREADS = 1024;      // one block, 16 waves: a one-block kernel has nothing else to hide its latencies
+
+// W1 [H][C] -> LDS rows of pitch C+1; C % 4 == 0: float4 loads, eight of them in flight per thread before the first LDS store
+__device__ __forceinline__ void stage_w1(float *sw, const float *__restrict__ w1, int H, int C, int tid) {
+    if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(w1) & 15) == 0) {
+        const int n4 = (H * C) >> 2;
+        for (int i0 = tid; i0 < n4; i0 += PH_THREADS * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * PH_THREADS; v[u] = i < n4 ? reinterpret_cast<const float4 *>(w1)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * PH_THREADS;
+                if (i < n4) {
+                    const int e = i * 4, r = e / C, c = e - r * C;
+                    float *d = sw + r * (C + 1) + c;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                }
+            }
+        }
+    } else {
+        for (int i = tid; i < H * C; i += PH_THREADS) sw[(i / C) * (C + 1) + (i % C)] = w1[i];
+    }
+}
 
 __global__ __launch_bounds__(PH_THREADS) void pose_head_fwd_kernel(int B, int C, int H, const float *__restrict__ pooled, const float *__restrict__ w1,
                                                                    const float *__restrict__ b1, const float *__restrict__ mask,
@@ -154,31 +179,70 @@ __global__ __launch_bounds__(PH_THREADS) void pose_head_fwd_kernel(int B, int C,
     extern __shared__ float ph[];                           // pooled [B][C], hidden [B][H], out [B][8], W1 [H][C+1]
     float *sp = ph, *sh = ph + B * C, *so = sh + B * H, *sw = so + B * 8;
     const int tid = threadIdx.x;
-    for (int i = tid; i < B * C; i += PH_THREADS) sp[i] = pooled[i];
-    for (int i = tid; i < H * C; i += PH_THREADS) sw[(i / C) * (C + 1) + (i % C)] = w1[i];      // coalesced; row pitch C+1: conflict-free row reads
+    float *swo = sw + H * (C + 1);                          // [7][H]: the two output layers' weights
+    // A one-block kernel pays ~2 us for every dependent global round trip and the compiler will not move one staging loop's loads
+    // above the previous loop's LDS stores: request everything first (registers), store afterwards — one round trip for the prologue.
+    if (B * C <= 2 * PH_THREADS && 7 * H <= 7 * PH_THREADS && (C & 3) == 0 && H * C <= 16 * 4 * PH_THREADS && (reinterpret_cast<uintptr_t>(w1) & 15) == 0) {
+        float rp[2], ro[7];
+        float4 rw[16];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = tid + u * PH_THREADS; rp[u] = i < B * C ? pooled[i] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) { const int i = tid + u * PH_THREADS; ro[u] = i < 7 * H ? (i < 4 * H ? wq[i] : wt[i - 4 * H]) : 0.f; }
+        const int n4 = (H * C) >> 2;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = tid + u * PH_THREADS; rw[u] = i < n4 ? reinterpret_cast<const float4 *>(w1)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = tid + u * PH_THREADS; if (i < B * C) sp[i] = rp[u]; }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) { const int i = tid + u * PH_THREADS; if (i < 7 * H) swo[i] = ro[u]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = tid + u * PH_THREADS;
+            if (i < n4) {
+                const int e = i * 4, r = e / C, c = e - r * C;
+                float *d = sw + r * (C + 1) + c;
+                d[0] = rw[u].x; d[1] = rw[u].y; d[2] = rw[u].z; d[3] = rw[u].w;
+            }
+        }
+    } else {
+        for (int i = tid; i < B * C; i += PH_THREADS) sp[i] = pooled[i];
+        for (int i = tid; i < 7 * H; i += PH_THREADS) swo[i] = i < 4 * H ? wq[i] : wt[i - 4 * H];
+        stage_w1(sw, w1, H, C, tid);                        // coalesced 16-byte loads, 8 in flight; row pitch C+1: conflict-free row reads
+    }
     __syncthreads();
-    for (int h = tid; h < H; h += PH_THREADS)
-        for (int b0 = 0; b0 < B; b0 += 8) {
+    // phase 1: thread = (hidden unit h, batch slice): PH_THREADS / H slices, a slice takes batches part, part + nb, ...
+    const int nb = H <= PH_THREADS ? PH_THREADS / H : 1;
+    for (int item = tid; item < H * nb; item += PH_THREADS) {
+        const int h = item % H, part = item / H;
+        for (int bb = part; bb < B; bb += 8 * nb) {
+            const float bias = b1[h];
+            float mk[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mk[j] = (mask && bb + j * nb < B) ? mask[(bb + j * nb) * H + h] : 1.f;
             float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
             for (int c = 0; c < C; ++c) {
                 const float w = sw[h * (C + 1) + c];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (b0 + j < B) a[j] = __builtin_fmaf(w, sp[(b0 + j) * C + c], a[j]);
+                for (int j = 0; j < 8; ++j) if (bb + j * nb < B) a[j] = __builtin_fmaf(w, sp[(bb + j * nb) * C + c], a[j]);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (b0 + j < B) {
-                    float v = a[j] + b1[h];
-                    if (mask) v *= mask[(b0 + j) * H + h];
-                    sh[(b0 + j) * H + h] = v; hid[(b0 + j) * H + h] = v;
+                if (bb + j * nb < B) {
+                    float v = a[j] + bias;
+                    if (mask) v *= mk[j];
+                    sh[(bb + j * nb) * H + h] = v; hid[(bb + j * nb) * H + h] = v;
                 }
         }
+    }
     __syncthreads();
     // the 7*B output dot products of length H: one 16-lane group per (b, o), partial sums combined with DPP row adds
     for (int i = tid >> 4; i < B * 7; i += PH_THREADS / 16) {
         const int b = i / 7, o = i - b * 7, l = tid & 15;
-        const float *w = o < 4 ? wq + (size_t)o * H : wt + (size_t)(o - 4) * H;
+        const float *w = swo + o * H;
         float a = 0.f;
+#pragma unroll 8
         for (int h = l; h < H; h += 16) a = __builtin_fmaf(w[h], sh[b * H + h], a);
         a = __uint_as_float(i2p_row16_add_f32(a));
         if (l == 0) {
@@ -206,8 +270,7 @@ __global__ __launch_bounds__(PH_THREADS) void pose_head_bwd_kernel(int B, int C,
     float *sp = ph, *sd = ph + B * C, *so = sd + B * H, *sw = so + B * 8;
     const int tid = threadIdx.x;
     for (int i = tid; i < B * C; i += PH_THREADS) sp[i] = pooled[i];
-    if (d_pooled)
-        for (int i = tid; i < H * C; i += PH_THREADS) sw[(i / C) * (C + 1) + (i % C)] = w1[i];
+    if (d_pooled) stage_w1(sw, w1, H, C, tid);
     for (int b = tid; b < B; b += PH_THREADS) {             // normalisation backward (quat_unit_bwd_kernel, mode 1), then [d_qraw | d_t]
         const float x = qraw[b * 4], y = qraw[b * 4 + 1], z = qraw[b * 4 + 2], w = qraw[b * 4 + 3];
         const float g0 = gq ? gq[b * 4] : 0.f, g1 = gq ? gq[b * 4 + 1] : 0.f, g2 = gq ? gq[b * 4 + 2] : 0.f, g3 = gq ? gq[b * 4 + 3] : 0.f;
@@ -227,13 +290,24 @@ __global__ __launch_bounds__(PH_THREADS) void pose_head_bwd_kernel(int B, int C,
 #pragma unroll
         for (int o = 0; o < 7; ++o) wcol[o] = o < 4 ? wq[(size_t)o * H + h] : wt[(size_t)(o - 4) * H + h];
         float dwo[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dbh = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const float hv = hid[b * H + h];
-            float dh = 0.f;
+        for (int b0 = 0; b0 < B; b0 += 8) {
+            float hv[8], mk[8];                              // (all global reads of the chunk in flight before the arithmetic)
 #pragma unroll
-            for (int o = 0; o < 7; ++o) { dh = __builtin_fmaf(so[b * 8 + o], wcol[o], dh); dwo[o] = __builtin_fmaf(so[b * 8 + o], hv, dwo[o]); }
-            if (mask) dh *= mask[b * H + h];
-            sd[b * H + h] = dh; dbh += dh;
+            for (int j = 0; j < 8; ++j) {
+                hv[j] = b0 + j < B ? hid[(b0 + j) * H + h] : 0.f;
+                mk[j] = (mask && b0 + j < B) ? mask[(b0 + j) * H + h] : 1.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int b = b0 + j;
+                if (b < B) {
+                    float dh = 0.f;
+#pragma unroll
+                    for (int o = 0; o < 7; ++o) { dh = __builtin_fmaf(so[b * 8 + o], wcol[o], dh); dwo[o] = __builtin_fmaf(so[b * 8 + o], hv[j], dwo[o]); }
+                    if (mask) dh *= mk[j];
+                    sd[b * H + h] = dh; dbh += dh;
+                }
+            }
         }
 #pragma unroll
         for (int o = 0; o < 7; ++o) { if (o < 4) dwq[(size_t)o * H + h] = dwo[o]; else dwt[(size_t)(o - 4) * H + h] = dwo[o]; }
@@ -249,15 +323,25 @@ __global__ __launch_bounds__(PH_THREADS) void pose_head_bwd_kernel(int B, int C,
     if (d_pooled)
         for (int i = tid; i < B * C; i += PH_THREADS) {     // d_pooled[b,c] = sum_h d_hidden[b,h] * W1[h,c]
             const int b = i / C, c = i - b * C;
-            float a = 0.f;
-            for (int h = 0; h < H; ++h) a = __builtin_fmaf(sd[b * H + h], sw[h * (C + 1) + c], a);
-            d_pooled[i] = a;
+            // (a serial 256-step chain of two LDS reads + one FMA is latency-bound at ~130 cycles per step in a one-block kernel:
+            // four independent partial sums, eight steps in flight)
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int h = 0;
+#pragma unroll 2
+            for (; h + 3 < H; h += 4) {
+                a0 = __builtin_fmaf(sd[b * H + h], sw[h * (C + 1) + c], a0);
+                a1 = __builtin_fmaf(sd[b * H + h + 1], sw[(h + 1) * (C + 1) + c], a1);
+                a2 = __builtin_fmaf(sd[b * H + h + 2], sw[(h + 2) * (C + 1) + c], a2);
+                a3 = __builtin_fmaf(sd[b * H + h + 3], sw[(h + 3) * (C + 1) + c], a3);
+            }
+            for (; h < H; ++h) a0 = __builtin_fmaf(sd[b * H + h], sw[h * (C + 1) + c], a0);
+            d_pooled[i] = (a0 + a1) + (a2 + a3);
         }
 }
 
 }  // namespace
 
-static size_t pose_head_lds(int B, int C, int H) { return ((size_t)B * C + (size_t)B * H + (size_t)B * 8 + (size_t)H * (C + 1)) * sizeof(float); }
+static size_t pose_head_lds(int B, int C, int H) { return ((size_t)B * C + (size_t)B * H + (size_t)B * 8 + (size_t)H * (C + 1) + (size_t)7 * H) * sizeof(float); }
 static void pose_head_attr() {
     static bool done = false;
     if (!done) {
@@ -298,7 +382,7 @@ namespace {
 extern "C" int i2p_max_response_fwd(int B, int N, int M, int C, const float *pts, const float *pix, const float *valid, float *respond,
                                     float *fmaxmin, int *imaxmin, int *anyv, void *stream) {
     if (B <= 0 || N <= 0 || M <= 0 || C <= 0 || !pts || !pix || !valid || !respond || !fmaxmin || !imaxmin || !anyv) return I2P_ERR_BAD_ARG;
-    hipLaunchKernelGGL(maxresp_fwd_kernel, dim3(B, (C + MR_CH - 1) / MR_CH), dim3(256), 0, (hipStream_t)stream, N, M, C, pts, pix, valid, respond,
+    hipLaunchKernelGGL(maxresp_fwd_kernel, dim3(B, (C + MR_CH - 1) / MR_CH), dim3(MR_THREADS), 0, (hipStream_t)stream, N, M, C, pts, pix, valid, respond,
                        fmaxmin, imaxmin, anyv);
     I2P_RETURN_LAUNCH_STATUS();
 }
@@ -307,7 +391,7 @@ extern "C" int i2p_max_response_fwd(int B, int N, int M, int C, const float *pts
 extern "C" int i2p_max_response_bwd(int B, int N, int M, int C, const float *g, const float *pix, const float *fmaxmin, const int *imaxmin,
                                     const int *anyv, float *d_pts, float *d_pix, void *stream) {
     if (B <= 0 || N <= 0 || M <= 0 || C <= 0 || !g || !pix || !fmaxmin || !imaxmin || !anyv || !d_pts || !d_pix) return I2P_ERR_BAD_ARG;
-    hipLaunchKernelGGL(maxresp_bwd_kernel, dim3(B, (C + MR_CH - 1) / MR_CH), dim3(256), 0, (hipStream_t)stream, N, M, C, g, pix, fmaxmin, imaxmin,
+    hipLaunchKernelGGL(maxresp_bwd_kernel, dim3(B, (C + MR_CH - 1) / MR_CH), dim3(MR_THREADS), 0, (hipStream_t)stream, N, M, C, g, pix, fmaxmin, imaxmin,
                        anyv, d_pts, d_pix);
     I2P_RETURN_LAUNCH_STATUS();
 }

@@ -780,7 +780,7 @@ class _PoseHeadMlp(torch.autograd.Function):
 
 def _pose_head_fits(B, C, H):
     """LDS of the one-block pose-head kernels: pooled [B,C] + hidden [B,H] + outputs + W1 [H,C+1] (csrc/glue.hip pose_head_lds)"""
-    return (B * C + B * H + 8 * B + H * (C + 1)) * 4 <= 150 * 1024
+    return (B * C + B * H + 8 * B + H * (C + 1) + 7 * H) * 4 <= 150 * 1024
 
 
 _DROP_ONES = {}
