@@ -46,9 +46,18 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_update_kernel(long long n4,
                                                                    float b1, float b2, float w1, float w2, float eps, float wd, float clip,
                                                                    float gscale, float *__restrict__ total_out) {
     __shared__ float s_scale, s_bc2s, s_lrbc1;
-    if (threadIdx.x == 0) {
+    __shared__ double s_tot;
+    if (threadIdx.x < 64) {                 // the <= 256 partials: four per lane in index order, then a fixed shuffle tree (same result in every block)
         double t = 0.0;
-        for (int i = 0; i < nparts; ++i) t += partials[i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = threadIdx.x * 4 + u; if (i < nparts) t += partials[i]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (threadIdx.x == 0) s_tot = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = s_tot;
         const float total = (float)sqrt(t);
         float sc = 1.0f;
         if (clip > 0.f) sc = fminf(clip / (total + 1e-6f), 1.0f);       // torch.clamp(clip / (total + 1e-6), max=1)
@@ -101,7 +110,9 @@ extern "C" int i2p_clip_adam(long long n, float *param, float *grad, float *exp_
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_norm_kernel, dim3((unsigned)nb), dim3(ADAM_THREADS), 0, st, n4, reinterpret_cast<const float4 *>(grad), gscale,
                        partials, step);
-    hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)nb), dim3(ADAM_THREADS), 0, st, n4, reinterpret_cast<float4 *>(param),
+    long long nu = (n4 + ADAM_THREADS - 1) / ADAM_THREADS;       // the update streams 8 tensors: one float4 per thread, the whole chip
+    if (nu > 4096) nu = 4096;
+    hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)nu), dim3(ADAM_THREADS), 0, st, n4, reinterpret_cast<float4 *>(param),
                        reinterpret_cast<float4 *>(grad), reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq),
                        reinterpret_cast<const float4 *>(mask), partials, (int)nb, step, lr, (float)beta1, (float)beta2,
                        (float)(1.0 - beta1), (float)(1.0 - beta2),        // the lerp / addcmul weights as torch forms them: in double, then rounded

@@ -385,7 +385,17 @@ __global__ __launch_bounds__(128) void knn_rows_bwd_kernel(int n, int m, int K, 
     for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
         const float f = pts[((size_t)bi * n + pn) * c + ch];
         float acc = 0.f;
-        for (int k = 0; k < K; ++k) {
+        int k = 0;
+        for (; k + 3 < K; k += 4) {          // four neighbours' loads in flight (index -> pixel row is a dependent pair); same summation order
+            long long cell[4]; float gv[4], pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cell[u] = idx[row0 + k + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { gv[u] = g[(row0 + k + u) * cpad + 6 + ch]; pv[u] = pix[((size_t)bi * m + cell[u]) * c + ch]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc = fmaf(gv[u], pv[u], acc); gq[(row0 + k + u) * c + ch] = gv[u] * f; }
+        }
+        for (; k < K; ++k) {
             const long long cell = idx[row0 + k];
             const float gv = g[(row0 + k) * cpad + 6 + ch];
             acc = fmaf(gv, pix[((size_t)bi * m + cell) * c + ch], acc);
