@@ -689,10 +689,10 @@ def _json_line(res, args, world):
         "config": {"workload": {1: "configs[1]: synthetic KITTI-shaped batch, 375x1242 RGB + %d-pt cloud (%s layout), "
                                    "fp32 forward+loss+backward+clip+Adam",
                                 2: "configs[2]: synthetic KITTI-shaped batch, 375x1242 RGB + %d-pt cloud (%s layout), bf16 storage of "
-                                   "the fused chains' activations/gradients + bf16 MFMA point-MLP (fp32 accumulate, parameters, "
-                                   "image encoder), forward+loss+backward+clip+Adam",
+                                   "the fused chains' and the image encoder's activations/gradients + bf16 MFMA point-MLP and MIOpen "
+                                   "bf16 convolutions (fp32 accumulate, parameters, BN statistics fp64), forward+loss+backward+clip+Adam",
                                 4: "configs[4]: synthetic nuScenes-shaped batch (21x1800 range image), 375x1242 RGB + %d-pt cloud "
-                                   "(%s layout), bf16 storage + bf16 MFMA point-MLP, forward+loss+backward+clip+Adam"}[args.config]
+                                   "(%s layout), bf16 storage (fused chains + image encoder) + bf16 MFMA point-MLP, forward+loss+backward+clip+Adam"}[args.config]
                                % (args.points, args.layout),
                    "per_gpu_batch": args.batch, "global_batch": global_batch,
                    "parallelism": f"dp{world}", "hipgraph": res["graph_live"], "final_loss": round(res["loss"], 4)},

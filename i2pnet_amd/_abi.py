@@ -85,6 +85,8 @@ DEVICE_ONLY = {
     "i2p_clip_adam": ["l"] + ["p"] * 8 + ["d", "d"] + ["f"] * 4 + ["p"],
     "i2p_img_bn_stats_fin": ["i", "i", "i", "i", "p", "p", "p", "f", "f", "p", "p", "p", "p"],
     "i2p_img_bn_pool_bwd_fin": ["i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "f", "p", "p", "p", "p", "p"],
+    "i2p_img_block_fwd": ["i"] * 7 + ["p", "p", "p", "p", "f", "f", "f"] + ["p"] * 6,
+    "i2p_img_block_bwd": ["i"] * 7 + ["p"] * 6 + ["f"] + ["p"] * 4,
     "i2p_pc_rows_fwd": ["i"] * 6 + ["p"] * 8,
     "i2p_pc_rows_bwd": ["i"] * 6 + ["p"] * 9,
     "i2p_pose_head_fwd": ["i"] * 3 + ["p"] * 12,

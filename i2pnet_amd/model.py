@@ -111,6 +111,8 @@ class RegNet_v2(nn.Module):
         self.RGB_net1 = createCNNs(*cfg.rgb_encoder_channels[0])
         self.RGB_net2 = createCNNs(*cfg.rgb_encoder_channels[1])
         self.RGB_net3 = createCNNs(*cfg.rgb_encoder_channels[2])
+        for i, net in enumerate((self.RGB_net1, self.RGB_net2, self.RGB_net3)):
+            net.encoder_index = i                              # (bf16 storage mode: which stacks keep bf16 activations)
         # NHWC image encoder: MIOpen's fp32 3x3 conv / BN / pooling kernels run ~1.85x faster in
         # channels_last on MI355X (13.5 -> 7.3 ms fwd+bwd at B=8), and RF3 comes out as [B,h,w,C]
         for net in (self.RGB_net1, self.RGB_net2, self.RGB_net3):

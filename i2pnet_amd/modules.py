@@ -236,16 +236,26 @@ class Conv1d(nn.Module):
 class _BnActPool(torch.autograd.Function):
     """BatchNorm2d(train) + LeakyReLU + MaxPool2d(3, stride, 1) on a channels_last conv output, two HIP
     launches each way (csrc/image_block.hip); saves the conv output, the 1-byte arg-max and 2C statistics
-    (PyTorch saves the conv output, the BN output, the activation output and int64 pool indices)."""
+    (PyTorch saves the conv output, the BN output, the activation output and int64 pool indices).
+    The conv output may be bf16 (bf16 storage mode: MIOpen bf16 convolutions); `out_bf16` = the pooled output too."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, conv_bias, running_mean, running_var, stride, momentum, eps, slope):
+    def forward(ctx, y, gamma, beta, conv_bias, running_mean, running_var, stride, momentum, eps, slope, out_bf16=False):
         y_nhwc = y.permute(0, 2, 3, 1)                      # channels_last storage seen as [B,H,W,C]
         if not y_nhwc.is_contiguous():
             y_nhwc = y_nhwc.contiguous()
-        out, arg, mi = ops.get_backend().img_bn_pool_forward(
-            y_nhwc, gamma.detach(), beta.detach(), eps, slope, stride, momentum, conv_bias.detach(),
-            running_mean, running_var)
+        be = ops.get_backend()
+        # second-generation kernels (coefficients in the consumers' prologues, no finalize launches): what the bf16 storage runs on.
+        # In fp32 they measure the same as the first generation with its 64-thread finalize launches (628.0 vs 629.6 samples/s, A/B on
+        # one box: the prologue's dependent load -> barrier -> rsqrt chain costs what the launch did), so fp32 stays on generation 1
+        # unless I2P_IMG_GEN2=1.
+        ctx.gen2 = be.name == "hip" and (y.dtype == torch.bfloat16 or os.environ.get("I2P_IMG_GEN2") == "1")
+        if ctx.gen2:
+            out, arg, mi = be.img_block_forward(y_nhwc, gamma.detach(), beta.detach(), eps, slope, stride, momentum, conv_bias.detach(),
+                                                running_mean, running_var, out_bf16=out_bf16)
+        else:
+            out, arg, mi = be.img_bn_pool_forward(y_nhwc, gamma.detach(), beta.detach(), eps, slope, stride, momentum,
+                                                  conv_bias.detach(), running_mean, running_var)
         ctx.save_for_backward(y_nhwc, arg, mi, gamma, beta)
         ctx.stride, ctx.slope = stride, slope
         return out.permute(0, 3, 1, 2)                      # [B,C,Ho,Wo] view with channels_last strides
@@ -256,9 +266,35 @@ class _BnActPool(torch.autograd.Function):
         g_nhwc = g.permute(0, 2, 3, 1)
         if not g_nhwc.is_contiguous():
             g_nhwc = g_nhwc.contiguous()
-        dy, dgamma, dbeta = ops.get_backend().img_bn_pool_backward(g_nhwc, arg, y_nhwc, mi, gamma.detach(), beta.detach(),
-                                                                   ctx.slope, ctx.stride)
-        return dy.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, None
+        be = ops.get_backend()
+        fn = be.img_block_backward if ctx.gen2 else be.img_bn_pool_backward
+        dy, dgamma, dbeta = fn(g_nhwc, arg, y_nhwc, mi, gamma.detach(), beta.detach(), ctx.slope, ctx.stride)
+        return dy.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+class _CastBf16(torch.autograd.Function):
+    """the encoder's 15 conv weights fp32 -> bf16 in one multi-tensor copy (and their bf16 gradients back to fp32 in one)"""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        outs = [torch.empty_like(w, dtype=torch.bfloat16) for w in ws]
+        torch._foreach_copy_(outs, [w.detach() for w in ws])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        outs = [torch.empty_like(g, dtype=torch.float32) for g in gs]
+        torch._foreach_copy_(outs, list(gs))
+        return tuple(outs)
+
+
+# bf16 storage mode (ops.set_precision("bf16"), BASELINE.json configs[2] / [4]): the image encoder's activations are bf16 too — MIOpen
+# bf16 NHWC convolutions (fp32 accumulate) + the bf16 instantiations of the block-tail kernels; parameters, BN statistics and the
+# encoder's output stay fp32.  I2P_IMG_BF16_NETS = how many of the encoder's three 5-block stacks (from the input side) do that.
+def _img_bf16_nets():
+    if ops.get_precision() != "bf16" or ops.get_backend().name != "hip":
+        return 0
+    return int(os.environ.get("I2P_IMG_BF16_NETS", "3"))
 
 
 class _ImageCNN(nn.Sequential):
@@ -275,7 +311,7 @@ class _ImageCNN(nn.Sequential):
             c = conv.out_channels
             ok = (bn.track_running_stats and bn.momentum is not None and isinstance(act, nn.LeakyReLU)
                   and pool.kernel_size == 3 and pool.padding == 1 and pool.stride in (1, 2) and pool.dilation == 1
-                  and not pool.ceil_mode and c % 4 == 0 and 256 % (c // 4) == 0)
+                  and not pool.ceil_mode and c % 4 == 0 and 256 % (c // 4) == 0 and c <= 512)
             if not ok:
                 return False
         return True
@@ -287,15 +323,26 @@ class _ImageCNN(nn.Sequential):
         if not fast:
             return super().forward(x)
         bns = [mods[i + 1] for i in range(0, len(mods), 4)]
-        if USE_FUSED_IMG and x.dtype == torch.float32 and self._fusable(mods):
+        if USE_FUSED_IMG and x.dtype in (torch.float32, torch.bfloat16) and self._fusable(mods):
             with torch.no_grad():
                 torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
             x = x.contiguous(memory_format=torch.channels_last)
-            for i in range(0, len(mods), 4):
+            nbf = _img_bf16_nets()
+            idx = getattr(self, "encoder_index", None)         # (a stack on its own: bf16 inside, fp32 out)
+            bf = x.is_cuda and (nbf > 0 if idx is None else idx < nbf)
+            last = idx is None or idx == nbf - 1               # what leaves the bf16 part of the encoder is fp32
+            if not bf and x.dtype != torch.float32:
+                x = x.float()
+            nb = len(mods) // 4
+            if bf:
+                ws = _CastBf16.apply(*[mods[i].weight for i in range(0, len(mods), 4)])
+                if x.dtype != torch.bfloat16:
+                    x = x.to(torch.bfloat16)
+            for j, i in enumerate(range(0, len(mods), 4)):
                 conv, bn, act, pool = mods[i:i + 4]
-                y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+                y = F.conv2d(x, ws[j] if bf else conv.weight, None, conv.stride, conv.padding)
                 x = _BnActPool.apply(y, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
-                                     bn.momentum, bn.eps, act.negative_slope)
+                                     bn.momentum, bn.eps, act.negative_slope, bf and not (last and j == nb - 1))
             return x
         with torch.no_grad():
             # rm' = (1-m) rm + m (mean_without_bias + bias): pre-add m/(1-m) * bias (before autograd saves the buffer)

@@ -456,6 +456,42 @@ class CBackend:
             self._call("i2p_img_bn_pool_bwd", *args, stream=self._stream())
         return dy, dgamma, dbeta
 
+    def img_block_forward(self, y, gamma, beta, eps, slope, stride, momentum=0.0, conv_bias=None, running_mean=None,
+                          running_var=None, out_bf16=False):
+        """second generation of `img_bn_pool_forward` (device library only): y [B,H,W,C] fp32 or bf16 -> (out fp32 / bf16, arg u8,
+        mean_invstd [2C]); statistics + pooling in two launches, the coefficients formed in the pooling kernel's prologue."""
+        B, H, W, Cc = y.shape
+        if y.dtype not in (_F32, _BF16):
+            raise RuntimeError(f"y must be torch.float32 or torch.bfloat16 (got {y.dtype})")
+        ybf = y.dtype == _BF16
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        odt = _BF16 if out_bf16 else _F32
+        out = torch.empty(B, Ho, Wo, Cc, dtype=odt, device=y.device)
+        arg = torch.empty(B, Ho, Wo, Cc, dtype=torch.uint8, device=y.device)
+        mean_invstd = torch.empty(2 * Cc, dtype=_F32, device=y.device)
+        sums = zeros(BN_REPLICAS * 2 * Cc, torch.float64, y.device)
+        opt = lambda t, what: self._p(t, _F32, what) if t is not None else None
+        self._call("i2p_img_block_fwd", int(B), int(H), int(W), int(Cc), int(stride), int(ybf), int(bool(out_bf16)),
+                   self._p(y, y.dtype, "y"), self._p(sums, torch.float64, "sums"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"),
+                   float(eps), float(slope), float(momentum), opt(conv_bias, "conv_bias"), opt(running_mean, "running_mean"),
+                   opt(running_var, "running_var"), self._p(out, odt, "out"), self._p(arg, torch.uint8, "arg"),
+                   self._p(mean_invstd, _F32, "mean_invstd"), stream=self._stream())
+        return out, arg, mean_invstd
+
+    def img_block_backward(self, gout, arg, y, mean_invstd, gamma, beta, slope, stride):
+        """-> (dy [B,H,W,C] in y's storage type, dgamma [C], dbeta [C]); gout fp32 or bf16"""
+        B, H, W, Cc = y.shape
+        dy = torch.empty_like(y)
+        dgamma = torch.empty(Cc, dtype=_F32, device=y.device)
+        dbeta = torch.empty(Cc, dtype=_F32, device=y.device)
+        dsums = zeros(BN_REPLICAS * 2 * Cc, torch.float64, y.device)
+        self._call("i2p_img_block_bwd", int(B), int(H), int(W), int(Cc), int(stride), int(y.dtype == _BF16), int(gout.dtype == _BF16),
+                   self._p(gout, gout.dtype, "gout"), self._p(arg, torch.uint8, "arg"), self._p(y, y.dtype, "y"),
+                   self._p(mean_invstd, _F32, "mean_invstd"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(slope),
+                   self._p(dsums, torch.float64, "dsums"), self._p(dy, y.dtype, "dy"), self._p(dgamma, _F32, "dgamma"),
+                   self._p(dbeta, _F32, "dbeta"), stream=self._stream())
+        return dy, dgamma, dbeta
+
     # ---- batch-stat BatchNorm + activation (PPBackbone_center.py:28-46) ---------------------------
     def bn_act_forward(self, y, gamma, beta, eps, slope):
         """y [rows,c] f32 -> (out [rows,c], mean_invstd [2c]) with batch statistics.

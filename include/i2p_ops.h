@@ -299,6 +299,17 @@ int i2p_img_bn_pool_bwd_fin(int B, int H, int W, int C, int stride, const float 
 int i2p_img_bn_pool_bwd(int B, int H, int W, int C, int stride, const float *gout, const unsigned char *arg,
                         const float *y, const float *mean_invstd, const float *gamma, const float *beta,
                         float slope, double *dsums, float *dy, float *dgamma, float *dbeta, void *stream);
+/* Device library only — second generation of the same block tail, two launches each way: the statistics pass is part of the call
+ * (sums / dsums: zeroed [I2P_BN_REPLICAS][2C] doubles) and every block of the consumer kernel forms mean / invstd (forward) and
+ * dbeta / dgamma (backward) from the replica sums in its prologue.  y_bf16: the conv output y and its gradient dy are bf16 bits
+ * (MIOpen bf16 convolutions of the bf16 storage mode, BASELINE.json configs[2] / [4]); out_bf16: the pooled output and its gradient
+ * are bf16.  Arithmetic fp32, statistics fp64, arg-max decided on the fp32 values; C <= 512. */
+int i2p_img_block_fwd(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *y, double *sums, const float *gamma,
+                      const float *beta, float eps, float slope, float momentum, const float *conv_bias, float *running_mean,
+                      float *running_var, void *out, unsigned char *arg, float *mean_invstd, void *stream);
+int i2p_img_block_bwd(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout, const unsigned char *arg,
+                      const void *y, const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums, void *dy,
+                      float *dgamma, float *dbeta, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * First layer of the all-pixel cost volume (src/projectPN/PPBackbone_center.py:383-418): the

@@ -319,6 +319,105 @@ def test_img_bn_pool_parity(oracle_backend, hip_backend, stride, C, H, W, fin, m
     assert torch.allclose(gt.grad, hdg, rtol=1e-3, atol=1e-3 * float(rdg.abs().max()))
 
 
+@pytest.mark.parametrize("ybf,obf", [(False, False), (True, True), (True, False)])
+@pytest.mark.parametrize("stride,C,H,W", [(1, 16, 37, 53), (2, 16, 37, 53), (2, 32, 24, 40), (1, 64, 12, 20), (2, 128, 24, 78)])
+def test_img_block_gen2_parity(oracle_backend, hip_backend, stride, C, H, W, ybf, obf):
+    """second generation of the block tail (i2p_img_block_fwd / _bwd: coefficients formed in the consumers' prologues; fp32 or bf16
+    storage of the conv output / the pooled output) vs the oracle on the values the kernels find in memory: fp32 storage to the
+    limits of test_img_bn_pool_parity; bf16 storage — arg-max and fp32 results to the same limits, bf16 results to one bf16 ulp
+    (2^-8 relative)."""
+    g = torch.Generator().manual_seed(C + stride + 7)
+    B = 3
+    bf = torch.bfloat16
+    y = torch.randn(B, H, W, C, generator=g) * 2 + 0.3
+    if ybf:
+        y = y.to(bf).float()
+    gam = torch.randn(C, generator=g); bet = torch.randn(C, generator=g) * 0.2; bias = torch.randn(C, generator=g) * 0.1
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    rm_o, rv_o, rm_h, rv_h = rm.clone(), rv.clone(), rm.clone().to(DEV), rv.clone().to(DEV)
+    ro, ra, rmi = oracle_backend.img_bn_pool_forward(y, gam, bet, 1e-5, 0.1, stride, 0.1, bias, rm_o, rv_o)
+    yd = y.to(DEV).to(bf) if ybf else y.to(DEV)
+    ho, ha, hmi = hip_backend.img_block_forward(yd, gam.to(DEV), bet.to(DEV), 1e-5, 0.1, stride, 0.1, bias.to(DEV), rm_h, rv_h,
+                                                out_bf16=obf)
+    assert ho.dtype == (bf if obf else torch.float32)
+    assert torch.allclose(rmi, hmi.cpu(), rtol=1e-5, atol=1e-6)
+    assert (ra == ha.cpu()).float().mean() > 0.9999
+    if obf:
+        assert torch.allclose(ro, ho.float().cpu(), rtol=2.0 ** -8, atol=1e-5)
+    else:
+        assert torch.allclose(ro, ho.cpu(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(rm_o, rm_h.cpu(), rtol=1e-5, atol=1e-6) and torch.allclose(rv_o, rv_h.cpu(), rtol=1e-5, atol=1e-6)
+    gout = torch.randn(ro.shape, generator=g)
+    if obf:
+        gout = gout.to(bf).float()
+    rdy, rdg, rdb = oracle_backend.img_bn_pool_backward(gout, ra, y, rmi, gam, bet, 0.1, stride)
+    gd = gout.to(DEV).to(bf) if obf else gout.to(DEV)
+    hdy, hdg, hdb = hip_backend.img_block_backward(gd, ra.to(DEV), yd, rmi.to(DEV), gam.to(DEV), bet.to(DEV), 0.1, stride)
+    assert hdy.dtype == yd.dtype
+    sc = float(rdy.abs().max())
+    if ybf:
+        assert torch.allclose(rdy, hdy.float().cpu(), rtol=2.0 ** -8, atol=1e-5 * sc)
+    else:
+        assert torch.allclose(rdy, hdy.cpu(), rtol=1e-4, atol=1e-5 * sc)
+    assert torch.allclose(rdg, hdg.cpu(), rtol=1e-4, atol=1e-4 * float(rdg.abs().max()))
+    assert torch.allclose(rdb, hdb.cpu(), rtol=1e-4, atol=1e-4 * float(rdb.abs().max()))
+
+
+def test_image_encoder_bf16_storage_matches_torch_bf16(hip_backend):
+    """the 15-block image encoder in bf16 storage mode (MIOpen bf16 convolutions + the bf16 block tails of csrc/image_block.hip,
+    one multi-tensor weight cast) against plain torch ops with the same storage points (conv output and pooled output in bf16;
+    BN / activation / pooling math in fp32; RF3 fp32).
+    (a) block by block on identical input bits: the pooled outputs agree to 1e-4 of rms with < 1 % of the elements one bf16 ulp
+        apart (fp32 rounding of the BN coefficients deciding a bf16 tie);
+    (b) the whole encoder: every such flip re-rounds the 9*C outputs it feeds, so two bf16 runs drift apart to the bf16 rounding
+        floor (measured 3.4e-2 of rms at RF3; bf16 against fp32 storage measures 0.15 on this random-init encoder) — limit 0.1;
+        parameter gradients fp32 and finite.  The network-level limits of test_bf16_gpu.py are the contract for the bf16 mode."""
+    import torch.nn.functional as F
+    from i2pnet_amd import modules, ops
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    bf = torch.bfloat16
+    torch.manual_seed(3)
+    nets = torch.nn.Sequential(*[modules.createCNNs(*c) for c in cfg.rgb_encoder_channels]).to(DEV).to(memory_format=torch.channels_last)
+    for i, net in enumerate(nets):
+        net.encoder_index = i
+    nets.train()
+    x = torch.rand(2, 3, 96, 320, device=DEV).contiguous(memory_format=torch.channels_last)
+    blocks = [m for net in nets for m in net]
+    nb = len(blocks) // 4
+    with torch.no_grad():
+        h = x.to(bf)
+        for j in range(nb):
+            conv, bn, act, pool = blocks[4 * j:4 * j + 4]
+            y = F.conv2d(h, conv.weight.to(bf), None, 1, 1)
+            z = F.batch_norm(y.float(), None, None, bn.weight, bn.bias, True, 0.1, bn.eps)
+            ref = pool(F.leaky_relu(z, 0.1))
+            ref = ref if j == nb - 1 else ref.to(bf)
+            got, _, _ = hip_backend.img_block_forward(y.permute(0, 2, 3, 1).contiguous(), bn.weight, bn.bias, bn.eps, 0.1, pool.stride,
+                                                      0.1, conv.bias, None, None, out_bf16=j < nb - 1)
+            got = got.permute(0, 3, 1, 2)
+            assert got.dtype == ref.dtype
+            d = got.float() - ref.float()
+            assert float(d.pow(2).mean().sqrt() / ref.float().pow(2).mean().sqrt()) < 1e-4, j
+            assert j == nb - 1 or float((got != ref).float().mean()) < 1e-2, j      # (the last block's output is fp32)
+            h = ref
+        ref_out = h
+    prev = ops.set_precision("bf16")
+    try:
+        out = nets(x)
+    finally:
+        ops.set_precision(prev)
+    assert out.dtype == torch.float32
+    assert float((out.detach() - ref_out).pow(2).mean().sqrt() / ref_out.pow(2).mean().sqrt()) < 0.1
+    w = torch.linspace(-1, 1, out.numel(), device=DEV).view_as(out)
+    (out * w).sum().backward()
+    n = 0
+    for k, p in nets.named_parameters():
+        if p.grad is not None:
+            assert p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
+            n += 1
+    assert n == 3 * nb                                     # conv weight, BN weight, BN bias of every block
+
+
 @pytest.mark.parametrize("rows,cin,cout,slope_out", [(3000, 64, 128, 0.0), (5000, 32, 32, 0.1), (2000, 36, 32, 0.0),
                                                      (4000, 128, 64, 0.1), (1500, 68, 64, 0.0)])
 def test_lin_bwd_last_layer_slope_out(oracle_backend, hip_backend, rows, cin, cout, slope_out):
