@@ -339,12 +339,29 @@ __device__ __forceinline__ void finalize_by_last_block(const LinFwdParams &p, in
     }
     __syncthreads();
     if (!*flag) return;
-    const int c = p.cout_total;
+    const int c = p.cout_total, n2 = 2 * c;
+    // the [REP][2c] replica sums: one round trip for the whole block (REP/ng independent loads per thread, combined through the
+    // dead LDS) instead of 2*REP loads per channel thread in register-limited batches — this tail is serial time of every launch
+    double *part = reinterpret_cast<double *>(const_cast<int *>(flag)) + 1;
+    const bool spread = n2 <= NTHREADS;
+    const int ng = spread ? NTHREADS / n2 : 1;
+    if (spread) {
+        const int idx = tid % n2, grp = tid / n2;
+        double a = 0.0;
+        if (grp < ng)
+            for (int r = grp; r < REP; r += ng) a += __hip_atomic_load(p.sums + (size_t)r * n2 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        part[tid] = a;
+        __syncthreads();
+    }
     for (int ch = tid; ch < c; ch += NTHREADS) {
         double s = 0.0, q = 0.0;
-        for (int r = 0; r < REP; ++r) {                     // agent-scope loads: the sums live in L2 (written by atomics only)
-            s += __hip_atomic_load(p.sums + (size_t)r * 2 * c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            q += __hip_atomic_load(p.sums + (size_t)r * 2 * c + c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (spread) {
+            for (int g2 = 0; g2 < ng; ++g2) { s += part[g2 * n2 + ch]; q += part[g2 * n2 + c + ch]; }
+        } else {
+            for (int r = 0; r < REP; ++r) {                 // agent-scope loads: the sums live in L2 (written by atomics only)
+                s += __hip_atomic_load(p.sums + (size_t)r * 2 * c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q += __hip_atomic_load(p.sums + (size_t)r * 2 * c + c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         const double m = s / (double)p.rows;
         double var = q / (double)p.rows - m * m;
@@ -390,63 +407,9 @@ __global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(L
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *As = smem + (size_t)p.cout_p * ldk + (size_t)wave * F2_ROWS * ldk;   // this wave's strip
 
-    // weights -> LDS with 16-byte loads (cin, cout and ch_off are multiples of 4): 8 independent loads per thread for a
-    // 128x128 layer instead of 32 dependent scalar iterations — this prologue is most of a launch on the small layers
-    if (!p.w_vec) {                                         // weights not 16-byte aligned (caller's tensor view): scalar loads
-        for (int i = tid; i < p.cout_p * p.cin; i += F2_THREADS) {
-            const int co = i / p.cin, ci = i - co * p.cin;
-            float wv = 0.f;
-            if (co < p.cout) wv = (DGRAD && p.w_transposed) ? p.w[(size_t)ci * p.cout_total + p.ch_off + co] : p.w[(size_t)co * p.cin + ci];
-            Ws[co * ldk + ci] = wv;
-        }
-    } else if (DGRAD && p.w_transposed) {                   // Ws[co][ci] = w[ci][ch_off + co]: contiguous along co
-        const int o4 = p.cout_p >> 2;
-        for (int i = tid; i < p.cin * o4; i += F2_THREADS) {
-            const int ci = i / o4, c4 = i - ci * o4;
-            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c4 * 4 < p.cout) wv = *reinterpret_cast<const float4 *>(p.w + (size_t)ci * p.cout_total + p.ch_off + c4 * 4);
-            Ws[(c4 * 4 + 0) * ldk + ci] = wv.x; Ws[(c4 * 4 + 1) * ldk + ci] = wv.y;
-            Ws[(c4 * 4 + 2) * ldk + ci] = wv.z; Ws[(c4 * 4 + 3) * ldk + ci] = wv.w;
-        }
-    } else {
-        const int c4n_w = p.cin >> 2;
-        for (int i = tid; i < p.cout_p * c4n_w; i += F2_THREADS) {
-            const int co = i / c4n_w, c4 = i - co * c4n_w;
-            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co < p.cout) wv = *reinterpret_cast<const float4 *>(p.w + (size_t)co * p.cin + c4 * 4);
-            float2 *dst = reinterpret_cast<float2 *>(Ws + co * ldk + c4 * 4);
-            dst[0] = make_float2(wv.x, wv.y); dst[1] = make_float2(wv.z, wv.w);
-        }
-    }
-    // dgrad: per-channel constants live in an LDS table behind the strips (30 float4 registers per lane otherwise:
-    // the dgrad instantiation spilled).  Gt [6][cin] = BN-backward constants of the layer behind (identity if none),
-    // Et [4][cout_total] = mean, scale, beta, invstd of the BN in front (per destination in two-destination mode).
+    // (LDS tables of the dgrad instantiation, filled below)
     float *Gt = smem + ((size_t)p.cout_p + 8 * F2_ROWS) * ldk;
     float *Et = Gt + 6 * p.cin;
-    if (DGRAD) {
-        // (formed here from the replica sums: a separate 1-block kernel per layer used to do this — 35 launches per step)
-        for (int ch = tid; ch < p.cin; ch += F2_THREADS) {
-            float m1 = 0.f, m2 = 0.f, sc = 1.f, mu = 0.f, is = 1.f, be = 0.f;
-            if (p.g_coef) {
-                double sd = 0.0, sx = 0.0;
-#pragma unroll 8
-                for (int rp = 0; rp < REP; ++rp) { sd += p.g_dsums[(size_t)rp * 2 * p.cin + ch]; sx += p.g_dsums[(size_t)rp * 2 * p.cin + p.cin + ch]; }
-                m1 = (float)(sd / (double)p.g_rows); m2 = (float)(sx / (double)p.g_rows);
-                sc = p.g_oc[p.cin + ch]; mu = p.g_omi[ch]; is = p.g_omi[p.cin + ch]; be = p.g_oc[2 * p.cin + ch];
-            }
-            Gt[ch] = m1; Gt[p.cin + ch] = m2; Gt[2 * p.cin + ch] = sc; Gt[3 * p.cin + ch] = mu; Gt[4 * p.cin + ch] = is; Gt[5 * p.cin + ch] = be;
-        }
-        for (int i = tid; i < 4 * p.cout_total; i += F2_THREADS) {
-            const int row = i / p.cout_total, ch = i - row * p.cout_total;
-            const bool b = p.yb && ch >= p.split_c;
-            const float *cf = b ? p.e_coef_b : p.e_coef, *mi = b ? p.e_mi_b : p.e_mi;
-            const int ld = p.yb ? (b ? p.cout_total - p.split_c : p.split_c) : p.cout_total, c = b ? ch - p.split_c : ch;
-            float v = (row == 1 || row == 3) ? 1.f : 0.f;
-            if (cf) v = row < 3 ? cf[row * ld + c] : mi[ld + c];
-            Et[i] = v;
-        }
-    }
-    __syncthreads();                                        // the only block barrier
 
     // ---- per-lane chunk geometry, fixed for the whole kernel -----------------------------------------
     const int c4n = p.cin >> 2, nchunk = F2_ROWS * c4n;
@@ -533,6 +496,87 @@ __global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(L
         }
     };
 
+    // the first strip's loads (and the BN coefficients above) are in flight while the weights are staged: one memory round trip
+    // of the prologue instead of two (the small layers' launches are chains of such round trips, ~2 us each)
+    float4 pf[F2_CH], pf2[F2_CH];
+#pragma unroll
+    for (int u = 0; u < F2_CH; ++u) pf2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (strip < nstrips) fetch(strip, pf, pf2);
+
+    // weights -> LDS with 16-byte loads (cin, cout and ch_off are multiples of 4): 8 independent loads per thread for a
+    // 128x128 layer instead of 32 dependent scalar iterations — this prologue is most of a launch on the small layers
+    if (!p.w_vec) {                                         // weights not 16-byte aligned (caller's tensor view): scalar loads
+        for (int i = tid; i < p.cout_p * p.cin; i += F2_THREADS) {
+            const int co = i / p.cin, ci = i - co * p.cin;
+            float wv = 0.f;
+            if (co < p.cout) wv = (DGRAD && p.w_transposed) ? p.w[(size_t)ci * p.cout_total + p.ch_off + co] : p.w[(size_t)co * p.cin + ci];
+            Ws[co * ldk + ci] = wv;
+        }
+    } else if (DGRAD && p.w_transposed) {                   // Ws[co][ci] = w[ci][ch_off + co]: contiguous along co
+        const int o4 = p.cout_p >> 2;
+        for (int i = tid; i < p.cin * o4; i += F2_THREADS) {
+            const int ci = i / o4, c4 = i - ci * o4;
+            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c4 * 4 < p.cout) wv = *reinterpret_cast<const float4 *>(p.w + (size_t)ci * p.cout_total + p.ch_off + c4 * 4);
+            Ws[(c4 * 4 + 0) * ldk + ci] = wv.x; Ws[(c4 * 4 + 1) * ldk + ci] = wv.y;
+            Ws[(c4 * 4 + 2) * ldk + ci] = wv.z; Ws[(c4 * 4 + 3) * ldk + ci] = wv.w;
+        }
+    } else {
+        const int c4n_w = p.cin >> 2;
+        for (int i = tid; i < p.cout_p * c4n_w; i += F2_THREADS) {
+            const int co = i / c4n_w, c4 = i - co * c4n_w;
+            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < p.cout) wv = *reinterpret_cast<const float4 *>(p.w + (size_t)co * p.cin + c4 * 4);
+            float2 *dst = reinterpret_cast<float2 *>(Ws + co * ldk + c4 * 4);
+            dst[0] = make_float2(wv.x, wv.y); dst[1] = make_float2(wv.z, wv.w);
+        }
+    }
+    // dgrad: per-channel constants live in an LDS table behind the strips (30 float4 registers per lane otherwise:
+    // the dgrad instantiation spilled).  Gt [6][cin] = BN-backward constants of the layer behind (identity if none),
+    // Et [4][cout_total] = mean, scale, beta, invstd of the BN in front (per destination in two-destination mode).
+    if (DGRAD) {
+        // (formed here from the replica sums: a separate 1-block kernel per layer used to do this — 35 launches per step)
+        // (the [REP][2cin] sums in one round trip: REP/ng independent loads per thread, combined through the strips' LDS, which is
+        //  not staged yet — 2*REP loads per channel thread in batches of 8 were four dependent round trips of every dgrad launch)
+        double *gpart = reinterpret_cast<double *>(smem + (size_t)p.cout_p * ldk);
+        const int gn2 = 2 * p.cin;
+        const bool gspread = p.g_coef && gn2 <= F2_THREADS && (size_t)F2_THREADS * 2 <= (size_t)8 * F2_ROWS * ldk;
+        const int gng = gspread ? F2_THREADS / gn2 : 1;
+        if (gspread) {
+            const int idx = tid % gn2, grp = tid / gn2;
+            double a = 0.0;
+            if (grp < gng)
+                for (int rp = grp; rp < REP; rp += gng) a += p.g_dsums[(size_t)rp * gn2 + idx];
+            gpart[tid] = a;
+            __syncthreads();
+        }
+        for (int ch = tid; ch < p.cin; ch += F2_THREADS) {
+            float m1 = 0.f, m2 = 0.f, sc = 1.f, mu = 0.f, is = 1.f, be = 0.f;
+            if (p.g_coef) {
+                double sd = 0.0, sx = 0.0;
+                if (gspread) {
+                    for (int g2 = 0; g2 < gng; ++g2) { sd += gpart[g2 * gn2 + ch]; sx += gpart[g2 * gn2 + p.cin + ch]; }
+                } else {
+#pragma unroll 8
+                    for (int rp = 0; rp < REP; ++rp) { sd += p.g_dsums[(size_t)rp * 2 * p.cin + ch]; sx += p.g_dsums[(size_t)rp * 2 * p.cin + p.cin + ch]; }
+                }
+                m1 = (float)(sd / (double)p.g_rows); m2 = (float)(sx / (double)p.g_rows);
+                sc = p.g_oc[p.cin + ch]; mu = p.g_omi[ch]; is = p.g_omi[p.cin + ch]; be = p.g_oc[2 * p.cin + ch];
+            }
+            Gt[ch] = m1; Gt[p.cin + ch] = m2; Gt[2 * p.cin + ch] = sc; Gt[3 * p.cin + ch] = mu; Gt[4 * p.cin + ch] = is; Gt[5 * p.cin + ch] = be;
+        }
+        for (int i = tid; i < 4 * p.cout_total; i += F2_THREADS) {
+            const int row = i / p.cout_total, ch = i - row * p.cout_total;
+            const bool b = p.yb && ch >= p.split_c;
+            const float *cf = b ? p.e_coef_b : p.e_coef, *mi = b ? p.e_mi_b : p.e_mi;
+            const int ld = p.yb ? (b ? p.cout_total - p.split_c : p.split_c) : p.cout_total, c = b ? ch - p.split_c : ch;
+            float v = (row == 1 || row == 3) ? 1.f : 0.f;
+            if (cf) v = row < 3 ? cf[row * ld + c] : mi[ld + c];
+            Et[i] = v;
+        }
+    }
+    __syncthreads();                                        // the only block barrier
+
     // Order inside an iteration (vmcnt retires in order and counts stores too):
     //   MFMA(s) -> outputs of s to registers -> commit(s+1) [waits the loads issued one MFMA phase ago]
     //   -> stores(s) -> fetch(s+2).   The stores of a strip are thus always OLDER than the loads the next
@@ -581,11 +625,7 @@ __global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(L
         }
     };
 
-    float4 pf[F2_CH], pf2[F2_CH];
-#pragma unroll
-    for (int u = 0; u < F2_CH; ++u) pf2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (strip < nstrips) {
-        fetch(strip, pf, pf2);
         commit(strip, pf, pf2);
         if (strip + sstride < nstrips) fetch(strip + sstride, pf, pf2);
     }
@@ -743,14 +783,36 @@ __global__ __launch_bounds__(F2_THREADS, CH <= 4 ? 4 : 2) void lin_fwd2_kernel(L
     }
 
     if (p.sums || (DGRAD && p.sums_b)) {
-        // lanes with equal (lane & (o4n-1)) own the same 4 channels
+        // lanes with equal (lane & (o4n-1)) own the same 4 channels.  The 8 waves of a block combine through their (now dead) strips
+        // and wave 0 issues the block's atomics: 8x fewer same-address fp64 atomics at L2 (a mid-size layer's 1800 waves put ~57
+        // serialized atomics on each of the 32 x 2c replica words — microseconds on a 20 us launch); I2P_LIN_ABLATE bit 64 = per wave.
+        const bool per_wave = (p.ablate & 64) != 0;
+        double *wred = reinterpret_cast<double *>(smem + (size_t)p.cout_p * ldk);       // [8 waves][o4n lanes][8]
+        const int wstride = F2_ROWS * ldk / 2;                                            // doubles per wave strip (ldk is even)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             double a = ssum[q], b = ssq[q];
             for (int off = 32; off >= o4n; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
-            if (lane < o4n && dst_sums) {
-                double *rep = dst_sums + (size_t)((blockIdx.x * 8 + wave) % REP) * 2 * sums_c;
-                atomicAdd(rep + dst_c0 + q, a); atomicAdd(rep + sums_c + dst_c0 + q, b);
+            if (per_wave) {
+                if (lane < o4n && dst_sums) {
+                    double *rep = dst_sums + (size_t)((blockIdx.x * 8 + wave) % REP) * 2 * sums_c;
+                    atomicAdd(rep + dst_c0 + q, a); atomicAdd(rep + sums_c + dst_c0 + q, b);
+                }
+            } else if (lane < o4n) {
+                wred[(size_t)wave * wstride + lane * 8 + q] = a; wred[(size_t)wave * wstride + lane * 8 + 4 + q] = b;
+            }
+        }
+        if (!per_wave) {
+            __syncthreads();
+            if (wave == 0 && lane < o4n && dst_sums) {
+                double *rep = dst_sums + (size_t)(blockIdx.x % REP) * 2 * sums_c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double a = 0.0, b = 0.0;
+#pragma unroll
+                    for (int w8 = 0; w8 < 8; ++w8) { a += wred[(size_t)w8 * wstride + lane * 8 + q]; b += wred[(size_t)w8 * wstride + lane * 8 + 4 + q]; }
+                    atomicAdd(rep + dst_c0 + q, a); atomicAdd(rep + sums_c + dst_c0 + q, b);
+                }
             }
         }
     }
