@@ -317,56 +317,78 @@ __global__ __launch_bounds__(THREADS) void img_bwd_dx_kernel(PoolGeom g, const f
 
 // ---- second generation: storage type per tensor + coefficients formed in the consumer's prologue -------------------------------
 // YBF: the conv output y / its gradient dy are bf16 (MIOpen bf16 convolutions, ops.set_precision("bf16")); OBF: the pooled output /
-// its gradient are bf16 (every block but the last, whose output feeds the fp32 cost volume).  Arithmetic is fp32, statistics fp64.
-// The per-channel mean / invstd (forward) and dbeta / dgamma (backward) are no longer written by a 64-thread launch between the
+// its gradient are bf16 (every block but the last of the bf16 part, whose output feeds fp32 consumers).  Arithmetic is fp32,
+// statistics fp64.  A lane owns CPL consecutive channels of a pixel: 4 with fp32 y (16-byte loads), 8 with bf16 y (again 16-byte
+// loads: with 4 the bf16 kernels issued twice the load instructions per byte and ran no faster than fp32).
+// The per-channel mean / invstd (forward) and dbeta / dgamma (backward) are not written by a 64-thread launch between the
 // statistics kernel and its consumer: every consumer block reduces the [REP][2C] fp64 replica sums itself (2C*REP loads spread over
-// the block, through LDS) — 30 launches per step less; block 0 also writes them out and updates the running buffers.
+// the block, through LDS); block 0 also writes them out and updates the running buffers.
 constexpr int MAX_C2 = 512;
 
-template <bool BF> __device__ __forceinline__ void ld4(const void *p, long long i, float (&f)[4]) {
-    if constexpr (BF) {
-        const uint2 v = reinterpret_cast<const uint2 *>(p)[i];
-        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-    } else {
-        const float4 v = reinterpret_cast<const float4 *>(p)[i];
-        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-    }
-}
-typedef unsigned v2u __attribute__((ext_vector_type(2)));
-template <bool BF> __device__ __forceinline__ void ld4_stream(const void *p, long long i, float (&f)[4]) {
-    if constexpr (BF) {
-        const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(p) + i);
-        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-    } else {
-        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p) + i);
-        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-    }
-}
+__device__ __forceinline__ float bfl(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bfh(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {            // v_cvt_pk_bf16_f32 (RNE)
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
 }
-template <bool BF> __device__ __forceinline__ void st4(void *p, long long i, const float (&f)[4]) {
-    if constexpr (BF) reinterpret_cast<uint2 *>(p)[i] = make_uint2(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]));
-    else reinterpret_cast<float4 *>(p)[i] = make_float4(f[0], f[1], f[2], f[3]);
-}
-template <bool BF> __device__ __forceinline__ void st4_stream(void *p, long long i, const float (&f)[4]) {
-    if constexpr (BF) {
-        const v2u o = {pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3])};
-        __builtin_nontemporal_store(o, reinterpret_cast<v2u *>(p) + i);
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+// N channels at vector index i (units of N channels); NT: streamed once (non-temporal)
+template <bool BF, int N, bool NT = false> __device__ __forceinline__ void ldv(const void *p, long long i, float (&f)[N]) {
+    if constexpr (BF && N == 8) {
+        v4u v;
+        if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p) + i);
+        else v = reinterpret_cast<const v4u *>(p)[i];
+        f[0] = bfl(v.x); f[1] = bfh(v.x); f[2] = bfl(v.y); f[3] = bfh(v.y); f[4] = bfl(v.z); f[5] = bfh(v.z); f[6] = bfl(v.w); f[7] = bfh(v.w);
+    } else if constexpr (BF) {
+        v2u v;
+        if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(p) + i);
+        else v = reinterpret_cast<const v2u *>(p)[i];
+        f[0] = bfl(v.x); f[1] = bfh(v.x); f[2] = bfl(v.y); f[3] = bfh(v.y);
     } else {
-        const v4f o = {f[0], f[1], f[2], f[3]};
-        __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(p) + i);
+#pragma unroll
+        for (int h = 0; h < N / 4; ++h) {
+            v4f v;
+            if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p) + i * (N / 4) + h);
+            else v = reinterpret_cast<const v4f *>(p)[i * (N / 4) + h];
+            f[4 * h] = v.x; f[4 * h + 1] = v.y; f[4 * h + 2] = v.z; f[4 * h + 3] = v.w;
+        }
+    }
+}
+template <bool BF, int N, bool NT = false> __device__ __forceinline__ void stv(void *p, long long i, const float (&f)[N]) {
+    if constexpr (BF && N == 8) {
+        const v4u o = {pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7])};
+        if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<v4u *>(p) + i);
+        else reinterpret_cast<v4u *>(p)[i] = o;
+    } else if constexpr (BF) {
+        const v2u o = {pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3])};
+        if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<v2u *>(p) + i);
+        else reinterpret_cast<v2u *>(p)[i] = o;
+    } else {
+#pragma unroll
+        for (int h = 0; h < N / 4; ++h) {
+            const v4f o = {f[4 * h], f[4 * h + 1], f[4 * h + 2], f[4 * h + 3]};
+            if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(p) + i * (N / 4) + h);
+            else reinterpret_cast<v4f *>(p)[i * (N / 4) + h] = o;
+        }
     }
 }
 template <bool BF> __device__ __forceinline__ float ld1(const void *p, long long e) {
     if constexpr (BF) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(p)[e] << 16);
     else return reinterpret_cast<const float *>(p)[e];
 }
+// the N arg-max bytes of a lane (window position 0..8 per channel)
+template <int N> struct ArgW { unsigned w[N / 4]; };
+template <int N> __device__ __forceinline__ ArgW<N> ld_arg(const unsigned char *arg, long long i) {
+    ArgW<N> a;
+    if constexpr (N == 8) { const uint2 v = reinterpret_cast<const uint2 *>(arg)[i]; a.w[0] = v.x; a.w[1] = v.y; }
+    else a.w[0] = reinterpret_cast<const unsigned *>(arg)[i];
+    return a;
+}
+template <int N> __device__ __forceinline__ unsigned arg_byte(const ArgW<N> &a, int k) { return (a.w[k >> 2] >> (8 * (k & 3))) & 0xffu; }
 
 // stat[i] = sum over the REP replicas of sums[r][i], i < 2C, for the whole block (fixed summation order); ends with a barrier
 __device__ __forceinline__ void block_rep_sums(const double *__restrict__ sums, int c, double *stat, double *part) {
@@ -388,37 +410,58 @@ __device__ __forceinline__ void block_rep_sums(const double *__restrict__ sums, 
     __syncthreads();
 }
 
+template <int N> struct CoefN { float mean[N], invstd[N], scale[N], beta[N]; };
+template <int N> __device__ __forceinline__ CoefN<N> load_coef_n(const float *mean_invstd, const float *gamma, const float *beta, int c, int vcol) {
+    CoefN<N> k;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int ch = vcol * N + i;
+        k.mean[i] = mean_invstd[ch]; k.invstd[i] = mean_invstd[c + ch];
+        k.scale[i] = k.invstd[i] * gamma[ch]; k.beta[i] = beta[ch];
+    }
+    return k;
+}
+template <int N> __device__ __forceinline__ float bn_zn(float y, const CoefN<N> &k, int i) { return (y - k.mean[i]) * k.scale[i] + k.beta[i]; }
+
 template <bool BF>
 __global__ __launch_bounds__(THREADS) void img_stats2_kernel(long long n, int c, int cv, int rpb, const void *__restrict__ y,
                                                              double *__restrict__ sums) {
-    __shared__ double red[THREADS][8];
+    constexpr int N = BF ? 8 : 4;
+    __shared__ double red[THREADS][2 * N];
     const int vcol = threadIdx.x % cv, rsub = threadIdx.x / cv;
-    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    double s[N], q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { s[i] = 0.0; q[i] = 0.0; }
     const long long stride = (long long)gridDim.x * rpb;
     for (long long r0 = (long long)blockIdx.x * rpb + rsub; r0 < n; r0 += stride * 4) {
-        float v[4][4];
+        float v[4][N];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long long r = r0 + u * stride;
-            if (r < n) ld4<BF>(y, r * cv + vcol, v[u]);
-            else { v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f; }
+            if (r < n) ldv<BF, N>(y, r * cv + vcol, v[u]);
+            else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) v[u][i] = 0.f;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { s[i] += v[u][i]; q[i] += (double)v[u][i] * v[u][i]; }
+            for (int i = 0; i < N; ++i) { s[i] += v[u][i]; q[i] += (double)v[u][i] * v[u][i]; }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][4 + i] = q[i]; }
+    for (int i = 0; i < N; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][N + i] = q[i]; }
     __syncthreads();
     if (threadIdx.x < cv) {
-        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double a[2 * N];
+#pragma unroll
+        for (int i = 0; i < 2 * N; ++i) a[i] = 0.0;
         for (int t = threadIdx.x; t < THREADS; t += cv)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] += red[t][i];
+            for (int i = 0; i < 2 * N; ++i) a[i] += red[t][i];
         double *rep = sums + (size_t)(blockIdx.x % REP) * 2 * c;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { atomicAdd(rep + vcol * 4 + i, a[i]); atomicAdd(rep + c + vcol * 4 + i, a[4 + i]); }
+        for (int i = 0; i < N; ++i) { atomicAdd(rep + vcol * N + i, a[i]); atomicAdd(rep + c + vcol * N + i, a[N + i]); }
     }
 }
 
@@ -427,16 +470,17 @@ __global__ __launch_bounds__(THREADS) void img_pool_fwd2_kernel(PoolGeom g, cons
                                                                 const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                                 float slope, float momentum, const float *__restrict__ conv_bias,
                                                                 float *__restrict__ running_mean, float *__restrict__ running_var,
-                                                                void *__restrict__ out, uchar4 *__restrict__ arg,
+                                                                void *__restrict__ out, unsigned char *__restrict__ arg,
                                                                 float *__restrict__ mean_invstd) {
+    constexpr int N = YBF ? 8 : 4;
     __shared__ double stat[2 * MAX_C2], part[THREADS];
     block_rep_sums(sums, g.C, stat, part);
     const double n = (double)((long long)g.B * g.H * g.W);
     const int vcol = threadIdx.x & (g.cv - 1);
-    Coef4 k;
+    CoefN<N> k;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = vcol * 4 + i;
+    for (int i = 0; i < N; ++i) {
+        const int ch = vcol * N + i;
         const double m = stat[ch] / n;
         double var = stat[g.C + ch] / n - m * m;
         var = var < 0.0 ? 0.0 : var;
@@ -461,8 +505,10 @@ __global__ __launch_bounds__(THREADS) void img_pool_fwd2_kernel(PoolGeom g, cons
     for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, ho, wo;
         decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.Ho, g.Wo, b, ho, wo);
-        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        unsigned char bi[4] = {0, 0, 0, 0};
+        float best[N];
+        unsigned bi[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { best[i] = -INFINITY; bi[i] = 0u; }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int h = ho * g.s - 1 + kh;
@@ -471,106 +517,124 @@ __global__ __launch_bounds__(THREADS) void img_pool_fwd2_kernel(PoolGeom g, cons
             for (int kw = 0; kw < 3; ++kw) {
                 const int w = wo * g.s - 1 + kw;
                 if (w < 0 || w >= g.W) continue;
-                float vv[4];
-                ld4<YBF>(y, (((long long)b * g.H + h) * g.W + w) * g.cv + vcol, vv);
+                float vv[N];
+                ldv<YBF, N>(y, (((long long)b * g.H + h) * g.W + w) * g.cv + vcol, vv);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float z = bn_z(vv[i], k, i);
+                for (int i = 0; i < N; ++i) {
+                    const float z = bn_zn<N>(vv[i], k, i);
                     const float a = z > 0.f ? z : z * slope;
-                    if (a > best[i] || a != a) { best[i] = a; bi[i] = (unsigned char)(kh * 3 + kw); }   // first max wins
+                    if (a > best[i] || a != a) { best[i] = a; bi[i] = (unsigned)(kh * 3 + kw); }   // first max wins
                 }
             }
         }
-        st4<OBF>(out, t, best);
-        arg[t] = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+        stv<OBF, N>(out, t, best);
+        if constexpr (N == 8)
+            reinterpret_cast<uint2 *>(arg)[t] = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24),
+                                                           bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24));
+        else
+            reinterpret_cast<unsigned *>(arg)[t] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
     }
 }
 
 template <bool WIDE, bool YBF, bool OBF>
-__global__ __launch_bounds__(THREADS) void img_bwd_stats2_kernel(PoolGeom g, const void *__restrict__ gout, const uchar4 *__restrict__ arg,
+__global__ __launch_bounds__(THREADS) void img_bwd_stats2_kernel(PoolGeom g, const void *__restrict__ gout, const unsigned char *__restrict__ arg,
                                                                  const void *__restrict__ y, const float *__restrict__ mean_invstd,
                                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                  float slope, double *__restrict__ dsums) {
-    __shared__ double red[THREADS][8];
+    constexpr int N = YBF ? 8 : 4;
+    __shared__ double red[THREADS][2 * N];
     const long long total = (long long)g.B * g.Ho * g.Wo * g.cv;
     const int vcol = threadIdx.x & (g.cv - 1);
-    const Coef4 k = load_coef(mean_invstd, gamma, beta, g.C, vcol);
-    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const CoefN<N> k = load_coef_n<N>(mean_invstd, gamma, beta, g.C, vcol);
+    double s[N], q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { s[i] = 0.0; q[i] = 0.0; }
     for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, ho, wo;
         decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.Ho, g.Wo, b, ho, wo);
-        float gv[4];
-        ld4<OBF>(gout, t, gv);
-        const uchar4 a = arg[t];
-        const unsigned char av[4] = {a.x, a.y, a.z, a.w};
+        float gv[N];
+        ldv<OBF, N>(gout, t, gv);
+        const ArgW<N> a = ld_arg<N>(arg, t);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int h = ho * g.s - 1 + av[i] / 3, w = wo * g.s - 1 + av[i] % 3;
-            const float yv = ld1<YBF>(y, ((((long long)b * g.H + h) * g.W + w) * g.cv + vcol) * 4 + i);
-            const float z = bn_z(yv, k, i);
+        for (int i = 0; i < N; ++i) {
+            const int av = (int)arg_byte<N>(a, i);
+            const int h = ho * g.s - 1 + av / 3, w = wo * g.s - 1 + av % 3;
+            const float yv = ld1<YBF>(y, ((((long long)b * g.H + h) * g.W + w) * g.cv + vcol) * N + i);
+            const float z = bn_zn<N>(yv, k, i);
             const float gz = z > 0.f ? gv[i] : gv[i] * slope;
             const float xh = (yv - k.mean[i]) * k.invstd[i];
             s[i] += gz; q[i] += (double)gz * xh;
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][4 + i] = q[i]; }
+    for (int i = 0; i < N; ++i) { red[threadIdx.x][i] = s[i]; red[threadIdx.x][N + i] = q[i]; }
     __syncthreads();
     if (threadIdx.x < g.cv) {
-        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double acc[2 * N];
+#pragma unroll
+        for (int i = 0; i < 2 * N; ++i) acc[i] = 0.0;
         for (int t = threadIdx.x; t < THREADS; t += g.cv)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += red[t][i];
+            for (int i = 0; i < 2 * N; ++i) acc[i] += red[t][i];
         double *rep = dsums + (size_t)(blockIdx.x % REP) * 2 * g.C;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { atomicAdd(rep + vcol * 4 + i, acc[i]); atomicAdd(rep + g.C + vcol * 4 + i, acc[4 + i]); }
+        for (int i = 0; i < N; ++i) { atomicAdd(rep + vcol * N + i, acc[i]); atomicAdd(rep + g.C + vcol * N + i, acc[N + i]); }
     }
 }
 
 template <bool WIDE, bool YBF, bool OBF>
-__global__ __launch_bounds__(THREADS) void img_bwd_dx2_kernel(PoolGeom g, const void *__restrict__ gout, const uchar4 *__restrict__ arg,
+__global__ __launch_bounds__(THREADS) void img_bwd_dx2_kernel(PoolGeom g, const void *__restrict__ gout, const unsigned char *__restrict__ arg,
                                                               const void *__restrict__ y, const float *__restrict__ mean_invstd,
                                                               const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
                                                               const double *__restrict__ dsums, void *__restrict__ dy,
                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    constexpr int N = YBF ? 8 : 4;
     __shared__ double stat[2 * MAX_C2], part[THREADS];
     block_rep_sums(dsums, g.C, stat, part);
     if (blockIdx.x == 0)
         for (int ch = threadIdx.x; ch < g.C; ch += THREADS) { dbeta[ch] = (float)stat[ch]; dgamma[ch] = (float)stat[g.C + ch]; }
     const long long total = (long long)g.B * g.H * g.W * g.cv;
     const int vcol = threadIdx.x & (g.cv - 1);
-    const Coef4 k = load_coef(mean_invstd, gamma, beta, g.C, vcol);
+    const CoefN<N> k = load_coef_n<N>(mean_invstd, gamma, beta, g.C, vcol);
     const float n = (float)((long long)g.B * g.H * g.W);
-    float mg[4], mgx[4];
+    float mg[N], mgx[N];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { mg[i] = (float)stat[vcol * 4 + i] / n; mgx[i] = (float)stat[g.C + vcol * 4 + i] / n; }
+    for (int i = 0; i < N; ++i) { mg[i] = (float)stat[vcol * N + i] / n; mgx[i] = (float)stat[g.C + vcol * N + i] / n; }
     for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, h, w;
         decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.H, g.W, b, h, w);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float acc[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] = 0.f;
+        // (a version that requested the arg-max words of all 9 candidate outputs in one batch and their gradients in a second one
+        //  measured 1.7x SLOWER: these kernels are bound by VALU work per element — index math, byte compares, unpacking — not by
+        //  the latency of the dependent loads)
         const int ho0 = max(0, (h - 1 + g.s - 1) / g.s), ho1 = min(g.Ho - 1, (h + 1) / g.s);
         const int wo0 = max(0, (w - 1 + g.s - 1) / g.s), wo1 = min(g.Wo - 1, (w + 1) / g.s);
         for (int ho = ho0; ho <= ho1; ++ho)
             for (int wo = wo0; wo <= wo1; ++wo) {
-                const unsigned char p = (unsigned char)((h - (ho * g.s - 1)) * 3 + (w - (wo * g.s - 1)));
+                const unsigned p = (unsigned)((h - (ho * g.s - 1)) * 3 + (w - (wo * g.s - 1)));
                 const long long o = (((long long)b * g.Ho + ho) * g.Wo + wo) * g.cv + vcol;
-                const uchar4 a = arg[o];
-                if (a.x != p && a.y != p && a.z != p && a.w != p) continue;
-                float go[4];
-                ld4<OBF>(gout, o, go);
-                acc[0] += a.x == p ? go[0] : 0.f; acc[1] += a.y == p ? go[1] : 0.f;
-                acc[2] += a.z == p ? go[2] : 0.f; acc[3] += a.w == p ? go[3] : 0.f;
-            }
-        float vv[4], o4[4];
-        ld4_stream<YBF>(y, t, vv);                          // streamed once: keep arg / gout in L2
+                const ArgW<N> a = ld_arg<N>(arg, o);
+                bool any = false;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float z = bn_z(vv[i], k, i);
+                for (int i = 0; i < N; ++i) any = any || arg_byte<N>(a, i) == p;
+                if (!any) continue;
+                float go[N];
+                ldv<OBF, N>(gout, o, go);
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc[i] += arg_byte<N>(a, i) == p ? go[i] : 0.f;
+            }
+        float vv[N], o4[N];
+        ldv<YBF, N, true>(y, t, vv);                        // streamed once: keep arg / gout in L2
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float z = bn_zn<N>(vv[i], k, i);
             const float gz = z > 0.f ? acc[i] : acc[i] * slope;
             const float xh = (vv[i] - k.mean[i]) * k.invstd[i];
             o4[i] = k.scale[i] * (gz - mg[i] - xh * mgx[i]);
         }
-        st4_stream<YBF>(dy, t, o4);
+        stv<YBF, N, true>(dy, t, o4);
     }
 }
 
@@ -678,6 +742,20 @@ static int img_bn_pool_bwd_impl(int B, int H, int W, int C, int stride, const fl
     I2P_RETURN_LAUNCH_STATUS();
 }
 
+// gen-2 geometry: a lane owns 8 channels when y is bf16 (16-byte loads), 4 otherwise
+static bool geom2_ok(int B, int H, int W, int C, int s, int y_bf16) {
+    const int cpl = y_bf16 ? 8 : 4;
+    return B >= 0 && H > 0 && W > 0 && C >= cpl && C % cpl == 0 && C <= MAX_C2 && (THREADS % (C / cpl)) == 0 && ((C / cpl) & (C / cpl - 1)) == 0 &&
+           (s == 1 || s == 2);
+}
+static PoolGeom make_geom2(int B, int H, int W, int C, int s, int y_bf16) {
+    PoolGeom g = make_geom(B, H, W, C, s);
+    g.cv = C / (y_bf16 ? 8 : 4);
+    g.cvs = 0;
+    while ((1 << g.cvs) < g.cv) ++g.cvs;
+    return g;
+}
+
 static int gen2_grid(int dflt) {
     static const int v = [] { const char *e = getenv("I2P_IMG_GRID"); return e ? atoi(e) : 0; }();
     return v > 0 ? v : dflt;
@@ -705,10 +783,10 @@ static int gen2_grid(int dflt) {
 extern "C" int i2p_img_block_fwd(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *y, double *sums,
                                  const float *gamma, const float *beta, float eps, float slope, float momentum, const float *conv_bias,
                                  float *running_mean, float *running_var, void *out, unsigned char *arg, float *mean_invstd, void *stream) {
-    if (!geom_ok(B, H, W, C, stride) || C > MAX_C2) return I2P_ERR_BAD_ARG;
+    if (!geom2_ok(B, H, W, C, stride, y_bf16)) return I2P_ERR_BAD_ARG;
     if (B == 0) return 0;
     if (!y || !sums || !gamma || !beta || !out || !arg || !mean_invstd) return I2P_ERR_BAD_ARG;
-    const PoolGeom g = make_geom(B, H, W, C, stride);
+    const PoolGeom g = make_geom2(B, H, W, C, stride, y_bf16);
     hipStream_t st = (hipStream_t)stream;
     const long long n = (long long)B * H * W;
     const int rpb = THREADS / g.cv;
@@ -721,7 +799,7 @@ extern "C" int i2p_img_block_fwd(int B, int H, int W, int C, int stride, int y_b
     const long long total = (long long)B * g.Ho * g.Wo * g.cv;
     const bool wide = n * g.cv >= (1ll << 31);
     IMG_DISPATCH(img_pool_fwd2_kernel, dim3(grid_for(total, gen2_grid(1 << 12))), g, y, (const double *)sums, gamma, beta, eps, slope, momentum,
-                 conv_bias, running_mean, running_var, out, (uchar4 *)arg, mean_invstd);
+                 conv_bias, running_mean, running_var, out, arg, mean_invstd);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
@@ -730,16 +808,15 @@ extern "C" int i2p_img_block_fwd(int B, int H, int W, int C, int stride, int y_b
 extern "C" int i2p_img_block_bwd(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout, const unsigned char *arg,
                                  const void *y, const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums,
                                  void *dy, float *dgamma, float *dbeta, void *stream) {
-    if (!geom_ok(B, H, W, C, stride) || C > MAX_C2) return I2P_ERR_BAD_ARG;
+    if (!geom2_ok(B, H, W, C, stride, y_bf16)) return I2P_ERR_BAD_ARG;
     if (B == 0) return 0;
     if (!gout || !arg || !y || !mean_invstd || !gamma || !beta || !dsums || !dy || !dgamma || !dbeta) return I2P_ERR_BAD_ARG;
-    const PoolGeom g = make_geom(B, H, W, C, stride);
+    const PoolGeom g = make_geom2(B, H, W, C, stride, y_bf16);
     hipStream_t st = (hipStream_t)stream;
     const long long tot_o = (long long)B * g.Ho * g.Wo * g.cv, tot_i = (long long)B * H * W * g.cv;
     const bool wide = tot_i >= (1ll << 31);
-    IMG_DISPATCH(img_bwd_stats2_kernel, dim3(grid_for(tot_o, MAX_STAT_BLOCKS)), g, gout, (const uchar4 *)arg, y, mean_invstd, gamma, beta,
-                 slope, dsums);
-    IMG_DISPATCH(img_bwd_dx2_kernel, dim3(grid_for(tot_i, gen2_grid(1 << 12))), g, gout, (const uchar4 *)arg, y, mean_invstd, gamma, beta, slope,
+    IMG_DISPATCH(img_bwd_stats2_kernel, dim3(grid_for(tot_o, MAX_STAT_BLOCKS)), g, gout, arg, y, mean_invstd, gamma, beta, slope, dsums);
+    IMG_DISPATCH(img_bwd_dx2_kernel, dim3(grid_for(tot_i, gen2_grid(1 << 12))), g, gout, arg, y, mean_invstd, gamma, beta, slope,
                  (const double *)dsums, dy, dgamma, dbeta);
     I2P_RETURN_LAUNCH_STATUS();
 }
