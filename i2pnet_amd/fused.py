@@ -160,9 +160,30 @@ class _MlpChain(Function):
         ctx.w0_cin = None
         if nl and not first_bn and x.shape[1] > p[k].shape[1]:
             ctx.w0_cin = p[k].shape[1]
-            p[k] = _pad_cols(p[k].detach(), x.shape[1])
         bf = chain_bf16_ok(x, first_bn, [p[k + 3 * i] for i in range(nl)])
         ctx.bf16 = bf
+        # few rows, 64-multiple widths: the whole chain (layers, BN finalisations, activation / max-over-K tail, weight pad) in ONE
+        # launch on a resident grid (csrc/mlp_chain.hip); the node saves exactly what the layer-by-layer path saves
+        if (nl and not first_bn and not bf and running is None and x.dtype == torch.float32 and x.is_cuda
+                and (not pool_k or (256 % (params[-3].shape[0] // 4) == 0 and pool_k <= 255))
+                and be.chain_fits(rows, [x.shape[1]] + [params[k + 3 * i].shape[0] for i in range(nl)], pool_k)):
+            d = lambda t: t.detach()
+            Ws = [d(params[k + 3 * i]) for i in range(nl)]
+            ys_, coefs_, mis_, out, arg, w0p = be.chain_forward(x, Ws, [d(p[k + 3 * i + 1]) for i in range(nl)],
+                                                                [d(p[k + 3 * i + 2]) for i in range(nl)], slopes[1:], _EPS, pool_k,
+                                                                ctx.w0_cin is not None)
+            if w0p is not None:
+                p[k] = w0p
+            ys += ys_; coefs += coefs_; mis += mis_
+            ctx.pool_k = pool_k
+            ctx.first_bn, ctx.slopes, ctx.nl, ctx.k = first_bn, slopes, nl, k
+            ctx.save_for_backward(*ys, *[c for c in coefs if c is not None], *[m for m in mis if m is not None], *p,
+                                  *([arg] if pool_k else []))
+            ctx.n_ys, ctx.n_coef = len(ys), len([c for c in coefs if c is not None])
+            ctx.x_needs_grad = x.requires_grad
+            return out
+        if ctx.w0_cin is not None:
+            p[k] = _pad_cols(p[k].detach(), x.shape[1])
         for i in range(nl):
             W, g, b = p[k + 3 * i], p[k + 3 * i + 1], p[k + 3 * i + 2]
             y, sums, in_coef, mi = be.lin_forward_fin(ys[-1], in_coef, slope_in, W.detach(), g.detach(), b.detach(), _EPS,

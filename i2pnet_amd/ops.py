@@ -94,6 +94,7 @@ class _ZeroArena:
 
 _arena = _ZeroArena()
 _ZERO = {}
+_CHAIN_OK = {}        # (rows, widths, pool_k) -> does i2p_chain_fwd take it on this device
 
 
 def zero_scalar(device, dtype=torch.float32):
@@ -953,6 +954,54 @@ class CBackend:
         self._call("i2p_mask_fill", int(x2.shape[0]), int(x2.shape[1]), self._p(x2, _F32, "x"), self._p(valid, _F32, "valid"), float(fill),
                    self._p(out, _F32, "out"), stream=self._stream())
         return out
+
+    # ---- whole small MLP chain in one launch (csrc/mlp_chain.hip) --------------------------------
+    def chain_fits(self, rows, widths, pool_k):
+        """does i2p_chain_fwd take this chain on the current device?  widths = [row length of x, cout_1, ..., cout_nl]"""
+        if self.name != "hip" or self.device_type != "cuda" or os.environ.get("I2P_NO_CHAIN") == "1":
+            return False
+        key = (int(rows), tuple(int(c) for c in widths), int(pool_k))
+        hit = _CHAIN_OK.get(key)
+        if hit is None:
+            arr = (C.c_int * len(widths))(*key[1])
+            hit = bool(_lib.helper("i2p_chain_fwd_ok", key[0], len(widths) - 1, C.cast(arr, C.c_void_p), key[2]))
+            _CHAIN_OK[key] = hit
+        return hit
+
+    def chain_forward(self, x, weights, gammas, betas, slopes, eps, pool_k, want_w0_pad):
+        """x [rows, c0]; weights[l] [c_{l+1}, cin_l] with cin_0 <= c0 -> (ys, coefs, mis, out, arg or None, w0_pad or None):
+        every pre-BN output, its coef [3,c] / mean_invstd [2c], and out = act(bn(y_last)) or its max over groups of pool_k rows."""
+        rows, c0 = x.shape
+        nl = len(weights)
+        dev = x.device
+        widths = [int(c0)] + [int(w.shape[0]) for w in weights]
+        ys = [torch.empty(rows, c, dtype=_F32, device=dev) for c in widths[1:]]
+        coefs = [torch.empty(3, c, dtype=_F32, device=dev) for c in widths[1:]]
+        mis = [torch.empty(2 * c, dtype=_F32, device=dev) for c in widths[1:]]
+        c_last = widths[-1]
+        if pool_k:
+            out = torch.empty(rows // pool_k, c_last, dtype=_F32, device=dev)
+            arg = torch.empty(rows // pool_k, c_last, dtype=torch.uint8, device=dev)
+        else:
+            out, arg = torch.empty(rows, c_last, dtype=_F32, device=dev), None
+        w0_pad = torch.empty(widths[1], c0, dtype=_F32, device=dev) if want_w0_pad else None
+        sums = zeros(int(_lib.helper("i2p_chain_sums_len", nl, max(widths[1:]))), torch.float64, dev)
+        sync = zeros(4, torch.int32, dev)
+        i_arr = lambda v: (C.c_int * len(v))(*[int(a) for a in v])
+        wd, ld = i_arr(widths), i_arr([w.shape[1] for w in weights])
+        sl = (C.c_float * nl)(*[float(a) for a in slopes])
+        pa = [_abi.ptr_array(ts) for ts in (weights, gammas, betas, ys, coefs, mis)]
+        for ts in (weights, gammas, betas):
+            for t in ts:
+                self._p(t, _F32, "chain parameter")
+        cast = lambda a: C.cast(a, C.c_void_p)
+        self._call("i2p_chain_fwd", int(rows), nl, cast(wd), cast(ld), self._p(x, _F32, "x"), cast(pa[0]), cast(pa[1]), cast(pa[2]),
+                   cast(sl), float(eps), cast(pa[3]), cast(pa[4]), cast(pa[5]), self._p(sums, torch.float64, "sums"), int(pool_k),
+                   self._p(out, _F32, "out"), self._p(arg, torch.uint8, "arg") if arg is not None else None,
+                   self._p(w0_pad, _F32, "w0_pad") if w0_pad is not None else None, self._p(sync, torch.int32, "sync"),
+                   stream=self._stream())
+        self.last_chain_sync = sync
+        return ys, coefs, mis, out, arg, w0_pad
 
     def pad_cols(self, w, cpad):
         out = torch.empty(w.shape[0], cpad, dtype=_F32, device=w.device)

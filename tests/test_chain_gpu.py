@@ -1,0 +1,144 @@
+"""One-launch MLP chains (csrc/mlp_chain.hip: resident grid, activations in LDS, grid barrier per BN) against an fp64 torch
+evaluation of the stack (reference op: PPBackbone_center.py:34-46 Conv2d = 1x1 conv + batch-statistics BN + LeakyReLU, stacked
+and max-pooled over the K neighbours as in PPBackbone_center.py:77-131) and against the layer-by-layer kernels it replaces.
+
+fp32 contract: 1e-4 relative to the tensor's scale.  Shapes = the small chains of the KITTI step at batch 8 (levels 3-4,
+cost-volume resampling, up-convolutions, flow predictors, pc-stage encodings)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+EPS = 1e-5
+
+#        rows   c0   real cin  widths          pool  slopes
+CASES = [(29184, 128, 67, (64, 64, 128), 16, (0.0, 0.0, 0.0)),
+         (14848, 132, 131, (128, 128), 0, (0.0, 0.0)),
+         (14848, 128, 67, (128, 64, 64), 16, (0.0, 0.0, 0.0)),
+         (14592, 128, 67, (128, 64), 8, (0.1, 0.1)),
+         (7296, 12, 10, (64,), 0, (0.1,)),
+         (7296, 128, 128, (64,), 0, (0.1,)),
+         (928, 128, 128, (64,), 0, (0.1,)),
+         (1824, 128, 128, (64,), 0, (0.1,)),
+         (1000, 64, 64, (192, 256, 64), 4, (0.2, 0.0, 0.1)),       # 3 / 4 column tiles per wave, ragged last strip
+         (37, 16, 13, (64,), 0, (0.1,))]                           # less than one strip
+
+
+def _rel(got, want):
+    return float((got.double() - want.double()).abs().max() / want.double().abs().max().clamp_min(1e-30))
+
+
+def _make(rows, c0, cin, widths, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, c0, generator=g) * 1.3 + 0.2
+    x[:, cin:] = 0.0
+    params, c_prev = [], cin
+    for c in widths:
+        params += [torch.randn(c, c_prev, generator=g) / c_prev ** 0.5, torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1]
+        c_prev = c
+    return x.to(DEV), [t.to(DEV) for t in params]
+
+
+def _reference(x, cin, params, slopes, pool_k):
+    a = x.double()[:, :cin]
+    pre = []
+    for l in range(len(params) // 3):
+        W, g, b = [t.double() for t in params[3 * l:3 * l + 3]]
+        y = a @ W.t()
+        pre.append(y)
+        m, v = y.mean(0), y.var(0, unbiased=False)
+        z = (y - m) / torch.sqrt(v + EPS) * g + b
+        a = torch.where(z > 0, z, z * slopes[l])
+    if pool_k:
+        a = a.view(-1, pool_k, a.shape[1]).max(1)[0]
+    return a, pre
+
+
+def _run(x, params, slopes, pool_k, chain):
+    from i2pnet_amd import fused
+    old = os.environ.get("I2P_NO_CHAIN")
+    os.environ["I2P_NO_CHAIN"] = "0" if chain else "1"
+    try:
+        xs = x.clone().requires_grad_(True)
+        ps = [p.clone().requires_grad_(True) for p in params]
+        out = fused._MlpChain.apply(xs, False, (1.0,) + tuple(slopes), pool_k, None, *ps)
+        g = torch.Generator().manual_seed(7)
+        go = torch.randn(out.shape, generator=g).to(DEV)
+        out.backward(go)
+        return out.detach(), xs.grad, [p.grad for p in ps]
+    finally:
+        if old is None:
+            os.environ.pop("I2P_NO_CHAIN", None)
+        else:
+            os.environ["I2P_NO_CHAIN"] = old
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}x{c[1]}-{'-'.join(map(str, c[3]))}-k{c[4]}")
+def test_chain_forward_and_node_gradients(hip_backend, case):
+    rows, c0, cin, widths, pool_k, slopes = case
+    be = hip_backend
+    x, params = _make(rows, c0, cin, widths, seed=rows + c0)
+    assert be.chain_fits(rows, [c0] + list(widths), pool_k), "shape expected on the one-launch path"
+    # the kernel's own outputs against fp64
+    d = lambda t: t.detach()
+    ys, coefs, mis, out, arg, w0p = be.chain_forward(x, [d(params[3 * l]) for l in range(len(widths))],
+                                                     [d(params[3 * l + 1]) for l in range(len(widths))],
+                                                     [d(params[3 * l + 2]) for l in range(len(widths))], slopes, EPS, pool_k, c0 > cin)
+    torch.cuda.synchronize()
+    assert int(be.last_chain_sync[2]) == 0, "grid barrier timed out (grid not resident)"
+    assert int(be.last_chain_sync[0]) == 0 and int(be.last_chain_sync[1]) == 0, "barrier words must be left zero"
+    ref_out, ref_pre = _reference(x, cin, params, slopes, pool_k)
+    for l, (y, r) in enumerate(zip(ys, ref_pre)):
+        assert _rel(y, r) < 1e-4, f"pre-BN output of layer {l}"
+        c = r.shape[1]
+        assert _rel(mis[l][:c], r.mean(0)) < 1e-4 * max(1.0, float(r.abs().mean() / r.mean(0).abs().max()))
+        assert _rel(mis[l][c:], 1.0 / torch.sqrt(r.var(0, unbiased=False) + EPS)) < 1e-4
+        assert torch.equal(coefs[l][0], mis[l][:c]) and torch.equal(coefs[l][2], params[3 * l + 2])
+        assert torch.allclose(coefs[l][1], mis[l][c:] * params[3 * l + 1], rtol=1e-6, atol=0)
+    assert _rel(out, ref_out) < 1e-4
+    if w0p is not None:
+        assert torch.equal(w0p[:, :cin], params[0]) and not w0p[:, cin:].any()
+    if pool_k:   # arg-max: the activated value at the recorded row reproduces the maximum
+        zl = ys[-1].double()
+        c = zl.shape[1]
+        z = (zl - coefs[-1][0].double()) * coefs[-1][1].double() + coefs[-1][2].double()
+        a = torch.where(z > 0, z, z * slopes[-1]).view(-1, pool_k, c)
+        picked = a.gather(1, arg.long().unsqueeze(1)).squeeze(1)
+        assert _rel(picked, a.max(1)[0]) < 1e-6
+    # the autograd node on the one-launch path against the layer-by-layer path (same backward kernels, same saved tensors)
+    o1, gx1, gp1 = _run(x, params, slopes, pool_k, chain=True)
+    o0, gx0, gp0 = _run(x, params, slopes, pool_k, chain=False)
+    assert _rel(o1, o0) < 1e-5
+    assert _rel(gx1[:, :cin], gx0[:, :cin]) < 2e-4
+    for a, b in zip(gp1, gp0):
+        assert a.shape == b.shape and _rel(a, b) < 2e-4
+
+
+def test_chain_is_stable_over_many_launches(hip_backend):
+    """the grid barrier and the reset of its words hold over back-to-back launches; results move only by the summation
+    order of the fp64 statistics atomics"""
+    be = hip_backend
+    rows, c0, cin, widths, pool_k, slopes = CASES[0]
+    x, params = _make(rows, c0, cin, widths, seed=3)
+    d = lambda t: t.detach()
+    args = ([d(params[3 * l]) for l in range(3)], [d(params[3 * l + 1]) for l in range(3)], [d(params[3 * l + 2]) for l in range(3)])
+    first = None
+    for it in range(200):
+        ys, coefs, mis, out, arg, _ = be.chain_forward(x, *args, slopes, EPS, pool_k, False)
+        if first is None:
+            first = out.clone()
+        elif it % 20 == 0:
+            assert int(be.last_chain_sync[2]) == 0
+            assert torch.allclose(out, first, rtol=1e-5, atol=1e-6)
+    torch.cuda.synchronize()
+    assert int(be.last_chain_sync[2]) == 0
+
+
+def test_chain_refuses_what_it_cannot_hold(hip_backend):
+    be = hip_backend
+    assert not be.chain_fits(1 << 20, [128, 64], 0)          # grid would not be resident
+    assert not be.chain_fits(4096, [128, 32], 0)             # output width not a multiple of 64
+    assert not be.chain_fits(4096, [130, 64], 0)             # rows of x not 16-byte aligned
+    assert not be.chain_fits(4096, [128, 64], 24)            # pool size must divide the 64-row strip
