@@ -114,8 +114,9 @@ HELPERS = {
     "i2p_lin_bwd_splittable": ["l", "i", "i", "i"],
     "i2p_chain_fwd_ok": ["l", "i", "p", "i"],
     "i2p_chain_sums_len": ["i", "i"],                               # returns long long (doubles)
+    "i2p_chain_sync_words": [],                                     # returns long long (uint32 words)
 }
-LONG_HELPERS = {"i2p_pair_lin_bwd_scratch", "i2p_pair_bias_bn_bwd_scratch", "i2p_gather_rows_grad_fx_scratch", "i2p_gemm_tn_scratch", "i2p_chain_sums_len"}
+LONG_HELPERS = {"i2p_pair_lin_bwd_scratch", "i2p_pair_bias_bn_bwd_scratch", "i2p_gather_rows_grad_fx_scratch", "i2p_gemm_tn_scratch", "i2p_chain_sums_len", "i2p_chain_sync_words"}
 
 _CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "d": C.c_double, "p": C.c_void_p, "pp": C.c_void_p}
 

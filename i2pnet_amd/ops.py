@@ -986,7 +986,8 @@ class CBackend:
             out, arg = torch.empty(rows, c_last, dtype=_F32, device=dev), None
         w0_pad = torch.empty(widths[1], c0, dtype=_F32, device=dev) if want_w0_pad else None
         sums = zeros(int(_lib.helper("i2p_chain_sums_len", nl, max(widths[1:]))), torch.float64, dev)
-        sync = zeros(4, torch.int32, dev)
+        nsync = int(_lib.helper("i2p_chain_sync_words"))
+        sync = zeros(nsync, torch.int32, dev)
         i_arr = lambda v: (C.c_int * len(v))(*[int(a) for a in v])
         wd, ld = i_arr(widths), i_arr([w.shape[1] for w in weights])
         sl = (C.c_float * nl)(*[float(a) for a in slopes])
@@ -1000,7 +1001,7 @@ class CBackend:
                    self._p(out, _F32, "out"), self._p(arg, torch.uint8, "arg") if arg is not None else None,
                    self._p(w0_pad, _F32, "w0_pad") if w0_pad is not None else None, self._p(sync, torch.int32, "sync"),
                    stream=self._stream())
-        self.last_chain_sync = sync
+        self.last_chain_sync = sync            # word [-32]: 1 if a grid barrier timed out (tests read it)
         return ys, coefs, mis, out, arg, w0_pad
 
     def pad_cols(self, w, cpad):

@@ -461,14 +461,15 @@ int i2p_pair_lin_fwd_fin(int B, int N, int M, int cin, int cout, const float *f,
  *   w_ld[l] = row length of w[l] = the layer's real input width (<= widths[l]; x columns beyond it are ignored);
  *   w / gamma / beta / y / coef / mean_invstd: HOST arrays of nl device pointers; slopes: host array of nl floats;
  *   y[l] f32 [rows, widths[l+1]] pre-BN outputs, coef[l] [3][c] and mean_invstd[l] [2c] as i2p_bn_finalize writes them;
- *   sums: i2p_chain_sums_len(nl, max output width) zeroed doubles; sync: 4 zeroed uint32 (left zero; word 2 = 1 if a grid
- *   barrier timed out, i.e. the grid was not resident and the results are invalid);
+ *   sums: i2p_chain_sums_len(nl, max output width) zeroed doubles; sync: i2p_chain_sync_words() zeroed uint32 (left zero; word
+ *   i2p_chain_sync_words() - 32 is set to 1 if a grid barrier timed out, i.e. the grid was not resident and the results are invalid);
  *   pool_k = 0: out f32 [rows, c_last] = act(bn(y_last));  pool_k > 0 (divides 64 and rows): out [rows / pool_k, c_last] = max over
  *   consecutive groups of pool_k rows and arg u8 (first k attaining it) as i2p_bn_act_maxk_fwd;
  *   w0_pad: NULL or f32 [widths[1]][widths[0]] receiving w[0] with zero columns appended.
  * i2p_chain_fwd_ok: 1 if the shape is taken on the current device (needs a GPU), else 0. */
 int i2p_chain_fwd_ok(long long rows, int nl, const int *widths, int pool_k);
 long long i2p_chain_sums_len(int nl, int cmax_out);
+long long i2p_chain_sync_words(void);
 int i2p_chain_fwd(long long rows, int nl, const int *widths, const int *w_ld, const float *x, const float *const *w,
                   const float *const *gamma, const float *const *beta, const float *slopes, float eps, float *const *y,
                   float *const *coef, float *const *mean_invstd, double *sums, int pool_k, float *out, unsigned char *arg,
