@@ -41,6 +41,64 @@ def _event_time_us(launch, iters):
     return start.elapsed_time(end) / iters * 1e3
 
 
+def _graph_time_us(launch, per_replay=20, replays=10):
+    """per-launch time of a host-bound small launch: `per_replay` launches captured in one hipGraph (zero-arena active, as in a step)"""
+    from i2pnet_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ops.begin_step(dev)
+    try:
+        for _ in range(3):
+            launch()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(per_replay):
+                launch()
+    finally:
+        ops.end_step(dev)
+    for _ in range(3):
+        g.replay()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(replays):
+        g.replay()
+    end.record(); end.synchronize()
+    return start.elapsed_time(end) * 1e3 / (replays * per_replay)
+
+
+def _mlp_chain_entry(B, device):
+    """level-3 set-abstraction MLP (67 -> 64 -> 64 -> 128 on B*228*16 rows, max over K = 16) as ONE launch (chain_fwd_kernel: resident
+    grid, strips in LDS, a grid barrier per BN) against the layer-by-layer launches it replaces (3 x lin_fwd_fin + weight pad + BN /
+    activation / max tail); in-graph launches, forward only"""
+    import os
+    from i2pnet_amd import fused
+    rows, c0, cin, widths, K = B * 228 * 16, 128, 67, (64, 64, 128), 16
+    g = torch.Generator(device=device).manual_seed(5)
+    x = torch.randn(rows, c0, generator=g, device=device); x[:, cin:] = 0
+    params, cp = [], cin
+    for c in widths:
+        params += [torch.randn(c, cp, generator=g, device=device) / cp ** 0.5, torch.ones(c, device=device), torch.zeros(c, device=device)]
+        cp = c
+    slopes = (1.0, 0.0, 0.0, 0.0)
+    run = lambda: fused._MlpChain.apply(x, False, slopes, K, None, *params)
+    old = os.environ.get("I2P_NO_CHAIN")
+    try:
+        with torch.no_grad():
+            os.environ["I2P_NO_CHAIN"] = "1"; t_layers = _graph_time_us(run)
+            os.environ["I2P_NO_CHAIN"] = "0"; t_chain = _graph_time_us(run)
+    finally:
+        if old is None:
+            os.environ.pop("I2P_NO_CHAIN", None)
+        else:
+            os.environ["I2P_NO_CHAIN"] = old
+    by = rows * 4 * (c0 + sum(widths)) + rows // K * widths[-1] * 5
+    fl = 2.0 * rows * (c0 * 64 + 64 * 64 + 64 * 128)
+    return {"kernel": "chain_fwd_kernel (level-3 set-abstraction MLP 67->64->64->128 + max over K=16, one launch; 12 such chains per step)",
+            "bound": "latency (3 grid barriers, 456 resident blocks)", "avg_kernel_us": round(t_chain, 1), "layer_by_layer_us": round(t_layers, 1),
+            "achieved": round(by / t_chain / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / t_chain / 1e3 / HBM_PEAK_GBS, 4),
+            "bytes_per_launch_algorithmic": by, "mfma_TFLOPs": round(fl / t_chain / 1e6, 1), "timed_as": "20 launches per hipGraph replay"}
+
+
 PMC_JSON = ROOT / "profiles" / "r03_pmc_traffic.json"
 
 
@@ -285,7 +343,7 @@ def kernel_rooflines(B, device):
     group = {"kernel": "sa_l1_kernel<9> (level-1 selection + gather + feature build in one launch; unfused = fused_conv_select_k + 2 row "
                        "gathers + subtract + norm + cat, host-timed eager launches)", "bound": "hbm (in practice L2 / LDS / issue)",
              "bytes_per_launch": B * (2 * 64 * 1800 * 12 + 3600 * 32 * 48), "cases": grp}
-    dgrad["other_kernels"] = [fwd, wg, two, pf, selk, group]
+    dgrad["other_kernels"] = [fwd, wg, two, pf, selk, group, _mlp_chain_entry(B, device)]
     del f, gk, bn, bk
     torch.cuda.empty_cache()
     dgrad["chain"] = chain_roofline(B, device)

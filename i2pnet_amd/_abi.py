@@ -83,6 +83,7 @@ DEVICE_ONLY = {
     "i2p_lin_fwd_2src_fin": ["l", "i", "i", "i", "p", "p", "f", "p", "p", "f", "p", "p", "p", "p", "p", "f", "p", "p", "p"],
     "i2p_pair_lin_fwd_fin": ["i"] * 5 + ["p"] * 7 + ["p", "p", "f", "p", "p", "p"],
     "i2p_chain_fwd": ["l", "i", "p", "p", "p", "pp", "pp", "pp", "p", "f", "pp", "pp", "pp", "p", "i", "p", "p", "p", "p"],
+    "i2p_chain_bwd": ["l", "i", "p", "p", "p", "pp", "pp", "pp", "pp", "p", "p", "p", "i", "p", "p", "p", "pp", "pp", "p", "p"],
     "i2p_clip_adam": ["l"] + ["p"] * 8 + ["d", "d"] + ["f"] * 4 + ["p"],
     "i2p_img_bn_stats_fin": ["i", "i", "i", "i", "p", "p", "p", "f", "f", "p", "p", "p", "p"],
     "i2p_img_bn_pool_bwd_fin": ["i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "f", "p", "p", "p", "p", "p"],
@@ -113,10 +114,12 @@ HELPERS = {
     "i2p_gemm_tn_scratch": ["l", "i", "i"],                         # returns long long (bytes)
     "i2p_lin_bwd_splittable": ["l", "i", "i", "i"],
     "i2p_chain_fwd_ok": ["l", "i", "p", "i"],
+    "i2p_chain_bwd_ok": ["l", "i", "p", "i"],
+    "i2p_chain_bwd_slab": ["i", "p", "p"],                          # returns long long (floats)
     "i2p_chain_sums_len": ["i", "i"],                               # returns long long (doubles)
     "i2p_chain_sync_words": [],                                     # returns long long (uint32 words)
 }
-LONG_HELPERS = {"i2p_pair_lin_bwd_scratch", "i2p_pair_bias_bn_bwd_scratch", "i2p_gather_rows_grad_fx_scratch", "i2p_gemm_tn_scratch", "i2p_chain_sums_len", "i2p_chain_sync_words"}
+LONG_HELPERS = {"i2p_pair_lin_bwd_scratch", "i2p_pair_bias_bn_bwd_scratch", "i2p_gather_rows_grad_fx_scratch", "i2p_gemm_tn_scratch", "i2p_chain_sums_len", "i2p_chain_sync_words", "i2p_chain_bwd_slab"}
 
 _CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "d": C.c_double, "p": C.c_void_p, "pp": C.c_void_p}
 

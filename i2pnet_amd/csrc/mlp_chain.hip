@@ -311,6 +311,361 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_fwd_kernel(ChainP p) {
     }
 }
 
+// ---- backward of a whole chain in one launch (+ one reduction launch for the weight-gradient partials) ------------------------------
+// Same resident grid and 64-row strips.  Going from the last layer to the first, per layer l (a_0 = x, y_l = a_{l-1} W_l^T,
+// a_l = act(bn_l(y_l)); G_l = dL/da_l strip in LDS buffer P):
+//   P1  t = G_l * act'(bn_l(y_l)) in place (y_l strip from HBM), column sums {sum t, sum t * xhat_l} -> atomics   -> GRID BARRIER
+//   P2  totals: dbeta_l = S1, dgamma_l = S2 (block 0 writes them), m1 = S1 / rows, m2 = S2 / rows
+//   P3  g^y = scale_l * (t - m1 - xhat_l * m2) in place (y_l strip re-read: L2-hot)           [BN backward, batch statistics]
+//   P4  a_{l-1} strip = act(bn_{l-1}(y_{l-1})) (or the x strip) into LDS buffer Q
+//   P5  dW_l partial of the strip = (g^y)^T a_{l-1} on MFMA (64-row contraction) -> this block's slab of dw_part
+//   P6  G_{l-1} = g^y W_l on MFMA (W from L2) -> replaces P (or goes to gx for the first layer)
+// chain_reduce_kernel then sums the slabs in block order (deterministic), all layers of the chain in one launch.
+struct ChainBP {
+    long long rows;
+    int nl;
+    int c[CH_MAXL + 1];
+    int w_ld[CH_MAXL];
+    int w_off[CH_MAXL];               // offset of layer l's [c_l][w_ld_l] block inside a slab of `tw` floats
+    int tw;
+    const float *x;
+    const float *w[CH_MAXL], *y[CH_MAXL], *coef[CH_MAXL], *mi[CH_MAXL];
+    float slope[CH_MAXL];
+    const float *g;                   // dL/dout: [rows, c_L], or [rows / pool_k, c_L] with arg
+    const unsigned char *arg;
+    int pool_k;
+    float *gx;                        // [rows, c0] or nullptr
+    float *dw_part;                   // [grid][tw]
+    float *dgamma[CH_MAXL], *dbeta[CH_MAXL];
+    double *sums;                     // [nl][CH_REP][2 * smax], zero on entry
+    int smax;
+    unsigned *sync;
+    int ldp, ldq;
+    int abl;
+};
+
+struct BStrip {
+    float *P, *Q, *tab;
+    int ldp, ldq, tid, nvalid;
+    long long row0;
+};
+
+// P1: see above.  `first`: G_L comes from p.g (dense, or un-pooled on the fly from the arg-max bytes) instead of P.
+__device__ __forceinline__ void bwd_p1(const ChainBP &p, const BStrip &s, int l, bool first) {
+    const int c = p.c[l + 1], v = c >> 2, rpp = CH_THREADS / v, tr = s.tid / v, c4 = (s.tid - tr * v) * 4;
+    float *red = s.Q;                                    // [rpp][2][c] floats (Q is free until P4)
+    if (tr < rpp) {
+        const float *cf = p.coef[l];
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(cf + c4), sc = *reinterpret_cast<const f32x4 *>(cf + c + c4),
+                    be = *reinterpret_cast<const f32x4 *>(cf + 2 * c + c4), inv = *reinterpret_cast<const f32x4 *>(p.mi[l] + c + c4);
+        const float slope = p.slope[l];
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        for (int rb = tr; rb < CH_ROWS; rb += 8 * rpp) {
+            f32x4 yv[8], gv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + u * rpp;
+                yv[u] = f32x4{0.f, 0.f, 0.f, 0.f}; gv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r < s.nvalid) {
+                    yv[u] = *reinterpret_cast<const f32x4 *>(p.y[l] + (size_t)(s.row0 + r) * c + c4);
+                    if (first) {
+                        if (p.pool_k) {
+                            const long long row = s.row0 + r, grp = row / p.pool_k;
+                            const unsigned char k = (unsigned char)(row - grp * p.pool_k);
+                            const f32x4 t = *reinterpret_cast<const f32x4 *>(p.g + (size_t)grp * c + c4);
+                            const uchar4 a = *reinterpret_cast<const uchar4 *>(p.arg + (size_t)grp * c + c4);
+                            gv[u] = f32x4{a.x == k ? t[0] : 0.f, a.y == k ? t[1] : 0.f, a.z == k ? t[2] : 0.f, a.w == k ? t[3] : 0.f};
+                        } else {
+                            gv[u] = *reinterpret_cast<const f32x4 *>(p.g + (size_t)(s.row0 + r) * c + c4);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + u * rpp;
+                if (r < CH_ROWS) {
+                    f32x4 g = first ? gv[u] : *reinterpret_cast<const f32x4 *>(s.P + (size_t)r * s.ldp + c4);
+                    f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float z = (yv[u][e] - mu[e]) * sc[e] + be[e];
+                        t[e] = r < s.nvalid ? (z > 0.f ? g[e] : g[e] * slope) : 0.f;
+                        s1[e] += t[e];
+                        s2[e] += t[e] * ((yv[u][e] - mu[e]) * inv[e]);
+                    }
+                    *reinterpret_cast<f32x4 *>(s.P + (size_t)r * s.ldp + c4) = t;
+                }
+            }
+        }
+        *reinterpret_cast<f32x4 *>(red + (size_t)(tr * 2) * c + c4) = s1;
+        *reinterpret_cast<f32x4 *>(red + (size_t)(tr * 2 + 1) * c + c4) = s2;
+    }
+    __syncthreads();
+    if (s.tid < c && !(p.abl & 4)) {
+        double a = 0.0, b = 0.0;
+        for (int g2 = 0; g2 < rpp; ++g2) { a += (double)red[(size_t)(g2 * 2) * c + s.tid]; b += (double)red[(size_t)(g2 * 2 + 1) * c + s.tid]; }
+        double *sums = p.sums + ((size_t)l * CH_REP + (blockIdx.x % CH_REP)) * 2 * p.smax;
+        atomicAdd(sums + s.tid, a);
+        atomicAdd(sums + p.smax + s.tid, b);
+    }
+}
+
+// P2: totals of the BN-backward sums -> tab[0][c] = m1, tab[1][c] = m2; block 0 writes dbeta / dgamma
+__device__ __forceinline__ void bwd_p2(const ChainBP &p, const BStrip &s, int l) {
+    const int c = p.c[l + 1];
+    if (s.tid < c) {
+        double *sl = p.sums + (size_t)l * CH_REP * 2 * p.smax;
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int r = 0; r < CH_REP; ++r) {
+            a += __hip_atomic_load(sl + (size_t)r * 2 * p.smax + s.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b += __hip_atomic_load(sl + (size_t)r * 2 * p.smax + p.smax + s.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s.tab[s.tid] = (float)(a / (double)p.rows);
+        s.tab[256 + s.tid] = (float)(b / (double)p.rows);
+        if (blockIdx.x == 0) { p.dbeta[l][s.tid] = (float)a; p.dgamma[l][s.tid] = (float)b; }
+    }
+    __syncthreads();
+}
+
+// P3: g^y in place in P
+__device__ __forceinline__ void bwd_p3(const ChainBP &p, const BStrip &s, int l) {
+    const int c = p.c[l + 1], v = c >> 2, rpp = CH_THREADS / v, tr = s.tid / v, c4 = (s.tid - tr * v) * 4;
+    if (tr >= rpp) return;
+    const f32x4 mu = *reinterpret_cast<const f32x4 *>(p.coef[l] + c4), sc = *reinterpret_cast<const f32x4 *>(p.coef[l] + c + c4),
+                inv = *reinterpret_cast<const f32x4 *>(p.mi[l] + c + c4), m1 = *reinterpret_cast<const f32x4 *>(s.tab + c4),
+                m2 = *reinterpret_cast<const f32x4 *>(s.tab + 256 + c4);
+    for (int rb = tr; rb < CH_ROWS; rb += 8 * rpp) {
+        f32x4 yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = rb + u * rpp;
+            yv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < s.nvalid) yv[u] = *reinterpret_cast<const f32x4 *>(p.y[l] + (size_t)(s.row0 + r) * c + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = rb + u * rpp;
+            if (r < CH_ROWS) {
+                f32x4 t = *reinterpret_cast<const f32x4 *>(s.P + (size_t)r * s.ldp + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = r < s.nvalid ? sc[e] * (t[e] - m1[e] - ((yv[u][e] - mu[e]) * inv[e]) * m2[e]) : 0.f;
+                *reinterpret_cast<f32x4 *>(s.P + (size_t)r * s.ldp + c4) = t;
+            }
+        }
+    }
+}
+
+// P4: the layer's input strip into Q: act(bn_{l-1}(y_{l-1})) for l > 0, the x strip (zero beyond its columns up to a multiple of 16) for l = 0
+__device__ __forceinline__ void bwd_p4(const ChainBP &p, const BStrip &s, int l) {
+    const int c = p.c[l], kp = (c + 15) & ~15, v = kp >> 2, rpp = CH_THREADS / v, tr = s.tid / v, c4 = (s.tid - tr * v) * 4;
+    if (tr >= rpp) return;
+    const float *src = l ? p.y[l - 1] : p.x;
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, sc = mu, be = mu;
+    const float slope = l ? p.slope[l - 1] : 1.f;
+    if (l && c4 < c) {
+        const float *cf = p.coef[l - 1];
+        mu = *reinterpret_cast<const f32x4 *>(cf + c4); sc = *reinterpret_cast<const f32x4 *>(cf + c + c4); be = *reinterpret_cast<const f32x4 *>(cf + 2 * c + c4);
+    }
+    for (int rb = tr; rb < CH_ROWS; rb += 8 * rpp) {
+        f32x4 buf[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = rb + u * rpp;
+            buf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < s.nvalid && c4 < c) buf[u] = *reinterpret_cast<const f32x4 *>(src + (size_t)(s.row0 + r) * c + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = rb + u * rpp;
+            if (r < CH_ROWS) {
+                f32x4 a = buf[u];
+                if (l) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = (r < s.nvalid && c4 < c) ? act((a[e] - mu[e]) * sc[e] + be[e], slope) : 0.f;
+                }
+                *reinterpret_cast<f32x4 *>(s.Q + (size_t)r * s.ldq + c4) = a;
+            }
+        }
+    }
+}
+
+// P5: dW partial [c_out][w_ld] = (g^y)^T a_in over the strip's 64 rows.  Wave w owns output-channel tiles w*NTM .. w*NTM+NTM-1 and walks
+// the input-channel tiles; A = g^y transposed out of P, B = a_in out of Q (one LDS word per k-step and lane each).
+template <int NTM>
+__device__ __forceinline__ void bwd_wgrad(const ChainBP &p, const BStrip &s, int l, int wave, int i, int q) {
+    const int kp = (p.c[l] + 15) & ~15, ntiles = kp >> 4, w_ld = p.w_ld[l];
+    float *part = p.dw_part + (size_t)blockIdx.x * p.tw + p.w_off[l];
+    for (int nt = 0; nt < ntiles; ++nt) {
+        f32x4 acc[NTM];
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            float b[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e] = s.Q[(size_t)(16 * kc + 4 * q + e) * s.ldq + nt * 16 + i];
+#pragma unroll
+            for (int t = 0; t < NTM; ++t) {
+                const int m0 = (wave * NTM + t) * 16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = s.P[(size_t)(16 * kc + 4 * q + e) * s.ldp + m0 + i];
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[e], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        const int n = nt * 16 + i;
+        if (n < w_ld) {
+#pragma unroll
+            for (int t = 0; t < NTM; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[(size_t)((wave * NTM + t) * 16 + 4 * q + e) * w_ld + n] = acc[t][e];
+        }
+    }
+}
+
+// P6: G_in [64][c_in] = g^y W.  Wave w owns input-channel tiles w, w+4, ... (NTN of them at most); W is read as 64-byte runs of its rows.
+template <int NTN>
+__device__ __forceinline__ void bwd_dgrad(const ChainBP &p, const BStrip &s, int l, int wave, int i, int q) {
+    const int cin = p.c[l], kp = (cin + 15) & ~15, ntiles = kp >> 4, cout = p.c[l + 1], w_ld = p.w_ld[l];
+    const float *W = p.w[l];
+    f32x4 acc[4][NTN];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto loadw = [&](int k0, f32x4 (&b)[NTN]) {
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) {
+            const int n = (wave + 4 * t) * 16 + i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (wave + 4 * t < ntiles && n < w_ld) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = W[(size_t)(k0 + 4 * q + e) * w_ld + n];
+            }
+            b[t] = v;
+        }
+    };
+    f32x4 cur[NTN], nxt[NTN];
+    loadw(0, cur);
+    for (int k0 = 0; k0 < cout; k0 += 16) {
+        if (k0 + 16 < cout) loadw(k0 + 16, nxt);
+        f32x4 a[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) a[rt] = *reinterpret_cast<const f32x4 *>(s.P + (size_t)(rt * 16 + i) * s.ldp + k0 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int t = 0; t < NTN; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][e], cur[t][e], acc[rt][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) cur[t] = nxt[t];
+    }
+    __syncthreads();                                     // every wave is done with g^y in P
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) {
+        const int n = (wave + 4 * t) * 16 + i;
+        if (wave + 4 * t >= ntiles) continue;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = rt * 16 + 4 * q + e;
+                if (l) s.P[(size_t)r * s.ldp + n] = acc[rt][t][e];
+                else if (r < s.nvalid && n < cin) p.gx[(size_t)(s.row0 + r) * cin + n] = acc[rt][t][e];
+            }
+    }
+}
+
+__global__ __launch_bounds__(CH_THREADS, 2) void chain_bwd_kernel(ChainBP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    BStrip s;
+    s.P = smem;
+    s.Q = smem + (size_t)CH_ROWS * p.ldp;
+    s.tab = s.Q + (size_t)CH_ROWS * p.ldq;                // [2][256]: m1, m2 of the current layer
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+    s.ldp = p.ldp; s.ldq = p.ldq; s.tid = tid;
+    s.row0 = (long long)blockIdx.x * CH_ROWS;
+    s.nvalid = (int)((p.rows - s.row0) < CH_ROWS ? (p.rows - s.row0) : CH_ROWS);
+    const unsigned G = gridDim.x;
+
+    for (int l = p.nl - 1; l >= 0; --l) {
+        bwd_p1(p, s, l, l == p.nl - 1);
+        if (!(p.abl & 8)) grid_barrier(p.sync, (unsigned)(p.nl - l), G, tid); else __syncthreads();
+        bwd_p2(p, s, l);
+        bwd_p3(p, s, l);
+        bwd_p4(p, s, l);
+        __syncthreads();
+        if (!(p.abl & 1)) {
+            switch (p.c[l + 1] >> 6) {
+                case 1: bwd_wgrad<1>(p, s, l, wave, i, q); break;
+                case 2: bwd_wgrad<2>(p, s, l, wave, i, q); break;
+                case 3: bwd_wgrad<3>(p, s, l, wave, i, q); break;
+                default: bwd_wgrad<4>(p, s, l, wave, i, q); break;
+            }
+        }
+        if ((l || p.gx) && !(p.abl & 2)) {
+            const int ntn = ((((p.c[l] + 15) & ~15) >> 4) + 3) >> 2;
+            switch (ntn) {
+                case 1: bwd_dgrad<1>(p, s, l, wave, i, q); break;
+                case 2: bwd_dgrad<2>(p, s, l, wave, i, q); break;
+                case 3: bwd_dgrad<3>(p, s, l, wave, i, q); break;
+                default: bwd_dgrad<4>(p, s, l, wave, i, q); break;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(p.sync + CH_EXIT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == G - 1)
+            for (int j = 0; j <= 2 * CH_NG + 1; ++j) __hip_atomic_store(p.sync + j * CH_LINE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// dW of every layer of the chain = sum over the blocks' slabs, in block order: 16 float4 columns x 16 slab lanes per block
+__global__ __launch_bounds__(256) void chain_reduce_kernel(int nparts, int n4, const float4 *__restrict__ parts, float4 *__restrict__ out) {
+    __shared__ float4 red[16][16];
+    const int tx = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + tx;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o < n4) {
+        int b = pl;
+        for (; b + 48 < nparts; b += 64) {
+            const float4 v0 = parts[(size_t)b * n4 + o], v1 = parts[(size_t)(b + 16) * n4 + o];
+            const float4 v2 = parts[(size_t)(b + 32) * n4 + o], v3 = parts[(size_t)(b + 48) * n4 + o];
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+            a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+            a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+            a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+        }
+        for (; b < nparts; b += 16) {
+            const float4 v = parts[(size_t)b * n4 + o];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    red[pl][tx] = a;
+    __syncthreads();
+    if (pl == 0 && o < n4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const float4 v = red[j][tx]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        out[o] = t;
+    }
+}
+
+// LDS rows of the backward: P holds gradients of the layer outputs, Q the layer inputs
+void chain_bwd_ld(int nl, const int *widths, int &ldp, int &ldq) {
+    int mp = 0, mq = 0;
+    for (int l = 1; l <= nl; ++l) mp = widths[l] > mp ? widths[l] : mp;
+    for (int l = 0; l < nl; ++l) { const int k = (widths[l] + 15) & ~15; mq = k > mq ? k : mq; }
+    ldp = mp + 4; ldq = (mq < 32 ? 32 : mq) + 4;
+}
+
+size_t chain_bwd_lds_bytes(int ldp, int ldq) { return ((size_t)CH_ROWS * (ldp + ldq) + 512) * sizeof(float); }
+
 int chain_cmax(int nl, const int *widths) {
     int m = 0;
     for (int l = 0; l <= nl; ++l) m = widths[l] > m ? widths[l] : m;
@@ -365,7 +720,7 @@ extern "C" int i2p_chain_fwd(long long rows, int nl, const int *widths, const in
     ChainP p{};
     p.rows = rows; p.nl = nl; p.x = x; p.eps = eps; p.sums = sums; p.pool_k = pool_k; p.out = out; p.arg = arg; p.w0_pad = w0_pad;
     p.sync = sync;
-    { const char *e = getenv("I2P_CHAIN_ABL"); p.abl = e ? atoi(e) : 0; }
+    { const char *e = getenv("I2P_CHAIN_ABL"); p.abl = e ? atoi(e) : 0; }     /* read per call: tools/time_chain.py switches it */
     p.c[0] = widths[0];
     for (int l = 0; l < nl; ++l) {
         p.c[l + 1] = widths[l + 1]; p.w_ld[l] = w_ld[l];
@@ -384,5 +739,68 @@ extern "C" int i2p_chain_fwd(long long rows, int nl, const int *widths, const in
     }
     const unsigned grid = (unsigned)((rows + CH_ROWS - 1) / CH_ROWS);
     hipLaunchKernelGGL(chain_fwd_kernel, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------------------------------
+extern "C" int i2p_chain_bwd_ok(long long rows, int nl, const int *widths, int pool_k) {
+    if (rows <= 0 || nl < 1 || nl > CH_MAXL || !widths) return 0;
+    if (widths[0] <= 0 || (widths[0] & 3) || widths[0] > 256) return 0;
+    for (int l = 1; l <= nl; ++l)
+        if (widths[l] <= 0 || (widths[l] & 63) || widths[l] > 256) return 0;
+    if (pool_k < 0 || pool_k > 255 || (pool_k && rows % pool_k)) return 0;
+    int ldp, ldq;
+    chain_bwd_ld(nl, widths, ldp, ldq);
+    const size_t lds = chain_bwd_lds_bytes(ldp, ldq);
+    if (lds > 160 * 1024) return 0;
+    const int per_cu = (int)((160 * 1024) / lds) > 2 ? 2 : (int)((160 * 1024) / lds);
+    const int cus = chain_cus();
+    const long long blocks = (rows + CH_ROWS - 1) / CH_ROWS;
+    return cus > 0 && blocks <= (long long)cus * per_cu ? 1 : 0;
+}
+
+// floats of one block's weight-gradient slab (= of the reduced `dw` buffer): layer l's [widths[l+1]][w_ld[l]] block starts at the sum
+// of the blocks before it; dw_part needs ceil(rows / 64) slabs
+extern "C" long long i2p_chain_bwd_slab(int nl, const int *widths, const int *w_ld) {
+    long long t = 0;
+    for (int l = 0; l < nl; ++l) t += (long long)widths[l + 1] * w_ld[l];
+    return t;
+}
+
+extern "C" int i2p_chain_bwd(long long rows, int nl, const int *widths, const int *w_ld, const float *x, const float *const *w,
+                             const float *const *y, const float *const *coef, const float *const *mean_invstd, const float *slopes,
+                             const float *g, const unsigned char *arg, int pool_k, float *gx, float *dw_part, float *dw,
+                             float *const *dgamma, float *const *dbeta, double *sums, unsigned *sync, void *stream) {
+    if (!i2p_chain_bwd_ok(rows, nl, widths, pool_k)) return I2P_ERR_BAD_ARG;
+    if (!w_ld || !x || !w || !y || !coef || !mean_invstd || !slopes || !g || !dw_part || !dw || !dgamma || !dbeta || !sums || !sync ||
+        (pool_k && !arg))
+        return I2P_ERR_BAD_ARG;
+    ChainBP p{};
+    p.rows = rows; p.nl = nl; p.x = x; p.g = g; p.arg = arg; p.pool_k = pool_k; p.gx = gx; p.dw_part = dw_part; p.sums = sums; p.sync = sync;
+    { const char *e = getenv("I2P_CHAIN_ABL"); p.abl = e ? atoi(e) : 0; }
+    p.c[0] = widths[0];
+    int off = 0;
+    for (int l = 0; l < nl; ++l) {
+        if (w_ld[l] <= 0 || w_ld[l] > widths[l] || !w[l] || !y[l] || !coef[l] || !mean_invstd[l] || !dgamma[l] || !dbeta[l]) return I2P_ERR_BAD_ARG;
+        p.c[l + 1] = widths[l + 1]; p.w_ld[l] = w_ld[l]; p.w_off[l] = off;
+        off += widths[l + 1] * w_ld[l];
+        p.w[l] = w[l]; p.y[l] = y[l]; p.coef[l] = coef[l]; p.mi[l] = mean_invstd[l]; p.slope[l] = slopes[l];
+        p.dgamma[l] = dgamma[l]; p.dbeta[l] = dbeta[l];
+        p.smax = widths[l + 1] > p.smax ? widths[l + 1] : p.smax;
+    }
+    p.tw = off;
+    if ((off & 3) || ((reinterpret_cast<uintptr_t>(dw_part) | reinterpret_cast<uintptr_t>(dw)) & 15)) return I2P_ERR_BAD_ARG;
+    chain_bwd_ld(nl, widths, p.ldp, p.ldq);
+    const size_t bytes = chain_bwd_lds_bytes(p.ldp, p.ldq);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)((rows + CH_ROWS - 1) / CH_ROWS);
+    hipLaunchKernelGGL(chain_bwd_kernel, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
+    const int n4 = off >> 2;
+    hipLaunchKernelGGL(chain_reduce_kernel, dim3((n4 + 15) / 16), dim3(256), 0, (hipStream_t)stream, (int)grid, n4,
+                       reinterpret_cast<const float4 *>(dw_part), reinterpret_cast<float4 *>(dw));
     I2P_RETURN_LAUNCH_STATUS();
 }

@@ -169,9 +169,12 @@ class _MlpChain(Function):
                 and be.chain_fits(rows, [x.shape[1]] + [params[k + 3 * i].shape[0] for i in range(nl)], pool_k)):
             d = lambda t: t.detach()
             Ws = [d(params[k + 3 * i]) for i in range(nl)]
+            # the backward of the chain in one launch too (csrc/mlp_chain.hip: chain_bwd_kernel) when its two LDS strips fit; otherwise the
+            # layer-by-layer backward, which wants W_0 with its zero columns
+            ctx.chain_bwd = be.chain_bwd_fits(rows, [x.shape[1]] + [w.shape[0] for w in Ws], pool_k)
             ys_, coefs_, mis_, out, arg, w0p = be.chain_forward(x, Ws, [d(p[k + 3 * i + 1]) for i in range(nl)],
                                                                 [d(p[k + 3 * i + 2]) for i in range(nl)], slopes[1:], _EPS, pool_k,
-                                                                ctx.w0_cin is not None)
+                                                                ctx.w0_cin is not None and not ctx.chain_bwd)
             if w0p is not None:
                 p[k] = w0p
             ys += ys_; coefs += coefs_; mis += mis_
@@ -236,6 +239,16 @@ class _MlpChain(Function):
         saved = list(ctx.saved_tensors)
         bf = getattr(ctx, "bf16", False)
         fused_ds = None
+        if getattr(ctx, "chain_bwd", False):
+            arg = saved.pop() if ctx.pool_k else None
+            n_ys, n_cf, nl = ctx.n_ys, ctx.n_coef, ctx.nl
+            ys, cf, ms, p = saved[:n_ys], saved[n_ys:n_ys + n_cf], saved[n_ys + n_cf:n_ys + 2 * n_cf], saved[n_ys + 2 * n_cf:]
+            gx, dws, dgs, dbs = be.chain_backward(ys[0], [p[3 * i].detach() for i in range(nl)], ys[1:], cf, ms, ctx.slopes[1:],
+                                                  g_out.contiguous(), arg, ctx.pool_k, ctx.x_needs_grad)
+            grads = [None] * len(p)
+            for i in range(nl):
+                grads[3 * i], grads[3 * i + 1], grads[3 * i + 2] = dws[i], dgs[i], dbs[i]
+            return gx, None, None, None, None, *grads
         if ctx.pool_k:
             arg = saved.pop()
             if (not bf and be.name == "hip" and ctx.nl and 256 % (g_out.shape[1] // 4) == 0 and os.environ.get("I2P_NO_UNPOOL_STATS") != "1"):

@@ -1004,6 +1004,56 @@ class CBackend:
         self.last_chain_sync = sync            # word [-32]: 1 if a grid barrier timed out (tests read it)
         return ys, coefs, mis, out, arg, w0_pad
 
+    def chain_bwd_fits(self, rows, widths, pool_k):
+        # opt-in (I2P_CHAIN_BWD=1): correct (tests/test_chain_gpu.py) but not yet faster than the layer-by-layer backward — 190 vs 177 us
+        # forward + backward on the 29 184-row chain, 58 vs 46 us on the 7 296-row layers (tools/time_chain.py); see DESIGN.md
+        if (self.name != "hip" or self.device_type != "cuda" or os.environ.get("I2P_NO_CHAIN") == "1"
+                or os.environ.get("I2P_CHAIN_BWD") != "1"):
+            return False
+        key = ("bwd", int(rows), tuple(int(c) for c in widths), int(pool_k))
+        hit = _CHAIN_OK.get(key)
+        if hit is None:
+            arr = (C.c_int * len(widths))(*key[2])
+            hit = bool(_lib.helper("i2p_chain_bwd_ok", key[1], len(widths) - 1, C.cast(arr, C.c_void_p), key[3]))
+            _CHAIN_OK[key] = hit
+        return hit
+
+    def chain_backward(self, x, weights, ys, coefs, mis, slopes, g, arg, pool_k, need_gx):
+        """backward of chain_forward in two launches (chain + slab reduction): g = dL/dout ([rows, c] or pooled [rows / pool_k, c]
+        with arg) -> (dL/dx [rows, c0] or None, [dW_l] (shapes of weights), [dgamma_l], [dbeta_l])"""
+        rows, c0 = x.shape
+        nl = len(weights)
+        dev = x.device
+        widths = [int(c0)] + [int(w.shape[0]) for w in weights]
+        i_arr = lambda v: (C.c_int * len(v))(*[int(a) for a in v])
+        wd, ld = i_arr(widths), i_arr([w.shape[1] for w in weights])
+        cast = lambda a: C.cast(a, C.c_void_p)
+        tw = int(_lib.helper("i2p_chain_bwd_slab", nl, cast(wd), cast(ld)))
+        grid = (rows + 63) // 64
+        dw_part = torch.empty(grid * tw, dtype=_F32, device=dev)
+        dw = torch.empty(tw, dtype=_F32, device=dev)
+        gx = torch.empty(rows, c0, dtype=_F32, device=dev) if need_gx else None
+        dgs = [torch.empty(c, dtype=_F32, device=dev) for c in widths[1:]]
+        dbs = [torch.empty(c, dtype=_F32, device=dev) for c in widths[1:]]
+        sums = zeros(int(_lib.helper("i2p_chain_sums_len", nl, max(widths[1:]))), torch.float64, dev)
+        sync = zeros(int(_lib.helper("i2p_chain_sync_words")), torch.int32, dev)
+        sl = (C.c_float * nl)(*[float(a) for a in slopes])
+        for ts in (weights, ys, coefs, mis):
+            for t in ts:
+                self._p(t, _F32, "chain tensor")
+        pa = [_abi.ptr_array(ts) for ts in (weights, ys, coefs, mis, dgs, dbs)]
+        self._call("i2p_chain_bwd", int(rows), nl, cast(wd), cast(ld), self._p(x, _F32, "x"), cast(pa[0]), cast(pa[1]), cast(pa[2]), cast(pa[3]),
+                   cast(sl), self._p(g, _F32, "g"), self._p(arg, torch.uint8, "arg") if arg is not None else None, int(pool_k),
+                   self._p(gx, _F32, "gx") if gx is not None else None, self._p(dw_part, _F32, "dw_part"), self._p(dw, _F32, "dw"),
+                   cast(pa[4]), cast(pa[5]), self._p(sums, torch.float64, "sums"), self._p(sync, torch.int32, "sync"), stream=self._stream())
+        self.last_chain_sync = sync
+        dws, off = [], 0
+        for w in weights:
+            n = w.shape[0] * w.shape[1]
+            dws.append(dw[off:off + n].view(w.shape[0], w.shape[1]))
+            off += n
+        return gx, dws, dgs, dbs
+
     def pad_cols(self, w, cpad):
         out = torch.empty(w.shape[0], cpad, dtype=_F32, device=w.device)
         self._call("i2p_pad_cols", int(w.shape[0]), int(w.shape[1]), int(cpad), self._p(w, _F32, "w"), self._p(out, _F32, "out"),

@@ -474,6 +474,20 @@ int i2p_chain_fwd(long long rows, int nl, const int *widths, const int *w_ld, co
                   const float *const *gamma, const float *const *beta, const float *slopes, float eps, float *const *y,
                   float *const *coef, float *const *mean_invstd, double *sums, int pool_k, float *out, unsigned char *arg,
                   float *w0_pad, unsigned *sync, void *stream);
+/* Backward of i2p_chain_fwd in TWO launches (the chain on the same resident grid, then the reduction of the per-block weight-gradient
+ * slabs in block order, i.e. deterministic): replaces, per layer, i2p_bn_act_bwd_stats / i2p_lin_bwd (dgrad + wgrad + reduction) and
+ * the un-pooling launch (reference: autograd of Conv2d.forward, PPBackbone_center.py:34-46, and of torch.max over K, :129).
+ *   x, w, widths, w_ld, slopes, pool_k, arg as in the forward; y / coef / mean_invstd: the forward's outputs (host arrays of nl pointers);
+ *   g = dL/dout: f32 [rows, c_last], or [rows / pool_k, c_last] when pool_k > 0;
+ *   gx: NULL or f32 [rows, widths[0]] = dL/dx;  dgamma[l], dbeta[l]: f32 [widths[l+1]];
+ *   dw: f32 [i2p_chain_bwd_slab(...)] = the dW_l [widths[l+1]][w_ld[l]] back to back; dw_part: ceil(rows / 64) slabs of scratch;
+ *   sums: i2p_chain_sums_len(nl, max output width) zeroed doubles; sync: as in the forward. */
+int i2p_chain_bwd_ok(long long rows, int nl, const int *widths, int pool_k);
+long long i2p_chain_bwd_slab(int nl, const int *widths, const int *w_ld);
+int i2p_chain_bwd(long long rows, int nl, const int *widths, const int *w_ld, const float *x, const float *const *w,
+                  const float *const *y, const float *const *coef, const float *const *mean_invstd, const float *slopes,
+                  const float *g, const unsigned char *arg, int pool_k, float *gx, float *dw_part, float *dw,
+                  float *const *dgamma, float *const *dbeta, double *sums, unsigned *sync, void *stream);
 /* deterministic variants (no floating-point atomics; fixed summation order => bitwise reproducible gradients):
  * i2p_pair_lin_bwd takes its slabs from dw_partial, which must hold i2p_pair_lin_bwd_scratch(...) floats;
  * i2p_pair_bias_bn_bwd_det is i2p_pair_bias_bn_bwd with caller scratch of i2p_pair_bias_bn_bwd_scratch(...) floats. */

@@ -56,10 +56,14 @@ def _reference(x, cin, params, slopes, pool_k):
     return a, pre
 
 
-def _run(x, params, slopes, pool_k, chain):
+def _run(x, params, slopes, pool_k, mode):
+    """the autograd node in one of three modes: "chain" (one-launch forward AND backward), "fwd" (one-launch forward, layer-by-layer
+    backward), "layers" (layer by layer both ways)"""
     from i2pnet_amd import fused
-    old = os.environ.get("I2P_NO_CHAIN")
-    os.environ["I2P_NO_CHAIN"] = "0" if chain else "1"
+    keys = ("I2P_NO_CHAIN", "I2P_CHAIN_BWD")
+    old = {k: os.environ.get(k) for k in keys}
+    os.environ["I2P_NO_CHAIN"] = "1" if mode == "layers" else "0"
+    os.environ["I2P_CHAIN_BWD"] = "1" if mode == "chain" else "0"
     try:
         xs = x.clone().requires_grad_(True)
         ps = [p.clone().requires_grad_(True) for p in params]
@@ -69,10 +73,30 @@ def _run(x, params, slopes, pool_k, chain):
         out.backward(go)
         return out.detach(), xs.grad, [p.grad for p in ps]
     finally:
-        if old is None:
-            os.environ.pop("I2P_NO_CHAIN", None)
-        else:
-            os.environ["I2P_NO_CHAIN"] = old
+        for k in keys:
+            if old[k] is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = old[k]
+
+
+def _reference_grads(x, cin, params, slopes, pool_k):
+    """fp64 autograd of the stack for the same dL/dout"""
+    xd = x.double()[:, :cin].clone().requires_grad_(True)
+    pd = [p.double().clone().requires_grad_(True) for p in params]
+    a = xd
+    for l in range(len(pd) // 3):
+        W, g, b = pd[3 * l:3 * l + 3]
+        y = a @ W.t()
+        m, v = y.mean(0), y.var(0, unbiased=False)
+        z = (y - m) / torch.sqrt(v + EPS) * g + b
+        a = torch.where(z > 0, z, z * slopes[l])
+    if pool_k:
+        a = a.view(-1, pool_k, a.shape[1]).max(1)[0]
+    gen = torch.Generator().manual_seed(7)
+    go = torch.randn(a.shape, generator=gen).to(DEV).double()
+    a.backward(go)
+    return xd.grad, [p.grad for p in pd]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}x{c[1]}-{'-'.join(map(str, c[3]))}-k{c[4]}")
@@ -107,13 +131,25 @@ def test_chain_forward_and_node_gradients(hip_backend, case):
         a = torch.where(z > 0, z, z * slopes[-1]).view(-1, pool_k, c)
         picked = a.gather(1, arg.long().unsqueeze(1)).squeeze(1)
         assert _rel(picked, a.max(1)[0]) < 1e-6
-    # the autograd node on the one-launch path against the layer-by-layer path (same backward kernels, same saved tensors)
-    o1, gx1, gp1 = _run(x, params, slopes, pool_k, chain=True)
-    o0, gx0, gp0 = _run(x, params, slopes, pool_k, chain=False)
-    assert _rel(o1, o0) < 1e-5
-    assert _rel(gx1[:, :cin], gx0[:, :cin]) < 2e-4
-    for a, b in zip(gp1, gp0):
-        assert a.shape == b.shape and _rel(a, b) < 2e-4
+    # the autograd node: one-launch forward + one-launch backward (chain_bwd_kernel), one-launch forward + layer-by-layer backward,
+    # layer by layer both ways — against each other and against fp64 autograd of the stack
+    o0, gx0, gp0 = _run(x, params, slopes, pool_k, "layers")
+    rgx, rgp = _reference_grads(x, cin, params, slopes, pool_k)
+    for mode in ("fwd", "chain"):
+        o1, gx1, gp1 = _run(x, params, slopes, pool_k, mode)
+        if mode == "chain":
+            os.environ["I2P_CHAIN_BWD"] = "1"
+            try:
+                assert be.chain_bwd_fits(rows, [c0] + list(widths), pool_k), "shape expected on the one-launch backward"
+            finally:
+                os.environ.pop("I2P_CHAIN_BWD", None)
+            assert not be.last_chain_sync.any(), "backward barrier words must be left zero (word -32 set: a barrier timed out)"
+        assert _rel(o1, o0) < 1e-5
+        assert _rel(gx1[:, :cin], gx0[:, :cin]) < 2e-4, mode
+        assert _rel(gx1[:, :cin], rgx) < 2e-4, mode
+        for j, (a, b, r) in enumerate(zip(gp1, gp0, rgp)):
+            assert a.shape == b.shape and _rel(a, b) < 2e-4, (mode, j)
+            assert _rel(a, r) < 2e-4, (mode, j)
 
 
 def test_chain_is_stable_over_many_launches(hip_backend):

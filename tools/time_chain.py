@@ -1,6 +1,7 @@
 """Per-launch time of the one-launch MLP chains (csrc/mlp_chain.hip) on the step's shapes, next to the layer-by-layer kernels,
 with the kernel's diagnostic ablation bits (I2P_CHAIN_ABL: 1 no MFMA loop, 2 constant weights (no global loads in the loop),
-4 no statistics atomics, 8 no grid barrier, 16 no replica-sum loads, 32 no y store).  20 launches per hipGraph replay.
+4 no statistics atomics, 8 no grid barrier, 16 no replica-sum loads, 32 no y store; in the backward: 1 no wgrad, 2 no dgrad,
+4 no atomics, 8 no barrier).  20 launches per hipGraph replay.
 
     python tools/time_chain.py [abl ...]
 """
@@ -71,6 +72,29 @@ def main():
                 t = timed(lambda: fused._MlpChain.apply(x, False, slopes, pool_k, None, *params))
             line += f"  abl{a}: {t:6.1f}"
         os.environ.pop("I2P_CHAIN_ABL", None)
+        print(line, flush=True)
+        # forward + backward of the autograd node: layer by layer / one-launch forward only / one-launch both ways
+        xs = x.clone().requires_grad_(True)
+        ps = [q.clone().requires_grad_(True) for q in params]
+        go = torch.randn(rows // pool_k if pool_k else rows, widths[-1], device=DEV)
+
+        def fb():
+            xs.grad = None
+            for q in ps:
+                q.grad = None
+            fused._MlpChain.apply(xs, False, slopes, pool_k, None, *ps).backward(go)
+        line = " " * 42 + "fwd+bwd:"
+        for tag, nc, cb in (("layers", "1", "0"), ("chain fwd", "0", "0"), ("chain both", "0", "1")):
+            os.environ["I2P_NO_CHAIN"], os.environ["I2P_CHAIN_BWD"] = nc, cb
+            if tag == "chain both":
+                for a in abls:
+                    os.environ["I2P_CHAIN_ABL"] = str(a)
+                    line += f"  {tag} abl{a} {timed(fb):6.1f}"
+                os.environ.pop("I2P_CHAIN_ABL", None)
+            else:
+                line += f"  {tag} {timed(fb):6.1f} us |"
+        os.environ["I2P_NO_CHAIN"] = "0"
+        os.environ.pop("I2P_CHAIN_BWD", None)
         print(line, flush=True)
 
 
