@@ -84,6 +84,8 @@ DEVICE_ONLY = {
     "i2p_pair_lin_fwd_fin": ["i"] * 5 + ["p"] * 7 + ["p", "p", "f", "p", "p", "p"],
     "i2p_chain_fwd": ["l", "i", "p", "p", "p", "pp", "pp", "pp", "p", "f", "pp", "pp", "pp", "p", "i", "p", "p", "p", "p"],
     "i2p_chain_bwd": ["l", "i", "p", "p", "p", "pp", "pp", "pp", "pp", "p", "p", "p", "i", "p", "p", "p", "pp", "pp", "p", "p"],
+    "i2p_pose_compose_fwd": ["i", "p", "p", "p", "p", "p"],
+    "i2p_pose_compose_bwd": ["i"] + ["p"] * 8,
     "i2p_clip_adam": ["l"] + ["p"] * 8 + ["d", "d"] + ["f"] * 4 + ["p"],
     "i2p_img_bn_stats_fin": ["i", "i", "i", "i", "p", "p", "p", "f", "f", "p", "p", "p", "p"],
     "i2p_img_bn_pool_bwd_fin": ["i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "f", "p", "p", "p", "p", "p"],

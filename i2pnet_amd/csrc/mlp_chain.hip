@@ -350,7 +350,11 @@ struct BStrip {
     long long row0;
 };
 
+// RB = rows of a strip (64 dispatched; see chain_bwd_rb).  The backward runs ONE block = four waves per CU, one wave per SIMD: the whole
+// register file per wave.
+
 // P1: see above.  `first`: G_L comes from p.g (dense, or un-pooled on the fly from the arg-max bytes) instead of P.
+template <int RB>
 __device__ __forceinline__ void bwd_p1(const ChainBP &p, const BStrip &s, int l, bool first) {
     const int c = p.c[l + 1], v = c >> 2, rpp = CH_THREADS / v, tr = s.tid / v, c4 = (s.tid - tr * v) * 4;
     float *red = s.Q;                                    // [rpp][2][c] floats (Q is free until P4)
@@ -360,7 +364,7 @@ __device__ __forceinline__ void bwd_p1(const ChainBP &p, const BStrip &s, int l,
                     be = *reinterpret_cast<const f32x4 *>(cf + 2 * c + c4), inv = *reinterpret_cast<const f32x4 *>(p.mi[l] + c + c4);
         const float slope = p.slope[l];
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-        for (int rb = tr; rb < CH_ROWS; rb += 8 * rpp) {
+        for (int rb = tr; rb < RB; rb += 8 * rpp) {
             f32x4 yv[8], gv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -384,7 +388,7 @@ __device__ __forceinline__ void bwd_p1(const ChainBP &p, const BStrip &s, int l,
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int r = rb + u * rpp;
-                if (r < CH_ROWS) {
+                if (r < RB) {
                     f32x4 g = first ? gv[u] : *reinterpret_cast<const f32x4 *>(s.P + (size_t)r * s.ldp + c4);
                     f32x4 t;
 #pragma unroll
@@ -430,13 +434,14 @@ __device__ __forceinline__ void bwd_p2(const ChainBP &p, const BStrip &s, int l)
 }
 
 // P3: g^y in place in P
+template <int RB>
 __device__ __forceinline__ void bwd_p3(const ChainBP &p, const BStrip &s, int l) {
     const int c = p.c[l + 1], v = c >> 2, rpp = CH_THREADS / v, tr = s.tid / v, c4 = (s.tid - tr * v) * 4;
     if (tr >= rpp) return;
     const f32x4 mu = *reinterpret_cast<const f32x4 *>(p.coef[l] + c4), sc = *reinterpret_cast<const f32x4 *>(p.coef[l] + c + c4),
                 inv = *reinterpret_cast<const f32x4 *>(p.mi[l] + c + c4), m1 = *reinterpret_cast<const f32x4 *>(s.tab + c4),
                 m2 = *reinterpret_cast<const f32x4 *>(s.tab + 256 + c4);
-    for (int rb = tr; rb < CH_ROWS; rb += 8 * rpp) {
+    for (int rb = tr; rb < RB; rb += 8 * rpp) {
         f32x4 yv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -447,7 +452,7 @@ __device__ __forceinline__ void bwd_p3(const ChainBP &p, const BStrip &s, int l)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int r = rb + u * rpp;
-            if (r < CH_ROWS) {
+            if (r < RB) {
                 f32x4 t = *reinterpret_cast<const f32x4 *>(s.P + (size_t)r * s.ldp + c4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] = r < s.nvalid ? sc[e] * (t[e] - m1[e] - ((yv[u][e] - mu[e]) * inv[e]) * m2[e]) : 0.f;
@@ -458,6 +463,7 @@ __device__ __forceinline__ void bwd_p3(const ChainBP &p, const BStrip &s, int l)
 }
 
 // P4: the layer's input strip into Q: act(bn_{l-1}(y_{l-1})) for l > 0, the x strip (zero beyond its columns up to a multiple of 16) for l = 0
+template <int RB>
 __device__ __forceinline__ void bwd_p4(const ChainBP &p, const BStrip &s, int l) {
     const int c = p.c[l], kp = (c + 15) & ~15, v = kp >> 2, rpp = CH_THREADS / v, tr = s.tid / v, c4 = (s.tid - tr * v) * 4;
     if (tr >= rpp) return;
@@ -468,7 +474,7 @@ __device__ __forceinline__ void bwd_p4(const ChainBP &p, const BStrip &s, int l)
         const float *cf = p.coef[l - 1];
         mu = *reinterpret_cast<const f32x4 *>(cf + c4); sc = *reinterpret_cast<const f32x4 *>(cf + c + c4); be = *reinterpret_cast<const f32x4 *>(cf + 2 * c + c4);
     }
-    for (int rb = tr; rb < CH_ROWS; rb += 8 * rpp) {
+    for (int rb = tr; rb < RB; rb += 8 * rpp) {
         f32x4 buf[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -479,7 +485,7 @@ __device__ __forceinline__ void bwd_p4(const ChainBP &p, const BStrip &s, int l)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int r = rb + u * rpp;
-            if (r < CH_ROWS) {
+            if (r < RB) {
                 f32x4 a = buf[u];
                 if (l) {
 #pragma unroll
@@ -491,9 +497,10 @@ __device__ __forceinline__ void bwd_p4(const ChainBP &p, const BStrip &s, int l)
     }
 }
 
-// P5: dW partial [c_out][w_ld] = (g^y)^T a_in over the strip's 64 rows.  Wave w owns output-channel tiles w*NTM .. w*NTM+NTM-1 and walks
-// the input-channel tiles; A = g^y transposed out of P, B = a_in out of Q (one LDS word per k-step and lane each).
-template <int NTM>
+// P5: dW partial [c_out][w_ld] = (g^y)^T a_in over the strip's RB rows.  Wave w owns output-channel tiles w*NTM .. w*NTM+NTM-1 and walks
+// the input-channel tiles; A = g^y transposed out of P (the compiler keeps the wave's A fragments in registers across the walk), B =
+// a_in out of Q (one LDS word per k-step and lane).
+template <int NTM, int RB>
 __device__ __forceinline__ void bwd_wgrad(const ChainBP &p, const BStrip &s, int l, int wave, int i, int q) {
     const int kp = (p.c[l] + 15) & ~15, ntiles = kp >> 4, w_ld = p.w_ld[l];
     float *part = p.dw_part + (size_t)blockIdx.x * p.tw + p.w_off[l];
@@ -502,7 +509,7 @@ __device__ __forceinline__ void bwd_wgrad(const ChainBP &p, const BStrip &s, int
 #pragma unroll
         for (int t = 0; t < NTM; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
+        for (int kc = 0; kc < RB / 16; ++kc) {
             float b[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) b[e] = s.Q[(size_t)(16 * kc + 4 * q + e) * s.ldq + nt * 16 + i];
@@ -526,97 +533,119 @@ __device__ __forceinline__ void bwd_wgrad(const ChainBP &p, const BStrip &s, int
     }
 }
 
-// P6: G_in [64][c_in] = g^y W.  Wave w owns input-channel tiles w, w+4, ... (NTN of them at most); W is read as 64-byte runs of its rows.
-template <int NTN>
-__device__ __forceinline__ void bwd_dgrad(const ChainBP &p, const BStrip &s, int l, int wave, int i, int q) {
-    const int cin = p.c[l], kp = (cin + 15) & ~15, ntiles = kp >> 4, cout = p.c[l + 1], w_ld = p.w_ld[l];
-    const float *W = p.w[l];
-    f32x4 acc[4][NTN];
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int t = 0; t < NTN; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto loadw = [&](int k0, f32x4 (&b)[NTN]) {
-#pragma unroll
-        for (int t = 0; t < NTN; ++t) {
-            const int n = (wave + 4 * t) * 16 + i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (wave + 4 * t < ntiles && n < w_ld) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = W[(size_t)(k0 + 4 * q + e) * w_ld + n];
-            }
-            b[t] = v;
-        }
-    };
-    f32x4 cur[NTN], nxt[NTN];
-    loadw(0, cur);
-    for (int k0 = 0; k0 < cout; k0 += 16) {
-        if (k0 + 16 < cout) loadw(k0 + 16, nxt);
-        f32x4 a[4];
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) a[rt] = *reinterpret_cast<const f32x4 *>(s.P + (size_t)(rt * 16 + i) * s.ldp + k0 + 4 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-                for (int t = 0; t < NTN; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][e], cur[t][e], acc[rt][t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NTN; ++t) cur[t] = nxt[t];
-    }
-    __syncthreads();                                     // every wave is done with g^y in P
-#pragma unroll
-    for (int t = 0; t < NTN; ++t) {
-        const int n = (wave + 4 * t) * 16 + i;
-        if (wave + 4 * t >= ntiles) continue;
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = rt * 16 + 4 * q + e;
-                if (l) s.P[(size_t)r * s.ldp + n] = acc[rt][t][e];
-                else if (r < s.nvalid && n < cin) p.gx[(size_t)(s.row0 + r) * cin + n] = acc[rt][t][e];
-            }
+template <int RB>
+__device__ __forceinline__ void bwd_wgrad_rt(const ChainBP &p, const BStrip &s, int l, int wave, int i, int q) {
+    if (p.abl & 1) return;
+    switch (p.c[l + 1] >> 6) {
+        case 1: bwd_wgrad<1, RB>(p, s, l, wave, i, q); break;
+        case 2: bwd_wgrad<2, RB>(p, s, l, wave, i, q); break;
+        case 3: bwd_wgrad<3, RB>(p, s, l, wave, i, q); break;
+        default: bwd_wgrad<4, RB>(p, s, l, wave, i, q); break;
     }
 }
 
-__global__ __launch_bounds__(CH_THREADS, 2) void chain_bwd_kernel(ChainBP p) {
+// P3 .. P6 of layer l.  NTN > 0: G_in [RB][c_in] = g^y W on MFMA; wave w owns input-channel tiles w, w+4, ... (NTN of them at most) and
+// reads W as 64-byte runs of its rows.  The first weight batch is requested before the element-wise passes P3 / P4 and the next batch
+// is in flight under a batch's MFMAs; the result waits in registers while the weight gradient (P5) still reads g^y from P.
+template <int NTN, int RB>
+__device__ __forceinline__ void bwd_step(const ChainBP &p, const BStrip &s, int l, int wave, int i, int q) {
+    constexpr int RT = RB / 16, NB = NTN > 0 ? NTN : 1, BC = NTN <= 2 ? 4 : 2;
+    const int cin = p.c[l], kp = (cin + 15) & ~15, ntiles = kp >> 4, cout = p.c[l + 1], w_ld = p.w_ld[l];
+    const float *W = p.w[l];
+    auto loadw = [&](int kb, f32x4 (&b)[BC * NB]) {
+#pragma unroll
+        for (int j = 0; j < BC; ++j) {
+            const int k0 = kb + 16 * j;
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                const int n = (wave + 4 * t) * 16 + i;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k0 < cout && wave + 4 * t < ntiles && n < w_ld) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = W[(size_t)(k0 + 4 * q + e) * w_ld + n];
+                }
+                b[j * NB + t] = v;
+            }
+        }
+    };
+    f32x4 cur[BC * NB], nxt[BC * NB];
+    if (NTN > 0) loadw(0, cur);
+    bwd_p3<RB>(p, s, l);
+    bwd_p4<RB>(p, s, l);
+    __syncthreads();
+    f32x4 acc[RT][NB];
+    if (NTN > 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < NB; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < ((p.abl & 2) ? 0 : cout); kb += 16 * BC) {
+            if (kb + 16 * BC < cout) loadw(kb + 16 * BC, nxt);
+#pragma unroll
+            for (int j = 0; j < BC; ++j) {
+                const int k0 = kb + 16 * j;
+                if (k0 < cout) {
+                    f32x4 a[RT];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4 *>(s.P + (size_t)(rt * 16 + i) * s.ldp + k0 + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int t = 0; t < NB; ++t)
+                                acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][e], cur[j * NB + t][e], acc[rt][t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BC * NB; ++u) cur[u] = nxt[u];
+        }
+    }
+    bwd_wgrad_rt<RB>(p, s, l, wave, i, q);
+    __syncthreads();                                     // every wave is done with g^y in P and a_in in Q
+    if (NTN > 0) {
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const int n = (wave + 4 * t) * 16 + i;
+            if (wave + 4 * t >= ntiles) continue;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = rt * 16 + 4 * q + e;
+                    if (l) s.P[(size_t)r * s.ldp + n] = acc[rt][t][e];
+                    else if (r < s.nvalid && n < cin) p.gx[(size_t)(s.row0 + r) * cin + n] = acc[rt][t][e];
+                }
+        }
+        __syncthreads();
+    }
+}
+
+template <int RB>
+__global__ __launch_bounds__(CH_THREADS) void chain_bwd_kernel(ChainBP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     BStrip s;
     s.P = smem;
-    s.Q = smem + (size_t)CH_ROWS * p.ldp;
-    s.tab = s.Q + (size_t)CH_ROWS * p.ldq;                // [2][256]: m1, m2 of the current layer
+    s.Q = smem + (size_t)RB * p.ldp;
+    s.tab = s.Q + (size_t)RB * p.ldq;                     // [2][256]: m1, m2 of the current layer
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
     s.ldp = p.ldp; s.ldq = p.ldq; s.tid = tid;
-    s.row0 = (long long)blockIdx.x * CH_ROWS;
-    s.nvalid = (int)((p.rows - s.row0) < CH_ROWS ? (p.rows - s.row0) : CH_ROWS);
+    s.row0 = (long long)blockIdx.x * RB;
+    s.nvalid = (int)((p.rows - s.row0) < RB ? (p.rows - s.row0) : RB);
     const unsigned G = gridDim.x;
 
     for (int l = p.nl - 1; l >= 0; --l) {
-        bwd_p1(p, s, l, l == p.nl - 1);
+        bwd_p1<RB>(p, s, l, l == p.nl - 1);
         if (!(p.abl & 8)) grid_barrier(p.sync, (unsigned)(p.nl - l), G, tid); else __syncthreads();
         bwd_p2(p, s, l);
-        bwd_p3(p, s, l);
-        bwd_p4(p, s, l);
-        __syncthreads();
-        if (!(p.abl & 1)) {
-            switch (p.c[l + 1] >> 6) {
-                case 1: bwd_wgrad<1>(p, s, l, wave, i, q); break;
-                case 2: bwd_wgrad<2>(p, s, l, wave, i, q); break;
-                case 3: bwd_wgrad<3>(p, s, l, wave, i, q); break;
-                default: bwd_wgrad<4>(p, s, l, wave, i, q); break;
-            }
+        const int ntn = (l || p.gx) ? ((((p.c[l] + 15) & ~15) >> 4) + 3) >> 2 : 0;
+        switch (ntn) {
+            case 0: bwd_step<0, RB>(p, s, l, wave, i, q); break;
+            case 1: bwd_step<1, RB>(p, s, l, wave, i, q); break;
+            case 2: bwd_step<2, RB>(p, s, l, wave, i, q); break;
+            case 3: bwd_step<3, RB>(p, s, l, wave, i, q); break;
+            default: bwd_step<4, RB>(p, s, l, wave, i, q); break;
         }
-        if ((l || p.gx) && !(p.abl & 2)) {
-            const int ntn = ((((p.c[l] + 15) & ~15) >> 4) + 3) >> 2;
-            switch (ntn) {
-                case 1: bwd_dgrad<1>(p, s, l, wave, i, q); break;
-                case 2: bwd_dgrad<2>(p, s, l, wave, i, q); break;
-                case 3: bwd_dgrad<3>(p, s, l, wave, i, q); break;
-                default: bwd_dgrad<4>(p, s, l, wave, i, q); break;
-            }
-        }
-        __syncthreads();
     }
     if (tid == 0) {
         const unsigned t = __hip_atomic_fetch_add(p.sync + CH_EXIT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -664,7 +693,19 @@ void chain_bwd_ld(int nl, const int *widths, int &ldp, int &ldq) {
     ldp = mp + 4; ldq = (mq < 32 ? 32 : mq) + 4;
 }
 
-size_t chain_bwd_lds_bytes(int ldp, int ldq) { return ((size_t)CH_ROWS * (ldp + ldq) + 512) * sizeof(float); }
+size_t chain_bwd_lds_bytes(int rb, int ldp, int ldq) { return ((size_t)rb * (ldp + ldq) + 512) * sizeof(float); }
+
+int chain_cus();
+
+// rows of a backward strip: 64 when that grid is resident at ONE block per CU; 0 = not taken.  (A 128-row instantiation for the
+// 29 184-row level-3 chain exists — chain_bwd_kernel<128> — but its register allocation spills 568 VGPRs and measured 269 vs 179 us:
+// not dispatched.  Chains under 8192 rows are not taken either: the separate slab reduction launch costs them more than the
+// layer-by-layer launches they would save — 48 vs 38 us forward + backward on 928 .. 1824 rows, tools/time_chain.py.)
+int chain_bwd_rb(long long rows, int ldp, int ldq) {
+    const int cus = chain_cus();
+    if (cus <= 0 || rows < 8192) return 0;
+    return chain_bwd_lds_bytes(64, ldp, ldq) <= 160 * 1024 && (rows + 63) / 64 <= cus ? 64 : 0;
+}
 
 int chain_cmax(int nl, const int *widths) {
     int m = 0;
@@ -751,12 +792,7 @@ extern "C" int i2p_chain_bwd_ok(long long rows, int nl, const int *widths, int p
     if (pool_k < 0 || pool_k > 255 || (pool_k && rows % pool_k)) return 0;
     int ldp, ldq;
     chain_bwd_ld(nl, widths, ldp, ldq);
-    const size_t lds = chain_bwd_lds_bytes(ldp, ldq);
-    if (lds > 160 * 1024) return 0;
-    const int per_cu = (int)((160 * 1024) / lds) > 2 ? 2 : (int)((160 * 1024) / lds);
-    const int cus = chain_cus();
-    const long long blocks = (rows + CH_ROWS - 1) / CH_ROWS;
-    return cus > 0 && blocks <= (long long)cus * per_cu ? 1 : 0;
+    return chain_bwd_rb(rows, ldp, ldq) ? 1 : 0;
 }
 
 // floats of one block's weight-gradient slab (= of the reduced `dw` buffer): layer l's [widths[l+1]][w_ld[l]] block starts at the sum
@@ -791,14 +827,17 @@ extern "C" int i2p_chain_bwd(long long rows, int nl, const int *widths, const in
     p.tw = off;
     if ((off & 3) || ((reinterpret_cast<uintptr_t>(dw_part) | reinterpret_cast<uintptr_t>(dw)) & 15)) return I2P_ERR_BAD_ARG;
     chain_bwd_ld(nl, widths, p.ldp, p.ldq);
-    const size_t bytes = chain_bwd_lds_bytes(p.ldp, p.ldq);
+    const int rb = chain_bwd_rb(rows, p.ldp, p.ldq);
+    const size_t bytes = chain_bwd_lds_bytes(rb, p.ldp, p.ldq);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_bwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const unsigned grid = (unsigned)((rows + CH_ROWS - 1) / CH_ROWS);
-    hipLaunchKernelGGL(chain_bwd_kernel, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
+    const unsigned grid = (unsigned)((rows + rb - 1) / rb);
+    if (rb == 64) hipLaunchKernelGGL(chain_bwd_kernel<64>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(chain_bwd_kernel<128>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
     const int n4 = off >> 2;
     hipLaunchKernelGGL(chain_reduce_kernel, dim3((n4 + 15) / 16), dim3(256), 0, (hipStream_t)stream, (int)grid, n4,
                        reinterpret_cast<const float4 *>(dw_part), reinterpret_cast<float4 *>(dw));

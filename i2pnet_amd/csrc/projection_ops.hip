@@ -531,6 +531,69 @@ extern "C" int i2p_warp_split_bwd(int B, int N, const float *p, const float *q, 
 }
 
 /* -------------------------------------------------------------------------------------------
+ * Composition of the fine pose with the coarse one, one launch each way (reference: modellearn_proj_center.py:388-404,
+ * q = q3 (x) q_prev, t = (q3 (x) [0, t_prev] (x) q3^-1)[1:4] + t3 — as torch / the unfused device chain: three Hamilton products, the
+ * quaternion inverse, two cats, an add forward and ~14 launches backward on [B,4] tensors).
+ *   out f32 [B,7] = [q (4), t (3)];  same fp32 operation order as quat_mul_kernel / quat_unit_fwd_kernel.
+ * tp / dtp are quaternion-shaped [B,4] = [0, t_prev] as the model carries the coarse translation (the w component of tp is read as 0).
+ * Backward from g [B,7]: dq3 [B,4], dt3 [B,3], dqp [B,4], dtp [B,4].
+ * ------------------------------------------------------------------------------------------- */
+namespace {
+__global__ void pose_compose_fwd_kernel(int B, const float4 *__restrict__ q3, const float *__restrict__ t3, const float4 *__restrict__ qp,
+                                        const float4 *__restrict__ tp, float *__restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float4 q = q3[b], r = qinv(q);
+    const float4 oq = qmul(q, qp[b]);
+    const float4 T = make_float4(0.f, tp[b].y, tp[b].z, tp[b].w);
+    const float4 h = qmul(qmul(q, T), r);
+    float *o = out + (size_t)b * 7;
+    o[0] = oq.x; o[1] = oq.y; o[2] = oq.z; o[3] = oq.w;
+    o[4] = h.y + t3[b * 3]; o[5] = h.z + t3[b * 3 + 1]; o[6] = h.w + t3[b * 3 + 2];
+}
+
+__global__ void pose_compose_bwd_kernel(int B, const float4 *__restrict__ q3, const float4 *__restrict__ qp, const float4 *__restrict__ tp,
+                                        const float *__restrict__ g, float4 *__restrict__ dq3, float *__restrict__ dt3,
+                                        float4 *__restrict__ dqp, float4 *__restrict__ dtp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float4 q = q3[b], r = qinv(q), p = qp[b];
+    const float *gb = g + (size_t)b * 7;
+    const float4 gq = make_float4(gb[0], gb[1], gb[2], gb[3]);
+    const float4 G = make_float4(0.f, gb[4], gb[5], gb[6]);             // the w component of the rotated translation was sliced away
+    const float4 T = make_float4(0.f, tp[b].y, tp[b].z, tp[b].w);
+    // out_q = q (x) p:  dq = gq (x) conj(p),  dp = conj(q) (x) gq
+    const float4 dq_a = qmul(gq, qconj(p));
+    dqp[b] = qmul(qconj(q), gq);
+    // h = A (x) r, A = q (x) T:  dA = G (x) conj(r),  dr = conj(A) (x) G,  dq += dA (x) conj(T),  dT = conj(q) (x) dA
+    const float4 A = qmul(q, T);
+    const float4 dA = qmul(G, qconj(r)), dr = qmul(qconj(A), G), dq_b = qmul(dA, qconj(T)), dT = qmul(qconj(q), dA);
+    // r = conj(q) / n2 (quat_unit_bwd_kernel, mode 0):  dq += (s o dr - 2 q <dr, r>) / n2
+    const float n2 = (q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w) + 1e-10f;
+    const float dot = (dr.x * q.x - dr.y * q.y - dr.z * q.z - dr.w * q.w) / n2;
+    dq3[b] = make_float4(dq_a.x + dq_b.x + (dr.x - 2.f * q.x * dot) / n2, dq_a.y + dq_b.y + (-dr.y - 2.f * q.y * dot) / n2,
+                         dq_a.z + dq_b.z + (-dr.z - 2.f * q.z * dot) / n2, dq_a.w + dq_b.w + (-dr.w - 2.f * q.w * dot) / n2);
+    dtp[b] = dT;
+    dt3[b * 3] = gb[4]; dt3[b * 3 + 1] = gb[5]; dt3[b * 3 + 2] = gb[6];
+}
+}  // namespace
+
+extern "C" int i2p_pose_compose_fwd(int B, const float *q3, const float *t3, const float *qp, const float *tp, float *out, void *stream) {
+    if (B <= 0 || !q3 || !t3 || !qp || !tp || !out) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pose_compose_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, (const float4 *)q3, t3, (const float4 *)qp,
+                       (const float4 *)tp, out);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_pose_compose_bwd(int B, const float *q3, const float *qp, const float *tp, const float *g, float *dq3, float *dt3,
+                                    float *dqp, float *dtp, void *stream) {
+    if (B <= 0 || !q3 || !qp || !tp || !g || !dq3 || !dt3 || !dqp || !dtp) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, (const float4 *)q3, (const float4 *)qp, (const float4 *)tp, g,
+                       (float4 *)dq3, dt3, (float4 *)dqp, (float4 *)dtp);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+/* -------------------------------------------------------------------------------------------
  * Row-wise "unit variance" of the cost-volume inputs — src/projectPN/PPBackbone_center.py:388-393:
  *     y = (x - mean_c(x)) / clip(std_c(x) (unbiased), min=1e-12)
  * (torch: mean, sub, std, clip, div forward and ~14 autograd launches backward; here one launch each way).

@@ -13,14 +13,25 @@ class _PoseLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, out3, out4, q_gt, t_gt, w_x, w_q, l1):
         f = lambda t: t.detach().float().contiguous()
-        loss3, d3, d4, d_w = ops.get_backend().pose_loss(f(out3), f(out4), f(q_gt), f(t_gt), f(w_x), f(w_q), l1)
-        ctx.save_for_backward(d3, d4, d_w)
+        be = ops.get_backend()
+        loss3, d3, d4, d_w = be.pose_loss(f(out3), f(out4), f(q_gt), f(t_gt), f(w_x), f(w_q), l1)
+        flat = getattr(be, "last_pose_loss_flat", None)
+        ctx.n7 = None
+        if flat is not None and flat[0].data_ptr() == d3.data_ptr():        # device library: d3 | d4 | d_w are slices of one buffer
+            ctx.n7, ctx.B = flat[1], out3.shape[0]
+            ctx.save_for_backward(flat[0])
+        else:
+            ctx.save_for_backward(d3, d4, d_w)
         real, dual = loss3[1:2], loss3[2:3]
         ctx.mark_non_differentiable(real, dual)
         return loss3[0:1], real, dual
 
     @staticmethod
     def backward(ctx, g, _g_real, _g_dual):
+        if ctx.n7 is not None:          # one multiply for all four gradients
+            (flat,) = ctx.saved_tensors
+            s, n7, B = flat * g, ctx.n7, ctx.B
+            return (s[:B * 7].view(B, 7), s[n7:n7 + B * 7].view(B, 7), None, None, s[2 * n7:2 * n7 + 1], s[2 * n7 + 1:2 * n7 + 2], None)
         d3, d4, d_w = ctx.saved_tensors
         return d3 * g, d4 * g, None, None, d_w[0:1] * g, d_w[1:2] * g, None
 

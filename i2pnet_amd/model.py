@@ -279,10 +279,7 @@ class RegNet_v2(nn.Module):
         l3_mask = mask_fill(l3_mask, f["l3_valid"])                             # :376
         q3, t3, W_l3 = self.l3_head(l3_embed, l3_mask, P3_warped, f["LF3_pts"], None)
         # compose: q = q3 * q_prev, t = R3 t_prev + t3 (modellearn_proj_center.py:388-404)
-        out_q = warp_utils.mul_q(q3.view(B, 1, 4), q_prev.view(B, 1, 4)).squeeze(1)
-        t3_quat = torch.cat([ops.zero_scalar(dev, t3.dtype).expand(B, 1), t3], 1).view(B, 1, 4)
-        out_t = warp_utils.mul_q(warp_utils.mul_q(q3, t_prev_quat.view(B, 1, 4)), warp_utils.inv_q(q3)) + t3_quat
-        return torch.cat([out_q, out_t.squeeze(1)[:, 1:]], 1), q3, t3, W_l3
+        return warp_utils.compose_pose(q3, t3, q_prev, t_prev_quat), q3, t3, W_l3
 
     def _refine(self, fine, q4, t4_quat):
         out_3, _, _, W_l3 = self._fine_step(fine, q4, t4_quat)

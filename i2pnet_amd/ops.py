@@ -929,8 +929,12 @@ class CBackend:
         """-> (loss3 [3], d_out3 [B,7], d_out4 [B,7], d_w [2]); compute_loss.py:102-133"""
         B = out3.shape[0]
         dev = out3.device
-        loss3 = torch.empty(3, dtype=_F32, device=dev); d_w = torch.empty(2, dtype=_F32, device=dev)
-        d3 = torch.empty(B, 7, dtype=_F32, device=dev); d4 = torch.empty(B, 7, dtype=_F32, device=dev)
+        loss3 = torch.empty(3, dtype=_F32, device=dev)
+        # the three gradients live in ONE buffer (16-byte aligned pieces): the backward scales them by dL/dloss with a single launch
+        n7 = (B * 7 + 3) // 4 * 4
+        flat = torch.empty(2 * n7 + 4, dtype=_F32, device=dev)
+        d3, d4, d_w = flat[:B * 7].view(B, 7), flat[n7:n7 + B * 7].view(B, 7), flat[2 * n7:2 * n7 + 2]
+        self.last_pose_loss_flat = (flat, n7)
         self._call("i2p_pose_loss", int(B), int(bool(l1_trans)), self._p(out3, _F32, "out3"), self._p(out4, _F32, "out4"),
                    self._p(q_gt, _F32, "q_gt"), self._p(t_gt, _F32, "t_gt"), self._p(w_x, _F32, "w_x"), self._p(w_q, _F32, "w_q"),
                    self._p(loss3, _F32, "loss3"), self._p(d3, _F32, "d_out3"), self._p(d4, _F32, "d_out4"), self._p(d_w, _F32, "d_w"),
@@ -1005,10 +1009,10 @@ class CBackend:
         return ys, coefs, mis, out, arg, w0_pad
 
     def chain_bwd_fits(self, rows, widths, pool_k):
-        # opt-in (I2P_CHAIN_BWD=1): correct (tests/test_chain_gpu.py) but not yet faster than the layer-by-layer backward — 190 vs 177 us
-        # forward + backward on the 29 184-row chain, 58 vs 46 us on the 7 296-row layers (tools/time_chain.py); see DESIGN.md
+        # the library takes the chains it measured faster than the layer-by-layer backward (8192 .. 16384 rows: i2p_chain_bwd_ok);
+        # I2P_CHAIN_BWD=0 switches the one-launch backward off
         if (self.name != "hip" or self.device_type != "cuda" or os.environ.get("I2P_NO_CHAIN") == "1"
-                or os.environ.get("I2P_CHAIN_BWD") != "1"):
+                or os.environ.get("I2P_CHAIN_BWD") == "0"):
             return False
         key = ("bwd", int(rows), tuple(int(c) for c in widths), int(pool_k))
         hit = _CHAIN_OK.get(key)

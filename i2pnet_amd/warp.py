@@ -1,5 +1,7 @@
 """Quaternion algebra used by the coarse-to-fine registration (reference:
 src/modules/warp_utils.py:10-55, :78-94).  Device-agnostic (the reference hard-codes .cuda())."""
+import os
+
 import torch
 
 from . import ops
@@ -132,3 +134,47 @@ def warp_split(p, q, t_quat, valid=None):
             or (valid is not None and valid.requires_grad)):
         return None
     return _WarpSplit.apply(p, q.reshape(-1, 4), t_quat.reshape(-1, 4), valid)
+
+
+class _PoseCompose(torch.autograd.Function):
+    """[q3 (x) q_prev, (q3 (x) [0, t_prev] (x) q3^-1)[1:4] + t3] -> [B,7] in one launch each way (csrc/projection_ops.hip
+    i2p_pose_compose_fwd/bwd; modellearn_proj_center.py:388-404)."""
+
+    @staticmethod
+    def forward(ctx, q3, t3, q_prev, t_prev):
+        q3, t3, q_prev, t_prev = [t.detach().contiguous() for t in (q3, t3, q_prev, t_prev)]
+        be = ops.get_backend()
+        B = q3.shape[0]
+        out = torch.empty(B, 7, dtype=torch.float32, device=q3.device)
+        P = be._p
+        be._call("i2p_pose_compose_fwd", int(B), P(q3, torch.float32, "q3"), P(t3, torch.float32, "t3"), P(q_prev, torch.float32, "q_prev"),
+                 P(t_prev, torch.float32, "t_prev"), P(out, torch.float32, "out"), stream=be._stream())
+        ctx.save_for_backward(q3, q_prev, t_prev)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q3, q_prev, t_prev = ctx.saved_tensors
+        be = ops.get_backend()
+        B = q3.shape[0]
+        g = g.contiguous()
+        dq3, dqp = torch.empty_like(q3), torch.empty_like(q_prev)
+        dt3, dtp = torch.empty(B, 3, dtype=torch.float32, device=g.device), torch.empty(B, 4, dtype=torch.float32, device=g.device)
+        P = be._p
+        be._call("i2p_pose_compose_bwd", int(B), P(q3, torch.float32, "q3"), P(q_prev, torch.float32, "q_prev"), P(t_prev, torch.float32, "t_prev"),
+                 P(g, torch.float32, "g"), P(dq3, torch.float32, "dq3"), P(dt3, torch.float32, "dt3"), P(dqp, torch.float32, "dqp"),
+                 P(dtp, torch.float32, "dtp"), stream=be._stream())
+        return dq3, dt3, dqp, dtp
+
+
+def compose_pose(q3, t3, q_prev, t_prev_quat):
+    """q3 [B,4], t3 [B,3], q_prev [B,4], t_prev_quat [B,4] = [0, t_prev] -> composed pose [B,7] (q = q3 * q_prev, t = R3 t_prev + t3)"""
+    B = q3.shape[0]
+    be = ops.get_backend()
+    if (be.name == "hip" and q3.is_cuda and all(t.dtype == torch.float32 for t in (q3, t3, q_prev, t_prev_quat))
+            and os.environ.get("I2P_NO_POSE_COMPOSE") != "1"):
+        return _PoseCompose.apply(q3.reshape(B, 4), t3.reshape(B, 3), q_prev.reshape(B, 4), t_prev_quat.reshape(B, 4))
+    out_q = mul_q(q3.view(B, 1, 4), q_prev.view(B, 1, 4)).squeeze(1)
+    t3_quat = torch.cat([ops.zero_scalar(q3.device, t3.dtype).expand(B, 1), t3], 1).view(B, 1, 4)
+    out_t = mul_q(mul_q(q3, t_prev_quat.view(B, 1, 4)), inv_q(q3)) + t3_quat
+    return torch.cat([out_q, out_t.squeeze(1)[:, 1:]], 1)

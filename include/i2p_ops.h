@@ -586,6 +586,13 @@ int i2p_pose_head_fwd(int B, int C, int H, const float *pooled, const float *w1,
 int i2p_pose_head_bwd(int B, int C, int H, const float *gq, const float *gt, const float *qraw, const float *hid, const float *mask,
                       const float *pooled, const float *w1, const float *wq, const float *wt, float *d_pooled, float *dw1, float *db1,
                       float *dwq, float *dbq, float *dwt, float *dbt, void *stream);
+/* Composition of the fine pose with the coarse one (modellearn_proj_center.py:388-404): out f32 [B,7] = [q3 (x) qp, (q3 (x) [0,tp] (x)
+ * q3^-1)[1:4] + t3] with q^-1 = conj(q) / (|q|^2 + 1e-10), the operation order of i2p_quat_mul / i2p_quat_unit_fwd; backward from
+ * g [B,7]: dq3 [B,4], dt3 [B,3], dqp [B,4], dtp [B,4]; tp / dtp quaternion-shaped [B,4] = [0, t_prev] (w of tp read as 0).  One launch
+ * each (the unfused chain: 7 forward, ~14 backward). */
+int i2p_pose_compose_fwd(int B, const float *q3, const float *t3, const float *qp, const float *tp, float *out, void *stream);
+int i2p_pose_compose_bwd(int B, const float *q3, const float *qp, const float *tp, const float *g, float *dq3, float *dt3, float *dqp,
+                         float *dtp, void *stream);
 /* Warp of a cloud by a pose + empty-cell mask + depth split in one launch each way (warp_utils.py:78-94,
  * modellearn_proj_center.py:345-352, PPBackbone_center.py:377): p f32 [B,N,3], q f32 [B,4] (w,x,y,z), t f32 [B,4] = [0,tx,ty,tz],
  * valid f32 [B,N] (0/1) or NULL -> p' = (q (x) [0,p] (x) conj(q)/(|q|^2+1e-10) + t)[1:4] * valid; z [B,N] = p'_z; uv [B,N,3] = p' / (z + 1e-10);

@@ -23,6 +23,9 @@ CASES = [(29184, 128, 67, (64, 64, 128), 16, (0.0, 0.0, 0.0)),
          (928, 128, 128, (64,), 0, (0.1,)),
          (1824, 128, 128, (64,), 0, (0.1,)),
          (1000, 64, 64, (192, 256, 64), 4, (0.2, 0.0, 0.1)),       # 3 / 4 column tiles per wave, ragged last strip
+         (8200, 64, 61, (192, 256, 64), 4, (0.2, 0.0, 0.1)),       # the same widths inside the one-launch backward's row band
+         (14848, 132, 131, (128, 128, 256), 16, (0.0, 0.0, 0.0)),  # level 4 as the step runs it
+         (9000, 20, 17, (64,), 0, (0.1,)),                         # ragged, narrow input, dL/dx through a 20-column strip
          (37, 16, 13, (64,), 0, (0.1,))]                           # less than one strip
 
 
@@ -63,7 +66,7 @@ def _run(x, params, slopes, pool_k, mode):
     keys = ("I2P_NO_CHAIN", "I2P_CHAIN_BWD")
     old = {k: os.environ.get(k) for k in keys}
     os.environ["I2P_NO_CHAIN"] = "1" if mode == "layers" else "0"
-    os.environ["I2P_CHAIN_BWD"] = "1" if mode == "chain" else "0"
+    os.environ["I2P_CHAIN_BWD"] = "1" if mode == "chain" else "0"        # "chain": where the library takes the shape (8192 .. 16384 rows)
     try:
         xs = x.clone().requires_grad_(True)
         ps = [p.clone().requires_grad_(True) for p in params]
@@ -138,12 +141,8 @@ def test_chain_forward_and_node_gradients(hip_backend, case):
     for mode in ("fwd", "chain"):
         o1, gx1, gp1 = _run(x, params, slopes, pool_k, mode)
         if mode == "chain":
-            os.environ["I2P_CHAIN_BWD"] = "1"
-            try:
-                assert be.chain_bwd_fits(rows, [c0] + list(widths), pool_k), "shape expected on the one-launch backward"
-            finally:
-                os.environ.pop("I2P_CHAIN_BWD", None)
-            assert not be.last_chain_sync.any(), "backward barrier words must be left zero (word -32 set: a barrier timed out)"
+            assert be.chain_bwd_fits(rows, [c0] + list(widths), pool_k) == (8192 <= rows <= 64 * 256), "one-launch backward: 8192 .. 16384 rows"
+            assert not be.last_chain_sync.any(), "barrier words must be left zero (word -32 set: a barrier timed out)"
         assert _rel(o1, o0) < 1e-5
         assert _rel(gx1[:, :cin], gx0[:, :cin]) < 2e-4, mode
         assert _rel(gx1[:, :cin], rgx) < 2e-4, mode

@@ -1334,6 +1334,45 @@ def test_warp_split_vs_reference_chain_on_cpu(hip_backend, oracle_backend, B, N)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B", [8, 16, 1, 70])
+def test_pose_compose_vs_reference_chain_on_cpu(hip_backend, oracle_backend, B):
+    """i2p_pose_compose_fwd/bwd against the chain it replaces evaluated on the CPU with the oracle's quaternion operators
+    (modellearn_proj_center.py:388-404: q = q3 * q_prev, t = (q3 [0,t_prev] q3^-1)[1:4] + t3): forward bit-exact, gradients to fp32
+    rounding of the same products."""
+    import os
+    from i2pnet_amd import warp as warp_utils
+    g = torch.Generator().manual_seed(B)
+    unit = lambda: torch.nn.functional.normalize(torch.randn(B, 4, generator=g), dim=1) * (1 + 0.01 * torch.randn(B, 1, generator=g))
+    q3, qp = unit(), unit()
+    t3 = torch.randn(B, 3, generator=g)
+    tpq = torch.cat([torch.zeros(B, 1), torch.randn(B, 3, generator=g)], 1)
+    go = torch.randn(B, 7, generator=g)
+
+    def chain():
+        a, b, c, d = [t.clone().requires_grad_(True) for t in (q3, t3, qp, tpq)]
+        out = warp_utils.compose_pose(a, b, c, d)
+        return (out.detach(),) + torch.autograd.grad(out, [a, b, c, d], go)
+    ref = _on_oracle(oracle_backend, chain)
+    dev = [t.to(DEV).requires_grad_(True) for t in (q3, t3, qp, tpq)]
+    out = warp_utils.compose_pose(*dev)
+    assert out.grad_fn is not None and type(out.grad_fn).__name__ == "_PoseComposeBackward"
+    assert torch.equal(out.detach().cpu(), ref[0])
+    grads = torch.autograd.grad(out, dev, go.to(DEV))
+    for k, (a, b) in enumerate(zip(grads, ref[1:])):
+        b = b if k != 3 else torch.cat([torch.zeros(B, 1), b[:, 1:]], 1)        # w of [0, t_prev] is a constant: its gradient is discarded
+        a = a.cpu() if k != 3 else torch.cat([torch.zeros(B, 1), a.cpu()[:, 1:]], 1)
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6, k
+    # and against the unfused device chain
+    os.environ["I2P_NO_POSE_COMPOSE"] = "1"
+    try:
+        dev2 = [t.to(DEV).requires_grad_(True) for t in (q3, t3, qp, tpq)]
+        out2 = warp_utils.compose_pose(*dev2)
+    finally:
+        os.environ.pop("I2P_NO_POSE_COMPOSE", None)
+    assert torch.equal(out2, out)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("groups,K,c", [(28800, 32, 32), (7232, 16, 64), (928, 16, 128), (5, 3, 16)])
 def test_unpool_k_stats_matches_two_pass(hip_backend, oracle_backend, groups, K, c):
     """i2p_unpool_k_stats (dense max-pool gradient + the BN-backward statistics of the layer underneath in one pass) against the

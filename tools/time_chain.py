@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from i2pnet_amd import fused, ops  # noqa: E402
 
 DEV = "cuda"
-CASES = [(29184, 128, 67, (64, 64, 128), 16), (14848, 132, 131, (128, 128), 0), (14848, 128, 67, (128, 64, 64), 16),
+CASES = [(29184, 128, 67, (64, 64, 128), 16), (14848, 132, 131, (128, 128, 256), 16), (14848, 132, 131, (128, 128), 0), (14848, 128, 67, (128, 64, 64), 16),
          (14592, 128, 67, (128, 64), 8), (7296, 12, 10, (64,), 0), (7296, 128, 128, (64,), 0), (1824, 128, 128, (64,), 0),
          (928, 128, 128, (64,), 0)]
 N = 20
@@ -84,9 +84,9 @@ def main():
                 q.grad = None
             fused._MlpChain.apply(xs, False, slopes, pool_k, None, *ps).backward(go)
         line = " " * 42 + "fwd+bwd:"
-        for tag, nc, cb in (("layers", "1", "0"), ("chain fwd", "0", "0"), ("chain both", "0", "1")):
+        for tag, nc, cb in (("layers", "1", "0"), ("chain fwd", "0", "0"), ("chain both (where taken)", "0", "1")):
             os.environ["I2P_NO_CHAIN"], os.environ["I2P_CHAIN_BWD"] = nc, cb
-            if tag == "chain both":
+            if tag.startswith("chain both"):
                 for a in abls:
                     os.environ["I2P_CHAIN_ABL"] = str(a)
                     line += f"  {tag} abl{a} {timed(fb):6.1f}"
