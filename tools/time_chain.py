@@ -57,7 +57,9 @@ def timed(fn):
 def main():
     abls = [int(a) for a in sys.argv[1:]] or [0]
     be = ops.hip_backend()
-    for rows, c0, cin, widths, pool_k in CASES:
+    pick = os.environ.get("TIME_CHAIN_CASES")          # comma-separated case indices (PMC passes: tools/pmc_chain.sh)
+    cases = [CASES[int(i)] for i in pick.split(",")] if pick else CASES
+    for rows, c0, cin, widths, pool_k in cases:
         x, params = make(rows, c0, cin, widths)
         slopes = (1.0,) + (0.1,) * len(widths)
         line = f"{rows:6d} x {c0:3d} -> {'-'.join(map(str, widths)):>10s} k{pool_k:<2d}"
