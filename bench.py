@@ -708,6 +708,11 @@ def _run_workload(config, args, rank, local_rank, world, device):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         assert torch.isfinite(loss).all()
+        from i2pnet_amd import ops as _ops
+        if _ops.chain_errors():                 # a grid barrier of the one-launch MLP chains timed out: the steps computed garbage
+            print("bench.py: chain-kernel grid barrier timed out (%d) — the grid was not resident; I2P_NO_CHAIN=1 runs the layer kernels" %
+                  _ops.chain_errors(), file=sys.stderr, flush=True)
+            sys.exit(4)
         out = {"dt": dt, "loss": float(loss), "graph_live": graph_live}
         del tr, batch
         import gc

@@ -119,6 +119,7 @@ HELPERS = {
     "i2p_chain_bwd_ok": ["l", "i", "p", "i"],
     "i2p_chain_bwd_slab": ["i", "p", "p"],                          # returns long long (floats)
     "i2p_chain_sums_len": ["i", "i"],                               # returns long long (doubles)
+    "i2p_chain_set_error_counter": ["p"],
     "i2p_chain_sync_words": [],                                     # returns long long (uint32 words)
 }
 LONG_HELPERS = {"i2p_pair_lin_bwd_scratch", "i2p_pair_bias_bn_bwd_scratch", "i2p_gather_rows_grad_fx_scratch", "i2p_gemm_tn_scratch", "i2p_chain_sums_len", "i2p_chain_sync_words", "i2p_chain_bwd_slab"}

@@ -42,6 +42,7 @@ struct ChainP {
     unsigned char *arg;
     float *w0_pad;                    // optional [c[1]][c[0]]: W_0 with zero columns (what the backward kernels take)
     unsigned *sync;                   // i2p_chain_sync_words() words, zero on entry and (but for the error word) on exit
+    unsigned *sticky;                 // process-wide count of timed-out barriers (i2p_chain_set_error_counter) or nullptr
     int lda;
     int abl;                          // diagnostic ablation bits (I2P_CHAIN_ABL; tools/time_chain.py): 0 in production
 };
@@ -56,7 +57,7 @@ __device__ __forceinline__ float act(float z, float slope) { return z > 0.f ? z 
 constexpr int CH_NG = 8, CH_LINE = 32, CH_TOP = CH_NG * CH_LINE, CH_FLAG = (CH_NG + 1) * CH_LINE, CH_EXIT = (2 * CH_NG + 1) * CH_LINE,
               CH_ERR = (2 * CH_NG + 2) * CH_LINE, CH_SYNC_WORDS = (2 * CH_NG + 3) * CH_LINE;
 
-__device__ __forceinline__ void grid_barrier(unsigned *sync, unsigned k, unsigned G, int tid) {
+__device__ __forceinline__ void grid_barrier(unsigned *sync, unsigned k, unsigned G, int tid, unsigned *sticky) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's statistics atomics are acknowledged (performed at L2 / memory side)
     __syncthreads();
     if (tid == 0) {
@@ -72,6 +73,7 @@ __device__ __forceinline__ void grid_barrier(unsigned *sync, unsigned k, unsigne
             __builtin_amdgcn_s_sleep(2);
             if (++polls > (1u << 19)) {                  // ~ a second: the grid was not co-resident; give up loudly instead of hanging
                 __hip_atomic_store(sync + CH_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sticky) __hip_atomic_fetch_add(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_fwd_kernel(ChainP p) {
                 atomicAdd(sums + p.smax + tid, s2);
             }
         }
-        if (!(p.abl & 8)) grid_barrier(p.sync, (unsigned)(l + 1), G, tid);
+        if (!(p.abl & 8)) grid_barrier(p.sync, (unsigned)(l + 1), G, tid, p.sticky);
         double *sl = p.sums + (size_t)l * CH_REP * 2 * p.smax;
         if (tid < cout) {
             const int c = tid;
@@ -339,7 +341,7 @@ struct ChainBP {
     float *dgamma[CH_MAXL], *dbeta[CH_MAXL];
     double *sums;                     // [nl][CH_REP][2 * smax], zero on entry
     int smax;
-    unsigned *sync;
+    unsigned *sync, *sticky;
     int ldp, ldq;
     int abl;
 };
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_bwd_kernel(ChainBP p) {
 
     for (int l = p.nl - 1; l >= 0; --l) {
         bwd_p1<RB>(p, s, l, l == p.nl - 1);
-        if (!(p.abl & 8)) grid_barrier(p.sync, (unsigned)(p.nl - l), G, tid); else __syncthreads();
+        if (!(p.abl & 8)) grid_barrier(p.sync, (unsigned)(p.nl - l), G, tid, p.sticky); else __syncthreads();
         bwd_p2(p, s, l);
         const int ntn = (l || p.gx) ? ((((p.c[l] + 15) & ~15) >> 4) + 3) >> 2 : 0;
         switch (ntn) {
@@ -707,6 +709,8 @@ int chain_bwd_rb(long long rows, int ldp, int ldq) {
     return chain_bwd_lds_bytes(64, ldp, ldq) <= 160 * 1024 && (rows + 63) / 64 <= cus ? 64 : 0;
 }
 
+unsigned *g_chain_sticky = nullptr;
+
 int chain_cmax(int nl, const int *widths) {
     int m = 0;
     for (int l = 0; l <= nl; ++l) m = widths[l] > m ? widths[l] : m;
@@ -735,6 +739,10 @@ int chain_cus() {
 extern "C" long long i2p_chain_sums_len(int nl, int cmax_out) { return (long long)nl * CH_REP * 2 * cmax_out; }
 
 // widths[0] = row length of x, widths[1..nl] = output widths
+// A device word the chain kernels add 1 to whenever a grid barrier times out (results of that launch are invalid): the host checks it
+// where it synchronises anyway (end of a benchmark, tests) — the per-launch error word lives in arena scratch that the next step clears.
+extern "C" int i2p_chain_set_error_counter(unsigned *device_word) { g_chain_sticky = device_word; return 0; }
+
 // uint32 words of zeroed scratch behind `sync`; word i2p_chain_sync_words() - 32 is the error word
 extern "C" long long i2p_chain_sync_words(void) { return CH_SYNC_WORDS; }
 
@@ -760,7 +768,7 @@ extern "C" int i2p_chain_fwd(long long rows, int nl, const int *widths, const in
         return I2P_ERR_BAD_ARG;
     ChainP p{};
     p.rows = rows; p.nl = nl; p.x = x; p.eps = eps; p.sums = sums; p.pool_k = pool_k; p.out = out; p.arg = arg; p.w0_pad = w0_pad;
-    p.sync = sync;
+    p.sync = sync; p.sticky = g_chain_sticky;
     { const char *e = getenv("I2P_CHAIN_ABL"); p.abl = e ? atoi(e) : 0; }     /* read per call: tools/time_chain.py switches it */
     p.c[0] = widths[0];
     for (int l = 0; l < nl; ++l) {
@@ -812,7 +820,7 @@ extern "C" int i2p_chain_bwd(long long rows, int nl, const int *widths, const in
         (pool_k && !arg))
         return I2P_ERR_BAD_ARG;
     ChainBP p{};
-    p.rows = rows; p.nl = nl; p.x = x; p.g = g; p.arg = arg; p.pool_k = pool_k; p.gx = gx; p.dw_part = dw_part; p.sums = sums; p.sync = sync;
+    p.rows = rows; p.nl = nl; p.x = x; p.g = g; p.arg = arg; p.pool_k = pool_k; p.gx = gx; p.dw_part = dw_part; p.sums = sums; p.sync = sync; p.sticky = g_chain_sticky;
     { const char *e = getenv("I2P_CHAIN_ABL"); p.abl = e ? atoi(e) : 0; }
     p.c[0] = widths[0];
     int off = 0;

@@ -95,6 +95,23 @@ class _ZeroArena:
 _arena = _ZeroArena()
 _ZERO = {}
 _CHAIN_OK = {}        # (rows, widths, pool_k) -> does i2p_chain_fwd take it on this device
+_CHAIN_ERR = {}       # device -> persistent int32 [1]: grid barriers of the chain kernels that timed out (must stay 0)
+
+
+def x_dev_key(be):
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _register_chain_counter(be):
+    dev = x_dev_key(be)
+    t = torch.zeros(1, dtype=torch.int32, device=dev)
+    _CHAIN_ERR[dev] = t
+    _lib.helper("i2p_chain_set_error_counter", C.c_void_p(t.data_ptr()))
+
+
+def chain_errors(device=None):
+    """number of chain-kernel grid barriers that timed out in this process (synchronises); a non-zero count means results were invalid"""
+    return sum(int(t.item()) for d, t in _CHAIN_ERR.items() if device is None or d == torch.device(device))
 
 
 def zero_scalar(device, dtype=torch.float32):
@@ -965,6 +982,8 @@ class CBackend:
         if self.name != "hip" or self.device_type != "cuda" or os.environ.get("I2P_NO_CHAIN") == "1":
             return False
         key = (int(rows), tuple(int(c) for c in widths), int(pool_k))
+        if x_dev_key(self) not in _CHAIN_ERR:
+            _register_chain_counter(self)
         hit = _CHAIN_OK.get(key)
         if hit is None:
             arr = (C.c_int * len(widths))(*key[1])

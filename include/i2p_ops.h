@@ -470,6 +470,9 @@ int i2p_pair_lin_fwd_fin(int B, int N, int M, int cin, int cout, const float *f,
 int i2p_chain_fwd_ok(long long rows, int nl, const int *widths, int pool_k);
 long long i2p_chain_sums_len(int nl, int cmax_out);
 long long i2p_chain_sync_words(void);
+/* registers ONE device uint32 (zeroed by the caller, kept alive) that every chain launch of this process increments when one of its grid
+ * barriers times out; NULL unregisters */
+int i2p_chain_set_error_counter(unsigned *device_word);
 int i2p_chain_fwd(long long rows, int nl, const int *widths, const int *w_ld, const float *x, const float *const *w,
                   const float *const *gamma, const float *const *beta, const float *slopes, float eps, float *const *y,
                   float *const *coef, float *const *mean_invstd, double *sums, int pool_k, float *out, unsigned char *arg,
