@@ -98,12 +98,13 @@ _CHAIN_OK = {}        # (rows, widths, pool_k) -> does i2p_chain_fwd take it on 
 _CHAIN_ERR = {}       # device -> persistent int32 [1]: grid barriers of the chain kernels that timed out (must stay 0)
 
 
-def x_dev_key(be):
+def _cur_dev():
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def _register_chain_counter(be):
-    dev = x_dev_key(be)
+def _register_chain_counter():
+    """one persistent device word per process / GPU that the chain kernels bump when a grid barrier times out (i2p_chain_set_error_counter)"""
+    dev = _cur_dev()
     t = torch.zeros(1, dtype=torch.int32, device=dev)
     _CHAIN_ERR[dev] = t
     _lib.helper("i2p_chain_set_error_counter", C.c_void_p(t.data_ptr()))
@@ -982,8 +983,8 @@ class CBackend:
         if self.name != "hip" or self.device_type != "cuda" or os.environ.get("I2P_NO_CHAIN") == "1":
             return False
         key = (int(rows), tuple(int(c) for c in widths), int(pool_k))
-        if x_dev_key(self) not in _CHAIN_ERR:
-            _register_chain_counter(self)
+        if _cur_dev() not in _CHAIN_ERR:
+            _register_chain_counter()
         hit = _CHAIN_OK.get(key)
         if hit is None:
             arr = (C.c_int * len(widths))(*key[1])
