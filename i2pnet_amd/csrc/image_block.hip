@@ -19,8 +19,28 @@ constexpr int MAX_STAT_BLOCKS = 1024;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// exact unsigned 32-bit division by a run-time constant without the ~25-instruction software divide (round-up multiplier, Granlund &
+// Montgomery; the branch-free form of libdivide): q = mulhi(m, n); result = (((n - q) >> 1) + q) >> (L - 1), L = ceil(log2 d)
+struct FastDiv { unsigned d, m, sh; };
+inline FastDiv fast_div(unsigned d) {
+    FastDiv f; f.d = d; f.m = 0; f.sh = 0;
+    if (d > 1) {
+        unsigned L = 0;
+        while ((1ull << L) < d) ++L;
+        f.m = (unsigned)((((1ull << 32) * ((1ull << L) - d)) / d) + 1);
+        f.sh = L - 1;
+    }
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv &f) {
+    if (f.d == 1) return n;
+    const unsigned q = __umulhi(f.m, n);
+    return (((n - q) >> 1) + q) >> f.sh;
+}
+
 struct PoolGeom {
     int B, H, W, C, s, Ho, Wo, cv, cvs;      // cvs = log2(cv) (cv divides THREADS, so it is a power of two)
+    FastDiv fH, fW, fHo, fWo;
 };
 
 // flat float4 index -> (b, row, col): 32-bit divisions unless the tensor has 2^31 float4 or more (a 64-bit
@@ -29,12 +49,20 @@ struct PoolGeom {
 template <bool WIDE> struct Idx { using type = unsigned; };
 template <> struct Idx<true> { using type = unsigned long long; };
 template <bool WIDE>
-__device__ __forceinline__ void decode(typename Idx<WIDE>::type t, int cvs, int rows, int cols, int &b, int &r, int &c) {
+__device__ __forceinline__ void decode(typename Idx<WIDE>::type t, int cvs, const FastDiv &rows, const FastDiv &cols, int &b, int &r, int &c) {
     typename Idx<WIDE>::type q = t >> cvs;
-    const typename Idx<WIDE>::type q2 = q / (unsigned)cols;
-    c = (int)(q - q2 * (unsigned)cols);
-    b = (int)(q2 / (unsigned)rows);
-    r = (int)(q2 - (typename Idx<WIDE>::type)b * (unsigned)rows);
+    if constexpr (WIDE) {
+        const unsigned long long q2 = q / cols.d;
+        c = (int)(q - q2 * cols.d);
+        b = (int)(q2 / rows.d);
+        r = (int)(q2 - (unsigned long long)b * rows.d);
+    } else {     // two multiply-high divisions (the software 32-bit divide: ~25 VALU instructions each, in kernels that are VALU-bound)
+        const unsigned q2 = fdiv(q, cols);
+        c = (int)(q - q2 * cols.d);
+        const unsigned bb = fdiv(q2, rows);
+        b = (int)bb;
+        r = (int)(q2 - bb * rows.d);
+    }
 }
 
 __device__ __forceinline__ double rep_sum(const double *sums, int c, int idx) {
@@ -166,7 +194,7 @@ __global__ __launch_bounds__(THREADS) void img_pool_fwd_kernel(PoolGeom g, const
     const Coef4 k = load_coef(mean_invstd, gamma, beta, g.C, vcol);
     for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, ho, wo;
-        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.Ho, g.Wo, b, ho, wo);
+        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.fHo, g.fWo, b, ho, wo);
         float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         unsigned char bi[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -211,7 +239,7 @@ __global__ __launch_bounds__(THREADS) void img_bwd_stats_kernel(PoolGeom g, cons
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, ho, wo;
-        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.Ho, g.Wo, b, ho, wo);
+        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.fHo, g.fWo, b, ho, wo);
         const float4 go = gout[t];
         const uchar4 a = arg[t];
         const float gv[4] = {go.x, go.y, go.z, go.w};
@@ -284,11 +312,13 @@ __global__ __launch_bounds__(THREADS) void img_bwd_dx_kernel(PoolGeom g, const f
     for (int i = 0; i < 4; ++i) { mg[i] = dbeta[vcol * 4 + i] / n; mgx[i] = dgamma[vcol * 4 + i] / n; }
     for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, h, w;
-        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.H, g.W, b, h, w);
+        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.fH, g.fW, b, h, w);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         // outputs ho with ho*s-1 <= h <= ho*s+1
-        const int ho0 = max(0, (h - 1 + g.s - 1) / g.s), ho1 = min(g.Ho - 1, (h + 1) / g.s);
-        const int wo0 = max(0, (w - 1 + g.s - 1) / g.s), wo1 = min(g.Wo - 1, (w + 1) / g.s);
+        // stride 1 or 2 (geom_ok): the four signed divisions by it are shifts (s = 1: the numerator may be -1 and stays -1; s = 2: it is >= 0)
+        const int ssh = g.s - 1;
+        const int ho0 = max(0, (h - 1 + g.s - 1) >> ssh), ho1 = min(g.Ho - 1, (h + 1) >> ssh);
+        const int wo0 = max(0, (w - 1 + g.s - 1) >> ssh), wo1 = min(g.Wo - 1, (w + 1) >> ssh);
         for (int ho = ho0; ho <= ho1; ++ho)
             for (int wo = wo0; wo <= wo1; ++wo) {
                 const unsigned char p = (unsigned char)((h - (ho * g.s - 1)) * 3 + (w - (wo * g.s - 1)));
@@ -504,7 +534,7 @@ __global__ __launch_bounds__(THREADS) void img_pool_fwd2_kernel(PoolGeom g, cons
     const long long total = (long long)g.B * g.Ho * g.Wo * g.cv;
     for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, ho, wo;
-        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.Ho, g.Wo, b, ho, wo);
+        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.fHo, g.fWo, b, ho, wo);
         float best[N];
         unsigned bi[N];
 #pragma unroll
@@ -551,7 +581,7 @@ __global__ __launch_bounds__(THREADS) void img_bwd_stats2_kernel(PoolGeom g, con
     for (int i = 0; i < N; ++i) { s[i] = 0.0; q[i] = 0.0; }
     for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, ho, wo;
-        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.Ho, g.Wo, b, ho, wo);
+        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.fHo, g.fWo, b, ho, wo);
         float gv[N];
         ldv<OBF, N>(gout, t, gv);
         const ArgW<N> a = ld_arg<N>(arg, t);
@@ -602,15 +632,17 @@ __global__ __launch_bounds__(THREADS) void img_bwd_dx2_kernel(PoolGeom g, const 
     for (int i = 0; i < N; ++i) { mg[i] = (float)stat[vcol * N + i] / n; mgx[i] = (float)stat[g.C + vcol * N + i] / n; }
     for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, h, w;
-        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.H, g.W, b, h, w);
+        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.fH, g.fW, b, h, w);
         float acc[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) acc[i] = 0.f;
         // (a version that requested the arg-max words of all 9 candidate outputs in one batch and their gradients in a second one
         //  measured 1.7x SLOWER: these kernels are bound by VALU work per element — index math, byte compares, unpacking — not by
         //  the latency of the dependent loads)
-        const int ho0 = max(0, (h - 1 + g.s - 1) / g.s), ho1 = min(g.Ho - 1, (h + 1) / g.s);
-        const int wo0 = max(0, (w - 1 + g.s - 1) / g.s), wo1 = min(g.Wo - 1, (w + 1) / g.s);
+        // stride 1 or 2 (geom_ok): the four signed divisions by it are shifts (s = 1: the numerator may be -1 and stays -1; s = 2: it is >= 0)
+        const int ssh = g.s - 1;
+        const int ho0 = max(0, (h - 1 + g.s - 1) >> ssh), ho1 = min(g.Ho - 1, (h + 1) >> ssh);
+        const int wo0 = max(0, (w - 1 + g.s - 1) >> ssh), wo1 = min(g.Wo - 1, (w + 1) >> ssh);
         for (int ho = ho0; ho <= ho1; ++ho)
             for (int wo = wo0; wo <= wo1; ++wo) {
                 const unsigned p = (unsigned)((h - (ho * g.s - 1)) * 3 + (w - (wo * g.s - 1)));
@@ -648,6 +680,7 @@ PoolGeom make_geom(int B, int H, int W, int C, int s) {
     g.cvs = 0;
     while ((1 << g.cvs) < g.cv) ++g.cvs;
     g.Ho = (H - 1) / s + 1; g.Wo = (W - 1) / s + 1;        // floor((H + 2*1 - 3)/s) + 1
+    g.fH = fast_div((unsigned)H); g.fW = fast_div((unsigned)W); g.fHo = fast_div((unsigned)g.Ho); g.fWo = fast_div((unsigned)g.Wo);
     return g;
 }
 
