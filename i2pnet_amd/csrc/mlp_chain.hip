@@ -9,15 +9,22 @@
 // every block's 64-row strip of activations in LDS through the whole chain:
 //
 //   per layer:  y = a W^T on v_mfma_f32_16x16x4_f32 (A operand from the LDS strip, W straight from L2: each wave owns a
-//               quarter of the output columns for all 64 rows, so a block reads W exactly once) -> strip of y back into LDS
-//               -> fp64 column sums {sum y, sum y^2} of the strip, one atomic per block and column on an 8-way replica
-//               -> y written to HBM once (saved for the backward, never re-read here) -> GRID BARRIER
-//               -> every block forms mean / scale / beta from the replica sums -> BN + activation in place in LDS.
+//               quarter of the output columns for all 64 rows, so a block reads W exactly once; the first weight batch is requested
+//               before the input phase, the next one is in flight under the current one's MFMAs) -> strip of y back into LDS
+//               -> fp64 column sums {sum y, sum y^2} of the strip, one atomic per block and column on a 16-way replica
+//               -> GRID BARRIER -> every block forms mean / scale / beta from the replica sums
+//               -> one pass: y to HBM (once, saved for the backward, never re-read here; issued after the barrier so its latency
+//               hides under the next layer) and BN + activation in place in LDS.
 //   last layer: the activated strip (or its max over K consecutive rows + arg-max byte) is the only other thing written.
 //
-// The grid barrier is a counter in global memory (arrive = one agent-scope atomic per block after its own atomics are
-// acknowledged, wait = agent-scope polling); the launcher only accepts row counts whose grid is co-resident
-// (i2p_chain_fwd_ok), and a poll limit turns a lost barrier into an error word instead of a hung GPU.
+// The grid barrier (grid_barrier below) is two levels of counters in global memory with per-group release flags — a single
+// polled counter cost 15 us per barrier at 456 blocks; arrive = one agent-scope atomic per block after its own atomics are
+// acknowledged, wait = agent-scope polling of the group's flag.  The launcher only accepts row counts whose grid is co-resident
+// (i2p_chain_fwd_ok), and a poll limit turns a lost barrier into an error word (+ a process-wide counter the host checks,
+// i2p_chain_set_error_counter) instead of a hung GPU.
+//
+// The second half of the file is the backward of a chain on the same scheme (chain_bwd_kernel + chain_reduce_kernel) and the C ABI.
+// Measurements and counters: tools/time_chain.py (ablation bits I2P_CHAIN_ABL), tools/pmc_chain.sh, profiles/r03_pmc_chain.txt.
 #include "common.h"
 
 namespace {
