@@ -124,10 +124,12 @@ struct Strip {              // what a block knows about its 64-row strip
 
 // input strip: x rows (coalesced 16-byte loads, eight in flight per thread), zero beyond the row / column range up to the next multiple
 // of 16; thread = (row of a pass, 16-byte column): no division per element
+template <int RT>
 __device__ __forceinline__ void load_x_strip(const ChainP &p, const Strip &s) {
+    constexpr int FR = 16 * RT;
     const int c0 = p.c[0], kp = (c0 + 15) & ~15, v = kp >> 2, rpp = CH_THREADS / v, tr = s.tid / v, c4 = (s.tid - tr * v) * 4;
     if (tr < rpp) {
-        for (int rb = tr; rb < CH_ROWS; rb += 8 * rpp) {
+        for (int rb = tr; rb < FR; rb += 8 * rpp) {
             f32x4 buf[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -138,7 +140,7 @@ __device__ __forceinline__ void load_x_strip(const ChainP &p, const Strip &s) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int r = rb + u * rpp;
-                if (r < CH_ROWS) *reinterpret_cast<f32x4 *>(s.A + (size_t)r * s.lda + c4) = buf[u];
+                if (r < FR) *reinterpret_cast<f32x4 *>(s.A + (size_t)r * s.lda + c4) = buf[u];
             }
         }
     }
@@ -148,7 +150,9 @@ __device__ __forceinline__ void load_x_strip(const ChainP &p, const Strip &s) {
 // AFTER the barrier, so their latency hides under the next layer instead of in front of the barrier), BN + activation in place (or
 // straight to `out` for the last layer of an un-pooled chain); rows beyond the range stay zero (they must not enter the next
 // layer's statistics).
+template <int RT>
 __device__ __forceinline__ void apply_strip(const ChainP &p, const Strip &s, int l) {
+    constexpr int FR = 16 * RT;
     const int cout = p.c[l + 1], v = cout >> 2, rpp = CH_THREADS / v, tr = s.tid / v, c4 = (s.tid - tr * v) * 4;
     const float slope = p.slope[l];
     const bool to_out = l == p.nl - 1 && !p.pool_k, ywr = !(p.abl & 32);
@@ -156,7 +160,7 @@ __device__ __forceinline__ void apply_strip(const ChainP &p, const Strip &s, int
     if (tr >= rpp) return;
     const f32x4 mu = *reinterpret_cast<const f32x4 *>(s.cf + c4), sc = *reinterpret_cast<const f32x4 *>(s.cf + CH_MAXC + c4),
                 be = *reinterpret_cast<const f32x4 *>(s.cf + 2 * CH_MAXC + c4);
-    for (int r = tr; r < CH_ROWS; r += rpp) {
+    for (int r = tr; r < FR; r += rpp) {
         f32x4 val = *reinterpret_cast<const f32x4 *>(s.A + (size_t)r * s.lda + c4);
         const bool r_ok = r < s.nvalid;
         if (r_ok && ywr) *reinterpret_cast<f32x4 *>(y + (size_t)(s.row0 + r) * cout + c4) = val;
@@ -173,7 +177,7 @@ __device__ __forceinline__ void apply_strip(const ChainP &p, const Strip &s, int
 // Layer l on the strip: wave `wave` computes columns [wave*16*NT, (wave+1)*16*NT) for the four 16-row tiles, so a block reads W exactly
 // once.  The first batch of W is requested FIRST and rides out the input phase (the x strip's loads for layer 0, the BN + activation
 // pass over the previous layer's strip otherwise); afterwards the next batch is in flight while a batch's 16 * BC * NT MFMAs run.
-template <int NT>
+template <int NT, int RT>
 __device__ __forceinline__ void layer_step(const ChainP &p, const Strip &s, int l, int wave, int i, int q) {
     const int kpad = (p.c[l] + 15) & ~15, w_ld = p.w_ld[l], lda = s.lda;
     const float *W = p.w[l];
@@ -182,11 +186,11 @@ __device__ __forceinline__ void layer_step(const ChainP &p, const Strip &s, int 
     constexpr int BC = NT <= 2 ? 4 : 2;                  // 16-element chunks per weight batch (registers: 2 * BC * NT float4)
     f32x4 cur[BC * NT], nxt[BC * NT];
     load_wbatch<NT, BC>(cur, W, w_ld, w_vec, 0, kpad, wave, i, q, p.abl);
-    if (l == 0) load_x_strip(p, s); else apply_strip(p, s, l - 1);
+    if (l == 0) load_x_strip<RT>(p, s); else apply_strip<RT>(p, s, l - 1);
     __syncthreads();
-    f32x4 acc[4][NT];
+    f32x4 acc[RT][NT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int kb = 0; kb < ((p.abl & 1) ? 0 : kpad); kb += 16 * BC) {
@@ -195,13 +199,13 @@ __device__ __forceinline__ void layer_step(const ChainP &p, const Strip &s, int 
         for (int j = 0; j < BC; ++j) {
             const int k0 = kb + 16 * j;
             if (k0 < kpad) {
-                f32x4 a[4];
+                f32x4 a[RT];
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) a[rt] = *reinterpret_cast<const f32x4 *>(A + (size_t)(rt * 16 + i) * lda + k0 + 4 * q);
+                for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4 *>(A + (size_t)(rt * 16 + i) * lda + k0 + 4 * q);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt)
+                    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
                             acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][e], cur[j * NT + t][e], acc[rt][t], 0, 0, 0);
@@ -213,7 +217,7 @@ __device__ __forceinline__ void layer_step(const ChainP &p, const Strip &s, int 
     __syncthreads();                                     // every wave is done reading the input strip: the output strip replaces it
     // D of a tile: lane (column i, q), register e = row 4q + e of the 16
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -221,16 +225,18 @@ __device__ __forceinline__ void layer_step(const ChainP &p, const Strip &s, int 
     __syncthreads();
 }
 
+template <int RT>
 __global__ __launch_bounds__(CH_THREADS, 2) void chain_fwd_kernel(ChainP p) {
+    constexpr int FR = 16 * RT;                          // rows of a strip: 16, 32 or 64 (chain_fwd_rows)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     Strip s;
     s.A = smem;                                          // [64][lda]
-    s.cf = smem + (size_t)CH_ROWS * p.lda;                // [3][CH_MAXC]: mean, scale, beta of the current layer
+    s.cf = smem + (size_t)FR * p.lda;                // [3][CH_MAXC]: mean, scale, beta of the current layer
     double *red = reinterpret_cast<double *>(s.cf + 3 * CH_MAXC);     // [row groups][2][cout] partial column sums (<= 512 doubles)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
     s.lda = p.lda; s.tid = tid;
-    s.row0 = (long long)blockIdx.x * CH_ROWS;
-    s.nvalid = (int)((p.rows - s.row0) < CH_ROWS ? (p.rows - s.row0) : CH_ROWS);
+    s.row0 = (long long)blockIdx.x * FR;
+    s.nvalid = (int)((p.rows - s.row0) < FR ? (p.rows - s.row0) : FR);
     const unsigned G = gridDim.x;
     float *A = s.A, *cf = s.cf;
 
@@ -246,15 +252,15 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_fwd_kernel(ChainP p) {
         float gam = 0.f, bet = 0.f;
         if (tid < cout) { gam = p.gamma[l][tid]; bet = p.beta[l][tid]; }
         switch (cout >> 6) {
-            case 1: layer_step<1>(p, s, l, wave, i, q); break;
-            case 2: layer_step<2>(p, s, l, wave, i, q); break;
-            case 3: layer_step<3>(p, s, l, wave, i, q); break;
-            default: layer_step<4>(p, s, l, wave, i, q); break;
+            case 1: layer_step<1, RT>(p, s, l, wave, i, q); break;
+            case 2: layer_step<2, RT>(p, s, l, wave, i, q); break;
+            case 3: layer_step<3, RT>(p, s, l, wave, i, q); break;
+            default: layer_step<4, RT>(p, s, l, wave, i, q); break;
         }
         // column sums of the strip (rows beyond the range are exact zeros): 256 / cout row groups in parallel, combined through LDS,
         // then one atomic per block, column and moment
         {
-            const int ngr = CH_THREADS / cout, gr = tid / cout, c = tid - gr * cout, rpg = CH_ROWS / ngr;
+            const int ngr = CH_THREADS / cout, gr = tid / cout, c = tid - gr * cout, rpg = FR / ngr;
             if (gr < ngr) {
                 double sm = 0.0, s2 = 0.0;
 #pragma unroll 16
@@ -293,11 +299,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_fwd_kernel(ChainP p) {
         }
         __syncthreads();
     }
-    apply_strip(p, s, p.nl - 1);
+    apply_strip<RT>(p, s, p.nl - 1);
     __syncthreads();
 
     if (p.pool_k) {      // max over groups of pool_k consecutive rows (pool_k divides 64: a group never leaves the strip); first k wins ties, NaN propagates
-        const int cout = p.c[p.nl], v = cout >> 2, K = p.pool_k, ng = CH_ROWS / K, gpp = CH_THREADS / v, tg = tid / v, c4 = (tid - tg * v) * 4;
+        const int cout = p.c[p.nl], v = cout >> 2, K = p.pool_k, ng = FR / K, gpp = CH_THREADS / v, tg = tid / v, c4 = (tid - tg * v) * 4;
         const long long g0 = s.row0 / K;
         for (int g = tg; tg < gpp && g < ng && g * K < s.nvalid; g += gpp) {
             f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -724,9 +730,31 @@ int chain_cmax(int nl, const int *widths) {
     return m;
 }
 
-size_t chain_lds_bytes(int cmax) {
+size_t chain_lds_bytes(int cmax, int fr) {
     const int lda = ((cmax + 15) & ~15) + 4;
-    return ((size_t)CH_ROWS * lda + 3 * CH_MAXC) * sizeof(float) + 512 * sizeof(double);
+    return ((size_t)fr * lda + 3 * CH_MAXC) * sizeof(float) + 512 * sizeof(double);
+}
+
+// rows of a forward strip: the smallest of 16 / 32 / 64 whose grid still has at most one block per CU — few-row chains then spread over
+// more CUs (928 rows: 13.0 -> 10.9 us, 1824: 13.1 -> 11.2, 7296 x 128: 14.7 -> 13.8 with 32-row strips, tools/time_chain.py) — while
+// the 14 848-row chains stay on 64-row strips (32-row ones read W twice as often and double the barrier's arrivals: 58 -> 63 us);
+// 64-row grids may also run two blocks per CU.  0 = the chain does not fit.
+int chain_fwd_rows(long long rows, int cmax, int pool_k) {
+    const int cus = chain_cus();
+    if (cus <= 0) return 0;
+    static const char *env = getenv("I2P_CHAIN_FR");       // diagnostic: 64 = always 64-row strips
+    for (int fr = 16; fr <= 64; fr *= 2) {
+        if (pool_k && fr % pool_k) continue;
+        const long long blocks = (rows + fr - 1) / fr;
+        if (fr < 64) {
+            if ((env && env[0] == '6') || blocks > cus) continue;
+            return fr;
+        }
+        const size_t lds = chain_lds_bytes(cmax, fr);
+        const int per_cu = (int)((160 * 1024) / lds) > 2 ? 2 : (int)((160 * 1024) / lds);
+        if (per_cu >= 1 && blocks <= (long long)cus * per_cu) return fr;
+    }
+    return 0;
 }
 
 int chain_cus() {
@@ -759,11 +787,7 @@ extern "C" int i2p_chain_fwd_ok(long long rows, int nl, const int *widths, int p
     for (int l = 1; l <= nl; ++l)
         if (widths[l] <= 0 || (widths[l] & 63) || widths[l] > 256) return 0;
     if (pool_k < 0 || pool_k > CH_ROWS || (pool_k && (CH_ROWS % pool_k || rows % pool_k))) return 0;
-    const size_t lds = chain_lds_bytes(chain_cmax(nl, widths));
-    const int per_cu = (int)((160 * 1024) / lds) > 2 ? 2 : (int)((160 * 1024) / lds);
-    const int cus = chain_cus();
-    const long long blocks = (rows + CH_ROWS - 1) / CH_ROWS;
-    return per_cu >= 1 && cus > 0 && blocks <= (long long)cus * per_cu ? 1 : 0;
+    return chain_fwd_rows(rows, chain_cmax(nl, widths), pool_k) ? 1 : 0;
 }
 
 extern "C" int i2p_chain_fwd(long long rows, int nl, const int *widths, const int *w_ld, const float *x, const float *const *w,
@@ -787,14 +811,19 @@ extern "C" int i2p_chain_fwd(long long rows, int nl, const int *widths, const in
     for (int l = 1; l <= nl; ++l) p.smax = widths[l] > p.smax ? widths[l] : p.smax;
     const int cmax = chain_cmax(nl, widths);
     p.lda = ((cmax + 15) & ~15) + 4;
-    const size_t bytes = chain_lds_bytes(cmax);
+    const int fr = chain_fwd_rows(rows, cmax, pool_k);
+    const size_t bytes = chain_lds_bytes(cmax, fr);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const unsigned grid = (unsigned)((rows + CH_ROWS - 1) / CH_ROWS);
-    hipLaunchKernelGGL(chain_fwd_kernel, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
+    const unsigned grid = (unsigned)((rows + fr - 1) / fr);
+    if (fr == 16) hipLaunchKernelGGL(chain_fwd_kernel<1>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
+    else if (fr == 32) hipLaunchKernelGGL(chain_fwd_kernel<2>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(chain_fwd_kernel<4>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
