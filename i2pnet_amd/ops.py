@@ -979,7 +979,9 @@ class CBackend:
 
     # ---- whole small MLP chain in one launch (csrc/mlp_chain.hip) --------------------------------
     def chain_fits(self, rows, widths, pool_k):
-        """does i2p_chain_fwd take this chain on the current device?  widths = [row length of x, cout_1, ..., cout_nl]"""
+        """does i2p_chain_fwd take this chain on the current device?  widths = [row length of x, cout_1, ..., cout_nl].
+        (Chain launches need their whole grid resident: they must not overlap another chain launch on the same GPU — the step runs
+        them on one stream; the side-stream weight-gradient option only moves layer kernels, never these.)"""
         if self.name != "hip" or self.device_type != "cuda" or os.environ.get("I2P_NO_CHAIN") == "1":
             return False
         key = (int(rows), tuple(int(c) for c in widths), int(pool_k))
