@@ -985,7 +985,7 @@ class CBackend:
         if self.name != "hip" or self.device_type != "cuda" or os.environ.get("I2P_NO_CHAIN") == "1":
             return False
         key = (int(rows), tuple(int(c) for c in widths), int(pool_k))
-        if _cur_dev() not in _CHAIN_ERR:
+        if _cur_dev() not in _CHAIN_ERR and not torch.cuda.is_current_stream_capturing():     # (never allocated inside a graph's pool)
             _register_chain_counter()
         hit = _CHAIN_OK.get(key)
         if hit is None:
