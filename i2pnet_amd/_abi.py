@@ -86,7 +86,7 @@ DEVICE_ONLY = {
     "i2p_chain_bwd": ["l", "i", "p", "p", "p", "pp", "pp", "pp", "pp", "p", "p", "p", "i", "p", "p", "p", "pp", "pp", "p", "p"],
     "i2p_pose_compose_fwd": ["i", "p", "p", "p", "p", "p"],
     "i2p_pose_compose_bwd": ["i"] + ["p"] * 8,
-    "i2p_clip_adam": ["l"] + ["p"] * 8 + ["d", "d"] + ["f"] * 4 + ["p"],
+    "i2p_clip_adam": ["l"] + ["p"] * 8 + ["d", "d"] + ["f"] * 4 + ["p", "p"],
     "i2p_img_bn_stats_fin": ["i", "i", "i", "i", "p", "p", "p", "f", "f", "p", "p", "p", "p"],
     "i2p_img_bn_pool_bwd_fin": ["i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "f", "p", "p", "p", "p", "p"],
     "i2p_img_block_fwd": ["i"] * 7 + ["p", "p", "p", "p", "f", "f", "f"] + ["p"] * 6,
@@ -119,7 +119,8 @@ HELPERS = {
     "i2p_chain_bwd_ok": ["l", "i", "p", "i"],
     "i2p_chain_bwd_slab": ["i", "p", "p"],                          # returns long long (floats)
     "i2p_chain_sums_len": ["i", "i"],                               # returns long long (doubles)
-    "i2p_chain_set_error_counter": ["p"],
+    "i2p_chain_set_error_words": ["p", "p"],
+    "i2p_chain_resident_blocks": ["i", "l"],
     "i2p_chain_sync_words": [],                                     # returns long long (uint32 words)
 }
 LONG_HELPERS = {"i2p_pair_lin_bwd_scratch", "i2p_pair_bias_bn_bwd_scratch", "i2p_gather_rows_grad_fx_scratch", "i2p_gemm_tn_scratch", "i2p_chain_sums_len", "i2p_chain_sync_words", "i2p_chain_bwd_slab"}

@@ -12,8 +12,11 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
-LIB = PKG / "lib" / "libi2p_ops.so"
-OBJ = PKG / "lib" / "obj"
+# I2P_BUILD_VARIANT=name [I2P_BUILD_DEFS="-DX -DY"]: a second build of the same ABI next to the product library
+# (lib/libi2p_ops_<name>.so, objects in lib/obj_<name>) for A/B timing through I2P_OPS_LIB (i2pnet_amd/_lib.py); never loaded by default
+_VARIANT = os.environ.get("I2P_BUILD_VARIANT", "")
+LIB = PKG / "lib" / (f"libi2p_ops_{_VARIANT}.so" if _VARIANT else "libi2p_ops.so")
+OBJ = PKG / "lib" / (f"obj_{_VARIANT}" if _VARIANT else "obj")
 SOURCES = ["fused_conv_select_k.hip", "pointnet2_ops.hip", "projection_ops.hip", "bn_act.hip", "mlp.hip", "cv_softmax.hip",
            "image_block.hip", "mlp_bf16.hip", "bf16_stream.hip", "sa_group.hip", "scatter_det.hip", "mlp_wreg.hip", "mlp_wreg_bf16.hip", "gemm_tn.hip", "mlp_big.hip", "optim.hip", "glue.hip", "mlp_chain.hip"]
 # mlp_wreg.hip: one strip = 256 MFMAs with the rest of the wave's work slotted between them, written as ONE fully
@@ -27,7 +30,7 @@ FLAGS = [
     "-ffp-contract=off",        # bit-exact distance order: only the explicit fmaf()s fuse
     "-munsafe-fp-atomics",      # hardware global_atomic_add_f32 where a kernel still accumulates with atomics
     "-Wall", "-Wno-unused-function", "-Wno-pass-failed",
-]
+] + (os.environ.get("I2P_BUILD_DEFS", "").split() if _VARIANT else [])
 
 
 def _sources():

@@ -61,6 +61,25 @@ __device__ __forceinline__ unsigned i2p_xcd_swizzle(unsigned bid, unsigned nbloc
     return (bid & 7u) * per + (bid >> 3);
 }
 
+// "The last block to finish finalises" ticket of the layer kernels (mlp.hip, mlp_wreg.hip).  Called by ONE lane of the block after a
+// `s_waitcnt vmcnt(0)` of every thread and the block's __syncthreads(); `total` = blocks of the grid.  Ordering (MI355X_MICROARCH.md,
+// inter-workgroup visibility; cdna_hip_programming.md Guideline 16): an agent-scope RELEASE before the ticket (buffer_wbl2 sc1 — what
+// the block published for the finaliser are agent-scope atomics, already performed at the memory side, but the ordering no longer
+// rests on that), the asm wait restating the post-write-back wait where the compiler cannot drop it, the relaxed ticket, and an
+// agent-scope ACQUIRE in the block that drew the last one, before it reads the other blocks' sums.  -DI2P_RELAXED_SYNC builds the
+// round-3 form (acknowledged atomics + relaxed ticket) for A/B timing (I2P_BUILD_VARIANT, i2pnet_amd/build.py).
+__device__ __forceinline__ bool i2p_ticket_is_last(unsigned *ticket, unsigned total) {
+#ifndef I2P_RELAXED_SYNC
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    const bool last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u;
+#ifndef I2P_RELAXED_SYNC
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    return last;
+}
+
 // deterministic (owner-scans-in-row-order) scatter-add backward kernels, csrc/scatter_det.hip
 int i2p_det_gather_rows_grad(int b, int hw, int c, int q, int W, const float *grad_out, const int64_t *h_idx, const int64_t *w_idx,
                              float *grad_feat, void *stream);

@@ -107,7 +107,7 @@ __device__ __forceinline__ double rep_sum_dev(const double *sums, int c, int idx
 }
 __device__ __forceinline__ bool last_block(unsigned *ticket, int *flag) {
     __syncthreads();                                       // every thread of the block has its atomics' return values
-    if (threadIdx.x == 0) *flag = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+    if (threadIdx.x == 0) *flag = i2p_ticket_is_last(ticket, gridDim.x) ? 1 : 0;
     __syncthreads();
     return *flag != 0;
 }

@@ -328,15 +328,11 @@ constexpr int F2_ROWS = 16;
 // (`flag`: one word of the kernel's dynamic LDS, dead by now: a static __shared__ on top of the 160 KB carve-out fails to launch)
 template <int NTHREADS>
 __device__ __forceinline__ void finalize_by_last_block(const LinFwdParams &p, int tid, volatile int *flag) {
-    // Only device-scope ATOMICS are published here (performed at the coherence point, no cache line to write back): it is
-    // enough that this thread's atomics are acknowledged before the block takes its ticket — a full release fence
-    // (buffer_wbl2 of the freshly written y tile, by 512 threads) cost ~1 ms per step over the ~40 layer launches.
+    // every thread's statistics atomics are acknowledged, then ONE lane releases, takes the ticket and (last block) acquires:
+    // i2p_ticket_is_last (common.h).  (A release fence issued by all 512 threads cost ~1 ms per step over the ~40 layer launches.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-        const unsigned t = atomicAdd(p.fin_counter, 1u);
-        *flag = (t == gridDim.x * gridDim.y - 1) ? 1 : 0;
-    }
+    if (tid == 0) *flag = i2p_ticket_is_last(p.fin_counter, gridDim.x * gridDim.y) ? 1 : 0;
     __syncthreads();
     if (!*flag) return;
     const int c = p.cout_total, n2 = 2 * c;

@@ -32,6 +32,15 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int CH_THREADS = 256, CH_ROWS = 64, CH_MAXL = 4, CH_MAXC = 272, CH_REP = 16;
 
+// Where a lost grid barrier is reported: the launch's own error word (sync[CH_ERR]), a per-device fp32 counter in device memory
+// (the trainer appends it to the flat gradient, so that the optimiser kernel — and, through the all-reduce, every rank — skips the
+// update of a poisoned step) and a HOST-MAPPED word the host reads without synchronising (Trainer.step checks it every step).
+struct ChainErr {
+    float *counter;                   // device fp32 [>= 1] or nullptr
+    unsigned *hflag;                  // pinned host uint32 [1], device-accessible, or nullptr
+    unsigned poll_limit;              // polls of one barrier wait before it gives up (~1.5 us each)
+};
+
 struct ChainP {
     long long rows;
     int nl;
@@ -49,7 +58,7 @@ struct ChainP {
     unsigned char *arg;
     float *w0_pad;                    // optional [c[1]][c[0]]: W_0 with zero columns (what the backward kernels take)
     unsigned *sync;                   // i2p_chain_sync_words() words, zero on entry and (but for the error word) on exit
-    unsigned *sticky;                 // process-wide count of timed-out barriers (i2p_chain_set_error_counter) or nullptr
+    ChainErr err;                     // where a timed-out barrier is reported (i2p_chain_set_error_words) + the poll limit
     int lda;
     int abl;                          // diagnostic ablation bits (I2P_CHAIN_ABL; tools/time_chain.py): 0 in production
 };
@@ -64,10 +73,30 @@ __device__ __forceinline__ float act(float z, float slope) { return z > 0.f ? z 
 constexpr int CH_NG = 8, CH_LINE = 32, CH_TOP = CH_NG * CH_LINE, CH_FLAG = (CH_NG + 1) * CH_LINE, CH_EXIT = (2 * CH_NG + 1) * CH_LINE,
               CH_ERR = (2 * CH_NG + 2) * CH_LINE, CH_SYNC_WORDS = (2 * CH_NG + 3) * CH_LINE;
 
-__device__ __forceinline__ void grid_barrier(unsigned *sync, unsigned k, unsigned G, int tid, unsigned *sticky) {
+// Memory ordering (VERDICT r3 #1b / MI355X_MICROARCH.md, inter-workgroup visibility): per-XCD L2s are not coherent and a CU's L1 is
+// never refreshed by other CUs, so the arrival is preceded by an AGENT-scope RELEASE (buffer_wbl2 sc1: everything this block stored
+// before the barrier — the statistics it added with agent-scope atomics are already performed at the memory side, its plain stores
+// are written back) and the wait is followed by ONE agent-scope ACQUIRE (buffer_inv sc1) by the polling lane, which covers the block
+// through the __syncthreads() behind it; the polls themselves stay relaxed (an acquire per poll would invalidate the L1 every
+// iteration).  The asm wait after the release fence restates the post-write-back wait where the compiler cannot drop it (ROCm 7.2
+// drops it when its scoreboard is provably empty: guide, Guideline 16 pitfall 12).  abl bit 64 = the round-3 relaxed form (A/B timing).
+//
+// Returns false when the barrier was abandoned (the grid is not co-resident: CU mask, another process, an over-sized grid): the
+// poll limit is reached or another block already gave up (the launch's error word is checked every 64 polls, so one time-out ends
+// every waiter).  The caller stops using barriers (its results are garbage anyway) and the three error sinks of ChainErr are set.
+__device__ __forceinline__ bool grid_barrier(unsigned *sync, unsigned k, unsigned G, int tid, const ChainErr &err, unsigned *s_ok, int abl) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's statistics atomics are acknowledged (performed at L2 / memory side)
     __syncthreads();
     if (tid == 0) {
+#ifdef I2P_RELAXED_SYNC
+        const bool fenced = false;
+#else
+        const bool fenced = !(abl & 64);
+#endif
+        if (fenced) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const unsigned g = blockIdx.x & (CH_NG - 1), ng = G < CH_NG ? G : CH_NG, n_g = (G - g + CH_NG - 1) / CH_NG;
         const unsigned t = __hip_atomic_fetch_add(sync + g * CH_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == k * n_g - 1) {
@@ -75,17 +104,25 @@ __device__ __forceinline__ void grid_barrier(unsigned *sync, unsigned k, unsigne
             if (t2 == k * ng - 1)
                 for (unsigned j = 0; j < ng; ++j) __hip_atomic_store(sync + CH_FLAG + j * CH_LINE, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        unsigned polls = 0;
+        unsigned polls = 0, ok = 1u;
         while (__hip_atomic_load(sync + CH_FLAG + g * CH_LINE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
             __builtin_amdgcn_s_sleep(2);
-            if (++polls > (1u << 19)) {                  // ~ a second: the grid was not co-resident; give up loudly instead of hanging
-                __hip_atomic_store(sync + CH_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sticky) __hip_atomic_fetch_add(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ++polls;
+            if ((polls & 63u) == 0u && __hip_atomic_load(sync + CH_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0u; break; }
+            if (polls > err.poll_limit) {                // ~ a second by default: the grid was not co-resident; give up loudly instead of hanging
+                if (!__hip_atomic_exchange(sync + CH_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {      // first block to give up
+                    if (err.counter) __hip_atomic_fetch_add(err.counter, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (err.hflag) __hip_atomic_store(err.hflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                ok = 0u;
                 break;
             }
         }
+        if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *s_ok = ok;
     }
     __syncthreads();
+    return *s_ok != 0u;
 }
 
 // Weights of one BATCH of BC 16-element contraction chunks for this wave's NT column tiles (k-step e of a chunk takes elements
@@ -233,6 +270,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_fwd_kernel(ChainP p) {
     s.A = smem;                                          // [64][lda]
     s.cf = smem + (size_t)FR * p.lda;                // [3][CH_MAXC]: mean, scale, beta of the current layer
     double *red = reinterpret_cast<double *>(s.cf + 3 * CH_MAXC);     // [row groups][2][cout] partial column sums (<= 512 doubles)
+    unsigned *s_ok = reinterpret_cast<unsigned *>(red + 512);         // the polling lane's verdict on the last barrier
+    bool alive = true;                                   // false once a barrier was abandoned: no further barriers (results are invalid)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
     s.lda = p.lda; s.tid = tid;
     s.row0 = (long long)blockIdx.x * FR;
@@ -276,7 +315,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_fwd_kernel(ChainP p) {
                 atomicAdd(sums + p.smax + tid, s2);
             }
         }
-        if (!(p.abl & 8)) grid_barrier(p.sync, (unsigned)(l + 1), G, tid, p.sticky);
+        if (!(p.abl & 8) && alive) alive = grid_barrier(p.sync, (unsigned)(l + 1), G, tid, p.err, s_ok, p.abl);
         double *sl = p.sums + (size_t)l * CH_REP * 2 * p.smax;
         if (tid < cout) {
             const int c = tid;
@@ -354,7 +393,8 @@ struct ChainBP {
     float *dgamma[CH_MAXL], *dbeta[CH_MAXL];
     double *sums;                     // [nl][CH_REP][2 * smax], zero on entry
     int smax;
-    unsigned *sync, *sticky;
+    unsigned *sync;
+    ChainErr err;
     int ldp, ldq;
     int abl;
 };
@@ -643,6 +683,8 @@ __global__ __launch_bounds__(CH_THREADS) void chain_bwd_kernel(ChainBP p) {
     s.P = smem;
     s.Q = smem + (size_t)RB * p.ldp;
     s.tab = s.Q + (size_t)RB * p.ldq;                     // [2][256]: m1, m2 of the current layer
+    unsigned *s_ok = reinterpret_cast<unsigned *>(s.tab + 512);
+    bool alive = true;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
     s.ldp = p.ldp; s.ldq = p.ldq; s.tid = tid;
     s.row0 = (long long)blockIdx.x * RB;
@@ -651,7 +693,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_bwd_kernel(ChainBP p) {
 
     for (int l = p.nl - 1; l >= 0; --l) {
         bwd_p1<RB>(p, s, l, l == p.nl - 1);
-        if (!(p.abl & 8)) grid_barrier(p.sync, (unsigned)(p.nl - l), G, tid, p.sticky); else __syncthreads();
+        if (!(p.abl & 8) && alive) alive = grid_barrier(p.sync, (unsigned)(p.nl - l), G, tid, p.err, s_ok, p.abl); else __syncthreads();
         bwd_p2(p, s, l);
         const int ntn = (l || p.gx) ? ((((p.c[l] + 15) & ~15) >> 4) + 3) >> 2 : 0;
         switch (ntn) {
@@ -708,21 +750,88 @@ void chain_bwd_ld(int nl, const int *widths, int &ldp, int &ldq) {
     ldp = mp + 4; ldq = (mq < 32 ? 32 : mq) + 4;
 }
 
-size_t chain_bwd_lds_bytes(int rb, int ldp, int ldq) { return ((size_t)rb * (ldp + ldq) + 512) * sizeof(float); }
+size_t chain_bwd_lds_bytes(int rb, int ldp, int ldq) { return ((size_t)rb * (ldp + ldq) + 512 + 4) * sizeof(float); }
 
-int chain_cus();
+// ---- residency: what the launcher checks a grid against (VERDICT r3 #1b) -----------------------------------------------------------
+// Blocks of kernel `kind` (0 / 1 / 2: chain_fwd_kernel<1 / 2 / 4>, 3: chain_bwd_kernel<64>, 4: chain_bwd_kernel<128>) the CURRENT device
+// holds at once with `lds` bytes of dynamic LDS: hipOccupancyMaxActiveBlocksPerMultiprocessor (registers, LDS, waves) x CUs of that
+// device, capped by the blocks per CU the kernel is written for (launch bounds: two for the forward, one wave per SIMD for the
+// backward) and by the 256-thread admission rule of MI355X_MICROARCH.md (min(API, 8, 800 / (ceil(sgpr / 16) * 16 + 16)): 6 at the 106
+// SGPRs of these kernels — above the caps).  Cached per (device, kind, lds).  A plain launch of a grid within this number has the
+// same residency as a cooperative launch of it (same guide: hipLaunchCooperativeKernel adds only the check made here, at +15-19 us
+// per launch); what the query cannot see — a CU mask, another process on the GPU, a second chain launch on another stream — is what
+// the barrier's poll limit and the error words are for.
+constexpr int CH_MAX_DEV = 16;
+struct ResKey { int kind; size_t lds; int blocks; };
+struct DevState {
+    int cus = 0;
+    bool attr_set = false;
+    ResKey cache[32];
+    int ncache = 0;
+    ChainErr err{nullptr, nullptr, 0};
+};
+DevState g_dev[CH_MAX_DEV];
+
+DevState *chain_dev() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CH_MAX_DEV) return nullptr;
+    DevState &d = g_dev[dev];
+    if (!d.cus) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
+        d.cus = prop.multiProcessorCount;
+    }
+    if (!d.attr_set) {                 // (function attributes are per device)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_bwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        d.attr_set = true;
+    }
+    return &d;
+}
+
+int chain_cus() { DevState *d = chain_dev(); return d ? d->cus : 0; }
+
+int chain_resident(int kind, size_t lds) {
+    DevState *d = chain_dev();
+    if (!d || lds > 160 * 1024) return 0;
+    for (int i = 0; i < d->ncache; ++i)
+        if (d->cache[i].kind == kind && d->cache[i].lds == lds) return d->cache[i].blocks;
+    const void *fn = kind == 0 ? reinterpret_cast<const void *>(chain_fwd_kernel<1>) : kind == 1 ? reinterpret_cast<const void *>(chain_fwd_kernel<2>)
+                   : kind == 2 ? reinterpret_cast<const void *>(chain_fwd_kernel<4>) : kind == 3 ? reinterpret_cast<const void *>(chain_bwd_kernel<64>)
+                   : reinterpret_cast<const void *>(chain_bwd_kernel<128>);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, CH_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+    const int cap = kind <= 2 ? 2 : 1;
+    per_cu = per_cu > cap ? cap : per_cu;
+    const int blocks = per_cu * d->cus;
+    if (d->ncache < 32) d->cache[d->ncache++] = ResKey{kind, lds, blocks};
+    return blocks;
+}
+
+// diagnostic switch of tests/test_chain_gpu.py::test_chain_timeout_surfaces: accept grids that are NOT resident (the barrier then times out)
+bool chain_force_nonresident() { const char *e = getenv("I2P_CHAIN_FORCE_NONRESIDENT"); return e && e[0] == '1'; }
+
+ChainErr chain_err() {
+    DevState *d = chain_dev();
+    ChainErr e = d ? d->err : ChainErr{nullptr, nullptr, 0};
+    const char *lim = getenv("I2P_CHAIN_POLL_LIMIT");       // polls before a barrier gives up (default 2^19 ~ one second)
+    e.poll_limit = lim ? (unsigned)strtoul(lim, nullptr, 10) : (1u << 19);
+    return e;
+}
 
 // rows of a backward strip: 64 when that grid is resident at ONE block per CU; 0 = not taken.  (A 128-row instantiation for the
 // 29 184-row level-3 chain exists — chain_bwd_kernel<128> — but its register allocation spills 568 VGPRs and measured 269 vs 179 us:
 // not dispatched.  Chains under 8192 rows are not taken either: the separate slab reduction launch costs them more than the
 // layer-by-layer launches they would save — 48 vs 38 us forward + backward on 928 .. 1824 rows, tools/time_chain.py.)
 int chain_bwd_rb(long long rows, int ldp, int ldq) {
-    const int cus = chain_cus();
-    if (cus <= 0 || rows < 8192) return 0;
-    return chain_bwd_lds_bytes(64, ldp, ldq) <= 160 * 1024 && (rows + 63) / 64 <= cus ? 64 : 0;
+    if (rows < 8192) return 0;
+    const size_t lds = chain_bwd_lds_bytes(64, ldp, ldq);
+    if (lds > 160 * 1024) return 0;
+    return ((rows + 63) / 64 <= chain_resident(3, lds) || (chain_force_nonresident() && chain_cus() > 0)) ? 64 : 0;
 }
-
-unsigned *g_chain_sticky = nullptr;
 
 int chain_cmax(int nl, const int *widths) {
     int m = 0;
@@ -732,13 +841,13 @@ int chain_cmax(int nl, const int *widths) {
 
 size_t chain_lds_bytes(int cmax, int fr) {
     const int lda = ((cmax + 15) & ~15) + 4;
-    return ((size_t)fr * lda + 3 * CH_MAXC) * sizeof(float) + 512 * sizeof(double);
+    return ((size_t)fr * lda + 3 * CH_MAXC) * sizeof(float) + 512 * sizeof(double) + 16;
 }
 
 // rows of a forward strip: the smallest of 16 / 32 / 64 whose grid still has at most one block per CU — few-row chains then spread over
 // more CUs (928 rows: 13.0 -> 10.9 us, 1824: 13.1 -> 11.2, 7296 x 128: 14.7 -> 13.8 with 32-row strips, tools/time_chain.py) — while
 // the 14 848-row chains stay on 64-row strips (32-row ones read W twice as often and double the barrier's arrivals: 58 -> 63 us);
-// 64-row grids may also run two blocks per CU.  0 = the chain does not fit.
+// 64-row grids may also run two blocks per CU (what the occupancy query admits).  0 = the chain does not fit.
 int chain_fwd_rows(long long rows, int cmax, int pool_k) {
     const int cus = chain_cus();
     if (cus <= 0) return 0;
@@ -746,26 +855,15 @@ int chain_fwd_rows(long long rows, int cmax, int pool_k) {
     for (int fr = 16; fr <= 64; fr *= 2) {
         if (pool_k && fr % pool_k) continue;
         const long long blocks = (rows + fr - 1) / fr;
+        const size_t lds = chain_lds_bytes(cmax, fr);
+        const int resident = chain_resident(fr == 16 ? 0 : fr == 32 ? 1 : 2, lds);
         if (fr < 64) {
-            if ((env && env[0] == '6') || blocks > cus) continue;
+            if ((env && env[0] == '6') || blocks > cus || blocks > resident) continue;
             return fr;
         }
-        const size_t lds = chain_lds_bytes(cmax, fr);
-        const int per_cu = (int)((160 * 1024) / lds) > 2 ? 2 : (int)((160 * 1024) / lds);
-        if (per_cu >= 1 && blocks <= (long long)cus * per_cu) return fr;
+        if (blocks <= resident || (chain_force_nonresident() && lds <= 160 * 1024)) return fr;
     }
     return 0;
-}
-
-int chain_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        cus = prop.multiProcessorCount;
-    }
-    return cus;
 }
 
 }  // namespace
@@ -773,10 +871,19 @@ int chain_cus() {
 // doubles of zeroed scratch i2p_chain_fwd needs for a chain of `nl` layers whose widest output is `cmax_out`
 extern "C" long long i2p_chain_sums_len(int nl, int cmax_out) { return (long long)nl * CH_REP * 2 * cmax_out; }
 
-// widths[0] = row length of x, widths[1..nl] = output widths
-// A device word the chain kernels add 1 to whenever a grid barrier times out (results of that launch are invalid): the host checks it
-// where it synchronises anyway (end of a benchmark, tests) — the per-launch error word lives in arena scratch that the next step clears.
-extern "C" int i2p_chain_set_error_counter(unsigned *device_word) { g_chain_sticky = device_word; return 0; }
+// Error sinks of the CURRENT device (see ChainErr): a device fp32 counter (+1 per launch with a timed-out grid barrier — results of that
+// launch are invalid) and a host-mapped word set to 1 at the same moment; both zeroed by the caller and kept alive; NULLs unregister.
+// The per-launch error word lives in arena scratch that the next step clears.
+extern "C" int i2p_chain_set_error_words(float *device_counter, unsigned *host_flag) {
+    DevState *d = chain_dev();
+    if (!d) return I2P_ERR_BAD_ARG;
+    d->err.counter = device_counter; d->err.hflag = host_flag;
+    return 0;
+}
+
+extern "C" int i2p_chain_resident_blocks(int kind, long long lds_bytes) {
+    return (kind < 0 || kind > 4 || lds_bytes < 0) ? 0 : chain_resident(kind, (size_t)lds_bytes);
+}
 
 // uint32 words of zeroed scratch behind `sync`; word i2p_chain_sync_words() - 32 is the error word
 extern "C" long long i2p_chain_sync_words(void) { return CH_SYNC_WORDS; }
@@ -799,7 +906,7 @@ extern "C" int i2p_chain_fwd(long long rows, int nl, const int *widths, const in
         return I2P_ERR_BAD_ARG;
     ChainP p{};
     p.rows = rows; p.nl = nl; p.x = x; p.eps = eps; p.sums = sums; p.pool_k = pool_k; p.out = out; p.arg = arg; p.w0_pad = w0_pad;
-    p.sync = sync; p.sticky = g_chain_sticky;
+    p.sync = sync; p.err = chain_err();
     { const char *e = getenv("I2P_CHAIN_ABL"); p.abl = e ? atoi(e) : 0; }     /* read per call: tools/time_chain.py switches it */
     p.c[0] = widths[0];
     for (int l = 0; l < nl; ++l) {
@@ -813,13 +920,6 @@ extern "C" int i2p_chain_fwd(long long rows, int nl, const int *widths, const in
     p.lda = ((cmax + 15) & ~15) + 4;
     const int fr = chain_fwd_rows(rows, cmax, pool_k);
     const size_t bytes = chain_lds_bytes(cmax, fr);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     const unsigned grid = (unsigned)((rows + fr - 1) / fr);
     if (fr == 16) hipLaunchKernelGGL(chain_fwd_kernel<1>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
     else if (fr == 32) hipLaunchKernelGGL(chain_fwd_kernel<2>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
@@ -856,7 +956,7 @@ extern "C" int i2p_chain_bwd(long long rows, int nl, const int *widths, const in
         (pool_k && !arg))
         return I2P_ERR_BAD_ARG;
     ChainBP p{};
-    p.rows = rows; p.nl = nl; p.x = x; p.g = g; p.arg = arg; p.pool_k = pool_k; p.gx = gx; p.dw_part = dw_part; p.sums = sums; p.sync = sync; p.sticky = g_chain_sticky;
+    p.rows = rows; p.nl = nl; p.x = x; p.g = g; p.arg = arg; p.pool_k = pool_k; p.gx = gx; p.dw_part = dw_part; p.sums = sums; p.sync = sync; p.err = chain_err();
     { const char *e = getenv("I2P_CHAIN_ABL"); p.abl = e ? atoi(e) : 0; }
     p.c[0] = widths[0];
     int off = 0;
@@ -873,12 +973,6 @@ extern "C" int i2p_chain_bwd(long long rows, int nl, const int *widths, const in
     chain_bwd_ld(nl, widths, p.ldp, p.ldq);
     const int rb = chain_bwd_rb(rows, p.ldp, p.ldq);
     const size_t bytes = chain_bwd_lds_bytes(rb, p.ldp, p.ldq);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_bwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     const unsigned grid = (unsigned)((rows + rb - 1) / rb);
     if (rb == 64) hipLaunchKernelGGL(chain_bwd_kernel<64>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(chain_bwd_kernel<128>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);

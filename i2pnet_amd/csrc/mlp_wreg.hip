@@ -241,13 +241,10 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_fwd_kernel(WregP p) {
             }
     }
     if (p.fin_counter) {
-        // (as mlp.hip finalize_by_last_block: only device-scope atomics are published, an acknowledged-atomics wait is enough)
+        // (as mlp.hip finalize_by_last_block: acknowledged atomics, then one lane's release -> ticket -> acquire, common.h)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            const unsigned t = atomicAdd(p.fin_counter, 1u);
-            fin_flag = (t == gridDim.x - 1) ? 1 : 0;
-        }
+        if (tid == 0) fin_flag = i2p_ticket_is_last(p.fin_counter, gridDim.x) ? 1 : 0;
         __syncthreads();
         if (!fin_flag) return;
         for (int ch = tid; ch < COUT; ch += NTHREADS) {
@@ -1247,10 +1244,7 @@ __global__ __launch_bounds__(WR_THREADS, 1) void wreg_pair_fwd_kernel(WregPairFw
     if (p.fin_counter) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            const unsigned t = atomicAdd(p.fin_counter, 1u);
-            fin_flag = (t == gridDim.x - 1) ? 1 : 0;
-        }
+        if (tid == 0) fin_flag = i2p_ticket_is_last(p.fin_counter, gridDim.x) ? 1 : 0;
         __syncthreads();
         if (!fin_flag) return;
         const double rows = (double)p.B * p.N * p.M;

@@ -18,7 +18,8 @@ constexpr int ADAM_THREADS = 256;
 constexpr int ADAM_MAX_BLOCKS = 256;
 
 __global__ __launch_bounds__(ADAM_THREADS) void adam_norm_kernel(long long n4, const float4 *__restrict__ grad, float gscale,
-                                                                 double *__restrict__ partials, float *__restrict__ step) {
+                                                                 double *__restrict__ partials, float *__restrict__ step,
+                                                                 const float *__restrict__ poison) {
     __shared__ double red[ADAM_THREADS / 64];
     double acc = 0.0;
     for (long long i = (long long)blockIdx.x * ADAM_THREADS + threadIdx.x; i < n4; i += (long long)gridDim.x * ADAM_THREADS) {
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_norm_kernel(long long n4, c
 #pragma unroll
         for (int w = 0; w < ADAM_THREADS / 64; ++w) t += red[w];
         partials[blockIdx.x] = t;
-        if (blockIdx.x == 0) step[0] = step[0] + 1.0f;                 // (launch 2 reads the advanced counter)
+        if (blockIdx.x == 0 && !(poison && poison[0] != 0.f)) step[0] = step[0] + 1.0f;     // (launch 2 reads the advanced counter)
     }
 }
 
@@ -44,7 +45,9 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_update_kernel(long long n4,
                                                                    const float4 *__restrict__ mask, const double *__restrict__ partials,
                                                                    int nparts, const float *__restrict__ step, const float *__restrict__ lr,
                                                                    float b1, float b2, float w1, float w2, float eps, float wd, float clip,
-                                                                   float gscale, float *__restrict__ total_out) {
+                                                                   float gscale, float *__restrict__ total_out,
+                                                                   const float *__restrict__ poison) {
+    if (poison && poison[0] != 0.f) return;         // gradients of an abandoned grid barrier (mlp_chain.hip): the step is not applied
     __shared__ float s_scale, s_bc2s, s_lrbc1;
     __shared__ double s_tot;
     if (threadIdx.x < 64) {                 // the <= 256 partials: four per lane in index order, then a fixed shuffle tree (same result in every block)
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_update_kernel(long long n4,
 // (the pre-clip global norm).  clip <= 0: no clipping.
 extern "C" int i2p_clip_adam(long long n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, const float *mask,
                              double *partials, float *step, const float *lr, double beta1, double beta2, float eps, float weight_decay,
-                             float clip, float gscale, float *total_out, void *stream) {
+                             float clip, float gscale, float *total_out, const float *poison, void *stream) {
     if (n <= 0 || (n & 3) || !param || !grad || !exp_avg || !exp_avg_sq || !partials || !step || !lr) return I2P_ERR_BAD_ARG;
     if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
          reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(mask)) & 15)
@@ -109,13 +112,13 @@ extern "C" int i2p_clip_adam(long long n, float *param, float *grad, float *exp_
     if (nb < 1) nb = 1;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_norm_kernel, dim3((unsigned)nb), dim3(ADAM_THREADS), 0, st, n4, reinterpret_cast<const float4 *>(grad), gscale,
-                       partials, step);
+                       partials, step, poison);
     long long nu = (n4 + ADAM_THREADS - 1) / ADAM_THREADS;       // the update streams 8 tensors: one float4 per thread, the whole chip
     if (nu > 4096) nu = 4096;
     hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)nu), dim3(ADAM_THREADS), 0, st, n4, reinterpret_cast<float4 *>(param),
                        reinterpret_cast<float4 *>(grad), reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq),
                        reinterpret_cast<const float4 *>(mask), partials, (int)nb, step, lr, (float)beta1, (float)beta2,
                        (float)(1.0 - beta1), (float)(1.0 - beta2),        // the lerp / addcmul weights as torch forms them: in double, then rounded
-                       eps, weight_decay, clip, gscale, total_out);
+                       eps, weight_decay, clip, gscale, total_out, poison);
     I2P_RETURN_LAUNCH_STATUS();
 }

@@ -165,6 +165,83 @@ def _linear_taps(n_out, n_in, clamp_weight, device):
     return i0.to(device), i1.to(device), w0.to(device), w1.to(device)
 
 
+# --------------------------------------------------------------------------------------------------------------
+# colour jitter of the training images (torchvision.transforms.ColorJitter on a PIL image, as the reference loaders call it)
+# --------------------------------------------------------------------------------------------------------------
+# nuScenes (nuscenes_loader_proj_nolidar.py:172-187, :308-310): ColorJitter(brightness (0.8, 1.2), contrast (0.8, 1.2), saturation
+# (0.8, 1.2), hue (-0.1, 0.1)) on the cropped uint8 image in train mode.  KITTI (kitti_odometry_corr_lidarnone_proj.py:499-514,
+# :746-750): `augment_img` builds `transforms.ColorJitter()` WITHOUT ranges — the identity — and discards the result of
+# `get_params`, so the reference's default path (crop=False, :256) changes no pixel; only `augment_img_crop` (crop=True) jitters.
+# Hence: NuScenesSampleBuilder jitters by default, DeviceSampleBuilder (KITTI) does not (`color_jitter=` overrides both).
+#
+# The four operations run on the device on the uint8 image with PIL's own integer / float32 arithmetic (libImaging Blend.c,
+# Convert.c rgb2hsv / hsv2rgb, ImageEnhance's degenerate images), so that a given (order, factors) draw reproduces what
+# torchvision's PIL path returns bit for bit (tests/test_data_pipeline.py compares against PIL where it is importable).
+def _cj_blend(deg, img, f):
+    """PIL Image.blend(deg, img, f) on uint8: float32 arithmetic, clip to [0, 255], truncate"""
+    t = deg.float() + torch.as_tensor(f, dtype=torch.float32, device=img.device) * (img.float() - deg.float())
+    return torch.floor(t.clamp(0.0, 255.0)).to(torch.uint8)
+
+
+def _cj_gray(img):
+    """PIL convert("L") of RGB: (R*19595 + G*38470 + B*7471 + 0x8000) >> 16"""
+    i = img.to(torch.int64)
+    return ((i[..., 0] * 19595 + i[..., 1] * 38470 + i[..., 2] * 7471 + 0x8000) >> 16).to(torch.uint8)
+
+
+def _cj_hue(img, f):
+    """torchvision adjust_hue on a PIL image: RGB -> HSV (uint8, libImaging rgb2hsv_row), H += uint8(f * 255) with wrap-around,
+    HSV -> RGB (hsv2rgb_row); float32 / double roundings as in the C code"""
+    r, g, b = [img[..., k].float() for k in range(3)]
+    maxc = torch.maximum(r, torch.maximum(g, b)); minc = torch.minimum(r, torch.minimum(g, b))
+    cr = maxc - minc
+    ok = cr > 0
+    crs = torch.where(ok, cr, torch.ones_like(cr))
+    s = cr / torch.where(ok, maxc, torch.ones_like(maxc))
+    rc, gc, bc = (maxc - r) / crs, (maxc - g) / crs, (maxc - b) / crs
+    h = torch.where(r == maxc, (bc - gc).double(), torch.where(g == maxc, 2.0 + rc.double() - bc.double(), 4.0 + gc.double() - rc.double())).float()
+    h = torch.fmod(h.double() / 6.0 + 1.0, 1.0).float().double()
+    zero = torch.zeros_like(h, dtype=torch.int64)
+    uh = torch.where(ok, (h * 255.0).to(torch.int64).clamp(0, 255), zero)
+    us = torch.where(ok, (s.double() * 255.0).to(torch.int64).clamp(0, 255), zero)
+    v = maxc.double()
+    uh = (uh + int(f * 255) % 256) % 256
+    h6 = uh.double() * 6.0 / 255.0
+    fs = us.double() / 255.0
+    i = torch.floor(h6)
+    fr = h6 - i
+    rnd = lambda x: torch.floor(x + 0.5)
+    p, q, t = rnd(v * (1.0 - fs)), rnd(v * (1.0 - fs * fr)), rnd(v * (1.0 - fs * (1.0 - fr)))
+    i = i.to(torch.int64) % 6
+    pick = lambda c0, c1, c2, c3, c4, c5: torch.where(i == 0, c0, torch.where(i == 1, c1, torch.where(i == 2, c2, torch.where(i == 3, c3, torch.where(i == 4, c4, c5)))))
+    out = torch.stack([pick(v, q, p, p, t, v), pick(t, v, v, q, p, p), pick(p, p, t, v, v, q)], -1)
+    out = torch.where((us == 0).unsqueeze(-1), v.unsqueeze(-1).expand_as(out), out)
+    return out.clamp(0, 255).to(torch.uint8)
+
+
+def color_jitter_u8(img, order, brightness, contrast, saturation, hue):
+    """img uint8 [H,W,3] (any device) -> jittered uint8 image.  `order`: permutation of (0 brightness, 1 contrast, 2 saturation,
+    3 hue) = torchvision's `fn_idx`; factors as torchvision samples them.  No host synchronisation."""
+    for k in order:
+        if k == 0:
+            img = _cj_blend(torch.zeros_like(img), img, brightness)
+        elif k == 1:
+            mean = torch.floor(_cj_gray(img).double().mean() + 0.5)          # int(ImageStat.Stat(L).mean[0] + 0.5), stays on the device
+            img = _cj_blend(mean.float().expand(img.shape), img, contrast)
+        elif k == 2:
+            img = _cj_blend(_cj_gray(img).unsqueeze(-1).expand_as(img), img, saturation)
+        else:
+            img = _cj_hue(img, hue)
+    return img
+
+
+def draw_color_jitter(rng, brightness=(0.8, 1.2), contrast=(0.8, 1.2), saturation=(0.8, 1.2), hue=(-0.1, 0.1)):
+    """one draw of ColorJitter.get_params: (random order of the four operations, four uniform factors)"""
+    order = list(range(4))
+    rng.shuffle(order)
+    return (tuple(order), rng.uniform(*brightness), rng.uniform(*contrast), rng.uniform(*saturation), rng.uniform(*hue))
+
+
 def resize_linear_u8(img, oh, ow):
     """`cv2.resize(img, (ow, oh), interpolation=cv2.INTER_LINEAR)` of a uint8 image [H,W,C], on any device.
 
@@ -203,12 +280,28 @@ class DeviceSampleBuilder:
     Padding rows stay exactly zero in `lidar`, `raw_point_xyz` and `lidar_feats` (:699-711); `rgb` is float [B,3,160,512]
     in 0..255 (the reference does not normalise, :757-760)."""
 
+    COLOR_JITTER_DEFAULT = False     # the reference's KITTI augment_img is the identity (see color_jitter_u8 above)
+
     def __init__(self, device, mode="train", sample_point=150000, img_H=160, img_W=512, img_scale=0.5, crop_top=50,
-                 rng=None, jitter=True):
+                 rng=None, jitter=True, color_jitter=None):
+        """`jitter`: per-point N(0, 0.01^2) noise of the cloud in train mode; `color_jitter`: ColorJitter of the cropped image
+        in train mode (None = the reference loader's effective behaviour: off for KITTI, on for nuScenes).  The random draws
+        (perturbation, crop offsets, colour jitter) come from `rng` in this order per sample; the reference draws from the
+        global `random` / numpy / torch generators in its own order, so equal seeds do not reproduce its samples — the
+        golden vectors pin the arithmetic by passing the reference's draws in (`Pr`, `perm`, `crop`, `jitter_params`)."""
         self.device, self.mode = torch.device(device), mode
         self.sample_point, self.img_H, self.img_W, self.img_scale, self.crop_top = sample_point, img_H, img_W, img_scale, crop_top
         self.rng = rng or random
         self.jitter = jitter and mode == "train"
+        self.color_jitter = (self.COLOR_JITTER_DEFAULT if color_jitter is None else bool(color_jitter)) and mode == "train"
+
+    def _crop_rgb(self, img, dx, dy, host):
+        """crop -> (train mode) colour jitter on the uint8 crop -> float [3,H,W] in 0..255"""
+        crop = img[dy:dy + self.img_H, dx:dx + self.img_W]
+        if self.color_jitter:
+            params = host.get("jitter_params") or draw_color_jitter(self.rng)
+            crop = color_jitter_u8(crop, *params)
+        return crop.permute(2, 0, 1).float()
 
     def perturbation(self, host):
         """host-side part of a sample: Pr, init_extrinsic, ground truth (float64 4x4 algebra, :583-612)"""
@@ -260,7 +353,7 @@ class DeviceSampleBuilder:
             else:
                 dx, dy = int((w - self.img_W) / 2), int((h - self.img_H) / 2)
             dx, dy = host.get("crop", (dx, dy))
-            rgb[b] = img[dy:dy + self.img_H, dx:dx + self.img_W].permute(2, 0, 1).float()
+            rgb[b] = self._crop_rgb(img, dx, dy, host)
             K[0, 2] -= dx; K[1, 2] -= dy
             Ks.append(K)
             ext[b] = torch.as_tensor(E, dtype=torch.float32); q_gt[b] = torch.as_tensor(q, dtype=torch.float32)
@@ -348,10 +441,11 @@ class NuScenesSampleBuilder(DeviceSampleBuilder):
     (y, -x, z) of the sensor-frame points, zero padding to 150 000 rows; image: top 100 rows dropped, resized by
     (0.32, 0.2) with cv2's bilinear rule, 160x512 crop, intrinsics adjusted alike."""
     TAN_UP, TAN_DOWN = 0.03492076949, -0.4620648698           # +2 deg / -24.8 deg elevation window (:271-275)
+    COLOR_JITTER_DEFAULT = True      # nuscenes_loader_proj_nolidar.py:172-187, :308-310
 
     def __init__(self, device, mode="train", sample_point=150000, img_H=160, img_W=512, img_scale_H=0.2, img_scale_W=0.32,
-                 crop_top=100, rng=None, jitter=True):
-        super().__init__(device, mode, sample_point, img_H, img_W, img_scale_H, crop_top, rng, jitter)
+                 crop_top=100, rng=None, jitter=True, color_jitter=None):
+        super().__init__(device, mode, sample_point, img_H, img_W, img_scale_H, crop_top, rng, jitter, color_jitter)
         self.img_scale_H, self.img_scale_W = img_scale_H, img_scale_W
 
     def perturbation(self, host):
@@ -408,7 +502,7 @@ class NuScenesSampleBuilder(DeviceSampleBuilder):
             else:
                 dx, dy = int((w - self.img_W) / 2), int((h - self.img_H) / 2)
             dx, dy = host.get("crop", (dx, dy))
-            rgb[b] = img[dy:dy + self.img_H, dx:dx + self.img_W].permute(2, 0, 1).float()
+            rgb[b] = self._crop_rgb(img, dx, dy, host)
             K[0, 2] -= dx; K[1, 2] -= dy
             Ks.append(K)
             ext[b] = torch.as_tensor(E, dtype=torch.float32); q_gt[b] = torch.as_tensor(q, dtype=torch.float32)

@@ -94,25 +94,70 @@ class _ZeroArena:
 
 _arena = _ZeroArena()
 _ZERO = {}
-_CHAIN_OK = {}        # (rows, widths, pool_k) -> does i2p_chain_fwd take it on this device
-_CHAIN_ERR = {}       # device -> persistent int32 [1]: grid barriers of the chain kernels that timed out (must stay 0)
+_CHAIN_OK = {}        # (device index, rows, widths, pool_k) -> does i2p_chain_fwd take it on that device
+_CHAIN_ERR = {}       # device -> (device fp32 [4] counter, pinned int32 [1] flag): timed-out grid barriers of the chain kernels (must stay 0)
 
 
 def _cur_dev():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+class ChainBarrierTimeout(RuntimeError):
+    """a grid barrier of the one-launch MLP chains (csrc/mlp_chain.hip) was abandoned: the launch's grid was not co-resident
+    (CU mask, another process on the GPU, two chain launches overlapping) and its results are invalid"""
+
+
+def _dev_key(device=None):
+    """torch.device('cuda', index) of `device` (None / 'cuda' = the current device)"""
+    d = torch.device("cuda" if device is None else device)
+    if d.type != "cuda":
+        return d
+    return torch.device("cuda", torch.cuda.current_device() if d.index is None else d.index)
+
+
 def _register_chain_counter():
-    """one persistent device word per process / GPU that the chain kernels bump when a grid barrier times out (i2p_chain_set_error_counter)"""
+    """Error sinks of the chain kernels for the CURRENT device (i2p_chain_set_error_words; the library keeps them per device):
+    a device fp32 [4] whose element 0 counts the launches with a timed-out grid barrier (four floats so that the trainer can
+    append it to its 16-byte-granular flat gradient: the optimiser kernel skips a poisoned step, and the all-reduce makes
+    every rank skip it) and a pinned host word the kernels set at the same moment, read without synchronising."""
     dev = _cur_dev()
-    t = torch.zeros(1, dtype=torch.int32, device=dev)
-    _CHAIN_ERR[dev] = t
-    _lib.helper("i2p_chain_set_error_counter", C.c_void_p(t.data_ptr()))
+    t = torch.zeros(4, dtype=torch.float32, device=dev)
+    h = torch.zeros(1, dtype=torch.int32).pin_memory()
+    _CHAIN_ERR[dev] = (t, h)
+    with torch.cuda.device(dev):
+        _lib.helper("i2p_chain_set_error_words", C.c_void_p(t.data_ptr()), C.c_void_p(h.data_ptr()))
+
+
+def chain_error_words(device=None):
+    """(device fp32 [4] counter, pinned host int32 [1] flag) of `device`, registering them on first use; None while a graph
+    is being captured and nothing is registered yet (never allocated inside a graph's pool)"""
+    dev = _dev_key(device)
+    if dev not in _CHAIN_ERR:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        with torch.cuda.device(dev):
+            _register_chain_counter()
+    return _CHAIN_ERR[dev]
+
+
+def chain_error_flag(device=None):
+    """True if a chain launch on `device` (None: any device of this process) has reported a timed-out barrier.  Reads the
+    host-mapped flags only: no synchronisation, so it sees the launches that have RUN so far."""
+    dev = None if device is None else _dev_key(device)
+    return any(int(h[0]) != 0 for d, (t, h) in _CHAIN_ERR.items() if dev is None or d == dev)
 
 
 def chain_errors(device=None):
-    """number of chain-kernel grid barriers that timed out in this process (synchronises); a non-zero count means results were invalid"""
-    return sum(int(t.item()) for d, t in _CHAIN_ERR.items() if device is None or d == torch.device(device))
+    """number of chain launches of this process whose grid barrier timed out (synchronises); non-zero means invalid results"""
+    dev = None if device is None else _dev_key(device)
+    return sum(int(t[0].item()) for d, (t, h) in _CHAIN_ERR.items() if dev is None or d == dev)
+
+
+def chain_errors_reset(device=None):
+    dev = None if device is None else _dev_key(device)
+    for d, (t, h) in _CHAIN_ERR.items():
+        if dev is None or d == dev:
+            t.zero_(); h.zero_()
 
 
 def zero_scalar(device, dtype=torch.float32):
@@ -984,13 +1029,12 @@ class CBackend:
         them on one stream; the side-stream weight-gradient option only moves layer kernels, never these.)"""
         if self.name != "hip" or self.device_type != "cuda" or os.environ.get("I2P_NO_CHAIN") == "1":
             return False
-        key = (int(rows), tuple(int(c) for c in widths), int(pool_k))
-        if _cur_dev() not in _CHAIN_ERR and not torch.cuda.is_current_stream_capturing():     # (never allocated inside a graph's pool)
-            _register_chain_counter()
+        key = (torch.cuda.current_device(), int(rows), tuple(int(c) for c in widths), int(pool_k))
+        chain_error_words()                    # registers this device's error sinks on first use (outside graph capture)
         hit = _CHAIN_OK.get(key)
         if hit is None:
-            arr = (C.c_int * len(widths))(*key[1])
-            hit = bool(_lib.helper("i2p_chain_fwd_ok", key[0], len(widths) - 1, C.cast(arr, C.c_void_p), key[2]))
+            arr = (C.c_int * len(widths))(*key[2])
+            hit = bool(_lib.helper("i2p_chain_fwd_ok", key[1], len(widths) - 1, C.cast(arr, C.c_void_p), key[3]))
             _CHAIN_OK[key] = hit
         return hit
 
@@ -1036,11 +1080,11 @@ class CBackend:
         if (self.name != "hip" or self.device_type != "cuda" or os.environ.get("I2P_NO_CHAIN") == "1"
                 or os.environ.get("I2P_CHAIN_BWD") == "0"):
             return False
-        key = ("bwd", int(rows), tuple(int(c) for c in widths), int(pool_k))
+        key = ("bwd", torch.cuda.current_device(), int(rows), tuple(int(c) for c in widths), int(pool_k))
         hit = _CHAIN_OK.get(key)
         if hit is None:
-            arr = (C.c_int * len(widths))(*key[2])
-            hit = bool(_lib.helper("i2p_chain_bwd_ok", key[1], len(widths) - 1, C.cast(arr, C.c_void_p), key[3]))
+            arr = (C.c_int * len(widths))(*key[3])
+            hit = bool(_lib.helper("i2p_chain_bwd_ok", key[2], len(widths) - 1, C.cast(arr, C.c_void_p), key[4]))
             _CHAIN_OK[key] = hit
         return hit
 

@@ -95,10 +95,11 @@ class FlatAdam:
         self.param.sub_(self.exp_avg / denom * (self.lr_t / bc1))
 
     @torch.no_grad()
-    def fused_clip_step(self, clip, gscale=1.0):
+    def fused_clip_step(self, clip, gscale=1.0, poison=None):
         """average (gscale = 1/world), clip to global norm `clip` and take the Adam step in two launches of
         i2p_clip_adam (csrc/optim.hip) instead of ~25 elementwise launches; same arithmetic as `_update()`'s torch
-        formulation (tests/test_train_gpu.py).  HIP backend / device tensors only."""
+        formulation (tests/test_train_gpu.py).  HIP backend / device tensors only.  `poison`: device fp32 [>= 1] or None — a
+        non-zero value makes the call a no-op (Trainer: the chain kernels' error counter behind the all-reduced gradient)."""
         be = ops.get_backend()
         if self._partials is None:
             self._partials = torch.zeros(256, dtype=torch.float64, device=self.param.device)
@@ -107,7 +108,7 @@ class FlatAdam:
         be._call("i2p_clip_adam", int(self.param.numel()), P(self.param), P(self.grad), P(self.exp_avg), P(self.exp_avg_sq),
                  P(self.mask) if self.mask is not None else None, P(self._partials, torch.float64), P(self.step_t.view(1)),
                  P(self.lr_t.view(1)), float(self.beta1), float(self.beta2), float(self.eps), float(self.weight_decay), float(clip),
-                 float(gscale), P(self._total), stream=be._stream())
+                 float(gscale), P(self._total), P(poison) if poison is not None else None, stream=be._stream())
 
     @torch.no_grad()
     def decay_lr(self, gamma):
@@ -122,10 +123,16 @@ STEP_KEYS = ("rgb", "lidar", "raw_point_xyz", "lidar_feats", "init_intrinsic", "
 
 class Trainer:
     def __init__(self, cfg=I2PNetConfig, device="cuda", lr=1e-3, clip=10.0, world_size=1, local_rank=0,
-                 seed=0, capturable=None, net_cls=RegNet_v2, call=None, side_wgrad=None):
+                 seed=0, capturable=None, net_cls=RegNet_v2, call=None, side_wgrad=None, on_chain_error="raise"):
         """`capturable` is accepted for compatibility and ignored (FlatAdam is always graph-safe).
         `net_cls` / `call`: another registration network with the same outputs (e.g. the small-range model,
-        i2pnet_amd.small_range.RegNet_v2) and how to call it: call(net, batch, cfg) -> its output tuple."""
+        i2pnet_amd.small_range.RegNet_v2) and how to call it: call(net, batch, cfg) -> its output tuple.
+        `on_chain_error`: what `step()` does when a one-launch MLP chain reported an abandoned grid barrier (its grid was not
+        co-resident — CU mask, another process on the GPU; csrc/mlp_chain.hip): "raise" ops.ChainBarrierTimeout (default), or
+        "fallback": log, switch the chains off (I2P_NO_CHAIN=1: the layer-by-layer kernels), re-capture and go on (single-process
+        training only: with several ranks a rank-local re-capture would desynchronise the collectives, so it always raises).
+        Either way the poisoned step is never applied: the error counter rides at the end of the flat gradient, through the
+        all-reduce, and a non-zero value turns clip + Adam into a no-op on every rank (i2p_clip_adam `poison`)."""
         torch.manual_seed(seed)                 # identical initial weights on every rank
         self.cfg, self.device, self.clip = cfg, torch.device(device), clip
         self.world_size = world_size
@@ -147,7 +154,16 @@ class Trainer:
             self._offsets.append(n)
             n += (p.numel() + 3) // 4 * 4
         self.flat_param = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=self.device)
+        # the gradient buffer carries four more floats: [n] = the chain kernels' error counter of this step (0 on a healthy GPU),
+        # summed over the ranks by the same all-reduce; `flat_grad` is the view the optimiser and named_grads() see
+        self._grad_buf = torch.zeros(n + 4, dtype=torch.float32, device=self.device)
+        self.flat_grad = self._grad_buf[:n]
+        self._poison = self._grad_buf[n:]
+        self.on_chain_error = on_chain_error
+        self._chain_words = None                # (device counter fp32 [4], pinned host flag) of this device, HIP backend only
+        if self.device.type == "cuda" and ops.get_backend().name == "hip":
+            with torch.cuda.device(self.device):
+                self._chain_words = ops.chain_error_words(self.device)
         self._zero = torch.zeros((), dtype=torch.float32, device=self.device)
         self._nhwc = []                         # 4-D parameters kept in channels_last storage (image-encoder conv weights)
         with torch.no_grad():
@@ -219,7 +235,8 @@ class Trainer:
                 grads.append((p.grad.permute(0, 2, 3, 1) if nhwc else p.grad).reshape(-1))
             if p.numel() % 4:                   # alignment padding of the flat layout
                 grads.append(zero.expand(4 - p.numel() % 4))
-        torch.cat(grads, out=self.flat_grad)
+        grads.append(self._chain_words[0] if self._chain_words is not None else zero.expand(4))
+        torch.cat(grads, out=self._grad_buf)
         return loss.detach(), real_loss.detach(), dual_loss.detach()
 
     def named_grads(self):
@@ -232,17 +249,43 @@ class Trainer:
         return out
 
     def epoch_end(self):
+        self.check_chain_errors(sync=True)
         self.optimizer.decay_lr(self.lr_gamma)
+
+    # ---- abandoned grid barriers of the chain kernels reach the caller (VERDICT r3 #1c / ADVICE r3) ----------------------------------
+    def check_chain_errors(self, sync=False):
+        """Raise (or fall back, see `on_chain_error`) if a chain launch of this device reported a timed-out grid barrier.
+        sync=False reads the host-mapped flag only — free, called at the top of every `step()`, sees every launch that has run
+        so far; sync=True also synchronises and reads the device counter (epoch_end, save_checkpoint)."""
+        if self._chain_words is None:
+            return
+        bad = ops.chain_error_flag(self.device) or (sync and ops.chain_errors(self.device) != 0)
+        if not bad:
+            return
+        torch.cuda.synchronize(self.device)
+        count = ops.chain_errors(self.device)
+        msg = (f"{count} chain launch(es) on {self.device} abandoned a grid barrier: the grid was not co-resident (CU mask, another "
+               "process on the GPU, overlapping chain launches).  The affected optimisation steps were NOT applied (clip + Adam skip "
+               "a poisoned gradient).  I2P_NO_CHAIN=1 runs the layer-by-layer kernels instead.")
+        if self.on_chain_error == "fallback" and self.world_size == 1 and not dist.is_initialized():
+            print("[i2pnet_amd.train] " + msg + "  Falling back to I2P_NO_CHAIN=1 and re-capturing.", flush=True)
+            os.environ["I2P_NO_CHAIN"] = "1"
+            ops.chain_errors_reset(self.device)
+            if self._graph_a is not None:
+                self._graph_a = self._graph_b = None
+                self.capture(self._static)
+            return
+        raise ops.ChainBarrierTimeout(msg)
 
     def _all_reduce(self):
         if self.world_size > 1 or (os.environ.get("I2P_FORCE_DP") and dist.is_initialized()):
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self._grad_buf, op=dist.ReduceOp.SUM)
 
     def _update(self):
         be = ops.get_backend()
         if (USE_FUSED_ADAM and self.device.type == "cuda" and be.name == "hip" and self.flat_param.numel() % 4 == 0
                 and self.flat_param.data_ptr() % 16 == 0 and self.flat_grad.data_ptr() % 16 == 0):
-            self.optimizer.fused_clip_step(self.clip, 1.0 / self.world_size)
+            self.optimizer.fused_clip_step(self.clip, 1.0 / self.world_size, poison=self._poison if self._chain_words is not None else None)
             return
         if self.world_size > 1:
             self.flat_grad.mul_(1.0 / self.world_size)
@@ -357,14 +400,17 @@ class Trainer:
         return {"state": state, "param_groups": [group]}, sched
 
     def save_checkpoint(self, path, epoch=0):
+        self.check_chain_errors(sync=True)       # never write weights of a run whose chains computed garbage without saying so
         opt_sd, sched_sd = self._adam_state_dict(epoch)
         torch.save({"epoch": epoch, "model_state_dict": self.net.state_dict(), "optimizer_state_dict": opt_sd,
                     "scheduler_state_dict": sched_sd}, path)
 
-    def load_checkpoint(self, path):
+    def load_checkpoint(self, path, trust_pickle=False):
         """a checkpoint of this trainer OR of the reference trainer (torch.optim.Adam + ExponentialLR state dicts): weights,
-        Adam moments / step count and the decayed learning rate are all restored"""
-        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        Adam moments / step count and the decayed learning rate are all restored.  The layout holds tensors and plain
+        containers only, so the file is read with `weights_only=True`; `trust_pickle=True` opts into full unpickling for
+        third-party files that carry other objects (arbitrary code execution: only for files you trust)."""
+        ckpt = torch.load(path, map_location="cpu", weights_only=not trust_pickle)
         sd = {k[7:] if k.startswith("module.") else k: v for k, v in ckpt["model_state_dict"].items()}
         with torch.no_grad():                       # parameters are views into the flat buffer: copy, never rebind
             self.net.load_state_dict(sd, strict=True)
@@ -398,6 +444,7 @@ class Trainer:
     def step(self, batch):
         """one optimisation step on a sample dict (keys of the reference loader); returns the
         loss tensors without synchronising."""
+        self.check_chain_errors()                 # host-mapped flag of the chain kernels: no synchronisation
         if self._graph_a is not None:
             for k, dst in self._static.items():
                 v = batch[k]

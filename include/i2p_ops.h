@@ -470,9 +470,16 @@ int i2p_pair_lin_fwd_fin(int B, int N, int M, int cin, int cout, const float *f,
 int i2p_chain_fwd_ok(long long rows, int nl, const int *widths, int pool_k);
 long long i2p_chain_sums_len(int nl, int cmax_out);
 long long i2p_chain_sync_words(void);
-/* registers ONE device uint32 (zeroed by the caller, kept alive) that every chain launch of this process increments when one of its grid
- * barriers times out; NULL unregisters */
-int i2p_chain_set_error_counter(unsigned *device_word);
+/* Error sinks of the CURRENT device for the chain kernels' grid barriers (a barrier that is not complete after the poll limit —
+ * the grid was not co-resident: CU mask, another process, an over-sized grid — is abandoned, the launch's results are invalid):
+ *   device_counter: device f32 [>= 1], +1.0 per launch with a timed-out barrier (i2p_clip_adam's `poison` argument reads it);
+ *   host_flag: pinned (device-accessible) host uint32 [1], set to 1 at the same moment: the host polls it without synchronising.
+ * Both zeroed by the caller and kept alive; NULLs unregister.  The per-launch error word is sync[i2p_chain_sync_words() - 32].
+ * i2p_chain_resident_blocks: blocks of chain kernel `kind` (0/1/2: forward with 16/32/64-row strips, 3: backward) the current
+ * device holds at once with `lds_bytes` of dynamic LDS = hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs (capped at the
+ * blocks per CU the kernel is written for): the number i2p_chain_fwd_ok / i2p_chain_bwd_ok check a grid against. */
+int i2p_chain_set_error_words(float *device_counter, unsigned *host_flag);
+int i2p_chain_resident_blocks(int kind, long long lds_bytes);
 int i2p_chain_fwd(long long rows, int nl, const int *widths, const int *w_ld, const float *x, const float *const *w,
                   const float *const *gamma, const float *const *beta, const float *slopes, float eps, float *const *y,
                   float *const *coef, float *const *mean_invstd, double *sums, int pool_k, float *out, unsigned char *arg,
@@ -550,10 +557,13 @@ int i2p_pair_bias_bn_bwd_bf16(int B, int N, int M, int C, const i2p_bf16 *gz, co
  * :472-476 clip_grad_norm_(max_norm 10)).  n % 4 == 0, buffers 16-byte aligned; grad is replaced by gscale*clip_factor*grad
  * (what the optimiser consumed); step / lr are device scalars (step is advanced by one); mask NULL or [n] of 0/1 (parameters
  * autograd leaves without a gradient take no decay and no update, as torch.optim.Adam skips them); partials: scratch of
- * >= 256 doubles; total_out NULL or [1] = the global norm before clipping.  clip <= 0: no clipping. */
+ * >= 256 doubles; total_out NULL or [1] = the global norm before clipping.  clip <= 0: no clipping.
+ * poison: NULL or device f32 [1]; a non-zero value (the chain kernels' error counter, i2p_chain_set_error_words, which the
+ * trainer carries at the end of the all-reduced gradient buffer) turns the call into a no-op: step, moments and parameters
+ * stay as they are — a step whose gradients came from an abandoned grid barrier is never applied, on any rank. */
 int i2p_clip_adam(long long n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, const float *mask, double *partials,
                   float *step, const float *lr, double beta1, double beta2, float eps, float weight_decay, float clip, float gscale,
-                  float *total_out, void *stream);
+                  float *total_out, const float *poison, void *stream);
 
 /* One-launch replacements for clusters of small elementwise launches (csrc/glue.hip).
  * i2p_row_valid: out[r] = 1.0 if any x[r, 0..c) != 0 else 0.0 — check_valid (src/projectPN/utils.py:106-108).
