@@ -38,6 +38,13 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv &f) {
     return (((n - q) >> 1) + q) >> f.sh;
 }
 
+// Logical block id of the pooling kernels.  A pooled element reads a 3x3 window of the conv output, so vertically adjacent rows share
+// input rows; rows are ~10 blocks apart and the dispatcher places consecutive blocks on consecutive XCDs (b % 8, observed), each with
+// its own L2: every XCD fetched the shared rows again — PMC FETCH_SIZE (profiles/r04_pmc_img_*): 1.53x the conv output in
+// img_pool_fwd at stride 2, 3.1x at stride 1, 1.5-2.2x in img_bwd_dx / img_bwd_stats.  With the swizzle the blocks an XCD runs at a
+// time cover a contiguous band of rows (grids are multiples of 8: grid_for), the shared rows hit in that XCD's L2.
+__device__ __forceinline__ unsigned img_block_id() { return i2p_xcd_swizzle(blockIdx.x, gridDim.x); }
+
 struct PoolGeom {
     int B, H, W, C, s, Ho, Wo, cv, cvs;      // cvs = log2(cv) (cv divides THREADS, so it is a power of two)
     FastDiv fH, fW, fHo, fWo;
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(THREADS) void img_pool_fwd_kernel(PoolGeom g, const
     const long long total = (long long)g.B * g.Ho * g.Wo * g.cv;
     const int vcol = threadIdx.x & (g.cv - 1);              // THREADS % cv == 0 and the grid stride is a multiple of THREADS
     const Coef4 k = load_coef(mean_invstd, gamma, beta, g.C, vcol);
-    for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
+    for (long long t = (long long)img_block_id() * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, ho, wo;
         decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.fHo, g.fWo, b, ho, wo);
         float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(THREADS) void img_bwd_stats_kernel(PoolGeom g, cons
     const int vcol = threadIdx.x & (g.cv - 1);
     const Coef4 k = load_coef(mean_invstd, gamma, beta, g.C, vcol);
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
+    for (long long t = (long long)img_block_id() * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, ho, wo;
         decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.fHo, g.fWo, b, ho, wo);
         const float4 go = gout[t];
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(THREADS) void img_bwd_dx_kernel(PoolGeom g, const f
     float mg[4], mgx[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { mg[i] = dbeta[vcol * 4 + i] / n; mgx[i] = dgamma[vcol * 4 + i] / n; }
-    for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
+    for (long long t = (long long)img_block_id() * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, h, w;
         decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.fH, g.fW, b, h, w);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(THREADS) void img_pool_fwd2_kernel(PoolGeom g, cons
                                                                 float slope, float momentum, const float *__restrict__ conv_bias,
                                                                 float *__restrict__ running_mean, float *__restrict__ running_var,
                                                                 void *__restrict__ out, unsigned char *__restrict__ arg,
-                                                                float *__restrict__ mean_invstd) {
+                                                                float *__restrict__ mean_invstd, int POOL_RC) {
     constexpr int N = YBF ? 8 : 4;
     __shared__ double stat[2 * MAX_C2], part[THREADS];
     block_rep_sums(sums, g.C, stat, part);
@@ -531,38 +538,83 @@ __global__ __launch_bounds__(THREADS) void img_pool_fwd2_kernel(PoolGeom g, cons
                 running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
             }
         }
-    const long long total = (long long)g.B * g.Ho * g.Wo * g.cv;
-    for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
-        int b, ho, wo;
-        decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.fHo, g.fWo, b, ho, wo);
-        float best[N];
-        unsigned bi[N];
+    // Sliding window down a column of outputs (round 4; the round-3 form visited the 3x3 window of every pooled element from scratch:
+    // 9 loads and 9 x N BN + activation evaluations per element — SQ counters, profiles/r04_pmc_img_SQ*.txt: ~500 VALU instructions per
+    // lane and element, the stride-1 blocks were VALU-bound at 2.8 TB/s).  A block owns a tile of POOL_RC output rows x (THREADS / cv)
+    // output columns of one image; a lane walks its column downwards and keeps, per INPUT row, the first maximum over the row's three
+    // window columns (value + column index): stride 1 forms one new row result per output (3 loads, 3 x N evaluations), stride 2 two.
+    // The window maximum = first maximum over the three row results = first maximum in (kh, kw) scan order, NaN propagating to the LAST
+    // NaN, exactly as the flat scan (max_pool2d's rule; bit-exact arg-max against the oracle, tests/test_ops_gpu.py).
+    const int twp = THREADS >> g.cvs;                              // output columns of a tile
+    const int tiles_w = (g.Wo + twp - 1) / twp, chunks_h = (g.Ho + POOL_RC - 1) / POOL_RC;
+    const unsigned ntiles = (unsigned)(g.B * chunks_h * tiles_w);
+    const int wo_l = threadIdx.x >> g.cvs;
+    for (unsigned tile = img_block_id(); tile < ntiles; tile += gridDim.x) {
+        const unsigned bh = tile / (unsigned)tiles_w;
+        const int wt = (int)(tile - bh * (unsigned)tiles_w), b = (int)(bh / (unsigned)chunks_h), hc = (int)(bh - (unsigned)b * (unsigned)chunks_h);
+        const int wo = wt * twp + wo_l;
+        if (wo >= g.Wo) continue;
+        const int ho0 = hc * POOL_RC, ho1 = min(g.Ho, ho0 + POOL_RC);
+        const long long img = (long long)b * g.H;
+        float rv[3][N];
+        unsigned ra[3][N];
+        auto row = [&](int h, float (&v)[N], unsigned (&aw)[N]) {          // first maximum over the window columns of input row h
 #pragma unroll
-        for (int i = 0; i < N; ++i) { best[i] = -INFINITY; bi[i] = 0u; }
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int h = ho * g.s - 1 + kh;
-            if (h < 0 || h >= g.H) continue;
+            for (int i = 0; i < N; ++i) { v[i] = -INFINITY; aw[i] = 0u; }
+            if (h < 0 || h >= g.H) return;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int w = wo * g.s - 1 + kw;
                 if (w < 0 || w >= g.W) continue;
                 float vv[N];
-                ldv<YBF, N>(y, (((long long)b * g.H + h) * g.W + w) * g.cv + vcol, vv);
+                ldv<YBF, N>(y, ((img + h) * g.W + w) * g.cv + vcol, vv);
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
                     const float z = bn_zn<N>(vv[i], k, i);
                     const float a = z > 0.f ? z : z * slope;
-                    if (a > best[i] || a != a) { best[i] = a; bi[i] = (unsigned)(kh * 3 + kw); }   // first max wins
+                    if (a > v[i] || a != a) { v[i] = a; aw[i] = (unsigned)kw; }
                 }
             }
+        };
+        auto emit = [&](int ho) {
+            float best[N];
+            unsigned bi[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) { best[i] = -INFINITY; bi[i] = 0u; }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    if (rv[kh][i] > best[i] || rv[kh][i] != rv[kh][i]) { best[i] = rv[kh][i]; bi[i] = (unsigned)(kh * 3) + ra[kh][i]; }
+            const long long t = (((long long)b * g.Ho + ho) * g.Wo + wo) * g.cv + vcol;
+            stv<OBF, N>(out, t, best);
+            if constexpr (N == 8)
+                reinterpret_cast<uint2 *>(arg)[t] = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24),
+                                                               bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24));
+            else
+                reinterpret_cast<unsigned *>(arg)[t] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        };
+        auto shift = [&](int dst, int src) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { rv[dst][i] = rv[src][i]; ra[dst][i] = ra[src][i]; }
+        };
+        if (g.s == 1) {
+            row(ho0 - 1, rv[0], ra[0]);
+            row(ho0, rv[1], ra[1]);
+            for (int ho = ho0; ho < ho1; ++ho) {
+                row(ho + 1, rv[2], ra[2]);
+                emit(ho);
+                shift(0, 1); shift(1, 2);
+            }
+        } else {
+            row(2 * ho0 - 1, rv[0], ra[0]);
+            for (int ho = ho0; ho < ho1; ++ho) {
+                row(2 * ho, rv[1], ra[1]);
+                row(2 * ho + 1, rv[2], ra[2]);
+                emit(ho);
+                shift(0, 2);
+            }
         }
-        stv<OBF, N>(out, t, best);
-        if constexpr (N == 8)
-            reinterpret_cast<uint2 *>(arg)[t] = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24),
-                                                           bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24));
-        else
-            reinterpret_cast<unsigned *>(arg)[t] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
     }
 }
 
@@ -579,7 +631,7 @@ __global__ __launch_bounds__(THREADS) void img_bwd_stats2_kernel(PoolGeom g, con
     double s[N], q[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { s[i] = 0.0; q[i] = 0.0; }
-    for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
+    for (long long t = (long long)img_block_id() * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, ho, wo;
         decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.fHo, g.fWo, b, ho, wo);
         float gv[N];
@@ -630,7 +682,7 @@ __global__ __launch_bounds__(THREADS) void img_bwd_dx2_kernel(PoolGeom g, const 
     float mg[N], mgx[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { mg[i] = (float)stat[vcol * N + i] / n; mgx[i] = (float)stat[g.C + vcol * N + i] / n; }
-    for (long long t = (long long)blockIdx.x * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
+    for (long long t = (long long)img_block_id() * THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * THREADS) {
         int b, h, w;
         decode<WIDE>((typename Idx<WIDE>::type)t, g.cvs, g.fH, g.fW, b, h, w);
         float acc[N];
@@ -684,11 +736,11 @@ PoolGeom make_geom(int B, int H, int W, int C, int s) {
     return g;
 }
 
-unsigned grid_for(long long total, int cap) {
+unsigned grid_for(long long total, int cap) {      // a multiple of 8 (img_block_id): surplus blocks find t >= total and leave
     long long b = (total + THREADS - 1) / THREADS;
     if (b > cap) b = cap;
     if (b < 1) b = 1;
-    return (unsigned)b;
+    return (unsigned)((b + 7) & ~7LL);
 }
 
 }  // namespace
@@ -831,8 +883,14 @@ extern "C" int i2p_img_block_fwd(int B, int H, int W, int C, int stride, int y_b
         hipLaunchKernelGGL(img_stats2_kernel<false>, dim3((unsigned)blocks), dim3(THREADS), 0, st, n, C, g.cv, rpb, y, sums);
     const long long total = (long long)B * g.Ho * g.Wo * g.cv;
     const bool wide = n * g.cv >= (1ll << 31);
-    IMG_DISPATCH(img_pool_fwd2_kernel, dim3(grid_for(total, gen2_grid(1 << 12))), g, y, (const double *)sums, gamma, beta, eps, slope, momentum,
-                 conv_bias, running_mean, running_var, out, arg, mean_invstd);
+    // tiles of rc output rows x (THREADS / cv) output columns; rc = 8 while that still gives >= 2048 tiles (the small late blocks: fewer rows)
+    const int twp = THREADS / g.cv, tiles_w = (g.Wo + twp - 1) / twp;
+    int rc = 8;
+    while (rc > 1 && (long long)B * ((g.Ho + rc - 1) / rc) * tiles_w < 2048) rc >>= 1;
+    const long long tiles = (long long)B * ((g.Ho + rc - 1) / rc) * tiles_w;
+    (void)total;
+    IMG_DISPATCH(img_pool_fwd2_kernel, dim3(grid_for(tiles * THREADS, gen2_grid(1 << 14))), g, y, (const double *)sums, gamma, beta, eps, slope, momentum,
+                 conv_bias, running_mean, running_var, out, arg, mean_invstd, rc);
     I2P_RETURN_LAUNCH_STATUS();
 }
 

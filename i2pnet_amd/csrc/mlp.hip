@@ -852,13 +852,11 @@ int dispatch_fwd2(const LinFwdParams &p_in, hipStream_t st) {
     const int wide = p.cin > p.cout ? p.cin : p.cout;      // channels a strip row holds (input and output phases)
     static const char *env = getenv("I2P_LIN_CH");          // diagnostic: 8 = always the wide instantiation
     const bool narrow_ok = !PAIR && !(env && env[0] == '8');
-    const bool ch2 = narrow_ok && wide <= 32, ch4 = false;   // (4-chunk instantiations spill at 128 VGPRs and measure no faster: unused)
+    const bool ch2 = narrow_ok && wide <= 32;               // (a 4-chunk instantiation spilled at its 128 VGPRs and measured no faster: removed)
     switch (p.cout_p / 16) {
-        case 1: return ch2 ? launch_fwd2<1, PAIR, DGRAD, 2>(p, st) : ch4 ? launch_fwd2<1, PAIR, DGRAD, 4>(p, st)
-                                                                         : launch_fwd2<1, PAIR, DGRAD, 8>(p, st);
-        case 2: return ch2 ? launch_fwd2<2, PAIR, DGRAD, 2>(p, st) : ch4 ? launch_fwd2<2, PAIR, DGRAD, 4>(p, st)
-                                                                         : launch_fwd2<2, PAIR, DGRAD, 8>(p, st);
-        case 4: return ch4 ? launch_fwd2<4, PAIR, DGRAD, 4>(p, st) : launch_fwd2<4, PAIR, DGRAD, 8>(p, st);
+        case 1: return ch2 ? launch_fwd2<1, PAIR, DGRAD, 2>(p, st) : launch_fwd2<1, PAIR, DGRAD, 8>(p, st);
+        case 2: return ch2 ? launch_fwd2<2, PAIR, DGRAD, 2>(p, st) : launch_fwd2<2, PAIR, DGRAD, 8>(p, st);
+        case 4: return launch_fwd2<4, PAIR, DGRAD, 8>(p, st);
         case 8: return launch_fwd2<8, PAIR, DGRAD, 8>(p, st);
         default: return I2P_ERR_BAD_ARG;
     }
@@ -2103,7 +2101,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
             }
             const bool two_ok = !two || (in_coef && two->in_coef_b && two->split_c * 2 == cin && cin == 128 && two->slope_b >= 0.f && two->slope_b <= 1.f);
             if (two_ok && out_coef && p.slope_out == 1.f && slope_in >= 0.f && slope_in <= 1.f && grid == 256 &&
-                i2p_wreg_wgrad_ok(rows, cin, cout)) {
+                (in_coef || !(cin == 128 && cout == 128)) && i2p_wreg_wgrad_ok(rows, cin, cout)) {
                 // wide layer on many rows: the [cout][cin] accumulators stationary in registers (csrc/mlp_wreg.hip)
                 const int rc = i2p_wreg_wgrad(rows, cin, cout, gz, y, out_dsums, out_coef, out_mi, rows, g_coef, x, in_coef, slope_in,
                                               two ? two->xb : nullptr, two ? two->in_coef_b : nullptr, two ? two->slope_b : 1.f,

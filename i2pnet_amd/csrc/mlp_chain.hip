@@ -159,23 +159,23 @@ struct Strip {              // what a block knows about its 64-row strip
     long long row0;
 };
 
-// input strip: x rows (coalesced 16-byte loads, eight in flight per thread), zero beyond the row / column range up to the next multiple
+// input strip: x rows (coalesced 16-byte loads, DEPTH in flight per thread), zero beyond the row / column range up to the next multiple
 // of 16; thread = (row of a pass, 16-byte column): no division per element
-template <int RT>
+template <int RT, int DEPTH>
 __device__ __forceinline__ void load_x_strip(const ChainP &p, const Strip &s) {
     constexpr int FR = 16 * RT;
     const int c0 = p.c[0], kp = (c0 + 15) & ~15, v = kp >> 2, rpp = CH_THREADS / v, tr = s.tid / v, c4 = (s.tid - tr * v) * 4;
     if (tr < rpp) {
-        for (int rb = tr; rb < FR; rb += 8 * rpp) {
-            f32x4 buf[8];
+        for (int rb = tr; rb < FR; rb += DEPTH * rpp) {
+            f32x4 buf[DEPTH];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < DEPTH; ++u) {
                 const int r = rb + u * rpp;
                 buf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (r < s.nvalid && c4 < c0) buf[u] = *reinterpret_cast<const f32x4 *>(p.x + (size_t)(s.row0 + r) * c0 + c4);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < DEPTH; ++u) {
                 const int r = rb + u * rpp;
                 if (r < FR) *reinterpret_cast<f32x4 *>(s.A + (size_t)r * s.lda + c4) = buf[u];
             }
@@ -214,16 +214,18 @@ __device__ __forceinline__ void apply_strip(const ChainP &p, const Strip &s, int
 // Layer l on the strip: wave `wave` computes columns [wave*16*NT, (wave+1)*16*NT) for the four 16-row tiles, so a block reads W exactly
 // once.  The first batch of W is requested FIRST and rides out the input phase (the x strip's loads for layer 0, the BN + activation
 // pass over the previous layer's strip otherwise); afterwards the next batch is in flight while a batch's 16 * BC * NT MFMAs run.
-template <int NT, int RT>
+template <int NT, int RT, int XD>
 __device__ __forceinline__ void layer_step(const ChainP &p, const Strip &s, int l, int wave, int i, int q) {
     const int kpad = (p.c[l] + 15) & ~15, w_ld = p.w_ld[l], lda = s.lda;
     const float *W = p.w[l];
     const bool w_vec = (w_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
     float *A = s.A;
-    constexpr int BC = NT <= 2 ? 4 : 2;                  // 16-element chunks per weight batch (registers: 2 * BC * NT float4)
+    // 16-element chunks per weight batch (registers: 2 * BC * NT float4); 64-row strips with 3-4 column tiles per wave take ONE chunk: with
+    // two the kernel spilled 9-36 registers at the 256 of two blocks per CU
+    constexpr int BC = NT <= 2 ? 4 : (RT < 4 ? 2 : 1);
     f32x4 cur[BC * NT], nxt[BC * NT];
     load_wbatch<NT, BC>(cur, W, w_ld, w_vec, 0, kpad, wave, i, q, p.abl);
-    if (l == 0) load_x_strip<RT>(p, s); else apply_strip<RT>(p, s, l - 1);
+    if (l == 0) load_x_strip<RT, XD>(p, s); else apply_strip<RT>(p, s, l - 1);
     __syncthreads();
     f32x4 acc[RT][NT];
 #pragma unroll
@@ -262,8 +264,12 @@ __device__ __forceinline__ void layer_step(const ChainP &p, const Strip &s, int 
     __syncthreads();
 }
 
-template <int RT>
+// W3: the instantiation that also takes 192-wide layers (three column tiles per wave).  Kept apart because with all four tile counts in
+// one function the 64-row kernel sat 7 registers above the 256 of two blocks per CU (three 64-bit address bases spilled in the
+// prologue); the W3 one loads the x strip four rows deep instead of eight to stay inside.  No layer of the network is 192 wide.
+template <int RT, bool W3>
 __global__ __launch_bounds__(CH_THREADS, 2) void chain_fwd_kernel(ChainP p) {
+    constexpr int XD = (W3 && RT == 4) ? 4 : 8;
     constexpr int FR = 16 * RT;                          // rows of a strip: 16, 32 or 64 (chain_fwd_rows)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     Strip s;
@@ -291,10 +297,10 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_fwd_kernel(ChainP p) {
         float gam = 0.f, bet = 0.f;
         if (tid < cout) { gam = p.gamma[l][tid]; bet = p.beta[l][tid]; }
         switch (cout >> 6) {
-            case 1: layer_step<1, RT>(p, s, l, wave, i, q); break;
-            case 2: layer_step<2, RT>(p, s, l, wave, i, q); break;
-            case 3: layer_step<3, RT>(p, s, l, wave, i, q); break;
-            default: layer_step<4, RT>(p, s, l, wave, i, q); break;
+            case 1: layer_step<1, RT, XD>(p, s, l, wave, i, q); break;
+            case 2: layer_step<2, RT, XD>(p, s, l, wave, i, q); break;
+            case 3: if constexpr (W3) layer_step<3, RT, XD>(p, s, l, wave, i, q); break;
+            default: layer_step<4, RT, XD>(p, s, l, wave, i, q); break;
         }
         // column sums of the strip (rows beyond the range are exact zeros): 256 / cout row groups in parallel, combined through LDS,
         // then one atomic per block, column and moment
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void chain_fwd_kernel(ChainP p) {
 //   P3  g^y = scale_l * (t - m1 - xhat_l * m2) in place (y_l strip re-read: L2-hot)           [BN backward, batch statistics]
 //   P4  a_{l-1} strip = act(bn_{l-1}(y_{l-1})) (or the x strip) into LDS buffer Q
 //   P5  dW_l partial of the strip = (g^y)^T a_{l-1} on MFMA (64-row contraction) -> this block's slab of dw_part
-//   P6  G_{l-1} = g^y W_l on MFMA (W from L2) -> replaces P (or goes to gx for the first layer)
+//   P6  G_{l-1} = g^y W_l on MFMA (W from L2) -> into Q, whose a_{l-1} is consumed; P and Q swap roles (gx for the first layer)
 // chain_reduce_kernel then sums the slabs in block order (deterministic), all layers of the chain in one launch.
 struct ChainBP {
     long long rows;
@@ -405,8 +411,7 @@ struct BStrip {
     long long row0;
 };
 
-// RB = rows of a strip (64 dispatched; see chain_bwd_rb).  The backward runs ONE block = four waves per CU, one wave per SIMD: the whole
-// register file per wave.
+// RB = rows of a strip (64).  P / Q of the phase functions = the kernel's two strips in their current roles (gradient / other).
 
 // P1: see above.  `first`: G_L comes from p.g (dense, or un-pooled on the fly from the arg-max bytes) instead of P.
 template <int RB>
@@ -552,161 +557,126 @@ __device__ __forceinline__ void bwd_p4(const ChainBP &p, const BStrip &s, int l)
     }
 }
 
-// P5: dW partial [c_out][w_ld] = (g^y)^T a_in over the strip's RB rows.  Wave w owns output-channel tiles w*NTM .. w*NTM+NTM-1 and walks
-// the input-channel tiles; A = g^y transposed out of P (the compiler keeps the wave's A fragments in registers across the walk), B =
-// a_in out of Q (one LDS word per k-step and lane).
-template <int NTM, int RB>
-__device__ __forceinline__ void bwd_wgrad(const ChainBP &p, const BStrip &s, int l, int wave, int i, int q) {
-    const int kp = (p.c[l] + 15) & ~15, ntiles = kp >> 4, w_ld = p.w_ld[l];
+// ---- P5 / P6 and the kernel: run-time tile loops, ping-pong LDS strips, two blocks per CU -------------------------------------------
+// (Round 3 ran these phases as one fully unrolled function over all (input-gradient tiles x weight-gradient tiles) variants with the
+// input gradient's accumulators held across the weight gradient: the whole register file (256 + 256), 158 spilled dwords per lane, one
+// block per CU — the 456-block level-3 chain did not fit.  Measured against this form on one box (tools/time_chain.py, forward +
+// backward, us): 14 848 x 128-64-64 164.7 vs 162.2, 14 592 x 128-64 125.6 vs 123.9, level 3 not taken vs 183.5 (layer kernels 190.1);
+// the 256-wide chains 226.9 vs 260.8 — those go back to the layer kernels (235), see chain_bwd_fits.)
+//   P1 .. P4 as above (G = gradient strip, O = the other strip),
+//   weight gradient: a wave walks its output-channel tiles; per tile the 16 A fragments of g^y^T (LDS words) stay in registers, per
+//     input-channel tile 16 B words of a_in and 16 MFMAs -> the block's slab,
+//   sync (O is free now: a_in was only read by the weight gradient),
+//   input gradient: a wave walks the input-channel tiles w, w+4, ...; per tile 4 accumulators, g^y as float4 A operands from G, W as
+//     dwords from L2 with the next 16-chunk requested under the current one's MFMAs; the finished tile goes STRAIGHT into O (or to
+//     gx for the first layer) — no accumulators waiting for the other phase, no copy-back phase,
+//   sync, swap (G, O).
+// 213 registers, no scratch; LDS = 2 strips of the widest tensor: two blocks per CU for chains up to 128 wide (level 3, the resampling
+// set conv, the narrow up-convolution).
+template <int RB>
+__device__ __forceinline__ void bwd_wgrad(const ChainBP &p, const float *__restrict__ G, const float *__restrict__ O, int ld, int l, int wave,
+                                           int i, int q) {
+    const int cin_p = (p.c[l] + 15) & ~15, ntiles = cin_p >> 4, cout = p.c[l + 1], w_ld = p.w_ld[l], ntm = cout >> 6;
     float *part = p.dw_part + (size_t)blockIdx.x * p.tw + p.w_off[l];
-    for (int nt = 0; nt < ntiles; ++nt) {
-        f32x4 acc[NTM];
+    for (int tt = 0; tt < ntm; ++tt) {
+        const int m0 = (wave * ntm + tt) * 16;
+        float a[RB / 16][4];
 #pragma unroll
-        for (int t = 0; t < NTM; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < RB / 16; ++kc)
 #pragma unroll
-        for (int kc = 0; kc < RB / 16; ++kc) {
-            float b[4];
+            for (int e = 0; e < 4; ++e) a[kc][e] = G[(size_t)(16 * kc + 4 * q + e) * ld + m0 + i];
+        for (int nt = 0; nt < ntiles; ++nt) {
+            float b[RB / 16][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) b[e] = s.Q[(size_t)(16 * kc + 4 * q + e) * s.ldq + nt * 16 + i];
+            for (int kc = 0; kc < RB / 16; ++kc)
 #pragma unroll
-            for (int t = 0; t < NTM; ++t) {
-                const int m0 = (wave * NTM + t) * 16;
+                for (int e = 0; e < 4; ++e) b[kc][e] = O[(size_t)(16 * kc + 4 * q + e) * ld + nt * 16 + i];
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a = s.P[(size_t)(16 * kc + 4 * q + e) * s.ldp + m0 + i];
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[e], acc[t], 0, 0, 0);
-                }
+            for (int kc = 0; kc < RB / 16; ++kc)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc][e], b[kc][e], acc, 0, 0, 0);
+            const int n = nt * 16 + i;
+            if (n < w_ld) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[(size_t)(m0 + 4 * q + e) * w_ld + n] = acc[e];
             }
-        }
-        const int n = nt * 16 + i;
-        if (n < w_ld) {
-#pragma unroll
-            for (int t = 0; t < NTM; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) part[(size_t)((wave * NTM + t) * 16 + 4 * q + e) * w_ld + n] = acc[t][e];
         }
     }
 }
 
 template <int RB>
-__device__ __forceinline__ void bwd_wgrad_rt(const ChainBP &p, const BStrip &s, int l, int wave, int i, int q) {
-    if (p.abl & 1) return;
-    switch (p.c[l + 1] >> 6) {
-        case 1: bwd_wgrad<1, RB>(p, s, l, wave, i, q); break;
-        case 2: bwd_wgrad<2, RB>(p, s, l, wave, i, q); break;
-        case 3: bwd_wgrad<3, RB>(p, s, l, wave, i, q); break;
-        default: bwd_wgrad<4, RB>(p, s, l, wave, i, q); break;
-    }
-}
-
-// P3 .. P6 of layer l.  NTN > 0: G_in [RB][c_in] = g^y W on MFMA; wave w owns input-channel tiles w, w+4, ... (NTN of them at most) and
-// reads W as 64-byte runs of its rows.  The first weight batch is requested before the element-wise passes P3 / P4 and the next batch
-// is in flight under a batch's MFMAs; the result waits in registers while the weight gradient (P5) still reads g^y from P.
-template <int NTN, int RB>
-__device__ __forceinline__ void bwd_step(const ChainBP &p, const BStrip &s, int l, int wave, int i, int q) {
-    constexpr int RT = RB / 16, NB = NTN > 0 ? NTN : 1, BC = NTN <= 2 ? 4 : 2;
-    const int cin = p.c[l], kp = (cin + 15) & ~15, ntiles = kp >> 4, cout = p.c[l + 1], w_ld = p.w_ld[l];
+__device__ __forceinline__ void bwd_dgrad(const ChainBP &p, const float *__restrict__ G, float *__restrict__ O, int ld, int l, int wave, int i,
+                                           int q, int nvalid, long long row0) {
+    constexpr int RT = RB / 16;
+    const int cin = p.c[l], cin_p = (cin + 15) & ~15, ntiles = cin_p >> 4, cout = p.c[l + 1], w_ld = p.w_ld[l];
     const float *W = p.w[l];
-    auto loadw = [&](int kb, f32x4 (&b)[BC * NB]) {
+    for (int nt = wave; nt < ntiles; nt += 4) {
+        const int n = nt * 16 + i;
+        const bool n_ok = n < w_ld;
+        auto loadw = [&](int k0, float (&b)[4]) {
 #pragma unroll
-        for (int j = 0; j < BC; ++j) {
-            const int k0 = kb + 16 * j;
+            for (int e = 0; e < 4; ++e) b[e] = n_ok ? W[(size_t)(k0 + 4 * q + e) * w_ld + n] : 0.f;
+        };
+        float cur[4], nxt[4];
+        loadw(0, cur);
+        f32x4 acc[RT];
 #pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                const int n = (wave + 4 * t) * 16 + i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (k0 < cout && wave + 4 * t < ntiles && n < w_ld) {
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < cout; k0 += 16) {
+            if (k0 + 16 < cout) loadw(k0 + 16, nxt);
+            f32x4 a[RT];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = W[(size_t)(k0 + 4 * q + e) * w_ld + n];
-                }
-                b[j * NB + t] = v;
-            }
+            for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4 *>(G + (size_t)(rt * 16 + i) * ld + k0 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][e], cur[e], acc[rt], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
         }
-    };
-    f32x4 cur[BC * NB], nxt[BC * NB];
-    if (NTN > 0) loadw(0, cur);
-    bwd_p3<RB>(p, s, l);
-    bwd_p4<RB>(p, s, l);
-    __syncthreads();
-    f32x4 acc[RT][NB];
-    if (NTN > 0) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int t = 0; t < NB; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kb = 0; kb < ((p.abl & 2) ? 0 : cout); kb += 16 * BC) {
-            if (kb + 16 * BC < cout) loadw(kb + 16 * BC, nxt);
-#pragma unroll
-            for (int j = 0; j < BC; ++j) {
-                const int k0 = kb + 16 * j;
-                if (k0 < cout) {
-                    f32x4 a[RT];
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4 *>(s.P + (size_t)(rt * 16 + i) * s.ldp + k0 + 4 * q);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                            for (int t = 0; t < NB; ++t)
-                                acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][e], cur[j * NB + t][e], acc[rt][t], 0, 0, 0);
-                }
+            for (int e = 0; e < 4; ++e) {
+                const int r = rt * 16 + 4 * q + e;
+                if (l) O[(size_t)r * ld + n] = acc[rt][e];
+                else if (r < nvalid && n < cin) p.gx[(size_t)(row0 + r) * cin + n] = acc[rt][e];
             }
-#pragma unroll
-            for (int u = 0; u < BC * NB; ++u) cur[u] = nxt[u];
-        }
-    }
-    bwd_wgrad_rt<RB>(p, s, l, wave, i, q);
-    __syncthreads();                                     // every wave is done with g^y in P and a_in in Q
-    if (NTN > 0) {
-#pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            const int n = (wave + 4 * t) * 16 + i;
-            if (wave + 4 * t >= ntiles) continue;
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = rt * 16 + 4 * q + e;
-                    if (l) s.P[(size_t)r * s.ldp + n] = acc[rt][t][e];
-                    else if (r < s.nvalid && n < cin) p.gx[(size_t)(s.row0 + r) * cin + n] = acc[rt][t][e];
-                }
-        }
-        __syncthreads();
     }
 }
 
 template <int RB>
-__global__ __launch_bounds__(CH_THREADS) void chain_bwd_kernel(ChainBP p) {
+__global__ __launch_bounds__(CH_THREADS, 2) void chain_bwd_kernel(ChainBP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int ld = p.ldp;                                   // both strips: rows of the widest tensor of the chain (+4)
+    float *G = smem, *O = smem + (size_t)RB * ld;
     BStrip s;
-    s.P = smem;
-    s.Q = smem + (size_t)RB * p.ldp;
-    s.tab = s.Q + (size_t)RB * p.ldq;                     // [2][256]: m1, m2 of the current layer
+    s.tab = smem + 2 * (size_t)RB * ld;                     // [2][256]: m1, m2 of the current layer
     unsigned *s_ok = reinterpret_cast<unsigned *>(s.tab + 512);
-    bool alive = true;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
-    s.ldp = p.ldp; s.ldq = p.ldq; s.tid = tid;
+    s.ldp = ld; s.ldq = ld; s.tid = tid;
     s.row0 = (long long)blockIdx.x * RB;
     s.nvalid = (int)((p.rows - s.row0) < RB ? (p.rows - s.row0) : RB);
-    const unsigned G = gridDim.x;
-
+    const unsigned nblocks = gridDim.x;
+    bool alive = true;
     for (int l = p.nl - 1; l >= 0; --l) {
+        s.P = G; s.Q = O;
         bwd_p1<RB>(p, s, l, l == p.nl - 1);
-        if (!(p.abl & 8) && alive) alive = grid_barrier(p.sync, (unsigned)(p.nl - l), G, tid, p.err, s_ok, p.abl); else __syncthreads();
+        if (!(p.abl & 8) && alive) alive = grid_barrier(p.sync, (unsigned)(p.nl - l), nblocks, tid, p.err, s_ok, p.abl); else __syncthreads();
         bwd_p2(p, s, l);
-        const int ntn = (l || p.gx) ? ((((p.c[l] + 15) & ~15) >> 4) + 3) >> 2 : 0;
-        switch (ntn) {
-            case 0: bwd_step<0, RB>(p, s, l, wave, i, q); break;
-            case 1: bwd_step<1, RB>(p, s, l, wave, i, q); break;
-            case 2: bwd_step<2, RB>(p, s, l, wave, i, q); break;
-            case 3: bwd_step<3, RB>(p, s, l, wave, i, q); break;
-            default: bwd_step<4, RB>(p, s, l, wave, i, q); break;
-        }
+        bwd_p3<RB>(p, s, l);
+        bwd_p4<RB>(p, s, l);
+        __syncthreads();
+        if (!(p.abl & 1)) bwd_wgrad<RB>(p, G, O, ld, l, wave, i, q);
+        __syncthreads();                                    // a_in (O) is consumed: the input gradient may overwrite it
+        if ((l || p.gx) && !(p.abl & 2)) bwd_dgrad<RB>(p, G, O, ld, l, wave, i, q, s.nvalid, s.row0);
+        __syncthreads();
+        float *t = G; G = O; O = t;
     }
     if (tid == 0) {
         const unsigned t = __hip_atomic_fetch_add(p.sync + CH_EXIT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == G - 1)
+        if (t == nblocks - 1)
             for (int j = 0; j <= 2 * CH_NG + 1; ++j) __hip_atomic_store(p.sync + j * CH_LINE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -750,13 +720,12 @@ void chain_bwd_ld(int nl, const int *widths, int &ldp, int &ldq) {
     ldp = mp + 4; ldq = (mq < 32 ? 32 : mq) + 4;
 }
 
-size_t chain_bwd_lds_bytes(int rb, int ldp, int ldq) { return ((size_t)rb * (ldp + ldq) + 512 + 4) * sizeof(float); }
+int chain_cus();
 
 // ---- residency: what the launcher checks a grid against (VERDICT r3 #1b) -----------------------------------------------------------
-// Blocks of kernel `kind` (0 / 1 / 2: chain_fwd_kernel<1 / 2 / 4>, 3: chain_bwd_kernel<64>, 4: chain_bwd_kernel<128>) the CURRENT device
+// Blocks of kernel `kind` (0 / 1 / 2: chain_fwd_kernel<1 / 2 / 4>, 3: chain_bwd_kernel<64>) the CURRENT device
 // holds at once with `lds` bytes of dynamic LDS: hipOccupancyMaxActiveBlocksPerMultiprocessor (registers, LDS, waves) x CUs of that
-// device, capped by the blocks per CU the kernel is written for (launch bounds: two for the forward, one wave per SIMD for the
-// backward) and by the 256-thread admission rule of MI355X_MICROARCH.md (min(API, 8, 800 / (ceil(sgpr / 16) * 16 + 16)): 6 at the 106
+// device, capped by the blocks per CU the kernels are written for (launch bounds: two) and by the 256-thread admission rule of MI355X_MICROARCH.md (min(API, 8, 800 / (ceil(sgpr / 16) * 16 + 16)): 6 at the 106
 // SGPRs of these kernels — above the caps).  Cached per (device, kind, lds).  A plain launch of a grid within this number has the
 // same residency as a cooperative launch of it (same guide: hipLaunchCooperativeKernel adds only the check made here, at +15-19 us
 // per launch); what the query cannot see — a CU mask, another process on the GPU, a second chain launch on another stream — is what
@@ -782,11 +751,11 @@ DevState *chain_dev() {
         d.cus = prop.multiProcessorCount;
     }
     if (!d.attr_set) {                 // (function attributes are per device)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define CH_SET_LDS(K) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        CH_SET_LDS((chain_fwd_kernel<4, false>)); CH_SET_LDS((chain_fwd_kernel<2, false>)); CH_SET_LDS((chain_fwd_kernel<1, false>));
+        CH_SET_LDS((chain_fwd_kernel<4, true>)); CH_SET_LDS((chain_fwd_kernel<2, true>)); CH_SET_LDS((chain_fwd_kernel<1, true>));
+#undef CH_SET_LDS
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chain_bwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         d.attr_set = true;
     }
     return &d;
@@ -799,12 +768,11 @@ int chain_resident(int kind, size_t lds) {
     if (!d || lds > 160 * 1024) return 0;
     for (int i = 0; i < d->ncache; ++i)
         if (d->cache[i].kind == kind && d->cache[i].lds == lds) return d->cache[i].blocks;
-    const void *fn = kind == 0 ? reinterpret_cast<const void *>(chain_fwd_kernel<1>) : kind == 1 ? reinterpret_cast<const void *>(chain_fwd_kernel<2>)
-                   : kind == 2 ? reinterpret_cast<const void *>(chain_fwd_kernel<4>) : kind == 3 ? reinterpret_cast<const void *>(chain_bwd_kernel<64>)
-                   : reinterpret_cast<const void *>(chain_bwd_kernel<128>);
+    const void *fn = kind == 0 ? reinterpret_cast<const void *>(chain_fwd_kernel<1, true>) : kind == 1 ? reinterpret_cast<const void *>(chain_fwd_kernel<2, true>)
+                   : kind == 2 ? reinterpret_cast<const void *>(chain_fwd_kernel<4, true>) : reinterpret_cast<const void *>(chain_bwd_kernel<64>);
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, CH_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
-    const int cap = kind <= 2 ? 2 : 1;
+    const int cap = 2;
     per_cu = per_cu > cap ? cap : per_cu;
     const int blocks = per_cu * d->cus;
     if (d->ncache < 32) d->cache[d->ncache++] = ResKey{kind, lds, blocks};
@@ -822,15 +790,16 @@ ChainErr chain_err() {
     return e;
 }
 
-// rows of a backward strip: 64 when that grid is resident at ONE block per CU; 0 = not taken.  (A 128-row instantiation for the
-// 29 184-row level-3 chain exists — chain_bwd_kernel<128> — but its register allocation spills 568 VGPRs and measured 269 vs 179 us:
-// not dispatched.  Chains under 8192 rows are not taken either: the separate slab reduction launch costs them more than the
-// layer-by-layer launches they would save — 48 vs 38 us forward + backward on 928 .. 1824 rows, tools/time_chain.py.)
-int chain_bwd_rb(long long rows, int ldp, int ldq) {
-    if (rows < 8192) return 0;
-    const size_t lds = chain_bwd_lds_bytes(64, ldp, ldq);
-    if (lds > 160 * 1024) return 0;
-    return ((rows + 63) / 64 <= chain_resident(3, lds) || (chain_force_nonresident() && chain_cus() > 0)) ? 64 : 0;
+// The one-launch backward: both LDS strips as wide as the widest tensor of the chain; taken where TWO blocks per CU fit (chains up to
+// 128 wide) and the grid is resident.  Chains under 8192 rows are not taken: the separate slab reduction launch costs them more than
+// the layer-by-layer launches they would save (48 vs 38 us forward + backward on 928 .. 1824 rows, tools/time_chain.py); wider chains
+// (one block per CU) measured slower than the layer kernels (260.8 vs 235 us, 14 848 x 128-128-256).
+size_t chain_bwd_lds_bytes(int ldp, int ldq) { const int ld = ldp > ldq ? ldp : ldq; return ((size_t)2 * 64 * ld + 512 + 4) * sizeof(float); }
+bool chain_bwd_fits(long long rows, int ldp, int ldq) {
+    if (rows < 8192) return false;
+    const size_t lds = chain_bwd_lds_bytes(ldp, ldq);
+    if (2 * lds > 160 * 1024) return false;
+    return (rows + 63) / 64 <= chain_resident(3, lds) || (chain_force_nonresident() && chain_cus() > 0);
 }
 
 int chain_cmax(int nl, const int *widths) {
@@ -882,7 +851,7 @@ extern "C" int i2p_chain_set_error_words(float *device_counter, unsigned *host_f
 }
 
 extern "C" int i2p_chain_resident_blocks(int kind, long long lds_bytes) {
-    return (kind < 0 || kind > 4 || lds_bytes < 0) ? 0 : chain_resident(kind, (size_t)lds_bytes);
+    return (kind < 0 || kind > 3 || lds_bytes < 0) ? 0 : chain_resident(kind, (size_t)lds_bytes);
 }
 
 // uint32 words of zeroed scratch behind `sync`; word i2p_chain_sync_words() - 32 is the error word
@@ -921,9 +890,12 @@ extern "C" int i2p_chain_fwd(long long rows, int nl, const int *widths, const in
     const int fr = chain_fwd_rows(rows, cmax, pool_k);
     const size_t bytes = chain_lds_bytes(cmax, fr);
     const unsigned grid = (unsigned)((rows + fr - 1) / fr);
-    if (fr == 16) hipLaunchKernelGGL(chain_fwd_kernel<1>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
-    else if (fr == 32) hipLaunchKernelGGL(chain_fwd_kernel<2>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(chain_fwd_kernel<4>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
+    bool w3 = false;
+    for (int l = 1; l <= nl; ++l) w3 = w3 || widths[l] == 192;
+#define CH_LAUNCH(RT) do { if (w3) hipLaunchKernelGGL((chain_fwd_kernel<RT, true>), dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p); \
+                           else hipLaunchKernelGGL((chain_fwd_kernel<RT, false>), dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p); } while (0)
+    if (fr == 16) CH_LAUNCH(1); else if (fr == 32) CH_LAUNCH(2); else CH_LAUNCH(4);
+#undef CH_LAUNCH
     I2P_RETURN_LAUNCH_STATUS();
 }
 
@@ -936,7 +908,7 @@ extern "C" int i2p_chain_bwd_ok(long long rows, int nl, const int *widths, int p
     if (pool_k < 0 || pool_k > 255 || (pool_k && rows % pool_k)) return 0;
     int ldp, ldq;
     chain_bwd_ld(nl, widths, ldp, ldq);
-    return chain_bwd_rb(rows, ldp, ldq) ? 1 : 0;
+    return chain_bwd_fits(rows, ldp, ldq) ? 1 : 0;
 }
 
 // floats of one block's weight-gradient slab (= of the reduced `dw` buffer): layer l's [widths[l+1]][w_ld[l]] block starts at the sum
@@ -971,11 +943,10 @@ extern "C" int i2p_chain_bwd(long long rows, int nl, const int *widths, const in
     p.tw = off;
     if ((off & 3) || ((reinterpret_cast<uintptr_t>(dw_part) | reinterpret_cast<uintptr_t>(dw)) & 15)) return I2P_ERR_BAD_ARG;
     chain_bwd_ld(nl, widths, p.ldp, p.ldq);
-    const int rb = chain_bwd_rb(rows, p.ldp, p.ldq);
-    const size_t bytes = chain_bwd_lds_bytes(rb, p.ldp, p.ldq);
-    const unsigned grid = (unsigned)((rows + rb - 1) / rb);
-    if (rb == 64) hipLaunchKernelGGL(chain_bwd_kernel<64>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(chain_bwd_kernel<128>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
+    const unsigned grid = (unsigned)((rows + 63) / 64);
+    const size_t bytes = chain_bwd_lds_bytes(p.ldp, p.ldq);
+    p.ldp = p.ldq = p.ldp > p.ldq ? p.ldp : p.ldq;
+    hipLaunchKernelGGL(chain_bwd_kernel<64>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
     const int n4 = off >> 2;
     hipLaunchKernelGGL(chain_reduce_kernel, dim3((n4 + 15) / 16), dim3(256), 0, (hipStream_t)stream, (int)grid, n4,
                        reinterpret_cast<const float4 *>(dw_part), reinterpret_cast<float4 *>(dw));

@@ -718,7 +718,13 @@ int launch_wreg_wgrad(const WregWgradP &p, unsigned grid, hipStream_t st) {
     }
     if (p.xb) return I2P_ERR_BAD_ARG;
     if (p.in_coef) hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, true, false>), dim3(grid), dim3(WR_THREADS), 0, st, p);
-    else hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, false, false>), dim3(grid), dim3(WR_THREADS), 0, st, p);
+    else {
+        // 128 x 128 without an input BN is not instantiated: with the 256 accumulators it kept 13 operand registers in scratch INSIDE
+        // the strip loop (profiles/r04_resource_usage_start.txt); no layer of the network has that shape (i2p_wreg_wgrad_ok's caller
+        // falls back to lin_wgrad_kernel)
+        if constexpr (CO == 128 && CI == 128) return I2P_ERR_BAD_ARG;
+        else hipLaunchKernelGGL((wreg_wgrad_kernel<CO, CI, false, false>), dim3(grid), dim3(WR_THREADS), 0, st, p);
+    }
     I2P_RETURN_LAUNCH_STATUS();
 }
 

@@ -249,7 +249,7 @@ class _BnActPool(torch.autograd.Function):
         # In fp32 they measure the same as the first generation with its 64-thread finalize launches (628.0 vs 629.6 samples/s, A/B on
         # one box: the prologue's dependent load -> barrier -> rsqrt chain costs what the launch did), so fp32 stays on generation 1
         # unless I2P_IMG_GEN2=1.
-        ctx.gen2 = be.name == "hip" and (y.dtype == torch.bfloat16 or os.environ.get("I2P_IMG_GEN2") == "1")
+        ctx.gen2 = be.name == "hip" and (y.dtype == torch.bfloat16 or out_bf16 or os.environ.get("I2P_IMG_GEN2", "1") == "1")
         if ctx.gen2:
             out, arg, mi = be.img_block_forward(y_nhwc, gamma.detach(), beta.detach(), eps, slope, stride, momentum, conv_bias.detach(),
                                                 running_mean, running_var, out_bf16=out_bf16)
@@ -291,6 +291,13 @@ class _CastBf16(torch.autograd.Function):
 # bf16 storage mode (ops.set_precision("bf16"), BASELINE.json configs[2] / [4]): the image encoder's activations are bf16 too — MIOpen
 # bf16 NHWC convolutions (fp32 accumulate) + the bf16 instantiations of the block-tail kernels; parameters, BN statistics and the
 # encoder's output stay fp32.  I2P_IMG_BF16_NETS = how many of the encoder's three 5-block stacks (from the input side) do that.
+def _img_fp32_blocks():
+    """leading blocks of the image encoder that keep fp32 storage inside its bf16 part (I2P_IMG_FP32_BLOCKS, default 1: with the
+    first block in bf16 the pose of configs[2] sits 1.24e-1 from the fp32 reference, with it in fp32 7.0e-2 — the level of the
+    chains-only tier — for 2.5 % of the throughput; tools/diag_bf16_tiers.py, tests/test_model_sized.py)"""
+    return int(os.environ.get("I2P_IMG_FP32_BLOCKS", "1"))
+
+
 def _img_bf16_nets():
     if ops.get_precision() != "bf16" or ops.get_backend().name != "hip":
         return 0
@@ -330,19 +337,24 @@ class _ImageCNN(nn.Sequential):
             nbf = _img_bf16_nets()
             idx = getattr(self, "encoder_index", None)         # (a stack on its own: bf16 inside, fp32 out)
             bf = x.is_cuda and (nbf > 0 if idx is None else idx < nbf)
-            last = idx is None or idx == nbf - 1               # what leaves the bf16 part of the encoder is fp32
-            if not bf and x.dtype != torch.float32:
-                x = x.float()
             nb = len(mods) // 4
-            if bf:
+            # which blocks of this stack store bf16: the stack is inside the bf16 part of the encoder AND the block is past the leading
+            # `I2P_IMG_FP32_BLOCKS` blocks of the encoder, which stay fp32 (the first blocks' rounding is what the encoder amplifies most)
+            base = (idx or 0) * nb
+            nfp = _img_fp32_blocks()
+            blk_bf = [bf and base + j >= nfp for j in range(nb)]
+            next_stack_bf = idx is not None and idx + 1 < nbf and base + nb >= nfp      # what leaves the bf16 part of the encoder is fp32
+            out_bf = [blk_bf[j + 1] if j + 1 < nb else (bf and next_stack_bf) for j in range(nb)]
+            if any(blk_bf):
                 ws = _CastBf16.apply(*[mods[i].weight for i in range(0, len(mods), 4)])
-                if x.dtype != torch.bfloat16:
-                    x = x.to(torch.bfloat16)
             for j, i in enumerate(range(0, len(mods), 4)):
                 conv, bn, act, pool = mods[i:i + 4]
-                y = F.conv2d(x, ws[j] if bf else conv.weight, None, conv.stride, conv.padding)
+                want = torch.bfloat16 if blk_bf[j] else torch.float32
+                if x.dtype != want:
+                    x = x.to(want)
+                y = F.conv2d(x, ws[j] if blk_bf[j] else conv.weight, None, conv.stride, conv.padding)
                 x = _BnActPool.apply(y, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
-                                     bn.momentum, bn.eps, act.negative_slope, bf and not (last and j == nb - 1))
+                                     bn.momentum, bn.eps, act.negative_slope, out_bf[j])
             return x
         with torch.no_grad():
             # rm' = (1-m) rm + m (mean_without_bias + bias): pre-add m/(1-m) * bias (before autograd saves the buffer)

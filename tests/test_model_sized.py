@@ -208,18 +208,24 @@ def test_config2_shape_batch16_fp32_matches_reference_on_gpu(hip_backend):
     _check_fp32(*_run_sized("kitti_b16", "cuda"), tol=1e-4, grad_tol=1e-3, grad_tensor_tol=2e-3, rgb_tol=1.5e-2)
 
 
+BF16_POSE_TOL, BF16_ACT_TOL = 8e-2, 1.2e-1
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("img_nets,pose_tol,act_tol", [(0, 8e-2, 1e-1), (3, 1.6e-1, 1.5e-1)])
-def test_config2_batch16_bf16_against_reference_on_gpu(hip_backend, monkeypatch, img_nets, pose_tol, act_tol):
-    """BASELINE.json configs[2] (batch 16, bf16 storage + bf16 MFMA point-MLP) against the fp32 reference at that size.
-    img_nets = 0: bf16 storage of the fused point/cost-volume chains only, at the bf16 contract of DESIGN.md §2 /
-    tests/test_bf16_gpu.py — pose < 8e-2 of its scale, loss < 5e-2, every recorded activation < 1e-1 in relative L2 norm and
-    < 3e-1 max-norm on the fixture rows, the norm of the whole well-conditioned gradient within 25 % (measured: pose 6.5e-2,
-    activations <= 2.5e-2).
-    img_nets = 3 (what ops.set_precision("bf16") selects and `bench.py --config 2` measures): the image encoder's activations are
-    bf16 as well (MIOpen bf16 convolutions).  The encoder amplifies the rounding of its first blocks (iid-noise synthetic image,
-    15 batch-stat BN blocks: RF3 is 0.13 of its rms away from fp32 storage; fp32-accumulate everywhere) — measured pose 1.24e-1,
-    activations <= 1.15e-1; stated limits 1.6e-1 / 1.5e-1."""
+@pytest.mark.parametrize("img_nets,fp32_blocks", [(0, 0), (3, 1)])
+def test_config2_batch16_bf16_against_reference_on_gpu(hip_backend, monkeypatch, img_nets, fp32_blocks):
+    """BASELINE.json configs[2] (batch 16, bf16 storage + bf16 MFMA point-MLP) against the fp32 reference at that size, ONE contract
+    for every tier that ships: pose < 8e-2 of its scale, loss < 5e-2, every recorded activation < 1.2e-1 in relative
+    L2 norm and < 3e-1 max-norm on the fixture rows, the norm of the whole well-conditioned gradient within 25 %.
+    (0, 0): bf16 storage of the fused point / cost-volume chains only, image encoder fp32 (measured: pose 6.5e-2, activations <= 2.5e-2).
+    (3, 1): what ops.set_precision("bf16") selects and `bench.py --config 2` measures — the image encoder's activations are bf16
+    as well (MIOpen bf16 convolutions) EXCEPT its first block, which stays fp32 (I2P_IMG_FP32_BLOCKS=1, the default): the encoder
+    amplifies the rounding of its first block most (iid-noise synthetic image, 15 batch-stat BN blocks).  Measured at this size
+    (tools/diag_bf16_tiers.py): first k blocks fp32 -> pose 1.24e-1 / 7.0e-2 / 8.9e-2 / 7.8e-2 / 7.6e-2 for k = 0 / 1 / 2 / 3 / 5 —
+    from k = 1 on the pose sits at the level of the chains-only tier — at 1104 / 1076 / 1050 / - / 967 samples/s.  The all-bf16 encoder
+    (k = 0) is outside this contract and no longer the default."""
+    pose_tol, act_tol = BF16_POSE_TOL, BF16_ACT_TOL
+    monkeypatch.setenv("I2P_IMG_FP32_BLOCKS", str(fp32_blocks))
     monkeypatch.setenv("I2P_IMG_BF16_NETS", str(img_nets))
     torch.manual_seed(0)
     gold, model, acts, out3, out4, loss = _run_sized("kitti_b16", "cuda", precision="bf16")

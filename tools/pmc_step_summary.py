@@ -11,8 +11,10 @@ import re
 import sys
 from collections import OrderedDict
 
-KEEP = ("wreg_", "sm_fwd", "sm_bwd", "outer_sum", "pair_sum", "pair_bias", "bn_stats_v4", "bn_act_fwd_v4", "sa_l1_kernel", "fcsk_kernel",
-        "reduce_partials")
+import os
+KEEP = tuple(os.environ["PMC_KEEP"].split(",")) if os.environ.get("PMC_KEEP") else (
+    "wreg_", "sm_fwd", "sm_bwd", "outer_sum", "pair_sum", "pair_bias", "bn_stats_v4", "bn_act_fwd_v4", "sa_l1_kernel", "fcsk_kernel",
+    "reduce_partials")
 B = 8
 ROWS = B * 228 * 468
 TENSOR_KIB = ROWS * 128 * 4 / 1024.0
