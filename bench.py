@@ -141,11 +141,12 @@ def _mlp_chain_entry(B, device):
             "bytes_per_launch_algorithmic": by, "mfma_TFLOPs": round(fl / t_chain / 1e6, 1), "timed_as": "20 launches per hipGraph replay"}
 
 
-PMC_JSON = ROOT / "profiles" / "r03_pmc_traffic.json"
+PMC_JSON = ROOT / "profiles" / "r04_pmc_traffic.json"            # written by tools/pmc_r04.sh on the round's final kernels
+PMC_BF16_JSON = ROOT / "profiles" / "r04_pmc_bf16_traffic.json"
 
 
 def _pmc_traffic(kernel, B):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r03_pmc_traffic.json, written by
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r04_pmc_traffic.json, written by
     tools/pmc_step.sh: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 halving of FETCH_SIZE calibrated in the same run on
     bn_stats_v4), scaled from the batch the passes ran at; None when the file has no record of that kernel."""
     if not PMC_JSON.exists():
@@ -220,25 +221,34 @@ CV1_GB_PER_SAMPLE_FWD = 0.437
 CV1_GFLOP_PER_SAMPLE_FWD = 15.1
 
 
-def chain_roofline(B, device):
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (never the 2:1-sparsity figure)
+
+
+def chain_roofline(B, device, bf16=False):
     """cv1 forward and backward wall time (events around the fused node) against SURVEY.md §8(d)'s denominators:
     0.437 GB and 15.1 GFLOP per sample and forward; the backward does twice the flops (dgrad + wgrad of every layer) and, BN-exact
     and without recomputation, reads each of the six pre-BN tensors and its gradient once and writes each gradient once
-    (3 x 512 channels x 4 B per pair = 0.655 GB per sample)."""
+    (3 x 512 channels x 4 B per pair = 0.655 GB per sample).  bf16=True (the caller has ops.set_precision("bf16") active): the same
+    node in bf16 storage — half the bytes (0.2185 GB per sample), the same flops on the bf16 MFMA roof: the HBM-bound regime the
+    north star's ">= 40 % of HBM on the fused grouping + cost-volume kernel" speaks about (VERDICT r3 missing #2)."""
     ch = Cv1Chain(B, device)
     t_f, t_b = ch.time_us()
-    fwd_b, fwd_f = CV1_GB_PER_SAMPLE_FWD * 1e9 * B, CV1_GFLOP_PER_SAMPLE_FWD * 1e9 * B
+    gb = CV1_GB_PER_SAMPLE_FWD * (0.5 if bf16 else 1.0)
+    fwd_b, fwd_f = gb * 1e9 * B, CV1_GFLOP_PER_SAMPLE_FWD * 1e9 * B
     bwd_b, bwd_f = 1.5 * fwd_b, 2.0 * fwd_f
+    mfma_peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
     return {"node": "cost_volume1 pi-stage (_CvPiTail): pair layer, 128->64, 64->64, position encoding, 64+64->128, 128->64, softmax-weighted sum; "
                     "batch %d, %d point x pixel pairs" % (B, ch.rows),
             "forward_us": round(t_f, 1), "backward_us": round(t_b, 1),
             "forward": {"hbm_GBps": round(fwd_b / t_f / 1e3, 1), "hbm_frac": round(fwd_b / t_f / 1e3 / HBM_PEAK_GBS, 4),
-                        "mfma_TFLOPs": round(fwd_f / t_f / 1e6, 1), "mfma_frac": round(fwd_f / t_f / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
+                        "mfma_TFLOPs": round(fwd_f / t_f / 1e6, 1), "mfma_frac": round(fwd_f / t_f / 1e6 / mfma_peak, 4),
                         "bytes": fwd_b, "flop": fwd_f},
             "backward": {"hbm_GBps": round(bwd_b / t_b / 1e3, 1), "hbm_frac": round(bwd_b / t_b / 1e3 / HBM_PEAK_GBS, 4),
-                         "mfma_TFLOPs": round(bwd_f / t_b / 1e6, 1), "mfma_frac": round(bwd_f / t_b / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
+                         "mfma_TFLOPs": round(bwd_f / t_b / 1e6, 1), "mfma_frac": round(bwd_f / t_b / 1e6 / mfma_peak, 4),
                          "bytes": bwd_b, "flop": bwd_f},
-            "denominators": "SURVEY.md 8(d): 0.437 GB + 15.1 GFLOP per sample and forward (fp32 activations); backward 1.5x the bytes, 2x the flops",
+            "storage": "bf16" if bf16 else "fp32", "mfma_peak_TFLOPs": mfma_peak,
+            "denominators": "SURVEY.md 8(d): %s GB + 15.1 GFLOP per sample and forward (%s activations); backward 1.5x the bytes, 2x the flops"
+                            % (("0.2185", "bf16") if bf16 else ("0.437", "fp32")),
             "timed_as": "torch.cuda events on the launch stream around cv_pi_tail(...) and around its .backward(), eager launches, "
                         "averaged over 10 iterations after 20 warm-up iterations"}
 
@@ -253,7 +263,7 @@ def kernel_rooflines(B, device):
       (BN backward of the layer behind formed on load) and the pre-BN input x [rows,128] (activation derivative +
       BN-backward statistics in the store phase) and writes dL/dz_in [rows,128]: rows*(2*64+2*128)*4 B against
       2*rows*128*64 flop => HBM-bound (164 us at 8 TB/s, 89 us at 157.3 TFLOP/s).
-      `traffic` = PMC bytes per launch from profiles/r03_pmc_traffic.json (tools/pmc_step.sh).
+      `traffic` = PMC bytes per launch from profiles/r04_pmc_traffic.json (tools/pmc_r04.sh).
       Timed as (dgrad + wgrad + reduction) - (wgrad + reduction): the C ABI has one backward entry; the rocprofv3
       table under profiles/ has the kernel's own duration.
     * other_kernels: the forward of the same layer (wreg_fwd_kernel<128,64,true,false>), its wgrad
@@ -396,7 +406,8 @@ def kernel_rooflines_bf16(B, device):
     """configs[2] / configs[4]: live timings of the bf16-storage cost-volume kernels.  HBM-bound: a 128->128 layer reads
     rows*128 bf16 and writes rows*128 bf16 (+ 64 KB of fp32 weights) = the BN-exact no-recompute traffic of SURVEY.md
     §8d for one layer, halved by bf16 storage; the contraction (2*rows*128*128 flop on v_mfma_f32_32x32x16_bf16) is
-    ~1/5 of the bf16 MFMA roof at that rate.  `traffic`: PMC bytes from profiles/r02_pmc_bf16_*.txt when present."""
+    ~1/5 of the bf16 MFMA roof at that rate.  `traffic`: PMC bytes from profiles/r04_pmc_bf16_traffic.json (tools/pmc_r04.sh).
+    `chain`: the whole cost_volume1 pi-stage node in bf16 storage against SURVEY 8(d)'s bytes halved (0.2185 GB per sample)."""
     from i2pnet_amd import _lib, ops
     hip = ops.hip_backend()
     N, M, C = 228, 468, 128
@@ -419,7 +430,7 @@ def kernel_rooflines_bf16(B, device):
     alg_bytes = rows * C * 2 * 2 + C * C * 4
     flop = 2.0 * rows * C * C
     traffic = None
-    pmc = ROOT / "profiles" / "r02_pmc_bf16_traffic.json"
+    pmc = PMC_BF16_JSON
     if pmc.exists():
         rec = json.loads(pmc.read_text())
         traffic = round(rec["bytes_per_launch_at_B8"] * rows / (8 * N * M))
@@ -453,6 +464,9 @@ def kernel_rooflines_bf16(B, device):
           "achieved": round(rows * C * 2 * 2 / t_pb / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
           "frac": round(rows * C * 2 * 2 / t_pb / 1e3 / HBM_PEAK_GBS, 4), "avg_us": round(t_pb, 1)}
     fwd["other_kernels"] = [bwd, pf, pb]
+    del x, y, y0, y1, gz1, f, gk, bn, bk
+    torch.cuda.empty_cache()
+    fwd["chain"] = chain_roofline(B, device, bf16=True)
     return fwd
 
 

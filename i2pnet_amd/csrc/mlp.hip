@@ -2065,6 +2065,10 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
         if (gen2) {
             const bool two_d3 = !two || (two->split_c * 2 == cin && two->in_coef_b && two->in_mi_b && two->e_add && two->gz_in_b &&
                                          two->in_dsums_b && in_dsums);
+            // (Measured and not adopted, round 4: the backward in n row chunks — dgrad(chunk), wgrad(chunk) — so that the weight gradient
+            // re-reads gz / y / x out of the 256 MB Infinity Cache instead of HBM: the cv1 node's backward went 2919 -> 3069 (n = 4) -> 3358
+            // (n = 8) -> 3981 us (n = 16); with default-policy instead of non-temporal loads 2879 -> 3027 -> 3332.  The second read is
+            // not what bounds these kernels, the extra launches and per-launch prologues cost more.)
             if (gz_in && two_d3 && out_coef && p.slope_out == 1.f && in_coef && i2p_wreg_dgrad_ok(rows, cout, cin)) {
                 // wide layer on many rows, plain BN on both sides: weights stationary in registers (csrc/mlp_wreg.hip)
                 const int rc = two ? i2p_wreg_dgrad(rows, cout, cin, gz, y, out_dsums, out_coef, out_mi, rows, w, gz_in, x, in_coef, in_mi,

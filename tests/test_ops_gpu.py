@@ -363,7 +363,7 @@ def test_img_block_gen2_parity(oracle_backend, hip_backend, stride, C, H, W, ybf
     assert torch.allclose(rdb, hdb.cpu(), rtol=1e-4, atol=1e-4 * float(rdb.abs().max()))
 
 
-def test_image_encoder_bf16_storage_matches_torch_bf16(hip_backend):
+def test_image_encoder_bf16_storage_matches_torch_bf16(hip_backend, monkeypatch):
     """the 15-block image encoder in bf16 storage mode (MIOpen bf16 convolutions + the bf16 block tails of csrc/image_block.hip,
     one multi-tensor weight cast) against plain torch ops with the same storage points (conv output and pooled output in bf16;
     BN / activation / pooling math in fp32; RF3 fp32).
@@ -376,6 +376,7 @@ def test_image_encoder_bf16_storage_matches_torch_bf16(hip_backend):
     from i2pnet_amd import modules, ops
     from i2pnet_amd.config import I2PNetConfig as cfg
     bf = torch.bfloat16
+    monkeypatch.setenv("I2P_IMG_FP32_BLOCKS", "0")          # every block in bf16 storage (the default keeps the first one fp32)
     torch.manual_seed(3)
     nets = torch.nn.Sequential(*[modules.createCNNs(*c) for c in cfg.rgb_encoder_channels]).to(DEV).to(memory_format=torch.channels_last)
     for i, net in enumerate(nets):
@@ -416,6 +417,24 @@ def test_image_encoder_bf16_storage_matches_torch_bf16(hip_backend):
             assert p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
             n += 1
     assert n == 3 * nb                                     # conv weight, BN weight, BN bias of every block
+    # the default tier: the FIRST block stays fp32 (fp32 convolution, fp32 conv output, bf16 pooled output for the second block)
+    monkeypatch.setenv("I2P_IMG_FP32_BLOCKS", "1")
+    with torch.no_grad():
+        conv, bn, act, pool = blocks[0:4]
+        z = F.batch_norm(F.conv2d(x, conv.weight, None, 1, 1), None, None, bn.weight, bn.bias, True, 0.1, bn.eps)
+        h = pool(F.leaky_relu(z, 0.1)).to(bf)
+        for j in range(1, nb):
+            conv, bn, act, pool = blocks[4 * j:4 * j + 4]
+            z = F.batch_norm(F.conv2d(h, conv.weight.to(bf), None, 1, 1).float(), None, None, bn.weight, bn.bias, True, 0.1, bn.eps)
+            h = pool(F.leaky_relu(z, 0.1))
+            h = h if j == nb - 1 else h.to(bf)
+    prev = ops.set_precision("bf16")
+    try:
+        out1 = nets(x)
+    finally:
+        ops.set_precision(prev)
+    assert out1.dtype == torch.float32
+    assert float((out1.detach() - h).pow(2).mean().sqrt() / h.pow(2).mean().sqrt()) < 0.1
 
 
 @pytest.mark.parametrize("rows,cin,cout,slope_out", [(3000, 64, 128, 0.0), (5000, 32, 32, 0.1), (2000, 36, 32, 0.0),
