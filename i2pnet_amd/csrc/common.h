@@ -106,6 +106,11 @@ bool i2p_wreg_wgrad_ok(long long rows, int cin, int cout);
 int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
                    const float *g_omi, long long g_rows, float *bn_out, const float *x, const float *in_coef, float slope_in,
                    const float *xb, const float *in_coef_b, float slope_b, int split, float *dw_partial, unsigned grid, void *stream);
+// input gradient + weight gradient of an HBM-bound wide layer from ONE read of gz / y / x (csrc/mlp_wreg_fused.hip)
+bool i2p_wreg_bwd_fused_ok(long long rows, int k, int c);
+int i2p_wreg_bwd_fused(long long rows, int k, int c, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
+                       const float *g_omi, long long g_rows, const float *w, float *gz_in, const float *ex, const float *e_coef,
+                       const float *e_mi, float e_slope, double *sums, float *bn_out, float *dw_partial, unsigned grid, void *stream);
 bool i2p_wreg_pair_bwd_ok(int B, int N, int M, int cin, int cout);
 long long i2p_wreg_pair_bwd_scratch(int B, int N, int M, int cin, int cout);
 int i2p_wreg_pair_bwd(int B, int N, int M, int cin, int cout, const float *gz, const float *y2, const double *g_dsums,

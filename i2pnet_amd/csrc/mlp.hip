@@ -2069,6 +2069,15 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
             // re-reads gz / y / x out of the 256 MB Infinity Cache instead of HBM: the cv1 node's backward went 2919 -> 3069 (n = 4) -> 3358
             // (n = 8) -> 3981 us (n = 16); with default-policy instead of non-temporal loads 2879 -> 3027 -> 3332.  The second read is
             // not what bounds these kernels, the extra launches and per-launch prologues cost more.)
+            if (part == 3 && !two && gz_in && in_dsums && out_coef && p.slope_out == 1.f && in_coef && slope_in >= 0.f && slope_in <= 1.f && grid == 256 &&
+                i2p_wreg_bwd_fused_ok(rows, cout, cin)) {
+                // HBM-bound wide layer (64 output channels) on many rows: both gradients from one read of gz / y / x (csrc/mlp_wreg_fused.hip)
+                const int rc = i2p_wreg_bwd_fused(rows, cout, cin, gz, y, out_dsums, out_coef, out_mi, rows, w, gz_in, x, in_coef, in_mi, slope_in,
+                                                  in_dsums, g_coef, dw_partial, grid, stream);
+                if (rc) return rc;
+                launch_reduce_partials((int)grid, cout * cin, dw_partial, dw, st);
+                I2P_RETURN_LAUNCH_STATUS();
+            }
             if (gz_in && two_d3 && out_coef && p.slope_out == 1.f && in_coef && i2p_wreg_dgrad_ok(rows, cout, cin)) {
                 // wide layer on many rows, plain BN on both sides: weights stationary in registers (csrc/mlp_wreg.hip)
                 const int rc = two ? i2p_wreg_dgrad(rows, cout, cin, gz, y, out_dsums, out_coef, out_mi, rows, w, gz_in, x, in_coef, in_mi,
