@@ -21,7 +21,8 @@ SOURCES = ["fused_conv_select_k.hip", "pointnet2_ops.hip", "projection_ops.hip",
            "image_block.hip", "mlp_bf16.hip", "bf16_stream.hip", "sa_group.hip", "scatter_det.hip", "mlp_wreg.hip", "mlp_wreg_fused.hip", "mlp_wreg_bf16.hip", "gemm_tn.hip", "mlp_big.hip", "optim.hip", "glue.hip", "mlp_chain.hip"]
 # mlp_wreg.hip: one strip = 256 MFMAs with the rest of the wave's work slotted between them, written as ONE fully
 # unrolled loop — past clang's default size limit for `#pragma unroll`
-EXTRA_FLAGS = {"mlp_wreg.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
+EXTRA_FLAGS = {"mlp_wreg.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
+               "mlp_wreg_fused.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 if os.environ.get("WREG_ABL"):      # diagnostic build of the ablation switches in mlp_wreg.hip
     EXTRA_FLAGS["mlp_wreg.hip"].append("-DWREG_ABL=" + os.environ["WREG_ABL"])
 HEADERS = [CSRC / "common.h", PKG.parent / "include" / "i2p_ops.h"]

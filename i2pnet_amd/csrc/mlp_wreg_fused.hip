@@ -19,6 +19,12 @@
 // two-kernel form, which is what bounded those (tools/mfma_ceiling.py).
 #include "common.h"
 
+// build-time diagnostic (I2P_BUILD_VARIANT / I2P_BUILD_DEFS=-DFUSED_ABL=n): 1 no weight-gradient MFMAs, 2 no LDS tiles, 4 no stores,
+// 8 no requests of the next strip, 16 no input-gradient MFMAs
+#ifndef FUSED_ABL
+#define FUSED_ABL 0
+#endif
+
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -111,82 +117,114 @@ __global__ __launch_bounds__(WF_THREADS, 1) void wreg_bwd_fused_kernel(WregFused
         for (int f = 0; f < NF; ++f) { gn[f] = ldn(p.gz + koff + 16 * f); yn[f] = ldn(p.y2 + koff + 16 * f); }
 #pragma unroll
         for (int j = 0; j < NT; ++j) xn[j] = ldn(p.ex + coff + 16 * j);
+        // One strip = two MFMA streams of this wave, back to back: NT*L MFMAs of the input gradient, then NO*NI*4 of the weight gradient.
+        // The only wave of its SIMD overlaps nothing by itself, so everything else is cut into slots of a few instructions placed BETWEEN
+        // the MFMAs (sched_barrier(0) after every slot keeps the compiler from regrouping them — it otherwise hoists every tile's
+        // constants to the top, 200 bytes of scratch, or issues a tile's whole epilogue behind the last MFMA):
+        //   stream B (input gradient, SL = 16 slots per 16-channel tile ja of the layer input): constants from LDS, a = act(bn(x)) of the
+        //     tile, a and the raw x rows into the wave's LDS tiles, then the same float4 of the NEXT strip's x requested into the
+        //     register it leaves; gz / y of the next strip are requested in the first slots (g^y was formed before the stream);
+        //   stream C (weight gradient): the channel-per-lane operands of k-step t + 1 read from the LDS tiles during k-step t; the
+        //     input gradient's epilogue (act', statistics rows, store) of tile je in slots [SL je, SL je + 9].
+        constexpr int L = K / 4, NMF = NT * L, SL = NMF / NT, NWG = NO * NI * 4, SLC = NWG / NT, LAT = 6;
+        static_assert(SL >= 13 && SLC >= 10 && NWG / 4 >= 2, "slot plan");
+        f32x4 acc[NT];
         for (int k = 0; k < n_mine; ++k) {
+            const bool has_next = k + 1 < n_mine;
             f32x4 xg[NF];
-            // ---- this strip's operands out of the request registers; g^y formed; the next strip requested ------------------------
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const f32x4 tsc = *reinterpret_cast<const f32x4 *>(gq + 16 * f), tac = *reinterpret_cast<const f32x4 *>(gq + K + 16 * f),
                             tbc = *reinterpret_cast<const f32x4 *>(gq + 2 * K + 16 * f);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) xg[f][c] = __builtin_fmaf(tsc[c], gn[f][c], __builtin_fmaf(yn[f][c], tbc[c], tac[c]));
-            }
-            // a = act(bn(x)) and the raw x rows into the wave's LDS tiles BEFORE the request registers are reused
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const f32x4 esc = *reinterpret_cast<const f32x4 *>(eq + 16 * j), ezb = *reinterpret_cast<const f32x4 *>(eq + C + 16 * j);
-                f32x4 a;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float z = __builtin_fmaf(xn[j][c], esc[c], ezb[c]);
-                    a[c] = __builtin_fmaxf(z, z * p.e_slope);
-                }
-                *reinterpret_cast<f32x4 *>(ta + m * LDA + 16 * j + 4 * q) = a;
-                *reinterpret_cast<f32x4 *>(tx + m * LDA + 16 * j + 4 * q) = xn[j];
-                __builtin_amdgcn_sched_barrier(0);           // (keeps the fully unrolled loops from hoisting every tile's constants at once: registers)
+                *reinterpret_cast<f32x4 *>(tg + m * LDG + 16 * f + 4 * q) = xg[f];
             }
             const size_t coff_cur = coff;
-            if (k + 1 < n_mine) {
-                koff += k_step; coff += c_step;
+            // (no next strip: the offsets stay and the requests below fetch the last strip again, never used — UNCONDITIONAL requests, so that
+            //  the compiler's s_waitcnt vmcnt counts are exact: with the requests under `if (has_next)` it had to assume the path without
+            //  them and waited for every outstanding load, the ones just issued included: 6.9 us per strip instead of 3.4 us of MFMAs)
+            if (has_next) { koff += k_step; coff += c_step; }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- stream B ------------------------------------------------------------------------------------------------------------
+            f32x4 esc, ezb, av_t;
+            esc = ezb = av_t = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int f = 0; f < NF; ++f) { gn[f] = ldn(p.gz + koff + 16 * f); yn[f] = ldn(p.y2 + koff + 16 * f); }
+            for (int i = 0; i < NMF; ++i) {
+                const int t = i / NT, j = i % NT, f = t >> 2, e = t & 3;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                if (!(FUSED_ABL & 16)) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][f][e], xg[f][e], t == 0 ? zero : acc[j], 0, 0, 0);
+                else if (t == 0) acc[j] = xg[0];
+                // gz / y of the next strip: both 64-byte halves of a row's 128-byte line in ONE slot (requests a few slots apart fetch the
+                // line twice: PMC FETCH_SIZE 1.28x in mlp_wreg.hip's dgrad before it paired them)
+                if (i < NF && !(FUSED_ABL & 8)) {
+                    const int f2 = (i >> 1) * 2;
+                    if (i & 1) { yn[f2] = ldn(p.y2 + koff + 16 * f2); yn[f2 + 1] = ldn(p.y2 + koff + 16 * (f2 + 1)); }
+                    else { gn[f2] = ldn(p.gz + koff + 16 * f2); gn[f2 + 1] = ldn(p.gz + koff + 16 * (f2 + 1)); }
+                }
+                const int ja = i / SL, sub = i % SL;
+                if (sub == 2) { esc = *reinterpret_cast<const f32x4 *>(eq + 16 * ja); ezb = *reinterpret_cast<const f32x4 *>(eq + C + 16 * ja); }
+                if (sub == 2 + LAT) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) xn[j] = ldn(p.ex + coff + 16 * j);
-            }
-            // ---- g^y into the wave's LDS tile (row-per-lane layout) ----------------------------------------------------------------------
+                    for (int c = 0; c < 4; ++c) av_t[c] = __builtin_fmaf(xn[ja][c], esc[c], ezb[c]);
+                }
+                if (sub == 3 + LAT) {
 #pragma unroll
-            for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4 *>(tg + m * LDG + 16 * f + 4 * q) = xg[f];
-            // ---- input gradient ----------------------------------------------------------------------------------------------------
-            f32x4 acc[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int f = 0; f < NF; ++f)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][f][e], xg[f][e], acc[j], 0, 0, 0);
-            // ---- weight gradient: the tiles back in the channel-per-lane layout (same wave: its LDS queue keeps write -> read order) ----
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                f32x4 gv[HO], av[HI];
-#pragma unroll
-                for (int h = 0; h < HO; ++h) gv[h] = *reinterpret_cast<const f32x4 *>(tg + (4 * q + t) * LDG + NO * m + 4 * h);
-#pragma unroll
-                for (int h = 0; h < HI; ++h) av[h] = *reinterpret_cast<const f32x4 *>(ta + (4 * q + t) * LDA + NI * m + 4 * h);
-#pragma unroll
-                for (int jo = 0; jo < NO; ++jo)
-#pragma unroll
-                    for (int jc = 0; jc < NI; ++jc)
-                        dacc[jo][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[jo >> 2][jo & 3], av[jc >> 2][jc & 3], dacc[jo][jc], 0, 0, 0);
+                    for (int c = 0; c < 4; ++c) av_t[c] = __builtin_fmaxf(av_t[c], av_t[c] * p.e_slope);
+                }
+                if (sub == 4 + LAT && !(FUSED_ABL & 2)) {
+                    *reinterpret_cast<f32x4 *>(ta + m * LDA + 16 * ja + 4 * q) = av_t;
+                    *reinterpret_cast<f32x4 *>(tx + m * LDA + 16 * ja + 4 * q) = xn[ja];
+                }
+                if (sub == 5 + LAT && (ja & 1) && !(FUSED_ABL & 8)) { xn[ja - 1] = ldn(p.ex + coff + 16 * (ja - 1)); xn[ja] = ldn(p.ex + coff + 16 * ja); }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // ---- epilogue of the input gradient: act', BN-backward statistics of the layer in front, store -------------------------------
+            // ---- stream C ------------------------------------------------------------------------------------------------------------
+            f32x4 gv[2][HO], av[2][HI];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const f32x4 esc = *reinterpret_cast<const f32x4 *>(eq + 16 * j), ezb = *reinterpret_cast<const f32x4 *>(eq + C + 16 * j),
-                            eis = *reinterpret_cast<const f32x4 *>(eq + 2 * C + 16 * j), enm = *reinterpret_cast<const f32x4 *>(eq + 3 * C + 16 * j);
-                const f32x4 xr = *reinterpret_cast<const f32x4 *>(tx + m * LDA + 16 * j + 4 * q);
-                f32x4 v, r1 = st_lds[j * WF_THREADS + tid], r2 = st_lds[(NT + j) * WF_THREADS + tid];
+            for (int h = 0; h < HO; ++h) gv[0][h] = *reinterpret_cast<const f32x4 *>(tg + (4 * q) * LDG + NO * m + 4 * h);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float z = __builtin_fmaf(xr[c], esc[c], ezb[c]);
-                    v[c] = z > 0.f ? acc[j][c] : acc[j][c] * p.e_slope;
-                    r1[c] += v[c];
-                    r2[c] = __builtin_fmaf(v[c], __builtin_fmaf(xr[c], eis[c], enm[c]), r2[c]);
+            for (int h = 0; h < HI; ++h) av[0][h] = *reinterpret_cast<const f32x4 *>(ta + (4 * q) * LDA + NI * m + 4 * h);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 eis, enm, xr, r1, r2, ev, vkeep;
+            eis = enm = xr = r1 = r2 = ev = vkeep = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < NWG; ++u) {
+                const int t = u / (NO * NI), r = u % (NO * NI), jo = r / NI, jc = r % NI;
+                if (!(FUSED_ABL & 1)) dacc[jo][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[t & 1][jo >> 2][jo & 3], av[t & 1][jc >> 2][jc & 3], dacc[jo][jc], 0, 0, 0);
+                else if (r == 0) dacc[0][0] += gv[t & 1][0] + av[t & 1][0];
+                if (r == 1 && t < 3 && !(FUSED_ABL & 2)) {                                            // operands of k-step t + 1
+#pragma unroll
+                    for (int h = 0; h < HO; ++h) gv[(t + 1) & 1][h] = *reinterpret_cast<const f32x4 *>(tg + (4 * q + t + 1) * LDG + NO * m + 4 * h);
+#pragma unroll
+                    for (int h = 0; h < HI; ++h) av[(t + 1) & 1][h] = *reinterpret_cast<const f32x4 *>(ta + (4 * q + t + 1) * LDA + NI * m + 4 * h);
                 }
-                st_lds[j * WF_THREADS + tid] = r1; st_lds[(NT + j) * WF_THREADS + tid] = r2;
-                stn(p.gz_in + coff_cur + 16 * j, v);
+                const int je = u / SLC, sub = u % SLC;
+                if (sub == 0) {
+                    esc = *reinterpret_cast<const f32x4 *>(eq + 16 * je); ezb = *reinterpret_cast<const f32x4 *>(eq + C + 16 * je);
+                    xr = *reinterpret_cast<const f32x4 *>(tx + m * LDA + 16 * je + 4 * q);
+                }
+                if (sub == 2) {
+                    eis = *reinterpret_cast<const f32x4 *>(eq + 2 * C + 16 * je); enm = *reinterpret_cast<const f32x4 *>(eq + 3 * C + 16 * je);
+                    r1 = st_lds[je * WF_THREADS + tid]; r2 = st_lds[(NT + je) * WF_THREADS + tid];
+                }
+                if (sub == LAT) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float z = __builtin_fmaf(xr[c], esc[c], ezb[c]);
+                        ev[c] = z > 0.f ? acc[je][c] : acc[je][c] * p.e_slope;
+                    }
+                }
+                if (sub == LAT + 1) {                                             // stores too: one 128-byte line per row at a time
+                    if ((je & 1) && !(FUSED_ABL & 4)) { stn(p.gz_in + coff_cur + 16 * (je - 1), vkeep); stn(p.gz_in + coff_cur + 16 * je, ev); }
+                    else vkeep = ev;
+                    r1 += ev; st_lds[je * WF_THREADS + tid] = r1;
+                }
+                if (sub == LAT + 3) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) r2[c] = __builtin_fmaf(ev[c], __builtin_fmaf(xr[c], eis[c], enm[c]), r2[c]);
+                    st_lds[(NT + je) * WF_THREADS + tid] = r2;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -255,7 +293,7 @@ bool i2p_wreg_bwd_fused_ok(long long rows, int k, int c) {
     static const char *off = getenv("I2P_NO_FUSED_BWD");
     static const char *nw = getenv("I2P_NO_WREG");
     if ((off && off[0] == '1') || (nw && nw[0] == '1')) return false;
-    return rows >= 65536 && (rows % WF_ROWS) == 0 && k == 64 && (c == 64 || c == 128) &&
+    return rows >= 32768 && (rows % WF_ROWS) == 0 && k == 64 && (c == 64 || c == 128) &&
            (unsigned long long)rows * 128ull * 4ull < (1ull << 40);
 }
 

@@ -1,0 +1,36 @@
+"""Time of the one-pass backward (csrc/mlp_wreg_fused.hip) of the cost-volume layers on the step's shapes: lin_backward on
+[853632, 64] gradients with a 128- or 64-channel input, events on the launch stream, clocks warm.  I2P_NO_FUSED_BWD=1 times the
+two-kernel form (wreg_dgrad + wreg_wgrad); I2P_OPS_LIB selects an ablation build (FUSED_ABL)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from i2pnet_amd import ops  # noqa: E402
+
+be = ops.hip_backend()
+dev = "cuda"
+rows = 8 * 228 * 468
+for cin, cout in ((128, 64), (64, 64)):
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(rows, cin, device=dev, generator=g)
+    w = torch.randn(cout, cin, device=dev, generator=g) / cin ** 0.5
+    gam_i = torch.ones(cin, device=dev); bet_i = torch.zeros(cin, device=dev)
+    gam_o = torch.ones(cout, device=dev); bet_o = torch.zeros(cout, device=dev)
+    in_coef, in_mi = be.bn_finalize(rows, be.bn_stats(x), gam_i, bet_i, 1e-5)
+    y, ys = be.lin_forward(x, in_coef, 0.1, w)
+    out_coef, out_mi = be.bn_finalize(rows, ys, gam_o, bet_o, 1e-5)
+    gz = torch.randn(rows, cout, device=dev, generator=g) * 0.1
+    ods = be.bn_act_backward_stats(gz, y, out_mi, gam_o, bet_o, 0.1)
+    run = lambda: be.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w)
+    for _ in range(60):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record(); e1.synchronize()
+    t = e0.elapsed_time(e1) / 20 * 1e3
+    by = rows * (2 * cout + 2 * cin) * 4
+    print(f"{cin:3d} -> {cout:3d}: {t:7.1f} us per backward (incl. the slab reduction)  {by / t / 1e3:7.1f} GB/s on one read of gz, y, x + one write", flush=True)
