@@ -257,17 +257,13 @@ def kernel_rooflines(B, device):
     """Live timings (events on the launch stream) of hand-written kernels AS THE fp32 STEP RUNS THEM: every kernel named here
     is an instantiation that appears in the step's rocprofv3 table (profiles/r03_*_steady_kernel_stats.csv) on the same shapes.
 
-    * `roofline`: wreg_dgrad_kernel<64,128,false> — the dgrad of a 128->64 layer of the all-pixel cost volume on
-      [B*228*468] rows (mlp1[1] and mlp2[1] of cost_volume1: two launches per step, the largest per-step time of the
-      hand-written kernels).  Weights stationary in registers; it reads gz [rows,64], the layer's pre-BN output y [rows,64]
-      (BN backward of the layer behind formed on load) and the pre-BN input x [rows,128] (activation derivative +
-      BN-backward statistics in the store phase) and writes dL/dz_in [rows,128]: rows*(2*64+2*128)*4 B against
-      2*rows*128*64 flop => HBM-bound (164 us at 8 TB/s, 89 us at 157.3 TFLOP/s).
-      `traffic` = PMC bytes per launch from profiles/r04_pmc_traffic.json (tools/pmc_r04.sh).
-      Timed as (dgrad + wgrad + reduction) - (wgrad + reduction): the C ABI has one backward entry; the rocprofv3
-      table under profiles/ has the kernel's own duration.
-    * other_kernels: the forward of the same layer (wreg_fwd_kernel<128,64,true,false>), its wgrad
-      (wreg_wgrad_kernel<64,128,true,false> + reduction), the two-source 64+64->128 forward
+    * `roofline`: wreg_bwd_fused_kernel<64,128> — the backward of a 128->64 layer of the all-pixel cost volume on [B*228*468] rows
+      (mlp1[1] and mlp2[1] of cost_volume1: two launches per step, the largest per-step time of the hand-written kernels) as ONE
+      pass (csrc/mlp_wreg_fused.hip): it reads gz [rows,64], the layer's pre-BN output y [rows,64] (BN backward of the layer behind
+      formed on load) and the pre-BN input x [rows,128] ONCE, writes dL/dz_in [rows,128] and keeps the [64][128] weight gradient in
+      registers: rows*(2*64+2*128)*4 B against 4*rows*128*64 flop => HBM-bound (164 us at 8 TB/s, 178 us at 157.3 TFLOP/s: close
+      to the ridge).  `traffic` = PMC bytes per launch from profiles/r04_pmc_traffic.json (tools/pmc_r04.sh).
+    * other_kernels: the forward of the same layer (wreg_fwd_kernel<128,64,true,false>), the two-source 64+64->128 forward
       (wreg_fwd_kernel<128,128,true,true>), the factored first layer (wreg_pair_fwd_kernel<128,128>), level-1
       fused_conv_select_k and the fused level-1 grouping on the three input densities.
     * chain: the whole cost_volume1 pi-stage node against SURVEY.md 8(d)'s per-sample bytes / flops (chain_roofline).
@@ -305,24 +301,20 @@ def kernel_rooflines(B, device):
     out_coef, out_mi = hip.bn_finalize(rows, sy, gam_o, bet_o, 1e-5)
     gz = rnd(rows, CO)
     ods = torch.zeros(ops.BN_REPLICAS * 2 * CO, dtype=torch.float64, device=device)
+    _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), 40)
     t_bwd = _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), 20)
-    t_wg = _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w, need_gx=False), 20)
-    t_dg = t_bwd - t_wg
     dg_bytes = rows * (2 * CO + 2 * CI) * 4 + CI * CO * 4
-    dgrad = {"kernel": "wreg_dgrad_kernel<64,128,false> (cost-volume 128->64 layer dgrad, 2 launches per step: weights stationary in registers, "
-                       "BN backward of the layer behind formed between the MFMAs, activation derivative + BN-backward statistics in the store phase)",
-             "bound": "hbm", "achieved": round(dg_bytes / t_dg / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(dg_bytes / t_dg / 1e3 / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("wreg_dgrad_kernel<64, 128, false>", B),
-             "avg_kernel_us": round(t_dg, 1), "bytes_per_launch_algorithmic": dg_bytes,
-             "mfma_TFLOPs": round(flop / t_dg / 1e6, 1), "mfma_frac": round(flop / t_dg / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
-             "timed_as": "lin_bwd (dgrad + wgrad + reduction) minus lin_bwd without dgrad, events on the launch stream"}
-    wg_bytes = rows * (2 * CO + CI) * 4
-    wg = {"kernel": "wreg_wgrad_kernel<64,128,true,false> + reduce_partials (wgrad of the same layer: the 64x128 accumulators stationary in "
-                    "registers, gz / y / x rows as MFMA operands straight from global memory)", "bound": "hbm",
-          "achieved": round(wg_bytes / t_wg / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-          "frac": round(wg_bytes / t_wg / 1e3 / HBM_PEAK_GBS, 4), "avg_us": round(t_wg, 1),
-          "traffic": _pmc_traffic("wreg_wgrad_kernel<64, 128, true, false>", B), "bytes_per_launch_algorithmic": wg_bytes,
-          "mfma_TFLOPs": round(flop / t_wg / 1e6, 1), "mfma_frac": round(flop / t_wg / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)}
+    dgrad = {"kernel": "wreg_bwd_fused_kernel<64,128> (cost-volume 128->64 layer backward in ONE pass, 2 launches per step at this size: input "
+                       "gradient + weight gradient from a single read of gz, y, x; W and the dW accumulators stationary in registers, BN backward "
+                       "of the layer behind formed on load, operands of the weight gradient transposed through wave-private LDS tiles, activation "
+                       "derivative + BN-backward statistics in the store phase)",
+             "bound": "hbm", "achieved": round(dg_bytes / t_bwd / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(dg_bytes / t_bwd / 1e3 / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("wreg_bwd_fused_kernel<64, 128>", B),
+             "avg_kernel_us": round(t_bwd, 1), "bytes_per_launch_algorithmic": dg_bytes,
+             "mfma_TFLOPs": round(2 * flop / t_bwd / 1e6, 1), "mfma_frac": round(2 * flop / t_bwd / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
+             "timed_as": "i2p_lin_bwd = the fused kernel + the 256-slab reduction of dW (~5 us, included: the figure is a lower bound of the "
+                         "kernel's own rate; its duration alone is in profiles/r04_*_steady_kernel_stats.csv), events on the launch stream",
+             "replaces": "wreg_dgrad_kernel<64,128,false> + wreg_wgrad_kernel<64,128,true,false> (two reads of the same tensors: 430 us)"}
     del x, y, gz
     # --- two-source forward (position encoding 64 + mlp1 output 64 -> 128), 1 launch per step ------------------------
     C2 = 64
@@ -395,7 +387,7 @@ def kernel_rooflines(B, device):
     group = {"kernel": "sa_l1_kernel<9> (level-1 selection + gather + feature build in one launch; unfused = fused_conv_select_k + 2 row "
                        "gathers + subtract + norm + cat, host-timed eager launches)", "bound": "hbm (in practice L2 / LDS / issue)",
              "bytes_per_launch": B * (2 * 64 * 1800 * 12 + 3600 * 32 * 48), "cases": grp}
-    dgrad["other_kernels"] = [fwd, wg, two, pf, selk, group, _mlp_chain_entry(B, device)]
+    dgrad["other_kernels"] = [fwd, two, pf, selk, group, _mlp_chain_entry(B, device)]
     del f, gk, bn, bk
     torch.cuda.empty_cache()
     dgrad["chain"] = chain_roofline(B, device)

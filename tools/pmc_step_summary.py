@@ -57,7 +57,8 @@ def parse(path):
 
 
 # algorithmic bytes per launch at batch 8 (rows = 853632) of the in-step layer kernels: rows*(channels read + written)*4 B
-ALG = {"wreg_dgrad_kernel<64, 128, false>": ROWS * (2 * 64 + 2 * 128) * 4, "wreg_dgrad_kernel<64, 64, false>": ROWS * 4 * 64 * 4,
+ALG = {"wreg_bwd_fused_kernel<64, 128>": ROWS * (2 * 64 + 2 * 128) * 4, "wreg_bwd_fused_kernel<64, 64>": ROWS * 4 * 64 * 4,
+       "wreg_dgrad_kernel<64, 128, false>": ROWS * (2 * 64 + 2 * 128) * 4, "wreg_dgrad_kernel<64, 64, false>": ROWS * 4 * 64 * 4,
        "wreg_dgrad_kernel<128, 128, true>": ROWS * (2 * 128 + 2 * 128 + 64) * 4,          # + the added gradient ga3 [rows, 64]
        "wreg_fwd_kernel<128, 64, true, false>": ROWS * (128 + 64) * 4, "wreg_fwd_kernel<64, 64, true, false>": ROWS * 128 * 4,
        "wreg_fwd_kernel<128, 128, true, true>": ROWS * 256 * 4, "wreg_wgrad_kernel<64, 128, true, false>": ROWS * (2 * 64 + 128) * 4,
