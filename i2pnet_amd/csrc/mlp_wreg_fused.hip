@@ -129,8 +129,11 @@ __global__ __launch_bounds__(WF_THREADS, 1) void wreg_bwd_fused_kernel(WregFused
         constexpr int L = K / 4, NMF = NT * L, SL = NMF / NT, NWG = NO * NI * 4, SLC = NWG / NT, LAT = 6;
         static_assert(SL >= 13 && SLC >= 10 && NWG / 4 >= 2, "slot plan");
         f32x4 acc[NT];
-        for (int k = 0; k < n_mine; ++k) {
-            const bool has_next = k + 1 < n_mine;
+        // The first strip is PEELED (the body is instantiated in front of the loop and inside it): the compiler's s_waitcnt vmcnt counts at
+        // the loop header are the minimum over the entry path and the back edge, and on the entry path (the prologue's 16 requests, no
+        // stores behind them) fewer operations are younger than a needed register than in steady state (16 requests + 8 stores) — the
+        // steady-state iterations then waited for the x requests issued only half a strip earlier.
+        auto strip = [&](const bool has_next) {
             f32x4 xg[NF];
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
@@ -227,7 +230,9 @@ __global__ __launch_bounds__(WF_THREADS, 1) void wreg_bwd_fused_kernel(WregFused
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
+        };
+        strip(n_mine > 1);
+        for (int k = 1; k < n_mine; ++k) strip(k + 1 < n_mine);
     }
     __syncthreads();
     if (p.sums) {      // lanes with the same q hold the same channels: sum over the 16 rows (m), one fp64 atomic per wave, channel and moment
