@@ -73,6 +73,8 @@ def inverse_3x3(m):
 # on one box: 485-488 samples/s with the two branches against 491-495 in one stream — the pyramid's small launches do not
 # hide under the encoder's kernels, they slow them down — so it stays OFF unless I2P_OVERLAP=1.
 OVERLAP_BRANCHES = os.environ.get("I2P_OVERLAP", "0") == "1"
+# the first image block's batch statistics (csrc/image_first.hip) on a side stream beside the LiDAR pyramid (I2P_STATS_OVERLAP)
+STATS_BESIDE_PYRAMID = os.environ.get("I2P_STATS_OVERLAP", "0") == "1"
 _SIDE = {}
 
 
@@ -164,7 +166,6 @@ class RegNet_v2(nn.Module):
 
     def _image_branch(self, rgb_img, intrinsic):
         """image encoder -> (RF3 [B,128,h3,w3], pixel rays [B,M,3], RF3 as points [B,M,C], its unit-variance form)"""
-        rgb_img = rgb_img.contiguous(memory_format=torch.channels_last)
         RF3 = self.RGB_net3(self.RGB_net2(self.RGB_net1(rgb_img)))             # [B,128,h3,w3]
         pix_index = set_id_grid(RF3.permute(0, 2, 3, 1))                        # [B,M,3]
         # pixel rays in the normalised camera plane of the level-3 feature map
@@ -216,6 +217,18 @@ class RegNet_v2(nn.Module):
             for t in lidar:                               # produced on `side`, consumed (and later freed) under `cur`
                 if torch.is_tensor(t):
                     t.record_stream(cur)
+        elif STATS_BESIDE_PYRAMID and rgb_img.is_cuda and self.training:
+            # the first image block's statistics (an MFMA-bound pass over the input alone) beside the LiDAR pyramid's small launches
+            cur, st = torch.cuda.current_stream(dev), _side_stream(dev)
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                issued = self.RGB_net1.prefetch_first_stats(rgb_img)
+            lidar = self._lidar_branch(lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev)
+            cur.wait_stream(st)
+            if issued:
+                for t in self.RGB_net1._first_stats[:2]:
+                    t.record_stream(cur)
+            RF3, pix_rays, RF3_pts, RF3_unit = self._image_branch(rgb_img, intrinsic)
         else:
             RF3, pix_rays, RF3_pts, RF3_unit = self._image_branch(rgb_img, intrinsic)
             lidar = self._lidar_branch(lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev)

@@ -272,6 +272,43 @@ class _BnActPool(torch.autograd.Function):
         return dy.permute(0, 3, 1, 2), dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+class _FirstBlock(torch.autograd.Function):
+    """The encoder's first block — Conv2d(3, 16, 3, padding=1) + BatchNorm2d(train) + LeakyReLU + MaxPool2d(3, stride, 1)
+    (src/modules/basicConv.py:6-20) — on csrc/image_first.hip: three launches forward, two backward, the conv output (238 MB at
+    BASELINE configs[1]) never written.  x [B,3,H,W] fp32 in any storage order, not differentiated; saves x, the 1-byte arg-max,
+    32 statistics and the 27x27 Gram matrix of the input windows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, conv_bias, running_mean, running_var, stride, momentum, eps, slope, out_bf16=False, stats=None):
+        be = ops.get_backend()
+        out, arg, mi, gram = be.img_first_forward(x, weight.detach(), gamma.detach(), beta.detach(), eps, slope, stride, momentum,
+                                                  conv_bias.detach() if conv_bias is not None else None, running_mean, running_var,
+                                                  out_bf16=out_bf16, stats=stats)
+        ctx.save_for_backward(x, arg, mi, gram, weight, gamma, beta)
+        ctx.stride, ctx.slope = stride, slope
+        return out.permute(0, 3, 1, 2)                      # [B,16,Ho,Wo] view with channels_last strides
+
+    @staticmethod
+    def backward(ctx, g):
+        x, arg, mi, gram, weight, gamma, beta = ctx.saved_tensors
+        g_nhwc = g.permute(0, 2, 3, 1)
+        if not g_nhwc.is_contiguous():
+            g_nhwc = g_nhwc.contiguous()
+        dW, dgamma, dbeta = ops.get_backend().img_first_backward(g_nhwc, arg, x, weight.detach(), gamma.detach(), beta.detach(),
+                                                                 ctx.slope, ctx.stride, mi, gram)
+        return None, dW, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+def _first_block_ok(x, conv, act, pool, blk_bf):
+    """the encoder's first block on csrc/image_first.hip: fp32 RGB input that needs no gradient, 3 -> 16 channels (I2P_NO_IMG_FIRST=1: off)"""
+    return (ops.get_backend().name == "hip" and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad and not blk_bf
+            and conv.in_channels == 3 and conv.out_channels == 16 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and pool.stride in (1, 2)
+            and 0.0 <= act.negative_slope <= 1.0
+            and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31 and 3 * x.shape[2] * x.shape[3] < 2 ** 31
+            and os.environ.get("I2P_NO_IMG_FIRST") != "1")
+
+
 class _CastBf16(torch.autograd.Function):
     """the encoder's 15 conv weights fp32 -> bf16 in one multi-tensor copy (and their bf16 gradients back to fp32 in one)"""
 
@@ -323,32 +360,60 @@ class _ImageCNN(nn.Sequential):
                 return False
         return True
 
+    def _fast(self, mods):
+        return self.training and all(mods[i + 1].track_running_stats and mods[i + 1].momentum is not None for i in range(0, len(mods), 4))
+
+    def _storage_plan(self, x, nb):
+        """(blk_bf, out_bf): which blocks of this stack store bf16 — the stack is inside the bf16 part of the encoder AND the block is
+        past the leading `I2P_IMG_FP32_BLOCKS` blocks of the encoder, which stay fp32 (the first blocks' rounding is what the encoder
+        amplifies most) — and the storage type of every block's output"""
+        nbf = _img_bf16_nets()
+        idx = getattr(self, "encoder_index", None)         # (a stack on its own: bf16 inside, fp32 out)
+        bf = x.is_cuda and (nbf > 0 if idx is None else idx < nbf)
+        base = (idx or 0) * nb
+        nfp = _img_fp32_blocks()
+        blk_bf = [bf and base + j >= nfp for j in range(nb)]
+        next_stack_bf = idx is not None and idx + 1 < nbf and base + nb >= nfp      # what leaves the bf16 part of the encoder is fp32
+        out_bf = [blk_bf[j + 1] if j + 1 < nb else (bf and next_stack_bf) for j in range(nb)]
+        return blk_bf, out_bf
+
+    def prefetch_first_stats(self, x):
+        """Issue the first block's batch statistics (csrc/image_first.hip: Gram matrix of the input windows + coefficients) on the
+        CURRENT stream, ahead of `forward(x)` — they depend on the images and the conv weights only, so the model runs them beside the
+        LiDAR pyramid.  Returns False (nothing issued) when `forward` would not take the fused first block."""
+        mods = list(self)
+        self._first_stats = None
+        if not (self._fast(mods) and USE_FUSED_IMG and x.dtype == torch.float32 and self._fusable(mods)):
+            return False
+        conv, bn, act, pool = mods[:4]
+        if not _first_block_ok(x, conv, act, pool, self._storage_plan(x, len(mods) // 4)[0][0]):
+            return False
+        self._first_stats = ops.get_backend().img_first_stats(x, conv.weight.detach(), bn.eps, bn.momentum, conv.bias.detach(),
+                                                              bn.running_mean, bn.running_var) + (x,)
+        return True
+
     def forward(self, x):
         mods = list(self)
-        fast = self.training and all(mods[i + 1].track_running_stats and mods[i + 1].momentum is not None
-                                     for i in range(0, len(mods), 4))
-        if not fast:
+        pre, self._first_stats = getattr(self, "_first_stats", None), None
+        if not self._fast(mods):
             return super().forward(x)
         bns = [mods[i + 1] for i in range(0, len(mods), 4)]
         if USE_FUSED_IMG and x.dtype in (torch.float32, torch.bfloat16) and self._fusable(mods):
             with torch.no_grad():
                 torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
-            x = x.contiguous(memory_format=torch.channels_last)
-            nbf = _img_bf16_nets()
-            idx = getattr(self, "encoder_index", None)         # (a stack on its own: bf16 inside, fp32 out)
-            bf = x.is_cuda and (nbf > 0 if idx is None else idx < nbf)
             nb = len(mods) // 4
-            # which blocks of this stack store bf16: the stack is inside the bf16 part of the encoder AND the block is past the leading
-            # `I2P_IMG_FP32_BLOCKS` blocks of the encoder, which stay fp32 (the first blocks' rounding is what the encoder amplifies most)
-            base = (idx or 0) * nb
-            nfp = _img_fp32_blocks()
-            blk_bf = [bf and base + j >= nfp for j in range(nb)]
-            next_stack_bf = idx is not None and idx + 1 < nbf and base + nb >= nfp      # what leaves the bf16 part of the encoder is fp32
-            out_bf = [blk_bf[j + 1] if j + 1 < nb else (bf and next_stack_bf) for j in range(nb)]
+            blk_bf, out_bf = self._storage_plan(x, nb)
             if any(blk_bf):
                 ws = _CastBf16.apply(*[mods[i].weight for i in range(0, len(mods), 4)])
             for j, i in enumerate(range(0, len(mods), 4)):
                 conv, bn, act, pool = mods[i:i + 4]
+                if j == 0 and _first_block_ok(x, conv, act, pool, blk_bf[0]):
+                    stats = pre[:2] if (pre is not None and pre[2] is x) else None      # (issued ahead by prefetch_first_stats)
+                    x = _FirstBlock.apply(x, conv.weight, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
+                                          bn.momentum, bn.eps, act.negative_slope, out_bf[0], stats)
+                    continue
+                if j == 0:
+                    x = x.contiguous(memory_format=torch.channels_last)
                 want = torch.bfloat16 if blk_bf[j] else torch.float32
                 if x.dtype != want:
                     x = x.to(want)

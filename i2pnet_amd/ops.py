@@ -556,6 +556,93 @@ class CBackend:
                    self._p(dbeta, _F32, "dbeta"), stream=self._stream())
         return dy, dgamma, dbeta
 
+    # ---- first block of the image encoder without its conv output (csrc/image_first.hip) ----------
+    def _xview(self, x):
+        """x [B,3,H,W] fp32 by strides (NCHW or channels_last storage) -> (pointer, sb, sc, sh, sw)"""
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError("x must be a [B,3,H,W] tensor")
+        if x.device.type != self.device_type:
+            raise RuntimeError(f"x must be a {self.device_type} tensor (got {x.device})")
+        if x.dtype != _F32:
+            raise RuntimeError(f"x must be torch.float32 (got {x.dtype})")
+        return (C.c_void_p(x.data_ptr()),) + tuple(int(v) for v in x.stride())
+
+    def _wview(self, weight):
+        """weight [16,3,3,3] fp32 by strides (contiguous or channels_last storage) -> (pointer, host int[4] of element strides)"""
+        if not isinstance(weight, torch.Tensor) or tuple(weight.shape) != (16, 3, 3, 3):
+            raise RuntimeError(f"weight must be a [16,3,3,3] tensor (got {tuple(getattr(weight, 'shape', ()))})")
+        if weight.device.type != self.device_type or weight.dtype != _F32:
+            raise RuntimeError(f"weight must be a {self.device_type} torch.float32 tensor (got {weight.device}, {weight.dtype})")
+        return C.c_void_p(weight.data_ptr()), (C.c_int * 4)(*[int(v) for v in weight.stride()])
+
+    def img_first_stats(self, x, weight, eps, momentum=0.0, conv_bias=None, running_mean=None, running_var=None):
+        """the first block's batch statistics from the Gram matrix of the input windows -> (mean_invstd f32 [32], gram_red f64 [1024]);
+        updates the running buffers.  Depends on the images and the conv weights only: may be issued ahead of the block, on any stream."""
+        B, _, H, W = x.shape
+        if x.stride(3) != 1:                 # rows are read with vector loads: W must be the unit-stride dimension
+            x = x.contiguous()
+        xp, (wp, ws) = self._xview(x), self._wview(weight)
+        mean_invstd = torch.empty(32, dtype=_F32, device=x.device)
+        gram = zeros(BN_REPLICAS * 1024, torch.float64, x.device)
+        gram_red = torch.empty(1024, dtype=torch.float64, device=x.device)
+        opt = lambda t, what: self._p(t, _F32, what) if t is not None else None
+        self._call("i2p_img_first_fwd", int(B), int(H), int(W), 2, *xp, wp, ws, None, None, float(eps), 0.0, float(momentum),
+                   opt(conv_bias, "conv_bias"), opt(running_mean, "running_mean"), opt(running_var, "running_var"),
+                   self._p(gram, torch.float64, "gram"), self._p(gram_red, torch.float64, "gram_red"), 0, None, None,
+                   self._p(mean_invstd, _F32, "mean_invstd"), 1, stream=self._stream())
+        return mean_invstd, gram_red
+
+    def img_first_forward(self, x, weight, gamma, beta, eps, slope, stride, momentum=0.0, conv_bias=None, running_mean=None,
+                          running_var=None, out_bf16=False, stats=None):
+        """Conv2d(3,16,3,padding=1, no bias in y) + BN(batch statistics) + LeakyReLU + MaxPool2d(3,stride,1) of x [B,3,H,W] ->
+        (out [B,Ho,Wo,16] fp32 / bf16, arg u8, mean_invstd [32], gram_red f64 [1024] for the backward); three launches, the conv
+        output is never written (src/modules/basicConv.py:6-20, first block).  `stats` = what `img_first_stats` returned for the same
+        x and weight: only the output kernel runs."""
+        B, _, H, W = x.shape
+        if x.stride(3) != 1:
+            x = x.contiguous()
+        xp, (wp, ws) = self._xview(x), self._wview(weight)
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        odt = _BF16 if out_bf16 else _F32
+        out = torch.empty(B, Ho, Wo, 16, dtype=odt, device=x.device)
+        arg = torch.empty(B, Ho, Wo, 16, dtype=torch.uint8, device=x.device)
+        opt = lambda t, what: self._p(t, _F32, what) if t is not None else None
+        if stats is None:
+            mean_invstd = torch.empty(32, dtype=_F32, device=x.device)
+            gram = zeros(BN_REPLICAS * 1024, torch.float64, x.device)
+            gram_red = torch.empty(1024, dtype=torch.float64, device=x.device)
+            gp, grp, parts = self._p(gram, torch.float64, "gram"), self._p(gram_red, torch.float64, "gram_red"), 3
+        else:
+            mean_invstd, gram_red = stats
+            gp, grp, parts = None, None, 2
+        self._call("i2p_img_first_fwd", int(B), int(H), int(W), int(stride), *xp, wp, ws,
+                   self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(eps), float(slope), float(momentum),
+                   opt(conv_bias, "conv_bias"), opt(running_mean, "running_mean"), opt(running_var, "running_var"),
+                   gp, grp, int(bool(out_bf16)), self._p(out, odt, "out"), self._p(arg, torch.uint8, "arg"),
+                   self._p(mean_invstd, _F32, "mean_invstd"), parts, stream=self._stream())
+        return out, arg, mean_invstd, gram_red
+
+    def img_first_backward(self, gout, arg, x, weight, gamma, beta, slope, stride, mean_invstd, gram_red):
+        """-> (dW [16,3,3,3] in weight's layout, dgamma [16], dbeta [16]); gout [B,Ho,Wo,16] fp32 or bf16"""
+        B, _, H, W = x.shape
+        if x.stride(3) != 1:
+            x = x.contiguous()
+        xp, (wp, ws) = self._xview(x), self._wview(weight)
+        dev = x.device
+        rows = _lib.helper("i2p_img_first_bwd_rows", int(B), int(H), int(W), int(stride))
+        partials = torch.empty(max(rows, 1) * 16 * 29, dtype=_F32, device=dev)
+        dW = torch.empty_like(weight)
+        if dW.stride() != weight.stride():
+            raise RuntimeError("weight must be dense (contiguous or channels_last)")
+        dgamma = torch.empty(16, dtype=_F32, device=dev)
+        dbeta = torch.empty(16, dtype=_F32, device=dev)
+        self._call("i2p_img_first_bwd", int(B), int(H), int(W), int(stride), *xp, wp, ws,
+                   self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(slope), self._p(mean_invstd, _F32, "mean_invstd"),
+                   self._p(gram_red, torch.float64, "gram_red"), int(gout.dtype == _BF16), self._p(gout, gout.dtype, "gout"),
+                   self._p(arg, torch.uint8, "arg"), self._p(partials, _F32, "partials"), C.c_void_p(dW.data_ptr()),
+                   self._p(dgamma, _F32, "dgamma"), self._p(dbeta, _F32, "dbeta"), stream=self._stream())
+        return dW, dgamma, dbeta
+
     # ---- batch-stat BatchNorm + activation (PPBackbone_center.py:28-46) ---------------------------
     def bn_act_forward(self, y, gamma, beta, eps, slope):
         """y [rows,c] f32 -> (out [rows,c], mean_invstd [2c]) with batch statistics.

@@ -310,6 +310,29 @@ int i2p_img_block_fwd(int B, int H, int W, int C, int stride, int y_bf16, int ou
 int i2p_img_block_bwd(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout, const unsigned char *arg,
                       const void *y, const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums, void *dy,
                       float *dgamma, float *dbeta, void *stream);
+/* Device library only — the FIRST block of the image encoder (src/modules/basicConv.py:6-20 with in_channel = 3: Conv2d(3, 16, 3,
+ * padding 1) + BatchNorm2d + LeakyReLU + MaxPool2d(3, stride, 1)) without the conv output in memory (csrc/image_first.hip): the
+ * convolution is recomputed from the input where it is needed, the batch statistics and the dense parts of the weight gradient come from
+ * the 27 x 27 Gram matrix of the input windows.  Replaces F.conv2d (MIOpen) + i2p_img_block_fwd / F.conv2d's weight gradient +
+ * i2p_img_block_bwd for that block; the input is not differentiated.
+ *   x [B,3,H,W] fp32 addressed by element strides (sb, sc, sh, sw): NCHW or channels_last; wgt [16,3,3,3] addressed by the four element strides ws[4] (host
+ *   array; dW comes back in the same layout), no bias in y
+ *   (conv_bias only enters running_mean, as in i2p_img_block_fwd); gram: f64 [I2P_BN_REPLICAS][1024] zeroed by the caller;
+ *   gram_red f64 [1024] written (rows / columns 0..26 = taps ci*9+kh*3+kw, 27 = the constant 1; kept for the backward);
+ *   out [B,Ho,Wo,16] fp32 or bf16 (out_bf16), arg u8 [B,Ho,Wo,16] (window position of the first maximum), mean_invstd f32 [32].
+ *   backward: gout [B,Ho,Wo,16] fp32 or bf16 (g_bf16) -> dW [16,3,3,3], dgamma, dbeta [16];
+ *   partials: f32 [i2p_img_first_bwd_rows(B,H,W,stride)][16*29] scratch.  B*H*W < 2^31, stride 1 or 2, sw = 1, 0 <= slope <= 1.
+ *   parts: 1 = statistics only (gram, gram_red, mean_invstd, running buffers; out / arg / gamma / beta may be NULL), 2 = output only
+ *   (reads mean_invstd; gram / gram_red may be NULL), 3 = both. */
+int i2p_img_first_fwd(int B, int H, int W, int stride, const float *x, long long sb, long long sc, long long sh, long long sw,
+                      const float *wgt, const int *ws, const float *gamma, const float *beta, float eps, float slope, float momentum,
+                      const float *conv_bias, float *running_mean, float *running_var, double *gram, double *gram_red, int out_bf16,
+                      void *out, unsigned char *arg, float *mean_invstd, int parts, void *stream);
+int i2p_img_first_bwd_rows(int B, int H, int W, int stride);
+int i2p_img_first_bwd(int B, int H, int W, int stride, const float *x, long long sb, long long sc, long long sh, long long sw,
+                      const float *wgt, const int *ws, const float *gamma, const float *beta, float slope, const float *mean_invstd,
+                      const double *gram_red, int g_bf16, const void *gout, const unsigned char *arg, float *partials, float *dW,
+                      float *dgamma, float *dbeta, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * First layer of the all-pixel cost volume (src/projectPN/PPBackbone_center.py:383-418): the
