@@ -865,9 +865,9 @@ static int gen2_grid(int dflt) {
 // BN(batch statistics) + LeakyReLU + MaxPool(3, stride, 1) of the conv output y [B,H,W,C] (fp32, or bf16 bits when y_bf16):
 // statistics into `sums` (f64 [I2P_BN_REPLICAS][2C], zeroed by the caller), then the pooling kernel, which forms mean / invstd from
 // the sums in every block's prologue; out [B,Ho,Wo,C] fp32 or bf16 (out_bf16), arg u8, mean_invstd [2C] and the running buffers written.
-extern "C" int i2p_img_block_fwd(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *y, double *sums,
-                                 const float *gamma, const float *beta, float eps, float slope, float momentum, const float *conv_bias,
-                                 float *running_mean, float *running_var, void *out, unsigned char *arg, float *mean_invstd, void *stream) {
+static int img_block_fwd_impl(bool with_stats, int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *y, double *sums,
+                              const float *gamma, const float *beta, float eps, float slope, float momentum, const float *conv_bias,
+                              float *running_mean, float *running_var, void *out, unsigned char *arg, float *mean_invstd, void *stream) {
     if (!geom2_ok(B, H, W, C, stride, y_bf16)) return I2P_ERR_BAD_ARG;
     if (B == 0) return 0;
     if (!y || !sums || !gamma || !beta || !out || !arg || !mean_invstd) return I2P_ERR_BAD_ARG;
@@ -877,7 +877,8 @@ extern "C" int i2p_img_block_fwd(int B, int H, int W, int C, int stride, int y_b
     const int rpb = THREADS / g.cv;
     long long blocks = (n + (long long)rpb * 4 - 1) / ((long long)rpb * 4);
     if (blocks > MAX_STAT_BLOCKS) blocks = MAX_STAT_BLOCKS;
-    if (y_bf16)
+    if (!with_stats) {}
+    else if (y_bf16)
         hipLaunchKernelGGL(img_stats2_kernel<true>, dim3((unsigned)blocks), dim3(THREADS), 0, st, n, C, g.cv, rpb, y, sums);
     else
         hipLaunchKernelGGL(img_stats2_kernel<false>, dim3((unsigned)blocks), dim3(THREADS), 0, st, n, C, g.cv, rpb, y, sums);
@@ -892,6 +893,20 @@ extern "C" int i2p_img_block_fwd(int B, int H, int W, int C, int stride, int y_b
     IMG_DISPATCH(img_pool_fwd2_kernel, dim3(grid_for(tiles * THREADS, gen2_grid(1 << 14))), g, y, (const double *)sums, gamma, beta, eps, slope, momentum,
                  conv_bias, running_mean, running_var, out, arg, mean_invstd, rc);
     I2P_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int i2p_img_block_fwd(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *y, double *sums,
+                                 const float *gamma, const float *beta, float eps, float slope, float momentum, const float *conv_bias,
+                                 float *running_mean, float *running_var, void *out, unsigned char *arg, float *mean_invstd, void *stream) {
+    return img_block_fwd_impl(true, B, H, W, C, stride, y_bf16, out_bf16, y, sums, gamma, beta, eps, slope, momentum, conv_bias, running_mean,
+                              running_var, out, arg, mean_invstd, stream);
+}
+// the same with `sums` already holding sum y / sum y^2 (written by the producer of y: i2p_img_conv16_fwd): only the pooling launch
+extern "C" int i2p_img_block_pool(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *y, double *sums,
+                                  const float *gamma, const float *beta, float eps, float slope, float momentum, const float *conv_bias,
+                                  float *running_mean, float *running_var, void *out, unsigned char *arg, float *mean_invstd, void *stream) {
+    return img_block_fwd_impl(false, B, H, W, C, stride, y_bf16, out_bf16, y, sums, gamma, beta, eps, slope, momentum, conv_bias, running_mean,
+                              running_var, out, arg, mean_invstd, stream);
 }
 
 // backward of the same: (gout [B,Ho,Wo,C] fp32/bf16, arg, y, mean_invstd) -> dy [B,H,W,C] (storage of y), dgamma, dbeta [C] fp32;

@@ -1,0 +1,172 @@
+// 3x3 convolution (padding 1, stride 1) between 16-channel NHWC fp32 tensors — the image encoder's blocks 2-4 at 188 x 621
+// (src/modules/basicConv.py:6-20: Conv2d(16, 16, 3, padding=1)), forward and input gradient.  MIOpen's implicit-GEMM kernels spend
+// 97 us (forward) / 71 us + an 18 us zero-fill (input gradient) on each of them at BASELINE configs[1]: 120 MB of traffic and 4.3 GFLOP,
+// 28 % of the fp32 MFMA rate — 16 channels are a small GEMM.  Here a wave owns a strip of 16 columns and walks down the rows:
+//   * one 16-byte load per lane and input row (1 KB = 16 pixels x 16 channels) into four row registers, ALREADY in the layout of the
+//     MFMA B operand [k][pixel]: lane (j = lane & 15, kq = lane >> 4) holds channels 4 kq .. 4 kq + 3 of the strip's column j; three
+//     rows cover a conv row's windows and rotate, two more are in flight;
+//   * step (tap, u) of the 36 v_mfma_f32_16x16x4_f32 takes channel ci = 4 kq + u of column j + kw - 1: component u of the row register
+//     itself for the centre column, of the neighbour lane (one DPP row shift, VALU) for the other two — no LDS, no shuffle through
+//     memory; the weights (A operand, 36 registers) are ordered to match; two accumulators alternate (no dependent MFMA chain);
+//   * 36 MFMAs leave channels 4 kq .. 4 kq + 3 of pixel j in the lane = the NHWC vector, stored directly; lanes j = 1 .. 14 own an
+//     output column (their windows lie inside the strip's 16 columns);
+//   * forward: sum y and sum y^2 of the BatchNorm behind the convolution are accumulated from the registers (fp32 over 4 rows,
+//     then fp64) and added to the replicated fp64 sums the pooling kernel reads — the separate statistics pass over y is gone.
+// The input gradient is the same kernel on dL/dy with the weight indices swapped and the taps mirrored.
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int REP = I2P_BN_REPLICAS;
+constexpr int C = 16, KSTEPS = 36;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// W[out][in][kh][kw] by element strides; `flip`: the input-gradient view W'[out = ci][in = co][kh][kw] = W[co][ci][2 - kh][2 - kw]
+struct WView16 {
+    const float *p; int s_out, s_in, s_kh, s_kw, flip;
+    __device__ __forceinline__ float ld(int out, int in, int kh, int kw) const {
+        return p[out * s_out + in * s_in + (flip ? 2 - kh : kh) * s_kh + (flip ? 2 - kw : kw) * s_kw];
+    }
+};
+
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+struct Row { float q[4]; };
+
+// Work = the B x strips x H output rows of all strips in (image, strip, row) order, cut into equal contiguous ranges, one per wave of
+// a grid that is resident at once (4 waves per SIMD): every SIMD runs the same number of MFMAs.  A range that crosses a strip
+// boundary is walked as two segments.
+template <bool STATS>
+__global__ __launch_bounds__(THREADS) void conv16_kernel(const float *__restrict__ x, int B, int H, int W, int strips_w, WView16 wgt,
+                                                         float *__restrict__ y, double *__restrict__ sums) {
+    constexpr int NPW = 14;                                           // output columns per strip
+    const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
+    const unsigned wave = i2p_xcd_swizzle(blockIdx.x, gridDim.x) * (THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned nwaves = gridDim.x * (THREADS / 64);
+    const long long total = (long long)B * strips_w * H;
+    long long pos = total * wave / nwaves;
+    const long long end = total * (wave + 1) / nwaves;
+    if (!STATS && pos >= end) return;
+    // weights: step (tap, u) multiplies channel ci = 4 kq + u of the window column kw; A operand [co = j][k = kq]
+    float wr[KSTEPS];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wr[t * 4 + u] = wgt.ld(j, 4 * kq + u, t / 3, t % 3);
+    const long long img_px = (long long)H * W;
+    const int row4 = W * C * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
+    double ds[4] = {0.0, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};
+    while (pos < end) {
+        const long long bs = pos / H;
+        const int r0 = (int)(pos - bs * H), r1 = (int)min((long long)H, r0 + (end - pos));
+        const int b = (int)(bs / strips_w), strip = (int)(bs - (long long)b * strips_w);
+        pos += r1 - r0;
+        const int c0 = strip * NPW;                                   // output columns c0 .. c0 + 13, rows r0 .. r1 - 1
+        // the strip's 16 input columns c0 - 1 .. c0 + 14: lane (j, kq) loads the channel quad kq of column j
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (long long)b * img_px * C), 0,
+                                                                              (int)(img_px * C * 4), 0x00020000);
+        const int lcol = c0 - 1 + j;
+        const int lvoff = (lcol >= 0 && lcol < W) ? (lcol * C + kq * 4) * 4 : 0x7fffffff;           // outside the image: reads 0
+        auto load_x = [&](int xr) -> Row {
+            Row r;
+            if (xr < 0 || xr >= H) { r.q[0] = r.q[1] = r.q[2] = r.q[3] = 0.f; return r; }
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lvoff, xr * row4, 0);
+            r.q[0] = __uint_as_float(t[0]); r.q[1] = __uint_as_float(t[1]); r.q[2] = __uint_as_float(t[2]); r.q[3] = __uint_as_float(t[3]);
+            return r;
+        };
+        const int oc = c0 + j - 1;                                    // this lane's output column
+        const bool owns = j >= 1 && j <= 14 && oc < W;
+        Row R0 = load_x(r0 - 1), R1 = load_x(r0), R2 = load_x(r0 + 1), Rn = load_x(r0 + 2), Rnn;
+        float *yb = y + (long long)b * img_px * C;
+        for (int r = r0; r < r1; ++r) {
+            Rnn = load_x(r + 3);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const Row &R = kh == 0 ? R0 : (kh == 1 ? R1 : R2);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    // window column kw = strip column j + kw - 1: row_shr:1 reads lane j - 1, row_shl:1 lane j + 1 (lanes 0 / 15 own no output)
+                    const float left = dpp_f32<0x111>(R.q[u]), right = dpp_f32<0x101>(R.q[u]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kh * 3 + 0) * 4 + u], left, acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kh * 3 + 1) * 4 + u], R.q[u], acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kh * 3 + 2) * 4 + u], right, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += acc2[c];
+            if (owns) *reinterpret_cast<f32x4 *>(yb + ((long long)r * W + oc) * C + 4 * kq) = acc;
+            if constexpr (STATS) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = owns ? acc[c] : 0.f;
+                    s[c] += v;
+                    q2[c] = __fmaf_rn(v, v, q2[c]);
+                }
+                if (((r - r0) & 3) == 3 || r + 1 == r1) {             // fp32 over 4 rows, then fp64
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { ds[c] += (double)s[c]; dq[c] += (double)q2[c]; s[c] = 0.f; q2[c] = 0.f; }
+                }
+            }
+            R0 = R1; R1 = R2; R2 = Rn; Rn = Rnn;
+        }
+    }
+    if constexpr (STATS) {
+        // the 16 lanes of a row (same kq = same 4 channels) summed, the block's 4 waves through LDS, then one fp64 atomic per channel
+        __shared__ double red[THREADS / 64][2 * C];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { ds[c] += __shfl_xor(ds[c], m); dq[c] += __shfl_xor(dq[c], m); }
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { red[threadIdx.x >> 6][4 * kq + c] = ds[c]; red[threadIdx.x >> 6][C + 4 * kq + c] = dq[c]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * C) {
+            double t = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < THREADS / 64; ++w2) t += red[w2][threadIdx.x];
+            atomicAdd(sums + (size_t)(blockIdx.x % REP) * 2 * C + threadIdx.x, t);
+        }
+    }
+}
+
+unsigned round8(long long v) { return (unsigned)((v + 7) & ~7ll); }
+
+int launch(const float *x, int B, int H, int W, const float *w, const int *ws, int flip, float *y, double *sums, hipStream_t st) {
+    if (B < 0 || H <= 0 || W <= 0 || (long long)H * W * C * 4 >= (1ll << 31)) return I2P_ERR_BAD_ARG;
+    if (B == 0) return 0;
+    if (!x || !w || !ws || !y) return I2P_ERR_BAD_ARG;
+    // forward: W[co][ci][kh][kw] read as [out = co][in = ci]; input gradient: [out = ci][in = co], taps mirrored
+    const WView16 wv{w, flip ? ws[1] : ws[0], flip ? ws[0] : ws[1], ws[2], ws[3], flip};
+    const int strips = (W + 13) / 14;
+    // 4 waves per SIMD of the whole chip, all resident (<= 128 VGPRs); small tensors: one wave per 4 output rows of a strip
+    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    const long long total = (long long)B * strips * H;
+    long long blocks = (long long)cus * 4;
+    if (blocks * (THREADS / 64) * 4 > total) blocks = (total + 4 * (THREADS / 64) - 1) / (4 * (THREADS / 64));
+    const dim3 grid(round8(blocks));
+    if (sums) hipLaunchKernelGGL(conv16_kernel<true>, grid, dim3(THREADS), 0, st, x, B, H, W, strips, wv, y, sums);
+    else hipLaunchKernelGGL(conv16_kernel<false>, grid, dim3(THREADS), 0, st, x, B, H, W, strips, wv, y, sums);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+// y [B,H,W,16] = conv3x3(x [B,H,W,16], w [16,16,3,3] by element strides ws[4]), padding 1, no bias; sums (may be NULL): f64
+// [I2P_BN_REPLICAS][32] zeroed by the caller, receives sum y / sum y^2 per output channel (the layout i2p_img_block_pool reads)
+extern "C" int i2p_img_conv16_fwd(int B, int H, int W, const float *x, const float *w, const int *ws, float *y, double *sums, void *stream) {
+    return launch(x, B, H, W, w, ws, 0, y, sums, (hipStream_t)stream);
+}
+
+// dx [B,H,W,16] = the input gradient of the same convolution from dy [B,H,W,16]
+extern "C" int i2p_img_conv16_bwd_data(int B, int H, int W, const float *dy, const float *w, const int *ws, float *dx, void *stream) {
+    return launch(dy, B, H, W, w, ws, 1, dx, nullptr, (hipStream_t)stream);
+}

@@ -548,7 +548,9 @@ extern "C" int i2p_img_first_fwd(int B, int H, int W, int stride, const float *x
     if (parts & 1) {        // the statistics: Gram matrix of the input windows, then mean / invstd of the conv output and the running buffers
         const int ch = (H + GROWS - 1) / GROWS, sg = (W + GSEG - 1) / GSEG;
         static const int grid = env_int("I2P_IMG1_GRAM_GRID", 256);
-        hipLaunchKernelGGL(img1_gram_kernel, dim3(round8(grid)), dim3(GTHREADS), 0, st, xv, B, H, W, ch, sg, gram);
+        // (48 KB static + 40 KB dynamic LDS: one block per CU, the 256-block grid cannot double up on a CU)
+        static const unsigned pad = (unsigned)env_int("I2P_IMG1_GRAM_LDS_PAD", 40 * 1024);
+        hipLaunchKernelGGL(img1_gram_kernel, dim3(round8(grid)), dim3(GTHREADS), pad, st, xv, B, H, W, ch, sg, gram);
         hipLaunchKernelGGL(img1_coef_kernel, dim3(1), dim3(1024), 0, st, (const double *)gram, wv, (long long)B * H * W, eps, momentum, conv_bias,
                            running_mean, running_var, gram_red, mean_invstd);
     }
@@ -585,7 +587,8 @@ extern "C" int i2p_img_first_bwd(int B, int H, int W, int stride, const float *x
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const int th = (Ho + 7) / 8, tw = (Wo + 31) / 32;
     const int rows = i2p_img_first_bwd_rows(B, H, W, stride);
-#define I2P_BWD1(SS, BF) hipLaunchKernelGGL((img1_bwd_kernel<SS, BF>), dim3(rows), dim3(THREADS), 0, st, xv, B, H, W, Ho, Wo, th, tw, wv, \
+    static const unsigned pad = (unsigned)env_int("I2P_IMG1_BWD_LDS_PAD", 16 * 1024);        // 23 + 16 KB: 4 blocks per CU
+#define I2P_BWD1(SS, BF) hipLaunchKernelGGL((img1_bwd_kernel<SS, BF>), dim3(rows), dim3(THREADS), pad, st, xv, B, H, W, Ho, Wo, th, tw, wv, \
                                             mean_invstd, gamma, beta, slope, gout, arg, partials)
     if (stride == 2) { if (g_bf16) I2P_BWD1(2, true); else I2P_BWD1(2, false); }
     else { if (g_bf16) I2P_BWD1(1, true); else I2P_BWD1(1, false); }

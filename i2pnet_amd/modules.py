@@ -309,6 +309,47 @@ def _first_block_ok(x, conv, act, pool, blk_bf):
             and os.environ.get("I2P_NO_IMG_FIRST") != "1")
 
 
+class _Conv16Block(torch.autograd.Function):
+    """A 16 -> 16 channel encoder block (Conv2d(16, 16, 3, padding=1) + BatchNorm2d(train) + LeakyReLU + MaxPool2d(3, stride, 1),
+    src/modules/basicConv.py:6-20) with the convolution and its input gradient on csrc/image_conv16.hip: the forward kernel also
+    accumulates the BatchNorm statistics, so the block is conv + pooling (2 launches); backward = the block-tail kernels, the
+    input-gradient kernel and MIOpen's weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, conv_bias, running_mean, running_var, stride, momentum, eps, slope, out_bf16=False):
+        x_nhwc = x.permute(0, 2, 3, 1)
+        if not x_nhwc.is_contiguous():
+            x_nhwc = x_nhwc.contiguous()
+        be = ops.get_backend()
+        y, sums = be.img_conv16(x_nhwc, weight.detach(), with_sums=True)
+        out, arg, mi = be.img_block_forward(y, gamma.detach(), beta.detach(), eps, slope, stride, momentum, conv_bias.detach(),
+                                            running_mean, running_var, out_bf16=out_bf16, sums=sums)
+        ctx.save_for_backward(x_nhwc, y, arg, mi, weight, gamma, beta)
+        ctx.stride, ctx.slope = stride, slope
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        x_nhwc, y, arg, mi, weight, gamma, beta = ctx.saved_tensors
+        g_nhwc = g.permute(0, 2, 3, 1)
+        if not g_nhwc.is_contiguous():
+            g_nhwc = g_nhwc.contiguous()
+        be = ops.get_backend()
+        dy, dgamma, dbeta = be.img_block_backward(g_nhwc, arg, y, mi, gamma.detach(), beta.detach(), ctx.slope, ctx.stride)
+        dx = be.img_conv16(dy, weight.detach(), input_grad=True).permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None
+        dW = torch.ops.aten.convolution_backward(dy.permute(0, 3, 1, 2), x_nhwc.permute(0, 3, 1, 2), weight, None, (1, 1), (1, 1), (1, 1),
+                                                 False, (0, 0), 1, (False, True, False))[1]
+        return dx, dW, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def _conv16_ok(x, conv, blk_bf):
+    """a 16 -> 16 channel fp32 block on csrc/image_conv16.hip (I2P_NO_CONV16=1: MIOpen's convolution instead)"""
+    return (ops.get_backend().name == "hip" and x.is_cuda and x.dtype == torch.float32 and not blk_bf
+            and conv.in_channels == 16 and conv.out_channels == 16 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and x.shape[2] * x.shape[3] * 64 < 2 ** 31 and os.environ.get("I2P_NO_CONV16") != "1")
+
+
 class _CastBf16(torch.autograd.Function):
     """the encoder's 15 conv weights fp32 -> bf16 in one multi-tensor copy (and their bf16 gradients back to fp32 in one)"""
 
@@ -414,6 +455,10 @@ class _ImageCNN(nn.Sequential):
                     continue
                 if j == 0:
                     x = x.contiguous(memory_format=torch.channels_last)
+                if _conv16_ok(x, conv, blk_bf[j]):
+                    x = _Conv16Block.apply(x, conv.weight, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
+                                           bn.momentum, bn.eps, act.negative_slope, out_bf[j])
+                    continue
                 want = torch.bfloat16 if blk_bf[j] else torch.float32
                 if x.dtype != want:
                     x = x.to(want)

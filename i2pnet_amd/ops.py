@@ -520,8 +520,28 @@ class CBackend:
             self._call("i2p_img_bn_pool_bwd", *args, stream=self._stream())
         return dy, dgamma, dbeta
 
+    def img_conv16(self, x, weight, with_sums=False, input_grad=False):
+        """3x3 convolution (padding 1, no bias) of x [B,H,W,16] fp32 NHWC with weight [16,16,3,3] (any dense layout) on
+        csrc/image_conv16.hip -> y [B,H,W,16]; with_sums: also the replicated fp64 {sum y, sum y^2} for `img_block_forward(sums=...)`;
+        input_grad: x is dL/dy and the result dL/dx of that convolution."""
+        B, H, W, Cc = x.shape
+        if Cc != 16 or tuple(weight.shape) != (16, 16, 3, 3):
+            raise RuntimeError(f"img_conv16: 16-channel tensors only (got x {tuple(x.shape)}, weight {tuple(weight.shape)})")
+        if weight.device.type != self.device_type or weight.dtype != _F32:
+            raise RuntimeError("weight must be a torch.float32 tensor on the device")
+        ws = (C.c_int * 4)(*[int(v) for v in weight.stride()])
+        y = torch.empty_like(x)
+        if input_grad:
+            self._call("i2p_img_conv16_bwd_data", int(B), int(H), int(W), self._p(x, _F32, "dy"), C.c_void_p(weight.data_ptr()), ws,
+                       self._p(y, _F32, "dx"), stream=self._stream())
+            return y
+        sums = zeros(BN_REPLICAS * 32, torch.float64, x.device) if with_sums else None
+        self._call("i2p_img_conv16_fwd", int(B), int(H), int(W), self._p(x, _F32, "x"), C.c_void_p(weight.data_ptr()), ws,
+                   self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums") if with_sums else None, stream=self._stream())
+        return (y, sums) if with_sums else y
+
     def img_block_forward(self, y, gamma, beta, eps, slope, stride, momentum=0.0, conv_bias=None, running_mean=None,
-                          running_var=None, out_bf16=False):
+                          running_var=None, out_bf16=False, sums=None):
         """second generation of `img_bn_pool_forward` (device library only): y [B,H,W,C] fp32 or bf16 -> (out fp32 / bf16, arg u8,
         mean_invstd [2C]); statistics + pooling in two launches, the coefficients formed in the pooling kernel's prologue."""
         B, H, W, Cc = y.shape
@@ -533,9 +553,11 @@ class CBackend:
         out = torch.empty(B, Ho, Wo, Cc, dtype=odt, device=y.device)
         arg = torch.empty(B, Ho, Wo, Cc, dtype=torch.uint8, device=y.device)
         mean_invstd = torch.empty(2 * Cc, dtype=_F32, device=y.device)
-        sums = zeros(BN_REPLICAS * 2 * Cc, torch.float64, y.device)
+        entry = "i2p_img_block_fwd" if sums is None else "i2p_img_block_pool"       # `sums` = the producer of y accumulated them
+        if sums is None:
+            sums = zeros(BN_REPLICAS * 2 * Cc, torch.float64, y.device)
         opt = lambda t, what: self._p(t, _F32, what) if t is not None else None
-        self._call("i2p_img_block_fwd", int(B), int(H), int(W), int(Cc), int(stride), int(ybf), int(bool(out_bf16)),
+        self._call(entry, int(B), int(H), int(W), int(Cc), int(stride), int(ybf), int(bool(out_bf16)),
                    self._p(y, y.dtype, "y"), self._p(sums, torch.float64, "sums"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"),
                    float(eps), float(slope), float(momentum), opt(conv_bias, "conv_bias"), opt(running_mean, "running_mean"),
                    opt(running_var, "running_var"), self._p(out, odt, "out"), self._p(arg, torch.uint8, "arg"),

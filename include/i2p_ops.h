@@ -310,6 +310,18 @@ int i2p_img_block_fwd(int B, int H, int W, int C, int stride, int y_bf16, int ou
 int i2p_img_block_bwd(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout, const unsigned char *arg,
                       const void *y, const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums, void *dy,
                       float *dgamma, float *dbeta, void *stream);
+/* i2p_img_block_fwd without its statistics pass: `sums` already holds sum y / sum y^2 (the producer of y accumulated them:
+ * i2p_img_conv16_fwd). */
+int i2p_img_block_pool(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *y, double *sums, const float *gamma,
+                       const float *beta, float eps, float slope, float momentum, const float *conv_bias, float *running_mean,
+                       float *running_var, void *out, unsigned char *arg, float *mean_invstd, void *stream);
+/* Device library only — 3x3 convolution, padding 1, stride 1, between 16-channel NHWC fp32 tensors (the image encoder's blocks
+ * 2-4, src/modules/basicConv.py:6-20: Conv2d(16, 16, 3, padding=1) without its bias, which cancels in the BatchNorm behind it) and
+ * its input gradient (csrc/image_conv16.hip); replaces F.conv2d / MIOpen for those layers.  w [16,16,3,3] addressed by the four
+ * element strides ws[4] (host array).  sums (forward, may be NULL): f64 [I2P_BN_REPLICAS][32] zeroed by the caller, receives
+ * sum y / sum y^2 per channel for i2p_img_block_pool.  H*W*64 < 2^31. */
+int i2p_img_conv16_fwd(int B, int H, int W, const float *x, const float *w, const int *ws, float *y, double *sums, void *stream);
+int i2p_img_conv16_bwd_data(int B, int H, int W, const float *dy, const float *w, const int *ws, float *dx, void *stream);
 /* Device library only — the FIRST block of the image encoder (src/modules/basicConv.py:6-20 with in_channel = 3: Conv2d(3, 16, 3,
  * padding 1) + BatchNorm2d + LeakyReLU + MaxPool2d(3, stride, 1)) without the conv output in memory (csrc/image_first.hip): the
  * convolution is recomputed from the input where it is needed, the batch statistics and the dense parts of the weight gradient come from
