@@ -138,7 +138,112 @@ __global__ __launch_bounds__(THREADS) void conv16_kernel(const float *__restrict
     }
 }
 
+// ---- weight gradient ---------------------------------------------------------------------------------------------------------------
+// dW[co][ci][kh][kw] = sum over pixels dy[px][co] x[px + (kh - 1, kw - 1)][ci]: the pixels are the MFMA contraction index, one 16 x 16
+// accumulator tile per tap (36 registers).  In NHWC storage both operands are lane-linear in memory: A [co = i][k = kq] and B [k = kq][ci = j]
+// of a step are 64 consecutive floats per 4 ... here a wave owns 64 columns as four runs of 16 (kq picks the run, the step s the column
+// inside it), so that the three column taps of a row are the SAME 18 loads shifted by one register: 18 + 16 loads feed the 144 MFMAs of
+// a row.  Three input rows rotate, the next input / gradient rows are in flight under the MFMAs.  Waves take equal contiguous ranges of
+// the (image, strip, row) sequence; block sums go to `partials` [blocks][9][256], added up in fp64 by conv16_wgrad_fin_kernel.
+constexpr int WG_COLS = 64;
+
+__global__ __launch_bounds__(THREADS, 2) void conv16_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, int B, int H, int W,
+                                                                  int strips_w, float *__restrict__ partials) {
+    __shared__ float red[THREADS / 64][9 * 256];
+    const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned wave = i2p_xcd_swizzle(blockIdx.x, gridDim.x) * (THREADS / 64) + (unsigned)wv;
+    const unsigned nwaves = gridDim.x * (THREADS / 64);
+    const long long total = (long long)B * strips_w * H;
+    long long pos = total * wave / nwaves;
+    const long long end = total * (wave + 1) / nwaves;
+    const long long img_px = (long long)H * W;
+    const int row4 = W * C * 4;
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    while (pos < end) {
+        const long long bs = pos / H;
+        const int r0 = (int)(pos - bs * H), r1 = (int)min((long long)H, r0 + (end - pos));
+        const int b = (int)(bs / strips_w), strip = (int)(bs - (long long)b * strips_w);
+        pos += r1 - r0;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (long long)b * img_px * C), 0, (int)(img_px * C * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy + (long long)b * img_px * C), 0, (int)(img_px * C * 4), 0x00020000);
+        // slot t = 0 .. 17 of this lane: column strip * 64 + 16 kq + t - 1, channel j; outside the image: an offset that reads 0
+        int voff[18];
+        const int colb = strip * WG_COLS + 16 * kq - 1;
+#pragma unroll
+        for (int t = 0; t < 18; ++t) voff[t] = (colb + t >= 0 && colb + t < W) ? ((colb + t) * C + j) * 4 : 0x7fffffff;
+        auto xrow = [&](int xr, float (&v)[18]) {
+            if (xr < 0 || xr >= H) {
+#pragma unroll
+                for (int t = 0; t < 18; ++t) v[t] = 0.f;
+                return;
+            }
+#pragma unroll
+            for (int t = 0; t < 18; ++t) v[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, voff[t], xr * row4, 0));
+        };
+        auto grow = [&](int gr, float (&v)[16]) {                       // gr inside the image
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, voff[t + 1], gr * row4, 0));
+        };
+        float X0[18], X1[18], X2[18], Xn[18], G[16], Gn[16];
+        xrow(r0 - 1, X0); xrow(r0, X1); xrow(r0 + 1, X2); grow(r0, G);
+        for (int r = r0; r < r1; ++r) {
+            xrow(r + 2, Xn);
+            if (r + 1 < r1) grow(r + 1, Gn);
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    acc[0 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[s2], X0[s2 + kw], acc[0 + kw], 0, 0, 0);
+                    acc[3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[s2], X1[s2 + kw], acc[3 + kw], 0, 0, 0);
+                    acc[6 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[s2], X2[s2 + kw], acc[6 + kw], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 18; ++t) { X0[t] = X1[t]; X1[t] = X2[t]; X2[t] = Xn[t]; }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) G[t] = Gn[t];
+        }
+    }
+    // D[co = 4 kq + r][ci = j] of tap t -> red[wave][t][co * 16 + ci]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][t * 256 + (4 * kq + r) * 16 + j] = acc[t][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * 256; e += THREADS)
+        partials[(size_t)blockIdx.x * (9 * 256) + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+// dW[co][ci][kh][kw] (weight strides) = sum over the blocks' partial sums, fp64, fixed order.  Block (tap, quarter): 64 outputs x 16
+// row groups (every thread a short run of independent loads), the groups added through LDS.
+__global__ __launch_bounds__(1024) void conv16_wgrad_fin_kernel(int nblk, const float *__restrict__ partials, WView16 wgt, float *__restrict__ dW) {
+    __shared__ double part[16][64];
+    const int t = blockIdx.x >> 2, e = (blockIdx.x & 3) * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    double a = 0.0;
+#pragma unroll 8
+    for (int b = grp; b < nblk; b += 16) a += (double)partials[(size_t)b * (9 * 256) + t * 256 + e];
+    part[grp][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double v = 0.0;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) v += part[g2][threadIdx.x];
+        const int co = e >> 4, ci = e & 15;
+        dW[co * wgt.s_out + ci * wgt.s_in + (t / 3) * wgt.s_kh + (t % 3) * wgt.s_kw] = (float)v;
+    }
+}
+
 unsigned round8(long long v) { return (unsigned)((v + 7) & ~7ll); }
+int wgrad_blocks(int B, int H, int W) {
+    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    const long long total = (long long)B * ((W + WG_COLS - 1) / WG_COLS) * H;       // strip rows
+    long long blocks = (long long)cus * 2;                                            // 2 waves per SIMD
+    if (blocks * 4 > total) blocks = (total + 3) / 4;
+    return (int)round8(blocks < 1 ? 1 : blocks);
+}
 
 int launch(const float *x, int B, int H, int W, const float *w, const int *ws, int flip, float *y, double *sums, hipStream_t st) {
     if (B < 0 || H <= 0 || W <= 0 || (long long)H * W * C * 4 >= (1ll << 31)) return I2P_ERR_BAD_ARG;
@@ -164,6 +269,26 @@ int launch(const float *x, int B, int H, int W, const float *w, const int *ws, i
 // [I2P_BN_REPLICAS][32] zeroed by the caller, receives sum y / sum y^2 per output channel (the layout i2p_img_block_pool reads)
 extern "C" int i2p_img_conv16_fwd(int B, int H, int W, const float *x, const float *w, const int *ws, float *y, double *sums, void *stream) {
     return launch(x, B, H, W, w, ws, 0, y, sums, (hipStream_t)stream);
+}
+
+// rows of 9 * 256 floats the weight-gradient entry needs in `partials`
+extern "C" int i2p_img_conv16_wgrad_rows(int B, int H, int W) { return (B <= 0 || H <= 0 || W <= 0) ? 0 : wgrad_blocks(B, H, W); }
+
+// dW (16*16*9 floats, written in w's layout: element strides ws[4] of [co][ci][kh][kw]) = the weight gradient of the convolution from
+// x and dy [B,H,W,16]; partials: f32 [i2p_img_conv16_wgrad_rows()][2304] scratch
+extern "C" int i2p_img_conv16_wgrad(int B, int H, int W, const float *x, const float *dy, const int *ws, float *partials, float *dW, void *stream) {
+    if (B < 0 || H <= 0 || W <= 0 || (long long)H * W * C * 4 >= (1ll << 31) || !ws || !dW) return I2P_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const WView16 wv{nullptr, ws[0], ws[1], ws[2], ws[3], 0};
+    if (B == 0) {
+        hipLaunchKernelGGL(conv16_wgrad_fin_kernel, dim3(36), dim3(1024), 0, st, 0, (const float *)partials, wv, dW);
+        I2P_RETURN_LAUNCH_STATUS();
+    }
+    if (!x || !dy || !partials) return I2P_ERR_BAD_ARG;
+    const int blocks = wgrad_blocks(B, H, W);
+    hipLaunchKernelGGL(conv16_wgrad_kernel, dim3(blocks), dim3(THREADS), 0, st, x, dy, B, H, W, (W + WG_COLS - 1) / WG_COLS, partials);
+    hipLaunchKernelGGL(conv16_wgrad_fin_kernel, dim3(36), dim3(1024), 0, st, blocks, (const float *)partials, wv, dW);
+    I2P_RETURN_LAUNCH_STATUS();
 }
 
 // dx [B,H,W,16] = the input gradient of the same convolution from dy [B,H,W,16]

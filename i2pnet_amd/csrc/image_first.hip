@@ -487,8 +487,10 @@ __global__ __launch_bounds__(1024) void img1_bwd_fin_kernel(int nblk, const floa
     __shared__ double part[32][32], R[PROW];
     const int co = blockIdx.x, k = threadIdx.x & 31, grp = threadIdx.x >> 5;
     double a = 0.0;
-    if (k < PROW)
+    if (k < PROW) {
+#pragma unroll 8
         for (int b = grp; b < nblk; b += 32) a += (double)partials[(size_t)b * (CO * PROW) + co * PROW + k];
+    }
     part[grp][k] = a;
     __syncthreads();
     if (threadIdx.x < PROW) {

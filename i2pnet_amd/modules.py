@@ -313,7 +313,7 @@ class _Conv16Block(torch.autograd.Function):
     """A 16 -> 16 channel encoder block (Conv2d(16, 16, 3, padding=1) + BatchNorm2d(train) + LeakyReLU + MaxPool2d(3, stride, 1),
     src/modules/basicConv.py:6-20) with the convolution and its input gradient on csrc/image_conv16.hip: the forward kernel also
     accumulates the BatchNorm statistics, so the block is conv + pooling (2 launches); backward = the block-tail kernels, the
-    input-gradient kernel and MIOpen's weight gradient."""
+    input-gradient kernel and the weight-gradient kernel (+ its 9-block reduction)."""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, conv_bias, running_mean, running_var, stride, momentum, eps, slope, out_bf16=False):
@@ -337,8 +337,11 @@ class _Conv16Block(torch.autograd.Function):
         be = ops.get_backend()
         dy, dgamma, dbeta = be.img_block_backward(g_nhwc, arg, y, mi, gamma.detach(), beta.detach(), ctx.slope, ctx.stride)
         dx = be.img_conv16(dy, weight.detach(), input_grad=True).permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None
-        dW = torch.ops.aten.convolution_backward(dy.permute(0, 3, 1, 2), x_nhwc.permute(0, 3, 1, 2), weight, None, (1, 1), (1, 1), (1, 1),
-                                                 False, (0, 0), 1, (False, True, False))[1]
+        if os.environ.get("I2P_CONV16_MIOPEN_WGRAD") == "1":          # (A/B: MIOpen's split-K weight gradient)
+            dW = torch.ops.aten.convolution_backward(dy.permute(0, 3, 1, 2), x_nhwc.permute(0, 3, 1, 2), weight, None, (1, 1), (1, 1), (1, 1),
+                                                     False, (0, 0), 1, (False, True, False))[1]
+        else:
+            dW = be.img_conv16_wgrad(x_nhwc, dy, weight.detach())
         return dx, dW, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 

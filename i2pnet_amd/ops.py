@@ -540,6 +540,21 @@ class CBackend:
                    self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums") if with_sums else None, stream=self._stream())
         return (y, sums) if with_sums else y
 
+    def img_conv16_wgrad(self, x, dy, weight):
+        """dW of the 16 -> 16 channel 3x3 convolution from x, dy [B,H,W,16] fp32 NHWC, in `weight`'s layout (csrc/image_conv16.hip)"""
+        B, H, W, Cc = x.shape
+        if Cc != 16 or tuple(dy.shape) != tuple(x.shape) or tuple(weight.shape) != (16, 16, 3, 3):
+            raise RuntimeError(f"img_conv16_wgrad: 16-channel tensors only (got x {tuple(x.shape)}, dy {tuple(dy.shape)})")
+        dW = torch.empty_like(weight)
+        if dW.stride() != weight.stride():
+            raise RuntimeError("weight must be dense (contiguous or channels_last)")
+        ws = (C.c_int * 4)(*[int(v) for v in weight.stride()])
+        rows = _lib.helper("i2p_img_conv16_wgrad_rows", int(B), int(H), int(W))
+        partials = torch.empty(max(rows, 1) * 2304, dtype=_F32, device=x.device)
+        self._call("i2p_img_conv16_wgrad", int(B), int(H), int(W), self._p(x, _F32, "x"), self._p(dy, _F32, "dy"), ws,
+                   self._p(partials, _F32, "partials"), C.c_void_p(dW.data_ptr()), stream=self._stream())
+        return dW
+
     def img_block_forward(self, y, gamma, beta, eps, slope, stride, momentum=0.0, conv_bias=None, running_mean=None,
                           running_var=None, out_bf16=False, sums=None):
         """second generation of `img_bn_pool_forward` (device library only): y [B,H,W,C] fp32 or bf16 -> (out fp32 / bf16, arg u8,

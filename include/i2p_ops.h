@@ -322,6 +322,11 @@ int i2p_img_block_pool(int B, int H, int W, int C, int stride, int y_bf16, int o
  * sum y / sum y^2 per channel for i2p_img_block_pool.  H*W*64 < 2^31. */
 int i2p_img_conv16_fwd(int B, int H, int W, const float *x, const float *w, const int *ws, float *y, double *sums, void *stream);
 int i2p_img_conv16_bwd_data(int B, int H, int W, const float *dy, const float *w, const int *ws, float *dx, void *stream);
+/* the weight gradient of the same convolution: dW (2304 floats, written in w's layout by the element strides ws[4]) from x and dy
+ * [B,H,W,16]; partials: f32 [i2p_img_conv16_wgrad_rows(B,H,W)][2304] scratch (block sums, added in fp64 in a fixed order:
+ * reproducible run to run, unlike MIOpen's atomically accumulated split-K kernels it replaces) */
+int i2p_img_conv16_wgrad_rows(int B, int H, int W);
+int i2p_img_conv16_wgrad(int B, int H, int W, const float *x, const float *dy, const int *ws, float *partials, float *dW, void *stream);
 /* Device library only — the FIRST block of the image encoder (src/modules/basicConv.py:6-20 with in_channel = 3: Conv2d(3, 16, 3,
  * padding 1) + BatchNorm2d + LeakyReLU + MaxPool2d(3, stride, 1)) without the conv output in memory (csrc/image_first.hip): the
  * convolution is recomputed from the input where it is needed, the batch statistics and the dense parts of the weight gradient come from

@@ -31,6 +31,12 @@ def test_conv16_forward_sums_and_input_gradient(hip_backend, layout, B, H, W):
     dref = F.conv_transpose2d(dy.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
     dx = hip_backend.img_conv16(dy.to(DEV), wd, input_grad=True)
     assert (dx.cpu().double() - dref).abs().max().item() <= 2e-6 * dref.abs().max().item()
+    xr = x.permute(0, 3, 1, 2).double()
+    wref = torch.nn.grad.conv2d_weight(xr, (16, 16, 3, 3), dy.permute(0, 3, 1, 2).double(), 1, 1)
+    dW = hip_backend.img_conv16_wgrad(x.to(DEV), dy.to(DEV), wd)
+    assert dW.stride() == wd.stride()
+    assert (dW.cpu().double() - wref).abs().max().item() <= 5e-6 * wref.abs().max().item()
+    assert torch.equal(dW, hip_backend.img_conv16_wgrad(x.to(DEV), dy.to(DEV), wd))              # fixed summation order
 
 
 def test_conv16_rejects_other_shapes(hip_backend):

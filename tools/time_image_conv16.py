@@ -39,6 +39,7 @@ def main():
     print(f"conv16 forward + BN sums : {t:7.1f} us  ({2 * mb / t:.2f} TB/s on x + y, {2 * 2304 * x.numel() / 16 / t / 1e6:.1f} TFLOP/s)")
     t = timed(lambda: be.img_conv16(dy, w, input_grad=True))
     print(f"conv16 input gradient    : {t:7.1f} us")
+    print(f"conv16 weight gradient   : {timed(lambda: be.img_conv16_wgrad(x, dy, w)):7.1f} us  (pass + 9-block reduction)")
     import os
     if os.environ.get("I2P_TIME_CONV16_ONLY") == "1":
         return
@@ -49,6 +50,8 @@ def main():
     print(f"MIOpen weight gradient   : {timed(ww):7.1f} us")
     y = be.img_conv16(x, w)
     ref = F.conv2d(xc, w, None, 1, 1).permute(0, 2, 3, 1)
+    dW, dW2 = be.img_conv16_wgrad(x, dy, w), ww()[1]
+    print(f"max |dW - dW_miopen| / max = {(dW - dW2).abs().max().item() / dW2.abs().max().item():.2e}")
     print(f"max |y - y_miopen| / max = {(y - ref).abs().max().item() / ref.abs().max().item():.2e}")
 
 
