@@ -1,15 +1,16 @@
-// 3x3 convolution (padding 1, stride 1) between 16-channel NHWC fp32 tensors — the image encoder's blocks 2-4 at 188 x 621
-// (src/modules/basicConv.py:6-20: Conv2d(16, 16, 3, padding=1)), forward and input gradient.  MIOpen's implicit-GEMM kernels spend
-// 97 us (forward) / 71 us + an 18 us zero-fill (input gradient) on each of them at BASELINE configs[1]: 120 MB of traffic and 4.3 GFLOP,
-// 28 % of the fp32 MFMA rate — 16 channels are a small GEMM.  Here a wave owns a strip of 16 columns and walks down the rows:
-//   * one 16-byte load per lane and input row (1 KB = 16 pixels x 16 channels) into four row registers, ALREADY in the layout of the
-//     MFMA B operand [k][pixel]: lane (j = lane & 15, kq = lane >> 4) holds channels 4 kq .. 4 kq + 3 of the strip's column j; three
-//     rows cover a conv row's windows and rotate, two more are in flight;
-//   * step (tap, u) of the 36 v_mfma_f32_16x16x4_f32 takes channel ci = 4 kq + u of column j + kw - 1: component u of the row register
-//     itself for the centre column, of the neighbour lane (one DPP row shift, VALU) for the other two — no LDS, no shuffle through
-//     memory; the weights (A operand, 36 registers) are ordered to match; two accumulators alternate (no dependent MFMA chain);
-//   * 36 MFMAs leave channels 4 kq .. 4 kq + 3 of pixel j in the lane = the NHWC vector, stored directly; lanes j = 1 .. 14 own an
-//     output column (their windows lie inside the strip's 16 columns);
+// 3x3 convolution (padding 1, stride 1) between NHWC fp32 tensors of 16 or 32 channels — the image encoder's blocks 2-5 at 188 x 621
+// (src/modules/basicConv.py:6-20: Conv2d(16, 16, 3, padding=1) x 3 and Conv2d(16, 32, 3, padding=1)): forward, input gradient and
+// weight gradient.  MIOpen's implicit-GEMM kernels spend 101 us (forward), 79 us + an 18 us zero-fill (input gradient) and 130 us
+// (split-K weight gradient, atomics) on each 16 -> 16 layer at BASELINE configs[1]: 120 MB of traffic and 4.3 GFLOP, 28 % of the fp32
+// MFMA rate — 16 channels are a small GEMM.  Forward / input gradient: a wave owns a strip of 16 columns and walks down the rows:
+//   * one 16-byte load per lane, input row and 16 channels (1 KB = 16 pixels x 16 channels) into row registers, ALREADY in the layout
+//     of the MFMA B operand [k][pixel]: lane (j = lane & 15, kq = lane >> 4) holds channels 4 kq .. 4 kq + 3 of the strip's column j;
+//     three rows cover a conv row's windows and rotate, two more are in flight;
+//   * step (tap, q, u) of the v_mfma_f32_16x16x4_f32 chain takes channel ci = 16 q + 4 kq + u of column j + kw - 1: component u of the
+//     row register itself for the centre column, of the neighbour lane (one DPP row shift, VALU) for the other two — no LDS, no shuffle
+//     through memory; the weights (A operand) are ordered to match; two accumulators per output tile alternate;
+//   * the MFMAs leave channels 4 kq .. 4 kq + 3 (of each 16-channel tile) of pixel j in the lane = the NHWC vector, stored directly;
+//     lanes j = 1 .. 14 own an output column (their windows lie inside the strip's 16 columns);
 //   * forward: sum y and sum y^2 of the BatchNorm behind the convolution are accumulated from the registers (fp32 over 4 rows,
 //     then fp64) and added to the replicated fp64 sums the pooling kernel reads — the separate statistics pass over y is gone.
 // The input gradient is the same kernel on dL/dy with the weight indices swapped and the taps mirrored.
@@ -19,7 +20,7 @@ namespace {
 
 constexpr int THREADS = 256;
 constexpr int REP = I2P_BN_REPLICAS;
-constexpr int C = 16, KSTEPS = 36;
+constexpr int C = 16;                       // input channels of the weight-gradient kernel
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -35,15 +36,15 @@ template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
-struct Row { float q[4]; };
-
 // Work = the B x strips x H output rows of all strips in (image, strip, row) order, cut into equal contiguous ranges, one per wave of
 // a grid that is resident at once (4 waves per SIMD): every SIMD runs the same number of MFMAs.  A range that crosses a strip
 // boundary is walked as two segments.
-template <bool STATS>
-__global__ __launch_bounds__(THREADS) void conv16_kernel(const float *__restrict__ x, int B, int H, int W, int strips_w, WView16 wgt,
-                                                         float *__restrict__ y, double *__restrict__ sums) {
+template <int CIN, int COUT, bool STATS>
+__global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restrict__ x, int B, int H, int W, int strips_w, WView16 wgt,
+                                                          float *__restrict__ y, double *__restrict__ sums) {
     constexpr int NPW = 14;                                           // output columns per strip
+    constexpr int NQ = CIN / 16, NT = COUT / 16, KS = 9 * 4 * NQ;     // 16-channel groups of the input / output, MFMA steps per tile
+    struct Row { float q[NQ][4]; };
     const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
     const unsigned wave = i2p_xcd_swizzle(blockIdx.x, gridDim.x) * (THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned nwaves = gridDim.x * (THREADS / 64);
@@ -51,104 +52,127 @@ __global__ __launch_bounds__(THREADS) void conv16_kernel(const float *__restrict
     long long pos = total * wave / nwaves;
     const long long end = total * (wave + 1) / nwaves;
     if (!STATS && pos >= end) return;
-    // weights: step (tap, u) multiplies channel ci = 4 kq + u of the window column kw; A operand [co = j][k = kq]
-    float wr[KSTEPS];
+    // weights: step (tap, q, u) multiplies channel ci = 16 q + 4 kq + u of the window column kw; A operand [co = 16 nt + j][k = kq]
+    float wr[NT][KS];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) wr[t * 4 + u] = wgt.ld(j, 4 * kq + u, t / 3, t % 3);
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int qu = 0; qu < 4 * NQ; ++qu) wr[nt][t * 4 * NQ + qu] = wgt.ld(16 * nt + j, 16 * (qu >> 2) + 4 * kq + (qu & 3), t / 3, t % 3);
     const long long img_px = (long long)H * W;
-    const int row4 = W * C * 4;
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
-    double ds[4] = {0.0, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};
+    const int row4 = W * CIN * 4;
+    float s[NT][4], q2[NT][4];
+    double ds[NT][4], dq[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s[nt][c] = 0.f; q2[nt][c] = 0.f; ds[nt][c] = 0.0; dq[nt][c] = 0.0; }
     while (pos < end) {
         const long long bs = pos / H;
         const int r0 = (int)(pos - bs * H), r1 = (int)min((long long)H, r0 + (end - pos));
         const int b = (int)(bs / strips_w), strip = (int)(bs - (long long)b * strips_w);
         pos += r1 - r0;
         const int c0 = strip * NPW;                                   // output columns c0 .. c0 + 13, rows r0 .. r1 - 1
-        // the strip's 16 input columns c0 - 1 .. c0 + 14: lane (j, kq) loads the channel quad kq of column j
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (long long)b * img_px * C), 0,
-                                                                              (int)(img_px * C * 4), 0x00020000);
+        // the strip's 16 input columns c0 - 1 .. c0 + 14: lane (j, kq) loads the channel quads kq (+ 4 q) of column j
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (long long)b * img_px * CIN), 0,
+                                                                              (int)(img_px * CIN * 4), 0x00020000);
         const int lcol = c0 - 1 + j;
-        const int lvoff = (lcol >= 0 && lcol < W) ? (lcol * C + kq * 4) * 4 : 0x7fffffff;           // outside the image: reads 0
+        const int lvoff = (lcol >= 0 && lcol < W) ? (lcol * CIN + kq * 4) * 4 : 0x7fffffff;         // outside the image: reads 0
         auto load_x = [&](int xr) -> Row {
             Row r;
-            if (xr < 0 || xr >= H) { r.q[0] = r.q[1] = r.q[2] = r.q[3] = 0.f; return r; }
-            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lvoff, xr * row4, 0);
-            r.q[0] = __uint_as_float(t[0]); r.q[1] = __uint_as_float(t[1]); r.q[2] = __uint_as_float(t[2]); r.q[3] = __uint_as_float(t[3]);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (xr < 0 || xr >= H) { r.q[q][0] = r.q[q][1] = r.q[q][2] = r.q[q][3] = 0.f; continue; }
+                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lvoff == 0x7fffffff ? lvoff : lvoff + 64 * q, xr * row4, 0);
+                r.q[q][0] = __uint_as_float(t[0]); r.q[q][1] = __uint_as_float(t[1]); r.q[q][2] = __uint_as_float(t[2]); r.q[q][3] = __uint_as_float(t[3]);
+            }
             return r;
         };
         const int oc = c0 + j - 1;                                    // this lane's output column
         const bool owns = j >= 1 && j <= 14 && oc < W;
         Row R0 = load_x(r0 - 1), R1 = load_x(r0), R2 = load_x(r0 + 1), Rn = load_x(r0 + 2), Rnn;
-        float *yb = y + (long long)b * img_px * C;
+        float *yb = y + (long long)b * img_px * COUT;
         for (int r = r0; r < r1; ++r) {
             Rnn = load_x(r + 3);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+            f32x4 acc[NT], acc2[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[nt] = acc[nt]; }
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const Row &R = kh == 0 ? R0 : (kh == 1 ? R1 : R2);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int qu = 0; qu < 4 * NQ; ++qu) {
                     // window column kw = strip column j + kw - 1: row_shr:1 reads lane j - 1, row_shl:1 lane j + 1 (lanes 0 / 15 own no output)
-                    const float left = dpp_f32<0x111>(R.q[u]), right = dpp_f32<0x101>(R.q[u]);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kh * 3 + 0) * 4 + u], left, acc, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kh * 3 + 1) * 4 + u], R.q[u], acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kh * 3 + 2) * 4 + u], right, acc, 0, 0, 0);
+                    const float mid = R.q[qu >> 2][qu & 3], left = dpp_f32<0x111>(mid), right = dpp_f32<0x101>(mid);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[nt][(kh * 3 + 0) * 4 * NQ + qu], left, acc[nt], 0, 0, 0);
+                        acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[nt][(kh * 3 + 1) * 4 * NQ + qu], mid, acc2[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[nt][(kh * 3 + 2) * 4 * NQ + qu], right, acc[nt], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] += acc2[c];
-            if (owns) *reinterpret_cast<f32x4 *>(yb + ((long long)r * W + oc) * C + 4 * kq) = acc;
-            if constexpr (STATS) {
+            for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float v = owns ? acc[c] : 0.f;
-                    s[c] += v;
-                    q2[c] = __fmaf_rn(v, v, q2[c]);
+                for (int c = 0; c < 4; ++c) acc[nt][c] += acc2[nt][c];
+                if (owns) *reinterpret_cast<f32x4 *>(yb + ((long long)r * W + oc) * COUT + 16 * nt + 4 * kq) = acc[nt];
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float v = owns ? acc[nt][c] : 0.f;
+                        s[nt][c] += v;
+                        q2[nt][c] = __fmaf_rn(v, v, q2[nt][c]);
+                    }
                 }
+            }
+            if constexpr (STATS) {
                 if (((r - r0) & 3) == 3 || r + 1 == r1) {             // fp32 over 4 rows, then fp64
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { ds[c] += (double)s[c]; dq[c] += (double)q2[c]; s[c] = 0.f; q2[c] = 0.f; }
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { ds[nt][c] += (double)s[nt][c]; dq[nt][c] += (double)q2[nt][c]; s[nt][c] = 0.f; q2[nt][c] = 0.f; }
                 }
             }
             R0 = R1; R1 = R2; R2 = Rn; Rn = Rnn;
         }
     }
     if constexpr (STATS) {
-        // the 16 lanes of a row (same kq = same 4 channels) summed, the block's 4 waves through LDS, then one fp64 atomic per channel
-        __shared__ double red[THREADS / 64][2 * C];
+        // the 16 lanes of a row (same kq = same channels) summed, the block's 4 waves through LDS, then one fp64 atomic per channel
+        __shared__ double red[THREADS / 64][2 * COUT];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int m = 1; m < 16; m <<= 1) { ds[c] += __shfl_xor(ds[c], m); dq[c] += __shfl_xor(dq[c], m); }
-        }
-        if (j == 0) {
+            for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { red[threadIdx.x >> 6][4 * kq + c] = ds[c]; red[threadIdx.x >> 6][C + 4 * kq + c] = dq[c]; }
-        }
+                for (int m = 1; m < 16; m <<= 1) { ds[nt][c] += __shfl_xor(ds[nt][c], m); dq[nt][c] += __shfl_xor(dq[nt][c], m); }
+                if (j == 0) { red[threadIdx.x >> 6][16 * nt + 4 * kq + c] = ds[nt][c]; red[threadIdx.x >> 6][COUT + 16 * nt + 4 * kq + c] = dq[nt][c]; }
+            }
         __syncthreads();
-        if (threadIdx.x < 2 * C) {
+        if (threadIdx.x < 2 * COUT) {
             double t = 0.0;
 #pragma unroll
             for (int w2 = 0; w2 < THREADS / 64; ++w2) t += red[w2][threadIdx.x];
-            atomicAdd(sums + (size_t)(blockIdx.x % REP) * 2 * C + threadIdx.x, t);
+            atomicAdd(sums + (size_t)(blockIdx.x % REP) * 2 * COUT + threadIdx.x, t);
         }
     }
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------------------------------------------
 // dW[co][ci][kh][kw] = sum over pixels dy[px][co] x[px + (kh - 1, kw - 1)][ci]: the pixels are the MFMA contraction index, one 16 x 16
-// accumulator tile per tap (36 registers).  In NHWC storage both operands are lane-linear in memory: A [co = i][k = kq] and B [k = kq][ci = j]
-// of a step are 64 consecutive floats per 4 ... here a wave owns 64 columns as four runs of 16 (kq picks the run, the step s the column
-// inside it), so that the three column taps of a row are the SAME 18 loads shifted by one register: 18 + 16 loads feed the 144 MFMAs of
-// a row.  Three input rows rotate, the next input / gradient rows are in flight under the MFMAs.  Waves take equal contiguous ranges of
-// the (image, strip, row) sequence; block sums go to `partials` [blocks][9][256], added up in fp64 by conv16_wgrad_fin_kernel.
+// accumulator tile per tap and 16 output channels.  In NHWC storage both operands are lane-linear in memory (A [co = i][k = kq] and
+// B [k = kq][ci = j] of a step = 16 consecutive channels of 4 pixels); a wave owns 64 columns as four runs of 16 (kq picks the run, the
+// step s the column inside it), so that the three column taps of a row are the SAME 18 loads shifted by one register: 18 + 16 CO/16
+// loads feed the 144 CO/16 MFMAs of a row.  Three input rows rotate, the next input / gradient rows are in flight under the MFMAs.
+// Waves take equal contiguous ranges of the (image, strip, row) sequence; block sums go to `partials` [blocks][CO/16][9][256], added up
+// in fp64 by conv3x3_wgrad_fin_kernel (fixed order).  x has 16 channels.
 constexpr int WG_COLS = 64;
 
-__global__ __launch_bounds__(THREADS, 2) void conv16_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, int B, int H, int W,
-                                                                  int strips_w, float *__restrict__ partials) {
+template <int CO>
+__global__ __launch_bounds__(THREADS, 2) void conv3x3_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, int B, int H, int W,
+                                                                   int strips_w, float *__restrict__ partials) {
+    constexpr int NT = CO / 16;
     __shared__ float red[THREADS / 64][9 * 256];
     const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -158,17 +182,19 @@ __global__ __launch_bounds__(THREADS, 2) void conv16_wgrad_kernel(const float *_
     long long pos = total * wave / nwaves;
     const long long end = total * (wave + 1) / nwaves;
     const long long img_px = (long long)H * W;
-    const int row4 = W * C * 4;
-    f32x4 acc[9];
+    const int row4x = W * C * 4, row4g = W * CO * 4;
+    f32x4 acc[NT][9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[nt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     while (pos < end) {
         const long long bs = pos / H;
         const int r0 = (int)(pos - bs * H), r1 = (int)min((long long)H, r0 + (end - pos));
         const int b = (int)(bs / strips_w), strip = (int)(bs - (long long)b * strips_w);
         pos += r1 - r0;
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (long long)b * img_px * C), 0, (int)(img_px * C * 4), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy + (long long)b * img_px * C), 0, (int)(img_px * C * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy + (long long)b * img_px * CO), 0, (int)(img_px * CO * 4), 0x00020000);
         // slot t = 0 .. 17 of this lane: column strip * 64 + 16 kq + t - 1, channel j; outside the image: an offset that reads 0
         int voff[18];
         const int colb = strip * WG_COLS + 16 * kq - 1;
@@ -181,117 +207,149 @@ __global__ __launch_bounds__(THREADS, 2) void conv16_wgrad_kernel(const float *_
                 return;
             }
 #pragma unroll
-            for (int t = 0; t < 18; ++t) v[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, voff[t], xr * row4, 0));
+            for (int t = 0; t < 18; ++t) v[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, voff[t], xr * row4x, 0));
         };
-        auto grow = [&](int gr, float (&v)[16]) {                       // gr inside the image
+        auto grow = [&](int gr, int nt, float (&v)[16]) {               // gr inside the image; channels 16 nt + j of the gradient row
 #pragma unroll
-            for (int t = 0; t < 16; ++t) v[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, voff[t + 1], gr * row4, 0));
+            for (int t = 0; t < 16; ++t) {
+                // the gradient's pixel stride is CO floats: (x offset - 4 j) CO / 16 + 4 j
+                const int vo = voff[t + 1] == 0x7fffffff ? 0x7fffffff : (voff[t + 1] - 4 * j) * NT + 4 * j + 64 * nt;
+                v[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, vo, gr * row4g, 0));
+            }
         };
-        float X0[18], X1[18], X2[18], Xn[18], G[16], Gn[16];
-        xrow(r0 - 1, X0); xrow(r0, X1); xrow(r0 + 1, X2); grow(r0, G);
-        for (int r = r0; r < r1; ++r) {
-            xrow(r + 2, Xn);
-            if (r + 1 < r1) grow(r + 1, Gn);
+        auto tile = [&](int nt, const float (&g)[16], const float (&A0)[18], const float (&A1)[18], const float (&A2)[18]) {
 #pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) {
+            for (int s2 = 0; s2 < 16; ++s2)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    acc[0 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[s2], X0[s2 + kw], acc[0 + kw], 0, 0, 0);
-                    acc[3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[s2], X1[s2 + kw], acc[3 + kw], 0, 0, 0);
-                    acc[6 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(G[s2], X2[s2 + kw], acc[6 + kw], 0, 0, 0);
+                    acc[nt][0 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[s2], A0[s2 + kw], acc[nt][0 + kw], 0, 0, 0);
+                    acc[nt][3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[s2], A1[s2 + kw], acc[nt][3 + kw], 0, 0, 0);
+                    acc[nt][6 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[s2], A2[s2 + kw], acc[nt][6 + kw], 0, 0, 0);
                 }
+        };
+        float X0[18], X1[18], X2[18], Xn[18], G0[16], G1[16];
+        xrow(r0 - 1, X0); xrow(r0, X1); xrow(r0 + 1, X2); grow(r0, 0, G0);
+        for (int r = r0; r < r1; ++r) {
+            xrow(r + 2, Xn);
+            if constexpr (NT == 1) {
+                if (r + 1 < r1) grow(r + 1, 0, G1);                     // the next row's gradients under this row's 144 MFMAs
+                tile(0, G0, X0, X1, X2);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) G0[t] = G1[t];
+            } else {
+                grow(r, 1, G1);                                         // the second tile's gradients under the first tile's MFMAs,
+                tile(0, G0, X0, X1, X2);
+                if (r + 1 < r1) grow(r + 1, 0, G0);                     // the next row's first tile under the second's
+                tile(1, G1, X0, X1, X2);
             }
 #pragma unroll
             for (int t = 0; t < 18; ++t) { X0[t] = X1[t]; X1[t] = X2[t]; X2[t] = Xn[t]; }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) G[t] = Gn[t];
         }
     }
-    // D[co = 4 kq + r][ci = j] of tap t -> red[wave][t][co * 16 + ci]
+    // D[co = 16 nt + 4 kq + r][ci = j] of tap t -> partials[block][nt][t][(4 kq + r) * 16 + ci], the 4 waves added through LDS
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int nt = 0; nt < NT; ++nt) {
+        if (nt) __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wv][t * 256 + (4 * kq + r) * 16 + j] = acc[t][r];
-    __syncthreads();
-    for (int e = threadIdx.x; e < 9 * 256; e += THREADS)
-        partials[(size_t)blockIdx.x * (9 * 256) + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wv][t * 256 + (4 * kq + r) * 16 + j] = acc[nt][t][r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 9 * 256; e += THREADS)
+            partials[((size_t)blockIdx.x * NT + nt) * (9 * 256) + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    }
 }
 
-// dW[co][ci][kh][kw] (weight strides) = sum over the blocks' partial sums, fp64, fixed order.  Block (tap, quarter): 64 outputs x 16
+// dW[co][ci][kh][kw] (weight strides) = sum over the blocks' partial sums, fp64, fixed order.  Block (tile, tap, quarter): 64 outputs x 16
 // row groups (every thread a short run of independent loads), the groups added through LDS.
-__global__ __launch_bounds__(1024) void conv16_wgrad_fin_kernel(int nblk, const float *__restrict__ partials, WView16 wgt, float *__restrict__ dW) {
+__global__ __launch_bounds__(1024) void conv3x3_wgrad_fin_kernel(int nblk, int NT, const float *__restrict__ partials, WView16 wgt, float *__restrict__ dW) {
     __shared__ double part[16][64];
-    const int t = blockIdx.x >> 2, e = (blockIdx.x & 3) * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    const int tt = blockIdx.x >> 2, nt = tt / 9, t = tt - nt * 9, e = (blockIdx.x & 3) * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     double a = 0.0;
 #pragma unroll 8
-    for (int b = grp; b < nblk; b += 16) a += (double)partials[(size_t)b * (9 * 256) + t * 256 + e];
+    for (int b = grp; b < nblk; b += 16) a += (double)partials[((size_t)b * NT + nt) * (9 * 256) + t * 256 + e];
     part[grp][threadIdx.x & 63] = a;
     __syncthreads();
     if (threadIdx.x < 64) {
         double v = 0.0;
 #pragma unroll
         for (int g2 = 0; g2 < 16; ++g2) v += part[g2][threadIdx.x];
-        const int co = e >> 4, ci = e & 15;
+        const int co = 16 * nt + (e >> 4), ci = e & 15;
         dW[co * wgt.s_out + ci * wgt.s_in + (t / 3) * wgt.s_kh + (t % 3) * wgt.s_kw] = (float)v;
     }
 }
 
 unsigned round8(long long v) { return (unsigned)((v + 7) & ~7ll); }
-int wgrad_blocks(int B, int H, int W) {
+int num_cus() {
     static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    return cus;
+}
+bool pair_ok(int cin, int cout) { return cin == 16 && (cout == 16 || cout == 32); }
+bool size_ok(int B, int H, int W) { return B >= 0 && H > 0 && W > 0 && (long long)H * W * 32 * 4 < (1ll << 31); }
+int wgrad_blocks(int B, int H, int W) {
     const long long total = (long long)B * ((W + WG_COLS - 1) / WG_COLS) * H;       // strip rows
-    long long blocks = (long long)cus * 2;                                            // 2 waves per SIMD
+    long long blocks = (long long)num_cus() * 2;                                      // 2 waves per SIMD
     if (blocks * 4 > total) blocks = (total + 3) / 4;
     return (int)round8(blocks < 1 ? 1 : blocks);
 }
 
-int launch(const float *x, int B, int H, int W, const float *w, const int *ws, int flip, float *y, double *sums, hipStream_t st) {
-    if (B < 0 || H <= 0 || W <= 0 || (long long)H * W * C * 4 >= (1ll << 31)) return I2P_ERR_BAD_ARG;
+// forward (flip = 0): x [B,H,W,cin] -> y [B,H,W,cout]; input gradient (flip = 1): x = dL/dy [B,H,W,cout] -> y = dL/dx [B,H,W,cin]
+int launch(const float *x, int B, int H, int W, int cin, int cout, const float *w, const int *ws, int flip, float *y, double *sums, hipStream_t st) {
+    if (!size_ok(B, H, W) || !pair_ok(cin, cout)) return I2P_ERR_BAD_ARG;
     if (B == 0) return 0;
     if (!x || !w || !ws || !y) return I2P_ERR_BAD_ARG;
     // forward: W[co][ci][kh][kw] read as [out = co][in = ci]; input gradient: [out = ci][in = co], taps mirrored
     const WView16 wv{w, flip ? ws[1] : ws[0], flip ? ws[0] : ws[1], ws[2], ws[3], flip};
     const int strips = (W + 13) / 14;
     // 4 waves per SIMD of the whole chip, all resident (<= 128 VGPRs); small tensors: one wave per 4 output rows of a strip
-    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
     const long long total = (long long)B * strips * H;
-    long long blocks = (long long)cus * 4;
+    const int wps = cout == 16 ? 4 : 2;                               // the 32-channel variants hold 72 weight registers: 2 - 3 waves per SIMD fit
+    long long blocks = (long long)num_cus() * wps;
     if (blocks * (THREADS / 64) * 4 > total) blocks = (total + 4 * (THREADS / 64) - 1) / (4 * (THREADS / 64));
     const dim3 grid(round8(blocks));
-    if (sums) hipLaunchKernelGGL(conv16_kernel<true>, grid, dim3(THREADS), 0, st, x, B, H, W, strips, wv, y, sums);
-    else hipLaunchKernelGGL(conv16_kernel<false>, grid, dim3(THREADS), 0, st, x, B, H, W, strips, wv, y, sums);
+#define I2P_CONV(CI_, CO_, ST_) hipLaunchKernelGGL((conv3x3_kernel<CI_, CO_, ST_>), grid, dim3(THREADS), 0, st, x, B, H, W, strips, wv, y, sums)
+    if (!flip && cout == 16) { if (sums) I2P_CONV(16, 16, true); else I2P_CONV(16, 16, false); }
+    else if (!flip) { if (sums) I2P_CONV(16, 32, true); else I2P_CONV(16, 32, false); }
+    else if (cout == 16) I2P_CONV(16, 16, false);
+    else I2P_CONV(32, 16, false);
+#undef I2P_CONV
     I2P_RETURN_LAUNCH_STATUS();
 }
 
 }  // namespace
 
-// y [B,H,W,16] = conv3x3(x [B,H,W,16], w [16,16,3,3] by element strides ws[4]), padding 1, no bias; sums (may be NULL): f64
-// [I2P_BN_REPLICAS][32] zeroed by the caller, receives sum y / sum y^2 per output channel (the layout i2p_img_block_pool reads)
-extern "C" int i2p_img_conv16_fwd(int B, int H, int W, const float *x, const float *w, const int *ws, float *y, double *sums, void *stream) {
-    return launch(x, B, H, W, w, ws, 0, y, sums, (hipStream_t)stream);
+// y [B,H,W,cout] = conv3x3(x [B,H,W,cin], w [cout,cin,3,3] by element strides ws[4]), padding 1, no bias; (cin, cout) = (16, 16) or
+// (16, 32).  sums (may be NULL): f64 [I2P_BN_REPLICAS][2 cout] zeroed by the caller, receives sum y / sum y^2 per output channel (the
+// layout i2p_img_block_pool reads)
+extern "C" int i2p_img_conv_fwd(int B, int H, int W, int cin, int cout, const float *x, const float *w, const int *ws, float *y, double *sums,
+                                void *stream) {
+    return launch(x, B, H, W, cin, cout, w, ws, 0, y, sums, (hipStream_t)stream);
 }
 
-// rows of 9 * 256 floats the weight-gradient entry needs in `partials`
-extern "C" int i2p_img_conv16_wgrad_rows(int B, int H, int W) { return (B <= 0 || H <= 0 || W <= 0) ? 0 : wgrad_blocks(B, H, W); }
+// dx [B,H,W,cin] = the input gradient of the same convolution from dy [B,H,W,cout]
+extern "C" int i2p_img_conv_bwd_data(int B, int H, int W, int cin, int cout, const float *dy, const float *w, const int *ws, float *dx, void *stream) {
+    return launch(dy, B, H, W, cin, cout, w, ws, 1, dx, nullptr, (hipStream_t)stream);
+}
 
-// dW (16*16*9 floats, written in w's layout: element strides ws[4] of [co][ci][kh][kw]) = the weight gradient of the convolution from
-// x and dy [B,H,W,16]; partials: f32 [i2p_img_conv16_wgrad_rows()][2304] scratch
-extern "C" int i2p_img_conv16_wgrad(int B, int H, int W, const float *x, const float *dy, const int *ws, float *partials, float *dW, void *stream) {
-    if (B < 0 || H <= 0 || W <= 0 || (long long)H * W * C * 4 >= (1ll << 31) || !ws || !dW) return I2P_ERR_BAD_ARG;
+// rows of (cout / 16) * 9 * 256 floats the weight-gradient entry needs in `partials`
+extern "C" int i2p_img_conv_wgrad_rows(int B, int H, int W) { return (B <= 0 || H <= 0 || W <= 0) ? 0 : wgrad_blocks(B, H, W); }
+
+// dW (cout * cin * 9 floats, written in w's layout: element strides ws[4] of [co][ci][kh][kw]) = the weight gradient of the convolution
+// from x [B,H,W,cin] and dy [B,H,W,cout]; partials: f32 [i2p_img_conv_wgrad_rows()][(cout / 16) * 2304] scratch
+extern "C" int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, const float *x, const float *dy, const int *ws, float *partials, float *dW,
+                                  void *stream) {
+    if (!size_ok(B, H, W) || !pair_ok(cin, cout) || !ws || !dW) return I2P_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const WView16 wv{nullptr, ws[0], ws[1], ws[2], ws[3], 0};
+    const int nt = cout / 16;
     if (B == 0) {
-        hipLaunchKernelGGL(conv16_wgrad_fin_kernel, dim3(36), dim3(1024), 0, st, 0, (const float *)partials, wv, dW);
+        hipLaunchKernelGGL(conv3x3_wgrad_fin_kernel, dim3(36 * nt), dim3(1024), 0, st, 0, nt, (const float *)partials, wv, dW);
         I2P_RETURN_LAUNCH_STATUS();
     }
     if (!x || !dy || !partials) return I2P_ERR_BAD_ARG;
-    const int blocks = wgrad_blocks(B, H, W);
-    hipLaunchKernelGGL(conv16_wgrad_kernel, dim3(blocks), dim3(THREADS), 0, st, x, dy, B, H, W, (W + WG_COLS - 1) / WG_COLS, partials);
-    hipLaunchKernelGGL(conv16_wgrad_fin_kernel, dim3(36), dim3(1024), 0, st, blocks, (const float *)partials, wv, dW);
+    const int blocks = wgrad_blocks(B, H, W), strips = (W + WG_COLS - 1) / WG_COLS;
+    if (cout == 16) hipLaunchKernelGGL(conv3x3_wgrad_kernel<16>, dim3(blocks), dim3(THREADS), 0, st, x, dy, B, H, W, strips, partials);
+    else hipLaunchKernelGGL(conv3x3_wgrad_kernel<32>, dim3(blocks), dim3(THREADS), 0, st, x, dy, B, H, W, strips, partials);
+    hipLaunchKernelGGL(conv3x3_wgrad_fin_kernel, dim3(36 * nt), dim3(1024), 0, st, blocks, nt, (const float *)partials, wv, dW);
     I2P_RETURN_LAUNCH_STATUS();
-}
-
-// dx [B,H,W,16] = the input gradient of the same convolution from dy [B,H,W,16]
-extern "C" int i2p_img_conv16_bwd_data(int B, int H, int W, const float *dy, const float *w, const int *ws, float *dx, void *stream) {
-    return launch(dy, B, H, W, w, ws, 1, dx, nullptr, (hipStream_t)stream);
 }

@@ -310,7 +310,7 @@ def _first_block_ok(x, conv, act, pool, blk_bf):
 
 
 class _Conv16Block(torch.autograd.Function):
-    """A 16 -> 16 channel encoder block (Conv2d(16, 16, 3, padding=1) + BatchNorm2d(train) + LeakyReLU + MaxPool2d(3, stride, 1),
+    """A 16 -> 16 / 16 -> 32 channel encoder block (Conv2d(16, cout, 3, padding=1) + BatchNorm2d(train) + LeakyReLU + MaxPool2d(3, stride, 1),
     src/modules/basicConv.py:6-20) with the convolution and its input gradient on csrc/image_conv16.hip: the forward kernel also
     accumulates the BatchNorm statistics, so the block is conv + pooling (2 launches); backward = the block-tail kernels, the
     input-gradient kernel and the weight-gradient kernel (+ its 9-block reduction)."""
@@ -346,11 +346,13 @@ class _Conv16Block(torch.autograd.Function):
 
 
 def _conv16_ok(x, conv, blk_bf):
-    """a 16 -> 16 channel fp32 block on csrc/image_conv16.hip (I2P_NO_CONV16=1: MIOpen's convolution instead)"""
+    """a 16 -> 16 or 16 -> 32 channel fp32 block on csrc/image_conv16.hip (I2P_NO_CONV16=1: MIOpen's convolutions instead;
+    I2P_NO_CONV32=1: only for the 16 -> 32 block)"""
     return (ops.get_backend().name == "hip" and x.is_cuda and x.dtype == torch.float32 and not blk_bf
-            and conv.in_channels == 16 and conv.out_channels == 16 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.in_channels == 16 and conv.out_channels in (16, 32) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
-            and x.shape[2] * x.shape[3] * 64 < 2 ** 31 and os.environ.get("I2P_NO_CONV16") != "1")
+            and x.shape[2] * x.shape[3] * 128 < 2 ** 31 and os.environ.get("I2P_NO_CONV16") != "1"
+            and (conv.out_channels == 16 or os.environ.get("I2P_NO_CONV32") != "1"))
 
 
 class _CastBf16(torch.autograd.Function):

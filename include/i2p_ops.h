@@ -315,18 +315,18 @@ int i2p_img_block_bwd(int B, int H, int W, int C, int stride, int y_bf16, int ou
 int i2p_img_block_pool(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *y, double *sums, const float *gamma,
                        const float *beta, float eps, float slope, float momentum, const float *conv_bias, float *running_mean,
                        float *running_var, void *out, unsigned char *arg, float *mean_invstd, void *stream);
-/* Device library only — 3x3 convolution, padding 1, stride 1, between 16-channel NHWC fp32 tensors (the image encoder's blocks
- * 2-4, src/modules/basicConv.py:6-20: Conv2d(16, 16, 3, padding=1) without its bias, which cancels in the BatchNorm behind it) and
- * its input gradient (csrc/image_conv16.hip); replaces F.conv2d / MIOpen for those layers.  w [16,16,3,3] addressed by the four
- * element strides ws[4] (host array).  sums (forward, may be NULL): f64 [I2P_BN_REPLICAS][32] zeroed by the caller, receives
- * sum y / sum y^2 per channel for i2p_img_block_pool.  H*W*64 < 2^31. */
-int i2p_img_conv16_fwd(int B, int H, int W, const float *x, const float *w, const int *ws, float *y, double *sums, void *stream);
-int i2p_img_conv16_bwd_data(int B, int H, int W, const float *dy, const float *w, const int *ws, float *dx, void *stream);
-/* the weight gradient of the same convolution: dW (2304 floats, written in w's layout by the element strides ws[4]) from x and dy
- * [B,H,W,16]; partials: f32 [i2p_img_conv16_wgrad_rows(B,H,W)][2304] scratch (block sums, added in fp64 in a fixed order:
- * reproducible run to run, unlike MIOpen's atomically accumulated split-K kernels it replaces) */
-int i2p_img_conv16_wgrad_rows(int B, int H, int W);
-int i2p_img_conv16_wgrad(int B, int H, int W, const float *x, const float *dy, const int *ws, float *partials, float *dW, void *stream);
+/* Device library only — 3x3 convolution, padding 1, stride 1, between NHWC fp32 tensors, (cin, cout) = (16, 16) or (16, 32): the image
+ * encoder's blocks 2-5 (src/modules/basicConv.py:6-20: Conv2d(cin, cout, 3, padding=1) without its bias, which cancels in the
+ * BatchNorm behind it), its input gradient and its weight gradient (csrc/image_conv16.hip); replaces F.conv2d / MIOpen for those
+ * layers.  w [cout,cin,3,3] addressed by the four element strides ws[4] (host array).  sums (forward, may be NULL): f64
+ * [I2P_BN_REPLICAS][2 cout] zeroed by the caller, receives sum y / sum y^2 per channel for i2p_img_block_pool.  H*W*128 < 2^31.
+ * wgrad: dW (cout*cin*9 floats) is written in w's layout; partials: f32 [i2p_img_conv_wgrad_rows(B,H,W)][(cout/16)*2304] scratch
+ * (block sums, added in fp64 in a fixed order: reproducible run to run, unlike the atomically accumulated split-K kernels it replaces). */
+int i2p_img_conv_fwd(int B, int H, int W, int cin, int cout, const float *x, const float *w, const int *ws, float *y, double *sums, void *stream);
+int i2p_img_conv_bwd_data(int B, int H, int W, int cin, int cout, const float *dy, const float *w, const int *ws, float *dx, void *stream);
+int i2p_img_conv_wgrad_rows(int B, int H, int W);
+int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, const float *x, const float *dy, const int *ws, float *partials, float *dW,
+                       void *stream);
 /* Device library only — the FIRST block of the image encoder (src/modules/basicConv.py:6-20 with in_channel = 3: Conv2d(3, 16, 3,
  * padding 1) + BatchNorm2d + LeakyReLU + MaxPool2d(3, stride, 1)) without the conv output in memory (csrc/image_first.hip): the
  * convolution is recomputed from the input where it is needed, the batch statistics and the dense parts of the weight gradient come from

@@ -9,11 +9,12 @@ DEV = "cuda"
 
 
 @pytest.mark.parametrize("layout", ["contiguous", "channels_last"])
+@pytest.mark.parametrize("cout", [16, 32])
 @pytest.mark.parametrize("B,H,W", [(2, 37, 83), (1, 5, 14), (3, 1, 1), (1, 64, 29), (2, 3, 200)])
-def test_conv16_forward_sums_and_input_gradient(hip_backend, layout, B, H, W):
-    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+def test_conv16_forward_sums_and_input_gradient(hip_backend, layout, cout, B, H, W):
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W + cout)
     x = torch.randn(B, H, W, 16, generator=g)
-    w = torch.randn(16, 16, 3, 3, generator=g) * 0.2
+    w = torch.randn(cout, 16, 3, 3, generator=g) * 0.2
     wd = w.to(DEV)
     if layout == "channels_last":
         wd = wd.contiguous(memory_format=torch.channels_last)
@@ -23,16 +24,16 @@ def test_conv16_forward_sums_and_input_gradient(hip_backend, layout, B, H, W):
     assert (y.cpu().double() - ref).abs().max().item() <= 2e-6 * sc
     y2 = hip_backend.img_conv16(x.to(DEV), wd)
     assert torch.equal(y, y2)
-    s = sums.view(-1, 32).sum(0).cpu()
+    s = sums.view(-1, 2 * cout).sum(0).cpu()
     n = B * H * W
-    assert torch.allclose(s[:16], ref.sum((0, 1, 2)), rtol=1e-5, atol=2e-6 * sc * n)
-    assert torch.allclose(s[16:], (ref * ref).sum((0, 1, 2)), rtol=2e-6, atol=1e-9)
-    dy = torch.randn(B, H, W, 16, generator=g)
+    assert torch.allclose(s[:cout], ref.sum((0, 1, 2)), rtol=1e-5, atol=2e-6 * sc * n)
+    assert torch.allclose(s[cout:], (ref * ref).sum((0, 1, 2)), rtol=2e-6, atol=1e-9)
+    dy = torch.randn(B, H, W, cout, generator=g)
     dref = F.conv_transpose2d(dy.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
     dx = hip_backend.img_conv16(dy.to(DEV), wd, input_grad=True)
     assert (dx.cpu().double() - dref).abs().max().item() <= 2e-6 * dref.abs().max().item()
     xr = x.permute(0, 3, 1, 2).double()
-    wref = torch.nn.grad.conv2d_weight(xr, (16, 16, 3, 3), dy.permute(0, 3, 1, 2).double(), 1, 1)
+    wref = torch.nn.grad.conv2d_weight(xr, (cout, 16, 3, 3), dy.permute(0, 3, 1, 2).double(), 1, 1)
     dW = hip_backend.img_conv16_wgrad(x.to(DEV), dy.to(DEV), wd)
     assert dW.stride() == wd.stride()
     assert (dW.cpu().double() - wref).abs().max().item() <= 5e-6 * wref.abs().max().item()
@@ -44,6 +45,8 @@ def test_conv16_rejects_other_shapes(hip_backend):
         hip_backend.img_conv16(torch.zeros(1, 4, 4, 32, device=DEV), torch.zeros(16, 16, 3, 3, device=DEV))
     with pytest.raises(RuntimeError):
         hip_backend.img_conv16(torch.zeros(1, 4, 4, 16, device=DEV), torch.zeros(16, 16, 1, 1, device=DEV))
+    with pytest.raises(RuntimeError):
+        hip_backend.img_conv16(torch.zeros(1, 4, 4, 16, device=DEV), torch.zeros(64, 16, 3, 3, device=DEV))
     assert hip_backend.img_conv16(torch.zeros(0, 4, 4, 16, device=DEV), torch.zeros(16, 16, 3, 3, device=DEV)).shape == (0, 4, 4, 16)
 
 

@@ -26,17 +26,18 @@ def timed(fn, n=30, warm=5):
 
 def main():
     B, H, W = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (8, 188, 621)))
+    cout = int(sys.argv[4]) if len(sys.argv) > 4 else 16
     torch.backends.cudnn.benchmark = True
     be = ops.hip_backend()
     torch.manual_seed(0)
     x = torch.randn(B, H, W, 16, device="cuda")
-    w = (torch.randn(16, 16, 3, 3, device="cuda") * 0.2).contiguous(memory_format=torch.channels_last)
-    dy = torch.randn_like(x)
+    w = (torch.randn(cout, 16, 3, 3, device="cuda") * 0.2).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(B, H, W, cout, device="cuda")
     xc, dyc = x.permute(0, 3, 1, 2), dy.permute(0, 3, 1, 2)
     mb = x.numel() * 4 / 1e6
-    print(f"size {B}x{H}x{W}x16 ({mb:.0f} MB per tensor)")
+    print(f"size {B}x{H}x{W}x16 -> {cout} channels ({mb:.0f} MB input)")
     t = timed(lambda: be.img_conv16(x, w, with_sums=True))
-    print(f"conv16 forward + BN sums : {t:7.1f} us  ({2 * mb / t:.2f} TB/s on x + y, {2 * 2304 * x.numel() / 16 / t / 1e6:.1f} TFLOP/s)")
+    print(f"conv16 forward + BN sums : {t:7.1f} us  ({(1 + cout / 16) * mb / t:.2f} TB/s on x + y, {2 * 144 * cout * x.numel() / 16 / t / 1e6:.1f} TFLOP/s)")
     t = timed(lambda: be.img_conv16(dy, w, input_grad=True))
     print(f"conv16 input gradient    : {t:7.1f} us")
     print(f"conv16 weight gradient   : {timed(lambda: be.img_conv16_wgrad(x, dy, w)):7.1f} us  (pass + 9-block reduction)")
