@@ -660,6 +660,13 @@ def main():
             counts[v] = counts.get(v, 0) + 1
         line["config"]["miopen"] = {"find_mode": "cudnn.benchmark=True (miopenFind*, exhaustive)", "env": miopen_env(),
                                     "solvers": counts, "problems": len(sol)}
+        # which 3x3 convolutions of the 15-block image encoder are NOT on MIOpen (the switches restore MIOpen)
+        hip_first, hip_conv = os.environ.get("I2P_NO_IMG_FIRST") != "1", os.environ.get("I2P_NO_CONV16") != "1"
+        line["config"]["image_encoder"] = {
+            "block 1 (3->16, conv + BN + LeakyReLU + pool)": "csrc/image_first.hip" if hip_first else "MIOpen + csrc/image_block.hip",
+            "blocks 2-5 convolutions (16->16 x3, 16->32; fp32 tier)": "csrc/image_conv16.hip" if hip_conv else "MIOpen",
+            "blocks 6-15 convolutions": "MIOpen", "BN + LeakyReLU + MaxPool tails": "csrc/image_block.hip",
+            "switches": {k: os.environ[k] for k in ("I2P_NO_IMG_FIRST", "I2P_NO_CONV16", "I2P_NO_CONV32", "I2P_CONV16_MIOPEN_WGRAD") if k in os.environ}}
         prev = ops.set_precision("bf16" if bf16 else "fp32")
         line["roofline"] = (kernel_rooflines_bf16 if bf16 else kernel_rooflines)(args.batch, device)
         ops.set_precision(prev)

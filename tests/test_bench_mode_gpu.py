@@ -39,7 +39,8 @@ def test_config1_batch8_fp32_bench_mode(hip_backend, tmp_path):
     print({k: r[k] for k in ("knn_bench_vs_default", "knn_cpu_rf3_vs_default", "rf3_vs_cpu_torch", "bench_mode_grad")})
     print("solvers:", sorted(set(r["solvers"].values())))
     assert r["cudnn_benchmark"] is True and r["chain_errors"] == 0
-    assert len(r["solvers"]) >= 20, "the find-db of the process must name the solvers of the 8 + 8 + 7 convolution problems"
+    # (blocks 1-5 of the encoder run on csrc/image_first.hip / image_conv16.hip: MIOpen keeps the 5 distinct shapes of blocks 6-15)
+    assert len(r["solvers"]) >= 12, "the find-db of the process must name the solvers of the 5 + 5 + 5 convolution problems left on MIOpen"
     # the existing contract, same process, before the switch
     assert all(v <= TOL for v in r["default_mode"].values()), r["default_mode"]
     # bench mode: upstream of the integer decision
