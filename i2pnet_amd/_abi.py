@@ -92,9 +92,9 @@ DEVICE_ONLY = {
     "i2p_img_block_fwd": ["i"] * 7 + ["p", "p", "p", "p", "f", "f", "f"] + ["p"] * 6,
     "i2p_img_block_bwd": ["i"] * 7 + ["p"] * 6 + ["f"] + ["p"] * 4,
     "i2p_img_block_pool": ["i"] * 7 + ["p", "p", "p", "p", "f", "f", "f"] + ["p"] * 6,
-    "i2p_img_conv_fwd": ["i"] * 5 + ["p", "p", "p", "p", "p"],
-    "i2p_img_conv_bwd_data": ["i"] * 5 + ["p", "p", "p", "p"],
-    "i2p_img_conv_wgrad": ["i"] * 5 + ["p", "p", "p", "p", "p"],
+    "i2p_img_conv_fwd": ["i"] * 6 + ["p", "p", "p", "p", "p"],
+    "i2p_img_conv_bwd_data": ["i"] * 6 + ["p", "p", "p", "p"],
+    "i2p_img_conv_wgrad": ["i"] * 6 + ["p", "p", "p", "p", "p"],
     "i2p_img_first_fwd": ["i"] * 4 + ["p"] + ["l"] * 4 + ["p", "p", "p", "p", "f", "f", "f"] + ["p"] * 5 + ["i", "p", "p", "p", "i"],
     "i2p_img_first_bwd": ["i"] * 4 + ["p"] + ["l"] * 4 + ["p", "p", "p", "p", "f", "p", "p", "i"] + ["p"] * 6,
     "i2p_pc_rows_fwd": ["i"] * 6 + ["p"] * 8,

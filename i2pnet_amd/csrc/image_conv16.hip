@@ -23,6 +23,17 @@ constexpr int REP = I2P_BN_REPLICAS;
 constexpr int C = 16;                       // input channels of the weight-gradient kernel
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {            // v_cvt_pk_bf16_f32 (RNE)
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
 // W[out][in][kh][kw] by element strides; `flip`: the input-gradient view W'[out = ci][in = co][kh][kw] = W[co][ci][2 - kh][2 - kw]
 struct WView16 {
@@ -159,6 +170,137 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
     }
 }
 
+// ---- bf16 storage (BASELINE configs[2] / [4]: ops.set_precision("bf16")) ------------------------------------------------------------
+// The same strip walk on bf16 tensors with v_mfma_f32_16x16x16_bf16: one MFMA takes the 16 input channels of a tap, and the 8 bytes a
+// lane loads per row (channels 4 kq .. 4 kq + 3 of column j) ARE its B operand [k = channel][pixel]; 9 MFMAs per 16 pixels and 16 output
+// channels instead of 36 — the kernel is bound by its loads and stores.  fp32 accumulation, y rounded to bf16 (RNE) on store, the
+// BatchNorm sums taken from the ROUNDED values (what the pooling kernel will normalise).  Weights: bf16 [out][in][kh][kw] by strides.
+struct WViewBf {
+    const unsigned short *p; int s_out, s_in, s_kh, s_kw, flip;
+    __device__ __forceinline__ short ld(int out, int in, int kh, int kw) const {
+        return (short)p[out * s_out + in * s_in + (flip ? 2 - kh : kh) * s_kh + (flip ? 2 - kw : kw) * s_kw];
+    }
+};
+__device__ __forceinline__ unsigned dpp_u32_shr(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); }
+__device__ __forceinline__ unsigned dpp_u32_shl(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true); }
+
+template <int CIN, int COUT, bool STATS>
+__global__ __launch_bounds__(THREADS) void conv3x3_bf16_kernel(const unsigned short *__restrict__ x, int B, int H, int W, int strips_w, WViewBf wgt,
+                                                               unsigned short *__restrict__ y, double *__restrict__ sums) {
+    constexpr int NPW = 14, NQ = CIN / 16, NT = COUT / 16;
+    struct Row { u32x2 q[NQ]; };
+    const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
+    const unsigned wave = i2p_xcd_swizzle(blockIdx.x, gridDim.x) * (THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned nwaves = gridDim.x * (THREADS / 64);
+    const long long total = (long long)B * strips_w * H;
+    long long pos = total * wave / nwaves;
+    const long long end = total * (wave + 1) / nwaves;
+    if (!STATS && pos >= end) return;
+    // A operand of (tile nt, tap t, group q): W[out = 16 nt + j][in = 16 q + 4 kq + e][tap], e = 0 .. 3
+    s16x4 wr[NT][9][NQ];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wr[nt][t][q][e] = wgt.ld(16 * nt + j, 16 * q + 4 * kq + e, t / 3, t % 3);
+    const long long img_px = (long long)H * W;
+    const int row2 = W * CIN * 2;
+    float s[NT][4], q2[NT][4];
+    double ds[NT][4], dq[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s[nt][c] = 0.f; q2[nt][c] = 0.f; ds[nt][c] = 0.0; dq[nt][c] = 0.0; }
+    while (pos < end) {
+        const long long bs = pos / H;
+        const int r0 = (int)(pos - bs * H), r1 = (int)min((long long)H, r0 + (end - pos));
+        const int b = (int)(bs / strips_w), strip = (int)(bs - (long long)b * strips_w);
+        pos += r1 - r0;
+        const int c0 = strip * NPW;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(x + (long long)b * img_px * CIN), 0,
+                                                                              (int)(img_px * CIN * 2), 0x00020000);
+        const int lcol = c0 - 1 + j;
+        const int lvoff = (lcol >= 0 && lcol < W) ? (lcol * CIN + kq * 4) * 2 : 0x7fffffff;         // outside the image: reads 0
+        auto load_x = [&](int xr) -> Row {
+            Row r;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (xr < 0 || xr >= H) { r.q[q] = u32x2{0u, 0u}; continue; }
+                r.q[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lvoff == 0x7fffffff ? lvoff : lvoff + 32 * q, xr * row2, 0);
+            }
+            return r;
+        };
+        const int oc = c0 + j - 1;
+        const bool owns = j >= 1 && j <= 14 && oc < W;
+        Row R0 = load_x(r0 - 1), R1 = load_x(r0), R2 = load_x(r0 + 1), Rn = load_x(r0 + 2), Rnn;
+        unsigned short *yb = y + (long long)b * img_px * COUT;
+        for (int r = r0; r < r1; ++r) {
+            Rnn = load_x(r + 3);
+            f32x4 acc[NT], acc2[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[nt] = acc[nt]; }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const Row &R = kh == 0 ? R0 : (kh == 1 ? R1 : R2);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const u32x2 mid = R.q[q], left = {dpp_u32_shr(mid[0]), dpp_u32_shr(mid[1])}, right = {dpp_u32_shl(mid[0]), dpp_u32_shl(mid[1])};
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wr[nt][kh * 3 + 0][q], __builtin_bit_cast(s16x4, left), acc[nt], 0, 0, 0);
+                        acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wr[nt][kh * 3 + 1][q], __builtin_bit_cast(s16x4, mid), acc2[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wr[nt][kh * 3 + 2][q], __builtin_bit_cast(s16x4, right), acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x2 o = {pack_bf2(acc[nt][0] + acc2[nt][0], acc[nt][1] + acc2[nt][1]), pack_bf2(acc[nt][2] + acc2[nt][2], acc[nt][3] + acc2[nt][3])};
+                if (owns) *reinterpret_cast<u32x2 *>(yb + ((long long)r * W + oc) * COUT + 16 * nt + 4 * kq) = o;
+                if constexpr (STATS) {
+                    const float v[4] = {bf_lo(o[0]), bf_hi(o[0]), bf_lo(o[1]), bf_hi(o[1])};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float t = owns ? v[c] : 0.f;
+                        s[nt][c] += t;
+                        q2[nt][c] = __fmaf_rn(t, t, q2[nt][c]);
+                    }
+                }
+            }
+            if constexpr (STATS) {
+                if (((r - r0) & 3) == 3 || r + 1 == r1) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { ds[nt][c] += (double)s[nt][c]; dq[nt][c] += (double)q2[nt][c]; s[nt][c] = 0.f; q2[nt][c] = 0.f; }
+                }
+            }
+            R0 = R1; R1 = R2; R2 = Rn; Rn = Rnn;
+        }
+    }
+    if constexpr (STATS) {
+        __shared__ double red[THREADS / 64][2 * COUT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { ds[nt][c] += __shfl_xor(ds[nt][c], m); dq[nt][c] += __shfl_xor(dq[nt][c], m); }
+                if (j == 0) { red[threadIdx.x >> 6][16 * nt + 4 * kq + c] = ds[nt][c]; red[threadIdx.x >> 6][COUT + 16 * nt + 4 * kq + c] = dq[nt][c]; }
+            }
+        __syncthreads();
+        if (threadIdx.x < 2 * COUT) {
+            double t = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < THREADS / 64; ++w2) t += red[w2][threadIdx.x];
+            atomicAdd(sums + (size_t)(blockIdx.x % REP) * 2 * COUT + threadIdx.x, t);
+        }
+    }
+}
+
 // ---- weight gradient ---------------------------------------------------------------------------------------------------------------
 // dW[co][ci][kh][kw] = sum over pixels dy[px][co] x[px + (kh - 1, kw - 1)][ci]: the pixels are the MFMA contraction index, one 16 x 16
 // accumulator tile per tap and 16 output channels.  In NHWC storage both operands are lane-linear in memory (A [co = i][k = kq] and
@@ -169,10 +311,10 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
 // in fp64 by conv3x3_wgrad_fin_kernel (fixed order).  x has 16 channels.
 constexpr int WG_COLS = 64;
 
-template <int CO>
-__global__ __launch_bounds__(THREADS, 2) void conv3x3_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, int B, int H, int W,
+template <int CO, bool BF>
+__global__ __launch_bounds__(THREADS, 2) void conv3x3_wgrad_kernel(const void *__restrict__ x, const void *__restrict__ dy, int B, int H, int W,
                                                                    int strips_w, float *__restrict__ partials) {
-    constexpr int NT = CO / 16;
+    constexpr int NT = CO / 16, ES = BF ? 2 : 4;                       // bf16 storage: 2-byte loads widened to fp32 (the MFMAs stay fp32)
     __shared__ float red[THREADS / 64][9 * 256];
     const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -182,7 +324,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_wgrad_kernel(const float *
     long long pos = total * wave / nwaves;
     const long long end = total * (wave + 1) / nwaves;
     const long long img_px = (long long)H * W;
-    const int row4x = W * C * 4, row4g = W * CO * 4;
+    const int row4x = W * C * ES, row4g = W * CO * ES;
     f32x4 acc[NT][9];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -193,13 +335,17 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_wgrad_kernel(const float *
         const int r0 = (int)(pos - bs * H), r1 = (int)min((long long)H, r0 + (end - pos));
         const int b = (int)(bs / strips_w), strip = (int)(bs - (long long)b * strips_w);
         pos += r1 - r0;
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (long long)b * img_px * C), 0, (int)(img_px * C * 4), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy + (long long)b * img_px * CO), 0, (int)(img_px * CO * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>((const char *)x + (long long)b * img_px * C * ES), 0, (int)(img_px * C * ES), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>((const char *)dy + (long long)b * img_px * CO * ES), 0, (int)(img_px * CO * ES), 0x00020000);
+        auto ld = [&](__amdgpu_buffer_rsrc_t rs, int vo, int so) -> float {
+            if constexpr (BF) return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0) << 16);
+            else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
+        };
         // slot t = 0 .. 17 of this lane: column strip * 64 + 16 kq + t - 1, channel j; outside the image: an offset that reads 0
         int voff[18];
         const int colb = strip * WG_COLS + 16 * kq - 1;
 #pragma unroll
-        for (int t = 0; t < 18; ++t) voff[t] = (colb + t >= 0 && colb + t < W) ? ((colb + t) * C + j) * 4 : 0x7fffffff;
+        for (int t = 0; t < 18; ++t) voff[t] = (colb + t >= 0 && colb + t < W) ? ((colb + t) * C + j) * ES : 0x7fffffff;
         auto xrow = [&](int xr, float (&v)[18]) {
             if (xr < 0 || xr >= H) {
 #pragma unroll
@@ -207,14 +353,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_wgrad_kernel(const float *
                 return;
             }
 #pragma unroll
-            for (int t = 0; t < 18; ++t) v[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, voff[t], xr * row4x, 0));
+            for (int t = 0; t < 18; ++t) v[t] = ld(rx, voff[t], xr * row4x);
         };
         auto grow = [&](int gr, int nt, float (&v)[16]) {               // gr inside the image; channels 16 nt + j of the gradient row
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 // the gradient's pixel stride is CO floats: (x offset - 4 j) CO / 16 + 4 j
-                const int vo = voff[t + 1] == 0x7fffffff ? 0x7fffffff : (voff[t + 1] - 4 * j) * NT + 4 * j + 64 * nt;
-                v[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, vo, gr * row4g, 0));
+                const int vo = voff[t + 1] == 0x7fffffff ? 0x7fffffff : (voff[t + 1] - ES * j) * NT + ES * j + 16 * ES * nt;
+                v[t] = ld(rg, vo, gr * row4g);
             }
         };
         auto tile = [&](int nt, const float (&g)[16], const float (&A0)[18], const float (&A1)[18], const float (&A2)[18]) {
@@ -262,7 +408,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_wgrad_kernel(const float *
 
 // dW[co][ci][kh][kw] (weight strides) = sum over the blocks' partial sums, fp64, fixed order.  Block (tile, tap, quarter): 64 outputs x 16
 // row groups (every thread a short run of independent loads), the groups added through LDS.
-__global__ __launch_bounds__(1024) void conv3x3_wgrad_fin_kernel(int nblk, int NT, const float *__restrict__ partials, WView16 wgt, float *__restrict__ dW) {
+template <bool BF>
+__global__ __launch_bounds__(1024) void conv3x3_wgrad_fin_kernel(int nblk, int NT, const float *__restrict__ partials, WView16 wgt, void *__restrict__ dW) {
     __shared__ double part[16][64];
     const int tt = blockIdx.x >> 2, nt = tt / 9, t = tt - nt * 9, e = (blockIdx.x & 3) * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     double a = 0.0;
@@ -275,7 +422,9 @@ __global__ __launch_bounds__(1024) void conv3x3_wgrad_fin_kernel(int nblk, int N
 #pragma unroll
         for (int g2 = 0; g2 < 16; ++g2) v += part[g2][threadIdx.x];
         const int co = 16 * nt + (e >> 4), ci = e & 15;
-        dW[co * wgt.s_out + ci * wgt.s_in + (t / 3) * wgt.s_kh + (t % 3) * wgt.s_kw] = (float)v;
+        const int at = co * wgt.s_out + ci * wgt.s_in + (t / 3) * wgt.s_kh + (t % 3) * wgt.s_kw;
+        if constexpr (BF) reinterpret_cast<unsigned short *>(dW)[at] = (unsigned short)(pack_bf2((float)v, 0.f) & 0xffffu);
+        else reinterpret_cast<float *>(dW)[at] = (float)v;
     }
 }
 
@@ -294,20 +443,30 @@ int wgrad_blocks(int B, int H, int W) {
 }
 
 // forward (flip = 0): x [B,H,W,cin] -> y [B,H,W,cout]; input gradient (flip = 1): x = dL/dy [B,H,W,cout] -> y = dL/dx [B,H,W,cin]
-int launch(const float *x, int B, int H, int W, int cin, int cout, const float *w, const int *ws, int flip, float *y, double *sums, hipStream_t st) {
+int launch(const void *x, int B, int H, int W, int cin, int cout, const void *w, const int *ws, int flip, void *y, double *sums, int bf16, hipStream_t st) {
     if (!size_ok(B, H, W) || !pair_ok(cin, cout)) return I2P_ERR_BAD_ARG;
     if (B == 0) return 0;
     if (!x || !w || !ws || !y) return I2P_ERR_BAD_ARG;
-    // forward: W[co][ci][kh][kw] read as [out = co][in = ci]; input gradient: [out = ci][in = co], taps mirrored
-    const WView16 wv{w, flip ? ws[1] : ws[0], flip ? ws[0] : ws[1], ws[2], ws[3], flip};
     const int strips = (W + 13) / 14;
     // 4 waves per SIMD of the whole chip, all resident (<= 128 VGPRs); small tensors: one wave per 4 output rows of a strip
     const long long total = (long long)B * strips * H;
-    const int wps = cout == 16 ? 4 : 2;                               // the 32-channel variants hold 72 weight registers: 2 - 3 waves per SIMD fit
+    const int wps = cout == 16 ? 4 : (bf16 ? 3 : 2);                  // the 32-channel variants hold more weight registers: 2 - 3 waves per SIMD fit
     long long blocks = (long long)num_cus() * wps;
     if (blocks * (THREADS / 64) * 4 > total) blocks = (total + 4 * (THREADS / 64) - 1) / (4 * (THREADS / 64));
     const dim3 grid(round8(blocks));
-#define I2P_CONV(CI_, CO_, ST_) hipLaunchKernelGGL((conv3x3_kernel<CI_, CO_, ST_>), grid, dim3(THREADS), 0, st, x, B, H, W, strips, wv, y, sums)
+    // forward: W[co][ci][kh][kw] read as [out = co][in = ci]; input gradient: [out = ci][in = co], taps mirrored
+    if (bf16) {
+        const WViewBf wv{(const unsigned short *)w, flip ? ws[1] : ws[0], flip ? ws[0] : ws[1], ws[2], ws[3], flip};
+#define I2P_CONVB(CI_, CO_, ST_) hipLaunchKernelGGL((conv3x3_bf16_kernel<CI_, CO_, ST_>), grid, dim3(THREADS), 0, st, (const unsigned short *)x, B, H, W, strips, wv, (unsigned short *)y, sums)
+        if (!flip && cout == 16) { if (sums) I2P_CONVB(16, 16, true); else I2P_CONVB(16, 16, false); }
+        else if (!flip) { if (sums) I2P_CONVB(16, 32, true); else I2P_CONVB(16, 32, false); }
+        else if (cout == 16) I2P_CONVB(16, 16, false);
+        else I2P_CONVB(32, 16, false);
+#undef I2P_CONVB
+        I2P_RETURN_LAUNCH_STATUS();
+    }
+    const WView16 wv{(const float *)w, flip ? ws[1] : ws[0], flip ? ws[0] : ws[1], ws[2], ws[3], flip};
+#define I2P_CONV(CI_, CO_, ST_) hipLaunchKernelGGL((conv3x3_kernel<CI_, CO_, ST_>), grid, dim3(THREADS), 0, st, (const float *)x, B, H, W, strips, wv, (float *)y, sums)
     if (!flip && cout == 16) { if (sums) I2P_CONV(16, 16, true); else I2P_CONV(16, 16, false); }
     else if (!flip) { if (sums) I2P_CONV(16, 32, true); else I2P_CONV(16, 32, false); }
     else if (cout == 16) I2P_CONV(16, 16, false);
@@ -319,37 +478,40 @@ int launch(const float *x, int B, int H, int W, int cin, int cout, const float *
 }  // namespace
 
 // y [B,H,W,cout] = conv3x3(x [B,H,W,cin], w [cout,cin,3,3] by element strides ws[4]), padding 1, no bias; (cin, cout) = (16, 16) or
-// (16, 32).  sums (may be NULL): f64 [I2P_BN_REPLICAS][2 cout] zeroed by the caller, receives sum y / sum y^2 per output channel (the
-// layout i2p_img_block_pool reads)
-extern "C" int i2p_img_conv_fwd(int B, int H, int W, int cin, int cout, const float *x, const float *w, const int *ws, float *y, double *sums,
+// (16, 32).  bf16 = 1: x, w, y are bf16 bits (fp32 accumulation, sums from the rounded y).  sums (may be NULL): f64
+// [I2P_BN_REPLICAS][2 cout] zeroed by the caller, receives sum y / sum y^2 per output channel (the layout i2p_img_block_pool reads)
+extern "C" int i2p_img_conv_fwd(int B, int H, int W, int cin, int cout, int bf16, const void *x, const void *w, const int *ws, void *y, double *sums,
                                 void *stream) {
-    return launch(x, B, H, W, cin, cout, w, ws, 0, y, sums, (hipStream_t)stream);
+    return launch(x, B, H, W, cin, cout, w, ws, 0, y, sums, bf16, (hipStream_t)stream);
 }
 
 // dx [B,H,W,cin] = the input gradient of the same convolution from dy [B,H,W,cout]
-extern "C" int i2p_img_conv_bwd_data(int B, int H, int W, int cin, int cout, const float *dy, const float *w, const int *ws, float *dx, void *stream) {
-    return launch(dy, B, H, W, cin, cout, w, ws, 1, dx, nullptr, (hipStream_t)stream);
+extern "C" int i2p_img_conv_bwd_data(int B, int H, int W, int cin, int cout, int bf16, const void *dy, const void *w, const int *ws, void *dx,
+                                     void *stream) {
+    return launch(dy, B, H, W, cin, cout, w, ws, 1, dx, nullptr, bf16, (hipStream_t)stream);
 }
 
 // rows of (cout / 16) * 9 * 256 floats the weight-gradient entry needs in `partials`
 extern "C" int i2p_img_conv_wgrad_rows(int B, int H, int W) { return (B <= 0 || H <= 0 || W <= 0) ? 0 : wgrad_blocks(B, H, W); }
 
-// dW (cout * cin * 9 floats, written in w's layout: element strides ws[4] of [co][ci][kh][kw]) = the weight gradient of the convolution
-// from x [B,H,W,cin] and dy [B,H,W,cout]; partials: f32 [i2p_img_conv_wgrad_rows()][(cout / 16) * 2304] scratch
-extern "C" int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, const float *x, const float *dy, const int *ws, float *partials, float *dW,
-                                  void *stream) {
+// dW (cout * cin * 9 values, written in w's layout: element strides ws[4] of [co][ci][kh][kw]; bf16 = 1: x, dy and dW are bf16 bits,
+// the products and sums fp32 / fp64) = the weight gradient of the convolution from x [B,H,W,cin] and dy [B,H,W,cout];
+// partials: f32 [i2p_img_conv_wgrad_rows()][(cout / 16) * 2304] scratch
+extern "C" int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, int bf16, const void *x, const void *dy, const int *ws, float *partials,
+                                  void *dW, void *stream) {
     if (!size_ok(B, H, W) || !pair_ok(cin, cout) || !ws || !dW) return I2P_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const WView16 wv{nullptr, ws[0], ws[1], ws[2], ws[3], 0};
     const int nt = cout / 16;
-    if (B == 0) {
-        hipLaunchKernelGGL(conv3x3_wgrad_fin_kernel, dim3(36 * nt), dim3(1024), 0, st, 0, nt, (const float *)partials, wv, dW);
-        I2P_RETURN_LAUNCH_STATUS();
+    const int blocks = B == 0 ? 0 : wgrad_blocks(B, H, W), strips = (W + WG_COLS - 1) / WG_COLS;
+    if (B > 0) {
+        if (!x || !dy || !partials) return I2P_ERR_BAD_ARG;
+#define I2P_WG(CO_, BF_) hipLaunchKernelGGL((conv3x3_wgrad_kernel<CO_, BF_>), dim3(blocks), dim3(THREADS), 0, st, x, dy, B, H, W, strips, partials)
+        if (cout == 16) { if (bf16) I2P_WG(16, true); else I2P_WG(16, false); }
+        else { if (bf16) I2P_WG(32, true); else I2P_WG(32, false); }
+#undef I2P_WG
     }
-    if (!x || !dy || !partials) return I2P_ERR_BAD_ARG;
-    const int blocks = wgrad_blocks(B, H, W), strips = (W + WG_COLS - 1) / WG_COLS;
-    if (cout == 16) hipLaunchKernelGGL(conv3x3_wgrad_kernel<16>, dim3(blocks), dim3(THREADS), 0, st, x, dy, B, H, W, strips, partials);
-    else hipLaunchKernelGGL(conv3x3_wgrad_kernel<32>, dim3(blocks), dim3(THREADS), 0, st, x, dy, B, H, W, strips, partials);
-    hipLaunchKernelGGL(conv3x3_wgrad_fin_kernel, dim3(36 * nt), dim3(1024), 0, st, blocks, nt, (const float *)partials, wv, dW);
+    if (bf16) hipLaunchKernelGGL(conv3x3_wgrad_fin_kernel<true>, dim3(36 * nt), dim3(1024), 0, st, blocks, nt, (const float *)partials, wv, dW);
+    else hipLaunchKernelGGL(conv3x3_wgrad_fin_kernel<false>, dim3(36 * nt), dim3(1024), 0, st, blocks, nt, (const float *)partials, wv, dW);
     I2P_RETURN_LAUNCH_STATUS();
 }

@@ -346,9 +346,13 @@ class _Conv16Block(torch.autograd.Function):
 
 
 def _conv16_ok(x, conv, blk_bf):
-    """a 16 -> 16 or 16 -> 32 channel fp32 block on csrc/image_conv16.hip (I2P_NO_CONV16=1: MIOpen's convolutions instead;
-    I2P_NO_CONV32=1: only for the 16 -> 32 block)"""
-    return (ops.get_backend().name == "hip" and x.is_cuda and x.dtype == torch.float32 and not blk_bf
+    """a 16 -> 16 or 16 -> 32 channel block on csrc/image_conv16.hip (I2P_NO_CONV16=1: MIOpen's convolutions instead; I2P_NO_CONV32=1:
+    only for the 16 -> 32 block).  fp32 storage by default; the bf16-storage kernels (v_mfma_f32_16x16x16_bf16) are opt-in with
+    I2P_CONV16_BF16=1: configs[2] 1151 -> 1185 samples/s, but their correctly rounded outputs (99.996 % of the elements = RNE of the
+    exact sum; MIOpen's bf16 igemm: 50 %) land this random-init encoder's pose at 9.9e-2 of the fp32 reference instead of 7.0e-2 —
+    outside the 8e-2 contract of tests/test_model_sized.py, which is why MIOpen keeps those layers in the bf16 storage mode."""
+    return (ops.get_backend().name == "hip" and x.is_cuda and x.dtype == (torch.bfloat16 if blk_bf else torch.float32)
+            and not (blk_bf and os.environ.get("I2P_CONV16_BF16") != "1")
             and conv.in_channels == 16 and conv.out_channels in (16, 32) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
             and x.shape[2] * x.shape[3] * 128 < 2 ** 31 and os.environ.get("I2P_NO_CONV16") != "1"
@@ -460,13 +464,13 @@ class _ImageCNN(nn.Sequential):
                     continue
                 if j == 0:
                     x = x.contiguous(memory_format=torch.channels_last)
-                if _conv16_ok(x, conv, blk_bf[j]):
-                    x = _Conv16Block.apply(x, conv.weight, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
-                                           bn.momentum, bn.eps, act.negative_slope, out_bf[j])
-                    continue
                 want = torch.bfloat16 if blk_bf[j] else torch.float32
                 if x.dtype != want:
                     x = x.to(want)
+                if _conv16_ok(x, conv, blk_bf[j]):
+                    x = _Conv16Block.apply(x, ws[j] if blk_bf[j] else conv.weight, bn.weight, bn.bias, conv.bias, bn.running_mean,
+                                           bn.running_var, pool.stride, bn.momentum, bn.eps, act.negative_slope, out_bf[j])
+                    continue
                 y = F.conv2d(x, ws[j] if blk_bf[j] else conv.weight, None, conv.stride, conv.padding)
                 x = _BnActPool.apply(y, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
                                      bn.momentum, bn.eps, act.negative_slope, out_bf[j])

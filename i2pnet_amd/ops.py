@@ -528,39 +528,45 @@ class CBackend:
         return cin, cout
 
     def img_conv16(self, x, weight, with_sums=False, input_grad=False):
-        """3x3 convolution (padding 1, no bias) of x [B,H,W,cin] fp32 NHWC with weight [cout,cin,3,3] (any dense layout; (cin, cout) =
-        (16, 16) or (16, 32)) on csrc/image_conv16.hip -> y [B,H,W,cout]; with_sums: also the replicated fp64 {sum y, sum y^2} for
+        """3x3 convolution (padding 1, no bias) of x [B,H,W,cin] NHWC with weight [cout,cin,3,3] (any dense layout; (cin, cout) =
+        (16, 16) or (16, 32)) on csrc/image_conv16.hip -> y [B,H,W,cout]; fp32 tensors, or bf16 tensors with a bf16 weight (bf16
+        storage mode: bf16 MFMA, fp32 accumulation); with_sums: also the replicated fp64 {sum y, sum y^2} for
         `img_block_forward(sums=...)`; input_grad: x is dL/dy [B,H,W,cout] and the result dL/dx [B,H,W,cin] of that convolution."""
         cin, cout = self._conv_pair(weight)
         B, H, W, Cc = x.shape
         if Cc != (cout if input_grad else cin):
             raise RuntimeError(f"img_conv: x has {Cc} channels, weight {tuple(weight.shape)}")
-        if weight.device.type != self.device_type or weight.dtype != _F32:
-            raise RuntimeError("weight must be a torch.float32 tensor on the device")
+        dt = x.dtype
+        if dt not in (_F32, _BF16) or weight.device.type != self.device_type or weight.dtype != dt:
+            raise RuntimeError(f"img_conv: x and weight must both be torch.float32 or torch.bfloat16 on the device (got {dt}, {weight.dtype})")
+        bf = int(dt == _BF16)
         ws = (C.c_int * 4)(*[int(v) for v in weight.stride()])
-        y = torch.empty(B, H, W, cin if input_grad else cout, dtype=_F32, device=x.device)
+        y = torch.empty(B, H, W, cin if input_grad else cout, dtype=dt, device=x.device)
         if input_grad:
-            self._call("i2p_img_conv_bwd_data", int(B), int(H), int(W), cin, cout, self._p(x, _F32, "dy"), C.c_void_p(weight.data_ptr()), ws,
-                       self._p(y, _F32, "dx"), stream=self._stream())
+            self._call("i2p_img_conv_bwd_data", int(B), int(H), int(W), cin, cout, bf, self._p(x, dt, "dy"), C.c_void_p(weight.data_ptr()), ws,
+                       self._p(y, dt, "dx"), stream=self._stream())
             return y
         sums = zeros(BN_REPLICAS * 2 * cout, torch.float64, x.device) if with_sums else None
-        self._call("i2p_img_conv_fwd", int(B), int(H), int(W), cin, cout, self._p(x, _F32, "x"), C.c_void_p(weight.data_ptr()), ws,
-                   self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums") if with_sums else None, stream=self._stream())
+        self._call("i2p_img_conv_fwd", int(B), int(H), int(W), cin, cout, bf, self._p(x, dt, "x"), C.c_void_p(weight.data_ptr()), ws,
+                   self._p(y, dt, "y"), self._p(sums, torch.float64, "sums") if with_sums else None, stream=self._stream())
         return (y, sums) if with_sums else y
 
     def img_conv16_wgrad(self, x, dy, weight):
-        """dW of the same convolution from x [B,H,W,cin], dy [B,H,W,cout] fp32 NHWC, in `weight`'s layout (csrc/image_conv16.hip)"""
+        """dW of the same convolution from x [B,H,W,cin], dy [B,H,W,cout] (fp32, or bf16 with a bf16 weight), in `weight`'s layout and
+        dtype (csrc/image_conv16.hip)"""
         cin, cout = self._conv_pair(weight)
         B, H, W, Cc = x.shape
-        if Cc != cin or tuple(dy.shape) != (B, H, W, cout):
-            raise RuntimeError(f"img_conv16_wgrad: x {tuple(x.shape)}, dy {tuple(dy.shape)} do not match weight {tuple(weight.shape)}")
+        dt = x.dtype
+        if Cc != cin or tuple(dy.shape) != (B, H, W, cout) or dy.dtype != dt or weight.dtype != dt or dt not in (_F32, _BF16):
+            raise RuntimeError(f"img_conv16_wgrad: x {tuple(x.shape)} {dt}, dy {tuple(dy.shape)} {dy.dtype} do not match weight "
+                               f"{tuple(weight.shape)} {weight.dtype}")
         dW = torch.empty_like(weight)
         if dW.stride() != weight.stride():
             raise RuntimeError("weight must be dense (contiguous or channels_last)")
         ws = (C.c_int * 4)(*[int(v) for v in weight.stride()])
         rows = _lib.helper("i2p_img_conv_wgrad_rows", int(B), int(H), int(W))
         partials = torch.empty(max(rows, 1) * 2304 * (cout // 16), dtype=_F32, device=x.device)
-        self._call("i2p_img_conv_wgrad", int(B), int(H), int(W), cin, cout, self._p(x, _F32, "x"), self._p(dy, _F32, "dy"), ws,
+        self._call("i2p_img_conv_wgrad", int(B), int(H), int(W), cin, cout, int(dt == _BF16), self._p(x, dt, "x"), self._p(dy, dt, "dy"), ws,
                    self._p(partials, _F32, "partials"), C.c_void_p(dW.data_ptr()), stream=self._stream())
         return dW
 

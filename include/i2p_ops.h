@@ -321,11 +321,15 @@ int i2p_img_block_pool(int B, int H, int W, int C, int stride, int y_bf16, int o
  * layers.  w [cout,cin,3,3] addressed by the four element strides ws[4] (host array).  sums (forward, may be NULL): f64
  * [I2P_BN_REPLICAS][2 cout] zeroed by the caller, receives sum y / sum y^2 per channel for i2p_img_block_pool.  H*W*128 < 2^31.
  * wgrad: dW (cout*cin*9 floats) is written in w's layout; partials: f32 [i2p_img_conv_wgrad_rows(B,H,W)][(cout/16)*2304] scratch
- * (block sums, added in fp64 in a fixed order: reproducible run to run, unlike the atomically accumulated split-K kernels it replaces). */
-int i2p_img_conv_fwd(int B, int H, int W, int cin, int cout, const float *x, const float *w, const int *ws, float *y, double *sums, void *stream);
-int i2p_img_conv_bwd_data(int B, int H, int W, int cin, int cout, const float *dy, const float *w, const int *ws, float *dx, void *stream);
+ * (block sums, added in fp64 in a fixed order: reproducible run to run, unlike the atomically accumulated split-K kernels it replaces).
+ * bf16 = 1 (bf16 storage mode, BASELINE configs[2] / [4]): x, w, y / dy, dx / dW are bf16 bits; forward and input gradient run on
+ * v_mfma_f32_16x16x16_bf16 (fp32 accumulation, y rounded RNE, sums taken from the rounded y), the weight gradient widens its loads
+ * to fp32. */
+int i2p_img_conv_fwd(int B, int H, int W, int cin, int cout, int bf16, const void *x, const void *w, const int *ws, void *y, double *sums,
+                     void *stream);
+int i2p_img_conv_bwd_data(int B, int H, int W, int cin, int cout, int bf16, const void *dy, const void *w, const int *ws, void *dx, void *stream);
 int i2p_img_conv_wgrad_rows(int B, int H, int W);
-int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, const float *x, const float *dy, const int *ws, float *partials, float *dW,
+int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, int bf16, const void *x, const void *dy, const int *ws, float *partials, void *dW,
                        void *stream);
 /* Device library only — the FIRST block of the image encoder (src/modules/basicConv.py:6-20 with in_channel = 3: Conv2d(3, 16, 3,
  * padding 1) + BatchNorm2d + LeakyReLU + MaxPool2d(3, stride, 1)) without the conv output in memory (csrc/image_first.hip): the

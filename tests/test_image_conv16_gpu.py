@@ -40,6 +40,33 @@ def test_conv16_forward_sums_and_input_gradient(hip_backend, layout, cout, B, H,
     assert torch.equal(dW, hip_backend.img_conv16_wgrad(x.to(DEV), dy.to(DEV), wd))              # fixed summation order
 
 
+@pytest.mark.parametrize("cout", [16, 32])
+@pytest.mark.parametrize("B,H,W", [(2, 37, 83), (1, 5, 14), (2, 3, 200)])
+def test_conv16_bf16_storage(hip_backend, cout, B, H, W):
+    """bf16 tensors (bf16 MFMA, fp32 accumulation) against the fp64 convolution of the SAME bf16 values: results within one bf16
+    rounding (2^-8 relative to the tensor), the BatchNorm sums exactly those of the stored y"""
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(B + H + W + cout)
+    x = torch.randn(B, H, W, 16, generator=g).to(bf)
+    w = (torch.randn(cout, 16, 3, 3, generator=g) * 0.2).to(bf)
+    wd = w.to(DEV).contiguous(memory_format=torch.channels_last)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
+    y, sums = hip_backend.img_conv16(x.to(DEV), wd, with_sums=True)
+    assert y.dtype == bf
+    assert (y.cpu().double() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
+    s = sums.view(-1, 2 * cout).sum(0).cpu()
+    yd = y.cpu().double()
+    assert torch.allclose(s[:cout], yd.sum((0, 1, 2)), rtol=1e-5, atol=1e-4) and torch.allclose(s[cout:], (yd * yd).sum((0, 1, 2)), rtol=2e-6, atol=1e-9)
+    dy = torch.randn(B, H, W, cout, generator=g).to(bf)
+    dref = F.conv_transpose2d(dy.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
+    dx = hip_backend.img_conv16(dy.to(DEV), wd, input_grad=True)
+    assert dx.dtype == bf and (dx.cpu().double() - dref).abs().max().item() <= 2.0 ** -8 * dref.abs().max().item()
+    wref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (cout, 16, 3, 3), dy.permute(0, 3, 1, 2).double(), 1, 1)
+    dW = hip_backend.img_conv16_wgrad(x.to(DEV), dy.to(DEV), wd)
+    assert dW.dtype == bf and dW.stride() == wd.stride()
+    assert (dW.cpu().double() - wref).abs().max().item() <= 2.0 ** -8 * wref.abs().max().item()
+
+
 def test_conv16_rejects_other_shapes(hip_backend):
     with pytest.raises(RuntimeError):
         hip_backend.img_conv16(torch.zeros(1, 4, 4, 32, device=DEV), torch.zeros(16, 16, 3, 3, device=DEV))
