@@ -50,9 +50,17 @@ template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
 // Work = the B x strips x H output rows of all strips in (image, strip, row) order, cut into equal contiguous ranges, one per wave of
 // a grid that is resident at once (4 waves per SIMD): every SIMD runs the same number of MFMAs.  A range that crosses a strip
 // boundary is walked as two segments.
-template <int CIN, int COUT, bool STATS>
+// MODE 2 (input gradient only): what this kernel writes is dL/d(pooled output) of the block IN FRONT (16 channels, MaxPool stride 1).
+// Its BatchNorm-backward sums — sum gz and sum gz * xhat over the pooled elements, gz = g * act'(bn(y at the arg-max)) — are taken
+// here, from the registers that hold g: one arg-max word and four gathered y values per lane and row, in flight under the MFMAs.
+// `sums` then receives them in the [REP][2 C] layout i2p_img_block_bwd_dx reads, and that block's statistics pass disappears.
+struct PrevBlock { const unsigned char *arg; const float *y, *mean_invstd, *gamma, *beta; float slope; };
+
+template <int CIN, int COUT, int MODE>
 __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restrict__ x, int B, int H, int W, int strips_w, WView16 wgt,
-                                                          float *__restrict__ y, double *__restrict__ sums) {
+                                                          float *__restrict__ y, double *__restrict__ sums, PrevBlock pv) {
+    constexpr bool STATS = MODE != 0;
+    static_assert(MODE != 2 || COUT == 16, "the block in front has 16 channels");
     constexpr int NPW = 14;                                           // output columns per strip
     constexpr int NQ = CIN / 16, NT = COUT / 16, KS = 9 * 4 * NQ;     // 16-channel groups of the input / output, MFMA steps per tile
     struct Row { float q[NQ][4]; };
@@ -79,6 +87,14 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int c = 0; c < 4; ++c) { s[nt][c] = 0.f; q2[nt][c] = 0.f; ds[nt][c] = 0.0; dq[nt][c] = 0.0; }
+    float pmean[4], pinv[4], pscale[4], pbeta[4];
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ch = 4 * kq + c;
+            pmean[c] = pv.mean_invstd[ch]; pinv[c] = pv.mean_invstd[COUT + ch]; pscale[c] = pinv[c] * pv.gamma[ch]; pbeta[c] = pv.beta[ch];
+        }
+    }
     while (pos < end) {
         const long long bs = pos / H;
         const int r0 = (int)(pos - bs * H), r1 = (int)min((long long)H, r0 + (end - pos));
@@ -104,8 +120,25 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
         const bool owns = j >= 1 && j <= 14 && oc < W;
         Row R0 = load_x(r0 - 1), R1 = load_x(r0), R2 = load_x(r0 + 1), Rn = load_x(r0 + 2), Rnn;
         float *yb = y + (long long)b * img_px * COUT;
+        // MODE 2: the arg-max word of this lane's 4 channels at (r, oc), one row ahead; the pooled tensor has the output's geometry
+        const unsigned *argw = reinterpret_cast<const unsigned *>(pv.arg) + (long long)b * img_px * (COUT / 4);
+        const float *py = pv.y + (long long)b * img_px * COUT;
+        unsigned aw_next = 0u;
+        if constexpr (MODE == 2) aw_next = owns ? argw[((long long)r0 * W + oc) * (COUT / 4) + kq] : 0u;
         for (int r = r0; r < r1; ++r) {
             Rnn = load_x(r + 3);
+            float yv[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (MODE == 2) {
+                const unsigned aw = aw_next;
+                if (owns) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int av = (int)((aw >> (8 * c)) & 0xffu), ah = (av * 11) >> 5, ak = av - 3 * ah;      // window position kh * 3 + kw
+                        yv[c] = py[((long long)(r + ah - 1) * W + (oc + ak - 1)) * COUT + 4 * kq + c];
+                    }
+                    if (r + 1 < r1) aw_next = argw[((long long)(r + 1) * W + oc) * (COUT / 4) + kq];
+                }
+            }
             f32x4 acc[NT], acc2[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[nt] = acc[nt]; }
@@ -129,12 +162,22 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[nt][c] += acc2[nt][c];
                 if (owns) *reinterpret_cast<f32x4 *>(yb + ((long long)r * W + oc) * COUT + 16 * nt + 4 * kq) = acc[nt];
-                if constexpr (STATS) {
+                if constexpr (MODE == 1) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const float v = owns ? acc[nt][c] : 0.f;
                         s[nt][c] += v;
                         q2[nt][c] = __fmaf_rn(v, v, q2[nt][c]);
+                    }
+                }
+                if constexpr (MODE == 2) {                              // img_bwd_stats2_kernel's arithmetic on the registers
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float z = (yv[c] - pmean[c]) * pscale[c] + pbeta[c];
+                        const float g = owns ? acc[nt][c] : 0.f;
+                        const float gz = z > 0.f ? g : g * pv.slope;
+                        s[nt][c] += gz;
+                        q2[nt][c] = __fmaf_rn(gz, (yv[c] - pmean[c]) * pinv[c], q2[nt][c]);
                     }
                 }
             }
@@ -443,14 +486,16 @@ int wgrad_blocks(int B, int H, int W) {
 }
 
 // forward (flip = 0): x [B,H,W,cin] -> y [B,H,W,cout]; input gradient (flip = 1): x = dL/dy [B,H,W,cout] -> y = dL/dx [B,H,W,cin]
-int launch(const void *x, int B, int H, int W, int cin, int cout, const void *w, const int *ws, int flip, void *y, double *sums, int bf16, hipStream_t st) {
+int launch(const void *x, int B, int H, int W, int cin, int cout, const void *w, const int *ws, int flip, void *y, double *sums, int bf16, hipStream_t st,
+           const PrevBlock *prev = nullptr) {
     if (!size_ok(B, H, W) || !pair_ok(cin, cout)) return I2P_ERR_BAD_ARG;
     if (B == 0) return 0;
     if (!x || !w || !ws || !y) return I2P_ERR_BAD_ARG;
     const int strips = (W + 13) / 14;
     // 4 waves per SIMD of the whole chip, all resident (<= 128 VGPRs); small tensors: one wave per 4 output rows of a strip
     const long long total = (long long)B * strips * H;
-    const int wps = cout == 16 ? 4 : (bf16 ? 3 : 2);                  // the 32-channel variants hold more weight registers: 2 - 3 waves per SIMD fit
+    // the 32-channel variants hold more weight registers, the backward-statistics mode more state: 2 - 3 waves per SIMD fit
+    const int wps = cout == 16 ? (prev ? 3 : 4) : (bf16 ? 3 : 2);
     long long blocks = (long long)num_cus() * wps;
     if (blocks * (THREADS / 64) * 4 > total) blocks = (total + 4 * (THREADS / 64) - 1) / (4 * (THREADS / 64));
     const dim3 grid(round8(blocks));
@@ -466,11 +511,12 @@ int launch(const void *x, int B, int H, int W, int cin, int cout, const void *w,
         I2P_RETURN_LAUNCH_STATUS();
     }
     const WView16 wv{(const float *)w, flip ? ws[1] : ws[0], flip ? ws[0] : ws[1], ws[2], ws[3], flip};
-#define I2P_CONV(CI_, CO_, ST_) hipLaunchKernelGGL((conv3x3_kernel<CI_, CO_, ST_>), grid, dim3(THREADS), 0, st, (const float *)x, B, H, W, strips, wv, (float *)y, sums)
-    if (!flip && cout == 16) { if (sums) I2P_CONV(16, 16, true); else I2P_CONV(16, 16, false); }
-    else if (!flip) { if (sums) I2P_CONV(16, 32, true); else I2P_CONV(16, 32, false); }
-    else if (cout == 16) I2P_CONV(16, 16, false);
-    else I2P_CONV(32, 16, false);
+    const PrevBlock pv = prev ? *prev : PrevBlock{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f};
+#define I2P_CONV(CI_, CO_, MD_) hipLaunchKernelGGL((conv3x3_kernel<CI_, CO_, MD_>), grid, dim3(THREADS), 0, st, (const float *)x, B, H, W, strips, wv, (float *)y, sums, pv)
+    if (!flip && cout == 16) { if (sums) I2P_CONV(16, 16, 1); else I2P_CONV(16, 16, 0); }
+    else if (!flip) { if (sums) I2P_CONV(16, 32, 1); else I2P_CONV(16, 32, 0); }
+    else if (cout == 16) { if (prev) I2P_CONV(16, 16, 2); else I2P_CONV(16, 16, 0); }
+    else { if (prev) I2P_CONV(32, 16, 2); else I2P_CONV(32, 16, 0); }
 #undef I2P_CONV
     I2P_RETURN_LAUNCH_STATUS();
 }
@@ -489,6 +535,18 @@ extern "C" int i2p_img_conv_fwd(int B, int H, int W, int cin, int cout, int bf16
 extern "C" int i2p_img_conv_bwd_data(int B, int H, int W, int cin, int cout, int bf16, const void *dy, const void *w, const int *ws, void *dx,
                                      void *stream) {
     return launch(dy, B, H, W, cin, cout, w, ws, 1, dx, nullptr, bf16, (hipStream_t)stream);
+}
+
+// i2p_img_conv_bwd_data in fp32 that ALSO takes the BatchNorm-backward sums of the block in front of the convolution — a 16-channel
+// block with a stride-1 MaxPool whose pooled output is this convolution's input: prev_arg / prev_y / prev_mean_invstd / prev_gamma /
+// prev_beta / prev_slope are what i2p_img_block_bwd takes for that block, prev_dsums (f64 [I2P_BN_REPLICAS][32], zeroed by the caller)
+// receives sum gz / sum gz xhat; follow with i2p_img_block_bwd_dx.
+extern "C" int i2p_img_conv_bwd_data_stats(int B, int H, int W, int cin, int cout, const float *dy, const float *w, const int *ws, float *dx,
+                                           const unsigned char *prev_arg, const float *prev_y, const float *prev_mean_invstd,
+                                           const float *prev_gamma, const float *prev_beta, float prev_slope, double *prev_dsums, void *stream) {
+    if (cin != 16 || !prev_arg || !prev_y || !prev_mean_invstd || !prev_gamma || !prev_beta || !prev_dsums) return I2P_ERR_BAD_ARG;
+    const PrevBlock pv{prev_arg, prev_y, prev_mean_invstd, prev_gamma, prev_beta, prev_slope};
+    return launch(dy, B, H, W, cin, cout, w, ws, 1, dx, prev_dsums, 0, (hipStream_t)stream, &pv);
 }
 
 // rows of (cout / 16) * 9 * 256 floats the weight-gradient entry needs in `partials`

@@ -316,7 +316,11 @@ class _Conv16Block(torch.autograd.Function):
     input-gradient kernel and the weight-gradient kernel (+ its 9-block reduction)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, conv_bias, running_mean, running_var, stride, momentum, eps, slope, out_bf16=False):
+    def forward(ctx, x, weight, gamma, beta, conv_bias, running_mean, running_var, stride, momentum, eps, slope, out_bf16=False, link_in=None,
+                link_out=None):
+        """link_in / link_out: `_BwdLink`s shared with the block in front / behind (both fp32 conv16 blocks, consecutive in the
+        Sequential): this block's input-gradient kernel takes the BatchNorm-backward sums of the block in front (link_in), and finds
+        its own already taken by the block behind (link_out)"""
         x_nhwc = x.permute(0, 2, 3, 1)
         if not x_nhwc.is_contiguous():
             x_nhwc = x_nhwc.contiguous()
@@ -325,7 +329,9 @@ class _Conv16Block(torch.autograd.Function):
         out, arg, mi = be.img_block_forward(y, gamma.detach(), beta.detach(), eps, slope, stride, momentum, conv_bias.detach(),
                                             running_mean, running_var, out_bf16=out_bf16, sums=sums)
         ctx.save_for_backward(x_nhwc, y, arg, mi, weight, gamma, beta)
-        ctx.stride, ctx.slope = stride, slope
+        ctx.stride, ctx.slope, ctx.link_in, ctx.link_out = stride, slope, link_in, link_out
+        if link_out is not None:
+            link_out.prev, link_out.dsums = (arg, y, mi, gamma.detach(), beta.detach(), slope), None
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -335,14 +341,32 @@ class _Conv16Block(torch.autograd.Function):
         if not g_nhwc.is_contiguous():
             g_nhwc = g_nhwc.contiguous()
         be = ops.get_backend()
-        dy, dgamma, dbeta = be.img_block_backward(g_nhwc, arg, y, mi, gamma.detach(), beta.detach(), ctx.slope, ctx.stride)
-        dx = be.img_conv16(dy, weight.detach(), input_grad=True).permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None
+        own = ctx.link_out.dsums if ctx.link_out is not None else None          # taken by the block behind, from the registers that held g
+        if ctx.link_out is not None:
+            ctx.link_out.prev = ctx.link_out.dsums = None
+        dy, dgamma, dbeta = be.img_block_backward(g_nhwc, arg, y, mi, gamma.detach(), beta.detach(), ctx.slope, ctx.stride, dsums=own)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.link_in is not None and ctx.link_in.prev is not None:
+                dx, ctx.link_in.dsums = be.img_conv16(dy, weight.detach(), input_grad=True, prev=ctx.link_in.prev)
+            else:
+                dx = be.img_conv16(dy, weight.detach(), input_grad=True)
+            dx = dx.permute(0, 3, 1, 2)
         if os.environ.get("I2P_CONV16_MIOPEN_WGRAD") == "1":          # (A/B: MIOpen's split-K weight gradient)
             dW = torch.ops.aten.convolution_backward(dy.permute(0, 3, 1, 2), x_nhwc.permute(0, 3, 1, 2), weight, None, (1, 1), (1, 1), (1, 1),
                                                      False, (0, 0), 1, (False, True, False))[1]
         else:
             dW = be.img_conv16_wgrad(x_nhwc, dy, weight.detach())
-        return dx, dW, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dW, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+
+
+class _BwdLink:
+    """hand-off between two consecutive fp32 conv16 blocks of an encoder stack (see _Conv16Block.forward): the front block's saved
+    tensors for the back block's input-gradient kernel, and the BatchNorm-backward sums that kernel takes for the front block"""
+    __slots__ = ("prev", "dsums")
+
+    def __init__(self):
+        self.prev = self.dsums = None
 
 
 def _conv16_ok(x, conv, blk_bf):
@@ -455,6 +479,7 @@ class _ImageCNN(nn.Sequential):
             blk_bf, out_bf = self._storage_plan(x, nb)
             if any(blk_bf):
                 ws = _CastBf16.apply(*[mods[i].weight for i in range(0, len(mods), 4)])
+            link = None                                         # _BwdLink of the previous block when it can hand over its statistics
             for j, i in enumerate(range(0, len(mods), 4)):
                 conv, bn, act, pool = mods[i:i + 4]
                 if j == 0 and _first_block_ok(x, conv, act, pool, blk_bf[0]):
@@ -468,9 +493,21 @@ class _ImageCNN(nn.Sequential):
                 if x.dtype != want:
                     x = x.to(want)
                 if _conv16_ok(x, conv, blk_bf[j]):
+                    # fp32, 16 output channels, stride-1 pool, fp32 output, and the next block is a conv16 block too: its
+                    # BatchNorm-backward statistics CAN be taken by the next block's input-gradient kernel (I2P_BWD_LINK=1).  Measured
+                    # neutral (11.01 vs 10.99 ms per step: the gathers and the lost wave of occupancy cost the input-gradient
+                    # kernel 25 us, the statistics pass it replaces was 34): off by default
+                    nxt = mods[i + 4] if i + 4 < len(mods) else None
+                    linkable = (not blk_bf[j] and not out_bf[j] and conv.out_channels == 16 and pool.stride == 1 and nxt is not None
+                                and j + 1 < nb and not blk_bf[j + 1] and nxt.in_channels == 16 and nxt.out_channels in (16, 32)
+                                and (nxt.out_channels == 16 or os.environ.get("I2P_NO_CONV32") != "1")
+                                and os.environ.get("I2P_BWD_LINK") == "1" and torch.is_grad_enabled())
+                    link_out = _BwdLink() if linkable else None
                     x = _Conv16Block.apply(x, ws[j] if blk_bf[j] else conv.weight, bn.weight, bn.bias, conv.bias, bn.running_mean,
-                                           bn.running_var, pool.stride, bn.momentum, bn.eps, act.negative_slope, out_bf[j])
+                                           bn.running_var, pool.stride, bn.momentum, bn.eps, act.negative_slope, out_bf[j], link, link_out)
+                    link = link_out
                     continue
+                link = None
                 y = F.conv2d(x, ws[j] if blk_bf[j] else conv.weight, None, conv.stride, conv.padding)
                 x = _BnActPool.apply(y, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
                                      bn.momentum, bn.eps, act.negative_slope, out_bf[j])

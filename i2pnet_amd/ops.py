@@ -527,7 +527,7 @@ class CBackend:
             raise RuntimeError(f"img_conv: weight must be [16|32,16,3,3] (got {tuple(weight.shape)})")
         return cin, cout
 
-    def img_conv16(self, x, weight, with_sums=False, input_grad=False):
+    def img_conv16(self, x, weight, with_sums=False, input_grad=False, prev=None):
         """3x3 convolution (padding 1, no bias) of x [B,H,W,cin] NHWC with weight [cout,cin,3,3] (any dense layout; (cin, cout) =
         (16, 16) or (16, 32)) on csrc/image_conv16.hip -> y [B,H,W,cout]; fp32 tensors, or bf16 tensors with a bf16 weight (bf16
         storage mode: bf16 MFMA, fp32 accumulation); with_sums: also the replicated fp64 {sum y, sum y^2} for
@@ -542,6 +542,17 @@ class CBackend:
         bf = int(dt == _BF16)
         ws = (C.c_int * 4)(*[int(v) for v in weight.stride()])
         y = torch.empty(B, H, W, cin if input_grad else cout, dtype=dt, device=x.device)
+        if input_grad and prev is not None:
+            # prev = (arg, y, mean_invstd, gamma, beta, slope) of the 16-channel stride-1 block in front: its BN-backward sums come back too
+            p_arg, p_y, p_mi, p_gamma, p_beta, p_slope = prev
+            if bf or cin != 16 or tuple(p_y.shape) != (B, H, W, 16) or tuple(p_arg.shape) != (B, H, W, 16):
+                raise RuntimeError("img_conv: `prev` needs fp32 tensors and a 16-channel block of the output's geometry")
+            dsums = zeros(BN_REPLICAS * 32, torch.float64, x.device)
+            self._call("i2p_img_conv_bwd_data_stats", int(B), int(H), int(W), cin, cout, self._p(x, dt, "dy"), C.c_void_p(weight.data_ptr()), ws,
+                       self._p(y, dt, "dx"), self._p(p_arg, torch.uint8, "prev arg"), self._p(p_y, _F32, "prev y"),
+                       self._p(p_mi, _F32, "prev mean_invstd"), self._p(p_gamma, _F32, "prev gamma"), self._p(p_beta, _F32, "prev beta"),
+                       float(p_slope), self._p(dsums, torch.float64, "prev dsums"), stream=self._stream())
+            return y, dsums
         if input_grad:
             self._call("i2p_img_conv_bwd_data", int(B), int(H), int(W), cin, cout, bf, self._p(x, dt, "dy"), C.c_void_p(weight.data_ptr()), ws,
                        self._p(y, dt, "dx"), stream=self._stream())
@@ -594,14 +605,17 @@ class CBackend:
                    self._p(mean_invstd, _F32, "mean_invstd"), stream=self._stream())
         return out, arg, mean_invstd
 
-    def img_block_backward(self, gout, arg, y, mean_invstd, gamma, beta, slope, stride):
-        """-> (dy [B,H,W,C] in y's storage type, dgamma [C], dbeta [C]); gout fp32 or bf16"""
+    def img_block_backward(self, gout, arg, y, mean_invstd, gamma, beta, slope, stride, dsums=None):
+        """-> (dy [B,H,W,C] in y's storage type, dgamma [C], dbeta [C]); gout fp32 or bf16; `dsums` = the producer of gout took the
+        BatchNorm-backward sums already (img_conv16(..., prev=...)): only the dy launch"""
         B, H, W, Cc = y.shape
         dy = torch.empty_like(y)
         dgamma = torch.empty(Cc, dtype=_F32, device=y.device)
         dbeta = torch.empty(Cc, dtype=_F32, device=y.device)
-        dsums = zeros(BN_REPLICAS * 2 * Cc, torch.float64, y.device)
-        self._call("i2p_img_block_bwd", int(B), int(H), int(W), int(Cc), int(stride), int(y.dtype == _BF16), int(gout.dtype == _BF16),
+        entry = "i2p_img_block_bwd" if dsums is None else "i2p_img_block_bwd_dx"
+        if dsums is None:
+            dsums = zeros(BN_REPLICAS * 2 * Cc, torch.float64, y.device)
+        self._call(entry, int(B), int(H), int(W), int(Cc), int(stride), int(y.dtype == _BF16), int(gout.dtype == _BF16),
                    self._p(gout, gout.dtype, "gout"), self._p(arg, torch.uint8, "arg"), self._p(y, y.dtype, "y"),
                    self._p(mean_invstd, _F32, "mean_invstd"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(slope),
                    self._p(dsums, torch.float64, "dsums"), self._p(dy, y.dtype, "dy"), self._p(dgamma, _F32, "dgamma"),

@@ -328,6 +328,16 @@ int i2p_img_block_pool(int B, int H, int W, int C, int stride, int y_bf16, int o
 int i2p_img_conv_fwd(int B, int H, int W, int cin, int cout, int bf16, const void *x, const void *w, const int *ws, void *y, double *sums,
                      void *stream);
 int i2p_img_conv_bwd_data(int B, int H, int W, int cin, int cout, int bf16, const void *dy, const void *w, const int *ws, void *dx, void *stream);
+/* fp32 i2p_img_conv_bwd_data that ALSO takes the BatchNorm-backward sums of the 16-channel, pool-stride-1 block whose pooled output is
+ * this convolution's input (what it writes IS that block's incoming gradient): prev_* = that block's arg-max, conv output,
+ * mean_invstd, gamma, beta, slope; prev_dsums f64 [I2P_BN_REPLICAS][32] zeroed by the caller.  Follow with i2p_img_block_bwd_dx
+ * (= i2p_img_block_bwd without its statistics pass) for that block. */
+int i2p_img_conv_bwd_data_stats(int B, int H, int W, int cin, int cout, const float *dy, const float *w, const int *ws, float *dx,
+                                const unsigned char *prev_arg, const float *prev_y, const float *prev_mean_invstd, const float *prev_gamma,
+                                const float *prev_beta, float prev_slope, double *prev_dsums, void *stream);
+int i2p_img_block_bwd_dx(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout, const unsigned char *arg,
+                         const void *y, const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums, void *dy,
+                         float *dgamma, float *dbeta, void *stream);
 int i2p_img_conv_wgrad_rows(int B, int H, int W);
 int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, int bf16, const void *x, const void *dy, const int *ws, float *partials, void *dW,
                        void *stream);

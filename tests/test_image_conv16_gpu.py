@@ -107,3 +107,48 @@ def test_encoder_stack_with_and_without_conv16(hip_backend, monkeypatch):
             assert torch.allclose(s1[k].float(), s2[k].float(), rtol=1e-4, atol=1e-5), k
     finally:
         ops.set_backend(prev)
+
+
+@pytest.mark.parametrize("cout", [16, 32])
+def test_input_gradient_takes_the_front_blocks_bn_backward_sums(hip_backend, cout):
+    """i2p_img_conv_bwd_data_stats + i2p_img_block_bwd_dx against i2p_img_conv_bwd_data + i2p_img_block_bwd (its own statistics pass)"""
+    g = torch.Generator().manual_seed(cout)
+    B, H, W = 2, 41, 90
+    yk = (torch.randn(B, H, W, 16, generator=g) * 1.5 + 0.2).to(DEV)                     # conv output of the block in front
+    gam, bet = torch.randn(16, generator=g).to(DEV), (torch.randn(16, generator=g) * 0.2).to(DEV)
+    out, arg, mi = hip_backend.img_block_forward(yk, gam, bet, 1e-5, 0.1, 1)
+    w = (torch.randn(cout, 16, 3, 3, generator=g) * 0.2).to(DEV).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(B, H, W, cout, generator=g).to(DEV)
+    dx0 = hip_backend.img_conv16(dy, w, input_grad=True)
+    dx1, dsums = hip_backend.img_conv16(dy, w, input_grad=True, prev=(arg, yk, mi, gam, bet, 0.1))
+    assert torch.equal(dx0, dx1)
+    r0 = hip_backend.img_block_backward(dx0, arg, yk, mi, gam, bet, 0.1, 1)
+    r1 = hip_backend.img_block_backward(dx1, arg, yk, mi, gam, bet, 0.1, 1, dsums=dsums)
+    for name, a, b in zip(("dy", "dgamma", "dbeta"), r0, r1):
+        assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item(), name
+
+
+def test_encoder_stack_with_and_without_the_statistics_hand_off(hip_backend, monkeypatch):
+    from i2pnet_amd import ops
+    from i2pnet_amd.modules import createCNNs
+    prev = ops.set_backend(None)
+    try:
+        torch.manual_seed(5)
+        net = createCNNs(3, [16, 16, 16, 16, 32], [2, 1, 1, 1, 2]).to(DEV).to(memory_format=torch.channels_last).train()
+        x = torch.randn(2, 3, 75, 122, device=DEV)
+        res = {}
+        for tag, env in (("link", "1"), ("plain", "0")):
+            monkeypatch.setenv("I2P_BWD_LINK", env)
+            state = {k: v.clone() for k, v in net.state_dict().items()}
+            net.zero_grad(set_to_none=True)
+            out = net(x)
+            (out * torch.linspace(-1, 1, out.numel(), device=DEV).view_as(out)).sum().backward()
+            res[tag] = (out.detach().clone(), [p.grad.clone() if p.grad is not None else None for p in net.parameters()])
+            net.load_state_dict(state)
+        assert torch.equal(res["link"][0], res["plain"][0])
+        for (n, _), a, b in zip(net.named_parameters(), res["link"][1], res["plain"][1]):
+            assert (a is None) == (b is None), n
+            if a is not None:
+                assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1e-4), n
+    finally:
+        ops.set_backend(prev)
