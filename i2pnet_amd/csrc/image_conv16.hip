@@ -11,8 +11,8 @@
 //     through memory; the weights (A operand) are ordered to match; two accumulators per output tile alternate;
 //   * the MFMAs leave channels 4 kq .. 4 kq + 3 (of each 16-channel tile) of pixel j in the lane = the NHWC vector, stored directly;
 //     lanes j = 1 .. 14 own an output column (their windows lie inside the strip's 16 columns);
-//   * forward: sum y and sum y^2 of the BatchNorm behind the convolution are accumulated from the registers (fp32 over 4 rows,
-//     then fp64) and added to the replicated fp64 sums the pooling kernel reads — the separate statistics pass over y is gone.
+//   * forward: sum y and sum y^2 of the BatchNorm behind the convolution are accumulated from the registers (fp32 per lane over
+//     its ~17 rows, fp64 from there) and added to the replicated fp64 sums the pooling kernel reads — the separate statistics pass over y is gone.
 // The input gradient is the same kernel on dL/dy with the weight indices swapped and the taps mirrored.
 #include "common.h"
 
@@ -81,12 +81,12 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
             for (int qu = 0; qu < 4 * NQ; ++qu) wr[nt][t * 4 * NQ + qu] = wgt.ld(16 * nt + j, 16 * (qu >> 2) + 4 * kq + (qu & 3), t / 3, t % 3);
     const long long img_px = (long long)H * W;
     const int row4 = W * CIN * 4;
+    // a lane adds one value per row of its range (~17 rows at the encoder's sizes): fp32 per lane, fp64 from the wave reduction on
     float s[NT][4], q2[NT][4];
-    double ds[NT][4], dq[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { s[nt][c] = 0.f; q2[nt][c] = 0.f; ds[nt][c] = 0.0; dq[nt][c] = 0.0; }
+        for (int c = 0; c < 4; ++c) { s[nt][c] = 0.f; q2[nt][c] = 0.f; }
     float pmean[4], pinv[4], pscale[4], pbeta[4];
     if constexpr (MODE == 2) {
 #pragma unroll
@@ -181,14 +181,6 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
                     }
                 }
             }
-            if constexpr (STATS) {
-                if (((r - r0) & 3) == 3 || r + 1 == r1) {             // fp32 over 4 rows, then fp64
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) { ds[nt][c] += (double)s[nt][c]; dq[nt][c] += (double)q2[nt][c]; s[nt][c] = 0.f; q2[nt][c] = 0.f; }
-                }
-            }
             R0 = R1; R1 = R2; R2 = Rn; Rn = Rnn;
         }
     }
@@ -199,9 +191,10 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+                double a = (double)s[nt][c], b2 = (double)q2[nt][c];
 #pragma unroll
-                for (int m = 1; m < 16; m <<= 1) { ds[nt][c] += __shfl_xor(ds[nt][c], m); dq[nt][c] += __shfl_xor(dq[nt][c], m); }
-                if (j == 0) { red[threadIdx.x >> 6][16 * nt + 4 * kq + c] = ds[nt][c]; red[threadIdx.x >> 6][COUT + 16 * nt + 4 * kq + c] = dq[nt][c]; }
+                for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b2 += __shfl_xor(b2, m); }
+                if (j == 0) { red[threadIdx.x >> 6][16 * nt + 4 * kq + c] = a; red[threadIdx.x >> 6][COUT + 16 * nt + 4 * kq + c] = b2; }
             }
         __syncthreads();
         if (threadIdx.x < 2 * COUT) {
@@ -251,12 +244,12 @@ __global__ __launch_bounds__(THREADS) void conv3x3_bf16_kernel(const unsigned sh
                 for (int e = 0; e < 4; ++e) wr[nt][t][q][e] = wgt.ld(16 * nt + j, 16 * q + 4 * kq + e, t / 3, t % 3);
     const long long img_px = (long long)H * W;
     const int row2 = W * CIN * 2;
+    // a lane adds one value per row of its range (~17 rows at the encoder's sizes): fp32 per lane, fp64 from the wave reduction on
     float s[NT][4], q2[NT][4];
-    double ds[NT][4], dq[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { s[nt][c] = 0.f; q2[nt][c] = 0.f; ds[nt][c] = 0.0; dq[nt][c] = 0.0; }
+        for (int c = 0; c < 4; ++c) { s[nt][c] = 0.f; q2[nt][c] = 0.f; }
     while (pos < end) {
         const long long bs = pos / H;
         const int r0 = (int)(pos - bs * H), r1 = (int)min((long long)H, r0 + (end - pos));
@@ -313,14 +306,6 @@ __global__ __launch_bounds__(THREADS) void conv3x3_bf16_kernel(const unsigned sh
                     }
                 }
             }
-            if constexpr (STATS) {
-                if (((r - r0) & 3) == 3 || r + 1 == r1) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) { ds[nt][c] += (double)s[nt][c]; dq[nt][c] += (double)q2[nt][c]; s[nt][c] = 0.f; q2[nt][c] = 0.f; }
-                }
-            }
             R0 = R1; R1 = R2; R2 = Rn; Rn = Rnn;
         }
     }
@@ -330,9 +315,10 @@ __global__ __launch_bounds__(THREADS) void conv3x3_bf16_kernel(const unsigned sh
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+                double a = (double)s[nt][c], b2 = (double)q2[nt][c];
 #pragma unroll
-                for (int m = 1; m < 16; m <<= 1) { ds[nt][c] += __shfl_xor(ds[nt][c], m); dq[nt][c] += __shfl_xor(dq[nt][c], m); }
-                if (j == 0) { red[threadIdx.x >> 6][16 * nt + 4 * kq + c] = ds[nt][c]; red[threadIdx.x >> 6][COUT + 16 * nt + 4 * kq + c] = dq[nt][c]; }
+                for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b2 += __shfl_xor(b2, m); }
+                if (j == 0) { red[threadIdx.x >> 6][16 * nt + 4 * kq + c] = a; red[threadIdx.x >> 6][COUT + 16 * nt + 4 * kq + c] = b2; }
             }
         __syncthreads();
         if (threadIdx.x < 2 * COUT) {
@@ -495,7 +481,7 @@ int launch(const void *x, int B, int H, int W, int cin, int cout, const void *w,
     // 4 waves per SIMD of the whole chip, all resident (<= 128 VGPRs); small tensors: one wave per 4 output rows of a strip
     const long long total = (long long)B * strips * H;
     // the 32-channel variants hold more weight registers, the backward-statistics mode more state: 2 - 3 waves per SIMD fit
-    const int wps = cout == 16 ? (prev ? 3 : 4) : (bf16 ? 3 : 2);
+    const int wps = cout == 16 ? 4 : (prev ? 2 : 3);
     long long blocks = (long long)num_cus() * wps;
     if (blocks * (THREADS / 64) * 4 > total) blocks = (total + 4 * (THREADS / 64) - 1) / (4 * (THREADS / 64));
     const dim3 grid(round8(blocks));
