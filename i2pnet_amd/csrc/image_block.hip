@@ -911,27 +911,29 @@ extern "C" int i2p_img_block_pool(int B, int H, int W, int C, int stride, int y_
 
 // backward of the same: (gout [B,Ho,Wo,C] fp32/bf16, arg, y, mean_invstd) -> dy [B,H,W,C] (storage of y), dgamma, dbeta [C] fp32;
 // dsums: f64 [I2P_BN_REPLICAS][2C], zeroed by the caller
-static int img_block_bwd_impl(bool with_stats, int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout,
+static int img_block_bwd_impl(int parts, int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout,
                               const unsigned char *arg, const void *y, const float *mean_invstd, const float *gamma, const float *beta, float slope,
                               double *dsums, void *dy, float *dgamma, float *dbeta, void *stream) {
     if (!geom2_ok(B, H, W, C, stride, y_bf16)) return I2P_ERR_BAD_ARG;
     if (B == 0) return 0;
-    if (!gout || !arg || !y || !mean_invstd || !gamma || !beta || !dsums || !dy || !dgamma || !dbeta) return I2P_ERR_BAD_ARG;
+    if (!gout || !arg || !y || !mean_invstd || !gamma || !beta || !dsums) return I2P_ERR_BAD_ARG;
+    if ((parts & 2) && (!dy || !dgamma || !dbeta)) return I2P_ERR_BAD_ARG;
     const PoolGeom g = make_geom2(B, H, W, C, stride, y_bf16);
     hipStream_t st = (hipStream_t)stream;
     const long long tot_o = (long long)B * g.Ho * g.Wo * g.cv, tot_i = (long long)B * H * W * g.cv;
     const bool wide = tot_i >= (1ll << 31);
-    if (with_stats)
+    if (parts & 1)
         IMG_DISPATCH(img_bwd_stats2_kernel, dim3(grid_for(tot_o, MAX_STAT_BLOCKS)), g, gout, arg, y, mean_invstd, gamma, beta, slope, dsums);
-    IMG_DISPATCH(img_bwd_dx2_kernel, dim3(grid_for(tot_i, gen2_grid(1 << 12))), g, gout, arg, y, mean_invstd, gamma, beta, slope,
-                 (const double *)dsums, dy, dgamma, dbeta);
+    if (parts & 2)
+        IMG_DISPATCH(img_bwd_dx2_kernel, dim3(grid_for(tot_i, gen2_grid(1 << 12))), g, gout, arg, y, mean_invstd, gamma, beta, slope,
+                     (const double *)dsums, dy, dgamma, dbeta);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" int i2p_img_block_bwd(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout, const unsigned char *arg,
                                  const void *y, const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums,
                                  void *dy, float *dgamma, float *dbeta, void *stream) {
-    return img_block_bwd_impl(true, B, H, W, C, stride, y_bf16, out_bf16, gout, arg, y, mean_invstd, gamma, beta, slope, dsums, dy, dgamma, dbeta,
+    return img_block_bwd_impl(3, B, H, W, C, stride, y_bf16, out_bf16, gout, arg, y, mean_invstd, gamma, beta, slope, dsums, dy, dgamma, dbeta,
                               stream);
 }
 // the same with `dsums` already holding sum gz / sum gz xhat (written by the producer of gout: i2p_img_conv_bwd_data_stats): only the
@@ -939,6 +941,13 @@ extern "C" int i2p_img_block_bwd(int B, int H, int W, int C, int stride, int y_b
 extern "C" int i2p_img_block_bwd_dx(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout, const unsigned char *arg,
                                     const void *y, const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums,
                                     void *dy, float *dgamma, float *dbeta, void *stream) {
-    return img_block_bwd_impl(false, B, H, W, C, stride, y_bf16, out_bf16, gout, arg, y, mean_invstd, gamma, beta, slope, dsums, dy, dgamma, dbeta,
+    return img_block_bwd_impl(2, B, H, W, C, stride, y_bf16, out_bf16, gout, arg, y, mean_invstd, gamma, beta, slope, dsums, dy, dgamma, dbeta,
+                              stream);
+}
+// only the statistics pass of i2p_img_block_bwd (dsums: zeroed [I2P_BN_REPLICAS][2C] doubles): what i2p_img_conv_tail_bwd consumes
+extern "C" int i2p_img_block_bwd_stats(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout, const unsigned char *arg,
+                                       const void *y, const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums,
+                                       void *stream) {
+    return img_block_bwd_impl(1, B, H, W, C, stride, y_bf16, out_bf16, gout, arg, y, mean_invstd, gamma, beta, slope, dsums, nullptr, nullptr, nullptr,
                               stream);
 }

@@ -206,6 +206,150 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
     }
 }
 
+// ---- input gradient with the block tail's backward on load --------------------------------------------------------------------------
+// Backward of a 16 -> 16 block whose MaxPool has stride 1: dy = BN-backward(un-pool(g)) of the block's conv output and dx = the input
+// gradient of its convolution, in ONE kernel (img_bwd_dx2_kernel + conv3x3_kernel<16,16,0> before: dy written by one, read by the other).
+// The strip walk of conv3x3_kernel with one more stage in front: rows of g (float4 per lane) and of the arg-max bytes (one word per
+// lane) rotate through registers; dy of a row = the 9 windows that contain the position (three g / arg rows x {lane j - 1, j, j + 1} by
+// DPP), the activation derivative and the BN-backward formula from the y row — img_bwd_dx2_kernel's arithmetic — and is at once the
+// B operand of the next three conv rows.  dy is still written (the weight gradient reads it), each element by the one wave that owns it.
+// A strip yields 12 dx columns (dy needs g of 16 columns for its 14, dx needs dy of 14 for its 12).  dsums: the replica sums of the
+// block's BN-backward statistics (taken before, i2p_img_block_bwd_stats); block 0 writes dgamma / dbeta.
+struct TailBwd {
+    const float *g; const unsigned char *arg; const float *y, *mean_invstd, *gamma, *beta; float slope; const double *dsums;
+    float *dy, *dgamma, *dbeta;
+};
+
+__global__ __launch_bounds__(THREADS) void conv3x3_tail_bwd_kernel(int B, int H, int W, int strips_w, WView16 wgt, TailBwd tb, float *__restrict__ dx) {
+    constexpr int NPW = 12, CC = 16;
+    __shared__ double stat[2 * CC], part[THREADS];
+    {   // stat[i] = sum over the REP replicas (fixed order): groups of 32 threads share the replicas
+        const int idx = threadIdx.x & 31, grp = threadIdx.x >> 5;
+        double a = 0.0;
+        for (int r = grp; r < REP; r += THREADS / 32) a += tb.dsums[(size_t)r * 2 * CC + idx];
+        part[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            double t = 0.0;
+            for (int g2 = 0; g2 < THREADS / 32; ++g2) t += part[g2 * 32 + threadIdx.x];
+            stat[threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x < CC) { tb.dbeta[threadIdx.x] = (float)stat[threadIdx.x]; tb.dgamma[threadIdx.x] = (float)stat[CC + threadIdx.x]; }
+    }
+    const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
+    const unsigned wave = i2p_xcd_swizzle(blockIdx.x, gridDim.x) * (THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned nwaves = gridDim.x * (THREADS / 64);
+    const long long total = (long long)B * strips_w * H;
+    long long pos = total * wave / nwaves;
+    const long long end = total * (wave + 1) / nwaves;
+    if (pos >= end) return;
+    float wr[36];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wr[t * 4 + u] = wgt.ld(j, 4 * kq + u, t / 3, t % 3);
+    const float n = (float)((long long)B * H * W);
+    float mean[4], invstd[4], scale[4], bet[4], mg[4], mgx[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = 4 * kq + c;
+        mean[c] = tb.mean_invstd[ch]; invstd[c] = tb.mean_invstd[CC + ch]; scale[c] = invstd[c] * tb.gamma[ch]; bet[c] = tb.beta[ch];
+        mg[c] = (float)stat[ch] / n; mgx[c] = (float)stat[CC + ch] / n;
+    }
+    const long long img_px = (long long)H * W;
+    const int row4 = W * CC * 4, rowa = W * CC;
+    struct GRow { float g[4]; unsigned a; };
+    struct DRow { float q[4]; };
+    while (pos < end) {
+        const long long bs = pos / H;
+        const int r0 = (int)(pos - bs * H), r1 = (int)min((long long)H, r0 + (end - pos));
+        const int b = (int)(bs / strips_w), strip = (int)(bs - (long long)b * strips_w);
+        pos += r1 - r0;
+        const int c0 = strip * NPW, col = c0 - 2 + j;                   // strip column j = image column c0 - 2 + j; dx columns c0 .. c0 + 11
+        const bool col_in = col >= 0 && col < W;
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tb.g + (long long)b * img_px * CC), 0, (int)(img_px * CC * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tb.y + (long long)b * img_px * CC), 0, (int)(img_px * CC * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(tb.arg + (long long)b * img_px * CC), 0, (int)(img_px * CC), 0x00020000);
+        const int vo4 = col_in ? (col * CC + 4 * kq) * 4 : 0x7fffffff, voa = col_in ? col * CC + 4 * kq : 0x7fffffff;
+        auto load_g = [&](int rr) -> GRow {
+            GRow o;
+            if (rr < 0 || rr >= H) { o.g[0] = o.g[1] = o.g[2] = o.g[3] = 0.f; o.a = 0xffffffffu; return o; }
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rg, vo4, rr * row4, 0);
+            o.g[0] = __uint_as_float(t[0]); o.g[1] = __uint_as_float(t[1]); o.g[2] = __uint_as_float(t[2]); o.g[3] = __uint_as_float(t[3]);
+            o.a = __builtin_amdgcn_raw_buffer_load_b32(ra, voa, rr * rowa, 0);
+            return o;
+        };
+        auto load_y = [&](int rr) -> DRow {
+            DRow o;
+            if (rr < 0 || rr >= H) { o.q[0] = o.q[1] = o.q[2] = o.q[3] = 0.f; return o; }
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ry, vo4, rr * row4, 0);
+            o.q[0] = __uint_as_float(t[0]); o.q[1] = __uint_as_float(t[1]); o.q[2] = __uint_as_float(t[2]); o.q[3] = __uint_as_float(t[3]);
+            return o;
+        };
+        float *dyb = tb.dy + (long long)b * img_px * CC;
+        // dy of row rho from the g rows rho - 1, rho, rho + 1 (T, M, Bt) and the y row; written when this wave owns it (rows r0 .. r1 - 1,
+        // strip columns 2 .. 13)
+        auto make_dy = [&](int rho, const GRow &T, const GRow &M, const GRow &Bt, const DRow &Y) -> DRow {
+            DRow o;
+            if (rho < 0 || rho >= H) { o.q[0] = o.q[1] = o.q[2] = o.q[3] = 0.f; return o; }
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dh = -1; dh <= 1; ++dh) {
+                const GRow &G = dh < 0 ? T : (dh == 0 ? M : Bt);
+                const unsigned aL = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)G.a, 0x111, 0xF, 0xF, false);      // lane j - 1 (dw = -1)
+                const unsigned aR = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)G.a, 0x101, 0xF, 0xF, false);      // lane j + 1 (dw = +1)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float gL = dpp_f32<0x111>(G.g[c]), gR = dpp_f32<0x101>(G.g[c]);
+                    const unsigned code = (unsigned)((1 - dh) * 3);                    // window position (1 - dh) * 3 + (1 - dw)
+                    acc[c] += ((aL >> (8 * c)) & 0xffu) == code + 2u ? gL : 0.f;
+                    acc[c] += ((G.a >> (8 * c)) & 0xffu) == code + 1u ? G.g[c] : 0.f;
+                    acc[c] += ((aR >> (8 * c)) & 0xffu) == code ? gR : 0.f;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float z = (Y.q[c] - mean[c]) * scale[c] + bet[c];
+                const float gz = z > 0.f ? acc[c] : acc[c] * tb.slope;
+                const float xh = (Y.q[c] - mean[c]) * invstd[c];
+                o.q[c] = col_in ? scale[c] * (gz - mg[c] - xh * mgx[c]) : 0.f;
+            }
+            if (rho >= r0 && rho < r1 && j >= 2 && j <= 13 && col_in)
+                *reinterpret_cast<f32x4 *>(dyb + ((long long)rho * W + col) * CC + 4 * kq) = f32x4{o.q[0], o.q[1], o.q[2], o.q[3]};
+            return o;
+        };
+        // g rows r0 - 2 .. and dy rows r0 - 1, r0 to start; each iteration adds dy row r + 1
+        GRow G0 = load_g(r0 - 2), G1 = load_g(r0 - 1), G2 = load_g(r0), G3 = load_g(r0 + 1), G4 = load_g(r0 + 2), Gn;
+        DRow Y0 = load_y(r0 - 1), Y1 = load_y(r0), Y2 = load_y(r0 + 1), Yn;
+        DRow D0 = make_dy(r0 - 1, G0, G1, G2, Y0), D1 = make_dy(r0, G1, G2, G3, Y1), D2;
+        G0 = G2; G1 = G3; G2 = G4;                                        // now G0, G1, G2 = rows r0, r0 + 1, r0 + 2
+        float *dxb = dx + (long long)b * img_px * CC;
+        const bool owns = j >= 2 && j <= 13 && col_in;
+        for (int r = r0; r < r1; ++r) {
+            Gn = load_g(r + 3);
+            Yn = load_y(r + 2);
+            D2 = make_dy(r + 1, G0, G1, G2, Y2);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const DRow &R = kh == 0 ? D0 : (kh == 1 ? D1 : D2);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float mid = R.q[u], left = dpp_f32<0x111>(mid), right = dpp_f32<0x101>(mid);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kh * 3 + 0) * 4 + u], left, acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kh * 3 + 1) * 4 + u], mid, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kh * 3 + 2) * 4 + u], right, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += acc2[c];
+            if (owns) *reinterpret_cast<f32x4 *>(dxb + ((long long)r * W + col) * CC + 4 * kq) = acc;
+            D0 = D1; D1 = D2; G0 = G1; G1 = G2; G2 = Gn; Y2 = Yn;
+        }
+    }
+}
+
 // ---- bf16 storage (BASELINE configs[2] / [4]: ops.set_precision("bf16")) ------------------------------------------------------------
 // The same strip walk on bf16 tensors with v_mfma_f32_16x16x16_bf16: one MFMA takes the 16 input channels of a tap, and the 8 bytes a
 // lane loads per row (channels 4 kq .. 4 kq + 3 of column j) ARE its B operand [k = channel][pixel]; 9 MFMAs per 16 pixels and 16 output
@@ -481,7 +625,8 @@ int launch(const void *x, int B, int H, int W, int cin, int cout, const void *w,
     // 4 waves per SIMD of the whole chip, all resident (<= 128 VGPRs); small tensors: one wave per 4 output rows of a strip
     const long long total = (long long)B * strips * H;
     // the 32-channel variants hold more weight registers, the backward-statistics mode more state: 2 - 3 waves per SIMD fit
-    const int wps = cout == 16 ? 4 : (prev ? 2 : 3);
+    static const int wps32 = [] { const char *e = getenv("I2P_CONV32_WPS"); return e ? atoi(e) : 2; }();
+    const int wps = cout == 16 ? 4 : (prev ? 2 : wps32);
     long long blocks = (long long)num_cus() * wps;
     if (blocks * (THREADS / 64) * 4 > total) blocks = (total + 4 * (THREADS / 64) - 1) / (4 * (THREADS / 64));
     const dim3 grid(round8(blocks));
@@ -557,5 +702,24 @@ extern "C" int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, int bf
     }
     if (bf16) hipLaunchKernelGGL(conv3x3_wgrad_fin_kernel<true>, dim3(36 * nt), dim3(1024), 0, st, blocks, nt, (const float *)partials, wv, dW);
     else hipLaunchKernelGGL(conv3x3_wgrad_fin_kernel<false>, dim3(36 * nt), dim3(1024), 0, st, blocks, nt, (const float *)partials, wv, dW);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+// Backward of a 16 -> 16 block with a stride-1 MaxPool from its incoming gradient g [B,H,W,16]: dy [B,H,W,16] (gradient of the conv
+// output, for i2p_img_conv_wgrad), dx [B,H,W,16], dgamma, dbeta [16].  dsums: the block's BN-backward replica sums, already taken
+// (i2p_img_block_bwd_stats).  Replaces i2p_img_block_bwd_dx + i2p_img_conv_bwd_data.
+extern "C" int i2p_img_conv_tail_bwd(int B, int H, int W, const float *g, const unsigned char *arg, const float *y, const float *mean_invstd,
+                                     const float *gamma, const float *beta, float slope, const double *dsums, const float *w, const int *ws,
+                                     float *dy, float *dx, float *dgamma, float *dbeta, void *stream) {
+    if (!size_ok(B, H, W)) return I2P_ERR_BAD_ARG;
+    if (B == 0) return 0;
+    if (!g || !arg || !y || !mean_invstd || !gamma || !beta || !dsums || !w || !ws || !dy || !dx || !dgamma || !dbeta) return I2P_ERR_BAD_ARG;
+    const WView16 wv{w, ws[1], ws[0], ws[2], ws[3], 1};               // the input-gradient view of the weights
+    const TailBwd tb{g, arg, y, mean_invstd, gamma, beta, slope, dsums, dy, dgamma, dbeta};
+    const int strips = (W + 11) / 12;
+    const long long total = (long long)B * strips * H;
+    long long blocks = (long long)num_cus() * 3;
+    if (blocks * (THREADS / 64) * 4 > total) blocks = (total + 4 * (THREADS / 64) - 1) / (4 * (THREADS / 64));
+    hipLaunchKernelGGL(conv3x3_tail_bwd_kernel, dim3(round8(blocks)), dim3(THREADS), 0, (hipStream_t)stream, B, H, W, strips, wv, tb, dx);
     I2P_RETURN_LAUNCH_STATUS();
 }

@@ -344,9 +344,16 @@ class _Conv16Block(torch.autograd.Function):
         own = ctx.link_out.dsums if ctx.link_out is not None else None          # taken by the block behind, from the registers that held g
         if ctx.link_out is not None:
             ctx.link_out.prev = ctx.link_out.dsums = None
-        dy, dgamma, dbeta = be.img_block_backward(g_nhwc, arg, y, mi, gamma.detach(), beta.detach(), ctx.slope, ctx.stride, dsums=own)
-        dx = None
-        if ctx.needs_input_grad[0]:
+        fused = (own is None and ctx.needs_input_grad[0] and ctx.stride == 1 and tuple(weight.shape) == (16, 16, 3, 3) and y.dtype == torch.float32
+                 and g_nhwc.dtype == torch.float32 and not (ctx.link_in is not None and ctx.link_in.prev is not None)
+                 and os.environ.get("I2P_NO_TAIL_BWD") != "1")
+        if fused:       # un-pooling + BatchNorm backward + input gradient of the convolution in one kernel (dy still written for dW)
+            dy, dx, dgamma, dbeta = be.img_conv16_tail_backward(g_nhwc, arg, y, mi, gamma.detach(), beta.detach(), ctx.slope, weight.detach())
+            dx = dx.permute(0, 3, 1, 2)
+        else:
+            dy, dgamma, dbeta = be.img_block_backward(g_nhwc, arg, y, mi, gamma.detach(), beta.detach(), ctx.slope, ctx.stride, dsums=own)
+            dx = None
+        if ctx.needs_input_grad[0] and not fused:
             if ctx.link_in is not None and ctx.link_in.prev is not None:
                 dx, ctx.link_in.dsums = be.img_conv16(dy, weight.detach(), input_grad=True, prev=ctx.link_in.prev)
             else:

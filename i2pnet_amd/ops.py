@@ -605,6 +605,27 @@ class CBackend:
                    self._p(mean_invstd, _F32, "mean_invstd"), stream=self._stream())
         return out, arg, mean_invstd
 
+    def img_conv16_tail_backward(self, g, arg, y, mean_invstd, gamma, beta, slope, weight):
+        """backward of a fp32 16 -> 16 block with a stride-1 MaxPool from its incoming gradient g [B,H,W,16] ->
+        (dy [B,H,W,16], dx [B,H,W,16], dgamma, dbeta): the block tail's statistics pass, then ONE kernel for the un-pooling, the
+        BatchNorm backward and the convolution's input gradient (csrc/image_conv16.hip)"""
+        B, H, W, Cc = y.shape
+        if Cc != 16 or tuple(g.shape) != (B, H, W, 16) or tuple(weight.shape) != (16, 16, 3, 3) or g.dtype != _F32 or y.dtype != _F32:
+            raise RuntimeError("img_conv16_tail_backward: fp32 16 -> 16 blocks with a stride-1 pool only")
+        dev = y.device
+        dsums = zeros(BN_REPLICAS * 32, torch.float64, dev)
+        self._call("i2p_img_block_bwd_stats", int(B), int(H), int(W), 16, 1, 0, 0, self._p(g, _F32, "gout"), self._p(arg, torch.uint8, "arg"),
+                   self._p(y, _F32, "y"), self._p(mean_invstd, _F32, "mean_invstd"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"),
+                   float(slope), self._p(dsums, torch.float64, "dsums"), stream=self._stream())
+        dy, dx = torch.empty_like(y), torch.empty_like(y)
+        dgamma, dbeta = torch.empty(16, dtype=_F32, device=dev), torch.empty(16, dtype=_F32, device=dev)
+        ws = (C.c_int * 4)(*[int(v) for v in weight.stride()])
+        self._call("i2p_img_conv_tail_bwd", int(B), int(H), int(W), self._p(g, _F32, "g"), self._p(arg, torch.uint8, "arg"), self._p(y, _F32, "y"),
+                   self._p(mean_invstd, _F32, "mean_invstd"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(slope),
+                   self._p(dsums, torch.float64, "dsums"), C.c_void_p(weight.data_ptr()), ws, self._p(dy, _F32, "dy"), self._p(dx, _F32, "dx"),
+                   self._p(dgamma, _F32, "dgamma"), self._p(dbeta, _F32, "dbeta"), stream=self._stream())
+        return dy, dx, dgamma, dbeta
+
     def img_block_backward(self, gout, arg, y, mean_invstd, gamma, beta, slope, stride, dsums=None):
         """-> (dy [B,H,W,C] in y's storage type, dgamma [C], dbeta [C]); gout fp32 or bf16; `dsums` = the producer of gout took the
         BatchNorm-backward sums already (img_conv16(..., prev=...)): only the dy launch"""

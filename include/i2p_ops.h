@@ -338,6 +338,16 @@ int i2p_img_conv_bwd_data_stats(int B, int H, int W, int cin, int cout, const fl
 int i2p_img_block_bwd_dx(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout, const unsigned char *arg,
                          const void *y, const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums, void *dy,
                          float *dgamma, float *dbeta, void *stream);
+/* i2p_img_block_bwd's statistics pass alone, and the backward of a fp32 16 -> 16 block with a stride-1 MaxPool that consumes it:
+ * dy (gradient of the conv output, for i2p_img_conv_wgrad), dx (input gradient of the convolution), dgamma, dbeta from the incoming
+ * gradient g [B,H,W,16] in ONE kernel (csrc/image_conv16.hip: the un-pooling and the BatchNorm backward are formed on load, row by row,
+ * in front of the MFMAs); replaces i2p_img_block_bwd_dx + i2p_img_conv_bwd_data. */
+int i2p_img_block_bwd_stats(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout, const unsigned char *arg,
+                            const void *y, const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums,
+                            void *stream);
+int i2p_img_conv_tail_bwd(int B, int H, int W, const float *g, const unsigned char *arg, const float *y, const float *mean_invstd,
+                          const float *gamma, const float *beta, float slope, const double *dsums, const float *w, const int *ws, float *dy,
+                          float *dx, float *dgamma, float *dbeta, void *stream);
 int i2p_img_conv_wgrad_rows(int B, int H, int W);
 int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, int bf16, const void *x, const void *dy, const int *ws, float *partials, void *dW,
                        void *stream);

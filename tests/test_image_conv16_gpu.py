@@ -152,3 +152,20 @@ def test_encoder_stack_with_and_without_the_statistics_hand_off(hip_backend, mon
                 assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1e-4), n
     finally:
         ops.set_backend(prev)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 41, 90), (1, 3, 12), (1, 7, 5), (3, 20, 131)])
+def test_tail_backward_and_input_gradient_in_one_kernel(hip_backend, B, H, W):
+    """i2p_img_block_bwd_stats + i2p_img_conv_tail_bwd against i2p_img_block_bwd + i2p_img_conv_bwd_data"""
+    g = torch.Generator().manual_seed(B * 100 + W)
+    yk = (torch.randn(B, H, W, 16, generator=g) * 1.5 + 0.2).to(DEV)
+    gam, bet = torch.randn(16, generator=g).to(DEV), (torch.randn(16, generator=g) * 0.2).to(DEV)
+    out, arg, mi = hip_backend.img_block_forward(yk, gam, bet, 1e-5, 0.1, 1)
+    w = (torch.randn(16, 16, 3, 3, generator=g) * 0.2).to(DEV).contiguous(memory_format=torch.channels_last)
+    gin = torch.randn(B, H, W, 16, generator=g).to(DEV)
+    dy0, dg0, db0 = hip_backend.img_block_backward(gin, arg, yk, mi, gam, bet, 0.1, 1)
+    dx0 = hip_backend.img_conv16(dy0, w, input_grad=True)
+    dy1, dx1, dg1, db1 = hip_backend.img_conv16_tail_backward(gin, arg, yk, mi, gam, bet, 0.1, w)
+    assert torch.equal(dy0, dy1)                                 # the same arithmetic in the same order
+    assert (dx0 - dx1).abs().max().item() <= 1e-6 * max(dx0.abs().max().item(), 1e-6)
+    assert torch.allclose(dg0, dg1, rtol=1e-6, atol=1e-6) and torch.allclose(db0, db1, rtol=1e-6, atol=1e-6)
