@@ -253,6 +253,50 @@ def chain_roofline(B, device, bf16=False):
                         "averaged over 10 iterations after 20 warm-up iterations"}
 
 
+def _image_encoder_entry(B, device):
+    """the hand-written kernels of the image encoder's blocks 1-5 at the step's shapes (csrc/image_first.hip, csrc/image_conv16.hip;
+    DESIGN.md section 4): event timings on the launch stream, fp32 MFMA rate against 157.3 TFLOP/s and algorithmic bytes against 8 TB/s"""
+    from i2pnet_amd import ops
+    hip = ops.hip_backend()
+    g = torch.Generator(device=device).manual_seed(1)
+    rnd = lambda *s: torch.randn(*s, generator=g, device=device)
+    H, W = 375, 1242
+    x = rnd(B, 3, H, W)
+    w1 = (rnd(16, 3, 3, 3) * 0.3).contiguous(memory_format=torch.channels_last)
+    gam, bet = rnd(16), rnd(16) * 0.2
+    out, arg, mi, gram = hip.img_first_forward(x, w1, gam, bet, 1e-5, 0.1, 2)
+    go = torch.randn_like(out)
+    _event_time_us(lambda: hip.img_first_forward(x, w1, gam, bet, 1e-5, 0.1, 2), 30)
+    t1f = _event_time_us(lambda: hip.img_first_forward(x, w1, gam, bet, 1e-5, 0.1, 2), 15)
+    t1b = _event_time_us(lambda: hip.img_first_backward(go, arg, x, w1, gam, bet, 0.1, 2, mi, gram), 15)
+    H2, W2 = out.shape[1], out.shape[2]
+    a = rnd(B, H2, W2, 16)
+    w = (rnd(16, 16, 3, 3) * 0.2).contiguous(memory_format=torch.channels_last)
+    y = hip.img_conv16(a, w)
+    o2, arg2, mi2 = hip.img_block_forward(y, gam, bet, 1e-5, 0.1, 1)
+    gin = torch.randn_like(o2)
+    _event_time_us(lambda: hip.img_conv16(a, w), 30)
+    tcf = _event_time_us(lambda: hip.img_conv16(a, w), 20)
+    tcw = _event_time_us(lambda: hip.img_conv16_wgrad(a, y, w), 20)
+    tcb = _event_time_us(lambda: hip.img_conv16_tail_backward(gin, arg2, y, mi2, gam, bet, 0.1, w), 20)
+    tb = a.numel() * 4
+    flop = 2.0 * 144 * 16 * a.numel() / 16
+    mf = lambda t: round(flop / t / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)
+    return {"kernel": "image encoder blocks 1-5 (csrc/image_first.hip, csrc/image_conv16.hip): first block without its conv output; 3x3 "
+                      "convolutions of the 188x621 stage on MFMA",
+            "first_block": {"forward_us (Gram + coefficients + conv/BN/act/pool)": round(t1f, 1), "backward_us (sparse pass + reduction)": round(t1b, 1),
+                            "algorithmic_bytes_forward": int(2 * x.numel() * 4 + out.numel() * 5), "algorithmic_bytes_backward": int(x.numel() * 4 + out.numel() * 5),
+                            "hbm_frac_forward": round((2 * x.numel() * 4 + out.numel() * 5) / t1f / 1e3 / HBM_PEAK_GBS, 4),
+                            "hbm_frac_backward": round((x.numel() * 4 + out.numel() * 5) / t1b / 1e3 / HBM_PEAK_GBS, 4),
+                            "replaces": "channels_last copy + MIOpen zero-fill + igemm forward + statistics + pooling (310 us); BN-backward statistics "
+                                        "+ dy + MIOpen weight gradient (397 us)"},
+            "conv16_16_at_%dx%dx%d" % (B, H2, W2): {
+                "bound": "mfma", "flop": flop, "forward_us (no sums: host-timed wrapper without the zero-fill)": round(tcf, 1), "forward_mfma_frac": mf(tcf),
+                "weight_gradient_us (pass + fixed-order reduction)": round(tcw, 1), "weight_gradient_mfma_frac": mf(tcw),
+                "tail_backward_us (statistics pass + un-pool/BN-backward/input-gradient kernel)": round(tcb, 1),
+                "bytes_per_tensor": tb, "replaces": "MIOpen igemm: 101 us forward (+ 17 statistics), 79 + 18 zero-fill input gradient, 130 + 5 weight gradient"}}
+
+
 def kernel_rooflines(B, device):
     """Live timings (events on the launch stream) of hand-written kernels AS THE fp32 STEP RUNS THEM: every kernel named here
     is an instantiation that appears in the step's rocprofv3 table (profiles/r03_*_steady_kernel_stats.csv) on the same shapes.
@@ -387,7 +431,7 @@ def kernel_rooflines(B, device):
     group = {"kernel": "sa_l1_kernel<9> (level-1 selection + gather + feature build in one launch; unfused = fused_conv_select_k + 2 row "
                        "gathers + subtract + norm + cat, host-timed eager launches)", "bound": "hbm (in practice L2 / LDS / issue)",
              "bytes_per_launch": B * (2 * 64 * 1800 * 12 + 3600 * 32 * 48), "cases": grp}
-    dgrad["other_kernels"] = [fwd, two, pf, selk, group, _mlp_chain_entry(B, device)]
+    dgrad["other_kernels"] = [fwd, two, pf, selk, group, _mlp_chain_entry(B, device), _image_encoder_entry(B, device)]
     del f, gk, bn, bk
     torch.cuda.empty_cache()
     dgrad["chain"] = chain_roofline(B, device)
