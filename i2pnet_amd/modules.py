@@ -428,7 +428,8 @@ class _ImageCNN(nn.Sequential):
     output and its gradient is exactly zero, but adding it and reducing its gradient costs two passes over
     the largest tensors of the network (238 MB at level 1); it only enters the running mean, so that eval
     mode (running statistics, bias added) sees the same buffers.  With USE_FUSED_IMG the BN + LeakyReLU +
-    MaxPool tail of every block runs on the fused HIP kernels; the 3x3 convolution stays on MIOpen."""
+    MaxPool tail of every block runs on the fused HIP kernels; the 3x3 convolutions of the first five blocks (the 375x1242 and
+    188x621 stages) run on csrc/image_first.hip / csrc/image_conv16.hip in fp32 training on the device, the others on MIOpen."""
 
     def _fusable(self, mods):
         for i in range(0, len(mods), 4):
@@ -534,7 +535,7 @@ class _ImageCNN(nn.Sequential):
 
 def createCNNs(in_channel, channels, strides):
     """3x3 conv + BN(running stats) + LeakyReLU(0.1) + MaxPool3 stack — the image encoder
-    (src/modules/basicConv.py:6-20).  Stays on PyTorch-ROCm / MIOpen."""
+    (src/modules/basicConv.py:6-20).  A PyTorch Sequential with the reference's child names; see `_ImageCNN` for what runs where."""
     layers = _ImageCNN()
     last = in_channel
     for i, (out_channel, stride) in enumerate(zip(channels, strides)):
