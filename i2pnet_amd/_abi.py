@@ -99,6 +99,7 @@ DEVICE_ONLY = {
     "i2p_img_block_bwd_dx": ["i"] * 7 + ["p"] * 6 + ["f"] + ["p"] * 4,
     "i2p_img_block_bwd_stats": ["i"] * 7 + ["p"] * 6 + ["f", "p"],
     "i2p_img_conv_tail_bwd": ["i"] * 3 + ["p"] * 6 + ["f"] + ["p"] * 7,
+    "i2p_img_conv_pool_fwd": ["i"] * 4 + ["p"] * 4 + ["f", "f", "f"] + ["p"] * 10,
     "i2p_img_first_fwd": ["i"] * 4 + ["p"] + ["l"] * 4 + ["p", "p", "p", "p", "f", "f", "f"] + ["p"] * 5 + ["i", "p", "p", "p", "i"],
     "i2p_img_first_bwd": ["i"] * 4 + ["p"] + ["l"] * 4 + ["p", "p", "p", "p", "f", "p", "p", "i"] + ["p"] * 6,
     "i2p_pc_rows_fwd": ["i"] * 6 + ["p"] * 8,

@@ -350,6 +350,205 @@ __global__ __launch_bounds__(THREADS) void conv3x3_tail_bwd_kernel(int B, int H,
     }
 }
 
+// ---- forward with the block tail of the block in front on load -----------------------------------------------------------------------
+// BatchNorm + LeakyReLU + MaxPool(3, 1, 1) of a 16-channel block AND the convolution of the next block in one kernel
+// (img_pool_fwd2_kernel + conv3x3_kernel<16,COUT,1> before: the pooled tensor written by one, read by the other).  The strip walk with one
+// more stage in front: rows of the front block's conv output y are loaded (float4 per lane), normalised and activated once, the first
+// maximum over the three window columns comes from the neighbour lanes (DPP), the window's over three such row results — the pooling
+// kernel's arithmetic and tie rule, bit-identical output and arg-max — and a pooled row is at once the B operand of the next three
+// conv rows.  The pooled output and the arg-max bytes are still written (the backward reads them), each element by the wave that owns
+// it; 12 output columns per strip.  Coefficients of the front block from its replica sums in every block's prologue; block 0 writes
+// mean_invstd and the running buffers (as img_pool_fwd2_kernel does).
+struct TailFwd {
+    const float *y; const double *sums; const float *gamma, *beta; float eps, slope, momentum; const float *conv_bias;
+    float *running_mean, *running_var, *out; unsigned char *arg; float *mean_invstd;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(THREADS) void conv3x3_pool_fwd_kernel(int B, int H, int W, int strips_w, WView16 wgt, TailFwd tf, float *__restrict__ yo,
+                                                                   double *__restrict__ sums_o) {
+    constexpr int NPW = 12, CC = 16, NT = COUT / 16;
+    __shared__ double stat[2 * CC], part[THREADS];
+    __shared__ double red[THREADS / 64][2 * COUT];
+    const double n = (double)((long long)B * H * W);
+    {
+        const int idx = threadIdx.x & 31, grp = threadIdx.x >> 5;
+        double a = 0.0;
+        for (int r = grp; r < REP; r += THREADS / 32) a += tf.sums[(size_t)r * 2 * CC + idx];
+        part[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            double t = 0.0;
+            for (int g2 = 0; g2 < THREADS / 32; ++g2) t += part[g2 * 32 + threadIdx.x];
+            stat[threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x < CC) {
+            const int ch = threadIdx.x;
+            const double m = stat[ch] / n;
+            double var = stat[CC + ch] / n - m * m;
+            var = var < 0.0 ? 0.0 : var;
+            tf.mean_invstd[ch] = (float)m;
+            tf.mean_invstd[CC + ch] = rsqrtf((float)var + tf.eps);
+            if (tf.running_mean) {
+                const float mb = (float)m + (tf.conv_bias ? tf.conv_bias[ch] : 0.f);
+                tf.running_mean[ch] = (1.f - tf.momentum) * tf.running_mean[ch] + tf.momentum * mb;
+                const float unbiased = (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+                tf.running_var[ch] = (1.f - tf.momentum) * tf.running_var[ch] + tf.momentum * unbiased;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
+    const unsigned wave = i2p_xcd_swizzle(blockIdx.x, gridDim.x) * (THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned nwaves = gridDim.x * (THREADS / 64);
+    const long long total = (long long)B * strips_w * H;
+    long long pos = total * wave / nwaves;
+    const long long end = total * (wave + 1) / nwaves;
+    float wr[NT][36];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wr[nt][t * 4 + u] = wgt.ld(16 * nt + j, 4 * kq + u, t / 3, t % 3);
+    float mean[4], scale[4], bet[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = 4 * kq + c;
+        const double m = stat[ch] / n;
+        double var = stat[CC + ch] / n - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        mean[c] = (float)m; scale[c] = rsqrtf((float)var + tf.eps) * tf.gamma[ch]; bet[c] = tf.beta[ch];
+    }
+    const long long img_px = (long long)H * W;
+    const int row4 = W * CC * 4;
+    float s[NT][4], q2[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s[nt][c] = 0.f; q2[nt][c] = 0.f; }
+    struct HRow { float v[4]; unsigned k[4]; };                         // first maximum over the window columns of one input row: value, kw
+    struct ORow { float q[4]; };
+    while (pos < end) {
+        const long long bs = pos / H;
+        const int r0 = (int)(pos - bs * H), r1 = (int)min((long long)H, r0 + (end - pos));
+        const int b = (int)(bs / strips_w), strip = (int)(bs - (long long)b * strips_w);
+        pos += r1 - r0;
+        const int c0 = strip * NPW, col = c0 - 2 + j;                   // strip column j = image column c0 - 2 + j; conv columns c0 .. c0 + 11
+        const bool col_in = col >= 0 && col < W;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tf.y + (long long)b * img_px * CC), 0, (int)(img_px * CC * 4), 0x00020000);
+        const int vo4 = col_in ? (col * CC + 4 * kq) * 4 : 0x7fffffff;
+        auto load_y = [&](int rr) -> ORow {
+            ORow o;
+            if (rr < 0 || rr >= H) { o.q[0] = o.q[1] = o.q[2] = o.q[3] = 0.f; return o; }
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ry, vo4, rr * row4, 0);
+            o.q[0] = __uint_as_float(t[0]); o.q[1] = __uint_as_float(t[1]); o.q[2] = __uint_as_float(t[2]); o.q[3] = __uint_as_float(t[3]);
+            return o;
+        };
+        // activations of input row rr, then per lane the first maximum over the columns j - 1, j, j + 1 (-inf outside the image)
+        auto hrow = [&](int rr, const ORow &Y) -> HRow {
+            HRow h;
+            const bool in = rr >= 0 && rr < H && col_in;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float z = (Y.q[c] - mean[c]) * scale[c] + bet[c];
+                const float a = in ? (z > 0.f ? z : z * tf.slope) : -INFINITY;
+                const float left = __int_as_float(__builtin_amdgcn_update_dpp((int)0xff800000u, __float_as_int(a), 0x111, 0xF, 0xF, false));
+                const float right = __int_as_float(__builtin_amdgcn_update_dpp((int)0xff800000u, __float_as_int(a), 0x101, 0xF, 0xF, false));
+                float best = -INFINITY;
+                unsigned bi = 0u;
+                if (left > best || left != left) { best = left; bi = 0u; }
+                if (a > best || a != a) { best = a; bi = 1u; }
+                if (right > best || right != right) { best = right; bi = 2u; }
+                h.v[c] = best; h.k[c] = bi;
+            }
+            return h;
+        };
+        float *ob = tf.out + (long long)b * img_px * CC;
+        unsigned *ab = reinterpret_cast<unsigned *>(tf.arg) + (long long)b * img_px * (CC / 4);
+        // pooled row rho from the row results of rho - 1, rho, rho + 1; zero outside the image (the convolution's padding)
+        auto pooled = [&](int rho, const HRow &T, const HRow &M, const HRow &Bt) -> ORow {
+            ORow o;
+            if (rho < 0 || rho >= H) { o.q[0] = o.q[1] = o.q[2] = o.q[3] = 0.f; return o; }
+            unsigned bi[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float best = -INFINITY;
+                unsigned k = 0u;
+                if (T.v[c] > best || T.v[c] != T.v[c]) { best = T.v[c]; k = T.k[c]; }
+                if (M.v[c] > best || M.v[c] != M.v[c]) { best = M.v[c]; k = 3u + M.k[c]; }
+                if (Bt.v[c] > best || Bt.v[c] != Bt.v[c]) { best = Bt.v[c]; k = 6u + Bt.k[c]; }
+                o.q[c] = col_in ? best : 0.f;
+                bi[c] = k;
+            }
+            if (rho >= r0 && rho < r1 && j >= 2 && j <= 13 && col_in) {
+                const long long e = (long long)rho * W + col;
+                *reinterpret_cast<f32x4 *>(ob + e * CC + 4 * kq) = f32x4{o.q[0], o.q[1], o.q[2], o.q[3]};
+                ab[e * (CC / 4) + kq] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+            }
+            return o;
+        };
+        // input rows r0 - 2 .. r0 + 1 give the pooled rows r0 - 1, r0 to start; each iteration adds pooled row r + 1 (input row r + 2)
+        HRow H0 = hrow(r0 - 2, load_y(r0 - 2)), H1 = hrow(r0 - 1, load_y(r0 - 1)), H2 = hrow(r0, load_y(r0)), H3 = hrow(r0 + 1, load_y(r0 + 1));
+        ORow O0 = pooled(r0 - 1, H0, H1, H2), O1 = pooled(r0, H1, H2, H3), O2;
+        H0 = H2; H1 = H3;                                                 // row results of input rows r0, r0 + 1
+        ORow Yn = load_y(r0 + 2), Ynn;
+        float *yb = yo + (long long)b * img_px * COUT;
+        const bool owns = j >= 2 && j <= 13 && col_in;
+        for (int r = r0; r < r1; ++r) {
+            Ynn = load_y(r + 3);
+            const HRow Hn = hrow(r + 2, Yn);
+            O2 = pooled(r + 1, H0, H1, Hn);
+            f32x4 acc[NT], acc2[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[nt] = acc[nt]; }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const ORow &R = kh == 0 ? O0 : (kh == 1 ? O1 : O2);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float mid = R.q[u], left = dpp_f32<0x111>(mid), right = dpp_f32<0x101>(mid);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[nt][(kh * 3 + 0) * 4 + u], left, acc[nt], 0, 0, 0);
+                        acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[nt][(kh * 3 + 1) * 4 + u], mid, acc2[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[nt][(kh * 3 + 2) * 4 + u], right, acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[nt][c] += acc2[nt][c];
+                if (owns) *reinterpret_cast<f32x4 *>(yb + ((long long)r * W + col) * COUT + 16 * nt + 4 * kq) = acc[nt];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = owns ? acc[nt][c] : 0.f;
+                    s[nt][c] += v;
+                    q2[nt][c] = __fmaf_rn(v, v, q2[nt][c]);
+                }
+            }
+            O0 = O1; O1 = O2; H0 = H1; H1 = Hn; Yn = Ynn;
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double a = (double)s[nt][c], b2 = (double)q2[nt][c];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b2 += __shfl_xor(b2, m); }
+            if (j == 0) { red[threadIdx.x >> 6][16 * nt + 4 * kq + c] = a; red[threadIdx.x >> 6][COUT + 16 * nt + 4 * kq + c] = b2; }
+        }
+    __syncthreads();
+    if (threadIdx.x < 2 * COUT) {
+        double t = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < THREADS / 64; ++w2) t += red[w2][threadIdx.x];
+        atomicAdd(sums_o + (size_t)(blockIdx.x % REP) * 2 * COUT + threadIdx.x, t);
+    }
+}
+
 // ---- bf16 storage (BASELINE configs[2] / [4]: ops.set_precision("bf16")) ------------------------------------------------------------
 // The same strip walk on bf16 tensors with v_mfma_f32_16x16x16_bf16: one MFMA takes the 16 input channels of a tap, and the 8 bytes a
 // lane loads per row (channels 4 kq .. 4 kq + 3 of column j) ARE its B operand [k = channel][pixel]; 9 MFMAs per 16 pixels and 16 output
@@ -721,5 +920,26 @@ extern "C" int i2p_img_conv_tail_bwd(int B, int H, int W, const float *g, const 
     long long blocks = (long long)num_cus() * 3;
     if (blocks * (THREADS / 64) * 4 > total) blocks = (total + 4 * (THREADS / 64) - 1) / (4 * (THREADS / 64));
     hipLaunchKernelGGL(conv3x3_tail_bwd_kernel, dim3(round8(blocks)), dim3(THREADS), 0, (hipStream_t)stream, B, H, W, strips, wv, tb, dx);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
+// BatchNorm + LeakyReLU + MaxPool(3, 1, 1) of a fp32 16-channel block from its conv output y and replica sums (= i2p_img_block_pool:
+// out, arg, mean_invstd, running buffers written) AND the next block's convolution y_next [B,H,W,cout] = conv3x3(out, w) with its
+// replica sums (sums_next zeroed by the caller), in one kernel; cout = 16 or 32.
+extern "C" int i2p_img_conv_pool_fwd(int B, int H, int W, int cout, const float *y, const double *sums, const float *gamma, const float *beta,
+                                     float eps, float slope, float momentum, const float *conv_bias, float *running_mean, float *running_var,
+                                     float *out, unsigned char *arg, float *mean_invstd, const float *w, const int *ws, float *y_next,
+                                     double *sums_next, void *stream) {
+    if (!size_ok(B, H, W) || !pair_ok(16, cout)) return I2P_ERR_BAD_ARG;
+    if (B == 0) return 0;
+    if (!y || !sums || !gamma || !beta || !out || !arg || !mean_invstd || !w || !ws || !y_next || !sums_next) return I2P_ERR_BAD_ARG;
+    const WView16 wv{w, ws[0], ws[1], ws[2], ws[3], 0};
+    const TailFwd tf{y, sums, gamma, beta, eps, slope, momentum, conv_bias, running_mean, running_var, out, arg, mean_invstd};
+    const int strips = (W + 11) / 12;
+    const long long total = (long long)B * strips * H;
+    long long blocks = (long long)num_cus() * (cout == 16 ? 3 : 2);
+    if (blocks * (THREADS / 64) * 4 > total) blocks = (total + 4 * (THREADS / 64) - 1) / (4 * (THREADS / 64));
+    if (cout == 16) hipLaunchKernelGGL(conv3x3_pool_fwd_kernel<16>, dim3(round8(blocks)), dim3(THREADS), 0, (hipStream_t)stream, B, H, W, strips, wv, tf, y_next, sums_next);
+    else hipLaunchKernelGGL(conv3x3_pool_fwd_kernel<32>, dim3(round8(blocks)), dim3(THREADS), 0, (hipStream_t)stream, B, H, W, strips, wv, tf, y_next, sums_next);
     I2P_RETURN_LAUNCH_STATUS();
 }

@@ -367,6 +367,67 @@ class _Conv16Block(torch.autograd.Function):
         return dx, dW, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
+class _Conv16Run(torch.autograd.Function):
+    """A run of consecutive fp32 conv16 blocks of an encoder stack (blocks 2-5 of RGB_net1: 16 -> 16 x 3 with stride-1 pools, then
+    16 -> 32) as one autograd node, so that kernels can span block boundaries: forward = conv, then per boundary ONE kernel for the
+    front block's BatchNorm + LeakyReLU + MaxPool and the next block's convolution (i2p_img_conv_pool_fwd), then the last block's
+    tail; backward per block = statistics pass + one kernel for un-pooling, BatchNorm backward and the input gradient
+    (i2p_img_conv_tail_bwd; the stride-2 block: block-tail kernels + input-gradient kernel) + the weight-gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, x, meta, out_bf_last, *params):
+        """meta: per block (stride, momentum, eps, slope, running_mean, running_var); params: (weight, gamma, beta, conv_bias) per block"""
+        nb = len(meta)
+        x_nhwc = x.permute(0, 2, 3, 1)
+        if not x_nhwc.is_contiguous():
+            x_nhwc = x_nhwc.contiguous()
+        be = ops.get_backend()
+        P4 = lambda i: params[4 * i:4 * i + 4]
+        y, sums = be.img_conv16(x_nhwc, P4(0)[0].detach(), with_sums=True)
+        saved = [x_nhwc]
+        for i in range(nb):
+            w, gamma, beta, bias = P4(i)
+            stride, momentum, eps, slope, rm, rv = meta[i]
+            if i + 1 < nb:
+                out, arg, mi, y_next, sums_next = be.img_conv_pool_forward(y, sums, gamma.detach(), beta.detach(), eps, slope, momentum,
+                                                                          bias.detach(), rm, rv, P4(i + 1)[0].detach())
+            else:
+                out, arg, mi = be.img_block_forward(y, gamma.detach(), beta.detach(), eps, slope, stride, momentum, bias.detach(), rm, rv,
+                                                    out_bf16=out_bf_last, sums=sums)
+            saved += [y, arg, mi, out]
+            if i + 1 < nb:
+                y, sums = y_next, sums_next
+        ctx.save_for_backward(*saved[:-1], *params)          # (the last pooled output is the node's result, not needed again)
+        ctx.meta, ctx.nb = [(m[0], m[3]) for m in meta], nb
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        nb = ctx.nb
+        t = ctx.saved_tensors
+        nsv = 1 + 4 * nb - 1
+        sv, params = t[:nsv], t[nsv:]
+        be = ops.get_backend()
+        gcur = g.permute(0, 2, 3, 1)
+        if not gcur.is_contiguous():
+            gcur = gcur.contiguous()
+        grads = [None] * (4 * nb)
+        for i in range(nb - 1, -1, -1):
+            y, arg, mi = sv[1 + 4 * i], sv[2 + 4 * i], sv[3 + 4 * i]
+            xin = sv[0] if i == 0 else sv[4 * i]             # the pooled output of the block in front
+            w, gamma, beta = params[4 * i], params[4 * i + 1], params[4 * i + 2]
+            stride, slope = ctx.meta[i]
+            need_dx = i > 0 or ctx.needs_input_grad[0]
+            if need_dx and stride == 1 and tuple(w.shape) == (16, 16, 3, 3) and gcur.dtype == torch.float32:
+                dy, dx, dgamma, dbeta = be.img_conv16_tail_backward(gcur, arg, y, mi, gamma.detach(), beta.detach(), slope, w.detach())
+            else:
+                dy, dgamma, dbeta = be.img_block_backward(gcur, arg, y, mi, gamma.detach(), beta.detach(), slope, stride)
+                dx = be.img_conv16(dy, w.detach(), input_grad=True) if need_dx else None
+            grads[4 * i], grads[4 * i + 1], grads[4 * i + 2] = be.img_conv16_wgrad(xin, dy, w.detach()), dgamma, dbeta
+            gcur = dx
+        return (gcur.permute(0, 3, 1, 2) if gcur is not None and ctx.needs_input_grad[0] else None), None, None, *grads
+
+
 class _BwdLink:
     """hand-off between two consecutive fp32 conv16 blocks of an encoder stack (see _Conv16Block.forward): the front block's saved
     tensors for the back block's input-gradient kernel, and the BatchNorm-backward sums that kernel takes for the front block"""
@@ -488,8 +549,31 @@ class _ImageCNN(nn.Sequential):
             if any(blk_bf):
                 ws = _CastBf16.apply(*[mods[i].weight for i in range(0, len(mods), 4)])
             link = None                                         # _BwdLink of the previous block when it can hand over its statistics
+            skip_until = -1
             for j, i in enumerate(range(0, len(mods), 4)):
                 conv, bn, act, pool = mods[i:i + 4]
+                if j <= skip_until:
+                    continue
+                # a run of fp32 conv16 blocks (all but the last with 16 output channels, a stride-1 pool and an fp32 output) CAN run as one
+                # node whose forward kernels span the block boundaries (pooling of block k formed on load by the convolution of block
+                # k + 1, I2P_CONV_RUN=1).  Measured SLOWER, 10.97 / 11.02 against 10.92 / 10.92 ms per step: unlike the backward twin
+                # (i2p_img_conv_tail_bwd, which replaces a VALU-bound 65 us kernel) the 39 us pooling kernel it replaces costs less than
+                # the 12-for-14 column strips and the lost wave of occupancy cost the convolution — off by default
+                if (j > 0 and x.dtype == torch.float32 and not blk_bf[j] and _conv16_ok(x, conv, False)
+                        and os.environ.get("I2P_CONV_RUN") == "1" and os.environ.get("I2P_BWD_LINK") != "1"):
+                    e = j
+                    while (e + 1 < nb and not blk_bf[e + 1] and not out_bf[e] and mods[4 * e].out_channels == 16 and mods[4 * e + 3].stride == 1
+                           and mods[4 * (e + 1)].in_channels == 16 and _conv16_ok(x, mods[4 * (e + 1)], False)):
+                        e += 1
+                    if e > j:
+                        meta, params = [], []
+                        for q in range(j, e + 1):
+                            cq, bq, aq, pq = mods[4 * q:4 * q + 4]
+                            meta.append((pq.stride, bq.momentum, bq.eps, aq.negative_slope, bq.running_mean, bq.running_var))
+                            params += [cq.weight, bq.weight, bq.bias, cq.bias]
+                        x = _Conv16Run.apply(x, meta, out_bf[e], *params)
+                        skip_until, link = e, None
+                        continue
                 if j == 0 and _first_block_ok(x, conv, act, pool, blk_bf[0]):
                     stats = pre[:2] if (pre is not None and pre[2] is x) else None      # (issued ahead by prefetch_first_stats)
                     x = _FirstBlock.apply(x, conv.weight, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,

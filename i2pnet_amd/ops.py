@@ -605,6 +605,29 @@ class CBackend:
                    self._p(mean_invstd, _F32, "mean_invstd"), stream=self._stream())
         return out, arg, mean_invstd
 
+    def img_conv_pool_forward(self, y, sums, gamma, beta, eps, slope, momentum, conv_bias, running_mean, running_var, weight):
+        """block tail (BatchNorm + LeakyReLU + MaxPool(3, 1, 1)) of a fp32 16-channel block from its conv output y [B,H,W,16] and replica
+        sums, and the next block's convolution with `weight` [16|32,16,3,3], in one kernel ->
+        (out [B,H,W,16], arg u8, mean_invstd [32], y_next [B,H,W,cout], sums_next)"""
+        cin, cout = self._conv_pair(weight)
+        B, H, W, Cc = y.shape
+        if Cc != 16 or y.dtype != _F32 or weight.dtype != _F32:
+            raise RuntimeError("img_conv_pool_forward: fp32 16-channel blocks only")
+        dev = y.device
+        out = torch.empty_like(y)
+        arg = torch.empty(B, H, W, 16, dtype=torch.uint8, device=dev)
+        mean_invstd = torch.empty(32, dtype=_F32, device=dev)
+        y_next = torch.empty(B, H, W, cout, dtype=_F32, device=dev)
+        sums_next = zeros(BN_REPLICAS * 2 * cout, torch.float64, dev)
+        ws = (C.c_int * 4)(*[int(v) for v in weight.stride()])
+        opt = lambda t, what: self._p(t, _F32, what) if t is not None else None
+        self._call("i2p_img_conv_pool_fwd", int(B), int(H), int(W), cout, self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums"),
+                   self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(eps), float(slope), float(momentum),
+                   opt(conv_bias, "conv_bias"), opt(running_mean, "running_mean"), opt(running_var, "running_var"), self._p(out, _F32, "out"),
+                   self._p(arg, torch.uint8, "arg"), self._p(mean_invstd, _F32, "mean_invstd"), C.c_void_p(weight.data_ptr()), ws,
+                   self._p(y_next, _F32, "y_next"), self._p(sums_next, torch.float64, "sums_next"), stream=self._stream())
+        return out, arg, mean_invstd, y_next, sums_next
+
     def img_conv16_tail_backward(self, g, arg, y, mean_invstd, gamma, beta, slope, weight):
         """backward of a fp32 16 -> 16 block with a stride-1 MaxPool from its incoming gradient g [B,H,W,16] ->
         (dy [B,H,W,16], dx [B,H,W,16], dgamma, dbeta): the block tail's statistics pass, then ONE kernel for the un-pooling, the

@@ -348,6 +348,12 @@ int i2p_img_block_bwd_stats(int B, int H, int W, int C, int stride, int y_bf16, 
 int i2p_img_conv_tail_bwd(int B, int H, int W, const float *g, const unsigned char *arg, const float *y, const float *mean_invstd,
                           const float *gamma, const float *beta, float slope, const double *dsums, const float *w, const int *ws, float *dy,
                           float *dx, float *dgamma, float *dbeta, void *stream);
+/* Forward twin of i2p_img_conv_tail_bwd: i2p_img_block_pool of a fp32 16-channel block with a stride-1 MaxPool (out, arg, mean_invstd,
+ * running buffers: bit-identical) AND i2p_img_conv_fwd of the next block (y_next [B,H,W,cout], sums_next zeroed by the caller) in one
+ * kernel: the pooled rows are formed on load in front of the MFMAs. */
+int i2p_img_conv_pool_fwd(int B, int H, int W, int cout, const float *y, const double *sums, const float *gamma, const float *beta, float eps,
+                          float slope, float momentum, const float *conv_bias, float *running_mean, float *running_var, float *out,
+                          unsigned char *arg, float *mean_invstd, const float *w, const int *ws, float *y_next, double *sums_next, void *stream);
 int i2p_img_conv_wgrad_rows(int B, int H, int W);
 int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, int bf16, const void *x, const void *dy, const int *ws, float *partials, void *dW,
                        void *stream);

@@ -169,3 +169,55 @@ def test_tail_backward_and_input_gradient_in_one_kernel(hip_backend, B, H, W):
     assert torch.equal(dy0, dy1)                                 # the same arithmetic in the same order
     assert (dx0 - dx1).abs().max().item() <= 1e-6 * max(dx0.abs().max().item(), 1e-6)
     assert torch.allclose(dg0, dg1, rtol=1e-6, atol=1e-6) and torch.allclose(db0, db1, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("cout", [16, 32])
+@pytest.mark.parametrize("B,H,W", [(2, 41, 90), (1, 3, 12), (1, 7, 5), (3, 20, 131)])
+def test_block_tail_and_next_convolution_in_one_kernel(hip_backend, cout, B, H, W):
+    """i2p_img_conv_pool_fwd against i2p_img_block_pool + i2p_img_conv_fwd: pooled output, arg-max, statistics and running buffers
+    bit-identical, the next conv output the same MFMA sums"""
+    g = torch.Generator().manual_seed(B * 100 + W + cout)
+    x = torch.randn(B, H, W, 16, generator=g).to(DEV)
+    w0 = (torch.randn(16, 16, 3, 3, generator=g) * 0.2).to(DEV).contiguous(memory_format=torch.channels_last)
+    w1 = (torch.randn(cout, 16, 3, 3, generator=g) * 0.2).to(DEV).contiguous(memory_format=torch.channels_last)
+    gam, bet, bias = torch.randn(16, generator=g).to(DEV), (torch.randn(16, generator=g) * 0.2).to(DEV), (torch.randn(16, generator=g) * 0.1).to(DEV)
+    rm, rv = torch.randn(16, generator=g).to(DEV), (torch.rand(16, generator=g) + 0.5).to(DEV)
+    y, sums = hip_backend.img_conv16(x, w0, with_sums=True)
+    rm0, rv0, rm1, rv1 = rm.clone(), rv.clone(), rm.clone(), rv.clone()
+    o0, a0, mi0 = hip_backend.img_block_forward(y, gam, bet, 1e-5, 0.1, 1, 0.1, bias, rm0, rv0, sums=sums.clone())
+    y0, s0 = hip_backend.img_conv16(o0, w1, with_sums=True)
+    o1, a1, mi1, y1, s1 = hip_backend.img_conv_pool_forward(y, sums, gam, bet, 1e-5, 0.1, 0.1, bias, rm1, rv1, w1)
+    assert torch.equal(o0, o1) and torch.equal(a0, a1) and torch.equal(mi0, mi1) and torch.equal(rm0, rm1) and torch.equal(rv0, rv1)
+    assert torch.equal(y0, y1)
+    # (a lane's fp32 partial sums cover other rows in the two kernels: 12- against 14-column strips)
+    assert torch.allclose(s0.view(-1, 2 * cout).sum(0), s1.view(-1, 2 * cout).sum(0), rtol=1e-6, atol=1e-3)
+
+
+def test_encoder_stack_as_one_node_against_block_by_block(hip_backend, monkeypatch):
+    from i2pnet_amd import ops
+    from i2pnet_amd.modules import createCNNs
+    prev = ops.set_backend(None)
+    try:
+        torch.manual_seed(6)
+        net = createCNNs(3, [16, 16, 16, 16, 32], [2, 1, 1, 1, 2]).to(DEV).to(memory_format=torch.channels_last).train()
+        x = torch.randn(2, 3, 75, 122, device=DEV)
+        res = {}
+        for tag, env in (("run", "1"), ("blocks", "0")):
+            monkeypatch.setenv("I2P_CONV_RUN", env)
+            state = {k: v.clone() for k, v in net.state_dict().items()}
+            net.zero_grad(set_to_none=True)
+            out = net(x)
+            (out * torch.linspace(-1, 1, out.numel(), device=DEV).view_as(out)).sum().backward()
+            res[tag] = (out.detach().clone(), [p.grad.clone() if p.grad is not None else None for p in net.parameters()],
+                        {k: v.clone() for k, v in net.state_dict().items()})
+            net.load_state_dict(state)
+        # (the replica sums are added by fp64 atomics in another order: statistics agree to the last bits, not bit for bit)
+        assert torch.allclose(res["run"][0], res["blocks"][0], rtol=1e-5, atol=1e-6)
+        for (n, _), a, b in zip(net.named_parameters(), res["run"][1], res["blocks"][1]):
+            assert (a is None) == (b is None), n
+            if a is not None:
+                assert (a - b).abs().max().item() <= 1e-3 * max(b.abs().max().item(), 1e-4), n
+        for k in res["run"][2]:
+            assert torch.allclose(res["run"][2][k].float(), res["blocks"][2][k].float(), rtol=1e-6, atol=1e-7), k
+    finally:
+        ops.set_backend(prev)
