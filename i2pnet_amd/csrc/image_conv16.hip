@@ -20,6 +20,13 @@ namespace {
 
 constexpr int THREADS = 256;
 constexpr int REP = I2P_BN_REPLICAS;
+// s_setprio around the MFMA clusters: the waves of these kernels are independent, so at any time some are in their load / epilogue
+// phase and some in an MFMA cluster — the scheduler may prefer the latter (-DI2P_NO_MFMA_PRIO: off, for A/B)
+#ifndef I2P_NO_MFMA_PRIO
+#define I2P_MFMA_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define I2P_MFMA_PRIO(p)
+#endif
 constexpr int C = 16;                       // input channels of the weight-gradient kernel
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
             f32x4 acc[NT], acc2[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[nt] = acc[nt]; }
+            I2P_MFMA_PRIO(1);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const Row &R = kh == 0 ? R0 : (kh == 1 ? R1 : R2);
@@ -157,6 +165,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
                     }
                 }
             }
+            I2P_MFMA_PRIO(0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -331,6 +340,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_tail_bwd_kernel(int B, int H,
             Yn = load_y(r + 2);
             D2 = make_dy(r + 1, G0, G1, G2, Y2);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+            I2P_MFMA_PRIO(1);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const DRow &R = kh == 0 ? D0 : (kh == 1 ? D1 : D2);
@@ -342,6 +352,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_tail_bwd_kernel(int B, int H,
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(kh * 3 + 2) * 4 + u], right, acc, 0, 0, 0);
                 }
             }
+            I2P_MFMA_PRIO(0);
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[c] += acc2[c];
             if (owns) *reinterpret_cast<f32x4 *>(dxb + ((long long)r * W + col) * CC + 4 * kq) = acc;
@@ -621,6 +632,7 @@ __global__ __launch_bounds__(THREADS) void conv3x3_bf16_kernel(const unsigned sh
             f32x4 acc[NT], acc2[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[nt] = acc[nt]; }
+            I2P_MFMA_PRIO(1);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const Row &R = kh == 0 ? R0 : (kh == 1 ? R1 : R2);
@@ -736,6 +748,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_wgrad_kernel(const void *_
             }
         };
         auto tile = [&](int nt, const float (&g)[16], const float (&A0)[18], const float (&A1)[18], const float (&A2)[18]) {
+            I2P_MFMA_PRIO(1);
 #pragma unroll
             for (int s2 = 0; s2 < 16; ++s2)
 #pragma unroll
@@ -744,6 +757,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv3x3_wgrad_kernel(const void *_
                     acc[nt][3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[s2], A1[s2 + kw], acc[nt][3 + kw], 0, 0, 0);
                     acc[nt][6 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[s2], A2[s2 + kw], acc[nt][6 + kw], 0, 0, 0);
                 }
+            I2P_MFMA_PRIO(0);
         };
         float X0[18], X1[18], X2[18], Xn[18], G0[16], G1[16];
         xrow(r0 - 1, X0); xrow(r0, X1); xrow(r0 + 1, X2); grow(r0, 0, G0);

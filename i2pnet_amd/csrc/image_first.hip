@@ -155,12 +155,14 @@ __global__ __launch_bounds__(GTHREADS) void img1_gram_kernel(XView x, int B, int
         // off these sums
         auto mma = [&](const float (&v0)[16], const float (&v1)[16]) {
             f32x4 a00 = {0.f, 0.f, 0.f, 0.f}, a01 = a00, a11 = a00;
+            __builtin_amdgcn_s_setprio(1);              // (a wave in its MFMA cluster before one that is issuing loads)
 #pragma unroll
             for (int st = 0; st < 16; ++st) {
                 a00 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[st], v0[st], a00, 0, 0, 0);
                 a01 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[st], v1[st], a01, 0, 0, 0);
                 a11 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1[st], v1[st], a11, 0, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { d00[q] += (double)a00[q]; d01[q] += (double)a01[q]; d11[q] += (double)a11[q]; }
         };
