@@ -14,7 +14,7 @@ import csv, sys, collections
 agg = collections.OrderedDict()
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    if "conv3x3_kernel" not in k and "conv3x3_wgrad_kernel" not in k: continue
+    if "conv3x3_" not in k or "fin_kernel" in k: continue
     name = k[k.index("conv3x3"):].split("(")[0]
     e = agg.setdefault((name, r["Counter_Name"]), [0, 0.0]); e[0] += 1; e[1] += float(r["Counter_Value"])
 for (name, c), (n, v) in agg.items(): print(f"{name:16s} {c:32s} n={n:4d} avg={v / n:.6g}")
