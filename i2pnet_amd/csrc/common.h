@@ -139,3 +139,8 @@ bool i2p_wreg_wgrad_bf16_ok(long long rows, int cin, int cout);
 int i2p_wreg_wgrad_bf16(long long rows, int cin, int cout, const unsigned short *gz, const unsigned short *y, const float *g_coef,
                         float g_slope, const unsigned short *x, const float *in_coef, float slope_in, float *dw_partial, unsigned grid,
                         void *stream, const unsigned short *xb = nullptr, const float *in_coef_b = nullptr, float slope_b = 1.f);
+// input gradient + weight gradient of a bf16-storage layer with 64 output channels from ONE read of gz / y / x (csrc/mlp_bwd_fused_bf16.hip)
+bool i2p_bwd_fused_bf16_ok(long long rows, int cin, int cout);
+int i2p_bwd_fused_bf16(long long rows, int cin, int cout, const unsigned short *gz, const unsigned short *y, const float *g_coef,
+                       const unsigned short *x, const float *in_coef, const float *in_mi, float slope_in, const float *w,
+                       unsigned short *gz_in, double *in_dsums, float *dw_partial, unsigned grid, void *stream);

@@ -1387,6 +1387,15 @@ int bwd_impl(long long rows, int cin, int cout, const bf16_t *gz, const bf16_t *
         g_coef = dw_partial + (size_t)grid * cout * cin;
         hipLaunchKernelGGL(bnbwd_coef_bf16, dim3((cout + 63) / 64), dim3(64), 0, st, rows, cout, out_dsums, out_coef, out_mi, g_coef);
     }
+    if (gz_in && gz_in_bf16 && x_bf16 && !two && out_coef && in_coef && slope_out == 1.f && grid == 256 && i2p_bwd_fused_bf16_ok(rows, cin, cout)) {
+        // 64-output-channel layer on many rows: dgrad + wgrad from one read of gz / y / x (csrc/mlp_bwd_fused_bf16.hip)
+        const int rc = i2p_bwd_fused_bf16(rows, cin, cout, gz, y, g_coef, reinterpret_cast<const bf16_t *>(x), in_coef, in_mi, slope_in, w,
+                                          reinterpret_cast<bf16_t *>(gz_in), in_dsums, dw_partial, grid, stream);
+        if (rc) return rc;
+        const int n = cout * cin;
+        hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
+        I2P_RETURN_LAUNCH_STATUS();
+    }
     if (gz_in) {
         DgradP q{};
         q.rows = rows; q.kdim = cout; q.cout = cin; q.ncx = cout / 8; q.cpi_s = log2i(q.ncx); q.cpo_s = log2i(cin / 8);

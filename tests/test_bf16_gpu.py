@@ -197,6 +197,56 @@ def test_lin_bwd_bf16(cin, cout, xbf, in_bn, slope_out):
             assert float((gz_in.float() - ref).abs().max()) <= (1e-4 if gz_in.dtype == torch.float32 else ULP) * float(ref.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("cin,rows", [(128, 65536 + 5 * 32 + 13), (64, 65536 + 32 + 31), (128, 65536), (128, 1707264), (64, 1707264)])
+def test_lin_bwd_bf16_one_pass(cin, rows, monkeypatch):
+    """bwd_fused_bf16_kernel (64-output-channel layers, >= 65536 rows: input gradient + weight gradient from one read of
+    gz / y / x) against (a) fp64 torch on the bf16-rounded operands and (b) the two-kernel form (rg_dgrad + wreg_wgrad_bf16):
+    same operands, same MFMA accumulation order for the input gradient -> bit-identical dL/dz_in.  Sizes: partial last strip,
+    exact multiple, and the 1 707 264 rows of configs[2]'s all-pixel cost volume (16 x 228 x 468)."""
+    hip = _hip()
+    cout = 64
+    x = _rnd(rows, cin, seed=1).to(BF)
+    yv = _rnd(rows, cout, seed=2).to(BF)
+    gz = _rnd(rows, cout, seed=3, scale=0.1).to(BF)
+    w = _rnd(cout, cin, seed=4, scale=cin ** -0.5)
+    oc, omi = _coef(cout, 5)
+    ic, imi = _coef(cin, 6)
+    out_ds = hip.bn_act_backward_stats_bf16(gz, yv, oc, omi, 1.0)
+    gz_in, in_ds, dw = hip.lin_backward(gz, yv, oc, omi, out_ds, x, ic, imi, 0.1, w)
+    dgam, dbet = hip.take_bn_grads()
+    monkeypatch.setenv("I2P_NO_FUSED_BF16", "1")
+    gz_in0, in_ds0, dw0 = hip.lin_backward(gz, yv, oc, omi, out_ds, x, ic, imi, 0.1, w)
+    monkeypatch.delenv("I2P_NO_FUSED_BF16")
+    torch.cuda.synchronize()
+    assert torch.equal(gz_in.view(torch.int16), gz_in0.view(torch.int16)), float((gz_in.float() - gz_in0.float()).abs().max())
+    assert float((dw - dw0).abs().max()) <= 1e-4 * float(dw0.abs().max())
+    s = _sums(out_ds)
+    assert torch.allclose(dbet, s[0].float(), rtol=1e-5, atol=1e-3) and torch.allclose(dgam, s[1].float(), rtol=1e-5, atol=1e-3)
+    # fp64 on the bf16-rounded operands
+    G = _bfr(_g_of(gz, yv, oc, omi, out_ds, rows, 1.0))
+    xa = _bfr(_bn_act(x, ic, 0.1)[0])
+    want_dw = torch.zeros(cout, cin, dtype=torch.float64, device=DEV)
+    step = 1 << 18
+    for r0 in range(0, rows, step):                                            # (chunks: fp64 copies of 1.7 M x 128 add up)
+        want_dw += G[r0:r0 + step].double().t() @ xa[r0:r0 + step].double()
+    assert float((dw.double() - want_dw).abs().max()) <= 2e-3 * float(want_dw.abs().max()), "dw"
+    si = _sums(in_ds)
+    acc0 = torch.zeros(cin, dtype=torch.float64, device=DEV); acc1 = torch.zeros_like(acc0)
+    wb = _bfr(w).double()
+    for r0 in range(0, rows, step):
+        sl = slice(r0, r0 + step)
+        T = (G[sl].double() @ wb).float()
+        zi = _bn_act(x[sl], ic, 1.0)[1]
+        want = _bfr(torch.where(zi > 0, _bfr(T), _bfr(T) * 0.1))
+        _close_bf16(gz_in[sl], want, "gz_in", rel=2 * ULP)
+        gi = gz_in[sl].double()
+        acc0 += gi.sum(0); acc1 += (gi * ((x[sl].float() - imi[:cin]) * imi[cin:]).double()).sum(0)
+    scale = lambda t: float(t.abs().max())
+    assert float((si[0] - acc0).abs().max()) <= 1e-5 * float(gz_in.float().abs().sum(0).max()) + 1e-2
+    assert float((si[1] - acc1).abs().max()) <= 1e-5 * float(gz_in.float().abs().sum(0).max()) * 4 + 5e-2
+    assert torch.allclose(_sums(in_ds0), si, rtol=1e-4, atol=5e-2)
+
+
 def test_lin_bwd_2src_bf16():
     hip = _hip()
     rows, ca, cb, cout = 9000, 64, 64, 128
