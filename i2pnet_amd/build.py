@@ -14,11 +14,14 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 # I2P_BUILD_VARIANT=name [I2P_BUILD_DEFS="-DX -DY"]: a second build of the same ABI next to the product library
 # (lib/libi2p_ops_<name>.so, objects in lib/obj_<name>) for A/B timing through I2P_OPS_LIB (i2pnet_amd/_lib.py); never loaded by default
+# I2P_BUILD_VARIANT_FILES="a.hip b.hip": only these sources are compiled with the variant's defines; every other object is taken
+# from the product build (lib/obj), so a one-kernel ablation build costs one compile + one link
 _VARIANT = os.environ.get("I2P_BUILD_VARIANT", "")
+_VARIANT_FILES = os.environ.get("I2P_BUILD_VARIANT_FILES", "").split()
 LIB = PKG / "lib" / (f"libi2p_ops_{_VARIANT}.so" if _VARIANT else "libi2p_ops.so")
 OBJ = PKG / "lib" / (f"obj_{_VARIANT}" if _VARIANT else "obj")
 SOURCES = ["fused_conv_select_k.hip", "pointnet2_ops.hip", "projection_ops.hip", "bn_act.hip", "mlp.hip", "cv_softmax.hip",
-           "image_block.hip", "image_first.hip", "image_conv16.hip", "mlp_bf16.hip", "bf16_stream.hip", "sa_group.hip", "scatter_det.hip", "mlp_wreg.hip", "mlp_wreg_fused.hip", "mlp_wreg_bf16.hip", "mlp_bwd_fused_bf16.hip", "gemm_tn.hip", "mlp_big.hip", "optim.hip", "glue.hip", "mlp_chain.hip"]
+           "image_block.hip", "image_first.hip", "image_conv16.hip", "mlp_bf16.hip", "bf16_stream.hip", "sa_group.hip", "scatter_det.hip", "mlp_wreg.hip", "mlp_wreg_fused.hip", "mlp_wreg_bf16.hip", "mlp_bwd_fused_bf16.hip", "pair_bwd_bf16.hip", "gemm_tn.hip", "mlp_big.hip", "optim.hip", "glue.hip", "mlp_chain.hip"]
 # mlp_wreg.hip: one strip = 256 MFMAs with the rest of the wave's work slotted between them, written as ONE fully
 # unrolled loop — past clang's default size limit for `#pragma unroll`
 EXTRA_FLAGS = {"mlp_wreg.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
@@ -52,14 +55,19 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
-    if not force and not needs_build():
+    if not force and not needs_build() and not (_VARIANT and _VARIANT_FILES):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     OBJ.mkdir(parents=True, exist_ok=True)
     hdrs = HEADERS + list(CSRC.glob("*.h"))
     jobs = []
+    main_obj = PKG / "lib" / "obj"
+    objs = {}
     for s in _sources():
-        o = OBJ / (s + ".o")
+        if _VARIANT and _VARIANT_FILES and s not in _VARIANT_FILES:
+            objs[s] = main_obj / (s + ".o")             # (the product build must be current)
+            continue
+        o = objs[s] = OBJ / (s + ".o")
         if force or _stale(o, [CSRC / s] + hdrs):
             jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", str(CSRC / s), "-o", str(o)])
 
@@ -70,7 +78,7 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [str(OBJ / (s + ".o")) for s in _sources()] + ["-o", str(LIB)])
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [str(objs[s]) for s in _sources()] + ["-o", str(LIB)])
     return LIB
 
 

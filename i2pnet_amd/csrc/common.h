@@ -144,3 +144,9 @@ bool i2p_bwd_fused_bf16_ok(long long rows, int cin, int cout);
 int i2p_bwd_fused_bf16(long long rows, int cin, int cout, const unsigned short *gz, const unsigned short *y, const float *g_coef,
                        const unsigned short *x, const float *in_coef, const float *in_mi, float slope_in, const float *w,
                        unsigned short *gz_in, double *in_dsums, float *dw_partial, unsigned grid, void *stream);
+// second-generation bf16 pair-layer backward (csrc/pair_bwd_bf16.hip): d_f / d_g / d_bn / d_bk accumulate into the caller's zeroed
+// outputs, dw_partial[grid][128*128] is reduced by the caller
+bool i2p_pair_bwd2_bf16_ok(int B, int N, int M, int cin, int cout);
+int i2p_pair_bwd2_bf16_grid(int B, int N, int M);
+int i2p_pair_bwd2_bf16(int B, int N, int M, const unsigned short *gz, const unsigned short *y, const float *g_coef, const float *f,
+                       const float *g, const float *w, float *d_f, float *d_g, float *d_bn, float *d_bk, float *dw_partial, void *stream);

@@ -1517,11 +1517,17 @@ extern "C" int i2p_lin_bwd_2src_bf16(long long rows, int cin_a, int cin_b, int c
                     dw_partial, dw, 1.f, &t, stream);
 }
 
-extern "C" int i2p_pair_lin_bwd_bf16_grid(int B, int N, int M) {
+static int pair_bwd_gen1_grid(int B, int N, int M) {
     const int KT = (M + PB_PX - 1) / PB_PX;
     int NC = 256 / (B * KT > 0 ? B * KT : 1);
     NC = NC < 1 ? 1 : (NC > N ? N : NC);
     return B * KT * NC;
+}
+
+// blocks whose weight-gradient partials the caller's scratch must hold (whichever of the two kernels runs)
+extern "C" int i2p_pair_lin_bwd_bf16_grid(int B, int N, int M) {
+    const int g1 = pair_bwd_gen1_grid(B, N, M), g2 = i2p_pair_bwd2_bf16_grid(B, N, M);
+    return g1 > g2 ? g1 : g2;
 }
 
 extern "C" int i2p_pair_lin_bwd_bf16(int B, int N, int M, int cin, int cout, const bf16_t *gz, const bf16_t *y,
@@ -1533,10 +1539,21 @@ extern "C" int i2p_pair_lin_bwd_bf16(int B, int N, int M, int cin, int cout, con
     if (!gz || !f || !g || !w || !d_f || !d_g || !d_bias_n || !d_bias_k || !dw_partial || !dw) return I2P_ERR_BAD_ARG;
     if (out_coef && (!y || !out_mi || !out_dsums)) return I2P_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (out_coef && i2p_pair_bwd2_bf16_ok(B, N, M, cin, cout)) {
+        // 128 x 128 on many rows: persistent blocks over 32-pixel strips, three strips in flight per wave (csrc/pair_bwd_bf16.hip)
+        const unsigned galloc = (unsigned)i2p_pair_lin_bwd_bf16_grid(B, N, M), g2 = (unsigned)i2p_pair_bwd2_bf16_grid(B, N, M);
+        float *g_coef = dw_partial + (size_t)galloc * cout * cin;
+        hipLaunchKernelGGL(bnbwd_coef_bf16, dim3((cout + 63) / 64), dim3(64), 0, st, (long long)B * N * M, cout, out_dsums, out_coef, out_mi, g_coef);
+        const int rc = i2p_pair_bwd2_bf16(B, N, M, gz, y, g_coef, f, g, w, d_f, d_g, d_bias_n, d_bias_k, dw_partial, stream);
+        if (rc) return rc;
+        const int nel = cout * cin;
+        hipLaunchKernelGGL(reduce_partials_bf16, dim3((nel + 31) / 32), dim3(256), 0, st, (int)g2, nel, dw_partial, dw);
+        I2P_RETURN_LAUNCH_STATUS();
+    }
     PairBwdP p{};
     p.B = B; p.N = N; p.M = M; p.cin = cin; p.cout = cout;
     const int KT = (M + PB_PX - 1) / PB_PX;
-    const unsigned grid = (unsigned)i2p_pair_lin_bwd_bf16_grid(B, N, M);
+    const unsigned grid = (unsigned)pair_bwd_gen1_grid(B, N, M);
     p.NC = (int)grid / (B * KT); p.NL = (N + p.NC - 1) / p.NC;
     p.gz = gz; p.y = y; p.f = f; p.g = g; p.w = w; p.d_f = d_f; p.d_g = d_g; p.d_bn = d_bias_n; p.d_bk = d_bias_k; p.dw_partial = dw_partial;
     if (out_coef) {

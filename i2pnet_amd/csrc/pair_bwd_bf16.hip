@@ -1,0 +1,343 @@
+// Backward of the factored first cost-volume layer (pair mode, 128 -> 128) on bf16 gz / y — second generation of
+// mlp_bf16.hip's pair_bwd_bf16_kernel (BASELINE configs[2] / [4]; reference: PPBackbone_center.py:383-433, the first 1x1 conv of
+// mlp1 on cat[xyz, uv, LF (.) RF]; the factored form is DESIGN.md section 4).
+//
+//   rows (b, n, k): G = BN-backward(gz, y) (bf16-rounded), x' = bf16(f[b,n,:] * g[b,k,:])
+//   dW[co][ci]   = sum_{b,n,k} G[co] x'[ci]
+//   d_bn[b,n,co] = sum_k G,      d_bk[b,k,co] = sum_n G
+//   T = G . W (fp32);  d_f[b,n,ci] = sum_k T g[b,k,ci],   d_g[b,k,ci] = sum_n T f[b,n,ci]
+//
+// The only HBM traffic that matters is ONE read of gz and y (rows * 512 B); the first-generation kernel reached 0.19 of 8 TB/s
+// on it: 64-pixel tiles, __syncthreads() per point (whose workgroup-scope fence waits for the prefetched loads: nothing is in
+// flight across the barrier), fp32 scaling of every weight-gradient tile per point, three LDS images per point.
+//
+// Here: the strips (b, kt, n) — 32 pixels k0..k0+31 of point n: 32 consecutive rows of gz / y — are numbered with n fastest and
+// cut into equal contiguous ranges, one per block (persistent grid of 2 blocks per CU, balanced to one strip).  A block of four
+// waves shares each strip: wave w loads and stages rows 8w..8w+7 (dword loads, a whole 256-byte row per instruction; two strips in
+// flight per wave, four per SIMD), the images Gr (row-major, dgrad A operand) and Gt (transposed, wgrad A operand and the B operand
+// of the two pixel-axis sums) are double-buffered, the block meets at ONE s_barrier per strip that waits for LDS only.  Wave w owns
+// input-channel tile w:
+//   dW[:, tile w] += Gt . x'^T       4 MFMAs per 16 pixels, x' = bf16(f * g) formed in registers from the tile's pixel factors —
+//                                    the operand the FORWARD multiplies with, so dW is the gradient of what the forward computes;
+//   T[:, tile w]   = Gr . W          8 MFMAs, W^T tile from a block-resident LDS image; d_g accumulates in registers across the
+//                                    points (16 per lane), d_f is the lane's 16-register dot product with its pixel factors;
+//   d_bn[tile w]   = 1^T . Gt        2 MFMAs with an all-ones A operand: the pixel sum without a cross-lane reduction;
+//   d_bk[tile w]  += I . Gt          2 MFMAs with identity slices as A operand: G itself, accumulated over the points in the layout
+//                                    of d_g (no per-lane adds in the staging phase, no second flush path).
+// d_f / d_bn leave per strip as one coalesced 128-byte atomic per wave, d_g / d_bk per pixel tile; dW per block, reduced by the
+// caller as before.  Measured at batch 16 (tools/time_bf16_bwd.py; ablation builds P2_ABL, profiles/r05_pair_bwd2_*): first generation
+// 568 us -> one block per CU, three strips in flight 367 (streaming skeleton alone 181, staging +50, MFMA phase +130: the four waves
+// run their phases in lock-step and the phases add up) -> two blocks per CU, padded LDS pitches (one address register per image
+// instead of one per (row, chunk)), scalar strip iterator, short path for full pixel tiles: 280 us = 0.39 of 8 TB/s.  SQ counters:
+// ~350 instructions per strip and wave, 45 % of the wave cycles waiting; neither atomics, the barrier nor bank conflicts move it.
+#include "bf16_common.h"
+#include <cstdlib>
+
+#ifndef P2_ABL
+#define P2_ABL 0                 // diagnostic builds (I2P_BUILD_VARIANT): 1 no per-strip atomics, 2 no MFMA phase, 4 no staging, 8 no barrier, 16 no sched_barrier
+#endif
+
+namespace {
+
+constexpr int P2_THREADS = 256;
+constexpr int P2_C = 128;
+constexpr int P2_PX = 32;
+
+
+struct PairBwd2P {
+    int B, N, M, KT;
+    long long S;                 // strips = B * KT * N
+    const bf16_t *gz, *y;        // [B*N*M, 128]
+    const float *g_coef;         // [6][128] m1, m2, scale, mean, invstd, beta
+    const float *f, *g, *w;      // [B,N,128], [B,M,128], [128 co][128 ci]
+    float *d_f, *d_g, *d_bn, *d_bk, *dw_partial;
+};
+
+// LDS images with PADDED row pitches instead of XOR swizzles: 272 B for the 256-byte rows (Wt, Gr), 80 B for the 64-byte rows of the
+// transposed image Gt — an MFMA operand read (16 consecutive rows, one chunk) is conflict-free at both pitches, and every address is
+// one lane-dependent base register plus a compile-time offset (the swizzled form needed a register per (row, chunk) pair: ~50)
+constexpr int P2_PW = 272, P2_PT = 80;
+constexpr int P2_WT_BYTES = 128 * P2_PW, P2_GR_BYTES = 32 * P2_PW, P2_GT_BYTES = 128 * P2_PT, P2_BUF_BYTES = P2_GR_BYTES + P2_GT_BYTES;
+__device__ __forceinline__ uint4 lds_u4(const char *base, int off) { return *reinterpret_cast<const uint4 *>(base + off); }
+// block barrier on LDS traffic only: __syncthreads() carries a workgroup-scope fence that also waits for the global loads in flight
+__device__ __forceinline__ void p2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct StripIt {                 // position in the strip sequence, n fastest; wave-uniform
+    int b, kt, n;
+    __device__ __forceinline__ void next(int N, int KT) { if (++n == N) { n = 0; if (++kt == KT) { kt = 0; ++b; } } }
+};
+__device__ __forceinline__ StripIt strip_at(long long idx, int N, int KT) {
+    // (the 64-bit division runs on the vector unit: without the readfirstlane the iterator — and with it every address of the
+    //  loop — counts as lane-dependent, ~125 VALU instructions of 64-bit address arithmetic per strip)
+    StripIt it; const long long t = idx / N;
+    it.n = __builtin_amdgcn_readfirstlane((int)(idx - t * N)); it.b = __builtin_amdgcn_readfirstlane((int)(t / KT));
+    it.kt = __builtin_amdgcn_readfirstlane((int)(t - (long long)(t / KT) * KT)); return it;
+}
+
+struct RawStrip { unsigned g[8], y[8]; float f; };
+
+// Two blocks per CU (two waves per SIMD, 256 registers each): while one block's waves sit in an LDS round trip, an MFMA chain or
+// the barrier, the other block's waves issue — with one block per CU the four waves run their phases in lock-step and the phases
+// add up (measured: streaming skeleton 181 us, + staging 50, + MFMA phase 130 = 367 us at batch 16).
+__global__ __launch_bounds__(P2_THREADS, 2) void pair_bwd2_bf16_kernel(PairBwd2P p) {
+    extern __shared__ uint4 smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char *Wt = reinterpret_cast<char *>(smem); // [128 ci] rows of 16 chunks: chunk c of row ci = w[co = 8c .. 8c+7][ci]   (dgrad B operand)
+    char *Gb = Wt + P2_WT_BYTES;               // 2 x { Gr [32 px] rows of 16 chunks, Gt [128 co] rows of 4 chunks }
+    const int N = p.N, M = p.M, KT = p.KT;
+
+    for (int i = tid; i < 128 * 16; i += P2_THREADS) {
+        const int ci = i >> 4, c = i & 15;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = p.w[(size_t)(8 * c + q) * P2_C + ci];
+        *reinterpret_cast<uint4 *>(Wt + ci * P2_PW + c * 16) = bf_pack8(v);
+    }
+    // staging role: wave w, lane c2: channels 2 c2, 2 c2 + 1 of pixel rows 8w .. 8w+7
+    const int c2 = lane;
+    float gA[2], gB[2], gC[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int ch = 2 * c2 + u, K = P2_C;
+        const float m1 = p.g_coef[ch], m2 = p.g_coef[K + ch], sc = p.g_coef[2 * K + ch], mu = p.g_coef[3 * K + ch], is = p.g_coef[4 * K + ch];
+        gA[u] = sc; gB[u] = -(sc * m2) * is; gC[u] = -(sc * m1) - gB[u] * mu;
+    }
+    // MFMA role: input-channel tile `wave` (output-channel tile `wave` for the two pixel-axis sums), lane (n, h)
+    const int n = lane & 31, h = lane >> 5;
+    const int ci = 32 * wave + n;
+    // The contraction slots of a 16-pixel MFMA step s are numbered like the accumulator rows: slot (kh, q) of step s <-> pixel
+    // px(s, kh, q) = (q & 3) + 4 kh + 8 (q >> 2) + 16 s, so that the pixel factors a lane needs as x' operand (slots of its k-half)
+    // and for the d_f dot product (rows of its accumulator half) are the SAME 16 registers gk[8 s + q].
+    // identity A operand of the d_bk sum (rows = pixels): lane (m = n, kh = h) holds 1.0 at step m >> 4, slot q = (m & 3) + 4 ((m >> 3) & 1)
+    // iff ((m >> 2) & 1) == kh
+    i2p_bf16x8 ident[2];
+    {
+        const int m = n, q1 = (m & 3) + 4 * ((m >> 3) & 1);
+        const bool mine = ((m >> 2) & 1) == h;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            unsigned wv[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const bool lo = mine && (m >> 4) == s && q1 == 2 * d, hi = mine && (m >> 4) == s && q1 == 2 * d + 1;
+                wv[d] = (lo ? 0x3F80u : 0u) | (hi ? 0x3F800000u : 0u);
+            }
+            ident[s] = __builtin_bit_cast(i2p_bf16x8, make_uint4(wv[0], wv[1], wv[2], wv[3]));
+        }
+    }
+    const unsigned ones2 = 0x3F803F80u;
+    const i2p_bf16x8 ones = __builtin_bit_cast(i2p_bf16x8, make_uint4(ones2, ones2, ones2, ones2));
+
+    // this block's range of strips
+    const long long s_begin = (long long)blockIdx.x * p.S / gridDim.x, s_end = (long long)(blockIdx.x + 1) * p.S / gridDim.x;
+    const int count = __builtin_amdgcn_readfirstlane((int)(s_end - s_begin));
+
+    i2p_f32x16 accw[4], dbk;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        dbk[e] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) accw[mt][e] = 0.f;
+    }
+    float dg_acc[16], gk[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dg_acc[e] = 0.f; gk[e] = 0.f; }
+
+    // ---- requests of one strip: rows (b*N + n)*M + k0 + 8w + j.  Full pixel tiles (14 of 15 at M = 468) take the short path:
+    // one wave-uniform row pointer per tensor and compile-time offsets; a partial tile clamps every row into the tile's valid rows
+    // (the kernel is bound by instruction issue — ~400 instructions per strip and wave, two waves per SIMD —, not by any pipe)
+    auto request = [&](const StripIt &it, RawStrip &R) {
+        const int k0 = it.kt * P2_PX;
+        const size_t bn = (size_t)it.b * N + it.n;
+        R.f = (p.f + bn * P2_C)[ci];
+        const unsigned *gz32 = reinterpret_cast<const unsigned *>(p.gz), *y32 = reinterpret_cast<const unsigned *>(p.y);
+        if (k0 + P2_PX <= M) {
+            const size_t row = (bn * M + k0 + 8 * wave) * (P2_C / 2);
+            const unsigned *gp = gz32 + row + c2, *yp = y32 + row + c2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { R.g[j] = __builtin_nontemporal_load(gp + j * (P2_C / 2)); R.y[j] = __builtin_nontemporal_load(yp + j * (P2_C / 2)); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int k = k0 + 8 * wave + j; k = k < M ? k : M - 1;
+                const size_t row = (bn * M + k) * (P2_C / 2);
+                R.g[j] = __builtin_nontemporal_load(gz32 + row + c2);
+                R.y[j] = __builtin_nontemporal_load(y32 + row + c2);
+            }
+        }
+    };
+    // ---- staging of one strip into image buffer `buf` ---------------------------------------------------------------------------
+    auto stage = [&](const StripIt &it, const RawStrip &R, int buf) {
+        char *Gr = Gb + buf * P2_BUF_BYTES, *Gt = Gr + P2_GR_BYTES;
+        char *gr_w = Gr + wave * (8 * P2_PW) + c2 * 4;
+        char *gt_w = Gt + c2 * (2 * P2_PT) + (wave >> 1) * 32 + (wave & 1) * 8;
+        const int nv = M - it.kt * P2_PX;           // >= 32: every row of the strip is a pixel
+        float v[8][2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float g0 = bf_lo(R.g[j]), g1 = bf_hi(R.g[j]), y0 = bf_lo(R.y[j]), y1 = bf_hi(R.y[j]);
+            v[j][0] = __builtin_fmaf(gA[0], g0, __builtin_fmaf(gB[0], y0, gC[0]));
+            v[j][1] = __builtin_fmaf(gA[1], g1, __builtin_fmaf(gB[1], y1, gC[1]));
+        }
+        if (nv < P2_PX) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (8 * wave + j >= nv) { v[j][0] = 0.f; v[j][1] = 0.f; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<unsigned *>(gr_w + j * P2_PW) = bf_pack2(v[j][0], v[j][1]);
+        // transposed image: rows 8w + j sit at slots q = 4 (w & 1) + (j & 3) of chunk 2 (w >> 1) + (j >> 2) (see the slot numbering above)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh)
+                *reinterpret_cast<uint2 *>(gt_w + u * P2_PT + jh * 16) =
+                    make_uint2(bf_pack2(v[4 * jh][u], v[4 * jh + 1][u]), bf_pack2(v[4 * jh + 2][u], v[4 * jh + 3][u]));
+    };
+    // ---- pixel factors of a tile: gk[e] = g[b, k0 + px(e, h), ci], px(e, h) = (e & 3) + 8 (e >> 2) + 4 h --------------------------
+    auto load_tile = [&](const StripIt &it) {
+        const int k0 = it.kt * P2_PX;
+        const float *gb = p.g + ((size_t)it.b * M) * P2_C + ci;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {               // (branch-free: clamped address, value selected afterwards)
+            const int k = k0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float v = gb[(size_t)(k < M ? k : M - 1) * P2_C];
+            gk[e] = k < M ? v : 0.f;
+        }
+    };
+    // per pixel tile: d_g[b, k, tile w of ci] and d_bk[b, k, tile w of co] leave from the same accumulator layout
+    auto flush_tile = [&](const StripIt &it) {
+        const int k0 = it.kt * P2_PX;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int k = k0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (k < M) {
+                atomicAdd(p.d_g + ((size_t)it.b * M + k) * P2_C + ci, dg_acc[e]);
+                atomicAdd(p.d_bk + ((size_t)it.b * M + k) * P2_C + ci, dbk[e]);
+            }
+            dg_acc[e] = 0.f; dbk[e] = 0.f;
+        }
+    };
+    // ---- MFMA phase of one strip on image buffer `buf` ---------------------------------------------------------------------------
+    auto compute = [&](const StripIt &it, float fs, int buf) {
+        const char *Gr = Gb + buf * P2_BUF_BYTES, *Gt = Gr + P2_GR_BYTES;
+        const char *gr_r = Gr + n * P2_PW + h * 16, *wt_r = Wt + ci * P2_PW + h * 16, *gt_r = Gt + n * P2_PT + h * 16;
+        i2p_bf16x8 xb[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float pr[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pr[q] = gk[8 * s + q] * fs;
+            xb[s] = __builtin_bit_cast(i2p_bf16x8, bf_pack8(pr));
+        }
+        i2p_f32x16 T, sn;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { T[e] = 0.f; sn[e] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            // four steps of the T chain between the independent MFMAs of this 16-pixel step
+            const i2p_bf16x8 gs = __builtin_bit_cast(i2p_bf16x8, lds_u4(gt_r + wave * (32 * P2_PT), s * 32));
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int ks = 4 * s + mt;
+                const i2p_bf16x8 ga = __builtin_bit_cast(i2p_bf16x8, lds_u4(gr_r, ks * 32));
+                const i2p_bf16x8 wb = __builtin_bit_cast(i2p_bf16x8, lds_u4(wt_r, ks * 32));
+                T = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, wb, T, 0, 0, 0);
+                const i2p_bf16x8 av = __builtin_bit_cast(i2p_bf16x8, lds_u4(gt_r, mt * (32 * P2_PT) + s * 32));
+                accw[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, xb[s], accw[mt], 0, 0, 0);
+            }
+            sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, gs, sn, 0, 0, 0);          // sum over the strip's pixels
+            dbk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ident[s], gs, dbk, 0, 0, 0);     // G itself, added up over the points
+        }
+        float colsum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            dg_acc[e] = __builtin_fmaf(T[e], fs, dg_acc[e]);
+            colsum = __builtin_fmaf(T[e], gk[e], colsum);
+        }
+        colsum += __shfl_xor(colsum, 32);
+        if ((P2_ABL & 1) ? (lane < 32 && fs == 1234.5f) : lane < 32) {
+            const size_t bn = (size_t)it.b * N + it.n;
+            atomicAdd(p.d_f + bn * P2_C + ci, colsum);
+            atomicAdd(p.d_bn + bn * P2_C + ci, sn[0]);
+        }
+    };
+
+    p2_barrier();                              // Wt staged
+    if (count > 0) {
+        StripIt it_load = strip_at(s_begin, N, KT), it_stage = it_load, it_comp = it_load;
+        RawStrip R0, R1;
+        int loaded = 0;
+        // clamped request: past the end of the range the last strip is requested again (never staged)
+        auto req = [&](RawStrip &R) { request(it_load, R); if (loaded + 1 < count) { it_load.next(N, KT); } ++loaded; };
+        req(R0); req(R1);
+        load_tile(it_comp);
+        stage(it_stage, R0, 0);
+        float f_cur = R0.f, f_next = 0.f;
+        req(R0);
+        p2_barrier();
+        // iteration t: stage strip t+1 (register set (t+1) & 1) into buffer (t+1) & 1, request strip t+3 into that set, compute strip t
+        auto iter = [&](int t, RawStrip &Rs) {
+            const bool more = t + 1 < count;
+            if (more) {
+                it_stage.next(N, KT);
+                if (!(P2_ABL & 4) || Rs.f == 1234.5f) stage(it_stage, Rs, (t + 1) & 1);
+                f_next = Rs.f;
+                req(Rs);
+            }
+            if (!(P2_ABL & 16)) __builtin_amdgcn_sched_barrier(0);
+            if (!(P2_ABL & 2) || f_cur == 1234.5f) compute(it_comp, f_cur, t & 1);
+            if (more) {
+                StripIt it_old = it_comp;
+                it_comp.next(N, KT);
+                if (it_comp.n == 0) { flush_tile(it_old); load_tile(it_comp); }
+                f_cur = f_next;
+            }
+            if (!(P2_ABL & 8)) p2_barrier();
+        };
+        int t = 0;
+        for (; t + 1 < count; t += 2) { iter(t, R1); iter(t + 1, R0); }
+        if (t < count) iter(t, R1);
+        flush_tile(it_comp);
+    }
+
+    // ---- dW partial of the block: accw[mt] of wave w = dW[32 mt + row(e, h)][32 w + n]; every element owned by one lane ---------
+    float *part = p.dw_partial + (size_t)blockIdx.x * P2_C * P2_C;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * h;
+            part[(size_t)co * P2_C + ci] = accw[mt][e];
+        }
+}
+
+}  // namespace
+
+bool i2p_pair_bwd2_bf16_ok(int B, int N, int M, int cin, int cout) {
+    const char *e = getenv("I2P_NO_PAIR_BWD2");                     // (read per call: the tests compare the two kernels in one process)
+    if (e && e[0] == '1') return false;
+    return cin == P2_C && cout == P2_C && M >= 8 && (long long)B * N * M >= 16384 && (unsigned long long)B * N * M * 256ull < (1ull << 40);
+}
+
+int i2p_pair_bwd2_bf16_grid(int B, int N, int M) {
+    const long long S = (long long)B * ((M + P2_PX - 1) / P2_PX) * N;
+    return (int)(S < 512 ? S : 512);
+}
+
+int i2p_pair_bwd2_bf16(int B, int N, int M, const unsigned short *gz, const unsigned short *y, const float *g_coef, const float *f,
+                       const float *g, const float *w, float *d_f, float *d_g, float *d_bn, float *d_bk, float *dw_partial, void *stream) {
+    if (!gz || !y || !g_coef || !f || !g || !w || !d_f || !d_g || !d_bn || !d_bk || !dw_partial) return I2P_ERR_BAD_ARG;
+    PairBwd2P p;
+    p.B = B; p.N = N; p.M = M; p.KT = (M + P2_PX - 1) / P2_PX; p.S = (long long)B * p.KT * N;
+    p.gz = gz; p.y = y; p.g_coef = g_coef; p.f = f; p.g = g; p.w = w; p.d_f = d_f; p.d_g = d_g; p.d_bn = d_bn; p.d_bk = d_bk; p.dw_partial = dw_partial;
+    const size_t bytes = (size_t)P2_WT_BYTES + 2 * (size_t)P2_BUF_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pair_bwd2_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pair_bwd2_bf16_kernel, dim3((unsigned)i2p_pair_bwd2_bf16_grid(B, N, M)), dim3(P2_THREADS), bytes, (hipStream_t)stream, p);
+    I2P_RETURN_LAUNCH_STATUS();
+}

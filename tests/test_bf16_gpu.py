@@ -295,6 +295,46 @@ def test_pair_lin_bwd_bf16(B, N, M, C, Co):
     assert float((dw.double() - want_dw).abs().max()) <= 2e-3 * scale(want_dw)
 
 
+@pytest.mark.parametrize("B,N,M", [(2, 40, 468), (1, 300, 75), (3, 50, 200), (5, 8, 468), (1, 2500, 8), (16, 228, 468)])
+def test_pair_lin_bwd_bf16_second_generation(B, N, M, monkeypatch):
+    """pair_bwd2_bf16_kernel (128 x 128, >= 16384 rows: persistent blocks over 32-pixel strips) against fp64 on the bf16-rounded
+    operands and against the first-generation kernel.  Shapes: partial pixel tiles (M % 32 = 20, 11, 8), ranges that cross
+    several (sample, pixel tile) boundaries, fewer strips than blocks, and configs[2]'s own 16 x 228 x 468."""
+    hip = _hip()
+    C = Co = 128
+    rows = B * N * M
+    f, g = _rnd(B, N, C, seed=1), _rnd(B, M, C, seed=2)
+    w = _rnd(Co, C, seed=3, scale=C ** -0.5)
+    yv, gz = _rnd(rows, Co, seed=4).to(BF), _rnd(rows, Co, seed=5, scale=0.1).to(BF)
+    oc, omi = _coef(Co, 6)
+    ds = hip.bn_act_backward_stats_bf16(gz, yv, oc, omi, 1.0)
+    d_f, d_g, d_bn, d_bk, dw = hip.pair_lin_backward(gz, f, g, w, y=yv, out_coef=oc, out_mi=omi, out_dsums=ds)
+    monkeypatch.setenv("I2P_NO_PAIR_BWD2", "1")
+    r_f, r_g, r_bn, r_bk, r_dw = hip.pair_lin_backward(gz, f, g, w, y=yv, out_coef=oc, out_mi=omi, out_dsums=ds)
+    monkeypatch.delenv("I2P_NO_PAIR_BWD2")
+    torch.cuda.synchronize()
+    scale = lambda t: float(t.abs().max())
+    for a, b, what, tol in ((d_f, r_f, "d_f", 1e-3), (d_g, r_g, "d_g", 1e-3), (d_bn, r_bn, "d_bn", 1e-4), (d_bk, r_bk, "d_bk", 1e-4), (dw, r_dw, "dw", 8e-3)):   # (dW: the two kernels round different operands, bf16(f g) vs f bf16(g))
+        assert float((a - b).abs().max()) <= tol * scale(b) + 1e-6, what
+    # fp64 on the bf16-rounded operands, sample by sample (the [N, M, 128] products of one sample fit easily)
+    Gall = _bfr(_g_of(gz, yv, oc, omi, ds, rows, 1.0)).view(B, N, M, Co)
+    wb = _bfr(w).double()
+    want_dw = torch.zeros(Co, C, dtype=torch.float64, device=DEV)
+    for b in range(B):
+        G = Gall[b].double()
+        fd, gd = f[b].double(), g[b].double()
+        T = G @ wb                                                                     # [N,M,C]
+        assert float((d_bn[b].double() - G.sum(1)).abs().max()) <= 1e-4 * scale(G.sum(1)) + 1e-6
+        assert float((d_bk[b].double() - G.sum(0)).abs().max()) <= 1e-4 * scale(G.sum(0)) + 1e-6
+        want_df = (T * gd.unsqueeze(0)).sum(1); want_dg = (T * fd.unsqueeze(1)).sum(0)
+        assert float((d_f[b].double() - want_df).abs().max()) <= 1e-3 * scale(want_df)
+        assert float((d_g[b].double() - want_dg).abs().max()) <= 1e-3 * scale(want_dg)
+        # dW = G^T . bf16(f (.) g): the operand of the forward kernel
+        X = _bfr(f[b].unsqueeze(1) * g[b].unsqueeze(0)).double()                        # [N,M,C]
+        want_dw += torch.einsum("nmo,nmc->oc", G, X)
+    assert float((dw.double() - want_dw).abs().max()) <= 2e-3 * scale(want_dw)
+
+
 def test_stream_kernels_bf16():
     from i2pnet_amd import ops
     hip = _hip()

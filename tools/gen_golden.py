@@ -647,6 +647,10 @@ if __name__ == "__main__":
         run_sized("config_proj_lidarcenter", "kitti_b8", B=8, N=8192, img_h=375, img_w=1242, seed=8, beams=64)
         run_sized("config_proj_lidarcenter", "kitti_b16", B=16, N=8192, img_h=375, img_w=1242, seed=16, beams=64)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sized_nus":
+        # BASELINE.json configs[4] at its own per-GPU shape: nuScenes configuration, batch 8, 375 x 1242 image, 16 384 points
+        run_sized("config_proj_lidarcenter_nus", "nus_b8", B=8, N=16384, img_h=375, img_w=1242, seed=18, beams=32)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "iter":
         run_iter("config_proj_lidarcenter", "kitti_iter", B=2, N=8192, img_h=375, img_w=1242, seed=3, beams=64)
         sys.exit(0)
