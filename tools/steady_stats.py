@@ -18,6 +18,17 @@ def short(name):
     return name[:150]
 
 
+def grid_of(r):
+    """blocks of the launch (rocprofv3 reports the grid in work-items): launches of one kernel on tensors of different sizes are
+    kept apart, so that a row's average is the duration of ONE instantiation on ONE tensor size"""
+    try:
+        g = int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0) * max(1, int(r.get("Grid_Size_Y") or 1)) * max(1, int(r.get("Grid_Size_Z") or 1))
+        w = int(r.get("Workgroup_Size_X") or r.get("Workgroup_Size") or 1) * max(1, int(r.get("Workgroup_Size_Y") or 1)) * max(1, int(r.get("Workgroup_Size_Z") or 1))
+        return g // max(1, w)
+    except (TypeError, ValueError):
+        return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
@@ -38,13 +49,13 @@ def main():
     agg = defaultdict(lambda: [0, 0, 0])
     for r in sel:
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-        e = agg[short(r["Kernel_Name"])]
+        e = agg[(short(r["Kernel_Name"]), grid_of(r))]
         e[0] += 1; e[1] += d; e[2] = max(e[2], d)
     tot = sum(v[1] for v in agg.values())
     wall = t1 - t0
-    lines = [("kernel", "calls_per_step", "total_us_per_step", "avg_us", "pct_of_kernel_time", "max_us")]
-    for k, (c, d, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        lines.append((k, f"{c / a.steps:.1f}", f"{d / a.steps / 1e3:.1f}", f"{d / c / 1e3:.2f}", f"{100.0 * d / tot:.2f}", f"{mx / 1e3:.1f}"))
+    lines = [("kernel", "blocks", "calls_per_step", "total_us_per_step", "avg_us", "pct_of_kernel_time", "max_us")]
+    for (k, g), (c, d, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        lines.append((k, str(g), f"{c / a.steps:.1f}", f"{d / a.steps / 1e3:.1f}", f"{d / c / 1e3:.2f}", f"{100.0 * d / tot:.2f}", f"{mx / 1e3:.1f}"))
     print(f"# steps={a.steps} wall_per_step_ms={wall / a.steps / 1e6:.3f} kernel_time_per_step_ms={tot / a.steps / 1e6:.3f} "
           f"launches_per_step={len(sel) / a.steps:.0f} distinct_kernels={len(agg)}")
     for ln in lines[: a.top + 1]:
@@ -67,14 +78,14 @@ def tail_stats(rows, marks, n_train, out):
         if int(r["Start_Timestamp"]) < t_end:
             continue
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-        e = agg[short(r["Kernel_Name"])]
+        e = agg[(short(r["Kernel_Name"]), grid_of(r))]
         e[0] += 1; e[1] += d; e[2] = min(e[2], d); e[3] = max(e[3], d)
     with open(out, "w", newline="") as f:
         f.write("# kernels launched by bench.py after the timed steps (live roofline timings); rocprofv3 --kernel-trace\n")
         w = csv.writer(f)
-        w.writerow(("kernel", "calls", "avg_us", "min_us", "max_us"))
-        for k, (c, d, lo, hi) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
-            w.writerow((k, c, f"{d / c / 1e3:.2f}", f"{lo / 1e3:.2f}", f"{hi / 1e3:.2f}"))
+        w.writerow(("kernel", "blocks", "calls", "avg_us", "min_us", "max_us"))
+        for (k, g), (c, d, lo, hi) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+            w.writerow((k, g, c, f"{d / c / 1e3:.2f}", f"{lo / 1e3:.2f}", f"{hi / 1e3:.2f}"))
 
 
 if __name__ == "__main__":
