@@ -150,3 +150,8 @@ bool i2p_pair_bwd2_bf16_ok(int B, int N, int M, int cin, int cout);
 int i2p_pair_bwd2_bf16_grid(int B, int N, int M);
 int i2p_pair_bwd2_bf16(int B, int N, int M, const unsigned short *gz, const unsigned short *y, const float *g_coef, const float *f,
                        const float *g, const float *w, float *d_f, float *d_g, float *d_bn, float *d_bk, float *dw_partial, void *stream);
+bool i2p_bwd_fused2_bf16_ok(long long rows, int cin_a, int cin_b, int cout);
+int i2p_bwd_fused2_bf16(long long rows, const unsigned short *gz, const unsigned short *y, const float *g_coef, const unsigned short *xa,
+                        const float *coef_a, const float *mi_a, float slope_a, const unsigned short *xb, const float *coef_b,
+                        const float *mi_b, float slope_b, const unsigned short *e_add, const float *w, unsigned short *gz_a,
+                        double *sums_a, unsigned short *gz_b, double *sums_b, float *dw_partial, unsigned grid, void *stream);

@@ -1396,6 +1396,17 @@ int bwd_impl(long long rows, int cin, int cout, const bf16_t *gz, const bf16_t *
         hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
         I2P_RETURN_LAUNCH_STATUS();
     }
+    if (gz_in && gz_in_bf16 && x_bf16 && two && out_coef && in_coef && two->coef_b && two->mi_b && two->e_add && two->gz_b && in_dsums && two->dsums_b &&
+        slope_out == 1.f && grid == 256 && i2p_bwd_fused2_bf16_ok(rows, two->split, cin - two->split, cout)) {
+        // the two-source 64 + 64 -> 128 layer on many rows: one pass over gz / y / xa / xb / e_add (csrc/mlp_bwd_fused_bf16.hip)
+        const int rc = i2p_bwd_fused2_bf16(rows, gz, y, g_coef, reinterpret_cast<const bf16_t *>(x), in_coef, in_mi, slope_in, two->xb, two->coef_b,
+                                           two->mi_b, two->slope_b, two->e_add, w, reinterpret_cast<bf16_t *>(gz_in), in_dsums, two->gz_b,
+                                           two->dsums_b, dw_partial, grid, stream);
+        if (rc) return rc;
+        const int n = cout * cin;
+        hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
+        I2P_RETURN_LAUNCH_STATUS();
+    }
     if (gz_in) {
         DgradP q{};
         q.rows = rows; q.kdim = cout; q.cout = cin; q.ncx = cout / 8; q.cpi_s = log2i(q.ncx); q.cpo_s = log2i(cin / 8);

@@ -270,6 +270,50 @@ def test_lin_bwd_2src_bf16():
     assert torch.allclose(_sums(dsb)[0], gzb.double().sum(0), rtol=1e-5, atol=1e-2)
 
 
+@pytest.mark.parametrize("rows", [65536 + 7 * 16, 1707264])
+def test_lin_bwd_2src_bf16_one_pass(rows, monkeypatch):
+    """bwd_fused2_bf16_kernel (64 + 64 -> 128, >= 65536 rows: both input gradients and the weight gradient from one read of
+    gz / y / xa / xb / e_add) against the two-kernel form (bit-identical input gradients: same operands, same accumulation order
+    over k) and against fp64 on the bf16-rounded operands; second size = configs[2]'s 16 x 228 x 468 rows."""
+    hip = _hip()
+    ca = cb = 64; cout = 128
+    xa, xb = _rnd(rows, ca, seed=1).to(BF), _rnd(rows, cb, seed=2).to(BF)
+    yv, gz = _rnd(rows, cout, seed=3).to(BF), _rnd(rows, cout, seed=4, scale=0.1).to(BF)
+    eadd = _rnd(rows, cb, seed=5, scale=0.1).to(BF)
+    w = _rnd(cout, ca + cb, seed=6, scale=128 ** -0.5)
+    oc, omi = _coef(cout, 7); cfa, mia = _coef(ca, 8); cfb, mib = _coef(cb, 9)
+    out_ds = hip.bn_act_backward_stats_bf16(gz, yv, oc, omi, 1.0)
+    gza, dsa, gzb, dsb, dw = hip.lin_backward_2src(gz, yv, oc, omi, out_ds, xa, cfa, mia, 0.1, xb, cfb, mib, 0.2, eadd, w)
+    monkeypatch.setenv("I2P_NO_FUSED_BF16", "1")
+    gza0, dsa0, gzb0, dsb0, dw0 = hip.lin_backward_2src(gz, yv, oc, omi, out_ds, xa, cfa, mia, 0.1, xb, cfb, mib, 0.2, eadd, w)
+    monkeypatch.delenv("I2P_NO_FUSED_BF16")
+    torch.cuda.synchronize()
+    assert torch.equal(gza.view(torch.int16), gza0.view(torch.int16)), float((gza.float() - gza0.float()).abs().max())
+    assert torch.equal(gzb.view(torch.int16), gzb0.view(torch.int16)), float((gzb.float() - gzb0.float()).abs().max())
+    assert float((dw - dw0).abs().max()) <= 1e-4 * float(dw0.abs().max())
+    assert torch.allclose(_sums(dsa), _sums(dsa0), rtol=1e-4, atol=5e-2) and torch.allclose(_sums(dsb), _sums(dsb0), rtol=1e-4, atol=5e-2)
+    G = _bfr(_g_of(gz, yv, oc, omi, out_ds, rows, 1.0))
+    wb = _bfr(w).double()
+    want_dw = torch.zeros(cout, ca + cb, dtype=torch.float64, device=DEV)
+    step = 1 << 18
+    for r0 in range(0, rows, step):
+        sl = slice(r0, r0 + step)
+        X = _bfr(torch.cat([_bn_act(xa[sl], cfa, 0.1)[0], _bn_act(xb[sl], cfb, 0.2)[0]], 1))
+        want_dw += G[sl].double().t() @ X.double()
+        T = (G[sl].double() @ wb).float()
+        za, zb = _bn_act(xa[sl], cfa, 1.0)[1], _bn_act(xb[sl], cfb, 1.0)[1]
+        Ta = _bfr(T[:, :ca]); Tb = _bfr(T[:, ca:]) + eadd[sl].float()
+        _close_bf16(gza[sl], _bfr(torch.where(za > 0, Ta, Ta * 0.1)), "gz_a", rel=2 * ULP)
+        # (source b adds e_add to the rounded product: where the two cancel, one bf16 ulp of the PRODUCT is the error scale)
+        want_b = _bfr(torch.where(zb > 0, Tb, Tb * 0.2))
+        mag = (_bfr(T[:, ca:]).abs() + eadd[sl].float().abs()) * torch.where(zb > 0, 1.0, 0.2)
+        bad = (gzb[sl].float() - want_b).abs() > 2 * ULP * mag + 1e-30
+        assert not bool(bad.any()), ("gz_b", int(bad.sum()))
+    assert float((dw.double() - want_dw).abs().max()) <= 2e-3 * float(want_dw.abs().max())
+    assert torch.allclose(_sums(dsa)[0], gza.double().sum(0), rtol=1e-5, atol=1e-1)
+    assert torch.allclose(_sums(dsb)[0], gzb.double().sum(0), rtol=1e-5, atol=1e-1)
+
+
 @pytest.mark.parametrize("B,N,M,C,Co", [(2, 13, 150, 128, 128), (1, 40, 64, 64, 32), (2, 9, 468, 128, 128)])
 def test_pair_lin_bwd_bf16(B, N, M, C, Co):
     hip = _hip()
