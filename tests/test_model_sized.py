@@ -156,7 +156,7 @@ def _pgrad_floors():
     reference's own fp32 arithmetic lands from the exact gradient of that tensor (the fixtures carry both, `pgrad.*` from
     the imported reference, `pgrad64.*` from the fp64 evaluation; tools/gen_golden.py sized)"""
     if not _FLOORS:
-        for tag in ("kitti_b8", "kitti_b16"):
+        for tag in ("kitti_b8", "kitti_b16", "nus_b8"):
             g = np.load(GOLD / f"model_{tag}.npz")
             for f in g.files:
                 if f.startswith("pgrad64."):
@@ -226,7 +226,23 @@ def test_config2_shape_batch16_fp32_matches_reference_on_gpu(hip_backend):
     _check_fp32(*_run_sized("kitti_b16", "cuda"), tol=1e-4, grad_tol=1e-3, grad_tensor_tol=2e-3, rgb_tol=1.5e-2)
 
 
+@pytest.mark.gpu
+def test_config4_shape_batch8_fp32_matches_reference_on_gpu(hip_backend):
+    """BASELINE.json configs[4] at its own per-GPU shape — nuScenes configuration (21 x 1800 range image, 16 384 points,
+    src/config_proj_lidarcenter_nus.py), batch 8, 375 x 1242 image — in the reference's precision (VERDICT r4 missing #3:
+    `tests/golden/model_nus_b8.npz`, `tools/gen_golden.py sized_nus`)"""
+    torch.manual_seed(0)
+    _check_fp32(*_run_sized("nus_b8", "cuda"), tol=1e-4, grad_tol=1e-3, grad_tensor_tol=2e-3, rgb_tol=1.5e-2)
+
+
 BF16_POSE_TOL, BF16_ACT_TOL = 8e-2, 1.2e-1
+
+
+@pytest.mark.gpu
+def test_config4_batch8_bf16_against_reference_on_gpu(hip_backend, monkeypatch):
+    """configs[4] (nuScenes shapes, batch 8, bf16 storage as `bench.py --config 4` runs it) against the fp32 reference at that size,
+    under the same contract as configs[2]"""
+    _bf16_contract("nus_b8", monkeypatch, 3, 1)
 
 
 @pytest.mark.gpu
@@ -242,11 +258,15 @@ def test_config2_batch16_bf16_against_reference_on_gpu(hip_backend, monkeypatch,
     (tools/diag_bf16_tiers.py): first k blocks fp32 -> pose 1.24e-1 / 7.0e-2 / 8.9e-2 / 7.8e-2 / 7.6e-2 for k = 0 / 1 / 2 / 3 / 5 —
     from k = 1 on the pose sits at the level of the chains-only tier — at 1104 / 1076 / 1050 / - / 967 samples/s.  The all-bf16 encoder
     (k = 0) is outside this contract and no longer the default."""
+    _bf16_contract("kitti_b16", monkeypatch, img_nets, fp32_blocks)
+
+
+def _bf16_contract(tag, monkeypatch, img_nets, fp32_blocks):
     pose_tol, act_tol = BF16_POSE_TOL, BF16_ACT_TOL
     monkeypatch.setenv("I2P_IMG_FP32_BLOCKS", str(fp32_blocks))
     monkeypatch.setenv("I2P_IMG_BF16_NETS", str(img_nets))
     torch.manual_seed(0)
-    gold, model, acts, out3, out4, loss = _run_sized("kitti_b16", "cuda", precision="bf16")
+    gold, model, acts, out3, out4, loss = _run_sized(tag, "cuda", precision="bf16")
     assert _rel(out3.detach().cpu(), gold["out3"]) < pose_tol
     assert _rel(out4.detach().cpu(), gold["out4"]) < pose_tol
     assert abs(loss.item() - gold["loss"][0]) / abs(gold["loss"][0]) < 5e-2
