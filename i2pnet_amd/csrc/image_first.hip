@@ -548,7 +548,9 @@ extern "C" int i2p_img_first_fwd(int B, int H, int W, int stride, const float *x
     hipStream_t st = (hipStream_t)stream;
     const XView xv{x, sb, sc, sh, sw};
     const WView wv{wgt, ws[0], ws[1], ws[2], ws[3]};
-    if (sw != 1 || 3ll * H * W >= (1ll << 31)) return I2P_ERR_BAD_ARG;      // rows are read with vector loads / 32-bit offsets inside an image
+    // rows are read with vector loads and 32-bit BYTE offsets inside an image, formed from the caller's strides: the farthest byte
+    // the kernels address is (2 sc + (H + 1) sh + W) * 4 (a channel / row slice of a larger tensor can have large strides)
+    if (sw != 1 || sc < 0 || sh < 0 || 3ll * H * W >= (1ll << 31) || (2 * sc + (long long)(H + 1) * sh + W) * 4 >= (1ll << 31)) return I2P_ERR_BAD_ARG;
     if (parts & 1) {        // the statistics: Gram matrix of the input windows, then mean / invstd of the conv output and the running buffers
         const int ch = (H + GROWS - 1) / GROWS, sg = (W + GSEG - 1) / GSEG;
         static const int grid = env_int("I2P_IMG1_GRAM_GRID", 256);
@@ -586,6 +588,7 @@ extern "C" int i2p_img_first_bwd(int B, int H, int W, int stride, const float *x
         I2P_RETURN_LAUNCH_STATUS();
     }
     if (!x || !wgt || !ws || !gamma || !beta || !mean_invstd || !gram_red || !gout || !arg || !partials) return I2P_ERR_BAD_ARG;
+    if (sw != 1 || sc < 0 || sh < 0 || (2 * sc + (long long)(H + 1) * sh + W) * 4 >= (1ll << 31)) return I2P_ERR_BAD_ARG;      // (as in the forward entry)
     const XView xv{x, sb, sc, sh, sw};
     const WView wv{wgt, ws[0], ws[1], ws[2], ws[3]};
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;

@@ -179,7 +179,10 @@ def _linear_taps(n_out, n_in, clamp_weight, device):
 # torchvision's PIL path returns bit for bit (tests/test_data_pipeline.py compares against PIL where it is importable).
 def _cj_blend(deg, img, f):
     """PIL Image.blend(deg, img, f) on uint8: float32 arithmetic, clip to [0, 255], truncate"""
-    t = deg.float() + torch.as_tensor(f, dtype=torch.float32, device=img.device) * (img.float() - deg.float())
+    # (a Python scalar times a float32 tensor is computed in float32; a 0-d device tensor built from it would be a blocking
+    #  host-to-device copy per call)
+    import numpy as np
+    t = deg.float() + float(np.float32(f)) * (img.float() - deg.float())
     return torch.floor(t.clamp(0.0, 255.0)).to(torch.uint8)
 
 

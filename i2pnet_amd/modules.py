@@ -538,8 +538,11 @@ class _ImageCNN(nn.Sequential):
     def forward(self, x):
         mods = list(self)
         pre, self._first_stats = getattr(self, "_first_stats", None), None
+        # eval mode and the un-fused path run MIOpen's NHWC solvers like the fused path does (the model no longer converts rgb_img;
+        # the fused first block reads the NCHW image through its strides)
+        nhwc = lambda t: t.contiguous(memory_format=torch.channels_last) if (t.is_cuda and t.dim() == 4) else t
         if not self._fast(mods):
-            return super().forward(x)
+            return super().forward(nhwc(x))
         bns = [mods[i + 1] for i in range(0, len(mods), 4)]
         if USE_FUSED_IMG and x.dtype in (torch.float32, torch.bfloat16) and self._fusable(mods):
             with torch.no_grad():
@@ -609,6 +612,7 @@ class _ImageCNN(nn.Sequential):
             for i, b in zip(range(0, len(mods), 4), bns):
                 b.running_mean.add_(mods[i].bias, alpha=b.momentum / (1.0 - b.momentum))
             torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
+        x = nhwc(x)
         for i in range(0, len(mods), 4):
             conv, bn, act, pool = mods[i:i + 4]
             y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)

@@ -80,8 +80,12 @@ class FlatAdam:
             self.step_t.copy_(sd["step"]); self.lr_t.copy_(sd["lr"])
 
     @torch.no_grad()
-    def step(self):
+    def step(self, gate=None):
+        """`gate`: 0-d bool tensor or None; False leaves parameters, both moments and the step count untouched (a poisoned step,
+        see Trainer._update) without a host synchronisation"""
         g = self.grad
+        if gate is not None:
+            keep = (self.step_t.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.param.clone())
         self.step_t += 1.0
         if self.weight_decay != 0.0:
             g = g.add(self.param, alpha=self.weight_decay)
@@ -93,6 +97,9 @@ class FlatAdam:
         bc2_sqrt = (1.0 - torch.pow(self.beta2, self.step_t)).sqrt()
         denom = (self.exp_avg_sq.sqrt() / bc2_sqrt).add_(self.eps)
         self.param.sub_(self.exp_avg / denom * (self.lr_t / bc1))
+        if gate is not None:
+            for cur, old in zip((self.step_t, self.exp_avg, self.exp_avg_sq, self.param), keep):
+                cur.copy_(torch.where(gate, cur, old))
 
     @torch.no_grad()
     def fused_clip_step(self, clip, gscale=1.0, poison=None):
@@ -132,7 +139,10 @@ class Trainer:
         "fallback": log, switch the chains off (I2P_NO_CHAIN=1: the layer-by-layer kernels), re-capture and go on (single-process
         training only: with several ranks a rank-local re-capture would desynchronise the collectives, so it always raises).
         Either way the poisoned step is never applied: the error counter rides at the end of the flat gradient, through the
-        all-reduce, and a non-zero value turns clip + Adam into a no-op on every rank (i2p_clip_adam `poison`)."""
+        all-reduce, and a non-zero value turns clip + Adam into a no-op on every rank (i2p_clip_adam `poison`; the torch fallback of
+        `_update` gates its update the same way).  The word is the device's CUMULATIVE error counter: after one abandoned barrier every
+        later step is skipped until ops.chain_errors_reset(); check_chain_errors(sync=True) reads the all-reduced word, so every
+        rank raises, not only the faulty one."""
         torch.manual_seed(seed)                 # identical initial weights on every rank
         self.cfg, self.device, self.clip = cfg, torch.device(device), clip
         self.world_size = world_size
@@ -259,7 +269,10 @@ class Trainer:
         so far; sync=True also synchronises and reads the device counter (epoch_end, save_checkpoint)."""
         if self._chain_words is None:
             return
-        bad = ops.chain_error_flag(self.device) or (sync and ops.chain_errors(self.device) != 0)
+        # sync=True also reads the ALL-REDUCED poison word of the last step: with world_size > 1 only the faulty rank's host flag is
+        # set, the healthy ranks see the fault through the reduced gradient buffer and raise with it (instead of skipping steps
+        # silently and then hanging in the next all-reduce).  The counter is cumulative per device until chain_errors_reset().
+        bad = ops.chain_error_flag(self.device) or (sync and (ops.chain_errors(self.device) != 0 or float(self._poison[0]) != 0.0))
         if not bad:
             return
         torch.cuda.synchronize(self.device)
@@ -292,7 +305,8 @@ class Trainer:
         if self.clip > 0.0:                     # clip_grad_norm_ on the flat buffer (same total norm)
             total = torch.linalg.vector_norm(self.flat_grad)
             self.flat_grad.mul_(torch.clamp(self.clip / (total + 1e-6), max=1.0))
-        self.optimizer.step()
+        # (the un-fused path honours the poison word too: a step whose chain kernels abandoned a barrier is never applied)
+        self.optimizer.step(gate=(self._poison[0] == 0) if self._chain_words is not None else None)
 
     def _to_device(self, batch):
         """the tensors a step reads, on the trainer's device as fp32 (the reference moves each entry explicitly,
@@ -410,7 +424,27 @@ class Trainer:
         Adam moments / step count and the decayed learning rate are all restored.  The layout holds tensors and plain
         containers only, so the file is read with `weights_only=True`; `trust_pickle=True` opts into full unpickling for
         third-party files that carry other objects (arbitrary code execution: only for files you trust)."""
-        ckpt = torch.load(path, map_location="cpu", weights_only=not trust_pickle)
+        if trust_pickle:
+            ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        else:
+            # the reference trainer's ckpt.pt (train20v2learn_wandb_proj.py:255-268) also stores `training_params` (plain containers)
+            # and best_rotation_error / best_transition_error / best_acc, which are numpy float64 scalars: allow exactly those
+            # numpy reconstructors next to tensors and containers, nothing else
+            import numpy as np
+            allowed = [np.dtype, np.float64, np.float32, np.int64, np.ndarray]
+            for mod in ("numpy._core.multiarray", "numpy.core.multiarray"):
+                try:
+                    m = __import__(mod, fromlist=["scalar"])
+                    allowed += [m.scalar, m._reconstruct]
+                except (ImportError, AttributeError):
+                    pass
+            allowed += [type(np.dtype(np.float64)), type(np.dtype(np.float32)), type(np.dtype(np.int64))]
+            try:
+                with torch.serialization.safe_globals(allowed):
+                    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+            except Exception as e:     # (pickle.UnpicklingError and friends)
+                raise RuntimeError(f"{path}: not loadable with weights_only=True ({type(e).__name__}: {e}).  If the file is trusted and "
+                                   "carries other pickled objects, call load_checkpoint(path, trust_pickle=True).") from e
         sd = {k[7:] if k.startswith("module.") else k: v for k, v in ckpt["model_state_dict"].items()}
         with torch.no_grad():                       # parameters are views into the flat buffer: copy, never rebind
             self.net.load_state_dict(sd, strict=True)

@@ -1,3 +1,4 @@
+import pytest
 """Data-parallel step on CPU: 2 processes, gloo, oracle operators.  Checks what the RCCL path
 relies on: identical parameters on every rank after a step, and gradients equal to the mean of
 the per-rank gradients (flat-buffer all-reduce), with BN statistics local to a rank."""
@@ -144,5 +145,35 @@ def test_checkpoint_is_torch_adam_compatible(tmp_path, oracle_backend):
         assert torch.equal(tr2.flat_param, tr.flat_param)
         assert torch.equal(tr2.optimizer.exp_avg, tr.optimizer.exp_avg) and torch.equal(tr2.optimizer.exp_avg_sq, tr.optimizer.exp_avg_sq)
         assert float(tr2.optimizer.step_t) == 2.0 and abs(float(tr2.optimizer.lr_t) - 1e-3 * 0.99) < 1e-9
+        # a file shaped like the REFERENCE trainer's ckpt.pt (train20v2learn_wandb_proj.py:255-268): `training_params` and the
+        # best_* meters, which are numpy float64 scalars — loads under the default weights_only=True
+        import numpy as np
+        ck["training_params"] = {"dataset": "kitti", "max_t": 10.0, "val_sequence": [0]}
+        ck["best_rotation_error"] = np.float64(1.25); ck["best_transition_error"] = np.float64(0.5); ck["best_acc"] = np.float64(0.0)
+        torch.save(ck, tmp_path / "ref_like.pth")
+        tr3 = Trainer(cfg=cfg, device="cpu", seed=2)
+        assert tr3.load_checkpoint(tmp_path / "ref_like.pth") == 1 and torch.equal(tr3.flat_param, tr.flat_param)
+
+        class Evil:
+            def __reduce__(self):
+                return (print, ("pickle payload ran",))
+        ck["extra"] = Evil()
+        torch.save(ck, tmp_path / "evil.pth")
+        with pytest.raises(RuntimeError, match="trust_pickle"):
+            tr3.load_checkpoint(tmp_path / "evil.pth")
     finally:
         ops.set_backend(prev)
+
+
+def test_flat_adam_gate_skips_a_step():
+    """the torch fallback of Trainer._update gates its update by the poison word: gate False leaves everything untouched"""
+    import torch
+    from i2pnet_amd.train import FlatAdam
+    w, g = torch.randn(64), torch.randn(64)
+    opt = FlatAdam(w, g, 1e-2)
+    opt.step(gate=torch.tensor(True))
+    w1, m1, v1, t1 = w.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), float(opt.step_t)
+    opt.step(gate=torch.tensor(False))
+    assert torch.equal(w, w1) and torch.equal(opt.exp_avg, m1) and torch.equal(opt.exp_avg_sq, v1) and float(opt.step_t) == t1 == 1.0
+    opt.step(gate=torch.tensor(True))
+    assert not torch.equal(w, w1) and float(opt.step_t) == 2.0

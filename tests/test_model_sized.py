@@ -129,6 +129,7 @@ def _grad_norm_check(gold, model, grad_tol, rgb_tol, head_tol=HEAD_GRAD_TOL):
             m = k.split(".")[0]
             floor[m] = max(floor.get(m, 0.0), abs(gn[k] - g64[k]) / g64[k])
     worst, worst_key, checked = 0.0, None, 0
+    _grad_norm_check.head_worst = (0.0, None)
     _grad_norm_check.skipped = []           # tensors left out by the > 5 % floor rule (reported by the callers)
     for k, p in params.items():
         g = 0.0 if p.grad is None else float(p.grad.double().norm())
@@ -140,6 +141,8 @@ def _grad_norm_check(gold, model, grad_tol, rgb_tol, head_tol=HEAD_GRAD_TOL):
             _grad_norm_check.skipped.append(k)
             continue
         err = abs(g - g64[k]) / g64[k]
+        if k.startswith(("l3_head", "l4_head")):
+            _grad_norm_check.head_worst = max(getattr(_grad_norm_check, "head_worst", (0.0, None)), (err, k))
         tol_k = rgb_tol if k.startswith("RGB_net") else (max(grad_tol, head_tol) if k.startswith(("l3_head", "l4_head")) else grad_tol)
         score = err / max(4 * fl, tol_k)
         checked += 1
@@ -205,6 +208,7 @@ def _check_fp32(gold, model, acts, out3, out4, loss, tol, grad_tol, grad_tensor_
     # fp32 gradient of their module is > 5 % from its fp64 value, and how close the worst checked tensor comes to its limit
     print(f"[grad-norm check] checked {checked} tensors, skipped {len(skipped)} under the > 5 % reference-floor rule "
           f"(modules: {sorted({k.split('.')[0] for k in skipped})}), worst checked ratio to its limit {worst:.3f} at {worst_key}")
+    print(f"[grad-norm check] worst pose-head tensor: {_grad_norm_check.head_worst}")
     assert checked > 100
     if worst > 1.0:
         bad["grad_norm"] = worst_key
