@@ -142,7 +142,7 @@ def _mlp_chain_entry(B, device):
 
 
 PMC_JSON = ROOT / "profiles" / "r04_pmc_traffic.json"            # written by tools/pmc_r04.sh on the round's final kernels
-PMC_BF16_JSON = ROOT / "profiles" / "r04_pmc_bf16_traffic.json"
+PMC_BF16_JSON = ROOT / "profiles" / "r05_pmc_bf16_traffic.json"   # {kernel: {"bytes_per_row": ...}}, tools/pmc_bf16_json.py
 
 
 def _pmc_traffic(kernel, B):
@@ -165,9 +165,11 @@ class Cv1Chain:
 
     N, M, C = 228, 468, 128
 
-    def __init__(self, B, device, seed=0):
+    def __init__(self, B, device, seed=0, N=None):
         from i2pnet_amd import modules
         from i2pnet_amd.config import I2PNetConfig as cfg
+        if N is not None:
+            self.N = N
         from i2pnet_amd.model import RegNet_v2
         torch.manual_seed(seed)
         self.B, self.device = B, device
@@ -224,17 +226,17 @@ CV1_GFLOP_PER_SAMPLE_FWD = 15.1
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (never the 2:1-sparsity figure)
 
 
-def chain_roofline(B, device, bf16=False):
+def chain_roofline(B, device, bf16=False, N=228):
     """cv1 forward and backward wall time (events around the fused node) against SURVEY.md §8(d)'s denominators:
     0.437 GB and 15.1 GFLOP per sample and forward; the backward does twice the flops (dgrad + wgrad of every layer) and, BN-exact
     and without recomputation, reads each of the six pre-BN tensors and its gradient once and writes each gradient once
     (3 x 512 channels x 4 B per pair = 0.655 GB per sample).  bf16=True (the caller has ops.set_precision("bf16") active): the same
     node in bf16 storage — half the bytes (0.2185 GB per sample), the same flops on the bf16 MFMA roof: the HBM-bound regime the
     north star's ">= 40 % of HBM on the fused grouping + cost-volume kernel" speaks about (VERDICT r3 missing #2)."""
-    ch = Cv1Chain(B, device)
+    ch = Cv1Chain(B, device, N=N)
     t_f, t_b = ch.time_us()
-    gb = CV1_GB_PER_SAMPLE_FWD * (0.5 if bf16 else 1.0)
-    fwd_b, fwd_f = gb * 1e9 * B, CV1_GFLOP_PER_SAMPLE_FWD * 1e9 * B
+    gb = CV1_GB_PER_SAMPLE_FWD * (0.5 if bf16 else 1.0) * (N / 228.0)       # (per-sample figures of SURVEY 8(d) are for 228 points)
+    fwd_b, fwd_f = gb * 1e9 * B, CV1_GFLOP_PER_SAMPLE_FWD * 1e9 * B * (N / 228.0)
     bwd_b, bwd_f = 1.5 * fwd_b, 2.0 * fwd_f
     mfma_peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
     return {"node": "cost_volume1 pi-stage (_CvPiTail): pair layer, 128->64, 64->64, position encoding, 64+64->128, 128->64, softmax-weighted sum; "
@@ -297,6 +299,23 @@ def _image_encoder_entry(B, device):
                 "bytes_per_tensor": tb, "replaces": "MIOpen igemm: 101 us forward (+ 17 statistics), 79 + 18 zero-fill input gradient, 130 + 5 weight gradient"}}
 
 
+def _kernel_only_us(fn, iters):
+    """average duration of the headline kernel inside `fn()` — bracketed by the library's own events (i2p_ktime_*), see common.h"""
+    from i2pnet_amd import _lib
+    _lib.helper("i2p_ktime_enable", 1)
+    try:
+        tot = 0.0
+        for _ in range(iters):
+            fn()
+            t = float(_lib.helper("i2p_ktime_last_us"))
+            if t < 0:
+                return float("nan")
+            tot += t
+        return tot / iters
+    finally:
+        _lib.helper("i2p_ktime_enable", 0)
+
+
 def kernel_rooflines(B, device):
     """Live timings (events on the launch stream) of hand-written kernels AS THE fp32 STEP RUNS THEM: every kernel named here
     is an instantiation that appears in the step's rocprofv3 table (profiles/r03_*_steady_kernel_stats.csv) on the same shapes.
@@ -346,7 +365,10 @@ def kernel_rooflines(B, device):
     gz = rnd(rows, CO)
     ods = torch.zeros(ops.BN_REPLICAS * 2 * CO, dtype=torch.float64, device=device)
     _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), 40)
-    t_bwd = _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), 20)
+    t_entry = _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), 20)
+    # the kernel ALONE: events recorded by the launcher around wreg_bwd_fused_kernel itself (i2p_ktime_*), not around the entry's
+    # coefficient and slab-reduction launches — the figure the rocprofv3 table's per-size row can be compared with directly
+    t_bwd = _kernel_only_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), 20)
     dg_bytes = rows * (2 * CO + 2 * CI) * 4 + CI * CO * 4
     dgrad = {"kernel": "wreg_bwd_fused_kernel<64,128> (cost-volume 128->64 layer backward in ONE pass, 2 launches per step at this size: input "
                        "gradient + weight gradient from a single read of gz, y, x; W and the dW accumulators stationary in registers, BN backward "
@@ -356,8 +378,10 @@ def kernel_rooflines(B, device):
              "frac": round(dg_bytes / t_bwd / 1e3 / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("wreg_bwd_fused_kernel<64, 128>", B),
              "avg_kernel_us": round(t_bwd, 1), "bytes_per_launch_algorithmic": dg_bytes,
              "mfma_TFLOPs": round(2 * flop / t_bwd / 1e6, 1), "mfma_frac": round(2 * flop / t_bwd / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
-             "timed_as": "i2p_lin_bwd = the fused kernel + the 256-slab reduction of dW (~5 us, included: the figure is a lower bound of the "
-                         "kernel's own rate; its duration alone is in profiles/r04_*_steady_kernel_stats.csv), events on the launch stream",
+             "entry_us (kernel + BN-coefficient launch + 256-slab reduction of dW)": round(t_entry, 1),
+             "timed_as": "the kernel alone: HIP events recorded by its launcher on the launch stream directly before and after "
+                         "wreg_bwd_fused_kernel (i2p_ktime_enable / i2p_ktime_last_us), average of 20 launches with warm clocks; "
+                         "compare with the (kernel, blocks = 256, 853632-row) row of profiles/r05_*_steady_kernel_stats.csv",
              "replaces": "wreg_dgrad_kernel<64,128,false> + wreg_wgrad_kernel<64,128,true,false> (two reads of the same tensors: 430 us)"}
     del x, y, gz
     # --- two-source forward (position encoding 64 + mlp1 output 64 -> 128), 1 launch per step ------------------------
@@ -438,72 +462,115 @@ def kernel_rooflines(B, device):
     return dgrad
 
 
-def kernel_rooflines_bf16(B, device):
-    """configs[2] / configs[4]: live timings of the bf16-storage cost-volume kernels.  HBM-bound: a 128->128 layer reads
-    rows*128 bf16 and writes rows*128 bf16 (+ 64 KB of fp32 weights) = the BN-exact no-recompute traffic of SURVEY.md
-    §8d for one layer, halved by bf16 storage; the contraction (2*rows*128*128 flop on v_mfma_f32_32x32x16_bf16) is
-    ~1/5 of the bf16 MFMA roof at that rate.  `traffic`: PMC bytes from profiles/r04_pmc_bf16_traffic.json (tools/pmc_r04.sh).
-    `chain`: the whole cost_volume1 pi-stage node in bf16 storage against SURVEY 8(d)'s bytes halved (0.2185 GB per sample)."""
+def kernel_rooflines_bf16(B, device, N=228):
+    """configs[2] / configs[4]: live timings of the bf16-storage cost-volume kernels on the step's own tensors
+    (rows = B x N x 468; N = 228 level-3 points for KITTI, 171 for nuScenes).  All HBM-bound (the bf16 MFMA roof is ~300 flop/B).
+
+    * `roofline`: bwd_fused_bf16_kernel<128> — the backward of a 128->64 layer of the all-pixel cost volume (mlp1[1] and mlp2[1] of
+      cost_volume1: two launches per step, the largest per-step time among the hand-written kernels in
+      profiles/r05_bf16_c2_steady_kernel_stats.csv) in ONE pass (csrc/mlp_bwd_fused_bf16.hip): gz, y [rows,64] and x [rows,128] read
+      once, dL/dz_in [rows,128] written once = rows*(2*64+2*128)*2 B.  Timed as the kernel alone (i2p_ktime_*: events recorded by the
+      launcher around the kernel).  `traffic`: PMC bytes per launch from profiles/r05_pmc_bf16_traffic.json (tools/pmc_kernels.sh).
+    * other_kernels: the 64->64 one-pass backward, the two-source 64+64->128 one-pass backward, the pair-layer backward (second
+      generation) and forward, the 128->128 / 128->64 layer forwards.
+    * chain: the whole cost_volume1 pi-stage node in bf16 storage against SURVEY 8(d)'s bytes halved (0.2185 GB per sample)."""
     from i2pnet_amd import _lib, ops
     hip = ops.hip_backend()
-    N, M, C = 228, 468, 128
+    M, C = 468, 128
     rows = B * N * M
     g = torch.Generator(device=device).manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g, device=device)
     bf = torch.bfloat16
-    x = rnd(rows, C).to(bf); w = rnd(C, C) / C ** 0.5
-    gam = torch.ones(C, device=device); bet = torch.zeros(C, device=device)
-    y0, s0 = hip.lin_forward(x, None, 1.0, w, out_dtype=bf)
-    in_coef, in_mi = hip.bn_finalize(rows, s0, gam, bet, 1e-5)
-    x = y0                                                    # a genuine pre-BN tensor with its own statistics
-    y = torch.empty(rows, C, dtype=bf, device=device)
-    sy = torch.zeros(ops.BN_REPLICAS * 2 * C, dtype=torch.float64, device=device)
-    st = torch.cuda.current_stream().cuda_stream
-    _event_time_us(lambda: _lib.call("i2p_lin_fwd_bf16", rows, C, C, x.data_ptr(), 1, in_coef.data_ptr(), 0.1, w.data_ptr(),
-                                     y.data_ptr(), sy.data_ptr(), stream=st), 150)      # (clocks ramp for ~50 ms after idle)
-    t_fwd = _event_time_us(lambda: _lib.call("i2p_lin_fwd_bf16", rows, C, C, x.data_ptr(), 1, in_coef.data_ptr(), 0.1, w.data_ptr(),
-                                             y.data_ptr(), sy.data_ptr(), stream=st), 25)
-    alg_bytes = rows * C * 2 * 2 + C * C * 4
-    flop = 2.0 * rows * C * C
-    traffic = None
-    pmc = PMC_BF16_JSON
-    if pmc.exists():
-        rec = json.loads(pmc.read_text())
-        traffic = round(rec["bytes_per_launch_at_B8"] * rows / (8 * N * M))
-    fwd = {"kernel": "rg_fwd_kernel<4,true,false> (cost-volume 128->128 layer forward, bf16 storage: BN+act on load, "
-                     "v_mfma_f32_32x32x16_bf16, fp64 BN statistics of the rounded output)",
-           "bound": "hbm", "achieved": round(alg_bytes / t_fwd / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(alg_bytes / t_fwd / 1e3 / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_kernel_us": round(t_fwd, 1),
-           "bytes_per_launch_algorithmic": alg_bytes, "mfma_TFLOPs": round(flop / t_fwd / 1e6, 1)}
-    sy.zero_()
-    _lib.call("i2p_lin_fwd_bf16", rows, C, C, x.data_ptr(), 1, in_coef.data_ptr(), 0.1, w.data_ptr(), y.data_ptr(), sy.data_ptr(), stream=st)
-    out_coef, out_mi = hip.bn_finalize(rows, sy, gam, bet, 1e-5)
-    gz = (rnd(rows, C) * 0.1).to(bf)
-    ods = hip.bn_act_backward_stats_bf16(gz, y, out_coef, out_mi, 1.0)
-    t_bwd = _event_time_us(lambda: hip.lin_backward(gz, y, out_coef, out_mi, ods, x, in_coef, in_mi, 0.1, w), 10)
-    bwd_bytes = rows * C * 2 * (3 + 1) + rows * C * 2 * 3          # dgrad: gz, y, x in + gz_in out; wgrad: gz, y, x in
-    bwd = {"kernel": "rg_dgrad_kernel<4,false> + wreg_wgrad_bf16_kernel + reduce (backward of the same layer; the wgrad keeps its accumulators in registers and packs row pairs into the MFMA operands without LDS)", "bound": "hbm",
-           "achieved": round(bwd_bytes / t_bwd / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(bwd_bytes / t_bwd / 1e3 / HBM_PEAK_GBS, 4), "avg_us": round(t_bwd, 1), "bytes_per_call_algorithmic": bwd_bytes}
-    del gz
+    gam = lambda c: torch.ones(c, device=device)
+    bet = lambda c: torch.zeros(c, device=device)
+    pmc = json.loads(PMC_BF16_JSON.read_text()) if PMC_BF16_JSON.exists() else {}
+
+    def traffic_of(name):
+        rec = pmc.get(name)
+        return round(rec["bytes_per_row"] * rows) if rec else None
+
+    def entry(kernel, nbytes, t, **extra):
+        d = {"kernel": kernel, "bound": "hbm", "achieved": round(nbytes / t / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(nbytes / t / 1e3 / HBM_PEAK_GBS, 4), "avg_kernel_us": round(t, 1), "bytes_per_launch_algorithmic": nbytes}
+        d.update(extra)
+        return d
+
+    def layer(cin, cout):
+        """a genuine pre-BN bf16 tensor x with its statistics, the layer's output y, its BN, a gradient and its statistics"""
+        x0 = rnd(rows, cin).to(bf)
+        w0 = rnd(cin, cin) / cin ** 0.5
+        x, s0 = hip.lin_forward(x0, None, 1.0, w0, out_dtype=bf)
+        del x0
+        in_coef, in_mi = hip.bn_finalize(rows, s0, gam(cin), bet(cin), 1e-5)
+        w = rnd(cout, cin) / cin ** 0.5
+        y, sy = hip.lin_forward(x, in_coef, 0.1, w, out_dtype=bf)
+        out_coef, out_mi = hip.bn_finalize(rows, sy, gam(cout), bet(cout), 1e-5)
+        gz = (rnd(rows, cout) * 0.1).to(bf)
+        ods = hip.bn_act_backward_stats_bf16(gz, y, out_coef, out_mi, 1.0)
+        return x, in_coef, in_mi, w, y, out_coef, out_mi, gz, ods
+
+    # ---- headline: 128 -> 64 one-pass backward --------------------------------------------------------------------------------
+    x, ic, im, w, y, oc, om, gz, ods = layer(128, 64)
+    run = lambda: hip.lin_backward(gz, y, oc, om, ods, x, ic, im, 0.1, w)
+    _event_time_us(run, 150)                                        # (clocks ramp for ~50 ms after idle)
+    t_entry = _event_time_us(run, 20)
+    t_k = _kernel_only_us(run, 20)
+    nb = rows * (2 * 64 + 2 * 128) * 2
+    head = entry("bwd_fused_bf16_kernel<128> (cost-volume 128->64 layer backward in ONE pass, 2 launches per step: input gradient + "
+                 "weight gradient from a single read of gz, y, x; 32-row strips staged twice through wave-private LDS images — row-major "
+                 "for the input gradient, transposed for the weight gradient —, v_mfma_f32_32x32x16_bf16, BN backward on load, activation "
+                 "derivative + BN-backward statistics in the store phase)", nb, t_k,
+                 traffic=traffic_of("bwd_fused_bf16_kernel<128>"),
+                 **{"entry_us (kernel + BN-coefficient launch + 256-slab reduction of dW)": round(t_entry, 1),
+                    "timed_as": "the kernel alone: HIP events recorded by its launcher directly around bwd_fused_bf16_kernel "
+                                "(i2p_ktime_enable / i2p_ktime_last_us), average of 20 launches with warm clocks",
+                    "replaces": "rg_dgrad_kernel<4> + wreg_wgrad_bf16_kernel<64,128> (two reads of the same tensors: 551 us at batch 16)"})
+    t_f = _event_time_us(lambda: hip.lin_forward(x, ic, 0.1, w, out_dtype=bf), 20)
+    others = [entry("rg_fwd_kernel<2,true,false> (128->64 layer forward, 2 launches per step)", rows * (128 + 64) * 2, t_f)]
+    del x, y, gz
+    x, ic, im, w, y, oc, om, gz, ods = layer(64, 64)
+    run = lambda: hip.lin_backward(gz, y, oc, om, ods, x, ic, im, 0.1, w)
+    _event_time_us(run, 20)
+    others.append(entry("bwd_fused_bf16_kernel<64> (64->64 layer backward in one pass, 1 launch per step)", rows * 4 * 64 * 2, _kernel_only_us(run, 20),
+                        traffic=traffic_of("bwd_fused_bf16_kernel<64>")))
+    del x, y, gz
+    # ---- two-source 64 + 64 -> 128 ---------------------------------------------------------------------------------------------
+    w64 = rnd(64, 64) / 8.0
+    xa, sa = hip.lin_forward(rnd(rows, 64).to(bf), None, 1.0, w64, out_dtype=bf)
+    xb, sb = hip.lin_forward(rnd(rows, 64).to(bf), None, 1.0, w64, out_dtype=bf)
+    ca, ma = hip.bn_finalize(rows, sa, gam(64), bet(64), 1e-5)
+    cb, mb = hip.bn_finalize(rows, sb, gam(64), bet(64), 1e-5)
+    w2 = rnd(128, 128) / 128 ** 0.5
+    y2, s2 = hip.lin_forward_2src(xa, ca, 0.1, xb, cb, 0.1, w2)
+    t_2f = _event_time_us(lambda: hip.lin_forward_2src(xa, ca, 0.1, xb, cb, 0.1, w2), 20)
+    others.append(entry("rg_fwd_kernel<4,true,false> (64+64->128 two-source layer forward, 1 launch per step)", rows * 256 * 2, t_2f))
+    oc2, om2 = hip.bn_finalize(rows, s2, gam(128), bet(128), 1e-5)
+    gz2 = (rnd(rows, 128) * 0.1).to(bf); ea = (rnd(rows, 64) * 0.1).to(bf)
+    ods2 = hip.bn_act_backward_stats_bf16(gz2, y2, oc2, om2, 1.0)
+    run2 = lambda: hip.lin_backward_2src(gz2, y2, oc2, om2, ods2, xa, ca, ma, 0.1, xb, cb, mb, 0.1, ea, w2)
+    _event_time_us(run2, 20)
+    others.append(entry("bwd_fused2_bf16_kernel (64+64->128 backward in one pass: dW in all 256 accumulator registers, input gradient on "
+                        "v_mfma_f32_16x16x32_bf16; + coefficient and reduction launches)", rows * (2 * 128 + 3 * 64 + 128) * 2, _event_time_us(run2, 20),
+                        traffic=traffic_of("bwd_fused2_bf16_kernel")))
+    del xa, xb, y2, gz2, ea
+    # ---- pair layer --------------------------------------------------------------------------------------------------------------
+    w = rnd(C, C) / C ** 0.5
     f = rnd(B, N, C); gk = rnd(B, M, C); bn = rnd(B, N, C); bk = rnd(B, M, C)
     t_pf = _event_time_us(lambda: hip.pair_lin_forward(f, gk, bn, bk, w, out_dtype=bf), 10)
-    pf = {"kernel": "rg_fwd_kernel<4,pair> (first cost-volume layer forward: product formed on load, output bf16)", "bound": "hbm",
-          "achieved": round(rows * C * 2 / t_pf / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-          "frac": round(rows * C * 2 / t_pf / 1e3 / HBM_PEAK_GBS, 4), "avg_kernel_us": round(t_pf, 1)}
+    others.append(entry("pair_fwd_ps_kernel (first cost-volume layer forward: pixel tile stationary, output bf16)", rows * C * 2, t_pf))
     y1, s1 = hip.pair_lin_forward(f, gk, bn, bk, w, out_dtype=bf)
-    c1, m1 = hip.bn_finalize(rows, s1, gam, bet, 1e-5)
+    c1, m1 = hip.bn_finalize(rows, s1, gam(C), bet(C), 1e-5)
     gz1 = (rnd(rows, C) * 0.1).to(bf)
     ds1 = hip.bn_act_backward_stats_bf16(gz1, y1, c1, m1, 1.0)
-    t_pb = _event_time_us(lambda: hip.pair_lin_backward(gz1, f, gk, w, y=y1, out_coef=c1, out_mi=m1, out_dsums=ds1), 10)
-    pb = {"kernel": "pair_bwd_bf16_kernel (first cost-volume layer backward)", "bound": "hbm",
-          "achieved": round(rows * C * 2 * 2 / t_pb / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-          "frac": round(rows * C * 2 * 2 / t_pb / 1e3 / HBM_PEAK_GBS, 4), "avg_us": round(t_pb, 1)}
-    fwd["other_kernels"] = [bwd, pf, pb]
-    del x, y, y0, y1, gz1, f, gk, bn, bk
+    runp = lambda: hip.pair_lin_backward(gz1, f, gk, w, y=y1, out_coef=c1, out_mi=m1, out_dsums=ds1)
+    _event_time_us(runp, 10)
+    others.append(entry("pair_bwd2_bf16_kernel (first cost-volume layer backward, second generation; + coefficient and reduction launches)",
+                        rows * C * 2 * 2, _event_time_us(runp, 10), traffic=traffic_of("pair_bwd2_bf16_kernel")))
+    head["other_kernels"] = others
+    del y1, gz1, f, gk, bn, bk
     torch.cuda.empty_cache()
-    fwd["chain"] = chain_roofline(B, device, bf16=True)
-    return fwd
+    head["chain"] = chain_roofline(B, device, bf16=True, N=N)
+    return head
 
 
 def _oracle_op_times():
@@ -663,6 +730,9 @@ def main():
                     help="after the default (--config 1) line also measure configs[2] and configs[4] in the same process and report "
                          "them under `other_configs` (1 = at N=1 only, 2 = at any N, 0 = never)")
     ap.add_argument("--graph", type=int, default=1, help="capture the step in hipGraphs (0 = eager)")
+    ap.add_argument("--no-dp-proxy", action="store_true", help="skip the two-graph + 1-rank all-reduce proxy measurement")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to host-core groups")
+    ap.add_argument("--no-finddb-warmup", action="store_true", help="every rank runs MIOpen's find itself")
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:
@@ -680,7 +750,7 @@ def main():
 
     process_setup()
     _, lr0, w0 = dist_env()
-    pinned = _pin_cores(lr0, w0)            # before any helper thread exists (RCCL watchdog / proxy, MIOpen find, OpenMP pool inherit it)
+    pinned = None if args.no_pin else _pin_cores(lr0, w0)            # before any helper thread exists (RCCL watchdog / proxy, MIOpen find, OpenMP pool inherit it)
     rank, local_rank, world = init_distributed("nccl")
     if world != args.gpus:
         print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr, flush=True)
@@ -710,9 +780,9 @@ def main():
             "block 1 (3->16, conv + BN + LeakyReLU + pool)": "csrc/image_first.hip" if hip_first else "MIOpen + csrc/image_block.hip",
             "blocks 2-5 convolutions (16->16 x3, 16->32; fp32 tier)": "csrc/image_conv16.hip" if hip_conv else "MIOpen",
             "blocks 6-15 convolutions": "MIOpen", "BN + LeakyReLU + MaxPool tails": "csrc/image_block.hip",
-            "switches": {k: os.environ[k] for k in ("I2P_NO_IMG_FIRST", "I2P_NO_CONV16", "I2P_NO_CONV32", "I2P_CONV16_MIOPEN_WGRAD") if k in os.environ}}
+            "switches": {k: os.environ[k] for k in ("I2P_NO_IMG_FIRST", "I2P_NO_CONV16", "I2P_NO_CONV32", "I2P_NO_TAIL_BWD") if k in os.environ}}
         prev = ops.set_precision("bf16" if bf16 else "fp32")
-        line["roofline"] = (kernel_rooflines_bf16 if bf16 else kernel_rooflines)(args.batch, device)
+        line["roofline"] = kernel_rooflines_bf16(args.batch, device, N=171 if args.config == 4 else 228) if bf16 else kernel_rooflines(args.batch, device)
         ops.set_precision(prev)
     # the bf16 workloads (configs[2], configs[4]) in the same process after the default line, so that the driver's record
     # carries them too (N = 1 only: the scaling runs stay short)
@@ -725,10 +795,10 @@ def main():
             if rank == 0:
                 l2 = _json_line(r2, a2, world)
                 prev = ops.set_precision("bf16")
-                l2["roofline"] = kernel_rooflines_bf16(a2.batch, device)
+                l2["roofline"] = kernel_rooflines_bf16(a2.batch, device, N=171 if c == 4 else 228)
                 ops.set_precision(prev)
                 others.append(l2)
-    if rank == 0 and world == 1 and not os.environ.get("I2P_NO_DP_PROXY") and not dist.is_initialized():
+    if rank == 0 and world == 1 and not args.no_dp_proxy and not dist.is_initialized():
         # what ONE GPU can say about N > 1: the data-parallel step structure — graph A, RCCL all-reduce of the flat
         # gradient, graph B — with a 1-rank group, against the single-graph step measured above
         line["dp_proxy"] = dp_proxy(args, device, line["ms_per_step"])
@@ -761,7 +831,7 @@ def _pin_cores(local_rank, world):
     """One contiguous group of host cores per rank: the rank's launch thread, the RCCL proxy / watchdog
     threads and MIOpen's find threads stay off the other ranks' cores.  Groups are cut from the cores this process may
     run on (cgroup-aware); with one rank nothing is changed.  Returns the number of cores of the group (None = not pinned)."""
-    if world <= 1 or os.environ.get("I2P_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+    if world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
     try:
         cores = sorted(os.sched_getaffinity(0))
@@ -863,8 +933,8 @@ def dp_proxy(args, device, single_graph_ms):
 
 def _find_db_warmup(cfg, args, config, rank, device):
     """rank 0 runs one eager forward+backward of the image encoder's shapes (MIOpen exhaustive find -> user find-db on
-    disk), the others wait at a barrier and then find the records.  Skipped when I2P_NO_FINDDB_WARMUP=1."""
-    if os.environ.get("I2P_NO_FINDDB_WARMUP") == "1":
+    disk), the others wait at a barrier and then find the records.  Skipped with --no-finddb-warmup."""
+    if args.no_finddb_warmup:
         return
     if rank == 0:
         from i2pnet_amd.model import RegNet_v2

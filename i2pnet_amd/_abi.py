@@ -87,19 +87,15 @@ DEVICE_ONLY = {
     "i2p_pose_compose_fwd": ["i", "p", "p", "p", "p", "p"],
     "i2p_pose_compose_bwd": ["i"] + ["p"] * 8,
     "i2p_clip_adam": ["l"] + ["p"] * 8 + ["d", "d"] + ["f"] * 4 + ["p", "p"],
-    "i2p_img_bn_stats_fin": ["i", "i", "i", "i", "p", "p", "p", "f", "f", "p", "p", "p", "p"],
-    "i2p_img_bn_pool_bwd_fin": ["i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "f", "p", "p", "p", "p", "p"],
     "i2p_img_block_fwd": ["i"] * 7 + ["p", "p", "p", "p", "f", "f", "f"] + ["p"] * 6,
     "i2p_img_block_bwd": ["i"] * 7 + ["p"] * 6 + ["f"] + ["p"] * 4,
     "i2p_img_block_pool": ["i"] * 7 + ["p", "p", "p", "p", "f", "f", "f"] + ["p"] * 6,
     "i2p_img_conv_fwd": ["i"] * 6 + ["p", "p", "p", "p", "p"],
     "i2p_img_conv_bwd_data": ["i"] * 6 + ["p", "p", "p", "p"],
     "i2p_img_conv_wgrad": ["i"] * 6 + ["p", "p", "p", "p", "p"],
-    "i2p_img_conv_bwd_data_stats": ["i"] * 5 + ["p"] * 9 + ["f", "p"],
     "i2p_img_block_bwd_dx": ["i"] * 7 + ["p"] * 6 + ["f"] + ["p"] * 4,
     "i2p_img_block_bwd_stats": ["i"] * 7 + ["p"] * 6 + ["f", "p"],
     "i2p_img_conv_tail_bwd": ["i"] * 3 + ["p"] * 6 + ["f"] + ["p"] * 7,
-    "i2p_img_conv_pool_fwd": ["i"] * 4 + ["p"] * 4 + ["f", "f", "f"] + ["p"] * 10,
     "i2p_img_first_fwd": ["i"] * 4 + ["p"] + ["l"] * 4 + ["p", "p", "p", "p", "f", "f", "f"] + ["p"] * 5 + ["i", "p", "p", "p", "i"],
     "i2p_img_first_bwd": ["i"] * 4 + ["p"] + ["l"] * 4 + ["p", "p", "p", "p", "f", "p", "p", "i"] + ["p"] * 6,
     "i2p_pc_rows_fwd": ["i"] * 6 + ["p"] * 8,
@@ -115,7 +111,6 @@ DEVICE_ONLY = {
     "i2p_mask_fill": ["l", "i", "p", "p", "f", "p"],
     "i2p_pad_cols": ["i", "i", "i", "p", "p"],
     "i2p_strided_pick2": ["i"] * 7 + ["p"] * 4,
-    "i2p_lin_bwd_part": ["l", "i", "i"] + ["p"] * 8 + ["f"] + ["p"] * 5 + ["f", "i", "p"],
 }
 # plain `int f(...)` helpers without a stream argument
 HELPERS = {
@@ -125,7 +120,6 @@ HELPERS = {
     "i2p_pair_bias_bn_bwd_scratch": ["i", "i", "i", "i"],           # returns long long
     "i2p_gather_rows_grad_fx_scratch": ["i", "i", "i"],             # returns long long (bytes)
     "i2p_gemm_tn_scratch": ["l", "i", "i"],                         # returns long long (bytes)
-    "i2p_lin_bwd_splittable": ["l", "i", "i", "i"],
     "i2p_chain_fwd_ok": ["l", "i", "p", "i"],
     "i2p_chain_bwd_ok": ["l", "i", "p", "i"],
     "i2p_chain_bwd_slab": ["i", "p", "p"],                          # returns long long (floats)
@@ -135,8 +129,12 @@ HELPERS = {
     "i2p_img_conv_wgrad_rows": ["i", "i", "i"],
     "i2p_chain_resident_blocks": ["i", "l"],
     "i2p_chain_sync_words": [],                                     # returns long long (uint32 words)
+    "i2p_ktime_enable": ["i"],
+    "i2p_ktime_last_us": [],                                        # returns float (microseconds)
 }
 LONG_HELPERS = {"i2p_pair_lin_bwd_scratch", "i2p_pair_bias_bn_bwd_scratch", "i2p_gather_rows_grad_fx_scratch", "i2p_gemm_tn_scratch", "i2p_chain_sums_len", "i2p_chain_sync_words", "i2p_chain_bwd_slab"}
+
+FLOAT_HELPERS = {"i2p_ktime_last_us"}
 
 _CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "d": C.c_double, "p": C.c_void_p, "pp": C.c_void_p}
 
@@ -146,7 +144,7 @@ def bind(lib, name, symbol, with_stream):
     fn = getattr(lib, symbol)
     kinds = SIGNATURES.get(name) or DEVICE_ONLY.get(name) or HELPERS[name]
     fn.argtypes = [_CT[k] for k in kinds] + ([C.c_void_p] if with_stream else [])
-    fn.restype = C.c_longlong if name in LONG_HELPERS else C.c_int
+    fn.restype = C.c_longlong if name in LONG_HELPERS else (C.c_float if name in FLOAT_HELPERS else C.c_int)
     return fn
 
 

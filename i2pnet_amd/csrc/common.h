@@ -155,3 +155,10 @@ int i2p_bwd_fused2_bf16(long long rows, const unsigned short *gz, const unsigned
                         const float *coef_a, const float *mi_a, float slope_a, const unsigned short *xb, const float *coef_b,
                         const float *mi_b, float slope_b, const unsigned short *e_add, const float *w, unsigned short *gz_a,
                         double *sums_a, unsigned short *gz_b, double *sums_b, float *dw_partial, unsigned grid, void *stream);
+
+// Kernel-only timing for bench.py's roofline object: when enabled, the launchers of the headline kernels bracket
+// THE KERNEL (not the entry's coefficient / reduction launches) with two HIP events on the launch stream; i2p_ktime_last_us()
+// synchronises on the closing event and returns the duration of the last bracketed launch.  Off by default (no events recorded);
+// not usable inside a stream capture.  Defined in csrc/optim.hip.
+void i2p_ktime_begin(hipStream_t st);
+void i2p_ktime_end(hipStream_t st);

@@ -57,17 +57,10 @@ template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
 // Work = the B x strips x H output rows of all strips in (image, strip, row) order, cut into equal contiguous ranges, one per wave of
 // a grid that is resident at once (4 waves per SIMD): every SIMD runs the same number of MFMAs.  A range that crosses a strip
 // boundary is walked as two segments.
-// MODE 2 (input gradient only): what this kernel writes is dL/d(pooled output) of the block IN FRONT (16 channels, MaxPool stride 1).
-// Its BatchNorm-backward sums — sum gz and sum gz * xhat over the pooled elements, gz = g * act'(bn(y at the arg-max)) — are taken
-// here, from the registers that hold g: one arg-max word and four gathered y values per lane and row, in flight under the MFMAs.
-// `sums` then receives them in the [REP][2 C] layout i2p_img_block_bwd_dx reads, and that block's statistics pass disappears.
-struct PrevBlock { const unsigned char *arg; const float *y, *mean_invstd, *gamma, *beta; float slope; };
-
 template <int CIN, int COUT, int MODE>
 __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restrict__ x, int B, int H, int W, int strips_w, WView16 wgt,
-                                                          float *__restrict__ y, double *__restrict__ sums, PrevBlock pv) {
+                                                          float *__restrict__ y, double *__restrict__ sums) {
     constexpr bool STATS = MODE != 0;
-    static_assert(MODE != 2 || COUT == 16, "the block in front has 16 channels");
     constexpr int NPW = 14;                                           // output columns per strip
     constexpr int NQ = CIN / 16, NT = COUT / 16, KS = 9 * 4 * NQ;     // 16-channel groups of the input / output, MFMA steps per tile
     struct Row { float q[NQ][4]; };
@@ -94,14 +87,6 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int c = 0; c < 4; ++c) { s[nt][c] = 0.f; q2[nt][c] = 0.f; }
-    float pmean[4], pinv[4], pscale[4], pbeta[4];
-    if constexpr (MODE == 2) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int ch = 4 * kq + c;
-            pmean[c] = pv.mean_invstd[ch]; pinv[c] = pv.mean_invstd[COUT + ch]; pscale[c] = pinv[c] * pv.gamma[ch]; pbeta[c] = pv.beta[ch];
-        }
-    }
     while (pos < end) {
         const long long bs = pos / H;
         const int r0 = (int)(pos - bs * H), r1 = (int)min((long long)H, r0 + (end - pos));
@@ -127,25 +112,8 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
         const bool owns = j >= 1 && j <= 14 && oc < W;
         Row R0 = load_x(r0 - 1), R1 = load_x(r0), R2 = load_x(r0 + 1), Rn = load_x(r0 + 2), Rnn;
         float *yb = y + (long long)b * img_px * COUT;
-        // MODE 2: the arg-max word of this lane's 4 channels at (r, oc), one row ahead; the pooled tensor has the output's geometry
-        const unsigned *argw = reinterpret_cast<const unsigned *>(pv.arg) + (long long)b * img_px * (COUT / 4);
-        const float *py = pv.y + (long long)b * img_px * COUT;
-        unsigned aw_next = 0u;
-        if constexpr (MODE == 2) aw_next = owns ? argw[((long long)r0 * W + oc) * (COUT / 4) + kq] : 0u;
         for (int r = r0; r < r1; ++r) {
             Rnn = load_x(r + 3);
-            float yv[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (MODE == 2) {
-                const unsigned aw = aw_next;
-                if (owns) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int av = (int)((aw >> (8 * c)) & 0xffu), ah = (av * 11) >> 5, ak = av - 3 * ah;      // window position kh * 3 + kw
-                        yv[c] = py[((long long)(r + ah - 1) * W + (oc + ak - 1)) * COUT + 4 * kq + c];
-                    }
-                    if (r + 1 < r1) aw_next = argw[((long long)(r + 1) * W + oc) * (COUT / 4) + kq];
-                }
-            }
             f32x4 acc[NT], acc2[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[nt] = acc[nt]; }
@@ -177,16 +145,6 @@ __global__ __launch_bounds__(THREADS) void conv3x3_kernel(const float *__restric
                         const float v = owns ? acc[nt][c] : 0.f;
                         s[nt][c] += v;
                         q2[nt][c] = __fmaf_rn(v, v, q2[nt][c]);
-                    }
-                }
-                if constexpr (MODE == 2) {                              // img_bwd_stats2_kernel's arithmetic on the registers
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float z = (yv[c] - pmean[c]) * pscale[c] + pbeta[c];
-                        const float g = owns ? acc[nt][c] : 0.f;
-                        const float gz = z > 0.f ? g : g * pv.slope;
-                        s[nt][c] += gz;
-                        q2[nt][c] = __fmaf_rn(gz, (yv[c] - pmean[c]) * pinv[c], q2[nt][c]);
                     }
                 }
             }
@@ -361,329 +319,9 @@ __global__ __launch_bounds__(THREADS) void conv3x3_tail_bwd_kernel(int B, int H,
     }
 }
 
-// ---- forward with the block tail of the block in front on load -----------------------------------------------------------------------
-// BatchNorm + LeakyReLU + MaxPool(3, 1, 1) of a 16-channel block AND the convolution of the next block in one kernel
-// (img_pool_fwd2_kernel + conv3x3_kernel<16,COUT,1> before: the pooled tensor written by one, read by the other).  The strip walk with one
-// more stage in front: rows of the front block's conv output y are loaded (float4 per lane), normalised and activated once, the first
-// maximum over the three window columns comes from the neighbour lanes (DPP), the window's over three such row results — the pooling
-// kernel's arithmetic and tie rule, bit-identical output and arg-max — and a pooled row is at once the B operand of the next three
-// conv rows.  The pooled output and the arg-max bytes are still written (the backward reads them), each element by the wave that owns
-// it; 12 output columns per strip.  Coefficients of the front block from its replica sums in every block's prologue; block 0 writes
-// mean_invstd and the running buffers (as img_pool_fwd2_kernel does).
-struct TailFwd {
-    const float *y; const double *sums; const float *gamma, *beta; float eps, slope, momentum; const float *conv_bias;
-    float *running_mean, *running_var, *out; unsigned char *arg; float *mean_invstd;
-};
-
-template <int COUT>
-__global__ __launch_bounds__(THREADS) void conv3x3_pool_fwd_kernel(int B, int H, int W, int strips_w, WView16 wgt, TailFwd tf, float *__restrict__ yo,
-                                                                   double *__restrict__ sums_o) {
-    constexpr int NPW = 12, CC = 16, NT = COUT / 16;
-    __shared__ double stat[2 * CC], part[THREADS];
-    __shared__ double red[THREADS / 64][2 * COUT];
-    const double n = (double)((long long)B * H * W);
-    {
-        const int idx = threadIdx.x & 31, grp = threadIdx.x >> 5;
-        double a = 0.0;
-        for (int r = grp; r < REP; r += THREADS / 32) a += tf.sums[(size_t)r * 2 * CC + idx];
-        part[threadIdx.x] = a;
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            double t = 0.0;
-            for (int g2 = 0; g2 < THREADS / 32; ++g2) t += part[g2 * 32 + threadIdx.x];
-            stat[threadIdx.x] = t;
-        }
-        __syncthreads();
-        if (blockIdx.x == 0 && threadIdx.x < CC) {
-            const int ch = threadIdx.x;
-            const double m = stat[ch] / n;
-            double var = stat[CC + ch] / n - m * m;
-            var = var < 0.0 ? 0.0 : var;
-            tf.mean_invstd[ch] = (float)m;
-            tf.mean_invstd[CC + ch] = rsqrtf((float)var + tf.eps);
-            if (tf.running_mean) {
-                const float mb = (float)m + (tf.conv_bias ? tf.conv_bias[ch] : 0.f);
-                tf.running_mean[ch] = (1.f - tf.momentum) * tf.running_mean[ch] + tf.momentum * mb;
-                const float unbiased = (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
-                tf.running_var[ch] = (1.f - tf.momentum) * tf.running_var[ch] + tf.momentum * unbiased;
-            }
-        }
-    }
-    const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
-    const unsigned wave = i2p_xcd_swizzle(blockIdx.x, gridDim.x) * (THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned nwaves = gridDim.x * (THREADS / 64);
-    const long long total = (long long)B * strips_w * H;
-    long long pos = total * wave / nwaves;
-    const long long end = total * (wave + 1) / nwaves;
-    float wr[NT][36];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) wr[nt][t * 4 + u] = wgt.ld(16 * nt + j, 4 * kq + u, t / 3, t % 3);
-    float mean[4], scale[4], bet[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int ch = 4 * kq + c;
-        const double m = stat[ch] / n;
-        double var = stat[CC + ch] / n - m * m;
-        var = var < 0.0 ? 0.0 : var;
-        mean[c] = (float)m; scale[c] = rsqrtf((float)var + tf.eps) * tf.gamma[ch]; bet[c] = tf.beta[ch];
-    }
-    const long long img_px = (long long)H * W;
-    const int row4 = W * CC * 4;
-    float s[NT][4], q2[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { s[nt][c] = 0.f; q2[nt][c] = 0.f; }
-    struct HRow { float v[4]; unsigned k[4]; };                         // first maximum over the window columns of one input row: value, kw
-    struct ORow { float q[4]; };
-    while (pos < end) {
-        const long long bs = pos / H;
-        const int r0 = (int)(pos - bs * H), r1 = (int)min((long long)H, r0 + (end - pos));
-        const int b = (int)(bs / strips_w), strip = (int)(bs - (long long)b * strips_w);
-        pos += r1 - r0;
-        const int c0 = strip * NPW, col = c0 - 2 + j;                   // strip column j = image column c0 - 2 + j; conv columns c0 .. c0 + 11
-        const bool col_in = col >= 0 && col < W;
-        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tf.y + (long long)b * img_px * CC), 0, (int)(img_px * CC * 4), 0x00020000);
-        const int vo4 = col_in ? (col * CC + 4 * kq) * 4 : 0x7fffffff;
-        auto load_y = [&](int rr) -> ORow {
-            ORow o;
-            if (rr < 0 || rr >= H) { o.q[0] = o.q[1] = o.q[2] = o.q[3] = 0.f; return o; }
-            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(ry, vo4, rr * row4, 0);
-            o.q[0] = __uint_as_float(t[0]); o.q[1] = __uint_as_float(t[1]); o.q[2] = __uint_as_float(t[2]); o.q[3] = __uint_as_float(t[3]);
-            return o;
-        };
-        // activations of input row rr, then per lane the first maximum over the columns j - 1, j, j + 1 (-inf outside the image)
-        auto hrow = [&](int rr, const ORow &Y) -> HRow {
-            HRow h;
-            const bool in = rr >= 0 && rr < H && col_in;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float z = (Y.q[c] - mean[c]) * scale[c] + bet[c];
-                const float a = in ? (z > 0.f ? z : z * tf.slope) : -INFINITY;
-                const float left = __int_as_float(__builtin_amdgcn_update_dpp((int)0xff800000u, __float_as_int(a), 0x111, 0xF, 0xF, false));
-                const float right = __int_as_float(__builtin_amdgcn_update_dpp((int)0xff800000u, __float_as_int(a), 0x101, 0xF, 0xF, false));
-                float best = -INFINITY;
-                unsigned bi = 0u;
-                if (left > best || left != left) { best = left; bi = 0u; }
-                if (a > best || a != a) { best = a; bi = 1u; }
-                if (right > best || right != right) { best = right; bi = 2u; }
-                h.v[c] = best; h.k[c] = bi;
-            }
-            return h;
-        };
-        float *ob = tf.out + (long long)b * img_px * CC;
-        unsigned *ab = reinterpret_cast<unsigned *>(tf.arg) + (long long)b * img_px * (CC / 4);
-        // pooled row rho from the row results of rho - 1, rho, rho + 1; zero outside the image (the convolution's padding)
-        auto pooled = [&](int rho, const HRow &T, const HRow &M, const HRow &Bt) -> ORow {
-            ORow o;
-            if (rho < 0 || rho >= H) { o.q[0] = o.q[1] = o.q[2] = o.q[3] = 0.f; return o; }
-            unsigned bi[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float best = -INFINITY;
-                unsigned k = 0u;
-                if (T.v[c] > best || T.v[c] != T.v[c]) { best = T.v[c]; k = T.k[c]; }
-                if (M.v[c] > best || M.v[c] != M.v[c]) { best = M.v[c]; k = 3u + M.k[c]; }
-                if (Bt.v[c] > best || Bt.v[c] != Bt.v[c]) { best = Bt.v[c]; k = 6u + Bt.k[c]; }
-                o.q[c] = col_in ? best : 0.f;
-                bi[c] = k;
-            }
-            if (rho >= r0 && rho < r1 && j >= 2 && j <= 13 && col_in) {
-                const long long e = (long long)rho * W + col;
-                *reinterpret_cast<f32x4 *>(ob + e * CC + 4 * kq) = f32x4{o.q[0], o.q[1], o.q[2], o.q[3]};
-                ab[e * (CC / 4) + kq] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
-            }
-            return o;
-        };
-        // input rows r0 - 2 .. r0 + 1 give the pooled rows r0 - 1, r0 to start; each iteration adds pooled row r + 1 (input row r + 2)
-        HRow H0 = hrow(r0 - 2, load_y(r0 - 2)), H1 = hrow(r0 - 1, load_y(r0 - 1)), H2 = hrow(r0, load_y(r0)), H3 = hrow(r0 + 1, load_y(r0 + 1));
-        ORow O0 = pooled(r0 - 1, H0, H1, H2), O1 = pooled(r0, H1, H2, H3), O2;
-        H0 = H2; H1 = H3;                                                 // row results of input rows r0, r0 + 1
-        ORow Yn = load_y(r0 + 2), Ynn;
-        float *yb = yo + (long long)b * img_px * COUT;
-        const bool owns = j >= 2 && j <= 13 && col_in;
-        for (int r = r0; r < r1; ++r) {
-            Ynn = load_y(r + 3);
-            const HRow Hn = hrow(r + 2, Yn);
-            O2 = pooled(r + 1, H0, H1, Hn);
-            f32x4 acc[NT], acc2[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) { acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[nt] = acc[nt]; }
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const ORow &R = kh == 0 ? O0 : (kh == 1 ? O1 : O2);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float mid = R.q[u], left = dpp_f32<0x111>(mid), right = dpp_f32<0x101>(mid);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[nt][(kh * 3 + 0) * 4 + u], left, acc[nt], 0, 0, 0);
-                        acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[nt][(kh * 3 + 1) * 4 + u], mid, acc2[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[nt][(kh * 3 + 2) * 4 + u], right, acc[nt], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[nt][c] += acc2[nt][c];
-                if (owns) *reinterpret_cast<f32x4 *>(yb + ((long long)r * W + col) * COUT + 16 * nt + 4 * kq) = acc[nt];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float v = owns ? acc[nt][c] : 0.f;
-                    s[nt][c] += v;
-                    q2[nt][c] = __fmaf_rn(v, v, q2[nt][c]);
-                }
-            }
-            O0 = O1; O1 = O2; H0 = H1; H1 = Hn; Yn = Ynn;
-        }
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            double a = (double)s[nt][c], b2 = (double)q2[nt][c];
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b2 += __shfl_xor(b2, m); }
-            if (j == 0) { red[threadIdx.x >> 6][16 * nt + 4 * kq + c] = a; red[threadIdx.x >> 6][COUT + 16 * nt + 4 * kq + c] = b2; }
-        }
-    __syncthreads();
-    if (threadIdx.x < 2 * COUT) {
-        double t = 0.0;
-#pragma unroll
-        for (int w2 = 0; w2 < THREADS / 64; ++w2) t += red[w2][threadIdx.x];
-        atomicAdd(sums_o + (size_t)(blockIdx.x % REP) * 2 * COUT + threadIdx.x, t);
-    }
-}
-
-// ---- bf16 storage (BASELINE configs[2] / [4]: ops.set_precision("bf16")) ------------------------------------------------------------
-// The same strip walk on bf16 tensors with v_mfma_f32_16x16x16_bf16: one MFMA takes the 16 input channels of a tap, and the 8 bytes a
-// lane loads per row (channels 4 kq .. 4 kq + 3 of column j) ARE its B operand [k = channel][pixel]; 9 MFMAs per 16 pixels and 16 output
-// channels instead of 36 — the kernel is bound by its loads and stores.  fp32 accumulation, y rounded to bf16 (RNE) on store, the
-// BatchNorm sums taken from the ROUNDED values (what the pooling kernel will normalise).  Weights: bf16 [out][in][kh][kw] by strides.
-struct WViewBf {
-    const unsigned short *p; int s_out, s_in, s_kh, s_kw, flip;
-    __device__ __forceinline__ short ld(int out, int in, int kh, int kw) const {
-        return (short)p[out * s_out + in * s_in + (flip ? 2 - kh : kh) * s_kh + (flip ? 2 - kw : kw) * s_kw];
-    }
-};
-__device__ __forceinline__ unsigned dpp_u32_shr(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); }
-__device__ __forceinline__ unsigned dpp_u32_shl(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true); }
-
-template <int CIN, int COUT, bool STATS>
-__global__ __launch_bounds__(THREADS) void conv3x3_bf16_kernel(const unsigned short *__restrict__ x, int B, int H, int W, int strips_w, WViewBf wgt,
-                                                               unsigned short *__restrict__ y, double *__restrict__ sums) {
-    constexpr int NPW = 14, NQ = CIN / 16, NT = COUT / 16;
-    struct Row { u32x2 q[NQ]; };
-    const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
-    const unsigned wave = i2p_xcd_swizzle(blockIdx.x, gridDim.x) * (THREADS / 64) + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned nwaves = gridDim.x * (THREADS / 64);
-    const long long total = (long long)B * strips_w * H;
-    long long pos = total * wave / nwaves;
-    const long long end = total * (wave + 1) / nwaves;
-    if (!STATS && pos >= end) return;
-    // A operand of (tile nt, tap t, group q): W[out = 16 nt + j][in = 16 q + 4 kq + e][tap], e = 0 .. 3
-    s16x4 wr[NT][9][NQ];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) wr[nt][t][q][e] = wgt.ld(16 * nt + j, 16 * q + 4 * kq + e, t / 3, t % 3);
-    const long long img_px = (long long)H * W;
-    const int row2 = W * CIN * 2;
-    // a lane adds one value per row of its range (~17 rows at the encoder's sizes): fp32 per lane, fp64 from the wave reduction on
-    float s[NT][4], q2[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { s[nt][c] = 0.f; q2[nt][c] = 0.f; }
-    while (pos < end) {
-        const long long bs = pos / H;
-        const int r0 = (int)(pos - bs * H), r1 = (int)min((long long)H, r0 + (end - pos));
-        const int b = (int)(bs / strips_w), strip = (int)(bs - (long long)b * strips_w);
-        pos += r1 - r0;
-        const int c0 = strip * NPW;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(x + (long long)b * img_px * CIN), 0,
-                                                                              (int)(img_px * CIN * 2), 0x00020000);
-        const int lcol = c0 - 1 + j;
-        const int lvoff = (lcol >= 0 && lcol < W) ? (lcol * CIN + kq * 4) * 2 : 0x7fffffff;         // outside the image: reads 0
-        auto load_x = [&](int xr) -> Row {
-            Row r;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (xr < 0 || xr >= H) { r.q[q] = u32x2{0u, 0u}; continue; }
-                r.q[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lvoff == 0x7fffffff ? lvoff : lvoff + 32 * q, xr * row2, 0);
-            }
-            return r;
-        };
-        const int oc = c0 + j - 1;
-        const bool owns = j >= 1 && j <= 14 && oc < W;
-        Row R0 = load_x(r0 - 1), R1 = load_x(r0), R2 = load_x(r0 + 1), Rn = load_x(r0 + 2), Rnn;
-        unsigned short *yb = y + (long long)b * img_px * COUT;
-        for (int r = r0; r < r1; ++r) {
-            Rnn = load_x(r + 3);
-            f32x4 acc[NT], acc2[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) { acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[nt] = acc[nt]; }
-            I2P_MFMA_PRIO(1);
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const Row &R = kh == 0 ? R0 : (kh == 1 ? R1 : R2);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const u32x2 mid = R.q[q], left = {dpp_u32_shr(mid[0]), dpp_u32_shr(mid[1])}, right = {dpp_u32_shl(mid[0]), dpp_u32_shl(mid[1])};
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wr[nt][kh * 3 + 0][q], __builtin_bit_cast(s16x4, left), acc[nt], 0, 0, 0);
-                        acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wr[nt][kh * 3 + 1][q], __builtin_bit_cast(s16x4, mid), acc2[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wr[nt][kh * 3 + 2][q], __builtin_bit_cast(s16x4, right), acc[nt], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const u32x2 o = {pack_bf2(acc[nt][0] + acc2[nt][0], acc[nt][1] + acc2[nt][1]), pack_bf2(acc[nt][2] + acc2[nt][2], acc[nt][3] + acc2[nt][3])};
-                if (owns) *reinterpret_cast<u32x2 *>(yb + ((long long)r * W + oc) * COUT + 16 * nt + 4 * kq) = o;
-                if constexpr (STATS) {
-                    const float v[4] = {bf_lo(o[0]), bf_hi(o[0]), bf_lo(o[1]), bf_hi(o[1])};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float t = owns ? v[c] : 0.f;
-                        s[nt][c] += t;
-                        q2[nt][c] = __fmaf_rn(t, t, q2[nt][c]);
-                    }
-                }
-            }
-            R0 = R1; R1 = R2; R2 = Rn; Rn = Rnn;
-        }
-    }
-    if constexpr (STATS) {
-        __shared__ double red[THREADS / 64][2 * COUT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                double a = (double)s[nt][c], b2 = (double)q2[nt][c];
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b2 += __shfl_xor(b2, m); }
-                if (j == 0) { red[threadIdx.x >> 6][16 * nt + 4 * kq + c] = a; red[threadIdx.x >> 6][COUT + 16 * nt + 4 * kq + c] = b2; }
-            }
-        __syncthreads();
-        if (threadIdx.x < 2 * COUT) {
-            double t = 0.0;
-#pragma unroll
-            for (int w2 = 0; w2 < THREADS / 64; ++w2) t += red[w2][threadIdx.x];
-            atomicAdd(sums + (size_t)(blockIdx.x % REP) * 2 * COUT + threadIdx.x, t);
-        }
-    }
-}
+// (Two more uses of these kernels were built and measured in round 4 and removed in round 5: the forward twin of the one-kernel
+//  backward — pooling of block k formed on load by the convolution of block k + 1: 10.97 / 11.02 vs 10.92 ms per step — and bf16-storage
+//  variants on v_mfma_f32_16x16x16_bf16: configs[2] 1151 -> 1185 samples/s but outside the 8e-2 pose contract.  DESIGN.md section 4.)
 
 // ---- weight gradient ---------------------------------------------------------------------------------------------------------------
 // dW[co][ci][kh][kw] = sum over pixels dy[px][co] x[px + (kh - 1, kw - 1)][ci]: the pixels are the MFMA contraction index, one 16 x 16
@@ -829,38 +467,24 @@ int wgrad_blocks(int B, int H, int W) {
 }
 
 // forward (flip = 0): x [B,H,W,cin] -> y [B,H,W,cout]; input gradient (flip = 1): x = dL/dy [B,H,W,cout] -> y = dL/dx [B,H,W,cin]
-int launch(const void *x, int B, int H, int W, int cin, int cout, const void *w, const int *ws, int flip, void *y, double *sums, int bf16, hipStream_t st,
-           const PrevBlock *prev = nullptr) {
-    if (!size_ok(B, H, W) || !pair_ok(cin, cout)) return I2P_ERR_BAD_ARG;
+int launch(const void *x, int B, int H, int W, int cin, int cout, const void *w, const int *ws, int flip, void *y, double *sums, int bf16, hipStream_t st) {
+    if (!size_ok(B, H, W) || !pair_ok(cin, cout) || bf16) return I2P_ERR_BAD_ARG;      // (bf16 storage: MIOpen runs these layers, see the note above)
     if (B == 0) return 0;
     if (!x || !w || !ws || !y) return I2P_ERR_BAD_ARG;
     const int strips = (W + 13) / 14;
     // 4 waves per SIMD of the whole chip, all resident (<= 128 VGPRs); small tensors: one wave per 4 output rows of a strip
     const long long total = (long long)B * strips * H;
-    // the 32-channel variants hold more weight registers, the backward-statistics mode more state: 2 - 3 waves per SIMD fit
-    static const int wps32 = [] { const char *e = getenv("I2P_CONV32_WPS"); return e ? atoi(e) : 2; }();
-    const int wps = cout == 16 ? 4 : (prev ? 2 : wps32);
+    const int wps = cout == 16 ? 4 : 2;                  // the 32-channel variants hold more weight registers: 2 waves per SIMD fit
     long long blocks = (long long)num_cus() * wps;
     if (blocks * (THREADS / 64) * 4 > total) blocks = (total + 4 * (THREADS / 64) - 1) / (4 * (THREADS / 64));
     const dim3 grid(round8(blocks));
     // forward: W[co][ci][kh][kw] read as [out = co][in = ci]; input gradient: [out = ci][in = co], taps mirrored
-    if (bf16) {
-        const WViewBf wv{(const unsigned short *)w, flip ? ws[1] : ws[0], flip ? ws[0] : ws[1], ws[2], ws[3], flip};
-#define I2P_CONVB(CI_, CO_, ST_) hipLaunchKernelGGL((conv3x3_bf16_kernel<CI_, CO_, ST_>), grid, dim3(THREADS), 0, st, (const unsigned short *)x, B, H, W, strips, wv, (unsigned short *)y, sums)
-        if (!flip && cout == 16) { if (sums) I2P_CONVB(16, 16, true); else I2P_CONVB(16, 16, false); }
-        else if (!flip) { if (sums) I2P_CONVB(16, 32, true); else I2P_CONVB(16, 32, false); }
-        else if (cout == 16) I2P_CONVB(16, 16, false);
-        else I2P_CONVB(32, 16, false);
-#undef I2P_CONVB
-        I2P_RETURN_LAUNCH_STATUS();
-    }
     const WView16 wv{(const float *)w, flip ? ws[1] : ws[0], flip ? ws[0] : ws[1], ws[2], ws[3], flip};
-    const PrevBlock pv = prev ? *prev : PrevBlock{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f};
-#define I2P_CONV(CI_, CO_, MD_) hipLaunchKernelGGL((conv3x3_kernel<CI_, CO_, MD_>), grid, dim3(THREADS), 0, st, (const float *)x, B, H, W, strips, wv, (float *)y, sums, pv)
+#define I2P_CONV(CI_, CO_, MD_) hipLaunchKernelGGL((conv3x3_kernel<CI_, CO_, MD_>), grid, dim3(THREADS), 0, st, (const float *)x, B, H, W, strips, wv, (float *)y, sums)
     if (!flip && cout == 16) { if (sums) I2P_CONV(16, 16, 1); else I2P_CONV(16, 16, 0); }
     else if (!flip) { if (sums) I2P_CONV(16, 32, 1); else I2P_CONV(16, 32, 0); }
-    else if (cout == 16) { if (prev) I2P_CONV(16, 16, 2); else I2P_CONV(16, 16, 0); }
-    else { if (prev) I2P_CONV(32, 16, 2); else I2P_CONV(32, 16, 0); }
+    else if (cout == 16) I2P_CONV(16, 16, 0);
+    else I2P_CONV(32, 16, 0);
 #undef I2P_CONV
     I2P_RETURN_LAUNCH_STATUS();
 }
@@ -868,7 +492,7 @@ int launch(const void *x, int B, int H, int W, int cin, int cout, const void *w,
 }  // namespace
 
 // y [B,H,W,cout] = conv3x3(x [B,H,W,cin], w [cout,cin,3,3] by element strides ws[4]), padding 1, no bias; (cin, cout) = (16, 16) or
-// (16, 32).  bf16 = 1: x, w, y are bf16 bits (fp32 accumulation, sums from the rounded y).  sums (may be NULL): f64
+// (16, 32).  bf16 must be 0 (the bf16-storage variants were removed in round 5: I2P_ERR_BAD_ARG).  sums (may be NULL): f64
 // [I2P_BN_REPLICAS][2 cout] zeroed by the caller, receives sum y / sum y^2 per output channel (the layout i2p_img_block_pool reads)
 extern "C" int i2p_img_conv_fwd(int B, int H, int W, int cin, int cout, int bf16, const void *x, const void *w, const int *ws, void *y, double *sums,
                                 void *stream) {
@@ -881,27 +505,15 @@ extern "C" int i2p_img_conv_bwd_data(int B, int H, int W, int cin, int cout, int
     return launch(dy, B, H, W, cin, cout, w, ws, 1, dx, nullptr, bf16, (hipStream_t)stream);
 }
 
-// i2p_img_conv_bwd_data in fp32 that ALSO takes the BatchNorm-backward sums of the block in front of the convolution — a 16-channel
-// block with a stride-1 MaxPool whose pooled output is this convolution's input: prev_arg / prev_y / prev_mean_invstd / prev_gamma /
-// prev_beta / prev_slope are what i2p_img_block_bwd takes for that block, prev_dsums (f64 [I2P_BN_REPLICAS][32], zeroed by the caller)
-// receives sum gz / sum gz xhat; follow with i2p_img_block_bwd_dx.
-extern "C" int i2p_img_conv_bwd_data_stats(int B, int H, int W, int cin, int cout, const float *dy, const float *w, const int *ws, float *dx,
-                                           const unsigned char *prev_arg, const float *prev_y, const float *prev_mean_invstd,
-                                           const float *prev_gamma, const float *prev_beta, float prev_slope, double *prev_dsums, void *stream) {
-    if (cin != 16 || !prev_arg || !prev_y || !prev_mean_invstd || !prev_gamma || !prev_beta || !prev_dsums) return I2P_ERR_BAD_ARG;
-    const PrevBlock pv{prev_arg, prev_y, prev_mean_invstd, prev_gamma, prev_beta, prev_slope};
-    return launch(dy, B, H, W, cin, cout, w, ws, 1, dx, prev_dsums, 0, (hipStream_t)stream, &pv);
-}
-
 // rows of (cout / 16) * 9 * 256 floats the weight-gradient entry needs in `partials`
 extern "C" int i2p_img_conv_wgrad_rows(int B, int H, int W) { return (B <= 0 || H <= 0 || W <= 0) ? 0 : wgrad_blocks(B, H, W); }
 
-// dW (cout * cin * 9 values, written in w's layout: element strides ws[4] of [co][ci][kh][kw]; bf16 = 1: x, dy and dW are bf16 bits,
+// dW (cout * cin * 9 values, written in w's layout: element strides ws[4] of [co][ci][kh][kw]; bf16 must be 0; (formerly: x, dy and dW bf16 bits,
 // the products and sums fp32 / fp64) = the weight gradient of the convolution from x [B,H,W,cin] and dy [B,H,W,cout];
 // partials: f32 [i2p_img_conv_wgrad_rows()][(cout / 16) * 2304] scratch
 extern "C" int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, int bf16, const void *x, const void *dy, const int *ws, float *partials,
                                   void *dW, void *stream) {
-    if (!size_ok(B, H, W) || !pair_ok(cin, cout) || !ws || !dW) return I2P_ERR_BAD_ARG;
+    if (!size_ok(B, H, W) || !pair_ok(cin, cout) || !ws || !dW || bf16) return I2P_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const WView16 wv{nullptr, ws[0], ws[1], ws[2], ws[3], 0};
     const int nt = cout / 16;
@@ -909,12 +521,10 @@ extern "C" int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, int bf
     if (B > 0) {
         if (!x || !dy || !partials) return I2P_ERR_BAD_ARG;
 #define I2P_WG(CO_, BF_) hipLaunchKernelGGL((conv3x3_wgrad_kernel<CO_, BF_>), dim3(blocks), dim3(THREADS), 0, st, x, dy, B, H, W, strips, partials)
-        if (cout == 16) { if (bf16) I2P_WG(16, true); else I2P_WG(16, false); }
-        else { if (bf16) I2P_WG(32, true); else I2P_WG(32, false); }
+        if (cout == 16) I2P_WG(16, false); else I2P_WG(32, false);
 #undef I2P_WG
     }
-    if (bf16) hipLaunchKernelGGL(conv3x3_wgrad_fin_kernel<true>, dim3(36 * nt), dim3(1024), 0, st, blocks, nt, (const float *)partials, wv, dW);
-    else hipLaunchKernelGGL(conv3x3_wgrad_fin_kernel<false>, dim3(36 * nt), dim3(1024), 0, st, blocks, nt, (const float *)partials, wv, dW);
+    hipLaunchKernelGGL(conv3x3_wgrad_fin_kernel<false>, dim3(36 * nt), dim3(1024), 0, st, blocks, nt, (const float *)partials, wv, dW);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
@@ -934,26 +544,5 @@ extern "C" int i2p_img_conv_tail_bwd(int B, int H, int W, const float *g, const 
     long long blocks = (long long)num_cus() * 3;
     if (blocks * (THREADS / 64) * 4 > total) blocks = (total + 4 * (THREADS / 64) - 1) / (4 * (THREADS / 64));
     hipLaunchKernelGGL(conv3x3_tail_bwd_kernel, dim3(round8(blocks)), dim3(THREADS), 0, (hipStream_t)stream, B, H, W, strips, wv, tb, dx);
-    I2P_RETURN_LAUNCH_STATUS();
-}
-
-// BatchNorm + LeakyReLU + MaxPool(3, 1, 1) of a fp32 16-channel block from its conv output y and replica sums (= i2p_img_block_pool:
-// out, arg, mean_invstd, running buffers written) AND the next block's convolution y_next [B,H,W,cout] = conv3x3(out, w) with its
-// replica sums (sums_next zeroed by the caller), in one kernel; cout = 16 or 32.
-extern "C" int i2p_img_conv_pool_fwd(int B, int H, int W, int cout, const float *y, const double *sums, const float *gamma, const float *beta,
-                                     float eps, float slope, float momentum, const float *conv_bias, float *running_mean, float *running_var,
-                                     float *out, unsigned char *arg, float *mean_invstd, const float *w, const int *ws, float *y_next,
-                                     double *sums_next, void *stream) {
-    if (!size_ok(B, H, W) || !pair_ok(16, cout)) return I2P_ERR_BAD_ARG;
-    if (B == 0) return 0;
-    if (!y || !sums || !gamma || !beta || !out || !arg || !mean_invstd || !w || !ws || !y_next || !sums_next) return I2P_ERR_BAD_ARG;
-    const WView16 wv{w, ws[0], ws[1], ws[2], ws[3], 0};
-    const TailFwd tf{y, sums, gamma, beta, eps, slope, momentum, conv_bias, running_mean, running_var, out, arg, mean_invstd};
-    const int strips = (W + 11) / 12;
-    const long long total = (long long)B * strips * H;
-    long long blocks = (long long)num_cus() * (cout == 16 ? 3 : 2);
-    if (blocks * (THREADS / 64) * 4 > total) blocks = (total + 4 * (THREADS / 64) - 1) / (4 * (THREADS / 64));
-    if (cout == 16) hipLaunchKernelGGL(conv3x3_pool_fwd_kernel<16>, dim3(round8(blocks)), dim3(THREADS), 0, (hipStream_t)stream, B, H, W, strips, wv, tf, y_next, sums_next);
-    else hipLaunchKernelGGL(conv3x3_pool_fwd_kernel<32>, dim3(round8(blocks)), dim3(THREADS), 0, (hipStream_t)stream, B, H, W, strips, wv, tf, y_next, sums_next);
     I2P_RETURN_LAUNCH_STATUS();
 }

@@ -843,15 +843,13 @@ int dispatch_fwd2(const LinFwdParams &p_in, hipStream_t st) {
     LinFwdParams p = p_in;
     p.nslice = 1;
     {   // small layers: slice the output channels over blockIdx.y until ~256 blocks exist (slices stay >= 16 wide)
-        static const char *env = getenv("I2P_LIN_SLICE");   // diagnostic: 0 = never slice
         const long long g = ((p.rows + F2_ROWS - 1) / F2_ROWS + 7) / 8;
         int S = 1;
-        while (!(env && env[0] == '0') && g * S < 192 && p.cout / (2 * S) >= 16 && ((p.cout / (2 * S)) & 15) == 0) S *= 2;
+        while (g * S < 192 && p.cout / (2 * S) >= 16 && ((p.cout / (2 * S)) & 15) == 0) S *= 2;
         if (S > 1) { p.nslice = S; p.cout /= S; p.cout_p = p.cout; }
     }
     const int wide = p.cin > p.cout ? p.cin : p.cout;      // channels a strip row holds (input and output phases)
-    static const char *env = getenv("I2P_LIN_CH");          // diagnostic: 8 = always the wide instantiation
-    const bool narrow_ok = !PAIR && !(env && env[0] == '8');
+    const bool narrow_ok = !PAIR;
     const bool ch2 = narrow_ok && wide <= 32;               // (a 4-chunk instantiation spilled at its 128 VGPRs and measured no faster: removed)
     switch (p.cout_p / 16) {
         case 1: return ch2 ? launch_fwd2<1, PAIR, DGRAD, 2>(p, st) : launch_fwd2<1, PAIR, DGRAD, 8>(p, st);
@@ -1846,11 +1844,10 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
                             fin ? fin->mi : nullptr, stream, xb, in_coef_b, slope_b);
     }
     {
-        const char *ab = getenv("I2P_LIN_FWD_GEN");            // diagnostic: "1" forces the first-generation kernel
         auto pow2_16_128 = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
         const int slice_w = cout > 128 ? 128 : cout;
         const bool gen2_ok = (cin % 4 == 0) && cin <= 128 && cin >= 4 && (cout % slice_w == 0) && pow2_16_128(slice_w) &&
-                             !(ab && ab[0] == '1') && (!pair_f || pair_M >= F2_ROWS) &&
+                             (!pair_f || pair_M >= F2_ROWS) &&
                              ((!in_coef && !in_coef_b) || 64 % (cin / 4) == 0) && (!xb || (split_c % 4 == 0 && split_c > 0 && split_c < cin && 64 % (cin / 4) == 0));
         if (gen2_ok) {
             // strip LDS rows hold max(cin, slice) floats (+2): the epilogue transposes the outputs through them
@@ -1861,7 +1858,7 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
                 p.ldk = (cin > p.cout_p ? cin : p.cout_p) + ((cin & 15) == 0 ? 4 : 2);   // +4: 16-byte rows, ldk = 4 mod 32 (wide-K fragments)
                 p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.w = w + (size_t)off * cin; p.y = y; p.sums = sums;
                 p.y_ld = cout; p.ch_off = off; p.cout_total = cout;
-                { const char *abl = getenv("I2P_LIN_ABLATE"); p.ablate = abl ? atoi(abl) : 0; }   // diagnostic only
+                p.ablate = 0;
                 p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
                 p.x2 = nullptr; p.g_coef = nullptr; p.g_dsums = nullptr; p.g_oc = p.g_omi = nullptr; p.g_rows = 1; p.w_transposed = 0; p.ex = p.e_coef = p.e_mi = nullptr; p.e_slope = 1.f;
                 p.split_c = 0; p.xb = xb; p.in_coef_b = in_coef_b; p.slope_b = slope_b; p.yb = nullptr; p.exb = p.e_coef_b = p.e_mi_b = p.e_add = nullptr; p.sums_b = nullptr; p.e_slope_b = 1.f; p.split_c = split_c;
@@ -1889,7 +1886,7 @@ static int lin_fwd_impl(long long rows, int cin, int cout, const float *x, const
         p.x = x; p.in_coef = in_coef; p.slope_in = slope_in; p.w = w + (size_t)off * cin; p.y = y; p.sums = sums;
         p.y_ld = cout; p.ch_off = off; p.cout_total = cout;
         p.pair_f = pair_f; p.bias_n = bias_n; p.bias_k = bias_k; p.pair_N = pair_N; p.pair_M = pair_M;
-        { const char *ab = getenv("I2P_LIN_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
+        p.ablate = 0;
         p.x2 = nullptr; p.g_coef = nullptr; p.g_dsums = nullptr; p.g_oc = p.g_omi = nullptr; p.g_rows = 1; p.w_transposed = 0; p.ex = p.e_coef = p.e_mi = nullptr; p.e_slope = 1.f;
                 p.split_c = 0; p.xb = xb; p.in_coef_b = in_coef_b; p.slope_b = slope_b; p.yb = nullptr; p.exb = p.e_coef_b = p.e_mi_b = p.e_add = nullptr; p.sums_b = nullptr; p.e_slope_b = 1.f; p.split_c = split_c;
         p.fin_counter = nullptr; p.fin_gamma = p.fin_beta = nullptr; p.fin_eps = 0.f; p.fin_coef = p.fin_mi = nullptr;
@@ -2003,11 +2000,10 @@ struct TwoBwd { int split_c; const float *xb, *in_coef_b, *in_mi_b; float slope_
 // 1 = second / third generation (separate dgrad and wgrad launches), 2 = K-tiled wide layers (csrc/mlp_big.hip)
 static int lin_bwd_family(long long rows, int cin, int cout, bool need_gx, bool pair, bool two) {
     auto pow2w = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
-    const char *gen = getenv("I2P_LIN_BWD_GEN");
     const int cin_p = (cin + 31) & ~31, cout_p = (cout + 31) & ~31;
     const bool dgrad_ok = !need_gx || (pow2w(cin) && pow2w(cout));
     const size_t wg_lds = (2 * (size_t)WG_R * (cout_p + cin_p) + 6 * (size_t)cout + 3 * (size_t)cin) * sizeof(float);
-    if (!pair && !(gen && gen[0] == '1') && dgrad_ok && pow2w(cout) && wg_lds <= 160 * 1024 && cin <= 160) return 1;
+    if (!pair && dgrad_ok && pow2w(cout) && wg_lds <= 160 * 1024 && cin <= 160) return 1;
     if (!pair && !two && i2p_big_layer_ok(rows, cin, cout)) return 2;
     return 0;
 }
@@ -2047,11 +2043,10 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
     hipStream_t st = (hipStream_t)stream;
     {   // second-generation path: separate dgrad (lin_fwd2 DGRAD) and wgrad kernels
         auto pow2w = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
-        const char *gen = getenv("I2P_LIN_BWD_GEN");
         // (part 2 = the wgrad half of a split call: the kernel family is the one the WHOLE call — with its input gradient — lands on)
         const bool dgrad_ok = (!gz_in && part != 2) || (pow2w(cin) && pow2w(cout));
         const size_t wg_lds = (2 * (size_t)WG_R * (p.cout_p + p.cin_p) + 6 * (size_t)cout + 3 * (size_t)cin) * sizeof(float);
-        const bool gen2 = !pair && !(gen && gen[0] == '1') && dgrad_ok && pow2w(cout) && wg_lds <= 160 * 1024 && cin <= 160;
+        const bool gen2 = !pair && dgrad_ok && pow2w(cout) && wg_lds <= 160 * 1024 && cin <= 160;
         if (two && !(gen2 && pow2w(cin))) return I2P_ERR_BAD_ARG;
         // per-channel BN-backward constants behind the partials: [8][cout] = m1, m2, scale, mean, invstd, beta, and
         // the raw sums {sum gz, sum gz*xhat} = dbeta, dgamma of the BN behind (read back by the caller)
@@ -2157,20 +2152,6 @@ extern "C" int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, c
                            float slope_out, void *stream) {
     return lin_bwd_impl(rows, cin, cout, gz, y, out_coef, out_mi, out_dsums, x, in_coef, in_mi, slope_in, w, gz_in,
                         in_dsums, dw_partial, dw, nullptr, stream, nullptr, slope_out);
-}
-
-extern "C" int i2p_lin_bwd_splittable(long long rows, int cin, int cout, int need_gx) {
-    if (rows <= 0 || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3)) return 0;
-    return lin_bwd_family(rows, cin, cout, need_gx != 0, false, false) != 0 ? 1 : 0;
-}
-
-extern "C" int i2p_lin_bwd_part(long long rows, int cin, int cout, const float *gz, const float *y,
-                                const float *out_coef, const float *out_mi, const double *out_dsums,
-                                const float *x, const float *in_coef, const float *in_mi, float slope_in,
-                                const float *w, float *gz_in, double *in_dsums, float *dw_partial, float *dw,
-                                float slope_out, int part, float *coef_scratch, void *stream) {
-    return lin_bwd_impl(rows, cin, cout, gz, y, out_coef, out_mi, out_dsums, x, in_coef, in_mi, slope_in, w, gz_in,
-                        in_dsums, dw_partial, dw, nullptr, stream, nullptr, slope_out, part, coef_scratch);
 }
 
 extern "C" int i2p_pair_lin_bwd_grid(int B, int N, int M) {

@@ -303,8 +303,7 @@ bool i2p_big_layer_ok(long long rows, int cin, int cout) {
     if (e && e[0] == '1') return false;
     // cin in (128, 160] (132 = 128 + xyz, 136 = 128 + 6 + padding: level 4, the fine cost volume's first layer) used to run on the
     // first-generation block-synchronous kernels (lin_fwd_kernel<128,4> 91 us, lin_bwd_kernel<5,4> 128 us per launch)
-    static const char *e2 = getenv("I2P_BIG_MIN_CIN");
-    const int min_cin = e2 ? atoi(e2) : 128;
+    const int min_cin = 128;
     return rows > 0 && (cin & 3) == 0 && (cout & 3) == 0 && cin <= BG_MAXC && cout <= BG_MAXC && (cin > min_cin || cout > 128);
 }
 

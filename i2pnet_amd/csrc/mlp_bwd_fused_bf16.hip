@@ -676,7 +676,9 @@ int launch(const FusedBwdBf16P &p, unsigned grid, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_fused_bf16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    i2p_ktime_begin(st);
     hipLaunchKernelGGL(bwd_fused_bf16_kernel<C>, dim3(grid), dim3(FB_THREADS), bytes, st, p);
+    i2p_ktime_end(st);
     I2P_RETURN_LAUNCH_STATUS();
 }
 

@@ -820,14 +820,13 @@ size_t chain_lds_bytes(int cmax, int fr) {
 int chain_fwd_rows(long long rows, int cmax, int pool_k) {
     const int cus = chain_cus();
     if (cus <= 0) return 0;
-    static const char *env = getenv("I2P_CHAIN_FR");       // diagnostic: 64 = always 64-row strips
     for (int fr = 16; fr <= 64; fr *= 2) {
         if (pool_k && fr % pool_k) continue;
         const long long blocks = (rows + fr - 1) / fr;
         const size_t lds = chain_lds_bytes(cmax, fr);
         const int resident = chain_resident(fr == 16 ? 0 : fr == 32 ? 1 : 2, lds);
         if (fr < 64) {
-            if ((env && env[0] == '6') || blocks > cus || blocks > resident) continue;
+            if (blocks > cus || blocks > resident) continue;
             return fr;
         }
         if (blocks <= resident || (chain_force_nonresident() && lds <= 160 * 1024)) return fr;

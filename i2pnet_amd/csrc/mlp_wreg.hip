@@ -1375,13 +1375,11 @@ __global__ __launch_bounds__(SW_THREADS) void small_wgrad_kernel(SmallWgradP p) 
 
 }  // namespace
 
-// rows below which the weights-in-registers kernels hand over to the LDS-resident second generation (I2P_WREG_MIN_ROWS overrides)
+// rows below which the weights-in-registers kernels hand over to the LDS-resident second generation
 static long long wreg_min_rows() {
-    static const char *e = getenv("I2P_WREG_MIN_ROWS");
     // 32768: the fine cost volume's layers (8 x 228 x 32 = 58 368 rows; nuScenes 43 776) run 2-3x faster here than on the
     // second generation (A/B on one box: 615 -> 620 samples/s); below that a 1024-wave launch of 16-row strips is mostly pipeline fill
-    static const long long v = e ? atoll(e) : 32768;
-    return v;
+    return 32768;
 }
 
 bool i2p_wreg_fwd_ok(long long rows, int cin, int cout) {

@@ -287,7 +287,9 @@ int launch_fused(const WregFusedP &p, unsigned grid, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wreg_bwd_fused_kernel<K, C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    i2p_ktime_begin(st);
     hipLaunchKernelGGL((wreg_bwd_fused_kernel<K, C>), dim3(grid), dim3(WF_THREADS), bytes, st, p);
+    i2p_ktime_end(st);
     I2P_RETURN_LAUNCH_STATUS();
 }
 

@@ -122,3 +122,25 @@ extern "C" int i2p_clip_adam(long long n, float *param, float *grad, float *exp_
                        eps, weight_decay, clip, gscale, total_out, poison);
     I2P_RETURN_LAUNCH_STATUS();
 }
+
+// ---- kernel-only timing hook (see common.h) ---------------------------------------------------------------------------------
+namespace {
+bool g_ktime_on = false;
+hipEvent_t g_kt0 = nullptr, g_kt1 = nullptr;
+}
+void i2p_ktime_begin(hipStream_t st) { if (g_ktime_on) (void)hipEventRecord(g_kt0, st); }
+void i2p_ktime_end(hipStream_t st) { if (g_ktime_on) (void)hipEventRecord(g_kt1, st); }
+extern "C" int i2p_ktime_enable(int on) {
+    if (on && !g_kt0) {
+        if (hipEventCreate(&g_kt0) != hipSuccess || hipEventCreate(&g_kt1) != hipSuccess) return I2P_ERR_BAD_ARG;
+    }
+    g_ktime_on = on != 0;
+    return 0;
+}
+extern "C" float i2p_ktime_last_us(void) {
+    if (!g_kt1) return -1.f;
+    if (hipEventSynchronize(g_kt1) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_kt0, g_kt1) != hipSuccess) return -1.f;
+    return ms * 1e3f;
+}

@@ -402,8 +402,7 @@ extern "C" int i2p_furthest_point_sampling(int b, int n, int m, const float *dat
     int bs = 1 << pow_2;
     bs = bs > 1024 ? 1024 : bs; bs = bs < 1 ? 1 : bs;
     hipStream_t st = (hipStream_t)stream;
-    static const char *gen = getenv("I2P_FPS_GEN");                       // diagnostic: 1 = first-generation kernel
-    if (n <= FPS_THREADS * FPS_REG_PTS && !(gen && gen[0] == '1')) {
+    if (n <= FPS_THREADS * FPS_REG_PTS) {
         const size_t lds = (size_t)n * 3 * sizeof(float);
         if (n <= 64 * FPS_REG_PTS) {
             hipLaunchKernelGGL(fps_kernel_fast<64>, dim3(b), dim3(64), lds, st, n, m, bs, dataset, temp, idxs);

@@ -138,42 +138,10 @@ __device__ __forceinline__ unsigned long long knn_key(float d, int j) {
     return ((unsigned long long)u << 32) | (unsigned)j;
 }
 
-__global__ __launch_bounds__(256) void knn_kernel(int n, int s, int k, const float *__restrict__ xyz,
-                                                  const float *__restrict__ new_xyz,
-                                                  int *__restrict__ idx) {
-    const int bi = blockIdx.y;
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (qi >= s) return;
-    const float *q = new_xyz + ((size_t)bi * s + qi) * 3;
-    const float qx = q[0], qy = q[1], qz = q[2];
-    const float qq = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));
-    const float *src = xyz + (size_t)bi * n * 3;
-    int *o = idx + ((size_t)bi * s + qi) * k;
-    unsigned long long last = 0ull;
-    bool first = true;
-    for (int t = 0; t < k; ++t) {
-        unsigned long long best = ~0ull;
-        for (int j = lane; j < n; j += 64) {
-            const float d = knn_dist(qx, qy, qz, qq, src + (size_t)j * 3);
-            if (d != d) continue;                       // NaN never selected (as `<` in the oracle)
-            const unsigned long long key = knn_key(d, j);
-            if ((first || key > last) && key < best) best = key;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const unsigned long long ob = __shfl_xor(best, off);
-            best = ob < best ? ob : best;
-        }
-        if (lane == 0) o[t] = (int)(unsigned)(best & 0xffffffffull);
-        last = best; first = false;
-    }
-}
-
 // Second-generation kNN: ONE scan of the cloud per query instead of k.  Every lane keeps the KT smallest keys of its
 // own points in a sorted register list; the k winners are then popped by k wave-wide minimum reductions (DPP, no LDS).
 // A lane whose list runs dry although it had to drop candidates re-scans its points above its last popped key
-// (rare: k/64 winners per lane on average).  Same keys, same total order, same output as knn_kernel.
+// (rare: k/64 winners per lane on average).  Same keys, same total order, same output as the first-generation kernel (k scans per query, removed in round 5) and as the oracle.
 constexpr int KNN_KT = 4;
 
 template <int CTRL>
@@ -318,11 +286,7 @@ extern "C" int i2p_knn(int b, int n, int s, int k, const float *xyz, const float
     if (b < 0 || n < 0 || s < 0 || k < 0 || k > n) return I2P_ERR_BAD_ARG;
     if ((long long)b * s == 0 || k == 0) return 0;
     if (!xyz || !new_xyz || !idx) return I2P_ERR_BAD_ARG;
-    static const char *gen = getenv("I2P_KNN_GEN");                        // diagnostic: 1 = first-generation kernel
-    if (gen && gen[0] == '1')
-        hipLaunchKernelGGL(knn_kernel, dim3((s + 3) / 4, b), dim3(256), 0, (hipStream_t)stream, n, s, k, xyz, new_xyz, idx);
-    else
-        hipLaunchKernelGGL(knn_kernel2, dim3((s + 3) / 4, b), dim3(256), 0, (hipStream_t)stream, n, s, k, xyz, new_xyz, idx);
+    hipLaunchKernelGGL(knn_kernel2, dim3((s + 3) / 4, b), dim3(256), 0, (hipStream_t)stream, n, s, k, xyz, new_xyz, idx);
     I2P_RETURN_LAUNCH_STATUS();
 }
 

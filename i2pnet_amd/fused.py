@@ -251,7 +251,7 @@ class _MlpChain(Function):
             return gx, None, None, None, None, *grads
         if ctx.pool_k:
             arg = saved.pop()
-            if (not bf and be.name == "hip" and ctx.nl and 256 % (g_out.shape[1] // 4) == 0 and os.environ.get("I2P_NO_UNPOOL_STATS") != "1"):
+            if (not bf and be.name == "hip" and ctx.nl and 256 % (g_out.shape[1] // 4) == 0):
                 # dense dL/da AND the last block's BN-backward statistics in one pass (they only live on the arg-max rows)
                 n_ys = ctx.n_ys
                 last_y, last_mi = saved[n_ys - 1], saved[n_ys + 2 * ctx.n_coef - 1]

@@ -69,23 +69,9 @@ def inverse_3x3(m):
     return torch.stack([c0, c1, c2], dim=-1) / det.view(-1, 1, 1)
 
 
-# image encoder || LiDAR pyramid on two HIP streams (fork / join captured into the hipGraph).  Measured on MI355X, A/B
-# on one box: 485-488 samples/s with the two branches against 491-495 in one stream — the pyramid's small launches do not
-# hide under the encoder's kernels, they slow them down — so it stays OFF unless I2P_OVERLAP=1.
-OVERLAP_BRANCHES = os.environ.get("I2P_OVERLAP", "0") == "1"
-# the first image block's batch statistics (csrc/image_first.hip) on a side stream beside the LiDAR pyramid (I2P_STATS_OVERLAP)
-STATS_BESIDE_PYRAMID = os.environ.get("I2P_STATS_OVERLAP", "0") == "1"
-_SIDE = {}
-
-
-def _side_stream(dev):
-    dev = torch.device(dev)
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=key)
-    return _SIDE[key]
-
-
+# (Two-branch schedules — image encoder || LiDAR pyramid on two HIP streams, the first image block's statistics beside the pyramid —
+#  were measured in rounds 2-4 and always lost to the single stream: 485-488 vs 491-495 samples/s, 11.79 vs 11.40 ms.  The pyramid's
+#  small launches do not hide under the encoder's kernels, they slow them down.  The code paths were removed in round 5.)
 class RegNet_v2(nn.Module):
     def __init__(self, bn_decay=None, eval_info=False, cfg=cfg_default):
         super().__init__()
@@ -204,34 +190,8 @@ class RegNet_v2(nn.Module):
         B = rgb_img.shape[0]
         N = lidar_img.shape[1]
 
-        # The image encoder and the LiDAR pyramid are independent until the first cost volume; with OVERLAP_BRANCHES the
-        # pyramid is issued on a side stream (two parallel branches in the captured hipGraph, forward and backward).
-        side = _side_stream(dev) if (OVERLAP_BRANCHES and rgb_img.is_cuda) else None
-        if side is not None:
-            cur = torch.cuda.current_stream(dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                lidar = self._lidar_branch(lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev)
-            RF3, pix_rays, RF3_pts, RF3_unit = self._image_branch(rgb_img, intrinsic)
-            cur.wait_stream(side)
-            for t in lidar:                               # produced on `side`, consumed (and later freed) under `cur`
-                if torch.is_tensor(t):
-                    t.record_stream(cur)
-        elif STATS_BESIDE_PYRAMID and rgb_img.is_cuda and self.training:
-            # the first image block's statistics (an MFMA-bound pass over the input alone) beside the LiDAR pyramid's small launches
-            cur, st = torch.cuda.current_stream(dev), _side_stream(dev)
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                issued = self.RGB_net1.prefetch_first_stats(rgb_img)
-            lidar = self._lidar_branch(lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev)
-            cur.wait_stream(st)
-            if issued:
-                for t in self.RGB_net1._first_stats[:2]:
-                    t.record_stream(cur)
-            RF3, pix_rays, RF3_pts, RF3_unit = self._image_branch(rgb_img, intrinsic)
-        else:
-            RF3, pix_rays, RF3_pts, RF3_unit = self._image_branch(rgb_img, intrinsic)
-            lidar = self._lidar_branch(lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev)
+        RF3, pix_rays, RF3_pts, RF3_unit = self._image_branch(rgb_img, intrinsic)
+        lidar = self._lidar_branch(lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev)
         (P3_raw, P3, LF3, P4_raw, P4, LF4, sample_idx_4, P3_pts, LF3_pts, lidar_z, lidar_uv, LF3_unit) = lidar
         rfp = cfg.raw_feat_point
         H3, W3 = self.lidar_Hs[2], self.lidar_Ws[2]
@@ -276,7 +236,7 @@ class RegNet_v2(nn.Module):
         B = q_prev.shape[0]
         dev = q_prev.device
         # warp by the previous estimate, mask the empty cells, split off the depth: one launch each way on the device library
-        split = warp_utils.warp_split(f["P3_pts"], q_prev, t_prev_quat, f["p3_valid"]) if os.environ.get("I2P_NO_WARP_SPLIT") != "1" else None
+        split = warp_utils.warp_split(f["P3_pts"], q_prev, t_prev_quat, f["p3_valid"])
         if split is not None:
             lidar_uv, lidar_z, xyz3 = split
             P3_warped = None                                                     # (the pose head ignores its xyz argument)

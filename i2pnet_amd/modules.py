@@ -245,11 +245,9 @@ class _BnActPool(torch.autograd.Function):
         if not y_nhwc.is_contiguous():
             y_nhwc = y_nhwc.contiguous()
         be = ops.get_backend()
-        # second-generation kernels (coefficients in the consumers' prologues, no finalize launches): what the bf16 storage runs on.
-        # In fp32 they measure the same as the first generation with its 64-thread finalize launches (628.0 vs 629.6 samples/s, A/B on
-        # one box: the prologue's dependent load -> barrier -> rsqrt chain costs what the launch did), so fp32 stays on generation 1
-        # unless I2P_IMG_GEN2=1.
-        ctx.gen2 = be.name == "hip" and (y.dtype == torch.bfloat16 or out_bf16 or os.environ.get("I2P_IMG_GEN2", "1") == "1")
+        # device library: second-generation kernels (coefficients in the consumers' prologues, no finalize launches, a storage type per
+        # tensor); the CPU oracle backend restates the first generation's three-step form
+        ctx.gen2 = be.name == "hip"
         if ctx.gen2:
             out, arg, mi = be.img_block_forward(y_nhwc, gamma.detach(), beta.detach(), eps, slope, stride, momentum, conv_bias.detach(),
                                                 running_mean, running_var, out_bf16=out_bf16)
@@ -316,11 +314,7 @@ class _Conv16Block(torch.autograd.Function):
     input-gradient kernel and the weight-gradient kernel (+ its 9-block reduction)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, conv_bias, running_mean, running_var, stride, momentum, eps, slope, out_bf16=False, link_in=None,
-                link_out=None):
-        """link_in / link_out: `_BwdLink`s shared with the block in front / behind (both fp32 conv16 blocks, consecutive in the
-        Sequential): this block's input-gradient kernel takes the BatchNorm-backward sums of the block in front (link_in), and finds
-        its own already taken by the block behind (link_out)"""
+    def forward(ctx, x, weight, gamma, beta, conv_bias, running_mean, running_var, stride, momentum, eps, slope, out_bf16=False):
         x_nhwc = x.permute(0, 2, 3, 1)
         if not x_nhwc.is_contiguous():
             x_nhwc = x_nhwc.contiguous()
@@ -329,9 +323,7 @@ class _Conv16Block(torch.autograd.Function):
         out, arg, mi = be.img_block_forward(y, gamma.detach(), beta.detach(), eps, slope, stride, momentum, conv_bias.detach(),
                                             running_mean, running_var, out_bf16=out_bf16, sums=sums)
         ctx.save_for_backward(x_nhwc, y, arg, mi, weight, gamma, beta)
-        ctx.stride, ctx.slope, ctx.link_in, ctx.link_out = stride, slope, link_in, link_out
-        if link_out is not None:
-            link_out.prev, link_out.dsums = (arg, y, mi, gamma.detach(), beta.detach(), slope), None
+        ctx.stride, ctx.slope = stride, slope
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -341,110 +333,25 @@ class _Conv16Block(torch.autograd.Function):
         if not g_nhwc.is_contiguous():
             g_nhwc = g_nhwc.contiguous()
         be = ops.get_backend()
-        own = ctx.link_out.dsums if ctx.link_out is not None else None          # taken by the block behind, from the registers that held g
-        if ctx.link_out is not None:
-            ctx.link_out.prev = ctx.link_out.dsums = None
-        fused = (own is None and ctx.needs_input_grad[0] and ctx.stride == 1 and tuple(weight.shape) == (16, 16, 3, 3) and y.dtype == torch.float32
-                 and g_nhwc.dtype == torch.float32 and not (ctx.link_in is not None and ctx.link_in.prev is not None)
-                 and os.environ.get("I2P_NO_TAIL_BWD") != "1")
+        fused = (ctx.needs_input_grad[0] and ctx.stride == 1 and tuple(weight.shape) == (16, 16, 3, 3) and y.dtype == torch.float32
+                 and g_nhwc.dtype == torch.float32 and os.environ.get("I2P_NO_TAIL_BWD") != "1")
         if fused:       # un-pooling + BatchNorm backward + input gradient of the convolution in one kernel (dy still written for dW)
             dy, dx, dgamma, dbeta = be.img_conv16_tail_backward(g_nhwc, arg, y, mi, gamma.detach(), beta.detach(), ctx.slope, weight.detach())
             dx = dx.permute(0, 3, 1, 2)
         else:
-            dy, dgamma, dbeta = be.img_block_backward(g_nhwc, arg, y, mi, gamma.detach(), beta.detach(), ctx.slope, ctx.stride, dsums=own)
-            dx = None
-        if ctx.needs_input_grad[0] and not fused:
-            if ctx.link_in is not None and ctx.link_in.prev is not None:
-                dx, ctx.link_in.dsums = be.img_conv16(dy, weight.detach(), input_grad=True, prev=ctx.link_in.prev)
-            else:
-                dx = be.img_conv16(dy, weight.detach(), input_grad=True)
-            dx = dx.permute(0, 3, 1, 2)
-        if os.environ.get("I2P_CONV16_MIOPEN_WGRAD") == "1":          # (A/B: MIOpen's split-K weight gradient)
-            dW = torch.ops.aten.convolution_backward(dy.permute(0, 3, 1, 2), x_nhwc.permute(0, 3, 1, 2), weight, None, (1, 1), (1, 1), (1, 1),
-                                                     False, (0, 0), 1, (False, True, False))[1]
-        else:
-            dW = be.img_conv16_wgrad(x_nhwc, dy, weight.detach())
-        return dx, dW, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
-
-
-class _Conv16Run(torch.autograd.Function):
-    """A run of consecutive fp32 conv16 blocks of an encoder stack (blocks 2-5 of RGB_net1: 16 -> 16 x 3 with stride-1 pools, then
-    16 -> 32) as one autograd node, so that kernels can span block boundaries: forward = conv, then per boundary ONE kernel for the
-    front block's BatchNorm + LeakyReLU + MaxPool and the next block's convolution (i2p_img_conv_pool_fwd), then the last block's
-    tail; backward per block = statistics pass + one kernel for un-pooling, BatchNorm backward and the input gradient
-    (i2p_img_conv_tail_bwd; the stride-2 block: block-tail kernels + input-gradient kernel) + the weight-gradient kernel."""
-
-    @staticmethod
-    def forward(ctx, x, meta, out_bf_last, *params):
-        """meta: per block (stride, momentum, eps, slope, running_mean, running_var); params: (weight, gamma, beta, conv_bias) per block"""
-        nb = len(meta)
-        x_nhwc = x.permute(0, 2, 3, 1)
-        if not x_nhwc.is_contiguous():
-            x_nhwc = x_nhwc.contiguous()
-        be = ops.get_backend()
-        P4 = lambda i: params[4 * i:4 * i + 4]
-        y, sums = be.img_conv16(x_nhwc, P4(0)[0].detach(), with_sums=True)
-        saved = [x_nhwc]
-        for i in range(nb):
-            w, gamma, beta, bias = P4(i)
-            stride, momentum, eps, slope, rm, rv = meta[i]
-            if i + 1 < nb:
-                out, arg, mi, y_next, sums_next = be.img_conv_pool_forward(y, sums, gamma.detach(), beta.detach(), eps, slope, momentum,
-                                                                          bias.detach(), rm, rv, P4(i + 1)[0].detach())
-            else:
-                out, arg, mi = be.img_block_forward(y, gamma.detach(), beta.detach(), eps, slope, stride, momentum, bias.detach(), rm, rv,
-                                                    out_bf16=out_bf_last, sums=sums)
-            saved += [y, arg, mi, out]
-            if i + 1 < nb:
-                y, sums = y_next, sums_next
-        ctx.save_for_backward(*saved[:-1], *params)          # (the last pooled output is the node's result, not needed again)
-        ctx.meta, ctx.nb = [(m[0], m[3]) for m in meta], nb
-        return out.permute(0, 3, 1, 2)
-
-    @staticmethod
-    def backward(ctx, g):
-        nb = ctx.nb
-        t = ctx.saved_tensors
-        nsv = 1 + 4 * nb - 1
-        sv, params = t[:nsv], t[nsv:]
-        be = ops.get_backend()
-        gcur = g.permute(0, 2, 3, 1)
-        if not gcur.is_contiguous():
-            gcur = gcur.contiguous()
-        grads = [None] * (4 * nb)
-        for i in range(nb - 1, -1, -1):
-            y, arg, mi = sv[1 + 4 * i], sv[2 + 4 * i], sv[3 + 4 * i]
-            xin = sv[0] if i == 0 else sv[4 * i]             # the pooled output of the block in front
-            w, gamma, beta = params[4 * i], params[4 * i + 1], params[4 * i + 2]
-            stride, slope = ctx.meta[i]
-            need_dx = i > 0 or ctx.needs_input_grad[0]
-            if need_dx and stride == 1 and tuple(w.shape) == (16, 16, 3, 3) and gcur.dtype == torch.float32:
-                dy, dx, dgamma, dbeta = be.img_conv16_tail_backward(gcur, arg, y, mi, gamma.detach(), beta.detach(), slope, w.detach())
-            else:
-                dy, dgamma, dbeta = be.img_block_backward(gcur, arg, y, mi, gamma.detach(), beta.detach(), slope, stride)
-                dx = be.img_conv16(dy, w.detach(), input_grad=True) if need_dx else None
-            grads[4 * i], grads[4 * i + 1], grads[4 * i + 2] = be.img_conv16_wgrad(xin, dy, w.detach()), dgamma, dbeta
-            gcur = dx
-        return (gcur.permute(0, 3, 1, 2) if gcur is not None and ctx.needs_input_grad[0] else None), None, None, *grads
-
-
-class _BwdLink:
-    """hand-off between two consecutive fp32 conv16 blocks of an encoder stack (see _Conv16Block.forward): the front block's saved
-    tensors for the back block's input-gradient kernel, and the BatchNorm-backward sums that kernel takes for the front block"""
-    __slots__ = ("prev", "dsums")
-
-    def __init__(self):
-        self.prev = self.dsums = None
+            dy, dgamma, dbeta = be.img_block_backward(g_nhwc, arg, y, mi, gamma.detach(), beta.detach(), ctx.slope, ctx.stride)
+            dx = be.img_conv16(dy, weight.detach(), input_grad=True).permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None
+        dW = be.img_conv16_wgrad(x_nhwc, dy, weight.detach())
+        return dx, dW, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def _conv16_ok(x, conv, blk_bf):
     """a 16 -> 16 or 16 -> 32 channel block on csrc/image_conv16.hip (I2P_NO_CONV16=1: MIOpen's convolutions instead; I2P_NO_CONV32=1:
-    only for the 16 -> 32 block).  fp32 storage by default; the bf16-storage kernels (v_mfma_f32_16x16x16_bf16) are opt-in with
-    I2P_CONV16_BF16=1: configs[2] 1151 -> 1185 samples/s, but their correctly rounded outputs (99.996 % of the elements = RNE of the
-    exact sum; MIOpen's bf16 igemm: 50 %) land this random-init encoder's pose at 9.9e-2 of the fp32 reference instead of 7.0e-2 —
-    outside the 8e-2 contract of tests/test_model_sized.py, which is why MIOpen keeps those layers in the bf16 storage mode."""
-    return (ops.get_backend().name == "hip" and x.is_cuda and x.dtype == (torch.bfloat16 if blk_bf else torch.float32)
-            and not (blk_bf and os.environ.get("I2P_CONV16_BF16") != "1")
+    only for the 16 -> 32 block).  fp32 storage only: bf16-storage variants of these kernels (v_mfma_f32_16x16x16_bf16) were built and
+    measured in round 4 (configs[2] 1151 -> 1185 samples/s) but their correctly rounded outputs land this random-init encoder's pose
+    at 9.9e-2 of the fp32 reference instead of 7.0e-2, outside the 8e-2 contract of tests/test_model_sized.py; MIOpen keeps those
+    layers in the bf16 storage mode and the variants were removed in round 5 (numbers: DESIGN.md section 4)."""
+    return (ops.get_backend().name == "hip" and x.is_cuda and x.dtype == torch.float32 and not blk_bf
             and conv.in_channels == 16 and conv.out_channels in (16, 32) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
             and x.shape[2] * x.shape[3] * 128 < 2 ** 31 and os.environ.get("I2P_NO_CONV16") != "1"
@@ -520,24 +427,8 @@ class _ImageCNN(nn.Sequential):
         out_bf = [blk_bf[j + 1] if j + 1 < nb else (bf and next_stack_bf) for j in range(nb)]
         return blk_bf, out_bf
 
-    def prefetch_first_stats(self, x):
-        """Issue the first block's batch statistics (csrc/image_first.hip: Gram matrix of the input windows + coefficients) on the
-        CURRENT stream, ahead of `forward(x)` — they depend on the images and the conv weights only, so the model runs them beside the
-        LiDAR pyramid.  Returns False (nothing issued) when `forward` would not take the fused first block."""
-        mods = list(self)
-        self._first_stats = None
-        if not (self._fast(mods) and USE_FUSED_IMG and x.dtype == torch.float32 and self._fusable(mods)):
-            return False
-        conv, bn, act, pool = mods[:4]
-        if not _first_block_ok(x, conv, act, pool, self._storage_plan(x, len(mods) // 4)[0][0]):
-            return False
-        self._first_stats = ops.get_backend().img_first_stats(x, conv.weight.detach(), bn.eps, bn.momentum, conv.bias.detach(),
-                                                              bn.running_mean, bn.running_var) + (x,)
-        return True
-
     def forward(self, x):
         mods = list(self)
-        pre, self._first_stats = getattr(self, "_first_stats", None), None
         # eval mode and the un-fused path run MIOpen's NHWC solvers like the fused path does (the model no longer converts rgb_img;
         # the fused first block reads the NCHW image through its strides)
         nhwc = lambda t: t.contiguous(memory_format=torch.channels_last) if (t.is_cuda and t.dim() == 4) else t
@@ -551,36 +442,11 @@ class _ImageCNN(nn.Sequential):
             blk_bf, out_bf = self._storage_plan(x, nb)
             if any(blk_bf):
                 ws = _CastBf16.apply(*[mods[i].weight for i in range(0, len(mods), 4)])
-            link = None                                         # _BwdLink of the previous block when it can hand over its statistics
-            skip_until = -1
             for j, i in enumerate(range(0, len(mods), 4)):
                 conv, bn, act, pool = mods[i:i + 4]
-                if j <= skip_until:
-                    continue
-                # a run of fp32 conv16 blocks (all but the last with 16 output channels, a stride-1 pool and an fp32 output) CAN run as one
-                # node whose forward kernels span the block boundaries (pooling of block k formed on load by the convolution of block
-                # k + 1, I2P_CONV_RUN=1).  Measured SLOWER, 10.97 / 11.02 against 10.92 / 10.92 ms per step: unlike the backward twin
-                # (i2p_img_conv_tail_bwd, which replaces a VALU-bound 65 us kernel) the 39 us pooling kernel it replaces costs less than
-                # the 12-for-14 column strips and the lost wave of occupancy cost the convolution — off by default
-                if (j > 0 and x.dtype == torch.float32 and not blk_bf[j] and _conv16_ok(x, conv, False)
-                        and os.environ.get("I2P_CONV_RUN") == "1" and os.environ.get("I2P_BWD_LINK") != "1"):
-                    e = j
-                    while (e + 1 < nb and not blk_bf[e + 1] and not out_bf[e] and mods[4 * e].out_channels == 16 and mods[4 * e + 3].stride == 1
-                           and mods[4 * (e + 1)].in_channels == 16 and _conv16_ok(x, mods[4 * (e + 1)], False)):
-                        e += 1
-                    if e > j:
-                        meta, params = [], []
-                        for q in range(j, e + 1):
-                            cq, bq, aq, pq = mods[4 * q:4 * q + 4]
-                            meta.append((pq.stride, bq.momentum, bq.eps, aq.negative_slope, bq.running_mean, bq.running_var))
-                            params += [cq.weight, bq.weight, bq.bias, cq.bias]
-                        x = _Conv16Run.apply(x, meta, out_bf[e], *params)
-                        skip_until, link = e, None
-                        continue
                 if j == 0 and _first_block_ok(x, conv, act, pool, blk_bf[0]):
-                    stats = pre[:2] if (pre is not None and pre[2] is x) else None      # (issued ahead by prefetch_first_stats)
                     x = _FirstBlock.apply(x, conv.weight, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
-                                          bn.momentum, bn.eps, act.negative_slope, out_bf[0], stats)
+                                          bn.momentum, bn.eps, act.negative_slope, out_bf[0])
                     continue
                 if j == 0:
                     x = x.contiguous(memory_format=torch.channels_last)
@@ -588,21 +454,9 @@ class _ImageCNN(nn.Sequential):
                 if x.dtype != want:
                     x = x.to(want)
                 if _conv16_ok(x, conv, blk_bf[j]):
-                    # fp32, 16 output channels, stride-1 pool, fp32 output, and the next block is a conv16 block too: its
-                    # BatchNorm-backward statistics CAN be taken by the next block's input-gradient kernel (I2P_BWD_LINK=1).  Measured
-                    # neutral (11.01 vs 10.99 ms per step: the gathers and the lost wave of occupancy cost the input-gradient
-                    # kernel 25 us, the statistics pass it replaces was 34): off by default
-                    nxt = mods[i + 4] if i + 4 < len(mods) else None
-                    linkable = (not blk_bf[j] and not out_bf[j] and conv.out_channels == 16 and pool.stride == 1 and nxt is not None
-                                and j + 1 < nb and not blk_bf[j + 1] and nxt.in_channels == 16 and nxt.out_channels in (16, 32)
-                                and (nxt.out_channels == 16 or os.environ.get("I2P_NO_CONV32") != "1")
-                                and os.environ.get("I2P_BWD_LINK") == "1" and torch.is_grad_enabled())
-                    link_out = _BwdLink() if linkable else None
-                    x = _Conv16Block.apply(x, ws[j] if blk_bf[j] else conv.weight, bn.weight, bn.bias, conv.bias, bn.running_mean,
-                                           bn.running_var, pool.stride, bn.momentum, bn.eps, act.negative_slope, out_bf[j], link, link_out)
-                    link = link_out
+                    x = _Conv16Block.apply(x, conv.weight, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
+                                           bn.momentum, bn.eps, act.negative_slope, out_bf[j])
                     continue
-                link = None
                 y = F.conv2d(x, ws[j] if blk_bf[j] else conv.weight, None, conv.stride, conv.padding)
                 x = _BnActPool.apply(y, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
                                      bn.momentum, bn.eps, act.negative_slope, out_bf[j])
@@ -894,7 +748,7 @@ class _MaxResponseFused(torch.autograd.Function):
 
 def max_response(pts, pix, valid):
     be = ops.get_backend()
-    if be.name == "hip" and pts.is_cuda and pts.dtype == torch.float32 and pix.dtype == torch.float32 and os.environ.get("I2P_NO_MAXRESP") != "1":
+    if be.name == "hip" and pts.is_cuda and pts.dtype == torch.float32 and pix.dtype == torch.float32:
         return _MaxResponseFused.apply(pts, pix, valid)
     return _MaxResponse.apply(pts, pix, valid)
 
@@ -1039,7 +893,7 @@ class CostVolume(nn.Module):
         valid = gidx[-1]
         w = mask_fill(w, valid)                                                 # :481
         be = ops.get_backend()
-        if (USE_FUSED_MLP and os.environ.get("I2P_NO_SMK") != "1" and be.device_type == "cuda" and be.name == "hip" and w.dtype == torch.float32 and 256 % w.shape[-1] == 0
+        if (USE_FUSED_MLP and be.device_type == "cuda" and be.name == "hip" and w.dtype == torch.float32 and 256 % w.shape[-1] == 0
                 and w.shape == nb_feat.shape):
             out = softmax_wsum_k(w, nb_feat)                                    # :483-487 in one launch each way
         else:
@@ -1143,7 +997,7 @@ class PoseHead(nn.Module):
         be = ops.get_backend()
         heads = (self.hidden_layer, self.quat_head, self.trans_head)
         if (USE_FUSED_MLP and be.name == "hip" and pooled.is_cuda and pooled.dtype == torch.float32 and all(h._plain for h in heads)
-                and isinstance(self.DP2, nn.Identity) and os.environ.get("I2P_NO_POSE_HEAD") != "1"
+                and isinstance(self.DP2, nn.Identity)
                 and _pose_head_fits(pooled.shape[0], pooled.shape[-1], self.hidden_layer.composed_module[0].out_channels)
                 and all(isinstance(h.composed_module[2], nn.Identity) for h in heads)):
             conv = lambda h: h.composed_module[0]

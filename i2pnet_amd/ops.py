@@ -53,7 +53,7 @@ class _ZeroArena:
     slices.  Slices live until the next `begin_step` on that device — i.e. for exactly one
     forward+backward; with no arena active (inference, unit tests) `zeros` is `torch.zeros`."""
     SIZE = 32 << 20
-    MAX_REQUEST = int(os.environ.get("I2P_ARENA_MAX", 512 << 10))   # larger requests: no measurable gain (A/B on one box)
+    MAX_REQUEST = 512 << 10         # larger requests: no measurable gain (A/B on one box)
 
     def __init__(self):
         self.buf = {}
@@ -171,44 +171,6 @@ def zero_scalar(device, dtype=torch.float32):
 begin_step = _arena.begin_step      # called by the trainer at the top of every forward+backward
 end_step = _arena.end
 zeros = _arena.zeros
-
-
-class _SideWgrad:
-    """Weight gradients of the small fused layers on a second HIP stream (a parallel branch of the captured hipGraph): a
-    layer's dgrad is the only kernel the next layer's backward waits for, its wgrad + partial reduction (2 of the 3 launches)
-    only has to be done when the gradients are packed.  Opt-in per backward pass (`side_wgrad_begin` / `side_wgrad_end`, the
-    trainer's job): between the two calls every tensor a side-stream launch touches is kept alive here, `end` makes the
-    calling stream wait for the side stream.  Only valid when every weight receives ONE gradient per backward pass (a second
-    contribution would be accumulated on the main stream without waiting)."""
-    active = False
-    stream = None
-    keep = []
-    used = False
-    # layers above this many activation elements (rows * max(cin, cout)) keep both halves on one stream: they are
-    # HBM-bound and fill the chip, running two of them side by side gains nothing
-    MAX_ELEMS = int(os.environ.get("I2P_SIDE_WGRAD_MAX", 160 << 20))
-
-
-def side_wgrad_begin(device):
-    device = torch.device(device)
-    # measured on MI355X, A/B of 60-step runs on one box: 577 samples/s with the side stream against 582 without — inside the
-    # captured graph the concurrent small kernels slow each other down (lin_wgrad 14 -> 37 us, reduce_partials 5 -> 9 us) by more
-    # than the critical path gains, like the two-branch experiment of model.py (I2P_OVERLAP).  OFF unless I2P_SIDE_WGRAD=1.
-    if device.type != "cuda" or os.environ.get("I2P_SIDE_WGRAD") != "1":
-        return False
-    if _SideWgrad.stream is None or _SideWgrad.stream.device != device:
-        _SideWgrad.stream = torch.cuda.Stream(device=device)
-    _SideWgrad.active, _SideWgrad.used = True, False
-    return True
-
-
-def side_wgrad_end():
-    """join: the current stream waits for the side stream's weight gradients; releases the tensors kept for them"""
-    if _SideWgrad.active:
-        _SideWgrad.active = False
-        if _SideWgrad.used:
-            torch.cuda.current_stream(_SideWgrad.stream.device).wait_stream(_SideWgrad.stream)
-        _SideWgrad.keep.clear()
 
 
 class CBackend:
@@ -409,7 +371,7 @@ class CBackend:
     def gather_rows_grad(self, grad_out, h_idx, w_idx, W, grad_feat):
         B, HW, Cc = grad_feat.shape
         Q = h_idx.shape[1]
-        if self.device_type == "cuda" and not os.environ.get("I2P_SCATTER_SCAN"):
+        if self.device_type == "cuda":
             # fixed-point accumulation on int64 atomics: order-independent => bitwise reproducible (scratch zeroed here)
             nbytes = _lib.helper("i2p_gather_rows_grad_fx_scratch", int(B), int(HW), int(Cc))
             scratch = zeros(nbytes, torch.uint8, grad_feat.device)
@@ -480,21 +442,9 @@ class CBackend:
         arg = torch.empty(B, Ho, Wo, Cc, dtype=torch.uint8, device=y.device)
         mean_invstd = torch.empty(2 * Cc, dtype=_F32, device=y.device)
         opt = lambda t, what: self._p(t, _F32, what) if t is not None else None
-        # statistics + finalisation (mean / invstd / running buffers) in one launch, the last block finalising: measured SLOWER
-        # (583 vs 598 samples/s, A/B on one box — returning fp64 atomics in every block and the last block's serial re-read of
-        # the 32 replica sums cost more than the 64-thread finalize launch they replace).  Opt-in: I2P_IMG_FIN=1.
-        if self.name == "hip" and os.environ.get("I2P_IMG_FIN") == "1":
-            sums = zeros(BN_REPLICAS * 2 * Cc + 1, torch.float64, y.device)      # (+1: the ticket word)
-            ticket = sums[BN_REPLICAS * 2 * Cc:].view(torch.int32)[:1]
-            self._call("i2p_img_bn_stats_fin", int(B), int(H), int(W), int(Cc), self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums"),
-                       self._p(ticket, torch.int32, "ticket"), float(eps), float(momentum), opt(conv_bias, "conv_bias"),
-                       opt(running_mean, "running_mean"), opt(running_var, "running_var"), self._p(mean_invstd, _F32, "mean_invstd"),
-                       stream=self._stream())
-            sums = None
-        else:
-            sums = self.bn_stats(y.view(B * H * W, Cc))
+        sums = self.bn_stats(y.view(B * H * W, Cc))
         self._call("i2p_img_bn_pool_fwd", int(B), int(H), int(W), int(Cc), int(stride), self._p(y, _F32, "y"),
-                   self._p(sums, torch.float64, "sums") if sums is not None else None, self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"),
+                   self._p(sums, torch.float64, "sums"), self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"),
                    float(eps), float(slope), float(momentum), opt(conv_bias, "conv_bias"),
                    opt(running_mean, "running_mean"), opt(running_var, "running_var"), self._p(out, _F32, "out"),
                    self._p(arg, torch.uint8, "arg"), self._p(mean_invstd, _F32, "mean_invstd"), stream=self._stream())
@@ -506,18 +456,12 @@ class CBackend:
         dy = torch.empty_like(y)
         dgamma = torch.empty(Cc, dtype=_F32, device=y.device)
         dbeta = torch.empty(Cc, dtype=_F32, device=y.device)
-        fin = self.name == "hip" and os.environ.get("I2P_IMG_FIN") == "1"
-        dsums = zeros(BN_REPLICAS * 2 * Cc + (1 if fin else 0), torch.float64, y.device)
-        args = (int(B), int(H), int(W), int(Cc), int(stride), self._p(gout, _F32, "gout"),
-                self._p(arg, torch.uint8, "arg"), self._p(y, _F32, "y"), self._p(mean_invstd, _F32, "mean_invstd"),
-                self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(slope),
-                self._p(dsums, torch.float64, "dsums"), self._p(dy, _F32, "dy"), self._p(dgamma, _F32, "dgamma"),
-                self._p(dbeta, _F32, "dbeta"))
-        if fin:
-            ticket = dsums[BN_REPLICAS * 2 * Cc:].view(torch.int32)[:1]
-            self._call("i2p_img_bn_pool_bwd_fin", *args, self._p(ticket, torch.int32, "ticket"), stream=self._stream())
-        else:
-            self._call("i2p_img_bn_pool_bwd", *args, stream=self._stream())
+        dsums = zeros(BN_REPLICAS * 2 * Cc, torch.float64, y.device)
+        self._call("i2p_img_bn_pool_bwd", int(B), int(H), int(W), int(Cc), int(stride), self._p(gout, _F32, "gout"),
+                   self._p(arg, torch.uint8, "arg"), self._p(y, _F32, "y"), self._p(mean_invstd, _F32, "mean_invstd"),
+                   self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(slope),
+                   self._p(dsums, torch.float64, "dsums"), self._p(dy, _F32, "dy"), self._p(dgamma, _F32, "dgamma"),
+                   self._p(dbeta, _F32, "dbeta"), stream=self._stream())
         return dy, dgamma, dbeta
 
     @staticmethod
@@ -527,7 +471,7 @@ class CBackend:
             raise RuntimeError(f"img_conv: weight must be [16|32,16,3,3] (got {tuple(weight.shape)})")
         return cin, cout
 
-    def img_conv16(self, x, weight, with_sums=False, input_grad=False, prev=None):
+    def img_conv16(self, x, weight, with_sums=False, input_grad=False):
         """3x3 convolution (padding 1, no bias) of x [B,H,W,cin] NHWC with weight [cout,cin,3,3] (any dense layout; (cin, cout) =
         (16, 16) or (16, 32)) on csrc/image_conv16.hip -> y [B,H,W,cout]; fp32 tensors, or bf16 tensors with a bf16 weight (bf16
         storage mode: bf16 MFMA, fp32 accumulation); with_sums: also the replicated fp64 {sum y, sum y^2} for
@@ -542,17 +486,6 @@ class CBackend:
         bf = int(dt == _BF16)
         ws = (C.c_int * 4)(*[int(v) for v in weight.stride()])
         y = torch.empty(B, H, W, cin if input_grad else cout, dtype=dt, device=x.device)
-        if input_grad and prev is not None:
-            # prev = (arg, y, mean_invstd, gamma, beta, slope) of the 16-channel stride-1 block in front: its BN-backward sums come back too
-            p_arg, p_y, p_mi, p_gamma, p_beta, p_slope = prev
-            if bf or cin != 16 or tuple(p_y.shape) != (B, H, W, 16) or tuple(p_arg.shape) != (B, H, W, 16):
-                raise RuntimeError("img_conv: `prev` needs fp32 tensors and a 16-channel block of the output's geometry")
-            dsums = zeros(BN_REPLICAS * 32, torch.float64, x.device)
-            self._call("i2p_img_conv_bwd_data_stats", int(B), int(H), int(W), cin, cout, self._p(x, dt, "dy"), C.c_void_p(weight.data_ptr()), ws,
-                       self._p(y, dt, "dx"), self._p(p_arg, torch.uint8, "prev arg"), self._p(p_y, _F32, "prev y"),
-                       self._p(p_mi, _F32, "prev mean_invstd"), self._p(p_gamma, _F32, "prev gamma"), self._p(p_beta, _F32, "prev beta"),
-                       float(p_slope), self._p(dsums, torch.float64, "prev dsums"), stream=self._stream())
-            return y, dsums
         if input_grad:
             self._call("i2p_img_conv_bwd_data", int(B), int(H), int(W), cin, cout, bf, self._p(x, dt, "dy"), C.c_void_p(weight.data_ptr()), ws,
                        self._p(y, dt, "dx"), stream=self._stream())
@@ -605,29 +538,6 @@ class CBackend:
                    self._p(mean_invstd, _F32, "mean_invstd"), stream=self._stream())
         return out, arg, mean_invstd
 
-    def img_conv_pool_forward(self, y, sums, gamma, beta, eps, slope, momentum, conv_bias, running_mean, running_var, weight):
-        """block tail (BatchNorm + LeakyReLU + MaxPool(3, 1, 1)) of a fp32 16-channel block from its conv output y [B,H,W,16] and replica
-        sums, and the next block's convolution with `weight` [16|32,16,3,3], in one kernel ->
-        (out [B,H,W,16], arg u8, mean_invstd [32], y_next [B,H,W,cout], sums_next)"""
-        cin, cout = self._conv_pair(weight)
-        B, H, W, Cc = y.shape
-        if Cc != 16 or y.dtype != _F32 or weight.dtype != _F32:
-            raise RuntimeError("img_conv_pool_forward: fp32 16-channel blocks only")
-        dev = y.device
-        out = torch.empty_like(y)
-        arg = torch.empty(B, H, W, 16, dtype=torch.uint8, device=dev)
-        mean_invstd = torch.empty(32, dtype=_F32, device=dev)
-        y_next = torch.empty(B, H, W, cout, dtype=_F32, device=dev)
-        sums_next = zeros(BN_REPLICAS * 2 * cout, torch.float64, dev)
-        ws = (C.c_int * 4)(*[int(v) for v in weight.stride()])
-        opt = lambda t, what: self._p(t, _F32, what) if t is not None else None
-        self._call("i2p_img_conv_pool_fwd", int(B), int(H), int(W), cout, self._p(y, _F32, "y"), self._p(sums, torch.float64, "sums"),
-                   self._p(gamma, _F32, "gamma"), self._p(beta, _F32, "beta"), float(eps), float(slope), float(momentum),
-                   opt(conv_bias, "conv_bias"), opt(running_mean, "running_mean"), opt(running_var, "running_var"), self._p(out, _F32, "out"),
-                   self._p(arg, torch.uint8, "arg"), self._p(mean_invstd, _F32, "mean_invstd"), C.c_void_p(weight.data_ptr()), ws,
-                   self._p(y_next, _F32, "y_next"), self._p(sums_next, torch.float64, "sums_next"), stream=self._stream())
-        return out, arg, mean_invstd, y_next, sums_next
-
     def img_conv16_tail_backward(self, g, arg, y, mean_invstd, gamma, beta, slope, weight):
         """backward of a fp32 16 -> 16 block with a stride-1 MaxPool from its incoming gradient g [B,H,W,16] ->
         (dy [B,H,W,16], dx [B,H,W,16], dgamma, dbeta): the block tail's statistics pass, then ONE kernel for the un-pooling, the
@@ -650,8 +560,8 @@ class CBackend:
         return dy, dx, dgamma, dbeta
 
     def img_block_backward(self, gout, arg, y, mean_invstd, gamma, beta, slope, stride, dsums=None):
-        """-> (dy [B,H,W,C] in y's storage type, dgamma [C], dbeta [C]); gout fp32 or bf16; `dsums` = the producer of gout took the
-        BatchNorm-backward sums already (img_conv16(..., prev=...)): only the dy launch"""
+        """-> (dy [B,H,W,C] in y's storage type, dgamma [C], dbeta [C]); gout fp32 or bf16; `dsums` = BatchNorm-backward replica sums
+        taken elsewhere already (i2p_img_block_bwd_stats): only the dy launch"""
         B, H, W, Cc = y.shape
         dy = torch.empty_like(y)
         dgamma = torch.empty(Cc, dtype=_F32, device=y.device)
@@ -961,7 +871,6 @@ class CBackend:
         rows, cout = gz.shape
         cin = x.shape[1]
         dev = gz.device
-        self.last_split = False
         if gz.dtype == _BF16:
             gz_in = torch.empty(rows, cin, dtype=x.dtype, device=dev) if need_gx else None
             in_dsums = (zeros(BN_REPLICAS * 2 * cin, torch.float64, dev) if (need_gx and in_coef is not None) else None)
@@ -985,26 +894,6 @@ class CBackend:
         P = lambda t, dt=_F32, n="t": (self._p(t, dt, n) if t is not None else None)
         n = part.numel()
         self.last_bn_grads = (part[n - cout:], part[n - 2 * cout:n - cout]) if out_coef is not None else None
-        self.last_split = False
-        if (_SideWgrad.active and need_gx and self.name == "hip" and self.device_type == "cuda" and rows * max(cin, cout) <= _SideWgrad.MAX_ELEMS
-                and _lib.helper("i2p_lin_bwd_splittable", int(rows), int(cin), int(cout), 1)):
-            # dgrad on the current stream, wgrad + partial reduction on the side stream (forked BEFORE the dgrad launch)
-            coef8 = torch.empty(8 * cout, dtype=_F32, device=dev) if out_coef is not None else None
-            args = (int(rows), int(cin), int(cout), P(gz, _F32, "gz"), P(y, _F32, "y"), P(out_coef, _F32, "out_coef"), P(out_mi, _F32, "out_mi"),
-                    P(out_dsums, torch.float64, "out_dsums"), P(x, _F32, "x"), P(in_coef, _F32, "in_coef"), P(in_mi, _F32, "in_mi"),
-                    float(slope_in), P(w, _F32, "w"))
-            cur, side = torch.cuda.current_stream(dev), _SideWgrad.stream
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            self._call("i2p_lin_bwd_part", *args, P(gz_in, _F32, "gz_in"), P(in_dsums, torch.float64, "in_dsums"), None, None,
-                       float(slope_out), 1, P(coef8, _F32, "coef"), stream=cur.cuda_stream)
-            side.wait_event(ev)
-            self._call("i2p_lin_bwd_part", *args, None, None, P(part, _F32, "dw_partial"), P(dw, _F32, "dw"), float(slope_out), 2, None,
-                       stream=side.cuda_stream)
-            _SideWgrad.keep.append((gz, y, out_coef, out_mi, out_dsums, x, in_coef, in_mi, w, part, dw, coef8))
-            _SideWgrad.used = True
-            self.last_split = True
-            return gz_in, in_dsums, dw
         self._call("i2p_lin_bwd", int(rows), int(cin), int(cout), P(gz, _F32, "gz"), P(y, _F32, "y"),
                    P(out_coef, _F32, "out_coef"), P(out_mi, _F32, "out_mi"), P(out_dsums, torch.float64, "out_dsums"),
                    P(x, _F32, "x"), P(in_coef, _F32, "in_coef"), P(in_mi, _F32, "in_mi"), float(slope_in),
@@ -1013,13 +902,8 @@ class CBackend:
         return gz_in, in_dsums, dw
 
     def after_wgrad(self, fn):
-        """run `fn()` (launches that consume the weight gradient of the LAST lin_backward) where that gradient is produced:
-        on the side stream when the call was split, else in place"""
-        if getattr(self, "last_split", False) and _SideWgrad.active:
-            with torch.cuda.stream(_SideWgrad.stream):
-                out = fn()
-            _SideWgrad.keep.append(out)
-            return out
+        """run `fn()` (launches that consume the weight gradient of the LAST lin_backward) where that gradient is produced — in place
+        (a side stream for the weight gradients was measured in round 3, 577 vs 582 samples/s, and removed in round 5)"""
         return fn()
 
     def take_bn_grads(self):
@@ -1112,7 +996,6 @@ class CBackend:
         rows, cout = gz.shape
         ca, cb = xa.shape[1], xb.shape[1]
         dev = gz.device
-        self.last_split = False
         gz_a = torch.empty(rows, ca, dtype=gz.dtype, device=dev); gz_b = torch.empty(rows, cb, dtype=gz.dtype, device=dev)
         ds_a = zeros(BN_REPLICAS * 2 * ca, torch.float64, dev)
         ds_b = zeros(BN_REPLICAS * 2 * cb, torch.float64, dev)

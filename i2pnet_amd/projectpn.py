@@ -174,7 +174,7 @@ class _PcRows(Function):
 
 def pc_rows_fusable(xyz, pts, feat):
     be = ops.get_backend()
-    return (os.environ.get("I2P_NO_PC_ROWS") != "1" and be.device_type == "cuda" and be.name == "hip" and xyz.dtype == torch.float32
+    return (be.device_type == "cuda" and be.name == "hip" and xyz.dtype == torch.float32
             and pts.dtype == torch.float32 and feat.dtype == torch.float32 and pts.shape[-1] % 4 == 0 and feat.shape[-1] % 4 == 0)
 
 
@@ -186,7 +186,7 @@ def pc_rows(xyz, pts, feat, h_idx, w_idx, K, W):
 
 def knn_rows_fusable(xyz, pix_xyz, pts, pix):
     be = ops.get_backend()
-    return (os.environ.get("I2P_NO_KNN_ROWS") != "1" and be.device_type == "cuda" and be.name == "hip" and not pix_xyz.requires_grad
+    return (be.device_type == "cuda" and be.name == "hip" and not pix_xyz.requires_grad
             and pts.dtype == torch.float32 and pix.dtype == torch.float32 and xyz.dtype == torch.float32)
 
 

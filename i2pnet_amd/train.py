@@ -130,7 +130,7 @@ STEP_KEYS = ("rgb", "lidar", "raw_point_xyz", "lidar_feats", "init_intrinsic", "
 
 class Trainer:
     def __init__(self, cfg=I2PNetConfig, device="cuda", lr=1e-3, clip=10.0, world_size=1, local_rank=0,
-                 seed=0, capturable=None, net_cls=RegNet_v2, call=None, side_wgrad=None, on_chain_error="raise"):
+                 seed=0, capturable=None, net_cls=RegNet_v2, call=None, on_chain_error="raise"):
         """`capturable` is accepted for compatibility and ignored (FlatAdam is always graph-safe).
         `net_cls` / `call`: another registration network with the same outputs (e.g. the small-range model,
         i2pnet_amd.small_range.RegNet_v2) and how to call it: call(net, batch, cfg) -> its output tuple.
@@ -190,10 +190,6 @@ class Trainer:
                                   weight_decay=0.0001)
         self.lr_gamma = 0.99                    # ExponentialLR(0.99) per epoch: call `epoch_end()`
         self._lr0 = lr
-        # side-stream weight gradients need every weight to receive ONE gradient per backward pass (ops._SideWgrad): true for the
-        # single-pass networks, not for the iterative model that applies the fine step six times
-        self.side_wgrad = (self.device.type == "cuda" and getattr(net_cls, "n_iters", 1) == 1 and call is None
-                           if side_wgrad is None else bool(side_wgrad))
         self._graph_a = self._graph_b = None
         self._static = None
         self._static_out = None
@@ -221,13 +217,7 @@ class Trainer:
                                                   batch["lidar_feats"], cfg=self.cfg)
         loss, real_loss, dual_loss = Get_loss(out3, out4, batch["decalib_real_gt"], batch["decalib_dual_gt"], sx, sq,
                                               cfg=self.cfg)
-        # weight gradients of the small fused layers on a side stream (a parallel branch of the captured graph), joined here
-        side = self.side_wgrad and ops.side_wgrad_begin(self.device)
-        try:
-            loss.backward()
-        finally:
-            if side:
-                ops.side_wgrad_end()
+        loss.backward()
         zero = self._zero
         grads = []
         if not self._mask_known:                # first step: which parameters does this loss reach at all? (host-side

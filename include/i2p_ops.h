@@ -232,16 +232,6 @@ int i2p_lin_bwd(long long rows, int cin, int cout, const float *gz, const float 
                 const float *out_coef, const float *out_mi, const double *out_dsums, const float *x,
                 const float *in_coef, const float *in_mi, float slope_in, const float *w, float *gz_in,
                 double *in_dsums, float *dw_partial, float *dw, float slope_out, void *stream);
-/* The two halves of i2p_lin_bwd as separate calls (same arguments): part 1 = input gradient only (gz_in, in_dsums; dw_partial / dw
- * unused, coef_scratch = 8*cout floats of scratch when out_coef is given), part 2 = weight gradient only (dw, dw_partial; gz_in /
- * in_dsums unused), part 3 = both.  The halves read the same operands and write disjoint outputs: a caller may issue them on two
- * streams so that the weight gradients leave the critical path of the backward pass.  i2p_lin_bwd_splittable: 1 if this shape has
- * separate dgrad / wgrad kernels (parts 1 and 2 accepted), 0 if it runs on the one-kernel first-generation path (part 3 only). */
-int i2p_lin_bwd_splittable(long long rows, int cin, int cout, int need_gx);
-int i2p_lin_bwd_part(long long rows, int cin, int cout, const float *gz, const float *y,
-                     const float *out_coef, const float *out_mi, const double *out_dsums, const float *x,
-                     const float *in_coef, const float *in_mi, float slope_in, const float *w, float *gz_in,
-                     double *in_dsums, float *dw_partial, float *dw, float slope_out, int part, float *coef_scratch, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Hamilton product out = a (x) b with broadcasting over the point axis (src/modules/warp_utils.py:25-55
@@ -288,14 +278,6 @@ int i2p_img_bn_pool_fwd(int B, int H, int W, int C, int stride, const float *y, 
                         const float *gamma, const float *beta, float eps, float slope, float momentum,
                         const float *conv_bias, float *running_mean, float *running_var, float *out,
                         unsigned char *arg, float *mean_invstd, void *stream);
-/* Device library only: the statistics pass of i2p_img_bn_pool_fwd with the finalisation done by its last block (sums: zeroed
- * [I2P_BN_REPLICAS][2C] doubles, ticket: one zeroed uint32) — call i2p_img_bn_pool_fwd with sums = NULL afterwards; and the backward
- * with dgamma / dbeta formed by the last block of its statistics kernel. */
-int i2p_img_bn_stats_fin(int B, int H, int W, int C, const float *y, double *sums, unsigned *ticket, float eps, float momentum,
-                         const float *conv_bias, float *running_mean, float *running_var, float *mean_invstd, void *stream);
-int i2p_img_bn_pool_bwd_fin(int B, int H, int W, int C, int stride, const float *gout, const unsigned char *arg, const float *y,
-                            const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums, float *dy,
-                            float *dgamma, float *dbeta, unsigned *ticket, void *stream);
 int i2p_img_bn_pool_bwd(int B, int H, int W, int C, int stride, const float *gout, const unsigned char *arg,
                         const float *y, const float *mean_invstd, const float *gamma, const float *beta,
                         float slope, double *dsums, float *dy, float *dgamma, float *dbeta, void *stream);
@@ -322,19 +304,11 @@ int i2p_img_block_pool(int B, int H, int W, int C, int stride, int y_bf16, int o
  * [I2P_BN_REPLICAS][2 cout] zeroed by the caller, receives sum y / sum y^2 per channel for i2p_img_block_pool.  H*W*128 < 2^31.
  * wgrad: dW (cout*cin*9 floats) is written in w's layout; partials: f32 [i2p_img_conv_wgrad_rows(B,H,W)][(cout/16)*2304] scratch
  * (block sums, added in fp64 in a fixed order: reproducible run to run, unlike the atomically accumulated split-K kernels it replaces).
- * bf16 = 1 (bf16 storage mode, BASELINE configs[2] / [4]): x, w, y / dy, dx / dW are bf16 bits; forward and input gradient run on
- * v_mfma_f32_16x16x16_bf16 (fp32 accumulation, y rounded RNE, sums taken from the rounded y), the weight gradient widens its loads
- * to fp32. */
+ * bf16 must be 0: bf16-storage variants were measured in round 4 and removed in round 5 (outside the bf16 pose contract); the
+ * argument stays in the signatures and is rejected with I2P_ERR_BAD_ARG. */
 int i2p_img_conv_fwd(int B, int H, int W, int cin, int cout, int bf16, const void *x, const void *w, const int *ws, void *y, double *sums,
                      void *stream);
 int i2p_img_conv_bwd_data(int B, int H, int W, int cin, int cout, int bf16, const void *dy, const void *w, const int *ws, void *dx, void *stream);
-/* fp32 i2p_img_conv_bwd_data that ALSO takes the BatchNorm-backward sums of the 16-channel, pool-stride-1 block whose pooled output is
- * this convolution's input (what it writes IS that block's incoming gradient): prev_* = that block's arg-max, conv output,
- * mean_invstd, gamma, beta, slope; prev_dsums f64 [I2P_BN_REPLICAS][32] zeroed by the caller.  Follow with i2p_img_block_bwd_dx
- * (= i2p_img_block_bwd without its statistics pass) for that block. */
-int i2p_img_conv_bwd_data_stats(int B, int H, int W, int cin, int cout, const float *dy, const float *w, const int *ws, float *dx,
-                                const unsigned char *prev_arg, const float *prev_y, const float *prev_mean_invstd, const float *prev_gamma,
-                                const float *prev_beta, float prev_slope, double *prev_dsums, void *stream);
 int i2p_img_block_bwd_dx(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout, const unsigned char *arg,
                          const void *y, const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums, void *dy,
                          float *dgamma, float *dbeta, void *stream);
@@ -348,12 +322,6 @@ int i2p_img_block_bwd_stats(int B, int H, int W, int C, int stride, int y_bf16, 
 int i2p_img_conv_tail_bwd(int B, int H, int W, const float *g, const unsigned char *arg, const float *y, const float *mean_invstd,
                           const float *gamma, const float *beta, float slope, const double *dsums, const float *w, const int *ws, float *dy,
                           float *dx, float *dgamma, float *dbeta, void *stream);
-/* Forward twin of i2p_img_conv_tail_bwd: i2p_img_block_pool of a fp32 16-channel block with a stride-1 MaxPool (out, arg, mean_invstd,
- * running buffers: bit-identical) AND i2p_img_conv_fwd of the next block (y_next [B,H,W,cout], sums_next zeroed by the caller) in one
- * kernel: the pooled rows are formed on load in front of the MFMAs. */
-int i2p_img_conv_pool_fwd(int B, int H, int W, int cout, const float *y, const double *sums, const float *gamma, const float *beta, float eps,
-                          float slope, float momentum, const float *conv_bias, float *running_mean, float *running_var, float *out,
-                          unsigned char *arg, float *mean_invstd, const float *w, const int *ws, float *y_next, double *sums_next, void *stream);
 int i2p_img_conv_wgrad_rows(int B, int H, int W);
 int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, int bf16, const void *x, const void *dy, const int *ws, float *partials, void *dW,
                        void *stream);
@@ -693,6 +661,12 @@ int i2p_mask_fill(long long rows, int c, const float *x, const float *valid, flo
 int i2p_pad_cols(int rows, int c, int cpad, const float *w, float *out, void *stream);
 int i2p_strided_pick2(int B, int H, int W, int oh, int ow, int sh, int sw, const float *a, const float *b, float *oa, float *ob,
                       void *stream);
+
+/* Measurement hook (bench.py's roofline object): with i2p_ktime_enable(1) the launchers of wreg_bwd_fused_kernel (fp32) and
+ * bwd_fused_bf16_kernel bracket the kernel alone with HIP events on the launch stream; i2p_ktime_last_us() waits for the last
+ * bracketed launch and returns its duration in microseconds (-1 if none).  Not for use inside a stream capture. */
+int i2p_ktime_enable(int on);
+float i2p_ktime_last_us(void);
 
 #ifdef __cplusplus
 }

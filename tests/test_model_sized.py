@@ -107,22 +107,21 @@ def _digest_report(gold, acts, prefix, pick):
     return rep
 
 
-HEAD_GRAD_TOL = 3e-3
-
-
-def _grad_norm_check(gold, model, grad_tol, rgb_tol, head_tol=HEAD_GRAD_TOL):
+def _grad_norm_check(gold, model, grad_tol, rgb_tol):
     """same rule as tests/test_model_golden.py::_check: as close to the fp64 value as the reference's own fp32 gradient
     is (x4), and within `grad_tol` where the reference is well-conditioned.
-    `head_tol` (pose-head tensors, l3_head.* / l4_head.*): dL/dq reaches the quaternion branch through normalise_q, i.e. as the
-    tangential residual of a unit quaternion, which magnifies a forward difference about 200x.  Two legitimate fp32 evaluations of the
-    encoder's first convolution (MIOpen's sequential igemm accumulation, which the CPU-generated fixture happens to share, and the
-    4-products-per-step MFMA accumulation of csrc/image_first.hip: first-block outputs 3e-7 apart) land the level-4 pose 4.5e-6 and
-    8.0e-6 from the fixture and the norm of l4_head.quat_head's weight gradient 6.8e-5 and 1.75e-3 from its fp64 value (batch 16;
-    tools/first_block_parity.py, tools/diag_first_grads.py, profiles/r04_first_block_parity.txt); translation-head and level-3
-    tensors stay below 1e-4."""
+    Pose-head tensors (l3_head.* / l4_head.*): dL/dq reaches the quaternion branch through normalise_q, i.e. as the tangential
+    residual of a unit quaternion, which magnifies a forward difference about 200x.  How far a LEGITIMATE fp32 evaluation of the
+    reference lands from fp64 on these tensors is measured, not assumed: fixtures with `grad_norm_alt` carry a second fp32
+    evaluation of the reference itself with the first convolution's 27 terms summed in another order (tools/gen_golden.py
+    run_sized; what a different convolution algorithm — MIOpen solver, the MFMA kernel of csrc/image_first.hip — amounts to).
+    At batch 16 that alone moves the norm of l4_head.quat_head's weight gradient from 7.5e-5 to 1.80e-3 of its fp64 value (ours:
+    1.80e-3), while translation-head and level-3 tensors stay below 1e-4.  The limit of a tensor is therefore
+    max(grad_tol, 4 x module floor, 1.5 x the larger of the two reference evaluations' distances from fp64) — no widened constant."""
     params = dict(model.named_parameters())
     gn = dict(zip(gold["grad_keys"].tolist(), gold["grad_norm"].tolist()))
     g64 = dict(zip(gold["grad_keys"].tolist(), gold["grad_norm64"].tolist()))
+    galt = dict(zip(gold["grad_keys"].tolist(), gold["grad_norm_alt"].tolist())) if "grad_norm_alt" in gold.files else {}
     floor = {}
     for k in params:
         if gn[k] > 1e-4 and g64[k] > 0.0:
@@ -143,7 +142,9 @@ def _grad_norm_check(gold, model, grad_tol, rgb_tol, head_tol=HEAD_GRAD_TOL):
         err = abs(g - g64[k]) / g64[k]
         if k.startswith(("l3_head", "l4_head")):
             _grad_norm_check.head_worst = max(getattr(_grad_norm_check, "head_worst", (0.0, None)), (err, k))
-        tol_k = rgb_tol if k.startswith("RGB_net") else (max(grad_tol, head_tol) if k.startswith(("l3_head", "l4_head")) else grad_tol)
+        tol_k = rgb_tol if k.startswith("RGB_net") else grad_tol
+        if k.startswith(("l3_head", "l4_head")) and k in galt:
+            tol_k = max(tol_k, 1.5 * max(abs(gn[k] - g64[k]), abs(galt[k] - g64[k])) / g64[k])
         score = err / max(4 * fl, tol_k)
         checked += 1
         if score > worst:

@@ -279,15 +279,11 @@ def test_row_unitvar_parity(oracle_backend, hip_backend):
         assert torch.allclose(rg, hg.cpu(), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("fin", [False, True])
 @pytest.mark.parametrize("stride,C,H,W", [(1, 16, 37, 53), (2, 16, 37, 53), (2, 32, 24, 40), (1, 64, 12, 20), (2, 128, 24, 78)])
-def test_img_bn_pool_parity(oracle_backend, hip_backend, stride, C, H, W, fin, monkeypatch):
+def test_img_bn_pool_parity(oracle_backend, hip_backend, stride, C, H, W):
     """image-encoder block tail: HIP vs oracle (arg-max bit-exact away from ties, values 1e-5) and vs
-    torch's batch_norm -> leaky_relu -> max_pool2d on the GPU (gradient of the conv output).  `fin`: the variant whose statistics
-    kernels finalise in their last block (i2p_img_bn_stats_fin / i2p_img_bn_pool_bwd_fin, opt-in)."""
+    torch's batch_norm -> leaky_relu -> max_pool2d on the GPU (gradient of the conv output)."""
     import torch.nn.functional as F
-    if fin:
-        monkeypatch.setenv("I2P_IMG_FIN", "1")
     g = torch.Generator().manual_seed(C + stride)
     B = 3
     y = torch.randn(B, H, W, C, generator=g) * 2 + 0.3
@@ -1030,41 +1026,6 @@ def test_knn_rows_matches_gather_mul_cat(hip_backend, B, N, M, K, C):
         assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-6
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("rows,cin,cout", [(14592, 64, 128), (14848, 256, 128), (58368, 136, 128), (4133, 32, 64)])
-def test_lin_bwd_split_halves_match_whole(hip_backend, monkeypatch, rows, cin, cout):
-    """i2p_lin_bwd_part: dgrad half (part 1, launch stream) + wgrad half (part 2, side stream) against the one-call backward:
-    bit-identical gz_in / statistics / dW / BN gradients (same kernels, same operands)."""
-    from i2pnet_amd import ops
-    g = torch.Generator(device=DEV).manual_seed(rows)
-    x = torch.randn(rows, cin, generator=g, device=DEV); w = torch.randn(cout, cin, generator=g, device=DEV) / cin ** 0.5
-    gi = torch.ones(cin, device=DEV); bi = torch.zeros(cin, device=DEV); go = torch.ones(cout, device=DEV); bo = torch.zeros(cout, device=DEV)
-    in_coef, in_mi = hip_backend.bn_finalize(rows, hip_backend.bn_stats(x), gi, bi, 1e-5)
-    y, ys = hip_backend.lin_forward(x, in_coef, 0.1, w)
-    oc, omi = hip_backend.bn_finalize(rows, ys, go, bo, 1e-5)
-    gz = torch.randn(rows, cout, generator=g, device=DEV)
-    ods = hip_backend.bn_act_backward_stats(gz, y, omi, go, bo, 1.0)
-
-    def run(split):
-        if split:
-            monkeypatch.setenv("I2P_SIDE_WGRAD", "1")
-            assert ops.side_wgrad_begin(DEV)
-        try:
-            gzin, ids, dw = hip_backend.lin_backward(gz, y, oc, omi, ods, x, in_coef, in_mi, 0.1, w)
-            dg, db = hip_backend.take_bn_grads()
-            assert hip_backend.last_split == split
-        finally:
-            if split:
-                ops.side_wgrad_end()
-                monkeypatch.delenv("I2P_SIDE_WGRAD")
-        torch.cuda.synchronize()
-        return gzin.clone(), ids.clone(), dw.clone(), dg.clone(), db.clone()
-    whole, halves = run(False), run(True)
-    for a, b, name in zip(whole, halves, ("gz_in", "in_dsums", "dw", "dgamma", "dbeta")):
-        assert torch.equal(a, b), name
-
-
-# ---- device-only fused entries against the CPU ORACLE chain they replace (not against another HIP path) ----------------------
 def _on_oracle(oracle_backend, fn):
     from i2pnet_amd import ops
     prev = ops.set_backend(oracle_backend)

@@ -1,5 +1,5 @@
 """FPS at the small-range model's sizes: time per launch and per dependent iteration.
-    python tools/bench_fps.py      (I2P_FPS_GEN=1 selects the first-generation kernel)"""
+    python tools/bench_fps.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from i2pnet_amd.pointnet2_utils import furthest_point_sample

@@ -1,4 +1,4 @@
-"""kNN at the model's sizes: time per launch (I2P_KNN_GEN=1 selects the first-generation kernel)."""
+"""kNN at the model's sizes: time per launch ."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from i2pnet_amd import ops

@@ -57,6 +57,19 @@ def main():
         print(f"{name:44s} {t:8.1f} us  {nbytes / t / 1e3:7.0f} GB/s  = {nbytes / t / 1e3 / 8000:5.2f} of 8 TB/s   ({nbytes / 1e6:7.1f} MB algorithmic)", flush=True)
 
     want = lambda k: (not a.only) or k in a.only.split(",")
+    if a.only and "cal" in a.only.split(","):
+        # calibration of the PMC byte counters (tools/pmc_r05_bf16.py): kernels whose HBM traffic is known exactly on this tensor —
+        # bwd_stats_bf16_kernel reads gz and y [rows,128] bf16 and writes nothing; pair_fwd_ps_kernel writes y [rows,128] bf16 and reads ~nothing
+        yv, gz = rnd(rows, 128).to(BF), rnd(rows, 128, sc=0.1).to(BF)
+        oc, omi = coef(128, dev, 6)
+        for _ in range(10):
+            be.bn_act_backward_stats_bf16(gz, yv, oc, omi, 1.0)
+        f, gg, bn_, bk_, w = rnd(B, N, 128), rnd(B, M, 128), rnd(B, N, 128), rnd(B, M, 128), rnd(128, 128, sc=128 ** -0.5)
+        for _ in range(10):
+            be.pair_lin_forward(f, gg, bn_, bk_, w, out_dtype=BF)
+        torch.cuda.synchronize()
+        print("calibration launches done")
+        return
     if want("lin"):
         for cin, cout in ((128, 64), (64, 64)):
             x = rnd(rows, cin).to(BF); yv = rnd(rows, cout).to(BF); gz = rnd(rows, cout, sc=0.1).to(BF)
