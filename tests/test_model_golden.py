@@ -215,21 +215,6 @@ def test_iterative_model_vs_reference_gpu():
     assert _rel(out3, gold["out3"]) < 5e-4
 
 
-@pytest.mark.gpu
-def test_two_stream_branches_match_single_stream(monkeypatch):
-    """model.OVERLAP_BRANCHES (image encoder and LiDAR pyramid on two HIP streams; off by default, measured slower)
-    must not change results: same golden outputs as the single-stream order (eager forward; the captured training
-    step with the option on is what the A/B in DESIGN.md §7 timed)."""
-    from i2pnet_amd import model as M
-    gold = np.load(GOLD / "model_kitti_iter.npz")
-    monkeypatch.setattr(M, "OVERLAP_BRANCHES", False)
-    _, a3, a4 = _run_iter("cuda")
-    monkeypatch.setattr(M, "OVERLAP_BRANCHES", True)
-    _, b3, b4 = _run_iter("cuda")
-    assert _rel(b4, gold["out4"]) < 1e-4 and _rel(b3, gold["out3"]) < 5e-4
-    assert _rel(b4, a4) < 1e-5 and _rel(b3, a3) < 1e-5
-
-
 def _run_train_mode(device):
     """one TRAIN-mode step of the main model against the reference (fixture: tools/gen_golden.py train — the reference
     module in .train(), dropout probability 0): image-encoder BatchNorm2d layers on batch statistics + running-buffer
