@@ -557,7 +557,7 @@ def kernel_rooflines_bf16(B, device, N=228):
     w = rnd(C, C) / C ** 0.5
     f = rnd(B, N, C); gk = rnd(B, M, C); bn = rnd(B, N, C); bk = rnd(B, M, C)
     t_pf = _event_time_us(lambda: hip.pair_lin_forward(f, gk, bn, bk, w, out_dtype=bf), 10)
-    others.append(entry("pair_fwd_ps_kernel (first cost-volume layer forward: pixel tile stationary, output bf16)", rows * C * 2, t_pf))
+    others.append(entry("pair_fwd3_bf16_kernel (first cost-volume layer forward: 32-pixel strip shared by the four waves of a block, output bf16)", rows * C * 2, t_pf))
     y1, s1 = hip.pair_lin_forward(f, gk, bn, bk, w, out_dtype=bf)
     c1, m1 = hip.bn_finalize(rows, s1, gam(C), bet(C), 1e-5)
     gz1 = (rnd(rows, C) * 0.1).to(bf)

@@ -53,3 +53,22 @@ __device__ __forceinline__ int bf_swz(int row, int cps) {
     return cps >= 4 ? (row & 15) : ((row >> (4 - cps)) & ((1 << cps) - 1));
 }
 __device__ __forceinline__ int bf_chunk(int row, int c, int cps) { return (row << cps) + (c ^ bf_swz(row, cps)); }
+
+// BN-backward constants of the BN BEHIND a layer, formed in the consumer kernel's prologue from the replicated fp64 sums (what the
+// 64-thread launch bnbwd_coef_bf16 of mlp_bf16.hip computes; the same arithmetic in the same order, so the constants are
+// bit-identical): dsums [REP][2c] = {sum gz, sum gz * xhat}, coef [3][c] = mean, scale, beta, mi [2][c] = mean, invstd.
+// out8 (block 0 only, may be null): rows 6, 7 of the [8][c] scratch tail = dbeta, dgamma for the caller.
+struct BnBwdSrc { const double *dsums; const float *coef, *mi; long long rows; float *out8; int c; };
+__device__ __forceinline__ void bn_bwd_consts(const BnBwdSrc &s, int ch, float &gA, float &gB, float &gC) {
+    // all 64 loads first (one round trip), then the sums in replica order
+    double d0[I2P_BN_REPLICAS], d1[I2P_BN_REPLICAS];
+#pragma unroll
+    for (int r = 0; r < I2P_BN_REPLICAS; ++r) { d0[r] = s.dsums[(size_t)r * 2 * s.c + ch]; d1[r] = s.dsums[(size_t)r * 2 * s.c + s.c + ch]; }
+    double sd = 0.0, sx = 0.0;
+#pragma unroll
+    for (int r = 0; r < I2P_BN_REPLICAS; ++r) { sd += d0[r]; sx += d1[r]; }
+    const float m1 = (float)(sd / (double)s.rows), m2 = (float)(sx / (double)s.rows);
+    const float sc = s.coef[s.c + ch], mu = s.mi[ch], is = s.mi[s.c + ch];
+    gA = sc; gB = -(sc * m2) * is; gC = -(sc * m1) - gB * mu;
+    if (s.out8 && blockIdx.x == 0) { s.out8[6 * s.c + ch] = (float)sd; s.out8[7 * s.c + ch] = (float)sx; }
+}

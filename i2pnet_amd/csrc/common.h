@@ -141,17 +141,19 @@ int i2p_wreg_wgrad_bf16(long long rows, int cin, int cout, const unsigned short 
                         void *stream, const unsigned short *xb = nullptr, const float *in_coef_b = nullptr, float slope_b = 1.f);
 // input gradient + weight gradient of a bf16-storage layer with 64 output channels from ONE read of gz / y / x (csrc/mlp_bwd_fused_bf16.hip)
 bool i2p_bwd_fused_bf16_ok(long long rows, int cin, int cout);
-int i2p_bwd_fused_bf16(long long rows, int cin, int cout, const unsigned short *gz, const unsigned short *y, const float *g_coef,
-                       const unsigned short *x, const float *in_coef, const float *in_mi, float slope_in, const float *w,
+int i2p_bwd_fused_bf16(long long rows, int cin, int cout, const unsigned short *gz, const unsigned short *y, const double *out_dsums,
+                       const float *out_coef, const float *out_mi, float *coef8, const unsigned short *x, const float *in_coef, const float *in_mi, float slope_in, const float *w,
                        unsigned short *gz_in, double *in_dsums, float *dw_partial, unsigned grid, void *stream);
 // second-generation bf16 pair-layer backward (csrc/pair_bwd_bf16.hip): d_f / d_g / d_bn / d_bk accumulate into the caller's zeroed
 // outputs, dw_partial[grid][128*128] is reduced by the caller
 bool i2p_pair_bwd2_bf16_ok(int B, int N, int M, int cin, int cout);
 int i2p_pair_bwd2_bf16_grid(int B, int N, int M);
-int i2p_pair_bwd2_bf16(int B, int N, int M, const unsigned short *gz, const unsigned short *y, const float *g_coef, const float *f,
+int i2p_pair_bwd2_bf16(int B, int N, int M, const unsigned short *gz, const unsigned short *y, const double *out_dsums, const float *out_coef,
+                       const float *out_mi, float *coef8, const float *f,
                        const float *g, const float *w, float *d_f, float *d_g, float *d_bn, float *d_bk, float *dw_partial, void *stream);
 bool i2p_bwd_fused2_bf16_ok(long long rows, int cin_a, int cin_b, int cout);
-int i2p_bwd_fused2_bf16(long long rows, const unsigned short *gz, const unsigned short *y, const float *g_coef, const unsigned short *xa,
+int i2p_bwd_fused2_bf16(long long rows, const unsigned short *gz, const unsigned short *y, const double *out_dsums, const float *out_coef,
+                        const float *out_mi, float *coef8, const unsigned short *xa,
                         const float *coef_a, const float *mi_a, float slope_a, const unsigned short *xb, const float *coef_b,
                         const float *mi_b, float slope_b, const unsigned short *e_add, const float *w, unsigned short *gz_a,
                         double *sums_a, unsigned short *gz_b, double *sums_b, float *dw_partial, unsigned grid, void *stream);
@@ -162,3 +164,7 @@ int i2p_bwd_fused2_bf16(long long rows, const unsigned short *gz, const unsigned
 // not usable inside a stream capture.  Defined in csrc/optim.hip.
 void i2p_ktime_begin(hipStream_t st);
 void i2p_ktime_end(hipStream_t st);
+// first cost-volume layer forward, bf16 output, a strip shared by the four waves of a block (csrc/pair_fwd_bf16.hip)
+bool i2p_pair_fwd3_bf16_ok(int B, int N, int M, int cin, int cout);
+int i2p_pair_fwd3_bf16(int B, int N, int M, const float *f, const float *g, const float *bias_n, const float *bias_k, const float *w,
+                       unsigned short *y, double *sums, void *stream);

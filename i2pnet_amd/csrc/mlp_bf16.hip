@@ -322,163 +322,6 @@ __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Pair-mode forward with the PIXEL TILE STATIONARY (first cost-volume layer, 128 -> 128, bf16 output):
-//   y[(b,n,k), :] = bf16( (f[b,n,:] * g[b,k,:]) . W^T + bias_n[b,n,:] + bias_k[b,k,:] )
-// rg_fwd_kernel<4,false,PAIR> walks the rows (b,n,k) in memory order and re-reads, for EVERY 32-row strip, the fp32 pixel
-// rows g (16 KB), the two bias row sets (32 KB) and the point factors from L2: 52 16-byte loads per lane per strip against
-// 8 for a plain bf16 layer — it ran at 0.16 of the HBM rate of its only real traffic, the 256 B/row output.  Here a wave owns
-// (sample, 32-pixel tile, chunk of points) and walks the POINTS: its pixel rows of g and bias_k are loaded once into
-// registers (lane = (pixel, k-half): exactly the lanes' B-operand / accumulator slices of v_mfma_f32_32x32x16_bf16 in the
-// transposed formulation D[cout][pixel] = W . X'^T), the per-point rows f[b,n,:] / bias_n[b,n,:] (1 KB) go through a
-// double-buffered wave-private LDS row pair, the product is formed in fp32 and rounded straight into the operand registers
-// (same arithmetic as rg_fwd_kernel: bf16(f*g), fp32 accumulate, statistics of the rounded outputs).  Per strip: 2 global
-// loads per lane, 32 MFMAs, one 8 KB coalesced store.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int PS_C = 128, PS_NT = 4, PS_KS = 8;
-struct PairPsP {
-    int B, N, M, KT, NCH, PCH;           // pixel tiles per sample, point chunks per sample, points per chunk
-    const float *f, *g, *bias_n, *bias_k, *w;
-    bf16_t *y;
-    double *sums;
-};
-
-__global__ __launch_bounds__(RG_THREADS, 1) void pair_fwd_ps_kernel(PairPsP p) {
-    extern __shared__ uint4 smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int CPS = 4;                                       // 16 chunks of 8 channels per row
-    uint4 *Ws = smem;                                            // [128][16] bf16 chunks
-    uint4 *Ss = smem + (PS_C << CPS) + wave * (RG_ROWS << CPS);  // this wave's output strip (32 rows x 16 chunks)
-    float4 *Fs = reinterpret_cast<float4 *>(smem + (PS_C << CPS) + 4 * (RG_ROWS << CPS)) + wave * 128;   // [2 buffers][f row 32 float4 | bias_n row 32 float4]
-    stage_weights(Ws, p.w, PS_C, PS_C, PS_C, 16, CPS, false, PS_C, tid);
-    __syncthreads();                                             // the only block barrier
-
-    const int n = lane & 31, h = lane >> 5;
-    const int wrow0 = w_perm(n);
-    const long long ntask = (long long)p.B * p.KT * p.NCH;
-    double ssum[8], ssq[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { ssum[q] = 0.0; ssq[q] = 0.0; }
-    const int oc = lane & 15;                                    // this lane's output chunk in the store phase
-
-    for (long long task = (long long)blockIdx.x * 4 + wave; task < ntask; task += (long long)gridDim.x * 4) {
-        const int ch = (int)(task % p.NCH);
-        const int kt = (int)((task / p.NCH) % p.KT);
-        const int b = (int)(task / ((long long)p.NCH * p.KT));
-        const int k0 = kt * RG_ROWS, nvalid = min(RG_ROWS, p.M - k0);
-        const int n_lo = ch * p.PCH, n_hi = min(p.N, n_lo + p.PCH);
-        if (n_lo >= n_hi) continue;
-        // ---- stationary: this lane's pixel row of g (its 64 contraction channels) and of bias_k (its 64 output channels)
-        float gv[PS_KS][8], bk[PS_NT][16];
-        {
-            const bool ok = n < nvalid;
-            const float *gr = p.g + ((size_t)b * p.M + k0 + (ok ? n : 0)) * PS_C;
-            const float *br = p.bias_k + ((size_t)b * p.M + k0 + (ok ? n : 0)) * PS_C;
-#pragma unroll
-            for (int ks = 0; ks < PS_KS; ++ks) {
-                const float4 a = *reinterpret_cast<const float4 *>(gr + (2 * ks + h) * 8), c = *reinterpret_cast<const float4 *>(gr + (2 * ks + h) * 8 + 4);
-                gv[ks][0] = ok ? a.x : 0.f; gv[ks][1] = ok ? a.y : 0.f; gv[ks][2] = ok ? a.z : 0.f; gv[ks][3] = ok ? a.w : 0.f;
-                gv[ks][4] = ok ? c.x : 0.f; gv[ks][5] = ok ? c.y : 0.f; gv[ks][6] = ok ? c.z : 0.f; gv[ks][7] = ok ? c.w : 0.f;
-            }
-#pragma unroll
-            for (int t = 0; t < PS_NT; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 v = *reinterpret_cast<const float4 *>(br + t * 32 + 16 * h + 4 * j);
-                    bk[t][4 * j] = ok ? v.x : 0.f; bk[t][4 * j + 1] = ok ? v.y : 0.f; bk[t][4 * j + 2] = ok ? v.z : 0.f; bk[t][4 * j + 3] = ok ? v.w : 0.f;
-                }
-        }
-        // per-point rows: lanes 0..31 fetch f[b,n,:] (32 float4), lanes 32..63 bias_n[b,n,:]; double-buffered in LDS
-        auto fetch_pt = [&](int pn) -> float4 {
-            const float *src = (h == 0 ? p.f : p.bias_n) + ((size_t)b * p.N + pn) * PS_C + n * 4;
-            return *reinterpret_cast<const float4 *>(src);
-        };
-        float4 nxt = fetch_pt(n_lo);
-        Fs[0 * 64 + lane] = nxt;
-        if (n_lo + 1 < n_hi) nxt = fetch_pt(n_lo + 1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int pn = n_lo; pn < n_hi; ++pn) {
-            const int buf = (pn - n_lo) & 1;
-            const float4 *Fr = Fs + buf * 64, *Br = Fs + buf * 64 + 32;
-            // next point's rows into the other buffer (their loads were issued a point ago), the one after that in flight
-            if (pn + 1 < n_hi) Fs[(buf ^ 1) * 64 + lane] = nxt;
-            if (pn + 2 < n_hi) nxt = fetch_pt(pn + 2);
-            // ---- B operands: bf16(f * g) for this lane's (pixel, k-half) ------------------------------------------
-            i2p_bf16x8 xb[PS_KS];
-#pragma unroll
-            for (int ks = 0; ks < PS_KS; ++ks) {
-                const float4 f0 = Fr[(2 * ks + h) * 2], f1 = Fr[(2 * ks + h) * 2 + 1];
-                float pr[8] = {gv[ks][0] * f0.x, gv[ks][1] * f0.y, gv[ks][2] * f0.z, gv[ks][3] * f0.w,
-                               gv[ks][4] * f1.x, gv[ks][5] * f1.y, gv[ks][6] * f1.z, gv[ks][7] * f1.w};
-                xb[ks] = __builtin_bit_cast(i2p_bf16x8, bf_pack8(pr));
-            }
-            // ---- accumulators start at bias_k (+ bias_n added after the MFMAs, as rg_fwd_kernel does) ---------------
-            i2p_f32x16 acc[PS_NT];
-#pragma unroll
-            for (int t = 0; t < PS_NT; ++t)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[t][e] = bk[t][e];
-#pragma unroll
-            for (int t = 0; t < PS_NT; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 v = Br[(t * 32 + 16 * h) / 4 + j];
-                    acc[t][4 * j] += v.x; acc[t][4 * j + 1] += v.y; acc[t][4 * j + 2] += v.z; acc[t][4 * j + 3] += v.w;
-                }
-#pragma unroll
-            for (int ks = 0; ks < PS_KS; ++ks) {
-                const int kc = 2 * ks + h;
-#pragma unroll
-                for (int t = 0; t < PS_NT; ++t) {
-                    const i2p_bf16x8 wa = __builtin_bit_cast(i2p_bf16x8, Ws[bf_chunk(t * 32 + wrow0, kc, CPS)]);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb[ks], acc[t], 0, 0, 0);
-                }
-            }
-            // ---- fragments -> the wave's strip as bf16 rows (lane (n,h): channels t*32 + 16h + [0,16) of pixel row n) ----
-#pragma unroll
-            for (int t = 0; t < PS_NT; ++t) {
-                const int co = t * 32 + 16 * h;
-                float lo8[8], hi8[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { lo8[q] = acc[t][q]; hi8[q] = acc[t][8 + q]; }
-                Ss[bf_chunk(n, (co >> 3), CPS)] = bf_pack8(lo8);
-                Ss[bf_chunk(n, (co >> 3) + 1, CPS)] = bf_pack8(hi8);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- coalesced read-back: statistics of the ROUNDED values, 16-byte stores (rows k0 .. k0+nvalid-1 of point pn) ----
-            const size_t yrow0 = ((size_t)b * p.N + pn) * p.M + k0;
-            float s1[8], s2[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = (lane + 64 * u) >> 4;
-                if (r < nvalid) {
-                    const uint4 v = Ss[bf_chunk(r, oc, CPS)];
-                    float fq[8]; bf_unpack8(v, fq);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { s1[q] += fq[q]; s2[q] = __builtin_fmaf(fq[q], fq[q], s2[q]); }
-                    st_u4_stream(p.y + (yrow0 + r) * PS_C + oc * 8, v);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { ssum[q] += (double)s1[q]; ssq[q] += (double)s2[q]; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
-    if (p.sums) {       // lanes with equal (lane & 15) own the same 8 channels
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            double a = ssum[q], c = ssq[q];
-            for (int off = 32; off >= 16; off >>= 1) { a += __shfl_xor(a, off); c += __shfl_xor(c, off); }
-            if (lane < 16) {
-                double *rep = p.sums + (size_t)((blockIdx.x * 4 + wave) % REP) * 2 * PS_C;
-                atomicAdd(rep + oc * 8 + q, a); atomicAdd(rep + PS_C + oc * 8 + q, c);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // dgrad on the same strip machinery: input image = g^y = BN-backward(gz, y2) of the layer BEHIND formed on load
 // (K = that layer's output channels), weights transposed, output = dL/dz of the layer in front (bf16, activation
 // derivative + BN-backward statistics in the store phase, optionally split over two destination tensors with a
@@ -1382,14 +1225,10 @@ int bwd_impl(long long rows, int cin, int cout, const bf16_t *gz, const bf16_t *
     if (gz_in && !pow2_16_128(cin)) return I2P_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)i2p_lin_bwd_bf16_grid(rows);
-    float *g_coef = nullptr;
-    if (out_coef) {
-        g_coef = dw_partial + (size_t)grid * cout * cin;
-        hipLaunchKernelGGL(bnbwd_coef_bf16, dim3((cout + 63) / 64), dim3(64), 0, st, rows, cout, out_dsums, out_coef, out_mi, g_coef);
-    }
+    float *g_coef = out_coef ? dw_partial + (size_t)grid * cout * cin : nullptr;    // [8][cout] scratch tail; rows 6, 7 = dbeta, dgamma for the caller
     if (gz_in && gz_in_bf16 && x_bf16 && !two && out_coef && in_coef && slope_out == 1.f && grid == 256 && i2p_bwd_fused_bf16_ok(rows, cin, cout)) {
         // 64-output-channel layer on many rows: dgrad + wgrad from one read of gz / y / x (csrc/mlp_bwd_fused_bf16.hip)
-        const int rc = i2p_bwd_fused_bf16(rows, cin, cout, gz, y, g_coef, reinterpret_cast<const bf16_t *>(x), in_coef, in_mi, slope_in, w,
+        const int rc = i2p_bwd_fused_bf16(rows, cin, cout, gz, y, out_dsums, out_coef, out_mi, g_coef, reinterpret_cast<const bf16_t *>(x), in_coef, in_mi, slope_in, w,
                                           reinterpret_cast<bf16_t *>(gz_in), in_dsums, dw_partial, grid, stream);
         if (rc) return rc;
         const int n = cout * cin;
@@ -1399,7 +1238,7 @@ int bwd_impl(long long rows, int cin, int cout, const bf16_t *gz, const bf16_t *
     if (gz_in && gz_in_bf16 && x_bf16 && two && out_coef && in_coef && two->coef_b && two->mi_b && two->e_add && two->gz_b && in_dsums && two->dsums_b &&
         slope_out == 1.f && grid == 256 && i2p_bwd_fused2_bf16_ok(rows, two->split, cin - two->split, cout)) {
         // the two-source 64 + 64 -> 128 layer on many rows: one pass over gz / y / xa / xb / e_add (csrc/mlp_bwd_fused_bf16.hip)
-        const int rc = i2p_bwd_fused2_bf16(rows, gz, y, g_coef, reinterpret_cast<const bf16_t *>(x), in_coef, in_mi, slope_in, two->xb, two->coef_b,
+        const int rc = i2p_bwd_fused2_bf16(rows, gz, y, out_dsums, out_coef, out_mi, g_coef, reinterpret_cast<const bf16_t *>(x), in_coef, in_mi, slope_in, two->xb, two->coef_b,
                                            two->mi_b, two->slope_b, two->e_add, w, reinterpret_cast<bf16_t *>(gz_in), in_dsums, two->gz_b,
                                            two->dsums_b, dw_partial, grid, stream);
         if (rc) return rc;
@@ -1407,6 +1246,8 @@ int bwd_impl(long long rows, int cin, int cout, const bf16_t *gz, const bf16_t *
         hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
         I2P_RETURN_LAUNCH_STATUS();
     }
+    // (the one-pass kernels above form the BN-backward constants in their prologues; the two-kernel forms take them from this launch)
+    if (out_coef) hipLaunchKernelGGL(bnbwd_coef_bf16, dim3((cout + 63) / 64), dim3(64), 0, st, rows, cout, out_dsums, out_coef, out_mi, g_coef);
     if (gz_in) {
         DgradP q{};
         q.rows = rows; q.kdim = cout; q.cout = cin; q.ncx = cout / 8; q.cpi_s = log2i(q.ncx); q.cpo_s = log2i(cin / 8);
@@ -1483,27 +1324,9 @@ extern "C" int i2p_pair_lin_fwd_bf16(int B, int N, int M, int cin, int cout, con
                                      const float *bias_n, const float *bias_k, const float *w, bf16_t *y, double *sums,
                                      void *stream) {
     if (B <= 0 || N <= 0 || M <= 0 || (cin & 7) || cin > 128 || !f || !g || !bias_n || !bias_k) return I2P_ERR_BAD_ARG;
-    const char *no_ps = getenv("I2P_NO_PAIR_PS");                    // (read per call: the tests compare the two kernels in one process)
-    if (cin == PS_C && cout == PS_C && w && y && !(no_ps && no_ps[0] == '1')) {       // pixel-tile-stationary kernel (see pair_fwd_ps_kernel)
-        PairPsP p;
-        p.B = B; p.N = N; p.M = M; p.KT = (M + RG_ROWS - 1) / RG_ROWS;
-        // ~4000 wave tasks (sample, pixel tile, point chunk): a task reloads 64 KB of stationary rows, so chunks stay >= 8 points
-        int nch = 4000 / (B * p.KT > 0 ? B * p.KT : 1);
-        if (nch < 1) nch = 1;
-        p.PCH = (N + nch - 1) / nch; if (p.PCH < 8) p.PCH = N < 8 ? N : 8;
-        p.NCH = (N + p.PCH - 1) / p.PCH;
-        p.f = f; p.g = g; p.bias_n = bias_n; p.bias_k = bias_k; p.w = w; p.y = y; p.sums = sums;
-        const size_t bytes = ((size_t)(PS_C << 4) + 4 * (RG_ROWS << 4)) * sizeof(uint4) + 4 * 128 * sizeof(float4);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pair_fwd_ps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        const long long ntask = (long long)B * p.KT * p.NCH;
-        long long grid = (ntask + 3) / 4; if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(pair_fwd_ps_kernel, dim3((unsigned)grid), dim3(RG_THREADS), bytes, (hipStream_t)stream, p);
-        I2P_RETURN_LAUNCH_STATUS();
-    }
+    if (w && y && i2p_pair_fwd3_bf16_ok(B, N, M, cin, cout))                 // strip shared by the block's four waves (csrc/pair_fwd_bf16.hip)
+        return i2p_pair_fwd3_bf16(B, N, M, f, g, bias_n, bias_k, w, y, sums, stream);
+    // (few rows: the row-order kernel; a pixel-tile-stationary single-wave form, 0.27 of 8 TB/s, was superseded by pair_fwd3 in round 5)
     return fwd_impl((long long)B * N * M, cin, cout, g, 0, cin, nullptr, 0, 0, nullptr, 1.f, nullptr, 1.f, w, y, sums, f, bias_n,
                     bias_k, N, M, stream);
 }
@@ -1554,8 +1377,7 @@ extern "C" int i2p_pair_lin_bwd_bf16(int B, int N, int M, int cin, int cout, con
         // 128 x 128 on many rows: persistent blocks over 32-pixel strips, three strips in flight per wave (csrc/pair_bwd_bf16.hip)
         const unsigned galloc = (unsigned)i2p_pair_lin_bwd_bf16_grid(B, N, M), g2 = (unsigned)i2p_pair_bwd2_bf16_grid(B, N, M);
         float *g_coef = dw_partial + (size_t)galloc * cout * cin;
-        hipLaunchKernelGGL(bnbwd_coef_bf16, dim3((cout + 63) / 64), dim3(64), 0, st, (long long)B * N * M, cout, out_dsums, out_coef, out_mi, g_coef);
-        const int rc = i2p_pair_bwd2_bf16(B, N, M, gz, y, g_coef, f, g, w, d_f, d_g, d_bias_n, d_bias_k, dw_partial, stream);
+        const int rc = i2p_pair_bwd2_bf16(B, N, M, gz, y, out_dsums, out_coef, out_mi, g_coef, f, g, w, d_f, d_g, d_bias_n, d_bias_k, dw_partial, stream);
         if (rc) return rc;
         const int nel = cout * cin;
         hipLaunchKernelGGL(reduce_partials_bf16, dim3((nel + 31) / 32), dim3(256), 0, st, (int)g2, nel, dw_partial, dw);

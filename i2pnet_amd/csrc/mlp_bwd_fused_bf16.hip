@@ -37,7 +37,7 @@ constexpr int FB_K = 64;                 // output channels of the layer (= chan
 struct FusedBwdBf16P {
     long long rows;
     const bf16_t *gz, *y;        // [rows, 64]
-    const float *g_coef;         // [6][64] m1, m2, scale, mean, invstd, beta of the BN behind
+    BnBwdSrc g;                  // the BN behind: replica sums + finalised coefficients (constants formed in the prologue)
     const bf16_t *x;             // [rows, C] pre-BN tensor in front
     const float *e_coef, *e_mi;  // [3][C] mean, scale, beta; [2][C] mean, invstd
     float e_slope;
@@ -127,10 +127,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void bwd_fused_bf16_kernel(FusedBwdB
         Ws[ch8(prow, kc)] = bf_pack8(f);
     }
     if (tid < FB_K) {
-        const int ch = tid, K = FB_K;
-        const float m1 = p.g_coef[ch], m2 = p.g_coef[K + ch], sc = p.g_coef[2 * K + ch], mu = p.g_coef[3 * K + ch], is = p.g_coef[4 * K + ch];
-        const float gB = -(sc * m2) * is;
-        tab[ch] = sc; tab[64 + ch] = gB; tab[128 + ch] = -(sc * m1) - gB * mu;
+        const int ch = tid;
+        float gA, gB, gC;
+        bn_bwd_consts(p.g, ch, gA, gB, gC);
+        tab[ch] = gA; tab[64 + ch] = gB; tab[128 + ch] = gC;
     }
     if (tid < C) {
         const int ch = tid;
@@ -395,7 +395,7 @@ static_assert(F2_AT >= F2_ROWS * F2_PW, "the packed D strip re-uses the transpos
 struct Fused2P {
     long long rows;              // multiple of 16
     const bf16_t *gz, *y;        // [rows, 128]
-    const float *g_coef;         // [6][128]
+    BnBwdSrc g;                  // the BN behind (128 channels)
     const bf16_t *xa, *xb;       // [rows, 64] pre-BN tensors of the two sources
     const float *coef_a, *mi_a, *coef_b, *mi_b;
     float slope_a, slope_b;
@@ -439,9 +439,9 @@ __global__ __launch_bounds__(FB_THREADS, 1) void bwd_fused2_bf16_kernel(Fused2P 
     }
     if (tid < F2_K) {
         const int ch = tid, K = F2_K;
-        const float m1 = p.g_coef[ch], m2 = p.g_coef[K + ch], sc = p.g_coef[2 * K + ch], mu = p.g_coef[3 * K + ch], is = p.g_coef[4 * K + ch];
-        const float gB = -(sc * m2) * is;
-        tab[ch] = sc; tab[K + ch] = gB; tab[2 * K + ch] = -(sc * m1) - gB * mu;
+        float gA, gB, gC;
+        bn_bwd_consts(p.g, ch, gA, gB, gC);
+        tab[ch] = gA; tab[K + ch] = gB; tab[2 * K + ch] = gC;
         const bool b = ch >= F2_H;
         const float *cf = b ? p.coef_b : p.coef_a, *mi = b ? p.mi_b : p.mi_a;
         const int c = b ? ch - F2_H : ch;
@@ -690,13 +690,14 @@ bool i2p_bwd_fused_bf16_ok(long long rows, int cin, int cout) {
     return rows >= 65536 && cout == FB_K && (cin == 64 || cin == 128) && (unsigned long long)rows * 128ull * 2ull < (1ull << 32);
 }
 
-int i2p_bwd_fused_bf16(long long rows, int cin, int cout, const unsigned short *gz, const unsigned short *y, const float *g_coef,
+int i2p_bwd_fused_bf16(long long rows, int cin, int cout, const unsigned short *gz, const unsigned short *y, const double *out_dsums,
+                       const float *out_coef, const float *out_mi, float *coef8,
                        const unsigned short *x, const float *in_coef, const float *in_mi, float slope_in, const float *w,
                        unsigned short *gz_in, double *in_dsums, float *dw_partial, unsigned grid, void *stream) {
-    if (!i2p_bwd_fused_bf16_ok(rows, cin, cout) || !gz || !y || !g_coef || !x || !in_coef || !in_mi || !w || !gz_in || !dw_partial || grid == 0)
+    if (!i2p_bwd_fused_bf16_ok(rows, cin, cout) || !gz || !y || !out_dsums || !out_coef || !out_mi || !x || !in_coef || !in_mi || !w || !gz_in || !dw_partial || grid == 0)
         return I2P_ERR_BAD_ARG;
     FusedBwdBf16P p;
-    p.rows = rows; p.gz = gz; p.y = y; p.g_coef = g_coef; p.x = x; p.e_coef = in_coef; p.e_mi = in_mi; p.e_slope = slope_in; p.w = w;
+    p.rows = rows; p.gz = gz; p.y = y; p.g = BnBwdSrc{out_dsums, out_coef, out_mi, rows, coef8, FB_K}; p.x = x; p.e_coef = in_coef; p.e_mi = in_mi; p.e_slope = slope_in; p.w = w;
     p.gz_in = gz_in; p.sums = in_dsums; p.dw_partial = dw_partial;
     hipStream_t st = (hipStream_t)stream;
     return cin == 128 ? launch<128>(p, grid, st) : launch<64>(p, grid, st);
@@ -708,15 +709,16 @@ bool i2p_bwd_fused2_bf16_ok(long long rows, int cin_a, int cin_b, int cout) {
     return rows >= 65536 && (rows % F2_ROWS) == 0 && cout == F2_K && cin_a == F2_H && cin_b == F2_H && (unsigned long long)rows * 128ull * 2ull < (1ull << 32);
 }
 
-int i2p_bwd_fused2_bf16(long long rows, const unsigned short *gz, const unsigned short *y, const float *g_coef, const unsigned short *xa,
+int i2p_bwd_fused2_bf16(long long rows, const unsigned short *gz, const unsigned short *y, const double *out_dsums, const float *out_coef,
+                        const float *out_mi, float *coef8, const unsigned short *xa,
                         const float *coef_a, const float *mi_a, float slope_a, const unsigned short *xb, const float *coef_b,
                         const float *mi_b, float slope_b, const unsigned short *e_add, const float *w, unsigned short *gz_a,
                         double *sums_a, unsigned short *gz_b, double *sums_b, float *dw_partial, unsigned grid, void *stream) {
-    if (!gz || !y || !g_coef || !xa || !xb || !coef_a || !mi_a || !coef_b || !mi_b || !e_add || !w || !gz_a || !gz_b || !sums_a || !sums_b ||
+    if (!gz || !y || !out_dsums || !out_coef || !out_mi || !xa || !xb || !coef_a || !mi_a || !coef_b || !mi_b || !e_add || !w || !gz_a || !gz_b || !sums_a || !sums_b ||
         !dw_partial || grid == 0 || (rows % F2_ROWS))
         return I2P_ERR_BAD_ARG;
     Fused2P p;
-    p.rows = rows; p.gz = gz; p.y = y; p.g_coef = g_coef; p.xa = xa; p.xb = xb; p.coef_a = coef_a; p.mi_a = mi_a; p.coef_b = coef_b; p.mi_b = mi_b;
+    p.rows = rows; p.gz = gz; p.y = y; p.g = BnBwdSrc{out_dsums, out_coef, out_mi, rows, coef8, F2_K}; p.xa = xa; p.xb = xb; p.coef_a = coef_a; p.mi_a = mi_a; p.coef_b = coef_b; p.mi_b = mi_b;
     p.slope_a = slope_a; p.slope_b = slope_b; p.e_add = e_add; p.w = w; p.gz_a = gz_a; p.gz_b = gz_b; p.sums_a = sums_a; p.sums_b = sums_b;
     p.dw_partial = dw_partial;
     constexpr size_t bytes = (size_t)F2_WS + 4 * (size_t)F2_WAVE + F2_TAB;

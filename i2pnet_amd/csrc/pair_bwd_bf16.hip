@@ -48,7 +48,7 @@ struct PairBwd2P {
     int B, N, M, KT;
     long long S;                 // strips = B * KT * N
     const bf16_t *gz, *y;        // [B*N*M, 128]
-    const float *g_coef;         // [6][128] m1, m2, scale, mean, invstd, beta
+    BnBwdSrc gsrc;               // the BN behind: replica sums + finalised coefficients
     const float *f, *g, *w;      // [B,N,128], [B,M,128], [128 co][128 ci]
     float *d_f, *d_g, *d_bn, *d_bk, *dw_partial;
 };
@@ -99,9 +99,7 @@ __global__ __launch_bounds__(P2_THREADS, 2) void pair_bwd2_bf16_kernel(PairBwd2P
     float gA[2], gB[2], gC[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int ch = 2 * c2 + u, K = P2_C;
-        const float m1 = p.g_coef[ch], m2 = p.g_coef[K + ch], sc = p.g_coef[2 * K + ch], mu = p.g_coef[3 * K + ch], is = p.g_coef[4 * K + ch];
-        gA[u] = sc; gB[u] = -(sc * m2) * is; gC[u] = -(sc * m1) - gB[u] * mu;
+        bn_bwd_consts(p.gsrc, 2 * c2 + u, gA[u], gB[u], gC[u]);
     }
     // MFMA role: input-channel tile `wave` (output-channel tile `wave` for the two pixel-axis sums), lane (n, h)
     const int n = lane & 31, h = lane >> 5;
@@ -326,12 +324,13 @@ int i2p_pair_bwd2_bf16_grid(int B, int N, int M) {
     return (int)(S < 512 ? S : 512);
 }
 
-int i2p_pair_bwd2_bf16(int B, int N, int M, const unsigned short *gz, const unsigned short *y, const float *g_coef, const float *f,
+int i2p_pair_bwd2_bf16(int B, int N, int M, const unsigned short *gz, const unsigned short *y, const double *out_dsums, const float *out_coef,
+                       const float *out_mi, float *coef8, const float *f,
                        const float *g, const float *w, float *d_f, float *d_g, float *d_bn, float *d_bk, float *dw_partial, void *stream) {
-    if (!gz || !y || !g_coef || !f || !g || !w || !d_f || !d_g || !d_bn || !d_bk || !dw_partial) return I2P_ERR_BAD_ARG;
+    if (!gz || !y || !out_dsums || !out_coef || !out_mi || !f || !g || !w || !d_f || !d_g || !d_bn || !d_bk || !dw_partial) return I2P_ERR_BAD_ARG;
     PairBwd2P p;
     p.B = B; p.N = N; p.M = M; p.KT = (M + P2_PX - 1) / P2_PX; p.S = (long long)B * p.KT * N;
-    p.gz = gz; p.y = y; p.g_coef = g_coef; p.f = f; p.g = g; p.w = w; p.d_f = d_f; p.d_g = d_g; p.d_bn = d_bn; p.d_bk = d_bk; p.dw_partial = dw_partial;
+    p.gz = gz; p.y = y; p.gsrc = BnBwdSrc{out_dsums, out_coef, out_mi, (long long)B * N * M, coef8, P2_C}; p.f = f; p.g = g; p.w = w; p.d_f = d_f; p.d_g = d_g; p.d_bn = d_bn; p.d_bk = d_bk; p.dw_partial = dw_partial;
     const size_t bytes = (size_t)P2_WT_BYTES + 2 * (size_t)P2_BUF_BYTES;
     static bool attr_set = false;
     if (!attr_set) {

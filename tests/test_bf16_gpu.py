@@ -118,25 +118,26 @@ def test_pair_lin_fwd_bf16(C, Co):
     assert torch.allclose(_sums(sums)[0], y.double().sum(0), rtol=1e-6, atol=1e-3)
 
 
-@pytest.mark.parametrize("B,N,M", [(2, 228, 468), (3, 19, 33), (1, 7, 500)])
-def test_pair_fwd_pixel_stationary_matches_row_order_kernel(B, N, M, monkeypatch):
-    """pair_fwd_ps_kernel (pixel tile stationary, points walked) against rg_fwd_kernel<4,false,PAIR> (rows in memory order):
-    same products, same accumulation order -> bit-identical bf16 output; statistics equal up to fp64 summation order.
-    Covers partial pixel tiles (M % 32), point chunks that do not divide N and M < 64."""
+@pytest.mark.parametrize("B,N,M", [(2, 228, 468), (3, 190, 33), (1, 600, 75), (16, 228, 468), (1, 500, 40)])
+def test_pair_fwd_shared_strip_matches_row_order_kernel(B, N, M, monkeypatch):
+    """pair_fwd3_bf16_kernel (>= 16384 rows: the strip of 32 pixels shared by the block's four waves) against
+    rg_fwd_kernel<4,false,PAIR>: same products, same accumulation order -> bit-identical bf16 output; statistics equal up to
+    summation order and equal to the sums of the stored values.  Partial pixel tiles, ranges crossing several pixel tiles, M < 32."""
     hip = _hip()
     C = Co = 128
+    assert B * N * M >= 16384
     f, g = _rnd(B, N, C, seed=11), _rnd(B, M, C, seed=12)
     bn, bk = _rnd(B, N, Co, seed=13), _rnd(B, M, Co, seed=14)
     w = _rnd(Co, C, seed=15, scale=C ** -0.5)
     y1, s1 = hip.pair_lin_forward(f, g, bn, bk, w, out_dtype=BF)
-    monkeypatch.setenv("I2P_NO_PAIR_PS", "1")
+    monkeypatch.setenv("I2P_NO_PAIR_FWD3", "1")
     y0, s0 = hip.pair_lin_forward(f, g, bn, bk, w, out_dtype=BF)
-    monkeypatch.delenv("I2P_NO_PAIR_PS")
+    monkeypatch.delenv("I2P_NO_PAIR_FWD3")
     torch.cuda.synchronize()
     assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)), float((y1.float() - y0.float()).abs().max())
-    # (per-lane fp32 partial sums over the rows of a strip before the fp64 accumulation: the two kernels group rows differently)
     assert torch.allclose(_sums(s1), _sums(s0), rtol=1e-5, atol=1e-2)
-    assert torch.allclose(_sums(s1)[0], y1.double().sum(0), rtol=1e-6, atol=1e-3)
+    yd = y1.double()
+    assert torch.allclose(_sums(s1)[0], yd.sum(0), rtol=1e-6, atol=1e-3) and torch.allclose(_sums(s1)[1], (yd * yd).sum(0), rtol=1e-6, atol=1e-3)
 
 
 def _g_of(gz, y, coef, mi, dsums_rep, rows, slope_out):

@@ -10,3 +10,4 @@ tail -1 /tmp/prof_$tag.log | cut -c1-200
 trace=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
 mkdir -p gpurun_out
 python tools/steady_stats.py "$trace" --warmup 5 --steps 4 --top 70 --out gpurun_out/${tag}_steady_kernel_stats.csv --train-steps 10 --tail-out gpurun_out/${tag}_roofline_section_kernel_stats.csv
+python tools/step_sequence.py "$trace" 7 > gpurun_out/${tag}_step_sequence.txt 2>&1

@@ -59,7 +59,7 @@ def main():
     want = lambda k: (not a.only) or k in a.only.split(",")
     if a.only and "cal" in a.only.split(","):
         # calibration of the PMC byte counters (tools/pmc_r05_bf16.py): kernels whose HBM traffic is known exactly on this tensor —
-        # bwd_stats_bf16_kernel reads gz and y [rows,128] bf16 and writes nothing; pair_fwd_ps_kernel writes y [rows,128] bf16 and reads ~nothing
+        # bwd_stats_bf16_kernel reads gz and y [rows,128] bf16 and writes nothing; pair_fwd3_bf16_kernel writes y [rows,128] bf16 and reads ~nothing
         yv, gz = rnd(rows, 128).to(BF), rnd(rows, 128, sc=0.1).to(BF)
         oc, omi = coef(128, dev, 6)
         for _ in range(10):
