@@ -141,7 +141,7 @@ def _mlp_chain_entry(B, device):
             "bytes_per_launch_algorithmic": by, "mfma_TFLOPs": round(fl / t_chain / 1e6, 1), "timed_as": "20 launches per hipGraph replay"}
 
 
-PMC_JSON = ROOT / "profiles" / "r04_pmc_traffic.json"            # written by tools/pmc_r04.sh on the round's final kernels
+PMC_JSON = ROOT / "profiles" / "r05_pmc_traffic.json"            # written by tools/pmc_r05.sh on the round's final kernels
 PMC_BF16_JSON = ROOT / "profiles" / "r05_pmc_bf16_traffic.json"   # {kernel: {"bytes_per_row": ...}}, tools/pmc_bf16_json.py
 
 

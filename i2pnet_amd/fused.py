@@ -95,8 +95,10 @@ def chain_bf16_ok(x, first_bn, weights):
     return all(_p2(W.shape[0]) for W in weights)
 
 
-def _rep_sum(dsums, c):
-    return dsums.view(ops.BN_REPLICAS, 2, c).sum(0)
+def _rep_sum(dsums, c, dtype=None):
+    """[2, c] sums over the replicas; dtype=torch.float32: the cast happens inside the one reduction launch (the fp64 replica values
+    are each rounded to fp32 first: 6e-8 relative, far below the 1e-3 gradient contract; sum + two casts were three launches)"""
+    return dsums.view(ops.BN_REPLICAS, 2, c).sum(0, dtype=dtype)
 
 
 def _update_running(running, idx, mi, rows):
@@ -409,17 +411,17 @@ class _CvPiTail(Function):
         gz4, ds4, dW5 = be_.lin_backward(gz5, y5, c5, m5, ds5, y4, c4, m4, s4, d(W5)); dg5, db5 = be_.take_bn_grads()
         gze, dse, gz3, ds3, dW4 = be_.lin_backward_2src(gz4, y4, c4, m4, ds4, ye, ce, me, se, y3, c3, m3, s3, ga3, d(W4))
         dg4, db4 = be_.take_bn_grads()
-        re = _rep_sum(dse, ye.shape[1])
+        re = _rep_sum(dse, ye.shape[1], torch.float32)
         gz2, ds2, dW3 = be_.lin_backward(gz3, y3, c3, m3, ds3, y2, c2, m2, s2, d(W3)); dg3, db3 = be_.take_bn_grads()
         gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2)); dg2, db2 = be_.take_bn_grads()
-        r1 = _rep_sum(ds1, y1.shape[1])
+        r1 = _rep_sum(ds1, y1.shape[1], torch.float32)
         # first layer: BN backward of bn1 formed on load inside the pair kernel
         d_f, d_g, d_bn, d_bk, dW1 = be_.pair_lin_backward(gz1, f, g, W1, y=y1, out_coef=c1, out_mi=m1, out_dsums=ds1)
         # position encoding: k-/n-sums of dL/dye in closed form from one pass over gz_e
         d_en, d_ek = be_.pair_bias_bn_backward(B, N, M, gze, enc_n, enc_k, dse, ce, me)
         return (d_f, d_g, d_bn, d_bk, dW1, d_en, d_ek, None, None,
-                f32(r1[1]), f32(r1[0]), dW2, dg2, db2, dW3, dg3, db3,
-                f32(re[1]), f32(re[0]), dW4, dg4, db4, dW5, dg5, db5)
+                r1[1], r1[0], dW2, dg2, db2, dW3, dg3, db3,
+                re[1], re[0], dW4, dg4, db4, dW5, dg5, db5)
 
 
 class _CvKnnTail(Function):

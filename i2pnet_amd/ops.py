@@ -52,8 +52,9 @@ class _ZeroArena:
     (`begin_step`) instead of ~150 separate fills of a few KB each, and hands out 256-byte aligned
     slices.  Slices live until the next `begin_step` on that device — i.e. for exactly one
     forward+backward; with no arena active (inference, unit tests) `zeros` is `torch.zeros`."""
-    SIZE = 32 << 20
-    MAX_REQUEST = 512 << 10         # larger requests: no measurable gain (A/B on one box)
+    SIZE = 256 << 20
+    MAX_REQUEST = 16 << 20          # (larger requests in the arena: no measurable gain in time — A/B on one box, rounds 2 and 5: 730.0 / 732.1 vs
+                                    #  730.8 / 727.9 samples/s — but a dozen fill launches fewer per step)
 
     def __init__(self):
         self.buf = {}

@@ -70,7 +70,7 @@ def main():
         torch.cuda.synchronize()
         print("calibration launches done")
         return
-    if want("lin"):
+    if want("lin"):   # (under the PMC tool the A/B leg I2P_NO_FUSED_BF16 also runs: its kernels have other names)
         for cin, cout in ((128, 64), (64, 64)):
             x = rnd(rows, cin).to(BF); yv = rnd(rows, cout).to(BF); gz = rnd(rows, cout, sc=0.1).to(BF)
             w = rnd(cout, cin, sc=cin ** -0.5)
