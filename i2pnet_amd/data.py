@@ -24,8 +24,10 @@ copy stream) and the device-side build with the training step of the previous ba
 import math
 import os
 import random
+import atexit
 import threading
-from queue import Queue
+import weakref
+from queue import Full, Queue
 
 import numpy as np
 import torch
@@ -165,6 +167,25 @@ def _linear_taps(n_out, n_in, clamp_weight, device):
     return i0.to(device), i1.to(device), w0.to(device), w1.to(device)
 
 
+_RESIZE_PLANS = {}
+
+
+def _resize_plan(H, W, oh, ow, device):
+    """taps of both axes, the source rows the output touches and the tap rows renumbered within them — built on the host once
+    per (sizes, device) and kept on the device: a dataset has a handful of frame sizes, and building the plan per image cost
+    eight blocking copies and a `torch.unique` (a sort, and a host read of its size)"""
+    key = (H, W, oh, ow, str(device))
+    plan = _RESIZE_PLANS.get(key)
+    if plan is None:
+        x0, x1, a0, a1 = _linear_taps(ow, W, True, "cpu")
+        y0, y1, b0, b1 = _linear_taps(oh, H, False, "cpu")
+        rows = torch.unique(torch.cat([y0, y1]))
+        remap = torch.zeros(H, dtype=torch.int64); remap[rows] = torch.arange(rows.numel())
+        plan = tuple(t.to(device) for t in (x0, x1, a0, a1, remap[y0], remap[y1], b0, b1, rows))
+        _RESIZE_PLANS[key] = plan
+    return plan
+
+
 # --------------------------------------------------------------------------------------------------------------
 # colour jitter of the training images (torchvision.transforms.ColorJitter on a PIL image, as the reference loaders call it)
 # --------------------------------------------------------------------------------------------------------------
@@ -260,13 +281,10 @@ def resize_linear_u8(img, oh, ow):
     if H == 2 * oh and W == 2 * ow:
         s = v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2]
         return ((s + 2) >> 2).to(torch.uint8)
-    x0, x1, a0, a1 = _linear_taps(ow, W, True, dev)
-    y0, y1, b0, b1 = _linear_taps(oh, H, False, dev)
-    rows = torch.unique(torch.cat([y0, y1]))                       # horizontal pass only on the rows the output touches
-    remap = torch.zeros(H, dtype=torch.int64, device=dev); remap[rows] = torch.arange(rows.numel(), device=dev)
-    src = v[rows]
+    x0, x1, a0, a1, y0r, y1r, b0, b1, rows = _resize_plan(H, W, oh, ow, dev)
+    src = v[rows]                                                  # horizontal pass only on the rows the output touches
     hz = src[:, x0] * a0.view(1, -1, 1) + src[:, x1] * a1.view(1, -1, 1)                       # [rows, ow, C]
-    s0, s1 = hz[remap[y0]] >> 4, hz[remap[y1]] >> 4
+    s0, s1 = hz[y0r] >> 4, hz[y1r] >> 4
     out = (((b0.view(-1, 1, 1) * s0) >> 16) + ((b1.view(-1, 1, 1) * s1) >> 16) + 2) >> 2
     return out.to(torch.uint8)
 
@@ -275,6 +293,17 @@ def resize_half_u8(img):
     """cv2.resize(img, (round(w/2), round(h/2)), INTER_LINEAR) — the KITTI loader's call (:716-720)"""
     H, W, _ = img.shape
     return resize_linear_u8(img, int(round(H * 0.5)), int(round(W * 0.5)))
+
+
+def affine_f64(pc, E):
+    """Points [N,3] float32 through the host 3x4 float64 matrix `E` (R | t) in float64 arithmetic, float32 result — the
+    loaders' `np.dot(E, [pc; 1])` (:654-656).  Written out per coordinate with the twelve entries as scalars: a
+    `pc.double() @ E.T` goes to a rocBLAS kernel, and that kernel on the Prefetcher's stream next to the training step's
+    resident-grid chain kernels (mlp_chain.hip) made grid barriers time out (tools/chain_cotenancy.py); the scalars
+    also save the synchronous copy of `E` to the device."""
+    x, y, z = pc[:, 0].double(), pc[:, 1].double(), pc[:, 2].double()
+    E = np.asarray(E, dtype=np.float64)
+    return torch.stack([x * float(E[r, 0]) + y * float(E[r, 1]) + z * float(E[r, 2]) + float(E[r, 3]) for r in range(3)], 1).float()
 
 
 class DeviceSampleBuilder:
@@ -295,8 +324,46 @@ class DeviceSampleBuilder:
         self.device, self.mode = torch.device(device), mode
         self.sample_point, self.img_H, self.img_W, self.img_scale, self.crop_top = sample_point, img_H, img_W, img_scale, crop_top
         self.rng = rng or random
+        self.perm_gen = np.random.default_rng(self.rng.getrandbits(62))
+        self._small = [[None, None] for _ in range(8)]     # pinned blocks (+ the event of their last copy) of `_upload`
+        self._uploads = 0
         self.jitter = jitter and mode == "train"
         self.color_jitter = (self.COLOR_JITTER_DEFAULT if color_jitter is None else bool(color_jitter)) and mode == "train"
+
+    def draw_perm(self, n):
+        """the point shuffle of a sample (:532-533), drawn on the host: `torch.randperm` on the device is a radix sort whose blocks
+        wait on one another, which next to the training step's resident-grid kernels ended in grid-barrier time-outs
+        (tools/chain_cotenancy.py); the Prefetcher's reader thread draws it ahead and stages it in pinned memory.  numpy, not
+        `torch.randperm`: a multi-threaded torch CPU op called from a thread other than the main one cost 90 ms per call on the
+        256-thread GPU box (an OpenMP team per call) and stalled the main thread's launches with it (tools/time_loader.py)"""
+        return self.perm_gen.permutation(n)
+
+    def _upload(self, values):
+        """float32 [n] host values -> device without blocking the host: through a ring of pinned blocks (a pageable source
+        makes the copy synchronous, i.e. the host waits for everything queued on the stream)"""
+        values = np.ascontiguousarray(values, dtype=np.float32).ravel()
+        if self.device.type != "cuda":
+            return torch.from_numpy(values.copy())
+        slot = self._small[self._uploads % len(self._small)]
+        self._uploads += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        if slot[0] is None or slot[0].numel() < values.size:
+            slot[0] = torch.empty(max(256, values.size), dtype=torch.float32, pin_memory=True)
+        slot[0].numpy()[:values.size] = values
+        out = slot[0][:values.size].to(self.device, non_blocking=True)
+        slot[1] = torch.cuda.Event(); slot[1].record()
+        return out
+
+    def _upload_blocks(self, arrays):
+        """several small host arrays -> float32 device tensors of the same shapes through ONE copy (each starts 16-byte aligned)"""
+        sizes = [(a.size + 3) // 4 * 4 for a in arrays]
+        flat = np.zeros(sum(sizes), dtype=np.float32)
+        offs = np.cumsum([0] + sizes)
+        for a, o in zip(arrays, offs):
+            flat[o:o + a.size] = np.ravel(a)                 # float64 -> float32 here, as `torch.as_tensor(a, dtype=float32)` rounds
+        dev_flat = self._upload(flat)
+        return [dev_flat[o:o + a.size].view(a.shape) for a, o in zip(arrays, offs)]
 
     def _crop_rgb(self, img, dx, dy, host):
         """crop -> (train mode) colour jitter on the uint8 crop -> float [3,H,W] in 0..255"""
@@ -321,6 +388,8 @@ class DeviceSampleBuilder:
 
     @torch.no_grad()
     def __call__(self, hosts, stream=None):
+        """No step of this blocks the host when scan / image / perm arrive in pinned memory or on the device (the Prefetcher): the
+        per-sample matrices enter the kernels as scalars, the small outputs go up in one pinned block."""
         dev = self.device
         B = len(hosts)
         SP = self.sample_point
@@ -328,22 +397,18 @@ class DeviceSampleBuilder:
         raw = torch.zeros(B, SP, 3, device=dev)
         feats = torch.zeros(B, SP, 1, device=dev)
         rgb = torch.empty(B, 3, self.img_H, self.img_W, device=dev)
-        ext = torch.empty(B, 3, 4, device=dev); intr = torch.empty(B, 3, 3, device=dev)
-        q_gt = torch.empty(B, 4, device=dev); t_gt = torch.empty(B, 3, device=dev)
-        Ks, paths, idxs = [], [], []
+        Es, qs, ts, Ks, paths, idxs = [], [], [], [], [], []
         for b, host in enumerate(hosts):
             Pr, E, q, t = self.perturbation(host)
             scan = host["scan"].to(dev, non_blocking=True)                            # [N,4]
             n = min(scan.shape[0], SP)
             perm = host.get("perm")
-            perm = torch.randperm(scan.shape[0], device=dev) if perm is None else torch.as_tensor(perm, device=dev)   # :532-533
+            perm = torch.as_tensor(self.draw_perm(scan.shape[0]) if perm is None else perm).to(dev, non_blocking=True)   # :532-533
             scan = scan[perm][:n]
             pc = scan[:, :3]
             if self.jitter:                                                           # :332-343: N(0, 0.01^2) clipped at 5 cm
                 pc = pc + torch.clamp(0.01 * torch.randn_like(pc), -0.05, 0.05)
-            Ed = torch.as_tensor(E, dtype=torch.float64, device=dev)
-            cam = (pc.double() @ Ed[:, :3].t() + Ed[:, 3]).float()                    # :654-656 (float64 product, float32 result)
-            lidar[b, :n] = cam; raw[b, :n] = pc; feats[b, :n, 0] = scan[:, 3]
+            lidar[b, :n] = affine_f64(pc, E); raw[b, :n] = pc; feats[b, :n, 0] = scan[:, 3]   # :654-656
             # image: drop the top rows, halve, crop (:713-747)
             img = host["image"].to(dev, non_blocking=True)[self.crop_top:]
             K = np.copy(host["K"]).astype(np.float64); K[1, 2] -= self.crop_top
@@ -358,11 +423,9 @@ class DeviceSampleBuilder:
             dx, dy = host.get("crop", (dx, dy))
             rgb[b] = self._crop_rgb(img, dx, dy, host)
             K[0, 2] -= dx; K[1, 2] -= dy
-            Ks.append(K)
-            ext[b] = torch.as_tensor(E, dtype=torch.float32); q_gt[b] = torch.as_tensor(q, dtype=torch.float32)
-            t_gt[b] = torch.as_tensor(t, dtype=torch.float32)
+            Es.append(E); qs.append(q); ts.append(t); Ks.append(K)
             paths.append(host["path_info"]); idxs.append(host["index"])
-        intr.copy_(torch.as_tensor(np.stack(Ks), dtype=torch.float32))
+        ext, q_gt, t_gt, intr = self._upload_blocks([np.stack(Es), np.stack(qs), np.stack(ts), np.stack(Ks)])
         return {"rgb": rgb, "lidar": lidar, "raw_point_xyz": raw, "lidar_feats": feats, "init_extrinsic": ext, "init_intrinsic": intr,
                 "decalib_real_gt": q_gt, "decalib_dual_gt": t_gt, "path_info": paths, "index": idxs,
                 "resize_img": torch.tensor([[self.img_scale, self.img_scale]] * B)}
@@ -474,7 +537,7 @@ class NuScenesSampleBuilder(DeviceSampleBuilder):
             Pr, E, q, t = self.perturbation(host)
             scan = host["scan"].to(dev, non_blocking=True)                            # [N,4]
             perm = host.get("perm")
-            perm = torch.randperm(scan.shape[0], device=dev) if perm is None else torch.as_tensor(perm, device=dev)   # :238
+            perm = torch.as_tensor(self.draw_perm(scan.shape[0]) if perm is None else perm).to(dev, non_blocking=True)   # :238
             scan = scan[perm]
             x, y = scan[:, 0], scan[:, 1]
             inside = (x < 0.8) & (x > -0.8) & (y < 2.7) & (y > -2.7)                   # the ego vehicle, :243-247
@@ -489,8 +552,7 @@ class NuScenesSampleBuilder(DeviceSampleBuilder):
             pc = scan[:, :3]
             if self.jitter:
                 pc = pc + torch.clamp(0.01 * torch.randn_like(pc), -0.05, 0.05)
-            Ed = torch.as_tensor(E, dtype=torch.float64, device=dev)
-            lidar[b, :n] = (pc.double() @ Ed[:, :3].t() + Ed[:, 3]).float()             # :343-348
+            lidar[b, :n] = affine_f64(pc, E)                                            # :343-348
             raw[b, :n, 0] = pc[:, 1]; raw[b, :n, 1] = -pc[:, 0]; raw[b, :n, 2] = pc[:, 2]   # :337-341
             feats[b, :n, 0] = scan[:, 3]
             counts.append(n)
@@ -518,51 +580,191 @@ class NuScenesSampleBuilder(DeviceSampleBuilder):
                 "pc_stat": torch.stack(stats), "resize_img": torch.tensor([[self.img_scale_H, self.img_scale_W]] * B)}
 
 
-class Prefetcher:
-    """Iterates device sample dicts: a reader thread pulls half-samples from `dataset` (file I/O, pinned memory), the
-    device build of batch i+1 runs on a side stream under the step of batch i; `__next__` makes the current stream wait
-    for that side stream, no host synchronisation."""
+_LIVE = weakref.WeakSet()        # Prefetchers with a running reader thread
 
-    def __init__(self, dataset, builder, batch_size, indices=None, depth=2):
-        self.dataset, self.builder, self.batch_size = dataset, builder, batch_size
+
+@atexit.register
+def _close_prefetchers():
+    # a daemon thread still inside the interpreter at finalisation is torn down in C++ frames ("terminate called without an
+    # active exception"): stop the readers first
+    for p in list(_LIVE):
+        p.close()
+
+
+class Prefetcher:
+    """Iterates device sample dicts: a reader thread pulls half-samples from `dataset` (file reads on a small pool, copies into
+    pinned staging), the device build of batch i+1 runs on a side stream under the step of batch i; `__next__` makes the current
+    stream wait for that side stream, no host synchronisation.
+
+    The reader thread and its pool live as long as the Prefetcher (one `__iter__` = one epoch request to them): a thread's first
+    multi-threaded torch op creates an OpenMP team of its own, 60 - 190 ms on the 256-thread GPU box, and a reader started per
+    epoch paid that at every epoch start (tools/time_loader.py).
+
+    mode "copy" (default): the side stream carries only the host-to-device copies of scan, image and point shuffle (DMA engines);
+    the build's kernels are issued in `__next__` on the consumer's stream, in order with the training steps.  mode "side": the
+    whole build on the side stream, concurrent with the step.  That is NOT safe next to the step's chain kernels
+    (mlp_chain.hip): their grid barrier needs every block resident, and a side-stream kernel whose own blocks wait on one
+    another (rocPRIM's sort / select / scan look-back, rocBLAS GEMMs) can hold the slot the last chain block needs while it
+    waits itself — the barrier then times out (ChainBarrierTimeout; measured in tools/chain_cotenancy.py,
+    profiles/r05_chain_cotenancy.txt).  Use it only with I2P_NO_CHAIN=1 or a build made of element-wise kernels."""
+
+    STAGED = ("scan", "image", "perm")
+
+    def __init__(self, dataset, builder, batch_size, indices=None, depth=2, workers=4, mode="copy"):
+        self.dataset, self.builder, self.batch_size, self.mode = dataset, builder, batch_size, mode
         self.indices = list(range(len(dataset))) if indices is None else list(indices)
-        self.depth = depth
+        self.depth, self.workers = depth, max(1, int(workers))
         self.cuda = builder.device.type == "cuda"
         self.stream = torch.cuda.Stream(builder.device) if self.cuda else None
+        # pinned staging, allocated ONCE per (slot, sample, tensor) and re-used: `tensor.pin_memory()` per sample allocates page-locked
+        # memory every time — measured 8.7 ms per sample on the MI355X box, 70 ms per batch of 8 against a 5 ms step.  depth + 3
+        # slots; a slot is written again only after the device work that read it has finished (its event), so an H2D copy never
+        # reads a buffer the reader thread is refilling.
+        self._slots = [{"bufs": {}, "event": None} for _ in range(depth + 3)] if self.cuda else []
+        self._batches = 0                      # batches staged so far (slot rotation goes on across epochs)
+        self._requests, self._thread, self._pool = None, None, None
+        self.trace = None                      # a list here collects (batch, read ms, slot wait ms, stage ms) from the reader
 
-    def _reader(self, q):
+    def _stage(self, slot, j, key, t):
+        buf = slot["bufs"].get((j, key))
+        if buf is None or buf.numel() < t.numel() or buf.dtype != t.dtype:
+            buf = torch.empty(int(t.numel() * 1.25) + 16, dtype=t.dtype, pin_memory=True)
+            slot["bufs"][(j, key)] = buf
+        view = buf[:t.numel()].view(t.shape)
+        np.copyto(view.numpy(), t.numpy())     # plain memcpy (a torch copy_ of this size would go through the thread's OpenMP team)
+        return view
+
+    def _epoch(self, q, cancel, epochs=1):
+        """reader thread: `epochs` passes (None: endless) over `indices` into `q`, ended by None"""
+        import time
+
+        def put(item):
+            while not cancel.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except Full:
+                    pass
+            return False
         try:
-            for s in range(0, len(self.indices) - self.batch_size + 1, self.batch_size):
-                hosts = [self.dataset[i] for i in self.indices[s:s + self.batch_size]]
+            import itertools
+            starts = ((e, s) for e in (itertools.count() if epochs is None else range(epochs))
+                      for s in range(0, len(self.indices) - self.batch_size + 1, self.batch_size))
+            for e, s in starts:
+                if cancel.is_set():
+                    break
+                idx = self.indices
+                t0 = time.perf_counter()
+                hosts = list(self._pool.map(self.dataset.__getitem__, idx[s:s + self.batch_size]))   # numpy releases the GIL in I/O
+                t1 = t2 = time.perf_counter()
+                slot = None
                 if self.cuda:
-                    for h in hosts:
-                        h["scan"] = h["scan"].pin_memory(); h["image"] = h["image"].pin_memory()
-                q.put(hosts)
+                    slot = self._slots[self._batches % len(self._slots)]
+                    self._batches += 1
+                    if slot["event"] is not None:
+                        slot["event"].synchronize()
+                        slot["event"] = None
+                    t2 = time.perf_counter()
+                    for j, h in enumerate(hosts):
+                        if h.get("perm") is None and hasattr(self.builder, "draw_perm"):
+                            h["perm"] = self.builder.draw_perm(h["scan"].shape[0])     # (only this thread draws from perm_gen)
+                        for key in self.STAGED:
+                            if h.get(key) is not None:
+                                h[key] = self._stage(slot, j, key, torch.as_tensor(h[key]))
+                if self.trace is not None:
+                    self.trace.append((s // self.batch_size, t0, 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (time.perf_counter() - t2)))
+                if not put((hosts, slot)):
+                    break
+        except BaseException as e:             # surfaces in the consumer
+            put(e)
         finally:
-            q.put(None)
+            put(None)
+
+    def _serve(self):
+        while True:
+            req = self._requests.get()
+            if req is None:
+                return
+            self._epoch(*req)
+
+    def close(self):
+        """stop the reader thread (also done when the Prefetcher is collected)"""
+        if self._thread is not None:
+            self._requests.put(None)
+            self._thread.join(timeout=5)
+            self._pool.shutdown(wait=False)
+            self._thread = self._pool = self._requests = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __iter__(self):
-        q = Queue(maxsize=self.depth)
-        threading.Thread(target=self._reader, args=(q,), daemon=True).start()
-        pending = None
+        return self._stream(1)
 
-        def build(hosts):
+    def cycle(self, epochs=None):
+        """batches of `epochs` passes (None: endless) as ONE stream: the reader runs on across the epoch boundary, so the first
+        batch of the next pass is ready when the last one of this pass is consumed (an `__iter__` per epoch starts with an empty
+        pipeline: two batch reads before the first yield)"""
+        return self._stream(epochs)
+
+    def _stream(self, epochs):
+        from concurrent.futures import ThreadPoolExecutor
+        if self._thread is None:
+            self._requests, self._pool = Queue(), ThreadPoolExecutor(max_workers=self.workers)
+            self._thread = threading.Thread(target=self._serve, daemon=True)
+            self._thread.start()
+            _LIVE.add(self)
+        q, cancel = Queue(maxsize=self.depth), threading.Event()
+        self._requests.put((q, cancel, epochs))
+        dev = self.builder.device
+
+        def take():
+            item = q.get()
+            if isinstance(item, BaseException):
+                raise item
+            return item
+
+        def build(item):
+            hosts, slot = item
             if not self.cuda:
                 return self.builder(hosts), None
+            if self.mode == "side":
+                with torch.cuda.stream(self.stream):
+                    out = self.builder(hosts)
+                    ev = torch.cuda.Event(); ev.record(self.stream)
+                slot["event"] = ev                                           # the staging slot is free once this build has run
+                return out, ev
             with torch.cuda.stream(self.stream):
-                out = self.builder(hosts)
+                for h in hosts:
+                    for key in self.STAGED:
+                        if h.get(key) is not None:
+                            h[key] = h[key].to(dev, non_blocking=True)
                 ev = torch.cuda.Event(); ev.record(self.stream)
-            return out, ev
-        hosts = q.get()
-        if hosts is not None:
-            pending = build(hosts)
-        while pending is not None:
-            out, ev = pending
-            hosts = q.get()
-            pending = build(hosts) if hosts is not None else None           # next batch's copies / kernels start now
-            if ev is not None:
-                torch.cuda.current_stream(self.builder.device).wait_event(ev)
-                for v in out.values():
-                    if isinstance(v, torch.Tensor) and v.is_cuda:
-                        v.record_stream(torch.cuda.current_stream(self.builder.device))
-            yield out
+            slot["event"] = ev
+            return hosts, ev
+        try:
+            item = take()
+            pending = build(item) if item is not None else None
+            while pending is not None:
+                out, ev = pending
+                item = take()
+                pending = build(item) if item is not None else None         # next batch's copies / kernels start now
+                if ev is not None:
+                    cur = torch.cuda.current_stream(dev)
+                    cur.wait_event(ev)
+                    if self.mode == "side":
+                        for v in out.values():
+                            if isinstance(v, torch.Tensor) and v.is_cuda:
+                                v.record_stream(cur)
+                    else:
+                        for h in out:
+                            for key in self.STAGED:
+                                if h.get(key) is not None:
+                                    h[key].record_stream(cur)
+                        out = self.builder(out)
+                yield out
+        finally:
+            cancel.set()                       # an epoch left early: the reader drops what it has and takes the next request

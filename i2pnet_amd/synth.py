@@ -118,3 +118,35 @@ def make_batch(B, N=8192, img_h=375, img_w=1242, seed=0, device="cpu", zero_rows
         "init_intrinsic": K.unsqueeze(0).repeat(B, 1, 1), "init_extrinsic": ext,
         "decalib_real_gt": q_gt, "decalib_dual_gt": t_gt,
     }
+
+
+def write_kitti_tree(root, frames=16, seqs=(0,), seed=7, n_points=120000, img_h=376, img_w=1241):
+    """A synthetic KITTI odometry tree in the layout the reference loader walks (kitti_odometry_corr_lidarnone_proj.py:38-77:
+    velodyne .bin scans, colour frames as .npy, calib.txt, the SNR .npy it also opens) — `frames` frames per sequence with
+    HDL-64-like scans of `n_points` points.  For `bench.py --data tree` (a loader-inclusive step) and the data-pipeline tests;
+    seeded, so nothing has to be shipped."""
+    import os
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    P2 = np.array([[718.856, 0, 607.1928, 45.38225], [0, 718.856, 185.2157, -0.1130887], [0, 0, 1, 0.003779761]])
+    Tr = np.array([[4.276802e-04, -9.999672e-01, -8.084491e-03, -1.198459e-02], [-7.210626e-03, 8.081198e-03, -9.999413e-01, -5.403984e-02],
+                   [9.999738e-01, 4.859485e-04, -7.206933e-03, -2.921968e-01]])
+    for seq in seqs:
+        vel = os.path.join(root, "data_odometry_velodyne", "dataset", "%02d" % seq, "velodyne")
+        snr = os.path.join(root, "data_odometry_velodyne_deepi2p_new", "data_odometry_velodyne_NWU", "sequences", "%02d" % seq, "snr0.6")
+        img = os.path.join(root, "kitti_processed_DeepI2P", "data_odometry_color_npy", "sequences", "%02d" % seq, "image_2")
+        cal = os.path.join(root, "kitti_processed_DeepI2P", "data_odometry_calib", "dataset", "sequences", "%02d" % seq)
+        for d in (vel, snr, img, cal):
+            os.makedirs(d, exist_ok=True)
+        for i in range(frames):
+            n = n_points + 13 * i
+            az = rs.rand(n) * 2 * np.pi
+            el = np.deg2rad(-24.8 + 26.8 * rs.randint(0, 64, n) / 63.0)
+            r = 3.0 + 57.0 * rs.rand(n)
+            scan = np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el), rs.rand(n)], 1).astype(np.float32)
+            scan.tofile(os.path.join(vel, "%06d.bin" % i))
+            np.save(os.path.join(snr, "%06d.npy" % i), np.zeros((7, 1), np.float32))
+            np.save(os.path.join(img, "%06d.npy" % i), rs.randint(0, 256, (img_h, img_w, 3)).astype(np.uint8))
+        with open(os.path.join(cal, "calib.txt"), "w") as f:
+            for k, m in (("P0", P2), ("P1", P2), ("P2", P2), ("P3", P2), ("Tr", Tr)):
+                f.write(k + ": " + " ".join("%.9e" % v for v in m.reshape(-1)) + "\n")
