@@ -146,7 +146,7 @@ PMC_BF16_JSON = ROOT / "profiles" / "r05_pmc_bf16_traffic.json"   # {kernel: {"b
 
 
 def _pmc_traffic(kernel, B):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r04_pmc_traffic.json, written by
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r05_pmc_traffic.json, written by
     tools/pmc_step.sh: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 halving of FETCH_SIZE calibrated in the same run on
     bn_stats_v4), scaled from the batch the passes ran at; None when the file has no record of that kernel."""
     if not PMC_JSON.exists():
@@ -218,6 +218,54 @@ class Cv1Chain:
         return tf / iters * 1e3, tb / iters * 1e3
 
 
+    def graph_time_us(self, replays=20):
+        """(forward, backward) device time of the node as the training step runs it: replays of captured hipGraphs (the step's
+        zero-arena memset alone; + forward; + backward; the differences are the two halves), events around `replays` back-to-back
+        launches.  The eager
+        figure of `time_us` carries the host's launch gaps between the node's ~30 kernels, which the captured step does not
+        have (profiles/*_step_sequence.txt: gap 0.0 between them)."""
+        from i2pnet_amd import ops
+        ops.chain_error_words(self.device)                     # (registered outside any capture)
+
+        def run(with_backward):
+            ops.begin_step(self.device)
+            try:
+                out = self.forward() if with_backward is not None else None
+                if with_backward:
+                    out.backward(self.g_out)
+            finally:
+                ops.end_step(self.device)
+            return out
+        times = []
+        for with_backward in (None, False, True):              # None: the zero-arena memset of begin_step alone (once per STEP, not per node)
+            for t in self.inputs + list(self.cv.parameters()):
+                t.grad = None
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    run(with_backward)
+                    for t in self.inputs + list(self.cv.parameters()):
+                        t.grad = None
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                keep = run(with_backward)                      # noqa: F841 — keeps the graph's outputs alive
+            for _ in range(5):
+                graph.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(replays):
+                graph.replay()
+            e1.record(); e1.synchronize()
+            times.append(e0.elapsed_time(e1) / replays * 1e3)
+            del graph, keep
+        for t in self.inputs + list(self.cv.parameters()):
+            t.grad = None
+        return times[1] - times[0], times[2] - times[1]
+
+
 # SURVEY.md §8(d): BN-exact no-recompute traffic and flops of the cost-volume pi-stage per sample and forward (cv1, fp32)
 CV1_GB_PER_SAMPLE_FWD = 0.437
 CV1_GFLOP_PER_SAMPLE_FWD = 15.1
@@ -227,21 +275,32 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (n
 
 
 def chain_roofline(B, device, bf16=False, N=228):
-    """cv1 forward and backward wall time (events around the fused node) against SURVEY.md §8(d)'s denominators:
+    """cv1 forward and backward device time (hipGraph replays of the fused node as the step launches it, `Cv1Chain.graph_time_us`;
+    the eager event timing is reported beside it) against SURVEY.md §8(d)'s denominators:
     0.437 GB and 15.1 GFLOP per sample and forward; the backward does twice the flops (dgrad + wgrad of every layer) and, BN-exact
     and without recomputation, reads each of the six pre-BN tensors and its gradient once and writes each gradient once
     (3 x 512 channels x 4 B per pair = 0.655 GB per sample).  bf16=True (the caller has ops.set_precision("bf16") active): the same
     node in bf16 storage — half the bytes (0.2185 GB per sample), the same flops on the bf16 MFMA roof: the HBM-bound regime the
     north star's ">= 40 % of HBM on the fused grouping + cost-volume kernel" speaks about (VERDICT r3 missing #2)."""
     ch = Cv1Chain(B, device, N=N)
-    t_f, t_b = ch.time_us()
+    e_f, e_b = ch.time_us()
+    try:
+        t_f, t_b = ch.graph_time_us()
+        timed_as = ("replays of captured hipGraphs, as the training step launches the node (the step's zero-arena memset alone; + forward; "
+                    "+ backward; each half = the difference), events around 20 back-to-back replays after 5 warm-up replays; *_eager_us: events around "
+                    "cv_pi_tail(...) and its .backward() with eager launches (host launch gaps included), 10 iterations after 20")
+    except Exception as e:                                     # noqa: BLE001 — report the eager figure and say so
+        print("bench.py: hipGraph capture of the cv1 node failed (%s: %s); chain roofline from eager launches" % (type(e).__name__, e),
+              file=sys.stderr, flush=True)
+        t_f, t_b = e_f, e_b
+        timed_as = "torch.cuda events on the launch stream around cv_pi_tail(...) and around its .backward(), eager launches, 10 iterations after 20 warm-up iterations"
     gb = CV1_GB_PER_SAMPLE_FWD * (0.5 if bf16 else 1.0) * (N / 228.0)       # (per-sample figures of SURVEY 8(d) are for 228 points)
     fwd_b, fwd_f = gb * 1e9 * B, CV1_GFLOP_PER_SAMPLE_FWD * 1e9 * B * (N / 228.0)
     bwd_b, bwd_f = 1.5 * fwd_b, 2.0 * fwd_f
     mfma_peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
     return {"node": "cost_volume1 pi-stage (_CvPiTail): pair layer, 128->64, 64->64, position encoding, 64+64->128, 128->64, softmax-weighted sum; "
                     "batch %d, %d point x pixel pairs" % (B, ch.rows),
-            "forward_us": round(t_f, 1), "backward_us": round(t_b, 1),
+            "forward_us": round(t_f, 1), "backward_us": round(t_b, 1), "forward_eager_us": round(e_f, 1), "backward_eager_us": round(e_b, 1),
             "forward": {"hbm_GBps": round(fwd_b / t_f / 1e3, 1), "hbm_frac": round(fwd_b / t_f / 1e3 / HBM_PEAK_GBS, 4),
                         "mfma_TFLOPs": round(fwd_f / t_f / 1e6, 1), "mfma_frac": round(fwd_f / t_f / 1e6 / mfma_peak, 4),
                         "bytes": fwd_b, "flop": fwd_f},
@@ -251,8 +310,7 @@ def chain_roofline(B, device, bf16=False, N=228):
             "storage": "bf16" if bf16 else "fp32", "mfma_peak_TFLOPs": mfma_peak,
             "denominators": "SURVEY.md 8(d): %s GB + 15.1 GFLOP per sample and forward (%s activations); backward 1.5x the bytes, 2x the flops"
                             % (("0.2185", "bf16") if bf16 else ("0.437", "fp32")),
-            "timed_as": "torch.cuda events on the launch stream around cv_pi_tail(...) and around its .backward(), eager launches, "
-                        "averaged over 10 iterations after 20 warm-up iterations"}
+            "timed_as": timed_as}
 
 
 def _image_encoder_entry(B, device):
@@ -325,7 +383,7 @@ def kernel_rooflines(B, device):
       pass (csrc/mlp_wreg_fused.hip): it reads gz [rows,64], the layer's pre-BN output y [rows,64] (BN backward of the layer behind
       formed on load) and the pre-BN input x [rows,128] ONCE, writes dL/dz_in [rows,128] and keeps the [64][128] weight gradient in
       registers: rows*(2*64+2*128)*4 B against 4*rows*128*64 flop => HBM-bound (164 us at 8 TB/s, 178 us at 157.3 TFLOP/s: close
-      to the ridge).  `traffic` = PMC bytes per launch from profiles/r04_pmc_traffic.json (tools/pmc_r04.sh).
+      to the ridge).  `traffic` = PMC bytes per launch from profiles/r05_pmc_traffic.json (tools/pmc_r05.sh).
     * other_kernels: the forward of the same layer (wreg_fwd_kernel<128,64,true,false>), the two-source 64+64->128 forward
       (wreg_fwd_kernel<128,128,true,true>), the factored first layer (wreg_pair_fwd_kernel<128,128>), level-1
       fused_conv_select_k and the fused level-1 grouping on the three input densities.

@@ -3,8 +3,9 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-# usage: tools/pmc_traffic.sh [bf16]     (workload tools/pmc_traffic.py or tools/pmc_traffic_bf16.py)
-sfx=${1:+_$1}
+# usage: tools/pmc_traffic.sh     (workload tools/pmc_traffic.py: the fp32 128->128 layer kernels; the bf16 cost-volume kernels have
+# their own pass, tools/pmc_r05_bf16.py behind tools/pmc_r05.sh)
+sfx=
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python tools/pmc_traffic$sfx.py > /tmp/pmc_$c.log 2>&1
