@@ -791,7 +791,7 @@ def main():
     ap.add_argument("--data", default="synthetic", choices=["synthetic", "tree"],
                     help="tree: every rank reads a synthetic KITTI odometry tree (written to a temp dir) through the real input pipeline "
                          "(i2pnet_amd.data: file reads, pinned staging, device-side sample build on a copy stream, Prefetcher) — a "
-                         "loader-inclusive number on the reference loader's own shapes (160x512 crop, 150 000-row clouds); fp32 config 1 only")
+                         "loader-inclusive number on the reference loader's own shapes (160x512 crop, 150 000-row clouds); its own metric name, never `value` of the BASELINE metric")
     ap.add_argument("--no-dp-proxy", action="store_true", help="skip the two-graph + 1-rank all-reduce proxy measurement")
     ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to host-core groups")
     ap.add_argument("--no-finddb-warmup", action="store_true", help="every rank runs MIOpen's find itself")
@@ -1036,10 +1036,12 @@ def _json_line(res, args, world):
         # NOT the BASELINE metric's workload: the reference loader's own shapes, the input pipeline inside the timed region
         return {"metric": "train samples/sec, loader-inclusive (reference loader shapes)", "value": round(global_batch * args.steps / dt, 3),
                 "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32",
                 "data": "synthetic KITTI odometry tree on local disk (i2pnet_amd.synth.write_kitti_tree), read through i2pnet_amd.data",
                 "config": {"workload": "KITTI loader shapes: 160x512 crop of the x0.5 image, 150 000-row cloud (120 000 points + padding), "
-                                       "fp32 forward+loss+backward+clip+Adam, file reads + H2D + device-side sample build under the step (Prefetcher)",
+                                       + ("bf16 storage mode, " if bf16 else "fp32 ") +
+                                       "forward+loss+backward+clip+Adam; file reads, point shuffle, pinned staging + H2D under the step, the batch's "
+                                       "device-side build (two launches) in order with it (data.Prefetcher)",
                            "per_gpu_batch": args.batch, "global_batch": global_batch, "parallelism": f"dp{world}",
                            "hipgraph": res["graph_live"], "final_loss": round(res["loss"], 4)}}
     return {

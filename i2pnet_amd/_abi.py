@@ -54,6 +54,8 @@ SIGNATURES = {
 # entries that exist only in the device library (bf16 storage mode, deterministic scatter, fused grouping): the CPU
 # oracle restates the reference's algorithms, not our storage formats — these are checked against fp32 results
 DEVICE_ONLY = {
+    "i2p_kitti_points_build": ["i", "i", "p", "p", "p", "p", "p"],
+    "i2p_kitti_image_build": ["i", "i", "i", "p", "p"],
     "i2p_lin_fwd_bf16": ["l", "i", "i", "p", "i", "p", "f", "p", "p", "p"],
     "i2p_lin_fwd_2src_bf16": ["l", "i", "i", "i", "p", "p", "f", "p", "p", "f", "p", "p", "p"],
     "i2p_pair_lin_fwd_bf16": ["i"] * 5 + ["p"] * 7,

@@ -315,7 +315,7 @@ class DeviceSampleBuilder:
     COLOR_JITTER_DEFAULT = False     # the reference's KITTI augment_img is the identity (see color_jitter_u8 above)
 
     def __init__(self, device, mode="train", sample_point=150000, img_H=160, img_W=512, img_scale=0.5, crop_top=50,
-                 rng=None, jitter=True, color_jitter=None):
+                 rng=None, jitter=True, color_jitter=None, fused=True):
         """`jitter`: per-point N(0, 0.01^2) noise of the cloud in train mode; `color_jitter`: ColorJitter of the cropped image
         in train mode (None = the reference loader's effective behaviour: off for KITTI, on for nuScenes).  The random draws
         (perturbation, crop offsets, colour jitter) come from `rng` in this order per sample; the reference draws from the
@@ -323,37 +323,48 @@ class DeviceSampleBuilder:
         golden vectors pin the arithmetic by passing the reference's draws in (`Pr`, `perm`, `crop`, `jitter_params`)."""
         self.device, self.mode = torch.device(device), mode
         self.sample_point, self.img_H, self.img_W, self.img_scale, self.crop_top = sample_point, img_H, img_W, img_scale, crop_top
+        self.fused = fused                 # HIP device: the batch build in two launches (csrc/loader_build.hip); False = the torch path
         self.rng = rng or random
-        self.perm_gen = np.random.default_rng(self.rng.getrandbits(62))
-        self._small = [[None, None] for _ in range(8)]     # pinned blocks (+ the event of their last copy) of `_upload`
+        self.perm_seed = self.rng.getrandbits(62)
+        self.perm_gen = np.random.default_rng(self.perm_seed)
+        self._small = [[None, None] for _ in range(12)]     # pinned blocks (+ the event of their last copy) of `_upload`
         self._uploads = 0
         self.jitter = jitter and mode == "train"
         self.color_jitter = (self.COLOR_JITTER_DEFAULT if color_jitter is None else bool(color_jitter)) and mode == "train"
 
-    def draw_perm(self, n):
+    def draw_perm(self, n, key=None):
         """the point shuffle of a sample (:532-533), drawn on the host: `torch.randperm` on the device is a radix sort whose blocks
         wait on one another, which next to the training step's resident-grid kernels ended in grid-barrier time-outs
         (tools/chain_cotenancy.py); the Prefetcher's reader thread draws it ahead and stages it in pinned memory.  numpy, not
         `torch.randperm`: a multi-threaded torch CPU op called from a thread other than the main one cost 90 ms per call on the
-        256-thread GPU box (an OpenMP team per call) and stalled the main thread's launches with it (tools/time_loader.py)"""
+        256-thread GPU box (an OpenMP team per call) and stalled the main thread's launches with it (tools/time_loader.py).
+        `key` (the Prefetcher passes the running number of the sample): an independent stream per sample, so that the pool's workers
+        can draw in parallel (1.7 ms per 120 000-point scan) and the result does not depend on which worker ran first."""
+        if key is not None:
+            return np.random.default_rng([self.perm_seed, int(key)]).permutation(n)
         return self.perm_gen.permutation(n)
 
-    def _upload(self, values):
-        """float32 [n] host values -> device without blocking the host: through a ring of pinned blocks (a pageable source
-        makes the copy synchronous, i.e. the host waits for everything queued on the stream)"""
-        values = np.ascontiguousarray(values, dtype=np.float32).ravel()
+    def _upload_bytes(self, raw):
+        """host bytes (a contiguous numpy array of any dtype) -> device uint8 tensor without blocking the host: through a ring of
+        pinned blocks (a pageable source makes the copy synchronous, i.e. the host waits for everything queued on the stream)"""
+        raw = np.ascontiguousarray(raw).view(np.uint8).ravel()
         if self.device.type != "cuda":
-            return torch.from_numpy(values.copy())
+            return torch.from_numpy(raw.copy())
         slot = self._small[self._uploads % len(self._small)]
         self._uploads += 1
         if slot[1] is not None:
             slot[1].synchronize()
-        if slot[0] is None or slot[0].numel() < values.size:
-            slot[0] = torch.empty(max(256, values.size), dtype=torch.float32, pin_memory=True)
-        slot[0].numpy()[:values.size] = values
-        out = slot[0][:values.size].to(self.device, non_blocking=True)
+        if slot[0] is None or slot[0].numel() < raw.size:
+            slot[0] = torch.empty(max(4096, raw.size), dtype=torch.uint8, pin_memory=True)
+        slot[0].numpy()[:raw.size] = raw
+        out = slot[0][:raw.size].to(self.device, non_blocking=True)
         slot[1] = torch.cuda.Event(); slot[1].record()
         return out
+
+    def _upload(self, values):
+        """float32 [n] host values -> float32 device tensor (see _upload_bytes)"""
+        values = np.ascontiguousarray(values, dtype=np.float32).ravel()
+        return self._upload_bytes(values).view(torch.float32)
 
     def _upload_blocks(self, arrays):
         """several small host arrays -> float32 device tensors of the same shapes through ONE copy (each starts 16-byte aligned)"""
@@ -393,6 +404,8 @@ class DeviceSampleBuilder:
         dev = self.device
         B = len(hosts)
         SP = self.sample_point
+        if self._fused_ok(hosts):
+            return self._call_fused(hosts)
         lidar = torch.zeros(B, SP, 3, device=dev)
         raw = torch.zeros(B, SP, 3, device=dev)
         feats = torch.zeros(B, SP, 1, device=dev)
@@ -426,6 +439,60 @@ class DeviceSampleBuilder:
             Es.append(E); qs.append(q); ts.append(t); Ks.append(K)
             paths.append(host["path_info"]); idxs.append(host["index"])
         ext, q_gt, t_gt, intr = self._upload_blocks([np.stack(Es), np.stack(qs), np.stack(ts), np.stack(Ks)])
+        return {"rgb": rgb, "lidar": lidar, "raw_point_xyz": raw, "lidar_feats": feats, "init_extrinsic": ext, "init_intrinsic": intr,
+                "decalib_real_gt": q_gt, "decalib_dual_gt": t_gt, "path_info": paths, "index": idxs,
+                "resize_img": torch.tensor([[self.img_scale, self.img_scale]] * B)}
+
+
+    # ---- the same build in two launches per batch (csrc/loader_build.hip) ---------------------------------------------------
+    def _fused_ok(self, hosts):
+        """HIP device, KITTI builder proper (the nuScenes subclass has data-dependent filters), no colour jitter: the batch goes
+        through i2p_kitti_points_build / i2p_kitti_image_build — the arithmetic of the torch path below, operation for operation
+        (bit-identical: tests/test_data_pipeline.py), without its ~50 launches per sample"""
+        return (self.fused and self.device.type == "cuda" and type(self) is DeviceSampleBuilder and not self.color_jitter
+                and all(h["scan"].dtype == torch.float32 and h["image"].dtype == torch.uint8 for h in hosts))
+
+    @torch.no_grad()
+    def _call_fused(self, hosts):
+        from . import ops
+        be = ops.hip_backend()                                   # raises without the device library
+        dev, B, SP = self.device, len(hosts), self.sample_point
+        ptab = np.zeros((B, 16), dtype=np.int64)                 # i2p_kitti_points_build's table rows (include/i2p_ops.h)
+        itab = np.zeros((B, 8), dtype=np.int64)
+        keep, Es, qs, ts, Ks, paths, idxs = [], [], [], [], [], [], []
+        for b, host in enumerate(hosts):
+            Pr, E, q, t = self.perturbation(host)
+            scan = host["scan"].to(dev, non_blocking=True).contiguous()
+            perm = host.get("perm")
+            perm = torch.as_tensor(self.draw_perm(scan.shape[0]) if perm is None else perm).to(dev, non_blocking=True).contiguous()
+            if perm.dtype != torch.int64:
+                perm = perm.long()
+            ptab[b, 0], ptab[b, 1], ptab[b, 2] = scan.data_ptr(), perm.data_ptr(), min(scan.shape[0], SP)
+            ptab[b, 4:] = np.ascontiguousarray(E, dtype=np.float64).ravel().view(np.int64)
+            img = host["image"].to(dev, non_blocking=True).contiguous()
+            H0, W0, _ = img.shape
+            h0 = H0 - self.crop_top
+            K = np.copy(host["K"]).astype(np.float64); K[1, 2] -= self.crop_top
+            oh, ow = int(round(h0 * self.img_scale)), int(round(W0 * self.img_scale))
+            K[0, 0] *= self.img_scale; K[0, 2] *= self.img_scale; K[1, 1] *= self.img_scale; K[1, 2] *= self.img_scale
+            if self.mode == "train":
+                dx, dy = self.rng.randint(0, ow - self.img_W), self.rng.randint(0, oh - self.img_H)
+            else:
+                dx, dy = int((ow - self.img_W) / 2), int((oh - self.img_H) / 2)
+            dx, dy = host.get("crop", (dx, dy))
+            if not (0 <= dx <= ow - self.img_W and 0 <= dy <= oh - self.img_H):
+                raise ValueError("crop (%d, %d) of a %dx%d window leaves the %dx%d resized image" % (dx, dy, self.img_W, self.img_H, ow, oh))
+            itab[b] = (img.data_ptr() + self.crop_top * W0 * 3, h0, W0, oh, ow, dx, dy, int(h0 == 2 * oh and W0 == 2 * ow))
+            K[0, 2] -= dx; K[1, 2] -= dy
+            keep += [scan, perm, img]
+            Es.append(E); qs.append(q); ts.append(t); Ks.append(K)
+            paths.append(host["path_info"]); idxs.append(host["index"])
+        tables = self._upload_bytes(np.concatenate([ptab.ravel(), itab.ravel()]))
+        noise = torch.randn(B, SP, 3, device=dev) if self.jitter else None         # :332-343: one draw per batch
+        lidar, raw, feats = be.kitti_points_build(tables[:B * 128], B, SP, noise)
+        rgb = be.kitti_image_build(tables[B * 128:], B, self.img_H, self.img_W)
+        ext, q_gt, t_gt, intr = self._upload_blocks([np.stack(Es), np.stack(qs), np.stack(ts), np.stack(Ks)])
+        del keep                                                 # (the kernels are queued on this stream: the allocator orders the reuse)
         return {"rgb": rgb, "lidar": lidar, "raw_point_xyz": raw, "lidar_feats": feats, "init_extrinsic": ext, "init_intrinsic": intr,
                 "decalib_real_gt": q_gt, "decalib_dual_gt": t_gt, "path_info": paths, "index": idxs,
                 "resize_img": torch.tensor([[self.img_scale, self.img_scale]] * B)}
@@ -610,7 +677,7 @@ class Prefetcher:
 
     STAGED = ("scan", "image", "perm")
 
-    def __init__(self, dataset, builder, batch_size, indices=None, depth=2, workers=4, mode="copy"):
+    def __init__(self, dataset, builder, batch_size, indices=None, depth=2, workers=8, mode="copy"):
         self.dataset, self.builder, self.batch_size, self.mode = dataset, builder, batch_size, mode
         self.indices = list(range(len(dataset))) if indices is None else list(indices)
         self.depth, self.workers = depth, max(1, int(workers))
@@ -623,7 +690,7 @@ class Prefetcher:
         self._slots = [{"bufs": {}, "event": None} for _ in range(depth + 3)] if self.cuda else []
         self._batches = 0                      # batches staged so far (slot rotation goes on across epochs)
         self._requests, self._thread, self._pool = None, None, None
-        self.trace = None                      # a list here collects (batch, read ms, slot wait ms, stage ms) from the reader
+        self.trace = None                      # a list here collects (batch, start, slot wait ms, load ms) from the reader
 
     def _stage(self, slot, j, key, t):
         buf = slot["bufs"].get((j, key))
@@ -655,24 +722,31 @@ class Prefetcher:
                     break
                 idx = self.indices
                 t0 = time.perf_counter()
-                hosts = list(self._pool.map(self.dataset.__getitem__, idx[s:s + self.batch_size]))   # numpy releases the GIL in I/O
-                t1 = t2 = time.perf_counter()
                 slot = None
                 if self.cuda:
                     slot = self._slots[self._batches % len(self._slots)]
-                    self._batches += 1
                     if slot["event"] is not None:
                         slot["event"].synchronize()
                         slot["event"] = None
-                    t2 = time.perf_counter()
-                    for j, h in enumerate(hosts):
+                t1 = time.perf_counter()
+                serial0 = self._batches * self.batch_size
+                self._batches += 1
+
+                def load(jk, slot=slot, serial0=serial0):
+                    # one sample on a pool worker: file reads, the point shuffle, the copies into the slot's pinned staging
+                    # (numpy releases the GIL in all three)
+                    j, k = jk
+                    h = self.dataset[k]
+                    if self.cuda:
                         if h.get("perm") is None and hasattr(self.builder, "draw_perm"):
-                            h["perm"] = self.builder.draw_perm(h["scan"].shape[0])     # (only this thread draws from perm_gen)
+                            h["perm"] = self.builder.draw_perm(h["scan"].shape[0], key=serial0 + j)
                         for key in self.STAGED:
                             if h.get(key) is not None:
                                 h[key] = self._stage(slot, j, key, torch.as_tensor(h[key]))
+                    return h
+                hosts = list(self._pool.map(load, enumerate(idx[s:s + self.batch_size])))
                 if self.trace is not None:
-                    self.trace.append((s // self.batch_size, t0, 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (time.perf_counter() - t2)))
+                    self.trace.append((s // self.batch_size, t0, 1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1)))
                 if not put((hosts, slot)):
                     break
         except BaseException as e:             # surfaces in the consumer

@@ -1087,6 +1087,24 @@ class CBackend:
                    stream=self._stream())
         return loss3, d3, d4, d_w
 
+    # ---- loader: the device-side build of a KITTI batch (csrc/loader_build.hip; device library only) ------------------
+    def kitti_points_build(self, table, B, sample_point, noise):
+        """table: device uint8 [B*128] rows of i2p_kitti_points_build -> lidar, raw [B,SP,3], feats [B,SP,1] (padding rows zero)"""
+        dev = table.device
+        lidar = torch.empty(B, sample_point, 3, dtype=_F32, device=dev); raw = torch.empty_like(lidar)
+        feats = torch.empty(B, sample_point, 1, dtype=_F32, device=dev)
+        self._call("i2p_kitti_points_build", int(B), int(sample_point), self._p(table, torch.uint8, "table"),
+                   self._p(noise, _F32, "noise") if noise is not None else None, self._p(lidar, _F32, "lidar"), self._p(raw, _F32, "raw"),
+                   self._p(feats, _F32, "feats"), stream=self._stream())
+        return lidar, raw, feats
+
+    def kitti_image_build(self, table, B, out_h, out_w):
+        """table: device uint8 [B*64] rows of i2p_kitti_image_build -> rgb [B,3,out_h,out_w] float in 0..255"""
+        rgb = torch.empty(B, 3, out_h, out_w, dtype=_F32, device=table.device)
+        self._call("i2p_kitti_image_build", int(B), int(out_h), int(out_w), self._p(table, torch.uint8, "table"), self._p(rgb, _F32, "rgb"),
+                   stream=self._stream())
+        return rgb
+
     # ---- small glue kernels (csrc/glue.hip; device library only) -------------------------------------------------
     def row_valid(self, x):
         """x [..., c] -> 0/1 float [..., 1]: any(x != 0) over the last axis (check_valid)"""

@@ -662,6 +662,19 @@ int i2p_pad_cols(int rows, int c, int cpad, const float *w, float *out, void *st
 int i2p_strided_pick2(int B, int H, int W, int oh, int ow, int sh, int sw, const float *a, const float *b, float *oa, float *ob,
                       void *stream);
 
+/* Device-side build of a batch of KITTI odometry samples (csrc/loader_build.hip; host half: i2pnet_amd/data.py) — the per-point and
+ * per-pixel work of the reference loader's __getitem__ (src/kitti_odometry_corr_lidarnone_proj.py:524-533 shuffle, :332-343 jitter,
+ * :654-656 float64 extrinsic product, :699-711 zero padding, :713-747 top-row drop + cv2.resize x0.5 + crop) in one launch each per
+ * BATCH.  `table`: device array of B rows —
+ *   points: 128 bytes = { const float *scan [N,4]; const int64 *perm [N]; int64 n = min(N, sample_point); int64 0; double E[12] }
+ *   image :  64 bytes = { const uint8 *img [H,W,3] (top rows dropped); int64 H, W, oh, ow (resized size), dx, dy (crop), exact2 }
+ * noise: [B, sample_point, 3] standard-normal draws or NULL (no jitter); lidar / raw [B, sample_point, 3], feats [B, sample_point, 1]
+ * (rows >= n are written as zeros); rgb [B, 3, out_h, out_w] float in 0..255.  exact2 != 0 (H == 2 oh, W == 2 ow): the 2x2 mean
+ * rounded half up (cv2's INTER_AREA fast path for an exact 2x shrink); otherwise cv2's 8-bit bilinear rule (11-bit weights). */
+int i2p_kitti_points_build(int B, int sample_point, const void *table, const float *noise, float *lidar, float *raw, float *feats,
+                           void *stream);
+int i2p_kitti_image_build(int B, int out_h, int out_w, const void *table, float *rgb, void *stream);
+
 /* Measurement hook (bench.py's roofline object): with i2p_ktime_enable(1) the launchers of wreg_bwd_fused_kernel (fp32) and
  * bwd_fused_bf16_kernel bracket the kernel alone with HIP events on the launch stream; i2p_ktime_last_us() waits for the last
  * bracketed launch and returns its duration in microseconds (-1 if none).  Not for use inside a stream capture. */

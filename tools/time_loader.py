@@ -88,8 +88,8 @@ if pf is not None:
     base = marks[0][0]
     for i, (a, b) in enumerate(marks[:20]):
         print(f"main step {i}: next from {1e3 * (a - base):8.1f} to {1e3 * (b - base):8.1f}")
-    for k, t0, rd, sy, st in pf.trace:
+    for k, t0, sy, ld in pf.trace:
         if t0 >= base and (t0 - base) < marks[min(19, len(marks) - 1)][1] - base:
-            print(f"reader batch {k}: starts {1e3 * (t0 - base):8.1f}  read {rd:6.1f}  slot wait {sy:6.1f}  stage {st:6.1f}")
+            print(f"reader batch {k}: starts {1e3 * (t0 - base):8.1f}  slot wait {sy:6.1f}  read + shuffle + stage {ld:6.1f}")
 for name, ms, at in SLOW[:60]:
     print(f"slow call: {name:20s} {ms:7.1f} ms at {1e3 * (at - marks[0][0]):9.1f}")
