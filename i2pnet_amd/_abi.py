@@ -54,9 +54,6 @@ SIGNATURES = {
 # entries that exist only in the device library (bf16 storage mode, deterministic scatter, fused grouping): the CPU
 # oracle restates the reference's algorithms, not our storage formats — these are checked against fp32 results
 DEVICE_ONLY = {
-    "i2p_outer_prep_bf16": ["i"] * 4 + ["p"] * 5,
-    "i2p_lin_fwd_2src_outer_bf16": ["i"] * 6 + ["p", "p", "p", "f", "p", "p", "f", "p", "p", "p"],
-    "i2p_lin_bwd_2src_outer_bf16": ["i"] * 6 + ["p"] * 9 + ["f", "p", "p", "p", "f"] + ["p"] * 8,
     "i2p_kitti_points_build": ["i", "i", "p", "p", "p", "p", "p"],
     "i2p_kitti_image_build": ["i", "i", "i", "p", "p"],
     "i2p_lin_fwd_bf16": ["l", "i", "i", "p", "i", "p", "f", "p", "p", "p"],
@@ -119,7 +116,6 @@ DEVICE_ONLY = {
 }
 # plain `int f(...)` helpers without a stream argument
 HELPERS = {
-    "i2p_outer_on_load_ok": ["i"] * 6,
     "i2p_lin_bwd_bf16_grid": ["l"],
     "i2p_pair_lin_bwd_bf16_grid": ["i", "i", "i"],
     "i2p_pair_lin_bwd_scratch": ["i", "i", "i", "i", "i"],          # returns long long

@@ -359,46 +359,7 @@ __global__ __launch_bounds__(THREADS) void pair_sum_k_bf16_kernel(int M, int C, 
     }
 }
 
-// Position encoding formed ON LOAD (round 5): the consumers (rg_fwd_kernel<4,...,OUTER>, bwd_fused2_bf16_kernel<OUTER>) read
-// ye[b,n,k,:] = enc_n[b,n,:] + q[b,k,:] with q = bf16(enc_k) from the two small factors instead of a [rows, C] tensor.  This kernel
-// writes q (bf16, and its values as fp32 for the closed-form backward of the factors) and the BatchNorm sums of ye over all
-// (b, n, k) WITHOUT visiting the pairs: per sample sum ye = M sum_n a + N sum_k q, sum ye^2 = M sum_n a^2 + N sum_k q^2 +
-// 2 (sum_n a)(sum_k q), in float64.  One block per sample (its term goes to replica b % REP of the sums).
-__global__ __launch_bounds__(256) void outer_prep_kernel(int N, int M, int C, const float *__restrict__ en, const float *__restrict__ ek,
-                                                         bf16_t *__restrict__ q16, float *__restrict__ q32, double *__restrict__ sums) {
-    __shared__ double red[4][256];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int G = 256 / C, c = tid % C, g = tid / C;             // C in {32, 64, 128}: 8 / 4 / 2 row groups
-    double sa = 0.0, sa2 = 0.0, sq = 0.0, sq2 = 0.0;
-    if (g < G) {
-        for (int n = g; n < N; n += G) { const double a = (double)en[((size_t)b * N + n) * C + c]; sa += a; sa2 += a * a; }
-        for (int k = g; k < M; k += G) {
-            const size_t o = ((size_t)b * M + k) * C + c;
-            const float r = bf_round(ek[o]);
-            q16[o] = (bf16_t)(__float_as_uint(r) >> 16); q32[o] = r;
-            const double v = (double)r; sq += v; sq2 += v * v;
-        }
-    }
-    red[0][tid] = sa; red[1][tid] = sa2; red[2][tid] = sq; red[3][tid] = sq2;
-    __syncthreads();
-    if (tid < C) {
-        double t[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int j = 0; j < G; ++j)                              // fixed order
-            for (int i = 0; i < 4; ++i) t[i] += red[i][j * C + tid];
-        double *rep = sums + (size_t)(b % REP) * 2 * C;
-        atomicAdd(rep + tid, (double)M * t[0] + (double)N * t[2]);
-        atomicAdd(rep + C + tid, (double)M * t[1] + (double)N * t[3] + 2.0 * t[0] * t[2]);
-    }
-}
-
 }  // namespace
-
-extern "C" int i2p_outer_prep_bf16(int B, int N, int M, int C, const float *enc_n, const float *enc_k, bf16_t *q16, float *q32,
-                                   double *sums, void *stream) {
-    if (B <= 0 || N <= 0 || M <= 0 || !(C == 32 || C == 64 || C == 128) || !enc_n || !enc_k || !q16 || !q32 || !sums) return I2P_ERR_BAD_ARG;
-    hipLaunchKernelGGL(outer_prep_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, N, M, C, enc_n, enc_k, q16, q32, sums);
-    I2P_RETURN_LAUNCH_STATUS();
-}
 
 extern "C" int i2p_outer_sum_bf16(int B, int N, int M, int C, const float *enc_n, const float *enc_k, bf16_t *ye, double *sums,
                                   void *stream) {

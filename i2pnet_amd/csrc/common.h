@@ -157,11 +157,6 @@ int i2p_bwd_fused2_bf16(long long rows, const unsigned short *gz, const unsigned
                         const float *coef_a, const float *mi_a, float slope_a, const unsigned short *xb, const float *coef_b,
                         const float *mi_b, float slope_b, const unsigned short *e_add, const float *w, unsigned short *gz_a,
                         double *sums_a, unsigned short *gz_b, double *sums_b, float *dw_partial, unsigned grid, void *stream);
-int i2p_bwd_fused2_outer_bf16(int B, int N, int M, const unsigned short *gz, const unsigned short *y, const double *out_dsums, const float *out_coef,
-                              const float *out_mi, float *coef8, const float *enc_n, const unsigned short *q16, const float *coef_a, const float *mi_a,
-                              float slope_a, const unsigned short *xb, const float *coef_b, const float *mi_b, float slope_b, const unsigned short *e_add,
-                              const float *w, unsigned short *gz_a, double *sums_a, unsigned short *gz_b, double *sums_b, float *dw_partial, unsigned grid,
-                              void *stream);
 
 // Kernel-only timing for bench.py's roofline object: when enabled, the launchers of the headline kernels bracket
 // THE KERNEL (not the entry's coefficient / reduction launches) with two HIP events on the launch stream; i2p_ktime_last_us()

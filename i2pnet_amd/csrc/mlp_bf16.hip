@@ -50,9 +50,6 @@ struct FwdP {
     // pair mode: input row (b,n,k) = pair_f[b,n,:] * x[b,k,:], y += bias_n[b,n,:] + bias_k[b,k,:]
     const float *pair_f, *bias_n, *bias_k;
     int pN, pM;
-    // OUTER instantiation (position encoding formed on load): channels [0, split) of row (b,n,k) = enc_n[b,n,:] + q16[b,k,:]
-    // (fp32 sum of the fp32 point factor and the bf16 pixel factor; x is unused); pN, pM as in pair mode
-    const float *enc_n; const bf16_t *q16;
 };
 
 // weights -> LDS image [32*NT][CP] of bf16 chunks along k (zero padded); transposed: Ws[o][k] = w[k*ld + o]
@@ -95,9 +92,8 @@ __device__ __forceinline__ void pair_row_of(const PairStrip &t, int d, int N, in
     bn = t.bn0 + wrap; bk = b * M + k;
 }
 
-template <int NT, bool XBF16, bool PAIR, bool OUTER = false>
+template <int NT, bool XBF16, bool PAIR>
 __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP p) {
-    static_assert(!OUTER || (XBF16 && !PAIR), "the on-load position encoding is a bf16 two-source mode");
     extern __shared__ uint4 smem[];
     constexpr int UMAX = (XBF16 || PAIR) ? UMAX_BF : UMAX_F32;
     constexpr int PFN = XBF16 ? UMAX : 2 * UMAX;
@@ -148,19 +144,17 @@ __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP 
     (void)pfb; (void)pff;
     // pair mode: a 32-row strip spans at most two points (M >= 32), so the point factor f[b,n,:] of this lane's 8 input
     // channels is fetched ONCE per strip (two candidates) with the pixel rows, instead of one L2 round trip per row
-    float4 pf_f[PAIR ? 4 : (OUTER ? 2 : 1)];
+    float4 pf_f[PAIR ? 4 : 1];
     long long pf_bn0 = 0;
     int pf_k0 = 0;
     const long long total_bn = PAIR ? p.rows / p.pM : 0;        // points of the whole batch
-    int o_bn0 = 0;
-    const int o_total = OUTER ? (int)(p.rows / p.pM) : 0;
-    (void)pf_f; (void)pf_bn0; (void)pf_k0; (void)total_bn; (void)o_bn0; (void)o_total;
+    (void)pf_f; (void)pf_bn0; (void)pf_k0; (void)total_bn;
     const int lane_c = (lane & (ncx - 1)) * 8;                   // (pair / bf16 inputs: ncx is a power of two)
 
     auto fetch = [&](long long st) {
         const long long row0 = st * RG_ROWS;
         PairStrip ps; ps.bn0 = ps.k0 = ps.b0 = ps.n0 = 0;
-        if constexpr (PAIR || OUTER) ps = pair_strip(row0, p.pN, p.pM);
+        if constexpr (PAIR) ps = pair_strip(row0, p.pN, p.pM);
 #pragma unroll
         for (int u = 0; u < UMAX; ++u) {
             if (u < U) {
@@ -168,15 +162,9 @@ __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP 
                 long long row = row0 + r; if (row > last_row) { r = (int)(last_row - row0); row = last_row; }
                 if constexpr (XBF16) {
                     const int ch = c * 8;
-                    const bf16_t *src;
-                    if constexpr (OUTER) {
-                        int bn, bk; pair_row_of(ps, r, p.pN, p.pM, bn, bk);
-                        src = ch >= p.split ? p.xb + (size_t)row * p.xb_ld + (ch - p.split) : p.q16 + (unsigned)(bk * p.split + ch);
-                    } else {
-                        src = (p.xb && ch >= p.split) ? p.xb + (size_t)row * p.xb_ld + (ch - p.split)
-                                                      : reinterpret_cast<const bf16_t *>(p.x) + (size_t)row * p.x_ld + ch;
-                    }
-                    pfb[u] = (OUTER && ch < p.split) ? *reinterpret_cast<const uint4 *>(src) : ld_u4_stream(src);   // (the pixel factor is re-read by every point: cached)
+                    const bf16_t *src = (p.xb && ch >= p.split) ? p.xb + (size_t)row * p.xb_ld + (ch - p.split)
+                                                               : reinterpret_cast<const bf16_t *>(p.x) + (size_t)row * p.x_ld + ch;
+                    pfb[u] = ld_u4_stream(src);
                 } else {
                     long long src = row;
                     if constexpr (PAIR) { int bn, bk; pair_row_of(ps, r, p.pN, p.pM, bn, bk); src = bk; }
@@ -194,16 +182,6 @@ __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP 
             pf_f[0] = *reinterpret_cast<const float4 *>(fa); pf_f[1] = *reinterpret_cast<const float4 *>(fa + 4);
             pf_f[2] = *reinterpret_cast<const float4 *>(fb); pf_f[3] = *reinterpret_cast<const float4 *>(fb + 4);
         }
-        if constexpr (OUTER) {
-            // the point factor of this lane's 8 channels once per strip, prefetched for the strip's FIRST point only (register budget:
-            // 245 of 256 without it); the rows of a strip that belong to the next point (7 % of the strips have any, M >= 32) fetch
-            // theirs at the point of use
-            o_bn0 = ps.bn0; pf_k0 = ps.k0;
-            {   // (every lane loads — the lanes of the second source a valid, unused address: a conditional write sent pf_f to scratch)
-                const float *fa = p.enc_n + (unsigned)(o_bn0 * p.split + (lane_c < p.split ? lane_c : 0));
-                pf_f[0] = *reinterpret_cast<const float4 *>(fa); pf_f[1] = *reinterpret_cast<const float4 *>(fa + 4);
-            }
-        }
     };
     auto commit = [&](long long) {
 #pragma unroll
@@ -220,19 +198,6 @@ __global__ __launch_bounds__(RG_THREADS, XBF16 ? 2 : 1) void rg_fwd_kernel(FwdP 
                     const bool second = pf_k0 + r >= p.pM;           // (rows past the end: values never stored)
                     const float4 f0 = second ? pf_f[2] : pf_f[0], f1 = second ? pf_f[3] : pf_f[1];
                     f[0] *= f0.x; f[1] *= f0.y; f[2] *= f0.z; f[3] *= f0.w; f[4] *= f1.x; f[5] *= f1.y; f[6] *= f1.z; f[7] *= f1.w;
-                }
-                if constexpr (OUTER) {
-                    if (lane_c < p.split) {                          // ye = enc_n + q (fp32), then BN + activation as for a stored tensor
-                        float4 f0 = pf_f[0], f1 = pf_f[1];
-                        // (opaque copies: without them clang selects between the two ADDRESSES and loads once, which puts pf_f in scratch)
-                        asm volatile("" : "+v"(f0.x), "+v"(f0.y), "+v"(f0.z), "+v"(f0.w), "+v"(f1.x), "+v"(f1.y), "+v"(f1.z), "+v"(f1.w));
-                        if (pf_k0 + r >= p.pM) {
-                            const int bn1 = o_bn0 + 1 < o_total ? o_bn0 + 1 : o_bn0;
-                            const float *fb = p.enc_n + (unsigned)(bn1 * p.split + lane_c);
-                            f0 = *reinterpret_cast<const float4 *>(fb); f1 = *reinterpret_cast<const float4 *>(fb + 4);
-                        }
-                        f[0] += f0.x; f[1] += f0.y; f[2] += f0.z; f[3] += f0.w; f[4] += f1.x; f[5] += f1.y; f[6] += f1.z; f[7] += f1.w;
-                    }
                 }
                 if (has_coef) {
 #pragma unroll
@@ -1146,21 +1111,21 @@ __global__ void bnbwd_coef_bf16(long long rows, int c, const double *__restrict_
 inline bool pow2_16_128(int c) { return c == 16 || c == 32 || c == 64 || c == 128; }
 inline int log2i(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
-template <int NT, bool XBF16, bool PAIR, bool OUTER = false>
+template <int NT, bool XBF16, bool PAIR>
 int launch_fwd(const FwdP &p, hipStream_t st) {
     const int strip = RG_ROWS << (p.cpi_s > p.cpo_s ? p.cpi_s : p.cpo_s);
     const size_t bytes = ((size_t)((32 * NT) << p.cpi_s) + 4 * (size_t)strip) * sizeof(uint4);
     if (bytes > 160 * 1024) return I2P_ERR_BAD_ARG;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rg_fwd_kernel<NT, XBF16, PAIR, OUTER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rg_fwd_kernel<NT, XBF16, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const long long nstrips = (p.rows + RG_ROWS - 1) / RG_ROWS;
     long long g = (nstrips + 3) / 4;
     const long long cap = (XBF16 && bytes <= 80 * 1024) ? 512 : 256;
     const unsigned grid = (unsigned)(g < cap ? (g < 1 ? 1 : g) : cap);
-    hipLaunchKernelGGL((rg_fwd_kernel<NT, XBF16, PAIR, OUTER>), dim3(grid), dim3(RG_THREADS), bytes, st, p);
+    hipLaunchKernelGGL((rg_fwd_kernel<NT, XBF16, PAIR>), dim3(grid), dim3(RG_THREADS), bytes, st, p);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
@@ -1355,21 +1320,6 @@ extern "C" int i2p_lin_fwd_2src_bf16(long long rows, int cin_a, int cin_b, int c
                     nullptr, nullptr, nullptr, 1, 1, stream);
 }
 
-// the two-source layer with its FIRST source formed on load: xa[(b,n,k), :] = enc_n[b,n,:] + q16[b,k,:] (i2p_outer_prep_bf16)
-extern "C" int i2p_lin_fwd_2src_outer_bf16(int B, int N, int M, int cin_a, int cin_b, int cout, const float *enc_n, const bf16_t *q16,
-                                           const float *coef_a, float slope_a, const bf16_t *xb, const float *coef_b, float slope_b,
-                                           const float *w, bf16_t *y, double *sums, void *stream) {
-    const long long rows = (long long)B * N * M;
-    if (B <= 0 || N <= 0 || M < 32 || cin_a != 64 || cin_b != 64 || cout != 128 || rows >= (1LL << 31) || !enc_n || !q16 || !xb || !coef_a ||
-        !coef_b || !w || !y) return I2P_ERR_BAD_ARG;
-    FwdP p{};
-    p.rows = rows; p.cin = 128; p.cout = cout; p.ncx = 16; p.cpi_s = 4; p.cpo_s = log2i(cout / 8);
-    p.x = nullptr; p.x_ld = 0; p.xb = xb; p.xb_ld = cin_b; p.split = cin_a;
-    p.coef_a = coef_a; p.coef_b = coef_b; p.slope_a = slope_a; p.slope_b = slope_b; p.w = w; p.y = y; p.sums = sums;
-    p.pN = N; p.pM = M; p.enc_n = enc_n; p.q16 = q16;
-    return launch_fwd<4, true, false, true>(p, (hipStream_t)stream);
-}
-
 extern "C" int i2p_pair_lin_fwd_bf16(int B, int N, int M, int cin, int cout, const float *f, const float *g,
                                      const float *bias_n, const float *bias_k, const float *w, bf16_t *y, double *sums,
                                      void *stream) {
@@ -1399,35 +1349,6 @@ extern "C" int i2p_lin_bwd_2src_bf16(long long rows, int cin_a, int cin_b, int c
     t.e_add = e_add_b;
     return bwd_impl(rows, cin_a + cin_b, cout, gz, y, out_coef, out_mi, out_dsums, xa, 1, coef_a, mi_a, slope_a, w, gz_a, 1, dsums_a,
                     dw_partial, dw, 1.f, &t, stream);
-}
-
-// 1 when the position encoding of a [B, N, M] cost volume can be formed on load by the two-source 64 + 64 -> 128 layer (forward AND backward
-// kernels exist for the shape); I2P_NO_OUTER_ON_LOAD=1 keeps the stored [rows, 64] tensor (A/B)
-extern "C" int i2p_outer_on_load_ok(int B, int N, int M, int cin_a, int cin_b, int cout) {
-    const char *e = getenv("I2P_NO_OUTER_ON_LOAD");
-    if (e && e[0] == '1') return 0;
-    const long long rows = (long long)B * N * M;
-    return B > 0 && N > 0 && M >= 32 && rows < (1LL << 31) && cin_a == 64 && cin_b == 64 && cout == 128 && i2p_lin_bwd_bf16_grid(rows) == 256 &&
-           i2p_bwd_fused2_bf16_ok(rows, cin_a, cin_b, cout);
-}
-
-// i2p_lin_bwd_2src_bf16 with the first source formed on load (i2p_outer_prep_bf16): xa[(b,n,k), :] = enc_n[b,n,:] + q16[b,k,:]
-extern "C" int i2p_lin_bwd_2src_outer_bf16(int B, int N, int M, int cin_a, int cin_b, int cout, const bf16_t *gz, const bf16_t *y,
-                                           const float *out_coef, const float *out_mi, const double *out_dsums, const float *enc_n,
-                                           const bf16_t *q16, const float *coef_a, const float *mi_a, float slope_a, const bf16_t *xb,
-                                           const float *coef_b, const float *mi_b, float slope_b, const bf16_t *e_add_b, const float *w,
-                                           bf16_t *gz_a, double *dsums_a, bf16_t *gz_b, double *dsums_b, float *dw_partial, float *dw,
-                                           void *stream) {
-    if (!i2p_outer_on_load_ok(B, N, M, cin_a, cin_b, cout) || !dw_partial || !dw) return I2P_ERR_BAD_ARG;
-    const long long rows = (long long)B * N * M;
-    const unsigned grid = (unsigned)i2p_lin_bwd_bf16_grid(rows);
-    float *g_coef = dw_partial + (size_t)grid * cout * (cin_a + cin_b);              // [8][cout] scratch tail; rows 6, 7 = dbeta, dgamma for the caller
-    const int rc = i2p_bwd_fused2_outer_bf16(B, N, M, gz, y, out_dsums, out_coef, out_mi, g_coef, enc_n, q16, coef_a, mi_a, slope_a, xb, coef_b, mi_b,
-                                             slope_b, e_add_b, w, gz_a, dsums_a, gz_b, dsums_b, dw_partial, grid, stream);
-    if (rc) return rc;
-    const int n = cout * (cin_a + cin_b);
-    hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, (int)grid, n, dw_partial, dw);
-    I2P_RETURN_LAUNCH_STATUS();
 }
 
 static int pair_bwd_gen1_grid(int B, int N, int M) {

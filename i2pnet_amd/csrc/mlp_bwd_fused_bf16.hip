@@ -388,9 +388,7 @@ constexpr int F2_ROWS = 16, F2_K = 128, F2_C = 128, F2_H = 64;
 constexpr int F2_PW = 272, F2_PT = 48, F2_PE = 144;
 constexpr int F2_WS = 128 * F2_PW;                       // W^T image
 constexpr int F2_GR = F2_ROWS * F2_PW, F2_GT = F2_K * F2_PT, F2_AT = F2_C * F2_PT, F2_XR = F2_ROWS * F2_PW, F2_ER = F2_ROWS * F2_PE;
-constexpr int F2_EN = 2 * 64 * 4;                        // OUTER: the point factor of the strip's (at most two) points, 64 fp32 channels each
-constexpr int F2_ST = 4 * 64 * 16;                       // OUTER: the lanes' running statistics {s1a, s2a, s1b, s2b} as four [64 lanes] float4 rows
-constexpr int F2_WAVE = F2_GR + F2_GT + F2_AT + F2_XR + F2_ER + F2_EN + F2_ST;
+constexpr int F2_WAVE = F2_GR + F2_GT + F2_AT + F2_XR + F2_ER;
 constexpr int F2_TAB = (3 * F2_K + 4 * F2_C) * 4;
 static_assert(F2_AT >= F2_ROWS * F2_PW, "the packed D strip re-uses the transposed input image");
 
@@ -406,27 +404,9 @@ struct Fused2P {
     bf16_t *gz_a, *gz_b;         // [rows, 64]
     double *sums_a, *sums_b;     // [REP][2*64]
     float *dw_partial;           // [grid][128*128]
-    // OUTER instantiation: source a of row (b,n,k) = enc_n[b,n,:] + q16[b,k,:] (fp32 sum), xa unused; rows = B*N*M, M >= 16
-    const float *enc_n; const bf16_t *q16; int N, M;
 };
 
-struct Raw2 { uint4 g[4], y[4]; uint2 xa[4], xb[4], e[4]; float4 en, en1; };
-
-// (b,n) and k of the first row of a strip, wave-uniform (one 32-bit division pair per strip on the scalar unit)
-// bn0 = index of the point (b,n) of the strip's first row, k0 its pixel; qoff = byte offset of row (b, k0) in q16 [B*M, 64];
-// wrap_at = first row of the strip that belongs to the NEXT point (>= 16: none), wrap_sub = what its q16 offset lies back by
-// (M rows when the next point is in the same sample, 0 when it opens the next sample: the pixel rows then simply continue)
-struct Geo2 { int bn0, bn1, wrap_at; unsigned qoff, wrap_sub; };
-__device__ __forceinline__ Geo2 geo2(long long row0, int N, int M, int total_bn) {
-    Geo2 g;
-    const unsigned r = (unsigned)__builtin_amdgcn_readfirstlane((int)row0);
-    const unsigned bn0 = r / (unsigned)M, k0 = r - bn0 * (unsigned)M;
-    const unsigned b0 = bn0 / (unsigned)N, n0 = bn0 - b0 * (unsigned)N;
-    g.bn0 = (int)bn0; g.bn1 = (int)bn0 + 1 < total_bn ? (int)bn0 + 1 : (int)bn0; g.wrap_at = (int)((unsigned)M - k0);
-    g.qoff = (b0 * (unsigned)M + k0) * (unsigned)(F2_H * 2);
-    g.wrap_sub = n0 + 1u < (unsigned)N ? (unsigned)M * (unsigned)(F2_H * 2) : 0u;
-    return g;
-}
+struct Raw2 { uint4 g[4], y[4]; uint2 xa[4], xb[4], e[4]; };
 
 __device__ __forceinline__ uint2 ld_u2_stream(const void *ptr) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -439,7 +419,6 @@ __device__ __forceinline__ void st_u2_stream(void *ptr, const uint2 &v) {
     __builtin_nontemporal_store(t, reinterpret_cast<u32x2 *>(ptr));
 }
 
-template <bool OUTER>
 __global__ __launch_bounds__(FB_THREADS, 1) void bwd_fused2_bf16_kernel(Fused2P p) {
     extern __shared__ uint4 smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -447,10 +426,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void bwd_fused2_bf16_kernel(Fused2P 
     char *Ws = reinterpret_cast<char *>(smem);           // row 16t + m = W^T row of channel 32 (m >> 2) + 4t + (m & 3), 16 chunks along k
     char *Wv = Ws + F2_WS + wave * F2_WAVE;
     char *Gr = Wv, *Gt = Gr + F2_GR, *At = Gt + F2_GT, *Dr = At, *Xr = At + F2_AT, *Er = Xr + F2_XR;
-    float *En = reinterpret_cast<float *>(Er + F2_ER);   // [2][64]
-    // OUTER: the 16 running sums of a lane live in LDS (read - add - write once per strip and source: lane-private rows, no atomics) —
-    // the 16 registers they held are what the on-load position encoding needs (the kernel sits at 256 + 256)
-    float4 *St = reinterpret_cast<float4 *>(Er + F2_ER + F2_EN) + lane;
     float *tab = reinterpret_cast<float *>(Ws + F2_WS + 4 * F2_WAVE);        // gA, gB, gC [128]; sa, sb, xp, xq [128] (a | b)
 
     for (int i = tid; i < 128 * 16; i += FB_THREADS) {
@@ -489,16 +464,11 @@ __global__ __launch_bounds__(FB_THREADS, 1) void bwd_fused2_bf16_kernel(Fused2P 
     float s1a[4], s2a[4], s1b[4], s2b[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { s1a[q] = 0.f; s2a[q] = 0.f; s1b[q] = 0.f; s2b[q] = 0.f; }
-    if constexpr (OUTER) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) St[64 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
 
     Raw2 R;
     const char *gzb = reinterpret_cast<const char *>(p.gz), *yb = reinterpret_cast<const char *>(p.y);
     const char *xab = reinterpret_cast<const char *>(p.xa), *xbb = reinterpret_cast<const char *>(p.xb), *eb = reinterpret_cast<const char *>(p.e_add);
-    const unsigned q_lane = (unsigned)((rq_ * F2_H + 4 * cq_) * 2);
-    auto load_strip = [&](unsigned goff, unsigned xoff, const Geo2 &ge) {
+    auto load_strip = [&](unsigned goff, unsigned xoff) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             R.g[j] = ld_u4_stream(gzb + goff + j * (4 * F2_K * 2));
@@ -506,32 +476,16 @@ __global__ __launch_bounds__(FB_THREADS, 1) void bwd_fused2_bf16_kernel(Fused2P 
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if constexpr (OUTER) {                           // the pixel factor's row of (b, k): re-read by every point, cached loads
-                unsigned off = ge.qoff + q_lane + (unsigned)(j * 4 * F2_H * 2);
-                if (rq_ + 4 * j >= ge.wrap_at) off -= ge.wrap_sub;
-                R.xa[j] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(p.q16) + off);
-            } else {
-                R.xa[j] = ld_u2_stream(xab + xoff + j * (4 * F2_H * 2));
-            }
+            R.xa[j] = ld_u2_stream(xab + xoff + j * (4 * F2_H * 2));
             R.xb[j] = ld_u2_stream(xbb + xoff + j * (4 * F2_H * 2));
             R.e[j] = ld_u2_stream(eb + xoff + j * (4 * F2_H * 2));
         }
-        if constexpr (OUTER) {                               // the point factor of the strip's first point and of the next one (branch-free:
-            R.en = *reinterpret_cast<const float4 *>(p.enc_n + (unsigned)(ge.bn0 * F2_H + 4 * cq_));     // a conditional path here cost 66 spills)
-            R.en1 = *reinterpret_cast<const float4 *>(p.enc_n + (unsigned)(ge.bn1 * F2_H + 4 * cq_));
-        }
     };
 
-    auto strip = [&](auto prefetch_tag, long long row0, unsigned goff_next, unsigned xoff_next, const Geo2 &gcur, const Geo2 &gnext) {
+    auto strip = [&](auto prefetch_tag, long long row0, unsigned goff_next, unsigned xoff_next) {
         constexpr bool PREFETCH = decltype(prefetch_tag)::value;
         int cq = cq_, rq = rq_, n = n_, h = h_;
         asm volatile("" : "+v"(cq), "+v"(rq), "+v"(n), "+v"(h));
-        // OUTER: rows d >= wrap_at of this strip belong to the NEXT point (3 % of the strips have any: M >= 16)
-        const int wrap_at = OUTER ? gcur.wrap_at : F2_ROWS;
-        if constexpr (OUTER) {                               // (the four lanes of a channel group write the same values: no branch)
-            *reinterpret_cast<float4 *>(En + 4 * cq) = R.en;
-            *reinterpret_cast<float4 *>(En + 64 + 4 * cq) = R.en1;
-        }
         char *t_half = reinterpret_cast<char *>(0) + (rq >> 1) * 16 + (rq & 1) * 8;      // this lane's half chunk in a transposed row
         const int toff = (int)(t_half - reinterpret_cast<char *>(0));
         // -- staging: g^y -> Gr (row-major) + Gt (transposed) ---------------------------------------------------------------------
@@ -569,11 +523,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void bwd_fused2_bf16_kernel(Fused2P 
                 const uint2 raw = src ? R.xb[j] : R.xa[j];
                 *reinterpret_cast<uint2 *>(Xr + (rq + 4 * j) * F2_PW + 128 * src + cq * 8) = raw;
                 if (src) *reinterpret_cast<uint2 *>(Er + (rq + 4 * j) * F2_PE + cq * 8) = R.e[j];
-                float x0 = bf_lo(raw.x), x1 = bf_hi(raw.x), x2 = bf_lo(raw.y), x3 = bf_hi(raw.y);
-                if (OUTER && src == 0) {                     // ye = enc_n + q, fp32
-                    const bool w1 = rq + 4 * j >= wrap_at;
-                    x0 += w1 ? R.en1.x : R.en.x; x1 += w1 ? R.en1.y : R.en.y; x2 += w1 ? R.en1.z : R.en.z; x3 += w1 ? R.en1.w : R.en.w;
-                }
+                const float x0 = bf_lo(raw.x), x1 = bf_hi(raw.x), x2 = bf_lo(raw.y), x3 = bf_hi(raw.y);
                 a[j][0] = bf_act(bf_bnz(x0, sa[0], sb[0]), slope); a[j][1] = bf_act(bf_bnz(x1, sa[1], sb[1]), slope);
                 a[j][2] = bf_act(bf_bnz(x2, sa[2], sb[2]), slope); a[j][3] = bf_act(bf_bnz(x3, sa[3], sb[3]), slope);
             }
@@ -582,7 +532,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void bwd_fused2_bf16_kernel(Fused2P 
                 *reinterpret_cast<uint2 *>(At + (64 * src + 4 * cq + q) * F2_PT + toff) = make_uint2(bf_pack2(a[0][q], a[1][q]), bf_pack2(a[2][q], a[3][q]));
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (PREFETCH) load_strip(goff_next, xoff_next, gnext);
+        if constexpr (PREFETCH) load_strip(goff_next, xoff_next);
         __builtin_amdgcn_sched_barrier(0);
         wave_sync_lds();
         // -- dW += g^y^T a: ONE 16-row contraction step ---------------------------------------------------------------------------
@@ -632,22 +582,13 @@ __global__ __launch_bounds__(FB_THREADS, 1) void bwd_fused2_bf16_kernel(Fused2P 
             ldc<4>(tx, sa); ldc<4>(tx + F2_C, sb); ldc<4>(tx + 2 * F2_C, xp); ldc<4>(tx + 3 * F2_C, xq);
             const float slope = src ? p.slope_b : p.slope_a;
             bf16_t *dst = src ? p.gz_b : p.gz_a;
-            float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};     // OUTER: this strip's and source's running sums, from / to LDS
-            if constexpr (OUTER) {
-                const float4 a = St[64 * (2 * src)], b = St[64 * (2 * src + 1)];
-                t1[0] = a.x; t1[1] = a.y; t1[2] = a.z; t1[3] = a.w; t2[0] = b.x; t2[1] = b.y; t2[2] = b.z; t2[3] = b.w;
-            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = rq + 4 * j;
                 const uint2 dv = *reinterpret_cast<const uint2 *>(Dr + r * F2_PW + 128 * src + cq * 8);
                 const uint2 xr = *reinterpret_cast<const uint2 *>(Xr + r * F2_PW + 128 * src + cq * 8);
                 float f[4] = {bf_lo(dv.x), bf_hi(dv.x), bf_lo(dv.y), bf_hi(dv.y)};
-                float xv[4] = {bf_lo(xr.x), bf_hi(xr.x), bf_lo(xr.y), bf_hi(xr.y)};
-                if (OUTER && src == 0) {
-                    const float4 en = *reinterpret_cast<const float4 *>(En + (r >= wrap_at ? 64 : 0) + 4 * cq);
-                    xv[0] += en.x; xv[1] += en.y; xv[2] += en.z; xv[3] += en.w;
-                }
+                const float xv[4] = {bf_lo(xr.x), bf_hi(xr.x), bf_lo(xr.y), bf_hi(xr.y)};
                 if (src) {
                     const uint2 ev = *reinterpret_cast<const uint2 *>(Er + r * F2_PE + cq * 8);
                     f[0] += bf_lo(ev.x); f[1] += bf_hi(ev.x); f[2] += bf_lo(ev.y); f[3] += bf_hi(ev.y);
@@ -657,15 +598,11 @@ __global__ __launch_bounds__(FB_THREADS, 1) void bwd_fused2_bf16_kernel(Fused2P 
                     f[q] = bf_bnz(xv[q], sa[q], sb[q]) > 0.f ? f[q] : f[q] * slope;
                     f[q] = bf_round(f[q]);
                     const float xh = __builtin_fmaf(xv[q], xp[q], xq[q]);
-                    if constexpr (OUTER) { t1[q] += f[q]; t2[q] = __builtin_fmaf(f[q], xh, t2[q]); }
-                    else if (src) { s1b[q] += f[q]; s2b[q] = __builtin_fmaf(f[q], xh, s2b[q]); }
+                    if (src) { s1b[q] += f[q]; s2b[q] = __builtin_fmaf(f[q], xh, s2b[q]); }
                     else { s1a[q] += f[q]; s2a[q] = __builtin_fmaf(f[q], xh, s2a[q]); }
                 }
                 st_u2_stream(dst + (size_t)(row0 + r) * F2_H + 4 * cq, make_uint2(bf_pack2(f[0], f[1]), bf_pack2(f[2], f[3])));
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (OUTER) {
-                St[64 * (2 * src)] = make_float4(t1[0], t1[1], t1[2], t1[3]); St[64 * (2 * src + 1)] = make_float4(t2[0], t2[1], t2[2], t2[3]);
             }
         }
         wave_sync_lds();
@@ -681,26 +618,16 @@ __global__ __launch_bounds__(FB_THREADS, 1) void bwd_fused2_bf16_kernel(Fused2P 
         unsigned xoff = (unsigned)((((size_t)first * F2_ROWS + rq_) * F2_H + 4 * cq_) * 2);
         const unsigned g_step = __builtin_amdgcn_readfirstlane((unsigned)(stride * F2_ROWS * F2_K * 2));
         const unsigned x_step = __builtin_amdgcn_readfirstlane((unsigned)(stride * F2_ROWS * F2_H * 2));
+        load_strip(goff, xoff);
         long long row0 = first * F2_ROWS;
-        Geo2 gcur{0, 0, F2_ROWS, 0u, 0u}, gnext{0, 0, F2_ROWS, 0u, 0u};
-        const int total_bn = OUTER ? (int)(p.rows / p.M) : 0;
-        if constexpr (OUTER) gcur = geo2(row0, p.N, p.M, total_bn);
-        load_strip(goff, xoff, gcur);
         for (int k = 0; k + 1 < n_mine; ++k) {
             goff += g_step; xoff += x_step;
-            if constexpr (OUTER) gnext = geo2(row0 + stride * F2_ROWS, p.N, p.M, total_bn);
-            strip(yes, row0, goff, xoff, gcur, gnext);
+            strip(yes, row0, goff, xoff);
             row0 += stride * F2_ROWS;
-            gcur = gnext;
         }
-        strip(no, row0, 0u, 0u, gcur, gnext);
+        strip(no, row0, 0u, 0u);
     }
     // ---- statistics: lanes with equal cq own the same 4 channels of each source -----------------------------------------------
-    if constexpr (OUTER) {
-        const float4 a = St[0], b = St[64], c = St[128], d = St[192];
-        s1a[0] = a.x; s1a[1] = a.y; s1a[2] = a.z; s1a[3] = a.w; s2a[0] = b.x; s2a[1] = b.y; s2a[2] = b.z; s2a[3] = b.w;
-        s1b[0] = c.x; s1b[1] = c.y; s1b[2] = c.z; s1b[3] = c.w; s2b[0] = d.x; s2b[1] = d.y; s2b[2] = d.z; s2b[3] = d.w;
-    }
 #pragma unroll
     for (int src = 0; src < 2; ++src) {
         double *sums = src ? p.sums_b : p.sums_a;
@@ -737,20 +664,6 @@ __global__ __launch_bounds__(FB_THREADS, 1) void bwd_fused2_bf16_kernel(Fused2P 
     float *out = p.dw_partial + (size_t)blockIdx.x * F2_K * F2_C;
     for (int t = tid; t < F2_K * F2_C / 4; t += FB_THREADS)
         *reinterpret_cast<float4 *>(out + 4 * t) = *reinterpret_cast<const float4 *>(red + 4 * t);
-}
-
-template <bool OUTER>
-int launch2(const Fused2P &p, unsigned grid, hipStream_t st) {
-    constexpr size_t bytes = (size_t)F2_WS + 4 * (size_t)F2_WAVE + F2_TAB;
-    static_assert(bytes <= 160 * 1024, "LDS budget");
-    static_assert(bytes >= (size_t)F2_K * F2_C * sizeof(float), "dW reduction buffer");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_fused2_bf16_kernel<OUTER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(bwd_fused2_bf16_kernel<OUTER>, dim3(grid), dim3(FB_THREADS), bytes, st, p);
-    I2P_RETURN_LAUNCH_STATUS();
 }
 
 template <int C>
@@ -808,24 +721,14 @@ int i2p_bwd_fused2_bf16(long long rows, const unsigned short *gz, const unsigned
     p.rows = rows; p.gz = gz; p.y = y; p.g = BnBwdSrc{out_dsums, out_coef, out_mi, rows, coef8, F2_K}; p.xa = xa; p.xb = xb; p.coef_a = coef_a; p.mi_a = mi_a; p.coef_b = coef_b; p.mi_b = mi_b;
     p.slope_a = slope_a; p.slope_b = slope_b; p.e_add = e_add; p.w = w; p.gz_a = gz_a; p.gz_b = gz_b; p.sums_a = sums_a; p.sums_b = sums_b;
     p.dw_partial = dw_partial;
-    p.enc_n = nullptr; p.q16 = nullptr; p.N = p.M = 1;
-    return launch2<false>(p, grid, (hipStream_t)stream);
-}
-
-// the same pass with source a formed on load from the position-encoding factors (i2p_outer_prep_bf16)
-int i2p_bwd_fused2_outer_bf16(int B, int N, int M, const unsigned short *gz, const unsigned short *y, const double *out_dsums, const float *out_coef,
-                              const float *out_mi, float *coef8, const float *enc_n, const unsigned short *q16, const float *coef_a, const float *mi_a,
-                              float slope_a, const unsigned short *xb, const float *coef_b, const float *mi_b, float slope_b, const unsigned short *e_add,
-                              const float *w, unsigned short *gz_a, double *sums_a, unsigned short *gz_b, double *sums_b, float *dw_partial, unsigned grid,
-                              void *stream) {
-    const long long rows = (long long)B * N * M;
-    if (B <= 0 || N <= 0 || M < F2_ROWS || !i2p_bwd_fused2_bf16_ok(rows, F2_H, F2_H, F2_K) || !gz || !y || !out_dsums || !out_coef || !out_mi || !enc_n || !q16 ||
-        !xb || !coef_a || !mi_a || !coef_b || !mi_b || !e_add || !w || !gz_a || !gz_b || !sums_a || !sums_b || !dw_partial || grid == 0)
-        return I2P_ERR_BAD_ARG;
-    Fused2P p;
-    p.rows = rows; p.gz = gz; p.y = y; p.g = BnBwdSrc{out_dsums, out_coef, out_mi, rows, coef8, F2_K}; p.xa = nullptr; p.xb = xb; p.coef_a = coef_a; p.mi_a = mi_a; p.coef_b = coef_b; p.mi_b = mi_b;
-    p.slope_a = slope_a; p.slope_b = slope_b; p.e_add = e_add; p.w = w; p.gz_a = gz_a; p.gz_b = gz_b; p.sums_a = sums_a; p.sums_b = sums_b;
-    p.dw_partial = dw_partial;
-    p.enc_n = enc_n; p.q16 = q16; p.N = N; p.M = M;
-    return launch2<true>(p, grid, (hipStream_t)stream);
+    constexpr size_t bytes = (size_t)F2_WS + 4 * (size_t)F2_WAVE + F2_TAB;
+    static_assert(bytes <= 160 * 1024, "LDS budget");
+    static_assert(bytes >= (size_t)F2_K * F2_C * sizeof(float), "dW reduction buffer");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_fused2_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(bwd_fused2_bf16_kernel, dim3(grid), dim3(FB_THREADS), bytes, (hipStream_t)stream, p);
+    I2P_RETURN_LAUNCH_STATUS();
 }

@@ -379,13 +379,7 @@ class _CvPiTail(Function):
         y1, st1, c1, m1 = be_.pair_lin_forward_fin(f, g, bias_n, bias_k, W1, d(g1), d(b1), _EPS, out_dtype=dt)
         y2, st2, c2, m2 = be_.lin_forward_fin(y1, c1, s1, d(W2), d(g2), d(b2), _EPS, out_dtype=dt)
         y3, st3, c3, m3 = be_.lin_forward_fin(y2, c2, s2, d(W3), d(g3), d(b3), _EPS, out_dtype=dt)
-        on_load = bf and be_.outer_on_load_ok(B, N, M, enc_n.shape[-1], W3.shape[0], W4.shape[0])
-        q16 = q32 = None
-        if on_load:
-            # the position encoding is never written: the two-source kernels read enc_n[b,n] + bf16(enc_k[b,k]); its BN sums in closed form
-            q16, q32, ste = be_.outer_prep_bf16(enc_n, enc_k)
-            ye = None
-        elif bf:
+        if bf:
             ye, ste = be_.outer_sum_bf16(enc_n, enc_k)
         elif be_.device_type == "cuda" and be_.name == "hip" and enc_n.shape[-1] % 8 == 0:
             ye, ste = be_.outer_sum(enc_n, enc_k)              # the broadcast sum and its statistics in one pass
@@ -393,18 +387,13 @@ class _CvPiTail(Function):
             ye = (enc_n.unsqueeze(2) + enc_k.unsqueeze(1)).view(rows, -1)
             ste = be_.bn_stats(ye)
         ce, me = be_.bn_finalize(rows, ste, d(ge), d(be), _EPS)
-        if on_load:
-            y4, st4 = be_.lin_forward_2src_outer(enc_n, q16, ce, se, y3, c3, s3, d(W4))
-            c4, m4 = be_.bn_finalize(rows, st4, d(g4), d(b4), _EPS)
-        else:
-            y4, st4, c4, m4 = be_.lin_forward_2src_fin(ye, ce, se, y3, c3, s3, d(W4), d(g4), d(b4), _EPS)
+        y4, st4, c4, m4 = be_.lin_forward_2src_fin(ye, ce, se, y3, c3, s3, d(W4), d(g4), d(b4), _EPS)
         y5, st5, c5, m5 = be_.lin_forward_fin(y4, c4, s4, d(W5), d(g5), d(b5), _EPS, out_dtype=dt)
         for i_, m_ in enumerate((m1, m2, m3, me, m4, m5)):       # BatchNorm2d running buffers (small-range model)
             _update_running(running, i_, m_, rows)
         out, msave = be_.cv_softmax_wsum_forward(B, N, M, y5, c5, s5, y3, c3, s3)
-        ctx.on_load = on_load
-        ctx.save_for_backward(y1, q16 if on_load else ye, y2, y3, y4, y5, c1, m1, c2, m2, c3, m3, ce, me, c4, m4, c5, m5, out, msave,
-                              W2, W3, W4, W5, f, g, W1, enc_n, q32 if on_load else enc_k)
+        ctx.save_for_backward(y1, ye, y2, y3, y4, y5, c1, m1, c2, m2, c3, m3, ce, me, c4, m4, c5, m5, out, msave,
+                              W2, W3, W4, W5, f, g, W1, enc_n, enc_k)
         ctx.dims, ctx.slopes = (B, N, M), slopes
         return out
 
@@ -412,7 +401,7 @@ class _CvPiTail(Function):
     def backward(ctx, g_out):
         be_ = ops.get_backend()
         (y1, ye, y2, y3, y4, y5, c1, m1, c2, m2, c3, m3, ce, me, c4, m4, c5, m5, out, msave,
-         W2, W3, W4, W5, f, g, W1, enc_n, enc_k) = ctx.saved_tensors          # (on_load: ye = q16, enc_k = q32 = the rounded pixel factor)
+         W2, W3, W4, W5, f, g, W1, enc_n, enc_k) = ctx.saved_tensors
         B, N, M = ctx.dims
         s1, s2, s3, se, s4, s5 = ctx.slopes
         d = lambda t: t.detach()
@@ -420,12 +409,9 @@ class _CvPiTail(Function):
         gz5, ds5, ga3 = be_.cv_softmax_wsum_backward(B, N, M, g_out.contiguous(), out, msave, y5, c5, m5, s5, y3, c3, s3)
         # (gamma/beta gradients of a BN come back reduced from the call that consumes its sums: `last_bn_grads`)
         gz4, ds4, dW5 = be_.lin_backward(gz5, y5, c5, m5, ds5, y4, c4, m4, s4, d(W5)); dg5, db5 = be_.take_bn_grads()
-        if ctx.on_load:
-            gze, dse, gz3, ds3, dW4 = be_.lin_backward_2src_outer(gz4, y4, c4, m4, ds4, enc_n, ye, ce, me, se, y3, c3, m3, s3, ga3, d(W4))
-        else:
-            gze, dse, gz3, ds3, dW4 = be_.lin_backward_2src(gz4, y4, c4, m4, ds4, ye, ce, me, se, y3, c3, m3, s3, ga3, d(W4))
+        gze, dse, gz3, ds3, dW4 = be_.lin_backward_2src(gz4, y4, c4, m4, ds4, ye, ce, me, se, y3, c3, m3, s3, ga3, d(W4))
         dg4, db4 = be_.take_bn_grads()
-        re = _rep_sum(dse, enc_n.shape[-1], torch.float32)
+        re = _rep_sum(dse, ye.shape[1], torch.float32)
         gz2, ds2, dW3 = be_.lin_backward(gz3, y3, c3, m3, ds3, y2, c2, m2, s2, d(W3)); dg3, db3 = be_.take_bn_grads()
         gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2)); dg2, db2 = be_.take_bn_grads()
         r1 = _rep_sum(ds1, y1.shape[1], torch.float32)

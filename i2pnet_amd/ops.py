@@ -729,55 +729,6 @@ class CBackend:
                    self._p(ye, _BF16, "ye"), self._p(sums, torch.float64, "sums"), stream=self._stream())
         return ye, sums
 
-    def outer_prep_bf16(self, enc_n, enc_k):
-        """enc_n [B,N,C], enc_k [B,M,C] -> (q16 bf16 [B,M,C], q32 = its values as fp32, replicated BN sums of enc_n[b,n] + q[b,k] over all pairs)
-        — the position encoding is then formed on load by lin_forward_2src_outer / lin_backward_2src_outer"""
-        B, N, C = enc_n.shape
-        M = enc_k.shape[1]
-        q16 = torch.empty(B, M, C, dtype=_BF16, device=enc_n.device); q32 = torch.empty(B, M, C, dtype=_F32, device=enc_n.device)
-        sums = zeros(BN_REPLICAS * 2 * C, torch.float64, enc_n.device)
-        self._call("i2p_outer_prep_bf16", int(B), int(N), int(M), int(C), self._p(enc_n, _F32, "enc_n"), self._p(enc_k, _F32, "enc_k"),
-                   self._p(q16, _BF16, "q16"), self._p(q32, _F32, "q32"), self._p(sums, torch.float64, "sums"), stream=self._stream())
-        return q16, q32, sums
-
-    def lin_forward_2src_outer(self, enc_n, q16, coef_a, slope_a, xb, coef_b, slope_b, w):
-        """lin_forward_2src with xa[(b,n,k)] = enc_n[b,n] + q16[b,k] formed on load -> (y bf16 [B*N*M, cout], sums)"""
-        B, N, ca = enc_n.shape
-        M = q16.shape[1]
-        rows, cb, cout = B * N * M, xb.shape[1], w.shape[0]
-        y = torch.empty(rows, cout, dtype=_BF16, device=xb.device)
-        sums = zeros(BN_REPLICAS * 2 * cout, torch.float64, xb.device)
-        self._call("i2p_lin_fwd_2src_outer_bf16", int(B), int(N), int(M), int(ca), int(cb), int(cout), self._p(enc_n, _F32, "enc_n"),
-                   self._p(q16, _BF16, "q16"), self._p(coef_a, _F32, "coef_a"), float(slope_a), self._p(xb, _BF16, "xb"),
-                   self._p(coef_b, _F32, "coef_b"), float(slope_b), self._p(w, _F32, "w"), self._p(y, _BF16, "y"),
-                   self._p(sums, torch.float64, "sums"), stream=self._stream())
-        return y, sums
-
-    def outer_on_load_ok(self, B, N, M, ca, cb, cout):
-        return self.device_type == "cuda" and self.name == "hip" and bool(_lib.helper("i2p_outer_on_load_ok", int(B), int(N), int(M), int(ca), int(cb), int(cout)))
-
-    def lin_backward_2src_outer(self, gz, y, out_coef, out_mi, out_dsums, enc_n, q16, coef_a, mi_a, slope_a, xb, coef_b, mi_b, slope_b, e_add_b, w):
-        """lin_backward_2src with the first source formed on load -> (gz_a, dsums_a, gz_b, dsums_b, dw)"""
-        B, N, ca = enc_n.shape
-        M = q16.shape[1]
-        rows, cout = gz.shape
-        cb = xb.shape[1]
-        dev = gz.device
-        gz_a = torch.empty(rows, ca, dtype=_BF16, device=dev); gz_b = torch.empty(rows, cb, dtype=_BF16, device=dev)
-        ds_a = zeros(BN_REPLICAS * 2 * ca, torch.float64, dev)
-        ds_b = zeros(BN_REPLICAS * 2 * cb, torch.float64, dev)
-        grid = _lib.helper("i2p_lin_bwd_bf16_grid", int(rows))
-        part = torch.empty(grid * cout * (ca + cb) + 8 * cout, dtype=_F32, device=dev)
-        dw = torch.empty(cout, ca + cb, dtype=_F32, device=dev)
-        P = lambda t, dt=_F32: (self._p(t, dt, "t") if t is not None else None)
-        self._call("i2p_lin_bwd_2src_outer_bf16", int(B), int(N), int(M), int(ca), int(cb), int(cout), P(gz, _BF16), P(y, _BF16), P(out_coef),
-                   P(out_mi), P(out_dsums, torch.float64), P(enc_n), P(q16, _BF16), P(coef_a), P(mi_a), float(slope_a), P(xb, _BF16),
-                   P(coef_b), P(mi_b), float(slope_b), P(e_add_b, _BF16), P(w), P(gz_a, _BF16), P(ds_a, torch.float64),
-                   P(gz_b, _BF16), P(ds_b, torch.float64), P(part), P(dw), stream=self._stream())
-        n = part.numel()
-        self.last_bn_grads = (part[n - cout:], part[n - 2 * cout:n - cout])
-        return gz_a, ds_a, gz_b, ds_b, dw
-
     def outer_sum(self, enc_n, enc_k):
         """enc_n [B,N,C], enc_k [B,M,C] -> (ye f32 [B*N*M, C] = enc_n[b,n] + enc_k[b,k], replicated BN sums) in one pass"""
         B, N, C = enc_n.shape

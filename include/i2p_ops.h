@@ -465,24 +465,6 @@ int i2p_outer_sum_bf16(int B, int N, int M, int C, const float *enc_n, const flo
                        void *stream); /* the same in fp32 storage: ye f32 [B*N*M, C] = enc_n[b,n,:] + enc_k[b,k,:] (PPBackbone_center.py:416-421 position encoding of all
  * point x pixel pairs, pre-BN) and its replicated BN sums in ONE pass (was: broadcast add + i2p_bn_stats) */
 int i2p_outer_sum(int B, int N, int M, int C, const float *enc_n, const float *enc_k, float *ye, double *sums, void *stream);
-/* The position encoding formed ON LOAD (bf16 storage mode, round 5): no [rows, C] tensor.  i2p_outer_prep_bf16 writes the pixel factor
- * rounded to bf16 (q16 [B,M,C]; q32 = the same values as fp32) and the BatchNorm sums of ye[b,n,k,:] = enc_n[b,n,:] + q[b,k,:] over all
- * pairs in closed form (per sample: M sum_n a + N sum_k q, M sum_n a^2 + N sum_k q^2 + 2 sum_n a sum_k q; float64), C in {32,64,128}.
- * i2p_lin_fwd_2src_outer_bf16 / i2p_lin_bwd_2src_outer_bf16 = i2p_lin_fwd_2src_bf16 / i2p_lin_bwd_2src_bf16 of the 64 + 64 -> 128 layer
- * (PPBackbone_center.py:416-426) with the first source read as enc_n[b,n,:] + q16[b,k,:] (fp32 sum) instead of xa; M >= 32,
- * rows = B*N*M < 2^31.  The backward writes gz_a [rows,64] (consumed by i2p_pair_bias_bn_bwd with q32 as its enc_k) as before. */
-int i2p_outer_prep_bf16(int B, int N, int M, int C, const float *enc_n, const float *enc_k, i2p_bf16 *q16, float *q32, double *sums,
-                        void *stream);
-int i2p_lin_fwd_2src_outer_bf16(int B, int N, int M, int cin_a, int cin_b, int cout, const float *enc_n, const i2p_bf16 *q16,
-                                const float *coef_a, float slope_a, const i2p_bf16 *xb, const float *coef_b, float slope_b,
-                                const float *w, i2p_bf16 *y, double *sums, void *stream);
-int i2p_outer_on_load_ok(int B, int N, int M, int cin_a, int cin_b, int cout);     /* 1: both kernels take the shape */
-int i2p_lin_bwd_2src_outer_bf16(int B, int N, int M, int cin_a, int cin_b, int cout, const i2p_bf16 *gz, const i2p_bf16 *y,
-                                const float *out_coef, const float *out_mi, const double *out_dsums, const float *enc_n,
-                                const i2p_bf16 *q16, const float *coef_a, const float *mi_a, float slope_a, const i2p_bf16 *xb,
-                                const float *coef_b, const float *mi_b, float slope_b, const i2p_bf16 *e_add_b, const float *w,
-                                i2p_bf16 *gz_a, double *dsums_a, i2p_bf16 *gz_b, double *dsums_b, float *dw_partial, float *dw,
-                                void *stream);
          /* ye[b,n,k,:] = bf16(enc_n[b,n,:] + enc_k[b,k,:]), sums += {sum, sum^2} */
 int i2p_to_bf16(long long n, const float *x, i2p_bf16 *y, void *stream);
 int i2p_bn_act_fwd_bf16(long long rows, int c, const i2p_bf16 *y, const float *coef, float slope, float *out, void *stream);

@@ -104,36 +104,6 @@ def test_lin_fwd_2src_bf16():
     assert torch.allclose(_sums(sums)[0], y.double().sum(0), rtol=1e-6, atol=1e-3)
 
 
-@pytest.mark.parametrize("B,N,M", [(2, 228, 468), (3, 57, 33), (1, 700, 100)])
-def test_position_encoding_on_load_forward(B, N, M):
-    """i2p_outer_prep_bf16 + i2p_lin_fwd_2src_outer_bf16: the two-source layer with its first source read as enc_n[b,n] + bf16(enc_k[b,k])
-    instead of a stored [rows, 64] tensor.  (a) q = bf16(enc_k) bit for bit, the closed-form sums = the sums over the materialised fp64
-    tensor; (b) y against fp64 on the operands the kernel forms (BN + activation of the fp32 sum, rounded to bf16 for the MFMA); (c) against
-    the stored-tensor kernel fed bf16(enc_n + q): equal up to the one rounding the stored form adds.  Strips that straddle two points
-    (M = 33, 100: every few strips) and partial last strips included."""
-    hip = _hip()
-    C = 64
-    en, ek = _rnd(B, N, C, seed=21), _rnd(B, M, C, seed=22)
-    xb = _rnd(B * N * M, 64, seed=23).to(BF)
-    ca, cb = _coef(64, 3)[0], _coef(64, 4)[0]
-    w = _rnd(128, 128, seed=5, scale=128 ** -0.5)
-    q16, q32, ste = hip.outer_prep_bf16(en, ek)
-    assert torch.equal(q16, ek.to(BF)) and torch.equal(q32, ek.to(BF).float())
-    ye = (en.double().unsqueeze(2) + q32.double().unsqueeze(1)).reshape(-1, C)
-    s = _sums(ste)
-    assert torch.allclose(s[0], ye.sum(0), rtol=1e-9, atol=1e-6) and torch.allclose(s[1], (ye * ye).sum(0), rtol=1e-9, atol=1e-6)
-    y, sums = hip.lin_forward_2src_outer(en, q16, ca, 0.1, xb, cb, 0.0, w)
-    x32 = (en.unsqueeze(2) + q32.unsqueeze(1)).reshape(-1, C)                       # the fp32 sum the kernel forms
-    a = torch.cat([_bn_act(x32, ca, 0.1)[0], _bn_act(xb, cb, 0.0)[0]], 1)
-    want = _bfr(a).double() @ _bfr(w).double().t()
-    _close_bf16(y, _bfr(want.float()), "y")
-    yd = y.double()
-    assert torch.allclose(_sums(sums)[0], yd.sum(0), rtol=1e-6, atol=1e-3) and torch.allclose(_sums(sums)[1], (yd * yd).sum(0), rtol=1e-6, atol=1e-3)
-    y_st, _ = hip.lin_forward_2src(x32.to(BF), ca, 0.1, xb, cb, 0.0, w)
-    d = (y.float() - y_st.float()).abs()
-    assert float(d.max()) <= 0.06 * float(y.float().abs().max()) and float(d.mean()) <= 4e-3 * float(y.float().abs().mean())
-
-
 @pytest.mark.parametrize("C,Co", [(128, 128), (64, 32)])
 def test_pair_lin_fwd_bf16(C, Co):
     hip = _hip()
@@ -343,50 +313,6 @@ def test_lin_bwd_2src_bf16_one_pass(rows, monkeypatch):
     assert float((dw.double() - want_dw).abs().max()) <= 2e-3 * float(want_dw.abs().max())
     assert torch.allclose(_sums(dsa)[0], gza.double().sum(0), rtol=1e-5, atol=1e-1)
     assert torch.allclose(_sums(dsb)[0], gzb.double().sum(0), rtol=1e-5, atol=1e-1)
-
-
-@pytest.mark.parametrize("B,N,M", [(2, 228, 468), (4, 512, 33), (16, 228, 468), (5, 171, 80)])
-def test_position_encoding_on_load_backward(B, N, M):
-    """bwd_fused2_bf16_kernel<OUTER> (i2p_lin_bwd_2src_outer_bf16): the one-pass backward of the 64 + 64 -> 128 layer with its first source
-    read as enc_n[b,n] + bf16(enc_k[b,k]).  Against fp64 on the operands the kernel forms (fp32 sum -> BN -> activation -> bf16 operand; act'
-    and xhat from the same fp32 sum), as test_lin_bwd_2src_bf16_one_pass does for the stored form; source b's gradient bit for bit against
-    the stored-tensor kernel (it does not depend on how source a is read).  M = 33 / 80: strips straddling two points, points and samples."""
-    hip = _hip()
-    ca = cb = 64; cout = 128
-    rows = B * N * M
-    assert rows % 16 == 0 and hip.outer_on_load_ok(B, N, M, ca, cb, cout)
-    en, ek = _rnd(B, N, ca, seed=31), _rnd(B, M, ca, seed=32)
-    q16, q32, _ = hip.outer_prep_bf16(en, ek)
-    xb = _rnd(rows, cb, seed=2).to(BF)
-    yv, gz = _rnd(rows, cout, seed=3).to(BF), _rnd(rows, cout, seed=4, scale=0.1).to(BF)
-    eadd = _rnd(rows, cb, seed=5, scale=0.1).to(BF)
-    w = _rnd(cout, ca + cb, seed=6, scale=128 ** -0.5)
-    oc, omi = _coef(cout, 7); cfa, mia = _coef(ca, 8); cfb, mib = _coef(cb, 9)
-    out_ds = hip.bn_act_backward_stats_bf16(gz, yv, oc, omi, 1.0)
-    gza, dsa, gzb, dsb, dw = hip.lin_backward_2src_outer(gz, yv, oc, omi, out_ds, en, q16, cfa, mia, 0.1, xb, cfb, mib, 0.2, eadd, w)
-    x32 = (en.unsqueeze(2) + q32.unsqueeze(1)).reshape(rows, ca)                    # the fp32 sum the kernel forms
-    gza0, dsa0, gzb0, dsb0, dw0 = hip.lin_backward_2src(gz, yv, oc, omi, out_ds, x32.to(BF), cfa, mia, 0.1, xb, cfb, mib, 0.2, eadd, w)
-    torch.cuda.synchronize()
-    assert torch.equal(gzb.view(torch.int16), gzb0.view(torch.int16))
-    assert torch.allclose(_sums(dsb), _sums(dsb0), rtol=1e-4, atol=5e-2)
-    G = _bfr(_g_of(gz, yv, oc, omi, out_ds, rows, 1.0))
-    wb = _bfr(w).double()
-    want_dw = torch.zeros(cout, ca + cb, dtype=torch.float64, device=DEV)
-    s2 = torch.zeros(ca, dtype=torch.float64, device=DEV)
-    step = 1 << 18
-    for r0 in range(0, rows, step):
-        sl = slice(r0, r0 + step)
-        X = _bfr(torch.cat([_bn_act(x32[sl], cfa, 0.1)[0], _bn_act(xb[sl], cfb, 0.2)[0]], 1))
-        want_dw += G[sl].double().t() @ X.double()
-        T = (G[sl].double() @ wb).float()
-        za = _bn_act(x32[sl], cfa, 1.0)[1]
-        Ta = _bfr(T[:, :ca])
-        _close_bf16(gza[sl], _bfr(torch.where(za > 0, Ta, Ta * 0.1)), "gz_a", rel=2 * ULP)
-        xhat = (x32[sl].double() - mia[:ca].double()) * mia[ca:].double()
-        s2 += (gza[sl].double() * xhat).sum(0)
-    assert float((dw.double() - want_dw).abs().max()) <= 2e-3 * float(want_dw.abs().max())
-    assert torch.allclose(_sums(dsa)[0], gza.double().sum(0), rtol=1e-5, atol=1e-1)
-    assert torch.allclose(_sums(dsa)[1], s2, rtol=1e-4, atol=1e-1 + 1e-4 * float(s2.abs().max()))
 
 
 @pytest.mark.parametrize("B,N,M,C,Co", [(2, 13, 150, 128, 128), (1, 40, 64, 64, 32), (2, 9, 468, 128, 128)])
