@@ -480,7 +480,7 @@ def test_zero_arena_prefix_reset():
     assert a2.data_ptr() == a.data_ptr() and float(a2.abs().sum()) == 0 and int(b2.sum()) == 0 and float(c2.sum()) == 0
     c2.fill_(1)
     ops.begin_step(d)
-    big = ops.zeros((2 << 20,), torch.float32, d)                   # 8 MB: not from the arena
+    big = ops.zeros((5 << 20,), torch.float32, d)                   # 20 MB: above the arena's request limit (16 MB), plain torch.zeros
     a3 = ops.zeros((1000,), torch.float32, d); ops.zeros((300 << 10,), torch.uint8, d)
     c3 = ops.zeros((100 << 10,), torch.float32, d)
     assert float(big.sum()) == 0 and a3.data_ptr() == a.data_ptr() and c3.data_ptr() == c2.data_ptr() and float(c3.sum()) == 0
