@@ -54,6 +54,7 @@ SIGNATURES = {
 # entries that exist only in the device library (bf16 storage mode, deterministic scatter, fused grouping): the CPU
 # oracle restates the reference's algorithms, not our storage formats — these are checked against fp32 results
 DEVICE_ONLY = {
+    "i2p_intrinsic_inverse": ["i", "p", "f", "f", "p"],
     "i2p_kitti_points_build": ["i", "i", "p", "p", "p", "p", "p"],
     "i2p_kitti_image_build": ["i", "i", "i", "p", "p"],
     "i2p_lin_fwd_bf16": ["l", "i", "i", "p", "i", "p", "f", "p", "p", "p"],

@@ -128,7 +128,8 @@ int i2p_small_wgrad(long long rows, int cin, int cout, const float *gz, const fl
 bool i2p_big_layer_ok(long long rows, int cin, int cout);
 int i2p_big_fwd(long long rows, int cin, int cout, const float *x, const float *in_coef, float slope_in, const float *w, float *y,
                 double *sums, void *stream);
-int i2p_big_bwd(long long rows, int cin, int cout, const float *gz, const float *y, const float *g_coef, float slope_out, const float *x,
+int i2p_big_bwd(long long rows, int cin, int cout, const float *gz, const float *y, float *g_out, const double *out_dsums, const float *out_coef,
+                const float *out_mi, float slope_out, const float *x,
                 const float *in_coef, const float *in_mi, float slope_in, const float *w, float *gz_in, double *in_dsums,
                 float *dw_partial, int max_chunks, float *dw, void *stream);
 bool i2p_small_wgrad_bf16_ok(long long rows, int cin, int cout, int x_bf16);

@@ -396,6 +396,33 @@ extern "C" int i2p_max_response_bwd(int B, int N, int M, int C, const float *g, 
     I2P_RETURN_LAUNCH_STATUS();
 }
 
+// K_inv[b] = inverse of the intrinsic matrix rescaled to a feature map (fx, cx by sx; fy, cy by sy): change_intrinsic + the adjugate
+// inverse of model.py (modellearn_proj_center.py:457-463, :282 — torch.inverse on the CPU there) in one launch instead of eight
+// (scale multiply, three cross products, multiply, sum, stack, divide).  Same arithmetic, operation for operation (no contraction).
+__global__ void intrinsic_inverse_kernel(int B, const float *__restrict__ K, float sx, float sy, float *__restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *k = K + 9 * b;
+    const float r0[3] = {k[0] * sx, k[1] * 1.0f, k[2] * sx}, r1[3] = {k[3] * 1.0f, k[4] * sy, k[5] * sy}, r2[3] = {k[6], k[7], k[8]};
+    auto cross = [](const float *a, const float *c, float *o) {
+        o[0] = a[1] * c[2] - a[2] * c[1]; o[1] = a[2] * c[0] - a[0] * c[2]; o[2] = a[0] * c[1] - a[1] * c[0];
+    };
+    float c0[3], c1[3], c2[3];
+    cross(r1, r2, c0); cross(r2, r0, c1); cross(r0, r1, c2);
+    const float det = (r0[0] * c0[0] + r0[1] * c0[1]) + r0[2] * c0[2];
+    float *o = out + 9 * b;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o[3 * i] = c0[i] / det; o[3 * i + 1] = c1[i] / det; o[3 * i + 2] = c2[i] / det; }
+}
+
+extern "C" int i2p_intrinsic_inverse(int B, const float *K, float sx, float sy, float *out, void *stream) {
+    if (B < 0) return I2P_ERR_BAD_ARG;
+    if (B == 0) return 0;
+    if (!K || !out) return I2P_ERR_BAD_ARG;
+    hipLaunchKernelGGL(intrinsic_inverse_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, K, sx, sy, out);
+    I2P_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int i2p_row_valid(long long rows, int c, const float *x, float *out, void *stream) {
     if (rows < 0 || c <= 0) return I2P_ERR_BAD_ARG;
     if (rows == 0) return 0;

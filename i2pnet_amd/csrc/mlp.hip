@@ -2053,7 +2053,8 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
         float *g_coef = nullptr;
         if (out_coef && !pair) {
             g_coef = (part & 2) ? dw_partial + (size_t)grid * cout * cin : coef_scratch;   // [8][cout] scratch tail; rows 6, 7 = dbeta, dgamma for the caller
-            if (!gen2)                                              // (the second-generation kernels form the constants in their prologues)
+            const bool big = !two && i2p_big_layer_ok(rows, cin, cout);
+            if (!gen2 && !big)                                      // (the second-generation and the K-tiled kernels form the constants in their prologues)
                 hipLaunchKernelGGL(bnbwd_coef_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, rows, cout, out_dsums, out_coef,
                                    out_mi, g_coef);
         }
@@ -2132,7 +2133,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
     }
     if (!pair && !two && i2p_big_layer_ok(rows, cin, cout))        // wide layer on few rows: K-tiled dgrad + row-split wgrad (csrc/mlp_big.hip)
         return i2p_big_bwd(rows, cin, cout, gz, y, out_coef ? ((part & 2) ? dw_partial + (size_t)grid * cout * cin : coef_scratch) : nullptr,
-                           p.slope_out, x, in_coef, in_mi, slope_in, w, gz_in, in_dsums, (part & 2) ? dw_partial : nullptr, (int)grid,
+                           out_dsums, out_coef, out_mi, p.slope_out, x, in_coef, in_mi, slope_in, w, gz_in, in_dsums, (part & 2) ? dw_partial : nullptr, (int)grid,
                            (part & 2) ? dw : nullptr, stream);
     if (part != 3) return I2P_ERR_BAD_ARG;
     switch (p.cin_p / 32) {

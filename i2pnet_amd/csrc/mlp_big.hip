@@ -32,6 +32,9 @@ struct BigP {
     const float *in_coef;         // fwd: [3][K] mean, scale, beta of the BN in front, or nullptr
     float slope_in;
     const float *g_coef;          // dgrad: [8][K] m1, m2, scale, mean, invstd, beta (bnbwd_coef_kernel) or nullptr
+    // or (round 5: no coefficient launch) the raw material: dsums [REP][2K] = {sum gz, sum gz*xhat}, coef [3][K], mean_invstd [2][K] of the BN
+    // behind, its row count, and g_out [8][K] whose rows 6, 7 block (0,0) fills with dbeta, dgamma for the caller
+    const double *g_dsums; const float *g_oc, *g_omi; long long g_rows; float *g_out;
     float g_slope;
     const float *w;               // [cout][cin]: fwd [C][K], dgrad [K][C]
     float *out;                   // [rows, C]
@@ -41,18 +44,30 @@ struct BigP {
 
 __device__ __forceinline__ f32x4 ld4g(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
+// the six constants bnbwd_coef_kernel (mlp.hip) wrote per channel, formed here from the same sums in the same order (bit-identical)
+__device__ __forceinline__ void bnbwd_consts_of(const double *dsums, const float *oc, const float *omi, long long rows, int c, int ch,
+                                                float &m1, float &m2, float &sc, float &mu, float &is, float &be, float *out8) {
+    double sd = 0.0, sx = 0.0;
+    for (int r = 0; r < I2P_BN_REPLICAS; ++r) { sd += dsums[(size_t)r * 2 * c + ch]; sx += dsums[(size_t)r * 2 * c + c + ch]; }
+    m1 = (float)(sd / (double)rows); m2 = (float)(sx / (double)rows);
+    sc = oc[c + ch]; mu = omi[ch]; is = omi[c + ch]; be = oc[2 * c + ch];
+    if (out8) { out8[6 * c + ch] = (float)sd; out8[7 * c + ch] = (float)sx; }          // dbeta, dgamma of this BN (read back by the caller)
+}
+
 template <bool DGRAD>
 __global__ __launch_bounds__(BG_THREADS) void big_nt_kernel(BigP p) {
     __shared__ __attribute__((aligned(16))) float tab[5][BG_MAXC];                            // per contraction index: fwd {a, b}; dgrad {gA, gB, gC, za, zb}
     __shared__ double red[2][4][BG_COLS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
-    const bool xf = DGRAD ? p.g_coef != nullptr : p.in_coef != nullptr;
+    const bool xf = DGRAD ? (p.g_coef != nullptr || p.g_dsums != nullptr) : p.in_coef != nullptr;
     const bool g_act = DGRAD && xf && p.g_slope != 1.f;
     if (xf) {
         for (int k = tid; k < p.K; k += BG_THREADS) {
             if constexpr (DGRAD) {
-                const float m1 = p.g_coef[k], m2 = p.g_coef[p.K + k], sc = p.g_coef[2 * p.K + k], mu = p.g_coef[3 * p.K + k],
-                            is = p.g_coef[4 * p.K + k], be = p.g_coef[5 * p.K + k];
+                float m1, m2, sc, mu, is, be;
+                if (p.g_dsums) bnbwd_consts_of(p.g_dsums, p.g_oc, p.g_omi, p.g_rows, p.K, k, m1, m2, sc, mu, is, be,
+                                               (blockIdx.x == 0 && blockIdx.y == 0) ? p.g_out : nullptr);
+                else { m1 = p.g_coef[k]; m2 = p.g_coef[p.K + k]; sc = p.g_coef[2 * p.K + k]; mu = p.g_coef[3 * p.K + k]; is = p.g_coef[4 * p.K + k]; be = p.g_coef[5 * p.K + k]; }
                 const float gB = -(sc * m2) * is;
                 tab[0][k] = sc; tab[1][k] = gB; tab[2][k] = -(sc * m1) - gB * mu; tab[3][k] = sc; tab[4][k] = be - mu * sc;
             } else {
@@ -182,6 +197,7 @@ struct BigTnP {
     int m, n;                     // cout, cin
     const float *gz, *y;          // [rows, m]
     const float *g_coef; float g_slope;
+    const double *g_dsums; const float *g_oc, *g_omi; long long g_rows; float *g_out;      // see BigP
     const float *x;               // [rows, n]
     const float *in_coef; float slope_in;
     int tiles_n, chunk_rows;
@@ -197,14 +213,17 @@ __global__ __launch_bounds__(BG_THREADS) void big_tn_kernel(BigTnP p) {
     long long r_end = r_begin + p.chunk_rows; if (r_end > p.rows) r_end = p.rows;
     const int ca = m0 + 4 * i, cb = n0 + 4 * i;
     const bool a_ok = ca < p.m, b_ok = cb < p.n;                 // m, n % 4 == 0
-    const bool has_g = p.g_coef != nullptr, g_act = has_g && p.g_slope != 1.f, has_x = p.in_coef != nullptr;
+    const bool has_g = p.g_coef != nullptr || p.g_dsums != nullptr, g_act = has_g && p.g_slope != 1.f, has_x = p.in_coef != nullptr;
     f32x4 gA = {1.f, 1.f, 1.f, 1.f}, gB = {0.f, 0.f, 0.f, 0.f}, gC = gB, za = gA, zb = gB, xa = gA, xb = gB;
     if (has_g && a_ok) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int ch = ca + e;
-            const float m1 = p.g_coef[ch], m2 = p.g_coef[p.m + ch], sc = p.g_coef[2 * p.m + ch], mu = p.g_coef[3 * p.m + ch],
-                        is = p.g_coef[4 * p.m + ch], be = p.g_coef[5 * p.m + ch];
+            float m1, m2, sc, mu, is, be;
+            // (rows 6, 7 for the caller: the n-tile 0 blocks of chunk 0 cover every channel once; written only when no dgrad launch did it)
+            if (p.g_dsums) bnbwd_consts_of(p.g_dsums, p.g_oc, p.g_omi, p.g_rows, p.m, ch, m1, m2, sc, mu, is, be,
+                                           (p.g_out && blockIdx.y == 0 && n0 == 0 && (lane >> 4) == 0 && (threadIdx.x >> 6) == 0) ? p.g_out : nullptr);
+            else { m1 = p.g_coef[ch]; m2 = p.g_coef[p.m + ch]; sc = p.g_coef[2 * p.m + ch]; mu = p.g_coef[3 * p.m + ch]; is = p.g_coef[4 * p.m + ch]; be = p.g_coef[5 * p.m + ch]; }
             gA[e] = sc; gB[e] = -(sc * m2) * is; gC[e] = -(sc * m1) - gB[e] * mu; za[e] = sc; zb[e] = be - mu * sc;
         }
     }
@@ -317,24 +336,30 @@ int i2p_big_fwd(long long rows, int cin, int cout, const float *x, const float *
     I2P_RETURN_LAUNCH_STATUS();
 }
 
-// g_coef: [8][cout] constants of the BN behind (bnbwd_coef_kernel) or nullptr; dw_partial holds max_chunks * cout * cin floats
-int i2p_big_bwd(long long rows, int cin, int cout, const float *gz, const float *y, const float *g_coef, float slope_out, const float *x,
+// g_out: [8][cout] scratch of the BN behind (rows 6, 7 receive dbeta, dgamma; the kernels form the constants themselves from out_dsums /
+// out_coef / out_mi in their prologues) or nullptr = no BN behind; dw_partial holds max_chunks * cout * cin floats
+int i2p_big_bwd(long long rows, int cin, int cout, const float *gz, const float *y, float *g_out, const double *out_dsums, const float *out_coef,
+                const float *out_mi, float slope_out, const float *x,
                 const float *in_coef, const float *in_mi, float slope_in, const float *w, float *gz_in, double *in_dsums,
                 float *dw_partial, int max_chunks, float *dw, void *stream) {
     // dw == nullptr: input gradient only (the weight gradient is issued by another call, possibly on another stream)
-    if (!i2p_big_layer_ok(rows, cin, cout) || !gz || !x || !w || (dw && !dw_partial) || (!dw && !gz_in) || max_chunks < 1 || (g_coef && !y)) return I2P_ERR_BAD_ARG;
+    const bool g_coef = g_out != nullptr;
+    if (!i2p_big_layer_ok(rows, cin, cout) || !gz || !x || !w || (dw && !dw_partial) || (!dw && !gz_in) || max_chunks < 1 ||
+        (g_coef && (!y || !out_dsums || !out_coef || !out_mi))) return I2P_ERR_BAD_ARG;
     if ((reinterpret_cast<uintptr_t>(dw_partial) | reinterpret_cast<uintptr_t>(dw)) & 15) return I2P_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (gz_in) {
         BigP p{};
-        p.rows = rows; p.K = cout; p.C = cin; p.a = gz; p.a2 = y; p.g_coef = g_coef; p.g_slope = g_coef ? slope_out : 1.f; p.w = w; p.out = gz_in;
+        p.rows = rows; p.K = cout; p.C = cin; p.a = gz; p.a2 = y; p.g_coef = nullptr; p.g_slope = g_coef ? slope_out : 1.f; p.w = w; p.out = gz_in;
+        p.g_dsums = g_coef ? out_dsums : nullptr; p.g_oc = out_coef; p.g_omi = out_mi; p.g_rows = rows; p.g_out = g_out;
         p.sums = in_coef ? in_dsums : nullptr; p.ex = in_coef ? x : nullptr; p.e_coef = in_coef; p.e_mi = in_mi; p.e_slope = slope_in;
         const dim3 grid((unsigned)((rows + BG_ROWS - 1) / BG_ROWS), (unsigned)((cin + BG_COLS - 1) / BG_COLS));
         hipLaunchKernelGGL(big_nt_kernel<true>, grid, dim3(BG_THREADS), 0, st, p);
     }
     if (!dw) I2P_RETURN_LAUNCH_STATUS();
     BigTnP q{};
-    q.rows = rows; q.m = cout; q.n = cin; q.gz = gz; q.y = y; q.g_coef = g_coef; q.g_slope = g_coef ? slope_out : 1.f; q.x = x; q.in_coef = in_coef;
+    q.rows = rows; q.m = cout; q.n = cin; q.gz = gz; q.y = y; q.g_coef = nullptr; q.g_slope = g_coef ? slope_out : 1.f; q.x = x; q.in_coef = in_coef;
+    q.g_dsums = g_coef ? out_dsums : nullptr; q.g_oc = out_coef; q.g_omi = out_mi; q.g_rows = rows; q.g_out = gz_in ? nullptr : g_out;
     q.slope_in = slope_in; q.partial = dw_partial;
     const int tiles_m = (cout + 63) / 64; q.tiles_n = (cin + 63) / 64;
     long long want = 512 / ((long long)tiles_m * q.tiles_n); if (want < 1) want = 1; if (want > max_chunks) want = max_chunks;

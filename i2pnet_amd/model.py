@@ -58,6 +58,16 @@ def change_intrinsic(intrinsic, RF, rgb_img):
     return intrinsic * scale
 
 
+def scaled_intrinsic_inverse(intrinsic, RF, rgb_img):
+    """inverse_3x3(change_intrinsic(...)): on the HIP backend one launch (i2p_intrinsic_inverse, the same arithmetic) instead of eight;
+    the intrinsics are inputs (no gradient)"""
+    from . import ops
+    be = ops.get_backend()
+    if (be.name == "hip" and intrinsic.is_cuda and intrinsic.dtype == torch.float32 and not intrinsic.requires_grad and intrinsic.dim() == 3):
+        return be.intrinsic_inverse(intrinsic.contiguous(), RF.shape[3] / rgb_img.shape[3], RF.shape[2] / rgb_img.shape[2])
+    return inverse_3x3(change_intrinsic(intrinsic, RF, rgb_img))
+
+
 def inverse_3x3(m):
     """adjugate inverse of [B,3,3] on the device (replaces torch.inverse on the CPU, :282):
     rows of the adjugate-transpose are cross products of the rows of m, det = r0 . (r1 x r2)."""
@@ -155,7 +165,7 @@ class RegNet_v2(nn.Module):
         RF3 = self.RGB_net3(self.RGB_net2(self.RGB_net1(rgb_img)))             # [B,128,h3,w3]
         pix_index = set_id_grid(RF3.permute(0, 2, 3, 1))                        # [B,M,3]
         # pixel rays in the normalised camera plane of the level-3 feature map
-        K3_inv = inverse_3x3(change_intrinsic(intrinsic, RF3, rgb_img))
+        K3_inv = scaled_intrinsic_inverse(intrinsic, RF3, rgb_img)
         pix_rays = torch.bmm(K3_inv, pix_index.permute(0, 2, 1)).permute(0, 2, 1)   # [B,M,3]
         RF3_pts = RF3.reshape(RF3.shape[0], RF3.shape[1], -1).permute(0, 2, 1)  # [B,M,C]
         return RF3, pix_rays, RF3_pts, _unit_variance(RF3_pts)

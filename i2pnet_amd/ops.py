@@ -1106,6 +1106,12 @@ class CBackend:
         return rgb
 
     # ---- small glue kernels (csrc/glue.hip; device library only) -------------------------------------------------
+    def intrinsic_inverse(self, K, sx, sy):
+        """K [B,3,3] -> inverse of K with fx, cx scaled by sx and fy, cy by sy (change_intrinsic + inverse_3x3 of model.py in one launch)"""
+        out = torch.empty_like(K)
+        self._call("i2p_intrinsic_inverse", int(K.shape[0]), self._p(K, _F32, "K"), float(sx), float(sy), self._p(out, _F32, "out"), stream=self._stream())
+        return out
+
     def row_valid(self, x):
         """x [..., c] -> 0/1 float [..., 1]: any(x != 0) over the last axis (check_valid)"""
         c = x.shape[-1]

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import projectpn as P
 from . import warp as warp_utils
-from .model import change_intrinsic, inverse_3x3, set_id_grid
+from .model import scaled_intrinsic_inverse, set_id_grid
 from .modules import (Conv2d, CostVolume, FlowPredictor, PoseHead, _MaxResponse, _unit_variance, createCNNs,
                       run_stack)
 from .pointnet_util import PointNetSetAbstraction, index_points, knn_point
@@ -208,7 +208,7 @@ class RegNet_v2(nn.Module):
         P3, LF3, _, _, P3_raw = self.LiDAR_lv3(P2, LF2, raw_feat_point=rfp, raw_xyz=P2_raw)
         P4, LF4, _, fps_idx_4, P4_raw = self.LiDAR_lv4(P3, LF3, raw_feat_point=rfp, raw_xyz=P3_raw)
 
-        K3_inv = inverse_3x3(change_intrinsic(intrinsic, RF3, rgb_img))
+        K3_inv = scaled_intrinsic_inverse(intrinsic, RF3, rgb_img)
         pix_rays = torch.bmm(K3_inv, pix_index.permute(0, 2, 1)).permute(0, 2, 1)
         P3_pts = P3.permute(0, 2, 1)                                            # [B,n3,3]
         LF3_pts = LF3.permute(0, 2, 1)

@@ -657,6 +657,9 @@ int i2p_warp_split_bwd(int B, int N, const float *p, const float *q, const float
 int i2p_unpool_k_stats(long long groups, int K, int c, const float *g, const unsigned char *arg, const float *y, const float *mean_invstd,
                        const float *gamma, const float *beta, float slope, float *gd, double *dsums, void *stream);
 int i2p_row_valid(long long rows, int c, const float *x, float *out, void *stream);
+/* out [B,3,3] = inverse of the intrinsic matrices K [B,3,3] rescaled to a feature map (row 0 entries fx, cx times sx; row 1 entries fy, cy
+ * times sy): change_intrinsic (modellearn_proj_center.py:457-463) + torch.inverse (:282) in one launch. */
+int i2p_intrinsic_inverse(int B, const float *K, float sx, float sy, float *out, void *stream);
 int i2p_mask_fill(long long rows, int c, const float *x, const float *valid, float fill, float *out, void *stream);
 int i2p_pad_cols(int rows, int c, int cpad, const float *w, float *out, void *stream);
 int i2p_strided_pick2(int B, int H, int W, int oh, int ow, int sh, int sw, const float *a, const float *b, float *oa, float *ob,

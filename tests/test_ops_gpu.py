@@ -1370,3 +1370,22 @@ def test_unpool_k_stats_matches_two_pass(hip_backend, oracle_backend, groups, K,
     assert torch.equal(gd.cpu(), want_gd)
     a, b = ds.cpu().view(32, 2, c).sum(0), want_ds.view(32, 2, c).sum(0)
     assert torch.allclose(a, b, rtol=1e-9, atol=1e-7 * groups ** 0.5)
+
+@pytest.mark.gpu
+def test_intrinsic_inverse_matches_the_torch_form(hip_backend):
+    """i2p_intrinsic_inverse = change_intrinsic + inverse_3x3 of model.py (modellearn_proj_center.py:457-463, :282) in one launch: the same
+    arithmetic, so bit-identical to the torch expression; and an inverse (K_scaled @ K_inv = I to fp32 rounding, fp64 torch.inverse 1e-6)."""
+    from i2pnet_amd import model
+    g = torch.Generator().manual_seed(3)
+    B = 16
+    K = torch.zeros(B, 3, 3)
+    K[:, 0, 0] = 700 + 50 * torch.rand(B, generator=g); K[:, 1, 1] = 700 + 50 * torch.rand(B, generator=g)
+    K[:, 0, 2] = 600 + 20 * torch.rand(B, generator=g); K[:, 1, 2] = 180 + 10 * torch.rand(B, generator=g); K[:, 2, 2] = 1.0
+    K[:, 0, 1] = 0.01 * torch.randn(B, generator=g)                      # a little skew: the general adjugate, not only the triangular case
+    Kd = K.to(DEV)
+    RF, img = torch.empty(1, 1, 24, 78), torch.empty(1, 1, 375, 1242)
+    want = model.inverse_3x3(model.change_intrinsic(Kd, RF, img))
+    got = hip_backend.intrinsic_inverse(Kd, 78 / 1242, 24 / 375)
+    assert torch.equal(got, want)
+    ref = torch.linalg.inv((K.double() * torch.tensor([[78 / 1242, 1.0, 78 / 1242], [1.0, 24 / 375, 24 / 375], [1.0, 1.0, 1.0]], dtype=torch.float64)))
+    assert float((got.cpu().double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--top", type=int, default=60)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    import bench
+    bench.process_setup()                 # the bench's MIOpen mode (exhaustive find in the warm-up steps): the launch count of the MEASURED configuration
     tr = Trainer(cfg=cfg, device=dev)
     batch = synth.make_batch(a.batch, 8192, 375, 1242, seed=1, device=dev)
     from torch.profiler import record_function
