@@ -913,6 +913,7 @@ struct LinBwdParams {
     const float *gz, *y, *out_coef, *out_mi;
     float slope_out;            // gz is dL/da of this layer's activation (slope_out): act'(z) applied on load; 1 = gz is dL/dz
     const double *out_dsums;
+    float *bn_out;              // [8][cout] or nullptr: rows 6, 7 receive dbeta = sum gz, dgamma = sum gz*xhat of the BN behind (block 0)
     const float *x, *in_coef, *in_mi;
     float slope_in;
     const float *w;
@@ -956,6 +957,7 @@ __global__ __launch_bounds__(THREADS) void lin_bwd_kernel(LinBwdParams p) {
             for (int rp = 0; rp < REP; ++rp) { sd += p.out_dsums[(size_t)rp * 2 * p.cout + ch]; sx += p.out_dsums[(size_t)rp * 2 * p.cout + p.cout + ch]; }
             m1 = (float)(sd / (double)p.rows); m2 = (float)(sx / (double)p.rows);
             sc = p.out_coef[p.cout + ch]; mu = p.out_mi[ch]; is = p.out_mi[p.cout + ch]; be = p.out_coef[2 * p.cout + ch];
+            if (p.bn_out && blockIdx.x == 0) { p.bn_out[6 * p.cout + ch] = (float)sd; p.bn_out[7 * p.cout + ch] = (float)sx; }   // (what bnbwd_coef_kernel returned)
         }
         Co[ch] = m1; Co[p.cout_p + ch] = m2; Co[2 * p.cout_p + ch] = sc; Co[3 * p.cout_p + ch] = mu; Co[4 * p.cout_p + ch] = is;
         Co[5 * p.cout_p + ch] = be;
@@ -1515,17 +1517,8 @@ struct WgradParams {
 constexpr int WG_THREADS = 512;
 constexpr int WG_R = 64;
 
-__global__ void bnbwd_coef_kernel(long long rows, int c, const double *__restrict__ dsums,
-                                  const float *__restrict__ coef, const float *__restrict__ mi, float *__restrict__ out) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    double sd = 0.0, sx = 0.0;
-    for (int r = 0; r < REP; ++r) { sd += dsums[(size_t)r * 2 * c + ch]; sx += dsums[(size_t)r * 2 * c + c + ch]; }
-    out[ch] = (float)(sd / (double)rows); out[c + ch] = (float)(sx / (double)rows);
-    out[2 * c + ch] = coef[c + ch]; out[3 * c + ch] = mi[ch]; out[4 * c + ch] = mi[c + ch];
-    out[5 * c + ch] = coef[2 * c + ch];
-    out[6 * c + ch] = (float)sd; out[7 * c + ch] = (float)sx;      // = dbeta, dgamma of this BN (returned to the caller)
-}
+// (bnbwd_coef_kernel — a 64-thread launch that turned the replica sums {sum gz, sum gz*xhat} of a BN into its backward constants
+// [8][c] — is gone since round 5: every consumer forms them in its prologue and its block 0 writes rows 6, 7 = dbeta, dgamma)
 
 template <int NTI, int NTO, bool FIXC>
 __global__ __launch_bounds__(WG_THREADS, 2) void lin_wgrad_kernel(WgradParams p) {
@@ -2030,7 +2023,7 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
     p.rows = rows; p.cin = cin; p.cout = cout;
     p.cin_p = (cin + 31) & ~31; p.cout_p = (cout + 31) & ~31;
     p.ldw = p.cin_p + 1; p.ldg = p.cout_p + 1; p.ldx = p.cin_p + 1;
-    p.gz = gz; p.y = y; p.out_coef = out_coef; p.out_mi = out_mi; p.out_dsums = out_dsums;
+    p.gz = gz; p.y = y; p.out_coef = out_coef; p.out_mi = out_mi; p.out_dsums = out_dsums; p.bn_out = nullptr;
     p.slope_out = out_coef ? slope_out : 1.f;
     p.x = x; p.in_coef = in_coef; p.in_mi = in_mi; p.slope_in = slope_in; p.w = w;
     p.gz_in = gz_in; p.in_dsums = in_dsums; p.dw_partial = dw_partial;
@@ -2053,10 +2046,9 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
         float *g_coef = nullptr;
         if (out_coef && !pair) {
             g_coef = (part & 2) ? dw_partial + (size_t)grid * cout * cin : coef_scratch;   // [8][cout] scratch tail; rows 6, 7 = dbeta, dgamma for the caller
-            const bool big = !two && i2p_big_layer_ok(rows, cin, cout);
-            if (!gen2 && !big)                                      // (the second-generation and the K-tiled kernels form the constants in their prologues)
-                hipLaunchKernelGGL(bnbwd_coef_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, rows, cout, out_dsums, out_coef,
-                                   out_mi, g_coef);
+            // (every kernel family forms the BN-backward constants in its prologue and its block 0 returns dbeta / dgamma in rows 6, 7:
+            //  no coefficient launch — the first-generation kernel through p.bn_out)
+            p.bn_out = g_coef;
         }
         if (gen2) {
             const bool two_d3 = !two || (two->split_c * 2 == cin && two->in_coef_b && two->in_mi_b && two->e_add && two->gz_in_b &&
