@@ -792,6 +792,9 @@ def main():
                     help="tree: every rank reads a synthetic KITTI odometry tree (written to a temp dir) through the real input pipeline "
                          "(i2pnet_amd.data: file reads, pinned staging, device-side sample build on a copy stream, Prefetcher) — a "
                          "loader-inclusive number on the reference loader's own shapes (160x512 crop, 150 000-row clouds); its own metric name, never `value` of the BASELINE metric")
+    ap.add_argument("--loader-line", type=int, default=1, help="after the default line also time the step fed by the input pipeline "
+                    "(--data tree workload) and report it as `loader_inclusive` (0 = skip)")
+    ap.add_argument("--loader-steps", type=int, default=60)
     ap.add_argument("--no-dp-proxy", action="store_true", help="skip the two-graph + 1-rank all-reduce proxy measurement")
     ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to host-core groups")
     ap.add_argument("--no-finddb-warmup", action="store_true", help="every rank runs MIOpen's find itself")
@@ -861,11 +864,30 @@ def main():
                 l2["roofline"] = kernel_rooflines_bf16(a2.batch, device, N=171 if c == 4 else 228)
                 ops.set_precision(prev)
                 others.append(l2)
+    # the same step fed by the real input pipeline (every rank its own synthetic KITTI tree through data.Prefetcher: the reference
+    # loader's shapes, file reads + staging + device-side build inside the timed region) — its own metric, never `value`; at every N,
+    # so that a multi-GPU record carries a loader-inclusive aggregate too.  A failure here is reported, not raised.
+    loader_line = None
+    if args.config == 1 and args.data == "synthetic" and args.loader_line:
+        a3 = argparse.Namespace(**vars(args))
+        a3.data, a3.steps, a3.warmup = "tree", min(args.loader_steps, 200), 10
+        try:
+            r3 = _run_workload(1, a3, rank, local_rank, world, device)
+            if rank == 0:
+                l3 = _json_line(r3, a3, world)
+                loader_line = {k: l3[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "data")}
+                loader_line["workload"] = l3["config"]["workload"]; loader_line["per_gpu_batch"] = l3["config"]["per_gpu_batch"]
+        except Exception as e:                                  # noqa: BLE001
+            loader_line = {"error": "%s: %s" % (type(e).__name__, e)}
+            if world > 1:
+                raise                                            # (ranks must not diverge: with N > 1 a one-sided failure would hang the others)
     if rank == 0 and world == 1 and not args.no_dp_proxy and not dist.is_initialized() and args.data == "synthetic":
         # what ONE GPU can say about N > 1: the data-parallel step structure — graph A, RCCL all-reduce of the flat
         # gradient, graph B — with a 1-rank group, against the single-graph step measured above
         line["dp_proxy"] = dp_proxy(args, device, line["ms_per_step"])
     if rank == 0:
+        if loader_line is not None:
+            line["loader_inclusive"] = loader_line
         if others:
             line["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline and args.data == "synthetic":

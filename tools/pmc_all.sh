@@ -5,7 +5,7 @@
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcall_$c
-  timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcall_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --other-configs 0 --graph 0 > /tmp/pmcall_$c.log 2>&1
+  timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcall_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --other-configs 0 --loader-line 0 --graph 0 > /tmp/pmcall_$c.log 2>&1
   f=$(find /tmp/pmcall_$c -name '*counter_collection.csv' | head -1)
   python - "$f" $c <<'PY' > gpurun_out/r03_pmc_all_$c.txt
 import csv, sys, collections, re

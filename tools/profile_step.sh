@@ -5,7 +5,7 @@ tag=${1:-step}
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$tag -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --other-configs 0 $BENCH_ARGS > /tmp/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$tag -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --other-configs 0 --loader-line 0 $BENCH_ARGS > /tmp/prof_$tag.log 2>&1
 tail -1 /tmp/prof_$tag.log | cut -c1-200
 trace=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
 mkdir -p gpurun_out

@@ -2,7 +2,7 @@
 # every kernel of ONE graph-replayed training step longer than 35 us that is not a layer/conv kernel, with its grid:
 # the list to scan for small kernels that are slower than their bytes justify.  usage (GPU box): bash tools/slow_kernels.sh   |   PATTERN=FillFunctor bash tools/slow_kernels.sh
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-rm -rf /tmp/tr; rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/tr.log 2>&1
+rm -rf /tmp/tr; rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --loader-line 0 > /tmp/tr.log 2>&1
 f=$(find /tmp/tr -name '*kernel_trace.csv' | head -1)
 python - "$f" <<'PY'
 import csv, sys
