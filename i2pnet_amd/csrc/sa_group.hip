@@ -257,7 +257,10 @@ __global__ __launch_bounds__(SA_THREADS) void sa_l1_kernel(SaParams p) {
         const float dx = nx - crx, dy = ny - cry, dz = nz - crz;
         const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
         float4 *o = reinterpret_cast<float4 *>(p.feat + (obase + s) * 12);
-        o[0] = make_float4(dx, dy, dz, cx); o[1] = make_float4(cy, cz, nx, ny); o[2] = make_float4(nz, dn, 0.f, 0.f);
+#if defined(SA_ABL) && (SA_ABL & 1)
+        if (dn == 12345.678f)                                           // ablation build (-DSA_ABL=1): no feature stores — profiles/r05_sa_l1_ablation.txt
+#endif
+        { o[0] = make_float4(dx, dy, dz, cx); o[1] = make_float4(cy, cz, nx, ny); o[2] = make_float4(nz, dn, 0.f, 0.f); }
     }
 }
 
