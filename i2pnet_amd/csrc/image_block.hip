@@ -813,7 +813,7 @@ extern "C" int i2p_img_block_bwd(int B, int H, int W, int C, int stride, int y_b
     return img_block_bwd_impl(3, B, H, W, C, stride, y_bf16, out_bf16, gout, arg, y, mean_invstd, gamma, beta, slope, dsums, dy, dgamma, dbeta,
                               stream);
 }
-// the same with `dsums` already holding sum gz / sum gz xhat (written by the producer of gout: i2p_img_conv_bwd_data_stats): only the
+// the same with `dsums` already holding sum gz / sum gz xhat (written by an earlier i2p_img_block_bwd_stats call): only the
 // dy launch
 extern "C" int i2p_img_block_bwd_dx(int B, int H, int W, int C, int stride, int y_bf16, int out_bf16, const void *gout, const unsigned char *arg,
                                     const void *y, const float *mean_invstd, const float *gamma, const float *beta, float slope, double *dsums,

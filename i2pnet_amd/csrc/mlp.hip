@@ -2003,8 +2003,7 @@ static int lin_bwd_family(long long rows, int cin, int cout, bool need_gx, bool 
 
 // `part`: 3 = the whole backward; 1 = input gradient only (dgrad: gz_in, in_dsums; no dw / dw_partial — `coef_scratch` [8*cout]
 // floats takes the BN-backward constants of the wide-layer kernels); 2 = weight gradient only (dw, the BN gradients behind the
-// partials).  The two halves read the same operands and write disjoint outputs, so a caller may issue them on two streams
-// (families 1 and 2 only: i2p_lin_bwd_splittable).
+// partials).  The two halves read the same operands and write disjoint outputs.
 static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, const float *y,
                         const float *out_coef, const float *out_mi, const double *out_dsums,
                         const float *x, const float *in_coef, const float *in_mi, float slope_in,

@@ -315,17 +315,23 @@ class DeviceSampleBuilder:
     COLOR_JITTER_DEFAULT = False     # the reference's KITTI augment_img is the identity (see color_jitter_u8 above)
 
     def __init__(self, device, mode="train", sample_point=150000, img_H=160, img_W=512, img_scale=0.5, crop_top=50,
-                 rng=None, jitter=True, color_jitter=None, fused=True):
+                 rng=None, jitter=True, color_jitter=None, fused=True, perm_seed=None):
         """`jitter`: per-point N(0, 0.01^2) noise of the cloud in train mode; `color_jitter`: ColorJitter of the cropped image
         in train mode (None = the reference loader's effective behaviour: off for KITTI, on for nuScenes).  The random draws
         (perturbation, crop offsets, colour jitter) come from `rng` in this order per sample; the reference draws from the
         global `random` / numpy / torch generators in its own order, so equal seeds do not reproduce its samples — the
-        golden vectors pin the arithmetic by passing the reference's draws in (`Pr`, `perm`, `crop`, `jitter_params`)."""
+        golden vectors pin the arithmetic by passing the reference's draws in (`Pr`, `perm`, `crop`, `jitter_params`).
+        `perm_seed`: seed of the host-drawn point shuffles (`draw_perm`: numpy streams keyed by (perm_seed, sample number), NOT
+        `rng` and not torch's generator — `torch.manual_seed` alone does not fix them).  None: one draw from
+        `rng.getrandbits(62)` when the rng has it (this consumes one value of its stream before the first sample), else from
+        its `random()`."""
         self.device, self.mode = torch.device(device), mode
         self.sample_point, self.img_H, self.img_W, self.img_scale, self.crop_top = sample_point, img_H, img_W, img_scale, crop_top
         self.fused = fused                 # HIP device: the batch build in two launches (csrc/loader_build.hip); False = the torch path
         self.rng = rng or random
-        self.perm_seed = self.rng.getrandbits(62)
+        if perm_seed is None:
+            perm_seed = self.rng.getrandbits(62) if hasattr(self.rng, "getrandbits") else int(self.rng.random() * (1 << 62))
+        self.perm_seed = int(perm_seed)
         self.perm_gen = np.random.default_rng(self.perm_seed)
         self._small = [[None, None] for _ in range(12)]     # pinned blocks (+ the event of their last copy) of `_upload`
         self._uploads = 0
@@ -690,6 +696,7 @@ class Prefetcher:
         self._slots = [{"bufs": {}, "event": None} for _ in range(depth + 3)] if self.cuda else []
         self._batches = 0                      # batches staged so far (slot rotation goes on across epochs)
         self._requests, self._thread, self._pool = None, None, None
+        self._active = None                    # (queue, cancel event) of the epoch request the reader is serving
         self.trace = None                      # a list here collects (batch, start, slot wait ms, load ms) from the reader
 
     def _stage(self, slot, j, key, t):
@@ -754,20 +761,31 @@ class Prefetcher:
         finally:
             put(None)
 
-    def _serve(self):
-        while True:
-            req = self._requests.get()
-            if req is None:
-                return
-            self._epoch(*req)
+    def _serve(self, requests, pool):
+        # the reader owns `pool` for its lifetime and shuts it down itself: close() never pulls it from under a running map()
+        try:
+            while True:
+                req = requests.get()
+                if req is None:
+                    return
+                self._epoch(*req)
+        finally:
+            pool.shutdown(wait=False)
 
     def close(self):
-        """stop the reader thread (also done when the Prefetcher is collected)"""
-        if self._thread is not None:
+        """stop the reader thread (also done when the Prefetcher is collected): the epoch being served is cancelled first — an
+        endless `cycle(None)` or a generator nobody closed would otherwise never look at the request queue — then the reader is
+        asked to leave and joined; it shuts its pool down itself on the way out"""
+        th = self._thread
+        if th is not None:
+            active = self._active
+            if active is not None:
+                active[1].set()
             self._requests.put(None)
-            self._thread.join(timeout=5)
-            self._pool.shutdown(wait=False)
-            self._thread = self._pool = self._requests = None
+            th.join(timeout=5)
+            if th.is_alive():                  # still inside a file read: it leaves at the next cancel check; nothing is pulled away under it
+                th.join(timeout=30)
+            self._thread = self._pool = self._requests = self._active = None
 
     def __del__(self):
         try:
@@ -788,10 +806,11 @@ class Prefetcher:
         from concurrent.futures import ThreadPoolExecutor
         if self._thread is None:
             self._requests, self._pool = Queue(), ThreadPoolExecutor(max_workers=self.workers)
-            self._thread = threading.Thread(target=self._serve, daemon=True)
+            self._thread = threading.Thread(target=self._serve, args=(self._requests, self._pool), daemon=True)
             self._thread.start()
             _LIVE.add(self)
         q, cancel = Queue(maxsize=self.depth), threading.Event()
+        self._active = (q, cancel)
         self._requests.put((q, cancel, epochs))
         dev = self.builder.device
 

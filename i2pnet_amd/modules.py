@@ -174,10 +174,11 @@ class Conv2d(nn.Module):
         if bn:
             self.bn_linear = nn.BatchNorm2d(out_channels, track_running_stats=not use_bn_input)
             if use_bn_input:
-                # a bias in front of a batch-statistics BN cancels in the mean subtraction: it is kept
-                # in the state_dict for checkpoint compatibility but takes no part in training
-                # (keeps DDP free of unused-parameter bookkeeping)
+                # a bias in front of a batch-statistics BN cancels in the mean subtraction: its gradient is exactly zero, so
+                # autograd never sees it (no unused-parameter bookkeeping); train.Trainer still steps it like the reference's
+                # Adam does (g = 0 + weight_decay * p: train20v2learn_wandb_proj.py:198-202), see `_i2p_cancelled`
                 self.conv.bias.requires_grad_(False)
+                self.conv.bias._i2p_cancelled = True
 
     def weight2d(self):
         return self.conv.weight.view(self.out_channels, self.in_channels)
@@ -482,6 +483,7 @@ def createCNNs(in_channel, channels, strides):
     last = in_channel
     for i, (out_channel, stride) in enumerate(zip(channels, strides)):
         layers.add_module(str(i * 4), nn.Conv2d(last, out_channel, kernel_size=3, stride=1, padding=1, bias=True))
+        layers[-1].bias._i2p_cancelled = True      # in front of a train-mode BatchNorm2d: zero gradient, stepped by weight decay only
         layers.add_module(str(i * 4 + 1), nn.BatchNorm2d(out_channel))
         layers.add_module(str(i * 4 + 2), nn.LeakyReLU(negative_slope=0.1))
         layers.add_module(str(i * 4 + 3), nn.MaxPool2d(3, stride=stride, padding=1))

@@ -84,13 +84,50 @@ def drop_duplicate_cells(xyz, H, W, fup=2.0, fdown=-24.8):
     return out
 
 
+def above_fup_points(raw, count, fup=2.0):
+    """overwrite the first `count` rows of every cloud with returns ABOVE the upper field-of-view limit (elevation fup + 1.5 ...
+    fup + 2 degrees): the projection clamps them into image row 0 (utils.py:152-154), the row the NaN cell (0, W/2) of the zero
+    padding rows lives in; a quarter of them look straight ahead (azimuth ~ 0 -> columns W/2 - 1, W/2) so that real points and
+    padding rows compete for that cell in point order."""
+    B = raw.shape[0]
+    i = torch.arange(count, device=raw.device, dtype=torch.float32)
+    el = math.radians(fup + 1.5) + math.radians(0.5) * (i / max(count - 1, 1))
+    az = torch.where(i % 4 == 0, (i / count - 0.5) * 0.006, (i / count - 0.5) * 5.0)
+    r = 5.0 + i
+    pts = torch.stack([r * torch.cos(el) * torch.cos(az), r * torch.cos(el) * torch.sin(az), r * torch.sin(el)], -1)
+    out = raw.clone()
+    out[:, :count] = pts.unsqueeze(0).expand(B, -1, -1)
+    return out
+
+
+def drop_bin_edge_points(xyz, H, W, fup=2.0, fdown=-24.8, margin=2e-3):
+    """zero every point whose fractional row / column coordinate under utils.py:144-155 lies within `margin` cells of a bin edge:
+    host libm and the device's OCML differ by ulps in atan2 / asin, so such a point may land in either cell (SURVEY App. A.4:
+    "keep edge-adjacent points out of exact-match fixtures").  The zeroed rows become padding rows in the MIDDLE of the cloud."""
+    az_res = 2 * math.pi / W
+    vdown, vup = math.radians(fdown), math.radians(fup)
+    vres = (vup - vdown) / (H - 1)
+    d = xyz.double()
+    r = d.norm(dim=2).clamp_min(1e-30)
+    fcol = (math.pi - torch.atan2(d[..., 1], d[..., 0])) / az_res
+    frow = torch.asin((d[..., 2] / r).clamp(-1, 1)) / vres + (-vdown / vres)
+    edge = ((fcol - fcol.round()).abs() < margin) | ((frow - frow.round()).abs() < margin)
+    return xyz * (~edge).unsqueeze(-1)
+
+
 def make_batch(B, N=8192, img_h=375, img_w=1242, seed=0, device="cpu", zero_rows=0, beams=64, fup=2.0,
-               fdown=-24.8, layout="scan", unique_cells=None):
+               fdown=-24.8, layout="scan", unique_cells=None, edge_margin=None, above_fup=0):
     """-> dict with the reference loader's keys: rgb, lidar, raw_point_xyz, lidar_feats,
-    init_intrinsic, init_extrinsic, decalib_real_gt (quat w,x,y,z), decalib_dual_gt (trans)."""
+    init_intrinsic, init_extrinsic, decalib_real_gt (quat w,x,y,z), decalib_dual_gt (trans).
+    `edge_margin` = (H, W, margin): drop_bin_edge_points; `above_fup` = count: above_fup_points — the loader-shaped fixtures
+    (N = 150 000 with 30 000 padding rows, duplicate cells kept: kitti_odometry_corr_lidarnone_proj.py:264,699-711)."""
     g = torch.Generator(device=device).manual_seed(seed)
     rgb = torch.rand(B, 3, img_h, img_w, generator=g, device=device) * 255.0
     raw = lidar_scan(B, N, g, device, beams=beams, fup=fup, fdown=fdown, zero_rows=zero_rows, layout=layout)
+    if above_fup:
+        raw = above_fup_points(raw, above_fup, fup)
+    if edge_margin is not None:
+        raw = drop_bin_edge_points(raw, edge_margin[0], edge_margin[1], fup, fdown, edge_margin[2])
     if unique_cells is not None:                       # (H, W) of the range image
         raw = drop_duplicate_cells(raw, unique_cells[0], unique_cells[1], fup, fdown)
     # velodyne -> camera axes: x_c = -y_v, y_c = -z_v, z_c = x_v

@@ -82,24 +82,29 @@ class FlatAdam:
     @torch.no_grad()
     def step(self, gate=None):
         """`gate`: 0-d bool tensor or None; False leaves parameters, both moments and the step count untouched (a poisoned step,
-        see Trainer._update) without a host synchronisation"""
+        see Trainer._update) without a host synchronisation.  The gate multiplies the INPUTS of the update (step increment, lerp
+        weight, decay of the second moment, learning rate): with gate = 0 every line below is an exact identity, no model-sized
+        copies are made"""
         g = self.grad
-        if gate is not None:
-            keep = (self.step_t.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.param.clone())
-        self.step_t += 1.0
+        on = 1.0 if gate is None else gate.to(torch.float32)
+        if gate is not None:                  # a poisoned gradient may hold NaN / inf: 0 * NaN would leak through the zero weights
+            g = torch.where(gate, g, torch.zeros((), dtype=g.dtype, device=g.device))
+        self.step_t += on
         if self.weight_decay != 0.0:
             g = g.add(self.param, alpha=self.weight_decay)
         if self.mask is not None:
             g = g * self.mask
-        self.exp_avg.lerp_(g, 1.0 - self.beta1)
-        self.exp_avg_sq.mul_(self.beta2).addcmul_(g, g, value=1.0 - self.beta2)
-        bc1 = 1.0 - torch.pow(self.beta1, self.step_t)
-        bc2_sqrt = (1.0 - torch.pow(self.beta2, self.step_t)).sqrt()
+        if gate is None:
+            self.exp_avg.lerp_(g, 1.0 - self.beta1)
+            self.exp_avg_sq.mul_(self.beta2).addcmul_(g, g, value=1.0 - self.beta2)
+        else:
+            self.exp_avg.lerp_(g, on * (1.0 - self.beta1))                        # weight 0: exp_avg + 0 * (g - exp_avg)
+            self.exp_avg_sq.mul_(1.0 - on * (1.0 - self.beta2)).add_(g * g * (on * (1.0 - self.beta2)))
+        # (a gated first step has step_t = 0: the bias corrections are 0; clamp so that lr_t * 0 / tiny stays 0, not NaN)
+        bc1 = (1.0 - torch.pow(self.beta1, self.step_t)).clamp_min(1e-30)
+        bc2_sqrt = (1.0 - torch.pow(self.beta2, self.step_t)).clamp_min(1e-30).sqrt()
         denom = (self.exp_avg_sq.sqrt() / bc2_sqrt).add_(self.eps)
-        self.param.sub_(self.exp_avg / denom * (self.lr_t / bc1))
-        if gate is not None:
-            for cur, old in zip((self.step_t, self.exp_avg, self.exp_avg_sq, self.param), keep):
-                cur.copy_(torch.where(gate, cur, old))
+        self.param.sub_(self.exp_avg / denom * (self.lr_t * on / bc1))
 
     @torch.no_grad()
     def fused_clip_step(self, clip, gscale=1.0, poison=None):
@@ -140,16 +145,21 @@ class Trainer:
         training only: with several ranks a rank-local re-capture would desynchronise the collectives, so it always raises).
         Either way the poisoned step is never applied: the error counter rides at the end of the flat gradient, through the
         all-reduce, and a non-zero value turns clip + Adam into a no-op on every rank (i2p_clip_adam `poison`; the torch fallback of
-        `_update` gates its update the same way).  The word is the device's CUMULATIVE error counter: after one abandoned barrier every
-        later step is skipped until ops.chain_errors_reset(); check_chain_errors(sync=True) reads the all-reduced word, so every
-        rank raises, not only the faulty one."""
+        `_update` gates its update the same way).  The word is the counter's increase over THIS step, so a transient time-out skips
+        one step.  The faulty rank raises at its next `step()` (host-mapped flag); with world_size > 1 every rank reads the all-reduced
+        word of step k at the top of step k + 2 and raises there (`_check_reduced_poison`), and check_chain_errors(sync=True)
+        (epoch_end, save_checkpoint) reads it as well."""
         torch.manual_seed(seed)                 # identical initial weights on every rank
         self.cfg, self.device, self.clip = cfg, torch.device(device), clip
         self.world_size = world_size
         self._call = call
         self.net = net_cls(cfg=cfg).to(self.device)
         self.model = self.net
-        self.params = [p for p in self.net.parameters() if p.requires_grad]
+        # every parameter the reference's torch.optim.Adam steps — i.e. all of them (train20v2learn_wandb_proj.py:198): conv biases
+        # in front of a batch-statistics BN (`_i2p_cancelled`, modules.Conv2d / createCNNs) have an exactly-zero gradient and never
+        # enter autograd here, but the reference still moves them by weight decay (g = 0 + 1e-4 p, i.e. ~lr per step through Adam's
+        # normalisation): they sit in the flat buffers with a zero gradient so that parameters evolve as in the reference
+        self.params = [p for p in self.net.parameters() if p.requires_grad or getattr(p, "_i2p_cancelled", False)]
         if world_size > 1:                      # belt and braces: same seed already gives identical replicas
             for p in self.net.parameters():
                 dist.broadcast(p.data, src=0)
@@ -174,6 +184,16 @@ class Trainer:
         if self.device.type == "cuda" and ops.get_backend().name == "hip":
             with torch.cuda.device(self.device):
                 self._chain_words = ops.chain_error_words(self.device)
+        # the poison word of a step is the counter's INCREASE over that step (snapshot at the step's start): one transient
+        # time-out poisons one step, not every later one
+        self._poison_base = torch.zeros(4, dtype=torch.float32, device=self.device)
+        # world_size > 1: the all-reduced poison word of step k is copied to pinned memory after the update and read at the top of
+        # step k + 2 (its copy has long finished: no stall) — EVERY rank then raises at the same step, instead of the healthy ranks
+        # hanging in an all-reduce the faulty rank (which sees its host flag one step earlier) never joins
+        self._poison_ring = None
+        if self._chain_words is not None and (world_size > 1 or os.environ.get("I2P_FORCE_DP")):
+            self._poison_ring = ([torch.zeros(1, dtype=torch.float32).pin_memory() for _ in range(2)], [None, None])
+        self._steps_issued = 0
         self._zero = torch.zeros((), dtype=torch.float32, device=self.device)
         self._nhwc = []                         # 4-D parameters kept in channels_last storage (image-encoder conv weights)
         with torch.no_grad():
@@ -209,6 +229,8 @@ class Trainer:
     def _forward_backward_in_step(self, batch):
         for p in self.params:                   # autograd then hands its buffers over instead of accumulating
             p.grad = None
+        if self._chain_words is not None:
+            self._poison_base.copy_(self._chain_words[0])
         if self._call is not None:
             out3, out4, _, _, sx, sq = self._call(self.model, batch, self.cfg)
         else:
@@ -222,10 +244,11 @@ class Trainer:
         grads = []
         if not self._mask_known:                # first step: which parameters does this loss reach at all? (host-side
             self._mask_known = True             # knowledge: no synchronisation)
-            if any(p.grad is None for p in self.params):
+            unreached = lambda p: p.grad is None and not getattr(p, "_i2p_cancelled", False)
+            if any(unreached(p) for p in self.params):
                 mask = torch.ones_like(self.flat_param)
                 for p, off in zip(self.params, self._offsets):
-                    if p.grad is None:
+                    if unreached(p):
                         mask[off:off + (p.numel() + 3) // 4 * 4] = 0.0
                 self.optimizer.mask = mask
         for p, nhwc in zip(self.params, self._nhwc):
@@ -235,13 +258,13 @@ class Trainer:
                 grads.append((p.grad.permute(0, 2, 3, 1) if nhwc else p.grad).reshape(-1))
             if p.numel() % 4:                   # alignment padding of the flat layout
                 grads.append(zero.expand(4 - p.numel() % 4))
-        grads.append(self._chain_words[0] if self._chain_words is not None else zero.expand(4))
+        grads.append(self._chain_words[0] - self._poison_base if self._chain_words is not None else zero.expand(4))
         torch.cat(grads, out=self._grad_buf)
         return loss.detach(), real_loss.detach(), dual_loss.detach()
 
     def named_grads(self):
         """the gradients the optimiser consumed last step (all-reduced, averaged, clipped), by parameter name"""
-        names = [k for k, p in self.net.named_parameters() if p.requires_grad]
+        names = [k for k, p in self.net.named_parameters() if p.requires_grad or getattr(p, "_i2p_cancelled", False)]
         out = {}
         for k, p, nhwc, off in zip(names, self.params, self._nhwc, self._offsets):
             seg = self.flat_grad[off:off + p.numel()]
@@ -279,6 +302,29 @@ class Trainer:
                 self.capture(self._static)
             return
         raise ops.ChainBarrierTimeout(msg)
+
+    def _post_poison(self):
+        """after the update of step k: the all-reduced poison word to pinned memory, asynchronously"""
+        if self._poison_ring is None:
+            return
+        host, events = self._poison_ring
+        slot = self._steps_issued % 2
+        host[slot].copy_(self._poison[:1], non_blocking=True)
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device))
+        events[slot] = ev
+        self._steps_issued += 1
+
+    def _check_reduced_poison(self):
+        """top of step k + 2: did any rank's chain kernels abandon a barrier in step k?  Same answer on every rank."""
+        if self._poison_ring is None or self._steps_issued < 2:
+            return
+        host, events = self._poison_ring
+        slot = self._steps_issued % 2              # the slot written two steps ago (about to be re-used)
+        events[slot].synchronize()
+        if float(host[slot][0]) != 0.0:
+            raise ops.ChainBarrierTimeout(
+                f"step {self._steps_issued - 2}: {int(host[slot][0])} chain launch(es) across the {self.world_size} ranks abandoned a grid "
+                "barrier; that step was not applied on any rank.  Raised on every rank at the same step.")
 
     def _all_reduce(self):
         if self.world_size > 1 or (os.environ.get("I2P_FORCE_DP") and dist.is_initialized()):
@@ -468,7 +514,10 @@ class Trainer:
     def step(self, batch):
         """one optimisation step on a sample dict (keys of the reference loader); returns the
         loss tensors without synchronising."""
-        self.check_chain_errors()                 # host-mapped flag of the chain kernels: no synchronisation
+        if self._poison_ring is not None:         # world_size > 1: every rank raises together, two steps after the fault — the faulty
+            self._check_reduced_poison()          # rank must not leave earlier on its own host flag (the others would hang in the all-reduce)
+        else:
+            self.check_chain_errors()             # host-mapped flag of the chain kernels: no synchronisation
         if self._graph_a is not None:
             for k, dst in self._static.items():
                 v = batch[k]
@@ -478,5 +527,8 @@ class Trainer:
             if self._graph_b is not None:
                 self._all_reduce()
                 self._graph_b.replay()
+            self._post_poison()
             return self._static_out
-        return self._eager_step(batch)
+        out = self._eager_step(batch)
+        self._post_poison()
+        return out

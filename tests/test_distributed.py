@@ -1,4 +1,3 @@
-import pytest
 """Data-parallel step on CPU: 2 processes, gloo, oracle operators.  Checks what the RCCL path
 relies on: identical parameters on every rank after a step, and gradients equal to the mean of
 the per-rank gradients (flat-buffer all-reduce), with BN statistics local to a rank."""
@@ -7,6 +6,7 @@ import socket
 import sys
 from pathlib import Path
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -173,7 +173,21 @@ def test_flat_adam_gate_skips_a_step():
     opt = FlatAdam(w, g, 1e-2)
     opt.step(gate=torch.tensor(True))
     w1, m1, v1, t1 = w.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), float(opt.step_t)
+    g_good = g.clone()
+    g.fill_(float("nan"))                 # what an abandoned grid barrier may leave behind
     opt.step(gate=torch.tensor(False))
     assert torch.equal(w, w1) and torch.equal(opt.exp_avg, m1) and torch.equal(opt.exp_avg_sq, v1) and float(opt.step_t) == t1 == 1.0
+    g.copy_(g_good)
     opt.step(gate=torch.tensor(True))
     assert not torch.equal(w, w1) and float(opt.step_t) == 2.0
+    # a gated-on step is the ungated step
+    w2, g2 = w1.clone(), g_good.clone()
+    ref = FlatAdam(w2, g2, 1e-2)
+    ref.exp_avg.copy_(m1); ref.exp_avg_sq.copy_(v1); ref.step_t.fill_(1.0)
+    ref.step()
+    assert torch.allclose(w, w2, rtol=0, atol=1e-7) and torch.allclose(opt.exp_avg_sq, ref.exp_avg_sq, rtol=1e-6, atol=0)
+    # a gated-off FIRST step (step count 0: zero bias corrections) stays finite and is the identity
+    w3 = torch.randn(16); w3_0 = w3.clone()
+    o3 = FlatAdam(w3, torch.randn(16), 1e-2)
+    o3.step(gate=torch.tensor(False))
+    assert torch.equal(w3, w3_0) and float(o3.step_t) == 0.0

@@ -289,6 +289,43 @@ def test_chain_timeout_surfaces_in_trainer_step(hip_backend, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_chain_timeout_raises_on_the_same_step_for_every_rank(hip_backend, monkeypatch):
+    """with several ranks only the faulty rank's host flag is set.  The poison word is per step (the counter's increase)
+    and rides through the all-reduce; every rank reads the reduced word of step k at the top of step k + 2 and raises THERE — the
+    faulty rank included, so nobody leaves early and nobody hangs in a collective.  Driven with the data-parallel step structure
+    on one GPU (I2P_FORCE_DP, no process group: the all-reduce is skipped, the bookkeeping is the same)."""
+    from i2pnet_amd import ops, synth
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd.train import Trainer
+    dev = torch.device("cuda", 0)
+    assert ops.chain_errors() == 0
+    batch = synth.make_batch(16, 8192, 160, 512, seed=3, device=dev)
+    monkeypatch.setenv("I2P_FORCE_DP", "1")
+    monkeypatch.delenv("I2P_NO_CHAIN", raising=False)
+    ops._CHAIN_OK.clear()
+    try:
+        tr = Trainer(cfg=cfg, device=dev, seed=0)
+        assert tr._poison_ring is not None
+        tr.step(batch); torch.cuda.synchronize()                     # step 0: healthy
+        p1 = tr.flat_param.clone()
+        assert float(tr.optimizer.step_t) == 1.0 and float(tr._poison[0]) == 0.0
+        monkeypatch.setenv("I2P_CHAIN_FORCE_NONRESIDENT", "1"); monkeypatch.setenv("I2P_CHAIN_POLL_LIMIT", "20000")
+        ops._CHAIN_OK.clear()
+        tr.step(batch); torch.cuda.synchronize()                     # step 1: barriers abandoned -> poisoned, not applied
+        assert float(tr._poison[0]) >= 1.0 and torch.equal(tr.flat_param, p1) and float(tr.optimizer.step_t) == 1.0
+        monkeypatch.delenv("I2P_CHAIN_FORCE_NONRESIDENT"); ops._CHAIN_OK.clear()
+        tr.step(batch); torch.cuda.synchronize()                     # step 2: healthy again, applied (the word is per step), no raise yet
+        assert float(tr._poison[0]) == 0.0 and float(tr.optimizer.step_t) == 2.0 and not torch.equal(tr.flat_param, p1)
+        with pytest.raises(ops.ChainBarrierTimeout, match="every rank"):
+            tr.step(batch)                                           # top of step 3 reads the reduced word of step 1
+    finally:
+        monkeypatch.undo()
+        ops._CHAIN_OK.clear()
+        ops.chain_errors_reset()
+    assert ops.chain_errors() == 0
+
+
+@pytest.mark.gpu
 def test_dp_step_structure_costs_less_than_3_percent():
     """what one GPU can measure of the N > 1 step — graph A -> RCCL all-reduce (1-rank group) -> graph B against
     the single captured graph, at the benchmark's own configuration (configs[1], batch 8), through bench.py's own functions.  The

@@ -153,7 +153,51 @@ def tensor_digest(t, name):
     return stats, t[sample_rows(t.shape[0], name)].float().numpy()
 
 
-def run_sized(cfg_name, tag, B, N, img_h, img_w, seed, beams):
+def winner_digest(win, name="proj"):
+    """[B, H*W] int winners (-1 = empty cell) -> (occupied cells [B], checksum [B], winners at 4096 seeded cells [B, 4096])"""
+    win = torch.as_tensor(win).long()
+    hw = win.shape[1]
+    wgt = (torch.arange(hw) % 65521 + 1)
+    cells = sample_cells(hw)
+    return (win >= 0).sum(1).numpy(), ((win + 1) * wgt).sum(1).numpy(), win[:, cells].numpy().astype(np.int32)
+
+
+def sample_cells(hw):
+    return torch.randperm(hw, generator=torch.Generator().manual_seed(hw * 31 + 5))[:4096].sort().values
+
+
+def pin_projection(net, cfg, record):
+    """Run the reference's project_seq (src/projectPN/utils.py:111-187) with ONE torch thread and check it against the oracle's
+    winner rule.  Why one thread: its scatter is `xyz_proj[i, iRow[i], iCol[i]] = xyz[i]` (:175-177), an index_put_ whose result
+    under duplicate cells depends on torch's intra-op thread count on the CPU (probe: 150 000 points into 64 x 1800 cells, 1 thread
+    = point order, i.e. the last writer wins, in 3 of 3 trials; 8 threads: 70 290 cells differ from that) and is unspecified on
+    CUDA.  One thread is the only reproducible evaluation of the reference there is; it is also what the oracle and the device
+    kernel implement (highest point index wins, one winner for all three images)."""
+    from i2pnet_amd import ops
+    orig = net.project_seq
+
+    def wrapped(xyz, features, H, W, use_rank=True, fup=2.0, fdown=-24.8):
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            img, feats = orig(xyz, features, H, W, use_rank, fup, fdown)
+        finally:
+            torch.set_num_threads(nt)
+        if not use_rank and "mismatch" not in record:
+            _, _, win = ops.get_backend().project_seq(xyz.detach().float().contiguous(), [], H, W, fup, fdown)
+            w = win.long().clamp(min=0); m = (win >= 0).unsqueeze(-1)
+            mine = (torch.gather(xyz.detach(), 1, w.unsqueeze(-1).expand(-1, -1, 3)) * m).view(img.shape)
+            # NaN padding rows write zeros into their cell: "winner is a zero row" and "cell empty" are the same image
+            record["mismatch"] = int((mine != img).any(-1).sum())
+            record["win"] = win.clone()
+            dup = xyz.shape[1] - (xyz == 0).all(-1).sum(1) - ((win >= 0) & (torch.gather(xyz, 1, w.unsqueeze(-1).expand(-1, -1, 3)) != 0).any(-1)).sum(1)
+            record["lost_to_duplicates"] = dup.numpy()
+        return img, feats
+    net.project_seq = wrapped
+    return orig
+
+
+def run_sized(cfg_name, tag, B, N, img_h, img_w, seed, beams, batch_kw=None):
     """The benchmark's own batch sizes (BASELINE.json configs[1]: B=8 fp32; configs[2]: B=16) against the reference in
     TRAIN mode (train20v2learn_wandb_proj.py:31,435-483; dropout p = 0: its RNG stream is not portable).  Batch-statistics
     BN (PPBackbone_center.py:30) makes the batch size part of the function, so the batch-2 fixtures do not pin these.  The
@@ -169,8 +213,12 @@ def run_sized(cfg_name, tag, B, N, img_h, img_w, seed, beams):
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-    batch = synth.make_batch(B, N, img_h, img_w, seed=seed, beams=beams, fup=cfg.fup, fdown=cfg.fdown,
-                             unique_cells=(cfg.init_H, cfg.init_W))
+    kw = {"unique_cells": (cfg.init_H, cfg.init_W)} if batch_kw is None else dict(batch_kw)
+    batch = synth.make_batch(B, N, img_h, img_w, seed=seed, beams=beams, fup=cfg.fup, fdown=cfg.fdown, **kw)
+    proj = {}
+    if batch_kw is not None:           # duplicate cells present: the reference's scatter pinned at one thread, checked vs the oracle
+        import importlib
+        pin_projection(importlib.import_module("src.modellearn_proj_center"), cfg, proj)
     captured = {}
 
     def hook(name):
@@ -246,9 +294,89 @@ def run_sized(cfg_name, tag, B, N, img_h, img_w, seed, beams):
     data["state_keys"] = np.array([k for k, _ in shapes])
     data["state_shapes"] = np.array([",".join(map(str, s)) for _, s in shapes])
     data["meta"] = np.array([cfg_name, str(B), str(N), str(img_h), str(img_w), str(seed), str(beams)])
+    if batch_kw is not None:
+        import json
+        data["batch_kw"] = np.array(json.dumps(batch_kw))
+        data["proj.occupied"], data["proj.checksum"], data["proj.winners"] = winner_digest(proj["win"])
+        data["proj.ref_vs_oracle_mismatch"] = np.array(proj["mismatch"])
+        data["proj.lost_to_duplicates"] = proj["lost_to_duplicates"]
+        print(tag, "projection: reference (1 thread) vs oracle winner rule:", proj["mismatch"], "cells differ; occupied",
+              data["proj.occupied"].tolist(), "points lost to duplicate cells", proj["lost_to_duplicates"].tolist())
     OUT.mkdir(parents=True, exist_ok=True)
     np.savez_compressed(OUT / f"model_{tag}.npz", **data)
     print(tag, "out3[0]", data["out3"][0].round(4).tolist(), "loss", data["loss"][0], "size", (OUT / f"model_{tag}.npz").stat().st_size)
+
+
+def run_trajectory(cfg_name, tag, B, N, img_h, img_w, seed, beams, steps=5):
+    """k optimisation steps of the REFERENCE model under the reference trainer's loop (train20v2learn_wandb_proj.py:198-205:
+    torch.optim.Adam(lr 1e-3, betas (0.9, 0.999), eps 1e-8, weight_decay 1e-4); :457-483: forward, zero_grad, Get_loss, backward,
+    clip_grad_norm_(10), step) on k seeded batches (seed + i), train mode, dropout p = 0 (its RNG stream is not portable).
+    Recorded per step: loss / real / dual, out3, out4, the total gradient norm clip_grad_norm_ returns; after the first and the
+    last step: the norm of every parameter's change.  The same trajectory is run three more times as algebraically identical
+    networks with other fp32 summation orders — the first convolution's input channels reversed (see run_sized), the batch's samples
+    reversed (the batch-statistics sums), both: |alt - ref| per step is how far legitimate fp32 evaluations of the reference drift
+    apart under Adam, whose first steps move every weight by ~lr * sign(g) and therefore turn rounding noise in small gradient
+    entries into +-lr differences."""
+    RegNet, cfg, Get_loss = ref_harness.load_model(cfg_name)
+
+    def trajectory(flip_c, flip_b):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = RegNet(cfg=cfg)
+        shapes = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+        model.load_state_dict(synthetic_state(shapes, seed=seed))
+        model.train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        if flip_c:
+            with torch.no_grad():
+                model.RGB_net1[0].weight.copy_(model.RGB_net1[0].weight.flip(1))
+        p0 = {k: p.detach().clone() for k, p in model.named_parameters()}
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0001)
+        rec = {"loss": [], "out3": [], "out4": [], "gnorm": []}
+        for i in range(steps):
+            b = synth.make_batch(B, N, img_h, img_w, seed=seed + i, beams=beams, fup=cfg.fup, fdown=cfg.fdown,
+                                 unique_cells=(cfg.init_H, cfg.init_W))
+            if flip_c:
+                b["rgb"] = b["rgb"].flip(1)
+            if flip_b:
+                b = {k: v.flip(0).contiguous() for k, v in b.items()}
+            out3, out4, _, _, sx, sq = model(b["rgb"], b["lidar"], b["raw_point_xyz"], b["init_extrinsic"], b["init_intrinsic"],
+                                             None, None, None, b["lidar_feats"], cfg=cfg)
+            opt.zero_grad()
+            loss, lq, lx = Get_loss(out3, out4, b["decalib_real_gt"], b["decalib_dual_gt"], sx, sq, cfg=cfg)
+            loss.backward()
+            total = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+            opt.step()
+            rec["loss"].append([loss.item(), lq.item(), lx.item()]); rec["gnorm"].append(float(total))
+            o3, o4 = out3.detach(), out4.detach()
+            if flip_b:
+                o3, o4 = o3.flip(0), o4.flip(0)
+            rec["out3"].append(o3.numpy().copy()); rec["out4"].append(o4.numpy().copy())
+            if i == 0:     # after ONE step |dp| ~ lr per entry whatever the sign of g: insensitive to rounding noise, sensitive to the optimiser's settings
+                rec["dnorm1"] = [float((p.detach() - p0[k]).double().norm()) for k, p in model.named_parameters()]
+        named = dict(model.named_parameters())
+        rec["keys"] = [k for k, _ in model.named_parameters()]
+        rec["dnorm"] = [float((named[k].detach() - p0[k]).double().norm()) for k in rec["keys"]]
+        rec["shapes"] = shapes
+        return rec
+
+    ref = trajectory(False, False)
+    alts = [trajectory(True, False), trajectory(False, True), trajectory(True, True)]
+    st = lambda key: np.stack([np.array(a[key]) for a in alts])
+    data = {"loss": np.array(ref["loss"]), "out3": np.stack(ref["out3"]), "out4": np.stack(ref["out4"]), "gnorm": np.array(ref["gnorm"]),
+            "loss_alt": st("loss"), "out3_alt": np.stack([np.stack(a["out3"]) for a in alts]), "gnorm_alt": st("gnorm"),
+            "param_keys": np.array(ref["keys"]), "param_delta_norm": np.array(ref["dnorm"]), "param_delta_norm_alt": st("dnorm"),
+            "param_delta_norm_step1": np.array(ref["dnorm1"]), "param_delta_norm_step1_alt": st("dnorm1"),
+            "state_keys": np.array([k for k, _ in ref["shapes"]]),
+            "state_shapes": np.array([",".join(map(str, s_)) for _, s_ in ref["shapes"]]),
+            "meta": np.array([cfg_name, str(B), str(N), str(img_h), str(img_w), str(seed), str(beams), str(steps)])}
+    OUT.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(OUT / f"model_{tag}.npz", **data)
+    print(tag, "loss", data["loss"][:, 0].tolist(), "\n alts", data["loss_alt"][:, :, 0].tolist(), "\n gnorm", data["gnorm"].tolist(),
+          "\n alts", data["gnorm_alt"].tolist())
+    print(tag, "max |out3 - out3_alt| per step", np.abs(data["out3"][None] - data["out3_alt"]).reshape(3, steps, -1).max(2).tolist())
 
 
 def run_iter(cfg_name, tag, B, N, img_h, img_w, seed, beams):
@@ -672,6 +800,17 @@ if __name__ == "__main__":
             run_sized("config_proj_lidarcenter", "kitti_b8", B=8, N=8192, img_h=375, img_w=1242, seed=8, beams=64)
         if "kitti_b16" in which:
             run_sized("config_proj_lidarcenter", "kitti_b16", B=16, N=8192, img_h=375, img_w=1242, seed=16, beams=64)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sized_loader":
+        # BASELINE.json configs[3]'s per-GPU workload as the reference's KITTI loader produces it (kitti_odometry_corr_lidarnone_proj.py:
+        # 264,278-279,699-711): batch 8, 160 x 512 crops, 150 000-row clouds = 120 000 scan points + 30 000 zero rows, duplicate cells
+        # kept (86 % range-image occupancy), a few returns above the field of view (row 0, where the padding rows' NaN cell lives)
+        run_sized("config_proj_lidarcenter", "kitti_loader_b8", B=8, N=150000, img_h=160, img_w=512, seed=28, beams=64,
+                  batch_kw={"zero_rows": 30000, "edge_margin": [64, 1800, 2e-3], "above_fup": 32})
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "trajectory":
+        # five steps of the reference's optimiser loop (VERDICT r5 missing #5): "matched pose-regression loss vs reference"
+        run_trajectory("config_proj_lidarcenter", "kitti_traj", B=2, N=8192, img_h=160, img_w=512, seed=40, beams=64, steps=5)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sized_nus":
         # BASELINE.json configs[4] at its own per-GPU shape: nuScenes configuration, batch 8, 375 x 1242 image, 16 384 points

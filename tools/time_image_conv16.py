@@ -51,8 +51,7 @@ def main():
         t3 = timed(lambda: be.img_conv16_tail_backward(dy, arg, yk, mi, gam, bet, 0.1, w))
         print(f"block backward, stride-1 pool : statistics + dy {t1:6.1f} us, then input gradient {t2:6.1f} us; statistics + ONE kernel {t3:6.1f} us")
         t4 = timed(lambda: be.img_block_forward(yk, gam, bet, 1e-5, 0.1, 1, sums=sums))
-        t5 = timed(lambda: be.img_conv_pool_forward(yk, sums, gam, bet, 1e-5, 0.1, 0.0, None, None, None, w))
-        print(f"block tail forward {t4:6.1f} us (+ the next convolution above); tail + next convolution in one kernel {t5:6.1f} us")
+        print(f"block tail forward {t4:6.1f} us (+ the next convolution above)")
     import os
     if os.environ.get("I2P_TIME_CONV16_ONLY") == "1":
         return
