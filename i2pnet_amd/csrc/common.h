@@ -107,6 +107,11 @@ int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const flo
                    const float *g_omi, long long g_rows, float *bn_out, const float *x, const float *in_coef, float slope_in,
                    const float *xb, const float *in_coef_b, float slope_b, int split, float *dw_partial, unsigned grid, void *stream);
 // input gradient + weight gradient of an HBM-bound wide layer from ONE read of gz / y / x (csrc/mlp_wreg_fused.hip)
+bool i2p_wreg_bwd_fused2_ok(long long rows, int k, int c, int split);
+int i2p_wreg_bwd_fused2(long long rows, const float *gz, const float *y2, const double *g_dsums, const float *g_oc, const float *g_omi,
+                        long long g_rows, const float *w, float *gz_in_a, const float *xa, const float *coef_a, const float *mi_a,
+                        float slope_a, double *sums_a, float *gz_in_b, const float *xb, const float *coef_b, const float *mi_b,
+                        float slope_b, double *sums_b, const float *e_add, float *bn_out, float *dw_partial, unsigned grid, void *stream);
 bool i2p_wreg_bwd_fused_ok(long long rows, int k, int c);
 int i2p_wreg_bwd_fused(long long rows, int k, int c, const float *gz, const float *y2, const double *g_dsums, const float *g_oc,
                        const float *g_omi, long long g_rows, const float *w, float *gz_in, const float *ex, const float *e_coef,

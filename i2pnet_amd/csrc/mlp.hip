@@ -2065,6 +2065,17 @@ static int lin_bwd_impl(long long rows, int cin, int cout, const float *gz, cons
                 launch_reduce_partials((int)grid, cout * cin, dw_partial, dw, st);
                 I2P_RETURN_LAUNCH_STATUS();
             }
+            if (part == 3 && two && two_d3 && gz_in && in_dsums && out_coef && p.slope_out == 1.f && in_coef && slope_in >= 0.f && slope_in <= 1.f &&
+                two->slope_b >= 0.f && two->slope_b <= 1.f && grid == 256 && i2p_wreg_bwd_fused2_ok(rows, cout, cin, two->split_c)) {
+                // the two-source layer 64 + 64 -> 128 on many rows: both gradients from one read of gz / y / xa / xb, a wave per
+                // (strip, source) (csrc/mlp_wreg_fused.hip, TWO instantiation)
+                const int rc = i2p_wreg_bwd_fused2(rows, gz, y, out_dsums, out_coef, out_mi, rows, w, gz_in, x, in_coef, in_mi, slope_in, in_dsums,
+                                                   two->gz_in_b, two->xb, two->in_coef_b, two->in_mi_b, two->slope_b, two->in_dsums_b, two->e_add,
+                                                   g_coef, dw_partial, grid, stream);
+                if (rc) return rc;
+                launch_reduce_partials((int)grid, cout * cin, dw_partial, dw, st);
+                I2P_RETURN_LAUNCH_STATUS();
+            }
             if (gz_in && two_d3 && out_coef && p.slope_out == 1.f && in_coef && i2p_wreg_dgrad_ok(rows, cout, cin)) {
                 // wide layer on many rows, plain BN on both sides: weights stationary in registers (csrc/mlp_wreg.hip)
                 const int rc = two ? i2p_wreg_dgrad(rows, cout, cin, gz, y, out_dsums, out_coef, out_mi, rows, w, gz_in, x, in_coef, in_mi,

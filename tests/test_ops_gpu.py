@@ -193,6 +193,46 @@ def test_gather_rows_parity(oracle_backend, hip_backend):
     assert torch.allclose(rg, gg.cpu(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("C,Q,hw,hot,ld_off", [(32, 904 * 16, 3600, 0.93, None), (128, 228 * 32, 468, 0.0, None), (64, 228 * 4, 228, 0.5, None),
+                                                (35, 1000, 77, 0.2, None), (3, 4099, 3600, 0.9, None), (200, 333, 50, 0.3, None),
+                                                (64, 116 * 16, 228, 0.1, (72, 4)), (300, 64, 10, 0.0, None)])
+def test_gather_rows_grad_preaggregated_scatter(oracle_backend, hip_backend, monkeypatch, C, Q, hw, hot, ld_off):
+    """round 6: the fixed-point scatter pre-aggregates a block's rows per cell in LDS (scatter_fx2_kernel) before the int64 atomics.
+    Against the oracle's serial scatter (i2p_oracle.c gather_rows_grad, the backward of utils.py:36-60) to fp32 rounding, and BIT for
+    BIT against the per-thread-run kernel of rounds 2-5 (I2P_SCATTER_V1=1): integer sums do not depend on the grouping.  Cases: the
+    level-2 shape with 93 % of the rows on the hot cell (0,0) (FLAG_COPY), the kNN cost volume's 128-channel rows, windows of
+    neighbouring queries (shared cells), odd channel counts, a strided source (pitch / offset), C > 256 (the old kernel's path)."""
+    B, W = 3, hw
+    g = torch.Generator().manual_seed(C * 7 + Q)
+    # neighbouring queries share cells: cell = a slowly drifting window + the hot cell with probability `hot`
+    base = (torch.arange(Q) // 16 * 3) % max(hw - 20, 1)
+    cell = (base.unsqueeze(0) + torch.randint(0, 20, (B, Q), generator=g)) % hw
+    cell = torch.where(torch.rand(B, Q, generator=g) < hot, torch.zeros_like(cell), cell)
+    h = torch.zeros(B, Q, dtype=torch.long); w = cell.long()
+    ld, off = ld_off if ld_off else (C, 0)
+    full = torch.randn(B, Q, ld, generator=g) * torch.logspace(-3, 2, Q).view(1, Q, 1)
+    gout = full[:, :, off:off + C].contiguous()
+    init = torch.randn(B, hw, C, generator=g)
+    rg = init.clone()
+    oracle_backend.gather_rows_grad(gout, h, w, W, rg)
+
+    def run():
+        gg = init.clone().to(DEV)
+        if ld_off:
+            hip_backend.gather_rows_grad_ld(full.to(DEV), ld, off, h.to(DEV), w.to(DEV), W, gg)
+        else:
+            hip_backend.gather_rows_grad(gout.to(DEV), h.to(DEV), w.to(DEV), W, gg)
+        torch.cuda.synchronize()
+        return gg.cpu()
+    monkeypatch.delenv("I2P_SCATTER_V1", raising=False)
+    new = run()
+    monkeypatch.setenv("I2P_SCATTER_V1", "1")
+    old = run()
+    assert torch.equal(new, old)
+    scale = float(rg.abs().max())
+    assert float((new - rg).abs().max()) <= 2e-5 * scale
+
+
 def test_knn_parity(oracle_backend, hip_backend):
     for (N, S, k) in [(468, 228, 32), (100, 7, 100), (2048, 64, 16)]:
         B = 2

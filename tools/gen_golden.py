@@ -314,12 +314,14 @@ def run_trajectory(cfg_name, tag, B, N, img_h, img_w, seed, beams, steps=5):
     Recorded per step: loss / real / dual, out3, out4, the total gradient norm clip_grad_norm_ returns; after the first and the
     last step: the norm of every parameter's change.  The same trajectory is run three more times as algebraically identical
     networks with other fp32 summation orders — the first convolution's input channels reversed (see run_sized), the batch's samples
-    reversed (the batch-statistics sums), both: |alt - ref| per step is how far legitimate fp32 evaluations of the reference drift
+    reversed (the batch-statistics sums) — and four times from initial weights moved by half an ulp (relative 6e-8 N(0,1); the summation-
+    order alternates do not touch the arithmetic of the ill-conditioned mask up-convolution, which consumes -1e10 mask values as
+    features and dominates the total gradient norm): |alt - ref| per step is how far legitimate fp32 evaluations of the reference drift
     apart under Adam, whose first steps move every weight by ~lr * sign(g) and therefore turn rounding noise in small gradient
     entries into +-lr differences."""
     RegNet, cfg, Get_loss = ref_harness.load_model(cfg_name)
 
-    def trajectory(flip_c, flip_b):
+    def trajectory(flip_c, flip_b, ulp_seed=0):
         torch.manual_seed(0)
         with contextlib.redirect_stdout(io.StringIO()):
             model = RegNet(cfg=cfg)
@@ -332,6 +334,11 @@ def run_trajectory(cfg_name, tag, B, N, img_h, img_w, seed, beams, steps=5):
         if flip_c:
             with torch.no_grad():
                 model.RGB_net1[0].weight.copy_(model.RGB_net1[0].weight.flip(1))
+        if ulp_seed:       # every initial weight moved by about half an ulp (relative 6e-8 N(0,1)): another rounding of the same initialisation
+            gu = torch.Generator().manual_seed(1000 + ulp_seed)
+            with torch.no_grad():
+                for p_ in model.parameters():
+                    p_.mul_(1.0 + 6e-8 * torch.randn(p_.shape, generator=gu))
         p0 = {k: p.detach().clone() for k, p in model.named_parameters()}
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0001)
         rec = {"loss": [], "out3": [], "out4": [], "gnorm": []}
@@ -363,7 +370,7 @@ def run_trajectory(cfg_name, tag, B, N, img_h, img_w, seed, beams, steps=5):
         return rec
 
     ref = trajectory(False, False)
-    alts = [trajectory(True, False), trajectory(False, True), trajectory(True, True)]
+    alts = [trajectory(True, False), trajectory(False, True)] + [trajectory(False, False, ulp_seed=u) for u in (1, 2, 3, 4)]
     st = lambda key: np.stack([np.array(a[key]) for a in alts])
     data = {"loss": np.array(ref["loss"]), "out3": np.stack(ref["out3"]), "out4": np.stack(ref["out4"]), "gnorm": np.array(ref["gnorm"]),
             "loss_alt": st("loss"), "out3_alt": np.stack([np.stack(a["out3"]) for a in alts]), "gnorm_alt": st("gnorm"),
@@ -376,7 +383,7 @@ def run_trajectory(cfg_name, tag, B, N, img_h, img_w, seed, beams, steps=5):
     np.savez_compressed(OUT / f"model_{tag}.npz", **data)
     print(tag, "loss", data["loss"][:, 0].tolist(), "\n alts", data["loss_alt"][:, :, 0].tolist(), "\n gnorm", data["gnorm"].tolist(),
           "\n alts", data["gnorm_alt"].tolist())
-    print(tag, "max |out3 - out3_alt| per step", np.abs(data["out3"][None] - data["out3_alt"]).reshape(3, steps, -1).max(2).tolist())
+    print(tag, "max |out3 - out3_alt| per step", np.abs(data["out3"][None] - data["out3_alt"]).reshape(len(alts), steps, -1).max(2).tolist())
 
 
 def run_iter(cfg_name, tag, B, N, img_h, img_w, seed, beams):

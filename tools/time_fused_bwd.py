@@ -34,3 +34,29 @@ for cin, cout in ((128, 64), (64, 64)):
     t = e0.elapsed_time(e1) / 20 * 1e3
     by = rows * (2 * cout + 2 * cin) * 4
     print(f"{cin:3d} -> {cout:3d}: {t:7.1f} us per backward (incl. the slab reduction)  {by / t / 1e3:7.1f} GB/s on one read of gz, y, x + one write", flush=True)
+
+# the two-source layer 64 + 64 -> 128 (round 6): one pass (wreg_bwd_fused_kernel<128,64,TWO>) — I2P_NO_FUSED_BWD2=1 times
+# wreg_dgrad_kernel<128,128,true> + wreg_wgrad_kernel<128,128,true,true>
+g = torch.Generator(device=dev).manual_seed(2)
+xa = torch.randn(rows, 64, device=dev, generator=g); xb = torch.randn(rows, 64, device=dev, generator=g) * 2 + 0.3
+w = torch.randn(128, 128, device=dev, generator=g) / 11
+one = lambda c: (torch.ones(c, device=dev), torch.zeros(c, device=dev))
+coef_a, mi_a = be.bn_finalize(rows, be.bn_stats(xa), *one(64), 1e-5)
+coef_b, mi_b = be.bn_finalize(rows, be.bn_stats(xb), *one(64), 1e-5)
+y, ys = be.lin_forward_2src(xa, coef_a, 0.1, xb, coef_b, 0.1, w)
+out_coef, out_mi = be.bn_finalize(rows, ys, *one(128), 1e-5)
+gz = torch.randn(rows, 128, device=dev, generator=g) * 0.1
+e_add = torch.randn(rows, 64, device=dev, generator=g) * 0.1
+ods = be.bn_act_backward_stats(gz, y, out_mi, *one(128), 0.1)
+run = lambda: be.lin_backward_2src(gz, y, out_coef, out_mi, ods, xa, coef_a, mi_a, 0.1, xb, coef_b, mi_b, 0.1, e_add, w)
+for _ in range(60):
+    run()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    run()
+e1.record(); e1.synchronize()
+t = e0.elapsed_time(e1) / 20 * 1e3
+by = rows * (2 * 128 + 2 * 128 + 64) * 4
+print(f"64+64 -> 128: {t:7.1f} us per backward (incl. the slab reduction)  {by / t / 1e3:7.1f} GB/s on one read of gz, y, xa, xb, e_add + one write; "
+      f"{4 * rows * 128 * 128 / t / 1e6:6.1f} TFLOP/s", flush=True)
