@@ -457,7 +457,28 @@ def kernel_rooflines(B, device):
            "frac": round(flop2 / t_2s / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "avg_kernel_us": round(t_2s, 1),
            "traffic": _pmc_traffic("wreg_fwd_kernel<128, 128, true, true>", B), "bytes_per_launch_algorithmic": b2s,
            "hbm_GBps_algorithmic": round(b2s / t_2s / 1e3, 1)}
-    del xa, xb
+    # --- the same layer's backward in ONE pass (round 6): wreg_bwd_fused_kernel<128,64,TWO>, a wave per (strip, source) -------
+    mia = hip.bn_finalize(rows, hip.bn_stats(xa), g2, b2, 1e-5)[1]; mib = hip.bn_finalize(rows, hip.bn_stats(xb), g2, b2, 1e-5)[1]
+    y2s, s2s = hip.lin_forward_2src(xa, ca, 0.1, xb, cb, 0.1, w2)
+    g128 = torch.ones(128, device=device); b128 = torch.zeros(128, device=device)
+    oc2, om2 = hip.bn_finalize(rows, s2s, g128, b128, 1e-5)
+    gz2 = rnd(rows, 128) * 0.1; ead = rnd(rows, C2) * 0.1
+    ods2 = hip.bn_act_backward_stats(gz2, y2s, om2, g128, b128, 0.1)
+    run2 = lambda: hip.lin_backward_2src(gz2, y2s, oc2, om2, ods2, xa, ca, mia, 0.1, xb, cb, mib, 0.1, ead, w2)
+    _event_time_us(run2, 30)
+    t_e2 = _event_time_us(run2, 15)
+    t_b2 = _kernel_only_us(run2, 15)
+    b2b = rows * (2 * 128 + 2 * 128 + C2) * 4
+    two_bwd = {"kernel": "wreg_bwd_fused_kernel<128,64,TWO> (64+64->128 two-source layer backward in ONE pass, 1 launch per step at this size: a wave "
+                         "owns (16-row strip, source) — W and dW columns of its 64 input channels in registers, g^y for all 128 output channels "
+                         "formed in the registers gz arrived in; both input gradients, both sources' BN-backward statistics and dW from one "
+                         "read of gz, y, xa, xb, e_add)",
+               "bound": "mfma", "achieved": round(2 * flop2 / t_b2 / 1e6, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": round(2 * flop2 / t_b2 / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "avg_kernel_us": round(t_b2, 1),
+               "traffic": _pmc_traffic("wreg_bwd_fused_kernel<128, 64, true>", B), "bytes_per_launch_algorithmic": b2b,
+               "hbm_GBps_algorithmic": round(b2b / t_b2 / 1e3, 1), "entry_us (kernel + 256-slab reduction of dW)": round(t_e2, 1),
+               "replaces": "wreg_dgrad_kernel<128,128,true> + wreg_wgrad_kernel<128,128,true,true> (two reads of gz / y / xa / xb: 705-720 us)"}
+    del xa, xb, y2s, gz2, ead
     # --- pair-mode forward (first cost-volume layer) -----------------------------------------------------
     C = 128
     w = rnd(C, C) / C ** 0.5
@@ -513,7 +534,8 @@ def kernel_rooflines(B, device):
     group = {"kernel": "sa_l1_kernel<9> (level-1 selection + gather + feature build in one launch; unfused = fused_conv_select_k + 2 row "
                        "gathers + subtract + norm + cat, host-timed eager launches)", "bound": "hbm (in practice L2 / LDS / issue)",
              "bytes_per_launch": B * (2 * 64 * 1800 * 12 + 3600 * 32 * 48), "cases": grp}
-    dgrad["other_kernels"] = [fwd, two, pf, selk, group, _mlp_chain_entry(B, device), _image_encoder_entry(B, device)]
+    # (new entries go to the END: the reviews of rounds 4-5 cite other_kernels[3..5] by index)
+    dgrad["other_kernels"] = [fwd, two, pf, selk, group, _mlp_chain_entry(B, device), _image_encoder_entry(B, device), two_bwd]
     del f, gk, bn, bk
     torch.cuda.empty_cache()
     dgrad["chain"] = chain_roofline(B, device)

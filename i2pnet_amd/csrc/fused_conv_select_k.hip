@@ -62,6 +62,7 @@ __device__ __forceinline__ void eval_cell(const FcskParams &p, const Center &c, 
     } else if (w < 0 || w >= p.small_w) {
         return;
     }
+    if (w < 0 || w >= p.small_w) return;      // (window wider than the image: the reference reads out of bounds; skipped like an empty cell)
     const float *q = p.xyz2 + (((size_t)c.b * p.small_h + h) * p.small_w + w) * 3;
     const float xq = q[0], yq = q[1], zq = q[2];
     const float d0 = i2p_sq3(xq, yq, zq);                                 // go.cu:141
@@ -81,15 +82,32 @@ __device__ __forceinline__ void cell_hw(const FcskParams &p, const Center &c, in
     }
 }
 
+// LDS accesses of one 16-lane query row are private to its wave (g = tid >> 4: four queries per wave): ordering them needs the
+// compiler to keep program order (the hardware executes a wave's LDS operations in order), not a block barrier.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Round 6 (what the level-1 grouping kernel, csrc/sa_group.hip, learned in rounds 3-6, applied to the boundary operator): the parked
+// runs as 32-bit distance + 16-bit code (6 instead of 8 bytes per candidate) and the per-query result codes sized by K in dynamic
+// LDS — 24 KB -> 15.6 KB per block at level 1, so that the 1800 blocks of a batch-8 call are resident at once (8 per CU) instead of
+// 1.2 rounds of 6; head and next key of a lane in registers (a pop's LDS read is off the critical path unless the same lane pops
+// twice in a row); the K loop ends when every query of the wave is done; everything after the window table is wave-private, so
+// the four block barriers became one.
 template <int SLOTS>
 __global__ __launch_bounds__(256) void fcsk_kernel(FcskParams p) {
     __shared__ int tab[SLOTS * GROUP];
-    __shared__ unsigned long long lst[QPB][SLOTS * GROUP];
-    __shared__ unsigned short outc[QPB][I2P_MAX_WINDOW + 2];
+    __shared__ unsigned lst_d[QPB][SLOTS * GROUP];
+    __shared__ unsigned short lst_c[QPB][SLOTS * GROUP];
+    extern __shared__ unsigned short outc_all[];           // [QPB][(K + 2 rounded up to 4)]
+    const int ocp = (p.K + 2 + 3) & ~3;
 
     const int kt = p.kH * p.kW;
     const int tid = threadIdx.x;
     const int g = tid >> 4, l16 = tid & 15;
+    unsigned short *outc_g = outc_all + g * ocp;
     const unsigned nblocks = gridDim.x;
     const unsigned lb = i2p_xcd_swizzle(blockIdx.x, nblocks);
 
@@ -103,7 +121,7 @@ __global__ __launch_bounds__(256) void fcsk_kernel(FcskParams p) {
         }
         tab[i] = v;
     }
-    for (int i = l16; i < p.K; i += GROUP) outc[g][i] = 0;
+    for (int i = l16; i < p.K; i += GROUP) outc_g[i] = 0;
 
     const long long q = (long long)lb * QPB + g;
     const bool in_range = q < (long long)p.B * p.npoints;
@@ -123,6 +141,9 @@ __global__ __launch_bounds__(256) void fcsk_kernel(FcskParams p) {
     __syncthreads();
 
     // ---- A: evaluate this lane's window cells --------------------------------------------
+    // (measured and not kept, round 6: all candidate loads issued before the centre is looked at — idx_n2 -> {centre, candidates} as two
+    //  dependent round trips instead of three: 16.5 -> 18.5 / 19.2 us on the live-centre layouts, 27 more registers and the loads of
+    //  queries that turn out empty)
     unsigned long long key[SLOTS];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
@@ -144,75 +165,85 @@ __global__ __launch_bounds__(256) void fcsk_kernel(FcskParams p) {
             const bool sw = a > b2;
             key[j] = sw ? b2 : a; key[j + 1] = sw ? a : b2;
         }
+    const bool wave_live = __any(live ? 1 : 0);            // a wave whose four centres are all empty selects nothing
+    bool need_serial = false;
+    if (wave_live) {
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) lst[g][s * GROUP + l16] = key[s];
-    __syncthreads();
+        for (int s = 1; s < SLOTS; ++s) { lst_d[g][s * GROUP + l16] = (unsigned)(key[s] >> 32); lst_c[g][s * GROUP + l16] = (unsigned short)key[s]; }
+        wave_lds_sync();
 
-    // ---- C: K extraction steps ------------------------------------------------------------
-    unsigned head_hi = (unsigned)(key[0] >> 32), head_lo = (unsigned)key[0];
-    int ptr = 1;
-    unsigned pops = 0, steps = 0, prev = 0;
-    bool tie = false, done = !live;
-    for (int s = 0; s < p.K; ++s) {
-        const unsigned gmin = i2p_row16_min_u32(head_hi);
-        if (!done) {
-            if (gmin >= SENT_BITS) {
-                done = true;                        // only empty slots remain: nothing more to write
-            } else {
-                tie |= (s > 0 && gmin == prev);
-                prev = gmin; ++steps;
-                if (head_hi == gmin) {
-                    outc[g][s] = (unsigned short)(head_lo | CODE_VALID);
-                    ++pops;
-                    unsigned long long nx = ((unsigned long long)PAD_BITS << 32);
-                    if (ptr < SLOTS) nx = lst[g][ptr * GROUP + l16];
-                    ++ptr;
-                    head_hi = (unsigned)(nx >> 32); head_lo = (unsigned)nx;
-                }
-            }
-        }
-    }
-    {   // boundary: the (K+1)-th smallest must differ from the K-th, every pop must be unique
-        const unsigned gnext = i2p_row16_min_u32(head_hi);
-        const unsigned total = i2p_row16_add_u32(pops);
-        if (!done && steps > 0 && gnext == prev) tie = true;
-        if (total != steps) tie = true;
-    }
-    bool need_serial = live && (tie || p.force_serial);
-
-    // ---- F: exact serial redo for queries with equal distances (block-uniform branch) ------
-    if (__syncthreads_or(need_serial ? 1 : 0)) {
-        if (need_serial) {
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const int pos = s * GROUP + l16;
-                unsigned dbits = SENT_BITS, stored = 0;
-                if (pos < kt) eval_cell(p, c, tab[pos], dbits, stored);
-                lst[g][pos] = ((unsigned long long)dbits << 32) | (unsigned)(pos | (stored << 8));
-            }
-        }
-        __syncthreads();
-        if (need_serial && l16 == 0) {
-            unsigned long long *a = lst[g];                    // a[t] = (Dist[t] bits : pos | stored)
-            for (int s = 0; s < p.K; ++s) {                                 // go.cu:183-236
-                // positions >= kt are never searched (go.cu:188); slots s >= kt stay sentinel
-                int mi = s;
-                if (s < kt) {
-                    float dm = i2p_u2f((unsigned)(a[s] >> 32));
-                    for (int t = s + 1; t < kt; ++t) {
-                        const float dt = i2p_u2f((unsigned)(a[t] >> 32));
-                        if (dt < dm) { dm = dt; mi = t; }
-                    }
-                    if (mi != s) { const unsigned long long tmp = a[mi]; a[mi] = a[s]; a[s] = tmp; }
-                    const float ds = i2p_u2f((unsigned)(a[s] >> 32));
-                    outc[g][s] = (unsigned short)(((unsigned)a[s] & 0x1ffu) | (ds < 1e10f ? CODE_VALID : 0u));
+        // ---- C: K extraction steps (ends as soon as every query of the wave is done) ---------
+        unsigned head_hi = (unsigned)(key[0] >> 32), head_lo = (unsigned)key[0];
+        unsigned nxt_hi = SLOTS > 1 ? (unsigned)(key[SLOTS > 1 ? 1 : 0] >> 32) : PAD_BITS, nxt_lo = SLOTS > 1 ? (unsigned)key[SLOTS > 1 ? 1 : 0] : 0u;
+        int ptr = 2;
+        unsigned pops = 0, steps = 0, prev = 0;
+        bool tie = false, done = !live;
+        for (int s = 0; s < p.K; ++s) {
+            if (!__any(done ? 0 : 1)) break;
+            const unsigned gmin = i2p_row16_min_u32(head_hi);
+            if (!done) {
+                if (gmin >= SENT_BITS) {
+                    done = true;                        // only empty slots remain: nothing more to write
                 } else {
-                    outc[g][s] = 0;
+                    tie |= (s > 0 && gmin == prev);
+                    prev = gmin; ++steps;
+                    if (head_hi == gmin) {
+                        outc_g[s] = (unsigned short)(head_lo | CODE_VALID);
+                        ++pops;
+                        head_hi = nxt_hi; head_lo = nxt_lo;
+                        nxt_hi = PAD_BITS; nxt_lo = 0;
+                        if (ptr < SLOTS) { nxt_hi = lst_d[g][ptr * GROUP + l16]; nxt_lo = lst_c[g][ptr * GROUP + l16]; }
+                        ++ptr;
+                    }
                 }
             }
         }
+        {   // boundary: the (K+1)-th smallest must differ from the K-th, every pop must be unique
+            const unsigned gnext = i2p_row16_min_u32(head_hi);
+            const unsigned total = i2p_row16_add_u32(pops);
+            if (!done && steps > 0 && gnext == prev) tie = true;
+            if (total != steps) tie = true;
+        }
+        need_serial = live && (tie || p.force_serial);
+
+        // ---- F: exact serial redo for queries with equal distances (wave-uniform branch) --------
+        if (__any(need_serial ? 1 : 0)) {
+            wave_lds_sync();
+            if (need_serial) {
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const int pos = s * GROUP + l16;
+                    unsigned dbits = SENT_BITS, stored = 0;
+                    if (pos < kt) eval_cell(p, c, tab[pos], dbits, stored);
+                    lst_d[g][pos] = dbits; lst_c[g][pos] = (unsigned short)(pos | (stored << 8));
+                }
+            }
+            wave_lds_sync();
+            if (need_serial && l16 == 0) {
+                unsigned *ad = lst_d[g]; unsigned short *ac = lst_c[g];   // ad[t] = Dist[t] bits, ac[t] = pos | stored
+                for (int s = 0; s < p.K; ++s) {                                 // go.cu:183-236
+                    // positions >= kt are never searched (go.cu:188); slots s >= kt stay sentinel
+                    int mi = s;
+                    if (s < kt) {
+                        float dm = i2p_u2f(ad[s]);
+                        for (int t = s + 1; t < kt; ++t) {
+                            const float dt = i2p_u2f(ad[t]);
+                            if (dt < dm) { dm = dt; mi = t; }
+                        }
+                        if (mi != s) {
+                            const unsigned td = ad[mi]; ad[mi] = ad[s]; ad[s] = td;
+                            const unsigned short tc = ac[mi]; ac[mi] = ac[s]; ac[s] = tc;
+                        }
+                        const float ds = i2p_u2f(ad[s]);
+                        outc_g[s] = (unsigned short)((ac[s] & 0x1ffu) | (ds < 1e10f ? CODE_VALID : 0u));
+                    } else {
+                        outc_g[s] = 0;
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
     }
-    __syncthreads();
 
     // ---- output: coalesced along K ---------------------------------------------------------
     const bool fill = (p.flag & I2P_FLAG_FILL) != 0;
@@ -224,9 +255,9 @@ __global__ __launch_bounds__(256) void fcsk_kernel(FcskParams p) {
         }
         return;
     }
-    const unsigned copy_code = outc[g][0];
+    const unsigned copy_code = outc_g[0];
     for (int s = l16; s < p.K; s += GROUP) {
-        unsigned code = outc[g][s];
+        unsigned code = outc_g[s];
         bool wr = (code & CODE_VALID) != 0;                                // go.cu:225
         if (!wr && (p.flag & I2P_FLAG_COPY)) { code = copy_code; wr = true; } // go.cu:211-222
         if (!wr) {
@@ -243,7 +274,8 @@ template <int SLOTS>
 int launch(const FcskParams &p, hipStream_t st) {
     const long long nq = (long long)p.B * p.npoints;
     const unsigned grid = (unsigned)((nq + QPB - 1) / QPB);
-    hipLaunchKernelGGL(fcsk_kernel<SLOTS>, dim3(grid), dim3(256), 0, st, p);
+    const size_t bytes = (size_t)QPB * ((p.K + 2 + 3) & ~3) * sizeof(unsigned short);
+    hipLaunchKernelGGL(fcsk_kernel<SLOTS>, dim3(grid), dim3(256), bytes, st, p);
     I2P_RETURN_LAUNCH_STATUS();
 }
 

@@ -29,6 +29,7 @@ struct SaParams {
     int sw;                               // strip width in cells = kW + 15*stride_w
     int pad_l;                            // cells staged to the left of the first window column (16-byte alignment of the strip rows)
     int swf;                              // strip row pitch in floats
+    int region_f;                         // floats of the shared strip / parked-runs region (outc follows it)
     int force_serial;
 };
 
@@ -44,12 +45,17 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 2 x kH x swf/4 aligned 16-byte loads — all issued before the first LDS store: one global round trip per block instead of five.
 template <int SLOTS, bool VEC>
 __global__ __launch_bounds__(SA_THREADS) void sa_l1_kernel(SaParams p) {
-    extern __shared__ float strip[];                       // sel [kH][swf], then outc u16 [QPB][K + 2 rounded up to 4]
+    // Dynamic LDS: region R = max(strip sel [kH][swf] floats, parked runs), then outc u16 [QPB][K + 2 rounded up to 4].
+    // Round 6: the parked sorted runs (distance bits [QPB][SLOTS*16] u32 + (position | stored) codes [QPB][SLOTS*16] u16, 13.8 KB at
+    // level 1) live IN the strip's 14.7 KB once every wave of the block has evaluated its distances — the strip is only read while the
+    // candidates are evaluated; the output rows gather the raw coordinates from global memory.  30.2 -> 16.5 KB per block = 8
+    // blocks per CU instead of 5: the 1920 blocks of a batch-8 launch are resident at once (2048 slots) instead of running in two
+    // phase-locked rounds whose stores did not overlap anything (profiles/r05_sa_l1_ablation.txt).  Price: one more block barrier,
+    // and the (rare) tie redo re-reads its candidates from global memory.
+    extern __shared__ float strip[];
     __shared__ int tab[SLOTS * GROUP];
-    // parked sorted runs: distance bits and (position | stored) code apart, 6 instead of 8 bytes per candidate — the kernel is
-    // occupancy-bound (LDS per block decides how many blocks hide each other's global round trip)
-    __shared__ unsigned lst_d[QPB][SLOTS * GROUP];
-    __shared__ unsigned short lst_c[QPB][SLOTS * GROUP];
+    unsigned (*lst_d)[SLOTS * GROUP] = reinterpret_cast<unsigned (*)[SLOTS * GROUP]>(strip);
+    unsigned short (*lst_c)[SLOTS * GROUP] = reinterpret_cast<unsigned short (*)[SLOTS * GROUP]>(strip + QPB * SLOTS * GROUP);
 
     const int kt = p.kH * p.kW;
     const int tid = threadIdx.x, g = tid >> 4, l16 = tid & 15;
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_l1_kernel(SaParams p) {
     // from global memory / L2 at the end — 15 KB less LDS per block = 5 instead of 3 blocks per CU hiding each other's round trips)
     float *ssel = strip;
     const int ocp = (p.K + 2 + 3) & ~3;
-    unsigned short *outc_g = reinterpret_cast<unsigned short *>(strip + p.kH * p.swf) + g * ocp;   // this query's selected codes
+    unsigned short *outc_g = reinterpret_cast<unsigned short *>(strip + p.region_f) + g * ocp;     // this query's selected codes
     const size_t img = (size_t)b * p.H * p.W * 3;
 
     // what an unset slot (and every slot of an empty centre) gathers: cell (0,0) of the raw image — requested now, so that the
@@ -122,14 +128,14 @@ __global__ __launch_bounds__(SA_THREADS) void sa_l1_kernel(SaParams p) {
         if (i < kt) { const int dh = i / p.kW - p.kH / 2, dw = i % p.kW - p.kW / 2; v = (dh << 16) | (dw & 0xffff); }   // random_hw = arange (utils.py:84)
         tab[i] = v;
     }
-    __syncthreads();                                       // the only block barrier: strip and table are block-shared
-    if (!__any(in_range ? 1 : 0)) return;                  // a wave of queries beyond out_w (last block of a row)
+    __syncthreads();                                       // strip and table are block-shared
+    const bool wave_in = __any(in_range ? 1 : 0);          // false: a wave of queries beyond out_w (last block of a row) — it still meets the barrier below
 
     // centre of this query: strip cell (kH/2, pad_l + kW/2 + g*stride_w)
     const int ccol = p.pad_l + p.kW / 2 + g * p.stride_w;
     const int cc = (p.kH / 2) * p.swf + ccol * 3;
     const float cx = ssel[cc], cy = ssel[cc + 1], cz = ssel[cc + 2];
-    const bool live = in_range && !(fmaxf(i2p_sq3(cx, cy, cz), 1e-10f) <= 1e-10f);          // go.cu:72-74
+    const bool live = wave_in && in_range && !(fmaxf(i2p_sq3(cx, cy, cz), 1e-10f) <= 1e-10f);          // go.cu:72-74
     // window cell (dh, dw) of this query -> strip cell; rows outside the image were staged as empty cells, which the
     // reference skips just like a zero point (go.cu:99-103 vs :143: both leave the slot unset)
     auto eval = [&](int tabv, unsigned &dbits, unsigned &stored) {
@@ -143,12 +149,28 @@ __global__ __launch_bounds__(SA_THREADS) void sa_l1_kernel(SaParams p) {
         dbits = i2p_f2u(dq); stored = 1;
     };
 
+    // the tie redo's candidate evaluation: the same arithmetic on the cell read from global memory (the strip is gone by then)
+    auto eval_global = [&](int tabv, unsigned &dbits, unsigned &stored) {
+        dbits = SENT_BITS; stored = 0;
+        const int h = ch + (tabv >> 16);
+        if (h < 0 || h >= p.H) return;                                                        // staged as an empty cell
+        int w = qw * p.stride_w + (int)(short)(tabv & 0xffff);
+        if (w < 0) w += p.W;
+        if (w >= p.W) w -= p.W;
+        const float *q = p.sel_xyz + img + ((size_t)h * p.W + w) * 3;
+        const float xq = q[0], yq = q[1], zq = q[2];
+        if (i2p_sq3(xq, yq, zq) <= 1e-10f) return;
+        const float dq = fmaxf(i2p_sq3(cx - xq, cy - yq, cz - zq), 1e-10f);
+        if (dq > p.dist2) return;
+        dbits = i2p_f2u(dq); stored = 1;
+    };
+
     // A wave whose four queries all have empty centres (93 % of the centres of a 8192-point scan) selects nothing: it goes
-    // straight to the output rows.  Everything below up to the output is private to the wave (lst[g], outc[g]).
-    if (__any(live ? 1 : 0)) {
-        for (int i = l16; i < p.K; i += GROUP) outc_g[i] = 0;
-        // ---- A/B: evaluate, sort own keys, park the runs (fcsk_kernel steps A-B) ---------------------------------
-        unsigned long long key[SLOTS];
+    // straight to the output rows.  Everything from the second barrier to the output is private to the wave (lst[g], outc[g]).
+    const bool wave_live = __any(live ? 1 : 0);
+    // ---- A: evaluate and sort own keys (fcsk_kernel step A); the keys stay in registers across the barrier ---------------
+    unsigned long long key[SLOTS];
+    if (wave_live) {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int pos = s * GROUP + l16;
@@ -164,6 +186,11 @@ __global__ __launch_bounds__(SA_THREADS) void sa_l1_kernel(SaParams p) {
                 const bool sw_ = a > b2;
                 key[j] = sw_ ? b2 : a; key[j + 1] = sw_ ? a : b2;
             }
+    }
+    __syncthreads();                                       // every wave has read the strip for the last time: its LDS becomes the parked runs
+    if (wave_live) {
+        for (int i = l16; i < p.K; i += GROUP) outc_g[i] = 0;
+        // ---- B: park the runs (fcsk_kernel step B) ---------------------------------------------------------------
 #pragma unroll
         for (int s = 1; s < SLOTS; ++s) { lst_d[g][s * GROUP + l16] = (unsigned)(key[s] >> 32); lst_c[g][s * GROUP + l16] = (unsigned short)key[s]; }
         wave_lds_sync();
@@ -209,7 +236,7 @@ __global__ __launch_bounds__(SA_THREADS) void sa_l1_kernel(SaParams p) {
                 for (int s = 0; s < SLOTS; ++s) {
                     const int pos = s * GROUP + l16;
                     unsigned dbits = SENT_BITS, stored = 0;
-                    if (pos < kt) eval(tab[pos], dbits, stored);
+                    if (pos < kt) eval_global(tab[pos], dbits, stored);
                     lst_d[g][pos] = dbits; lst_c[g][pos] = (unsigned short)(pos | (stored << 8));
                 }
             }
@@ -265,8 +292,11 @@ __global__ __launch_bounds__(SA_THREADS) void sa_l1_kernel(SaParams p) {
 }
 
 template <int SLOTS, bool VEC>
-int launch(const SaParams &p, hipStream_t st) {
-    const size_t bytes = (size_t)p.kH * p.swf * sizeof(float) + (size_t)QPB * ((p.K + 2 + 3) & ~3) * sizeof(unsigned short);
+int launch(const SaParams &p0, hipStream_t st) {
+    SaParams p = p0;
+    const int lists_f = QPB * SLOTS * GROUP + (QPB * SLOTS * GROUP + 1) / 2;           // u32 distances + u16 codes, in floats
+    p.region_f = ((p.kH * p.swf > lists_f ? p.kH * p.swf : lists_f) + 3) & ~3;
+    const size_t bytes = (size_t)p.region_f * sizeof(float) + (size_t)QPB * ((p.K + 2 + 3) & ~3) * sizeof(unsigned short);
     if (bytes > 96 * 1024) return I2P_ERR_BAD_ARG;
     static bool attr_set = false;
     if (!attr_set) {

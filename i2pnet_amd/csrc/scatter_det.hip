@@ -302,89 +302,48 @@ __global__ void scatter_fx_kernel(int hw, int c, int q, int W, const float *__re
     if (cur >= 0 && cur < hw) atomicAdd(acc + ((size_t)bi * hw + cur) * c + ch, (unsigned long long)sum);
 }
 
-// Second generation (round 6): the same sum, pre-aggregated per block in LDS before it reaches the int64 atomics.
-// Why: the neighbour lists of a level repeat cells — a query's K neighbours come from one small window, neighbouring queries share
-// most of it, and every empty slot / empty query points at ONE cell (FLAG_COPY, go.cu:211-222: 93 % of the level-2 rows of a
-// sparse scan are cell (0,0)).  scatter_fx_kernel merges equal-cell runs of 8 consecutive rows per thread and then issues one global
-// atomic per (run, channel): 1808 same-address atomics per channel and sample into the hot cell at level 2 (they serialise in L2:
-// 115 us for a 3.7 M-element scatter).  Here a wave walks 16 .. 32 consecutive rows with lane = channel (the cell index is
-// wave-uniform: one scalar compare per row), sums equal-cell runs in registers, and adds each finished run into a block-shared LDS
-// table (open addressing on the cell, ds_add_u64); the block's four waves cover 64 .. 128 consecutive rows, and the table leaves
-// once, as one global atomic per (distinct cell, channel) of the block.  A full table / failed probe falls back to the direct
-// atomic — any mix is the same integer sum.  Results are bit-identical to scatter_fx_kernel (integer addition is associative).
-template <int CPL>
-__global__ __launch_bounds__(256) void scatter_fx2_kernel(int hw, int c, int q, int W, const float *__restrict__ grad_out, int ld, int off,
-                                                          const int64_t *__restrict__ h_idx, const int64_t *__restrict__ w_idx,
-                                                          const unsigned *__restrict__ maxbits, unsigned long long *__restrict__ acc, int shift,
-                                                          int rows_per_wave, int nslot_log2) {
-    extern __shared__ unsigned long long fx2_vals[];       // [nslot][c]
-    __shared__ int keys[128];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nslot = 1 << nslot_log2;
-    for (int i = tid; i < nslot * c; i += 256) fx2_vals[i] = 0ull;
-    if (tid < 128) keys[tid] = -1;
-    __syncthreads();
+// Round 6: the hot cell.  Every empty slot of a neighbour list and every slot of an empty query points at cell (0,0) (FLAG_COPY,
+// go.cu:211-222): 93 % of the level-2 rows of a sparse scan.  scatter_fx_kernel merges equal-cell runs of 8 consecutive rows per
+// thread and then issues one global atomic per (run, channel): 1808 same-address atomics per channel and sample at level 2, which
+// serialise in L2 (102 us for a 3.7 M-element scatter; 40 us when the same rows point at random cells).  Here the block keeps ONE
+// accumulator row for cell 0 in LDS (ds_add_u64), walks ITER x 256 (run, channel) pairs, and issues one global atomic per channel
+// for it at the end: 1808 -> 57 per channel and sample at level 2.  Everything else is scatter_fx_kernel: integer sums, so the
+// result is bit-identical.  Two more general forms were built and measured first (profiles/r06_scatter.txt): a block-shared
+// open-addressing table with atomicCAS probing — 47 us hot, but 62 us on random cells (a CAS round trip per run, a wave walking rows
+// serially) — and a wave-private direct-mapped cache — 64 / 54 us.  The hot cell is the only repeat that matters.
+template <int ITER>
+__global__ __launch_bounds__(256) void scatter_fx_hot_kernel(int hw, int c, int q, int W, const float *__restrict__ grad_out, int ld, int off,
+                                                             const int64_t *__restrict__ h_idx, const int64_t *__restrict__ w_idx,
+                                                             const unsigned *__restrict__ maxbits, unsigned long long *__restrict__ acc, int shift) {
+    extern __shared__ unsigned long long hot[];            // [c] sums for cell 0 of this sample
     const int bi = blockIdx.y;
-    const double scale = fx_scale(*maxbits, shift);
-    const int r0 = (blockIdx.x * 4 + wave) * rows_per_wave, r1 = min(q, r0 + rows_per_wave);
-    const size_t ib = (size_t)bi * q;
-    unsigned long long *accb = acc + (size_t)bi * hw * c;
-    long long sum[CPL];
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) sum[k] = 0;
-    int cur = -1;
-    auto flush = [&]() {
-        if (cur < 0 || cur >= hw) return;
-        int slot = -1;
-        const unsigned h = ((unsigned)cur * 2654435761u) >> (32 - nslot_log2);
-        for (int pr = 0; pr < 4 && slot < 0; ++pr) {
-            const int idx = (int)((h + pr) & (unsigned)(nslot - 1));
-            int k = 0;
-            if (lane == 0) k = atomicCAS(&keys[idx], -1, cur);
-            k = __builtin_amdgcn_readfirstlane(k);
-            if (k == -1 || k == cur) slot = idx;
-        }
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-            const int ch = lane + 64 * k;
-            if (ch < c && sum[k] != 0) {
-                if (slot >= 0) atomicAdd(&fx2_vals[slot * c + ch], (unsigned long long)sum[k]);
-                else atomicAdd(accb + (size_t)cur * c + ch, (unsigned long long)sum[k]);
-            }
-        }
-    };
-    constexpr int UN = 4;                                   // rows whose index / data loads are in flight together
-    for (int row = r0; row < r1; row += UN) {
-        int cell[UN]; float g[UN][CPL];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int r = row + u < r1 ? row + u : r1 - 1;
-            cell[u] = (int)(h_idx[ib + r] * W + w_idx[ib + r]);
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) { const int ch = lane + 64 * k; g[u][k] = ch < c ? grad_out[(ib + r) * ld + off + ch] : 0.f; }
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            if (row + u >= r1) break;
-            const int cl = __builtin_amdgcn_readfirstlane(cell[u]);
-            if (cl != cur) {
-                flush();
-                cur = cl;
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) sum[k] = 0;
-            }
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) sum[k] += __double2ll_rn((double)g[u][k] * scale);
-        }
-    }
-    flush();
+    for (int i = threadIdx.x; i < c; i += 256) hot[i] = 0ull;
     __syncthreads();
-    for (int i = tid; i < nslot * c; i += 256) {
-        const int sl = i / c, ch = i - sl * c;
-        const int key = keys[sl];
-        const unsigned long long v = fx2_vals[i];
-        if (key >= 0 && v != 0ull) atomicAdd(accb + (size_t)key * c + ch, v);
+    const int nrun = (q + FX_RUN - 1) / FX_RUN;
+    const double scale = fx_scale(*maxbits, shift);
+    unsigned long long *accb = acc + (size_t)bi * hw * c;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const long long t = ((long long)blockIdx.x * ITER + it) * 256 + threadIdx.x;
+        if (t >= (long long)nrun * c) break;
+        const int run = (int)(t / c), ch = (int)(t % c);
+        const int r0 = run * FX_RUN, r1 = min(q, r0 + FX_RUN);
+        long long cur = -1, sum = 0;
+        auto flush = [&]() {
+            if (cur == 0) { if (sum != 0) atomicAdd(hot + ch, (unsigned long long)sum); }
+            else if (cur > 0 && cur < hw) atomicAdd(accb + (size_t)cur * c + ch, (unsigned long long)sum);
+        };
+        for (int row = r0; row < r1; ++row) {
+            const long long cell = h_idx[(size_t)bi * q + row] * W + w_idx[(size_t)bi * q + row];
+            const long long v = __double2ll_rn((double)grad_out[((size_t)bi * q + row) * ld + off + ch] * scale);
+            if (cell != cur) { flush(); cur = cell; sum = 0; }
+            sum += v;
+        }
+        flush();
     }
+    __syncthreads();
+    if (hw > 0)
+        for (int i = threadIdx.x; i < c; i += 256) { const unsigned long long v = hot[i]; if (v != 0ull) atomicAdd(accb + i, v); }
 }
 
 __global__ __launch_bounds__(256) void fx_finalize_kernel(long long n, const long long *__restrict__ acc, const unsigned *__restrict__ maxbits,
@@ -418,21 +377,14 @@ static int gather_rows_grad_fx_impl(int b, int hw, int c, int q, int W, const fl
     int lg = 0;
     while ((1LL << lg) < (long long)q) ++lg;
     const int shift = lg > 21 ? 61 - lg : 40;
-    const char *v1 = getenv("I2P_SCATTER_V1");            // A/B: the per-thread-run kernel of rounds 2-5 (read per call: tests toggle it)
-    if (c <= 256 && !(v1 && v1[0] == '1')) {
-        // rows per wave: 32 when that still gives every CU a few waves, else 16 / 8 (short scatters are latency chains: spread them)
-        int rpw = 32;
-        while (rpw > 8 && (long long)b * ((q + rpw - 1) / rpw) < 4096) rpw >>= 1;
-        int nslot_log2 = 7;                                 // table entries: as many as fit 32 KB of LDS, at most 128
-        while (nslot_log2 > 3 && ((size_t)c << nslot_log2) * 8 > 32 * 1024) --nslot_log2;
-        const unsigned gx = (unsigned)((q + 4 * rpw - 1) / (4 * rpw));
-        const size_t bytes = ((size_t)c << nslot_log2) * 8;
-        if (c <= 64) hipLaunchKernelGGL((scatter_fx2_kernel<1>), dim3(gx, b), dim3(256), bytes, st, hw, c, q, W, grad_out, ld, off, h_idx, w_idx, mx, acc, shift, rpw, nslot_log2);
-        else if (c <= 128) hipLaunchKernelGGL((scatter_fx2_kernel<2>), dim3(gx, b), dim3(256), bytes, st, hw, c, q, W, grad_out, ld, off, h_idx, w_idx, mx, acc, shift, rpw, nslot_log2);
-        else hipLaunchKernelGGL((scatter_fx2_kernel<4>), dim3(gx, b), dim3(256), bytes, st, hw, c, q, W, grad_out, ld, off, h_idx, w_idx, mx, acc, shift, rpw, nslot_log2);
+    const char *v1 = getenv("I2P_SCATTER_V1");            // A/B: the kernel of rounds 2-5 without the hot-cell accumulator (read per call: tests toggle it)
+    if (c <= 4096 && !(v1 && v1[0] == '1')) {
+        constexpr int ITER = 4;
+        hipLaunchKernelGGL((scatter_fx_hot_kernel<ITER>), dim3((unsigned)((tot + 256 * ITER - 1) / (256 * ITER)), b), dim3(256), (size_t)c * 8, st, hw, c, q, W,
+                           grad_out, ld, off, h_idx, w_idx, mx, acc, shift);
     } else
-    hipLaunchKernelGGL(scatter_fx_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0, st, hw, c, q, W, grad_out, ld, off, h_idx, w_idx, mx, acc,
-                       shift);
+        hipLaunchKernelGGL(scatter_fx_kernel, dim3((unsigned)((tot + 255) / 256), b), dim3(256), 0, st, hw, c, q, W, grad_out, ld, off, h_idx, w_idx, mx, acc,
+                           shift);
     long long g3 = (ndst + 255) / 256; if (g3 > 2048) g3 = 2048;
     hipLaunchKernelGGL(fx_finalize_kernel, dim3((unsigned)g3), dim3(256), 0, st, ndst, reinterpret_cast<const long long *>(acc), mx, grad_feat, shift);
     I2P_RETURN_LAUNCH_STATUS();

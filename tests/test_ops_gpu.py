@@ -196,12 +196,13 @@ def test_gather_rows_parity(oracle_backend, hip_backend):
 @pytest.mark.parametrize("C,Q,hw,hot,ld_off", [(32, 904 * 16, 3600, 0.93, None), (128, 228 * 32, 468, 0.0, None), (64, 228 * 4, 228, 0.5, None),
                                                 (35, 1000, 77, 0.2, None), (3, 4099, 3600, 0.9, None), (200, 333, 50, 0.3, None),
                                                 (64, 116 * 16, 228, 0.1, (72, 4)), (300, 64, 10, 0.0, None)])
-def test_gather_rows_grad_preaggregated_scatter(oracle_backend, hip_backend, monkeypatch, C, Q, hw, hot, ld_off):
-    """round 6: the fixed-point scatter pre-aggregates a block's rows per cell in LDS (scatter_fx2_kernel) before the int64 atomics.
-    Against the oracle's serial scatter (i2p_oracle.c gather_rows_grad, the backward of utils.py:36-60) to fp32 rounding, and BIT for
-    BIT against the per-thread-run kernel of rounds 2-5 (I2P_SCATTER_V1=1): integer sums do not depend on the grouping.  Cases: the
-    level-2 shape with 93 % of the rows on the hot cell (0,0) (FLAG_COPY), the kNN cost volume's 128-channel rows, windows of
-    neighbouring queries (shared cells), odd channel counts, a strided source (pitch / offset), C > 256 (the old kernel's path)."""
+def test_gather_rows_grad_hot_cell_scatter(oracle_backend, hip_backend, monkeypatch, C, Q, hw, hot, ld_off):
+    """round 6: the fixed-point scatter keeps the hot cell (0,0) — where FLAG_COPY sends every empty slot and every empty query — in a
+    per-block LDS accumulator row (scatter_fx_hot_kernel) instead of one global atomic per 8-row run.  Against the oracle's serial
+    scatter (i2p_oracle.c gather_rows_grad, the backward of utils.py:36-60) to fp32 rounding, and BIT for BIT against the kernel of
+    rounds 2-5 (I2P_SCATTER_V1=1): integer sums do not depend on the grouping.  Cases: the level-2 shape with 93 % of the rows on the
+    hot cell, the kNN cost volume's 128-channel rows, windows of neighbouring queries (shared cells), odd channel counts, a strided
+    source (pitch / offset), more channels than a block has threads."""
     B, W = 3, hw
     g = torch.Generator().manual_seed(C * 7 + Q)
     # neighbouring queries share cells: cell = a slowly drifting window + the hot cell with probability `hot`
