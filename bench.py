@@ -497,8 +497,10 @@ def kernel_rooflines(B, device):
     sel = torch.zeros(3, B, 3600, 32, 1, dtype=torch.long, device=device)
     mask = torch.zeros(B, 3600, 32, 1, device=device)
     unused = torch.zeros(1, device=device)
-    t_sel = _event_time_us(lambda: hip.fused_conv_select_k(img, img, idx, rhw, 64, 1800, 3600, 9, 15, 32, 3, 0.75, 1, 1,
-                                                           sel[0], sel[1], sel[2], unused, unused, mask, 64, 1800), 50)
+    run_sel = lambda: hip.fused_conv_select_k(img, img, idx, rhw, 64, 1800, 3600, 9, 15, 32, 3, 0.75, 1, 1,
+                                              sel[0], sel[1], sel[2], unused, unused, mask, 64, 1800)
+    _event_time_us(run_sel, 200)                                   # (clocks ramp for ~50 ms after idle: tools/time_fcsk.py does the same)
+    t_sel = _event_time_us(run_sel, 100)
     bytes_sel = B * (64 * 1800 * 12 + 3600 * 8 + 3600 * 32 * 28)
     selk = {"kernel": "fcsk_kernel<9> (fused_conv_select_k, level 1, all 3600 queries live)", "bound": "hbm",
             "achieved": round(bytes_sel / t_sel / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -516,7 +518,8 @@ def kernel_rooflines(B, device):
                                  beams=64)
         im, _, _ = hip.project_seq(cloud, [], 64, 1800, 2.0, -24.8)
         occ = float((im != 0).any(-1).float().mean())
-        t_f = _event_time_us(lambda: hip.sa_l1_group(im, im, 16, 225, 4, 8, 9, 15, 32, 0.75), 30)
+        _event_time_us(lambda: hip.sa_l1_group(im, im, 16, 225, 4, 8, 9, 15, 32, 0.75), 200)      # warm clocks, as tools/time_sa_l1.py
+        t_f = _event_time_us(lambda: hip.sa_l1_group(im, im, 16, 225, 4, 8, 9, 15, 32, 0.75), 100)
         feats = {}
         def chain(fused):
             modules.USE_FUSED_GROUP = fused
