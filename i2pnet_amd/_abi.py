@@ -90,6 +90,7 @@ DEVICE_ONLY = {
     "i2p_pose_compose_fwd": ["i", "p", "p", "p", "p", "p"],
     "i2p_pose_compose_bwd": ["i"] + ["p"] * 8,
     "i2p_clip_adam": ["l"] + ["p"] * 8 + ["d", "d"] + ["f"] * 4 + ["p", "p"],
+    "i2p_defer_flush": [],
     "i2p_img_block_fwd": ["i"] * 7 + ["p", "p", "p", "p", "f", "f", "f"] + ["p"] * 6,
     "i2p_img_block_bwd": ["i"] * 7 + ["p"] * 6 + ["f"] + ["p"] * 4,
     "i2p_img_block_pool": ["i"] * 7 + ["p", "p", "p", "p", "f", "f", "f"] + ["p"] * 6,
@@ -132,6 +133,10 @@ HELPERS = {
     "i2p_img_conv_wgrad_rows": ["i", "i", "i"],
     "i2p_chain_resident_blocks": ["i", "l"],
     "i2p_chain_sync_words": [],                                     # returns long long (uint32 words)
+    "i2p_defer_begin": [],
+    "i2p_defer_pause": ["i"],
+    "i2p_defer_pending": [],
+    "i2p_defer_end": [],
     "i2p_ktime_enable": ["i"],
     "i2p_ktime_last_us": [],                                        # returns float (microseconds)
 }
@@ -145,7 +150,7 @@ _CT = {"l": C.c_longlong, "i": C.c_int, "f": C.c_float, "d": C.c_double, "p": C.
 def bind(lib, name, symbol, with_stream):
     """Attach argtypes/restype to `lib.symbol` for table entry `name` and return it."""
     fn = getattr(lib, symbol)
-    kinds = SIGNATURES.get(name) or DEVICE_ONLY.get(name) or HELPERS[name]
+    kinds = SIGNATURES[name] if name in SIGNATURES else DEVICE_ONLY[name] if name in DEVICE_ONLY else HELPERS[name]
     fn.argtypes = [_CT[k] for k in kinds] + ([C.c_void_p] if with_stream else [])
     fn.restype = C.c_longlong if name in LONG_HELPERS else (C.c_float if name in FLOAT_HELPERS else C.c_int)
     return fn

@@ -107,6 +107,9 @@ int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const flo
                    const float *g_omi, long long g_rows, float *bn_out, const float *x, const float *in_coef, float slope_in,
                    const float *xb, const float *in_coef_b, float slope_b, int split, float *dw_partial, unsigned grid, void *stream);
 // input gradient + weight gradient of an HBM-bound wide layer from ONE read of gz / y / x (csrc/mlp_wreg_fused.hip)
+// csrc/deferred.hip: record a weight-gradient slab reduction instead of launching it (true = recorded).  kind 0: the 16 x 16 float4 shape
+// (n = float4 columns), kind 1: reduce_partials_bf16's 32 x 8 shape (n = floats)
+bool i2p_defer_reduce(int kind, int nparts, int n, const void *parts, void *out);
 bool i2p_wreg_bwd_fused2_ok(long long rows, int k, int c, int split);
 int i2p_wreg_bwd_fused2(long long rows, const float *gz, const float *y2, const double *g_dsums, const float *g_oc, const float *g_omi,
                         long long g_rows, const float *w, float *gz_in_a, const float *xa, const float *coef_a, const float *mi_a,

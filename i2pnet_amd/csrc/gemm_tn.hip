@@ -155,10 +155,11 @@ extern "C" int i2p_gemm_tn(long long rows, int m, int n, const float *a, int lda
     if (va && vb) GT_LAUNCH(true, true); else if (va) GT_LAUNCH(true, false); else if (vb) GT_LAUNCH(false, true); else GT_LAUNCH(false, false);
 #undef GT_LAUNCH
     const int count = m * n;
-    if ((count & 3) == 0 && ((reinterpret_cast<uintptr_t>(scratch) | reinterpret_cast<uintptr_t>(out)) & 15) == 0)
+    if ((count & 3) == 0 && ((reinterpret_cast<uintptr_t>(scratch) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        if (!i2p_defer_reduce(0, g.nchunks, count / 4, scratch, out))
         hipLaunchKernelGGL(gemm_tn_reduce_kernel<float4>, dim3((count / 4 + 15) / 16), dim3(256), 0, st, g.nchunks, count / 4, (const float4 *)scratch,
                            (float4 *)out);
-    else
+    } else
         hipLaunchKernelGGL(gemm_tn_reduce_kernel<float>, dim3((count + 15) / 16), dim3(256), 0, st, g.nchunks, count, (const float *)scratch, out);
     I2P_RETURN_LAUNCH_STATUS();
 }

@@ -1762,6 +1762,7 @@ __global__ __launch_bounds__(256) void reduce_partials_v4_kernel(int nparts, int
 inline void launch_reduce_partials(int nparts, int n, const float *parts, float *out, hipStream_t st) {
     if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(parts) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
         const int n4 = n >> 2;
+        if (i2p_defer_reduce(0, nparts, n4, parts, out)) return;           // summed by i2p_defer_flush with the step's other weight gradients
         hipLaunchKernelGGL(reduce_partials_v4_kernel, dim3((n4 + 15) / 16), dim3(256), 0, st, nparts, n4, reinterpret_cast<const float4 *>(parts),
                            reinterpret_cast<float4 *>(out));
     } else {

@@ -1199,7 +1199,8 @@ int wgrad_launch_t(WgradP &q, float *dw, hipStream_t st, unsigned grid, size_t b
     }
     hipLaunchKernelGGL(wgrad_bf16_kernel<XBF16>, dim3(grid), dim3(WG_THREADS), bytes, st, q);
     const int n = q.cout * q.cin;
-    hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, q.dw_partial, dw);
+    if (!i2p_defer_reduce(1, (int)grid, n, q.dw_partial, dw))
+        hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, q.dw_partial, dw);
     I2P_RETURN_LAUNCH_STATUS();
 }
 
@@ -1232,7 +1233,8 @@ int bwd_impl(long long rows, int cin, int cout, const bf16_t *gz, const bf16_t *
                                           reinterpret_cast<bf16_t *>(gz_in), in_dsums, dw_partial, grid, stream);
         if (rc) return rc;
         const int n = cout * cin;
-        hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
+        if (!i2p_defer_reduce(1, (int)grid, n, dw_partial, dw))
+            hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
         I2P_RETURN_LAUNCH_STATUS();
     }
     if (gz_in && gz_in_bf16 && x_bf16 && two && out_coef && in_coef && two->coef_b && two->mi_b && two->e_add && two->gz_b && in_dsums && two->dsums_b &&
@@ -1243,7 +1245,8 @@ int bwd_impl(long long rows, int cin, int cout, const bf16_t *gz, const bf16_t *
                                            two->dsums_b, dw_partial, grid, stream);
         if (rc) return rc;
         const int n = cout * cin;
-        hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
+        if (!i2p_defer_reduce(1, (int)grid, n, dw_partial, dw))
+            hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
         I2P_RETURN_LAUNCH_STATUS();
     }
     // (the one-pass kernels above form the BN-backward constants in their prologues; the two-kernel forms take them from this launch)
@@ -1277,7 +1280,8 @@ int bwd_impl(long long rows, int cin, int cout, const bf16_t *gz, const bf16_t *
                                            two ? two->slope_b : 1.f);
         if (rc) return rc;
         const int n = cout * cin;
-        hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
+        if (!i2p_defer_reduce(1, (int)grid, n, dw_partial, dw))
+            hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
         I2P_RETURN_LAUNCH_STATUS();
     }
     if (!two && grid == 256 && i2p_small_wgrad_bf16_ok(rows, cin, cout, x_bf16)) {
@@ -1286,7 +1290,8 @@ int bwd_impl(long long rows, int cin, int cout, const bf16_t *gz, const bf16_t *
                                             grid, stream);
         if (rc) return rc;
         const int n = cout * cin;
-        hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
+        if (!i2p_defer_reduce(1, (int)grid, n, dw_partial, dw))
+            hipLaunchKernelGGL(reduce_partials_bf16, dim3((n + 31) / 32), dim3(256), 0, st, (int)grid, n, dw_partial, dw);
         I2P_RETURN_LAUNCH_STATUS();
     }
     WgradP wq{};
@@ -1380,7 +1385,8 @@ extern "C" int i2p_pair_lin_bwd_bf16(int B, int N, int M, int cin, int cout, con
         const int rc = i2p_pair_bwd2_bf16(B, N, M, gz, y, out_dsums, out_coef, out_mi, g_coef, f, g, w, d_f, d_g, d_bias_n, d_bias_k, dw_partial, stream);
         if (rc) return rc;
         const int nel = cout * cin;
-        hipLaunchKernelGGL(reduce_partials_bf16, dim3((nel + 31) / 32), dim3(256), 0, st, (int)g2, nel, dw_partial, dw);
+        if (!i2p_defer_reduce(1, (int)g2, nel, dw_partial, dw))
+            hipLaunchKernelGGL(reduce_partials_bf16, dim3((nel + 31) / 32), dim3(256), 0, st, (int)g2, nel, dw_partial, dw);
         I2P_RETURN_LAUNCH_STATUS();
     }
     PairBwdP p{};
@@ -1406,6 +1412,7 @@ extern "C" int i2p_pair_lin_bwd_bf16(int B, int N, int M, int cin, int cout, con
     }
     hipLaunchKernelGGL(pair_bwd_bf16_kernel, dim3(grid), dim3(PB_THREADS), bytes, st, p);
     const int nel = cout * cin;
-    hipLaunchKernelGGL(reduce_partials_bf16, dim3((nel + 31) / 32), dim3(256), 0, st, (int)grid, nel, dw_partial, dw);
+    if (!i2p_defer_reduce(1, (int)grid, nel, dw_partial, dw))
+        hipLaunchKernelGGL(reduce_partials_bf16, dim3((nel + 31) / 32), dim3(256), 0, st, (int)grid, nel, dw_partial, dw);
     I2P_RETURN_LAUNCH_STATUS();
 }

@@ -368,6 +368,7 @@ int i2p_big_bwd(long long rows, int cin, int cout, const float *gz, const float 
     const int nchunks = (int)((rows + cr - 1) / cr);
     hipLaunchKernelGGL(big_tn_kernel, dim3(tiles_m * q.tiles_n, nchunks), dim3(BG_THREADS), 0, st, q);
     const int count4 = cout * cin / 4;
+    if (!i2p_defer_reduce(0, nchunks, count4, dw_partial, dw))
     hipLaunchKernelGGL(big_reduce_kernel, dim3((count4 + 15) / 16), dim3(256), 0, st, nchunks, count4, reinterpret_cast<const float4 *>(dw_partial),
                        reinterpret_cast<float4 *>(dw));
     I2P_RETURN_LAUNCH_STATUS();

@@ -947,6 +947,7 @@ extern "C" int i2p_chain_bwd(long long rows, int nl, const int *widths, const in
     p.ldp = p.ldq = p.ldp > p.ldq ? p.ldp : p.ldq;
     hipLaunchKernelGGL(chain_bwd_kernel<64>, dim3(grid), dim3(CH_THREADS), bytes, (hipStream_t)stream, p);
     const int n4 = off >> 2;
+    if (!i2p_defer_reduce(0, (int)grid, n4, dw_part, dw))
     hipLaunchKernelGGL(chain_reduce_kernel, dim3((n4 + 15) / 16), dim3(256), 0, (hipStream_t)stream, (int)grid, n4,
                        reinterpret_cast<const float4 *>(dw_part), reinterpret_cast<float4 *>(dw));
     I2P_RETURN_LAUNCH_STATUS();

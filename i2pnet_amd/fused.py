@@ -8,6 +8,8 @@ permute in eager PyTorch (src/projectPN/PPBackbone_center.py:34-46).
 """
 import os
 
+import contextlib
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -57,7 +59,10 @@ class _LinearTN(Function):
         x, w = ctx.saved_tensors
         g = g.contiguous()
         gx = g @ w if ctx.needs_input_grad[0] else None
-        dw = ops.get_backend().gemm_tn(g, x) if ctx.needs_input_grad[1] else None
+        # (w is a column slice of a parameter here — autograd concatenates the slices' gradients during backward, i.e. READS this one at
+        #  once: its slab reduction is not deferred)
+        with ops.defer_paused():
+            dw = ops.get_backend().gemm_tn(g, x) if ctx.needs_input_grad[1] else None
         return gx, dw
 
 
@@ -290,10 +295,12 @@ class _MlpChain(Function):
             W = p[k + 3 * (i - 1)]
             has_in = coefs[i - 1] is not None
             need_gx = has_in or ctx.x_needs_grad
-            gz_in, in_ds, dw = be.lin_backward(gz, y_out, out_coef, out_mi, out_ds, ys[i - 1], coefs[i - 1],
-                                               mis[i - 1], slopes[i - 1] if has_in else 1.0, W.detach(),
-                                               need_gx=need_gx, slope_out=slope_out)
-            if i == 1 and ctx.w0_cin is not None:
+            sliced = i == 1 and ctx.w0_cin is not None       # its weight gradient is read at once (column slice): reduced immediately
+            with (ops.defer_paused() if sliced else contextlib.nullcontext()):
+                gz_in, in_ds, dw = be.lin_backward(gz, y_out, out_coef, out_mi, out_ds, ys[i - 1], coefs[i - 1],
+                                                   mis[i - 1], slopes[i - 1] if has_in else 1.0, W.detach(),
+                                                   need_gx=need_gx, slope_out=slope_out)
+            if sliced:
                 dw = be.after_wgrad(lambda dw=dw: dw[:, :ctx.w0_cin].contiguous())
             grads[k + 3 * (i - 1)] = dw
             # gamma/beta gradients of the BN behind layer i: reduced from out_ds by the launcher (scratch tail)
@@ -337,7 +344,8 @@ class _PairLinear(Function):
     @staticmethod
     def backward(ctx, gy):
         f, g, W = ctx.saved_tensors
-        d_f, d_g, d_bn, d_bk, dw = ops.get_backend().pair_lin_backward(gy.contiguous(), f, g, W)
+        with ops.defer_paused():          # (W = a column slice of the first layer's weight: its gradient is concatenated during backward)
+            d_f, d_g, d_bn, d_bk, dw = ops.get_backend().pair_lin_backward(gy.contiguous(), f, g, W)
         return d_f, d_g, d_bn, d_bk, dw
 
 
@@ -416,7 +424,8 @@ class _CvPiTail(Function):
         gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2)); dg2, db2 = be_.take_bn_grads()
         r1 = _rep_sum(ds1, y1.shape[1], torch.float32)
         # first layer: BN backward of bn1 formed on load inside the pair kernel
-        d_f, d_g, d_bn, d_bk, dW1 = be_.pair_lin_backward(gz1, f, g, W1, y=y1, out_coef=c1, out_mi=m1, out_dsums=ds1)
+        with ops.defer_paused():          # (W1 = a column slice of mlp1_convs[0].weight: its gradient is concatenated during backward)
+            d_f, d_g, d_bn, d_bk, dW1 = be_.pair_lin_backward(gz1, f, g, W1, y=y1, out_coef=c1, out_mi=m1, out_dsums=ds1)
         # position encoding: k-/n-sums of dL/dye in closed form from one pass over gz_e
         d_en, d_ek = be_.pair_bias_bn_backward(B, N, M, gze, enc_n, enc_k, dse, ce, me)
         return (d_f, d_g, d_bn, d_bk, dW1, d_en, d_ek, None, None,
@@ -472,10 +481,12 @@ class _CvKnnTail(Function):
         dg4, db4 = be_.take_bn_grads()
         gz2, ds2, dW3 = be_.lin_backward(gz3, y3, c3, m3, ds3, y2, c2, m2, s2, d(W3)); dg3, db3 = be_.take_bn_grads()
         gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2)); dg2, db2 = be_.take_bn_grads()
-        dx1, _, dW1 = be_.lin_backward(gz1, y1, c1, m1, ds1, x1, None, None, 1.0, W1, need_gx=ctx.need[0]); dg1, db1 = be_.take_bn_grads()
+        with (ops.defer_paused() if W1.shape[1] != ctx.cins[0] else contextlib.nullcontext()):
+            dx1, _, dW1 = be_.lin_backward(gz1, y1, c1, m1, ds1, x1, None, None, 1.0, W1, need_gx=ctx.need[0]); dg1, db1 = be_.take_bn_grads()
         if W1.shape[1] > ctx.cins[0]:
             dW1 = be_.after_wgrad(lambda: dW1[:, :ctx.cins[0]].contiguous())
-        dxe, _, dWe = be_.lin_backward(gze, ye, ce, me, dse, xe, None, None, 1.0, We, need_gx=ctx.need[1]); dge, dbe = be_.take_bn_grads()
+        with (ops.defer_paused() if We.shape[1] != ctx.cins[1] else contextlib.nullcontext()):
+            dxe, _, dWe = be_.lin_backward(gze, ye, ce, me, dse, xe, None, None, 1.0, We, need_gx=ctx.need[1]); dge, dbe = be_.take_bn_grads()
         if We.shape[1] > ctx.cins[1]:
             dWe = be_.after_wgrad(lambda: dWe[:, :ctx.cins[1]].contiguous())
         return (dx1, dxe, dW1, dWe, None, None, None, dg1, db1, dW2, dg2, db2, dW3, dg3, db3, dge, dbe, dW4, dg4, db4, dW5, dg5, db5)

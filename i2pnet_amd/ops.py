@@ -161,6 +161,66 @@ def chain_errors_reset(device=None):
             t.zero_(); h.zero_()
 
 
+# ---- deferred weight-gradient reductions (csrc/deferred.hip) ------------------------------------------------------------------
+# Trainer: defer_begin() before the step's backward, defer_flush() after it (one launch instead of ~43), defer_end() in the finally.
+# While active, every partial-slab buffer a backward allocates is kept alive here until the flush: the caching allocator would
+# otherwise hand its memory to the next kernel of the same step.  I2P_NO_DEFER=1 switches the mechanism off (A/B).
+_DEFER = {"on": False, "keep": [], "dws": [], "paused": 0}
+
+
+def defer_begin():
+    if os.environ.get("I2P_NO_DEFER") == "1" or get_backend().name != "hip":
+        return False
+    _lib.helper("i2p_defer_begin")
+    _DEFER["on"] = True; _DEFER["keep"] = []; _DEFER["dws"] = []; _DEFER["paused"] = 0
+    return True
+
+
+def defer_keep(*tensors, dw=()):
+    """called by the backend's backward entries with their partial / scratch buffers, and with the weight-gradient tensors whose sums
+    were recorded: only their ADDRESSES are noted (a reference held here would make autograd's AccumulateGrad clone the gradient instead
+    of adopting it) — Trainer checks before the flush that each of them became a parameter's `.grad` untouched (`defer_noted`)"""
+    if _DEFER["on"] and not _DEFER["paused"]:
+        _DEFER["keep"].extend(t for t in tensors if t is not None)
+        _DEFER["dws"].extend(int(t.data_ptr()) for t in ((dw,) if isinstance(dw, torch.Tensor) else dw) if t is not None)
+
+
+def defer_noted():
+    return list(_DEFER["dws"])
+
+
+class defer_paused:
+    """`with ops.defer_paused():` around a backward call whose weight gradient is read at once (its reduction is launched immediately)"""
+    def __enter__(self):
+        if _DEFER["on"]:
+            _DEFER["paused"] += 1
+            _lib.helper("i2p_defer_pause", 1)
+
+    def __exit__(self, *exc):
+        if _DEFER["on"]:
+            _DEFER["paused"] = max(0, _DEFER["paused"] - 1)
+            _lib.helper("i2p_defer_pause", 0)
+
+
+def defer_flush():
+    """sum every recorded weight-gradient reduction on the current stream; -> number of reductions flushed"""
+    if not _DEFER["on"]:
+        return 0
+    n = _lib.helper("i2p_defer_pending")
+    if n:
+        _lib.call("i2p_defer_flush", stream=torch.cuda.current_stream().cuda_stream)
+    _DEFER["keep"] = []; _DEFER["dws"] = []
+    return n
+
+
+def defer_end():
+    if _DEFER["on"]:
+        _DEFER["on"] = False; _DEFER["keep"] = []; _DEFER["dws"] = []; _DEFER["paused"] = 0
+        dropped = _lib.helper("i2p_defer_end")
+        if dropped:
+            raise RuntimeError(f"{dropped} deferred weight-gradient reductions were never flushed: those gradients are invalid")
+
+
 def zero_scalar(device, dtype=torch.float32):
     """A permanent read-only 0-d zero on `device` (expand it where a constant zero operand is needed: padding
     channels of a cat, the real part of a pure quaternion) — a fresh `new_zeros(())` is one fill launch each time."""
@@ -326,6 +386,7 @@ class CBackend:
         self._call("i2p_gemm_tn", int(rows), int(m), int(n), self._p(a, _F32, "a"), int(m),
                    self._p(b, _F32, "b"), int(n), self._p(scratch, torch.uint8, "scratch"),
                    self._p(out, _F32, "out"), stream=self._stream())
+        defer_keep(scratch, dw=out)
         return out
 
     def knn_rows(self, xyz, pix_xyz, pts, pix, idx, K, cpad):
@@ -885,6 +946,7 @@ class CBackend:
                        stream=self._stream())
             n = part.numel()
             self.last_bn_grads = (part[n - cout:], part[n - 2 * cout:n - cout]) if out_coef is not None else None
+            defer_keep(part, dw=dw)
             return gz_in, in_dsums, dw
         gz_in = torch.empty(rows, cin, dtype=_F32, device=dev) if need_gx else None
         in_dsums = (zeros(BN_REPLICAS * 2 * cin, torch.float64, dev)
@@ -900,6 +962,7 @@ class CBackend:
                    P(x, _F32, "x"), P(in_coef, _F32, "in_coef"), P(in_mi, _F32, "in_mi"), float(slope_in),
                    P(w, _F32, "w"), P(gz_in, _F32, "gz_in"), P(in_dsums, torch.float64, "in_dsums"),
                    P(part, _F32, "dw_partial"), P(dw, _F32, "dw"), float(slope_out), stream=self._stream())
+        defer_keep(part, dw=dw)
         return gz_in, in_dsums, dw
 
     def after_wgrad(self, fn):
@@ -954,6 +1017,7 @@ class CBackend:
                        o(out_coef), o(out_mi), o(out_dsums, torch.float64), self._p(f, _F32, "f"), self._p(g, _F32, "g"),
                        self._p(w, _F32, "w"), self._p(d_f, _F32, "d_f"), self._p(d_g, _F32, "d_g"), self._p(d_bn, _F32, "d_bn"),
                        self._p(d_bk, _F32, "d_bk"), self._p(part, _F32, "part"), self._p(dw, _F32, "dw"), stream=self._stream())
+            defer_keep(part, dw=dw)
             return d_f, d_g, d_bn, d_bk, dw
         # per-block weight-gradient partials + the slabs of the deterministic pair sums (i2p_pair_lin_bwd_scratch)
         nscr = _lib.helper("i2p_pair_lin_bwd_scratch", int(B), int(N), int(M), int(C), int(Co)) if self.device_type == "cuda" else Co * C
@@ -965,6 +1029,7 @@ class CBackend:
                    self._p(d_f, _F32, "d_f"), self._p(d_g, _F32, "d_g"), self._p(d_bn, _F32, "d_bn"),
                    self._p(d_bk, _F32, "d_bk"), self._p(part, _F32, "part"), self._p(dw, _F32, "dw"),
                    stream=self._stream())
+        defer_keep(part, dw=dw)
         return d_f, d_g, d_bn, d_bk, dw
 
     # ---- cost-volume tail --------------------------------------------------------------------------
@@ -1013,6 +1078,7 @@ class CBackend:
                        P(gz_b, _BF16), P(ds_b, torch.float64), P(part), P(dw), stream=self._stream())
             n = part.numel()
             self.last_bn_grads = (part[n - cout:], part[n - 2 * cout:n - cout]) if out_coef is not None else None
+            defer_keep(part, dw=dw)
             return gz_a, ds_a, gz_b, ds_b, dw
         grid = 256 if self.device_type == "cuda" else 1
         part = torch.empty(min(grid, (rows + 63) // 64) * cout * (ca + cb) + 8 * cout, dtype=_F32, device=dev)
@@ -1024,6 +1090,7 @@ class CBackend:
                    P(part), P(dw), stream=self._stream())
         n = part.numel()
         self.last_bn_grads = (part[n - cout:], part[n - 2 * cout:n - cout]) if out_coef is not None else None
+        defer_keep(part, dw=dw)
         return gz_a, ds_a, gz_b, ds_b, dw
 
     def cv_softmax_wsum_forward(self, B, N, M, y5, coef5, slope5, y3, coef3, slope3):
@@ -1229,6 +1296,7 @@ class CBackend:
             n = w.shape[0] * w.shape[1]
             dws.append(dw[off:off + n].view(w.shape[0], w.shape[1]))
             off += n
+        defer_keep(dw_part, dw=dws)
         return gx, dws, dgs, dbs
 
     def pad_cols(self, w, cpad):

@@ -219,12 +219,18 @@ class Trainer:
     def _forward_backward(self, batch):
         self.model.train()
         ops.begin_step(self.device)             # one memset for every small accumulator of this step
+        # the weight gradients' slab sums are recorded during backward and formed in ONE launch behind it (csrc/deferred.hip): nothing
+        # reads a weight gradient before the packing below
+        self._deferring = self.device.type == "cuda" and ops.defer_begin()
         try:
             return self._forward_backward_in_step(batch)
         finally:
             # the arena belongs to THIS step: outside, ops.zeros() is torch.zeros again (a later graph capture — the
             # evaluator's, bench_infer's — would otherwise bake arena slices in as "zero" accumulators without a memset)
             ops.end_step(self.device)
+            if self._deferring:
+                self._deferring = False
+                ops.defer_end()
 
     def _forward_backward_in_step(self, batch):
         for p in self.params:                   # autograd then hands its buffers over instead of accumulating
@@ -240,6 +246,15 @@ class Trainer:
         loss, real_loss, dual_loss = Get_loss(out3, out4, batch["decalib_real_gt"], batch["decalib_dual_gt"], sx, sq,
                                               cfg=self.cfg)
         loss.backward()
+        if getattr(self, "_deferring", False):
+            # every weight gradient whose sum is still pending must have become a parameter's `.grad` UNTOUCHED (adopted, not cloned,
+            # not concatenated or added by autograd): anything else would have read it before it exists
+            have = {p.grad.data_ptr() for p in self.params if p.grad is not None}
+            early = [x for x in ops.defer_noted() if x not in have]
+            if early:
+                raise RuntimeError(f"{len(early)} weight gradients with a deferred reduction were consumed before the flush "
+                                   "(autograd post-processed them): wrap their producer in ops.defer_paused() or set I2P_NO_DEFER=1")
+            ops.defer_flush()
         zero = self._zero
         grads = []
         if not self._mask_known:                # first step: which parameters does this loss reach at all? (host-side

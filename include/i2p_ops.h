@@ -603,6 +603,21 @@ int i2p_clip_adam(long long n, float *param, float *grad, float *exp_avg, float 
                   float *step, const float *lr, double beta1, double beta2, float eps, float weight_decay, float clip, float gscale,
                   float *total_out, const float *poison, void *stream);
 
+/* Deferred weight-gradient reductions (csrc/deferred.hip).  The reference's step needs no weight gradient before clip + optimiser
+ * (train20v2learn_wandb_proj.py:473-481).  Between i2p_defer_begin() and i2p_defer_end() the layer-backward entries (i2p_lin_bwd*,
+ * i2p_gemm_tn, i2p_chain_bwd, the bf16 backward entries) RECORD the sum of their per-block weight-gradient slabs instead of
+ * launching it; i2p_defer_flush(stream) sums every recorded one in one launch per 24 entries, bit-identical to the immediate form.
+ * The caller keeps the `dw_partial` / scratch buffers alive and unread until the flush and does not read a `dw` earlier;
+ * i2p_defer_pause(1) ... i2p_defer_pause(0) brackets calls whose `dw` is consumed at once.  i2p_defer_pending(): recorded, not yet
+ * flushed; i2p_defer_end() switches deferral off and returns the number of recorded reductions it had to drop (non-zero = a bug in
+ * the caller: those weight gradients were never formed).  Process-wide state, guarded by a mutex (autograd's device thread records,
+ * the caller's thread flushes). */
+int i2p_defer_begin(void);
+int i2p_defer_pause(int on);
+int i2p_defer_pending(void);
+int i2p_defer_flush(void *stream);
+int i2p_defer_end(void);
+
 /* One-launch replacements for clusters of small elementwise launches (csrc/glue.hip).
  * i2p_row_valid: out[r] = 1.0 if any x[r, 0..c) != 0 else 0.0 — check_valid (src/projectPN/utils.py:106-108).
  * i2p_mask_fill: out[r, :] = valid[r] > 0 ? x[r, :] : fill — the reference's x*valid + (-1e10)*(1-valid) for a 0/1 row mask

@@ -326,6 +326,61 @@ def test_chain_timeout_raises_on_the_same_step_for_every_rank(hip_backend, monke
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_deferred_weight_gradient_reductions_are_bit_identical(hip_backend, monkeypatch, precision):
+    """round 6 (csrc/deferred.hip): during a Trainer step the per-block weight-gradient slabs of every layer backward are summed by ONE
+    launch behind backward() instead of one launch per layer; a block of that launch does what a block of the kernel it replaces did,
+    so the gradients of a step are BIT-identical to the immediate form (I2P_NO_DEFER=1) in fp32, eager and captured (the image encoder's
+    MIOpen weight gradients aside); in bf16 storage, which is not run-to-run reproducible, within the spread of two immediate runs.
+    Also: nothing is left pending, and the step really records reductions (the mechanism is on)."""
+    from i2pnet_amd import _lib, ops, synth
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd.train import Trainer
+    dev = torch.device("cuda", 0)
+    batch = synth.make_batch(2, 8192, 160, 512, seed=5, device=dev)
+    prev = ops.set_precision(precision)
+    prev_det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True       # (MIOpen's default weight-gradient solvers use atomics: the image encoder's own gradients are left out below)
+    try:
+        def run(no_defer, graph):
+            if no_defer:
+                monkeypatch.setenv("I2P_NO_DEFER", "1")
+            else:
+                monkeypatch.delenv("I2P_NO_DEFER", raising=False)
+            tr = Trainer(cfg=cfg, device=dev, seed=0, clip=0.0)      # no clipping: the packed gradient stays what backward produced
+            tr.net.l3_head.DP1.p = 0.0; tr.net.l4_head.DP1.p = 0.0
+            if graph:
+                assert tr.capture(batch)
+            tr.step(batch)
+            torch.cuda.synchronize()
+            assert _lib.helper("i2p_defer_pending") == 0
+            return {k: v for k, v in tr.named_grads().items() if not k.startswith("RGB_net")}
+        recorded = []
+        orig = ops.defer_flush
+        monkeypatch.setattr(ops, "defer_flush", lambda: recorded.append(orig()) or recorded[-1])
+        g_def = run(False, False)
+        assert recorded and recorded[-1] >= 20, recorded          # the step deferred its layer reductions
+        g_imm = run(True, False)
+        g_cap = run(False, True)
+        if precision == "fp32":
+            for g in (g_def, g_cap):
+                diff = [k for k in g_imm if not torch.equal(g[k], g_imm[k])]
+                assert not diff, diff[:8]
+        else:
+            # bf16 storage is not run-to-run reproducible (pair_bwd2_bf16_kernel accumulates d_f / d_bias_n with float atomics, and a
+            # flipped bf16 rounding propagates): the deferred form must sit inside the spread of two IMMEDIATE runs
+            g_imm2 = run(True, False)
+            rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+            spread = max(rel(g_imm2[k], g_imm[k]) for k in g_imm)
+            worst = max(max(rel(g[k], g_imm[k]) for k in g_imm) for g in (g_def, g_cap))
+            print(f"[deferred, bf16] worst per-tensor relative difference to the immediate form {worst:.3e}; two immediate runs differ by {spread:.3e}")
+            assert worst <= max(3.0 * spread, 1e-6), (worst, spread)
+    finally:
+        ops.set_precision(prev)
+        torch.backends.cudnn.deterministic = prev_det
+
+
+@pytest.mark.gpu
 def test_dp_step_structure_costs_less_than_3_percent():
     """what one GPU can measure of the N > 1 step — graph A -> RCCL all-reduce (1-rank group) -> graph B against
     the single captured graph, at the benchmark's own configuration (configs[1], batch 8), through bench.py's own functions.  The
