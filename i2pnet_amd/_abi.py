@@ -135,6 +135,7 @@ HELPERS = {
     "i2p_chain_sync_words": [],                                     # returns long long (uint32 words)
     "i2p_defer_begin": [],
     "i2p_defer_pause": ["i"],
+    "i2p_defer_compact_next": ["i", "i", "i"],
     "i2p_defer_pending": [],
     "i2p_defer_end": [],
     "i2p_ktime_enable": ["i"],

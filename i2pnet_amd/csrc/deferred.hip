@@ -17,7 +17,8 @@ namespace {
 
 struct DefEntry {
     const void *parts; void *out;
-    int nparts, n, block0, kind;      // kind 0: n = float4 columns (16 x 16 shape); 1: n = floats (32 x 8 shape)
+    int nparts, n, block0, kind;      // kind 0: n = float4 columns (16 x 16 shape); 1: n = floats (32 x 8 shape);
+    int pitch, cols;                  // kind 2: kind 0's sums of the first `cols` columns of [rows][pitch] slabs, written as [rows][cols] (n = rows * cols)
 };
 constexpr int DEF_MAX = 24;
 struct DefTable { DefEntry e[DEF_MAX]; int count; };
@@ -58,6 +59,29 @@ __global__ __launch_bounds__(256) void deferred_reduce_kernel(DefTable t) {
             for (int q = 0; q < 16; ++q) { const float4 v = red4[q][tx]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
             reinterpret_cast<float4 *>(e.out)[o] = s;
         }
+    } else if (e.kind == 2) {
+        // column-compacting form of kind 0 (the weight gradient of a layer whose input rows are zero-padded: only the real columns are
+        // kept): per element the same additions in the same order as kind 0 followed by a column slice
+        float (*red)[16] = reinterpret_cast<float (*)[16]>(&red4[0][0]);
+        const float *__restrict__ parts = reinterpret_cast<const float *>(e.parts);
+        const int nparts = e.nparts, cols = e.cols;
+        const size_t slab = (size_t)(e.n / cols) * e.pitch;
+        const int tx = threadIdx.x & 15, pl = threadIdx.x >> 4;
+        const int o = blk * 16 + tx;
+        float a = 0.f;
+        if (o < e.n) {
+            const int r = o / cols, c = o - r * cols;
+            const float *src = parts + (size_t)r * e.pitch + c;
+            for (int b = pl; b < nparts; b += 16) a += src[(size_t)b * slab];
+        }
+        red[pl][tx] = a;
+        __syncthreads();
+        if (pl == 0 && o < e.n) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s2 += red[q][tx];
+            reinterpret_cast<float *>(e.out)[o] = s2;
+        }
     } else {
         float (*red)[32] = reinterpret_cast<float (*)[32]>(&red4[0][0]);
         const float *__restrict__ parts = reinterpret_cast<const float *>(e.parts);
@@ -81,6 +105,8 @@ std::mutex g_mu;                       // (backward nodes run on the autograd en
 bool g_on = false;
 int g_pause = 0;
 std::vector<DefEntry> g_list;
+int g_c_rows = 0, g_c_pitch = 0, g_c_cols = 0;   // one-shot: the next recorded kind-0 reduction of rows * pitch floats keeps `cols` columns
+bool g_c_used = false;
 
 }  // namespace
 
@@ -88,13 +114,22 @@ std::vector<DefEntry> g_list;
 bool i2p_defer_reduce(int kind, int nparts, int n, const void *parts, void *out) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_on || g_pause > 0 || nparts <= 0 || n <= 0) return false;
-    g_list.push_back(DefEntry{parts, out, nparts, n, 0, kind});
+    if (g_c_rows > 0) {                // a compaction request is pending: this reduction is recorded in the compact form, or it runs NOW
+        const bool fits = kind == 0 && (long long)n * 4 == (long long)g_c_rows * g_c_pitch;
+        const int rows = g_c_rows;
+        g_c_rows = 0;
+        if (!fits) return false;       // (bf16 slabs, another shape: the caller slices the immediate result)
+        g_list.push_back(DefEntry{parts, out, nparts, rows * g_c_cols, 0, 2, g_c_pitch, g_c_cols});
+        g_c_used = true;
+        return true;
+    }
+    g_list.push_back(DefEntry{parts, out, nparts, n, 0, kind, 0, 0});
     return true;
 }
 
 extern "C" int i2p_defer_begin(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_on = true; g_pause = 0; g_list.clear();
+    g_on = true; g_pause = 0; g_list.clear(); g_c_rows = 0; g_c_used = false;
     return 0;
 }
 
@@ -103,6 +138,17 @@ extern "C" int i2p_defer_pause(int on) {
     g_pause += on ? 1 : -1;
     if (g_pause < 0) g_pause = 0;
     return 0;
+}
+
+// One-shot request for the NEXT recorded fp32 reduction, if it sums [rows][pitch] slabs: keep the first `cols` columns and write them
+// densely as [rows][cols] at the start of `out` (the weight gradient of a layer whose input rows carry zero padding).  rows = 0 withdraws
+// the request; the return value says whether the previous request was taken (1) — if not, the caller slices the full result itself.
+extern "C" int i2p_defer_compact_next(int rows, int pitch, int cols) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int used = g_c_used ? 1 : 0;
+    g_c_used = false;
+    g_c_rows = (rows > 0 && pitch >= cols && cols > 0) ? rows : 0; g_c_pitch = pitch; g_c_cols = cols;
+    return used;
 }
 
 extern "C" int i2p_defer_pending(void) {
@@ -124,7 +170,7 @@ extern "C" int i2p_defer_flush(void *stream) {
         for (int j = 0; j < t.count; ++j) {
             t.e[j] = todo[s0 + j];
             t.e[j].block0 = blocks;
-            blocks += t.e[j].kind == 0 ? (t.e[j].n + 15) / 16 : (t.e[j].n + 31) / 32;
+            blocks += t.e[j].kind == 1 ? (t.e[j].n + 31) / 32 : (t.e[j].n + 15) / 16;
         }
         hipLaunchKernelGGL(deferred_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
     }

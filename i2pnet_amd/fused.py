@@ -295,13 +295,12 @@ class _MlpChain(Function):
             W = p[k + 3 * (i - 1)]
             has_in = coefs[i - 1] is not None
             need_gx = has_in or ctx.x_needs_grad
-            sliced = i == 1 and ctx.w0_cin is not None       # its weight gradient is read at once (column slice): reduced immediately
-            with (ops.defer_paused() if sliced else contextlib.nullcontext()):
-                gz_in, in_ds, dw = be.lin_backward(gz, y_out, out_coef, out_mi, out_ds, ys[i - 1], coefs[i - 1],
-                                                   mis[i - 1], slopes[i - 1] if has_in else 1.0, W.detach(),
-                                                   need_gx=need_gx, slope_out=slope_out)
-            if sliced:
-                dw = be.after_wgrad(lambda dw=dw: dw[:, :ctx.w0_cin].contiguous())
+            call = lambda: be.lin_backward(gz, y_out, out_coef, out_mi, out_ds, ys[i - 1], coefs[i - 1], mis[i - 1],
+                                           slopes[i - 1] if has_in else 1.0, W.detach(), need_gx=need_gx, slope_out=slope_out)
+            if i == 1 and ctx.w0_cin is not None:            # zero-padded input rows: only the real columns of dW are the gradient
+                gz_in, in_ds, dw = ops.defer_compact(call, W.shape[0], W.shape[1], ctx.w0_cin)
+            else:
+                gz_in, in_ds, dw = call()
             grads[k + 3 * (i - 1)] = dw
             # gamma/beta gradients of the BN behind layer i: reduced from out_ds by the launcher (scratch tail)
             grads[k + 3 * (i - 1) + 1], grads[k + 3 * (i - 1) + 2] = be.take_bn_grads()
@@ -481,14 +480,12 @@ class _CvKnnTail(Function):
         dg4, db4 = be_.take_bn_grads()
         gz2, ds2, dW3 = be_.lin_backward(gz3, y3, c3, m3, ds3, y2, c2, m2, s2, d(W3)); dg3, db3 = be_.take_bn_grads()
         gz1, ds1, dW2 = be_.lin_backward(gz2, y2, c2, m2, ds2, y1, c1, m1, s1, d(W2)); dg2, db2 = be_.take_bn_grads()
-        with (ops.defer_paused() if W1.shape[1] != ctx.cins[0] else contextlib.nullcontext()):
-            dx1, _, dW1 = be_.lin_backward(gz1, y1, c1, m1, ds1, x1, None, None, 1.0, W1, need_gx=ctx.need[0]); dg1, db1 = be_.take_bn_grads()
-        if W1.shape[1] > ctx.cins[0]:
-            dW1 = be_.after_wgrad(lambda: dW1[:, :ctx.cins[0]].contiguous())
-        with (ops.defer_paused() if We.shape[1] != ctx.cins[1] else contextlib.nullcontext()):
-            dxe, _, dWe = be_.lin_backward(gze, ye, ce, me, dse, xe, None, None, 1.0, We, need_gx=ctx.need[1]); dge, dbe = be_.take_bn_grads()
-        if We.shape[1] > ctx.cins[1]:
-            dWe = be_.after_wgrad(lambda: dWe[:, :ctx.cins[1]].contiguous())
+        call1 = lambda: be_.lin_backward(gz1, y1, c1, m1, ds1, x1, None, None, 1.0, W1, need_gx=ctx.need[0])
+        dx1, _, dW1 = ops.defer_compact(call1, W1.shape[0], W1.shape[1], ctx.cins[0]) if W1.shape[1] > ctx.cins[0] else call1()
+        dg1, db1 = be_.take_bn_grads()
+        calle = lambda: be_.lin_backward(gze, ye, ce, me, dse, xe, None, None, 1.0, We, need_gx=ctx.need[1])
+        dxe, _, dWe = ops.defer_compact(calle, We.shape[0], We.shape[1], ctx.cins[1]) if We.shape[1] > ctx.cins[1] else calle()
+        dge, dbe = be_.take_bn_grads()
         return (dx1, dxe, dW1, dWe, None, None, None, dg1, db1, dW2, dg2, db2, dW3, dg3, db3, dge, dbe, dW4, dg4, db4, dW5, dg5, db5)
 
 

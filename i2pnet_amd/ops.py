@@ -189,6 +189,25 @@ def defer_noted():
     return list(_DEFER["dws"])
 
 
+def defer_compact(call, cout, cpad, cin):
+    """`call()` -> (..., dw [cout, cpad]) is a layer backward whose input rows are zero-padded from cin to cpad columns.  With deferral
+    active its slab sum is recorded in the column-compacting form and the [cout, cin] gradient is a dense view of dw's first elements
+    (no slice copy, and the sum joins the step's one flush); otherwise the full sum is formed at once and sliced."""
+    if _DEFER["on"] and not _DEFER["paused"]:
+        _lib.helper("i2p_defer_compact_next", int(cout), int(cpad), int(cin))
+        noted = len(_DEFER["dws"])
+        out = call()
+        if _lib.helper("i2p_defer_compact_next", 0, 0, 0):
+            return out[:-1] + (out[-1].view(-1)[:cout * cin].view(cout, cin),)
+        # (a reduction that cannot take the compact form — bf16 slabs, another shape — is not recorded under a pending request: it has
+        #  run; its full result is sliced, and it is not one of the gradients the flush still owes)
+        del _DEFER["dws"][noted:]
+        return out[:-1] + (out[-1][:, :cin].contiguous(),)
+    with defer_paused():
+        out = call()
+    return out[:-1] + (out[-1][:, :cin].contiguous(),)
+
+
 class defer_paused:
     """`with ops.defer_paused():` around a backward call whose weight gradient is read at once (its reduction is launched immediately)"""
     def __enter__(self):

@@ -614,6 +614,10 @@ int i2p_clip_adam(long long n, float *param, float *grad, float *exp_avg, float 
  * the caller's thread flushes). */
 int i2p_defer_begin(void);
 int i2p_defer_pause(int on);
+/* one-shot: the NEXT recorded fp32 reduction, if its slabs are [rows][pitch] floats, keeps the first `cols` columns and writes them
+ * densely as [rows][cols] at the start of its `dw` (weight gradient of a layer whose input rows are zero-padded); rows = 0 withdraws the
+ * request; returns 1 if the previous request was taken by a reduction, else 0 */
+int i2p_defer_compact_next(int rows, int pitch, int cols);
 int i2p_defer_pending(void);
 int i2p_defer_flush(void *stream);
 int i2p_defer_end(void);
