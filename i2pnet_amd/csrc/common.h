@@ -110,6 +110,7 @@ int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const flo
 // csrc/deferred.hip: record a weight-gradient slab reduction instead of launching it (true = recorded).  kind 0: the 16 x 16 float4 shape
 // (n = float4 columns), kind 1: reduce_partials_bf16's 32 x 8 shape (n = floats)
 bool i2p_defer_reduce(int kind, int nparts, int n, const void *parts, void *out);
+bool i2p_defer_conv_fin(int nblk, int NT, const float *partials, float *dW, int s_out, int s_in, int s_kh, int s_kw);
 bool i2p_wreg_bwd_fused2_ok(long long rows, int k, int c, int split);
 int i2p_wreg_bwd_fused2(long long rows, const float *gz, const float *y2, const double *g_dsums, const float *g_oc, const float *g_omi,
                         long long g_rows, const float *w, float *gz_in_a, const float *xa, const float *coef_a, const float *mi_a,

@@ -19,12 +19,13 @@ struct DefEntry {
     const void *parts; void *out;
     int nparts, n, block0, kind;      // kind 0: n = float4 columns (16 x 16 shape); 1: n = floats (32 x 8 shape);
     int pitch, cols;                  // kind 2: kind 0's sums of the first `cols` columns of [rows][pitch] slabs, written as [rows][cols] (n = rows * cols)
-};
+    int s_out, s_in, s_kh, s_kw;      // kind 3: conv3x3_wgrad_fin_kernel (image_conv16.hip): nparts blocks x [NT = n][9][256] partials, fp64 sums,
+};                                    //         written at the weight's element strides
 constexpr int DEF_MAX = 24;
 struct DefTable { DefEntry e[DEF_MAX]; int count; };
 
 __global__ __launch_bounds__(256) void deferred_reduce_kernel(DefTable t) {
-    __shared__ float4 red4[16][16];
+    __shared__ __attribute__((aligned(16))) float4 red4[16][16];        // 4 KB, re-viewed per kind
     int i = 0;
 #pragma unroll 1
     for (int j = 1; j < t.count; ++j) if ((int)blockIdx.x >= t.e[j].block0) i = j;
@@ -82,6 +83,24 @@ __global__ __launch_bounds__(256) void deferred_reduce_kernel(DefTable t) {
             for (int q = 0; q < 16; ++q) s2 += red[q][tx];
             reinterpret_cast<float *>(e.out)[o] = s2;
         }
+    } else if (e.kind == 3) {
+        // a quarter of a block of conv3x3_wgrad_fin_kernel: 16 outputs x 16 row groups, group g adding blocks g, g + 16, ... in fp64, the
+        // groups added in order — the same additions per element as the 1024-thread kernel it replaces
+        double (*part)[16] = reinterpret_cast<double (*)[16]>(&red4[0][0]);
+        const float *__restrict__ partials = reinterpret_cast<const float *>(e.parts);
+        const int NT = e.n, nblk = e.nparts;
+        const int tt = blk >> 4, nt = tt / 9, t = tt - nt * 9, el = (blk & 15) * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
+        double a = 0.0;
+        for (int b = grp; b < nblk; b += 16) a += (double)partials[((size_t)b * NT + nt) * (9 * 256) + t * 256 + el];
+        part[grp][threadIdx.x & 15] = a;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            double v = 0.0;
+#pragma unroll
+            for (int g2 = 0; g2 < 16; ++g2) v += part[g2][threadIdx.x];
+            const int co = 16 * nt + (el >> 4), ci = el & 15;
+            reinterpret_cast<float *>(e.out)[co * e.s_out + ci * e.s_in + (t / 3) * e.s_kh + (t % 3) * e.s_kw] = (float)v;
+        }
     } else {
         float (*red)[32] = reinterpret_cast<float (*)[32]>(&red4[0][0]);
         const float *__restrict__ parts = reinterpret_cast<const float *>(e.parts);
@@ -119,11 +138,20 @@ bool i2p_defer_reduce(int kind, int nparts, int n, const void *parts, void *out)
         const int rows = g_c_rows;
         g_c_rows = 0;
         if (!fits) return false;       // (bf16 slabs, another shape: the caller slices the immediate result)
-        g_list.push_back(DefEntry{parts, out, nparts, rows * g_c_cols, 0, 2, g_c_pitch, g_c_cols});
+        g_list.push_back(DefEntry{parts, out, nparts, rows * g_c_cols, 0, 2, g_c_pitch, g_c_cols, 0, 0, 0, 0});
         g_c_used = true;
         return true;
     }
-    g_list.push_back(DefEntry{parts, out, nparts, n, 0, kind, 0, 0});
+    g_list.push_back(DefEntry{parts, out, nparts, n, 0, kind, 0, 0, 0, 0, 0, 0});
+    return true;
+}
+
+// the finalisation of an image-encoder 3x3 weight gradient (csrc/image_conv16.hip): nblk blocks of [NT][9][256] fp32 partials, summed
+// in fp64, written at the weight's element strides
+bool i2p_defer_conv_fin(int nblk, int NT, const float *partials, float *dW, int s_out, int s_in, int s_kh, int s_kw) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_on || g_pause > 0 || g_c_rows > 0 || nblk <= 0 || NT <= 0) return false;
+    g_list.push_back(DefEntry{partials, dW, nblk, NT, 0, 3, 0, 0, s_out, s_in, s_kh, s_kw});
     return true;
 }
 
@@ -170,7 +198,7 @@ extern "C" int i2p_defer_flush(void *stream) {
         for (int j = 0; j < t.count; ++j) {
             t.e[j] = todo[s0 + j];
             t.e[j].block0 = blocks;
-            blocks += t.e[j].kind == 1 ? (t.e[j].n + 31) / 32 : (t.e[j].n + 15) / 16;
+            blocks += t.e[j].kind == 1 ? (t.e[j].n + 31) / 32 : t.e[j].kind == 3 ? 9 * t.e[j].n * 16 : (t.e[j].n + 15) / 16;
         }
         hipLaunchKernelGGL(deferred_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
     }

@@ -524,6 +524,7 @@ extern "C" int i2p_img_conv_wgrad(int B, int H, int W, int cin, int cout, int bf
         if (cout == 16) I2P_WG(16, false); else I2P_WG(32, false);
 #undef I2P_WG
     }
+    if (!(B > 0 && i2p_defer_conv_fin(blocks, nt, partials, (float *)dW, wv.s_out, wv.s_in, wv.s_kh, wv.s_kw)))    // (csrc/deferred.hip: with the step's other weight gradients)
     hipLaunchKernelGGL(conv3x3_wgrad_fin_kernel<false>, dim3(36 * nt), dim3(1024), 0, st, blocks, nt, (const float *)partials, wv, dW);
     I2P_RETURN_LAUNCH_STATUS();
 }

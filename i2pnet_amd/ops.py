@@ -593,6 +593,7 @@ class CBackend:
         partials = torch.empty(max(rows, 1) * 2304 * (cout // 16), dtype=_F32, device=x.device)
         self._call("i2p_img_conv_wgrad", int(B), int(H), int(W), cin, cout, int(dt == _BF16), self._p(x, dt, "x"), self._p(dy, dt, "dy"), ws,
                    self._p(partials, _F32, "partials"), C.c_void_p(dW.data_ptr()), stream=self._stream())
+        defer_keep(partials, dw=dW)
         return dW
 
     def img_block_forward(self, y, gamma, beta, eps, slope, stride, momentum=0.0, conv_bias=None, running_mean=None,

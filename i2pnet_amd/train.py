@@ -534,10 +534,17 @@ class Trainer:
         else:
             self.check_chain_errors()             # host-mapped flag of the chain kernels: no synchronisation
         if self._graph_a is not None:
+            dsts, srcs = [], []
             for k, dst in self._static.items():
                 v = batch[k]
-                if dst is not v:
+                if dst is v:
+                    continue
+                if v.device == dst.device and v.dtype == dst.dtype and v.shape == dst.shape:
+                    dsts.append(dst); srcs.append(v)
+                else:
                     dst.copy_(v, non_blocking=True)
+            if dsts:            # the step's eight input tensors into the graph's static buffers: ONE launch, not eight memcpy nodes (~5 us each)
+                torch._foreach_copy_(dsts, srcs)
             self._graph_a.replay()
             if self._graph_b is not None:
                 self._all_reduce()
