@@ -56,6 +56,14 @@ struct WregFusedP {
 };
 
 __device__ __forceinline__ f32x4 ldn(const float *ptr) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(ptr)); }
+// gz / y of the TWO instantiation: both waves of a strip read the same lines — a non-temporal first read does not stay in L2 and the
+// partner fetched the line from HBM again (PMC, profiles/r06_pmc_traffic.json first pass: 2.86 GB per launch = 1.45x the algorithmic
+// 1.97 GB); with the default policy the second read is an L2 hit
+template <bool SHARED>
+__device__ __forceinline__ f32x4 ldg(const float *ptr) {
+    if constexpr (SHARED) return *reinterpret_cast<const f32x4 *>(ptr);
+    else return ldn(ptr);
+}
 __device__ __forceinline__ void stn(float *ptr, const f32x4 &v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4_nt *>(ptr)); }
 
 // TWO (round 6): K = 128 output channels cannot keep W (K*C/64 registers) AND dW for C = 128 input channels in one wave (512 registers
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(WF_THREADS, 1) void wreg_bwd_fused_kernel(WregFused
         f32x4 gn[NF], yn[NF], xn[NT];                        // the strip being REQUESTED
         f32x4 ea[ADD ? NT : 1];                              // e_add rows of the strip whose epilogue comes next
 #pragma unroll
-        for (int f = 0; f < NF; ++f) { gn[f] = ldn(p.gz + koff + 16 * f); yn[f] = ldn(p.y2 + koff + 16 * f); }
+        for (int f = 0; f < NF; ++f) { gn[f] = ldg<TWO>(p.gz + koff + 16 * f); yn[f] = ldg<TWO>(p.y2 + koff + 16 * f); }
 #pragma unroll
         for (int j = 0; j < NT; ++j) xn[j] = ldn(src_x + coff + 16 * j);
         if (ADD) {
@@ -194,12 +202,12 @@ __global__ __launch_bounds__(WF_THREADS, 1) void wreg_bwd_fused_kernel(WregFused
                 // line twice: PMC FETCH_SIZE 1.28x in mlp_wreg.hip's dgrad before it paired them)
                 if (i < NF && !(FUSED_ABL & 8)) {
                     const int f2 = (i >> 1) * 2;
-                    if (i & 1) { yn[f2] = ldn(p.y2 + koff + 16 * f2); yn[f2 + 1] = ldn(p.y2 + koff + 16 * (f2 + 1)); }
-                    else if (!MERGE) { gn[f2] = ldn(p.gz + koff + 16 * f2); gn[f2 + 1] = ldn(p.gz + koff + 16 * (f2 + 1)); }
+                    if (i & 1) { yn[f2] = ldg<TWO>(p.y2 + koff + 16 * f2); yn[f2 + 1] = ldg<TWO>(p.y2 + koff + 16 * (f2 + 1)); }
+                    else if (!MERGE) { gn[f2] = ldg<TWO>(p.gz + koff + 16 * f2); gn[f2 + 1] = ldg<TWO>(p.gz + koff + 16 * (f2 + 1)); }
                 }
                 if (MERGE && !(FUSED_ABL & 8) && (i + 1) % (8 * NT) == 0) {      // the last MFMA that reads g^y block f2 + 1 has been issued
                     const int f2 = (i + 1) / (8 * NT) * 2 - 2;
-                    gn[f2] = ldn(p.gz + koff + 16 * f2); gn[f2 + 1] = ldn(p.gz + koff + 16 * (f2 + 1));
+                    gn[f2] = ldg<TWO>(p.gz + koff + 16 * f2); gn[f2 + 1] = ldg<TWO>(p.gz + koff + 16 * (f2 + 1));
                 }
                 const int ja = i / SL, sub = i % SL;
                 if (sub == 2) { esc = *reinterpret_cast<const f32x4 *>(eq + 16 * ja); ezb = *reinterpret_cast<const f32x4 *>(eq + C + 16 * ja); }
