@@ -21,11 +21,12 @@ _VARIANT_FILES = os.environ.get("I2P_BUILD_VARIANT_FILES", "").split()
 LIB = PKG / "lib" / (f"libi2p_ops_{_VARIANT}.so" if _VARIANT else "libi2p_ops.so")
 OBJ = PKG / "lib" / (f"obj_{_VARIANT}" if _VARIANT else "obj")
 SOURCES = ["fused_conv_select_k.hip", "pointnet2_ops.hip", "projection_ops.hip", "bn_act.hip", "mlp.hip", "cv_softmax.hip",
-           "image_block.hip", "image_first.hip", "image_conv16.hip", "mlp_bf16.hip", "bf16_stream.hip", "sa_group.hip", "scatter_det.hip", "mlp_wreg.hip", "mlp_wreg_fused.hip", "mlp_wreg_bf16.hip", "mlp_bwd_fused_bf16.hip", "pair_bwd_bf16.hip", "pair_fwd_bf16.hip", "gemm_tn.hip", "mlp_big.hip", "optim.hip", "glue.hip", "mlp_chain.hip", "loader_build.hip", "deferred.hip"]
+           "image_block.hip", "image_first.hip", "image_conv16.hip", "mlp_bf16.hip", "bf16_stream.hip", "sa_group.hip", "scatter_det.hip", "mlp_wreg.hip", "mlp_wreg_fused.hip", "mlp_wreg_bf16.hip", "mlp_bwd_fused_bf16.hip", "pair_bwd_bf16.hip", "pair_fwd_bf16.hip", "gemm_tn.hip", "mlp_big.hip", "optim.hip", "glue.hip", "mlp_chain.hip", "loader_build.hip", "deferred.hip", "mlp_wreg_pair_fused.hip"]
 # mlp_wreg.hip: one strip = 256 MFMAs with the rest of the wave's work slotted between them, written as ONE fully
 # unrolled loop — past clang's default size limit for `#pragma unroll`
 EXTRA_FLAGS = {"mlp_wreg.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
                "mlp_wreg_fused.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
+               "mlp_wreg_pair_fused.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"],
                # img1_bwd_kernel: the SLP vectoriser pairs the unrolled elements into v_pk_fma_f32 and spills 1.9 KB per lane doing it
                "image_first.hip": ["-fno-slp-vectorize"]}
 if os.environ.get("WREG_ABL"):      # diagnostic build of the ablation switches in mlp_wreg.hip

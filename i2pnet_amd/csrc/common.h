@@ -111,6 +111,10 @@ int i2p_wreg_wgrad(long long rows, int cin, int cout, const float *gz, const flo
 // (n = float4 columns), kind 1: reduce_partials_bf16's 32 x 8 shape (n = floats)
 bool i2p_defer_reduce(int kind, int nparts, int n, const void *parts, void *out);
 bool i2p_defer_conv_fin(int nblk, int NT, const float *partials, float *dW, int s_out, int s_in, int s_kh, int s_kw);
+bool i2p_wreg_pair_bwd_fused_ok(void);
+int i2p_wreg_pair_bwd_fused(int B, int N, int M, int KT, int NCH, int NL, const float *gz, const float *y2, const double *g_dsums,
+                            const float *g_oc, const float *g_omi, const float *f, const float *g, const float *w, float *dw_partial,
+                            float *s_df, float *s_dbn, float *s_dg, float *s_dbk, void *stream);
 bool i2p_wreg_bwd_fused2_ok(long long rows, int k, int c, int split);
 int i2p_wreg_bwd_fused2(long long rows, const float *gz, const float *y2, const double *g_dsums, const float *g_oc, const float *g_omi,
                         long long g_rows, const float *w, float *gz_in_a, const float *xa, const float *coef_a, const float *mi_a,

@@ -1493,6 +1493,9 @@ int i2p_wreg_pair_bwd(int B, int N, int M, int cin, int cout, const float *gz, c
     p.s_dg = p.s_dbn + (size_t)p.KT * B * N * cout;
     p.s_dbk = p.s_dg + (size_t)p.NCH * B * M * cin;
     *KT_out = p.KT; *NCH_out = p.NCH;
+    if (i2p_wreg_pair_bwd_fused_ok())      // both halves from ONE read of gz / y (csrc/mlp_wreg_pair_fused.hip): same slabs, same geometry
+        return i2p_wreg_pair_bwd_fused(B, N, M, p.KT, p.NCH, p.NL, gz, y2, g_dsums, g_oc, g_omi, f, g, w, p.dw_partial, p.s_df, p.s_dbn, p.s_dg,
+                                       p.s_dbk, stream);
     return launch_wreg_pair<128, 128>(p, 256u, (hipStream_t)stream);
 }
 

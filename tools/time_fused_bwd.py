@@ -60,3 +60,24 @@ t = e0.elapsed_time(e1) / 20 * 1e3
 by = rows * (2 * 128 + 2 * 128 + 64) * 4
 print(f"64+64 -> 128: {t:7.1f} us per backward (incl. the slab reduction)  {by / t / 1e3:7.1f} GB/s on one read of gz, y, xa, xb, e_add + one write; "
       f"{4 * rows * 128 * 128 / t / 1e6:6.1f} TFLOP/s", flush=True)
+
+# the pair layer (first cost-volume layer) backward at batch 8: one pass (wreg_pair_bwd_fused_kernel, csrc/mlp_wreg_pair_fused.hip) —
+# I2P_NO_PAIR_FUSED=1 times wreg_pair_dgrad_kernel + wreg_pair_wgrad_kernel; both incl. the slab reductions of the entry
+B, N, M, C = 8, 228, 468, 128
+g = torch.Generator(device=dev).manual_seed(3)
+rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+f, gk, bn, bk, w = rnd(B, N, C), rnd(B, M, C), rnd(B, N, C), rnd(B, M, C), rnd(C, C) / C ** 0.5
+y, sy = be.pair_lin_forward(f, gk, bn, bk, w)
+oc, om = be.bn_finalize(B * N * M, sy, torch.ones(C, device=dev), torch.zeros(C, device=dev), 1e-5)
+gz = rnd(B * N * M, C) * 0.1
+ods = be.bn_act_backward_stats(gz, y, om, torch.ones(C, device=dev), torch.zeros(C, device=dev), 0.1)
+run = lambda: be.pair_lin_backward(gz, f, gk, w, y=y, out_coef=oc, out_mi=om, out_dsums=ods)
+for _ in range(40):
+    run()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    run()
+e1.record(); e1.synchronize()
+t = e0.elapsed_time(e1) / 20 * 1e3
+print(f"pair 128x128: {t:7.1f} us per backward (incl. zero fill and 5 slab reductions)  {4 * B * N * M * C * C / t / 1e6:6.1f} TFLOP/s", flush=True)
