@@ -141,7 +141,7 @@ def _mlp_chain_entry(B, device):
             "bytes_per_launch_algorithmic": by, "mfma_TFLOPs": round(fl / t_chain / 1e6, 1), "timed_as": "20 launches per hipGraph replay"}
 
 
-PMC_JSON = ROOT / "profiles" / "r05_pmc_traffic.json"            # written by tools/pmc_r05.sh on the round's final kernels
+PMC_JSON = ROOT / "profiles" / "r06_pmc_traffic.json"            # written by tools/pmc_step.sh r06 on the round's final kernels
 PMC_BF16_JSON = ROOT / "profiles" / "r05_pmc_bf16_traffic.json"   # {kernel: {"bytes_per_row": ...}}, tools/pmc_r05_bf16.py
 
 
@@ -383,7 +383,7 @@ def kernel_rooflines(B, device):
       pass (csrc/mlp_wreg_fused.hip): it reads gz [rows,64], the layer's pre-BN output y [rows,64] (BN backward of the layer behind
       formed on load) and the pre-BN input x [rows,128] ONCE, writes dL/dz_in [rows,128] and keeps the [64][128] weight gradient in
       registers: rows*(2*64+2*128)*4 B against 4*rows*128*64 flop => HBM-bound (164 us at 8 TB/s, 178 us at 157.3 TFLOP/s: close
-      to the ridge).  `traffic` = PMC bytes per launch from profiles/r05_pmc_traffic.json (tools/pmc_r05.sh).
+      to the ridge).  `traffic` = PMC bytes per launch from profiles/r06_pmc_traffic.json (tools/pmc_step.sh r06).
     * other_kernels: the forward of the same layer (wreg_fwd_kernel<128,64,true,false>), the two-source 64+64->128 forward
       (wreg_fwd_kernel<128,128,true,true>), the factored first layer (wreg_pair_fwd_kernel<128,128>), level-1
       fused_conv_select_k and the fused level-1 grouping on the three input densities.
@@ -433,13 +433,13 @@ def kernel_rooflines(B, device):
                        "of the layer behind formed on load, operands of the weight gradient transposed through wave-private LDS tiles, activation "
                        "derivative + BN-backward statistics in the store phase)",
              "bound": "hbm", "achieved": round(dg_bytes / t_bwd / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(dg_bytes / t_bwd / 1e3 / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("wreg_bwd_fused_kernel<64, 128>", B),
+             "frac": round(dg_bytes / t_bwd / 1e3 / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("wreg_bwd_fused_kernel<64, 128, false>", B),
              "avg_kernel_us": round(t_bwd, 1), "bytes_per_launch_algorithmic": dg_bytes,
              "mfma_TFLOPs": round(2 * flop / t_bwd / 1e6, 1), "mfma_frac": round(2 * flop / t_bwd / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
              "entry_us (kernel + BN-coefficient launch + 256-slab reduction of dW)": round(t_entry, 1),
              "timed_as": "the kernel alone: HIP events recorded by its launcher on the launch stream directly before and after "
                          "wreg_bwd_fused_kernel (i2p_ktime_enable / i2p_ktime_last_us), average of 20 launches with warm clocks; "
-                         "compare with the (kernel, blocks = 256, 853632-row) row of profiles/r05_*_steady_kernel_stats.csv",
+                         "compare with the (kernel, blocks = 256, 853632-row) row of profiles/r06_*_steady_kernel_stats.csv",
              "replaces": "wreg_dgrad_kernel<64,128,false> + wreg_wgrad_kernel<64,128,true,false> (two reads of the same tensors: 430 us)"}
     del x, y, gz
     # --- two-source forward (position encoding 64 + mlp1 output 64 -> 128), 1 launch per step ------------------------

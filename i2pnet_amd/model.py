@@ -82,6 +82,19 @@ def inverse_3x3(m):
 # (Two-branch schedules — image encoder || LiDAR pyramid on two HIP streams, the first image block's statistics beside the pyramid —
 #  were measured in rounds 2-4 and always lost to the single stream: 485-488 vs 491-495 samples/s, 11.79 vs 11.40 ms.  The pyramid's
 #  small launches do not hide under the encoder's kernels, they slow them down.  The code paths were removed in round 5.)
+class _BranchJoin(torch.autograd.Function):
+    """identity on the image encoder's outputs, created on the main stream right behind the join of the two encoder streams: its
+    backward marks the point of the backward pass from which the two encoders' backward passes run side by side"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return a.view_as(a), b.view_as(b)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return ga, gb
+
+
 class RegNet_v2(nn.Module):
     def __init__(self, bn_decay=None, eval_info=False, cfg=cfg_default):
         super().__init__()
@@ -160,6 +173,16 @@ class RegNet_v2(nn.Module):
         self.sq = nn.Parameter(torch.tensor([cfg.sq_init]), requires_grad=True)
         self.sx = nn.Parameter(torch.tensor([cfg.sx_init]), requires_grad=True)
 
+    def _branch_stream(self, dev):
+        """second stream for the image encoder (None on the CPU oracle backend or with I2P_ONE_STREAM=1)"""
+        if dev.type != "cuda" or os.environ.get("I2P_ONE_STREAM") == "1":
+            return None
+        s = self.__dict__.get("_side_stream")
+        if s is None or s.device != dev:
+            s = torch.cuda.Stream(dev)
+            self.__dict__["_side_stream"] = s
+        return s
+
     def _image_branch(self, rgb_img, intrinsic):
         """image encoder -> (RF3 [B,128,h3,w3], pixel rays [B,M,3], RF3 as points [B,M,C], its unit-variance form)"""
         RF3 = self.RGB_net3(self.RGB_net2(self.RGB_net1(rgb_img)))             # [B,128,h3,w3]
@@ -200,8 +223,31 @@ class RegNet_v2(nn.Module):
         B = rgb_img.shape[0]
         N = lidar_img.shape[1]
 
-        RF3, pix_rays, RF3_pts, RF3_unit = self._image_branch(rgb_img, intrinsic)
-        lidar = self._lidar_branch(lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev)
+        side = self._branch_stream(dev)
+        if side is None:
+            RF3, pix_rays, RF3_pts, RF3_unit = self._image_branch(rgb_img, intrinsic)
+            lidar = self._lidar_branch(lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev)
+        else:
+            # the two encoders meet at the first cost volume: the image encoder is issued on a second HIP stream, and autograd runs
+            # every backward node on the stream of its forward, so the encoders' backward passes overlap as well (in a captured step
+            # they are two branches of the hipGraph).  Everything either branch allocates is its own (per-call scratch, ops.zeros
+            # arena slices); the outputs that cross over are handed to the consuming stream's allocator bookkeeping.
+            # The grid-barrier chain kernels must have the GPU to themselves, so the point-cloud encoder — the only
+            # work that runs next to the image encoder, forward and backward — takes the layer-by-layer kernels; everything behind
+            # the join keeps its chains: _BranchJoin's backward is the last node of that part (lowest sequence number, and the
+            # autograd engine runs ready nodes highest-first), and the event the engine records behind it on the main stream is what the
+            # image encoder's backward waits for, so the second stream is idle whenever a chain kernel runs.
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                image = self._image_branch(rgb_img, intrinsic)
+            with ops.chains_off():
+                lidar = self._lidar_branch(lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev)
+            main.wait_stream(side)
+            for t in image:
+                t.record_stream(main)
+            RF3, pix_rays, RF3_pts, RF3_unit = image
+            RF3_pts, RF3_unit = _BranchJoin.apply(RF3_pts, RF3_unit)
         (P3_raw, P3, LF3, P4_raw, P4, LF4, sample_idx_4, P3_pts, LF3_pts, lidar_z, lidar_uv, LF3_unit) = lidar
         rfp = cfg.raw_feat_point
         H3, W3 = self.lidar_Hs[2], self.lidar_Ws[2]

@@ -10,6 +10,7 @@ against the CPU oracle; nothing in this package ever installs a non-HIP backend.
 """
 import ctypes as C
 
+import contextlib
 import os
 
 import torch
@@ -248,6 +249,21 @@ def zero_scalar(device, dtype=torch.float32):
     if key not in _ZERO:
         _ZERO[key] = torch.zeros((), dtype=dtype, device=device)
     return _ZERO[key]
+_CHAINS_OFF = [0]
+
+
+@contextlib.contextmanager
+def chains_off():
+    """forward passes issued inside take the layer-by-layer kernels, and so do their backward passes (the choice is made in the
+    forward and kept on the autograd node).  For work that shares the GPU with another stream's kernels: a chain launch needs its
+    whole grid resident (csrc/mlp_chain.hip)."""
+    _CHAINS_OFF[0] += 1
+    try:
+        yield
+    finally:
+        _CHAINS_OFF[0] -= 1
+
+
 begin_step = _arena.begin_step      # called by the trainer at the top of every forward+backward
 end_step = _arena.end
 zeros = _arena.zeros
@@ -1221,7 +1237,7 @@ class CBackend:
         """does i2p_chain_fwd take this chain on the current device?  widths = [row length of x, cout_1, ..., cout_nl].
         (Chain launches need their whole grid resident: they must not overlap another chain launch on the same GPU — the step runs
         them on one stream; the side-stream weight-gradient option only moves layer kernels, never these.)"""
-        if self.name != "hip" or self.device_type != "cuda" or os.environ.get("I2P_NO_CHAIN") == "1":
+        if self.name != "hip" or self.device_type != "cuda" or os.environ.get("I2P_NO_CHAIN") == "1" or _CHAINS_OFF[0]:
             return False
         key = (torch.cuda.current_device(), int(rows), tuple(int(c) for c in widths), int(pool_k))
         chain_error_words()                    # registers this device's error sinks on first use (outside graph capture)

@@ -255,6 +255,7 @@ def test_chain_timeout_surfaces_in_trainer_step(hip_backend, monkeypatch):
     batch = synth.make_batch(16, 8192, 160, 512, seed=3, device=dev)
     monkeypatch.setenv("I2P_CHAIN_FORCE_NONRESIDENT", "1")
     monkeypatch.setenv("I2P_CHAIN_POLL_LIMIT", "20000")
+    monkeypatch.setenv("I2P_ONE_STREAM", "1")              # the level-3 encoder chain only exists in the one-stream step (model.forward)
     monkeypatch.delenv("I2P_NO_CHAIN", raising=False)
     ops._CHAIN_OK.clear()
     try:
@@ -301,6 +302,7 @@ def test_chain_timeout_raises_on_the_same_step_for_every_rank(hip_backend, monke
     assert ops.chain_errors() == 0
     batch = synth.make_batch(16, 8192, 160, 512, seed=3, device=dev)
     monkeypatch.setenv("I2P_FORCE_DP", "1")
+    monkeypatch.setenv("I2P_ONE_STREAM", "1")              # (the forced chain is the level-3 encoder chain: one-stream step only)
     monkeypatch.delenv("I2P_NO_CHAIN", raising=False)
     ops._CHAIN_OK.clear()
     try:

@@ -1,0 +1,125 @@
+"""The two encoders on two HIP streams (i2pnet_amd/model.py, `RegNet_v2.forward`; I2P_ONE_STREAM=1 = everything on one stream).
+
+The image encoder is issued on a second stream next to the point-cloud encoder; autograd runs every backward node on the stream of its
+forward, so the two backward passes overlap as well.  What has to hold:
+
+* the step computes what the one-stream step computes (same kernels except the point-cloud encoder's two chain launches, which become
+  layer-by-layer launches: same sums in another order);
+* no grid-barrier chain kernel (csrc/mlp_chain.hip: needs its whole grid resident) is ever in flight next to the second stream's work:
+  the point-cloud encoder takes no chain, and in the backward pass every chain launch behind the join is ISSUED before `_BranchJoin`'s
+  backward runs — the event the engine records behind that node is what the image encoder's backward waits for;
+* many captured steps in a row run without an abandoned barrier."""
+import pytest
+import torch
+
+
+@pytest.mark.gpu
+def test_two_stream_step_matches_the_one_stream_step(hip_backend, monkeypatch):
+    from i2pnet_amd import ops
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd.train import Trainer
+    from i2pnet_amd import synth
+    dev = torch.device("cuda", 0)
+    batch = synth.make_batch(4, 8192, 160, 512, seed=11, device=dev)
+
+    def run(one):
+        if one:
+            monkeypatch.setenv("I2P_ONE_STREAM", "1")
+        else:
+            monkeypatch.delenv("I2P_ONE_STREAM", raising=False)
+        tr = Trainer(cfg=cfg, device=dev, seed=0, clip=0.0)
+        tr.net.l3_head.DP1.p = 0.0; tr.net.l4_head.DP1.p = 0.0
+        out = tr._forward_backward(tr._to_device(batch))
+        torch.cuda.synchronize()
+        assert ops.chain_errors(dev) == 0
+        return [float(x) for x in out], tr.flat_grad.detach().clone()
+
+    l1, g1 = run(True)
+    l1b, g1b = run(True)
+    l2, g2 = run(False)
+    # two one-stream evaluations differ by the image encoder's MIOpen weight gradients (atomics); the two-stream one may differ from
+    # them by that much and by the regrouped sums of the two encoder levels that left the chain kernels
+    spread = float((g1 - g1b).norm() / g1.norm())
+    err = float((g2 - g1).norm() / g1.norm())
+    print(f"[two streams] loss {l2[0]:.6f} vs {l1[0]:.6f}; gradient: relative difference {err:.2e}, run-to-run spread of the one-stream step {spread:.2e}")
+    assert abs(l2[0] - l1[0]) <= 1e-5 * abs(l1[0])
+    assert err <= max(1e-4, 3.0 * spread)
+
+
+@pytest.mark.gpu
+def test_every_chain_launch_of_the_backward_pass_is_issued_before_the_branches_split(hip_backend, monkeypatch):
+    from i2pnet_amd import model as model_mod
+    from i2pnet_amd import ops
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd.train import Trainer
+    from i2pnet_amd import synth
+    monkeypatch.delenv("I2P_ONE_STREAM", raising=False)
+    monkeypatch.delenv("I2P_NO_CHAIN", raising=False)
+    dev = torch.device("cuda", 0)
+    batch = synth.make_batch(8, 8192, 160, 512, seed=3, device=dev)
+    be = ops.get_backend()
+    log = []
+    side_ids = set()
+    main_id = torch.cuda.current_stream(dev).cuda_stream
+    fwd0, bwd0, join0 = be.chain_forward, be.chain_backward, model_mod._BranchJoin.backward
+
+    def note(kind):
+        log.append((kind, torch.cuda.current_stream(dev).cuda_stream, ops._CHAINS_OFF[0]))
+
+    def chain_forward(*a, **k):
+        note("chain_fwd"); return fwd0(*a, **k)
+
+    def chain_backward(*a, **k):
+        note("chain_bwd"); return bwd0(*a, **k)
+
+    def join_backward(ctx, ga, gb):
+        note("join"); return join0(ctx, ga, gb)
+
+    monkeypatch.setattr(be, "chain_forward", chain_forward)
+    monkeypatch.setattr(be, "chain_backward", chain_backward)
+    monkeypatch.setattr(model_mod._BranchJoin, "backward", staticmethod(join_backward))
+    # where the image encoder is issued, forward and backward
+    tr = Trainer(cfg=cfg, device=dev, seed=0)
+    enc = tr.net.RGB_net1
+
+    def image_bwd(module, grads):
+        side_ids.add(torch.cuda.current_stream(dev).cuda_stream); note("image_bwd")
+
+    def image_fwd(module, args):
+        side_ids.add(torch.cuda.current_stream(dev).cuda_stream); note("image_fwd")
+
+    h = enc.register_full_backward_pre_hook(image_bwd)
+    hf = enc.register_forward_pre_hook(image_fwd)
+    try:
+        tr._forward_backward(tr._to_device(batch))
+        torch.cuda.synchronize()
+    finally:
+        h.remove(); hf.remove()
+    kinds = [k for k, _, _ in log]
+    print("[two streams] order of issue:", kinds)
+    assert ops.chain_errors(dev) == 0
+    assert len(side_ids) == 1 and main_id not in side_ids, "the image encoder runs on the second stream, forward and backward"
+    assert kinds.count("chain_fwd") >= 8 and kinds.count("chain_bwd") >= 2, "the part behind the join keeps its chain kernels"
+    assert all(s == main_id and off == 0 for k, s, off in log if k.startswith("chain")), "chains on the main stream, outside the encoder region"
+    j = kinds.index("join")
+    assert kinds.count("join") == 1
+    assert all(k != "chain_bwd" for k in kinds[j + 1:]), "a chain backward issued after the branches split"
+    assert kinds.index("image_bwd") > j, "the image encoder's backward starts behind the join node"
+    # forward: every chain launch comes after the image encoder was issued AND the main stream waited for it (model.forward joins first)
+    assert kinds.index("image_fwd") < kinds.index("chain_fwd")
+
+
+@pytest.mark.gpu
+def test_sixty_captured_two_stream_steps_abandon_no_barrier(hip_backend, monkeypatch):
+    from i2pnet_amd import ops, synth
+    from i2pnet_amd.config import I2PNetConfig as cfg
+    from i2pnet_amd.train import Trainer
+    monkeypatch.delenv("I2P_ONE_STREAM", raising=False)
+    monkeypatch.delenv("I2P_NO_CHAIN", raising=False)
+    dev = torch.device("cuda", 0)
+    batch = synth.make_batch(8, 8192, 160, 512, seed=4, device=dev)
+    tr = Trainer(cfg=cfg, device=dev, seed=0, capturable=True)
+    assert tr.capture(batch, warmup=1), "hipGraph capture failed"
+    losses = [float(tr.step(batch)[0]) for _ in range(60)]
+    tr.check_chain_errors(sync=True)
+    assert all(v == v and abs(v) < 1e6 for v in losses) and float(tr.optimizer.step_t) == 60.0
