@@ -73,11 +73,14 @@ def _run(device, precision="fp32", max_steps=None):
     return gold, np.array(losses), np.array(gnorms), per_param(d1), per_param(d5), frozen
 
 
-def _check(gold, losses, gnorms, d1, d5, frozen, loss_floor, gnorm_floor, step1_tol, gnorm_steps=None, disp_tol=1e-2):
+def _check(gold, losses, gnorms, d1, d5, frozen, loss_floor, gnorm_floor, step1_tol, gnorm_steps=None, disp_tol=1e-2, own_spread=None,
+           own_disp_spread=0.0):
     ref = gold["loss"]
     # spread of the reference's own evaluations at step k: the largest |alt - ref| over the three alternates, and never smaller
     # than at an earlier step (one sample of a chaotic quantity can land close by accident)
     spread = np.maximum.accumulate((np.abs(gold["loss_alt"][:, :, 0] - ref[None, :, 0]) / np.abs(ref[None, :, 0])).max(0)) * np.abs(ref[:, 0])
+    if own_spread is not None:            # a path that is not run-to-run reproducible: its own two runs' distance counts as spread too
+        spread = np.maximum(spread[:len(own_spread)], np.maximum.accumulate(np.asarray(own_spread)))
     report = []
     for k in range(len(losses)):
         lim = max((1e-4 if k == 0 and loss_floor < 1e-3 else loss_floor) * abs(ref[k, 0]), 3.0 * spread[k])
@@ -114,7 +117,7 @@ def _check(gold, losses, gnorms, d1, d5, frozen, loss_floor, gnorm_floor, step1_
     t_alt = [tot(dict(zip(keys, row.tolist()))) for row in gold["param_delta_norm_alt"]]
     print(f"[trajectory] {len(d1)} stepped parameters; worst first-update ratio to its limit "
           f"{worst[0]:.3f} at {worst[1]}; 5-step displacement {t_me:.5f} vs reference {t_ref:.5f} (alternates {[round(v, 5) for v in t_alt]})")
-    assert abs(t_me - t_ref) <= max(disp_tol * t_ref, 3.0 * max(abs(v - t_ref) for v in t_alt))
+    assert abs(t_me - t_ref) <= max(disp_tol * t_ref, 3.0 * max(abs(v - t_ref) for v in t_alt)) + 3.0 * own_disp_spread
 
 
 def test_five_steps_follow_the_reference_optimiser_loop_on_the_oracle_backend(oracle_backend):
@@ -142,4 +145,12 @@ def test_five_steps_in_bf16_storage_follow_the_reference_optimiser_loop_on_gpu(h
     torch.manual_seed(0)
     # (the gradient norm is held to the 25 % of the contract at step 1 only: from step 2 on it is the norm of a DIFFERENT weight vector —
     #  the bf16 run's first update flips other signs than the reference's — and swings by +-36 % between the reference's own alternates)
-    _check(*_run(torch.device("cuda", 0), precision="bf16"), loss_floor=8e-2, gnorm_floor=2.5e-1, step1_tol=5e-2, gnorm_steps=1, disp_tol=3e-2)
+    # The bf16 step is not run-to-run reproducible (fp32 atomics in the cost volume's backward), and from step 2 on that difference is
+    # amplified like any other: five runs of this test on one box put the step-2 loss 0.5 % .. 4.6 % from the reference and the 5-step
+    # displacement at 2.660 .. 2.708 (reference 2.659).  The run is therefore made twice and the distance between the two runs counts
+    # as spread, exactly like the distance between the reference's own alternates does.
+    a = _run(torch.device("cuda", 0), precision="bf16")
+    b = _run(torch.device("cuda", 0), precision="bf16")
+    tot = lambda d: float(np.sqrt(sum(v ** 2 for v in d.values())))
+    _check(*a, loss_floor=8e-2, gnorm_floor=2.5e-1, step1_tol=5e-2, gnorm_steps=1, disp_tol=3e-2,
+           own_spread=np.abs(a[1][:, 0] - b[1][:, 0]), own_disp_spread=abs(tot(a[4]) - tot(b[4])))

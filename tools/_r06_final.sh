@@ -15,4 +15,10 @@ F="--no-cpu-baseline --no-dp-proxy --loader-line 0 --other-configs 0 --steps 40 
 python bench.py $F --config $c 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config $c deferred ', l['value'], l['ms_per_step'])"
 I2P_NO_DEFER=1 python bench.py $F --config $c 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config $c immediate', l['value'], l['ms_per_step'])"
 done; done; } > gpurun_out/r06_defer_ab.txt
-cat gpurun_out/r06_gpu_suite.txt gpurun_out/r06_defer_ab.txt; head -c 300 gpurun_out/r06_final_bench.json
+{ echo "# same-box A/B of the two-stream step (image encoder on a second HIP stream; I2P_ONE_STREAM=1 = one stream, encoder chains on), bench.py $F --steps 200 --warmup 20"; for c in 1 2 4; do for i in 1 2; do
+python bench.py $F --steps 200 --warmup 20 --config $c 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config $c two streams', l['value'], l['ms_per_step'])"
+I2P_ONE_STREAM=1 python bench.py $F --steps 200 --warmup 20 --config $c 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config $c one stream ', l['value'], l['ms_per_step'])"
+done; done; } > gpurun_out/r06_two_stream_ab.txt
+{ echo "# tools/time_fwd_streams.py: captured forward pass at configs[1]'s shapes, no profiler"; python tools/time_fwd_streams.py 2>&1 | tail -4
+echo "# tools/graph_branch_probe.py: a two-branch hipGraph of one-block spin kernels (A on a second stream, B on the capturing stream), replay time"; python tools/graph_branch_probe.py 2>&1 | tail -17; } > gpurun_out/r06_graph_branches.txt
+cat gpurun_out/r06_gpu_suite.txt gpurun_out/r06_defer_ab.txt gpurun_out/r06_two_stream_ab.txt; head -c 300 gpurun_out/r06_final_bench.json

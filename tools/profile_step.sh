@@ -11,3 +11,6 @@ trace=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
 mkdir -p gpurun_out
 python tools/steady_stats.py "$trace" --warmup 5 --steps 4 --top 70 --out gpurun_out/${tag}_steady_kernel_stats.csv --train-steps 10 --tail-out gpurun_out/${tag}_roofline_section_kernel_stats.csv
 python tools/step_sequence.py "$trace" 7 > gpurun_out/${tag}_step_sequence.txt 2>&1
+# (two-stream step: under the profiler the second queue of a replayed graph starts late — compare tools/graph_branch_probe.py with and
+#  without rocprofv3 — so the timeline shows the overlap of the backward pass but understates that of the forward pass)
+python tools/step_timeline.py "$trace" 7 > gpurun_out/${tag}_step_timeline.txt 2>&1
