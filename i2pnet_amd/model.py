@@ -183,9 +183,17 @@ class RegNet_v2(nn.Module):
             self.__dict__["_side_stream"] = s
         return s
 
-    def _image_branch(self, rgb_img, intrinsic):
-        """image encoder -> (RF3 [B,128,h3,w3], pixel rays [B,M,3], RF3 as points [B,M,C], its unit-variance form)"""
-        RF3 = self.RGB_net3(self.RGB_net2(self.RGB_net1(rgb_img)))             # [B,128,h3,w3]
+    def _image_branch(self, rgb_img, intrinsic, marks=None):
+        """image encoder -> (RF3 [B,128,h3,w3], pixel rays [B,M,3], RF3 as points [B,M,C], its unit-variance form); marks: a list that
+        receives an event recorded on the current stream behind every block of the encoder (training path of `_ImageCNN`)"""
+        x = rgb_img
+        for net in (self.RGB_net1, self.RGB_net2, self.RGB_net3):
+            net._marks = marks
+            try:
+                x = net(x)
+            finally:
+                net._marks = None
+        RF3 = x                                                                 # [B,128,h3,w3]
         pix_index = set_id_grid(RF3.permute(0, 2, 3, 1))                        # [B,M,3]
         # pixel rays in the normalised camera plane of the level-3 feature map
         K3_inv = scaled_intrinsic_inverse(intrinsic, RF3, rgb_img)
@@ -237,10 +245,19 @@ class RegNet_v2(nn.Module):
             # the join keeps its chains: _BranchJoin's backward is the last node of that part (lowest sequence number, and the
             # autograd engine runs ready nodes highest-first), and the event the engine records behind it on the main stream is what the
             # image encoder's backward waits for, so the second stream is idle whenever a chain kernel runs.
+            # The point-cloud encoder starts when the image encoder's fourth block is through (an event of the second stream the main
+            # stream waits for; I2P_LIDAR_AFTER_BLOCK = 0 .. 15): the first blocks — the 375 x 1242 and 188 x 621 stages — fill the GPU, and
+            # two GPU-filling kernels side by side finish when their sum would, while blocks 6-15 are small library kernels that leave
+            # most of the GPU to the other queue.  Same box, 2 x 200 steps: configs[1] 10.23 -> 10.10 ms, configs[2] 11.60 -> 11.55 ms,
+            # configs[4] 7.27 -> 7.25 ms (after block 5: 10.14 / 11.63 / 7.31; after block 6: 10.21 / 11.68 / 7.36).
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)
+            marks = []
             with torch.cuda.stream(side):
-                image = self._image_branch(rgb_img, intrinsic)
+                image = self._image_branch(rgb_img, intrinsic, marks)
+            after = min(int(os.environ.get("I2P_LIDAR_AFTER_BLOCK", "4")), len(marks))
+            if after > 0:
+                main.wait_event(marks[after - 1])
             with ops.chains_off():
                 lidar = self._lidar_branch(lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev)
             main.wait_stream(side)

@@ -428,6 +428,23 @@ class _ImageCNN(nn.Sequential):
         out_bf = [blk_bf[j + 1] if j + 1 < nb else (bf and next_stack_bf) for j in range(nb)]
         return blk_bf, out_bf
 
+    @staticmethod
+    def _block(j, x, conv, bn, act, pool, blk_bf, out_bf, ws):
+        if j == 0 and _first_block_ok(x, conv, act, pool, blk_bf[0]):
+            return _FirstBlock.apply(x, conv.weight, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
+                                     bn.momentum, bn.eps, act.negative_slope, out_bf[0])
+        if j == 0:
+            x = x.contiguous(memory_format=torch.channels_last)
+        want = torch.bfloat16 if blk_bf[j] else torch.float32
+        if x.dtype != want:
+            x = x.to(want)
+        if _conv16_ok(x, conv, blk_bf[j]):
+            return _Conv16Block.apply(x, conv.weight, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
+                                      bn.momentum, bn.eps, act.negative_slope, out_bf[j])
+        y = F.conv2d(x, ws[j] if blk_bf[j] else conv.weight, None, conv.stride, conv.padding)
+        return _BnActPool.apply(y, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
+                                bn.momentum, bn.eps, act.negative_slope, out_bf[j])
+
     def forward(self, x):
         mods = list(self)
         # eval mode and the un-fused path run MIOpen's NHWC solvers like the fused path does (the model no longer converts rgb_img;
@@ -443,24 +460,13 @@ class _ImageCNN(nn.Sequential):
             blk_bf, out_bf = self._storage_plan(x, nb)
             if any(blk_bf):
                 ws = _CastBf16.apply(*[mods[i].weight for i in range(0, len(mods), 4)])
+            marks = getattr(self, "_marks", None)           # (model.forward: an event behind every block, for the other encoder's start)
             for j, i in enumerate(range(0, len(mods), 4)):
                 conv, bn, act, pool = mods[i:i + 4]
-                if j == 0 and _first_block_ok(x, conv, act, pool, blk_bf[0]):
-                    x = _FirstBlock.apply(x, conv.weight, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
-                                          bn.momentum, bn.eps, act.negative_slope, out_bf[0])
-                    continue
-                if j == 0:
-                    x = x.contiguous(memory_format=torch.channels_last)
-                want = torch.bfloat16 if blk_bf[j] else torch.float32
-                if x.dtype != want:
-                    x = x.to(want)
-                if _conv16_ok(x, conv, blk_bf[j]):
-                    x = _Conv16Block.apply(x, conv.weight, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
-                                           bn.momentum, bn.eps, act.negative_slope, out_bf[j])
-                    continue
-                y = F.conv2d(x, ws[j] if blk_bf[j] else conv.weight, None, conv.stride, conv.padding)
-                x = _BnActPool.apply(y, bn.weight, bn.bias, conv.bias, bn.running_mean, bn.running_var, pool.stride,
-                                     bn.momentum, bn.eps, act.negative_slope, out_bf[j])
+                x = self._block(j, x, conv, bn, act, pool, blk_bf, out_bf, ws if any(blk_bf) else None)
+                if marks is not None:
+                    marks.append(torch.cuda.Event())
+                    marks[-1].record(torch.cuda.current_stream(x.device))
             return x
         with torch.no_grad():
             # rm' = (1-m) rm + m (mean_without_bias + bias): pre-add m/(1-m) * bias (before autograd saves the buffer)
