@@ -197,6 +197,8 @@ class Evaluator:
             for _ in range(2):
                 self._forward(self._static)
         torch.cuda.current_stream(self.device).wait_stream(side)
+        from .train import _quiesce_watchdog           # (a live process group's watchdog must have nothing to poll while the
+        _quiesce_watchdog(self.device)                 #  two-stream forward is captured: train._CAPTURE_MODE)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):     # see train._CAPTURE_MODE
             self._out = self._forward(self._static)

@@ -183,16 +183,16 @@ class RegNet_v2(nn.Module):
             self.__dict__["_side_stream"] = s
         return s
 
-    def _image_branch(self, rgb_img, intrinsic, marks=None):
-        """image encoder -> (RF3 [B,128,h3,w3], pixel rays [B,M,3], RF3 as points [B,M,C], its unit-variance form); marks: a list that
-        receives an event recorded on the current stream behind every block of the encoder (training path of `_ImageCNN`)"""
+    def _image_branch(self, rgb_img, intrinsic, mark=None):
+        """image encoder -> (RF3 [B,128,h3,w3], pixel rays [B,M,3], RF3 as points [B,M,C], its unit-variance form); mark = (k, fn):
+        fn() is called behind block k (1 .. 15) of the encoder (training path of `_ImageCNN`)"""
         x = rgb_img
-        for net in (self.RGB_net1, self.RGB_net2, self.RGB_net3):
-            net._marks = marks
+        for i, net in enumerate((self.RGB_net1, self.RGB_net2, self.RGB_net3)):
+            net._mark = (mark[0] - 1 - 5 * i, mark[1]) if mark is not None else None
             try:
                 x = net(x)
             finally:
-                net._marks = None
+                net._mark = None
         RF3 = x                                                                 # [B,128,h3,w3]
         pix_index = set_id_grid(RF3.permute(0, 2, 3, 1))                        # [B,M,3]
         # pixel rays in the normalised camera plane of the level-3 feature map
@@ -252,12 +252,19 @@ class RegNet_v2(nn.Module):
             # configs[4] 7.27 -> 7.25 ms (after block 5: 10.14 / 11.63 / 7.31; after block 6: 10.21 / 11.68 / 7.36).
             main = torch.cuda.current_stream(dev)
             side.wait_stream(main)
-            marks = []
+            after = int(os.environ.get("I2P_LIDAR_AFTER_BLOCK", "4"))
+            ev = self.__dict__.get("_lidar_event")            # one event object for the model's life (not one per step)
+            if ev is None:
+                ev = self.__dict__["_lidar_event"] = torch.cuda.Event()
+            reached = []
+
+            def behind_block():
+                ev.record(torch.cuda.current_stream(dev))
+                reached.append(True)
             with torch.cuda.stream(side):
-                image = self._image_branch(rgb_img, intrinsic, marks)
-            after = min(int(os.environ.get("I2P_LIDAR_AFTER_BLOCK", "4")), len(marks))
-            if after > 0:
-                main.wait_event(marks[after - 1])
+                image = self._image_branch(rgb_img, intrinsic, (after, behind_block) if 1 <= after <= 15 else None)
+            if reached:
+                main.wait_event(ev)
             with ops.chains_off():
                 lidar = self._lidar_branch(lidar_img, lidar_img_raw, lidar_feature, cfg, B, N, dev)
             main.wait_stream(side)

@@ -460,13 +460,12 @@ class _ImageCNN(nn.Sequential):
             blk_bf, out_bf = self._storage_plan(x, nb)
             if any(blk_bf):
                 ws = _CastBf16.apply(*[mods[i].weight for i in range(0, len(mods), 4)])
-            marks = getattr(self, "_marks", None)           # (model.forward: an event behind every block, for the other encoder's start)
+            mark = getattr(self, "_mark", None)             # (block index, callable): model.forward's hook behind one block of the stack
             for j, i in enumerate(range(0, len(mods), 4)):
                 conv, bn, act, pool = mods[i:i + 4]
                 x = self._block(j, x, conv, bn, act, pool, blk_bf, out_bf, ws if any(blk_bf) else None)
-                if marks is not None:
-                    marks.append(torch.cuda.Event())
-                    marks[-1].record(torch.cuda.current_stream(x.device))
+                if mark is not None and mark[0] == j:
+                    mark[1]()
             return x
         with torch.no_grad():
             # rm' = (1-m) rm + m (mean_without_bias + bias): pre-add m/(1-m) * bias (before autograd saves the buffer)

@@ -18,6 +18,7 @@ graphs are captured as one.  The step never synchronises with the host (the refe
 `.item()` three times per step).
 """
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -40,8 +41,20 @@ def dist_env():
 # hipGraph capture mode.  With a process group alive, the RCCL watchdog thread polls its work events
 # (hipEventQuery) at any time; under the default "global" mode such a call from ANOTHER thread during a capture is an
 # error that invalidates the capture and kills the watchdog (SIGABRT, seen in ~1 of 4 launches).  "thread_local"
-# restricts the check to the capturing thread.
+# restricts the check to the capturing thread.  That covers the stream the capture is begun on; a stream that JOINS it later (the model's
+# second encoder stream) is not exempt on ROCm 7.0: a watchdog query while such a capture runs invalidates it ("capture failed, staying
+# eager"), leaves the joined stream capturing, the next all-reduce's event is then "recorded in a capturing stream" and the watchdog
+# dies on it (SIGABRT at the next destroy_process_group(); 2 of 3 runs of the GPU suite).  The watchdog only queries the events of work
+# it has not retired yet, so `capture()` lets it retire the warm-up steps' all-reduces first (_quiesce_watchdog) — graph A contains no
+# collective, and graph B is captured on one stream.
 _CAPTURE_MODE = "thread_local"
+
+
+def _quiesce_watchdog(device):
+    """nothing outstanding for the process group's watchdog thread to poll: device idle, then a few of its 100 ms cycles"""
+    torch.cuda.synchronize(device)
+    if dist.is_available() and dist.is_initialized():
+        time.sleep(0.5)
 
 
 def init_distributed(backend):
@@ -395,7 +408,7 @@ class Trainer:
                 for _ in range(warmup):
                     self._eager_step(self._static)
             torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
+            _quiesce_watchdog(self.device)
             if self.world_size == 1 and not os.environ.get("I2P_FORCE_DP"):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode=_CAPTURE_MODE):
