@@ -173,6 +173,13 @@ class RegNet_v2(nn.Module):
         self.sq = nn.Parameter(torch.tensor([cfg.sq_init]), requires_grad=True)
         self.sx = nn.Parameter(torch.tensor([cfg.sx_init]), requires_grad=True)
 
+    def __getstate__(self):
+        # (the second stream and its event are created on first use and are not part of the model: copy.deepcopy / pickling drop them)
+        state = self.__dict__.copy()
+        state.pop("_side_stream", None)
+        state.pop("_lidar_event", None)
+        return state
+
     def _branch_stream(self, dev):
         """second stream for the image encoder (None on the CPU oracle backend or with I2P_ONE_STREAM=1)"""
         if dev.type != "cuda" or os.environ.get("I2P_ONE_STREAM") == "1":

@@ -36,6 +36,10 @@ def test_two_stream_step_matches_the_one_stream_step(hip_backend, monkeypatch):
         out = tr._forward_backward(tr._to_device(batch))
         torch.cuda.synchronize()
         assert ops.chain_errors(dev) == 0
+        if not one:             # the stream and event the forward created stay behind when the model is copied
+            import copy
+            twin = copy.deepcopy(tr.net)
+            assert "_side_stream" in tr.net.__dict__ and "_side_stream" not in twin.__dict__ and "_lidar_event" not in twin.__dict__
         return [float(x) for x in out], tr.flat_grad.detach().clone()
 
     prev_det = torch.backends.cudnn.deterministic
