@@ -428,6 +428,11 @@ class Trainer:
         except Exception as e:                      # noqa: BLE001 — fall back to eager, loudly
             print(f"[i2pnet_amd.train] hipGraph capture failed, staying eager: {type(e).__name__}: {e}", flush=True)
             self._graph_a = self._graph_b = None
+            # A stream that had joined the failed capture (the model's second encoder stream) may be left in capture mode: eager work issued
+            # on it afterwards would be recorded instead of run, and pull every stream that waits for it into the dead capture.  The eager
+            # steps that follow get a fresh stream (and the event that goes with it).
+            for m in self.net.modules():
+                m.__dict__.pop("_side_stream", None); m.__dict__.pop("_lidar_event", None)
             torch.cuda.synchronize()
             self._restore(snap)
             return False
